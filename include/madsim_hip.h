@@ -1,0 +1,258 @@
+/*
+ * madsim_hip.h — C ABI of the MI355X many-seed runner for madsim's deterministic
+ * discrete-event executor (Executor + TimeRuntime + GlobalRng + NetSim delivery queue).
+ *
+ * This is the drop-in boundary.  The reference has no FFI for its executor; the
+ * seam this library plugs into is the per-seed fan-out of
+ *     madsim::runtime::Builder::run            madsim/src/sim/runtime/builder.rs:121-162
+ * (reached from #[madsim::test] / #[madsim::main], madsim-macros/src/lib.rs:134-151) and, per seed,
+ *     Runtime::with_seed_and_config + block_on madsim/src/sim/runtime/mod.rs:53-69,127-130
+ *     Executor::block_on / run_all_ready       madsim/src/sim/task/mod.rs:220-323
+ * One call to madsim_hip_run_batch replaces `count` iterations of that fan-out: seeds
+ * seed0 .. seed0+count-1, one GPU lane per seed.  INTEGRATION.md shows the Rust `extern "C"` stub.
+ *
+ * A GPU lane cannot poll an opaque Rust future (task/mod.rs:279-283), so the test body is handed
+ * over as a *workload*: a table-driven actor program whose instructions are one-to-one with the
+ * reference API calls a madsim test makes (Endpoint::bind/send_to/recv_from, time::sleep,
+ * spawn/JoinHandle, Handle::kill/restart/pause/resume, NetSim::clog_*).  The executor semantics
+ * underneath — ready-queue draw, 50..100 ns poll cost, timer heap order, 1 ms sleep floor, link
+ * test and latency draw, mailbox tag matching, async-task wake rules — are restated bit-exactly.
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ */
+#ifndef MADSIM_HIP_H
+#define MADSIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MADSIM_HIP_ABI_VERSION 1u
+
+/* ------------------------------------------------------------------------------------------------
+ * Workload: the actor program (read-only, caller-owned POD).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One instruction = 8 bytes.  Durations are encoded as  b seconds + imm nanoseconds. */
+typedef struct madsim_insn {
+    uint8_t  op;   /* enum madsim_op */
+    uint8_t  a;
+    uint16_t b;
+    uint32_t imm;
+} madsim_insn_t;
+
+/* Each op stands for one reference API call; "await" ops may return Pending to the executor. */
+enum madsim_op {
+    /* -- task / control -- */
+    MS_OP_DONE = 0,        /* async block returns: locals drop (endpoints close, net/mod.rs:483-493),
+                              JoinHandle awaiter is woken (async-task)                  */
+    MS_OP_SPAWN = 1,       /* a=prog: NodeHandle::spawn / task::spawn  (task/mod.rs:607-654);
+                              handle[prog] := new task                                               */
+    MS_OP_JOIN = 2,        /* a=prog: handle[prog].await (task/join.rs:59-72). b&1: expect Err
+                              (unwrap_err) else unwrap -> a mismatch panics the polling task         */
+    MS_OP_ABORT = 3,       /* a=prog: handle[prog].abort() (task/join.rs:158-163)                    */
+    MS_OP_YIELD = 4,       /* tokio::task::yield_now().await (re-export task/mod.rs:30)              */
+    MS_OP_PANIC = 5,       /* panic!()                                                               */
+    MS_OP_SET = 6,         /* a=reg(0..1): cnt[a] = imm (a loop bound; registers are 16 bit)          */
+    MS_OP_DJNZ = 7,        /* a=reg, b=target: if (--cnt[a] != 0) goto b                              */
+    MS_OP_JMP = 8,         /* b=target                                                               */
+    MS_OP_TRACE = 9,       /* obs_hash <- fold(imm + (b&1 ? cnt[a] : 0)): an observable side effect
+                              (the std::sync::mpsc send in task/mod.rs:1029)                         */
+    MS_OP_BUILD = 15,      /* a=node: create_node().init(..).build() inside a task body: spawns the node's
+                              MADSIM_PROG_INIT program(s) now (task/mod.rs:472-474)                  */
+    /* -- time -- */
+    MS_OP_SLEEP = 10,      /* time::sleep(b s + imm ns).await  (time/sleep.rs:5-8, mod.rs:111-124)   */
+    MS_OP_MARK = 11,       /* t0 = Instant::now()                                                    */
+    MS_OP_SLEEP_UNTIL = 12,/* time::sleep_until(t0 + b s + imm ns).await (time/mod.rs:118-124)       */
+    MS_OP_ASSERT_ELAPSED = 13, /* a=cmp (0 ==, 1 >=, 2 <): assert!(t0.elapsed() cmp b s + imm ns)    */
+    MS_OP_ADVANCE = 14,    /* time::advance(b s + imm ns) (time/mod.rs:195-198, 103-106)             */
+    /* -- net (datagram Endpoint API, net/endpoint.rs) -- */
+    MS_OP_BIND = 20,       /* a=sock: Endpoint::bind(addr(sock)).await.unwrap() (endpoint.rs:23-36)  */
+    MS_OP_SEND = 21,       /* a=src sock, b=(tag<<8)|dst addr, imm=payload:
+                              ep.send_to(addr(dst), tag, payload).await (endpoint.rs:69-72,120-133)  */
+    MS_OP_REPLY = 22,      /* a=src sock, b=(tag<<8), imm=payload: ep.send_to(from, tag, ..).await   */
+    MS_OP_RECV = 23,       /* a=sock, b=(tag<<8): (val, from) = ep.recv_from(tag).await
+                              (endpoint.rs:87-94,140-149)                                            */
+    MS_OP_ASSERT_VAL = 24, /* assert_eq!(val, imm)                                                   */
+    MS_OP_RECV_TIMEOUT = 25,/* a=sock, b=(tag<<8)|secs... see DESIGN.md; timeout(d, ep.recv_from(tag))
+                              d = imm ns; on Elapsed val := MADSIM_VAL_TIMEOUT (time/mod.rs:128-140)  */
+    MS_OP_CLOSE = 26,      /* a=sock: drop(ep) (BindGuard::drop, net/mod.rs:483-493)                 */
+    /* -- supervisor: fault injection (runtime/mod.rs:276-303, net/mod.rs:164-222) -- */
+    MS_OP_KILL = 30,       /* a=node: Handle::kill(node)     (task/mod.rs:356-371)                   */
+    MS_OP_RESTART = 31,    /* a=node: Handle::restart(node)  (task/mod.rs:374-401)                   */
+    MS_OP_PAUSE = 32,      /* a=node: Handle::pause(node)    (task/mod.rs:404-410)                   */
+    MS_OP_RESUME = 33,     /* a=node: Handle::resume(node)   (task/mod.rs:413-424)                   */
+    MS_OP_CLOG_NODE = 34,  /* a=node, b=dir(1 in,2 out,3 both): NetSim::clog_node{,_in,_out}         */
+    MS_OP_UNCLOG_NODE = 35,/* a=node, b=dir                                                          */
+    MS_OP_CLOG_LINK = 36,  /* a=src node, b=dst node: NetSim::clog_link (network.rs:184-189)         */
+    MS_OP_UNCLOG_LINK = 37,/* a=src node, b=dst node                                                 */
+    MS_OP_ASSERT_EXIT = 38,/* a=node, b=expected: assert_eq!(Handle::is_exit(node), b)               */
+    MS_OP_SET_LOSS = 39,   /* a=index into madsim_config_t.loss_table: NetSim::update_config(|c|
+                              c.packet_loss_rate = ..) (net/mod.rs:138-141)                          */
+    MS_OP_SLEEP_RAND = 40, /* sleep(thread_rng().gen_range(0 .. b s + imm ns)): the randomised fault
+                              loop of tonic-example/tests/test.rs:198-201 (UniformDuration, A.3)     */
+    MS_OP__COUNT
+};
+
+#define MADSIM_VAL_TIMEOUT 0xFFFFFFFFu
+
+/* A task program: where it runs and where it starts.  Program 0 is the body handed to block_on
+ * (the main task on node 0, task/mod.rs:222-235). */
+typedef struct madsim_prog {
+    uint8_t  node;   /* 0 = supervisor node "madsim-main"; 1..n_nodes = create_node() order          */
+    uint8_t  flags;  /* MADSIM_PROG_* */
+    uint16_t entry;  /* first instruction                                                            */
+} madsim_prog_t;
+#define MADSIM_PROG_INIT 1u /* NodeBuilder::init task: spawned at build() (MS_OP_BUILD, or before
+                               block_on when MADSIM_PROG_PRE is also set) and on every restart
+                               (runtime/mod.rs:405-418, task/mod.rs:395-400,472-474)                 */
+#define MADSIM_PROG_PRE  2u /* spawned before Runtime::block_on pushes the main task, in prog order:
+                               `node.spawn(..)` ahead of `runtime.block_on(..)` (task/mod.rs:859-897) */
+
+/* A socket address that an Endpoint may bind: node's IP 10.0.0.<node> and a port.  `addr` operands
+ * of SEND name one of these; resolution to a *bound* socket happens at try_send time
+ * (network.rs:296-313). */
+typedef struct madsim_sock {
+    uint8_t  node;
+    uint8_t  reserved;
+    uint16_t port;
+} madsim_sock_t;
+
+typedef struct madsim_node {
+    uint8_t flags;     /* MADSIM_NODE_* */
+    uint8_t reserved[3];
+} madsim_node_t;
+#define MADSIM_NODE_RESTART_ON_PANIC 1u /* NodeBuilder::restart_on_panic (task/mod.rs:298-316)      */
+
+typedef struct madsim_workload {
+    uint32_t n_nodes;   /* nodes 1..n_nodes besides node 0                                           */
+    uint32_t n_progs;   /* prog 0 = main                                                             */
+    uint32_t n_socks;
+    uint32_t n_insns;
+    const madsim_node_t* nodes;  /* [n_nodes+1], index = node id                                     */
+    const madsim_prog_t* progs;  /* [n_progs]                                                        */
+    const madsim_sock_t* socks;  /* [n_socks]                                                        */
+    const madsim_insn_t* insns;  /* [n_insns]                                                        */
+} madsim_workload_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * Inputs mirroring Builder's public fields (runtime/builder.rs:7-22) and net Config
+ * (net/network.rs:66-89).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct madsim_config {
+    double   packet_loss_rate;   /* Config.net.packet_loss_rate, default 0.0                         */
+    uint64_t lat_lo_ns;          /* Config.net.send_latency.start, default 1 ms                      */
+    uint64_t lat_hi_ns;          /* Config.net.send_latency.end (exclusive), default 10 ms           */
+    uint32_t buggify;            /* non-zero: buggify enabled for the whole run (rand.rs:113-134)    */
+    uint32_t n_loss_table;       /* entries in loss_table used by MS_OP_SET_LOSS                     */
+    double   loss_table[4];
+} madsim_config_t;
+
+typedef struct madsim_limits {
+    uint64_t time_limit_ns;      /* Builder.time_limit; 0 = None (task/mod.rs:253-258)               */
+    uint32_t max_steps;          /* device safety net; 0 = default (1<<24). Not a reference concept. */
+    uint32_t heap_lds_slots;     /* timer-heap entries kept in LDS per seed; 0 = auto                */
+    uint32_t heap_spill_slots;   /* further entries per seed in the coalesced HBM spill region       */
+    uint32_t max_tasks;          /* live task instances per seed; 0 = auto (n_progs + restarts)      */
+    uint32_t mbox_regs;          /* pending recv registrations per socket; 0 = auto (2)              */
+    uint32_t mbox_msgs;          /* undelivered messages per socket; 0 = auto (4)                    */
+    uint32_t reserved;
+} madsim_limits_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * Outputs.
+ * ---------------------------------------------------------------------------------------------- */
+enum madsim_verdict {
+    MADSIM_PASS = 0,        /* block_on returned                                                     */
+    MADSIM_PANIC = 1,       /* a task panicked and its node does not restart (task/mod.rs:315)       */
+    MADSIM_DEADLOCK = 2,    /* "no events, all tasks will block forever" (task/mod.rs:250)           */
+    MADSIM_TIME_LIMIT = 3,  /* "time limit exceeded" (task/mod.rs:253-258)                           */
+    MADSIM_OVERFLOW = 4,    /* a device capacity in madsim_limits_t was exceeded: re-run the seed with
+                               larger limits (not a reference verdict; never silently wrong)         */
+    MADSIM_STEP_LIMIT = 5   /* max_steps reached (not a reference verdict)                           */
+};
+
+/* 48 bytes per seed.  Everything here is compared bit-for-bit against the oracle. */
+typedef struct madsim_result {
+    uint32_t verdict;
+    uint32_t steps;       /* executor steps: task polls (incl. dropped runnables) + timer fires      */
+    uint64_t clock_ns;    /* Clock.elapsed() when block_on left (time/mod.rs:230-233)                */
+    uint64_t msg_count;   /* NetSim::stat().msg_count (network.rs:99-105,265)                        */
+    uint64_t rng_calls;   /* Xoshiro256PlusPlus::next_u64 invocations on the GlobalRng               */
+    uint64_t trace_hash;  /* FNV-1a-64 over the determinism-log bytes of rand.rs:64-88               */
+    uint64_t obs_hash;    /* FNV-1a-64 over MS_OP_TRACE values in execution order                    */
+} madsim_result_t;
+
+typedef struct madsim_summary {
+    uint64_t first_failing_seed; /* minimum seed with verdict != PASS, UINT64_MAX if none            */
+    uint64_t n_failed;
+    uint64_t total_steps;
+    uint64_t total_clock_ns;
+    double   kernel_ms;          /* HIP-event time of the simulation kernel(s) on the call's stream   */
+    double   wall_s;             /* host wall time of the call                                       */
+} madsim_summary_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * Entry points.  All return 0 on success, <0 on error (madsim_hip_strerror); they never unwind.
+ * Per-seed failures are data (verdict), not errors.
+ * ---------------------------------------------------------------------------------------------- */
+#define MADSIM_E_ARG      (-1)
+#define MADSIM_E_HIP      (-2)
+#define MADSIM_E_NOINIT   (-3)
+#define MADSIM_E_WORKLOAD (-4)
+#define MADSIM_E_LIMITS   (-5)
+
+uint32_t    madsim_hip_version(void);
+const char* madsim_hip_strerror(int code);
+const char* madsim_hip_last_error(void);
+
+/* Bind the calling process to one GPU (one process per GPU; replaces nothing in the reference —
+ * the reference's per-seed std::thread::spawn, builder.rs:134, has no device). */
+int madsim_hip_init(int device);
+int madsim_hip_shutdown(void);
+
+/* Replaces the seed loop of Builder::run (builder.rs:129-160) for `count` seeds from `seed0`.
+ * `out` is caller-allocated host memory [count] (may be NULL when only the summary is wanted). */
+int madsim_hip_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg,
+                         uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
+                         madsim_result_t* out, madsim_summary_t* summary);
+
+/* Same, results stay resident in HBM: `d_out` is device memory [count] owned by the caller,
+ * `stream` is a hipStream_t (NULL = the null stream).  Asynchronous unless `summary` != NULL
+ * (the summary needs a device reduction + D2H of 32 bytes, which synchronises `stream`). */
+int madsim_hip_run_batch_device(const madsim_workload_t* w, const madsim_config_t* cfg,
+                                uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
+                                void* d_out, void* stream, madsim_summary_t* summary);
+
+/* Re-run one seed and return the raw determinism log (rand.rs:64-88 byte per GlobalRng::with),
+ * the artefact MADSIM_TEST_CHECK_DETERMINISM compares (runtime/mod.rs:178-202).  Returns the number
+ * of bytes the log holds (may exceed cap; only cap bytes are written), <0 on error. */
+int64_t madsim_hip_trace_seed(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
+                              const madsim_limits_t* lim, uint8_t* log, uint64_t cap,
+                              madsim_result_t* out);
+
+/* Geometry the library picked for a workload (for DESIGN/bench reporting). */
+typedef struct madsim_geometry {
+    uint32_t lds_bytes_per_seed;
+    uint32_t lds_bytes_per_block;
+    uint32_t block_threads;
+    uint32_t blocks_per_cu;
+    uint32_t grid_blocks;
+    uint32_t heap_lds_slots;
+    uint32_t heap_spill_slots;
+    uint32_t max_tasks;
+} madsim_geometry_t;
+int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* g);
+
+/* Built-in workload of SURVEY.md §8d: N-node ping-pong, R rounds per pair.  Fills caller storage;
+ * returns the number of instructions written or <0 if `cap_insns` is too small. */
+int madsim_workload_pingpong(uint32_t n_nodes, uint32_t rounds, madsim_node_t* nodes /*[n_nodes+1]*/,
+                             madsim_prog_t* progs /*[n_nodes+1]*/, madsim_sock_t* socks /*[n_nodes]*/,
+                             madsim_insn_t* insns, uint32_t cap_insns, madsim_workload_t* w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MADSIM_HIP_H */

@@ -1,0 +1,111 @@
+"""ctypes mirror of include/madsim_hip.h (the C-ABI drop-in boundary).
+
+Pure data definitions: no device code, no oracle.  Both the product loader
+(`madsim_amd.runtime`) and the test-only oracle loader (`oracle/`) feed these
+same structs, so a parity test hands identical bytes to both sides.
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+U64_MAX = (1 << 64) - 1
+VAL_TIMEOUT = 0xFFFFFFFF
+
+
+class Insn(C.Structure):
+    _fields_ = [("op", C.c_uint8), ("a", C.c_uint8), ("b", C.c_uint16), ("imm", C.c_uint32)]
+
+
+class Prog(C.Structure):
+    _fields_ = [("node", C.c_uint8), ("flags", C.c_uint8), ("entry", C.c_uint16)]
+
+
+class Sock(C.Structure):
+    _fields_ = [("node", C.c_uint8), ("reserved", C.c_uint8), ("port", C.c_uint16)]
+
+
+class Node(C.Structure):
+    _fields_ = [("flags", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+
+
+class Workload(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_uint32), ("n_progs", C.c_uint32), ("n_socks", C.c_uint32), ("n_insns", C.c_uint32),
+        ("nodes", C.POINTER(Node)), ("progs", C.POINTER(Prog)), ("socks", C.POINTER(Sock)),
+        ("insns", C.POINTER(Insn)),
+    ]
+
+
+class Config(C.Structure):
+    """madsim::Config.net (net/network.rs:66-89) + the buggify switch (rand.rs:113-134)."""
+    _fields_ = [
+        ("packet_loss_rate", C.c_double), ("lat_lo_ns", C.c_uint64), ("lat_hi_ns", C.c_uint64),
+        ("buggify", C.c_uint32), ("n_loss_table", C.c_uint32), ("loss_table", C.c_double * 4),
+    ]
+
+    @classmethod
+    def default(cls, packet_loss_rate=0.0, lat_lo_ns=1_000_000, lat_hi_ns=10_000_000, buggify=False,
+                loss_table=()):
+        c = cls()
+        c.packet_loss_rate = packet_loss_rate
+        c.lat_lo_ns, c.lat_hi_ns = lat_lo_ns, lat_hi_ns
+        c.buggify = 1 if buggify else 0
+        c.n_loss_table = len(loss_table)
+        for i, p in enumerate(loss_table):
+            c.loss_table[i] = p
+        return c
+
+
+class Limits(C.Structure):
+    _fields_ = [
+        ("time_limit_ns", C.c_uint64), ("max_steps", C.c_uint32), ("heap_lds_slots", C.c_uint32),
+        ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32), ("mbox_regs", C.c_uint32),
+        ("mbox_msgs", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("verdict", C.c_uint32), ("steps", C.c_uint32), ("clock_ns", C.c_uint64), ("msg_count", C.c_uint64),
+        ("rng_calls", C.c_uint64), ("trace_hash", C.c_uint64), ("obs_hash", C.c_uint64),
+    ]
+
+    def astuple(self):
+        return (self.verdict, self.steps, self.clock_ns, self.msg_count, self.rng_calls, self.trace_hash,
+                self.obs_hash)
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("first_failing_seed", C.c_uint64), ("n_failed", C.c_uint64), ("total_steps", C.c_uint64),
+        ("total_clock_ns", C.c_uint64), ("kernel_ms", C.c_double), ("wall_s", C.c_double),
+    ]
+
+
+class Geometry(C.Structure):
+    _fields_ = [
+        ("lds_bytes_per_seed", C.c_uint32), ("lds_bytes_per_block", C.c_uint32), ("block_threads", C.c_uint32),
+        ("blocks_per_cu", C.c_uint32), ("grid_blocks", C.c_uint32), ("heap_lds_slots", C.c_uint32),
+        ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32),
+    ]
+
+
+assert C.sizeof(Insn) == 8 and C.sizeof(Prog) == 4 and C.sizeof(Sock) == 4 and C.sizeof(Node) == 4
+assert C.sizeof(Result) == 48 and C.sizeof(Summary) == 48 and C.sizeof(Limits) == 40
+
+# numpy view of a result array: one record per seed, same layout as madsim_result_t
+RESULT_DTYPE = [("verdict", "<u4"), ("steps", "<u4"), ("clock_ns", "<u8"), ("msg_count", "<u8"),
+                ("rng_calls", "<u8"), ("trace_hash", "<u8"), ("obs_hash", "<u8")]
+
+PASS, PANIC, DEADLOCK, TIME_LIMIT, OVERFLOW, STEP_LIMIT = range(6)
+VERDICT_NAMES = ["pass", "panic", "deadlock", "time-limit", "resource-overflow", "step-limit"]
+
+# enum madsim_op
+OP = dict(
+    DONE=0, SPAWN=1, JOIN=2, ABORT=3, YIELD=4, PANIC=5, SET=6, DJNZ=7, JMP=8, TRACE=9,
+    SLEEP=10, MARK=11, SLEEP_UNTIL=12, ASSERT_ELAPSED=13, ADVANCE=14, BUILD=15,
+    BIND=20, SEND=21, REPLY=22, RECV=23, ASSERT_VAL=24, RECV_TIMEOUT=25, CLOSE=26,
+    KILL=30, RESTART=31, PAUSE=32, RESUME=33, CLOG_NODE=34, UNCLOG_NODE=35, CLOG_LINK=36,
+    UNCLOG_LINK=37, ASSERT_EXIT=38, SET_LOSS=39, SLEEP_RAND=40,
+)
+PROG_INIT, PROG_PRE = 1, 2
+NODE_RESTART_ON_PANIC = 1

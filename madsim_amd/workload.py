@@ -1,0 +1,254 @@
+"""Workload assembler: a madsim test body written as an actor program.
+
+A GPU lane cannot poll an opaque Rust future, so the body of a `#[madsim::test]`
+is handed to the runner as a table of instructions, one per reference API call.
+The method names below are the reference's own (Endpoint::bind / send_to /
+recv_from in net/endpoint.rs, time::sleep in time/sleep.rs, spawn / JoinHandle
+in task/mod.rs + task/join.rs, Handle::kill/restart/pause/resume in
+runtime/mod.rs:276-303, NetSim::clog_* in net/mod.rs:164-222), so a workload
+reads like the Rust test it stands for.
+
+Pure host-side table construction: no device code, no oracle.
+"""
+import ctypes as C
+
+from . import _abi as A
+
+NS_PER_S = 1_000_000_000
+PING, PONG = 0x676E6970, 0x676E6F70  # b"ping", b"pong" little-endian
+
+
+def _dur(secs=0, ms=0, us=0, ns=0):
+    total = int(secs * NS_PER_S) + ms * 1_000_000 + us * 1_000 + ns
+    b, imm = divmod(total, NS_PER_S)
+    if b > 0xFFFF:
+        raise ValueError("duration too long for the 16-bit seconds field")
+    return b, imm
+
+
+class TaskBuilder:
+    """The async block of one task (`node.spawn(async move { ... })`)."""
+
+    def __init__(self, wl, index, node, flags=0):
+        self.wl, self.index, self.node, self.flags = wl, index, node, flags
+        self.code = []  # (op, a, b, imm, reloc)
+
+    def _emit(self, op, a=0, b=0, imm=0, reloc=False):
+        self.code.append([A.OP[op], a, b, imm & 0xFFFFFFFF, reloc])
+        return self
+
+    # -- control ---------------------------------------------------------------------------------
+    def label(self):
+        return len(self.code)
+
+    def done(self):
+        return self._emit("DONE")
+
+    def spawn(self, task):
+        return self._emit("SPAWN", a=task.index)
+
+    def join(self, task, expect_err=False):
+        return self._emit("JOIN", a=task.index, b=1 if expect_err else 0)
+
+    def abort(self, task):
+        return self._emit("ABORT", a=task.index)
+
+    def yield_now(self):
+        return self._emit("YIELD")
+
+    def panic(self):
+        return self._emit("PANIC")
+
+    def set(self, reg, value):
+        return self._emit("SET", a=reg, imm=value)
+
+    def djnz(self, reg, target):
+        return self._emit("DJNZ", a=reg, b=target, reloc=True)
+
+    def jmp(self, target):
+        return self._emit("JMP", b=target, reloc=True)
+
+    def trace(self, value, add_reg=None):
+        return self._emit("TRACE", a=add_reg or 0, b=1 if add_reg is not None else 0, imm=value)
+
+    def build_node(self, node):
+        return self._emit("BUILD", a=node)
+
+    # -- time ------------------------------------------------------------------------------------
+    def sleep(self, **kw):
+        b, imm = _dur(**kw)
+        return self._emit("SLEEP", b=b, imm=imm)
+
+    def mark(self):
+        return self._emit("MARK")
+
+    def sleep_until(self, **kw):
+        b, imm = _dur(**kw)
+        return self._emit("SLEEP_UNTIL", b=b, imm=imm)
+
+    def assert_elapsed(self, cmp, **kw):
+        b, imm = _dur(**kw)
+        return self._emit("ASSERT_ELAPSED", a={"==": 0, ">=": 1, "<": 2}[cmp], b=b, imm=imm)
+
+    def advance(self, **kw):
+        b, imm = _dur(**kw)
+        return self._emit("ADVANCE", b=b, imm=imm)
+
+    # -- net -------------------------------------------------------------------------------------
+    def bind(self, addr):
+        return self._emit("BIND", a=addr)
+
+    def send_to(self, ep, dst, tag, val):
+        return self._emit("SEND", a=ep, b=(tag << 8) | dst, imm=val)
+
+    def reply(self, ep, tag, val):
+        return self._emit("REPLY", a=ep, b=tag << 8, imm=val)
+
+    def recv_from(self, ep, tag):
+        return self._emit("RECV", a=ep, b=tag << 8)
+
+    def recv_from_timeout(self, ep, tag, **kw):
+        b, imm = _dur(**kw)
+        if b > 0xFF:
+            raise ValueError("timeout too long")
+        return self._emit("RECV_TIMEOUT", a=ep, b=(tag << 8) | b, imm=imm)
+
+    def assert_val(self, val):
+        return self._emit("ASSERT_VAL", imm=val)
+
+    def close(self, ep):
+        return self._emit("CLOSE", a=ep)
+
+    # -- supervisor ------------------------------------------------------------------------------
+    def kill(self, node):
+        return self._emit("KILL", a=node)
+
+    def restart(self, node):
+        return self._emit("RESTART", a=node)
+
+    def pause(self, node):
+        return self._emit("PAUSE", a=node)
+
+    def resume(self, node):
+        return self._emit("RESUME", a=node)
+
+    def clog_node(self, node, direction="both"):
+        return self._emit("CLOG_NODE", a=node, b={"in": 1, "out": 2, "both": 3}[direction])
+
+    def unclog_node(self, node, direction="both"):
+        return self._emit("UNCLOG_NODE", a=node, b={"in": 1, "out": 2, "both": 3}[direction])
+
+    def clog_link(self, src, dst):
+        return self._emit("CLOG_LINK", a=src, b=dst)
+
+    def unclog_link(self, src, dst):
+        return self._emit("UNCLOG_LINK", a=src, b=dst)
+
+    def assert_exit(self, node, expected):
+        return self._emit("ASSERT_EXIT", a=node, b=1 if expected else 0)
+
+    def set_loss(self, table_index):
+        return self._emit("SET_LOSS", a=table_index)
+
+    def sleep_rand(self, **kw):
+        b, imm = _dur(**kw)
+        return self._emit("SLEEP_RAND", b=b, imm=imm)
+
+
+class BuiltWorkload:
+    """Owns the ctypes arrays a `madsim_workload_t` points into."""
+
+    def __init__(self, nodes, progs, socks, insns):
+        self.nodes = (A.Node * len(nodes))(*nodes)
+        self.progs = (A.Prog * len(progs))(*progs)
+        self.socks = (A.Sock * max(1, len(socks)))(*socks)
+        self.insns = (A.Insn * len(insns))(*insns)
+        self.struct = A.Workload(len(nodes) - 1, len(progs), len(socks), len(insns), self.nodes, self.progs,
+                                 self.socks, self.insns)
+
+    def ref(self):
+        return C.byref(self.struct)
+
+
+class WorkloadBuilder:
+    def __init__(self):
+        self.nodes = [A.Node()]  # node 0 = "madsim-main"
+        self.socks = []
+        self.tasks = [TaskBuilder(self, 0, 0)]
+
+    def main(self):
+        """The future handed to Runtime::block_on / the #[madsim::test] body."""
+        return self.tasks[0]
+
+    def create_node(self, restart_on_panic=False):
+        n = A.Node()
+        n.flags = A.NODE_RESTART_ON_PANIC if restart_on_panic else 0
+        self.nodes.append(n)
+        return len(self.nodes) - 1
+
+    def addr(self, node, port):
+        """SocketAddr 10.0.0.<node>:<port> that an Endpoint may bind or send to."""
+        self.socks.append(A.Sock(node, 0, port))
+        return len(self.socks) - 1
+
+    def task(self, node, init=False, pre=False):
+        t = TaskBuilder(self, len(self.tasks), node,
+                        (A.PROG_INIT if init else 0) | (A.PROG_PRE if pre else 0))
+        self.tasks.append(t)
+        return t
+
+    def build(self):
+        insns, progs = [], []
+        for t in self.tasks:
+            base = len(insns)
+            if not t.code or t.code[-1][0] not in (A.OP["DONE"], A.OP["JMP"], A.OP["PANIC"]):
+                t.done()
+            progs.append(A.Prog(t.node, t.flags, base))
+            for op, a, b, imm, reloc in t.code:
+                insns.append(A.Insn(op, a, (b + base) if reloc else b, imm))
+        if len(insns) > 0xFFFF:
+            raise ValueError("program too long")
+        return BuiltWorkload(self.nodes, progs, self.socks, insns)
+
+
+def pingpong(n_nodes=4, rounds=64):
+    """SURVEY.md §8d synthetic workload: pairs (1,2),(3,4).. of Endpoint ping-pong.
+
+    Odd node = pinger: bind, sleep(1 s), R x {send_to(peer, 1, "ping"); recv_from(1); assert "pong"}.
+    Even node = ponger: bind, R x {recv_from(1); assert "ping"; send_to(from, 1, "pong")}.
+    Main (node 0) spawns one task per node in order and awaits every JoinHandle in order.
+    The C twin is madsim_workload_pingpong() in the library; tests check both emit the same table.
+    """
+    if n_nodes % 2 or n_nodes < 2:
+        raise ValueError("n_nodes must be even")
+    wl = WorkloadBuilder()
+    nodes = [wl.create_node() for _ in range(n_nodes)]
+    addrs = [wl.addr(n, 1) for n in nodes]
+    tasks = []
+    for i, n in enumerate(nodes):
+        t = wl.task(n)
+        t.bind(addrs[i])
+        if i % 2 == 0:
+            t.sleep(secs=1)
+            t.set(0, rounds)
+            top = t.label()
+            t.send_to(addrs[i], addrs[i + 1], 1, PING)
+            t.recv_from(addrs[i], 1)
+            t.assert_val(PONG)
+            t.djnz(0, top)
+        else:
+            t.set(0, rounds)
+            top = t.label()
+            t.recv_from(addrs[i], 1)
+            t.assert_val(PING)
+            t.reply(addrs[i], 1, PONG)
+            t.djnz(0, top)
+        t.done()
+        tasks.append(t)
+    m = wl.main()
+    for t in tasks:
+        m.spawn(t)
+    for t in tasks:
+        m.join(t)
+    m.done()
+    return wl.build()

@@ -1,0 +1,85 @@
+"""CPU oracle loader — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package.  The product (madsim_amd/) never does: it fails loudly when its
+HIP library is missing instead of falling back to anything here.
+
+Parity status: "parity unpinned" (see oracle/madsim_oracle.c header): the Rust
+reference cannot be built in this image and ships no golden vectors for the path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from madsim_amd import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libmadsim_oracle.so")
+
+
+class OracleStats(C.Structure):
+    _fields_ = [("max_heap", C.c_uint32), ("max_ready", C.c_uint32), ("max_tasks", C.c_uint32),
+                ("max_msgs", C.c_uint32), ("max_regs", C.c_uint32)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "madsim_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.madsim_oracle_run_batch.restype = C.c_int
+        L.madsim_oracle_run_batch.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64, C.c_uint64,
+                                              C.POINTER(A.Limits), C.c_void_p, C.POINTER(A.Summary),
+                                              C.POINTER(OracleStats)]
+        L.madsim_oracle_trace_seed.restype = C.c_int64
+        L.madsim_oracle_trace_seed.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64,
+                                               C.POINTER(A.Limits), C.c_void_p, C.c_uint64, C.POINTER(A.Result)]
+        L.oracle_seed_from_u64.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
+        L.oracle_xoshiro_next.restype = C.c_uint64
+        L.oracle_xoshiro_next.argtypes = [C.POINTER(C.c_uint64)]
+        L.madsim_oracle_gen_range.restype = C.c_uint64
+        L.madsim_oracle_gen_range.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.oracle_uniform_duration_params.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_int),
+                                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                                     C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+def run_batch(workload, seed0, count, config=None, limits=None, want_stats=False):
+    """Run `count` seeds on the CPU oracle. Returns (results ndarray[RESULT_DTYPE], Summary[, stats])."""
+    cfg = config or A.Config.default()
+    lim = limits or A.Limits()
+    out = np.zeros(count, dtype=A.RESULT_DTYPE)
+    summ = A.Summary()
+    st = OracleStats()
+    rc = lib().madsim_oracle_run_batch(workload.ref(), C.byref(cfg), seed0, count, C.byref(lim),
+                                       out.ctypes.data_as(C.c_void_p), C.byref(summ), C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"oracle error {rc}")
+    return (out, summ, st) if want_stats else (out, summ)
+
+
+def trace_seed(workload, seed, config=None, limits=None, cap=1 << 20):
+    """Determinism log (rand.rs:64-88) of one seed: (bytes, Result)."""
+    cfg = config or A.Config.default()
+    lim = limits or A.Limits()
+    buf = (C.c_uint8 * cap)()
+    res = A.Result()
+    n = lib().madsim_oracle_trace_seed(workload.ref(), C.byref(cfg), seed, C.byref(lim), buf, cap, C.byref(res))
+    if n < 0:
+        raise RuntimeError(f"oracle error {n}")
+    return bytes(buf[:min(n, cap)]), res

@@ -1,0 +1,758 @@
+/*
+ * madsim_oracle.c — CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A single-threaded plain-C restatement of madsim's deterministic executor for workloads expressed
+ * in the actor-program form of include/madsim_hip.h.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product path (madsim_amd/csrc) never
+ * links, imports or falls back to it.
+ *
+ * PARITY STATUS: "parity unpinned" for exact RNG values, heap tie order and wake order.  The
+ * reference (madsim 0.2.34) cannot be built here (no rustc/cargo, no vendored crates) and its own
+ * tests hold no golden vectors for this path — only relational properties, which
+ * tests/test_oracle_*.py restate.  The arithmetic that lives in unvendored crates is restated from
+ * the published algorithms and marked [DEP] below:
+ *   rand_xoshiro 0.6 (Xoshiro256PlusPlus, SplitMix64 seeding), rand 0.8 (UniformInt::sample_single,
+ *   UniformInt::sample, UniformDuration, Bernoulli), naive-timer 0.2 + alloc BinaryHeap, async-task 4.4
+ *   (wake/schedule state machine), tokio 1 (oneshot wake, yield_now outside a runtime).
+ * Known-answer anchors: the public xoshiro256++ / SplitMix64 vectors (tests/golden/).
+ *
+ * Every function cites the reference file:line (relative to /root/reference/madsim/src/sim/) it
+ * follows.  Data structures are deliberately literal (Vec + swap_remove ready queue, array
+ * BinaryHeap with Rust's sift order, Vec mailboxes) and deliberately different from the HIP
+ * kernel's LDS layout, so agreement between the two is evidence and not a tautology.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "madsim_oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * small growable vector helper
+ * ---------------------------------------------------------------------------------------------- */
+#define VEC(T) struct { T* p; size_t n, cap; }
+#define vec_push(v, x) do { if ((v).n == (v).cap) { (v).cap = (v).cap ? (v).cap * 2 : 8; \
+    (v).p = realloc((v).p, (v).cap * sizeof *(v).p); } (v).p[(v).n++] = (x); } while (0)
+#define vec_free(v) do { free((v).p); (v).p = NULL; (v).n = (v).cap = 0; } while (0)
+
+#define FNV_OFFSET 14695981039346656037ull
+#define FNV_PRIME  1099511628211ull
+#define NS_PER_S   1000000000ull
+#define NS_PER_MS  1000000ull
+
+/* ------------------------------------------------------------------------------------------------
+ * GlobalRng                                                           rand.rs:27-61, [DEP] A.1
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint64_t s[4]; } xoshiro_t;
+
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+/* [DEP rand_core 0.6 SeedableRng::seed_from_u64 as overridden by rand_xoshiro: SplitMix64 fill] */
+void oracle_seed_from_u64(uint64_t seed, uint64_t s[4]) {
+    uint64_t x = seed;
+    for (int i = 0; i < 4; i++) {
+        x += 0x9e3779b97f4a7c15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        s[i] = z ^ (z >> 31);
+    }
+}
+
+/* [DEP rand_xoshiro 0.6 Xoshiro256PlusPlus::next_u64] */
+uint64_t oracle_xoshiro_next(uint64_t s[4]) {
+    uint64_t r = rotl64(s[0] + s[3], 23) + s[0];
+    uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * simulation state
+ * ---------------------------------------------------------------------------------------------- */
+enum { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3 };
+
+typedef struct {           /* naive_timer::Event: deadline + boxed callback               [DEP A.5] */
+    uint64_t deadline;
+    uint8_t  kind;
+    uint16_t slot, gen;    /* EV_WAKE: task instance + generation (a cloned Waker)                   */
+    uint8_t  sock, sockgen, from, tag; /* EV_DELIVER: captured Arc<dyn Socket>, src addr, tag        */
+    uint32_t val;          /* EV_DELIVER payload                                                     */
+    uint8_t  node;         /* EV_RESTART                                                             */
+} event_t;
+
+typedef struct { uint8_t tag; uint16_t slot, gen; uint8_t rxseq; } reg_t;  /* (tag, oneshot::Sender) */
+typedef struct { uint8_t tag, from; uint32_t val; } msg_t;                 /* endpoint.rs:288-292    */
+
+typedef struct {
+    uint8_t bound; uint8_t gen;           /* gen: which Endpoint object currently owns the address   */
+    uint16_t owner_slot, owner_gen;
+    VEC(reg_t) registered;                /* endpoint.rs:298-303 Mailbox                             */
+    VEC(msg_t) msgs;
+} sock_t;
+
+enum { AW_NONE = 0 };
+
+typedef struct {
+    uint8_t  alive;        /* the future exists (spawned, not yet completed/dropped)                 */
+    uint16_t gen;
+    uint8_t  prog, node;
+    uint8_t  killed;       /* this task's Arc<NodeInfo>.killed                                       */
+    uint8_t  cancelled;    /* TaskInfo.cancelled (task/mod.rs:84)                                    */
+    uint8_t  scheduled, running;          /* async-task SCHEDULED / RUNNING bits            [DEP A.7] */
+    uint16_t pc; uint8_t sub;
+    uint64_t deadline;     /* the Sleep currently awaited (time/sleep.rs:21-24)                      */
+    uint64_t deadline2;    /* the Sleep inside timeout()                                             */
+    uint64_t t0;
+    uint16_t cnt[2];
+    uint32_t val; uint8_t from;
+    uint8_t  inbox_full; uint8_t rxseq;   /* the oneshot::Receiver currently held                    */
+    int32_t  joiner; uint16_t joiner_gen; /* async-task awaiter                                      */
+} task_t;
+
+enum { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
+typedef struct { uint8_t state; uint16_t slot, gen; } handle_t;
+
+typedef struct {
+    uint8_t killed, paused;
+    VEC(uint16_t) paused_list;            /* Node.paused: Vec<Runnable> (task/mod.rs:345-350)        */
+} node_t;
+
+typedef struct {
+    const madsim_workload_t* w;
+    /* GlobalRng */
+    xoshiro_t rng; uint64_t rng_calls; int buggify;
+    uint64_t trace_hash; uint8_t* log; uint64_t log_len, log_cap;
+    /* Clock + Timer */
+    uint64_t clock;
+    VEC(event_t) heap;
+    /* Executor */
+    VEC(uint16_t) ready;
+    VEC(task_t) tasks;
+    handle_t* handles;
+    node_t* nodes;
+    sock_t* socks;
+    /* Network */
+    uint64_t clog_in, clog_out;           /* HashSet<NodeId> as bit sets (network.rs:27-28)          */
+    uint64_t* clog_link;                  /* [n_nodes+1] rows of bits (network.rs:29)                */
+    uint64_t loss_pint; int loss_always;  /* Bernoulli p_int                                 [DEP A.4] */
+    int lat_mode; uint64_t lat_low, lat_range, lat_zone; /* UniformDuration               [DEP A.3] */
+    const madsim_config_t* cfg;
+    /* accounting */
+    uint64_t msg_count; uint32_t steps; uint64_t obs_hash;
+    uint32_t panic; int main_slot;
+    madsim_oracle_stats_t st;
+} sim_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * GlobalRng::with + determinism log                                   rand.rs:64-88, A.6
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint64_t rng_next(sim_t* S) { S->rng_calls++; return oracle_xoshiro_next(S->rng.s); }
+
+/* One call per GlobalRng::with(): v = clone.gen::<u8>() ^ xor-fold(elapsed.as_nanos() as u128).
+ * gen::<u8>() = next_u32() as u8 [DEP rand 0.8 Standard]; next_u32 = (next_u64 >> 32) [DEP xoshiro]. */
+static void rng_log(sim_t* S) {
+    xoshiro_t c = S->rng;
+    uint8_t v = (uint8_t)(oracle_xoshiro_next(c.s) >> 32);
+    uint64_t t = S->clock;
+    for (int i = 0; i < 8; i++) v ^= (uint8_t)(t >> (8 * i));
+    S->trace_hash = (S->trace_hash ^ v) * FNV_PRIME;
+    if (S->log && S->log_len < S->log_cap) S->log[S->log_len] = v;
+    S->log_len++;
+}
+
+/* [DEP rand 0.8 UniformInt<u64>::sample_single_inclusive via gen_range(lo..hi)] A.2
+ * call sites: utils/mpsc.rs:76, task/mod.rs:320, time/mod.rs:31, net/mod.rs:288,290 — each wrapped
+ * in ONE GlobalRng::with, so one log byte regardless of rejections. */
+static uint64_t gen_range_u64(sim_t* S, uint64_t lo, uint64_t hi) {
+    uint64_t range = hi - lo;   /* (hi-1) - lo + 1 */
+    uint64_t zone = (range << __builtin_clzll(range)) - 1;
+    uint64_t res;
+    for (;;) {
+        uint64_t v = rng_next(S);
+        unsigned __int128 m = (unsigned __int128)v * range;
+        if ((uint64_t)m <= zone) { res = lo + (uint64_t)(m >> 64); break; }
+    }
+    rng_log(S);
+    return res;
+}
+
+/* [DEP rand 0.8 Bernoulli] via GlobalRng's RngCore impl (rand.rs:142-158): one with() per draw. */
+static int gen_bool_pint(sim_t* S, uint64_t p_int, int always) {
+    if (always) return 1;
+    uint64_t v = rng_next(S);
+    rng_log(S);
+    return v < p_int;
+}
+
+/* [DEP rand 0.8 UniformDuration::new(lo,hi).sample] A.3.  `direct`: called on GlobalRng through its
+ * RngCore impl (network.rs:267) => one with() per attempt; otherwise inside one with(). */
+void oracle_uniform_duration_params(uint64_t lo, uint64_t hi, int* mode, uint64_t* low,
+                                    uint64_t* range, uint64_t* zone) {
+    uint64_t h = hi - 1;
+    uint64_t lo_s = lo / NS_PER_S, lo_n = lo % NS_PER_S, hi_s = h / NS_PER_S, hi_n = h % NS_PER_S;
+    if (hi_n < lo_n) { hi_s -= 1; hi_n += NS_PER_S; }
+    if (lo_s == hi_s) {            /* Small: Uniform<u32>::new_inclusive(lo_n, hi_n) */
+        uint32_t r = (uint32_t)(hi_n - lo_n + 1);
+        uint32_t reject = r ? (uint32_t)((0xffffffffu - r + 1u) % r) : 0;
+        *mode = 0; *low = lo_s * NS_PER_S + lo_n; *range = r; *zone = 0xffffffffu - reject;
+    } else {                       /* Medium: Uniform<u64>::new_inclusive(lo, hi-1) */
+        uint64_t r = h - lo + 1;
+        uint64_t reject = r ? (UINT64_MAX - r + 1) % r : 0;
+        *mode = 1; *low = lo; *range = r; *zone = UINT64_MAX - reject;
+    }
+}
+
+static uint64_t sample_duration(sim_t* S, int mode, uint64_t low, uint64_t range, uint64_t zone,
+                                int direct) {
+    uint64_t res;
+    for (;;) {
+        uint64_t v = rng_next(S);
+        if (direct) rng_log(S);
+        if (mode == 0) {
+            uint64_t m = (uint64_t)(uint32_t)(v >> 32) * (uint64_t)(uint32_t)range; /* next_u32 */
+            if ((uint32_t)m <= (uint32_t)zone) { res = low + (m >> 32); break; }
+        } else {
+            unsigned __int128 m = (unsigned __int128)v * range;
+            if ((uint64_t)m <= zone) { res = low + (uint64_t)(m >> 64); break; }
+        }
+    }
+    if (!direct) rng_log(S);
+    return res;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Timer = BinaryHeap<Event>, Ord reversed on deadline only            [DEP A.5]
+ * Rust alloc::collections::BinaryHeap push / pop / sift_up / sift_down_to_bottom restated on the
+ * array.  "a <= b" in heap order means a.deadline >= b.deadline.
+ * ---------------------------------------------------------------------------------------------- */
+static void heap_sift_up(event_t* d, size_t start, size_t pos) {
+    event_t hole = d[pos];
+    while (pos > start) {
+        size_t parent = (pos - 1) / 2;
+        if (hole.deadline >= d[parent].deadline) break;   /* hole <= parent: stop */
+        d[pos] = d[parent];
+        pos = parent;
+    }
+    d[pos] = hole;
+}
+
+static void timer_add(sim_t* S, event_t e) {              /* time/mod.rs:158-165 -> Timer::add */
+    vec_push(S->heap, e);
+    heap_sift_up(S->heap.p, 0, S->heap.n - 1);
+    if (S->heap.n > S->st.max_heap) S->st.max_heap = (uint32_t)S->heap.n;
+}
+
+static event_t timer_pop(sim_t* S) {                      /* BinaryHeap::pop */
+    event_t* d = S->heap.p;
+    event_t item = d[--S->heap.n];
+    if (S->heap.n > 0) {
+        event_t top = d[0]; d[0] = item; item = top;
+        size_t end = S->heap.n, pos = 0;
+        event_t hole = d[0];
+        size_t child = 1;
+        while (child + 1 < end) {                         /* child <= end.saturating_sub(2) */
+            if (d[child].deadline >= d[child + 1].deadline) child++;  /* left <= right: take right */
+            d[pos] = d[child]; pos = child; child = 2 * pos + 1;
+        }
+        if (child == end - 1) { d[pos] = d[child]; pos = child; }
+        d[pos] = hole;
+        heap_sift_up(d, 0, pos);
+    }
+    return item;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * async-task wake / schedule                                          [DEP A.7], task/mod.rs:640-651
+ * ---------------------------------------------------------------------------------------------- */
+static void ready_push(sim_t* S, uint16_t slot) {         /* utils/mpsc.rs:55-61 Vec::push */
+    vec_push(S->ready, slot);
+    if (S->ready.n > S->st.max_ready) S->st.max_ready = (uint32_t)S->ready.n;
+}
+
+static void wake(sim_t* S, uint16_t slot, uint16_t gen) {
+    if (slot >= S->tasks.n) return;
+    task_t* t = &S->tasks.p[slot];
+    if (!t->alive || t->gen != gen) return;               /* COMPLETED | CLOSED: no-op */
+    if (t->scheduled) return;
+    t->scheduled = 1;
+    if (!t->running) ready_push(S, slot);                 /* RUNNING: run() re-queues after the poll */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Network                                                             net/network.rs
+ * ---------------------------------------------------------------------------------------------- */
+static int link_clogged(sim_t* S, unsigned src, unsigned dst) {        /* network.rs:199-203 */
+    return ((S->clog_out >> src) & 1) || ((S->clog_in >> dst) & 1) || ((S->clog_link[src] >> dst) & 1);
+}
+
+static int find_bound(sim_t* S, unsigned node, unsigned port) {        /* network.rs:304-306 */
+    for (uint32_t i = 0; i < S->w->n_socks; i++)
+        if (S->socks[i].bound && S->w->socks[i].node == node && S->w->socks[i].port == port) return (int)i;
+    return -1;
+}
+
+/* Network::try_send (network.rs:296-313) + test_link (:261-269).  Returns 1 and the latency/socket
+ * when a delivery must be scheduled. */
+static int try_send(sim_t* S, unsigned src_node, unsigned dst_addr, uint64_t* latency, int* dst_sock) {
+    unsigned dst_node = S->w->socks[dst_addr].node;       /* resolve_dest_node :272-290 */
+    if (link_clogged(S, src_node, dst_node)) return 0;    /* no draw */
+    if (gen_bool_pint(S, S->loss_pint, S->loss_always)) return 0;
+    S->msg_count++;
+    *latency = sample_duration(S, S->lat_mode, S->lat_low, S->lat_range, S->lat_zone, 1);
+    int s = find_bound(S, dst_node, S->w->socks[dst_addr].port);
+    if (s < 0) return 0;                                  /* draws consumed, silently dropped */
+    *dst_sock = s;
+    return 1;
+}
+
+/* Mailbox::deliver (endpoint.rs:331-351) through EndpointSocket::deliver (:311-318). */
+static void mailbox_deliver(sim_t* S, event_t* e) {
+    sock_t* k = &S->socks[e->sock];
+    if (!k->bound || k->gen != e->sockgen) return;        /* Endpoint object gone: unobservable */
+    size_t i = 0;
+    while (i < k->registered.n) {
+        if (k->registered.p[i].tag == e->tag) {
+            reg_t r = k->registered.p[i];
+            k->registered.p[i] = k->registered.p[--k->registered.n];     /* swap_remove */
+            task_t* t = r.slot < S->tasks.n ? &S->tasks.p[r.slot] : NULL;
+            if (t && t->alive && t->gen == r.gen && t->rxseq == r.rxseq && !t->inbox_full) {
+                t->inbox_full = 1; t->val = e->val; t->from = e->from;   /* oneshot send Ok */
+                wake(S, r.slot, r.gen);                                   /* [DEP tokio oneshot] */
+                return;
+            }
+            /* receiver dropped: try next (i stays) */
+        } else {
+            i++;
+        }
+    }
+    msg_t m = { e->tag, e->from, e->val };
+    vec_push(k->msgs, m);
+    if (k->msgs.n > S->st.max_msgs) S->st.max_msgs = (uint32_t)k->msgs.n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * task lifecycle
+ * ---------------------------------------------------------------------------------------------- */
+static void sock_close_owned(sim_t* S, uint16_t slot, uint16_t gen, int node_killed) {
+    /* BindGuard::drop (net/mod.rs:483-493): skipped when the binder's NodeInfo is killed */
+    for (uint32_t i = 0; i < S->w->n_socks; i++) {
+        sock_t* k = &S->socks[i];
+        if (k->owner_slot == slot && k->owner_gen == gen && k->bound) {
+            if (!node_killed) { k->bound = 0; }
+            /* the Endpoint (and its mailbox) is unreachable from now on either way */
+        }
+    }
+}
+
+static int spawn_task(sim_t* S, unsigned prog, int record_handle) {   /* task/mod.rs:627-654 */
+    size_t slot = 0;
+    while (slot < S->tasks.n && S->tasks.p[slot].alive) slot++;
+    if (slot == S->tasks.n) { task_t z; memset(&z, 0, sizeof z); vec_push(S->tasks, z); }
+    task_t* t = &S->tasks.p[slot];
+    uint16_t gen = (uint16_t)(t->gen + 1);
+    memset(t, 0, sizeof *t);
+    t->alive = 1; t->gen = gen; t->prog = (uint8_t)prog; t->node = S->w->progs[prog].node;
+    t->killed = S->nodes[t->node].killed;                 /* spawning on a killed node :632-634 */
+    t->pc = S->w->progs[prog].entry; t->joiner = -1;
+    t->scheduled = 1;                                     /* runnable.schedule() :651 */
+    ready_push(S, (uint16_t)slot);
+    if (record_handle) { S->handles[prog].state = H_RUNNING; S->handles[prog].slot = (uint16_t)slot; S->handles[prog].gen = gen; }
+    uint32_t live = 0; for (size_t i = 0; i < S->tasks.n; i++) live += S->tasks.p[i].alive;
+    if (live > S->st.max_tasks) S->st.max_tasks = live;
+    return (int)slot;
+}
+
+/* The future is gone (completed, or dropped by the executor).  outcome: H_COMPLETED / H_CANCELLED. */
+static void task_finish(sim_t* S, uint16_t slot, int outcome) {
+    task_t* t = &S->tasks.p[slot];
+    sock_close_owned(S, slot, t->gen, t->killed);
+    handle_t* h = &S->handles[t->prog];
+    if (h->state == H_RUNNING && h->slot == slot && h->gen == t->gen) h->state = (uint8_t)outcome;
+    int32_t j = t->joiner; uint16_t jg = t->joiner_gen;
+    t->alive = 0; t->scheduled = 0; t->running = 0;
+    if (j >= 0) wake(S, (uint16_t)j, jg);                 /* async-task notifies the awaiter */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * one poll of a task's future (Runnable::run, task/mod.rs:279-283).  Returns 1 if the task panicked.
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint64_t insn_dur(const madsim_insn_t* in) { return (uint64_t)in->b * NS_PER_S + in->imm; }
+
+/* Sleep::poll (time/sleep.rs:47-54): Ready when elapsed, else register ANOTHER timer. */
+static int sleep_poll(sim_t* S, uint16_t slot, uint64_t deadline) {
+    if (S->clock >= deadline) return 1;
+    event_t e; memset(&e, 0, sizeof e);
+    e.deadline = deadline; e.kind = EV_WAKE; e.slot = slot; e.gen = S->tasks.p[slot].gen;
+    timer_add(S, e);
+    return 0;
+}
+
+/* TimeHandle::sleep / sleep_until (time/mod.rs:111-124): 1 ms floor. */
+static uint64_t sleep_deadline(sim_t* S, uint64_t deadline) {
+    uint64_t min_deadline = S->clock + NS_PER_MS;
+    return deadline > min_deadline ? deadline : min_deadline;
+}
+
+/* NetSim::rand_delay first half (net/mod.rs:287-292): draws, returns the Sleep deadline. */
+static uint64_t rand_delay_start(sim_t* S) {
+    uint64_t delay = gen_range_u64(S, 0, 5) * 1000ull;
+    if (S->buggify && gen_bool_pint(S, (uint64_t)(0.1 * 18446744073709551616.0), 0))
+        delay = gen_range_u64(S, 1, 5) * NS_PER_S;
+    return sleep_deadline(S, S->clock + delay);
+}
+
+static void timer_expire(sim_t* S, uint64_t now);
+
+static int poll_task(sim_t* S, uint16_t slot) {
+    const madsim_workload_t* w = S->w;
+    for (;;) {
+        task_t* t = &S->tasks.p[slot];
+        if (t->pc >= w->n_insns) return 1;
+        const madsim_insn_t* in = &w->insns[t->pc];
+        switch (in->op) {
+        case MS_OP_DONE:
+            task_finish(S, slot, H_COMPLETED);
+            return 0;
+        case MS_OP_SPAWN:
+            spawn_task(S, in->a, 1);
+            t = &S->tasks.p[slot]; t->pc++;
+            break;
+        case MS_OP_BUILD:                                  /* create_node().init(..).build(): task/mod.rs:472-474 */
+            for (uint32_t p = 1; p < w->n_progs; p++)
+                if (w->progs[p].node == in->a && (w->progs[p].flags & MADSIM_PROG_INIT)
+                    && !(w->progs[p].flags & MADSIM_PROG_PRE)) spawn_task(S, p, 0);
+            t = &S->tasks.p[slot]; t->pc++;
+            break;
+        case MS_OP_JOIN: {                                 /* task/join.rs:59-72 + async-task poll_task */
+            handle_t* h = &S->handles[in->a];
+            if (h->state == H_RUNNING) {
+                task_t* c = &S->tasks.p[h->slot];
+                c->joiner = slot; c->joiner_gen = t->gen;  /* header.register(cx.waker()) */
+                return 0;
+            }
+            int want_err = in->b & 1;
+            if (h->state == H_NONE) return 1;
+            if ((h->state == H_CANCELLED) != want_err) return 1;   /* unwrap()/unwrap_err() */
+            t->pc++;
+            break;
+        }
+        case MS_OP_YIELD:                                  /* [DEP tokio yield_now outside a runtime] */
+            if (t->sub == 0) { t->sub = 1; wake(S, slot, t->gen); return 0; }
+            t->sub = 0; t->pc++;
+            break;
+        case MS_OP_PANIC:
+            return 1;
+        case MS_OP_SET:
+            t->cnt[in->a & 1] = (uint16_t)in->imm; t->pc++;
+            break;
+        case MS_OP_DJNZ:
+            if (--t->cnt[in->a & 1] != 0) t->pc = in->b; else t->pc++;
+            break;
+        case MS_OP_JMP:
+            t->pc = in->b;
+            break;
+        case MS_OP_TRACE: {
+            uint64_t v = in->imm + ((in->b & 1) ? t->cnt[in->a & 1] : 0);
+            S->obs_hash = (S->obs_hash ^ v) * FNV_PRIME; t->pc++;
+            break;
+        }
+        case MS_OP_SLEEP:
+        case MS_OP_SLEEP_UNTIL:
+            if (t->sub == 0) {
+                uint64_t base = in->op == MS_OP_SLEEP ? S->clock : t->t0;
+                t->deadline = sleep_deadline(S, base + insn_dur(in));
+                t->sub = 1;
+            }
+            if (!sleep_poll(S, slot, t->deadline)) return 0;
+            t->sub = 0; t->pc++;
+            break;
+        case MS_OP_MARK:
+            t->t0 = S->clock; t->pc++;
+            break;
+        case MS_OP_ASSERT_ELAPSED: {
+            uint64_t el = S->clock - t->t0, d = insn_dur(in);
+            int ok = in->a == 0 ? el == d : in->a == 1 ? el >= d : el < d;
+            if (!ok) return 1;
+            t->pc++;
+            break;
+        }
+        case MS_OP_ADVANCE:                                /* time/mod.rs:103-106 */
+            S->clock += insn_dur(in);
+            t->pc++;
+            timer_expire(S, S->clock);
+            break;
+        case MS_OP_BIND:                                   /* net/mod.rs:446-470, network.rs:206-251 */
+            if (t->sub == 0) { t->deadline = rand_delay_start(S); t->sub = 1; }
+            if (!sleep_poll(S, slot, t->deadline)) return 0;
+            {
+                const madsim_sock_t* a = &w->socks[in->a];
+                if (a->node != t->node) return 1;          /* AddrNotAvailable -> unwrap panics */
+                if (find_bound(S, a->node, a->port) >= 0) return 1;   /* AddrInUse */
+                sock_t* k = &S->socks[in->a];
+                k->bound = 1; k->gen++; k->owner_slot = slot; k->owner_gen = t->gen;
+                k->registered.n = 0; k->msgs.n = 0;        /* a fresh Endpoint + Mailbox */
+            }
+            t->sub = 0; t->pc++;
+            break;
+        case MS_OP_SEND:
+        case MS_OP_REPLY:                                  /* net/mod.rs:298-333 */
+            if (t->sub == 0) { t->deadline = rand_delay_start(S); t->sub = 1; }
+            if (!sleep_poll(S, slot, t->deadline)) return 0;
+            {
+                unsigned dst = in->op == MS_OP_SEND ? (in->b & 0xff) : t->from;
+                uint64_t lat; int ds;
+                if (try_send(S, w->socks[in->a].node, dst, &lat, &ds)) {
+                    event_t e; memset(&e, 0, sizeof e);
+                    e.deadline = S->clock + lat; e.kind = EV_DELIVER; e.sock = (uint8_t)ds;
+                    e.sockgen = S->socks[ds].gen; e.from = in->a; e.tag = (uint8_t)(in->b >> 8);
+                    e.val = in->imm;
+                    timer_add(S, e);
+                }
+            }
+            t->sub = 0; t->pc++;
+            break;
+        case MS_OP_RECV: {                                 /* endpoint.rs:140-149, 353-362 */
+            sock_t* k = &S->socks[in->a];
+            uint8_t tag = (uint8_t)(in->b >> 8);
+            if (t->sub == 0) {
+                t->rxseq++; t->inbox_full = 0;
+                size_t idx = 0;
+                while (idx < k->msgs.n && k->msgs.p[idx].tag != tag) idx++;
+                if (idx < k->msgs.n) {
+                    msg_t m = k->msgs.p[idx];
+                    k->msgs.p[idx] = k->msgs.p[--k->msgs.n];            /* swap_remove */
+                    t->inbox_full = 1; t->val = m.val; t->from = m.from;
+                } else {
+                    reg_t r = { tag, slot, t->gen, t->rxseq };
+                    vec_push(k->registered, r);
+                    if (k->registered.n > S->st.max_regs) S->st.max_regs = (uint32_t)k->registered.n;
+                }
+                t->sub = 1;
+            }
+            if (t->sub == 1) {
+                if (!t->inbox_full) return 0;              /* oneshot rx Pending */
+                t->inbox_full = 0;
+                t->deadline = rand_delay_start(S); t->sub = 2;
+            }
+            if (!sleep_poll(S, slot, t->deadline)) return 0;
+            t->sub = 0; t->pc++;
+            break;
+        }
+        case MS_OP_ASSERT_VAL:
+            if (t->val != in->imm) return 1;
+            t->pc++;
+            break;
+        case MS_OP_CLOSE: {
+            sock_t* k = &S->socks[in->a];
+            if (k->bound && k->owner_slot == slot && k->owner_gen == t->gen && !t->killed) k->bound = 0;
+            t->pc++;
+            break;
+        }
+        case MS_OP_CLOG_NODE:                              /* network.rs:162-171 */
+            if (in->b & 1) S->clog_in |= 1ull << in->a;
+            if (in->b & 2) S->clog_out |= 1ull << in->a;
+            t->pc++;
+            break;
+        case MS_OP_UNCLOG_NODE:                            /* network.rs:173-182 */
+            if (in->b & 1) S->clog_in &= ~(1ull << in->a);
+            if (in->b & 2) S->clog_out &= ~(1ull << in->a);
+            t->pc++;
+            break;
+        case MS_OP_CLOG_LINK:
+            S->clog_link[in->a] |= 1ull << in->b; t->pc++;
+            break;
+        case MS_OP_UNCLOG_LINK:
+            S->clog_link[in->a] &= ~(1ull << in->b); t->pc++;
+            break;
+        case MS_OP_SET_LOSS: {                             /* net/mod.rs:138-141 */
+            double p = S->cfg->loss_table[in->a & 3];
+            S->loss_always = p == 1.0;
+            S->loss_pint = S->loss_always ? 0 : (uint64_t)(p * 18446744073709551616.0);
+            t->pc++;
+            break;
+        }
+        default:
+            return 1;                                      /* unsupported op in this oracle build */
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Timer::expire                                                        [DEP A.5], time/mod.rs:54,105
+ * ---------------------------------------------------------------------------------------------- */
+static void timer_expire(sim_t* S, uint64_t now) {
+    while (S->heap.n > 0 && S->heap.p[0].deadline <= now) {
+        event_t e = timer_pop(S);
+        S->steps++;
+        switch (e.kind) {
+        case EV_WAKE: wake(S, e.slot, e.gen); break;       /* time/sleep.rs:52 waker.wake() */
+        case EV_DELIVER: mailbox_deliver(S, &e); break;    /* net/mod.rs:323-330 */
+        default: break;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Executor::run_all_ready                                              task/mod.rs:263-323
+ * ---------------------------------------------------------------------------------------------- */
+static void run_all_ready(sim_t* S, uint32_t max_steps) {
+    while (S->ready.n > 0 && !S->panic && S->steps < max_steps) {
+        /* try_recv_random (utils/mpsc.rs:73-83): idx drawn even when len == 1 */
+        size_t idx = (size_t)gen_range_u64(S, 0, S->ready.n);
+        uint16_t slot = S->ready.p[idx];
+        S->ready.p[idx] = S->ready.p[--S->ready.n];        /* swap_remove */
+        task_t* t = &S->tasks.p[slot];
+        S->steps++;
+        if (t->cancelled || t->killed) {                   /* :269-273 drop(runnable) */
+            task_finish(S, slot, H_CANCELLED);
+        } else if (S->nodes[t->node].paused) {             /* :274-277 */
+            vec_push(S->nodes[t->node].paused_list, slot);
+            S->steps--;                                    /* no poll, no time advance */
+            continue;
+        } else {
+            t->scheduled = 0; t->running = 1;              /* async-task run(): clear SCHEDULED, set RUNNING */
+            int panicked = poll_task(S, slot);
+            t = &S->tasks.p[slot];
+            if (panicked) {                                /* :289-317 (restart_on_panic: not in this build) */
+                S->panic = 1;
+                return;                                    /* resume_unwind: block_on unwinds */
+            }
+            if (t->alive) {
+                t->running = 0;
+                if (t->scheduled) ready_push(S, slot);     /* woken while running: re-queue after the poll */
+            }
+        }
+        /* :319-321 advance time 50..100 ns, then Timer::expire (time/mod.rs:103-106) */
+        uint64_t dur = gen_range_u64(S, 50, 100);
+        S->clock += dur;
+        timer_expire(S, S->clock);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Runtime::with_seed_and_config + block_on                             runtime/mod.rs:53-69,127-130
+ * ---------------------------------------------------------------------------------------------- */
+static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
+    if (!w || !w->insns || !w->progs || w->n_progs == 0 || w->n_progs > 255) return -1;
+    if (w->n_nodes > 62 || w->n_socks > 63) return -1;
+    if (w->n_socks && !w->socks) return -1;
+    if (cfg->lat_lo_ns >= cfg->lat_hi_ns) return -1;      /* "cannot sample empty range" */
+    if (!(cfg->packet_loss_rate >= 0.0 && cfg->packet_loss_rate <= 1.0)) return -1;
+    return 0;
+}
+
+static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim,
+                    uint64_t seed, madsim_result_t* out, uint8_t* log, uint64_t log_cap,
+                    uint64_t* log_len, madsim_oracle_stats_t* stats) {
+    sim_t S; memset(&S, 0, sizeof S);
+    S.w = w; S.cfg = cfg;
+    S.handles = calloc(w->n_progs, sizeof *S.handles);
+    S.nodes = calloc(w->n_nodes + 1, sizeof *S.nodes);
+    S.socks = calloc(w->n_socks ? w->n_socks : 1, sizeof *S.socks);
+    S.clog_link = calloc(w->n_nodes + 1, sizeof *S.clog_link);
+    S.trace_hash = FNV_OFFSET; S.obs_hash = FNV_OFFSET;
+    S.log = log; S.log_cap = log_cap;
+    S.buggify = cfg->buggify != 0;
+    S.loss_always = cfg->packet_loss_rate == 1.0;
+    S.loss_pint = S.loss_always ? 0 : (uint64_t)(cfg->packet_loss_rate * 18446744073709551616.0);
+    oracle_uniform_duration_params(cfg->lat_lo_ns, cfg->lat_hi_ns, &S.lat_mode, &S.lat_low, &S.lat_range, &S.lat_zone);
+    uint32_t max_steps = lim && lim->max_steps ? lim->max_steps : (1u << 24);
+    uint64_t time_limit = lim ? lim->time_limit_ns : 0;
+
+    /* GlobalRng::new_with_seed (rand.rs:42-61) */
+    oracle_seed_from_u64(seed, S.rng.s);
+    /* TimeRuntime::new (time/mod.rs:26-38): base_time draw.  Logging is enabled only after
+     * construction (runtime/mod.rs:185-186), so this draw is not in the determinism log. */
+    {
+        uint64_t h = S.trace_hash, n = S.log_len;
+        (void)gen_range_u64(&S, 0, 60ull * 60 * 24 * 365);
+        S.trace_hash = h; S.log_len = n;
+    }
+    /* Tasks spawned BEFORE block_on (the `runtime.create_node()..build(); node.spawn(..);
+     * runtime.block_on(..)` shape of task/mod.rs:859-897): they enter the ready Vec ahead of main. */
+    for (uint32_t p = 1; p < w->n_progs; p++)
+        if (w->progs[p].flags & MADSIM_PROG_PRE) spawn_task(&S, p, !(w->progs[p].flags & MADSIM_PROG_INIT));
+
+    /* Executor::block_on (task/mod.rs:220-260) */
+    S.main_slot = spawn_task(&S, 0, 1);
+    int verdict = MADSIM_PASS;
+    for (;;) {
+        run_all_ready(&S, max_steps);
+        if (S.panic) { verdict = MADSIM_PANIC; break; }
+        if (S.steps >= max_steps) { verdict = MADSIM_STEP_LIMIT; break; }
+        if (S.handles[0].state != H_RUNNING) break;        /* task.is_finished() :241-243 */
+        /* TimeRuntime::advance_to_next_event (time/mod.rs:45-60) */
+        if (S.heap.n == 0) { verdict = MADSIM_DEADLOCK; break; }      /* :250 */
+        uint64_t t = S.heap.p[0].deadline + 50;
+        timer_expire(&S, t);                               /* callbacks run before the clock is set */
+        S.clock = t;
+        if (time_limit && !(S.clock < time_limit)) { verdict = MADSIM_TIME_LIMIT; break; }  /* :253-258 */
+    }
+    out->verdict = (uint32_t)verdict; out->steps = S.steps; out->clock_ns = S.clock;
+    out->msg_count = S.msg_count; out->rng_calls = S.rng_calls; out->trace_hash = S.trace_hash;
+    out->obs_hash = S.obs_hash;
+    if (log_len) *log_len = S.log_len;
+    if (stats) {
+        if (S.st.max_heap > stats->max_heap) stats->max_heap = S.st.max_heap;
+        if (S.st.max_ready > stats->max_ready) stats->max_ready = S.st.max_ready;
+        if (S.st.max_tasks > stats->max_tasks) stats->max_tasks = S.st.max_tasks;
+        if (S.st.max_msgs > stats->max_msgs) stats->max_msgs = S.st.max_msgs;
+        if (S.st.max_regs > stats->max_regs) stats->max_regs = S.st.max_regs;
+    }
+    for (uint32_t i = 0; i < w->n_socks; i++) { vec_free(S.socks[i].registered); vec_free(S.socks[i].msgs); }
+    for (uint32_t i = 0; i <= w->n_nodes; i++) vec_free(S.nodes[i].paused_list);
+    vec_free(S.heap); vec_free(S.ready); vec_free(S.tasks);
+    free(S.handles); free(S.nodes); free(S.socks); free(S.clog_link);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * public API (mirrors madsim_hip_run_batch)
+ * ---------------------------------------------------------------------------------------------- */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+
+int madsim_oracle_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0,
+                            uint64_t count, const madsim_limits_t* lim, madsim_result_t* out,
+                            madsim_summary_t* summary, madsim_oracle_stats_t* stats) {
+    if (!cfg || validate(w, cfg)) return MADSIM_E_ARG;
+    double t0 = now_s();
+    uint64_t first = UINT64_MAX, nfail = 0, tsteps = 0, tclock = 0;
+    for (uint64_t i = 0; i < count; i++) {
+        madsim_result_t r;
+        run_one(w, cfg, lim, seed0 + i, &r, NULL, 0, NULL, stats);
+        if (out) out[i] = r;
+        if (r.verdict != MADSIM_PASS) { nfail++; if (seed0 + i < first) first = seed0 + i; }
+        tsteps += r.steps; tclock += r.clock_ns;
+    }
+    if (summary) {
+        summary->first_failing_seed = first; summary->n_failed = nfail; summary->total_steps = tsteps;
+        summary->total_clock_ns = tclock; summary->kernel_ms = 0.0; summary->wall_s = now_s() - t0;
+    }
+    return 0;
+}
+
+int64_t madsim_oracle_trace_seed(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
+                                 const madsim_limits_t* lim, uint8_t* log, uint64_t cap,
+                                 madsim_result_t* out) {
+    if (!cfg || validate(w, cfg)) return MADSIM_E_ARG;
+    madsim_result_t r; uint64_t n = 0;
+    run_one(w, cfg, lim, seed, &r, log, cap, &n, NULL);
+    if (out) *out = r;
+    return (int64_t)n;
+}
+
+/* [DEP rand 0.8 gen_range on u64] exposed for the known-answer tests. */
+uint64_t madsim_oracle_gen_range(uint64_t s[4], uint64_t lo, uint64_t hi, uint64_t* ncalls) {
+    uint64_t range = hi - lo, zone = (range << __builtin_clzll(range)) - 1, n = 0, res;
+    for (;;) {
+        uint64_t v = oracle_xoshiro_next(s); n++;
+        unsigned __int128 m = (unsigned __int128)v * range;
+        if ((uint64_t)m <= zone) { res = lo + (uint64_t)(m >> 64); break; }
+    }
+    if (ncalls) *ncalls = n;
+    return res;
+}
