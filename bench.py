@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric on BASELINE.json's config.
+
+One "step" = one pass of the hot path over one batch: 65 536 seeds of the 4-node ping-pong
+(R = 64 rounds per pair, Config::default()) per GPU, i.e. BASELINE.json configs[1].  With N GPUs each
+rank runs its own contiguous block of 65 536 seeds (weak scaling, no data-path collective) and the
+ranks exchange one first-failing-seed all-reduce per step (RCCL).
+
+Prints ONE JSON line (rank 0).  `value` = simulated seconds per wall second summed over every seed of
+every rank; seeds/s and executor-steps/s ride along in `extra`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEEDS_PER_GPU = 65536
+N_NODES, ROUNDS = 4, 64
+ALGO_BYTES_PER_STEP = 120      # pop 16 + push 16 + rng 32r+32w + clock 8r+8w + ready 4r+4w
+IO_BYTES_PER_SEED = 8 + 48     # seed in, madsim_result_t out
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seeds", type=int, default=SEEDS_PER_GPU, help="seeds per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from madsim_amd import _abi as A
+    from madsim_amd import dist as mdist
+    from madsim_amd import runtime, workload
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    runtime.init(local_rank)
+
+    w = workload.pingpong(N_NODES, ROUNDS)
+    lim = A.Limits()
+    lim.heap_lds_slots, lim.heap_spill_slots = 8, 8
+    lim.mbox_regs, lim.mbox_msgs = 1, 1
+    per_gpu = args.seeds
+    total = per_gpu * world
+    seed0, count = mdist.shard_range(0, total, rank, world)
+    d_out = torch.empty(count * 48, dtype=torch.uint8, device=dev)     # results stay resident in HBM
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k):
+        # a fresh block of seeds every step so nothing is cached between steps
+        s = runtime.run_batch_device(w, seed0 + k * total, count, d_out.data_ptr(), stream, None, lim)
+        ff, nf, st, ck = mdist.reduce_report(s.first_failing_seed, s.n_failed, s.total_steps, s.total_clock_ns, dev)
+        return s, (ff, nf, st, ck)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms, steps_total, clock_total, nfail = 0.0, 0, 0, 0
+    for k in range(args.steps):
+        s, (ff, nf, st, ck) = step(args.warmup + k)
+        kernel_ms += s.kernel_ms
+        steps_total += st
+        clock_total += ck
+        nfail += nf
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, kernel_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        seeds_total = total * args.steps
+        sim_s = clock_total / 1e9
+        # roofline of the dominant kernel (sim_kernel), per launch, from the library's HIP events
+        k_avg_ms = kernel_ms / args.steps
+        steps_per_launch = steps_total / args.steps / world
+        algo_bytes = steps_per_launch * ALGO_BYTES_PER_STEP + count * IO_BYTES_PER_SEED
+        achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
+        g = runtime.geometry(w, lim)
+        line = {
+            "metric": "sim_seconds_per_sec", "value": sim_s / dt, "unit": "sim-s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": f"{N_NODES}-node ping-pong, R={ROUNDS}, Config::default(), "
+                                   f"{per_gpu} seeds per GPU per step (BASELINE configs[1])",
+                       "seeds_per_step": total, "parallelism": f"seed-shard x{world}"},
+            "extra": {"seeds_per_sec": seeds_total / dt, "executor_steps_per_sec": steps_total / dt,
+                      "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms,
+                      "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "sim_kernel<false>", "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "LDS-resident path: algorithmic bytes (120 B/executor step) never touch HBM"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle
+            sample = 2 * SEEDS_PER_GPU // 1
+            t1 = time.perf_counter()
+            _, osum = oracle.run_batch(w, 0, sample)
+            cdt = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": osum.total_clock_ns / 1e9 / cdt, "unit": "sim-s/s", "cores": 1,
+                                    "kind": "port",
+                                    "sample": f"{sample} seeds of the same workload, single thread, "
+                                              f"{cdt:.1f} s ({sample / cdt:.0f} seeds/s, "
+                                              f"{osum.total_steps / cdt / 1e6:.1f} M steps/s)"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    runtime.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+// geometry.h — host-only (no HIP calls): workload validation and the LDS geometry the kernel runs with.
+// Shared by madsim_hip.cpp and by the device-code emulation harness under tests/emu (debug aid only).
+#ifndef MADSIM_GEOMETRY_H
+#define MADSIM_GEOMETRY_H
+
+#include <cstring>
+#include <string>
+
+#include "sim_kernel.h"
+
+namespace madsim_geo {
+
+using madsim_k::KParams;
+
+struct Device { int num_cus = 256; size_t lds_per_cu = 160 * 1024; };
+
+inline int fail(std::string* err, int code, const std::string& msg) { if (err) *err = msg; return code; }
+
+struct Geo {
+    KParams P;
+    uint32_t lds_bytes, lds_per_seed, blocks_per_cu, grid;
+};
+
+inline bool uses_op(const madsim_workload_t* w, int op) {
+    for (uint32_t i = 0; i < w->n_insns; i++) if (w->insns[i].op == op) return true;
+    return false;
+}
+
+// UniformDuration::new(lo, hi) [DEP rand 0.8]: see SURVEY.md Appendix A.3
+inline void uniform_duration_params(uint64_t lo, uint64_t hi, uint32_t* mode, uint64_t* low, uint64_t* range, uint64_t* zone) {
+    const uint64_t S = 1000000000ull;
+    uint64_t h = hi - 1;
+    uint64_t lo_s = lo / S, lo_n = lo % S, hi_s = h / S, hi_n = h % S;
+    if (hi_n < lo_n) { hi_s -= 1; hi_n += S; }
+    if (lo_s == hi_s) {
+        uint32_t r = (uint32_t)(hi_n - lo_n + 1);
+        uint32_t reject = r ? (uint32_t)((0xffffffffu - r + 1u) % r) : 0;
+        *mode = 0; *low = lo_s * S + lo_n; *range = r; *zone = 0xffffffffu - reject;
+    } else {
+        uint64_t r = h - lo + 1;
+        uint64_t reject = r ? (UINT64_MAX - r + 1) % r : 0;
+        *mode = 1; *low = lo; *range = r; *zone = UINT64_MAX - reject;
+    }
+}
+
+inline void bernoulli(double p, uint64_t* p_int, uint32_t* always) {   // [DEP rand 0.8 Bernoulli::new]
+    *always = p == 1.0;
+    *p_int = *always ? 0 : (uint64_t)(p * 18446744073709551616.0);
+}
+
+inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std::string* err) {
+    if (!w || !cfg) return fail(err, MADSIM_E_ARG, "null workload/config");
+    if (!w->insns || !w->progs || w->n_progs == 0 || w->n_progs > 255 || w->n_insns == 0 || w->n_insns > 0xffff)
+        return fail(err, MADSIM_E_WORKLOAD, "bad program table");
+    if (w->n_nodes > 31) return fail(err, MADSIM_E_WORKLOAD, "at most 31 nodes in this build");
+    if (w->n_socks > 63 || (w->n_socks && !w->socks)) return fail(err, MADSIM_E_WORKLOAD, "at most 63 socket addresses");
+    for (uint32_t i = 0; i < w->n_progs; i++)
+        if (w->progs[i].node > w->n_nodes || w->progs[i].entry >= w->n_insns) return fail(err, MADSIM_E_WORKLOAD, "bad prog entry");
+    for (uint32_t i = 0; i < w->n_socks; i++)
+        if (w->socks[i].node == 0 || w->socks[i].node > w->n_nodes) return fail(err, MADSIM_E_WORKLOAD, "bad socket node");
+    for (uint32_t i = 0; i < w->n_insns; i++) {
+        const madsim_insn_t& in = w->insns[i];
+        switch (in.op) {
+        case MS_OP_SPAWN: case MS_OP_JOIN: case MS_OP_ABORT:
+            if (in.a >= w->n_progs) return fail(err, MADSIM_E_WORKLOAD, "prog operand out of range"); break;
+        case MS_OP_DJNZ: case MS_OP_JMP:
+            if (in.b >= w->n_insns) return fail(err, MADSIM_E_WORKLOAD, "jump target out of range"); break;
+        case MS_OP_BIND: case MS_OP_REPLY: case MS_OP_RECV: case MS_OP_CLOSE: case MS_OP_RECV_TIMEOUT:
+            if (in.a >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range"); break;
+        case MS_OP_SEND:
+            if (in.a >= w->n_socks || (uint32_t)(in.b & 0xff) >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range"); break;
+        case MS_OP_BUILD: case MS_OP_KILL: case MS_OP_RESTART: case MS_OP_PAUSE: case MS_OP_RESUME:
+        case MS_OP_CLOG_NODE: case MS_OP_UNCLOG_NODE: case MS_OP_ASSERT_EXIT:
+            if (in.a > w->n_nodes) return fail(err, MADSIM_E_WORKLOAD, "node operand out of range"); break;
+        case MS_OP_CLOG_LINK: case MS_OP_UNCLOG_LINK:
+            if (in.a > w->n_nodes || in.b > w->n_nodes) return fail(err, MADSIM_E_WORKLOAD, "node operand out of range"); break;
+        default: break;
+        }
+    }
+    if (cfg->lat_lo_ns >= cfg->lat_hi_ns) return fail(err, MADSIM_E_ARG, "send_latency: cannot sample empty range");
+    if (!(cfg->packet_loss_rate >= 0.0 && cfg->packet_loss_rate <= 1.0)) return fail(err, MADSIM_E_ARG, "packet_loss_rate not in [0,1]");
+    return 0;
+}
+
+inline int make_geometry(const Device& g, const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim, uint64_t count, Geo* G, std::string* err) {
+    KParams& P = G->P;
+    memset(&P, 0, sizeof P);
+    madsim_limits_t L{};
+    if (lim) L = *lim;
+    P.n_insns = w->n_insns; P.n_progs = w->n_progs; P.n_socks = w->n_socks; P.n_nodes = w->n_nodes;
+    bernoulli(cfg->packet_loss_rate, &P.loss_pint, &P.loss_always);
+    P.buggify = cfg->buggify != 0;
+    uint32_t dummy; bernoulli(0.1, &P.bug_pint, &dummy);
+    uniform_duration_params(cfg->lat_lo_ns, cfg->lat_hi_ns, &P.lat_mode, &P.lat_low, &P.lat_range, &P.lat_zone);
+    for (int i = 0; i < 4; i++) bernoulli(i < (int)cfg->n_loss_table ? cfg->loss_table[i] : 0.0, &P.loss_table_pint[i], &P.loss_table_always[i]);
+    P.time_limit = L.time_limit_ns;
+    P.max_steps = L.max_steps ? L.max_steps : (1u << 24);
+    bool restarts = uses_op(w, MS_OP_RESTART);
+    for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) restarts |= (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) != 0;
+    P.max_tasks = L.max_tasks ? L.max_tasks : w->n_progs + (restarts ? w->n_progs : 0);
+    if (P.max_tasks > 254) return fail(err, MADSIM_E_LIMITS, "max_tasks must be <= 254");
+    P.mbox_regs = L.mbox_regs ? L.mbox_regs : 2;
+    P.mbox_msgs = L.mbox_msgs ? L.mbox_msgs : 2;
+    if (P.mbox_regs > 15 || P.mbox_msgs > 15) return fail(err, MADSIM_E_LIMITS, "mailbox capacities must be <= 15");
+    P.heap_lds = L.heap_lds_slots ? L.heap_lds_slots : 8;
+    P.heap_spill = (L.heap_lds_slots || L.heap_spill_slots) ? L.heap_spill_slots : 56;
+    bool t0 = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED);
+    P.task_words = t0 ? 9 : 7;
+    P.sock_words = 2 + P.mbox_regs + 2 * P.mbox_msgs;
+    P.has_clog_link = uses_op(w, MS_OP_CLOG_LINK);
+    P.off_tasks = 0;
+    P.off_ready = P.off_tasks + P.max_tasks * P.task_words;
+    P.off_socks = P.off_ready + P.max_tasks;
+    P.off_handles = P.off_socks + P.n_socks * P.sock_words;
+    P.off_nodes = P.off_handles + P.n_progs;
+    P.off_clog = P.off_nodes + 2;
+    P.lane_words = P.off_clog + 2 + (P.has_clog_link ? P.n_nodes + 1 : 0);
+    P.sh_insns = 0;
+    P.sh_progs = P.sh_insns + 2 * P.n_insns;
+    P.sh_socks = P.sh_progs + P.n_progs;
+    P.sh_heap = (P.sh_socks + P.n_socks + 3) & ~3u;
+    P.sh_planes = P.sh_heap + P.heap_lds * 64 * 4;
+    G->lds_per_seed = P.heap_lds * 16 + P.lane_words * 4;
+    G->lds_bytes = (P.sh_planes + P.lane_words * 64) * 4;
+    if (G->lds_bytes > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-workgroup LDS exceeds 160 KiB: lower heap_lds_slots / mailbox capacities");
+    uint32_t by_lds = (uint32_t)(g.lds_per_cu / G->lds_bytes);
+    uint32_t bpc = by_lds < 16 ? by_lds : 16;          // VGPR budget admits 4 waves/SIMD = 16 one-wave workgroups per CU
+    G->blocks_per_cu = bpc;
+    uint64_t want = (count + 63) / 64;
+    uint64_t resident = (uint64_t)bpc * (uint64_t)g.num_cus;
+    G->grid = (uint32_t)(want < resident ? want : resident);
+    if (G->grid == 0) G->grid = 1;
+    P.total_lanes = G->grid * 64;
+    return 0;
+}
+
+
+}  // namespace madsim_geo
+
+#endif

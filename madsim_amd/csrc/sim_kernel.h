@@ -1,0 +1,49 @@
+// sim_kernel.h — kernel parameter block shared by the host side (madsim_hip.cpp) and sim_kernel.hip.
+#ifndef MADSIM_SIM_KERNEL_H
+#define MADSIM_SIM_KERNEL_H
+
+#include <stdint.h>
+
+#include "../../include/madsim_hip.h"
+
+#define MADSIM_RUNNING 0xffu /* lane-internal: seed still executing */
+
+namespace madsim_k {
+
+struct KParams {
+    // workload tables in device memory (copied into LDS by every workgroup)
+    const uint2*    insns;     // madsim_insn_t as {op|a<<8|b<<16, imm}
+    const uint32_t* progs;     // node | flags<<8 | entry<<16
+    const uint32_t* socks;     // node | port<<16
+    uint32_t n_insns, n_progs, n_socks, n_nodes;
+    // net config (Bernoulli p_int, UniformDuration parameters precomputed on the host)
+    uint64_t loss_pint; uint32_t loss_always; uint32_t buggify; uint64_t bug_pint;
+    uint32_t lat_mode; uint32_t has_clog_link; uint64_t lat_low, lat_range, lat_zone;
+    uint64_t loss_table_pint[4]; uint32_t loss_table_always[4];
+    // limits
+    uint64_t time_limit; uint32_t max_steps;
+    // capacities
+    uint32_t heap_lds, heap_spill, max_tasks, mbox_regs, mbox_msgs;
+    uint32_t task_words, sock_words, lane_words;
+    // LDS layout, in 32-bit words: workgroup-shared tables, heap (16-byte aligned), then planes
+    uint32_t sh_insns, sh_progs, sh_socks, sh_heap, sh_planes;
+    // per-lane plane offsets (in words)
+    uint32_t off_tasks, off_ready, off_socks, off_handles, off_nodes, off_clog;
+    // batch
+    uint64_t seed0, count;
+    madsim_result_t* out;
+    uint4* spill;
+    uint32_t total_lanes;
+    // trace mode (single seed)
+    uint8_t* trace_log; uint64_t trace_cap; uint64_t* trace_len;
+};
+
+}  // namespace madsim_k
+
+extern "C" {
+void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace);
+void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream);
+int  madsim_k_set_max_lds(uint32_t lds_bytes);
+}
+
+#endif

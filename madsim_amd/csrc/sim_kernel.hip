@@ -1,0 +1,757 @@
+// sim_kernel.hip — the many-seed executor kernel for gfx950 (MI355X, CDNA4).
+//
+// One wavefront (64 lanes) per workgroup, ONE LANE = ONE SEED.  Each lane runs madsim's whole
+// per-seed executor loop:
+//     Executor::block_on / run_all_ready       madsim/src/sim/task/mod.rs:220-323
+//     mpsc::Receiver::try_recv_random          madsim/src/sim/utils/mpsc.rs:73-83
+//     TimeRuntime::advance_to_next_event       madsim/src/sim/time/mod.rs:45-60
+//     TimeHandle::advance / Sleep::poll        time/mod.rs:103-124, time/sleep.rs:47-54
+//     GlobalRng (xoshiro256++, gen_range ...)  madsim/src/sim/rand.rs:27-158
+//     NetSim::send / Network::try_send / Mailbox   net/mod.rs:287-333, net/network.rs:261-313,
+//                                                  net/endpoint.rs:331-362
+// on a workload given as an actor program (include/madsim_hip.h).
+//
+// Data placement (per seed):
+//   VGPRs : xoshiro256++ state (4 x u64), clock, counters, hashes, queue lengths.
+//   LDS   : timer heap (16-byte entries, [slot][lane] => ds_read/write_b128, conflict-free),
+//           task table, ready queue, mailboxes, handles, node/clog masks — all as 32-bit
+//           "word planes" [word][lane] so that any per-lane dynamic index hits bank = lane % 32.
+//           The workload tables (instructions, programs, socket addresses) sit once per
+//           workgroup in front of the planes.
+//   HBM   : heap entries beyond the LDS quota spill to a [slot][global lane] region
+//           (adjacent lanes -> adjacent 16-byte entries: coalesced), results 48 B/seed.
+//
+// Integer/indexing work only: no MFMA.  No inter-lane communication: lanes only share the
+// instruction stream, so there is no barrier anywhere in the kernel.
+#ifdef MADSIM_EMU
+#include "emu_shim.h"   // tests/emu: host emulation of this file, a debugging aid for GPU-less boxes
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+#include "sim_kernel.h"
+
+namespace madsim_k {
+
+#define FNV_OFFSET 14695981039346656037ull
+#define FNV_PRIME 1099511628211ull
+#define NS_PER_S 1000000000ull
+#define NS_PER_MS 1000000ull
+
+// task flag bits (TW_FLAGS low byte)
+enum : uint32_t { TF_ALIVE = 1, TF_SCHED = 2, TF_RUN = 4, TF_KILLED = 8, TF_CANCEL = 16, TF_INBOX = 32 };
+enum : uint32_t { TW_FLAGS = 0, TW_PC = 1, TW_CNT = 2, TW_VAL = 3, TW_LINK = 4, TW_DL_LO = 5, TW_DL_HI = 6, TW_T0_LO = 7, TW_T0_HI = 8 };
+enum : uint32_t { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3 };
+enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
+
+struct Lane {
+    // GlobalRng
+    uint64_t s0, s1, s2, s3;
+    uint64_t rng_calls;
+    uint64_t trace_hash;
+    uint64_t log_len;
+    // Clock
+    uint64_t clock;
+    // accounting
+    uint64_t obs_hash;
+    uint32_t msg_count;
+    uint32_t steps;
+    uint32_t ready_len;
+    uint32_t heap_len;
+    uint32_t verdict;
+    // runtime-mutable net config (MS_OP_SET_LOSS)
+    uint64_t loss_pint;
+    uint32_t loss_always;
+};
+
+struct Ctx {
+    const KParams& P;
+    uint32_t* lds;       // per-lane plane base: word w of this lane = lds[w * 64]
+    uint4* heap;         // heap[i * 64]
+    const uint2* insn;   // workgroup-shared tables in LDS
+    const uint32_t* prog;
+    const uint32_t* sock;
+    uint4* spill;        // this lane's column of the HBM spill region, stride P.total_lanes
+    uint8_t* tlog;       // trace mode only
+    __device__ Ctx(const KParams& p) : P(p) {}
+};
+
+__device__ __forceinline__ uint32_t& W(const Ctx& c, uint32_t w) { return c.lds[w * 64]; }
+__device__ __forceinline__ uint32_t& TW(const Ctx& c, uint32_t slot, uint32_t f) { return c.lds[(c.P.off_tasks + slot * c.P.task_words + f) * 64]; }
+__device__ __forceinline__ uint32_t& SW(const Ctx& c, uint32_t s, uint32_t f) { return c.lds[(c.P.off_socks + s * c.P.sock_words + f) * 64]; }
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+// ---- GlobalRng ---------------------------------------------------------------------------------
+// Xoshiro256PlusPlus::next_u64 [DEP rand_xoshiro 0.6]
+__device__ __forceinline__ uint64_t rng_next(Lane& L) {
+    uint64_t r = rotl64(L.s0 + L.s3, 23) + L.s0;
+    uint64_t t = L.s1 << 17;
+    L.s2 ^= L.s0; L.s3 ^= L.s1; L.s1 ^= L.s2; L.s0 ^= L.s3;
+    L.s2 ^= t;
+    L.s3 = rotl64(L.s3, 45);
+    L.rng_calls++;
+    return r;
+}
+
+// One determinism-log byte per GlobalRng::with (rand.rs:64-88): clone.gen::<u8>() ^ xor-fold(elapsed).
+template <bool TRACE>
+__device__ __forceinline__ void rng_log(const Ctx& c, Lane& L) {
+    uint64_t r = rotl64(L.s0 + L.s3, 23) + L.s0;   // what the clone's next_u64 would return
+    uint32_t v = (uint32_t)(r >> 32);
+    uint32_t f = (uint32_t)L.clock ^ (uint32_t)(L.clock >> 32);
+    f ^= f >> 16; f ^= f >> 8;
+    v = (v ^ f) & 0xff;
+    L.trace_hash = (L.trace_hash ^ v) * FNV_PRIME;
+    if (TRACE) { if (L.log_len < c.P.trace_cap) c.tlog[L.log_len] = (uint8_t)v; }
+    L.log_len++;
+}
+
+// gen_range(lo..hi) on u64 [DEP rand 0.8 UniformInt::sample_single_inclusive]; one with() per call.
+template <bool TRACE>
+__device__ __forceinline__ uint64_t gen_range_u64(const Ctx& c, Lane& L, uint64_t lo, uint64_t range) {
+    uint64_t zone = (range << __builtin_clzll(range)) - 1;
+    uint64_t res;
+    for (;;) {
+        uint64_t v = rng_next(L);
+        uint64_t mlo = v * range;
+        if (mlo <= zone) { res = lo + __umul64hi(v, range); break; }
+    }
+    rng_log<TRACE>(c, L);
+    return res;
+}
+
+// Same with range and zone known at compile time (idx over small queues uses the generic form).
+template <bool TRACE, uint64_t RANGE>
+__device__ __forceinline__ uint64_t gen_range_const(const Ctx& c, Lane& L, uint64_t lo) {
+    constexpr uint64_t zone = (RANGE << __builtin_clzll(RANGE)) - 1;
+    uint64_t res;
+    for (;;) {
+        uint64_t v = rng_next(L);
+        uint64_t mlo = v * RANGE;
+        if (mlo <= zone) { res = lo + __umul64hi(v, RANGE); break; }
+    }
+    rng_log<TRACE>(c, L);
+    return res;
+}
+
+// gen_bool through GlobalRng's RngCore impl (rand.rs:142-158): one with() per draw [DEP Bernoulli].
+template <bool TRACE>
+__device__ __forceinline__ bool gen_bool_pint(const Ctx& c, Lane& L, uint64_t p_int, uint32_t always) {
+    if (always) return true;
+    uint64_t v = rng_next(L);
+    rng_log<TRACE>(c, L);
+    return v < p_int;
+}
+
+// UniformDuration sample on the GlobalRng itself (network.rs:267): one with() per attempt [DEP A.3].
+template <bool TRACE>
+__device__ __forceinline__ uint64_t sample_latency(const Ctx& c, Lane& L) {
+    const KParams& P = c.P;
+    uint64_t res;
+    for (;;) {
+        uint64_t v = rng_next(L);
+        rng_log<TRACE>(c, L);
+        if (P.lat_mode == 0) {
+            uint64_t m = (uint64_t)(uint32_t)(v >> 32) * (uint64_t)(uint32_t)P.lat_range;
+            if ((uint32_t)m <= (uint32_t)P.lat_zone) { res = P.lat_low + (m >> 32); break; }
+        } else {
+            uint64_t mlo = v * P.lat_range;
+            if (mlo <= P.lat_zone) { res = P.lat_low + __umul64hi(v, P.lat_range); break; }
+        }
+    }
+    return res;
+}
+
+// ---- Timer = BinaryHeap<Event>, reversed Ord on deadline [DEP naive-timer 0.2 + alloc BinaryHeap] --
+// entry: x = deadline lo, y = deadline hi, z = meta, w = payload value
+__device__ __forceinline__ uint64_t ev_deadline(const uint4& e) { return ((uint64_t)e.y << 32) | e.x; }
+
+__device__ __forceinline__ uint4 heap_get(const Ctx& c, uint32_t i) {
+    if (i < c.P.heap_lds) return c.heap[i * 64];
+    return c.spill[(size_t)(i - c.P.heap_lds) * c.P.total_lanes];
+}
+__device__ __forceinline__ void heap_set(const Ctx& c, uint32_t i, const uint4& e) {
+    if (i < c.P.heap_lds) c.heap[i * 64] = e;
+    else c.spill[(size_t)(i - c.P.heap_lds) * c.P.total_lanes] = e;
+}
+
+__device__ __forceinline__ void heap_sift_up(const Ctx& c, uint32_t pos, const uint4& hole) {
+    uint64_t hd = ev_deadline(hole);
+    while (pos > 0) {
+        uint32_t parent = (pos - 1) >> 1;
+        uint4 p = heap_get(c, parent);
+        if (hd >= ev_deadline(p)) break;     // hole <= parent in heap order: stop
+        heap_set(c, pos, p);
+        pos = parent;
+    }
+    heap_set(c, pos, hole);
+}
+
+// returns false on capacity overflow
+__device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val) {
+    if (L.heap_len >= c.P.heap_lds + c.P.heap_spill) return false;
+    uint4 e = make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, val);
+    heap_sift_up(c, L.heap_len, e);
+    L.heap_len++;
+    return true;
+}
+
+__device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
+    uint32_t end = --L.heap_len;
+    uint4 item = heap_get(c, end);
+    if (end > 0) {
+        uint4 top = heap_get(c, 0);
+        // sift_down_to_bottom(0) with `item` as the hole element
+        uint32_t pos = 0, child = 1;
+        while (child + 1 < end) {
+            uint4 l = heap_get(c, child), r = heap_get(c, child + 1);
+            bool right = ev_deadline(l) >= ev_deadline(r);   // left <= right: take right
+            heap_set(c, pos, right ? r : l);
+            pos = child + (right ? 1u : 0u);
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1) { heap_set(c, pos, heap_get(c, child)); pos = child; }
+        heap_sift_up(c, pos, item);
+        item = top;
+    }
+    return item;
+}
+
+// ---- async-task wake / schedule [DEP A.7] -------------------------------------------------------
+__device__ __forceinline__ bool ready_push(const Ctx& c, Lane& L, uint32_t slot) {
+    if (L.ready_len >= c.P.max_tasks) return false;
+    W(c, c.P.off_ready + L.ready_len) = slot;
+    L.ready_len++;
+    return true;
+}
+
+__device__ __forceinline__ void wake(const Ctx& c, Lane& L, uint32_t slot, uint32_t gen) {
+    if (slot >= c.P.max_tasks) return;
+    uint32_t f = TW(c, slot, TW_FLAGS);
+    if (!(f & TF_ALIVE) || ((f >> 8) & 0xffff) != gen) return;
+    if (f & TF_SCHED) return;
+    TW(c, slot, TW_FLAGS) = f | TF_SCHED;
+    if (!(f & TF_RUN)) { if (!ready_push(c, L, slot)) L.verdict = MADSIM_OVERFLOW; }
+}
+
+// ---- Network -----------------------------------------------------------------------------------
+__device__ __forceinline__ int find_bound(const Ctx& c, uint32_t node, uint32_t port) {
+    uint32_t key = node | (port << 16);
+    for (uint32_t i = 0; i < c.P.n_socks; i++)
+        if ((c.sock[i] & 0xffff00ffu) == key && (SW(c, i, 0) & 1)) return (int)i;
+    return -1;
+}
+
+// Mailbox::deliver (endpoint.rs:331-351)
+__device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t meta, uint32_t val) {
+    uint32_t s = meta & 0x3f, from = (meta >> 6) & 0x3f, tag = (meta >> 12) & 0xff, sgen = (meta >> 20) & 0xff;
+    uint32_t h = SW(c, s, 0);
+    if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;
+    uint32_t nreg = (h >> 9) & 0xf, nmsg = (h >> 13) & 0xf;
+    uint32_t i = 0;
+    while (i < nreg) {
+        uint32_t r = SW(c, s, 2 + i);
+        if ((r & 0xff) == tag) {
+            nreg--;
+            SW(c, s, 2 + i) = SW(c, s, 2 + nreg);          // swap_remove
+            uint32_t slot = (r >> 8) & 0xff, rxseq = (r >> 16) & 0xff, g8 = r >> 24;
+            uint32_t f = TW(c, slot, TW_FLAGS);
+            uint32_t link = TW(c, slot, TW_LINK);
+            if ((f & TF_ALIVE) && ((f >> 8) & 0xff) == g8 && (link & 0xff) == rxseq && !(f & TF_INBOX)) {
+                TW(c, slot, TW_FLAGS) = f | TF_INBOX;      // oneshot::Sender::send Ok
+                TW(c, slot, TW_VAL) = val;
+                uint32_t pcw = TW(c, slot, TW_PC);
+                TW(c, slot, TW_PC) = (pcw & 0x00ffffffu) | (from << 24);
+                SW(c, s, 0) = (h & ~(0xfu << 9)) | (nreg << 9);
+                wake(c, L, slot, (f >> 8) & 0xffff);
+                return;
+            }
+        } else {
+            i++;
+        }
+    }
+    if (nmsg >= c.P.mbox_msgs) { L.verdict = MADSIM_OVERFLOW; return; }
+    SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);
+    SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg + 1) = val;
+    nmsg++;
+    SW(c, s, 0) = (h & ~((0xfu << 9) | (0xfu << 13))) | (nreg << 9) | (nmsg << 13);
+}
+
+// Timer::expire [DEP A.5]: fire every entry with deadline <= now
+__device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now) {
+    while (L.heap_len > 0 && L.verdict == MADSIM_RUNNING) {
+        uint4 top = heap_get(c, 0);
+        if (ev_deadline(top) > now) break;
+        uint4 e = timer_pop(c, L);
+        L.steps++;
+        uint32_t kind = e.z >> 28;
+        if (kind == EV_WAKE) wake(c, L, e.z & 0xff, (e.z >> 8) & 0xffff);   // time/sleep.rs:52
+        else if (kind == EV_DELIVER) mailbox_deliver(c, L, e.z, e.w);      // net/mod.rs:323-330
+    }
+}
+
+// ---- task lifecycle ----------------------------------------------------------------------------
+__device__ __forceinline__ void spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record) {
+    uint32_t slot = 0;
+    while (slot < c.P.max_tasks && (TW(c, slot, TW_FLAGS) & TF_ALIVE)) slot++;
+    if (slot >= c.P.max_tasks) { L.verdict = MADSIM_OVERFLOW; return; }
+    uint32_t gen = (((TW(c, slot, TW_FLAGS) >> 8) & 0xffff) + 1) & 0xffff;
+    uint32_t pw = c.prog[prog];
+    uint32_t node = pw & 0xff;
+    uint32_t killed = (W(c, c.P.off_nodes) >> node) & 1;
+    TW(c, slot, TW_FLAGS) = TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24);
+    TW(c, slot, TW_PC) = pw >> 16;                         // pc = entry, sub = 0, from = 0
+    TW(c, slot, TW_CNT) = 0;
+    TW(c, slot, TW_VAL) = 0;
+    TW(c, slot, TW_LINK) = 0xff << 8;                      // rxseq 0, joiner none (0xff)
+    if (!ready_push(c, L, slot)) L.verdict = MADSIM_OVERFLOW;
+    if (record) W(c, c.P.off_handles + prog) = H_RUNNING | (slot << 8) | (gen << 16);
+}
+
+__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome) {
+    uint32_t f = TW(c, slot, TW_FLAGS);
+    uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
+    // BindGuard::drop (net/mod.rs:483-493), skipped when the binder's NodeInfo is killed
+    if (!(f & TF_KILLED)) {
+        uint32_t own = slot | (gen << 16);
+        for (uint32_t i = 0; i < c.P.n_socks; i++)
+            if ((SW(c, i, 0) & 1) && SW(c, i, 1) == own) SW(c, i, 0) &= ~1u;
+    }
+    uint32_t h = W(c, c.P.off_handles + prog);
+    if (h == (H_RUNNING | (slot << 8) | (gen << 16))) W(c, c.P.off_handles + prog) = (h & ~3u) | outcome;
+    uint32_t link = TW(c, slot, TW_LINK);
+    TW(c, slot, TW_FLAGS) = f & ~(TF_ALIVE | TF_SCHED | TF_RUN | TF_INBOX);
+    uint32_t j = (link >> 8) & 0xff;
+    if (j != 0xff) wake(c, L, j, link >> 16);
+}
+
+// TimeHandle::sleep_until (time/mod.rs:118-124): 1 ms floor
+__device__ __forceinline__ uint64_t sleep_deadline(const Lane& L, uint64_t deadline) {
+    uint64_t m = L.clock + NS_PER_MS;
+    return deadline > m ? deadline : m;
+}
+
+// NetSim::rand_delay up to the creation of its Sleep (net/mod.rs:287-292)
+template <bool TRACE>
+__device__ __forceinline__ uint64_t rand_delay_start(const Ctx& c, Lane& L) {
+    uint64_t delay = gen_range_const<TRACE, 5>(c, L, 0) * 1000ull;
+    if (c.P.buggify) {
+        if (gen_bool_pint<TRACE>(c, L, c.P.bug_pint, 0)) delay = gen_range_const<TRACE, 4>(c, L, 1) * NS_PER_S;
+    }
+    return sleep_deadline(L, L.clock + delay);
+}
+
+// One poll of a task's future (Runnable::run).  Returns true if the task panicked.
+template <bool TRACE>
+__device__ bool poll_task(const Ctx& c, Lane& L, uint32_t slot) {
+    const KParams& P = c.P;
+    uint32_t pcw = TW(c, slot, TW_PC);
+    uint32_t pc = pcw & 0xffff, sub = (pcw >> 16) & 0xff, from = pcw >> 24;
+    const uint32_t flags0 = TW(c, slot, TW_FLAGS);
+    const uint32_t gen = (flags0 >> 8) & 0xffff;
+    const uint32_t node = c.prog[flags0 >> 24] & 0xff;
+    bool panicked = false, pending = false, finished = false;
+
+#define SAVE_PC() (TW(c, slot, TW_PC) = pc | (sub << 16) | (from << 24))
+
+    while (!pending && !finished && !panicked && L.verdict == MADSIM_RUNNING) {
+        if (pc >= P.n_insns) { panicked = true; break; }
+        uint2 in = c.insn[pc];
+        uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
+        uint64_t dur = (uint64_t)b * NS_PER_S + imm;
+        // ops that start with NetSim::rand_delay, then wait on its Sleep
+        bool delayed = (op == MS_OP_BIND) | (op == MS_OP_SEND) | (op == MS_OP_REPLY) | (op == MS_OP_RECV);
+        bool sleeping = false;          // this op (in its current sub-state) awaits the Sleep in TW_DL
+        switch (op) {
+        case MS_OP_DONE:
+            SAVE_PC();
+            task_finish(c, L, slot, H_COMPLETED);
+            finished = true;
+            break;
+        case MS_OP_SPAWN:
+            spawn_task(c, L, a, true);
+            pc++;
+            break;
+        case MS_OP_BUILD:
+            for (uint32_t p = 1; p < P.n_progs; p++) {
+                uint32_t pw = c.prog[p];
+                if ((pw & 0xff) == a && ((pw >> 8) & MADSIM_PROG_INIT) && !((pw >> 8) & MADSIM_PROG_PRE)) spawn_task(c, L, p, false);
+            }
+            pc++;
+            break;
+        case MS_OP_JOIN: {
+            uint32_t h = W(c, P.off_handles + a);
+            uint32_t st = h & 3;
+            if (st == H_RUNNING) {
+                uint32_t cs = (h >> 8) & 0xff;
+                uint32_t link = TW(c, cs, TW_LINK);
+                TW(c, cs, TW_LINK) = (link & 0xff) | (slot << 8) | (gen << 16);   // register awaiter
+                pending = true;
+            } else if (st == H_NONE || ((st == H_CANCELLED) != ((b & 1) != 0))) {
+                panicked = true;
+            } else {
+                pc++;
+            }
+            break;
+        }
+        case MS_OP_YIELD:
+            if (sub == 0) {
+                sub = 1;
+                TW(c, slot, TW_FLAGS) |= TF_SCHED;          // wake_by_ref while RUNNING
+                pending = true;
+            } else { sub = 0; pc++; }
+            break;
+        case MS_OP_PANIC:
+            panicked = true;
+            break;
+        case MS_OP_SET: {
+            uint32_t cw = TW(c, slot, TW_CNT);
+            TW(c, slot, TW_CNT) = (a & 1) ? ((cw & 0xffffu) | (imm << 16)) : ((cw & 0xffff0000u) | (imm & 0xffffu));
+            pc++;
+            break;
+        }
+        case MS_OP_DJNZ: {
+            uint32_t cw = TW(c, slot, TW_CNT);
+            uint32_t sh = (a & 1) * 16;
+            uint32_t v = (((cw >> sh) & 0xffff) - 1) & 0xffff;
+            TW(c, slot, TW_CNT) = (cw & ~(0xffffu << sh)) | (v << sh);
+            pc = v ? b : pc + 1;
+            break;
+        }
+        case MS_OP_JMP:
+            pc = b;
+            break;
+        case MS_OP_TRACE: {
+            uint64_t v = imm;
+            if (b & 1) v += (TW(c, slot, TW_CNT) >> ((a & 1) * 16)) & 0xffff;
+            L.obs_hash = (L.obs_hash ^ v) * FNV_PRIME;
+            pc++;
+            break;
+        }
+        case MS_OP_SLEEP:
+        case MS_OP_SLEEP_UNTIL:
+            if (sub == 0) {
+                uint64_t base = L.clock;
+                if (op == MS_OP_SLEEP_UNTIL) base = ((uint64_t)TW(c, slot, TW_T0_HI) << 32) | TW(c, slot, TW_T0_LO);
+                uint64_t d = sleep_deadline(L, base + dur);
+                TW(c, slot, TW_DL_LO) = (uint32_t)d; TW(c, slot, TW_DL_HI) = (uint32_t)(d >> 32);
+                sub = 1;
+            }
+            sleeping = true;
+            break;
+        case MS_OP_MARK:
+            TW(c, slot, TW_T0_LO) = (uint32_t)L.clock; TW(c, slot, TW_T0_HI) = (uint32_t)(L.clock >> 32);
+            pc++;
+            break;
+        case MS_OP_ASSERT_ELAPSED: {
+            uint64_t t0 = ((uint64_t)TW(c, slot, TW_T0_HI) << 32) | TW(c, slot, TW_T0_LO);
+            uint64_t el = L.clock - t0;
+            bool ok = a == 0 ? el == dur : a == 1 ? el >= dur : el < dur;
+            if (!ok) panicked = true; else pc++;
+            break;
+        }
+        case MS_OP_ADVANCE:                                 // time/mod.rs:103-106
+            L.clock += dur;
+            pc++;
+            SAVE_PC();
+            timer_expire(c, L, L.clock);
+            from = TW(c, slot, TW_PC) >> 24;
+            break;
+        case MS_OP_RECV:
+            if (sub == 0) {                                 // Mailbox::recv (endpoint.rs:353-362)
+                uint32_t tag = b >> 8;
+                uint32_t link = TW(c, slot, TW_LINK);
+                uint32_t rxseq = ((link & 0xff) + 1) & 0xff;
+                TW(c, slot, TW_LINK) = (link & ~0xffu) | rxseq;
+                uint32_t f = TW(c, slot, TW_FLAGS) & ~TF_INBOX;
+                uint32_t h = SW(c, a, 0);
+                uint32_t nreg = (h >> 9) & 0xf, nmsg = (h >> 13) & 0xf;
+                uint32_t idx = 0, mbase = 2 + P.mbox_regs;
+                while (idx < nmsg && (SW(c, a, mbase + 2 * idx) & 0xff) != tag) idx++;
+                if (idx < nmsg) {
+                    uint32_t m0 = SW(c, a, mbase + 2 * idx), m1 = SW(c, a, mbase + 2 * idx + 1);
+                    nmsg--;
+                    SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);        // swap_remove
+                    SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
+                    f |= TF_INBOX;
+                    TW(c, slot, TW_VAL) = m1;
+                    from = (m0 >> 8) & 0xff;
+                } else {
+                    if (nreg >= P.mbox_regs) { L.verdict = MADSIM_OVERFLOW; break; }
+                    SW(c, a, 2 + nreg) = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                    nreg++;
+                }
+                SW(c, a, 0) = (h & ~((0xfu << 9) | (0xfu << 13))) | (nreg << 9) | (nmsg << 13);
+                TW(c, slot, TW_FLAGS) = f;
+                sub = 1;
+            }
+            if (sub == 1) {
+                uint32_t f = TW(c, slot, TW_FLAGS);
+                if (!(f & TF_INBOX)) { pending = true; break; }     // oneshot::Receiver Pending
+                TW(c, slot, TW_FLAGS) = f & ~TF_INBOX;
+                from = TW(c, slot, TW_PC) >> 24;
+                sub = 2;                                            // -> rand_delay (endpoint.rs:145)
+            }
+            sleeping = true;
+            break;
+        case MS_OP_BIND:
+        case MS_OP_SEND:
+        case MS_OP_REPLY:
+            sleeping = true;
+            break;
+        case MS_OP_ASSERT_VAL:
+            if (TW(c, slot, TW_VAL) != imm) panicked = true; else pc++;
+            break;
+        case MS_OP_CLOSE: {
+            uint32_t h = SW(c, a, 0);
+            if ((h & 1) && SW(c, a, 1) == (slot | (gen << 16)) && !(flags0 & TF_KILLED)) SW(c, a, 0) = h & ~1u;
+            pc++;
+            break;
+        }
+        case MS_OP_CLOG_NODE:
+            if (b & 1) W(c, P.off_clog + 0) |= 1u << a;
+            if (b & 2) W(c, P.off_clog + 1) |= 1u << a;
+            pc++;
+            break;
+        case MS_OP_UNCLOG_NODE:
+            if (b & 1) W(c, P.off_clog + 0) &= ~(1u << a);
+            if (b & 2) W(c, P.off_clog + 1) &= ~(1u << a);
+            pc++;
+            break;
+        case MS_OP_CLOG_LINK:
+            W(c, P.off_clog + 2 + a) |= 1u << b;
+            pc++;
+            break;
+        case MS_OP_UNCLOG_LINK:
+            W(c, P.off_clog + 2 + a) &= ~(1u << b);
+            pc++;
+            break;
+        case MS_OP_SET_LOSS:
+            L.loss_pint = P.loss_table_pint[a & 3];
+            L.loss_always = P.loss_table_always[a & 3];
+            pc++;
+            break;
+        default:
+            panicked = true;
+            break;
+        }
+        if (!sleeping || pending || panicked || L.verdict != MADSIM_RUNNING) continue;
+
+        // ---- shared tail for every op that awaits a Sleep (time/sleep.rs:47-54) ------------------
+        uint32_t wait_sub = (op == MS_OP_RECV) ? 3 : 1;      // sub value meaning "Sleep registered"
+        uint64_t deadline;
+        if (delayed && sub != wait_sub) {                    // first half of NetSim::rand_delay
+            deadline = rand_delay_start<TRACE>(c, L);
+            TW(c, slot, TW_DL_LO) = (uint32_t)deadline; TW(c, slot, TW_DL_HI) = (uint32_t)(deadline >> 32);
+            sub = wait_sub;
+        } else {
+            deadline = ((uint64_t)TW(c, slot, TW_DL_HI) << 32) | TW(c, slot, TW_DL_LO);
+        }
+        if (L.clock < deadline) {                            // Sleep::poll: register ANOTHER timer
+            if (!timer_add(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.verdict = MADSIM_OVERFLOW;
+            pending = true;
+            continue;
+        }
+        // the Sleep is Ready: finish the op
+        sub = 0;
+        if (op == MS_OP_BIND) {                              // Network::bind (network.rs:206-251)
+            uint32_t sw = c.sock[a];
+            if ((sw & 0xff) != node || find_bound(c, sw & 0xff, sw >> 16) >= 0) { panicked = true; continue; }
+            uint32_t h = SW(c, a, 0);
+            SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);   // bound, gen+1, empty mailbox
+            SW(c, a, 1) = slot | (gen << 16);
+        } else if (op == MS_OP_SEND || op == MS_OP_REPLY) {  // net/mod.rs:307-331, network.rs:296-313
+            uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : from;
+            uint32_t src_node = c.sock[a] & 0xff;
+            uint32_t dw = c.sock[dst];
+            uint32_t dst_node = dw & 0xff;
+            bool clogged = ((W(c, P.off_clog + 1) >> src_node) & 1) | ((W(c, P.off_clog + 0) >> dst_node) & 1);
+            if (P.has_clog_link) clogged |= (W(c, P.off_clog + 2 + src_node) >> dst_node) & 1;
+            if (!clogged && !gen_bool_pint<TRACE>(c, L, L.loss_pint, L.loss_always)) {   // test_link :261-269
+                L.msg_count++;
+                uint64_t lat = sample_latency<TRACE>(c, L);
+                int ds = find_bound(c, dst_node, dw >> 16);
+                if (ds >= 0) {
+                    uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
+                    uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((b >> 8) << 12) | (a << 6) | (uint32_t)ds;
+                    if (!timer_add(c, L, L.clock + lat, meta, imm)) L.verdict = MADSIM_OVERFLOW;
+                }
+            }
+        }
+        pc++;
+    }
+    if (!finished) SAVE_PC();
+#undef SAVE_PC
+    return panicked;
+}
+
+// ---- per-seed init: Runtime::with_seed_and_config (runtime/mod.rs:53-69) ------------------------
+template <bool TRACE>
+__device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
+    const KParams& P = c.P;
+    for (uint32_t w = 0; w < P.lane_words; w++) W(c, w) = 0;
+    // GlobalRng::new_with_seed -> Xoshiro256PlusPlus::seed_from_u64: SplitMix64 [DEP A.1]
+    uint64_t x = seed, s[4];
+    for (int i = 0; i < 4; i++) {
+        x += 0x9e3779b97f4a7c15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        s[i] = z ^ (z >> 31);
+    }
+    L.s0 = s[0]; L.s1 = s[1]; L.s2 = s[2]; L.s3 = s[3];
+    L.rng_calls = 0; L.clock = 0; L.msg_count = 0; L.steps = 0;
+    L.ready_len = 0; L.heap_len = 0; L.verdict = MADSIM_RUNNING;
+    L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
+    // TimeRuntime::new (time/mod.rs:26-38): base_time draw, before logging is enabled
+    (void)gen_range_const<false, 31536000ull>(c, L, 0);
+    L.trace_hash = FNV_OFFSET; L.obs_hash = FNV_OFFSET; L.log_len = 0;
+    // tasks spawned before block_on, then the main task (task/mod.rs:222-235)
+    for (uint32_t p = 1; p < P.n_progs; p++) {
+        uint32_t fl = (c.prog[p] >> 8) & 0xff;
+        if (fl & MADSIM_PROG_PRE) spawn_task(c, L, p, !(fl & MADSIM_PROG_INIT));
+    }
+    spawn_task(c, L, 0, true);
+}
+
+template <bool TRACE>
+__global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
+#ifdef MADSIM_EMU
+    uint32_t* smem = emu_smem;
+#else
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+#endif
+    const uint32_t lane = threadIdx.x;
+    // workgroup-shared tables
+    uint32_t* sh = smem;
+#ifdef MADSIM_EMU
+    const uint32_t cp0 = 0, cps = 1;      // emulated threads run one after another: each copies everything
+#else
+    const uint32_t cp0 = lane, cps = 64;
+#endif
+    for (uint32_t i = cp0; i < P.n_insns * 2; i += cps) sh[P.sh_insns + i] = ((const uint32_t*)P.insns)[i];
+    for (uint32_t i = cp0; i < P.n_progs; i += cps) sh[P.sh_progs + i] = P.progs[i];
+    for (uint32_t i = cp0; i < P.n_socks; i += cps) sh[P.sh_socks + i] = P.socks[i];
+    __syncthreads();
+
+    Ctx c(P);
+    c.insn = (const uint2*)(sh + P.sh_insns);
+    c.prog = sh + P.sh_progs;
+    c.sock = sh + P.sh_socks;
+    c.heap = (uint4*)(sh + P.sh_heap) + lane;
+    c.lds = sh + P.sh_planes + lane;
+    const uint32_t glane = blockIdx.x * 64 + lane;
+    c.spill = P.spill ? P.spill + glane : nullptr;
+    c.tlog = P.trace_log;
+
+    Lane L;
+    uint64_t next = glane;          // static striding: lane g runs seeds g, g+G, g+2G, ...
+    bool have = false;
+    for (;;) {
+        if (!have) {
+            if (next >= P.count) break;
+            seed_init<TRACE>(c, L, P.seed0 + next);
+            have = true;
+        }
+        // ---- Executor::block_on loop body (task/mod.rs:239-259), one executor step per iteration
+        uint64_t expire_to;
+        bool idle = false;
+        if (L.ready_len > 0) {
+            // try_recv_random (utils/mpsc.rs:73-83)
+            uint32_t idx = (uint32_t)gen_range_u64<TRACE>(c, L, 0, L.ready_len);
+            uint32_t slot = W(c, P.off_ready + idx);
+            L.ready_len--;
+            W(c, P.off_ready + idx) = W(c, P.off_ready + L.ready_len);   // swap_remove
+            uint32_t f = TW(c, slot, TW_FLAGS);
+            L.steps++;
+            bool panicked = false;
+            if (f & (TF_CANCEL | TF_KILLED)) {               // task/mod.rs:269-273
+                task_finish(c, L, slot, H_CANCELLED);
+            } else {
+                TW(c, slot, TW_FLAGS) = (f & ~TF_SCHED) | TF_RUN;
+                panicked = poll_task<TRACE>(c, L, slot);
+                f = TW(c, slot, TW_FLAGS);
+                if (!panicked && (f & TF_ALIVE)) {
+                    TW(c, slot, TW_FLAGS) = f & ~TF_RUN;
+                    if (f & TF_SCHED) { if (!ready_push(c, L, slot)) L.verdict = MADSIM_OVERFLOW; }
+                }
+            }
+            if (panicked) {
+                if (L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_PANIC;
+            } else {
+                // task/mod.rs:319-321: advance 50..100 ns, then Timer::expire
+                L.clock += gen_range_const<TRACE, 50>(c, L, 50);
+            }
+            expire_to = L.clock;
+        } else {
+            idle = true;
+            uint32_t h0 = W(c, P.off_handles + 0);
+            if ((h0 & 3) != H_RUNNING) { L.verdict = MADSIM_PASS; expire_to = 0; }            // :241-243
+            else if (L.heap_len == 0) { L.verdict = MADSIM_DEADLOCK; expire_to = 0; }         // :250
+            else expire_to = ev_deadline(heap_get(c, 0)) + 50;                                  // time/mod.rs:47-53
+        }
+        if (L.verdict == MADSIM_RUNNING) {
+            timer_expire(c, L, expire_to);
+            if (idle) {
+                L.clock = expire_to;                          // time/mod.rs:55 (after the callbacks)
+                if (P.time_limit && L.clock >= P.time_limit && L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_TIME_LIMIT;
+            }
+            if (L.steps >= P.max_steps && L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_STEP_LIMIT;
+        }
+        if (L.verdict != MADSIM_RUNNING) {
+            madsim_result_t r;
+            r.verdict = L.verdict; r.steps = L.steps; r.clock_ns = L.clock; r.msg_count = L.msg_count;
+            r.rng_calls = L.rng_calls; r.trace_hash = L.trace_hash; r.obs_hash = L.obs_hash;
+            P.out[next] = r;
+            if (TRACE) *P.trace_len = L.log_len;
+            have = false;
+            next += P.total_lanes;
+        }
+    }
+}
+
+#ifndef MADSIM_EMU
+// ---- summary reduction over the result array (first failing seed = min) -------------------------
+__global__ __launch_bounds__(256) void summary_kernel(const madsim_result_t* __restrict__ out, uint64_t count,
+                                                      uint64_t seed0, unsigned long long* __restrict__ acc) {
+    unsigned long long first = ~0ull, nfail = 0, steps = 0, clk = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        madsim_result_t r = out[i];
+        if (r.verdict != MADSIM_PASS) { nfail++; unsigned long long s = seed0 + i; first = s < first ? s : first; }
+        steps += r.steps; clk += r.clock_ns;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long f2 = __shfl_xor(first, o), n2 = __shfl_xor(nfail, o), s2 = __shfl_xor(steps, o), c2 = __shfl_xor(clk, o);
+        first = f2 < first ? f2 : first; nfail += n2; steps += s2; clk += c2;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&acc[0], first); atomicAdd(&acc[1], nfail); atomicAdd(&acc[2], steps); atomicAdd(&acc[3], clk);
+    }
+}
+
+#endif  // !MADSIM_EMU
+
+}  // namespace madsim_k
+
+#ifndef MADSIM_EMU
+extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace) {
+    if (trace) hipLaunchKernelGGL(madsim_k::sim_kernel<true>, dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    else hipLaunchKernelGGL(madsim_k::sim_kernel<false>, dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+}
+
+extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream) {
+    uint32_t grid = (uint32_t)((count + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(madsim_k::summary_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, count, seed0, acc);
+}
+
+extern "C" int madsim_k_set_max_lds(uint32_t lds_bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)madsim_k::sim_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)madsim_k::sim_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    return (int)e;
+}
+#endif  // !MADSIM_EMU

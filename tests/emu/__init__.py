@@ -1,0 +1,76 @@
+"""Host emulation of the device code (tests/emu/emu_shim.h): a debugging aid for GPU-less boxes.
+
+Test-only.  Never imported by madsim_amd/.  Agreement of the emulation with the oracle checks the
+kernel's *logic* on CPU; the GPU build is checked by the `-m gpu` tests.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from madsim_amd import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_LIB = os.path.join(_HERE, "libmadsim_emu.so")
+_SRCS = [os.path.join(_HERE, "emu_driver.cpp"), os.path.join(_HERE, "emu_shim.h"),
+         os.path.join(_ROOT, "madsim_amd", "csrc", "sim_kernel.hip"),
+         os.path.join(_ROOT, "madsim_amd", "csrc", "sim_kernel.h"),
+         os.path.join(_ROOT, "madsim_amd", "csrc", "geometry.h"),
+         os.path.join(_ROOT, "include", "madsim_hip.h")]
+
+
+def build():
+    if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in _SRCS):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DMADSIM_EMU", "-x", "c++",
+                               "-I" + _HERE, "-o", _LIB, _SRCS[0]])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.madsim_emu_run_batch.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64, C.c_uint64,
+                                           C.POINTER(A.Limits), C.c_void_p, C.c_int, C.c_void_p, C.c_uint64,
+                                           C.POINTER(C.c_uint64)]
+        L.madsim_emu_last_error.restype = C.c_char_p
+        L.madsim_emu_geometry.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Limits), C.POINTER(A.Geometry)]
+        _lib = L
+    return _lib
+
+
+def run_batch(workload, seed0, count, config=None, limits=None, num_cus=2):
+    cfg = config or A.Config.default()
+    lim = limits or A.Limits()
+    out = np.zeros(count, dtype=A.RESULT_DTYPE)
+    rc = lib().madsim_emu_run_batch(workload.ref(), C.byref(cfg), seed0, count, C.byref(lim),
+                                    out.ctypes.data_as(C.c_void_p), num_cus, None, 0, None)
+    if rc:
+        raise RuntimeError(f"emu error {rc}: {lib().madsim_emu_last_error().decode()}")
+    return out
+
+
+def trace_seed(workload, seed, config=None, limits=None, cap=1 << 20):
+    cfg = config or A.Config.default()
+    lim = limits or A.Limits()
+    out = np.zeros(1, dtype=A.RESULT_DTYPE)
+    buf = (C.c_uint8 * cap)()
+    n = C.c_uint64(0)
+    rc = lib().madsim_emu_run_batch(workload.ref(), C.byref(cfg), seed, 1, C.byref(lim),
+                                    out.ctypes.data_as(C.c_void_p), 1, buf, cap, C.byref(n))
+    if rc:
+        raise RuntimeError(f"emu error {rc}: {lib().madsim_emu_last_error().decode()}")
+    return bytes(buf[:min(n.value, cap)]), out[0]
+
+
+def geometry(workload, limits=None):
+    g = A.Geometry()
+    rc = lib().madsim_emu_geometry(workload.ref(), C.byref(limits or A.Limits()), C.byref(g))
+    if rc:
+        raise RuntimeError(lib().madsim_emu_last_error().decode())
+    return g

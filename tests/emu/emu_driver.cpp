@@ -1,0 +1,63 @@
+// emu_driver.cpp — runs madsim_amd/csrc/sim_kernel.hip's kernel body on the host, one emulated
+// thread after another (see emu_shim.h: debugging aid, not product, not a fallback).
+#include "emu_shim.h"
+thread_local emu_dim3 threadIdx, blockIdx;
+thread_local uint32_t* emu_smem;
+
+#include <string>
+#include <vector>
+#include <cstring>
+
+#include "../../madsim_amd/csrc/sim_kernel.hip"
+#include "../../madsim_amd/csrc/geometry.h"
+
+static thread_local std::string emu_err;
+
+extern "C" const char* madsim_emu_last_error(void) { return emu_err.c_str(); }
+
+extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                                    const madsim_limits_t* lim, madsim_result_t* out, int num_cus, uint8_t* tlog,
+                                    uint64_t tcap, uint64_t* tlen) {
+    int rc = madsim_geo::validate(w, cfg, &emu_err);
+    if (rc) return rc;
+    madsim_geo::Device dev; dev.num_cus = num_cus > 0 ? num_cus : 2;
+    madsim_geo::Geo G;
+    if ((rc = madsim_geo::make_geometry(dev, w, cfg, lim, count, &G, &emu_err))) return rc;
+    madsim_k::KParams& P = G.P;
+    std::vector<uint2> insns(w->n_insns);
+    std::vector<uint32_t> progs(w->n_progs), socks(w->n_socks ? w->n_socks : 1);
+    for (uint32_t i = 0; i < w->n_insns; i++) {
+        const madsim_insn_t& in = w->insns[i];
+        insns[i] = make_uint2((uint32_t)in.op | ((uint32_t)in.a << 8) | ((uint32_t)in.b << 16), in.imm);
+    }
+    for (uint32_t i = 0; i < w->n_progs; i++) progs[i] = (uint32_t)w->progs[i].node | ((uint32_t)w->progs[i].flags << 8) | ((uint32_t)w->progs[i].entry << 16);
+    for (uint32_t i = 0; i < w->n_socks; i++) socks[i] = (uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].port << 16);
+    P.insns = insns.data(); P.progs = progs.data(); P.socks = socks.data();
+    std::vector<uint4> spill((size_t)P.heap_spill * P.total_lanes + 1);
+    P.spill = P.heap_spill ? spill.data() : nullptr;
+    P.seed0 = seed0; P.count = count; P.out = out;
+    uint64_t dummy_len = 0;
+    P.trace_log = tlog; P.trace_cap = tcap; P.trace_len = tlen ? tlen : &dummy_len;
+    std::vector<uint32_t> lds(G.lds_bytes / 4 + 4);
+    uint32_t* base = lds.data();
+    while (((uintptr_t)base) & 15) base++;
+    for (uint32_t b = 0; b < G.grid; b++) {
+        for (uint32_t t = 0; t < 64; t++) {
+            blockIdx.x = b; threadIdx.x = t; emu_smem = base;
+            if (tlog) madsim_k::sim_kernel<true>(P); else madsim_k::sim_kernel<false>(P);
+        }
+    }
+    return 0;
+}
+
+extern "C" int madsim_emu_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* out) {
+    madsim_config_t cfg{}; cfg.lat_lo_ns = 1000000; cfg.lat_hi_ns = 10000000;
+    int rc = madsim_geo::validate(w, &cfg, &emu_err);
+    if (rc) return rc;
+    madsim_geo::Geo G; madsim_geo::Device dev;
+    if ((rc = madsim_geo::make_geometry(dev, w, &cfg, lim, UINT64_MAX / 2, &G, &emu_err))) return rc;
+    out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64;
+    out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
+    out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks;
+    return 0;
+}

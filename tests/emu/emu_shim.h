@@ -1,0 +1,25 @@
+// emu_shim.h — lets madsim_amd/csrc/sim_kernel.hip compile as plain host C++ (g++), one emulated
+// GPU thread at a time.  DEBUGGING AID for this GPU-less container: it exercises the device code's
+// logic (LDS layout arithmetic, heap, mailbox, interpreter) against the oracle before GPU minutes
+// are spent.  It is not part of the product, is never loaded by madsim_amd/, and proves nothing
+// about the GPU build — the -m gpu tests do that.
+#ifndef MADSIM_EMU_SHIM_H
+#define MADSIM_EMU_SHIM_H
+#include <stdint.h>
+#include <stddef.h>
+
+struct uint2 { uint32_t x, y; };
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct emu_dim3 { uint32_t x, y, z; };
+extern thread_local emu_dim3 threadIdx, blockIdx;
+extern thread_local uint32_t* emu_smem;
+#define __device__
+#define __global__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__
+static inline void __syncthreads() {}
+static inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+#endif
