@@ -105,11 +105,14 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.heap_lds = L.heap_lds_slots ? L.heap_lds_slots : 8;
     P.heap_spill = (L.heap_lds_slots || L.heap_spill_slots) ? L.heap_spill_slots : 56;
     bool t0 = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED);
-    P.task_words = t0 ? 9 : 7;
+    P.task_units = t0 ? 3 : 2;
     P.sock_words = 2 + P.mbox_regs + 2 * P.mbox_msgs;
     P.has_clog_link = uses_op(w, MS_OP_CLOG_LINK);
-    P.off_tasks = 0;
-    P.off_ready = P.off_tasks + P.max_tasks * P.task_words;
+    P.uniq_addr = 1;
+    for (uint32_t i = 0; i < w->n_socks; i++)
+        for (uint32_t j = i + 1; j < w->n_socks; j++)
+            if (w->socks[i].node == w->socks[j].node && w->socks[i].port == w->socks[j].port) P.uniq_addr = 0;
+    P.off_ready = 0;
     P.off_socks = P.off_ready + P.max_tasks;
     P.off_handles = P.off_socks + P.n_socks * P.sock_words;
     P.off_nodes = P.off_handles + P.n_progs;
@@ -119,8 +122,9 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.sh_progs = P.sh_insns + 2 * P.n_insns;
     P.sh_socks = P.sh_progs + P.n_progs;
     P.sh_heap = (P.sh_socks + P.n_socks + 3) & ~3u;
-    P.sh_planes = P.sh_heap + P.heap_lds * 64 * 4;
-    G->lds_per_seed = P.heap_lds * 16 + P.lane_words * 4;
+    P.sh_tasks = P.sh_heap + P.heap_lds * 64 * 4;
+    P.sh_planes = P.sh_tasks + P.max_tasks * P.task_units * 64 * 4;
+    G->lds_per_seed = P.heap_lds * 16 + P.max_tasks * P.task_units * 16 + P.lane_words * 4;
     G->lds_bytes = (P.sh_planes + P.lane_words * 64) * 4;
     if (G->lds_bytes > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-workgroup LDS exceeds 160 KiB: lower heap_lds_slots / mailbox capacities");
     uint32_t by_lds = (uint32_t)(g.lds_per_cu / G->lds_bytes);

@@ -24,11 +24,12 @@ struct KParams {
     uint64_t time_limit; uint32_t max_steps;
     // capacities
     uint32_t heap_lds, heap_spill, max_tasks, mbox_regs, mbox_msgs;
-    uint32_t task_words, sock_words, lane_words;
-    // LDS layout, in 32-bit words: workgroup-shared tables, heap (16-byte aligned), then planes
-    uint32_t sh_insns, sh_progs, sh_socks, sh_heap, sh_planes;
+    uint32_t task_units, sock_words, lane_words, uniq_addr;
+    // LDS layout, in 32-bit words: workgroup-shared tables, heap units and task units (16-byte
+    // aligned, [unit][lane]), then the 32-bit planes ([word][lane])
+    uint32_t sh_insns, sh_progs, sh_socks, sh_heap, sh_tasks, sh_planes;
     // per-lane plane offsets (in words)
-    uint32_t off_tasks, off_ready, off_socks, off_handles, off_nodes, off_clog;
+    uint32_t off_ready, off_socks, off_handles, off_nodes, off_clog;
     // batch
     uint64_t seed0, count;
     madsim_result_t* out;

@@ -39,9 +39,11 @@ namespace madsim_k {
 #define NS_PER_S 1000000000ull
 #define NS_PER_MS 1000000ull
 
-// task flag bits (TW_FLAGS low byte)
+// Task state = 16-byte units [unit][lane] (ds_read/write_b128, conflict-free):
+//   unit0 {x: flags:8 | gen:16 | prog:8,  y: pc:16 | sub:8 | from:8,  z: cnt0:16 | cnt1:16,  w: val}
+//   unit1 {x: rxseq:8 | joiner:8 | joiner_gen:16,  y: -,  z: deadline lo,  w: deadline hi}
+//   unit2 {x: t0 lo, y: t0 hi, z/w: -}                       (only when the workload uses MS_OP_MARK)
 enum : uint32_t { TF_ALIVE = 1, TF_SCHED = 2, TF_RUN = 4, TF_KILLED = 8, TF_CANCEL = 16, TF_INBOX = 32 };
-enum : uint32_t { TW_FLAGS = 0, TW_PC = 1, TW_CNT = 2, TW_VAL = 3, TW_LINK = 4, TW_DL_LO = 5, TW_DL_HI = 6, TW_T0_LO = 7, TW_T0_HI = 8 };
 enum : uint32_t { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3 };
 enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 
@@ -53,6 +55,8 @@ struct Lane {
     uint64_t log_len;
     // Clock
     uint64_t clock;
+    // Timer: write-through mirror of heap[0]'s deadline (UINT64_MAX when empty)
+    uint64_t top_dl;
     // accounting
     uint64_t obs_hash;
     uint32_t msg_count;
@@ -69,6 +73,7 @@ struct Ctx {
     const KParams& P;
     uint32_t* lds;       // per-lane plane base: word w of this lane = lds[w * 64]
     uint4* heap;         // heap[i * 64]
+    uint4* tasks;        // tasks[(slot * task_units + u) * 64]
     const uint2* insn;   // workgroup-shared tables in LDS
     const uint32_t* prog;
     const uint32_t* sock;
@@ -78,10 +83,12 @@ struct Ctx {
 };
 
 __device__ __forceinline__ uint32_t& W(const Ctx& c, uint32_t w) { return c.lds[w * 64]; }
-__device__ __forceinline__ uint32_t& TW(const Ctx& c, uint32_t slot, uint32_t f) { return c.lds[(c.P.off_tasks + slot * c.P.task_words + f) * 64]; }
 __device__ __forceinline__ uint32_t& SW(const Ctx& c, uint32_t s, uint32_t f) { return c.lds[(c.P.off_socks + s * c.P.sock_words + f) * 64]; }
+__device__ __forceinline__ uint4& TU(const Ctx& c, uint32_t slot, uint32_t u) { return c.tasks[(slot * c.P.task_units + u) * 64]; }
+__device__ __forceinline__ uint32_t& TWORD(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) { return ((uint32_t*)&c.tasks[(slot * c.P.task_units + u) * 64])[k]; }
 
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+__device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // ---- GlobalRng ---------------------------------------------------------------------------------
 // Xoshiro256PlusPlus::next_u64 [DEP rand_xoshiro 0.6]
@@ -122,15 +129,35 @@ __device__ __forceinline__ uint64_t gen_range_u64(const Ctx& c, Lane& L, uint64_
     return res;
 }
 
-// Same with range and zone known at compile time (idx over small queues uses the generic form).
-template <bool TRACE, uint64_t RANGE>
-__device__ __forceinline__ uint64_t gen_range_const(const Ctx& c, Lane& L, uint64_t lo) {
-    constexpr uint64_t zone = (RANGE << __builtin_clzll(RANGE)) - 1;
-    uint64_t res;
+// ready-queue index draw: range = len <= 255, so the 128-bit product splits into two 32x32 pieces.
+template <bool TRACE>
+__device__ __forceinline__ uint32_t gen_index(const Ctx& c, Lane& L, uint32_t len) {
+    uint64_t zone = ((uint64_t)len << __builtin_clzll((uint64_t)len)) - 1;
+    uint32_t res;
     for (;;) {
         uint64_t v = rng_next(L);
-        uint64_t mlo = v * RANGE;
-        if (mlo <= zone) { res = lo + __umul64hi(v, RANGE); break; }
+        uint64_t plo = (uint64_t)(uint32_t)v * len;            // < 2^40
+        uint64_t phi = (uint64_t)(uint32_t)(v >> 32) * len;    // < 2^40
+        uint64_t mid = phi + (plo >> 32);
+        uint64_t mlo = (mid << 32) | (uint32_t)plo;
+        if (mlo <= zone) { res = (uint32_t)(mid >> 32); break; }
+    }
+    rng_log<TRACE>(c, L);
+    return res;
+}
+
+// gen_range with a compile-time range < 2^32.
+template <bool TRACE, uint32_t RANGE>
+__device__ __forceinline__ uint32_t gen_range_small(const Ctx& c, Lane& L) {
+    constexpr uint64_t zone = ((uint64_t)RANGE << __builtin_clzll((uint64_t)RANGE)) - 1;
+    uint32_t res;
+    for (;;) {
+        uint64_t v = rng_next(L);
+        uint64_t plo = (uint64_t)(uint32_t)v * RANGE;
+        uint64_t phi = (uint64_t)(uint32_t)(v >> 32) * RANGE;
+        uint64_t mid = phi + (plo >> 32);
+        uint64_t mlo = (mid << 32) | (uint32_t)plo;
+        if (mlo <= zone) { res = (uint32_t)(mid >> 32); break; }
     }
     rng_log<TRACE>(c, L);
     return res;
@@ -166,7 +193,7 @@ __device__ __forceinline__ uint64_t sample_latency(const Ctx& c, Lane& L) {
 
 // ---- Timer = BinaryHeap<Event>, reversed Ord on deadline [DEP naive-timer 0.2 + alloc BinaryHeap] --
 // entry: x = deadline lo, y = deadline hi, z = meta, w = payload value
-__device__ __forceinline__ uint64_t ev_deadline(const uint4& e) { return ((uint64_t)e.y << 32) | e.x; }
+__device__ __forceinline__ uint64_t ev_deadline(const uint4& e) { return u64of(e.x, e.y); }
 
 __device__ __forceinline__ uint4 heap_get(const Ctx& c, uint32_t i) {
     if (i < c.P.heap_lds) return c.heap[i * 64];
@@ -177,7 +204,8 @@ __device__ __forceinline__ void heap_set(const Ctx& c, uint32_t i, const uint4& 
     else c.spill[(size_t)(i - c.P.heap_lds) * c.P.total_lanes] = e;
 }
 
-__device__ __forceinline__ void heap_sift_up(const Ctx& c, uint32_t pos, const uint4& hole) {
+// BinaryHeap::sift_up(0, pos) with `hole` as the moving element; keeps the root mirror current.
+__device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos, const uint4& hole) {
     uint64_t hd = ev_deadline(hole);
     while (pos > 0) {
         uint32_t parent = (pos - 1) >> 1;
@@ -187,58 +215,69 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, uint32_t pos, const u
         pos = parent;
     }
     heap_set(c, pos, hole);
+    if (pos == 0) L.top_dl = hd;
 }
 
-// returns false on capacity overflow
+// Timer::add -> BinaryHeap::push.  Returns false on capacity overflow.
 __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val) {
     if (L.heap_len >= c.P.heap_lds + c.P.heap_spill) return false;
     uint4 e = make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, val);
-    heap_sift_up(c, L.heap_len, e);
+    heap_sift_up(c, L, L.heap_len, e);
     L.heap_len++;
     return true;
 }
 
+// BinaryHeap::pop: swap the last element into the root, sift_down_to_bottom(0), then sift_up.
 __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
     uint32_t end = --L.heap_len;
     uint4 item = heap_get(c, end);
     if (end > 0) {
         uint4 top = heap_get(c, 0);
-        // sift_down_to_bottom(0) with `item` as the hole element
         uint32_t pos = 0, child = 1;
         while (child + 1 < end) {
             uint4 l = heap_get(c, child), r = heap_get(c, child + 1);
-            bool right = ev_deadline(l) >= ev_deadline(r);   // left <= right: take right
-            heap_set(c, pos, right ? r : l);
+            bool right = ev_deadline(l) >= ev_deadline(r);   // left <= right in heap order: take right
+            uint4 m = right ? r : l;
+            heap_set(c, pos, m);
+            if (pos == 0) L.top_dl = ev_deadline(m);
             pos = child + (right ? 1u : 0u);
             child = 2 * pos + 1;
         }
-        if (child == end - 1) { heap_set(c, pos, heap_get(c, child)); pos = child; }
-        heap_sift_up(c, pos, item);
+        if (child == end - 1) {
+            uint4 m = heap_get(c, child);
+            heap_set(c, pos, m);
+            if (pos == 0) L.top_dl = ev_deadline(m);
+            pos = child;
+        }
+        heap_sift_up(c, L, pos, item);
         item = top;
+    } else {
+        L.top_dl = ~0ull;
     }
     return item;
 }
 
 // ---- async-task wake / schedule [DEP A.7] -------------------------------------------------------
-__device__ __forceinline__ bool ready_push(const Ctx& c, Lane& L, uint32_t slot) {
-    if (L.ready_len >= c.P.max_tasks) return false;
+__device__ __forceinline__ void ready_push(const Ctx& c, Lane& L, uint32_t slot) {
+    if (L.ready_len >= c.P.max_tasks) { L.verdict = MADSIM_OVERFLOW; return; }
     W(c, c.P.off_ready + L.ready_len) = slot;
     L.ready_len++;
-    return true;
 }
 
 __device__ __forceinline__ void wake(const Ctx& c, Lane& L, uint32_t slot, uint32_t gen) {
     if (slot >= c.P.max_tasks) return;
-    uint32_t f = TW(c, slot, TW_FLAGS);
-    if (!(f & TF_ALIVE) || ((f >> 8) & 0xffff) != gen) return;
+    uint32_t f = TWORD(c, slot, 0, 0);
+    if (!(f & TF_ALIVE) || ((f >> 8) & 0xffff) != gen) return;   // COMPLETED | CLOSED
     if (f & TF_SCHED) return;
-    TW(c, slot, TW_FLAGS) = f | TF_SCHED;
-    if (!(f & TF_RUN)) { if (!ready_push(c, L, slot)) L.verdict = MADSIM_OVERFLOW; }
+    TWORD(c, slot, 0, 0) = f | TF_SCHED;
+    if (!(f & TF_RUN)) ready_push(c, L, slot);                   // RUNNING: run() re-queues after the poll
 }
 
 // ---- Network -----------------------------------------------------------------------------------
-__device__ __forceinline__ int find_bound(const Ctx& c, uint32_t node, uint32_t port) {
-    uint32_t key = node | (port << 16);
+// Network::try_send's socket lookup (network.rs:304-306): the bound socket at addr(dst), if any.
+__device__ __forceinline__ int find_bound(const Ctx& c, uint32_t addr) {
+    if (c.P.uniq_addr) return (SW(c, addr, 0) & 1) ? (int)addr : -1;
+    uint32_t key = c.sock[addr] & 0xffff00ffu;
     for (uint32_t i = 0; i < c.P.n_socks; i++)
         if ((c.sock[i] & 0xffff00ffu) == key && (SW(c, i, 0) & 1)) return (int)i;
     return -1;
@@ -248,7 +287,7 @@ __device__ __forceinline__ int find_bound(const Ctx& c, uint32_t node, uint32_t 
 __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t meta, uint32_t val) {
     uint32_t s = meta & 0x3f, from = (meta >> 6) & 0x3f, tag = (meta >> 12) & 0xff, sgen = (meta >> 20) & 0xff;
     uint32_t h = SW(c, s, 0);
-    if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;
+    if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;     // that Endpoint object is gone
     uint32_t nreg = (h >> 9) & 0xf, nmsg = (h >> 13) & 0xf;
     uint32_t i = 0;
     while (i < nreg) {
@@ -257,15 +296,17 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
             nreg--;
             SW(c, s, 2 + i) = SW(c, s, 2 + nreg);          // swap_remove
             uint32_t slot = (r >> 8) & 0xff, rxseq = (r >> 16) & 0xff, g8 = r >> 24;
-            uint32_t f = TW(c, slot, TW_FLAGS);
-            uint32_t link = TW(c, slot, TW_LINK);
-            if ((f & TF_ALIVE) && ((f >> 8) & 0xff) == g8 && (link & 0xff) == rxseq && !(f & TF_INBOX)) {
-                TW(c, slot, TW_FLAGS) = f | TF_INBOX;      // oneshot::Sender::send Ok
-                TW(c, slot, TW_VAL) = val;
-                uint32_t pcw = TW(c, slot, TW_PC);
-                TW(c, slot, TW_PC) = (pcw & 0x00ffffffu) | (from << 24);
+            uint4 u0 = TU(c, slot, 0);
+            uint32_t link = TWORD(c, slot, 1, 0);
+            if ((u0.x & TF_ALIVE) && ((u0.x >> 8) & 0xff) == g8 && (link & 0xff) == rxseq && !(u0.x & TF_INBOX)) {
+                // oneshot::Sender::send Ok -> value stored, receiver task woken [DEP tokio oneshot]
+                bool sched = u0.x & TF_SCHED;
+                u0.x |= TF_INBOX | TF_SCHED;
+                u0.y = (u0.y & 0x00ffffffu) | (from << 24);
+                u0.w = val;
+                TU(c, slot, 0) = u0;
                 SW(c, s, 0) = (h & ~(0xfu << 9)) | (nreg << 9);
-                wake(c, L, slot, (f >> 8) & 0xffff);
+                if (!sched && !(u0.x & TF_RUN)) ready_push(c, L, slot);
                 return;
             }
         } else {
@@ -281,9 +322,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
 
 // Timer::expire [DEP A.5]: fire every entry with deadline <= now
 __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now) {
-    while (L.heap_len > 0 && L.verdict == MADSIM_RUNNING) {
-        uint4 top = heap_get(c, 0);
-        if (ev_deadline(top) > now) break;
+    while (L.top_dl <= now && L.verdict == MADSIM_RUNNING) {
         uint4 e = timer_pop(c, L);
         L.steps++;
         uint32_t kind = e.z >> 28;
@@ -295,23 +334,21 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
 // ---- task lifecycle ----------------------------------------------------------------------------
 __device__ __forceinline__ void spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record) {
     uint32_t slot = 0;
-    while (slot < c.P.max_tasks && (TW(c, slot, TW_FLAGS) & TF_ALIVE)) slot++;
+    while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
     if (slot >= c.P.max_tasks) { L.verdict = MADSIM_OVERFLOW; return; }
-    uint32_t gen = (((TW(c, slot, TW_FLAGS) >> 8) & 0xffff) + 1) & 0xffff;
+    uint32_t gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
     uint32_t pw = c.prog[prog];
     uint32_t node = pw & 0xff;
     uint32_t killed = (W(c, c.P.off_nodes) >> node) & 1;
-    TW(c, slot, TW_FLAGS) = TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24);
-    TW(c, slot, TW_PC) = pw >> 16;                         // pc = entry, sub = 0, from = 0
-    TW(c, slot, TW_CNT) = 0;
-    TW(c, slot, TW_VAL) = 0;
-    TW(c, slot, TW_LINK) = 0xff << 8;                      // rxseq 0, joiner none (0xff)
-    if (!ready_push(c, L, slot)) L.verdict = MADSIM_OVERFLOW;
+    TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
+    TU(c, slot, 1) = make_uint4(0xffu << 8, 0, 0, 0);        // rxseq 0, no awaiter
+    ready_push(c, L, slot);
     if (record) W(c, c.P.off_handles + prog) = H_RUNNING | (slot << 8) | (gen << 16);
 }
 
+// The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
 __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome) {
-    uint32_t f = TW(c, slot, TW_FLAGS);
+    uint32_t f = TWORD(c, slot, 0, 0);
     uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
     // BindGuard::drop (net/mod.rs:483-493), skipped when the binder's NodeInfo is killed
     if (!(f & TF_KILLED)) {
@@ -321,10 +358,10 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
     }
     uint32_t h = W(c, c.P.off_handles + prog);
     if (h == (H_RUNNING | (slot << 8) | (gen << 16))) W(c, c.P.off_handles + prog) = (h & ~3u) | outcome;
-    uint32_t link = TW(c, slot, TW_LINK);
-    TW(c, slot, TW_FLAGS) = f & ~(TF_ALIVE | TF_SCHED | TF_RUN | TF_INBOX);
+    uint32_t link = TWORD(c, slot, 1, 0);
+    TWORD(c, slot, 0, 0) = f & ~(TF_ALIVE | TF_SCHED | TF_RUN | TF_INBOX);
     uint32_t j = (link >> 8) & 0xff;
-    if (j != 0xff) wake(c, L, j, link >> 16);
+    if (j != 0xff) wake(c, L, j, link >> 16);              // async-task notifies the awaiter
 }
 
 // TimeHandle::sleep_until (time/mod.rs:118-124): 1 ms floor
@@ -333,139 +370,116 @@ __device__ __forceinline__ uint64_t sleep_deadline(const Lane& L, uint64_t deadl
     return deadline > m ? deadline : m;
 }
 
-// NetSim::rand_delay up to the creation of its Sleep (net/mod.rs:287-292)
-template <bool TRACE>
-__device__ __forceinline__ uint64_t rand_delay_start(const Ctx& c, Lane& L) {
-    uint64_t delay = gen_range_const<TRACE, 5>(c, L, 0) * 1000ull;
-    if (c.P.buggify) {
-        if (gen_bool_pint<TRACE>(c, L, c.P.bug_pint, 0)) delay = gen_range_const<TRACE, 4>(c, L, 1) * NS_PER_S;
-    }
-    return sleep_deadline(L, L.clock + delay);
+__device__ __forceinline__ bool is_light(uint32_t op) {
+    return op == MS_OP_ASSERT_VAL || op == MS_OP_DJNZ || op == MS_OP_SET || op == MS_OP_JMP || op == MS_OP_TRACE;
 }
 
-// One poll of a task's future (Runnable::run).  Returns true if the task panicked.
+// One poll of a task's future (Runnable::run, task/mod.rs:279-283).  `u0` is the task's unit0, held
+// in registers for the whole poll and written back by the caller.  Returns true if the task panicked.
+//
+// A poll is a sequence of rounds; one round = [A] resolve the await the task is parked on and run its
+// completion action, [B] run the cheap straight-line ops that follow, [C] begin the next awaiting op.
+// In steady state every poll is exactly one round, and all lanes walk A -> B -> C together, so the
+// expensive primitives (RNG draws, heap pushes, link test, mailbox scan) sit at fixed points that the
+// whole wave reaches at the same time.
 template <bool TRACE>
-__device__ bool poll_task(const Ctx& c, Lane& L, uint32_t slot) {
+__device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t slot, uint4& u0) {
     const KParams& P = c.P;
-    uint32_t pcw = TW(c, slot, TW_PC);
-    uint32_t pc = pcw & 0xffff, sub = (pcw >> 16) & 0xff, from = pcw >> 24;
-    const uint32_t flags0 = TW(c, slot, TW_FLAGS);
-    const uint32_t gen = (flags0 >> 8) & 0xffff;
-    const uint32_t node = c.prog[flags0 >> 24] & 0xff;
+    uint4 u1 = TU(c, slot, 1);
+    bool u1_dirty = false;
+    uint32_t pc = u0.y & 0xffff, sub = (u0.y >> 16) & 0xff, from = u0.y >> 24;
+    const uint32_t gen = (u0.x >> 8) & 0xffff;
+    const uint32_t node = c.prog[u0.x >> 24] & 0xff;
     bool panicked = false, pending = false, finished = false;
-
-#define SAVE_PC() (TW(c, slot, TW_PC) = pc | (sub << 16) | (from << 24))
 
     while (!pending && !finished && !panicked && L.verdict == MADSIM_RUNNING) {
         if (pc >= P.n_insns) { panicked = true; break; }
         uint2 in = c.insn[pc];
         uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
-        uint64_t dur = (uint64_t)b * NS_PER_S + imm;
-        // ops that start with NetSim::rand_delay, then wait on its Sleep
-        bool delayed = (op == MS_OP_BIND) | (op == MS_OP_SEND) | (op == MS_OP_REPLY) | (op == MS_OP_RECV);
-        bool sleeping = false;          // this op (in its current sub-state) awaits the Sleep in TW_DL
-        switch (op) {
-        case MS_OP_DONE:
-            SAVE_PC();
-            task_finish(c, L, slot, H_COMPLETED);
-            finished = true;
-            break;
-        case MS_OP_SPAWN:
-            spawn_task(c, L, a, true);
-            pc++;
-            break;
-        case MS_OP_BUILD:
-            for (uint32_t p = 1; p < P.n_progs; p++) {
-                uint32_t pw = c.prog[p];
-                if ((pw & 0xff) == a && ((pw >> 8) & MADSIM_PROG_INIT) && !((pw >> 8) & MADSIM_PROG_PRE)) spawn_task(c, L, p, false);
+
+        // ================= [A] the task is parked on an await of this op =========================
+        if (sub != 0) {
+            if (op == MS_OP_RECV && sub == 1) {            // oneshot::Receiver (endpoint.rs:142-144)
+                if (!(u0.x & TF_INBOX)) { pending = true; break; }
+                u0.x &= ~TF_INBOX;
+                from = u0.y >> 24;
+                sub = 2;                                   // -> rand_delay, begun in [C]
+            } else if (op == MS_OP_YIELD) {
+                sub = 0; pc++;
+                continue;
+            } else {                                       // a Sleep (time/sleep.rs:47-54)
+                uint64_t deadline = u64of(u1.z, u1.w);
+                if (L.clock < deadline) {                  // not elapsed: register ANOTHER timer
+                    if (!timer_add(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.verdict = MADSIM_OVERFLOW;
+                    pending = true;
+                    break;
+                }
+                sub = 0;
+                if (op == MS_OP_BIND) {                    // Network::bind (network.rs:206-251)
+                    uint32_t sw = c.sock[a];
+                    if ((sw & 0xff) != node || find_bound(c, a) >= 0) { panicked = true; break; }
+                    uint32_t h = SW(c, a, 0);
+                    SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);     // bound, gen+1, empty mailbox
+                    SW(c, a, 1) = slot | (gen << 16);
+                } else if (op == MS_OP_SEND || op == MS_OP_REPLY) {        // net/mod.rs:307-331
+                    uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : from;
+                    uint32_t src_node = c.sock[a] & 0xff;
+                    uint32_t dst_node = c.sock[dst] & 0xff;
+                    // Network::try_send -> test_link (network.rs:261-269, 296-313)
+                    bool clogged = ((W(c, P.off_clog + 1) >> src_node) & 1) | ((W(c, P.off_clog + 0) >> dst_node) & 1);
+                    if (P.has_clog_link) clogged |= (W(c, P.off_clog + 2 + src_node) >> dst_node) & 1;
+                    if (!clogged && !gen_bool_pint<TRACE>(c, L, L.loss_pint, L.loss_always)) {
+                        L.msg_count++;
+                        uint64_t lat = sample_latency<TRACE>(c, L);
+                        int ds = find_bound(c, dst);
+                        if (ds >= 0) {
+                            uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
+                            uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((b >> 8) << 12) | (a << 6) | (uint32_t)ds;
+                            if (!timer_add(c, L, L.clock + lat, meta, imm)) L.verdict = MADSIM_OVERFLOW;
+                        }
+                    }
+                }
+                pc++;
+                continue;                                  // fetch the next op
             }
-            pc++;
-            break;
-        case MS_OP_JOIN: {
-            uint32_t h = W(c, P.off_handles + a);
-            uint32_t st = h & 3;
-            if (st == H_RUNNING) {
-                uint32_t cs = (h >> 8) & 0xff;
-                uint32_t link = TW(c, cs, TW_LINK);
-                TW(c, cs, TW_LINK) = (link & 0xff) | (slot << 8) | (gen << 16);   // register awaiter
-                pending = true;
-            } else if (st == H_NONE || ((st == H_CANCELLED) != ((b & 1) != 0))) {
-                panicked = true;
-            } else {
+        }
+
+        // ================= [B] cheap ops that never await ========================================
+        while (is_light(op)) {
+            if (op == MS_OP_ASSERT_VAL) {
+                if (u0.w != imm) { panicked = true; break; }
+                pc++;
+            } else if (op == MS_OP_DJNZ) {
+                uint32_t sh = (a & 1) * 16;
+                uint32_t v = (((u0.z >> sh) & 0xffff) - 1) & 0xffff;
+                u0.z = (u0.z & ~(0xffffu << sh)) | (v << sh);
+                pc = v ? b : pc + 1;
+            } else if (op == MS_OP_SET) {
+                u0.z = (a & 1) ? ((u0.z & 0xffffu) | (imm << 16)) : ((u0.z & 0xffff0000u) | (imm & 0xffffu));
+                pc++;
+            } else if (op == MS_OP_JMP) {
+                pc = b;
+            } else {                                       // MS_OP_TRACE
+                uint64_t v = imm;
+                if (b & 1) v += (u0.z >> ((a & 1) * 16)) & 0xffff;
+                L.obs_hash = (L.obs_hash ^ v) * FNV_PRIME;
                 pc++;
             }
-            break;
+            if (pc >= P.n_insns) { panicked = true; break; }
+            in = c.insn[pc];
+            op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
         }
-        case MS_OP_YIELD:
-            if (sub == 0) {
-                sub = 1;
-                TW(c, slot, TW_FLAGS) |= TF_SCHED;          // wake_by_ref while RUNNING
-                pending = true;
-            } else { sub = 0; pc++; }
-            break;
-        case MS_OP_PANIC:
-            panicked = true;
-            break;
-        case MS_OP_SET: {
-            uint32_t cw = TW(c, slot, TW_CNT);
-            TW(c, slot, TW_CNT) = (a & 1) ? ((cw & 0xffffu) | (imm << 16)) : ((cw & 0xffff0000u) | (imm & 0xffffu));
-            pc++;
-            break;
-        }
-        case MS_OP_DJNZ: {
-            uint32_t cw = TW(c, slot, TW_CNT);
-            uint32_t sh = (a & 1) * 16;
-            uint32_t v = (((cw >> sh) & 0xffff) - 1) & 0xffff;
-            TW(c, slot, TW_CNT) = (cw & ~(0xffffu << sh)) | (v << sh);
-            pc = v ? b : pc + 1;
-            break;
-        }
-        case MS_OP_JMP:
-            pc = b;
-            break;
-        case MS_OP_TRACE: {
-            uint64_t v = imm;
-            if (b & 1) v += (TW(c, slot, TW_CNT) >> ((a & 1) * 16)) & 0xffff;
-            L.obs_hash = (L.obs_hash ^ v) * FNV_PRIME;
-            pc++;
-            break;
-        }
-        case MS_OP_SLEEP:
-        case MS_OP_SLEEP_UNTIL:
-            if (sub == 0) {
-                uint64_t base = L.clock;
-                if (op == MS_OP_SLEEP_UNTIL) base = ((uint64_t)TW(c, slot, TW_T0_HI) << 32) | TW(c, slot, TW_T0_LO);
-                uint64_t d = sleep_deadline(L, base + dur);
-                TW(c, slot, TW_DL_LO) = (uint32_t)d; TW(c, slot, TW_DL_HI) = (uint32_t)(d >> 32);
-                sub = 1;
-            }
-            sleeping = true;
-            break;
-        case MS_OP_MARK:
-            TW(c, slot, TW_T0_LO) = (uint32_t)L.clock; TW(c, slot, TW_T0_HI) = (uint32_t)(L.clock >> 32);
-            pc++;
-            break;
-        case MS_OP_ASSERT_ELAPSED: {
-            uint64_t t0 = ((uint64_t)TW(c, slot, TW_T0_HI) << 32) | TW(c, slot, TW_T0_LO);
-            uint64_t el = L.clock - t0;
-            bool ok = a == 0 ? el == dur : a == 1 ? el >= dur : el < dur;
-            if (!ok) panicked = true; else pc++;
-            break;
-        }
-        case MS_OP_ADVANCE:                                 // time/mod.rs:103-106
-            L.clock += dur;
-            pc++;
-            SAVE_PC();
-            timer_expire(c, L, L.clock);
-            from = TW(c, slot, TW_PC) >> 24;
-            break;
-        case MS_OP_RECV:
-            if (sub == 0) {                                 // Mailbox::recv (endpoint.rs:353-362)
+        if (panicked) break;
+
+        // ================= [C] begin the next op =================================================
+        bool want_delay = false, want_sleep = false;
+        uint64_t deadline = 0;
+        if (op == MS_OP_RECV) {
+            if (sub == 0) {                                // Mailbox::recv (endpoint.rs:353-362)
                 uint32_t tag = b >> 8;
-                uint32_t link = TW(c, slot, TW_LINK);
-                uint32_t rxseq = ((link & 0xff) + 1) & 0xff;
-                TW(c, slot, TW_LINK) = (link & ~0xffu) | rxseq;
-                uint32_t f = TW(c, slot, TW_FLAGS) & ~TF_INBOX;
+                uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;
+                u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
+                u0.x &= ~TF_INBOX;
                 uint32_t h = SW(c, a, 0);
                 uint32_t nreg = (h >> 9) & 0xf, nmsg = (h >> 13) & 0xf;
                 uint32_t idx = 0, mbase = 2 + P.mbox_regs;
@@ -475,115 +489,145 @@ __device__ bool poll_task(const Ctx& c, Lane& L, uint32_t slot) {
                     nmsg--;
                     SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);        // swap_remove
                     SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
-                    f |= TF_INBOX;
-                    TW(c, slot, TW_VAL) = m1;
+                    u0.w = m1;
                     from = (m0 >> 8) & 0xff;
+                    sub = 2;                               // oneshot already holds the value
+                    SW(c, a, 0) = (h & ~(0xfu << 13)) | (nmsg << 13);
                 } else {
                     if (nreg >= P.mbox_regs) { L.verdict = MADSIM_OVERFLOW; break; }
                     SW(c, a, 2 + nreg) = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
-                    nreg++;
+                    SW(c, a, 0) = (h & ~(0xfu << 9)) | ((nreg + 1) << 9);
+                    sub = 1;
+                    pending = true;
                 }
-                SW(c, a, 0) = (h & ~((0xfu << 9) | (0xfu << 13))) | (nreg << 9) | (nmsg << 13);
-                TW(c, slot, TW_FLAGS) = f;
-                sub = 1;
             }
-            if (sub == 1) {
-                uint32_t f = TW(c, slot, TW_FLAGS);
-                if (!(f & TF_INBOX)) { pending = true; break; }     // oneshot::Receiver Pending
-                TW(c, slot, TW_FLAGS) = f & ~TF_INBOX;
-                from = TW(c, slot, TW_PC) >> 24;
-                sub = 2;                                            // -> rand_delay (endpoint.rs:145)
-            }
-            sleeping = true;
-            break;
-        case MS_OP_BIND:
-        case MS_OP_SEND:
-        case MS_OP_REPLY:
-            sleeping = true;
-            break;
-        case MS_OP_ASSERT_VAL:
-            if (TW(c, slot, TW_VAL) != imm) panicked = true; else pc++;
-            break;
-        case MS_OP_CLOSE: {
-            uint32_t h = SW(c, a, 0);
-            if ((h & 1) && SW(c, a, 1) == (slot | (gen << 16)) && !(flags0 & TF_KILLED)) SW(c, a, 0) = h & ~1u;
-            pc++;
-            break;
-        }
-        case MS_OP_CLOG_NODE:
-            if (b & 1) W(c, P.off_clog + 0) |= 1u << a;
-            if (b & 2) W(c, P.off_clog + 1) |= 1u << a;
-            pc++;
-            break;
-        case MS_OP_UNCLOG_NODE:
-            if (b & 1) W(c, P.off_clog + 0) &= ~(1u << a);
-            if (b & 2) W(c, P.off_clog + 1) &= ~(1u << a);
-            pc++;
-            break;
-        case MS_OP_CLOG_LINK:
-            W(c, P.off_clog + 2 + a) |= 1u << b;
-            pc++;
-            break;
-        case MS_OP_UNCLOG_LINK:
-            W(c, P.off_clog + 2 + a) &= ~(1u << b);
-            pc++;
-            break;
-        case MS_OP_SET_LOSS:
-            L.loss_pint = P.loss_table_pint[a & 3];
-            L.loss_always = P.loss_table_always[a & 3];
-            pc++;
-            break;
-        default:
-            panicked = true;
-            break;
-        }
-        if (!sleeping || pending || panicked || L.verdict != MADSIM_RUNNING) continue;
-
-        // ---- shared tail for every op that awaits a Sleep (time/sleep.rs:47-54) ------------------
-        uint32_t wait_sub = (op == MS_OP_RECV) ? 3 : 1;      // sub value meaning "Sleep registered"
-        uint64_t deadline;
-        if (delayed && sub != wait_sub) {                    // first half of NetSim::rand_delay
-            deadline = rand_delay_start<TRACE>(c, L);
-            TW(c, slot, TW_DL_LO) = (uint32_t)deadline; TW(c, slot, TW_DL_HI) = (uint32_t)(deadline >> 32);
-            sub = wait_sub;
+            want_delay = (sub == 2);                       // endpoint.rs:145 rand_delay
+        } else if (op == MS_OP_SEND || op == MS_OP_REPLY || op == MS_OP_BIND) {
+            want_delay = true;                             // net/mod.rs:306,457 rand_delay first
+        } else if (op == MS_OP_SLEEP || op == MS_OP_SLEEP_UNTIL) {
+            uint64_t base = L.clock;
+            if (op == MS_OP_SLEEP_UNTIL) { uint4 u2 = TU(c, slot, 2); base = u64of(u2.x, u2.y); }
+            deadline = sleep_deadline(L, base + (uint64_t)b * NS_PER_S + imm);
+            want_sleep = true;
         } else {
-            deadline = ((uint64_t)TW(c, slot, TW_DL_HI) << 32) | TW(c, slot, TW_DL_LO);
+            // ---- everything else: rare, control-plane ops ----
+            switch (op) {
+            case MS_OP_DONE:
+                u0.y = pc | (sub << 16) | (from << 24);
+                TU(c, slot, 0) = u0;
+                if (u1_dirty) { TU(c, slot, 1) = u1; u1_dirty = false; }
+                task_finish(c, L, slot, H_COMPLETED);
+                u0.x = TWORD(c, slot, 0, 0);
+                finished = true;
+                break;
+            case MS_OP_SPAWN:
+                spawn_task(c, L, a, true);
+                pc++;
+                break;
+            case MS_OP_BUILD:
+                for (uint32_t p = 1; p < P.n_progs; p++) {
+                    uint32_t pw = c.prog[p];
+                    if ((pw & 0xff) == a && ((pw >> 8) & MADSIM_PROG_INIT) && !((pw >> 8) & MADSIM_PROG_PRE)) spawn_task(c, L, p, false);
+                }
+                pc++;
+                break;
+            case MS_OP_JOIN: {                             // task/join.rs:59-72 + async-task poll_task
+                uint32_t h = W(c, P.off_handles + a);
+                uint32_t st = h & 3;
+                if (st == H_RUNNING) {
+                    uint32_t cs = (h >> 8) & 0xff;
+                    uint32_t link = TWORD(c, cs, 1, 0);
+                    TWORD(c, cs, 1, 0) = (link & 0xff) | (slot << 8) | (gen << 16);   // register awaiter
+                    pending = true;
+                } else if (st == H_NONE || ((st == H_CANCELLED) != ((b & 1) != 0))) {
+                    panicked = true;
+                } else {
+                    pc++;
+                }
+                break;
+            }
+            case MS_OP_YIELD:                              // [DEP tokio yield_now outside a runtime]
+                sub = 1;
+                u0.x |= TF_SCHED;                          // wake_by_ref while RUNNING
+                pending = true;
+                break;
+            case MS_OP_PANIC:
+                panicked = true;
+                break;
+            case MS_OP_MARK:
+                TU(c, slot, 2) = make_uint4((uint32_t)L.clock, (uint32_t)(L.clock >> 32), 0, 0);
+                pc++;
+                break;
+            case MS_OP_ASSERT_ELAPSED: {
+                uint4 u2 = TU(c, slot, 2);
+                uint64_t el = L.clock - u64of(u2.x, u2.y), d = (uint64_t)b * NS_PER_S + imm;
+                bool ok = a == 0 ? el == d : a == 1 ? el >= d : el < d;
+                if (!ok) panicked = true; else pc++;
+                break;
+            }
+            case MS_OP_ADVANCE:                            // time/mod.rs:103-106
+                L.clock += (uint64_t)b * NS_PER_S + imm;
+                pc++;
+                u0.y = pc | (sub << 16) | (from << 24);
+                TU(c, slot, 0) = u0;
+                if (u1_dirty) { TU(c, slot, 1) = u1; u1_dirty = false; }
+                timer_expire(c, L, L.clock);
+                u0 = TU(c, slot, 0); u1 = TU(c, slot, 1);
+                from = u0.y >> 24;
+                break;
+            case MS_OP_CLOSE: {
+                uint32_t h = SW(c, a, 0);
+                if ((h & 1) && SW(c, a, 1) == (slot | (gen << 16)) && !(u0.x & TF_KILLED)) SW(c, a, 0) = h & ~1u;
+                pc++;
+                break;
+            }
+            case MS_OP_CLOG_NODE:
+                if (b & 1) W(c, P.off_clog + 0) |= 1u << a;
+                if (b & 2) W(c, P.off_clog + 1) |= 1u << a;
+                pc++;
+                break;
+            case MS_OP_UNCLOG_NODE:
+                if (b & 1) W(c, P.off_clog + 0) &= ~(1u << a);
+                if (b & 2) W(c, P.off_clog + 1) &= ~(1u << a);
+                pc++;
+                break;
+            case MS_OP_CLOG_LINK:
+                W(c, P.off_clog + 2 + a) |= 1u << b;
+                pc++;
+                break;
+            case MS_OP_UNCLOG_LINK:
+                W(c, P.off_clog + 2 + a) &= ~(1u << b);
+                pc++;
+                break;
+            case MS_OP_SET_LOSS:
+                L.loss_pint = P.loss_table_pint[a & 3];
+                L.loss_always = P.loss_table_always[a & 3];
+                pc++;
+                break;
+            default:
+                panicked = true;
+                break;
+            }
         }
-        if (L.clock < deadline) {                            // Sleep::poll: register ANOTHER timer
+        if (want_delay) {                                  // NetSim::rand_delay (net/mod.rs:287-292)
+            uint64_t delay = (uint64_t)gen_range_small<TRACE, 5>(c, L) * 1000ull;
+            if (P.buggify) {
+                if (gen_bool_pint<TRACE>(c, L, P.bug_pint, 0)) delay = (uint64_t)(1 + gen_range_small<TRACE, 4>(c, L)) * NS_PER_S;
+            }
+            deadline = sleep_deadline(L, L.clock + delay);
+            want_sleep = true;
+        }
+        if (want_sleep) {                                  // first Sleep::poll: never elapsed (1 ms floor)
+            u1.z = (uint32_t)deadline; u1.w = (uint32_t)(deadline >> 32); u1_dirty = true;
+            sub = (op == MS_OP_RECV) ? 3 : 1;
             if (!timer_add(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.verdict = MADSIM_OVERFLOW;
             pending = true;
-            continue;
         }
-        // the Sleep is Ready: finish the op
-        sub = 0;
-        if (op == MS_OP_BIND) {                              // Network::bind (network.rs:206-251)
-            uint32_t sw = c.sock[a];
-            if ((sw & 0xff) != node || find_bound(c, sw & 0xff, sw >> 16) >= 0) { panicked = true; continue; }
-            uint32_t h = SW(c, a, 0);
-            SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);   // bound, gen+1, empty mailbox
-            SW(c, a, 1) = slot | (gen << 16);
-        } else if (op == MS_OP_SEND || op == MS_OP_REPLY) {  // net/mod.rs:307-331, network.rs:296-313
-            uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : from;
-            uint32_t src_node = c.sock[a] & 0xff;
-            uint32_t dw = c.sock[dst];
-            uint32_t dst_node = dw & 0xff;
-            bool clogged = ((W(c, P.off_clog + 1) >> src_node) & 1) | ((W(c, P.off_clog + 0) >> dst_node) & 1);
-            if (P.has_clog_link) clogged |= (W(c, P.off_clog + 2 + src_node) >> dst_node) & 1;
-            if (!clogged && !gen_bool_pint<TRACE>(c, L, L.loss_pint, L.loss_always)) {   // test_link :261-269
-                L.msg_count++;
-                uint64_t lat = sample_latency<TRACE>(c, L);
-                int ds = find_bound(c, dst_node, dw >> 16);
-                if (ds >= 0) {
-                    uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
-                    uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((b >> 8) << 12) | (a << 6) | (uint32_t)ds;
-                    if (!timer_add(c, L, L.clock + lat, meta, imm)) L.verdict = MADSIM_OVERFLOW;
-                }
-            }
-        }
-        pc++;
     }
-    if (!finished) SAVE_PC();
-#undef SAVE_PC
+    if (!finished) {
+        u0.y = pc | (sub << 16) | (from << 24);
+        if (u1_dirty) TU(c, slot, 1) = u1;
+    }
     return panicked;
 }
 
@@ -592,21 +636,17 @@ template <bool TRACE>
 __device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     const KParams& P = c.P;
     for (uint32_t w = 0; w < P.lane_words; w++) W(c, w) = 0;
+    for (uint32_t t = 0; t < P.max_tasks; t++) TWORD(c, t, 0, 0) = 0;
     // GlobalRng::new_with_seed -> Xoshiro256PlusPlus::seed_from_u64: SplitMix64 [DEP A.1]
-    uint64_t x = seed, s[4];
-    for (int i = 0; i < 4; i++) {
-        x += 0x9e3779b97f4a7c15ull;
-        uint64_t z = x;
-        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-        s[i] = z ^ (z >> 31);
-    }
-    L.s0 = s[0]; L.s1 = s[1]; L.s2 = s[2]; L.s3 = s[3];
+    uint64_t x = seed, z;
+#define SPLITMIX(dst) x += 0x9e3779b97f4a7c15ull; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; dst = z ^ (z >> 31)
+    SPLITMIX(L.s0); SPLITMIX(L.s1); SPLITMIX(L.s2); SPLITMIX(L.s3);
+#undef SPLITMIX
     L.rng_calls = 0; L.clock = 0; L.msg_count = 0; L.steps = 0;
-    L.ready_len = 0; L.heap_len = 0; L.verdict = MADSIM_RUNNING;
+    L.ready_len = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING;
     L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
     // TimeRuntime::new (time/mod.rs:26-38): base_time draw, before logging is enabled
-    (void)gen_range_const<false, 31536000ull>(c, L, 0);
+    (void)gen_range_small<false, 31536000u>(c, L);
     L.trace_hash = FNV_OFFSET; L.obs_hash = FNV_OFFSET; L.log_len = 0;
     // tasks spawned before block_on, then the main task (task/mod.rs:222-235)
     for (uint32_t p = 1; p < P.n_progs; p++) {
@@ -641,6 +681,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
     c.prog = sh + P.sh_progs;
     c.sock = sh + P.sh_socks;
     c.heap = (uint4*)(sh + P.sh_heap) + lane;
+    c.tasks = (uint4*)(sh + P.sh_tasks) + lane;
     c.lds = sh + P.sh_planes + lane;
     const uint32_t glane = blockIdx.x * 64 + lane;
     c.spill = P.spill ? P.spill + glane : nullptr;
@@ -655,50 +696,56 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
             seed_init<TRACE>(c, L, P.seed0 + next);
             have = true;
         }
-        // ---- Executor::block_on loop body (task/mod.rs:239-259), one executor step per iteration
-        uint64_t expire_to;
-        bool idle = false;
-        if (L.ready_len > 0) {
-            // try_recv_random (utils/mpsc.rs:73-83)
-            uint32_t idx = (uint32_t)gen_range_u64<TRACE>(c, L, 0, L.ready_len);
+        // One iteration = the block_on loop body (task/mod.rs:239-259) taken as
+        //   [idle]  ready queue empty: is_finished / deadlock checks, advance_to_next_event
+        //   [poll]  ready queue non-empty: one run_all_ready iteration
+        // in that order, so a lane that was idle fires its timer AND polls the woken task in the same
+        // pass: all lanes of the wave walk the same two phases.
+
+        // ---------------- [idle] ----------------
+        if (L.ready_len == 0) {
+            uint32_t h0 = W(c, P.off_handles + 0);
+            if ((h0 & 3) != H_RUNNING) L.verdict = MADSIM_PASS;                       // :241-243
+            else if (L.heap_len == 0) L.verdict = MADSIM_DEADLOCK;                    // :250
+            else {
+                uint64_t t = L.top_dl + 50;                                           // time/mod.rs:47-53
+                timer_expire(c, L, t);
+                L.clock = t;                                                          // :55, after the callbacks
+                if (L.verdict == MADSIM_RUNNING) {
+                    if (P.time_limit && L.clock >= P.time_limit) L.verdict = MADSIM_TIME_LIMIT;   // task/mod.rs:253-258
+                    else if (L.steps >= P.max_steps) L.verdict = MADSIM_STEP_LIMIT;
+                }
+            }
+        }
+        // ---------------- [poll] ----------------
+        if (L.verdict == MADSIM_RUNNING && L.ready_len > 0) {
+            // try_recv_random (utils/mpsc.rs:73-83): idx drawn even when len == 1
+            uint32_t idx = gen_index<TRACE>(c, L, L.ready_len);
             uint32_t slot = W(c, P.off_ready + idx);
             L.ready_len--;
             W(c, P.off_ready + idx) = W(c, P.off_ready + L.ready_len);   // swap_remove
-            uint32_t f = TW(c, slot, TW_FLAGS);
+            uint4 u0 = TU(c, slot, 0);
             L.steps++;
             bool panicked = false;
-            if (f & (TF_CANCEL | TF_KILLED)) {               // task/mod.rs:269-273
+            if (u0.x & (TF_CANCEL | TF_KILLED)) {            // task/mod.rs:269-273: drop(runnable)
                 task_finish(c, L, slot, H_CANCELLED);
             } else {
-                TW(c, slot, TW_FLAGS) = (f & ~TF_SCHED) | TF_RUN;
-                panicked = poll_task<TRACE>(c, L, slot);
-                f = TW(c, slot, TW_FLAGS);
-                if (!panicked && (f & TF_ALIVE)) {
-                    TW(c, slot, TW_FLAGS) = f & ~TF_RUN;
-                    if (f & TF_SCHED) { if (!ready_push(c, L, slot)) L.verdict = MADSIM_OVERFLOW; }
+                u0.x = (u0.x & ~TF_SCHED) | TF_RUN;          // async-task run(): SCHEDULED -> RUNNING
+                panicked = poll_task<TRACE>(c, L, slot, u0);
+                if (!panicked && (u0.x & TF_ALIVE)) {
+                    if (u0.x & TF_SCHED) ready_push(c, L, slot);   // woken while running: re-queue after the poll
+                    u0.x &= ~TF_RUN;
+                    TU(c, slot, 0) = u0;
                 }
             }
             if (panicked) {
-                if (L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_PANIC;
-            } else {
-                // task/mod.rs:319-321: advance 50..100 ns, then Timer::expire
-                L.clock += gen_range_const<TRACE, 50>(c, L, 50);
+                if (L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_PANIC;   // resume_unwind (:315)
+            } else if (L.verdict == MADSIM_RUNNING) {
+                // task/mod.rs:319-321: advance 50..100 ns, then Timer::expire (time/mod.rs:103-106)
+                L.clock += 50 + gen_range_small<TRACE, 50>(c, L);
+                timer_expire(c, L, L.clock);
+                if (L.steps >= P.max_steps && L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_STEP_LIMIT;
             }
-            expire_to = L.clock;
-        } else {
-            idle = true;
-            uint32_t h0 = W(c, P.off_handles + 0);
-            if ((h0 & 3) != H_RUNNING) { L.verdict = MADSIM_PASS; expire_to = 0; }            // :241-243
-            else if (L.heap_len == 0) { L.verdict = MADSIM_DEADLOCK; expire_to = 0; }         // :250
-            else expire_to = ev_deadline(heap_get(c, 0)) + 50;                                  // time/mod.rs:47-53
-        }
-        if (L.verdict == MADSIM_RUNNING) {
-            timer_expire(c, L, expire_to);
-            if (idle) {
-                L.clock = expire_to;                          // time/mod.rs:55 (after the callbacks)
-                if (P.time_limit && L.clock >= P.time_limit && L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_TIME_LIMIT;
-            }
-            if (L.steps >= P.max_steps && L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_STEP_LIMIT;
         }
         if (L.verdict != MADSIM_RUNNING) {
             madsim_result_t r;
