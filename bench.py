@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--seeds", type=int, default=SEEDS_PER_GPU, help="seeds per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lpw", type=int, default=0, help="seed-carrying lanes per wave (0 = library auto)")
     args = ap.parse_args()
 
     import torch
@@ -55,8 +56,9 @@ def main():
 
     w = workload.pingpong(N_NODES, ROUNDS)
     lim = A.Limits()
-    lim.heap_lds_slots, lim.heap_spill_slots = 8, 8
+    lim.heap_lds_slots, lim.heap_spill_slots = 8, 0      # pingpong needs <= 4 timers; overflow would be a verdict
     lim.mbox_regs, lim.mbox_msgs = 1, 1
+    lim.lanes_per_wave = args.lpw
     per_gpu = args.seeds
     total = per_gpu * world
     seed0, count = mdist.shard_range(0, total, rank, world)
@@ -111,7 +113,8 @@ def main():
                        "seeds_per_step": total, "parallelism": f"seed-shard x{world}"},
             "extra": {"seeds_per_sec": seeds_total / dt, "executor_steps_per_sec": steps_total / dt,
                       "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms,
-                      "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu},
+                      "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu,
+                      "lanes_per_wave": g.lanes_per_wave},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "sim_kernel<false>", "algorithmic_bytes_per_launch": algo_bytes,

@@ -158,7 +158,7 @@ typedef struct madsim_limits {
     uint32_t max_tasks;          /* live task instances per seed; 0 = auto (n_progs + restarts)      */
     uint32_t mbox_regs;          /* pending recv registrations per socket; 0 = auto (2)              */
     uint32_t mbox_msgs;          /* undelivered messages per socket; 0 = auto (4)                    */
-    uint32_t reserved;
+    uint32_t lanes_per_wave;     /* seeds carried per 64-lane wave (8/16/32/64); 0 = auto            */
 } madsim_limits_t;
 
 /* ------------------------------------------------------------------------------------------------
@@ -243,6 +243,8 @@ typedef struct madsim_geometry {
     uint32_t heap_lds_slots;
     uint32_t heap_spill_slots;
     uint32_t max_tasks;
+    uint32_t lanes_per_wave;
+    uint32_t reserved;
 } madsim_geometry_t;
 int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* g);
 

@@ -59,7 +59,7 @@ class Limits(C.Structure):
     _fields_ = [
         ("time_limit_ns", C.c_uint64), ("max_steps", C.c_uint32), ("heap_lds_slots", C.c_uint32),
         ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32), ("mbox_regs", C.c_uint32),
-        ("mbox_msgs", C.c_uint32), ("reserved", C.c_uint32),
+        ("mbox_msgs", C.c_uint32), ("lanes_per_wave", C.c_uint32),
     ]
 
 
@@ -85,7 +85,8 @@ class Geometry(C.Structure):
     _fields_ = [
         ("lds_bytes_per_seed", C.c_uint32), ("lds_bytes_per_block", C.c_uint32), ("block_threads", C.c_uint32),
         ("blocks_per_cu", C.c_uint32), ("grid_blocks", C.c_uint32), ("heap_lds_slots", C.c_uint32),
-        ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32),
+        ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32), ("lanes_per_wave", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -18,7 +18,7 @@ inline int fail(std::string* err, int code, const std::string& msg) { if (err) *
 
 struct Geo {
     KParams P;
-    uint32_t lds_bytes, lds_per_seed, blocks_per_cu, grid;
+    uint32_t lds_bytes, lds_per_seed, blocks_per_cu, grid, lanes_per_wave;
 };
 
 inline bool uses_op(const madsim_workload_t* w, int op) {
@@ -122,19 +122,34 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.sh_progs = P.sh_insns + 2 * P.n_insns;
     P.sh_socks = P.sh_progs + P.n_progs;
     P.sh_heap = (P.sh_socks + P.n_socks + 3) & ~3u;
-    P.sh_tasks = P.sh_heap + P.heap_lds * 64 * 4;
-    P.sh_planes = P.sh_tasks + P.max_tasks * P.task_units * 64 * 4;
+    const uint32_t sh_bytes = P.sh_heap * 4;
     G->lds_per_seed = P.heap_lds * 16 + P.max_tasks * P.task_units * 16 + P.lane_words * 4;
-    G->lds_bytes = (P.sh_planes + P.lane_words * 64) * 4;
+    if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
+    // Lanes per wave (lw): how many of a wave's 64 lanes carry a seed.  Measured on MI355X (4-node
+    // ping-pong, 65 536 seeds, profiles/r1_lanes_per_wave.md): every wave-instruction costs the SIMD
+    // ~4 cycles whatever the number of active lanes, and at 16 lanes/wave the VALU pipe is already
+    // ~98 % busy, so trading lanes for more waves loses (64: 5.36 ms, 32: 6.08, 16: 8.32, 8: 16.7).
+    // Full waves are the default; the knob stays for experiments (madsim_limits_t.lanes_per_wave).
+    const uint32_t cus = g.num_cus > 0 ? (uint32_t)g.num_cus : 256u;
+    uint32_t lw = 64;
+    if (L.lanes_per_wave) {
+        lw = L.lanes_per_wave;
+        if (lw != 8 && lw != 16 && lw != 32 && lw != 64) return fail(err, MADSIM_E_LIMITS, "lanes_per_wave must be 8, 16, 32 or 64");
+    }
+    P.lw_shift = lw == 8 ? 3 : lw == 16 ? 4 : lw == 32 ? 5 : 6;
+    P.sh_tasks = P.sh_heap + P.heap_lds * lw * 4;
+    P.sh_planes = P.sh_tasks + P.max_tasks * P.task_units * lw * 4;
+    G->lds_bytes = (P.sh_planes + P.lane_words * lw) * 4;
     if (G->lds_bytes > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-workgroup LDS exceeds 160 KiB: lower heap_lds_slots / mailbox capacities");
     uint32_t by_lds = (uint32_t)(g.lds_per_cu / G->lds_bytes);
     uint32_t bpc = by_lds < 16 ? by_lds : 16;          // VGPR budget admits 4 waves/SIMD = 16 one-wave workgroups per CU
     G->blocks_per_cu = bpc;
-    uint64_t want = (count + 63) / 64;
-    uint64_t resident = (uint64_t)bpc * (uint64_t)g.num_cus;
+    G->lanes_per_wave = lw;
+    uint64_t want = (count + lw - 1) / lw;
+    uint64_t resident = (uint64_t)bpc * cus;
     G->grid = (uint32_t)(want < resident ? want : resident);
     if (G->grid == 0) G->grid = 1;
-    P.total_lanes = G->grid * 64;
+    P.total_lanes = G->grid * lw;
     return 0;
 }
 

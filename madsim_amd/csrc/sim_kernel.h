@@ -25,6 +25,7 @@ struct KParams {
     // capacities
     uint32_t heap_lds, heap_spill, max_tasks, mbox_regs, mbox_msgs;
     uint32_t task_units, sock_words, lane_words, uniq_addr;
+    uint32_t lw_shift;         // log2(seed-carrying lanes per wave): lane stride of every per-lane LDS array
     // LDS layout, in 32-bit words: workgroup-shared tables, heap units and task units (16-byte
     // aligned, [unit][lane]), then the 32-bit planes ([word][lane])
     uint32_t sh_insns, sh_progs, sh_socks, sh_heap, sh_tasks, sh_planes;

@@ -14,6 +14,7 @@
 // Data placement (per seed):
 //   VGPRs : xoshiro256++ state (4 x u64), clock, counters, hashes, queue lengths.
 //   LDS   : timer heap (16-byte entries, [slot][lane] => ds_read/write_b128, conflict-free),
+//           lane stride = lw, the number of seed-carrying lanes per wave (8..64, see geometry.h),
 //           task table, ready queue, mailboxes, handles, node/clog masks — all as 32-bit
 //           "word planes" [word][lane] so that any per-lane dynamic index hits bank = lane % 32.
 //           The workload tables (instructions, programs, socket addresses) sit once per
@@ -47,6 +48,11 @@ enum : uint32_t { TF_ALIVE = 1, TF_SCHED = 2, TF_RUN = 4, TF_KILLED = 8, TF_CANC
 enum : uint32_t { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3 };
 enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 
+// Compile-time kernel variant: TRACE = also emit the raw determinism log (single-seed trace mode);
+// SPILL = the timer heap may overflow from LDS into the HBM spill region.
+template <bool TRACE_, bool SPILL_> struct Variant { static constexpr bool TRACE = TRACE_, SPILL = SPILL_; };
+struct NoTrace { static constexpr bool TRACE = false, SPILL = false; };
+
 struct Lane {
     // GlobalRng
     uint64_t s0, s1, s2, s3;
@@ -69,23 +75,38 @@ struct Lane {
     uint32_t loss_always;
 };
 
+// All LDS traffic goes through the workgroup's one `extern __shared__` array, indexed by per-lane
+// offsets held in VGPRs: the compiler then knows every access is LDS (ds_read/ds_write) — pointer
+// members that may alias the HBM spill region degrade to flat_* instructions.
+#ifdef MADSIM_EMU
+#define SMEM emu_smem
+#else
+extern __shared__ __attribute__((aligned(16))) uint32_t madsim_smem[];
+#define SMEM madsim_smem
+#endif
+#define LDS128(i) (reinterpret_cast<uint4*>(SMEM)[(i)])
+#define LDS64(i) (reinterpret_cast<uint2*>(SMEM)[(i)])
+
 struct Ctx {
     const KParams& P;
-    uint32_t* lds;       // per-lane plane base: word w of this lane = lds[w * 64]
-    uint4* heap;         // heap[i * 64]
-    uint4* tasks;        // tasks[(slot * task_units + u) * 64]
-    const uint2* insn;   // workgroup-shared tables in LDS
-    const uint32_t* prog;
-    const uint32_t* sock;
+    uint32_t pl;         // word index of this lane's plane 0: word w = SMEM[pl + w * 64]
+    uint32_t sock0;      // word index of this lane's socket region
+    uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + i * 64)
+    uint32_t task0;      // uint4 index of task unit 0: unit (slot,u) = LDS128(task0 + (slot * task_units + u) * 64)
+    uint32_t insn0;      // uint2 index of the workgroup-shared instruction table
+    uint32_t prog0, sockt0;   // word indices of the shared prog / socket-address tables
     uint4* spill;        // this lane's column of the HBM spill region, stride P.total_lanes
     uint8_t* tlog;       // trace mode only
     __device__ Ctx(const KParams& p) : P(p) {}
 };
 
-__device__ __forceinline__ uint32_t& W(const Ctx& c, uint32_t w) { return c.lds[w * 64]; }
-__device__ __forceinline__ uint32_t& SW(const Ctx& c, uint32_t s, uint32_t f) { return c.lds[(c.P.off_socks + s * c.P.sock_words + f) * 64]; }
-__device__ __forceinline__ uint4& TU(const Ctx& c, uint32_t slot, uint32_t u) { return c.tasks[(slot * c.P.task_units + u) * 64]; }
-__device__ __forceinline__ uint32_t& TWORD(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) { return ((uint32_t*)&c.tasks[(slot * c.P.task_units + u) * 64])[k]; }
+__device__ __forceinline__ uint32_t& W(const Ctx& c, uint32_t w) { return SMEM[c.pl + (w << c.P.lw_shift)]; }
+__device__ __forceinline__ uint32_t& SW(const Ctx& c, uint32_t s, uint32_t f) { return SMEM[c.sock0 + ((s * c.P.sock_words + f) << c.P.lw_shift)]; }
+__device__ __forceinline__ uint4& TU(const Ctx& c, uint32_t slot, uint32_t u) { return LDS128(c.task0 + ((slot * c.P.task_units + u) << c.P.lw_shift)); }
+__device__ __forceinline__ uint32_t& TWORD(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) { return SMEM[(c.task0 + ((slot * c.P.task_units + u) << c.P.lw_shift)) * 4 + k]; }
+__device__ __forceinline__ uint2 INSN(const Ctx& c, uint32_t pc) { return LDS64(c.insn0 + pc); }
+__device__ __forceinline__ uint32_t PROGW(const Ctx& c, uint32_t p) { return SMEM[c.prog0 + p]; }
+__device__ __forceinline__ uint32_t SOCKW(const Ctx& c, uint32_t s) { return SMEM[c.sockt0 + s]; }
 
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
@@ -103,7 +124,7 @@ __device__ __forceinline__ uint64_t rng_next(Lane& L) {
 }
 
 // One determinism-log byte per GlobalRng::with (rand.rs:64-88): clone.gen::<u8>() ^ xor-fold(elapsed).
-template <bool TRACE>
+template <class K>
 __device__ __forceinline__ void rng_log(const Ctx& c, Lane& L) {
     uint64_t r = rotl64(L.s0 + L.s3, 23) + L.s0;   // what the clone's next_u64 would return
     uint32_t v = (uint32_t)(r >> 32);
@@ -111,75 +132,59 @@ __device__ __forceinline__ void rng_log(const Ctx& c, Lane& L) {
     f ^= f >> 16; f ^= f >> 8;
     v = (v ^ f) & 0xff;
     L.trace_hash = (L.trace_hash ^ v) * FNV_PRIME;
-    if (TRACE) { if (L.log_len < c.P.trace_cap) c.tlog[L.log_len] = (uint8_t)v; }
+    if (K::TRACE) { if (L.log_len < c.P.trace_cap) c.tlog[L.log_len] = (uint8_t)v; }
     L.log_len++;
 }
 
 // gen_range(lo..hi) on u64 [DEP rand 0.8 UniformInt::sample_single_inclusive]; one with() per call.
-template <bool TRACE>
+template <class K>
 __device__ __forceinline__ uint64_t gen_range_u64(const Ctx& c, Lane& L, uint64_t lo, uint64_t range) {
     uint64_t zone = (range << __builtin_clzll(range)) - 1;
-    uint64_t res;
-    for (;;) {
-        uint64_t v = rng_next(L);
-        uint64_t mlo = v * range;
-        if (mlo <= zone) { res = lo + __umul64hi(v, range); break; }
-    }
-    rng_log<TRACE>(c, L);
-    return res;
+    uint64_t v;
+    do { v = rng_next(L); } while (v * range > zone);
+    rng_log<K>(c, L);
+    return lo + __umul64hi(v, range);
 }
 
 // ready-queue index draw: range = len <= 255, so the 128-bit product splits into two 32x32 pieces.
-template <bool TRACE>
+template <class K>
 __device__ __forceinline__ uint32_t gen_index(const Ctx& c, Lane& L, uint32_t len) {
     uint64_t zone = ((uint64_t)len << __builtin_clzll((uint64_t)len)) - 1;
-    uint32_t res;
-    for (;;) {
-        uint64_t v = rng_next(L);
-        uint64_t plo = (uint64_t)(uint32_t)v * len;            // < 2^40
-        uint64_t phi = (uint64_t)(uint32_t)(v >> 32) * len;    // < 2^40
-        uint64_t mid = phi + (plo >> 32);
-        uint64_t mlo = (mid << 32) | (uint32_t)plo;
-        if (mlo <= zone) { res = (uint32_t)(mid >> 32); break; }
-    }
-    rng_log<TRACE>(c, L);
-    return res;
+    uint64_t v;
+    do { v = rng_next(L); } while (v * (uint64_t)len > zone);   // accept test on the low 64 bits only
+    rng_log<K>(c, L);
+    uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * len + (((uint64_t)(uint32_t)v * len) >> 32);
+    return (uint32_t)(mid >> 32);                               // high 64 bits of v * len
 }
 
 // gen_range with a compile-time range < 2^32.
-template <bool TRACE, uint32_t RANGE>
+template <class K, uint32_t RANGE>
 __device__ __forceinline__ uint32_t gen_range_small(const Ctx& c, Lane& L) {
     constexpr uint64_t zone = ((uint64_t)RANGE << __builtin_clzll((uint64_t)RANGE)) - 1;
-    uint32_t res;
-    for (;;) {
-        uint64_t v = rng_next(L);
-        uint64_t plo = (uint64_t)(uint32_t)v * RANGE;
-        uint64_t phi = (uint64_t)(uint32_t)(v >> 32) * RANGE;
-        uint64_t mid = phi + (plo >> 32);
-        uint64_t mlo = (mid << 32) | (uint32_t)plo;
-        if (mlo <= zone) { res = (uint32_t)(mid >> 32); break; }
-    }
-    rng_log<TRACE>(c, L);
-    return res;
+    uint64_t v;
+    do { v = rng_next(L); } while (v * (uint64_t)RANGE > zone);
+    rng_log<K>(c, L);
+    uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * RANGE + (((uint64_t)(uint32_t)v * RANGE) >> 32);
+    return (uint32_t)(mid >> 32);
 }
 
 // gen_bool through GlobalRng's RngCore impl (rand.rs:142-158): one with() per draw [DEP Bernoulli].
-template <bool TRACE>
+template <class K>
 __device__ __forceinline__ bool gen_bool_pint(const Ctx& c, Lane& L, uint64_t p_int, uint32_t always) {
     if (always) return true;
     uint64_t v = rng_next(L);
-    rng_log<TRACE>(c, L);
+    rng_log<K>(c, L);
     return v < p_int;
 }
 
 // UniformDuration sample on the GlobalRng itself (network.rs:267): one with() per attempt [DEP A.3].
-template <bool TRACE>
+template <class K>
 __device__ __forceinline__ uint64_t sample_latency(const Ctx& c, Lane& L) {
     const KParams& P = c.P;
     uint64_t res;
     for (;;) {
         uint64_t v = rng_next(L);
-        rng_log<TRACE>(c, L);
+        rng_log<K>(c, L);
         if (P.lat_mode == 0) {
             uint64_t m = (uint64_t)(uint32_t)(v >> 32) * (uint64_t)(uint32_t)P.lat_range;
             if ((uint32_t)m <= (uint32_t)P.lat_zone) { res = P.lat_low + (m >> 32); break; }
@@ -195,61 +200,73 @@ __device__ __forceinline__ uint64_t sample_latency(const Ctx& c, Lane& L) {
 // entry: x = deadline lo, y = deadline hi, z = meta, w = payload value
 __device__ __forceinline__ uint64_t ev_deadline(const uint4& e) { return u64of(e.x, e.y); }
 
+// Entries [0, heap_lds) live in LDS; entries beyond spill to HBM as [slot][global lane] (coalesced
+// across the wave).  Variants without a spill region drop the HBM path.  The LDS load is issued
+// unconditionally (clamped index) and the HBM value selected afterwards, so the two address spaces
+// never merge into a flat_* access.
+template <class K>
 __device__ __forceinline__ uint4 heap_get(const Ctx& c, uint32_t i) {
-    if (i < c.P.heap_lds) return c.heap[i * 64];
-    return c.spill[(size_t)(i - c.P.heap_lds) * c.P.total_lanes];
+    if (!K::SPILL) return LDS128(c.heap0 + (i << c.P.lw_shift));
+    uint32_t cap = c.P.heap_lds;
+    uint4 v = LDS128(c.heap0 + ((i < cap ? i : cap - 1) << c.P.lw_shift));
+    if (i >= cap) v = c.spill[(size_t)(i - cap) * c.P.total_lanes];
+    return v;
 }
+template <class K>
 __device__ __forceinline__ void heap_set(const Ctx& c, uint32_t i, const uint4& e) {
-    if (i < c.P.heap_lds) c.heap[i * 64] = e;
+    if (!K::SPILL || i < c.P.heap_lds) LDS128(c.heap0 + (i << c.P.lw_shift)) = e;
     else c.spill[(size_t)(i - c.P.heap_lds) * c.P.total_lanes] = e;
 }
 
 // BinaryHeap::sift_up(0, pos) with `hole` as the moving element; keeps the root mirror current.
+template <class K>
 __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos, const uint4& hole) {
     uint64_t hd = ev_deadline(hole);
     while (pos > 0) {
         uint32_t parent = (pos - 1) >> 1;
-        uint4 p = heap_get(c, parent);
+        uint4 p = heap_get<K>(c, parent);
         if (hd >= ev_deadline(p)) break;     // hole <= parent in heap order: stop
-        heap_set(c, pos, p);
+        heap_set<K>(c, pos, p);
         pos = parent;
     }
-    heap_set(c, pos, hole);
+    heap_set<K>(c, pos, hole);
     if (pos == 0) L.top_dl = hd;
 }
 
 // Timer::add -> BinaryHeap::push.  Returns false on capacity overflow.
+template <class K>
 __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val) {
-    if (L.heap_len >= c.P.heap_lds + c.P.heap_spill) return false;
+    if (L.heap_len >= c.P.heap_lds + (K::SPILL ? c.P.heap_spill : 0u)) return false;
     uint4 e = make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, val);
-    heap_sift_up(c, L, L.heap_len, e);
+    heap_sift_up<K>(c, L, L.heap_len, e);
     L.heap_len++;
     return true;
 }
 
 // BinaryHeap::pop: swap the last element into the root, sift_down_to_bottom(0), then sift_up.
+template <class K>
 __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
     uint32_t end = --L.heap_len;
-    uint4 item = heap_get(c, end);
+    uint4 item = heap_get<K>(c, end);
     if (end > 0) {
-        uint4 top = heap_get(c, 0);
+        uint4 top = heap_get<K>(c, 0);
         uint32_t pos = 0, child = 1;
         while (child + 1 < end) {
-            uint4 l = heap_get(c, child), r = heap_get(c, child + 1);
+            uint4 l = heap_get<K>(c, child), r = heap_get<K>(c, child + 1);
             bool right = ev_deadline(l) >= ev_deadline(r);   // left <= right in heap order: take right
             uint4 m = right ? r : l;
-            heap_set(c, pos, m);
+            heap_set<K>(c, pos, m);
             if (pos == 0) L.top_dl = ev_deadline(m);
             pos = child + (right ? 1u : 0u);
             child = 2 * pos + 1;
         }
         if (child == end - 1) {
-            uint4 m = heap_get(c, child);
-            heap_set(c, pos, m);
+            uint4 m = heap_get<K>(c, child);
+            heap_set<K>(c, pos, m);
             if (pos == 0) L.top_dl = ev_deadline(m);
             pos = child;
         }
-        heap_sift_up(c, L, pos, item);
+        heap_sift_up<K>(c, L, pos, item);
         item = top;
     } else {
         L.top_dl = ~0ull;
@@ -277,9 +294,9 @@ __device__ __forceinline__ void wake(const Ctx& c, Lane& L, uint32_t slot, uint3
 // Network::try_send's socket lookup (network.rs:304-306): the bound socket at addr(dst), if any.
 __device__ __forceinline__ int find_bound(const Ctx& c, uint32_t addr) {
     if (c.P.uniq_addr) return (SW(c, addr, 0) & 1) ? (int)addr : -1;
-    uint32_t key = c.sock[addr] & 0xffff00ffu;
+    uint32_t key = SOCKW(c, addr) & 0xffff00ffu;
     for (uint32_t i = 0; i < c.P.n_socks; i++)
-        if ((c.sock[i] & 0xffff00ffu) == key && (SW(c, i, 0) & 1)) return (int)i;
+        if ((SOCKW(c, i) & 0xffff00ffu) == key && (SW(c, i, 0) & 1)) return (int)i;
     return -1;
 }
 
@@ -321,9 +338,10 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
 }
 
 // Timer::expire [DEP A.5]: fire every entry with deadline <= now
+template <class K>
 __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now) {
     while (L.top_dl <= now && L.verdict == MADSIM_RUNNING) {
-        uint4 e = timer_pop(c, L);
+        uint4 e = timer_pop<K>(c, L);
         L.steps++;
         uint32_t kind = e.z >> 28;
         if (kind == EV_WAKE) wake(c, L, e.z & 0xff, (e.z >> 8) & 0xffff);   // time/sleep.rs:52
@@ -337,7 +355,7 @@ __device__ __forceinline__ void spawn_task(const Ctx& c, Lane& L, uint32_t prog,
     while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
     if (slot >= c.P.max_tasks) { L.verdict = MADSIM_OVERFLOW; return; }
     uint32_t gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
-    uint32_t pw = c.prog[prog];
+    uint32_t pw = PROGW(c, prog);
     uint32_t node = pw & 0xff;
     uint32_t killed = (W(c, c.P.off_nodes) >> node) & 1;
     TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
@@ -382,19 +400,19 @@ __device__ __forceinline__ bool is_light(uint32_t op) {
 // In steady state every poll is exactly one round, and all lanes walk A -> B -> C together, so the
 // expensive primitives (RNG draws, heap pushes, link test, mailbox scan) sit at fixed points that the
 // whole wave reaches at the same time.
-template <bool TRACE>
+template <class K>
 __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t slot, uint4& u0) {
     const KParams& P = c.P;
     uint4 u1 = TU(c, slot, 1);
     bool u1_dirty = false;
     uint32_t pc = u0.y & 0xffff, sub = (u0.y >> 16) & 0xff, from = u0.y >> 24;
     const uint32_t gen = (u0.x >> 8) & 0xffff;
-    const uint32_t node = c.prog[u0.x >> 24] & 0xff;
+    const uint32_t node = PROGW(c, u0.x >> 24) & 0xff;
     bool panicked = false, pending = false, finished = false;
 
     while (!pending && !finished && !panicked && L.verdict == MADSIM_RUNNING) {
         if (pc >= P.n_insns) { panicked = true; break; }
-        uint2 in = c.insn[pc];
+        uint2 in = INSN(c, pc);
         uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
 
         // ================= [A] the task is parked on an await of this op =========================
@@ -410,32 +428,32 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             } else {                                       // a Sleep (time/sleep.rs:47-54)
                 uint64_t deadline = u64of(u1.z, u1.w);
                 if (L.clock < deadline) {                  // not elapsed: register ANOTHER timer
-                    if (!timer_add(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.verdict = MADSIM_OVERFLOW;
+                    if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.verdict = MADSIM_OVERFLOW;
                     pending = true;
                     break;
                 }
                 sub = 0;
                 if (op == MS_OP_BIND) {                    // Network::bind (network.rs:206-251)
-                    uint32_t sw = c.sock[a];
+                    uint32_t sw = SOCKW(c, a);
                     if ((sw & 0xff) != node || find_bound(c, a) >= 0) { panicked = true; break; }
                     uint32_t h = SW(c, a, 0);
                     SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);     // bound, gen+1, empty mailbox
                     SW(c, a, 1) = slot | (gen << 16);
                 } else if (op == MS_OP_SEND || op == MS_OP_REPLY) {        // net/mod.rs:307-331
                     uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : from;
-                    uint32_t src_node = c.sock[a] & 0xff;
-                    uint32_t dst_node = c.sock[dst] & 0xff;
+                    uint32_t src_node = SOCKW(c, a) & 0xff;
+                    uint32_t dst_node = SOCKW(c, dst) & 0xff;
                     // Network::try_send -> test_link (network.rs:261-269, 296-313)
                     bool clogged = ((W(c, P.off_clog + 1) >> src_node) & 1) | ((W(c, P.off_clog + 0) >> dst_node) & 1);
                     if (P.has_clog_link) clogged |= (W(c, P.off_clog + 2 + src_node) >> dst_node) & 1;
-                    if (!clogged && !gen_bool_pint<TRACE>(c, L, L.loss_pint, L.loss_always)) {
+                    if (!clogged && !gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) {
                         L.msg_count++;
-                        uint64_t lat = sample_latency<TRACE>(c, L);
+                        uint64_t lat = sample_latency<K>(c, L);
                         int ds = find_bound(c, dst);
                         if (ds >= 0) {
                             uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
                             uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((b >> 8) << 12) | (a << 6) | (uint32_t)ds;
-                            if (!timer_add(c, L, L.clock + lat, meta, imm)) L.verdict = MADSIM_OVERFLOW;
+                            if (!timer_add<K>(c, L, L.clock + lat, meta, imm)) L.verdict = MADSIM_OVERFLOW;
                         }
                     }
                 }
@@ -466,7 +484,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 pc++;
             }
             if (pc >= P.n_insns) { panicked = true; break; }
-            in = c.insn[pc];
+            in = INSN(c, pc);
             op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
         }
         if (panicked) break;
@@ -526,7 +544,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             case MS_OP_BUILD:
                 for (uint32_t p = 1; p < P.n_progs; p++) {
-                    uint32_t pw = c.prog[p];
+                    uint32_t pw = PROGW(c, p);
                     if ((pw & 0xff) == a && ((pw >> 8) & MADSIM_PROG_INIT) && !((pw >> 8) & MADSIM_PROG_PRE)) spawn_task(c, L, p, false);
                 }
                 pc++;
@@ -571,7 +589,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.y = pc | (sub << 16) | (from << 24);
                 TU(c, slot, 0) = u0;
                 if (u1_dirty) { TU(c, slot, 1) = u1; u1_dirty = false; }
-                timer_expire(c, L, L.clock);
+                timer_expire<K>(c, L, L.clock);
                 u0 = TU(c, slot, 0); u1 = TU(c, slot, 1);
                 from = u0.y >> 24;
                 break;
@@ -610,9 +628,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             }
         }
         if (want_delay) {                                  // NetSim::rand_delay (net/mod.rs:287-292)
-            uint64_t delay = (uint64_t)gen_range_small<TRACE, 5>(c, L) * 1000ull;
+            uint64_t delay = (uint64_t)gen_range_small<K, 5>(c, L) * 1000ull;
             if (P.buggify) {
-                if (gen_bool_pint<TRACE>(c, L, P.bug_pint, 0)) delay = (uint64_t)(1 + gen_range_small<TRACE, 4>(c, L)) * NS_PER_S;
+                if (gen_bool_pint<K>(c, L, P.bug_pint, 0)) delay = (uint64_t)(1 + gen_range_small<K, 4>(c, L)) * NS_PER_S;
             }
             deadline = sleep_deadline(L, L.clock + delay);
             want_sleep = true;
@@ -620,7 +638,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (want_sleep) {                                  // first Sleep::poll: never elapsed (1 ms floor)
             u1.z = (uint32_t)deadline; u1.w = (uint32_t)(deadline >> 32); u1_dirty = true;
             sub = (op == MS_OP_RECV) ? 3 : 1;
-            if (!timer_add(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.verdict = MADSIM_OVERFLOW;
+            if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.verdict = MADSIM_OVERFLOW;
             pending = true;
         }
     }
@@ -632,7 +650,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
 }
 
 // ---- per-seed init: Runtime::with_seed_and_config (runtime/mod.rs:53-69) ------------------------
-template <bool TRACE>
+template <class K>
 __device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     const KParams& P = c.P;
     for (uint32_t w = 0; w < P.lane_words; w++) W(c, w) = 0;
@@ -646,26 +664,21 @@ __device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     L.ready_len = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING;
     L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
     // TimeRuntime::new (time/mod.rs:26-38): base_time draw, before logging is enabled
-    (void)gen_range_small<false, 31536000u>(c, L);
+    (void)gen_range_small<NoTrace, 31536000u>(c, L);
     L.trace_hash = FNV_OFFSET; L.obs_hash = FNV_OFFSET; L.log_len = 0;
     // tasks spawned before block_on, then the main task (task/mod.rs:222-235)
     for (uint32_t p = 1; p < P.n_progs; p++) {
-        uint32_t fl = (c.prog[p] >> 8) & 0xff;
+        uint32_t fl = (PROGW(c, p) >> 8) & 0xff;
         if (fl & MADSIM_PROG_PRE) spawn_task(c, L, p, !(fl & MADSIM_PROG_INIT));
     }
     spawn_task(c, L, 0, true);
 }
 
-template <bool TRACE>
+template <class K>
 __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
-#ifdef MADSIM_EMU
-    uint32_t* smem = emu_smem;
-#else
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-#endif
     const uint32_t lane = threadIdx.x;
     // workgroup-shared tables
-    uint32_t* sh = smem;
+    uint32_t* sh = SMEM;
 #ifdef MADSIM_EMU
     const uint32_t cp0 = 0, cps = 1;      // emulated threads run one after another: each copies everything
 #else
@@ -677,13 +690,15 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
     __syncthreads();
 
     Ctx c(P);
-    c.insn = (const uint2*)(sh + P.sh_insns);
-    c.prog = sh + P.sh_progs;
-    c.sock = sh + P.sh_socks;
-    c.heap = (uint4*)(sh + P.sh_heap) + lane;
-    c.tasks = (uint4*)(sh + P.sh_tasks) + lane;
-    c.lds = sh + P.sh_planes + lane;
-    const uint32_t glane = blockIdx.x * 64 + lane;
+    c.insn0 = P.sh_insns / 2;
+    c.prog0 = P.sh_progs;
+    c.sockt0 = P.sh_socks;
+    c.heap0 = P.sh_heap / 4 + lane;
+    c.task0 = P.sh_tasks / 4 + lane;
+    c.pl = P.sh_planes + lane;
+    c.sock0 = c.pl + (P.off_socks << P.lw_shift);
+    if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
+    const uint32_t glane = (blockIdx.x << P.lw_shift) + lane;
     c.spill = P.spill ? P.spill + glane : nullptr;
     c.tlog = P.trace_log;
 
@@ -693,7 +708,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
     for (;;) {
         if (!have) {
             if (next >= P.count) break;
-            seed_init<TRACE>(c, L, P.seed0 + next);
+            seed_init<K>(c, L, P.seed0 + next);
             have = true;
         }
         // One iteration = the block_on loop body (task/mod.rs:239-259) taken as
@@ -709,7 +724,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
             else if (L.heap_len == 0) L.verdict = MADSIM_DEADLOCK;                    // :250
             else {
                 uint64_t t = L.top_dl + 50;                                           // time/mod.rs:47-53
-                timer_expire(c, L, t);
+                timer_expire<K>(c, L, t);
                 L.clock = t;                                                          // :55, after the callbacks
                 if (L.verdict == MADSIM_RUNNING) {
                     if (P.time_limit && L.clock >= P.time_limit) L.verdict = MADSIM_TIME_LIMIT;   // task/mod.rs:253-258
@@ -720,7 +735,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
         // ---------------- [poll] ----------------
         if (L.verdict == MADSIM_RUNNING && L.ready_len > 0) {
             // try_recv_random (utils/mpsc.rs:73-83): idx drawn even when len == 1
-            uint32_t idx = gen_index<TRACE>(c, L, L.ready_len);
+            uint32_t idx = gen_index<K>(c, L, L.ready_len);
             uint32_t slot = W(c, P.off_ready + idx);
             L.ready_len--;
             W(c, P.off_ready + idx) = W(c, P.off_ready + L.ready_len);   // swap_remove
@@ -731,7 +746,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
                 task_finish(c, L, slot, H_CANCELLED);
             } else {
                 u0.x = (u0.x & ~TF_SCHED) | TF_RUN;          // async-task run(): SCHEDULED -> RUNNING
-                panicked = poll_task<TRACE>(c, L, slot, u0);
+                panicked = poll_task<K>(c, L, slot, u0);
                 if (!panicked && (u0.x & TF_ALIVE)) {
                     if (u0.x & TF_SCHED) ready_push(c, L, slot);   // woken while running: re-queue after the poll
                     u0.x &= ~TF_RUN;
@@ -742,8 +757,8 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
                 if (L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_PANIC;   // resume_unwind (:315)
             } else if (L.verdict == MADSIM_RUNNING) {
                 // task/mod.rs:319-321: advance 50..100 ns, then Timer::expire (time/mod.rs:103-106)
-                L.clock += 50 + gen_range_small<TRACE, 50>(c, L);
-                timer_expire(c, L, L.clock);
+                L.clock += 50 + gen_range_small<K, 50>(c, L);
+                timer_expire<K>(c, L, L.clock);
                 if (L.steps >= P.max_steps && L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_STEP_LIMIT;
             }
         }
@@ -752,7 +767,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
             r.verdict = L.verdict; r.steps = L.steps; r.clock_ns = L.clock; r.msg_count = L.msg_count;
             r.rng_calls = L.rng_calls; r.trace_hash = L.trace_hash; r.obs_hash = L.obs_hash;
             P.out[next] = r;
-            if (TRACE) *P.trace_len = L.log_len;
+            if (K::TRACE) *P.trace_len = L.log_len;
             have = false;
             next += P.total_lanes;
         }
@@ -784,8 +799,11 @@ __global__ __launch_bounds__(256) void summary_kernel(const madsim_result_t* __r
 
 #ifndef MADSIM_EMU
 extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace) {
-    if (trace) hipLaunchKernelGGL(madsim_k::sim_kernel<true>, dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
-    else hipLaunchKernelGGL(madsim_k::sim_kernel<false>, dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    using namespace madsim_k;
+    const bool spill = P->spill != nullptr && P->heap_spill > 0;
+    if (trace) hipLaunchKernelGGL((sim_kernel<Variant<true, true>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    else if (spill) hipLaunchKernelGGL((sim_kernel<Variant<false, true>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    else hipLaunchKernelGGL((sim_kernel<Variant<false, false>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
 }
 
 extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream) {
@@ -796,9 +814,12 @@ extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t cou
 }
 
 extern "C" int madsim_k_set_max_lds(uint32_t lds_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)madsim_k::sim_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    using namespace madsim_k;
+    hipError_t e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, false>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)madsim_k::sim_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<true, true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     return (int)e;
 }
 #endif  // !MADSIM_EMU

@@ -42,9 +42,11 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
     uint32_t* base = lds.data();
     while (((uintptr_t)base) & 15) base++;
     for (uint32_t b = 0; b < G.grid; b++) {
-        for (uint32_t t = 0; t < 64; t++) {
+        for (uint32_t t = 0; t < G.lanes_per_wave; t++) {
             blockIdx.x = b; threadIdx.x = t; emu_smem = base;
-            if (tlog) madsim_k::sim_kernel<true>(P); else madsim_k::sim_kernel<false>(P);
+            if (tlog) madsim_k::sim_kernel<madsim_k::Variant<true, true>>(P);
+            else if (P.spill) madsim_k::sim_kernel<madsim_k::Variant<false, true>>(P);
+            else madsim_k::sim_kernel<madsim_k::Variant<false, false>>(P);
         }
     }
     return 0;
@@ -58,6 +60,6 @@ extern "C" int madsim_emu_geometry(const madsim_workload_t* w, const madsim_limi
     if ((rc = madsim_geo::make_geometry(dev, w, &cfg, lim, UINT64_MAX / 2, &G, &emu_err))) return rc;
     out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64;
     out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
-    out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks;
+    out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave; out->reserved = 0;
     return 0;
 }
