@@ -1,0 +1,111 @@
+"""Random workload generator for parity testing (oracle vs device code).
+
+Generates small, always-valid actor programs that mix the op set both sides implement:
+bind / send_to / recv_from / reply / sleep / yield / loops / trace / spawn / join / clog / set_loss.
+Programs may deadlock, panic (assert_val mismatch) or pass — every verdict is a valid comparison
+point, what matters is that both sides agree bit-for-bit on all 48 result bytes.
+"""
+import random
+
+from madsim_amd import _abi as A
+from madsim_amd import workload as W
+
+
+def random_workload(rng: random.Random, max_nodes=4, max_rounds=6):
+    """Returns (BuiltWorkload, Config, description)."""
+    n_nodes = rng.randint(1, max_nodes)
+    wl = W.WorkloadBuilder()
+    nodes = [wl.create_node() for _ in range(n_nodes)]
+    addrs = [wl.addr(n, 1) for n in nodes]               # one endpoint address per node
+    loss_table = (0.0, rng.choice([0.0, 0.02, 0.3]), 1.0)
+    tasks = []
+    desc = []
+    for i, n in enumerate(nodes):
+        t = wl.task(n)
+        kind = rng.choice(["echo", "chatter", "sleeper", "yielder"]) if n_nodes > 1 else rng.choice(["sleeper", "yielder"])
+        desc.append(kind)
+        t.bind(addrs[i])
+        rounds = rng.randint(1, max_rounds)
+        if kind == "echo":
+            # receive `rounds` messages with tag 1, reply to each
+            t.set(0, rounds)
+            top = t.label()
+            t.recv_from(addrs[i], 1)
+            t.trace(100 + i, add_reg=0)
+            t.reply(addrs[i], rng.choice([1, 2]), 0xA0 + i)
+            t.djnz(0, top)
+        elif kind == "chatter":
+            # send to a random peer, sometimes wait for a reply with a (possibly wrong) tag
+            peer = rng.choice([j for j in range(n_nodes) if j != i])
+            if rng.random() < 0.5:
+                t.sleep(ms=rng.randint(0, 30))
+            t.set(0, rounds)
+            top = t.label()
+            t.send_to(addrs[i], addrs[peer], 1, 0xB0 + i)
+            if rng.random() < 0.6:
+                t.recv_from(addrs[i], rng.choice([1, 1, 2]))
+                if rng.random() < 0.3:
+                    t.assert_val(0xA0 + peer)
+            else:
+                t.sleep(us=rng.randint(0, 5000))
+            t.trace(200 + i, add_reg=0)
+            t.djnz(0, top)
+        elif kind == "sleeper":
+            t.set(1, rounds)
+            top = t.label()
+            t.sleep(ns=rng.choice([0, 1, 999_999, 1_000_000, 1_000_001, 50_000_000]))
+            t.trace(300 + i, add_reg=1)
+            t.djnz(1, top)
+        else:  # yielder
+            t.set(0, rounds)
+            top = t.label()
+            t.trace(400 + i, add_reg=0)
+            t.yield_now()
+            t.djnz(0, top)
+        if rng.random() < 0.2:
+            t.close(addrs[i])
+        t.done()
+        tasks.append(t)
+    m = wl.main()
+    order = list(range(n_nodes))
+    rng.shuffle(order)
+    for i in order:
+        m.spawn(tasks[i])
+    # supervisor actions between spawn and join
+    for _ in range(rng.randint(0, 3)):
+        act = rng.choice(["sleep", "clog", "unclog", "link", "loss", "yield"])
+        if act == "sleep":
+            m.sleep(ms=rng.randint(0, 20))
+        elif act == "clog":
+            m.clog_node(rng.choice(nodes), rng.choice(["in", "out", "both"]))
+        elif act == "unclog":
+            m.unclog_node(rng.choice(nodes), rng.choice(["in", "out", "both"]))
+        elif act == "link" and n_nodes > 1:
+            a, b = rng.sample(nodes, 2)
+            (m.clog_link if rng.random() < 0.7 else m.unclog_link)(a, b)
+        elif act == "loss":
+            m.set_loss(rng.randint(0, 2))
+        else:
+            m.yield_now()
+    joined = [i for i in order if rng.random() < 0.8]
+    for i in joined:
+        m.join(tasks[i])
+    m.done()
+    lo, hi = rng.choice([(1_000_000, 10_000_000), (1, 2), (0, 10_000_000), (900_000_000, 1_100_000_000),
+                         (900_000_000, 2_100_000_000), (5_000_000, 5_000_001)])
+    cfg = A.Config.default(
+        packet_loss_rate=rng.choice([0.0, 0.0, 0.05]),
+        lat_lo_ns=lo,
+        lat_hi_ns=hi,
+        buggify=rng.random() < 0.2,
+        loss_table=loss_table,
+    )
+    return wl.build(), cfg, "+".join(desc)
+
+
+def generous_limits():
+    lim = A.Limits()
+    lim.max_steps = 200_000
+    lim.heap_lds_slots, lim.heap_spill_slots = 4, 60     # small LDS quota: the spill path gets exercised too
+    lim.mbox_regs, lim.mbox_msgs = 4, 12
+    return lim

@@ -1,0 +1,88 @@
+"""The C-ABI boundary: the library loads, exports every symbol include/madsim_hip.h declares, its structs
+have the documented layout, and it fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from madsim_amd import _abi as A
+from madsim_amd import runtime, workload
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "madsim_hip.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    L = runtime.lib()
+    names = set(re.findall(r"\b(madsim_(?:hip|workload)_[a-z_]+)\s*\(", HEADER))
+    assert {"madsim_hip_run_batch", "madsim_hip_run_batch_device", "madsim_hip_trace_seed", "madsim_hip_init",
+            "madsim_hip_shutdown", "madsim_hip_version", "madsim_hip_geometry", "madsim_workload_pingpong",
+            "madsim_hip_strerror", "madsim_hip_last_error"} <= names
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/madsim_hip.h but not exported"
+    assert L.madsim_hip_version() == A.ABI_VERSION == int(re.search(r"MADSIM_HIP_ABI_VERSION (\d+)u", HEADER).group(1))
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(A.Insn) == 8 and C.sizeof(A.Result) == 48 and C.sizeof(A.Summary) == 48
+    assert C.sizeof(A.Limits) == 40 and C.sizeof(A.Geometry) == 40
+    assert A.Result.clock_ns.offset == 8 and A.Result.trace_hash.offset == 32 and A.Result.obs_hash.offset == 40
+    for name, val in A.OP.items():
+        m = re.search(r"MS_OP_%s = (\d+)," % name, HEADER)
+        assert m and int(m.group(1)) == val, name
+
+
+def test_c_twin_of_pingpong_matches_python_assembler():
+    L = runtime.lib()
+    for n, r in ((2, 64), (4, 64), (16, 3)):
+        nodes, progs, socks = (A.Node * (n + 1))(), (A.Prog * (n + 1))(), (A.Sock * n)()
+        insns = (A.Insn * 512)()
+        w = A.Workload()
+        cnt = L.madsim_workload_pingpong(n, r, nodes, progs, socks, insns, 512, C.byref(w))
+        py = workload.pingpong(n, r)
+        assert cnt == py.struct.n_insns == w.n_insns
+        assert bytes(insns)[:cnt * 8] == bytes(py.insns)
+        assert bytes(progs) == bytes(py.progs) and bytes(socks) == bytes(py.socks)
+    assert L.madsim_workload_pingpong(3, 1, nodes, progs, socks, insns, 512, C.byref(w)) == -1   # odd node count
+
+
+def test_geometry_and_validation_need_no_gpu():
+    g = runtime.geometry(workload.pingpong(4, 64))
+    assert g.block_threads == 64 and g.lanes_per_wave == 64 and g.lds_bytes_per_seed > 0
+    lim = A.Limits(); lim.lanes_per_wave = 7
+    with pytest.raises(runtime.MadsimHipError, match="lanes_per_wave"):
+        runtime.geometry(workload.pingpong(4, 64), lim)
+    bad = workload.WorkloadBuilder(); bad.main().jmp(500)
+    with pytest.raises(runtime.MadsimHipError, match="jump target"):
+        runtime.geometry(bad.build())
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(runtime.MadsimHipError):
+        runtime.init(0)
+    L = runtime.lib()
+    cfg, lim, summ = A.Config.default(), A.Limits(), A.Summary()
+    w = workload.pingpong(2, 1)
+    rc = L.madsim_hip_run_batch(w.ref(), C.byref(cfg), 0, 1, C.byref(lim), None, C.byref(summ))
+    assert rc == -3 and b"not initialised" in L.madsim_hip_strerror(rc)        # MADSIM_E_NOINIT
+
+
+def test_builder_from_env_mirrors_reference(tmp_path):
+    """runtime/builder.rs:64-118"""
+    b = runtime.Builder.from_env({"MADSIM_TEST_SEED": "42", "MADSIM_TEST_NUM": "7", "MADSIM_TEST_JOBS": "3",
+                                  "MADSIM_TEST_TIME_LIMIT": "1.5"})
+    assert (b.seed, b.count, b.jobs, b.time_limit, b.check) == (42, 7, 3, 1.5, False)
+    assert b.limits().time_limit_ns == 1_500_000_000
+    b = runtime.Builder.from_env({"MADSIM_TEST_CHECK_DETERMINISM": "1"})
+    assert b.check and b.count == 2 and b.jobs == 1 and 0 < b.seed < 2**64
+    with pytest.raises(ValueError, match="MADSIM_TEST_SEED should be an integer"):
+        runtime.Builder.from_env({"MADSIM_TEST_SEED": "x"})
+    cfgfile = tmp_path / "c.toml"
+    cfgfile.write_text('[net]\npacket_loss_rate = 0.25\nsend_latency = { start = { secs = 0, nanos = 2000000 }, '
+                       'end = { secs = 0, nanos = 3000000 } }\n')
+    b = runtime.Builder.from_env({"MADSIM_TEST_CONFIG": str(cfgfile)})
+    assert (b.config.packet_loss_rate, b.config.lat_lo_ns, b.config.lat_hi_ns) == (0.25, 2_000_000, 3_000_000)

@@ -1,0 +1,63 @@
+"""The N>1 path on CPU: two gloo ranks shard a seed range and combine their first-fail reports with the same
+collective code bench.py runs over RCCL (madsim_amd/dist.py).  The per-rank 'simulation' here is the CPU
+oracle because this container has no GPU; the sharding + reduction logic is what is under test."""
+import os
+import socket
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from madsim_amd import dist as mdist
+
+
+def test_shard_range_tiles_the_batch():
+    for count in (0, 1, 5, 64, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            blocks = [mdist.shard_range(1000, count, r, world) for r in range(world)]
+            assert sum(n for _, n in blocks) == count
+            nxt = 1000
+            for s, n in blocks:
+                if n:
+                    assert s == nxt
+                    nxt += n
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from madsim_amd import _abi as A
+    from madsim_amd import workload as W
+    w = W.pingpong(4, 16)
+    cfg = A.Config.default(packet_loss_rate=0.02)
+    seed0, count = mdist.shard_range(0, 600, rank, world)
+    out, s = oracle.run_batch(w, seed0, count, cfg)
+    rep = mdist.reduce_report(s.first_failing_seed, s.n_failed, s.total_steps, s.total_clock_ns)
+    # a rank with no failure reports UINT64_MAX: the unsigned-min mapping must not be fooled by it
+    rep2 = mdist.reduce_report((1 << 64) - 1 if rank == 0 else 5, 0, 0, 0)
+    q.put((rank, rep, rep2))
+    dist.destroy_process_group()
+
+
+def test_two_rank_first_fail_report():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    import oracle
+    from madsim_amd import _abi as A
+    from madsim_amd import workload as W
+    out, s = oracle.run_batch(W.pingpong(4, 16), 0, 600, A.Config.default(packet_loss_rate=0.02))
+    want = (s.first_failing_seed, s.n_failed, s.total_steps, s.total_clock_ns)
+    assert s.n_failed > 0
+    for rank, rep, rep2 in res:
+        assert rep == want, (rank, rep, want)
+        assert rep2[0] == 5

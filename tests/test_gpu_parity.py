@@ -56,3 +56,135 @@ def test_trace_log_bytes(hip):
         olog, ores = oracle.trace_seed(w, seed)
         assert glog == olog
         assert gres.astuple() == ores.astuple()
+
+
+def test_fuzz_random_workloads_gpu(hip):
+    """Random actor programs (every verdict, clog/set_loss/close/yield, HBM spill path) through the C-ABI."""
+    import random
+    from tests import fuzz
+    verdicts = set()
+    for k in range(120):
+        w, cfg, desc = fuzz.random_workload(random.Random(5000 + k))
+        got, _ = _cmp(hip, w, k * 13, 96, cfg, fuzz.generous_limits())
+        verdicts |= set(got["verdict"].tolist())
+    assert {A.PASS, A.DEADLOCK, A.PANIC} <= verdicts
+
+
+@pytest.mark.parametrize("nodes,rounds,count", [(2, 64, 1024), (8, 8, 1024), (16, 4, 512)])
+def test_pingpong_topologies(hip, nodes, rounds, count):
+    _cmp(hip, W.pingpong(nodes, rounds), 10_000, count)
+
+
+@pytest.mark.parametrize("cfg", [A.Config.default(buggify=True), A.Config.default(packet_loss_rate=1.0),
+                                 A.Config.default(lat_lo_ns=9 * 10**8, lat_hi_ns=21 * 10**8)])
+def test_pingpong_configs(hip, cfg):
+    _cmp(hip, W.pingpong(4, 16), 3, 1024, cfg)
+
+
+@pytest.mark.parametrize("lw", [8, 16, 32, 64])
+def test_lanes_per_wave_invariant(hip, lw):
+    lim = A.Limits(); lim.lanes_per_wave = lw
+    _cmp(hip, W.pingpong(4, 8), 0, 2048, None, lim)
+
+
+def test_heap_spill_path_hbm(hip):
+    """Only 2 timer entries per seed in LDS: the rest goes through the coalesced HBM spill region."""
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 2, 30
+    _cmp(hip, W.pingpong(8, 8), 0, 4096, None, lim)
+
+
+def test_overflow_is_reported_not_hidden(hip):
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 2, 0
+    got, summ = hip.run_batch(W.pingpong(4, 4), 0, 256, None, lim)
+    assert (got["verdict"] == A.OVERFLOW).all() and summ.n_failed == 256
+
+
+def test_full_size_properties_65536(hip):
+    """BASELINE configs[1] at full size through size-independent properties:
+    every seed passes, 2 messages and 12 executor steps per round trip, determinism
+    (same batch twice), and partition invariance (a batch equals the concatenation of its halves)."""
+    w = W.pingpong(4, 64)
+    a, sa = hip.run_batch(w, 0, 65536)
+    assert sa.n_failed == 0 and sa.first_failing_seed == A.U64_MAX
+    assert (a["msg_count"] == 2 * 2 * 64).all()
+    assert (a["steps"] >= 2 * 64 * 12).all() and (a["steps"] < 2 * 64 * 12 + 40).all()
+    assert len(np.unique(a["trace_hash"])) == 65536
+    b, _ = hip.run_batch(w, 0, 65536)
+    assert (a == b).all()
+    lo, _ = hip.run_batch(w, 0, 30000)
+    hi, _ = hip.run_batch(w, 30000, 35536)
+    assert (np.concatenate([lo, hi]) == a).all()
+    assert sa.total_steps == int(a["steps"].astype(np.int64).sum())
+    assert sa.total_clock_ns == int(a["clock_ns"].astype(np.int64).sum())
+
+
+def test_262144_seeds_sampled(hip):
+    """BASELINE configs[2] batch size on one GPU (4-node ping-pong with packet loss as the injected fault)."""
+    w = W.pingpong(4, 64)
+    cfg = A.Config.default(packet_loss_rate=0.002)
+    got, summ = hip.run_batch(w, 0, 262144, cfg)
+    fails = np.nonzero(got["verdict"] != A.PASS)[0]
+    assert summ.n_failed == len(fails) > 0 and summ.first_failing_seed == fails[0]
+    for s in list(fails[:8]) + [(k * 1021) % 262144 for k in range(64)]:
+        want, _ = oracle.run_batch(w, int(s), 1, cfg)
+        assert got[s] == want[0], f"seed {s}"
+
+
+def test_device_resident_entry_point_on_torch_stream(hip):
+    """madsim_hip_run_batch_device: results stay in HBM (a torch buffer), launched on torch's stream."""
+    import torch
+    w = W.pingpong(4, 8)
+    n = 4096
+    buf = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        summ = hip.run_batch_device(w, 77, n, buf.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    got = np.frombuffer(buf.cpu().numpy().tobytes(), dtype=A.RESULT_DTYPE)
+    want, osumm = oracle.run_batch(w, 77, n)
+    assert (got == want).all() and summ.total_steps == osumm.total_steps and summ.kernel_ms > 0
+
+
+def test_builder_run_reports_first_failing_seed(hip, capfd):
+    """Builder::run (runtime/builder.rs:121-162): pass -> returns; failure -> the reference's note + raise."""
+    from madsim_amd import runtime
+    w = W.pingpong(4, 16)
+    out = runtime.Builder(seed=5, count=100).run(w)
+    assert len(out) == 100
+    cfg = A.Config.default(packet_loss_rate=0.05)
+    want, osumm = oracle.run_batch(w, 0, 500, cfg)
+    with pytest.raises(runtime.SimulationFailure) as ei:
+        runtime.Builder(seed=0, count=500, config=cfg).run(w)
+    assert ei.value.seed == osumm.first_failing_seed and ei.value.verdict == A.DEADLOCK
+    assert f"note: run with `MADSIM_TEST_SEED={osumm.first_failing_seed}` environment variable" in capfd.readouterr().err
+    r = runtime.Builder(seed=9, check=True).run(w)          # MADSIM_TEST_CHECK_DETERMINISM
+    assert r.verdict == A.PASS
+
+
+def test_time_limit_and_step_limit(hip):
+    wl = W.WorkloadBuilder(); m = wl.main(); m.sleep(secs=10)
+    lim = A.Limits(); lim.time_limit_ns = 5 * 10**9
+    got, _ = _cmp(hip, wl.build(), 0, 64, None, lim)
+    assert (got["verdict"] == A.TIME_LIMIT).all()
+    lim = A.Limits(); lim.max_steps = 100
+    got, _ = _cmp(hip, W.pingpong(2, 64), 0, 64, None, lim)
+    assert (got["verdict"] == A.STEP_LIMIT).all()
+
+
+def test_reference_property_tests_on_gpu(hip):
+    """random_select_from_ready_tasks (task/mod.rs:1018-1041) and deterministic_std_instant
+    (time/system_time.rs:140-154) executed by the kernel."""
+    wl = W.WorkloadBuilder()
+    ts = []
+    for i in range(3):
+        t = wl.task(0); t.set(0, 5); top = t.label(); t.trace(i * 10, add_reg=0); t.yield_now(); t.djnz(0, top); ts.append(t)
+    m = wl.main()
+    for t in ts:
+        m.spawn(t)
+    for t in ts:
+        m.join(t)
+    got, summ = _cmp(hip, wl.build(), 0, 10)
+    assert summ.n_failed == 0 and len(set(got["obs_hash"].tolist())) == 10
+    wl = W.WorkloadBuilder(); m = wl.main(); m.mark(); m.sleep(secs=1); m.assert_elapsed("==", secs=1, ns=50)
+    got, summ = _cmp(hip, wl.build(), 0, 512)
+    assert summ.n_failed == 0
