@@ -103,6 +103,13 @@ def main():
         algo_bytes = steps_per_launch * ALGO_BYTES_PER_STEP + count * IO_BYTES_PER_SEED
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
         g = runtime.geometry(w, lim)
+        # HBM traffic per launch from the rocprofv3 PMC passes of this same command (tools/prof_pmc.sh ->
+        # profiles/r1_traffic.json): FETCH_SIZE (x2, the gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if world == 1 and per_gpu == SEEDS_PER_GPU and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = (2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0
         line = {
             "metric": "sim_seconds_per_sec", "value": sim_s / dt, "unit": "sim-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -116,13 +123,13 @@ def main():
                       "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu,
                       "lanes_per_wave": g.lanes_per_wave},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "sim_kernel<false>", "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "LDS-resident path: algorithmic bytes (120 B/executor step) never touch HBM"},
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle
-            sample = 2 * SEEDS_PER_GPU // 1
+            sample = 4 * SEEDS_PER_GPU          # ~14 s of single-thread CPU work
             t1 = time.perf_counter()
             _, osum = oracle.run_batch(w, 0, sample)
             cdt = time.perf_counter() - t1

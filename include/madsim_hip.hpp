@@ -1,0 +1,237 @@
+// madsim_hip.hpp — C++17 host-side mirror of madsim's seed driver over the C-ABI (include/madsim_hip.h).
+//
+// The reference's host code is Rust; this image has no Rust toolchain, so the host side above the C-ABI
+// is written in C++ with the reference's own names and behaviour:
+//   madsim::runtime::Builder            madsim/src/sim/runtime/builder.rs:7-22   (same public fields)
+//   Builder::from_env()                 builder.rs:64-118                         (same environment variables)
+//   Builder::run(workload)              builder.rs:121-162                        (returns on success; on the
+//                                       first failing seed prints the reproduction note of
+//                                       runtime/mod.rs:205-210 and throws — the C++ stand-in for the panic)
+//   madsim::WorkloadBuilder / Task      the body of a #[madsim::test] as an actor program; method names are
+//                                       the reference API calls they stand for (net/endpoint.rs, time/sleep.rs,
+//                                       task/mod.rs, runtime/mod.rs:276-303, net/mod.rs:164-222)
+// Header-only; link with libmadsim_hip.so.  There is no CPU fallback: without a GPU every run throws.
+#ifndef MADSIM_HIP_HPP
+#define MADSIM_HIP_HPP
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "madsim_hip.h"
+
+namespace madsim {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// A failing seed: what `cargo test` would report as the test's panic.
+struct SimulationFailure : std::runtime_error {
+    uint64_t seed;
+    madsim_result_t result;
+    SimulationFailure(uint64_t s, const madsim_result_t& r)
+        : std::runtime_error("seed " + std::to_string(s) + ": " + verdict_name(r.verdict)), seed(s), result(r) {}
+    static const char* verdict_name(uint32_t v) {
+        static const char* n[] = {"pass", "panic", "no events, all tasks will block forever", "time limit exceeded",
+                                  "device capacity overflow", "step limit"};
+        return v < 6 ? n[v] : "?";
+    }
+};
+
+inline void check(int rc) {
+    if (rc < 0) throw Error(rc, std::string(madsim_hip_strerror(rc)) + ": " + madsim_hip_last_error());
+}
+
+// madsim::Config.net (net/network.rs:66-89)
+struct Config {
+    double packet_loss_rate = 0.0;
+    uint64_t send_latency_start_ns = 1000000, send_latency_end_ns = 10000000;
+    bool buggify = false;
+    madsim_config_t raw() const {
+        madsim_config_t c{};
+        c.packet_loss_rate = packet_loss_rate; c.lat_lo_ns = send_latency_start_ns; c.lat_hi_ns = send_latency_end_ns;
+        c.buggify = buggify ? 1 : 0;
+        return c;
+    }
+};
+
+class WorkloadBuilder;
+
+// One async block (`node.spawn(async move { ... })`).
+class Task {
+  public:
+    int index() const { return index_; }
+    int label() const { return (int)code_.size(); }
+    Task& done() { return emit(MS_OP_DONE); }
+    Task& spawn(const Task& t) { return emit(MS_OP_SPAWN, (uint8_t)t.index_); }
+    Task& join(const Task& t, bool expect_err = false) { return emit(MS_OP_JOIN, (uint8_t)t.index_, expect_err ? 1 : 0); }
+    Task& yield_now() { return emit(MS_OP_YIELD); }
+    Task& panic() { return emit(MS_OP_PANIC); }
+    Task& set(int reg, uint32_t v) { return emit(MS_OP_SET, (uint8_t)reg, 0, v); }
+    Task& djnz(int reg, int target) { return emit(MS_OP_DJNZ, (uint8_t)reg, (uint16_t)target, 0, true); }
+    Task& jmp(int target) { return emit(MS_OP_JMP, 0, (uint16_t)target, 0, true); }
+    Task& trace(uint32_t v) { return emit(MS_OP_TRACE, 0, 0, v); }
+    Task& sleep(std::chrono::nanoseconds d) { return dur(MS_OP_SLEEP, 0, d); }
+    Task& mark() { return emit(MS_OP_MARK); }
+    Task& sleep_until(std::chrono::nanoseconds after_mark) { return dur(MS_OP_SLEEP_UNTIL, 0, after_mark); }
+    Task& assert_elapsed_eq(std::chrono::nanoseconds d) { return dur(MS_OP_ASSERT_ELAPSED, 0, d); }
+    Task& assert_elapsed_ge(std::chrono::nanoseconds d) { return dur(MS_OP_ASSERT_ELAPSED, 1, d); }
+    Task& bind(int addr) { return emit(MS_OP_BIND, (uint8_t)addr); }
+    Task& send_to(int ep, int dst, uint8_t tag, uint32_t payload) { return emit(MS_OP_SEND, (uint8_t)ep, (uint16_t)((tag << 8) | dst), payload); }
+    Task& reply(int ep, uint8_t tag, uint32_t payload) { return emit(MS_OP_REPLY, (uint8_t)ep, (uint16_t)(tag << 8), payload); }
+    Task& recv_from(int ep, uint8_t tag) { return emit(MS_OP_RECV, (uint8_t)ep, (uint16_t)(tag << 8)); }
+    Task& assert_val(uint32_t v) { return emit(MS_OP_ASSERT_VAL, 0, 0, v); }
+    Task& close(int ep) { return emit(MS_OP_CLOSE, (uint8_t)ep); }
+    Task& clog_node(int node) { return emit(MS_OP_CLOG_NODE, (uint8_t)node, 3); }
+    Task& unclog_node(int node) { return emit(MS_OP_UNCLOG_NODE, (uint8_t)node, 3); }
+    Task& clog_link(int src, int dst) { return emit(MS_OP_CLOG_LINK, (uint8_t)src, (uint16_t)dst); }
+    Task& unclog_link(int src, int dst) { return emit(MS_OP_UNCLOG_LINK, (uint8_t)src, (uint16_t)dst); }
+
+  private:
+    friend class WorkloadBuilder;
+    struct Ins { madsim_insn_t in; bool reloc; };
+    Task(int index, int node, uint8_t flags) : index_(index), node_(node), flags_(flags) {}
+    Task& emit(uint8_t op, uint8_t a = 0, uint16_t b = 0, uint32_t imm = 0, bool reloc = false) {
+        code_.push_back({madsim_insn_t{op, a, b, imm}, reloc});
+        return *this;
+    }
+    Task& dur(uint8_t op, uint8_t a, std::chrono::nanoseconds d) {
+        uint64_t ns = (uint64_t)d.count();
+        return emit(op, a, (uint16_t)(ns / 1000000000ull), (uint32_t)(ns % 1000000000ull));
+    }
+    int index_, node_;
+    uint8_t flags_;
+    std::vector<Ins> code_;
+};
+
+// Owns the tables a madsim_workload_t points into.
+struct Workload {
+    std::vector<madsim_node_t> nodes;
+    std::vector<madsim_prog_t> progs;
+    std::vector<madsim_sock_t> socks;
+    std::vector<madsim_insn_t> insns;
+    madsim_workload_t raw() const {
+        return madsim_workload_t{(uint32_t)nodes.size() - 1, (uint32_t)progs.size(), (uint32_t)socks.size(),
+                                 (uint32_t)insns.size(), nodes.data(), progs.data(), socks.data(), insns.data()};
+    }
+};
+
+class WorkloadBuilder {
+  public:
+    WorkloadBuilder() { nodes_.push_back(madsim_node_t{}); tasks_.push_back(Task(0, 0, 0)); }
+    Task& main() { return tasks_[0]; }                                   // the future handed to block_on
+    int create_node() { nodes_.push_back(madsim_node_t{}); return (int)nodes_.size() - 1; }   // Handle::create_node().build()
+    int addr(int node, uint16_t port) { socks_.push_back(madsim_sock_t{(uint8_t)node, 0, port}); return (int)socks_.size() - 1; }
+    Task& task(int node) { tasks_.reserve(256); tasks_.push_back(Task((int)tasks_.size(), node, 0)); return tasks_.back(); }
+    Workload build() {
+        Workload w;
+        w.nodes = nodes_; w.socks = socks_;
+        for (auto& t : tasks_) {
+            uint16_t base = (uint16_t)w.insns.size();
+            if (t.code_.empty() || (t.code_.back().in.op != MS_OP_DONE && t.code_.back().in.op != MS_OP_JMP)) t.done();
+            w.progs.push_back(madsim_prog_t{(uint8_t)t.node_, t.flags_, base});
+            for (auto& i : t.code_) {
+                madsim_insn_t in = i.in;
+                if (i.reloc) in.b = (uint16_t)(in.b + base);
+                w.insns.push_back(in);
+            }
+        }
+        return w;
+    }
+
+  private:
+    std::vector<madsim_node_t> nodes_;
+    std::vector<madsim_sock_t> socks_;
+    std::vector<Task> tasks_;
+};
+
+namespace runtime {
+
+// runtime/mod.rs:205-210
+inline void panic_with_info(uint64_t seed) {
+    std::fprintf(stderr, "note: run with `MADSIM_TEST_SEED=%llu` environment variable to reproduce this error\n",
+                 (unsigned long long)seed);
+}
+
+struct Builder {
+    uint64_t seed = 0;
+    uint64_t count = 1;
+    uint16_t jobs = 1;
+    Config config;
+    std::optional<double> time_limit;        // seconds
+    bool check = false;
+    bool allow_system_thread = false;
+    int device = 0;
+
+    // builder.rs:64-118
+    static Builder from_env() {
+        Builder b;
+        auto env = [](const char* k) -> const char* { return std::getenv(k); };
+        auto parse_u64 = [](const char* s, const char* what) -> uint64_t {
+            char* end = nullptr;
+            unsigned long long v = std::strtoull(s, &end, 10);
+            if (!s[0] || *end) throw std::invalid_argument(std::string(what) + " should be an integer");
+            return v;
+        };
+        if (auto s = env("MADSIM_TEST_SEED")) b.seed = parse_u64(s, "MADSIM_TEST_SEED");
+        else b.seed = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                          std::chrono::system_clock::now().time_since_epoch()).count();
+        if (auto s = env("MADSIM_TEST_JOBS")) b.jobs = (uint16_t)parse_u64(s, "MADSIM_TEST_JOBS");
+        if (auto s = env("MADSIM_TEST_NUM")) b.count = parse_u64(s, "MADSIM_TEST_NUM");
+        if (auto s = env("MADSIM_TEST_TIME_LIMIT")) {
+            char* end = nullptr;
+            double v = std::strtod(s, &end);
+            if (!s[0] || *end) throw std::invalid_argument("MADSIM_TEST_TIME_LIMIT should be an number");
+            b.time_limit = v;
+        }
+        b.check = env("MADSIM_TEST_CHECK_DETERMINISM") != nullptr;
+        if (b.check && b.count < 2) b.count = 2;
+        b.allow_system_thread = env("MADSIM_ALLOW_SYSTEM_THREAD") != nullptr;
+        return b;
+    }
+
+    // builder.rs:121-162: run seeds seed..seed+count; return on success, "panic" on the first failing seed.
+    // Reports the numerically smallest failing seed (the reference reports the first to complete).
+    std::vector<madsim_result_t> run(const Workload& wl) const {
+        madsim::check(madsim_hip_init(device));
+        madsim_workload_t w = wl.raw();
+        madsim_config_t cfg = config.raw();
+        madsim_limits_t lim{};
+        if (time_limit) lim.time_limit_ns = (uint64_t)(*time_limit * 1e9 + 0.5);
+        if (check) {                                   // Runtime::check_determinism (runtime/mod.rs:178-202)
+            std::vector<uint8_t> l1(1 << 20), l2(1 << 20);
+            madsim_result_t r1{}, r2{};
+            int64_t n1 = madsim_hip_trace_seed(&w, &cfg, seed, &lim, l1.data(), l1.size(), &r1);
+            int64_t n2 = madsim_hip_trace_seed(&w, &cfg, seed, &lim, l2.data(), l2.size(), &r2);
+            if (n1 < 0) madsim::check((int)n1);
+            if (n2 < 0) madsim::check((int)n2);
+            size_t n = (size_t)(n1 < (int64_t)l1.size() ? n1 : (int64_t)l1.size());
+            if (n1 != n2 || std::memcmp(l1.data(), l2.data(), n) != 0) {
+                panic_with_info(seed);
+                throw std::runtime_error("non-determinism detected");
+            }
+            if (r1.verdict != MADSIM_PASS) { panic_with_info(seed); throw SimulationFailure(seed, r1); }
+            return {r1};
+        }
+        std::vector<madsim_result_t> out(count);
+        madsim_summary_t s{};
+        madsim::check(madsim_hip_run_batch(&w, &cfg, seed, count, &lim, out.data(), &s));
+        if (s.n_failed) {
+            panic_with_info(s.first_failing_seed);
+            throw SimulationFailure(s.first_failing_seed, out[s.first_failing_seed - seed]);
+        }
+        return out;
+    }
+};
+
+}  // namespace runtime
+}  // namespace madsim
+
+#endif

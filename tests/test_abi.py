@@ -86,3 +86,17 @@ def test_builder_from_env_mirrors_reference(tmp_path):
                        'end = { secs = 0, nanos = 3000000 } }\n')
     b = runtime.Builder.from_env({"MADSIM_TEST_CONFIG": str(cfgfile)})
     assert (b.config.packet_loss_rate, b.config.lat_lo_ns, b.config.lat_hi_ns) == (0.25, 2_000_000, 3_000_000)
+
+
+def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu():
+    """include/madsim_hip.hpp + examples/pingpong_test.cpp: the C++ Builder::from_env().run(workload)."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "examples", "pingpong_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "examples", "pingpong_test.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "madsim_amd"), "-lmadsim_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "madsim_amd")])
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the run itself is covered by the gpu test")
+    p = subprocess.run([exe], env=dict(os.environ, MADSIM_TEST_SEED="1", MADSIM_TEST_NUM="4"), capture_output=True, text=True)
+    assert p.returncode == 2 and "no CPU fallback" in p.stderr

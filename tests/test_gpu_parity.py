@@ -188,3 +188,20 @@ def test_reference_property_tests_on_gpu(hip):
     wl = W.WorkloadBuilder(); m = wl.main(); m.mark(); m.sleep(secs=1); m.assert_elapsed("==", secs=1, ns=50)
     got, summ = _cmp(hip, wl.build(), 0, 512)
     assert summ.n_failed == 0
+
+
+def test_cpp_host_mirror_runs_like_cargo_test(hip):
+    """examples/pingpong_test.cpp (C++ Builder mirror): exit 0 on pass, reference-style note on failure."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "pingpong_test")
+    if not os.path.exists(exe):
+        pytest.skip("example not built (run __graft_entry__.build())")
+    hip.shutdown()
+    p = subprocess.run([exe], env=dict(os.environ, MADSIM_TEST_SEED="3", MADSIM_TEST_NUM="4096"), capture_output=True, text=True)
+    assert p.returncode == 0 and "test ping_pong ... ok (4096 seeds from 3" in p.stdout, p.stderr
+    p = subprocess.run([exe], env=dict(os.environ, MADSIM_TEST_SEED="3", MADSIM_TEST_NUM="64", MADSIM_TEST_TIME_LIMIT="1.5"),
+                       capture_output=True, text=True)
+    assert p.returncode == 101 and "note: run with `MADSIM_TEST_SEED=3` environment variable" in p.stderr
+    hip.init(0)

@@ -40,3 +40,9 @@ if "FETCH_SIZE" in m:
 if "WRITE_SIZE" in m:
     out.append(f"WRITE_SIZE = {m['WRITE_SIZE']:.1f} KB/dispatch")
 print("\n".join(out))
+
+if "FETCH_SIZE" in m and "WRITE_SIZE" in m and len(sys.argv) > 2:
+    import json
+    json.dump({"FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"], "source": d,
+               "note": "mean per sim_kernel dispatch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes"},
+              open(sys.argv[2], "w"), indent=1)
