@@ -124,7 +124,7 @@ def main():
                       "lanes_per_wave": g.lanes_per_wave},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "sim_kernel<false>", "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel": "sim_kernel<Variant<false,false>>", "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "LDS-resident path: algorithmic bytes (120 B/executor step) never touch HBM"},
         }
         if world == 1 and not args.no_cpu_baseline:
