@@ -248,6 +248,9 @@ typedef struct madsim_geometry {
 } madsim_geometry_t;
 int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* g);
 
+/* Debug aid: per-phase cycle accumulators of a profiling build of the kernel (all zero otherwise). */
+int madsim_hip_debug_counters(uint64_t* out16);
+
 /* Built-in workload of SURVEY.md §8d: N-node ping-pong, R rounds per pair.  Fills caller storage;
  * returns the number of instructions written or <0 if `cap_insns` is too small. */
 int madsim_workload_pingpong(uint32_t n_nodes, uint32_t rounds, madsim_node_t* nodes /*[n_nodes+1]*/,

@@ -38,6 +38,7 @@ struct State {
     uint8_t* d_tlog = nullptr; size_t tlog_cap = 0; uint64_t* d_tlen = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t lds_attr = 0;
+    uint64_t* d_prof = nullptr;               // debug counters (EXP_PROF kernel builds)
 };
 
 State g;
@@ -114,7 +115,7 @@ int run_device(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t 
     if ((rc = upload_workload(w, G.P))) return rc;
     if ((rc = ensure_spill(G.P))) return rc;
     G.P.spill = G.P.heap_spill ? g.d_spill : nullptr;
-    G.P.seed0 = seed0; G.P.count = count; G.P.out = d_out;
+    G.P.seed0 = seed0; G.P.count = count; G.P.out = d_out; G.P.prof = g.d_prof;
     if (G.lds_bytes > g.lds_attr) {
         int e = madsim_k_set_max_lds((uint32_t)g.lds_per_cu);
         if (e) return fail(MADSIM_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -178,6 +179,7 @@ int madsim_hip_init(int device) {
     if (g.lds_per_cu > 160 * 1024) g.lds_per_cu = 160 * 1024;
     if (!g.d_acc) HIP_TRY(hipMalloc(&g.d_acc, 4 * sizeof(unsigned long long)));
     if (!g.d_tlen) HIP_TRY(hipMalloc(&g.d_tlen, sizeof(uint64_t)));
+    if (!g.d_prof) { HIP_TRY(hipMalloc(&g.d_prof, 16 * sizeof(uint64_t))); HIP_TRY(hipMemset(g.d_prof, 0, 16 * sizeof(uint64_t))); }
     if (!g.ev0) HIP_TRY(hipEventCreate(&g.ev0));
     if (!g.ev1) HIP_TRY(hipEventCreate(&g.ev1));
     g.inited = true;
@@ -196,6 +198,7 @@ int madsim_hip_shutdown(void) {
     if (g.d_out) (void)hipFree(g.d_out);
     if (g.d_tlog) (void)hipFree(g.d_tlog);
     if (g.d_tlen) (void)hipFree(g.d_tlen);
+    if (g.d_prof) (void)hipFree(g.d_prof);
     if (g.ev0) (void)hipEventDestroy(g.ev0);
     if (g.ev1) (void)hipEventDestroy(g.ev1);
     g = State();
@@ -272,6 +275,16 @@ int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, 
     out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64;
     out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
     out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave; out->reserved = 0;
+    return 0;
+}
+
+// Debug: read and clear the per-phase cycle accumulators an EXP_PROF kernel build fills (zeros otherwise).
+int madsim_hip_debug_counters(uint64_t* out16) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.inited) return fail(MADSIM_E_NOINIT, "madsim_hip_init has not been called");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out16, g.d_prof, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(g.d_prof, 0, 16 * sizeof(uint64_t)));
     return 0;
 }
 

@@ -38,6 +38,7 @@ struct KParams {
     uint32_t total_lanes;
     // trace mode (single seed)
     uint8_t* trace_log; uint64_t trace_cap; uint64_t* trace_len;
+    uint64_t* prof;            // EXP_PROF builds: per-phase cycle accumulators (debug only)
 };
 
 }  // namespace madsim_k

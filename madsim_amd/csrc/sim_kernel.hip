@@ -35,6 +35,11 @@
 
 namespace madsim_k {
 
+#ifdef EXP_ALWAYS_ACCEPT
+#define EXP_ACCEPT(x) ((x) && false)   /* timing experiment only: breaks parity */
+#else
+#define EXP_ACCEPT(x) (x)
+#endif
 #define FNV_OFFSET 14695981039346656037ull
 #define FNV_PRIME 1099511628211ull
 #define NS_PER_S 1000000000ull
@@ -50,8 +55,14 @@ enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 
 // Compile-time kernel variant: TRACE = also emit the raw determinism log (single-seed trace mode);
 // SPILL = the timer heap may overflow from LDS into the HBM spill region.
-template <bool TRACE_, bool SPILL_> struct Variant { static constexpr bool TRACE = TRACE_, SPILL = SPILL_; };
-struct NoTrace { static constexpr bool TRACE = false, SPILL = false; };
+// LWS = log2(lane stride) when known at compile time (6: full 64-lane waves), or -1: read it from KParams.
+template <bool TRACE_, bool SPILL_, int LWS_> struct Variant { static constexpr bool TRACE = TRACE_, SPILL = SPILL_; static constexpr int LWS = LWS_; };
+
+#ifdef EXP_PROF
+#define PROBE(i) do { uint64_t t_ = __builtin_readcyclecounter(); L.prof_acc[i] += t_ - L.prof_t; L.prof_t = t_; } while (0)
+#else
+#define PROBE(i) do { } while (0)
+#endif
 
 struct Lane {
     // GlobalRng
@@ -70,6 +81,10 @@ struct Lane {
     uint32_t ready_len;
     uint32_t heap_len;
     uint32_t verdict;
+#ifdef EXP_PROF
+    uint64_t prof_acc[12]; uint64_t prof_t;
+#endif
+    uint32_t ovf;        // sticky: a device capacity was exceeded this iteration (=> MADSIM_OVERFLOW)
     // runtime-mutable net config (MS_OP_SET_LOSS)
     uint64_t loss_pint;
     uint32_t loss_always;
@@ -89,10 +104,11 @@ extern __shared__ __attribute__((aligned(16))) uint32_t madsim_smem[];
 
 struct Ctx {
     const KParams& P;
-    uint32_t pl;         // word index of this lane's plane 0: word w = SMEM[pl + w * 64]
+    uint32_t lws;        // log2(lane stride) (runtime copy; K::LWS overrides when >= 0)
+    uint32_t ready0, hand0, node0, clog0;   // word indices of this lane's plane regions
     uint32_t sock0;      // word index of this lane's socket region
-    uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + i * 64)
-    uint32_t task0;      // uint4 index of task unit 0: unit (slot,u) = LDS128(task0 + (slot * task_units + u) * 64)
+    uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + (i << lws))
+    uint32_t task0;      // uint4 index of task unit 0
     uint32_t insn0;      // uint2 index of the workgroup-shared instruction table
     uint32_t prog0, sockt0;   // word indices of the shared prog / socket-address tables
     uint4* spill;        // this lane's column of the HBM spill region, stride P.total_lanes
@@ -100,10 +116,14 @@ struct Ctx {
     __device__ Ctx(const KParams& p) : P(p) {}
 };
 
-__device__ __forceinline__ uint32_t& W(const Ctx& c, uint32_t w) { return SMEM[c.pl + (w << c.P.lw_shift)]; }
-__device__ __forceinline__ uint32_t& SW(const Ctx& c, uint32_t s, uint32_t f) { return SMEM[c.sock0 + ((s * c.P.sock_words + f) << c.P.lw_shift)]; }
-__device__ __forceinline__ uint4& TU(const Ctx& c, uint32_t slot, uint32_t u) { return LDS128(c.task0 + ((slot * c.P.task_units + u) << c.P.lw_shift)); }
-__device__ __forceinline__ uint32_t& TWORD(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) { return SMEM[(c.task0 + ((slot * c.P.task_units + u) << c.P.lw_shift)) * 4 + k]; }
+template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { return K::LWS >= 0 ? (uint32_t)K::LWS : c.lws; }
+#define RW(i) SMEM[c.ready0 + ((i) << LWSH<K>(c))]
+#define HW(p) SMEM[c.hand0 + ((p) << LWSH<K>(c))]
+#define NODEW(i) SMEM[c.node0 + ((i) << LWSH<K>(c))]
+#define CLOGW(i) SMEM[c.clog0 + ((i) << LWSH<K>(c))]
+#define SW(c_, s_, f_) SMEM[(c_).sock0 + (((s_) * (c_).P.sock_words + (f_)) << LWSH<K>(c_))]
+#define TU(c_, slot_, u_) LDS128((c_).task0 + (((slot_) * (c_).P.task_units + (u_)) << LWSH<K>(c_)))
+#define TWORD(c_, slot_, u_, k_) SMEM[((c_).task0 + (((slot_) * (c_).P.task_units + (u_)) << LWSH<K>(c_))) * 4 + (k_)]
 __device__ __forceinline__ uint2 INSN(const Ctx& c, uint32_t pc) { return LDS64(c.insn0 + pc); }
 __device__ __forceinline__ uint32_t PROGW(const Ctx& c, uint32_t p) { return SMEM[c.prog0 + p]; }
 __device__ __forceinline__ uint32_t SOCKW(const Ctx& c, uint32_t s) { return SMEM[c.sockt0 + s]; }
@@ -126,6 +146,9 @@ __device__ __forceinline__ uint64_t rng_next(Lane& L) {
 // One determinism-log byte per GlobalRng::with (rand.rs:64-88): clone.gen::<u8>() ^ xor-fold(elapsed).
 template <class K>
 __device__ __forceinline__ void rng_log(const Ctx& c, Lane& L) {
+#ifdef EXP_NOLOG
+    return;
+#endif
     uint64_t r = rotl64(L.s0 + L.s3, 23) + L.s0;   // what the clone's next_u64 would return
     uint32_t v = (uint32_t)(r >> 32);
     uint32_t f = (uint32_t)L.clock ^ (uint32_t)(L.clock >> 32);
@@ -151,7 +174,7 @@ template <class K>
 __device__ __forceinline__ uint32_t gen_index(const Ctx& c, Lane& L, uint32_t len) {
     uint64_t zone = ((uint64_t)len << __builtin_clzll((uint64_t)len)) - 1;
     uint64_t v;
-    do { v = rng_next(L); } while (v * (uint64_t)len > zone);   // accept test on the low 64 bits only
+    do { v = rng_next(L); } while (EXP_ACCEPT(v * (uint64_t)len > zone));   // accept test on the low 64 bits only
     rng_log<K>(c, L);
     uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * len + (((uint64_t)(uint32_t)v * len) >> 32);
     return (uint32_t)(mid >> 32);                               // high 64 bits of v * len
@@ -162,7 +185,7 @@ template <class K, uint32_t RANGE>
 __device__ __forceinline__ uint32_t gen_range_small(const Ctx& c, Lane& L) {
     constexpr uint64_t zone = ((uint64_t)RANGE << __builtin_clzll((uint64_t)RANGE)) - 1;
     uint64_t v;
-    do { v = rng_next(L); } while (v * (uint64_t)RANGE > zone);
+    do { v = rng_next(L); } while (EXP_ACCEPT(v * (uint64_t)RANGE > zone));
     rng_log<K>(c, L);
     uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * RANGE + (((uint64_t)(uint32_t)v * RANGE) >> 32);
     return (uint32_t)(mid >> 32);
@@ -206,15 +229,15 @@ __device__ __forceinline__ uint64_t ev_deadline(const uint4& e) { return u64of(e
 // never merge into a flat_* access.
 template <class K>
 __device__ __forceinline__ uint4 heap_get(const Ctx& c, uint32_t i) {
-    if (!K::SPILL) return LDS128(c.heap0 + (i << c.P.lw_shift));
+    if (!K::SPILL) return LDS128(c.heap0 + (i << LWSH<K>(c)));
     uint32_t cap = c.P.heap_lds;
-    uint4 v = LDS128(c.heap0 + ((i < cap ? i : cap - 1) << c.P.lw_shift));
+    uint4 v = LDS128(c.heap0 + ((i < cap ? i : cap - 1) << LWSH<K>(c)));
     if (i >= cap) v = c.spill[(size_t)(i - cap) * c.P.total_lanes];
     return v;
 }
 template <class K>
 __device__ __forceinline__ void heap_set(const Ctx& c, uint32_t i, const uint4& e) {
-    if (!K::SPILL || i < c.P.heap_lds) LDS128(c.heap0 + (i << c.P.lw_shift)) = e;
+    if (!K::SPILL || i < c.P.heap_lds) LDS128(c.heap0 + (i << LWSH<K>(c))) = e;
     else c.spill[(size_t)(i - c.P.heap_lds) * c.P.total_lanes] = e;
 }
 
@@ -275,23 +298,24 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
 }
 
 // ---- async-task wake / schedule [DEP A.7] -------------------------------------------------------
+template <class K>
 __device__ __forceinline__ void ready_push(const Ctx& c, Lane& L, uint32_t slot) {
-    if (L.ready_len >= c.P.max_tasks) { L.verdict = MADSIM_OVERFLOW; return; }
-    W(c, c.P.off_ready + L.ready_len) = slot;
+    RW(L.ready_len) = slot;
     L.ready_len++;
 }
 
+template <class K>
 __device__ __forceinline__ void wake(const Ctx& c, Lane& L, uint32_t slot, uint32_t gen) {
-    if (slot >= c.P.max_tasks) return;
     uint32_t f = TWORD(c, slot, 0, 0);
     if (!(f & TF_ALIVE) || ((f >> 8) & 0xffff) != gen) return;   // COMPLETED | CLOSED
     if (f & TF_SCHED) return;
     TWORD(c, slot, 0, 0) = f | TF_SCHED;
-    if (!(f & TF_RUN)) ready_push(c, L, slot);                   // RUNNING: run() re-queues after the poll
+    if (!(f & TF_RUN)) ready_push<K>(c, L, slot);                   // RUNNING: run() re-queues after the poll
 }
 
 // ---- Network -----------------------------------------------------------------------------------
 // Network::try_send's socket lookup (network.rs:304-306): the bound socket at addr(dst), if any.
+template <class K>
 __device__ __forceinline__ int find_bound(const Ctx& c, uint32_t addr) {
     if (c.P.uniq_addr) return (SW(c, addr, 0) & 1) ? (int)addr : -1;
     uint32_t key = SOCKW(c, addr) & 0xffff00ffu;
@@ -301,6 +325,7 @@ __device__ __forceinline__ int find_bound(const Ctx& c, uint32_t addr) {
 }
 
 // Mailbox::deliver (endpoint.rs:331-351)
+template <class K>
 __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t meta, uint32_t val) {
     uint32_t s = meta & 0x3f, from = (meta >> 6) & 0x3f, tag = (meta >> 12) & 0xff, sgen = (meta >> 20) & 0xff;
     uint32_t h = SW(c, s, 0);
@@ -323,14 +348,14 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
                 u0.w = val;
                 TU(c, slot, 0) = u0;
                 SW(c, s, 0) = (h & ~(0xfu << 9)) | (nreg << 9);
-                if (!sched && !(u0.x & TF_RUN)) ready_push(c, L, slot);
+                if (!sched && !(u0.x & TF_RUN)) ready_push<K>(c, L, slot);
                 return;
             }
         } else {
             i++;
         }
     }
-    if (nmsg >= c.P.mbox_msgs) { L.verdict = MADSIM_OVERFLOW; return; }
+    if (nmsg >= c.P.mbox_msgs) { L.ovf = 1; return; }
     SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);
     SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg + 1) = val;
     nmsg++;
@@ -340,31 +365,33 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
 // Timer::expire [DEP A.5]: fire every entry with deadline <= now
 template <class K>
 __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now) {
-    while (L.top_dl <= now && L.verdict == MADSIM_RUNNING) {
+    while (L.top_dl <= now) {
         uint4 e = timer_pop<K>(c, L);
         L.steps++;
         uint32_t kind = e.z >> 28;
-        if (kind == EV_WAKE) wake(c, L, e.z & 0xff, (e.z >> 8) & 0xffff);   // time/sleep.rs:52
-        else if (kind == EV_DELIVER) mailbox_deliver(c, L, e.z, e.w);      // net/mod.rs:323-330
+        if (kind == EV_WAKE) wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff);   // time/sleep.rs:52
+        else if (kind == EV_DELIVER) mailbox_deliver<K>(c, L, e.z, e.w);      // net/mod.rs:323-330
     }
 }
 
 // ---- task lifecycle ----------------------------------------------------------------------------
+template <class K>
 __device__ __forceinline__ void spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record) {
     uint32_t slot = 0;
     while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
-    if (slot >= c.P.max_tasks) { L.verdict = MADSIM_OVERFLOW; return; }
+    if (slot >= c.P.max_tasks) { L.ovf = 1; return; }
     uint32_t gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
     uint32_t pw = PROGW(c, prog);
     uint32_t node = pw & 0xff;
-    uint32_t killed = (W(c, c.P.off_nodes) >> node) & 1;
+    uint32_t killed = (NODEW(0) >> node) & 1;
     TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
     TU(c, slot, 1) = make_uint4(0xffu << 8, 0, 0, 0);        // rxseq 0, no awaiter
-    ready_push(c, L, slot);
-    if (record) W(c, c.P.off_handles + prog) = H_RUNNING | (slot << 8) | (gen << 16);
+    ready_push<K>(c, L, slot);
+    if (record) HW(prog) = H_RUNNING | (slot << 8) | (gen << 16);
 }
 
 // The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
+template <class K>
 __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome) {
     uint32_t f = TWORD(c, slot, 0, 0);
     uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
@@ -374,12 +401,12 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
         for (uint32_t i = 0; i < c.P.n_socks; i++)
             if ((SW(c, i, 0) & 1) && SW(c, i, 1) == own) SW(c, i, 0) &= ~1u;
     }
-    uint32_t h = W(c, c.P.off_handles + prog);
-    if (h == (H_RUNNING | (slot << 8) | (gen << 16))) W(c, c.P.off_handles + prog) = (h & ~3u) | outcome;
+    uint32_t h = HW(prog);
+    if (h == (H_RUNNING | (slot << 8) | (gen << 16))) HW(prog) = (h & ~3u) | outcome;
     uint32_t link = TWORD(c, slot, 1, 0);
     TWORD(c, slot, 0, 0) = f & ~(TF_ALIVE | TF_SCHED | TF_RUN | TF_INBOX);
     uint32_t j = (link >> 8) & 0xff;
-    if (j != 0xff) wake(c, L, j, link >> 16);              // async-task notifies the awaiter
+    if (j != 0xff) wake<K>(c, L, j, link >> 16);              // async-task notifies the awaiter
 }
 
 // TimeHandle::sleep_until (time/mod.rs:118-124): 1 ms floor
@@ -402,40 +429,41 @@ __device__ __forceinline__ bool is_light(uint32_t op) {
 // whole wave reaches at the same time.
 template <class K>
 __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t slot, uint4& u0) {
+    enum : uint32_t { ST_RUN = 0, ST_PENDING = 1, ST_FINISHED = 2, ST_PANIC = 3 };
     const KParams& P = c.P;
     uint4 u1 = TU(c, slot, 1);
     bool u1_dirty = false;
     uint32_t pc = u0.y & 0xffff, sub = (u0.y >> 16) & 0xff, from = u0.y >> 24;
     const uint32_t gen = (u0.x >> 8) & 0xffff;
     const uint32_t node = PROGW(c, u0.x >> 24) & 0xff;
-    bool panicked = false, pending = false, finished = false;
+    uint32_t st = ST_RUN;
 
-    while (!pending && !finished && !panicked && L.verdict == MADSIM_RUNNING) {
-        if (pc >= P.n_insns) { panicked = true; break; }
+    while (st == ST_RUN) {
+        if (pc >= P.n_insns) { st = ST_PANIC; break; }
         uint2 in = INSN(c, pc);
         uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
 
+        PROBE(5);
         // ================= [A] the task is parked on an await of this op =========================
         if (sub != 0) {
+            bool completed = false;                        // this op is done: step to the next one below
             if (op == MS_OP_RECV && sub == 1) {            // oneshot::Receiver (endpoint.rs:142-144)
-                if (!(u0.x & TF_INBOX)) { pending = true; break; }
+                if (!(u0.x & TF_INBOX)) { st = ST_PENDING; break; }
                 u0.x &= ~TF_INBOX;
                 from = u0.y >> 24;
                 sub = 2;                                   // -> rand_delay, begun in [C]
             } else if (op == MS_OP_YIELD) {
-                sub = 0; pc++;
-                continue;
+                completed = true;
             } else {                                       // a Sleep (time/sleep.rs:47-54)
                 uint64_t deadline = u64of(u1.z, u1.w);
                 if (L.clock < deadline) {                  // not elapsed: register ANOTHER timer
-                    if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.verdict = MADSIM_OVERFLOW;
-                    pending = true;
+                    if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+                    st = ST_PENDING;
                     break;
                 }
-                sub = 0;
                 if (op == MS_OP_BIND) {                    // Network::bind (network.rs:206-251)
                     uint32_t sw = SOCKW(c, a);
-                    if ((sw & 0xff) != node || find_bound(c, a) >= 0) { panicked = true; break; }
+                    if ((sw & 0xff) != node || find_bound<K>(c, a) >= 0) { st = ST_PANIC; break; }
                     uint32_t h = SW(c, a, 0);
                     SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);     // bound, gen+1, empty mailbox
                     SW(c, a, 1) = slot | (gen << 16);
@@ -444,28 +472,34 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     uint32_t src_node = SOCKW(c, a) & 0xff;
                     uint32_t dst_node = SOCKW(c, dst) & 0xff;
                     // Network::try_send -> test_link (network.rs:261-269, 296-313)
-                    bool clogged = ((W(c, P.off_clog + 1) >> src_node) & 1) | ((W(c, P.off_clog + 0) >> dst_node) & 1);
-                    if (P.has_clog_link) clogged |= (W(c, P.off_clog + 2 + src_node) >> dst_node) & 1;
+                    bool clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
+                    if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
                     if (!clogged && !gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) {
                         L.msg_count++;
                         uint64_t lat = sample_latency<K>(c, L);
-                        int ds = find_bound(c, dst);
+                        int ds = find_bound<K>(c, dst);
                         if (ds >= 0) {
                             uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
                             uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((b >> 8) << 12) | (a << 6) | (uint32_t)ds;
-                            if (!timer_add<K>(c, L, L.clock + lat, meta, imm)) L.verdict = MADSIM_OVERFLOW;
+                            if (!timer_add<K>(c, L, L.clock + lat, meta, imm)) L.ovf = 1;
                         }
                     }
                 }
-                pc++;
-                continue;                                  // fetch the next op
+                completed = true;
+            }
+            if (completed) {                               // fall through to [B]/[C] with the next op: one pass per poll
+                sub = 0; pc++;
+                if (pc >= P.n_insns) { st = ST_PANIC; break; }
+                in = INSN(c, pc);
+                op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
             }
         }
 
+        PROBE(6);
         // ================= [B] cheap ops that never await ========================================
         while (is_light(op)) {
             if (op == MS_OP_ASSERT_VAL) {
-                if (u0.w != imm) { panicked = true; break; }
+                if (u0.w != imm) { st = ST_PANIC; break; }
                 pc++;
             } else if (op == MS_OP_DJNZ) {
                 uint32_t sh = (a & 1) * 16;
@@ -483,12 +517,13 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 L.obs_hash = (L.obs_hash ^ v) * FNV_PRIME;
                 pc++;
             }
-            if (pc >= P.n_insns) { panicked = true; break; }
+            if (pc >= P.n_insns) { st = ST_PANIC; break; }
             in = INSN(c, pc);
             op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
         }
-        if (panicked) break;
+        if (st != ST_RUN) break;
 
+        PROBE(7);
         // ================= [C] begin the next op =================================================
         bool want_delay = false, want_sleep = false;
         uint64_t deadline = 0;
@@ -512,11 +547,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     sub = 2;                               // oneshot already holds the value
                     SW(c, a, 0) = (h & ~(0xfu << 13)) | (nmsg << 13);
                 } else {
-                    if (nreg >= P.mbox_regs) { L.verdict = MADSIM_OVERFLOW; break; }
+                    if (nreg >= P.mbox_regs) { L.ovf = 1; st = ST_PENDING; break; }
                     SW(c, a, 2 + nreg) = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
                     SW(c, a, 0) = (h & ~(0xfu << 9)) | ((nreg + 1) << 9);
                     sub = 1;
-                    pending = true;
+                    st = ST_PENDING;
                 }
             }
             want_delay = (sub == 2);                       // endpoint.rs:145 rand_delay
@@ -534,31 +569,31 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.y = pc | (sub << 16) | (from << 24);
                 TU(c, slot, 0) = u0;
                 if (u1_dirty) { TU(c, slot, 1) = u1; u1_dirty = false; }
-                task_finish(c, L, slot, H_COMPLETED);
+                task_finish<K>(c, L, slot, H_COMPLETED);
                 u0.x = TWORD(c, slot, 0, 0);
-                finished = true;
+                st = ST_FINISHED;
                 break;
             case MS_OP_SPAWN:
-                spawn_task(c, L, a, true);
+                spawn_task<K>(c, L, a, true);
                 pc++;
                 break;
             case MS_OP_BUILD:
                 for (uint32_t p = 1; p < P.n_progs; p++) {
                     uint32_t pw = PROGW(c, p);
-                    if ((pw & 0xff) == a && ((pw >> 8) & MADSIM_PROG_INIT) && !((pw >> 8) & MADSIM_PROG_PRE)) spawn_task(c, L, p, false);
+                    if ((pw & 0xff) == a && ((pw >> 8) & MADSIM_PROG_INIT) && !((pw >> 8) & MADSIM_PROG_PRE)) spawn_task<K>(c, L, p, false);
                 }
                 pc++;
                 break;
             case MS_OP_JOIN: {                             // task/join.rs:59-72 + async-task poll_task
-                uint32_t h = W(c, P.off_handles + a);
-                uint32_t st = h & 3;
-                if (st == H_RUNNING) {
+                uint32_t h = HW(a);
+                uint32_t hs = h & 3;
+                if (hs == H_RUNNING) {
                     uint32_t cs = (h >> 8) & 0xff;
                     uint32_t link = TWORD(c, cs, 1, 0);
                     TWORD(c, cs, 1, 0) = (link & 0xff) | (slot << 8) | (gen << 16);   // register awaiter
-                    pending = true;
-                } else if (st == H_NONE || ((st == H_CANCELLED) != ((b & 1) != 0))) {
-                    panicked = true;
+                    st = ST_PENDING;
+                } else if (hs == H_NONE || ((hs == H_CANCELLED) != ((b & 1) != 0))) {
+                    st = ST_PANIC;
                 } else {
                     pc++;
                 }
@@ -567,10 +602,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_YIELD:                              // [DEP tokio yield_now outside a runtime]
                 sub = 1;
                 u0.x |= TF_SCHED;                          // wake_by_ref while RUNNING
-                pending = true;
+                st = ST_PENDING;
                 break;
             case MS_OP_PANIC:
-                panicked = true;
+                st = ST_PANIC;
                 break;
             case MS_OP_MARK:
                 TU(c, slot, 2) = make_uint4((uint32_t)L.clock, (uint32_t)(L.clock >> 32), 0, 0);
@@ -580,7 +615,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 uint4 u2 = TU(c, slot, 2);
                 uint64_t el = L.clock - u64of(u2.x, u2.y), d = (uint64_t)b * NS_PER_S + imm;
                 bool ok = a == 0 ? el == d : a == 1 ? el >= d : el < d;
-                if (!ok) panicked = true; else pc++;
+                if (!ok) st = ST_PANIC; else pc++;
                 break;
             }
             case MS_OP_ADVANCE:                            // time/mod.rs:103-106
@@ -600,21 +635,21 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             }
             case MS_OP_CLOG_NODE:
-                if (b & 1) W(c, P.off_clog + 0) |= 1u << a;
-                if (b & 2) W(c, P.off_clog + 1) |= 1u << a;
+                if (b & 1) CLOGW(0) |= 1u << a;
+                if (b & 2) CLOGW(1) |= 1u << a;
                 pc++;
                 break;
             case MS_OP_UNCLOG_NODE:
-                if (b & 1) W(c, P.off_clog + 0) &= ~(1u << a);
-                if (b & 2) W(c, P.off_clog + 1) &= ~(1u << a);
+                if (b & 1) CLOGW(0) &= ~(1u << a);
+                if (b & 2) CLOGW(1) &= ~(1u << a);
                 pc++;
                 break;
             case MS_OP_CLOG_LINK:
-                W(c, P.off_clog + 2 + a) |= 1u << b;
+                CLOGW(2 + a) |= 1u << b;
                 pc++;
                 break;
             case MS_OP_UNCLOG_LINK:
-                W(c, P.off_clog + 2 + a) &= ~(1u << b);
+                CLOGW(2 + a) &= ~(1u << b);
                 pc++;
                 break;
             case MS_OP_SET_LOSS:
@@ -623,10 +658,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 pc++;
                 break;
             default:
-                panicked = true;
+                st = ST_PANIC;
                 break;
             }
         }
+        PROBE(8);
         if (want_delay) {                                  // NetSim::rand_delay (net/mod.rs:287-292)
             uint64_t delay = (uint64_t)gen_range_small<K, 5>(c, L) * 1000ull;
             if (P.buggify) {
@@ -638,22 +674,23 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (want_sleep) {                                  // first Sleep::poll: never elapsed (1 ms floor)
             u1.z = (uint32_t)deadline; u1.w = (uint32_t)(deadline >> 32); u1_dirty = true;
             sub = (op == MS_OP_RECV) ? 3 : 1;
-            if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.verdict = MADSIM_OVERFLOW;
-            pending = true;
+            if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+            st = ST_PENDING;
         }
     }
-    if (!finished) {
+    PROBE(9);
+    if (st != ST_FINISHED) {
         u0.y = pc | (sub << 16) | (from << 24);
         if (u1_dirty) TU(c, slot, 1) = u1;
     }
-    return panicked;
+    return st == ST_PANIC;
 }
 
 // ---- per-seed init: Runtime::with_seed_and_config (runtime/mod.rs:53-69) ------------------------
 template <class K>
 __device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     const KParams& P = c.P;
-    for (uint32_t w = 0; w < P.lane_words; w++) W(c, w) = 0;
+    for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;          // plane 0 is the ready queue: RW spans all planes
     for (uint32_t t = 0; t < P.max_tasks; t++) TWORD(c, t, 0, 0) = 0;
     // GlobalRng::new_with_seed -> Xoshiro256PlusPlus::seed_from_u64: SplitMix64 [DEP A.1]
     uint64_t x = seed, z;
@@ -661,17 +698,17 @@ __device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     SPLITMIX(L.s0); SPLITMIX(L.s1); SPLITMIX(L.s2); SPLITMIX(L.s3);
 #undef SPLITMIX
     L.rng_calls = 0; L.clock = 0; L.msg_count = 0; L.steps = 0;
-    L.ready_len = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING;
+    L.ready_len = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING; L.ovf = 0;
     L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
     // TimeRuntime::new (time/mod.rs:26-38): base_time draw, before logging is enabled
-    (void)gen_range_small<NoTrace, 31536000u>(c, L);
+    { uint64_t h = L.trace_hash, n = L.log_len; (void)gen_range_small<Variant<false, false, K::LWS>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n; }
     L.trace_hash = FNV_OFFSET; L.obs_hash = FNV_OFFSET; L.log_len = 0;
     // tasks spawned before block_on, then the main task (task/mod.rs:222-235)
     for (uint32_t p = 1; p < P.n_progs; p++) {
         uint32_t fl = (PROGW(c, p) >> 8) & 0xff;
-        if (fl & MADSIM_PROG_PRE) spawn_task(c, L, p, !(fl & MADSIM_PROG_INIT));
+        if (fl & MADSIM_PROG_PRE) spawn_task<K>(c, L, p, !(fl & MADSIM_PROG_INIT));
     }
-    spawn_task(c, L, 0, true);
+    spawn_task<K>(c, L, 0, true);
 }
 
 template <class K>
@@ -695,14 +732,23 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
     c.sockt0 = P.sh_socks;
     c.heap0 = P.sh_heap / 4 + lane;
     c.task0 = P.sh_tasks / 4 + lane;
-    c.pl = P.sh_planes + lane;
-    c.sock0 = c.pl + (P.off_socks << P.lw_shift);
+    c.lws = P.lw_shift;
+    const uint32_t pl = P.sh_planes + lane;
+    c.ready0 = pl + (P.off_ready << P.lw_shift);
+    c.sock0 = pl + (P.off_socks << P.lw_shift);
+    c.hand0 = pl + (P.off_handles << P.lw_shift);
+    c.node0 = pl + (P.off_nodes << P.lw_shift);
+    c.clog0 = pl + (P.off_clog << P.lw_shift);
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
     const uint32_t glane = (blockIdx.x << P.lw_shift) + lane;
     c.spill = P.spill ? P.spill + glane : nullptr;
     c.tlog = P.trace_log;
 
     Lane L;
+#ifdef EXP_PROF
+    for (int i = 0; i < 12; i++) L.prof_acc[i] = 0;
+    L.prof_t = __builtin_readcyclecounter(); uint64_t prof_iters = 0;
+#endif
     uint64_t next = glane;          // static striding: lane g runs seeds g, g+G, g+2G, ...
     bool have = false;
     for (;;) {
@@ -711,57 +757,62 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
             seed_init<K>(c, L, P.seed0 + next);
             have = true;
         }
-        // One iteration = the block_on loop body (task/mod.rs:239-259) taken as
-        //   [idle]  ready queue empty: is_finished / deadlock checks, advance_to_next_event
-        //   [poll]  ready queue non-empty: one run_all_ready iteration
-        // in that order, so a lane that was idle fires its timer AND polls the woken task in the same
-        // pass: all lanes of the wave walk the same two phases.
-
-        // ---------------- [idle] ----------------
-        if (L.ready_len == 0) {
-            uint32_t h0 = W(c, P.off_handles + 0);
-            if ((h0 & 3) != H_RUNNING) L.verdict = MADSIM_PASS;                       // :241-243
-            else if (L.heap_len == 0) L.verdict = MADSIM_DEADLOCK;                    // :250
-            else {
-                uint64_t t = L.top_dl + 50;                                           // time/mod.rs:47-53
-                timer_expire<K>(c, L, t);
-                L.clock = t;                                                          // :55, after the callbacks
-                if (L.verdict == MADSIM_RUNNING) {
-                    if (P.time_limit && L.clock >= P.time_limit) L.verdict = MADSIM_TIME_LIMIT;   // task/mod.rs:253-258
-                    else if (L.steps >= P.max_steps) L.verdict = MADSIM_STEP_LIMIT;
-                }
-            }
-        }
-        // ---------------- [poll] ----------------
-        if (L.verdict == MADSIM_RUNNING && L.ready_len > 0) {
+        // One iteration = one pass of the block_on loop body (task/mod.rs:239-259):
+        //   [poll]  ready queue non-empty: one run_all_ready iteration (pop, poll, 50..100 ns advance)
+        //   [fire]  Timer::expire up to `now`; while the queue stays empty: is_finished / deadlock checks
+        //           and advance_to_next_event, firing again — the ONLY place timers fire.
+        // A lane that polls and then runs dry fires its next timer in the same pass, so in steady state
+        // every lane does one poll and one timer fire per iteration and the wave stays in phase.
+#ifdef EXP_PROF
+        prof_iters++;
+#endif
+        uint64_t now = L.clock;
+        PROBE(0);
+        if (L.ready_len > 0) {
             // try_recv_random (utils/mpsc.rs:73-83): idx drawn even when len == 1
             uint32_t idx = gen_index<K>(c, L, L.ready_len);
-            uint32_t slot = W(c, P.off_ready + idx);
+            uint32_t slot = RW(idx);
             L.ready_len--;
-            W(c, P.off_ready + idx) = W(c, P.off_ready + L.ready_len);   // swap_remove
+            RW(idx) = RW(L.ready_len);                       // swap_remove
             uint4 u0 = TU(c, slot, 0);
             L.steps++;
             bool panicked = false;
+            PROBE(1);
             if (u0.x & (TF_CANCEL | TF_KILLED)) {            // task/mod.rs:269-273: drop(runnable)
-                task_finish(c, L, slot, H_CANCELLED);
+                task_finish<K>(c, L, slot, H_CANCELLED);
             } else {
                 u0.x = (u0.x & ~TF_SCHED) | TF_RUN;          // async-task run(): SCHEDULED -> RUNNING
                 panicked = poll_task<K>(c, L, slot, u0);
                 if (!panicked && (u0.x & TF_ALIVE)) {
-                    if (u0.x & TF_SCHED) ready_push(c, L, slot);   // woken while running: re-queue after the poll
+                    if (u0.x & TF_SCHED) ready_push<K>(c, L, slot);   // woken while running: re-queue after the poll
                     u0.x &= ~TF_RUN;
                     TU(c, slot, 0) = u0;
                 }
             }
-            if (panicked) {
-                if (L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_PANIC;   // resume_unwind (:315)
-            } else if (L.verdict == MADSIM_RUNNING) {
-                // task/mod.rs:319-321: advance 50..100 ns, then Timer::expire (time/mod.rs:103-106)
-                L.clock += 50 + gen_range_small<K, 50>(c, L);
-                timer_expire<K>(c, L, L.clock);
-                if (L.steps >= P.max_steps && L.verdict == MADSIM_RUNNING) L.verdict = MADSIM_STEP_LIMIT;
-            }
+            PROBE(2);
+            if (panicked) L.verdict = MADSIM_PANIC;          // resume_unwind (:315): no advance, no expire
+            else L.clock += 50 + gen_range_small<K, 50>(c, L);   // :319-321, then Timer::expire (time/mod.rs:103-106)
+            now = L.clock;
+            PROBE(3);
         }
+        bool idle_jump = false;
+        while (L.verdict == MADSIM_RUNNING) {
+            timer_expire<K>(c, L, now);
+            if (idle_jump) {
+                L.clock = now;                                // time/mod.rs:55: after the callbacks
+                idle_jump = false;
+                if (P.time_limit && L.clock >= P.time_limit) { L.verdict = MADSIM_TIME_LIMIT; break; }   // task/mod.rs:253-258
+            }
+            if (L.steps >= P.max_steps) { L.verdict = MADSIM_STEP_LIMIT; break; }
+            if (L.ready_len > 0) break;                       // back to run_all_ready
+            uint32_t h0 = HW(0);
+            if ((h0 & 3) != H_RUNNING) { L.verdict = MADSIM_PASS; break; }                // :241-243
+            if (L.heap_len == 0) { L.verdict = MADSIM_DEADLOCK; break; }                  // :250
+            now = L.top_dl + 50;                              // advance_to_next_event (time/mod.rs:47-53)
+            idle_jump = true;
+        }
+        PROBE(4);
+        if (L.ovf) L.verdict = MADSIM_OVERFLOW;
         if (L.verdict != MADSIM_RUNNING) {
             madsim_result_t r;
             r.verdict = L.verdict; r.steps = L.steps; r.clock_ns = L.clock; r.msg_count = L.msg_count;
@@ -772,6 +823,9 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
             next += P.total_lanes;
         }
     }
+#ifdef EXP_PROF
+    if (lane == 0 && P.prof) { for (int i = 0; i < 12; i++) atomicAdd((unsigned long long*)&P.prof[i], (unsigned long long)L.prof_acc[i]); atomicAdd((unsigned long long*)&P.prof[12], (unsigned long long)prof_iters); atomicAdd((unsigned long long*)&P.prof[13], 1ull); }
+#endif
 }
 
 #ifndef MADSIM_EMU
@@ -801,9 +855,9 @@ __global__ __launch_bounds__(256) void summary_kernel(const madsim_result_t* __r
 extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace) {
     using namespace madsim_k;
     const bool spill = P->spill != nullptr && P->heap_spill > 0;
-    if (trace) hipLaunchKernelGGL((sim_kernel<Variant<true, true>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
-    else if (spill) hipLaunchKernelGGL((sim_kernel<Variant<false, true>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
-    else hipLaunchKernelGGL((sim_kernel<Variant<false, false>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    if (trace) hipLaunchKernelGGL((sim_kernel<Variant<true, true, -1>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    else if (spill || P->lw_shift != 6) hipLaunchKernelGGL((sim_kernel<Variant<false, true, -1>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    else hipLaunchKernelGGL((sim_kernel<Variant<false, false, 6>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
 }
 
 extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream) {
@@ -815,11 +869,11 @@ extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t cou
 
 extern "C" int madsim_k_set_max_lds(uint32_t lds_bytes) {
     using namespace madsim_k;
-    hipError_t e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, false>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, false, 6>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, true, -1>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<true, true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<true, true, -1>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     return (int)e;
 }
 #endif  // !MADSIM_EMU

@@ -21,7 +21,7 @@ import numpy as np
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmadsim_hip.so")
+LIB_PATH = os.environ.get("MADSIM_HIP_LIB", os.path.join(_HERE, "libmadsim_hip.so"))   # override: A/B builds of the same library
 
 
 class MadsimHipError(RuntimeError):

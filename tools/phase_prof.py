@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown from an EXP_PROF build (MADSIM_HIP_LIB=.../libmadsim_hip_prof.so)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from madsim_amd import runtime, workload, _abi as A
+import torch
+runtime.init(0)
+w = workload.pingpong(4, 64)
+lim = A.Limits(); lim.heap_lds_slots = 8; lim.mbox_regs = lim.mbox_msgs = 1
+buf = torch.empty(65536 * 48, dtype=torch.uint8, device="cuda")
+out = (C.c_uint64 * 16)()
+L = runtime.lib()
+runtime.run_batch_device(w, 0, 65536, buf.data_ptr(), 0, None, lim)
+L.madsim_hip_debug_counters(out)
+s = runtime.run_batch_device(w, 65536, 65536, buf.data_ptr(), 0, None, lim)
+L.madsim_hip_debug_counters(out)
+v = list(out)
+names = ["loop top/seed init+result", "idx draw + ready pop + task load", "poll_task exit (writeback u1)", "writeback + advance draw", "fire/idle loop",
+         "poll: entry, u1 load, insn fetch", "poll [A] await check + completion (try_send)", "poll [B] light ops", "poll [C] begin op (mailbox / rare switch)", "poll [C] rand_delay draw + timer push"]
+waves, iters = v[13], v[12]
+tot = sum(v[:10])
+print(f"kernel {s.kernel_ms:.3f} ms, waves {waves}, iterations/wave {iters / waves:.0f}, cycles/wave {tot / waves:.0f}")
+for i, n in enumerate(names):
+    if i >= len(v): break
+    print(f"  {n:36s} {v[i] / waves:12.0f} cycles/wave  {100 * v[i] / tot:5.1f} %   {v[i] / iters:8.0f} cycles/iteration")
