@@ -93,6 +93,11 @@ enum madsim_op {
                               c.packet_loss_rate = ..) (net/mod.rs:138-141)                          */
     MS_OP_SLEEP_RAND = 40, /* sleep(thread_rng().gen_range(0 .. b s + imm ns)): the randomised fault
                               loop of tonic-example/tests/test.rs:198-201 (UniformDuration, A.3)     */
+    /* -- shared test flags: the Arc<AtomicUsize> the reference's tests observe (task/mod.rs:864-1015) -- */
+    MS_OP_GSET = 41,       /* a=flag(0..3): flag.store(imm)                                         */
+    MS_OP_GADD = 42,       /* a=flag: flag.fetch_add(imm)                                            */
+    MS_OP_ASSERT_G = 43,   /* a=flag: assert_eq!(flag.load(), imm)                                   */
+    MS_OP_PANIC_IF_G_LT = 44, /* a=flag: if flag.load() < imm { panic!() }                            */
     MS_OP__COUNT
 };
 

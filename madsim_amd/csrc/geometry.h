@@ -98,6 +98,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     bool restarts = uses_op(w, MS_OP_RESTART);
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) restarts |= (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) != 0;
     P.max_tasks = L.max_tasks ? L.max_tasks : w->n_progs + (restarts ? w->n_progs : 0);
+    if (P.max_tasks > 254) P.max_tasks = 254;
     if (P.max_tasks > 254) return fail(err, MADSIM_E_LIMITS, "max_tasks must be <= 254");
     P.mbox_regs = L.mbox_regs ? L.mbox_regs : 2;
     P.mbox_msgs = L.mbox_msgs ? L.mbox_msgs : 2;
@@ -116,8 +117,20 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.off_socks = P.off_ready + P.max_tasks;
     P.off_handles = P.off_socks + P.n_socks * P.sock_words;
     P.off_nodes = P.off_handles + P.n_progs;
-    P.off_clog = P.off_nodes + 2;
-    P.lane_words = P.off_clog + 2 + (P.has_clog_link ? P.n_nodes + 1 : 0);
+    // node region: killed / paused / gen0_killed masks, spawn counter, one info_gen byte per node
+    P.off_clog = P.off_nodes + 4 + (P.n_nodes + 4) / 4;
+    P.off_pause = P.off_clog + 2 + (P.has_clog_link ? P.n_nodes + 1 : 0);
+    P.uses_pause = uses_op(w, MS_OP_PAUSE);
+    P.off_greg = P.off_pause + (P.uses_pause ? 1 + P.max_tasks : 0);
+    bool gregs = uses_op(w, MS_OP_GSET) || uses_op(w, MS_OP_GADD) || uses_op(w, MS_OP_ASSERT_G) || uses_op(w, MS_OP_PANIC_IF_G_LT);
+    P.lane_words = P.off_greg + (gregs ? 4 : 0);
+    P.restart_nodes = 0;
+    for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
+        if (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) P.restart_nodes |= 1u << i;
+    P.has_restart_on_panic = P.restart_nodes != 0;
+    P.lifecycle = P.has_restart_on_panic || uses_op(w, MS_OP_KILL) || uses_op(w, MS_OP_RESTART) || uses_op(w, MS_OP_PAUSE) ||
+                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT);
+    for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.lifecycle = 1;
     P.sh_insns = 0;
     P.sh_progs = P.sh_insns + 2 * P.n_insns;
     P.sh_socks = P.sh_progs + P.n_progs;

@@ -56,7 +56,9 @@ enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 // Compile-time kernel variant: TRACE = also emit the raw determinism log (single-seed trace mode);
 // SPILL = the timer heap may overflow from LDS into the HBM spill region.
 // LWS = log2(lane stride) when known at compile time (6: full 64-lane waves), or -1: read it from KParams.
-template <bool TRACE_, bool SPILL_, int LWS_> struct Variant { static constexpr bool TRACE = TRACE_, SPILL = SPILL_; static constexpr int LWS = LWS_; };
+// LIFE = the workload uses node lifecycle (kill/restart/pause/abort ops, init programs, restart_on_panic);
+// the fast variant compiles that cold code out of the hot loop.
+template <bool TRACE_, bool SPILL_, int LWS_, bool LIFE_> struct Variant { static constexpr bool TRACE = TRACE_, SPILL = SPILL_, LIFE = LIFE_; static constexpr int LWS = LWS_; };
 
 #ifdef EXP_PROF
 #define PROBE(i) do { uint64_t t_ = __builtin_readcyclecounter(); L.prof_acc[i] += t_ - L.prof_t; L.prof_t = t_; } while (0)
@@ -84,6 +86,7 @@ struct Lane {
 #ifdef EXP_PROF
     uint64_t prof_acc[12]; uint64_t prof_t;
 #endif
+    uint32_t main_done;  // handle[0] left H_RUNNING: block_on's task.is_finished()
     uint32_t ovf;        // sticky: a device capacity was exceeded this iteration (=> MADSIM_OVERFLOW)
     // runtime-mutable net config (MS_OP_SET_LOSS)
     uint64_t loss_pint;
@@ -105,7 +108,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t madsim_smem[];
 struct Ctx {
     const KParams& P;
     uint32_t lws;        // log2(lane stride) (runtime copy; K::LWS overrides when >= 0)
-    uint32_t ready0, hand0, node0, clog0;   // word indices of this lane's plane regions
+    uint32_t ready0, hand0, node0, clog0, pause0, greg0;   // word indices of this lane's plane regions
     uint32_t sock0;      // word index of this lane's socket region
     uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + (i << lws))
     uint32_t task0;      // uint4 index of task unit 0
@@ -121,6 +124,10 @@ template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { retu
 #define HW(p) SMEM[c.hand0 + ((p) << LWSH<K>(c))]
 #define NODEW(i) SMEM[c.node0 + ((i) << LWSH<K>(c))]
 #define CLOGW(i) SMEM[c.clog0 + ((i) << LWSH<K>(c))]
+#define PAUSEW(i) SMEM[c.pause0 + ((i) << LWSH<K>(c))]   /* [0] = length, [1..] = paused Runnables in pop order */
+#define GREGW(i) SMEM[c.greg0 + ((i) << LWSH<K>(c))]
+// node region: [0] killed mask, [1] paused mask, [2] gen0_killed mask, [3] spawn counter, [4 + n/4] info_gen bytes
+#define NODE_INFO_GEN(n_) ((NODEW(4 + ((n_) >> 2)) >> (((n_) & 3) * 8)) & 0xff)
 #define SW(c_, s_, f_) SMEM[(c_).sock0 + (((s_) * (c_).P.sock_words + (f_)) << LWSH<K>(c_))]
 #define TU(c_, slot_, u_) LDS128((c_).task0 + (((slot_) * (c_).P.task_units + (u_)) << LWSH<K>(c_)))
 #define TWORD(c_, slot_, u_, k_) SMEM[((c_).task0 + (((slot_) * (c_).P.task_units + (u_)) << LWSH<K>(c_))) * 4 + (k_)]
@@ -247,6 +254,7 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos
     uint64_t hd = ev_deadline(hole);
     while (pos > 0) {
         uint32_t parent = (pos - 1) >> 1;
+        if (parent == 0 && hd >= L.top_dl) break;      // root deadline is mirrored in a register
         uint4 p = heap_get<K>(c, parent);
         if (hd >= ev_deadline(p)) break;     // hole <= parent in heap order: stop
         heap_set<K>(c, pos, p);
@@ -362,6 +370,8 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     SW(c, s, 0) = (h & ~((0xfu << 9) | (0xfu << 13))) | (nreg << 9) | (nmsg << 13);
 }
 
+template <class K> __device__ void node_restart(const Ctx& c, Lane& L, uint32_t node);
+
 // Timer::expire [DEP A.5]: fire every entry with deadline <= now
 template <class K>
 __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now) {
@@ -371,21 +381,32 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
         uint32_t kind = e.z >> 28;
         if (kind == EV_WAKE) wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff);   // time/sleep.rs:52
         else if (kind == EV_DELIVER) mailbox_deliver<K>(c, L, e.z, e.w);      // net/mod.rs:323-330
+        else if (K::LIFE && kind == EV_RESTART) node_restart<K>(c, L, e.z & 0xff);   // task/mod.rs:313
     }
 }
 
 // ---- task lifecycle ----------------------------------------------------------------------------
+// `via_handle`: spawned through a NodeHandle captured at build() (NodeHandle::spawn from another node's task:
+// that Spawner holds the ORIGINAL Arc<NodeInfo>); otherwise task::spawn / init on the node's current info.
 template <class K>
-__device__ __forceinline__ void spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record) {
+__device__ __forceinline__ void spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record, bool via_handle = false) {
     uint32_t slot = 0;
     while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
     if (slot >= c.P.max_tasks) { L.ovf = 1; return; }
     uint32_t gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
     uint32_t pw = PROGW(c, prog);
     uint32_t node = pw & 0xff;
-    uint32_t killed = (NODEW(0) >> node) & 1;
+    uint32_t killed = 0, info_gen = 0;
+    if (K::LIFE) {
+        uint32_t cur_gen = NODE_INFO_GEN(node);
+        info_gen = cur_gen;
+        if (via_handle && cur_gen != 0) { killed = 1; info_gen = 0; }             // stale handle: dead info
+        else killed = ((via_handle ? NODEW(2) : NODEW(0)) >> node) & 1;          // task/mod.rs:632-634
+    }
+    uint32_t seq = NODEW(3);
+    NODEW(3) = seq + 1;
     TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
-    TU(c, slot, 1) = make_uint4(0xffu << 8, 0, 0, 0);        // rxseq 0, no awaiter
+    TU(c, slot, 1) = make_uint4(0xffu << 8, (seq & 0xffffff) | (info_gen << 24), 0, 0);   // rxseq 0, no awaiter; spawn order
     ready_push<K>(c, L, slot);
     if (record) HW(prog) = H_RUNNING | (slot << 8) | (gen << 16);
 }
@@ -402,11 +423,77 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
             if ((SW(c, i, 0) & 1) && SW(c, i, 1) == own) SW(c, i, 0) &= ~1u;
     }
     uint32_t h = HW(prog);
-    if (h == (H_RUNNING | (slot << 8) | (gen << 16))) HW(prog) = (h & ~3u) | outcome;
+    if (h == (H_RUNNING | (slot << 8) | (gen << 16))) { HW(prog) = (h & ~3u) | outcome; if (prog == 0) L.main_done = 1; }
     uint32_t link = TWORD(c, slot, 1, 0);
     TWORD(c, slot, 0, 0) = f & ~(TF_ALIVE | TF_SCHED | TF_RUN | TF_INBOX);
     uint32_t j = (link >> 8) & 0xff;
     if (j != 0xff) wake<K>(c, L, j, link >> 16);              // async-task notifies the awaiter
+}
+
+// NodeInfo::kill (task/mod.rs:133-140): mark + wake every live task holding NodeInfo `info_gen` of `node`, in
+// spawn order (the order of NodeInfo.tasks).  Tasks carry their spawn sequence number, so no list is stored.
+template <class K>
+__device__ void info_kill(const Ctx& c, Lane& L, uint32_t node, uint32_t info_gen) {
+    uint32_t last = 0xffffffffu;                            // "none yet": sequence numbers are < 2^24
+    for (;;) {
+        uint32_t best = 0xffffffffu, best_seq = 0xffffffffu;
+        for (uint32_t t = 0; t < c.P.max_tasks; t++) {
+            uint32_t f = TWORD(c, t, 0, 0);
+            if (!(f & TF_ALIVE) || (PROGW(c, f >> 24) & 0xff) != node) continue;
+            uint32_t sw = TWORD(c, t, 1, 1);
+            uint32_t seq = sw & 0xffffff;
+            if ((sw >> 24) != info_gen) continue;
+            if ((last == 0xffffffffu || seq > last) && seq < best_seq) { best = t; best_seq = seq; }
+        }
+        if (best == 0xffffffffu) break;
+        uint32_t f = TWORD(c, best, 0, 0);
+        TWORD(c, best, 0, 0) = f | TF_KILLED;
+        wake<K>(c, L, best, (f >> 8) & 0xffff);
+        last = best_seq;
+    }
+}
+
+template <class K>
+__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome);
+
+// node.paused.clear() (task/mod.rs:365,392): the parked Runnables of `node` are dropped, in order.
+template <class K>
+__device__ void paused_clear(const Ctx& c, Lane& L, uint32_t node) {
+    if (!c.P.uses_pause) return;
+    uint32_t n = PAUSEW(0), keep = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t slot = PAUSEW(1 + i);
+        if ((PROGW(c, TWORD(c, slot, 0, 0) >> 24) & 0xff) == node) task_finish<K>(c, L, slot, H_CANCELLED);
+        else { PAUSEW(1 + keep) = slot; keep++; }
+    }
+    PAUSEW(0) = keep;
+}
+
+template <class K>
+__device__ void node_kill(const Ctx& c, Lane& L, uint32_t node) {        // TaskHandle::kill_id (task/mod.rs:362-371)
+    paused_clear<K>(c, L, node);
+    uint32_t g = NODE_INFO_GEN(node);
+    NODEW(0) |= 1u << node;
+    if (g == 0) NODEW(2) |= 1u << node;
+    info_kill<K>(c, L, node, g);
+    for (uint32_t i = 0; i < c.P.n_socks; i++)               // NetSim::reset_node (network.rs:142-147)
+        if ((SOCKW(c, i) & 0xff) == node) SW(c, i, 0) &= ~1u;
+}
+
+template <class K>
+__device__ void node_restart(const Ctx& c, Lane& L, uint32_t node) {     // TaskHandle::restart (task/mod.rs:374-401)
+    uint32_t g = NODE_INFO_GEN(node);
+    if (g == 0) NODEW(2) |= 1u << node;
+    uint32_t w = NODEW(4 + (node >> 2)), sh = (node & 3) * 8;
+    NODEW(4 + (node >> 2)) = (w & ~(0xffu << sh)) | (((g + 1) & 0xff) << sh);      // new_info
+    NODEW(0) &= ~(1u << node);
+    NODEW(1) &= ~(1u << node);
+    paused_clear<K>(c, L, node);
+    info_kill<K>(c, L, node, g);                             // old_info.kill()
+    for (uint32_t p = 1; p < c.P.n_progs; p++) {             // init(&Spawner { new info })
+        uint32_t pw = PROGW(c, p);
+        if ((pw & 0xff) == node && ((pw >> 8) & MADSIM_PROG_INIT)) spawn_task<K>(c, L, p, false);
+    }
 }
 
 // TimeHandle::sleep_until (time/mod.rs:118-124): 1 ms floor
@@ -569,12 +656,19 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.y = pc | (sub << 16) | (from << 24);
                 TU(c, slot, 0) = u0;
                 if (u1_dirty) { TU(c, slot, 1) = u1; u1_dirty = false; }
+                // an init task is `async { future.await; h.exit() }` (runtime/mod.rs:362-370): Spawner::exit =
+                // NodeInfo::kill on the info it was spawned with (task/mod.rs:657-661), before the future drops
+                if (K::LIFE && ((PROGW(c, u0.x >> 24) >> 8) & MADSIM_PROG_INIT) && (u1.y >> 24) == NODE_INFO_GEN(node)) {
+                    NODEW(0) |= 1u << node;
+                    if ((u1.y >> 24) == 0) NODEW(2) |= 1u << node;
+                    info_kill<K>(c, L, node, u1.y >> 24);
+                }
                 task_finish<K>(c, L, slot, H_COMPLETED);
                 u0.x = TWORD(c, slot, 0, 0);
                 st = ST_FINISHED;
                 break;
             case MS_OP_SPAWN:
-                spawn_task<K>(c, L, a, true);
+                spawn_task<K>(c, L, a, true, (PROGW(c, a) & 0xff) != node);
                 pc++;
                 break;
             case MS_OP_BUILD:
@@ -607,6 +701,52 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_PANIC:
                 st = ST_PANIC;
                 break;
+            case MS_OP_ABORT: {                            // AbortHandle::abort (task/join.rs:158-163)
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint32_t h = HW(a);
+                if ((h & 3) == H_RUNNING) {
+                    uint32_t cs = (h >> 8) & 0xff;
+                    TWORD(c, cs, 0, 0) |= TF_CANCEL;
+                    wake<K>(c, L, cs, h >> 16);
+                }
+                pc++;
+                break;
+            }
+            case MS_OP_KILL: case MS_OP_RESTART:
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                u0.y = pc | (sub << 16) | (from << 24);     // this task may be woken/killed by the call: sync LDS first
+                TU(c, slot, 0) = u0;
+                if (op == MS_OP_KILL) node_kill<K>(c, L, a); else node_restart<K>(c, L, a);
+                u0.x = TWORD(c, slot, 0, 0);
+                pc++;
+                break;
+            case MS_OP_PAUSE:                               // task/mod.rs:404-410
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                NODEW(1) |= 1u << a;
+                pc++;
+                break;
+            case MS_OP_RESUME: {                            // task/mod.rs:413-424: parked Runnables go back, in order
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                NODEW(1) &= ~(1u << a);
+                if (P.uses_pause) {
+                    uint32_t n = PAUSEW(0), keep = 0;
+                    for (uint32_t i = 0; i < n; i++) {
+                        uint32_t ps = PAUSEW(1 + i);
+                        if ((PROGW(c, TWORD(c, ps, 0, 0) >> 24) & 0xff) == a) ready_push<K>(c, L, ps);
+                        else { PAUSEW(1 + keep) = ps; keep++; }
+                    }
+                    PAUSEW(0) = keep;
+                }
+                pc++;
+                break;
+            }
+            case MS_OP_ASSERT_EXIT:                         // Handle::is_exit (task/mod.rs:444-449)
+                if (((NODEW(0) >> a) & 1) != (b & 1)) st = ST_PANIC; else pc++;
+                break;
+            case MS_OP_GSET: GREGW(a & 3) = imm; pc++; break;
+            case MS_OP_GADD: GREGW(a & 3) += imm; pc++; break;
+            case MS_OP_ASSERT_G: if (GREGW(a & 3) != imm) st = ST_PANIC; else pc++; break;
+            case MS_OP_PANIC_IF_G_LT: if (GREGW(a & 3) < imm) st = ST_PANIC; else pc++; break;
             case MS_OP_MARK:
                 TU(c, slot, 2) = make_uint4((uint32_t)L.clock, (uint32_t)(L.clock >> 32), 0, 0);
                 pc++;
@@ -698,10 +838,10 @@ __device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     SPLITMIX(L.s0); SPLITMIX(L.s1); SPLITMIX(L.s2); SPLITMIX(L.s3);
 #undef SPLITMIX
     L.rng_calls = 0; L.clock = 0; L.msg_count = 0; L.steps = 0;
-    L.ready_len = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING; L.ovf = 0;
+    L.ready_len = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING; L.ovf = 0; L.main_done = 0;
     L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
     // TimeRuntime::new (time/mod.rs:26-38): base_time draw, before logging is enabled
-    { uint64_t h = L.trace_hash, n = L.log_len; (void)gen_range_small<Variant<false, false, K::LWS>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n; }
+    { uint64_t h = L.trace_hash, n = L.log_len; (void)gen_range_small<Variant<false, false, K::LWS, false>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n; }
     L.trace_hash = FNV_OFFSET; L.obs_hash = FNV_OFFSET; L.log_len = 0;
     // tasks spawned before block_on, then the main task (task/mod.rs:222-235)
     for (uint32_t p = 1; p < P.n_progs; p++) {
@@ -739,6 +879,8 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
     c.hand0 = pl + (P.off_handles << P.lw_shift);
     c.node0 = pl + (P.off_nodes << P.lw_shift);
     c.clog0 = pl + (P.off_clog << P.lw_shift);
+    c.pause0 = pl + (P.off_pause << P.lw_shift);
+    c.greg0 = pl + (P.off_greg << P.lw_shift);
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
     const uint32_t glane = (blockIdx.x << P.lw_shift) + lane;
     c.spill = P.spill ? P.spill + glane : nullptr;
@@ -778,8 +920,14 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
             L.steps++;
             bool panicked = false;
             PROBE(1);
-            if (u0.x & (TF_CANCEL | TF_KILLED)) {            // task/mod.rs:269-273: drop(runnable)
+            bool parked = false;
+            if (K::LIFE && (u0.x & (TF_CANCEL | TF_KILLED))) {   // task/mod.rs:269-273: drop(runnable)
                 task_finish<K>(c, L, slot, H_CANCELLED);
+            } else if (K::LIFE && P.uses_pause && ((NODEW(1) >> (PROGW(c, u0.x >> 24) & 0xff)) & 1)) {
+                uint32_t n = PAUSEW(0);                       // :274-277: park the Runnable; no poll, no time advance
+                PAUSEW(1 + n) = slot; PAUSEW(0) = n + 1;
+                L.steps--;
+                parked = true;
             } else {
                 u0.x = (u0.x & ~TF_SCHED) | TF_RUN;          // async-task run(): SCHEDULED -> RUNNING
                 panicked = poll_task<K>(c, L, slot, u0);
@@ -790,8 +938,25 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
                 }
             }
             PROBE(2);
+            if (K::LIFE && panicked && P.has_restart_on_panic) {   // task/mod.rs:289-314
+                uint32_t node = PROGW(c, u0.x >> 24) & 0xff;
+                if ((P.restart_nodes >> node) & 1) {
+                    // async-task's panic guard already dropped the future and notified the awaiter
+                    TU(c, slot, 0) = u0;
+                    task_finish<K>(c, L, slot, H_CANCELLED);
+                    // delay = gen_range(1 s..10 s) in ONE with(): UniformDuration Medium path [DEP A.3]
+                    const uint64_t range = 9000000000ull, zone = ~0ull - ((~0ull - range + 1) % range);
+                    uint64_t v;
+                    do { v = rng_next(L); } while (v * range > zone);
+                    rng_log<K>(c, L);
+                    uint64_t delay = NS_PER_S + __umul64hi(v, range);
+                    node_kill<K>(c, L, node);                 // self.kill(node_id)
+                    if (!timer_add<K>(c, L, L.clock + delay, (EV_RESTART << 28) | node, 0)) L.ovf = 1;
+                    panicked = false;
+                }
+            }
             if (panicked) L.verdict = MADSIM_PANIC;          // resume_unwind (:315): no advance, no expire
-            else L.clock += 50 + gen_range_small<K, 50>(c, L);   // :319-321, then Timer::expire (time/mod.rs:103-106)
+            else if (!parked) L.clock += 50 + gen_range_small<K, 50>(c, L);   // :319-321, then Timer::expire (time/mod.rs:103-106)
             now = L.clock;
             PROBE(3);
         }
@@ -805,8 +970,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
             }
             if (L.steps >= P.max_steps) { L.verdict = MADSIM_STEP_LIMIT; break; }
             if (L.ready_len > 0) break;                       // back to run_all_ready
-            uint32_t h0 = HW(0);
-            if ((h0 & 3) != H_RUNNING) { L.verdict = MADSIM_PASS; break; }                // :241-243
+            if (L.main_done) { L.verdict = MADSIM_PASS; break; }                          // :241-243
             if (L.heap_len == 0) { L.verdict = MADSIM_DEADLOCK; break; }                  // :250
             now = L.top_dl + 50;                              // advance_to_next_event (time/mod.rs:47-53)
             idle_jump = true;
@@ -855,9 +1019,9 @@ __global__ __launch_bounds__(256) void summary_kernel(const madsim_result_t* __r
 extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace) {
     using namespace madsim_k;
     const bool spill = P->spill != nullptr && P->heap_spill > 0;
-    if (trace) hipLaunchKernelGGL((sim_kernel<Variant<true, true, -1>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
-    else if (spill || P->lw_shift != 6) hipLaunchKernelGGL((sim_kernel<Variant<false, true, -1>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
-    else hipLaunchKernelGGL((sim_kernel<Variant<false, false, 6>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    if (trace) hipLaunchKernelGGL((sim_kernel<Variant<true, true, -1, true>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    else if (spill || P->lw_shift != 6 || P->lifecycle) hipLaunchKernelGGL((sim_kernel<Variant<false, true, -1, true>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    else hipLaunchKernelGGL((sim_kernel<Variant<false, false, 6, false>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
 }
 
 extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream) {
@@ -869,11 +1033,11 @@ extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t cou
 
 extern "C" int madsim_k_set_max_lds(uint32_t lds_bytes) {
     using namespace madsim_k;
-    hipError_t e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, false, 6>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, false, 6, false>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, true, -1>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, true, -1, true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<true, true, -1>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<true, true, -1, true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     return (int)e;
 }
 #endif  // !MADSIM_EMU

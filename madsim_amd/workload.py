@@ -150,6 +150,19 @@ class TaskBuilder:
     def set_loss(self, table_index):
         return self._emit("SET_LOSS", a=table_index)
 
+    # -- shared flags (Arc<AtomicUsize> in the reference's tests) ------------------------------------
+    def flag_store(self, flag, value):
+        return self._emit("GSET", a=flag, imm=value)
+
+    def flag_add(self, flag, value):
+        return self._emit("GADD", a=flag, imm=value)
+
+    def assert_flag(self, flag, value):
+        return self._emit("ASSERT_G", a=flag, imm=value)
+
+    def panic_if_flag_lt(self, flag, value):
+        return self._emit("PANIC_IF_G_LT", a=flag, imm=value)
+
     def sleep_rand(self, **kw):
         b, imm = _dur(**kw)
         return self._emit("SLEEP_RAND", b=b, imm=imm)

@@ -101,6 +101,7 @@ typedef struct {
     uint8_t  alive;        /* the future exists (spawned, not yet completed/dropped)                 */
     uint16_t gen;
     uint8_t  prog, node;
+    uint8_t  info_gen;     /* which NodeInfo of its node this task holds                             */
     uint8_t  killed;       /* this task's Arc<NodeInfo>.killed                                       */
     uint8_t  cancelled;    /* TaskInfo.cancelled (task/mod.rs:84)                                    */
     uint8_t  scheduled, running;          /* async-task SCHEDULED / RUNNING bits            [DEP A.7] */
@@ -117,9 +118,13 @@ typedef struct {
 enum { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 typedef struct { uint8_t state; uint16_t slot, gen; } handle_t;
 
+typedef struct { uint16_t slot, gen; } tref_t;
 typedef struct {
-    uint8_t killed, paused;
+    uint8_t killed, paused;               /* the CURRENT Arc<NodeInfo>'s flags (task/mod.rs:100-103)  */
+    uint8_t info_gen;                     /* how many times Handle::restart replaced the NodeInfo     */
+    uint8_t gen0_killed;                  /* the NodeInfo captured by NodeHandles at build() is dead  */
     VEC(uint16_t) paused_list;            /* Node.paused: Vec<Runnable> (task/mod.rs:345-350)        */
+    VEC(tref_t) tasks;                    /* NodeInfo.tasks: Vec<Weak<TaskInfo>> in spawn order (:105) */
 } node_t;
 
 typedef struct {
@@ -144,6 +149,7 @@ typedef struct {
     const madsim_config_t* cfg;
     /* accounting */
     uint64_t msg_count; uint32_t steps; uint64_t obs_hash;
+    uint32_t greg[4];                     /* Arc<AtomicUsize> flags shared by the test's tasks       */
     uint32_t panic; int main_slot;
     madsim_oracle_stats_t st;
 } sim_t;
@@ -349,7 +355,11 @@ static void sock_close_owned(sim_t* S, uint16_t slot, uint16_t gen, int node_kil
     }
 }
 
-static int spawn_task(sim_t* S, unsigned prog, int record_handle) {   /* task/mod.rs:627-654 */
+/* `via_handle`: spawned through a NodeHandle captured at build() (NodeHandle::spawn from another node's
+ * task: the Spawner holds the ORIGINAL Arc<NodeInfo>); otherwise task::spawn / init on the current info. */
+static int spawn_task_on(sim_t* S, unsigned prog, int record_handle, int via_handle);
+static int spawn_task(sim_t* S, unsigned prog, int record_handle) { return spawn_task_on(S, prog, record_handle, 0); }
+static int spawn_task_on(sim_t* S, unsigned prog, int record_handle, int via_handle) {   /* task/mod.rs:627-654 */
     size_t slot = 0;
     while (slot < S->tasks.n && S->tasks.p[slot].alive) slot++;
     if (slot == S->tasks.n) { task_t z; memset(&z, 0, sizeof z); vec_push(S->tasks, z); }
@@ -357,7 +367,12 @@ static int spawn_task(sim_t* S, unsigned prog, int record_handle) {   /* task/mo
     uint16_t gen = (uint16_t)(t->gen + 1);
     memset(t, 0, sizeof *t);
     t->alive = 1; t->gen = gen; t->prog = (uint8_t)prog; t->node = S->w->progs[prog].node;
-    t->killed = S->nodes[t->node].killed;                 /* spawning on a killed node :632-634 */
+    {
+        node_t* n = &S->nodes[t->node];
+        if (via_handle && n->info_gen != 0) { t->killed = 1; t->info_gen = 0; }        /* stale handle: dead info */
+        else { t->killed = via_handle ? n->gen0_killed : n->killed; t->info_gen = n->info_gen; }  /* :632-634 */
+        if (t->info_gen == n->info_gen) { tref_t r = { (uint16_t)slot, gen }; vec_push(n->tasks, r); }
+    }
     t->pc = S->w->progs[prog].entry; t->joiner = -1;
     t->scheduled = 1;                                     /* runnable.schedule() :651 */
     ready_push(S, (uint16_t)slot);
@@ -365,6 +380,56 @@ static int spawn_task(sim_t* S, unsigned prog, int record_handle) {   /* task/mo
     uint32_t live = 0; for (size_t i = 0; i < S->tasks.n; i++) live += S->tasks.p[i].alive;
     if (live > S->st.max_tasks) S->st.max_tasks = live;
     return (int)slot;
+}
+
+
+/* NodeInfo::kill (task/mod.rs:133-140): flag + wake every task of that info, in spawn order. */
+static void info_kill(sim_t* S, unsigned node) {
+    node_t* n = &S->nodes[node];
+    n->killed = 1;
+    if (n->info_gen == 0) n->gen0_killed = 1;
+    size_t cnt = n->tasks.n;
+    tref_t* list = n->tasks.p;
+    n->tasks.p = NULL; n->tasks.n = n->tasks.cap = 0;       /* drain(..) */
+    for (size_t i = 0; i < cnt; i++) {
+        task_t* t = list[i].slot < S->tasks.n ? &S->tasks.p[list[i].slot] : NULL;
+        if (t && t->alive && t->gen == list[i].gen) { t->killed = 1; wake(S, list[i].slot, list[i].gen); }
+    }
+    free(list);
+}
+
+static void task_finish(sim_t* S, uint16_t slot, int outcome);
+
+static void paused_clear(sim_t* S, unsigned node) {       /* node.paused.clear(): drops the Runnables */
+    node_t* n = &S->nodes[node];
+    size_t cnt = n->paused_list.n;
+    uint16_t* list = n->paused_list.p;
+    n->paused_list.p = NULL; n->paused_list.n = n->paused_list.cap = 0;
+    for (size_t i = 0; i < cnt; i++) task_finish(S, list[i], H_CANCELLED);
+    free(list);
+}
+
+static void node_kill(sim_t* S, unsigned node) {          /* TaskHandle::kill_id (task/mod.rs:362-371) */
+    paused_clear(S, node);
+    info_kill(S, node);
+    for (uint32_t i = 0; i < S->w->n_socks; i++)          /* NetSim::reset_node -> sockets.clear() (network.rs:142-147) */
+        if (S->w->socks[i].node == node) S->socks[i].bound = 0;
+}
+
+static void node_restart(sim_t* S, unsigned node) {       /* TaskHandle::restart (task/mod.rs:374-401) */
+    node_t* n = &S->nodes[node];
+    size_t cnt = n->tasks.n; tref_t* old = n->tasks.p;    /* old_info keeps its own task list */
+    n->tasks.p = NULL; n->tasks.n = n->tasks.cap = 0;
+    if (n->info_gen == 0) n->gen0_killed = 1;
+    n->info_gen++; n->killed = 0; n->paused = 0;          /* new_info */
+    paused_clear(S, node);
+    for (size_t i = 0; i < cnt; i++) {                    /* old_info.kill() */
+        task_t* t = old[i].slot < S->tasks.n ? &S->tasks.p[old[i].slot] : NULL;
+        if (t && t->alive && t->gen == old[i].gen) { t->killed = 1; wake(S, old[i].slot, old[i].gen); }
+    }
+    free(old);
+    for (uint32_t p = 1; p < S->w->n_progs; p++)          /* init(&Spawner { new info }) */
+        if (S->w->progs[p].node == node && (S->w->progs[p].flags & MADSIM_PROG_INIT)) spawn_task(S, p, 0);
 }
 
 /* The future is gone (completed, or dropped by the executor).  outcome: H_COMPLETED / H_CANCELLED. */
@@ -416,10 +481,16 @@ static int poll_task(sim_t* S, uint16_t slot) {
         const madsim_insn_t* in = &w->insns[t->pc];
         switch (in->op) {
         case MS_OP_DONE:
+            /* an init task is `async { future.await; h.exit() }` (runtime/mod.rs:362-370): Spawner::exit =
+             * info.kill() on the NodeInfo it was spawned with (task/mod.rs:657-661), before the future drops */
+            if ((w->progs[t->prog].flags & MADSIM_PROG_INIT) && t->info_gen == S->nodes[t->node].info_gen) {
+                info_kill(S, t->node);
+                t = &S->tasks.p[slot];
+            }
             task_finish(S, slot, H_COMPLETED);
             return 0;
         case MS_OP_SPAWN:
-            spawn_task(S, in->a, 1);
+            spawn_task_on(S, in->a, 1, w->progs[in->a].node != t->node);
             t = &S->tasks.p[slot]; t->pc++;
             break;
         case MS_OP_BUILD:                                  /* create_node().init(..).build(): task/mod.rs:472-474 */
@@ -441,6 +512,31 @@ static int poll_task(sim_t* S, uint16_t slot) {
             t->pc++;
             break;
         }
+        case MS_OP_ABORT: {                                /* AbortHandle::abort (task/join.rs:158-163) */
+            handle_t* h = &S->handles[in->a];
+            if (h->state == H_RUNNING) { S->tasks.p[h->slot].cancelled = 1; wake(S, h->slot, h->gen); }
+            t = &S->tasks.p[slot]; t->pc++;
+            break;
+        }
+        case MS_OP_KILL: node_kill(S, in->a); t = &S->tasks.p[slot]; t->pc++; break;
+        case MS_OP_RESTART: node_restart(S, in->a); t = &S->tasks.p[slot]; t->pc++; break;
+        case MS_OP_PAUSE: S->nodes[in->a].paused = 1; t->pc++; break;       /* task/mod.rs:404-410 */
+        case MS_OP_RESUME: {                               /* task/mod.rs:413-424 */
+            node_t* n = &S->nodes[in->a];
+            n->paused = 0;
+            for (size_t i = 0; i < n->paused_list.n; i++) ready_push(S, n->paused_list.p[i]);
+            n->paused_list.n = 0;
+            t->pc++;
+            break;
+        }
+        case MS_OP_ASSERT_EXIT:                            /* Handle::is_exit (task/mod.rs:444-449) */
+            if ((S->nodes[in->a].killed != 0) != ((in->b & 1) != 0)) return 1;
+            t->pc++;
+            break;
+        case MS_OP_GSET: S->greg[in->a & 3] = in->imm; t->pc++; break;
+        case MS_OP_GADD: S->greg[in->a & 3] += in->imm; t->pc++; break;
+        case MS_OP_ASSERT_G: if (S->greg[in->a & 3] != in->imm) return 1; t->pc++; break;
+        case MS_OP_PANIC_IF_G_LT: if (S->greg[in->a & 3] < in->imm) return 1; t->pc++; break;
         case MS_OP_YIELD:                                  /* [DEP tokio yield_now outside a runtime] */
             if (t->sub == 0) { t->sub = 1; wake(S, slot, t->gen); return 0; }
             t->sub = 0; t->pc++;
@@ -592,6 +688,7 @@ static void timer_expire(sim_t* S, uint64_t now) {
         switch (e.kind) {
         case EV_WAKE: wake(S, e.slot, e.gen); break;       /* time/sleep.rs:52 waker.wake() */
         case EV_DELIVER: mailbox_deliver(S, &e); break;    /* net/mod.rs:323-330 */
+        case EV_RESTART: node_restart(S, e.node); break;   /* task/mod.rs:313 */
         default: break;
         }
     }
@@ -618,9 +715,24 @@ static void run_all_ready(sim_t* S, uint32_t max_steps) {
             t->scheduled = 0; t->running = 1;              /* async-task run(): clear SCHEDULED, set RUNNING */
             int panicked = poll_task(S, slot);
             t = &S->tasks.p[slot];
-            if (panicked) {                                /* :289-317 (restart_on_panic: not in this build) */
-                S->panic = 1;
-                return;                                    /* resume_unwind: block_on unwinds */
+            if (panicked) {                                /* :289-317 */
+                unsigned node = t->node;
+                int restart = (S->w->nodes[node].flags & MADSIM_NODE_RESTART_ON_PANIC) != 0;
+                if (!restart) {
+                    S->panic = 1;
+                    return;                                /* resume_unwind: block_on unwinds */
+                }
+                /* async-task's panic guard: the future is dropped, the task closed, the awaiter notified */
+                task_finish(S, slot, H_CANCELLED);
+                /* delay = gen_range(1 s..10 s) inside ONE with() (:302-304): UniformDuration Medium path */
+                int mode; uint64_t low, range, zone;
+                oracle_uniform_duration_params(1 * NS_PER_S, 10 * NS_PER_S, &mode, &low, &range, &zone);
+                uint64_t delay = sample_duration(S, mode, low, range, zone, 0);
+                node_kill(S, node);                        /* self.kill(node_id) :309 */
+                event_t e; memset(&e, 0, sizeof e);
+                e.deadline = S->clock + delay; e.kind = EV_RESTART; e.node = (uint8_t)node;
+                timer_add(S, e);                           /* add_timer(delay, restart(node)) :311-313 */
+                t = &S->tasks.p[slot];
             }
             if (t->alive) {
                 t->running = 0;
@@ -705,7 +817,7 @@ static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, cons
         if (S.st.max_regs > stats->max_regs) stats->max_regs = S.st.max_regs;
     }
     for (uint32_t i = 0; i < w->n_socks; i++) { vec_free(S.socks[i].registered); vec_free(S.socks[i].msgs); }
-    for (uint32_t i = 0; i <= w->n_nodes; i++) vec_free(S.nodes[i].paused_list);
+    for (uint32_t i = 0; i <= w->n_nodes; i++) { vec_free(S.nodes[i].paused_list); vec_free(S.nodes[i].tasks); }
     vec_free(S.heap); vec_free(S.ready); vec_free(S.tasks);
     free(S.handles); free(S.nodes); free(S.socks); free(S.clog_link);
 }

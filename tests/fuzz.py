@@ -103,6 +103,81 @@ def random_workload(rng: random.Random, max_nodes=4, max_rounds=6):
     return wl.build(), cfg, "+".join(desc)
 
 
+def random_lifecycle_workload(rng: random.Random, max_nodes=4):
+    """Programs that also exercise node lifecycle: init tasks, kill / restart / pause / resume / abort,
+    restart_on_panic nodes, spawns on dead nodes, shared flags.  Returns (BuiltWorkload, Config, description)."""
+    n_nodes = rng.randint(1, max_nodes)
+    wl = W.WorkloadBuilder()
+    nodes = [wl.create_node(restart_on_panic=rng.random() < 0.3) for _ in range(n_nodes)]
+    addrs = [wl.addr(n, 1) for n in nodes]
+    tasks, inits, desc = [], {}, []
+    for i, n in enumerate(nodes):
+        is_init = rng.random() < 0.6
+        t = wl.task(n, init=is_init)
+        kind = rng.choice(["server", "client", "ticker", "crasher", "short"])
+        if n_nodes == 1 and kind in ("server", "client"):
+            kind = "ticker"
+        desc.append(("i:" if is_init else "") + kind)
+        if kind == "server":
+            t.bind(addrs[i])
+            top = t.label()
+            t.recv_from(addrs[i], 1); t.flag_add(0, 1); t.jmp(top)
+        elif kind == "client":
+            peer = rng.choice([j for j in range(n_nodes) if j != i])
+            t.bind(addrs[i]); t.set(0, rng.randint(1, 6))
+            top = t.label()
+            t.send_to(addrs[i], addrs[peer], 1, 5); t.sleep(ms=rng.randint(1, 40)); t.djnz(0, top)
+        elif kind == "ticker":
+            top = t.label()
+            t.sleep(ms=rng.choice([1, 7, 30, 100])); t.flag_add(1, 1); t.trace(7, add_reg=0)
+            if rng.random() < 0.5:
+                t.jmp(top)
+        elif kind == "crasher":
+            t.flag_add(2, 1); t.sleep(ms=rng.randint(0, 20)); t.panic_if_flag_lt(2, rng.randint(1, 4)); t.sleep(ms=5)
+        else:
+            t.sleep(ms=rng.randint(0, 10)); t.flag_add(3, 1)
+        t.done()
+        tasks.append(t)
+        if is_init:
+            inits[n] = t
+    m = wl.main()
+    for i, n in enumerate(nodes):
+        if n in inits:
+            m.build_node(n)
+        else:
+            m.spawn(tasks[i])
+    for _ in range(rng.randint(1, 8)):
+        act = rng.choice(["sleep", "sleep", "kill", "restart", "pause", "resume", "abort", "spawn", "yield", "exit?"])
+        n = rng.choice(nodes)
+        if act == "sleep":
+            m.sleep(ms=rng.choice([0, 3, 25, 150, 2500]))
+        elif act == "kill":
+            m.kill(n)
+        elif act == "restart":
+            m.restart(n)
+        elif act == "pause":
+            m.pause(n)
+        elif act == "resume":
+            m.resume(n)
+        elif act == "abort":
+            cand = [t for i, t in enumerate(tasks) if nodes[i] not in inits]
+            if cand:
+                m.abort(rng.choice(cand))
+        elif act == "spawn":
+            cand = [t for i, t in enumerate(tasks) if nodes[i] not in inits]
+            if cand:
+                m.spawn(rng.choice(cand))
+        elif act == "yield":
+            m.yield_now()
+    for n in nodes:
+        if rng.random() < 0.3:
+            m.resume(n)
+    m.sleep(ms=rng.choice([10, 500, 12000]))
+    m.done()
+    cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.1]), buggify=rng.random() < 0.15)
+    return wl.build(), cfg, "+".join(desc)
+
+
 def generous_limits():
     lim = A.Limits()
     lim.max_steps = 200_000

@@ -1,0 +1,141 @@
+"""The reference's node-lifecycle unit tests (madsim/src/sim/task/mod.rs:859-1182) restated as workloads.
+Shared by the oracle tests (CPU) and the GPU parity tests."""
+from madsim_amd import workload as W
+
+
+def _ticker(wl, node, flag, **kw):
+    """`loop { sleep(2 s).await; flag.fetch_add(2) }`"""
+    t = wl.task(node, **kw)
+    top = t.label()
+    t.sleep(secs=2); t.flag_add(flag, 2); t.jmp(top)
+    return t
+
+
+def kill():
+    """task/mod.rs:859-897"""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    _ticker(wl, n1, 0, pre=True); _ticker(wl, n2, 1, pre=True)
+    m = wl.main()
+    m.mark(); m.sleep_until(secs=3); m.assert_flag(0, 2); m.assert_flag(1, 2)
+    m.kill(n1); m.kill(n1); m.assert_exit(n1, True)
+    m.sleep_until(secs=5); m.assert_flag(0, 2); m.assert_flag(1, 4)
+    return wl.build()
+
+
+def restart():
+    """task/mod.rs:899-936"""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n, init=True, pre=True)
+    t.flag_store(0, 0)
+    top = t.label()
+    t.sleep(secs=2); t.flag_add(0, 2); t.jmp(top)
+    m = wl.main()
+    m.mark(); m.sleep_until(secs=3); m.assert_flag(0, 2)
+    m.kill(n); m.restart(n); m.assert_exit(n, False)
+    m.sleep_until(secs=6); m.assert_flag(0, 2)
+    m.sleep_until(secs=8); m.assert_flag(0, 4)
+    return wl.build()
+
+
+def restart_on_panic():
+    """task/mod.rs:938-962: panics 3 times, succeeds once; restart delays are random 1..10 s."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node(restart_on_panic=True)
+    t = wl.task(n, init=True, pre=True)
+    t.flag_add(0, 1); t.panic_if_flag_lt(0, 4)
+    m = wl.main()
+    m.sleep(secs=60); m.assert_flag(0, 4)
+    return wl.build()
+
+
+def panic_without_restart():
+    """task/mod.rs:315 resume_unwind: a panic on a node that does not restart fails the run."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n, init=True, pre=True)
+    t.sleep(ms=5); t.panic()
+    m = wl.main(); m.sleep(secs=1)
+    return wl.build()
+
+
+def pause_resume():
+    """task/mod.rs:985-1015"""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    _ticker(wl, n, 0, pre=True)
+    m = wl.main()
+    m.mark(); m.sleep_until(secs=3); m.assert_flag(0, 2)
+    m.pause(n); m.pause(n)
+    m.sleep_until(secs=5); m.assert_flag(0, 2)
+    m.resume(n); m.resume(n)
+    m.sleep_until(secs=5, ms=500); m.assert_flag(0, 4)
+    return wl.build()
+
+
+def kill_drop_futures():
+    """task/mod.rs:1112-1135 (the Arc strong counts are not observable; the scheduling is)."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    a = wl.addr(n, 1)
+    t = wl.task(n, pre=True); t.bind(a); t.recv_from(a, 9)          # pending forever
+    m = wl.main(); m.sleep(secs=1); m.kill(n); m.sleep(secs=1)
+    return wl.build()
+
+
+def join_cancelled():
+    """task/mod.rs:1137-1151"""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    a = wl.addr(n, 1)
+    t = wl.task(n, pre=True); t.bind(a); t.recv_from(a, 9)
+    m = wl.main(); m.abort(t); m.join(t, expect_err=True)
+    return wl.build()
+
+
+def exited():
+    """task/mod.rs:1153-1182: the init future returns => node exits, its other tasks are killed."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    sub = _ticker(wl, n, 0)
+    t = wl.task(n, init=True, pre=True)
+    t.spawn(sub); t.sleep(secs=5)
+    m = wl.main()
+    m.assert_exit(n, False); m.sleep(secs=10); m.assert_exit(n, True); m.assert_flag(0, 4)
+    return wl.build()
+
+
+def spawn_on_killed_node():
+    """task/mod.rs:1219-1253 shape: NodeHandle::spawn on a killed node succeeds but the task never runs."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n); t.flag_add(0, 1)
+    m = wl.main(); m.kill(n); m.spawn(t); m.join(t, expect_err=True); m.sleep(secs=1); m.assert_flag(0, 0)
+    return wl.build()
+
+
+def kill_restart_with_traffic():
+    """A server node is killed and restarted by the supervisor while a client keeps pinging it
+    (the kill/restart fault loop of tonic-example/tests/test.rs:234-271 on the datagram API)."""
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
+    srv = wl.task(ns, init=True, pre=True)
+    srv.bind(asv)
+    top = srv.label()
+    srv.recv_from(asv, 1); srv.flag_add(0, 1); srv.jmp(top)
+    cl = wl.task(nc, pre=True)
+    cl.bind(acl); cl.set(0, 40)
+    top = cl.label()
+    cl.send_to(acl, asv, 1, 3); cl.sleep(ms=50); cl.djnz(0, top)
+    m = wl.main()
+    m.sleep(ms=300); m.kill(ns); m.sleep(ms=200); m.restart(ns); m.sleep(ms=400); m.kill(ns); m.restart(ns)
+    m.join(cl)
+    return wl.build()
+
+
+ALL = dict(kill=kill, restart=restart, restart_on_panic=restart_on_panic, panic_without_restart=panic_without_restart,
+           pause_resume=pause_resume, kill_drop_futures=kill_drop_futures, join_cancelled=join_cancelled,
+           exited=exited, spawn_on_killed_node=spawn_on_killed_node, kill_restart_with_traffic=kill_restart_with_traffic)
+EXPECT_PANIC = {"panic_without_restart"}

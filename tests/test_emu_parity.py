@@ -70,3 +70,24 @@ def test_fuzz_random_workloads():
         o = _same(w, k * 11, 16, cfg, fuzz.generous_limits())
         verdicts |= set(o["verdict"].tolist())
     assert {A.PASS, A.DEADLOCK, A.PANIC} <= verdicts
+
+
+from tests import lifecycle_workloads as LW  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(LW.ALL))
+def test_lifecycle_reference_tests(name):
+    """kill / restart / restart_on_panic / pause_resume / exited / join_cancelled ... (task/mod.rs:859-1182)."""
+    o = _same(LW.ALL[name](), 0, 128)
+    assert (o["verdict"] == (A.PANIC if name in LW.EXPECT_PANIC else A.PASS)).all()
+
+
+def test_fuzz_lifecycle_workloads():
+    """200 random programs with init tasks, kill/restart/pause/resume/abort, restart_on_panic, dead-node spawns."""
+    for k in range(200):
+        w, cfg, desc = fuzz.random_lifecycle_workload(random.Random(9000 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        o, _ = oracle.run_batch(w, k * 3, 12, cfg, lim)
+        e = emu.run_batch(w, k * 3, 12, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])

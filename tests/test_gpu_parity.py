@@ -205,3 +205,26 @@ def test_cpp_host_mirror_runs_like_cargo_test(hip):
                        capture_output=True, text=True)
     assert p.returncode == 101 and "note: run with `MADSIM_TEST_SEED=3` environment variable" in p.stderr
     hip.init(0)
+
+
+from tests import lifecycle_workloads as LW  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(LW.ALL))
+def test_lifecycle_reference_tests_gpu(hip, name):
+    """The reference's node-lifecycle unit tests (task/mod.rs:859-1182) executed by the kernel, 1024 seeds each."""
+    got, _ = _cmp(hip, LW.ALL[name](), 0, 1024)
+    assert (got["verdict"] == (A.PANIC if name in LW.EXPECT_PANIC else A.PASS)).all()
+
+
+def test_fuzz_lifecycle_workloads_gpu(hip):
+    import random
+    from tests import fuzz
+    for k in range(150):
+        w, cfg, desc = fuzz.random_lifecycle_workload(random.Random(7000 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        got, _ = hip.run_batch(w, k * 17, 64, cfg, lim)
+        want, _ = oracle.run_batch(w, k * 17, 64, cfg, lim)
+        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+        assert (got["verdict"] == A.OVERFLOW).sum() == 0
