@@ -76,8 +76,8 @@ enum madsim_op {
     MS_OP_RECV = 23,       /* a=sock, b=(tag<<8): (val, from) = ep.recv_from(tag).await
                               (endpoint.rs:87-94,140-149)                                            */
     MS_OP_ASSERT_VAL = 24, /* assert_eq!(val, imm)                                                   */
-    MS_OP_RECV_TIMEOUT = 25,/* a=sock, b=(tag<<8)|secs... see DESIGN.md; timeout(d, ep.recv_from(tag))
-                              d = imm ns; on Elapsed val := MADSIM_VAL_TIMEOUT (time/mod.rs:128-140)  */
+    MS_OP_RECV_TIMEOUT = 25,/* a=sock, b=(tag<<8)|secs, imm=ns: timeout(secs s + ns, ep.recv_from(tag)).await;
+                              on Err(Elapsed) val := MADSIM_VAL_TIMEOUT (time/mod.rs:128-140)         */
     MS_OP_CLOSE = 26,      /* a=sock: drop(ep) (BindGuard::drop, net/mod.rs:483-493)                 */
     /* -- supervisor: fault injection (runtime/mod.rs:276-303, net/mod.rs:164-222) -- */
     MS_OP_KILL = 30,       /* a=node: Handle::kill(node)     (task/mod.rs:356-371)                   */
@@ -91,13 +91,14 @@ enum madsim_op {
     MS_OP_ASSERT_EXIT = 38,/* a=node, b=expected: assert_eq!(Handle::is_exit(node), b)               */
     MS_OP_SET_LOSS = 39,   /* a=index into madsim_config_t.loss_table: NetSim::update_config(|c|
                               c.packet_loss_rate = ..) (net/mod.rs:138-141)                          */
-    MS_OP_SLEEP_RAND = 40, /* sleep(thread_rng().gen_range(0 .. b s + imm ns)): the randomised fault
-                              loop of tonic-example/tests/test.rs:198-201 (UniformDuration, A.3)     */
+    MS_OP_SLEEP_RAND = 40, /* sleep(thread_rng().gen_range(a*50 ms .. b s + imm ns)).await: the randomised
+                              fault loop of tonic-example/tests/test.rs:198-201 (UniformDuration, A.3) */
     /* -- shared test flags: the Arc<AtomicUsize> the reference's tests observe (task/mod.rs:864-1015) -- */
     MS_OP_GSET = 41,       /* a=flag(0..3): flag.store(imm)                                         */
     MS_OP_GADD = 42,       /* a=flag: flag.fetch_add(imm)                                            */
     MS_OP_ASSERT_G = 43,   /* a=flag: assert_eq!(flag.load(), imm)                                   */
     MS_OP_PANIC_IF_G_LT = 44, /* a=flag: if flag.load() < imm { panic!() }                            */
+    MS_OP_JEQ = 45,        /* b=target: if val == imm { goto b } (react to a timeout / a reply value)    */
     MS_OP__COUNT
 };
 

@@ -5,6 +5,7 @@
 
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "sim_kernel.h"
 
@@ -105,7 +106,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     if (P.mbox_regs > 15 || P.mbox_msgs > 15) return fail(err, MADSIM_E_LIMITS, "mailbox capacities must be <= 15");
     P.heap_lds = L.heap_lds_slots ? L.heap_lds_slots : 8;
     P.heap_spill = (L.heap_lds_slots || L.heap_spill_slots) ? L.heap_spill_slots : 56;
-    bool t0 = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED);
+    bool t0 = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_RECV_TIMEOUT);
     P.task_units = t0 ? 3 : 2;
     P.sock_words = 2 + P.mbox_regs + 2 * P.mbox_msgs;
     P.has_clog_link = uses_op(w, MS_OP_CLOG_LINK);
@@ -129,7 +130,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         if (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) P.restart_nodes |= 1u << i;
     P.has_restart_on_panic = P.restart_nodes != 0;
     P.lifecycle = P.has_restart_on_panic || uses_op(w, MS_OP_KILL) || uses_op(w, MS_OP_RESTART) || uses_op(w, MS_OP_PAUSE) ||
-                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT);
+                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND);
     for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.lifecycle = 1;
     P.sh_insns = 0;
     P.sh_progs = P.sh_insns + 2 * P.n_insns;
@@ -166,6 +167,31 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     return 0;
 }
 
+
+// Device form of the workload tables.  MS_OP_SLEEP_RAND's `a` (lo in 50 ms units) is replaced by an index
+// into `durs` = {mode, low, range, zone} of UniformDuration::new(lo, hi) [DEP rand 0.8, SURVEY A.3].
+struct DeviceTables { std::vector<uint32_t> insns, progs, socks; std::vector<uint64_t> durs; };
+inline int build_tables(const madsim_workload_t* w, DeviceTables* T, std::string* err) {
+    T->insns.resize(2 * (size_t)w->n_insns); T->progs.resize(w->n_progs); T->socks.resize(w->n_socks ? w->n_socks : 1);
+    T->durs.assign(4, 0);
+    for (uint32_t i = 0; i < w->n_insns; i++) {
+        madsim_insn_t in = w->insns[i];
+        if (in.op == MS_OP_SLEEP_RAND) {
+            uint64_t lo = (uint64_t)in.a * 50000000ull, hi = (uint64_t)in.b * 1000000000ull + in.imm;
+            if (lo >= hi) return fail(err, MADSIM_E_WORKLOAD, "sleep_rand: cannot sample empty range");
+            if (T->durs.size() / 4 > 255) return fail(err, MADSIM_E_WORKLOAD, "too many sleep_rand ops");
+            uint32_t mode; uint64_t low, range, zone;
+            uniform_duration_params(lo, hi, &mode, &low, &range, &zone);
+            in.a = (uint8_t)(T->durs.size() / 4);
+            T->durs.push_back(mode); T->durs.push_back(low); T->durs.push_back(range); T->durs.push_back(zone);
+        }
+        T->insns[2 * i] = (uint32_t)in.op | ((uint32_t)in.a << 8) | ((uint32_t)in.b << 16);
+        T->insns[2 * i + 1] = in.imm;
+    }
+    for (uint32_t i = 0; i < w->n_progs; i++) T->progs[i] = (uint32_t)w->progs[i].node | ((uint32_t)w->progs[i].flags << 8) | ((uint32_t)w->progs[i].entry << 16);
+    for (uint32_t i = 0; i < w->n_socks; i++) T->socks[i] = (uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].port << 16);
+    return 0;
+}
 
 }  // namespace madsim_geo
 

@@ -29,8 +29,8 @@ struct State {
     size_t max_lds_block = 64 * 1024;
     // cached device copies of the workload tables
     uint64_t wl_hash = 0;
-    uint2* d_insns = nullptr; uint32_t* d_progs = nullptr; uint32_t* d_socks = nullptr;
-    size_t cap_insns = 0, cap_progs = 0, cap_socks = 0;
+    uint2* d_insns = nullptr; uint32_t* d_progs = nullptr; uint32_t* d_socks = nullptr; uint64_t* d_durs = nullptr;
+    size_t cap_insns = 0, cap_progs = 0, cap_socks = 0, cap_durs = 0;   // capacities in 32-bit (durs: 64-bit) words
     // scratch
     uint4* d_spill = nullptr; size_t spill_bytes = 0;
     unsigned long long* d_acc = nullptr;      // 4 x u64 summary accumulators
@@ -64,27 +64,25 @@ uint64_t fnv(const void* p, size_t n, uint64_t h) {
 using madsim_geo::Geo;
 
 int upload_workload(const madsim_workload_t* w, KParams& P) {
-    std::vector<uint2> insns(w->n_insns);
-    std::vector<uint32_t> progs(w->n_progs), socks(w->n_socks ? w->n_socks : 1);
-    for (uint32_t i = 0; i < w->n_insns; i++) {
-        const madsim_insn_t& in = w->insns[i];
-        insns[i] = make_uint2((uint32_t)in.op | ((uint32_t)in.a << 8) | ((uint32_t)in.b << 16), in.imm);
-    }
-    for (uint32_t i = 0; i < w->n_progs; i++) progs[i] = (uint32_t)w->progs[i].node | ((uint32_t)w->progs[i].flags << 8) | ((uint32_t)w->progs[i].entry << 16);
-    for (uint32_t i = 0; i < w->n_socks; i++) socks[i] = (uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].port << 16);
-    uint64_t h = fnv(insns.data(), insns.size() * sizeof(uint2), 14695981039346656037ull);
-    h = fnv(progs.data(), w->n_progs * 4, h);
-    h = fnv(socks.data(), w->n_socks * 4, h);
+    madsim_geo::DeviceTables T;
+    int rc = madsim_geo::build_tables(w, &T, &g_err);
+    if (rc) return rc;
+    uint64_t h = fnv(T.insns.data(), T.insns.size() * 4, 14695981039346656037ull);
+    h = fnv(T.progs.data(), w->n_progs * 4, h);
+    h = fnv(T.socks.data(), w->n_socks * 4, h);
+    h = fnv(T.durs.data(), T.durs.size() * 8, h);
     if (h != g.wl_hash || !g.d_insns) {
-        if (g.cap_insns < insns.size()) { if (g.d_insns) (void)hipFree(g.d_insns); HIP_TRY(hipMalloc(&g.d_insns, insns.size() * sizeof(uint2))); g.cap_insns = insns.size(); }
-        if (g.cap_progs < progs.size()) { if (g.d_progs) (void)hipFree(g.d_progs); HIP_TRY(hipMalloc(&g.d_progs, progs.size() * 4)); g.cap_progs = progs.size(); }
-        if (g.cap_socks < socks.size()) { if (g.d_socks) (void)hipFree(g.d_socks); HIP_TRY(hipMalloc(&g.d_socks, socks.size() * 4)); g.cap_socks = socks.size(); }
-        HIP_TRY(hipMemcpy(g.d_insns, insns.data(), insns.size() * sizeof(uint2), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(g.d_progs, progs.data(), progs.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(g.d_socks, socks.data(), socks.size() * 4, hipMemcpyHostToDevice));
+        if (g.cap_insns < T.insns.size()) { if (g.d_insns) (void)hipFree(g.d_insns); HIP_TRY(hipMalloc(&g.d_insns, T.insns.size() * 4)); g.cap_insns = T.insns.size(); }
+        if (g.cap_progs < T.progs.size()) { if (g.d_progs) (void)hipFree(g.d_progs); HIP_TRY(hipMalloc(&g.d_progs, T.progs.size() * 4)); g.cap_progs = T.progs.size(); }
+        if (g.cap_socks < T.socks.size()) { if (g.d_socks) (void)hipFree(g.d_socks); HIP_TRY(hipMalloc(&g.d_socks, T.socks.size() * 4)); g.cap_socks = T.socks.size(); }
+        if (g.cap_durs < T.durs.size()) { if (g.d_durs) (void)hipFree(g.d_durs); HIP_TRY(hipMalloc(&g.d_durs, T.durs.size() * 8)); g.cap_durs = T.durs.size(); }
+        HIP_TRY(hipMemcpy(g.d_insns, T.insns.data(), T.insns.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(g.d_progs, T.progs.data(), T.progs.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(g.d_socks, T.socks.data(), T.socks.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(g.d_durs, T.durs.data(), T.durs.size() * 8, hipMemcpyHostToDevice));
         g.wl_hash = h;
     }
-    P.insns = g.d_insns; P.progs = g.d_progs; P.socks = g.d_socks;
+    P.insns = g.d_insns; P.progs = g.d_progs; P.socks = g.d_socks; P.dur_table = g.d_durs;
     return 0;
 }
 
@@ -193,6 +191,7 @@ int madsim_hip_shutdown(void) {
     if (g.d_insns) (void)hipFree(g.d_insns);
     if (g.d_progs) (void)hipFree(g.d_progs);
     if (g.d_socks) (void)hipFree(g.d_socks);
+    if (g.d_durs) (void)hipFree(g.d_durs);
     if (g.d_spill) (void)hipFree(g.d_spill);
     if (g.d_acc) (void)hipFree(g.d_acc);
     if (g.d_out) (void)hipFree(g.d_out);

@@ -15,6 +15,7 @@ struct KParams {
     const uint2*    insns;     // madsim_insn_t as {op|a<<8|b<<16, imm}
     const uint32_t* progs;     // node | flags<<8 | entry<<16
     const uint32_t* socks;     // node | port<<16
+    const uint64_t* dur_table; // per MS_OP_SLEEP_RAND (its `a` is rewritten to an index): {mode, low, range, zone}
     uint32_t n_insns, n_progs, n_socks, n_nodes;
     // net config (Bernoulli p_int, UniformDuration parameters precomputed on the host)
     uint64_t loss_pint; uint32_t loss_always; uint32_t buggify; uint64_t bug_pint;

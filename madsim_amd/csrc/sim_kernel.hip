@@ -502,8 +502,18 @@ __device__ __forceinline__ uint64_t sleep_deadline(const Lane& L, uint64_t deadl
     return deadline > m ? deadline : m;
 }
 
+// NetSim::rand_delay up to the creation of its Sleep (net/mod.rs:287-292): returns the Sleep's deadline.
+template <class K>
+__device__ __forceinline__ uint64_t rand_delay_deadline(const Ctx& c, Lane& L) {
+    uint64_t delay = (uint64_t)gen_range_small<K, 5>(c, L) * 1000ull;
+    if (c.P.buggify) {
+        if (gen_bool_pint<K>(c, L, c.P.bug_pint, 0)) delay = (uint64_t)(1 + gen_range_small<K, 4>(c, L)) * NS_PER_S;
+    }
+    return sleep_deadline(L, L.clock + delay);
+}
+
 __device__ __forceinline__ bool is_light(uint32_t op) {
-    return op == MS_OP_ASSERT_VAL || op == MS_OP_DJNZ || op == MS_OP_SET || op == MS_OP_JMP || op == MS_OP_TRACE;
+    return op == MS_OP_ASSERT_VAL || op == MS_OP_DJNZ || op == MS_OP_SET || op == MS_OP_JMP || op == MS_OP_TRACE || op == MS_OP_JEQ;
 }
 
 // One poll of a task's future (Runnable::run, task/mod.rs:279-283).  `u0` is the task's unit0, held
@@ -525,6 +535,37 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     const uint32_t node = PROGW(c, u0.x >> 24) & 0xff;
     uint32_t st = ST_RUN;
 
+    // timeout(d, ep.recv_from(tag)) = select_biased! { fut, sleep } (time/mod.rs:128-140): poll the recv future,
+    // then the timeout's Sleep — which registers ANOTHER timer on every not-elapsed poll (time/sleep.rs:51-53).
+    // Returns true when the op completed (Ok or Err(Elapsed)); otherwise the task is Pending.
+    auto recv_timeout_poll = [&]() -> bool {
+        bool fut_ready = false;
+        if (sub == 1 && (u0.x & TF_INBOX)) {                 // oneshot ready -> rand_delay (endpoint.rs:145)
+            u0.x &= ~TF_INBOX;
+            from = u0.y >> 24;
+            uint64_t d1 = rand_delay_deadline<K>(c, L);
+            u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
+            sub = 2;
+        }
+        if (sub == 2) {
+            uint64_t d1 = u64of(u1.z, u1.w);
+            if (L.clock >= d1) fut_ready = true;
+            else if (!timer_add<K>(c, L, d1, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        }
+        if (fut_ready) return true;                          // Ok((len, from))
+        uint4 u2 = TU(c, slot, 2);
+        uint64_t d2 = u64of(u2.z, u2.w);
+        if (L.clock >= d2) {                                 // Err(Elapsed): the recv future is dropped
+            u1.x = (u1.x & ~0xffu) | (((u1.x & 0xff) + 1) & 0xff); u1_dirty = true;   // its oneshot::Receiver is gone
+            u0.x &= ~TF_INBOX;
+            u0.w = MADSIM_VAL_TIMEOUT;
+            return true;
+        }
+        if (!timer_add<K>(c, L, d2, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        st = ST_PENDING;
+        return false;
+    };
+
     while (st == ST_RUN) {
         if (pc >= P.n_insns) { st = ST_PANIC; break; }
         uint2 in = INSN(c, pc);
@@ -541,6 +582,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 sub = 2;                                   // -> rand_delay, begun in [C]
             } else if (op == MS_OP_YIELD) {
                 completed = true;
+            } else if (K::LIFE && op == MS_OP_RECV_TIMEOUT) {
+                completed = recv_timeout_poll();
+                if (!completed) break;
             } else {                                       // a Sleep (time/sleep.rs:47-54)
                 uint64_t deadline = u64of(u1.z, u1.w);
                 if (L.clock < deadline) {                  // not elapsed: register ANOTHER timer
@@ -598,6 +642,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 pc++;
             } else if (op == MS_OP_JMP) {
                 pc = b;
+            } else if (op == MS_OP_JEQ) {
+                pc = (u0.w == imm) ? b : pc + 1;
             } else {                                       // MS_OP_TRACE
                 uint64_t v = imm;
                 if (b & 1) v += (u0.z >> ((a & 1) * 16)) & 0xffff;
@@ -644,6 +690,49 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             want_delay = (sub == 2);                       // endpoint.rs:145 rand_delay
         } else if (op == MS_OP_SEND || op == MS_OP_REPLY || op == MS_OP_BIND) {
             want_delay = true;                             // net/mod.rs:306,457 rand_delay first
+        } else if (K::LIFE && op == MS_OP_RECV_TIMEOUT) {
+            uint32_t tag = b >> 8;
+            uint64_t d2 = sleep_deadline(L, L.clock + (uint64_t)(b & 0xff) * NS_PER_S + imm);   // timeout()'s Sleep
+            uint4 u2 = TU(c, slot, 2);
+            u2.z = (uint32_t)d2; u2.w = (uint32_t)(d2 >> 32);
+            TU(c, slot, 2) = u2;
+            uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;       // Mailbox::recv (endpoint.rs:353-362)
+            u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
+            u0.x &= ~TF_INBOX;
+            uint32_t h = SW(c, a, 0);
+            uint32_t nreg = (h >> 9) & 0xf, nmsg = (h >> 13) & 0xf;
+            uint32_t idx = 0, mbase = 2 + P.mbox_regs;
+            while (idx < nmsg && (SW(c, a, mbase + 2 * idx) & 0xff) != tag) idx++;
+            if (idx < nmsg) {
+                uint32_t m0 = SW(c, a, mbase + 2 * idx), m1 = SW(c, a, mbase + 2 * idx + 1);
+                nmsg--;
+                SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);
+                SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
+                u0.w = m1;
+                u0.y = (u0.y & 0x00ffffffu) | (((m0 >> 8) & 0xff) << 24);
+                u0.x |= TF_INBOX;
+                SW(c, a, 0) = (h & ~(0xfu << 13)) | (nmsg << 13);
+            } else if (nreg >= P.mbox_regs) {
+                L.ovf = 1;
+            } else {
+                SW(c, a, 2 + nreg) = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                SW(c, a, 0) = (h & ~(0xfu << 9)) | ((nreg + 1) << 9);
+            }
+            sub = 1;
+            if (recv_timeout_poll()) { sub = 0; pc++; }
+        } else if (K::LIFE && op == MS_OP_SLEEP_RAND) {        // sleep(thread_rng().gen_range(lo..hi)): [DEP A.3],
+            const uint64_t* dp = P.dur_table + 4 * a;          // host-precomputed UniformDuration {mode, low, range, zone}
+            uint64_t mode = dp[0], low = dp[1], range = dp[2], zone = dp[3], d;
+            for (;;) {                                         // on the GlobalRng itself: one with() per attempt
+                uint64_t v = rng_next(L);
+                rng_log<K>(c, L);
+                if (mode == 0) {
+                    uint64_t m = (uint64_t)(uint32_t)(v >> 32) * (uint64_t)(uint32_t)range;
+                    if ((uint32_t)m <= (uint32_t)zone) { d = low + (m >> 32); break; }
+                } else if (v * range <= zone) { d = low + __umul64hi(v, range); break; }
+            }
+            deadline = sleep_deadline(L, L.clock + d);
+            want_sleep = true;
         } else if (op == MS_OP_SLEEP || op == MS_OP_SLEEP_UNTIL) {
             uint64_t base = L.clock;
             if (op == MS_OP_SLEEP_UNTIL) { uint4 u2 = TU(c, slot, 2); base = u64of(u2.x, u2.y); }
@@ -804,11 +893,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         }
         PROBE(8);
         if (want_delay) {                                  // NetSim::rand_delay (net/mod.rs:287-292)
-            uint64_t delay = (uint64_t)gen_range_small<K, 5>(c, L) * 1000ull;
-            if (P.buggify) {
-                if (gen_bool_pint<K>(c, L, P.bug_pint, 0)) delay = (uint64_t)(1 + gen_range_small<K, 4>(c, L)) * NS_PER_S;
-            }
-            deadline = sleep_deadline(L, L.clock + delay);
+            deadline = rand_delay_deadline<K>(c, L);
             want_sleep = true;
         }
         if (want_sleep) {                                  // first Sleep::poll: never elapsed (1 ms floor)

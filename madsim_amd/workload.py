@@ -163,9 +163,15 @@ class TaskBuilder:
     def panic_if_flag_lt(self, flag, value):
         return self._emit("PANIC_IF_G_LT", a=flag, imm=value)
 
-    def sleep_rand(self, **kw):
+    def sleep_rand(self, lo_ms=0, **kw):
+        """sleep(thread_rng().gen_range(lo..hi)): lo in multiples of 50 ms, hi as keyword duration."""
+        if lo_ms % 50 or lo_ms > 255 * 50:
+            raise ValueError("lo_ms must be a multiple of 50 ms up to 12750 ms")
         b, imm = _dur(**kw)
-        return self._emit("SLEEP_RAND", b=b, imm=imm)
+        return self._emit("SLEEP_RAND", a=lo_ms // 50, b=b, imm=imm)
+
+    def jeq(self, value, target):
+        return self._emit("JEQ", b=target, imm=value, reloc=True)
 
 
 class BuiltWorkload:

@@ -643,6 +643,61 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (t->val != in->imm) return 1;
             t->pc++;
             break;
+        case MS_OP_JEQ:                                    /* if val == imm { goto b } */
+            t->pc = (t->val == in->imm) ? in->b : t->pc + 1;
+            break;
+        case MS_OP_SLEEP_RAND:                             /* sleep(thread_rng().gen_range(lo..hi)).await:
+                                                              tonic-example/tests/test.rs:199; UniformDuration on the
+                                                              GlobalRng itself => one with() per attempt (A.3/A.4) */
+            if (t->sub == 0) {
+                int mode; uint64_t low, range, zone;
+                oracle_uniform_duration_params((uint64_t)in->a * 50 * NS_PER_MS, insn_dur(in), &mode, &low, &range, &zone);
+                uint64_t d = sample_duration(S, mode, low, range, zone, 1);
+                t->deadline = sleep_deadline(S, S->clock + d);
+                t->sub = 1;
+            }
+            if (!sleep_poll(S, slot, t->deadline)) return 0;
+            t->sub = 0; t->pc++;
+            break;
+        case MS_OP_RECV_TIMEOUT: {                         /* timeout(d, ep.recv_from(tag)) — time/mod.rs:128-140:
+                                                              select_biased! { fut, sleep }: the inner future is polled
+                                                              first, then the timeout's Sleep, which registers ANOTHER
+                                                              timer on every not-elapsed poll (time/sleep.rs:51-53) */
+            sock_t* k = &S->socks[in->a];
+            uint8_t tag = (uint8_t)(in->b >> 8);
+            if (t->sub == 0) {
+                t->deadline2 = sleep_deadline(S, S->clock + (uint64_t)(in->b & 0xff) * NS_PER_S + in->imm);
+                t->rxseq++; t->inbox_full = 0;
+                size_t idx = 0;
+                while (idx < k->msgs.n && k->msgs.p[idx].tag != tag) idx++;
+                if (idx < k->msgs.n) {
+                    msg_t m = k->msgs.p[idx];
+                    k->msgs.p[idx] = k->msgs.p[--k->msgs.n];
+                    t->inbox_full = 1; t->val = m.val; t->from = m.from;
+                } else {
+                    reg_t r = { tag, slot, t->gen, t->rxseq };
+                    vec_push(k->registered, r);
+                    if (k->registered.n > S->st.max_regs) S->st.max_regs = (uint32_t)k->registered.n;
+                }
+                t->sub = 1;
+            }
+            int ready = 0;
+            if (t->sub == 1 && t->inbox_full) {            /* oneshot ready -> rand_delay (endpoint.rs:145) */
+                t->inbox_full = 0;
+                t->deadline = rand_delay_start(S); t->sub = 2;
+            }
+            if (t->sub == 2) ready = sleep_poll(S, slot, t->deadline);
+            if (ready) { t->sub = 0; t->pc++; break; }     /* Ok((len, from)) */
+            if (S->clock >= t->deadline2) {                /* Err(Elapsed): the recv future is dropped */
+                t->rxseq++; t->inbox_full = 0;             /* oneshot::Receiver gone; a message taken in sub 2 is lost */
+                t->val = MADSIM_VAL_TIMEOUT;
+                t->sub = 0; t->pc++;
+                break;
+            }
+            { event_t e; memset(&e, 0, sizeof e);          /* Sleep::poll of the timeout: a NEW timer every time */
+              e.deadline = t->deadline2; e.kind = EV_WAKE; e.slot = slot; e.gen = t->gen; timer_add(S, e); }
+            return 0;
+        }
         case MS_OP_CLOSE: {
             sock_t* k = &S->socks[in->a];
             if (k->bound && k->owner_slot == slot && k->owner_gen == t->gen && !t->killed) k->bound = 0;

@@ -24,15 +24,9 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
     madsim_geo::Geo G;
     if ((rc = madsim_geo::make_geometry(dev, w, cfg, lim, count, &G, &emu_err))) return rc;
     madsim_k::KParams& P = G.P;
-    std::vector<uint2> insns(w->n_insns);
-    std::vector<uint32_t> progs(w->n_progs), socks(w->n_socks ? w->n_socks : 1);
-    for (uint32_t i = 0; i < w->n_insns; i++) {
-        const madsim_insn_t& in = w->insns[i];
-        insns[i] = make_uint2((uint32_t)in.op | ((uint32_t)in.a << 8) | ((uint32_t)in.b << 16), in.imm);
-    }
-    for (uint32_t i = 0; i < w->n_progs; i++) progs[i] = (uint32_t)w->progs[i].node | ((uint32_t)w->progs[i].flags << 8) | ((uint32_t)w->progs[i].entry << 16);
-    for (uint32_t i = 0; i < w->n_socks; i++) socks[i] = (uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].port << 16);
-    P.insns = insns.data(); P.progs = progs.data(); P.socks = socks.data();
+    madsim_geo::DeviceTables T;
+    if ((rc = madsim_geo::build_tables(w, &T, &emu_err))) return rc;
+    P.insns = (const uint2*)T.insns.data(); P.progs = T.progs.data(); P.socks = T.socks.data(); P.dur_table = T.durs.data();
     std::vector<uint4> spill((size_t)P.heap_spill * P.total_lanes + 1);
     P.spill = P.heap_spill ? spill.data() : nullptr;
     P.seed0 = seed0; P.count = count; P.out = out;

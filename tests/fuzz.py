@@ -42,10 +42,19 @@ def random_workload(rng: random.Random, max_nodes=4, max_rounds=6):
             t.set(0, rounds)
             top = t.label()
             t.send_to(addrs[i], addrs[peer], 1, 0xB0 + i)
-            if rng.random() < 0.6:
+            r = rng.random()
+            if r < 0.3:
+                # timeout(d, recv_from): on Elapsed skip the trace (time/mod.rs:128-140)
+                t.recv_from_timeout(addrs[i], rng.choice([1, 1, 2]), ms=rng.choice([0, 2, 9, 40, 1500]))
+                skip = t.label() + 2
+                t.jeq(A.VAL_TIMEOUT, skip)
+                t.trace(500 + i)
+            elif r < 0.6:
                 t.recv_from(addrs[i], rng.choice([1, 1, 2]))
                 if rng.random() < 0.3:
                     t.assert_val(0xA0 + peer)
+            elif r < 0.7:
+                t.sleep_rand(lo_ms=rng.choice([0, 50]), ms=rng.choice([60, 300, 2500]))
             else:
                 t.sleep(us=rng.randint(0, 5000))
             t.trace(200 + i, add_reg=0)
@@ -126,7 +135,12 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4):
             peer = rng.choice([j for j in range(n_nodes) if j != i])
             t.bind(addrs[i]); t.set(0, rng.randint(1, 6))
             top = t.label()
-            t.send_to(addrs[i], addrs[peer], 1, 5); t.sleep(ms=rng.randint(1, 40)); t.djnz(0, top)
+            t.send_to(addrs[i], addrs[peer], 1, 5)
+            if rng.random() < 0.5:
+                t.recv_from_timeout(addrs[i], 2, ms=rng.choice([1, 15, 80]))
+            else:
+                t.sleep_rand(lo_ms=0, ms=rng.randint(1, 40))
+            t.djnz(0, top)
         elif kind == "ticker":
             top = t.label()
             t.sleep(ms=rng.choice([1, 7, 30, 100])); t.flag_add(1, 1); t.trace(7, add_reg=0)
@@ -182,5 +196,5 @@ def generous_limits():
     lim = A.Limits()
     lim.max_steps = 200_000
     lim.heap_lds_slots, lim.heap_spill_slots = 4, 60     # small LDS quota: the spill path gets exercised too
-    lim.mbox_regs, lim.mbox_msgs = 4, 12
+    lim.mbox_regs, lim.mbox_msgs = 15, 15      # timed-out recv_from leaves dead registrations behind (reference: unbounded Vec)
     return lim

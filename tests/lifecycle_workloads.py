@@ -135,7 +135,52 @@ def kill_restart_with_traffic():
     return wl.build()
 
 
-ALL = dict(kill=kill, restart=restart, restart_on_panic=restart_on_panic, panic_without_restart=panic_without_restart,
+def receiver_drop():
+    """net/endpoint.rs:410-444 receiver_drop (Barrier replaced by sleeps): a recv_from wrapped in timeout() elapses,
+    its receiver is dropped, and a later recv_from on the same endpoint still gets the message."""
+    from madsim_amd import _abi as A
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+    s = wl.task(n1); s.bind(a1); s.sleep(secs=2); s.send_to(a1, a2, 1, 1)
+    r = wl.task(n2); r.bind(a2); r.recv_from_timeout(a2, 1, secs=1); r.assert_val(A.VAL_TIMEOUT); r.recv_from(a2, 1); r.assert_val(1)
+    m = wl.main(); m.spawn(s); m.spawn(r); m.join(r)
+    return wl.build()
+
+
+def request_timeout_with_stale_timers():
+    """tonic-example/tests/test.rs:369 request_timeout shape: a reply arrives before the timeout; the timeout's Sleep
+    has registered duplicate timers (time/sleep.rs:51-53) that later wake the task spuriously while it sleeps."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+    srv = wl.task(n1); srv.bind(a1); srv.recv_from(a1, 1); srv.sleep(ms=300); srv.reply(a1, 2, 9)
+    cl = wl.task(n2); cl.bind(a2); cl.sleep(ms=50); cl.send_to(a2, a1, 1, 4); cl.recv_from_timeout(a2, 2, secs=2); cl.assert_val(9)
+    cl.mark(); cl.sleep(secs=5); cl.assert_elapsed(">=", secs=5)
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.join(cl)
+    return wl.build()
+
+
+def random_restart_loop():
+    """tonic-example/tests/test.rs:198-201: `for _ in 0..10 { sleep(gen_range(0..5 s)); handle.restart(node) }`."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    a = wl.addr(n, 1)
+    srv = wl.task(n, init=True, pre=True)
+    srv.bind(a); srv.flag_add(0, 1)
+    top = srv.label()
+    srv.sleep(ms=700); srv.flag_add(1, 1); srv.jmp(top)
+    m = wl.main()
+    m.set(0, 10)
+    top = m.label()
+    m.sleep_rand(lo_ms=0, secs=5); m.kill(n); m.restart(n); m.djnz(0, top)
+    m.sleep(ms=10); m.assert_exit(n, False)
+    return wl.build()
+
+
+ALL = dict(receiver_drop=receiver_drop, request_timeout_with_stale_timers=request_timeout_with_stale_timers,
+           random_restart_loop=random_restart_loop,
+           kill=kill, restart=restart, restart_on_panic=restart_on_panic, panic_without_restart=panic_without_restart,
            pause_resume=pause_resume, kill_drop_futures=kill_drop_futures, join_cancelled=join_cancelled,
            exited=exited, spawn_on_killed_node=spawn_on_killed_node, kill_restart_with_traffic=kill_restart_with_traffic)
 EXPECT_PANIC = {"panic_without_restart"}
