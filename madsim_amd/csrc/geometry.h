@@ -51,7 +51,7 @@ inline void bernoulli(double p, uint64_t* p_int, uint32_t* always) {   // [DEP r
 
 inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std::string* err) {
     if (!w || !cfg) return fail(err, MADSIM_E_ARG, "null workload/config");
-    if (!w->insns || !w->progs || w->n_progs == 0 || w->n_progs > 255 || w->n_insns == 0 || w->n_insns > 0xffff)
+    if (!w->insns || !w->progs || w->n_progs == 0 || w->n_progs > 255 || w->n_insns == 0 || w->n_insns > 4096)   /* the table is copied into LDS, 16 B per instruction */
         return fail(err, MADSIM_E_WORKLOAD, "bad program table");
     if (w->n_nodes > 31) return fail(err, MADSIM_E_WORKLOAD, "at most 31 nodes in this build");
     if (w->n_socks > 63 || (w->n_socks && !w->socks)) return fail(err, MADSIM_E_WORKLOAD, "at most 63 socket addresses");
@@ -110,6 +110,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.task_units = t0 ? 3 : 2;
     P.sock_words = 2 + P.mbox_regs + 2 * P.mbox_msgs;
     P.has_clog_link = uses_op(w, MS_OP_CLOG_LINK);
+    P.has_clog = P.has_clog_link || uses_op(w, MS_OP_CLOG_NODE);
     P.uniq_addr = 1;
     for (uint32_t i = 0; i < w->n_socks; i++)
         for (uint32_t j = i + 1; j < w->n_socks; j++)
@@ -133,7 +134,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
                   uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND);
     for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.lifecycle = 1;
     P.sh_insns = 0;
-    P.sh_progs = P.sh_insns + 2 * P.n_insns;
+    P.sh_progs = P.sh_insns + 4 * P.n_insns;
     P.sh_socks = P.sh_progs + P.n_progs;
     P.sh_heap = (P.sh_socks + P.n_socks + 3) & ~3u;
     const uint32_t sh_bytes = P.sh_heap * 4;
@@ -172,7 +173,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
 // into `durs` = {mode, low, range, zone} of UniformDuration::new(lo, hi) [DEP rand 0.8, SURVEY A.3].
 struct DeviceTables { std::vector<uint32_t> insns, progs, socks; std::vector<uint64_t> durs; };
 inline int build_tables(const madsim_workload_t* w, DeviceTables* T, std::string* err) {
-    T->insns.resize(2 * (size_t)w->n_insns); T->progs.resize(w->n_progs); T->socks.resize(w->n_socks ? w->n_socks : 1);
+    T->insns.resize(4 * (size_t)w->n_insns); T->progs.resize(w->n_progs); T->socks.resize(w->n_socks ? w->n_socks : 1);
     T->durs.assign(4, 0);
     for (uint32_t i = 0; i < w->n_insns; i++) {
         madsim_insn_t in = w->insns[i];
@@ -185,8 +186,20 @@ inline int build_tables(const madsim_workload_t* w, DeviceTables* T, std::string
             in.a = (uint8_t)(T->durs.size() / 4);
             T->durs.push_back(mode); T->durs.push_back(low); T->durs.push_back(range); T->durs.push_back(zone);
         }
-        T->insns[2 * i] = (uint32_t)in.op | ((uint32_t)in.a << 8) | ((uint32_t)in.b << 16);
-        T->insns[2 * i + 1] = in.imm;
+        T->insns[4 * i] = (uint32_t)in.op | ((uint32_t)in.a << 8) | ((uint32_t)in.b << 16);
+        T->insns[4 * i + 1] = in.imm;
+        // Fused post-chain: the cheap ops that follow this one (an optional assert_eq!(val, ..) and an optional
+        // loop-back / jump) are summarised in words 2-3, so completing an awaiting op steps straight to the next
+        // awaiting op without dependent instruction fetches.  Pure acceleration: the ops keep their own records.
+        //   word 3: bit0 has_assert | bit1 has_djnz | bit2 djnz reg | bit3 has_jmp | next_pc << 4 | target << 18
+        uint32_t j = i + 1, flags = 0, aval = 0, target = 0;
+        {
+            if (j < w->n_insns && w->insns[j].op == MS_OP_ASSERT_VAL) { flags |= 1; aval = w->insns[j].imm; j++; }
+            if (j < w->n_insns && w->insns[j].op == MS_OP_DJNZ) { flags |= 2 | ((w->insns[j].a & 1u) << 2); target = w->insns[j].b; j++; }
+            else if (j < w->n_insns && w->insns[j].op == MS_OP_JMP) { flags |= 8; target = w->insns[j].b; j++; }
+        }
+        T->insns[4 * i + 2] = aval;
+        T->insns[4 * i + 3] = flags | ((j & 0x3fffu) << 4) | ((target & 0x3fffu) << 18);
     }
     for (uint32_t i = 0; i < w->n_progs; i++) T->progs[i] = (uint32_t)w->progs[i].node | ((uint32_t)w->progs[i].flags << 8) | ((uint32_t)w->progs[i].entry << 16);
     for (uint32_t i = 0; i < w->n_socks; i++) T->socks[i] = (uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].port << 16);

@@ -29,7 +29,7 @@ struct State {
     size_t max_lds_block = 64 * 1024;
     // cached device copies of the workload tables
     uint64_t wl_hash = 0;
-    uint2* d_insns = nullptr; uint32_t* d_progs = nullptr; uint32_t* d_socks = nullptr; uint64_t* d_durs = nullptr;
+    uint4* d_insns = nullptr; uint32_t* d_progs = nullptr; uint32_t* d_socks = nullptr; uint64_t* d_durs = nullptr;
     size_t cap_insns = 0, cap_progs = 0, cap_socks = 0, cap_durs = 0;   // capacities in 32-bit (durs: 64-bit) words
     // scratch
     uint4* d_spill = nullptr; size_t spill_bytes = 0;

@@ -12,14 +12,14 @@ namespace madsim_k {
 
 struct KParams {
     // workload tables in device memory (copied into LDS by every workgroup)
-    const uint2*    insns;     // madsim_insn_t as {op|a<<8|b<<16, imm}
+    const uint4*    insns;     // {op|a<<8|b<<16, imm, fused assert value, fused post-chain word} (geometry.h build_tables)
     const uint32_t* progs;     // node | flags<<8 | entry<<16
     const uint32_t* socks;     // node | port<<16
     const uint64_t* dur_table; // per MS_OP_SLEEP_RAND (its `a` is rewritten to an index): {mode, low, range, zone}
     uint32_t n_insns, n_progs, n_socks, n_nodes;
     // net config (Bernoulli p_int, UniformDuration parameters precomputed on the host)
     uint64_t loss_pint; uint32_t loss_always; uint32_t buggify; uint64_t bug_pint;
-    uint32_t lat_mode; uint32_t has_clog_link; uint64_t lat_low, lat_range, lat_zone;
+    uint32_t lat_mode; uint32_t has_clog_link; uint32_t has_clog; uint32_t pad0; uint64_t lat_low, lat_range, lat_zone;
     uint64_t loss_table_pint[4]; uint32_t loss_table_always[4];
     // limits
     uint64_t time_limit; uint32_t max_steps;

@@ -112,7 +112,7 @@ struct Ctx {
     uint32_t sock0;      // word index of this lane's socket region
     uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + (i << lws))
     uint32_t task0;      // uint4 index of task unit 0
-    uint32_t insn0;      // uint2 index of the workgroup-shared instruction table
+    uint32_t insn0;      // uint4 index of the workgroup-shared instruction table
     uint32_t prog0, sockt0;   // word indices of the shared prog / socket-address tables
     uint4* spill;        // this lane's column of the HBM spill region, stride P.total_lanes
     uint8_t* tlog;       // trace mode only
@@ -131,7 +131,7 @@ template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { retu
 #define SW(c_, s_, f_) SMEM[(c_).sock0 + (((s_) * (c_).P.sock_words + (f_)) << LWSH<K>(c_))]
 #define TU(c_, slot_, u_) LDS128((c_).task0 + (((slot_) * (c_).P.task_units + (u_)) << LWSH<K>(c_)))
 #define TWORD(c_, slot_, u_, k_) SMEM[((c_).task0 + (((slot_) * (c_).P.task_units + (u_)) << LWSH<K>(c_))) * 4 + (k_)]
-__device__ __forceinline__ uint2 INSN(const Ctx& c, uint32_t pc) { return LDS64(c.insn0 + pc); }
+__device__ __forceinline__ uint4 INSN(const Ctx& c, uint32_t pc) { return LDS128(c.insn0 + pc); }
 __device__ __forceinline__ uint32_t PROGW(const Ctx& c, uint32_t p) { return SMEM[c.prog0 + p]; }
 __device__ __forceinline__ uint32_t SOCKW(const Ctx& c, uint32_t s) { return SMEM[c.sockt0 + s]; }
 
@@ -568,7 +568,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
 
     while (st == ST_RUN) {
         if (pc >= P.n_insns) { st = ST_PANIC; break; }
-        uint2 in = INSN(c, pc);
+        uint4 in = INSN(c, pc);
         uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
 
         PROBE(5);
@@ -603,7 +603,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     uint32_t src_node = SOCKW(c, a) & 0xff;
                     uint32_t dst_node = SOCKW(c, dst) & 0xff;
                     // Network::try_send -> test_link (network.rs:261-269, 296-313)
-                    bool clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
+                    bool clogged = false;
+                    if (P.has_clog) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
                     if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
                     if (!clogged && !gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) {
                         L.msg_count++;
@@ -619,7 +620,19 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 completed = true;
             }
             if (completed) {                               // fall through to [B]/[C] with the next op: one pass per poll
-                sub = 0; pc++;
+                sub = 0;
+                // fused post-chain of this op (geometry.h build_tables): assert_eq!(val, ..), then djnz / jmp
+                const uint32_t pf = in.w;
+                if ((pf & 1) && u0.w != in.z) { st = ST_PANIC; break; }
+                pc = (pf >> 4) & 0x3fff;
+                if (pf & 2) {
+                    uint32_t sh = ((pf >> 2) & 1) * 16;
+                    uint32_t v = (((u0.z >> sh) & 0xffff) - 1) & 0xffff;
+                    u0.z = (u0.z & ~(0xffffu << sh)) | (v << sh);
+                    if (v) pc = pf >> 18;
+                } else if (pf & 8) {
+                    pc = pf >> 18;
+                }
                 if (pc >= P.n_insns) { st = ST_PANIC; break; }
                 in = INSN(c, pc);
                 op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
@@ -946,13 +959,13 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
 #else
     const uint32_t cp0 = lane, cps = 64;
 #endif
-    for (uint32_t i = cp0; i < P.n_insns * 2; i += cps) sh[P.sh_insns + i] = ((const uint32_t*)P.insns)[i];
+    for (uint32_t i = cp0; i < P.n_insns * 4; i += cps) sh[P.sh_insns + i] = ((const uint32_t*)P.insns)[i];
     for (uint32_t i = cp0; i < P.n_progs; i += cps) sh[P.sh_progs + i] = P.progs[i];
     for (uint32_t i = cp0; i < P.n_socks; i += cps) sh[P.sh_socks + i] = P.socks[i];
     __syncthreads();
 
     Ctx c(P);
-    c.insn0 = P.sh_insns / 2;
+    c.insn0 = P.sh_insns / 4;
     c.prog0 = P.sh_progs;
     c.sockt0 = P.sh_socks;
     c.heap0 = P.sh_heap / 4 + lane;
