@@ -44,15 +44,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # MADSIM_BENCH_BACKEND=gloo is a functional-test hook (several ranks sharing one GPU on a 1-GPU box);
+    # the real multi-GPU run is one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("MADSIM_BENCH_BACKEND", "nccl")
+    gpu = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    runtime.init(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", gpu)
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where the 32-byte report tensors live
+    runtime.init(gpu)
 
     w = workload.pingpong(N_NODES, ROUNDS)
     lim = A.Limits()
@@ -68,7 +74,7 @@ def main():
     def step(k):
         # a fresh block of seeds every step so nothing is cached between steps
         s = runtime.run_batch_device(w, seed0 + k * total, count, d_out.data_ptr(), stream, None, lim)
-        ff, nf, st, ck = mdist.reduce_report(s.first_failing_seed, s.n_failed, s.total_steps, s.total_clock_ns, dev)
+        ff, nf, st, ck = mdist.reduce_report(s.first_failing_seed, s.n_failed, s.total_steps, s.total_clock_ns, cdev)
         return s, (ff, nf, st, ck)
 
     def sync():
@@ -90,7 +96,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(t[0]), float(t[1])
 
@@ -124,7 +130,7 @@ def main():
                       "lanes_per_wave": g.lanes_per_wave},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "sim_kernel<Variant<false,false>>", "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel": "sim_kernel<Variant<false,false,6,false>>", "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "LDS-resident path: algorithmic bytes (120 B/executor step) never touch HBM"},
         }
         if world == 1 and not args.no_cpu_baseline:
