@@ -49,7 +49,7 @@ enum madsim_op {
     MS_OP_DONE = 0,        /* async block returns: locals drop (endpoints close, net/mod.rs:483-493),
                               JoinHandle awaiter is woken (async-task)                  */
     MS_OP_SPAWN = 1,       /* a=prog: NodeHandle::spawn / task::spawn  (task/mod.rs:607-654);
-                              handle[prog] := new task                                               */
+                              handle[prog] := new task.  b&2: `async move` takes the spawner's (tx, rx) */
     MS_OP_JOIN = 2,        /* a=prog: handle[prog].await (task/join.rs:59-72). b&1: expect Err
                               (unwrap_err) else unwrap -> a mismatch panics the polling task         */
     MS_OP_ABORT = 3,       /* a=prog: handle[prog].abort() (task/join.rs:158-163)                    */
@@ -99,10 +99,21 @@ enum madsim_op {
     MS_OP_ASSERT_G = 43,   /* a=flag: assert_eq!(flag.load(), imm)                                   */
     MS_OP_PANIC_IF_G_LT = 44, /* a=flag: if flag.load() < imm { panic!() }                            */
     MS_OP_JEQ = 45,        /* b=target: if val == imm { goto b } (react to a timeout / a reply value)    */
+    /* -- reliable channel: what madsim-tonic / etcd / kafka sims ride on (net/mod.rs:337-430) -- */
+    MS_OP_CONNECT = 46,    /* a=ep, b=dst addr: (tx, rx) = ep.connect1(addr).await; val := 0, or
+                              MADSIM_VAL_REFUSED on ConnectionRefused (endpoint.rs:178-193)           */
+    MS_OP_ACCEPT = 47,     /* a=ep: (tx, rx, _) = ep.accept1().await (endpoint.rs:197-211)           */
+    MS_OP_CSEND = 48,      /* imm=payload: tx.send(payload).await; val := MADSIM_VAL_RESET when the
+                              peer's receiver is gone (endpoint.rs:240-245, net/mod.rs:417-421)      */
+    MS_OP_CRECV = 49,      /* val = rx.recv().await: in-order delivery, 1 ms -> 10 s backoff while the link
+                              is down (net/mod.rs:385-402); MADSIM_VAL_RESET when the channel closed */
+    MS_OP_CCLOSE = 50,     /* drop(tx); drop(rx)                                                     */
     MS_OP__COUNT
 };
 
 #define MADSIM_VAL_TIMEOUT 0xFFFFFFFFu
+#define MADSIM_VAL_REFUSED 0xFFFFFFFEu
+#define MADSIM_VAL_RESET   0xFFFFFFFDu
 
 /* A task program: where it runs and where it starts.  Program 0 is the body handed to block_on
  * (the main task on node 0, task/mod.rs:222-235). */
@@ -165,6 +176,8 @@ typedef struct madsim_limits {
     uint32_t mbox_regs;          /* pending recv registrations per socket; 0 = auto (2)              */
     uint32_t mbox_msgs;          /* undelivered messages per socket; 0 = auto (4)                    */
     uint32_t lanes_per_wave;     /* seeds carried per 64-lane wave (8/16/32/64); 0 = auto            */
+    uint32_t max_conns;          /* live reliable-channel connections per seed; 0 = auto (4)         */
+    uint32_t chan_queue;         /* queued payloads per channel direction; 0 = auto (2)              */
 } madsim_limits_t;
 
 /* ------------------------------------------------------------------------------------------------

@@ -9,6 +9,8 @@ import ctypes as C
 ABI_VERSION = 1
 U64_MAX = (1 << 64) - 1
 VAL_TIMEOUT = 0xFFFFFFFF
+VAL_REFUSED = 0xFFFFFFFE
+VAL_RESET = 0xFFFFFFFD
 
 
 class Insn(C.Structure):
@@ -59,7 +61,7 @@ class Limits(C.Structure):
     _fields_ = [
         ("time_limit_ns", C.c_uint64), ("max_steps", C.c_uint32), ("heap_lds_slots", C.c_uint32),
         ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32), ("mbox_regs", C.c_uint32),
-        ("mbox_msgs", C.c_uint32), ("lanes_per_wave", C.c_uint32),
+        ("mbox_msgs", C.c_uint32), ("lanes_per_wave", C.c_uint32), ("max_conns", C.c_uint32), ("chan_queue", C.c_uint32),
     ]
 
 
@@ -91,7 +93,7 @@ class Geometry(C.Structure):
 
 
 assert C.sizeof(Insn) == 8 and C.sizeof(Prog) == 4 and C.sizeof(Sock) == 4 and C.sizeof(Node) == 4
-assert C.sizeof(Result) == 48 and C.sizeof(Summary) == 48 and C.sizeof(Limits) == 40
+assert C.sizeof(Result) == 48 and C.sizeof(Summary) == 48 and C.sizeof(Limits) == 48
 
 # numpy view of a result array: one record per seed, same layout as madsim_result_t
 RESULT_DTYPE = [("verdict", "<u4"), ("steps", "<u4"), ("clock_ns", "<u8"), ("msg_count", "<u8"),
@@ -106,7 +108,7 @@ OP = dict(
     SLEEP=10, MARK=11, SLEEP_UNTIL=12, ASSERT_ELAPSED=13, ADVANCE=14, BUILD=15,
     BIND=20, SEND=21, REPLY=22, RECV=23, ASSERT_VAL=24, RECV_TIMEOUT=25, CLOSE=26,
     KILL=30, RESTART=31, PAUSE=32, RESUME=33, CLOG_NODE=34, UNCLOG_NODE=35, CLOG_LINK=36,
-    UNCLOG_LINK=37, ASSERT_EXIT=38, SET_LOSS=39, SLEEP_RAND=40, GSET=41, GADD=42, ASSERT_G=43, PANIC_IF_G_LT=44, JEQ=45,
+    UNCLOG_LINK=37, ASSERT_EXIT=38, SET_LOSS=39, SLEEP_RAND=40, GSET=41, GADD=42, ASSERT_G=43, PANIC_IF_G_LT=44, JEQ=45, CONNECT=46, ACCEPT=47, CSEND=48, CRECV=49, CCLOSE=50,
 )
 PROG_INIT, PROG_PRE = 1, 2
 NODE_RESTART_ON_PANIC = 1

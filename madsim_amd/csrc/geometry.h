@@ -66,9 +66,9 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
             if (in.a >= w->n_progs) return fail(err, MADSIM_E_WORKLOAD, "prog operand out of range"); break;
         case MS_OP_DJNZ: case MS_OP_JMP:
             if (in.b >= w->n_insns) return fail(err, MADSIM_E_WORKLOAD, "jump target out of range"); break;
-        case MS_OP_BIND: case MS_OP_REPLY: case MS_OP_RECV: case MS_OP_CLOSE: case MS_OP_RECV_TIMEOUT:
+        case MS_OP_BIND: case MS_OP_REPLY: case MS_OP_RECV: case MS_OP_CLOSE: case MS_OP_RECV_TIMEOUT: case MS_OP_ACCEPT:
             if (in.a >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range"); break;
-        case MS_OP_SEND:
+        case MS_OP_SEND: case MS_OP_CONNECT:
             if (in.a >= w->n_socks || (uint32_t)(in.b & 0xff) >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range"); break;
         case MS_OP_BUILD: case MS_OP_KILL: case MS_OP_RESTART: case MS_OP_PAUSE: case MS_OP_RESUME:
         case MS_OP_CLOG_NODE: case MS_OP_UNCLOG_NODE: case MS_OP_ASSERT_EXIT:
@@ -98,7 +98,9 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.max_steps = L.max_steps ? L.max_steps : (1u << 24);
     bool restarts = uses_op(w, MS_OP_RESTART);
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) restarts |= (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) != 0;
-    P.max_tasks = L.max_tasks ? L.max_tasks : w->n_progs + (restarts ? w->n_progs : 0);
+    // request-per-connection servers spawn a handler per accept: leave room for a few concurrent ones
+    bool chan = uses_op(w, MS_OP_CONNECT) || uses_op(w, MS_OP_ACCEPT);
+    P.max_tasks = L.max_tasks ? L.max_tasks : w->n_progs + (restarts ? w->n_progs : 0) + (chan ? 8 : 0);
     if (P.max_tasks > 254) P.max_tasks = 254;
     if (P.max_tasks > 254) return fail(err, MADSIM_E_LIMITS, "max_tasks must be <= 254");
     P.mbox_regs = L.mbox_regs ? L.mbox_regs : 2;
@@ -107,8 +109,14 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.heap_lds = L.heap_lds_slots ? L.heap_lds_slots : 8;
     P.heap_spill = (L.heap_lds_slots || L.heap_spill_slots) ? L.heap_spill_slots : 56;
     bool t0 = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_RECV_TIMEOUT);
-    P.task_units = t0 ? 3 : 2;
-    P.sock_words = 2 + P.mbox_regs + 2 * P.mbox_msgs;
+    P.uses_chan = uses_op(w, MS_OP_CONNECT) || uses_op(w, MS_OP_ACCEPT) || uses_op(w, MS_OP_CSEND) || uses_op(w, MS_OP_CRECV);
+    P.task_units = P.uses_chan ? 4 : t0 ? 3 : 2;
+    // per socket: header, owner, registrations, queued messages (+ accept queue, parked acceptor)
+    P.sock_words = 2 + P.mbox_regs + 2 * P.mbox_msgs + (P.uses_chan ? 2 : 0);
+    P.max_conns = L.max_conns ? L.max_conns : 4;
+    P.chan_queue = L.chan_queue ? L.chan_queue : 2;
+    if (P.max_conns > 127 || P.chan_queue > 15) return fail(err, MADSIM_E_LIMITS, "max_conns <= 127, chan_queue <= 15");
+    P.conn_words = 3 + 2 * P.chan_queue * 3;
     P.has_clog_link = uses_op(w, MS_OP_CLOG_LINK);
     P.has_clog = P.has_clog_link || uses_op(w, MS_OP_CLOG_NODE);
     P.uniq_addr = 1;
@@ -125,13 +133,14 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.uses_pause = uses_op(w, MS_OP_PAUSE);
     P.off_greg = P.off_pause + (P.uses_pause ? 1 + P.max_tasks : 0);
     bool gregs = uses_op(w, MS_OP_GSET) || uses_op(w, MS_OP_GADD) || uses_op(w, MS_OP_ASSERT_G) || uses_op(w, MS_OP_PANIC_IF_G_LT);
-    P.lane_words = P.off_greg + (gregs ? 4 : 0);
+    P.off_conn = P.off_greg + (gregs ? 4 : 0);
+    P.lane_words = P.off_conn + (P.uses_chan ? P.max_conns * P.conn_words : 0);
     P.restart_nodes = 0;
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
         if (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) P.restart_nodes |= 1u << i;
     P.has_restart_on_panic = P.restart_nodes != 0;
     P.lifecycle = P.has_restart_on_panic || uses_op(w, MS_OP_KILL) || uses_op(w, MS_OP_RESTART) || uses_op(w, MS_OP_PAUSE) ||
-                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND);
+                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND) || P.uses_chan;
     for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.lifecycle = 1;
     P.sh_insns = 0;
     P.sh_progs = P.sh_insns + 4 * P.n_insns;

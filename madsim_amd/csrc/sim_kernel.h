@@ -31,7 +31,8 @@ struct KParams {
     // aligned, [unit][lane]), then the 32-bit planes ([word][lane])
     uint32_t sh_insns, sh_progs, sh_socks, sh_heap, sh_tasks, sh_planes;
     // per-lane plane offsets (in words)
-    uint32_t off_ready, off_socks, off_handles, off_nodes, off_clog, off_pause, off_greg;
+    uint32_t off_ready, off_socks, off_handles, off_nodes, off_clog, off_pause, off_greg, off_conn;
+    uint32_t uses_chan, max_conns, chan_queue, conn_words;   // reliable channel (connect1/accept1) state, if used
     uint32_t lifecycle;        // any kill/restart/pause/resume/abort op, init program or restart_on_panic node
     uint32_t uses_pause, has_restart_on_panic, restart_nodes;   // restart_nodes: bit n = NodeBuilder::restart_on_panic
     // batch

@@ -108,7 +108,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t madsim_smem[];
 struct Ctx {
     const KParams& P;
     uint32_t lws;        // log2(lane stride) (runtime copy; K::LWS overrides when >= 0)
-    uint32_t ready0, hand0, node0, clog0, pause0, greg0;   // word indices of this lane's plane regions
+    uint32_t ready0, hand0, node0, clog0, pause0, greg0, conn0;   // word indices of this lane's plane regions
     uint32_t sock0;      // word index of this lane's socket region
     uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + (i << lws))
     uint32_t task0;      // uint4 index of task unit 0
@@ -126,6 +126,9 @@ template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { retu
 #define CLOGW(i) SMEM[c.clog0 + ((i) << LWSH<K>(c))]
 #define PAUSEW(i) SMEM[c.pause0 + ((i) << LWSH<K>(c))]   /* [0] = length, [1..] = paused Runnables in pop order */
 #define GREGW(i) SMEM[c.greg0 + ((i) << LWSH<K>(c))]
+// connection id_: [0] alive:1 | c_ep:6<<1 | s_ep:6<<7 | tx0:1<<13 rx0<<14 tx1<<15 rx1<<16 | qn0:4<<17 | qn1:4<<21
+//                 [1 + dir] parked receiver: valid:1 | slot:8<<1 | gen:16<<9;  [3 + (dir * Q + i) * 3 ..] {val, arrive lo, arrive hi}
+#define CONNW(id_, f_) SMEM[c.conn0 + (((id_) * c.P.conn_words + (f_)) << LWSH<K>(c))]
 // node region: [0] killed mask, [1] paused mask, [2] gen0_killed mask, [3] spawn counter, [4 + n/4] info_gen bytes
 #define NODE_INFO_GEN(n_) ((NODEW(4 + ((n_) >> 2)) >> (((n_) & 3) * 8)) & 0xff)
 #define SW(c_, s_, f_) SMEM[(c_).sock0 + (((s_) * (c_).P.sock_words + (f_)) << LWSH<K>(c_))]
@@ -389,10 +392,10 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
 // `via_handle`: spawned through a NodeHandle captured at build() (NodeHandle::spawn from another node's task:
 // that Spawner holds the ORIGINAL Arc<NodeInfo>); otherwise task::spawn / init on the node's current info.
 template <class K>
-__device__ __forceinline__ void spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record, bool via_handle = false) {
+__device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record, bool via_handle = false) {
     uint32_t slot = 0;
     while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
-    if (slot >= c.P.max_tasks) { L.ovf = 1; return; }
+    if (slot >= c.P.max_tasks) { L.ovf = 1; return 0xffffffffu; }
     uint32_t gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
     uint32_t pw = PROGW(c, prog);
     uint32_t node = pw & 0xff;
@@ -407,20 +410,32 @@ __device__ __forceinline__ void spawn_task(const Ctx& c, Lane& L, uint32_t prog,
     NODEW(3) = seq + 1;
     TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
     TU(c, slot, 1) = make_uint4(0xffu << 8, (seq & 0xffffff) | (info_gen << 24), 0, 0);   // rxseq 0, no awaiter; spawn order
+    if (K::LIFE && c.P.uses_chan) TU(c, slot, 3) = make_uint4(0xff, 0, 0, 0);                // no connection held
     ready_push<K>(c, L, slot);
     if (record) HW(prog) = H_RUNNING | (slot << 8) | (gen << 16);
+    return slot;
 }
+
+template <class K> __device__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side);
+template <class K> __device__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s);
 
 // The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
 template <class K>
 __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome) {
     uint32_t f = TWORD(c, slot, 0, 0);
     uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
-    // BindGuard::drop (net/mod.rs:483-493), skipped when the binder's NodeInfo is killed
-    if (!(f & TF_KILLED)) {
+    if (K::LIFE && c.P.uses_chan) {                          // the task's (Sender, Receiver) pair drops with its future
+        uint32_t cx = TWORD(c, slot, 3, 0);
+        if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, 3, 0) = cx | 0xff; }
+    }
+    {
         uint32_t own = slot | (gen << 16);
-        for (uint32_t i = 0; i < c.P.n_socks; i++)
-            if ((SW(c, i, 0) & 1) && SW(c, i, 1) == own) SW(c, i, 0) &= ~1u;
+        for (uint32_t i = 0; i < c.P.n_socks; i++) {
+            if (SW(c, i, 1) != own) continue;
+            // BindGuard::drop (net/mod.rs:483-493), skipped when the binder's NodeInfo is killed
+            if (!(f & TF_KILLED) && (SW(c, i, 0) & 1)) SW(c, i, 0) &= ~1u;
+            if (K::LIFE && c.P.uses_chan && (SW(c, i, 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, i);
+        }
     }
     uint32_t h = HW(prog);
     if (h == (H_RUNNING | (slot << 8) | (gen << 16))) { HW(prog) = (h & ~3u) | outcome; if (prog == 0) L.main_done = 1; }
@@ -496,6 +511,59 @@ __device__ void node_restart(const Ctx& c, Lane& L, uint32_t node) {     // Task
     }
 }
 
+// ---- reliable channel (NetSim::connect1 / channel, net/mod.rs:337-430) — LIFE variants only ---------------------
+// Network::try_send as a function (the datagram path has it inlined in poll_task's [A] stage).
+template <class K>
+__device__ bool try_send_fn(const Ctx& c, Lane& L, uint32_t src_node, uint32_t dst_addr, uint64_t* latency, int* dst_sock) {
+    const KParams& P = c.P;
+    uint32_t dst_node = SOCKW(c, dst_addr) & 0xff;
+    bool clogged = false;
+    if (P.has_clog) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
+    if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
+    if (clogged) return false;
+    if (gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) return false;
+    L.msg_count++;
+    *latency = sample_latency<K>(c, L);
+    int ds = find_bound<K>(c, dst_addr);
+    if (ds < 0) return false;
+    *dst_sock = ds;
+    return true;
+}
+
+// the `test_link` closure of channel() (net/mod.rs:375-380): Some(now + latency) or None
+template <class K>
+__device__ uint64_t chan_test_link(const Ctx& c, Lane& L, uint32_t cw, uint32_t dir) {
+    uint32_t c_ep = (cw >> 1) & 0x3f, s_ep = (cw >> 7) & 0x3f;
+    uint64_t lat; int ds;
+    if (!try_send_fn<K>(c, L, SOCKW(c, dir == 0 ? c_ep : s_ep) & 0xff, dir == 0 ? s_ep : c_ep, &lat, &ds)) return ~0ull;
+    return L.clock + lat;
+}
+
+// drop the (Sender, Receiver) pair of one end of connection `id`
+template <class K>
+__device__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side) {
+    uint32_t cw = CONNW(id, 0);
+    if (cw & (1u << (13 + 2 * side))) {                       // my PayloadSender: last mpsc sender gone
+        cw &= ~(1u << (13 + 2 * side));
+        uint32_t r = CONNW(id, 1 + side);
+        if (r & 1) { CONNW(id, 1 + side) = 0; CONNW(id, 0) = cw; wake<K>(c, L, (r >> 1) & 0xff, r >> 9); }   // parked receiver sees None
+    }
+    cw &= ~(1u << (14 + 2 * (1 - side)));                     // my PayloadReceiver
+    CONNW(id, 1 + (1 - side)) = 0;
+    if (!(cw & (0xfu << 13))) cw = 0;                         // all four handles gone: slot is free
+    CONNW(id, 0) = cw;
+}
+
+// the listening Endpoint is dropped: connections still queued in conn_rx go with it
+template <class K>
+__device__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s) {
+    uint32_t base = 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs;
+    uint32_t q = SW(c, s, base);
+    SW(c, s, base) = 0; SW(c, s, base + 1) = 0;
+    uint32_t n = q & 0xf;
+    for (uint32_t i = 0; i < n; i++) conn_drop_handles<K>(c, L, (q >> (4 + 7 * i)) & 0x7f, 1);
+}
+
 // TimeHandle::sleep_until (time/mod.rs:118-124): 1 ms floor
 __device__ __forceinline__ uint64_t sleep_deadline(const Lane& L, uint64_t deadline) {
     uint64_t m = L.clock + NS_PER_MS;
@@ -566,6 +634,31 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         return false;
     };
 
+    // accept1's conn_rx.recv() (endpoint.rs:200): take the oldest queued connection or park. true = op completed.
+    auto accept_check = [&](uint32_t a) -> bool {
+        uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
+        uint32_t q = SW(c, a, base);
+        uint32_t n = q & 0xf;
+        if (n == 0) { SW(c, a, base + 1) = 1u | (slot << 1) | (gen << 9); st = ST_PENDING; return false; }
+        uint32_t id = (q >> 4) & 0x7f;
+        SW(c, a, base) = (n - 1) | ((q >> 11) << 4);           // pop front
+        uint32_t cx = TWORD(c, slot, 3, 0);
+        if ((cx & 0xff) != 0xff) conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1);
+        TWORD(c, slot, 3, 0) = id | (1u << 8);                 // server side
+        return true;
+    };
+    // the receiver stream of channel() (net/mod.rs:386-400) from "a payload is in hand" (sub 1): either sleep(backoff)
+    // while its State is None (sub 2) or sleep_until(arrive_time) (sub 3).  Always ends Pending (1 ms floor).
+    auto crecv_arm = [&]() {
+        uint4 u3 = TU(c, slot, 3);
+        uint64_t arrive = u64of(u3.z, u3.w), d;
+        if (arrive != ~0ull) { d = sleep_deadline(L, arrive); sub = 3; }
+        else { d = sleep_deadline(L, L.clock + (uint64_t)(u3.x >> 16) * NS_PER_MS); sub = 2; }
+        u1.z = (uint32_t)d; u1.w = (uint32_t)(d >> 32); u1_dirty = true;
+        if (!timer_add<K>(c, L, d, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        st = ST_PENDING;
+    };
+
     while (st == ST_RUN) {
         if (pc >= P.n_insns) { st = ST_PANIC; break; }
         uint4 in = INSN(c, pc);
@@ -585,6 +678,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             } else if (K::LIFE && op == MS_OP_RECV_TIMEOUT) {
                 completed = recv_timeout_poll();
                 if (!completed) break;
+            } else if (K::LIFE && op == MS_OP_ACCEPT && sub == 2) {
+                completed = accept_check(a);
+                if (!completed) break;
             } else {                                       // a Sleep (time/sleep.rs:47-54)
                 uint64_t deadline = u64of(u1.z, u1.w);
                 if (L.clock < deadline) {                  // not elapsed: register ANOTHER timer
@@ -592,12 +688,51 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     st = ST_PENDING;
                     break;
                 }
-                if (op == MS_OP_BIND) {                    // Network::bind (network.rs:206-251)
+                if (K::LIFE && op == MS_OP_ACCEPT) {       // rand_delay done -> conn_rx.recv()
+                    sub = 2;
+                    if (!accept_check(a)) break;
+                } else if (K::LIFE && op == MS_OP_CRECV) {
+                    uint4 u3 = TU(c, slot, 3);
+                    if (sub == 2) {                        // sleep(backoff) done: backoff = min(2 * backoff, 10 s); retry the link
+                        uint32_t bo = (u3.x >> 16) * 2; if (bo > 10000) bo = 10000;
+                        uint32_t cw = CONNW(u3.x & 0xff, 0);
+                        uint64_t arrive = chan_test_link<K>(c, L, cw, 1 - ((u3.x >> 8) & 1));
+                        u3.x = (u3.x & 0xffff) | (bo << 16); u3.z = (uint32_t)arrive; u3.w = (uint32_t)(arrive >> 32);
+                        TU(c, slot, 3) = u3;
+                        crecv_arm();
+                        break;
+                    }
+                    u0.w = u3.y;                           // sub 3: sleep_until(arrive_time) done -> yield value
+                } else if (K::LIFE && op == MS_OP_CONNECT) {   // NetSim::connect1 (net/mod.rs:345-363)
+                    uint32_t cx = TWORD(c, slot, 3, 0);
+                    if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, 3, 0) = cx | 0xff; }
+                    uint64_t lat; int ds;
+                    if (!try_send_fn<K>(c, L, SOCKW(c, a) & 0xff, b & 0xff, &lat, &ds)) {
+                        u0.w = MADSIM_VAL_REFUSED;
+                    } else {
+                        uint32_t id = 0;
+                        while (id < P.max_conns && (CONNW(id, 0) & 1)) id++;
+                        uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
+                        uint32_t q = SW(c, ds, base);
+                        if (id >= P.max_conns || (q & 0xf) >= 4) { L.ovf = 1; }
+                        else {
+                            CONNW(id, 0) = 1u | (a << 1) | ((uint32_t)ds << 7) | (0xfu << 13);
+                            CONNW(id, 1) = 0; CONNW(id, 2) = 0;
+                            TWORD(c, slot, 3, 0) = id;             // client side
+                            u0.w = 0;
+                            uint32_t n = q & 0xf;                  // socket.new_connection -> conn_tx.try_send
+                            SW(c, ds, base) = (q & ~0xfu) | (n + 1) | (id << (4 + 7 * n));
+                            uint32_t acc = SW(c, ds, base + 1);
+                            if (acc & 1) { SW(c, ds, base + 1) = 0; wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9); }
+                        }
+                    }
+                } else if (op == MS_OP_BIND) {                    // Network::bind (network.rs:206-251)
                     uint32_t sw = SOCKW(c, a);
                     if ((sw & 0xff) != node || find_bound<K>(c, a) >= 0) { st = ST_PANIC; break; }
                     uint32_t h = SW(c, a, 0);
                     SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);     // bound, gen+1, empty mailbox
                     SW(c, a, 1) = slot | (gen << 16);
+                    if (K::LIFE && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
                 } else if (op == MS_OP_SEND || op == MS_OP_REPLY) {        // net/mod.rs:307-331
                     uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : from;
                     uint32_t src_node = SOCKW(c, a) & 0xff;
@@ -701,8 +836,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 }
             }
             want_delay = (sub == 2);                       // endpoint.rs:145 rand_delay
-        } else if (op == MS_OP_SEND || op == MS_OP_REPLY || op == MS_OP_BIND) {
-            want_delay = true;                             // net/mod.rs:306,457 rand_delay first
+        } else if (op == MS_OP_SEND || op == MS_OP_REPLY || op == MS_OP_BIND || (K::LIFE && (op == MS_OP_CONNECT || op == MS_OP_ACCEPT))) {
+            want_delay = true;                             // net/mod.rs:306,344,457, endpoint.rs:198: rand_delay first
         } else if (K::LIFE && op == MS_OP_RECV_TIMEOUT) {
             uint32_t tag = b >> 8;
             uint64_t d2 = sleep_deadline(L, L.clock + (uint64_t)(b & 0xff) * NS_PER_S + imm);   // timeout()'s Sleep
@@ -769,8 +904,14 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.x = TWORD(c, slot, 0, 0);
                 st = ST_FINISHED;
                 break;
-            case MS_OP_SPAWN:
-                spawn_task<K>(c, L, a, true, (PROGW(c, a) & 0xff) != node);
+            case MS_OP_SPAWN: {
+                uint32_t child = spawn_task<K>(c, L, a, true, (PROGW(c, a) & 0xff) != node);
+                if (K::LIFE && P.uses_chan && (b & 2) && child != 0xffffffffu) {   // `async move`: the (tx, rx) pair moves
+                    uint32_t cx = TWORD(c, slot, 3, 0);
+                    TWORD(c, child, 3, 0) = cx & 0x1ff;
+                    TWORD(c, slot, 3, 0) = cx | 0xff;
+                }
+            }
                 pc++;
                 break;
             case MS_OP_BUILD:
@@ -845,6 +986,53 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_ASSERT_EXIT:                         // Handle::is_exit (task/mod.rs:444-449)
                 if (((NODEW(0) >> a) & 1) != (b & 1)) st = ST_PANIC; else pc++;
                 break;
+            case MS_OP_CSEND: {                            // PayloadSender::send (net/mod.rs:417-421)
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint32_t cx = TWORD(c, slot, 3, 0);
+                if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
+                uint32_t id = cx & 0xff, side = (cx >> 8) & 1;
+                uint32_t cw = CONNW(id, 0);
+                uint64_t arrive = chan_test_link<K>(c, L, cw, side);          // draws happen before the closed check
+                if (!(cw & (1u << (14 + 2 * side)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // ConnectionReset
+                uint32_t qn = (cw >> (17 + 4 * side)) & 0xf;
+                if (qn >= P.chan_queue) { L.ovf = 1; pc++; break; }
+                uint32_t e = 3 + (side * P.chan_queue + qn) * 3;
+                CONNW(id, e) = imm; CONNW(id, e + 1) = (uint32_t)arrive; CONNW(id, e + 2) = (uint32_t)(arrive >> 32);
+                CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * side))) | ((qn + 1) << (17 + 4 * side));
+                uint32_t r = CONNW(id, 1 + side);
+                if (r & 1) { CONNW(id, 1 + side) = 0; wake<K>(c, L, (r >> 1) & 0xff, r >> 9); }   // mpsc wakes the parked receiver
+                pc++;
+                break;
+            }
+            case MS_OP_CRECV: {                            // rx.recv().await (net/mod.rs:386), sub == 0 here
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint32_t cx = TWORD(c, slot, 3, 0);
+                if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
+                uint32_t id = cx & 0xff, dir = 1 - ((cx >> 8) & 1);
+                uint32_t cw = CONNW(id, 0);
+                uint32_t qn = (cw >> (17 + 4 * dir)) & 0xf;
+                if (qn == 0) {
+                    if (!(cw & (1u << (13 + 2 * dir)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // all senders gone
+                    CONNW(id, 1 + dir) = 1u | (slot << 1) | (gen << 9);
+                    st = ST_PENDING;
+                    break;
+                }
+                uint32_t e0 = 3 + dir * P.chan_queue * 3;
+                uint4 u3 = make_uint4((cx & 0x1ff) | (1u << 16), CONNW(id, e0), CONNW(id, e0 + 1), CONNW(id, e0 + 2));   // backoff = 1 ms
+                for (uint32_t i = 1; i < qn; i++)              // VecDeque::pop_front
+                    for (uint32_t k = 0; k < 3; k++) CONNW(id, e0 + (i - 1) * 3 + k) = CONNW(id, e0 + i * 3 + k);
+                CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * dir))) | ((qn - 1) << (17 + 4 * dir));
+                TU(c, slot, 3) = u3;
+                crecv_arm();
+                break;
+            }
+            case MS_OP_CCLOSE: {
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint32_t cx = TWORD(c, slot, 3, 0);
+                if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, 3, 0) = cx | 0xff; }
+                pc++;
+                break;
+            }
             case MS_OP_GSET: GREGW(a & 3) = imm; pc++; break;
             case MS_OP_GADD: GREGW(a & 3) += imm; pc++; break;
             case MS_OP_ASSERT_G: if (GREGW(a & 3) != imm) st = ST_PANIC; else pc++; break;
@@ -873,6 +1061,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_CLOSE: {
                 uint32_t h = SW(c, a, 0);
                 if ((h & 1) && SW(c, a, 1) == (slot | (gen << 16)) && !(u0.x & TF_KILLED)) SW(c, a, 0) = h & ~1u;
+                if (K::LIFE && P.uses_chan && SW(c, a, 1) == (slot | (gen << 16)) && (SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, a);
                 pc++;
                 break;
             }
@@ -979,6 +1168,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
     c.clog0 = pl + (P.off_clog << P.lw_shift);
     c.pause0 = pl + (P.off_pause << P.lw_shift);
     c.greg0 = pl + (P.off_greg << P.lw_shift);
+    c.conn0 = pl + (P.off_conn << P.lw_shift);
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
     const uint32_t glane = (blockIdx.x << P.lw_shift) + lane;
     c.spill = P.spill ? P.spill + glane : nullptr;

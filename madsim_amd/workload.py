@@ -44,8 +44,8 @@ class TaskBuilder:
     def done(self):
         return self._emit("DONE")
 
-    def spawn(self, task):
-        return self._emit("SPAWN", a=task.index)
+    def spawn(self, task, move_conn=False):
+        return self._emit("SPAWN", a=task.index, b=2 if move_conn else 0)
 
     def join(self, task, expect_err=False):
         return self._emit("JOIN", a=task.index, b=1 if expect_err else 0)
@@ -115,6 +115,22 @@ class TaskBuilder:
 
     def assert_val(self, val):
         return self._emit("ASSERT_VAL", imm=val)
+
+    # -- reliable channel (Endpoint::connect1 / accept1, net/mod.rs:337-430) -----------------------
+    def connect1(self, ep, dst):
+        return self._emit("CONNECT", a=ep, b=dst)
+
+    def accept1(self, ep):
+        return self._emit("ACCEPT", a=ep)
+
+    def chan_send(self, val):
+        return self._emit("CSEND", imm=val)
+
+    def chan_recv(self):
+        return self._emit("CRECV")
+
+    def chan_close(self):
+        return self._emit("CCLOSE")
 
     def close(self, ep):
         return self._emit("CLOSE", a=ep)

@@ -21,7 +21,7 @@ _LIB = os.path.join(_HERE, "libmadsim_oracle.so")
 
 class OracleStats(C.Structure):
     _fields_ = [("max_heap", C.c_uint32), ("max_ready", C.c_uint32), ("max_tasks", C.c_uint32),
-                ("max_msgs", C.c_uint32), ("max_regs", C.c_uint32)]
+                ("max_msgs", C.c_uint32), ("max_regs", C.c_uint32), ("max_conns", C.c_uint32), ("max_cq", C.c_uint32)]
 
 
 def build(force=False):

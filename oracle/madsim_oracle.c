@@ -88,11 +88,25 @@ typedef struct {           /* naive_timer::Event: deadline + boxed callback     
 typedef struct { uint8_t tag; uint16_t slot, gen; uint8_t rxseq; } reg_t;  /* (tag, oneshot::Sender) */
 typedef struct { uint8_t tag, from; uint32_t val; } msg_t;                 /* endpoint.rs:288-292    */
 
+typedef struct { uint32_t val; uint8_t has_arrive; uint64_t arrive; } cmsg_t;   /* (Payload, State) net/mod.rs:411-415 */
+typedef struct {                          /* one direction of a connection: net/mod.rs:367-405 channel()            */
+    uint8_t tx_alive, rx_alive;           /* PayloadSender / PayloadReceiver still held                              */
+    VEC(cmsg_t) q;                        /* tokio unbounded mpsc                                                    */
+    int32_t rx_task; uint16_t rx_gen;     /* task parked in rx.recv()                                                */
+} cdir_t;
+typedef struct {
+    uint8_t alive;
+    uint8_t c_ep, s_ep;                   /* client endpoint address, listening endpoint address                    */
+    cdir_t d[2];                          /* [0] client -> server, [1] server -> client                             */
+} conn_t;
+
 typedef struct {
     uint8_t bound; uint8_t gen;           /* gen: which Endpoint object currently owns the address   */
     uint16_t owner_slot, owner_gen;
     VEC(reg_t) registered;                /* endpoint.rs:298-303 Mailbox                             */
     VEC(msg_t) msgs;
+    VEC(uint8_t) acceptq;                 /* conn_tx/conn_rx: pending connections (endpoint.rs:18,307) */
+    int32_t acc_task; uint16_t acc_gen;   /* task parked in accept1's conn_rx.recv()                  */
 } sock_t;
 
 enum { AW_NONE = 0 };
@@ -113,6 +127,8 @@ typedef struct {
     uint32_t val; uint8_t from;
     uint8_t  inbox_full; uint8_t rxseq;   /* the oneshot::Receiver currently held                    */
     int32_t  joiner; uint16_t joiner_gen; /* async-task awaiter                                      */
+    int8_t   conn; uint8_t side;          /* the (Sender, Receiver) pair this task holds, and which end */
+    uint32_t cval; uint8_t chas; uint64_t carrive; uint32_t backoff_ms;   /* receiver stream state (net/mod.rs:386-400) */
 } task_t;
 
 enum { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
@@ -150,6 +166,7 @@ typedef struct {
     /* accounting */
     uint64_t msg_count; uint32_t steps; uint64_t obs_hash;
     uint32_t greg[4];                     /* Arc<AtomicUsize> flags shared by the test's tasks       */
+    VEC(conn_t) conns;
     uint32_t panic; int main_slot;
     madsim_oracle_stats_t st;
 } sim_t;
@@ -344,6 +361,7 @@ static void mailbox_deliver(sim_t* S, event_t* e) {
 /* ------------------------------------------------------------------------------------------------
  * task lifecycle
  * ---------------------------------------------------------------------------------------------- */
+static void sock_drop_acceptq(sim_t* S, sock_t* k);
 static void sock_close_owned(sim_t* S, uint16_t slot, uint16_t gen, int node_killed) {
     /* BindGuard::drop (net/mod.rs:483-493): skipped when the binder's NodeInfo is killed */
     for (uint32_t i = 0; i < S->w->n_socks; i++) {
@@ -352,6 +370,7 @@ static void sock_close_owned(sim_t* S, uint16_t slot, uint16_t gen, int node_kil
             if (!node_killed) { k->bound = 0; }
             /* the Endpoint (and its mailbox) is unreachable from now on either way */
         }
+        if (k->owner_slot == slot && k->owner_gen == gen && k->acceptq.n) sock_drop_acceptq(S, k);
     }
 }
 
@@ -373,7 +392,7 @@ static int spawn_task_on(sim_t* S, unsigned prog, int record_handle, int via_han
         else { t->killed = via_handle ? n->gen0_killed : n->killed; t->info_gen = n->info_gen; }  /* :632-634 */
         if (t->info_gen == n->info_gen) { tref_t r = { (uint16_t)slot, gen }; vec_push(n->tasks, r); }
     }
-    t->pc = S->w->progs[prog].entry; t->joiner = -1;
+    t->pc = S->w->progs[prog].entry; t->joiner = -1; t->conn = -1;
     t->scheduled = 1;                                     /* runnable.schedule() :651 */
     ready_push(S, (uint16_t)slot);
     if (record_handle) { S->handles[prog].state = H_RUNNING; S->handles[prog].slot = (uint16_t)slot; S->handles[prog].gen = gen; }
@@ -432,9 +451,46 @@ static void node_restart(sim_t* S, unsigned node) {       /* TaskHandle::restart
         if (S->w->progs[p].node == node && (S->w->progs[p].flags & MADSIM_PROG_INIT)) spawn_task(S, p, 0);
 }
 
+/* ---- reliable channel: NetSim::connect1 / channel (net/mod.rs:337-430), Endpoint::accept1 (endpoint.rs:197-211) ---- */
+static int try_send(sim_t* S, unsigned src_node, unsigned dst_addr, uint64_t* latency, int* dst_sock);
+
+/* the `test_link` closure of channel(): try_send(..).map(|latency| now + latency) (net/mod.rs:375-380) */
+static int chan_test_link(sim_t* S, conn_t* c, int dir, uint64_t* arrive) {
+    unsigned src_node = S->w->socks[dir == 0 ? c->c_ep : c->s_ep].node;
+    unsigned dst_addr = dir == 0 ? c->s_ep : c->c_ep;
+    uint64_t lat; int ds;
+    if (!try_send(S, src_node, dst_addr, &lat, &ds)) return 0;
+    *arrive = S->clock + lat;
+    return 1;
+}
+
+static void conn_drop_handles(sim_t* S, int id, int side);
+/* the listening Endpoint is dropped: connections still queued in conn_rx go with it (their server-side handles).
+ * Modelling note: the reference frees them when the last Arc<EndpointSocket> dies, which an in-flight
+ * datagram closure can postpone; here it happens with the Endpoint. */
+static void sock_drop_acceptq(sim_t* S, sock_t* k) {
+    size_t n = k->acceptq.n; k->acceptq.n = 0; k->acc_task = -1;
+    for (size_t i = 0; i < n; i++) conn_drop_handles(S, k->acceptq.p[i], 1);
+}
+
+static void conn_drop_handles(sim_t* S, int id, int side) {   /* drop (Sender, Receiver) of one end */
+    if (id < 0) return;
+    conn_t* c = &S->conns.p[id];
+    cdir_t* out = &c->d[side], *in = &c->d[1 - side];
+    if (out->tx_alive) {
+        out->tx_alive = 0;                                    /* last mpsc sender dropped: a parked receiver wakes */
+        if (out->rx_task >= 0) { int32_t r = out->rx_task; out->rx_task = -1; wake(S, (uint16_t)r, out->rx_gen); }
+    }
+    in->rx_alive = 0; in->rx_task = -1;
+    if (!c->d[0].tx_alive && !c->d[0].rx_alive && !c->d[1].tx_alive && !c->d[1].rx_alive) {
+        c->alive = 0; c->d[0].q.n = 0; c->d[1].q.n = 0;
+    }
+}
+
 /* The future is gone (completed, or dropped by the executor).  outcome: H_COMPLETED / H_CANCELLED. */
 static void task_finish(sim_t* S, uint16_t slot, int outcome) {
     task_t* t = &S->tasks.p[slot];
+    if (t->conn >= 0) { conn_drop_handles(S, t->conn, t->side); t->conn = -1; }
     sock_close_owned(S, slot, t->gen, t->killed);
     handle_t* h = &S->handles[t->prog];
     if (h->state == H_RUNNING && h->slot == slot && h->gen == t->gen) h->state = (uint8_t)outcome;
@@ -490,8 +546,14 @@ static int poll_task(sim_t* S, uint16_t slot) {
             task_finish(S, slot, H_COMPLETED);
             return 0;
         case MS_OP_SPAWN:
-            spawn_task_on(S, in->a, 1, w->progs[in->a].node != t->node);
-            t = &S->tasks.p[slot]; t->pc++;
+            {
+                int child = spawn_task_on(S, in->a, 1, w->progs[in->a].node != t->node);
+                t = &S->tasks.p[slot];
+                if ((in->b & 2) && child >= 0) {           /* `spawn(async move { .. tx, rx .. })`: the handles move */
+                    S->tasks.p[child].conn = t->conn; S->tasks.p[child].side = t->side; t->conn = -1;
+                }
+            }
+            t->pc++;
             break;
         case MS_OP_BUILD:                                  /* create_node().init(..).build(): task/mod.rs:472-474 */
             for (uint32_t p = 1; p < w->n_progs; p++)
@@ -592,6 +654,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 sock_t* k = &S->socks[in->a];
                 k->bound = 1; k->gen++; k->owner_slot = slot; k->owner_gen = t->gen;
                 k->registered.n = 0; k->msgs.n = 0;        /* a fresh Endpoint + Mailbox */
+                k->acceptq.n = 0; k->acc_task = -1;
             }
             t->sub = 0; t->pc++;
             break;
@@ -639,6 +702,87 @@ static int poll_task(sim_t* S, uint16_t slot) {
             t->sub = 0; t->pc++;
             break;
         }
+        case MS_OP_CONNECT:                                /* Endpoint::connect1 -> NetSim::connect1 (net/mod.rs:337-364) */
+            if (t->sub == 0) { t->deadline = rand_delay_start(S); t->sub = 1; }
+            if (!sleep_poll(S, slot, t->deadline)) return 0;
+            {
+                if (t->conn >= 0) { conn_drop_handles(S, t->conn, t->side); t->conn = -1; }
+                uint64_t lat; int ds;
+                if (!try_send(S, w->socks[in->a].node, in->b & 0xff, &lat, &ds)) {
+                    t->val = MADSIM_VAL_REFUSED;           /* io::ErrorKind::ConnectionRefused */
+                } else {
+                    size_t id = 0;
+                    while (id < S->conns.n && S->conns.p[id].alive) id++;
+                    if (id == S->conns.n) { conn_t z; memset(&z, 0, sizeof z); vec_push(S->conns, z); }
+                    conn_t* c = &S->conns.p[id];
+                    c->alive = 1; c->c_ep = in->a; c->s_ep = (uint8_t)ds;
+                    for (int d = 0; d < 2; d++) { c->d[d].tx_alive = c->d[d].rx_alive = 1; c->d[d].q.n = 0; c->d[d].rx_task = -1; }
+                    t->conn = (int8_t)id; t->side = 0; t->val = 0;
+                    sock_t* k = &S->socks[ds];             /* socket.new_connection -> conn_tx.try_send (endpoint.rs:320-328) */
+                    vec_push(k->acceptq, (uint8_t)id);
+                    if (k->acc_task >= 0) { int32_t a = k->acc_task; k->acc_task = -1; wake(S, (uint16_t)a, k->acc_gen); }
+                    if (S->conns.n > S->st.max_conns) S->st.max_conns = (uint32_t)S->conns.n;
+                }
+            }
+            t = &S->tasks.p[slot]; t->sub = 0; t->pc++;
+            break;
+        case MS_OP_ACCEPT: {                               /* Endpoint::accept1 (endpoint.rs:197-211) */
+            if (t->sub == 0) { t->deadline = rand_delay_start(S); t->sub = 1; }
+            if (t->sub == 1) { if (!sleep_poll(S, slot, t->deadline)) return 0; t->sub = 2; }
+            sock_t* k = &S->socks[in->a];
+            if (k->acceptq.n == 0) { k->acc_task = slot; k->acc_gen = t->gen; return 0; }   /* conn_rx.recv() pending */
+            if (t->conn >= 0) { conn_drop_handles(S, t->conn, t->side); t->conn = -1; }
+            t->conn = (int8_t)k->acceptq.p[0];
+            memmove(k->acceptq.p, k->acceptq.p + 1, --k->acceptq.n);
+            t->side = 1; t->sub = 0; t->pc++;
+            break;
+        }
+        case MS_OP_CSEND: {                                /* Sender::send -> PayloadSender::send (net/mod.rs:417-421) */
+            if (t->conn < 0) { t->val = MADSIM_VAL_RESET; t->pc++; break; }
+            conn_t* c = &S->conns.p[t->conn];
+            cdir_t* d = &c->d[t->side];
+            cmsg_t m; m.val = in->imm; m.arrive = 0;
+            m.has_arrive = (uint8_t)chan_test_link(S, c, t->side, &m.arrive);      /* draws happen before the closed check */
+            if (!d->rx_alive) { t->val = MADSIM_VAL_RESET; t->pc++; break; }        /* ConnectionReset */
+            vec_push(d->q, m);
+            if (d->q.n > S->st.max_cq) S->st.max_cq = (uint32_t)d->q.n;
+            if (d->rx_task >= 0) { int32_t r = d->rx_task; d->rx_task = -1; wake(S, (uint16_t)r, d->rx_gen); }
+            t = &S->tasks.p[slot]; t->pc++;
+            break;
+        }
+        case MS_OP_CRECV: {                                /* Receiver::recv -> the stream of channel() (net/mod.rs:385-402) */
+            if (t->conn < 0) { t->val = MADSIM_VAL_RESET; t->pc++; break; }
+            conn_t* c = &S->conns.p[t->conn];
+            cdir_t* d = &c->d[1 - t->side];
+            if (t->sub == 0) {                             /* rx.recv().await */
+                if (d->q.n == 0) {
+                    if (!d->tx_alive) { t->val = MADSIM_VAL_RESET; t->pc++; break; }
+                    d->rx_task = slot; d->rx_gen = t->gen;
+                    return 0;
+                }
+                cmsg_t m = d->q.p[0];
+                memmove(d->q.p, d->q.p + 1, (--d->q.n) * sizeof(cmsg_t));
+                t->cval = m.val; t->chas = m.has_arrive; t->carrive = m.arrive; t->backoff_ms = 1;
+                t->sub = 1;
+            }
+            for (;;) {
+                if (t->sub == 1) {
+                    if (t->chas) { t->deadline = sleep_deadline(S, t->carrive); t->sub = 3; }          /* sleep_until(arrive_time) */
+                    else { t->deadline = sleep_deadline(S, S->clock + (uint64_t)t->backoff_ms * NS_PER_MS); t->sub = 2; }  /* sleep(backoff) */
+                }
+                if (!sleep_poll(S, slot, t->deadline)) return 0;
+                if (t->sub == 3) break;
+                t->backoff_ms = t->backoff_ms * 2 > 10000 ? 10000 : t->backoff_ms * 2;               /* min(backoff * 2, 10 s) */
+                t->chas = (uint8_t)chan_test_link(S, c, 1 - t->side, &t->carrive);                   /* retry */
+                t->sub = 1;
+            }
+            t->val = t->cval; t->sub = 0; t->pc++;
+            break;
+        }
+        case MS_OP_CCLOSE:
+            if (t->conn >= 0) { conn_drop_handles(S, t->conn, t->side); t = &S->tasks.p[slot]; t->conn = -1; }
+            t->pc++;
+            break;
         case MS_OP_ASSERT_VAL:
             if (t->val != in->imm) return 1;
             t->pc++;
@@ -701,6 +845,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
         case MS_OP_CLOSE: {
             sock_t* k = &S->socks[in->a];
             if (k->bound && k->owner_slot == slot && k->owner_gen == t->gen && !t->killed) k->bound = 0;
+            if (k->owner_slot == slot && k->owner_gen == t->gen && k->acceptq.n) { sock_drop_acceptq(S, k); t = &S->tasks.p[slot]; }
             t->pc++;
             break;
         }
@@ -822,6 +967,7 @@ static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, cons
     S.nodes = calloc(w->n_nodes + 1, sizeof *S.nodes);
     S.socks = calloc(w->n_socks ? w->n_socks : 1, sizeof *S.socks);
     S.clog_link = calloc(w->n_nodes + 1, sizeof *S.clog_link);
+    for (uint32_t i = 0; i < w->n_socks; i++) S.socks[i].acc_task = -1;
     S.trace_hash = FNV_OFFSET; S.obs_hash = FNV_OFFSET;
     S.log = log; S.log_cap = log_cap;
     S.buggify = cfg->buggify != 0;
@@ -870,8 +1016,12 @@ static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, cons
         if (S.st.max_tasks > stats->max_tasks) stats->max_tasks = S.st.max_tasks;
         if (S.st.max_msgs > stats->max_msgs) stats->max_msgs = S.st.max_msgs;
         if (S.st.max_regs > stats->max_regs) stats->max_regs = S.st.max_regs;
+        if (S.st.max_conns > stats->max_conns) stats->max_conns = S.st.max_conns;
+        if (S.st.max_cq > stats->max_cq) stats->max_cq = S.st.max_cq;
     }
-    for (uint32_t i = 0; i < w->n_socks; i++) { vec_free(S.socks[i].registered); vec_free(S.socks[i].msgs); }
+    for (uint32_t i = 0; i < w->n_socks; i++) { vec_free(S.socks[i].registered); vec_free(S.socks[i].msgs); vec_free(S.socks[i].acceptq); }
+    for (size_t i = 0; i < S.conns.n; i++) { vec_free(S.conns.p[i].d[0].q); vec_free(S.conns.p[i].d[1].q); }
+    vec_free(S.conns);
     for (uint32_t i = 0; i <= w->n_nodes; i++) { vec_free(S.nodes[i].paused_list); vec_free(S.nodes[i].tasks); }
     vec_free(S.heap); vec_free(S.ready); vec_free(S.tasks);
     free(S.handles); free(S.nodes); free(S.socks); free(S.clog_link);

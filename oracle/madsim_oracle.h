@@ -18,6 +18,8 @@ typedef struct madsim_oracle_stats {
     uint32_t max_tasks;  /* live futures */
     uint32_t max_msgs;   /* Mailbox.msgs per socket */
     uint32_t max_regs;   /* Mailbox.registered per socket */
+    uint32_t max_conns;  /* live connections */
+    uint32_t max_cq;     /* queued payloads per channel direction */
 } madsim_oracle_stats_t;
 
 int madsim_oracle_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0,

@@ -123,8 +123,8 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4):
     for i, n in enumerate(nodes):
         is_init = rng.random() < 0.6
         t = wl.task(n, init=is_init)
-        kind = rng.choice(["server", "client", "ticker", "crasher", "short"])
-        if n_nodes == 1 and kind in ("server", "client"):
+        kind = rng.choice(["server", "client", "ticker", "crasher", "short", "rpc_server", "rpc_client", "rpc_client"])
+        if n_nodes == 1 and kind in ("server", "client", "rpc_server", "rpc_client"):
             kind = "ticker"
         desc.append(("i:" if is_init else "") + kind)
         if kind == "server":
@@ -141,6 +141,30 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4):
             else:
                 t.sleep_rand(lo_ms=0, ms=rng.randint(1, 40))
             t.djnz(0, top)
+        elif kind == "rpc_server":
+            # loop { accept1; recv request; maybe reply; drop } (the madsim-etcd/tonic server shape, without per-request tasks)
+            t.bind(addrs[i])
+            top = t.label()
+            t.accept1(addrs[i]); t.chan_recv(); t.trace(900 + i)
+            if rng.random() < 0.8:
+                t.chan_send(0x50 + i)
+            if rng.random() < 0.3:
+                t.chan_recv()
+            t.jmp(top)
+        elif kind == "rpc_client":
+            peer = rng.choice([j for j in range(n_nodes) if j != i])
+            t.bind(addrs[i]); t.sleep(ms=rng.randint(0, 30)); t.set(0, rng.randint(1, 4))
+            top = t.label()
+            t.connect1(addrs[i], addrs[peer])
+            skip = t.label() + 5
+            t.jeq(A.VAL_REFUSED, skip)
+            t.chan_send(0x60 + i)
+            if rng.random() < 0.5:
+                t.chan_send(0x61 + i)
+            else:
+                t.sleep(ms=1)
+            t.chan_recv(); t.trace(950 + i)
+            t.sleep(ms=rng.choice([0, 5, 60])); t.djnz(0, top)
         elif kind == "ticker":
             top = t.label()
             t.sleep(ms=rng.choice([1, 7, 30, 100])); t.flag_add(1, 1); t.trace(7, add_reg=0)
@@ -161,7 +185,7 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4):
         else:
             m.spawn(tasks[i])
     for _ in range(rng.randint(1, 8)):
-        act = rng.choice(["sleep", "sleep", "kill", "restart", "pause", "resume", "abort", "spawn", "yield", "exit?"])
+        act = rng.choice(["sleep", "sleep", "kill", "restart", "pause", "resume", "abort", "spawn", "yield", "clog", "unclog"])
         n = rng.choice(nodes)
         if act == "sleep":
             m.sleep(ms=rng.choice([0, 3, 25, 150, 2500]))
@@ -183,9 +207,15 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4):
                 m.spawn(rng.choice(cand))
         elif act == "yield":
             m.yield_now()
+        elif act == "clog":
+            m.clog_node(n, rng.choice(["in", "out", "both"]))
+        elif act == "unclog":
+            m.unclog_node(n, "both")
     for n in nodes:
         if rng.random() < 0.3:
             m.resume(n)
+        if rng.random() < 0.5:
+            m.unclog_node(n, "both")
     m.sleep(ms=rng.choice([10, 500, 12000]))
     m.done()
     cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.1]), buggify=rng.random() < 0.15)
@@ -196,5 +226,7 @@ def generous_limits():
     lim = A.Limits()
     lim.max_steps = 200_000
     lim.heap_lds_slots, lim.heap_spill_slots = 4, 60     # small LDS quota: the spill path gets exercised too
+    lim.max_conns, lim.chan_queue = 8, 4
+    lim.lanes_per_wave = 16                    # generous per-seed state: carry fewer seeds per wave so it fits LDS
     lim.mbox_regs, lim.mbox_msgs = 15, 15      # timed-out recv_from leaves dead registrations behind (reference: unbounded Vec)
     return lim

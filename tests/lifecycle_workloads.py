@@ -184,3 +184,65 @@ ALL = dict(receiver_drop=receiver_drop, request_timeout_with_stale_timers=reques
            pause_resume=pause_resume, kill_drop_futures=kill_drop_futures, join_cancelled=join_cancelled,
            exited=exited, spawn_on_killed_node=spawn_on_killed_node, kill_restart_with_traffic=kill_restart_with_traffic)
 EXPECT_PANIC = {"panic_without_restart"}
+
+
+def kv_rpc(n_clients=2, n_ops=3):
+    """The request-per-connection shape every higher simulator uses (madsim-etcd-client/src/kv.rs:37-53,
+    server.rs:34-40; madsim-tonic client.rs:66): client connect1 -> send request -> recv response;
+    server: loop { accept1; spawn(handler with the moved (tx, rx)) }."""
+    wl = W.WorkloadBuilder()
+    ns = wl.create_node()
+    asv = wl.addr(ns, 2379)
+    handler = wl.task(ns)
+    handler.chan_recv(); handler.assert_val(0x11); handler.flag_add(0, 1); handler.chan_send(0x22)
+    srv = wl.task(ns)
+    srv.bind(asv)
+    top = srv.label()
+    srv.accept1(asv); srv.spawn(handler, move_conn=True); srv.jmp(top)
+    clients = []
+    for i in range(n_clients):
+        nc = wl.create_node()
+        acl = wl.addr(nc, 1)
+        c = wl.task(nc)
+        c.bind(acl); c.sleep(ms=10); c.set(0, n_ops)
+        top = c.label()
+        c.connect1(acl, asv); c.assert_val(0); c.chan_send(0x11); c.chan_recv(); c.assert_val(0x22); c.chan_close(); c.djnz(0, top)
+        clients.append(c)
+    m = wl.main()
+    m.spawn(srv)
+    for c in clients:
+        m.spawn(c)
+    for c in clients:
+        m.join(c)
+    m.assert_flag(0, n_clients * n_ops)
+    return wl.build()
+
+
+def channel_backoff():
+    """net/mod.rs:388-398: a payload sent while the link is clogged is stamped None; the receiver retries with
+    1 ms -> 2 -> 4 ... backoff and delivers once the supervisor unclogs the link."""
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
+    srv = wl.task(ns); srv.bind(asv); srv.accept1(asv); srv.mark(); srv.chan_recv(); srv.assert_val(7); srv.assert_elapsed(">=", secs=2)
+    cl = wl.task(nc); cl.bind(acl); cl.sleep(ms=10); cl.connect1(acl, asv); cl.assert_val(0); cl.sleep(ms=100); cl.chan_send(7); cl.sleep(secs=10)
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.sleep(ms=50); m.clog_link(nc, ns); m.sleep(secs=3); m.unclog_link(nc, ns); m.join(srv)
+    return wl.build()
+
+
+def connect_refused_and_reset():
+    """net/mod.rs:351-354 ConnectionRefused (nobody listening); endpoint.rs:243-244 / 259-260 ConnectionReset
+    (peer dropped its handles)."""
+    from madsim_amd import _abi as A
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
+    srv = wl.task(ns); srv.sleep(ms=100); srv.bind(asv); srv.accept1(asv); srv.chan_recv(); srv.assert_val(1)     # then drops (tx, rx)
+    cl = wl.task(nc); cl.bind(acl); cl.connect1(acl, asv); cl.assert_val(A.VAL_REFUSED)
+    cl.sleep(ms=300); cl.connect1(acl, asv); cl.assert_val(0); cl.chan_send(1); cl.chan_recv(); cl.assert_val(A.VAL_RESET)
+    cl.sleep(ms=100); cl.chan_send(2); cl.assert_val(A.VAL_RESET)
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.join(cl)
+    return wl.build()
+
+
+ALL.update(kv_rpc=kv_rpc, channel_backoff=channel_backoff, connect_refused_and_reset=connect_refused_and_reset)
