@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--seeds", type=int, default=SEEDS_PER_GPU, help="seeds per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lpw", type=int, default=0, help="seed-carrying lanes per wave (0 = library auto)")
+    ap.add_argument("--workload", default="pingpong", choices=["pingpong", "raft", "kv"],
+                    help="pingpong = BASELINE configs[1] (the headline); raft / kv = configs[2] / configs[3]-shaped extras")
     args = ap.parse_args()
 
     import torch
@@ -60,10 +62,18 @@ def main():
     cdev = dev if backend == "nccl" else torch.device("cpu")     # where the 32-byte report tensors live
     runtime.init(gpu)
 
-    w = workload.pingpong(N_NODES, ROUNDS)
-    lim = A.Limits()
-    lim.heap_lds_slots, lim.heap_spill_slots = 8, 0      # pingpong needs <= 4 timers; overflow would be a verdict
-    lim.mbox_regs, lim.mbox_msgs = 1, 1
+    if args.workload == "pingpong":
+        w = workload.pingpong(N_NODES, ROUNDS)
+        wname = f"{N_NODES}-node ping-pong, R={ROUNDS}, Config::default()"
+        lim = A.Limits()
+        lim.heap_lds_slots, lim.heap_spill_slots = 8, 0      # pingpong needs <= 4 timers; overflow would be a verdict
+        lim.mbox_regs, lim.mbox_msgs = 1, 1
+    elif args.workload == "raft":
+        w, lim = workload.raft_election(), workload.raft_election_limits()
+        wname = "5-node election loop with partition injection (configs[2] shape)"
+    else:
+        w, lim = workload.kv_rpc(), workload.kv_rpc_limits()
+        wname = "etcd-style KV ops over connect1/accept1 (configs[3] shape)"
     lim.lanes_per_wave = args.lpw
     per_gpu = args.seeds
     total = per_gpu * world
@@ -113,7 +123,7 @@ def main():
         # profiles/r1_traffic.json): FETCH_SIZE (x2, the gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if world == 1 and per_gpu == SEEDS_PER_GPU and os.path.exists(tpath):
+        if world == 1 and per_gpu == SEEDS_PER_GPU and args.workload == "pingpong" and os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = (2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0
         line = {
@@ -121,8 +131,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": f"{N_NODES}-node ping-pong, R={ROUNDS}, Config::default(), "
-                                   f"{per_gpu} seeds per GPU per step (BASELINE configs[1])",
+            "config": {"workload": f"{wname}, {per_gpu} seeds per GPU per step"
+                                   + (" (BASELINE configs[1])" if args.workload == "pingpong" else ""),
                        "seeds_per_step": total, "parallelism": f"seed-shard x{world}"},
             "extra": {"seeds_per_sec": seeds_total / dt, "executor_steps_per_sec": steps_total / dt,
                       "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms,
@@ -130,7 +140,7 @@ def main():
                       "lanes_per_wave": g.lanes_per_wave},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "sim_kernel<Variant<false,false,6,false>>", "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel": "sim_kernel<Variant<false,false,6,false>>" if args.workload == "pingpong" else "sim_kernel<Variant<false,true,-1,true>>", "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "LDS-resident path: algorithmic bytes (120 B/executor step) never touch HBM"},
         }
         if world == 1 and not args.no_cpu_baseline:

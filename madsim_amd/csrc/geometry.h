@@ -105,7 +105,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     if (P.max_tasks > 254) return fail(err, MADSIM_E_LIMITS, "max_tasks must be <= 254");
     P.mbox_regs = L.mbox_regs ? L.mbox_regs : 2;
     P.mbox_msgs = L.mbox_msgs ? L.mbox_msgs : 2;
-    if (P.mbox_regs > 15 || P.mbox_msgs > 15) return fail(err, MADSIM_E_LIMITS, "mailbox capacities must be <= 15");
+    if (P.mbox_regs > 255 || P.mbox_msgs > 255) return fail(err, MADSIM_E_LIMITS, "mailbox capacities must be <= 255");
     P.heap_lds = L.heap_lds_slots ? L.heap_lds_slots : 8;
     P.heap_spill = (L.heap_lds_slots || L.heap_spill_slots) ? L.heap_spill_slots : 56;
     bool t0 = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_RECV_TIMEOUT);
@@ -159,6 +159,9 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     if (L.lanes_per_wave) {
         lw = L.lanes_per_wave;
         if (lw != 8 && lw != 16 && lw != 32 && lw != 64) return fail(err, MADSIM_E_LIMITS, "lanes_per_wave must be 8, 16, 32 or 64");
+    } else {
+        // large per-seed state (big mailboxes, many tasks): carry fewer seeds per wave so a workgroup still fits
+        while (lw > 8 && (size_t)sh_bytes + (size_t)lw * G->lds_per_seed > g.lds_per_cu) lw >>= 1;
     }
     P.lw_shift = lw == 8 ? 3 : lw == 16 ? 4 : lw == 32 ? 5 : 6;
     P.sh_tasks = P.sh_heap + P.heap_lds * lw * 4;

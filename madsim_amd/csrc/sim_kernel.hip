@@ -341,7 +341,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     uint32_t s = meta & 0x3f, from = (meta >> 6) & 0x3f, tag = (meta >> 12) & 0xff, sgen = (meta >> 20) & 0xff;
     uint32_t h = SW(c, s, 0);
     if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;     // that Endpoint object is gone
-    uint32_t nreg = (h >> 9) & 0xf, nmsg = (h >> 13) & 0xf;
+    uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
     uint32_t i = 0;
     while (i < nreg) {
         uint32_t r = SW(c, s, 2 + i);
@@ -358,7 +358,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
                 u0.y = (u0.y & 0x00ffffffu) | (from << 24);
                 u0.w = val;
                 TU(c, slot, 0) = u0;
-                SW(c, s, 0) = (h & ~(0xfu << 9)) | (nreg << 9);
+                SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);
                 if (!sched && !(u0.x & TF_RUN)) ready_push<K>(c, L, slot);
                 return;
             }
@@ -370,7 +370,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);
     SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg + 1) = val;
     nmsg++;
-    SW(c, s, 0) = (h & ~((0xfu << 9) | (0xfu << 13))) | (nreg << 9) | (nmsg << 13);
+    SW(c, s, 0) = (h & ~((0xffu << 9) | (0xffu << 17))) | (nreg << 9) | (nmsg << 17);
 }
 
 template <class K> __device__ void node_restart(const Ctx& c, Lane& L, uint32_t node);
@@ -550,7 +550,7 @@ __device__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t s
     }
     cw &= ~(1u << (14 + 2 * (1 - side)));                     // my PayloadReceiver
     CONNW(id, 1 + (1 - side)) = 0;
-    if (!(cw & (0xfu << 13))) cw = 0;                         // all four handles gone: slot is free
+    if (!(cw & (0xfu << 13))) cw = 0;                          // all four handles gone: slot is free
     CONNW(id, 0) = cw;
 }
 
@@ -815,7 +815,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
                 u0.x &= ~TF_INBOX;
                 uint32_t h = SW(c, a, 0);
-                uint32_t nreg = (h >> 9) & 0xf, nmsg = (h >> 13) & 0xf;
+                uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
                 uint32_t idx = 0, mbase = 2 + P.mbox_regs;
                 while (idx < nmsg && (SW(c, a, mbase + 2 * idx) & 0xff) != tag) idx++;
                 if (idx < nmsg) {
@@ -826,11 +826,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     u0.w = m1;
                     from = (m0 >> 8) & 0xff;
                     sub = 2;                               // oneshot already holds the value
-                    SW(c, a, 0) = (h & ~(0xfu << 13)) | (nmsg << 13);
+                    SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
                 } else {
                     if (nreg >= P.mbox_regs) { L.ovf = 1; st = ST_PENDING; break; }
                     SW(c, a, 2 + nreg) = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
-                    SW(c, a, 0) = (h & ~(0xfu << 9)) | ((nreg + 1) << 9);
+                    SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
                     sub = 1;
                     st = ST_PENDING;
                 }
@@ -848,7 +848,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
             u0.x &= ~TF_INBOX;
             uint32_t h = SW(c, a, 0);
-            uint32_t nreg = (h >> 9) & 0xf, nmsg = (h >> 13) & 0xf;
+            uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
             uint32_t idx = 0, mbase = 2 + P.mbox_regs;
             while (idx < nmsg && (SW(c, a, mbase + 2 * idx) & 0xff) != tag) idx++;
             if (idx < nmsg) {
@@ -859,12 +859,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.w = m1;
                 u0.y = (u0.y & 0x00ffffffu) | (((m0 >> 8) & 0xff) << 24);
                 u0.x |= TF_INBOX;
-                SW(c, a, 0) = (h & ~(0xfu << 13)) | (nmsg << 13);
+                SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
             } else if (nreg >= P.mbox_regs) {
                 L.ovf = 1;
             } else {
                 SW(c, a, 2 + nreg) = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
-                SW(c, a, 0) = (h & ~(0xfu << 9)) | ((nreg + 1) << 9);
+                SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
             }
             sub = 1;
             if (recv_timeout_poll()) { sub = 0; pc++; }

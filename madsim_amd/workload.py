@@ -287,3 +287,126 @@ def pingpong(n_nodes=4, rounds=64):
         m.join(t)
     m.done()
     return wl.build()
+
+
+def raft_election(n_nodes=5, heartbeats=20, partitions=4):
+    """BASELINE configs[2] shape: an n-node leader-election loop under NetSim partition injection.
+
+    MadRaft itself is an external repository (only linked from README.md:78), so this is a stylised
+    election with the same *event shape*: per node a follower/candidate/leader task driven by
+    `timeout(election_timeout, ep.recv_from(..))` (staggered timeouts + a random candidate back-off), a voter task
+    answering RequestVote on the same endpoint, leader heartbeats every 50 ms, and a supervisor that clogs / unclogs
+    one node at a time at random moments (`NetSim::clog_node`, `sleep(gen_range(..))`).
+    All traffic to a node's main task uses one tag (heartbeats carry 100+leader, vote grants carry 1), so every
+    message is eventually consumed, as in a real single-mailbox Raft loop.  The run fails (panic verdict) if no leader
+    was ever elected.
+    """
+    MAIN, VREQ = 1, 2
+    GRANT = 1
+    wl = WorkloadBuilder()
+    nodes = [wl.create_node() for _ in range(n_nodes)]
+    addrs = [wl.addr(n, 1) for n in nodes]
+    need = n_nodes // 2                                   # grants needed besides the candidate's own vote
+    mains, voters = [], []
+    for i, n in enumerate(nodes):
+        peers = [j for j in range(n_nodes) if j != i]
+        t = wl.task(n)
+        v = wl.task(n)                                     # voter: shares the endpoint (Endpoint is Clone), starts after bind
+        t.bind(addrs[i])
+        t.spawn(v)
+        follower = t.label()
+        t.recv_from_timeout(addrs[i], MAIN, ms=150 + 40 * i)
+        cand_jump = len(t.code); t.jeq(A.VAL_TIMEOUT, 0)       # -> candidate (patched below)
+        t.jmp(follower)                                    # heartbeat or stale grant: stay follower, timer restarts
+        candidate = t.label()
+        t.code[cand_jump][2] = candidate
+        t.sleep_rand(lo_ms=0, ms=50)
+        for j in peers:
+            t.send_to(addrs[i], addrs[j], VREQ, i)
+        t.set(1, need)
+        collect = t.label()
+        t.recv_from_timeout(addrs[i], MAIN, ms=100)
+        t.jeq(A.VAL_TIMEOUT, follower)                     # split vote / partitioned: back to follower
+        got_grant = len(t.code); t.jeq(GRANT, 0)           # patched: count it
+        t.jmp(follower)                                    # someone else's heartbeat: step down
+        t.code[got_grant][2] = t.label()
+        t.djnz(1, collect)
+        t.flag_add(0, 1)                                   # elected
+        t.trace(0x200 + i)
+        t.set(0, heartbeats)
+        hb = t.label()
+        for j in peers:
+            t.send_to(addrs[i], addrs[j], MAIN, 100 + i)
+        t.recv_from_timeout(addrs[i], MAIN, ms=50)         # heartbeat interval; drains late grants / rival heartbeats
+        stay = len(t.code); t.jeq(A.VAL_TIMEOUT, 0)
+        keep = len(t.code); t.jeq(GRANT, 0)
+        t.jmp(follower)                                    # a rival leader's heartbeat: step down
+        t.code[stay][2] = t.label(); t.code[keep][2] = t.label()
+        t.djnz(0, hb)
+        t.jmp(follower)                                    # term over: step down
+        mains.append(t)
+        top = v.label()
+        v.recv_from(addrs[i], VREQ); v.reply(addrs[i], MAIN, GRANT); v.jmp(top)
+        voters.append(v)
+    m = wl.main()
+    for t in mains:
+        m.spawn(t)
+    for k in range(partitions):
+        victim = nodes[k % n_nodes]
+        m.sleep_rand(lo_ms=0, secs=1)
+        m.clog_node(victim, "both")
+        m.sleep(ms=300)
+        m.unclog_node(victim, "both")
+    m.sleep(secs=2)
+    m.panic_if_flag_lt(0, 1)
+    m.done()
+    return wl.build()
+
+
+def kv_rpc(n_clients=4, n_ops=8):
+    """BASELINE configs[3] shape: an etcd-style KV test.  Every operation is a fresh reliable connection
+    (madsim-etcd-client/src/kv.rs:37-53: connect1 -> send request -> recv response), the server accepts in a loop
+    and spawns one handler task per connection (madsim-etcd-client/src/server.rs:34-40)."""
+    REQ, RSP = 0x11, 0x22
+    wl = WorkloadBuilder()
+    ns = wl.create_node()
+    asv = wl.addr(ns, 2379)
+    handler = wl.task(ns)
+    handler.chan_recv(); handler.assert_val(REQ); handler.flag_add(0, 1); handler.chan_send(RSP)
+    srv = wl.task(ns)
+    srv.bind(asv)
+    top = srv.label()
+    srv.accept1(asv); srv.spawn(handler, move_conn=True); srv.jmp(top)
+    clients = []
+    for i in range(n_clients):
+        nc = wl.create_node()
+        acl = wl.addr(nc, 1)
+        c = wl.task(nc)
+        c.bind(acl); c.sleep(ms=10); c.set(0, n_ops)
+        top = c.label()
+        c.connect1(acl, asv); c.assert_val(0); c.chan_send(REQ); c.chan_recv(); c.assert_val(RSP); c.chan_close(); c.djnz(0, top)
+        clients.append(c)
+    m = wl.main()
+    m.spawn(srv)
+    for c in clients:
+        m.spawn(c)
+    for c in clients:
+        m.join(c)
+    m.assert_flag(0, n_clients * n_ops)
+    return wl.build()
+
+
+def raft_election_limits():
+    """Device capacities the election loop needs (high-water marks over 4 000 seeds on the CPU oracle: timer heap 95
+    — the duplicate timers of timeout() — so most of it lives in the HBM spill region; 67 dead recv registrations)."""
+    lim = A.Limits()
+    lim.heap_lds_slots, lim.heap_spill_slots = 16, 240
+    lim.mbox_regs, lim.mbox_msgs = 96, 12
+    return lim
+
+
+def kv_rpc_limits():
+    lim = A.Limits()
+    lim.max_tasks = 16
+    lim.heap_lds_slots, lim.heap_spill_slots = 8, 24
+    return lim

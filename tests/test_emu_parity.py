@@ -96,3 +96,12 @@ def test_fuzz_lifecycle_workloads():
         e = emu.run_batch(w, k * 3, 12, cfg, lim)
         ok = (o == e) | (e["verdict"] == A.OVERFLOW)
         assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+
+
+def test_baseline_config_shaped_workloads():
+    """configs[2]-shaped election loop (timeouts, partitions, HBM heap spill) and configs[3]-shaped KV-RPC."""
+    o = _same(W.raft_election(), 0, 300, None, W.raft_election_limits())
+    assert (o["verdict"] == A.PASS).all()
+    o = _same(W.raft_election(), 0, 300, A.Config.default(packet_loss_rate=0.05), W.raft_election_limits())
+    o = _same(W.kv_rpc(), 0, 300, None, W.kv_rpc_limits())
+    assert (o["verdict"] == A.PASS).all()

@@ -233,3 +233,27 @@ def test_fuzz_lifecycle_workloads_gpu(hip):
         want, _ = oracle.run_batch(w, k * 17, 64, cfg, lim)
         ok = (got == want) | (got["verdict"] == A.OVERFLOW)
         assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+
+
+def test_config2_election_loop_262144_seeds(hip):
+    """BASELINE configs[2]: 5-node election loop with NetSim partition injection, 262 144 seeds on one GPU
+    (timeout() duplicate timers push most of the timer heap into the HBM spill region)."""
+    w, lim = W.raft_election(), W.raft_election_limits()
+    got, summ = hip.run_batch(w, 0, 262144, None, lim)
+    assert summ.n_failed == 0 and (got["verdict"] == A.PASS).all()
+    assert len(np.unique(got["trace_hash"])) == 262144
+    for s in [(k * 4093) % 262144 for k in range(96)]:
+        want, _ = oracle.run_batch(w, s, 1, None, lim)
+        assert got[s] == want[0], f"seed {s}"
+    _cmp(hip, w, 1_000_000, 2048, A.Config.default(packet_loss_rate=0.05), lim)
+
+
+def test_config3_kv_rpc_131072_seeds(hip):
+    """BASELINE configs[3] per-GPU share (1 048 576 seeds / 8 GPUs): etcd-style KV ops over the reliable channel."""
+    w, lim = W.kv_rpc(), W.kv_rpc_limits()
+    got, summ = hip.run_batch(w, 0, 131072, None, lim)
+    assert summ.n_failed == 0
+    for s in [(k * 2039) % 131072 for k in range(96)]:
+        want, _ = oracle.run_batch(w, s, 1, None, lim)
+        assert got[s] == want[0], f"seed {s}"
+    _cmp(hip, w, 5_000_000, 2048, A.Config.default(packet_loss_rate=0.02), lim)
