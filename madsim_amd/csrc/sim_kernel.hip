@@ -60,6 +60,11 @@ enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 // the fast variant compiles that cold code out of the hot loop.
 template <bool TRACE_, bool SPILL_, int LWS_, bool LIFE_> struct Variant { static constexpr bool TRACE = TRACE_, SPILL = SPILL_, LIFE = LIFE_; static constexpr int LWS = LWS_; };
 
+#ifdef EXP_PROF2
+#define PROBE2(i) do { uint64_t t_ = __builtin_readcyclecounter(); L.prof_acc[i] += t_ - L.prof_t; L.prof_t = t_; } while (0)
+#else
+#define PROBE2(i) do { } while (0)
+#endif
 #ifdef EXP_PROF
 #define PROBE(i) do { uint64_t t_ = __builtin_readcyclecounter(); L.prof_acc[i] += t_ - L.prof_t; L.prof_t = t_; } while (0)
 #else
@@ -83,7 +88,7 @@ struct Lane {
     uint32_t ready_len;
     uint32_t heap_len;
     uint32_t verdict;
-#ifdef EXP_PROF
+#if defined(EXP_PROF) || defined(EXP_PROF2)
     uint64_t prof_acc[12]; uint64_t prof_t;
 #endif
     uint32_t main_done;  // handle[0] left H_RUNNING: block_on's task.is_finished()
@@ -270,16 +275,19 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos
 // Timer::add -> BinaryHeap::push.  Returns false on capacity overflow.
 template <class K>
 __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val) {
+    PROBE2(0);
     if (L.heap_len >= c.P.heap_lds + (K::SPILL ? c.P.heap_spill : 0u)) return false;
     uint4 e = make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, val);
     heap_sift_up<K>(c, L, L.heap_len, e);
     L.heap_len++;
+    PROBE2(10);
     return true;
 }
 
 // BinaryHeap::pop: swap the last element into the root, sift_down_to_bottom(0), then sift_up.
 template <class K>
 __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
+    PROBE2(0);
     uint32_t end = --L.heap_len;
     uint4 item = heap_get<K>(c, end);
     if (end > 0) {
@@ -305,6 +313,7 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
     } else {
         L.top_dl = ~0ull;
     }
+    PROBE2(11);
     return item;
 }
 
@@ -593,10 +602,9 @@ __device__ __forceinline__ bool is_light(uint32_t op) {
 // expensive primitives (RNG draws, heap pushes, link test, mailbox scan) sit at fixed points that the
 // whole wave reaches at the same time.
 template <class K>
-__device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t slot, uint4& u0) {
+__device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t slot, uint4& u0, uint4 u1) {
     enum : uint32_t { ST_RUN = 0, ST_PENDING = 1, ST_FINISHED = 2, ST_PANIC = 3 };
     const KParams& P = c.P;
-    uint4 u1 = TU(c, slot, 1);
     bool u1_dirty = false;
     uint32_t pc = u0.y & 0xffff, sub = (u0.y >> 16) & 0xff, from = u0.y >> 24;
     const uint32_t gen = (u0.x >> 8) & 0xffff;
@@ -883,7 +891,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             want_sleep = true;
         } else if (op == MS_OP_SLEEP || op == MS_OP_SLEEP_UNTIL) {
             uint64_t base = L.clock;
-            if (op == MS_OP_SLEEP_UNTIL) { uint4 u2 = TU(c, slot, 2); base = u64of(u2.x, u2.y); }
+            if (K::LIFE && op == MS_OP_SLEEP_UNTIL) { uint4 u2 = TU(c, slot, 2); base = u64of(u2.x, u2.y); }
             deadline = sleep_deadline(L, base + (uint64_t)b * NS_PER_S + imm);
             want_sleep = true;
         } else {
@@ -1038,10 +1046,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_ASSERT_G: if (GREGW(a & 3) != imm) st = ST_PANIC; else pc++; break;
             case MS_OP_PANIC_IF_G_LT: if (GREGW(a & 3) < imm) st = ST_PANIC; else pc++; break;
             case MS_OP_MARK:
+                if (!K::LIFE) { st = ST_PANIC; break; }     // t0 family and advance(): extended variant only
                 TU(c, slot, 2) = make_uint4((uint32_t)L.clock, (uint32_t)(L.clock >> 32), 0, 0);
                 pc++;
                 break;
             case MS_OP_ASSERT_ELAPSED: {
+                if (!K::LIFE) { st = ST_PANIC; break; }
                 uint4 u2 = TU(c, slot, 2);
                 uint64_t el = L.clock - u64of(u2.x, u2.y), d = (uint64_t)b * NS_PER_S + imm;
                 bool ok = a == 0 ? el == d : a == 1 ? el >= d : el < d;
@@ -1049,6 +1059,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             }
             case MS_OP_ADVANCE:                            // time/mod.rs:103-106
+                if (!K::LIFE) { st = ST_PANIC; break; }
                 L.clock += (uint64_t)b * NS_PER_S + imm;
                 pc++;
                 u0.y = pc | (sub << 16) | (from << 24);
@@ -1175,7 +1186,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
     c.tlog = P.trace_log;
 
     Lane L;
-#ifdef EXP_PROF
+#if defined(EXP_PROF) || defined(EXP_PROF2)
     for (int i = 0; i < 12; i++) L.prof_acc[i] = 0;
     L.prof_t = __builtin_readcyclecounter(); uint64_t prof_iters = 0;
 #endif
@@ -1193,7 +1204,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
         //           and advance_to_next_event, firing again — the ONLY place timers fire.
         // A lane that polls and then runs dry fires its next timer in the same pass, so in steady state
         // every lane does one poll and one timer fire per iteration and the wave stays in phase.
-#ifdef EXP_PROF
+#if defined(EXP_PROF) || defined(EXP_PROF2)
         prof_iters++;
 #endif
         uint64_t now = L.clock;
@@ -1205,6 +1216,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
             L.ready_len--;
             RW(idx) = RW(L.ready_len);                       // swap_remove
             uint4 u0 = TU(c, slot, 0);
+            uint4 u1 = TU(c, slot, 1);                       // issued together with u0: one LDS round trip
             L.steps++;
             bool panicked = false;
             PROBE(1);
@@ -1218,7 +1230,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
                 parked = true;
             } else {
                 u0.x = (u0.x & ~TF_SCHED) | TF_RUN;          // async-task run(): SCHEDULED -> RUNNING
-                panicked = poll_task<K>(c, L, slot, u0);
+                panicked = poll_task<K>(c, L, slot, u0, u1);
                 if (!panicked && (u0.x & TF_ALIVE)) {
                     if (u0.x & TF_SCHED) ready_push<K>(c, L, slot);   // woken while running: re-queue after the poll
                     u0.x &= ~TF_RUN;
@@ -1275,7 +1287,8 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
             next += P.total_lanes;
         }
     }
-#ifdef EXP_PROF
+#if defined(EXP_PROF) || defined(EXP_PROF2)
+    PROBE2(0);
     if (lane == 0 && P.prof) { for (int i = 0; i < 12; i++) atomicAdd((unsigned long long*)&P.prof[i], (unsigned long long)L.prof_acc[i]); atomicAdd((unsigned long long*)&P.prof[12], (unsigned long long)prof_iters); atomicAdd((unsigned long long*)&P.prof[13], 1ull); }
 #endif
 }

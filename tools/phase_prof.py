@@ -18,8 +18,10 @@ v = list(out)
 names = ["loop top/seed init+result", "idx draw + ready pop + task load", "poll_task exit (writeback u1)", "writeback + advance draw", "fire/idle loop",
          "poll: entry, u1 load, insn fetch", "poll [A] await check + completion (try_send)", "poll [B] light ops", "poll [C] begin op (mailbox / rare switch)", "poll [C] rand_delay draw + timer push"]
 waves, iters = v[13], v[12]
-tot = sum(v[:10])
+tot = sum(v[:12])
+if os.environ.get("PROF2"):
+    names = ["everything else"] + ["-"] * 9 + ["timer_add (heap push)", "timer_pop (heap pop)"]
 print(f"kernel {s.kernel_ms:.3f} ms, waves {waves}, iterations/wave {iters / waves:.0f}, cycles/wave {tot / waves:.0f}")
 for i, n in enumerate(names):
-    if i >= len(v): break
+    if i >= len(v) or n == "-": continue
     print(f"  {n:36s} {v[i] / waves:12.0f} cycles/wave  {100 * v[i] / tot:5.1f} %   {v[i] / iters:8.0f} cycles/iteration")
