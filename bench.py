@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=SEEDS_PER_GPU, help="seeds per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lpw", type=int, default=0, help="seed-carrying lanes per wave (0 = library auto)")
+    ap.add_argument("--generic", action="store_true", help="force the generic kernel variant (HBM heap spill enabled)")
     ap.add_argument("--workload", default="pingpong", choices=["pingpong", "raft", "kv"],
                     help="pingpong = BASELINE configs[1] (the headline); raft / kv = configs[2] / configs[3]-shaped extras")
     args = ap.parse_args()
@@ -75,6 +76,8 @@ def main():
         w, lim = workload.kv_rpc(), workload.kv_rpc_limits()
         wname = "etcd-style KV ops over connect1/accept1 (configs[3] shape)"
     lim.lanes_per_wave = args.lpw
+    if args.generic:
+        lim.heap_spill_slots = max(lim.heap_spill_slots, 8)
     per_gpu = args.seeds
     total = per_gpu * world
     seed0, count = mdist.shard_range(0, total, rank, world)

@@ -1317,12 +1317,29 @@ __global__ __launch_bounds__(256) void summary_kernel(const madsim_result_t* __r
 }  // namespace madsim_k
 
 #ifndef MADSIM_EMU
+// Kernel variants: the trace build, a fully generic build (runtime lane stride), and for full 64-lane waves
+// one build per (heap spill, extended ops) combination so that workloads only pay for what they use.
+#define MADSIM_FOR_EACH_VARIANT(X)      \
+    X(true, true, -1, true)             \
+    X(false, true, -1, true)            \
+    X(false, false, 6, false)           \
+    X(false, true, 6, false)            \
+    X(false, false, 6, true)            \
+    X(false, true, 6, true)
+
 extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace) {
     using namespace madsim_k;
     const bool spill = P->spill != nullptr && P->heap_spill > 0;
-    if (trace) hipLaunchKernelGGL((sim_kernel<Variant<true, true, -1, true>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
-    else if (spill || P->lw_shift != 6 || P->lifecycle) hipLaunchKernelGGL((sim_kernel<Variant<false, true, -1, true>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
-    else hipLaunchKernelGGL((sim_kernel<Variant<false, false, 6, false>>), dim3(grid), dim3(64), lds_bytes, (hipStream_t)stream, *P);
+    const bool life = P->lifecycle != 0;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(T, S, W, F) hipLaunchKernelGGL((sim_kernel<Variant<T, S, W, F>>), dim3(grid), dim3(64), lds_bytes, st, *P)
+    if (trace) LAUNCH(true, true, -1, true);
+    else if (P->lw_shift != 6) LAUNCH(false, true, -1, true);
+    else if (!spill && !life) LAUNCH(false, false, 6, false);
+    else if (spill && !life) LAUNCH(false, true, 6, false);
+    else if (!spill && life) LAUNCH(false, false, 6, true);
+    else LAUNCH(false, true, 6, true);
+#undef LAUNCH
 }
 
 extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream) {
@@ -1334,11 +1351,11 @@ extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t cou
 
 extern "C" int madsim_k_set_max_lds(uint32_t lds_bytes) {
     using namespace madsim_k;
-    hipError_t e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, false, 6, false>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<false, true, -1, true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)sim_kernel<Variant<true, true, -1, true>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipSuccess;
+#define SETATTR(T, S, W, F)                                                                                              \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sim_kernel<Variant<T, S, W, F>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    MADSIM_FOR_EACH_VARIANT(SETATTR)
+#undef SETATTR
     return (int)e;
 }
 #endif  // !MADSIM_EMU

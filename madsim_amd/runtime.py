@@ -43,6 +43,13 @@ def lib():
     """Load the product library. Raises if it has not been built (run __graft_entry__.build())."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and "MADSIM_HIP_LIB" not in os.environ:
+            # source-only checkout: build the gfx950 library in-tree once (hipcc cross-compiles without a GPU)
+            import subprocess
+            try:
+                subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
+            except (OSError, subprocess.CalledProcessError):
+                pass
         if not os.path.exists(LIB_PATH):
             raise MadsimHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

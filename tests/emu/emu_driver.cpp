@@ -38,9 +38,14 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
     for (uint32_t b = 0; b < G.grid; b++) {
         for (uint32_t t = 0; t < G.lanes_per_wave; t++) {
             blockIdx.x = b; threadIdx.x = t; emu_smem = base;
-            if (tlog) madsim_k::sim_kernel<madsim_k::Variant<true, true, -1, true>>(P);
-            else if (P.spill || P.lw_shift != 6 || P.lifecycle) madsim_k::sim_kernel<madsim_k::Variant<false, true, -1, true>>(P);
-            else madsim_k::sim_kernel<madsim_k::Variant<false, false, 6, false>>(P);
+            using namespace madsim_k;
+            const bool spill = P.spill != nullptr, life = P.lifecycle != 0;
+            if (tlog) sim_kernel<Variant<true, true, -1, true>>(P);
+            else if (P.lw_shift != 6) sim_kernel<Variant<false, true, -1, true>>(P);
+            else if (!spill && !life) sim_kernel<Variant<false, false, 6, false>>(P);
+            else if (spill && !life) sim_kernel<Variant<false, true, 6, false>>(P);
+            else if (!spill && life) sim_kernel<Variant<false, false, 6, true>>(P);
+            else sim_kernel<Variant<false, true, 6, true>>(P);
         }
     }
     return 0;
