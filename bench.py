@@ -84,11 +84,24 @@ def main():
     d_out = torch.empty(count * 48, dtype=torch.uint8, device=dev)     # results stay resident in HBM
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step(k):
+    # Fully asynchronous steps: the simulation kernel, the summary reduction and (N > 1) the RCCL all-reduce of the
+    # 32-byte report are all queued on the stream; the host never waits inside the timed region.
+    use_device_report = world == 1 or backend == "nccl"
+    ring = torch.zeros((args.steps + args.warmup, 4), dtype=torch.int64, device=dev)   # one 32-byte report per step
+
+    def step(k, timed):
         # a fresh block of seeds every step so nothing is cached between steps
-        s = runtime.run_batch_device(w, seed0 + k * total, count, d_out.data_ptr(), stream, None, lim)
-        ff, nf, st, ck = mdist.reduce_report(s.first_failing_seed, s.n_failed, s.total_steps, s.total_clock_ns, cdev)
-        return s, (ff, nf, st, ck)
+        if use_device_report:
+            runtime.run_batch_async(w, seed0 + k * total, count, d_out.data_ptr(), ring[k].data_ptr(), stream, None, lim,
+                                    timing_slot=(k % 64) if timed else -1)
+            mdist.reduce_report_device(ring[k])
+        else:   # functional-test hook (gloo on a 1-GPU box): host-side report
+            sm = runtime.run_batch_device(w, seed0 + k * total, count, d_out.data_ptr(), stream, None, lim)
+            rep = mdist.reduce_report(sm.first_failing_seed, sm.n_failed, sm.total_steps, sm.total_clock_ns, cdev)
+            if timed:
+                host_tot[0] += rep[1]; host_tot[1] += rep[2]; host_tot[2] += rep[3]; host_tot[3] += sm.kernel_ms
+
+    host_tot = [0, 0, 0, 0.0]
 
     def sync():
         if world > 1:
@@ -96,18 +109,20 @@ def main():
         torch.cuda.synchronize()
 
     for k in range(args.warmup):
-        step(k)
+        step(k, False)
     sync()
     t0 = time.perf_counter()
-    kernel_ms, steps_total, clock_total, nfail = 0.0, 0, 0, 0
     for k in range(args.steps):
-        s, (ff, nf, st, ck) = step(args.warmup + k)
-        kernel_ms += s.kernel_ms
-        steps_total += st
-        clock_total += ck
-        nfail += nf
+        step(args.warmup + k, True)
     sync()
     dt = time.perf_counter() - t0
+    if use_device_report:
+        rows = ring[args.warmup:].cpu()
+        nfail, steps_total, clock_total = (int(x) for x in rows[:, 1:4].sum(dim=0).tolist())
+        nslots = min(args.steps, 64)
+        kernel_ms = sum(runtime.timing_ms((args.warmup + args.steps - 1 - i) % 64) for i in range(nslots)) * args.steps / nslots
+    else:
+        nfail, steps_total, clock_total, kernel_ms = host_tot
     if world > 1:
         t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -245,6 +245,16 @@ int madsim_hip_run_batch_device(const madsim_workload_t* w, const madsim_config_
                                 uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
                                 void* d_out, void* stream, madsim_summary_t* summary);
 
+/* Fully asynchronous form: nothing is copied to the host.  `d_summary4` (device memory, 4 x uint64_t, may be NULL)
+ * receives {first failing seed ^ (1 << 63), n_failed, total_steps, total_clock_ns} from a reduction kernel queued behind
+ * the simulation on `stream`.  Word 0 is in order-preserving int64 form (none = INT64_MAX), so a signed RCCL
+ * all-reduce(MIN) on it and all-reduce(SUM) on words 1-3 combine ranks without touching the host.  `timing_slot` in [0,64) brackets
+ * the simulation kernel with a HIP event pair readable through madsim_hip_timing_ms after the stream has run; -1 = none. */
+int madsim_hip_run_batch_async(const madsim_workload_t* w, const madsim_config_t* cfg,
+                               uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
+                               void* d_out, void* d_summary4, void* stream, int timing_slot);
+int madsim_hip_timing_ms(int timing_slot, double* ms);
+
 /* Re-run one seed and return the raw determinism log (rand.rs:64-88 byte per GlobalRng::with),
  * the artefact MADSIM_TEST_CHECK_DETERMINISM compares (runtime/mod.rs:178-202).  Returns the number
  * of bytes the log holds (may exceed cap; only cap bytes are written), <0 on error. */

@@ -37,6 +37,7 @@ struct State {
     madsim_result_t* d_out = nullptr; size_t out_cap = 0;
     uint8_t* d_tlog = nullptr; size_t tlog_cap = 0; uint64_t* d_tlen = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t tev[2 * 64] = {};              // timing slots of madsim_hip_run_batch_async
     uint32_t lds_attr = 0;
     uint64_t* d_prof = nullptr;               // debug counters (EXP_PROF kernel builds)
 };
@@ -124,8 +125,8 @@ int run_device(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t 
     HIP_TRY(hipGetLastError());
     if (summary) {
         HIP_TRY(hipEventRecord(g.ev1, stream));
-        unsigned long long init[4] = {~0ull, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(g.d_acc, init, sizeof init, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(g.d_acc, 0xff, 8, stream));
+        HIP_TRY(hipMemsetAsync((char*)g.d_acc + 8, 0, 24, stream));
         madsim_k_launch_summary(d_out, count, seed0, g.d_acc, stream);
         HIP_TRY(hipGetLastError());
         unsigned long long acc[4];
@@ -200,6 +201,7 @@ int madsim_hip_shutdown(void) {
     if (g.d_prof) (void)hipFree(g.d_prof);
     if (g.ev0) (void)hipEventDestroy(g.ev0);
     if (g.ev1) (void)hipEventDestroy(g.ev1);
+    for (auto& e : g.tev) if (e) (void)hipEventDestroy(e);
     g = State();
     return 0;
 }
@@ -208,6 +210,44 @@ int madsim_hip_run_batch_device(const madsim_workload_t* w, const madsim_config_
                                 const madsim_limits_t* lim, void* d_out, void* stream, madsim_summary_t* summary) {
     std::lock_guard<std::mutex> lk(g_mu);
     return run_device(w, cfg, seed0, count, lim, (madsim_result_t*)d_out, (hipStream_t)stream, summary);
+}
+
+int madsim_hip_run_batch_async(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                               const madsim_limits_t* lim, void* d_out, void* d_summary4, void* stream, int timing_slot) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.inited) return fail(MADSIM_E_NOINIT, "madsim_hip_init has not been called");
+    if (timing_slot >= 64) return fail(MADSIM_E_ARG, "timing_slot must be < 64");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t* ev = nullptr;
+    if (timing_slot >= 0) {
+        ev = &g.tev[2 * timing_slot];
+        if (!ev[0]) { HIP_TRY(hipEventCreate(&ev[0])); HIP_TRY(hipEventCreate(&ev[1])); }
+        HIP_TRY(hipEventRecord(ev[0], st));
+    }
+    int rc = run_device(w, cfg, seed0, count, lim, (madsim_result_t*)d_out, st, nullptr);
+    if (rc) return rc;
+    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+    if (d_summary4 && count) {
+        // {UINT64_MAX, 0, 0, 0}, accumulated by the reduction kernel, then word 0 is flipped into its
+        // order-preserving int64 form (seed ^ 1<<63) so a signed all-reduce(MIN) yields the unsigned minimum
+        HIP_TRY(hipMemsetAsync(d_summary4, 0xff, 8, st));
+        HIP_TRY(hipMemsetAsync((char*)d_summary4 + 8, 0, 24, st));
+        madsim_k_launch_summary((const madsim_result_t*)d_out, count, seed0, (unsigned long long*)d_summary4, st);
+        HIP_TRY(hipGetLastError());
+        madsim_k_launch_keyflip((unsigned long long*)d_summary4, st);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int madsim_hip_timing_ms(int timing_slot, double* ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (timing_slot < 0 || timing_slot >= 64 || !g.tev[2 * timing_slot] || !ms) return fail(MADSIM_E_ARG, "bad timing slot");
+    float f = 0.f;
+    HIP_TRY(hipEventSynchronize(g.tev[2 * timing_slot + 1]));
+    HIP_TRY(hipEventElapsedTime(&f, g.tev[2 * timing_slot], g.tev[2 * timing_slot + 1]));
+    *ms = f;
+    return 0;
 }
 
 int madsim_hip_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,

@@ -1297,20 +1297,30 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
 // ---- summary reduction over the result array (first failing seed = min) -------------------------
 __global__ __launch_bounds__(256) void summary_kernel(const madsim_result_t* __restrict__ out, uint64_t count,
                                                       uint64_t seed0, unsigned long long* __restrict__ acc) {
+    __shared__ unsigned long long part[4][4];
     unsigned long long first = ~0ull, nfail = 0, steps = 0, clk = 0;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
-        madsim_result_t r = out[i];
-        if (r.verdict != MADSIM_PASS) { nfail++; unsigned long long s = seed0 + i; first = s < first ? s : first; }
-        steps += r.steps; clk += r.clock_ns;
+        const uint4* p = reinterpret_cast<const uint4*>(out + i);     // verdict|steps|clock_ns in the first 16 bytes
+        uint4 r = p[0];
+        if (r.x != MADSIM_PASS) { nfail++; unsigned long long s = seed0 + i; first = s < first ? s : first; }
+        steps += r.y; clk += ((unsigned long long)r.w << 32) | r.z;
     }
     for (int o = 32; o > 0; o >>= 1) {
         unsigned long long f2 = __shfl_xor(first, o), n2 = __shfl_xor(nfail, o), s2 = __shfl_xor(steps, o), c2 = __shfl_xor(clk, o);
         first = f2 < first ? f2 : first; nfail += n2; steps += s2; clk += c2;
     }
-    if ((threadIdx.x & 63) == 0) {
+    const uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[wv][0] = first; part[wv][1] = nfail; part[wv][2] = steps; part[wv][3] = clk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                             // one set of atomics per workgroup
+        for (int k = 1; k < 4; k++) {
+            first = part[k][0] < first ? part[k][0] : first; nfail += part[k][1]; steps += part[k][2]; clk += part[k][3];
+        }
         atomicMin(&acc[0], first); atomicAdd(&acc[1], nfail); atomicAdd(&acc[2], steps); atomicAdd(&acc[3], clk);
     }
 }
+
+__global__ void keyflip_kernel(unsigned long long* acc) { acc[0] ^= 0x8000000000000000ull; }
 
 #endif  // !MADSIM_EMU
 
@@ -1343,10 +1353,14 @@ extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, u
 }
 
 extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream) {
-    uint32_t grid = (uint32_t)((count + 255) / 256);
-    if (grid > 1024) grid = 1024;
+    uint32_t grid = (uint32_t)((count + 1023) / 1024);     // >= 4 results per thread, <= 256 workgroups (4 atomics each)
+    if (grid > 256) grid = 256;
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(madsim_k::summary_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, count, seed0, acc);
+}
+
+extern "C" void madsim_k_launch_keyflip(unsigned long long* acc, void* stream) {
+    hipLaunchKernelGGL(madsim_k::keyflip_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc);
 }
 
 extern "C" int madsim_k_set_max_lds(uint32_t lds_bytes) {

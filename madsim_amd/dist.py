@@ -39,3 +39,18 @@ def reduce_report(first_failing_seed, n_failed, total_steps, total_clock_ns, dev
     k = k + (1 << 64) if k < 0 else k
     n, s, c = (int(x) for x in sm.tolist())
     return k ^ (1 << 63), n, s, c
+
+
+def reduce_report_device(summary4, group=None):
+    """Device-side report exchange: `summary4` is the int64[4] CUDA tensor madsim_hip_run_batch_async fills
+    ({first failing seed ^ (1 << 63), n_failed, total_steps, total_clock_ns}).  Two in-place RCCL all-reduces, no host
+    synchronisation: signed MIN on word 0 is the unsigned minimum of the seeds, SUM on words 1-3."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(summary4[0:1], op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(summary4[1:4], op=dist.ReduceOp.SUM, group=group)
+    return summary4
+
+
+def decode_first_fail(key):
+    """int64 key of reduce_report_device -> u64 seed (U64_MAX = no failing seed)."""
+    return (int(key) & U64_MAX) ^ (1 << 63)

@@ -65,6 +65,9 @@ def lib():
         L.madsim_hip_run_batch_device.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64,
                                                   C.c_uint64, C.POINTER(A.Limits), C.c_void_p, C.c_void_p,
                                                   C.POINTER(A.Summary)]
+        L.madsim_hip_run_batch_async.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64, C.c_uint64,
+                                                 C.POINTER(A.Limits), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.madsim_hip_timing_ms.argtypes = [C.c_int, C.POINTER(C.c_double)]
         L.madsim_hip_trace_seed.restype = C.c_int64
         L.madsim_hip_trace_seed.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64,
                                             C.POINTER(A.Limits), C.c_void_p, C.c_uint64, C.POINTER(A.Result)]
@@ -126,6 +129,24 @@ def run_batch_device(workload, seed0, count, d_out_ptr, stream_ptr=0, config=Non
                                              C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr),
                                              C.byref(summ) if want_summary else None))
     return summ
+
+
+def run_batch_async(workload, seed0, count, d_out_ptr, d_summary_ptr=0, stream_ptr=0, config=None, limits=None,
+                    timing_slot=-1):
+    """Queue one batch on `stream_ptr` without any host synchronisation (results and the 4-word summary stay in HBM)."""
+    if _inited_device is None:
+        init(0)
+    cfg = config or A.Config.default()
+    lim = limits or A.Limits()
+    _check(lib().madsim_hip_run_batch_async(workload.ref(), C.byref(cfg), seed0, count, C.byref(lim),
+                                            C.c_void_p(d_out_ptr), C.c_void_p(d_summary_ptr), C.c_void_p(stream_ptr),
+                                            timing_slot))
+
+
+def timing_ms(slot):
+    ms = C.c_double(0.0)
+    _check(lib().madsim_hip_timing_ms(slot, C.byref(ms)))
+    return ms.value
 
 
 def trace_seed(workload, seed, config=None, limits=None, cap=1 << 20):

@@ -37,7 +37,14 @@ def _worker(rank, world, port, q):
     rep = mdist.reduce_report(s.first_failing_seed, s.n_failed, s.total_steps, s.total_clock_ns)
     # a rank with no failure reports UINT64_MAX: the unsigned-min mapping must not be fooled by it
     rep2 = mdist.reduce_report((1 << 64) - 1 if rank == 0 else 5, 0, 0, 0)
-    q.put((rank, rep, rep2))
+    # the device-side form bench.py uses over RCCL (here: CPU tensors over gloo); word 0 is seed ^ (1 << 63) as int64
+    import torch
+    key = (s.first_failing_seed ^ (1 << 63))
+    key = key - (1 << 64) if key >= (1 << 63) else key
+    t4 = torch.tensor([key, s.n_failed, s.total_steps, s.total_clock_ns], dtype=torch.int64)
+    mdist.reduce_report_device(t4)
+    rep3 = (mdist.decode_first_fail(t4[0]), int(t4[1]), int(t4[2]), int(t4[3]))
+    q.put((rank, rep, rep2, rep3))
     dist.destroy_process_group()
 
 
@@ -58,6 +65,7 @@ def test_two_rank_first_fail_report():
     out, s = oracle.run_batch(W.pingpong(4, 16), 0, 600, A.Config.default(packet_loss_rate=0.02))
     want = (s.first_failing_seed, s.n_failed, s.total_steps, s.total_clock_ns)
     assert s.n_failed > 0
-    for rank, rep, rep2 in res:
+    for rank, rep, rep2, rep3 in res:
         assert rep == want, (rank, rep, want)
         assert rep2[0] == 5
+        assert rep3 == want, (rank, rep3, want)

@@ -257,3 +257,26 @@ def test_config3_kv_rpc_131072_seeds(hip):
         want, _ = oracle.run_batch(w, s, 1, None, lim)
         assert got[s] == want[0], f"seed {s}"
     _cmp(hip, w, 5_000_000, 2048, A.Config.default(packet_loss_rate=0.02), lim)
+
+
+def test_async_entry_point_device_summary(hip):
+    """madsim_hip_run_batch_async: no host copies; the 4-word report lands in HBM in all-reduce-ready form."""
+    import torch
+    from madsim_amd import dist as mdist
+    w = W.pingpong(4, 16)
+    cfg = A.Config.default(packet_loss_rate=0.02)
+    n = 8192
+    buf = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+    rep = torch.zeros(4, dtype=torch.int64, device="cuda")
+    hip.run_batch_async(w, 1000, n, buf.data_ptr(), rep.data_ptr(), torch.cuda.current_stream().cuda_stream, cfg, None, timing_slot=3)
+    torch.cuda.synchronize()
+    want, osumm = oracle.run_batch(w, 1000, n, cfg)
+    got = np.frombuffer(buf.cpu().numpy().tobytes(), dtype=A.RESULT_DTYPE)
+    assert (got == want).all()
+    r = rep.cpu()
+    assert (mdist.decode_first_fail(r[0]), int(r[1]), int(r[2]), int(r[3])) == \
+        (osumm.first_failing_seed, osumm.n_failed, osumm.total_steps, osumm.total_clock_ns)
+    assert osumm.n_failed > 0 and hip.timing_ms(3) > 0
+    hip.run_batch_async(w, 0, n, buf.data_ptr(), rep.data_ptr(), torch.cuda.current_stream().cuda_stream)   # no failure
+    torch.cuda.synchronize()
+    assert mdist.decode_first_fail(rep.cpu()[0]) == A.U64_MAX
