@@ -89,6 +89,36 @@ class Task {
     Task& recv_from(int ep, uint8_t tag) { return emit(MS_OP_RECV, (uint8_t)ep, (uint16_t)(tag << 8)); }
     Task& assert_val(uint32_t v) { return emit(MS_OP_ASSERT_VAL, 0, 0, v); }
     Task& close(int ep) { return emit(MS_OP_CLOSE, (uint8_t)ep); }
+    // timeouts / random sleeps / branching on the received value
+    Task& recv_from_timeout(int ep, uint8_t tag, std::chrono::nanoseconds d) {
+        uint64_t ns = (uint64_t)d.count();
+        return emit(MS_OP_RECV_TIMEOUT, (uint8_t)ep, (uint16_t)((tag << 8) | (ns / 1000000000ull)), (uint32_t)(ns % 1000000000ull));
+    }
+    Task& sleep_rand(std::chrono::milliseconds lo /* multiple of 50 ms */, std::chrono::nanoseconds hi) {
+        uint64_t ns = (uint64_t)hi.count();
+        return emit(MS_OP_SLEEP_RAND, (uint8_t)(lo.count() / 50), (uint16_t)(ns / 1000000000ull), (uint32_t)(ns % 1000000000ull));
+    }
+    Task& jeq(uint32_t value, int target) { return emit(MS_OP_JEQ, 0, (uint16_t)target, value, true); }
+    // reliable channel (Endpoint::connect1 / accept1)
+    Task& connect1(int ep, int dst) { return emit(MS_OP_CONNECT, (uint8_t)ep, (uint16_t)dst); }
+    Task& accept1(int ep) { return emit(MS_OP_ACCEPT, (uint8_t)ep); }
+    Task& chan_send(uint32_t payload) { return emit(MS_OP_CSEND, 0, 0, payload); }
+    Task& chan_recv() { return emit(MS_OP_CRECV); }
+    Task& chan_close() { return emit(MS_OP_CCLOSE); }
+    Task& spawn_move_conn(const Task& t) { return emit(MS_OP_SPAWN, (uint8_t)t.index_, 2); }
+    // supervisor (Handle::kill / restart / pause / resume / is_exit, JoinHandle::abort)
+    Task& kill(int node) { return emit(MS_OP_KILL, (uint8_t)node); }
+    Task& restart(int node) { return emit(MS_OP_RESTART, (uint8_t)node); }
+    Task& pause(int node) { return emit(MS_OP_PAUSE, (uint8_t)node); }
+    Task& resume(int node) { return emit(MS_OP_RESUME, (uint8_t)node); }
+    Task& abort(const Task& t) { return emit(MS_OP_ABORT, (uint8_t)t.index_); }
+    Task& assert_exit(int node, bool expected) { return emit(MS_OP_ASSERT_EXIT, (uint8_t)node, expected ? 1 : 0); }
+    Task& build_node(int node) { return emit(MS_OP_BUILD, (uint8_t)node); }
+    // shared Arc<AtomicUsize>-style flags
+    Task& flag_store(int flag, uint32_t v) { return emit(MS_OP_GSET, (uint8_t)flag, 0, v); }
+    Task& flag_add(int flag, uint32_t v) { return emit(MS_OP_GADD, (uint8_t)flag, 0, v); }
+    Task& assert_flag(int flag, uint32_t v) { return emit(MS_OP_ASSERT_G, (uint8_t)flag, 0, v); }
+    Task& panic_if_flag_lt(int flag, uint32_t v) { return emit(MS_OP_PANIC_IF_G_LT, (uint8_t)flag, 0, v); }
     Task& clog_node(int node) { return emit(MS_OP_CLOG_NODE, (uint8_t)node, 3); }
     Task& unclog_node(int node) { return emit(MS_OP_UNCLOG_NODE, (uint8_t)node, 3); }
     Task& clog_link(int src, int dst) { return emit(MS_OP_CLOG_LINK, (uint8_t)src, (uint16_t)dst); }
@@ -127,9 +157,16 @@ class WorkloadBuilder {
   public:
     WorkloadBuilder() { nodes_.push_back(madsim_node_t{}); tasks_.push_back(Task(0, 0, 0)); }
     Task& main() { return tasks_[0]; }                                   // the future handed to block_on
-    int create_node() { nodes_.push_back(madsim_node_t{}); return (int)nodes_.size() - 1; }   // Handle::create_node().build()
+    int create_node(bool restart_on_panic = false) {                     // Handle::create_node()[.restart_on_panic()].build()
+        madsim_node_t n{}; n.flags = restart_on_panic ? MADSIM_NODE_RESTART_ON_PANIC : 0;
+        nodes_.push_back(n); return (int)nodes_.size() - 1;
+    }
     int addr(int node, uint16_t port) { socks_.push_back(madsim_sock_t{(uint8_t)node, 0, port}); return (int)socks_.size() - 1; }
-    Task& task(int node) { tasks_.reserve(256); tasks_.push_back(Task((int)tasks_.size(), node, 0)); return tasks_.back(); }
+    Task& task(int node, bool init = false, bool before_block_on = false) {
+        tasks_.reserve(256);
+        tasks_.push_back(Task((int)tasks_.size(), node, (uint8_t)((init ? MADSIM_PROG_INIT : 0) | (before_block_on ? MADSIM_PROG_PRE : 0))));
+        return tasks_.back();
+    }
     Workload build() {
         Workload w;
         w.nodes = nodes_; w.socks = socks_;
