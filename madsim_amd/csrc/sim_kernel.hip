@@ -1210,13 +1210,17 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
         uint64_t now = L.clock;
         PROBE(0);
         if (L.ready_len > 0) {
+            // Latency hiding: the queue usually holds exactly one task, so ready[0] and its two state units are
+            // loaded BEFORE the draw loop (whose rejection retries take hundreds of cycles) and used if idx == 0.
+            const uint32_t slot0 = RW(0);
+            const uint4 pu0 = TU(c, slot0, 0), pu1 = TU(c, slot0, 1);
             // try_recv_random (utils/mpsc.rs:73-83): idx drawn even when len == 1
             uint32_t idx = gen_index<K>(c, L, L.ready_len);
-            uint32_t slot = RW(idx);
             L.ready_len--;
-            RW(idx) = RW(L.ready_len);                       // swap_remove
-            uint4 u0 = TU(c, slot, 0);
-            uint4 u1 = TU(c, slot, 1);                       // issued together with u0: one LDS round trip
+            uint32_t slot = slot0;
+            uint4 u0 = pu0, u1 = pu1;
+            if (idx != 0) { slot = RW(idx); u0 = TU(c, slot, 0); u1 = TU(c, slot, 1); }
+            if (idx != L.ready_len) RW(idx) = RW(L.ready_len);   // swap_remove
             L.steps++;
             bool panicked = false;
             PROBE(1);

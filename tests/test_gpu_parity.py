@@ -280,3 +280,16 @@ def test_async_entry_point_device_summary(hip):
     hip.run_batch_async(w, 0, n, buf.data_ptr(), rep.data_ptr(), torch.cuda.current_stream().cuda_stream)   # no failure
     torch.cuda.synchronize()
     assert mdist.decode_first_fail(rep.cpu()[0]) == A.U64_MAX
+
+
+def test_capacity_verdicts_are_retried_with_larger_limits(hip):
+    """Builder.run never surfaces a device-capacity verdict as the answer: overflowed seeds are re-run with
+    doubled capacities (the reference's containers are unbounded)."""
+    from madsim_amd import runtime
+    w = W.raft_election()
+    tight = A.Limits(); tight.heap_lds_slots, tight.heap_spill_slots = 8, 8; tight.mbox_regs, tight.mbox_msgs = 4, 4
+    first, _ = hip.run_batch(w, 0, 256, None, tight)
+    assert (first["verdict"] == A.OVERFLOW).any()
+    got, summ = runtime.run_batch_auto(w, 0, 256, None, tight, max_rounds=6)
+    want, osumm = oracle.run_batch(w, 0, 256)
+    assert (got == want).all() and summ.n_failed == osumm.n_failed == 0
