@@ -161,8 +161,11 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         lw = L.lanes_per_wave;
         if (lw != 8 && lw != 16 && lw != 32 && lw != 64) return fail(err, MADSIM_E_LIMITS, "lanes_per_wave must be 8, 16, 32 or 64");
     } else {
-        // large per-seed state (big mailboxes, many tasks): carry fewer seeds per wave so a workgroup still fits
-        while (lw > 8 && (size_t)sh_bytes + (size_t)lw * G->lds_per_seed > g.lds_per_cu) lw >>= 1;
+        // Large per-seed state: a CU has 4 SIMDs and a wave runs on one of them, so when LDS admits fewer than four
+        // full waves per CU, carry fewer seeds per wave until at least four workgroups fit (one per SIMD) — the same
+        // seeds in flight, spread over all SIMDs.  (When >= 4 full waves fit, full waves win: r1_lanes_per_wave.md.)
+        auto blocks = [&](uint32_t l) { size_t b = (size_t)sh_bytes + (size_t)l * G->lds_per_seed; return b > g.lds_per_cu ? 0u : (uint32_t)(g.lds_per_cu / b); };
+        while (lw > 8 && blocks(lw) < 4) lw >>= 1;
     }
     P.lw_shift = lw == 8 ? 3 : lw == 16 ? 4 : lw == 32 ? 5 : 6;
     P.sh_tasks = P.sh_heap + P.heap_lds * lw * 4;
