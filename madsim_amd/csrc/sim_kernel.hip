@@ -58,7 +58,8 @@ enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 // LWS = log2(lane stride) when known at compile time (6: full 64-lane waves), or -1: read it from KParams.
 // LIFE = the workload uses node lifecycle (kill/restart/pause/abort ops, init programs, restart_on_panic);
 // the fast variant compiles that cold code out of the hot loop.
-template <bool TRACE_, bool SPILL_, int LWS_, bool LIFE_> struct Variant { static constexpr bool TRACE = TRACE_, SPILL = SPILL_, LIFE = LIFE_; static constexpr int LWS = LWS_; };
+// RQ = the ready queue (<= 8 tasks) lives in a 64-bit register, one byte per queued task, instead of LDS.
+template <bool TRACE_, bool SPILL_, int LWS_, bool LIFE_, bool RQ_ = false> struct Variant { static constexpr bool TRACE = TRACE_, SPILL = SPILL_, LIFE = LIFE_, RQ = RQ_; static constexpr int LWS = LWS_; };
 
 #ifdef EXP_PROF2
 #define PROBE2(i) do { uint64_t t_ = __builtin_readcyclecounter(); L.prof_acc[i] += t_ - L.prof_t; L.prof_t = t_; } while (0)
@@ -86,6 +87,7 @@ struct Lane {
     uint32_t msg_count;
     uint32_t steps;
     uint32_t ready_len;
+    uint64_t rq;         // K::RQ variants: the ready queue itself, byte i = i-th queued task slot
     uint32_t heap_len;
     uint32_t verdict;
 #if defined(EXP_PROF) || defined(EXP_PROF2)
@@ -320,7 +322,8 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
 // ---- async-task wake / schedule [DEP A.7] -------------------------------------------------------
 template <class K>
 __device__ __forceinline__ void ready_push(const Ctx& c, Lane& L, uint32_t slot) {
-    RW(L.ready_len) = slot;
+    if (K::RQ) L.rq |= (uint64_t)slot << (8 * L.ready_len);
+    else RW(L.ready_len) = slot;
     L.ready_len++;
 }
 
@@ -1136,10 +1139,10 @@ __device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     SPLITMIX(L.s0); SPLITMIX(L.s1); SPLITMIX(L.s2); SPLITMIX(L.s3);
 #undef SPLITMIX
     L.rng_calls = 0; L.clock = 0; L.msg_count = 0; L.steps = 0;
-    L.ready_len = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING; L.ovf = 0; L.main_done = 0;
+    L.ready_len = 0; L.rq = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING; L.ovf = 0; L.main_done = 0;
     L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
     // TimeRuntime::new (time/mod.rs:26-38): base_time draw, before logging is enabled
-    { uint64_t h = L.trace_hash, n = L.log_len; (void)gen_range_small<Variant<false, false, K::LWS, false>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n; }
+    { uint64_t h = L.trace_hash, n = L.log_len; (void)gen_range_small<Variant<false, false, K::LWS, false, K::RQ>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n; }
     L.trace_hash = FNV_OFFSET; L.obs_hash = FNV_OFFSET; L.log_len = 0;
     // tasks spawned before block_on, then the main task (task/mod.rs:222-235)
     for (uint32_t p = 1; p < P.n_progs; p++) {
@@ -1212,15 +1215,22 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
         if (L.ready_len > 0) {
             // Latency hiding: the queue usually holds exactly one task, so ready[0] and its two state units are
             // loaded BEFORE the draw loop (whose rejection retries take hundreds of cycles) and used if idx == 0.
-            const uint32_t slot0 = RW(0);
+            const uint32_t slot0 = K::RQ ? (uint32_t)(L.rq & 0xff) : RW(0);
             const uint4 pu0 = TU(c, slot0, 0), pu1 = TU(c, slot0, 1);
             // try_recv_random (utils/mpsc.rs:73-83): idx drawn even when len == 1
             uint32_t idx = gen_index<K>(c, L, L.ready_len);
             L.ready_len--;
             uint32_t slot = slot0;
             uint4 u0 = pu0, u1 = pu1;
-            if (idx != 0) { slot = RW(idx); u0 = TU(c, slot, 0); u1 = TU(c, slot, 1); }
-            if (idx != L.ready_len) RW(idx) = RW(L.ready_len);   // swap_remove
+            if (K::RQ) {
+                if (idx != 0) { slot = (uint32_t)(L.rq >> (8 * idx)) & 0xff; u0 = TU(c, slot, 0); u1 = TU(c, slot, 1); }
+                uint64_t last = (L.rq >> (8 * L.ready_len)) & 0xff;      // swap_remove on bytes
+                L.rq = (L.rq & ~(0xffull << (8 * idx))) | (last << (8 * idx));
+                L.rq &= ~(0xffull << (8 * L.ready_len));
+            } else {
+                if (idx != 0) { slot = RW(idx); u0 = TU(c, slot, 0); u1 = TU(c, slot, 1); }
+                if (idx != L.ready_len) RW(idx) = RW(L.ready_len);       // swap_remove
+            }
             L.steps++;
             bool panicked = false;
             PROBE(1);
@@ -1337,6 +1347,7 @@ __global__ void keyflip_kernel(unsigned long long* acc) { acc[0] ^= 0x8000000000
     X(true, true, -1, true)             \
     X(false, true, -1, true)            \
     X(false, false, 6, false)           \
+    X(false, false, 6, false, true)     \
     X(false, true, 6, false)            \
     X(false, false, 6, true)            \
     X(false, true, 6, true)
@@ -1346,9 +1357,10 @@ extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, u
     const bool spill = P->spill != nullptr && P->heap_spill > 0;
     const bool life = P->lifecycle != 0;
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(T, S, W, F) hipLaunchKernelGGL((sim_kernel<Variant<T, S, W, F>>), dim3(grid), dim3(64), lds_bytes, st, *P)
+#define LAUNCH(...) hipLaunchKernelGGL((sim_kernel<Variant<__VA_ARGS__>>), dim3(grid), dim3(64), lds_bytes, st, *P)
     if (trace) LAUNCH(true, true, -1, true);
     else if (P->lw_shift != 6) LAUNCH(false, true, -1, true);
+    else if (!spill && !life && P->max_tasks <= 8) LAUNCH(false, false, 6, false, true);
     else if (!spill && !life) LAUNCH(false, false, 6, false);
     else if (spill && !life) LAUNCH(false, true, 6, false);
     else if (!spill && life) LAUNCH(false, false, 6, true);
@@ -1370,8 +1382,8 @@ extern "C" void madsim_k_launch_keyflip(unsigned long long* acc, void* stream) {
 extern "C" int madsim_k_set_max_lds(uint32_t lds_bytes) {
     using namespace madsim_k;
     hipError_t e = hipSuccess;
-#define SETATTR(T, S, W, F)                                                                                              \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sim_kernel<Variant<T, S, W, F>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+#define SETATTR(...)                                                                                                     \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sim_kernel<Variant<__VA_ARGS__>>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     MADSIM_FOR_EACH_VARIANT(SETATTR)
 #undef SETATTR
     return (int)e;

@@ -42,6 +42,7 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
             const bool spill = P.spill != nullptr, life = P.lifecycle != 0;
             if (tlog) sim_kernel<Variant<true, true, -1, true>>(P);
             else if (P.lw_shift != 6) sim_kernel<Variant<false, true, -1, true>>(P);
+            else if (!spill && !life && P.max_tasks <= 8) sim_kernel<Variant<false, false, 6, false, true>>(P);
             else if (!spill && !life) sim_kernel<Variant<false, false, 6, false>>(P);
             else if (spill && !life) sim_kernel<Variant<false, true, 6, false>>(P);
             else if (!spill && life) sim_kernel<Variant<false, false, 6, true>>(P);
