@@ -33,8 +33,9 @@ def main():
     ap.add_argument("--seeds", type=int, default=SEEDS_PER_GPU, help="seeds per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lpw", type=int, default=0, help="seed-carrying lanes per wave (0 = library auto)")
+    ap.add_argument("--heap-lds", type=int, default=4, help="timers workload: timer-heap entries kept in LDS")
     ap.add_argument("--generic", action="store_true", help="force the generic kernel variant (HBM heap spill enabled)")
-    ap.add_argument("--workload", default="pingpong", choices=["pingpong", "raft", "kv"],
+    ap.add_argument("--workload", default="pingpong", choices=["pingpong", "raft", "kv", "timers"],
                     help="pingpong = BASELINE configs[1] (the headline); raft / kv = configs[2] / configs[3]-shaped extras")
     args = ap.parse_args()
 
@@ -72,6 +73,9 @@ def main():
     elif args.workload == "raft":
         w, lim = workload.raft_election(), workload.raft_election_limits()
         wname = "5-node election loop with partition injection (configs[2] shape)"
+    elif args.workload == "timers":
+        w, lim = workload.timer_storm(), workload.timer_storm_limits(args.heap_lds)
+        wname = f"timer storm: 24 tasks x sleep(gen_range(0..2 s)), heap_lds={args.heap_lds} (HBM heap-spill path)"
     else:
         w, lim = workload.kv_rpc(), workload.kv_rpc_limits()
         wname = "etcd-style KV ops over connect1/accept1 (configs[3] shape)"

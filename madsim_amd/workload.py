@@ -410,3 +410,31 @@ def kv_rpc_limits():
     lim.max_tasks = 16
     lim.heap_lds_slots, lim.heap_spill_slots = 8, 24
     return lim
+
+
+def timer_storm(n_tasks=24, rounds=16):
+    """A timer-heavy workload for the HBM heap-spill path (BASELINE configs[4]: "event-heap HBM spill path"):
+    n_tasks tasks each loop `sleep(gen_range(0..2 s))`, so the timer heap holds ~n_tasks entries at all times; with a
+    small LDS quota most of every sift walks the [slot][lane] spill region in HBM."""
+    wl = WorkloadBuilder()
+    n = wl.create_node()
+    tasks = []
+    for _ in range(n_tasks):
+        t = wl.task(n)
+        t.set(0, rounds)
+        top = t.label()
+        t.sleep_rand(lo_ms=0, secs=2)
+        t.djnz(0, top)
+        tasks.append(t)
+    m = wl.main()
+    for t in tasks:
+        m.spawn(t)
+    for t in tasks:
+        m.join(t)
+    return wl.build()
+
+
+def timer_storm_limits(lds_slots=4):
+    lim = A.Limits()
+    lim.heap_lds_slots, lim.heap_spill_slots = lds_slots, 64
+    return lim
