@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--seeds", type=int, default=SEEDS_PER_GPU, help="seeds per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lpw", type=int, default=0, help="seed-carrying lanes per wave (0 = library auto)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps are spread over. One 65 536-seed batch is 1 024 waves = one per SIMD; "
+                         "a second batch in flight on another stream fills the second wave slot the per-seed LDS allows")
     ap.add_argument("--heap-lds", type=int, default=4, help="timers workload: timer-heap entries kept in LDS")
     ap.add_argument("--generic", action="store_true", help="force the generic kernel variant (HBM heap spill enabled)")
     ap.add_argument("--workload", default="pingpong", choices=["pingpong", "raft", "kv", "timers"],
@@ -68,8 +71,10 @@ def main():
         w = workload.pingpong(N_NODES, ROUNDS)
         wname = f"{N_NODES}-node ping-pong, R={ROUNDS}, Config::default()"
         lim = A.Limits()
-        lim.heap_lds_slots, lim.heap_spill_slots = 8, 0      # pingpong needs <= 4 timers; overflow would be a verdict
-        lim.mbox_regs, lim.mbox_msgs = 1, 1
+        # tight capacities for this workload (high-water marks: 4 timers, 1 pending recv, never a queued message);
+        # exceeding one would show up as failed seeds (verdict MADSIM_OVERFLOW), never as a different answer
+        lim.heap_lds_slots, lim.heap_spill_slots = 4, 0
+        lim.mbox_regs, lim.mbox_msgs = 1, A.LIMIT_NONE
     elif args.workload == "raft":
         w, lim = workload.raft_election(), workload.raft_election_limits()
         wname = "5-node election loop with partition injection (configs[2] shape)"
@@ -85,8 +90,11 @@ def main():
     per_gpu = args.seeds
     total = per_gpu * world
     seed0, count = mdist.shard_range(0, total, rank, world)
-    d_out = torch.empty(count * 48, dtype=torch.uint8, device=dev)     # results stay resident in HBM
-    stream = torch.cuda.current_stream().cuda_stream
+    n_streams = max(1, args.streams)
+    d_outs = [torch.empty(count * 48, dtype=torch.uint8, device=dev) for _ in range(n_streams)]   # results stay in HBM
+    d_out = d_outs[0]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
+    stream = streams[0].cuda_stream
 
     # Fully asynchronous steps: the simulation kernel, the summary reduction and (N > 1) the RCCL all-reduce of the
     # 32-byte report are all queued on the stream; the host never waits inside the timed region.
@@ -96,9 +104,11 @@ def main():
     def step(k, timed):
         # a fresh block of seeds every step so nothing is cached between steps
         if use_device_report:
-            runtime.run_batch_async(w, seed0 + k * total, count, d_out.data_ptr(), ring[k].data_ptr(), stream, None, lim,
-                                    timing_slot=(k % 64) if timed else -1)
-            mdist.reduce_report_device(ring[k])
+            si = k % n_streams
+            with torch.cuda.stream(streams[si]):
+                runtime.run_batch_async(w, seed0 + k * total, count, d_outs[si].data_ptr(), ring[k].data_ptr(),
+                                        streams[si].cuda_stream, None, lim, timing_slot=(k % 64) if timed else -1)
+                mdist.reduce_report_device(ring[k])
         else:   # functional-test hook (gloo on a 1-GPU box): host-side report
             sm = runtime.run_batch_device(w, seed0 + k * total, count, d_out.data_ptr(), stream, None, lim)
             rep = mdist.reduce_report(sm.first_failing_seed, sm.n_failed, sm.total_steps, sm.total_clock_ns, cdev)
@@ -141,6 +151,9 @@ def main():
         algo_bytes = steps_per_launch * ALGO_BYTES_PER_STEP + count * IO_BYTES_PER_SEED
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
         g = runtime.geometry(w, lim)
+        b = lambda x: "true" if x else "false"
+        kname = ("sim_kernel<Variant<false,true,-1,true,false>>" if g.variant & 8 else
+                 f"sim_kernel<Variant<false,{b(g.variant & 1)},6,{b(g.variant & 2)},{b(g.variant & 4)}>>")
         # HBM traffic per launch from the rocprofv3 PMC passes of this same command (tools/prof_pmc.sh ->
         # profiles/r1_traffic.json): FETCH_SIZE (x2, the gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE
         traffic = None
@@ -155,15 +168,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{wname}, {per_gpu} seeds per GPU per step"
                                    + (" (BASELINE configs[1])" if args.workload == "pingpong" else ""),
-                       "seeds_per_step": total, "parallelism": f"seed-shard x{world}"},
+                       "seeds_per_step": total, "parallelism": f"seed-shard x{world}" + (f", {n_streams} concurrent batches per GPU" if n_streams > 1 else "")},
             "extra": {"seeds_per_sec": seeds_total / dt, "executor_steps_per_sec": steps_total / dt,
                       "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms,
                       "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu,
                       "lanes_per_wave": g.lanes_per_wave},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "sim_kernel<Variant<false,false,6,false>>" if args.workload == "pingpong" else "sim_kernel<Variant<false,true,-1,true>>", "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "LDS-resident path: algorithmic bytes (120 B/executor step) never touch HBM"},
+                         "kernel": kname, "algorithmic_bytes_per_launch": algo_bytes,
+                         "concurrent_launches": n_streams, "chip_achieved": algo_bytes * args.steps / dt / 1e9,
+                         "chip_frac": algo_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBPS,
+                         "note": "LDS-resident path: algorithmic bytes (120 B/executor step) never touch HBM; "
+                                 "achieved/frac are per launch, chip_* = all launches' bytes / wall time of the timed region"},
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle

@@ -167,6 +167,8 @@ typedef struct madsim_config {
     double   loss_table[4];
 } madsim_config_t;
 
+#define MADSIM_LIMIT_NONE 0xffffffffu  /* a capacity of zero (0 itself means "pick a default") */
+
 typedef struct madsim_limits {
     uint64_t time_limit_ns;      /* Builder.time_limit; 0 = None (task/mod.rs:253-258)               */
     uint32_t max_steps;          /* device safety net; 0 = default (1<<24). Not a reference concept. */
@@ -174,7 +176,7 @@ typedef struct madsim_limits {
     uint32_t heap_spill_slots;   /* further entries per seed in the coalesced HBM spill region       */
     uint32_t max_tasks;          /* live task instances per seed; 0 = auto (n_progs + restarts)      */
     uint32_t mbox_regs;          /* pending recv registrations per socket; 0 = auto (2)              */
-    uint32_t mbox_msgs;          /* undelivered messages per socket; 0 = auto (4)                    */
+    uint32_t mbox_msgs;          /* undelivered messages per socket; 0 = auto (2), MADSIM_LIMIT_NONE = none */
     uint32_t lanes_per_wave;     /* seeds carried per 64-lane wave (8/16/32/64); 0 = auto            */
     uint32_t max_conns;          /* live reliable-channel connections per seed; 0 = auto (4)         */
     uint32_t chan_queue;         /* queued payloads per channel direction; 0 = auto (2)              */
@@ -273,7 +275,8 @@ typedef struct madsim_geometry {
     uint32_t heap_spill_slots;
     uint32_t max_tasks;
     uint32_t lanes_per_wave;
-    uint32_t reserved;
+    uint32_t variant;              /* kernel specialisation: bit0 heap spill, bit1 extended (lifecycle/channel) ops,
+                                    * bit2 ready queue in a register, bit3 generic lanes-per-wave form */
 } madsim_geometry_t;
 int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* g);
 

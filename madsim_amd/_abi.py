@@ -8,6 +8,7 @@ import ctypes as C
 
 ABI_VERSION = 1
 U64_MAX = (1 << 64) - 1
+LIMIT_NONE = 0xFFFFFFFF
 VAL_TIMEOUT = 0xFFFFFFFF
 VAL_REFUSED = 0xFFFFFFFE
 VAL_RESET = 0xFFFFFFFD
@@ -88,7 +89,7 @@ class Geometry(C.Structure):
         ("lds_bytes_per_seed", C.c_uint32), ("lds_bytes_per_block", C.c_uint32), ("block_threads", C.c_uint32),
         ("blocks_per_cu", C.c_uint32), ("grid_blocks", C.c_uint32), ("heap_lds_slots", C.c_uint32),
         ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32), ("lanes_per_wave", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("variant", C.c_uint32),
     ]
 
 

@@ -83,7 +83,7 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
     return 0;
 }
 
-inline int make_geometry(const Device& g, const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim, uint64_t count, Geo* G, std::string* err) {
+inline int make_geometry(const Device& g, const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim, uint64_t count, Geo* G, std::string* err, bool trace = false) {
     KParams& P = G->P;
     memset(&P, 0, sizeof P);
     madsim_limits_t L{};
@@ -104,7 +104,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     if (P.max_tasks > 254) P.max_tasks = 254;
     if (P.max_tasks > 254) return fail(err, MADSIM_E_LIMITS, "max_tasks must be <= 254");
     P.mbox_regs = L.mbox_regs ? L.mbox_regs : 2;
-    P.mbox_msgs = L.mbox_msgs ? L.mbox_msgs : 2;
+    P.mbox_msgs = L.mbox_msgs == MADSIM_LIMIT_NONE ? 0 : L.mbox_msgs ? L.mbox_msgs : 2;
     if (P.mbox_regs > 255 || P.mbox_msgs > 255) return fail(err, MADSIM_E_LIMITS, "mailbox capacities must be <= 255");
     P.heap_lds = L.heap_lds_slots ? L.heap_lds_slots : 8;
     P.heap_spill = (L.heap_lds_slots || L.heap_spill_slots) ? L.heap_spill_slots : 56;
@@ -117,24 +117,13 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.chan_queue = L.chan_queue ? L.chan_queue : 2;
     if (P.max_conns > 127 || P.chan_queue > 15) return fail(err, MADSIM_E_LIMITS, "max_conns <= 127, chan_queue <= 15");
     P.conn_words = 3 + 2 * P.chan_queue * 3;
-    P.has_clog_link = uses_op(w, MS_OP_CLOG_LINK);
-    P.has_clog = P.has_clog_link || uses_op(w, MS_OP_CLOG_NODE);
+    P.has_clog_link = uses_op(w, MS_OP_CLOG_LINK) || uses_op(w, MS_OP_UNCLOG_LINK);
+    P.has_clog = P.has_clog_link || uses_op(w, MS_OP_CLOG_NODE) || uses_op(w, MS_OP_UNCLOG_NODE);
     P.uniq_addr = 1;
     for (uint32_t i = 0; i < w->n_socks; i++)
         for (uint32_t j = i + 1; j < w->n_socks; j++)
             if (w->socks[i].node == w->socks[j].node && w->socks[i].port == w->socks[j].port) P.uniq_addr = 0;
-    P.off_ready = 0;
-    P.off_socks = P.off_ready + P.max_tasks;
-    P.off_handles = P.off_socks + P.n_socks * P.sock_words;
-    P.off_nodes = P.off_handles + P.n_progs;
-    // node region: killed / paused / gen0_killed masks, spawn counter, one info_gen byte per node
-    P.off_clog = P.off_nodes + 4 + (P.n_nodes + 4) / 4;
-    P.off_pause = P.off_clog + 2 + (P.has_clog_link ? P.n_nodes + 1 : 0);
-    P.uses_pause = uses_op(w, MS_OP_PAUSE);
-    P.off_greg = P.off_pause + (P.uses_pause ? 1 + P.max_tasks : 0);
-    bool gregs = uses_op(w, MS_OP_GSET) || uses_op(w, MS_OP_GADD) || uses_op(w, MS_OP_ASSERT_G) || uses_op(w, MS_OP_PANIC_IF_G_LT);
-    P.off_conn = P.off_greg + (gregs ? 4 : 0);
-    P.lane_words = P.off_conn + (P.uses_chan ? P.max_conns * P.conn_words : 0);
+    // ---- which optional per-seed regions exist (LDS diet: a workload only carries what it can touch) ----
     P.restart_nodes = 0;
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
         if (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) P.restart_nodes |= 1u << i;
@@ -143,29 +132,53 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
                   uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND) || P.uses_chan ||
                   uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_ADVANCE);
     for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.lifecycle = 1;
-    P.sh_insns = 0;
-    P.sh_progs = P.sh_insns + 4 * P.n_insns;
-    P.sh_socks = P.sh_progs + P.n_progs;
-    P.sh_heap = (P.sh_socks + P.n_socks + 3) & ~3u;
-    const uint32_t sh_bytes = P.sh_heap * 4;
-    G->lds_per_seed = P.heap_lds * 16 + P.max_tasks * P.task_units * 16 + P.lane_words * 4;
-    if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
-    // Lanes per wave (lw): how many of a wave's 64 lanes carry a seed.  Measured on MI355X (4-node
-    // ping-pong, 65 536 seeds, profiles/r1_lanes_per_wave.md): every wave-instruction costs the SIMD
-    // ~4 cycles whatever the number of active lanes, and at 16 lanes/wave the VALU pipe is already
-    // ~98 % busy, so trading lanes for more waves loses (64: 5.36 ms, 32: 6.08, 16: 8.32, 8: 16.7).
-    // Full waves are the default; the knob stays for experiments (madsim_limits_t.lanes_per_wave).
+    // The generic kernel variants (trace, lanes_per_wave != 64) are compiled with the extended ops, so they need the
+    // node region: lay out lean first and redo the layout once with it if the lean form does not end up on a
+    // 64-lane specialised variant (see madsim_k_launch_sim).
+    if (trace) P.lifecycle = 1;
     const uint32_t cus = g.num_cus > 0 ? (uint32_t)g.num_cus : 256u;
     uint32_t lw = 64;
-    if (L.lanes_per_wave) {
-        lw = L.lanes_per_wave;
-        if (lw != 8 && lw != 16 && lw != 32 && lw != 64) return fail(err, MADSIM_E_LIMITS, "lanes_per_wave must be 8, 16, 32 or 64");
-    } else {
-        // Large per-seed state: a CU has 4 SIMDs and a wave runs on one of them, so when LDS admits fewer than four
-        // full waves per CU, carry fewer seeds per wave until at least four workgroups fit (one per SIMD) — the same
-        // seeds in flight, spread over all SIMDs.  (When >= 4 full waves fit, full waves win: r1_lanes_per_wave.md.)
-        auto blocks = [&](uint32_t l) { size_t b = (size_t)sh_bytes + (size_t)l * G->lds_per_seed; return b > g.lds_per_cu ? 0u : (uint32_t)(g.lds_per_cu / b); };
-        while (lw > 8 && blocks(lw) < 4) lw >>= 1;
+    uint32_t sh_bytes = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        // the ready queue lives in a register in the (no spill, no extended ops, <= 8 tasks) variant: see madsim_k_launch_sim
+        P.rq_in_reg = !P.lifecycle && P.heap_spill == 0 && P.max_tasks <= 8 && !trace;
+        P.off_ready = 0;
+        P.off_socks = P.off_ready + (P.rq_in_reg ? 0 : P.max_tasks);
+        P.off_handles = P.off_socks + P.n_socks * P.sock_words;
+        P.off_nodes = P.off_handles + P.n_progs;
+        // node region (extended ops only): killed / paused / gen0_killed masks, spawn counter, one info_gen byte per node
+        P.off_clog = P.off_nodes + (P.lifecycle ? 4 + (P.n_nodes + 4) / 4 : 0);
+        P.off_pause = P.off_clog + (P.has_clog ? 2 + (P.has_clog_link ? P.n_nodes + 1 : 0) : 0);
+        P.uses_pause = uses_op(w, MS_OP_PAUSE);
+        P.off_greg = P.off_pause + (P.uses_pause ? 1 + P.max_tasks : 0);
+        bool gregs = uses_op(w, MS_OP_GSET) || uses_op(w, MS_OP_GADD) || uses_op(w, MS_OP_ASSERT_G) || uses_op(w, MS_OP_PANIC_IF_G_LT);
+        P.off_conn = P.off_greg + (gregs ? 4 : 0);
+        P.lane_words = P.off_conn + (P.uses_chan ? P.max_conns * P.conn_words : 0);
+        P.sh_insns = 0;
+        P.sh_progs = P.sh_insns + 4 * P.n_insns;
+        P.sh_socks = P.sh_progs + P.n_progs;
+        P.sh_heap = (P.sh_socks + P.n_socks + 3) & ~3u;
+        sh_bytes = P.sh_heap * 4;
+        G->lds_per_seed = P.heap_lds * 16 + P.max_tasks * P.task_units * 16 + P.lane_words * 4;
+        if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
+        // Lanes per wave (lw): how many of a wave's 64 lanes carry a seed.  Measured on MI355X (4-node
+        // ping-pong, 65 536 seeds, profiles/r1_lanes_per_wave.md): every wave-instruction costs the SIMD
+        // ~4 cycles whatever the number of active lanes, and at 16 lanes/wave the VALU pipe is already
+        // ~98 % busy, so trading lanes for more waves loses (64: 5.36 ms, 32: 6.08, 16: 8.32, 8: 16.7).
+        // Full waves are the default; the knob stays for experiments (madsim_limits_t.lanes_per_wave).
+        lw = 64;
+        if (L.lanes_per_wave) {
+            lw = L.lanes_per_wave;
+            if (lw != 8 && lw != 16 && lw != 32 && lw != 64) return fail(err, MADSIM_E_LIMITS, "lanes_per_wave must be 8, 16, 32 or 64");
+        } else {
+            // Large per-seed state: a CU has 4 SIMDs and a wave runs on one of them, so when LDS admits fewer than four
+            // full waves per CU, carry fewer seeds per wave until at least four workgroups fit (one per SIMD) — the same
+            // seeds in flight, spread over all SIMDs.  (When >= 4 full waves fit, full waves win: r1_lanes_per_wave.md.)
+            auto blocks = [&](uint32_t l) { size_t b = (size_t)sh_bytes + (size_t)l * G->lds_per_seed; return b > g.lds_per_cu ? 0u : (uint32_t)(g.lds_per_cu / b); };
+            while (lw > 8 && blocks(lw) < 4) lw >>= 1;
+        }
+        if (lw == 64 || P.lifecycle) break;
+        P.lifecycle = 1;
     }
     P.lw_shift = lw == 8 ? 3 : lw == 16 ? 4 : lw == 32 ? 5 : 6;
     P.sh_tasks = P.sh_heap + P.heap_lds * lw * 4;

@@ -276,7 +276,7 @@ int64_t madsim_hip_trace_seed(const madsim_workload_t* w, const madsim_config_t*
     int rc = madsim_geo::validate(w, cfg, &g_err);
     if (rc) return rc;
     Geo G;
-    if ((rc = madsim_geo::make_geometry(dev(), w, cfg, lim, 1, &G, &g_err))) return rc;
+    if ((rc = madsim_geo::make_geometry(dev(), w, cfg, lim, 1, &G, &g_err, true))) return rc;
     if ((rc = upload_workload(w, G.P))) return rc;
     if ((rc = ensure_spill(G.P))) return rc;
     if (cap > g.tlog_cap) {
@@ -313,7 +313,8 @@ int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, 
     if ((rc = madsim_geo::make_geometry(dev(), w, &cfg, lim, UINT64_MAX / 2, &G, &g_err))) return rc;
     out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64;
     out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
-    out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave; out->reserved = 0;
+    out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave;
+    out->variant = G.P.lw_shift != 6 ? 8u | 3u : (G.P.heap_spill ? 1u : 0u) | (G.P.lifecycle ? 2u : 0u) | (G.P.rq_in_reg ? 4u : 0u);
     return 0;
 }
 

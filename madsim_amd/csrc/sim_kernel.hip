@@ -418,8 +418,8 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
         if (via_handle && cur_gen != 0) { killed = 1; info_gen = 0; }             // stale handle: dead info
         else killed = ((via_handle ? NODEW(2) : NODEW(0)) >> node) & 1;          // task/mod.rs:632-634
     }
-    uint32_t seq = NODEW(3);
-    NODEW(3) = seq + 1;
+    uint32_t seq = 0;
+    if (K::LIFE) { seq = NODEW(3); NODEW(3) = seq + 1; }      // spawn order matters only to NodeInfo::kill
     TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
     TU(c, slot, 1) = make_uint4(0xffu << 8, (seq & 0xffffff) | (info_gen << 24), 0, 0);   // rxseq 0, no awaiter; spawn order
     if (K::LIFE && c.P.uses_chan) TU(c, slot, 3) = make_uint4(0xff, 0, 0, 0);                // no connection held
@@ -1360,7 +1360,7 @@ extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, u
 #define LAUNCH(...) hipLaunchKernelGGL((sim_kernel<Variant<__VA_ARGS__>>), dim3(grid), dim3(64), lds_bytes, st, *P)
     if (trace) LAUNCH(true, true, -1, true);
     else if (P->lw_shift != 6) LAUNCH(false, true, -1, true);
-    else if (!spill && !life && P->max_tasks <= 8) LAUNCH(false, false, 6, false, true);
+    else if (!spill && !life && P->rq_in_reg) LAUNCH(false, false, 6, false, true);
     else if (!spill && !life) LAUNCH(false, false, 6, false);
     else if (spill && !life) LAUNCH(false, true, 6, false);
     else if (!spill && life) LAUNCH(false, false, 6, true);

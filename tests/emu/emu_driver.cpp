@@ -22,7 +22,7 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
     if (rc) return rc;
     madsim_geo::Device dev; dev.num_cus = num_cus > 0 ? num_cus : 2;
     madsim_geo::Geo G;
-    if ((rc = madsim_geo::make_geometry(dev, w, cfg, lim, count, &G, &emu_err))) return rc;
+    if ((rc = madsim_geo::make_geometry(dev, w, cfg, lim, count, &G, &emu_err, tlog != nullptr))) return rc;
     madsim_k::KParams& P = G.P;
     madsim_geo::DeviceTables T;
     if ((rc = madsim_geo::build_tables(w, &T, &emu_err))) return rc;
@@ -42,7 +42,7 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
             const bool spill = P.spill != nullptr, life = P.lifecycle != 0;
             if (tlog) sim_kernel<Variant<true, true, -1, true>>(P);
             else if (P.lw_shift != 6) sim_kernel<Variant<false, true, -1, true>>(P);
-            else if (!spill && !life && P.max_tasks <= 8) sim_kernel<Variant<false, false, 6, false, true>>(P);
+            else if (!spill && !life && P.rq_in_reg) sim_kernel<Variant<false, false, 6, false, true>>(P);
             else if (!spill && !life) sim_kernel<Variant<false, false, 6, false>>(P);
             else if (spill && !life) sim_kernel<Variant<false, true, 6, false>>(P);
             else if (!spill && life) sim_kernel<Variant<false, false, 6, true>>(P);
@@ -60,6 +60,7 @@ extern "C" int madsim_emu_geometry(const madsim_workload_t* w, const madsim_limi
     if ((rc = madsim_geo::make_geometry(dev, w, &cfg, lim, UINT64_MAX / 2, &G, &emu_err))) return rc;
     out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64;
     out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
-    out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave; out->reserved = 0;
+    out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave;
+    out->variant = G.P.lw_shift != 6 ? 8u | 3u : (G.P.heap_spill ? 1u : 0u) | (G.P.lifecycle ? 2u : 0u) | (G.P.rq_in_reg ? 4u : 0u);
     return 0;
 }
