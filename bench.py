@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=SEEDS_PER_GPU, help="seeds per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lpw", type=int, default=0, help="seed-carrying lanes per wave (0 = library auto)")
+    ap.add_argument("--nodes", type=int, default=N_NODES, help="ping-pong nodes (experiments; the bench line is quoted on 4)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are spread over. One 65 536-seed batch is 1 024 waves = one per SIMD; "
                          "a second batch in flight on another stream fills the second wave slot the per-seed LDS allows")
@@ -68,8 +69,8 @@ def main():
     runtime.init(gpu)
 
     if args.workload == "pingpong":
-        w = workload.pingpong(N_NODES, ROUNDS)
-        wname = f"{N_NODES}-node ping-pong, R={ROUNDS}, Config::default()"
+        w = workload.pingpong(args.nodes, ROUNDS)
+        wname = f"{args.nodes}-node ping-pong, R={ROUNDS}, Config::default()"
         lim = A.Limits()
         # tight capacities for this workload (high-water marks: 4 timers, 1 pending recv, never a queued message);
         # exceeding one would show up as failed seeds (verdict MADSIM_OVERFLOW), never as a different answer
@@ -158,7 +159,7 @@ def main():
         # profiles/r1_traffic.json): FETCH_SIZE (x2, the gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if world == 1 and per_gpu == SEEDS_PER_GPU and args.workload == "pingpong" and os.path.exists(tpath):
+        if world == 1 and per_gpu == SEEDS_PER_GPU and args.workload == "pingpong" and args.nodes == N_NODES and os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = (2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0
         line = {
@@ -167,11 +168,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"{wname}, {per_gpu} seeds per GPU per step"
-                                   + (" (BASELINE configs[1])" if args.workload == "pingpong" else ""),
+                                   + (" (BASELINE configs[1])" if args.workload == "pingpong" and args.nodes == N_NODES else ""),
                        "seeds_per_step": total, "parallelism": f"seed-shard x{world}" + (f", {n_streams} concurrent batches per GPU" if n_streams > 1 else "")},
             "extra": {"seeds_per_sec": seeds_total / dt, "executor_steps_per_sec": steps_total / dt,
                       "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms,
-                      "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu,
+                      "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu * g.block_threads // 64,
                       "lanes_per_wave": g.lanes_per_wave},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -19,7 +19,7 @@ inline int fail(std::string* err, int code, const std::string& msg) { if (err) *
 
 struct Geo {
     KParams P;
-    uint32_t lds_bytes, lds_per_seed, blocks_per_cu, grid, lanes_per_wave;
+    uint32_t lds_bytes, lds_per_seed, blocks_per_cu, grid, lanes_per_wave, waves_per_block;
 };
 
 inline bool uses_op(const madsim_workload_t* w, int op) {
@@ -183,17 +183,33 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.lw_shift = lw == 8 ? 3 : lw == 16 ? 4 : lw == 32 ? 5 : 6;
     P.sh_tasks = P.sh_heap + P.heap_lds * lw * 4;
     P.sh_planes = P.sh_tasks + P.max_tasks * P.task_units * lw * 4;
-    G->lds_bytes = (P.sh_planes + P.lane_words * lw) * 4;
-    if (G->lds_bytes > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-workgroup LDS exceeds 160 KiB: lower heap_lds_slots / mailbox capacities");
-    uint32_t by_lds = (uint32_t)(g.lds_per_cu / G->lds_bytes);
-    uint32_t bpc = by_lds < 16 ? by_lds : 16;          // VGPR budget admits 4 waves/SIMD = 16 one-wave workgroups per CU
+    P.wave_words = P.sh_planes + P.lane_words * lw - P.sh_heap;
+    if ((size_t)(P.sh_heap + P.wave_words) * 4 > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-wave LDS exceeds 160 KiB: lower heap_lds_slots / mailbox capacities");
+    // Workgroup = W independent waves.  Measured on MI355X (tools/placement.hip, profiles/r1_placement.txt): the
+    // dispatcher spreads the waves of a 256-thread workgroup one per SIMD and keeps three or more such launches
+    // co-resident and balanced, while one-wave workgroups stop overlapping beyond two concurrent launches.  So take
+    // the largest W in {4, 2, 1} that does not cost a wave of LDS occupancy.
+    const uint64_t want = (count + lw - 1) / lw;      // waves this batch needs
+    uint32_t W = 1, waves_cu = 0;
+    for (uint32_t w2 = 4; w2 >= 1; w2 >>= 1) {
+        uint32_t blocks = (uint32_t)(g.lds_per_cu / ((size_t)(P.sh_heap + w2 * P.wave_words) * 4));
+        uint32_t wv = blocks * w2 < 16 ? blocks * w2 : 16;   // VGPR budget admits 4 waves per SIMD
+        if (wv > waves_cu) { waves_cu = wv; W = w2; }
+    }
+    if (want < W) W = want > 1 ? 2 : 1;
+    P.waves_per_block = W;
+    G->lds_bytes = (P.sh_heap + W * P.wave_words) * 4;
+    uint32_t bpc = (uint32_t)(g.lds_per_cu / G->lds_bytes);
+    if (bpc * W > 16) bpc = 16 / W;
+    if (bpc == 0) bpc = 1;
     G->blocks_per_cu = bpc;
+    G->waves_per_block = W;
     G->lanes_per_wave = lw;
-    uint64_t want = (count + lw - 1) / lw;
+    uint64_t want_blocks = (want + W - 1) / W;
     uint64_t resident = (uint64_t)bpc * cus;
-    G->grid = (uint32_t)(want < resident ? want : resident);
+    G->grid = (uint32_t)(want_blocks < resident ? want_blocks : resident);
     if (G->grid == 0) G->grid = 1;
-    P.total_lanes = G->grid * lw;
+    P.total_lanes = G->grid * W * lw;
     return 0;
 }
 

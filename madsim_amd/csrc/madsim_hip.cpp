@@ -311,7 +311,7 @@ int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, 
     if (rc) return rc;
     Geo G;
     if ((rc = madsim_geo::make_geometry(dev(), w, &cfg, lim, UINT64_MAX / 2, &G, &g_err))) return rc;
-    out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64;
+    out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64 * G.waves_per_block;
     out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
     out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave;
     out->variant = G.P.lw_shift != 6 ? 8u | 3u : (G.P.heap_spill ? 1u : 0u) | (G.P.lifecycle ? 2u : 0u) | (G.P.rq_in_reg ? 4u : 0u);

@@ -30,6 +30,9 @@ struct KParams {
     // LDS layout, in 32-bit words: workgroup-shared tables, heap units and task units (16-byte
     // aligned, [unit][lane]), then the 32-bit planes ([word][lane])
     uint32_t sh_insns, sh_progs, sh_socks, sh_heap, sh_tasks, sh_planes;
+    // a workgroup is waves_per_block independent waves (one per SIMD): the tables once, then one
+    // [heap][tasks][planes] slice of wave_words per wave; sh_heap/sh_tasks/sh_planes are wave 0's
+    uint32_t waves_per_block, wave_words;
     // per-lane plane offsets (in words)
     uint32_t off_ready, off_socks, off_handles, off_nodes, off_clog, off_pause, off_greg, off_conn;
     uint32_t uses_chan, max_conns, chan_queue, conn_words;   // reliable channel (connect1/accept1) state, if used

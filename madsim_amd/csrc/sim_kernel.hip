@@ -61,6 +61,10 @@ enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 // RQ = the ready queue (<= 8 tasks) lives in a 64-bit register, one byte per queued task, instead of LDS.
 template <bool TRACE_, bool SPILL_, int LWS_, bool LIFE_, bool RQ_ = false> struct Variant { static constexpr bool TRACE = TRACE_, SPILL = SPILL_, LIFE = LIFE_, RQ = RQ_; static constexpr int LWS = LWS_; };
 
+// REG(id): divergence-model markers, compiled in only by tools/divergence_model.py's host emulation build
+#ifndef REG
+#define REG(id) do { } while (0)
+#endif
 #ifdef EXP_PROF2
 #define PROBE2(i) do { uint64_t t_ = __builtin_readcyclecounter(); L.prof_acc[i] += t_ - L.prof_t; L.prof_t = t_; } while (0)
 #else
@@ -181,7 +185,7 @@ template <class K>
 __device__ __forceinline__ uint64_t gen_range_u64(const Ctx& c, Lane& L, uint64_t lo, uint64_t range) {
     uint64_t zone = (range << __builtin_clzll(range)) - 1;
     uint64_t v;
-    do { v = rng_next(L); } while (v * range > zone);
+    do { REG(16); v = rng_next(L); } while (v * range > zone);
     rng_log<K>(c, L);
     return lo + __umul64hi(v, range);
 }
@@ -191,7 +195,7 @@ template <class K>
 __device__ __forceinline__ uint32_t gen_index(const Ctx& c, Lane& L, uint32_t len) {
     uint64_t zone = ((uint64_t)len << __builtin_clzll((uint64_t)len)) - 1;
     uint64_t v;
-    do { v = rng_next(L); } while (EXP_ACCEPT(v * (uint64_t)len > zone));   // accept test on the low 64 bits only
+    do { REG(1); v = rng_next(L); } while (EXP_ACCEPT(v * (uint64_t)len > zone));   // accept test on the low 64 bits only
     rng_log<K>(c, L);
     uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * len + (((uint64_t)(uint32_t)v * len) >> 32);
     return (uint32_t)(mid >> 32);                               // high 64 bits of v * len
@@ -202,7 +206,7 @@ template <class K, uint32_t RANGE>
 __device__ __forceinline__ uint32_t gen_range_small(const Ctx& c, Lane& L) {
     constexpr uint64_t zone = ((uint64_t)RANGE << __builtin_clzll((uint64_t)RANGE)) - 1;
     uint64_t v;
-    do { v = rng_next(L); } while (EXP_ACCEPT(v * (uint64_t)RANGE > zone));
+    do { REG(RANGE == 50 ? 18 : 16); v = rng_next(L); } while (EXP_ACCEPT(v * (uint64_t)RANGE > zone));
     rng_log<K>(c, L);
     uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * RANGE + (((uint64_t)(uint32_t)v * RANGE) >> 32);
     return (uint32_t)(mid >> 32);
@@ -212,6 +216,7 @@ __device__ __forceinline__ uint32_t gen_range_small(const Ctx& c, Lane& L) {
 template <class K>
 __device__ __forceinline__ bool gen_bool_pint(const Ctx& c, Lane& L, uint64_t p_int, uint32_t always) {
     if (always) return true;
+    REG(7);
     uint64_t v = rng_next(L);
     rng_log<K>(c, L);
     return v < p_int;
@@ -223,6 +228,7 @@ __device__ __forceinline__ uint64_t sample_latency(const Ctx& c, Lane& L) {
     const KParams& P = c.P;
     uint64_t res;
     for (;;) {
+        REG(8);
         uint64_t v = rng_next(L);
         rng_log<K>(c, L);
         if (P.lat_mode == 0) {
@@ -263,6 +269,7 @@ template <class K>
 __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos, const uint4& hole) {
     uint64_t hd = ev_deadline(hole);
     while (pos > 0) {
+        REG(11);
         uint32_t parent = (pos - 1) >> 1;
         if (parent == 0 && hd >= L.top_dl) break;      // root deadline is mirrored in a register
         uint4 p = heap_get<K>(c, parent);
@@ -278,6 +285,7 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos
 template <class K>
 __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val) {
     PROBE2(0);
+    REG(10);
     if (L.heap_len >= c.P.heap_lds + (K::SPILL ? c.P.heap_spill : 0u)) return false;
     uint4 e = make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, val);
     heap_sift_up<K>(c, L, L.heap_len, e);
@@ -290,12 +298,14 @@ __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadli
 template <class K>
 __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
     PROBE2(0);
+    REG(20);
     uint32_t end = --L.heap_len;
     uint4 item = heap_get<K>(c, end);
     if (end > 0) {
         uint4 top = heap_get<K>(c, 0);
         uint32_t pos = 0, child = 1;
         while (child + 1 < end) {
+            REG(21);
             uint4 l = heap_get<K>(c, child), r = heap_get<K>(c, child + 1);
             bool right = ev_deadline(l) >= ev_deadline(r);   // left <= right in heap order: take right
             uint4 m = right ? r : l;
@@ -356,6 +366,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
     uint32_t i = 0;
     while (i < nreg) {
+        REG(24);
         uint32_t r = SW(c, s, 2 + i);
         if ((r & 0xff) == tag) {
             nreg--;
@@ -394,8 +405,8 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
         uint4 e = timer_pop<K>(c, L);
         L.steps++;
         uint32_t kind = e.z >> 28;
-        if (kind == EV_WAKE) wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff);   // time/sleep.rs:52
-        else if (kind == EV_DELIVER) mailbox_deliver<K>(c, L, e.z, e.w);      // net/mod.rs:323-330
+        if (kind == EV_WAKE) { REG(22); wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff); }   // time/sleep.rs:52
+        else if (kind == EV_DELIVER) { REG(23); mailbox_deliver<K>(c, L, e.z, e.w); }      // net/mod.rs:323-330
         else if (K::LIFE && kind == EV_RESTART) node_restart<K>(c, L, e.z & 0xff);   // task/mod.rs:313
     }
 }
@@ -676,10 +687,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
 
         PROBE(5);
+        REG(2);
         // ================= [A] the task is parked on an await of this op =========================
         if (sub != 0) {
             bool completed = false;                        // this op is done: step to the next one below
             if (op == MS_OP_RECV && sub == 1) {            // oneshot::Receiver (endpoint.rs:142-144)
+                REG(4);
                 if (!(u0.x & TF_INBOX)) { st = ST_PENDING; break; }
                 u0.x &= ~TF_INBOX;
                 from = u0.y >> 24;
@@ -694,7 +707,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (!completed) break;
             } else {                                       // a Sleep (time/sleep.rs:47-54)
                 uint64_t deadline = u64of(u1.z, u1.w);
+                REG(3);
                 if (L.clock < deadline) {                  // not elapsed: register ANOTHER timer
+                    REG(5);
                     if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
                     st = ST_PENDING;
                     break;
@@ -745,6 +760,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     SW(c, a, 1) = slot | (gen << 16);
                     if (K::LIFE && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
                 } else if (op == MS_OP_SEND || op == MS_OP_REPLY) {        // net/mod.rs:307-331
+                    REG(6);
                     uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : from;
                     uint32_t src_node = SOCKW(c, a) & 0xff;
                     uint32_t dst_node = SOCKW(c, dst) & 0xff;
@@ -766,6 +782,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 completed = true;
             }
             if (completed) {                               // fall through to [B]/[C] with the next op: one pass per poll
+                REG(12);
                 sub = 0;
                 // fused post-chain of this op (geometry.h build_tables): assert_eq!(val, ..), then djnz / jmp
                 const uint32_t pf = in.w;
@@ -788,6 +805,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         PROBE(6);
         // ================= [B] cheap ops that never await ========================================
         while (is_light(op)) {
+            REG(13);
             if (op == MS_OP_ASSERT_VAL) {
                 if (u0.w != imm) { st = ST_PANIC; break; }
                 pc++;
@@ -816,11 +834,13 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (st != ST_RUN) break;
 
         PROBE(7);
+        REG(9);
         // ================= [C] begin the next op =================================================
         bool want_delay = false, want_sleep = false;
         uint64_t deadline = 0;
         if (op == MS_OP_RECV) {
             if (sub == 0) {                                // Mailbox::recv (endpoint.rs:353-362)
+                REG(14);
                 uint32_t tag = b >> 8;
                 uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;
                 u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
@@ -1109,10 +1129,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         }
         PROBE(8);
         if (want_delay) {                                  // NetSim::rand_delay (net/mod.rs:287-292)
+            REG(15);
             deadline = rand_delay_deadline<K>(c, L);
             want_sleep = true;
         }
         if (want_sleep) {                                  // first Sleep::poll: never elapsed (1 ms floor)
+            REG(17);
             u1.z = (uint32_t)deadline; u1.w = (uint32_t)(deadline >> 32); u1_dirty = true;
             sub = (op == MS_OP_RECV) ? 3 : 1;
             if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
@@ -1153,14 +1175,14 @@ __device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
 }
 
 template <class K>
-__global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
-    const uint32_t lane = threadIdx.x;
+__global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // workgroup-shared tables
     uint32_t* sh = SMEM;
 #ifdef MADSIM_EMU
     const uint32_t cp0 = 0, cps = 1;      // emulated threads run one after another: each copies everything
 #else
-    const uint32_t cp0 = lane, cps = 64;
+    const uint32_t cp0 = threadIdx.x, cps = 64 * P.waves_per_block;
 #endif
     for (uint32_t i = cp0; i < P.n_insns * 4; i += cps) sh[P.sh_insns + i] = ((const uint32_t*)P.insns)[i];
     for (uint32_t i = cp0; i < P.n_progs; i += cps) sh[P.sh_progs + i] = P.progs[i];
@@ -1171,10 +1193,11 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
     c.insn0 = P.sh_insns / 4;
     c.prog0 = P.sh_progs;
     c.sockt0 = P.sh_socks;
-    c.heap0 = P.sh_heap / 4 + lane;
-    c.task0 = P.sh_tasks / 4 + lane;
+    const uint32_t wbase = wv * P.wave_words;       // this wave's slice of the workgroup's LDS
+    c.heap0 = (P.sh_heap + wbase) / 4 + lane;
+    c.task0 = (P.sh_tasks + wbase) / 4 + lane;
     c.lws = P.lw_shift;
-    const uint32_t pl = P.sh_planes + lane;
+    const uint32_t pl = P.sh_planes + wbase + lane;
     c.ready0 = pl + (P.off_ready << P.lw_shift);
     c.sock0 = pl + (P.off_socks << P.lw_shift);
     c.hand0 = pl + (P.off_handles << P.lw_shift);
@@ -1184,7 +1207,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
     c.greg0 = pl + (P.off_greg << P.lw_shift);
     c.conn0 = pl + (P.off_conn << P.lw_shift);
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
-    const uint32_t glane = (blockIdx.x << P.lw_shift) + lane;
+    const uint32_t glane = ((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane;
     c.spill = P.spill ? P.spill + glane : nullptr;
     c.tlog = P.trace_log;
 
@@ -1212,6 +1235,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
 #endif
         uint64_t now = L.clock;
         PROBE(0);
+        REG(0);
         if (L.ready_len > 0) {
             // Latency hiding: the queue usually holds exactly one task, so ready[0] and its two state units are
             // loaded BEFORE the draw loop (whose rejection retries take hundreds of cycles) and used if idx == 0.
@@ -1234,6 +1258,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
             L.steps++;
             bool panicked = false;
             PROBE(1);
+            REG(26);
             bool parked = false;
             if (K::LIFE && (u0.x & (TF_CANCEL | TF_KILLED))) {   // task/mod.rs:269-273: drop(runnable)
                 task_finish<K>(c, L, slot, H_CANCELLED);
@@ -1276,6 +1301,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
         }
         bool idle_jump = false;
         while (L.verdict == MADSIM_RUNNING) {
+            REG(19);
             timer_expire<K>(c, L, now);
             if (idle_jump) {
                 L.clock = now;                                // time/mod.rs:55: after the callbacks
@@ -1292,6 +1318,7 @@ __global__ __launch_bounds__(64) void sim_kernel(const KParams P) {
         PROBE(4);
         if (L.ovf) L.verdict = MADSIM_OVERFLOW;
         if (L.verdict != MADSIM_RUNNING) {
+            REG(25);
             madsim_result_t r;
             r.verdict = L.verdict; r.steps = L.steps; r.clock_ns = L.clock; r.msg_count = L.msg_count;
             r.rng_calls = L.rng_calls; r.trace_hash = L.trace_hash; r.obs_hash = L.obs_hash;
@@ -1357,7 +1384,7 @@ extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, u
     const bool spill = P->spill != nullptr && P->heap_spill > 0;
     const bool life = P->lifecycle != 0;
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(...) hipLaunchKernelGGL((sim_kernel<Variant<__VA_ARGS__>>), dim3(grid), dim3(64), lds_bytes, st, *P)
+#define LAUNCH(...) hipLaunchKernelGGL((sim_kernel<Variant<__VA_ARGS__>>), dim3(grid), dim3(64 * P->waves_per_block), lds_bytes, st, *P)
     if (trace) LAUNCH(true, true, -1, true);
     else if (P->lw_shift != 6) LAUNCH(false, true, -1, true);
     else if (!spill && !life && P->rq_in_reg) LAUNCH(false, false, 6, false, true);

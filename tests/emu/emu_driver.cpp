@@ -13,6 +13,28 @@ thread_local uint32_t* emu_smem;
 
 static thread_local std::string emu_err;
 
+#ifdef MADSIM_EMU_REGIONS
+// Divergence model: every lane logs how often it visits each marked code region in each main-loop iteration; a
+// wave executes a region max-over-lanes times per iteration (lanes re-converge at the loop top), so
+// sum(max) = wave trips and sum(visits) / (64 * trips) = lane utilisation of that region.
+#include <array>
+#include <stdio.h>
+#include <stdlib.h>
+static constexpr int NREG = 32;
+static thread_local std::vector<std::array<uint16_t, NREG>>* emu_lane_log = nullptr;
+void emu_region(int id) {
+    if (!emu_lane_log) return;
+    if (id == 0) emu_lane_log->push_back({});
+    if (emu_lane_log->empty()) return;
+    emu_lane_log->back()[id]++;
+}
+static double reg_trips[NREG], reg_visits[NREG], reg_iters;
+extern "C" void madsim_emu_region_stats(double* trips, double* visits, double* iters) {
+    for (int i = 0; i < NREG; i++) { trips[i] = reg_trips[i]; visits[i] = reg_visits[i]; }
+    *iters = reg_iters;
+}
+#endif
+
 extern "C" const char* madsim_emu_last_error(void) { return emu_err.c_str(); }
 
 extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
@@ -35,9 +57,19 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
     std::vector<uint32_t> lds(G.lds_bytes / 4 + 4);
     uint32_t* base = lds.data();
     while (((uintptr_t)base) & 15) base++;
-    for (uint32_t b = 0; b < G.grid; b++) {
+#ifdef MADSIM_EMU_REGIONS
+    for (int i = 0; i < NREG; i++) reg_trips[i] = reg_visits[i] = 0;
+    reg_iters = 0;
+#endif
+    for (uint32_t b = 0; b < G.grid * G.waves_per_block; b++) {       // b = wave index: waves are independent
+#ifdef MADSIM_EMU_REGIONS
+        std::vector<std::vector<std::array<uint16_t, NREG>>> logs(G.lanes_per_wave);
+#endif
         for (uint32_t t = 0; t < G.lanes_per_wave; t++) {
-            blockIdx.x = b; threadIdx.x = t; emu_smem = base;
+#ifdef MADSIM_EMU_REGIONS
+            emu_lane_log = &logs[t];
+#endif
+            blockIdx.x = b / G.waves_per_block; threadIdx.x = (b % G.waves_per_block) * 64 + t; emu_smem = base;
             using namespace madsim_k;
             const bool spill = P.spill != nullptr, life = P.lifecycle != 0;
             if (tlog) sim_kernel<Variant<true, true, -1, true>>(P);
@@ -48,6 +80,27 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
             else if (!spill && life) sim_kernel<Variant<false, false, 6, true>>(P);
             else sim_kernel<Variant<false, true, 6, true>>(P);
         }
+#ifdef MADSIM_EMU_REGIONS
+        emu_lane_log = nullptr;
+        size_t iters = 0;
+        for (auto& l : logs) iters = l.size() > iters ? l.size() : iters;
+        reg_iters += (double)iters;
+        if (const char* dp = getenv("MADSIM_EMU_DUMP")) {      // raw RNG-attempt counts: [wave][iter][lane][5] bytes
+            FILE* f = fopen(dp, b == 0 ? "wb" : "ab");
+            static const int ids[5] = {1, 7, 8, 16, 18};
+            uint32_t hdr[2] = {(uint32_t)iters, (uint32_t)logs.size()};
+            fwrite(hdr, 4, 2, f);
+            for (size_t i = 0; i < iters; i++)
+                for (auto& l : logs) { uint8_t v[5]; for (int k = 0; k < 5; k++) v[k] = i < l.size() ? (uint8_t)l[i][ids[k]] : 0; fwrite(v, 1, 5, f); }
+            fclose(f);
+        }
+        for (size_t i = 0; i < iters; i++)
+            for (int r = 0; r < NREG; r++) {
+                uint32_t mx = 0, sum = 0;
+                for (auto& l : logs) if (i < l.size()) { mx = l[i][r] > mx ? l[i][r] : mx; sum += l[i][r]; }
+                reg_trips[r] += mx; reg_visits[r] += sum;
+            }
+#endif
     }
     return 0;
 }
@@ -58,7 +111,7 @@ extern "C" int madsim_emu_geometry(const madsim_workload_t* w, const madsim_limi
     if (rc) return rc;
     madsim_geo::Geo G; madsim_geo::Device dev;
     if ((rc = madsim_geo::make_geometry(dev, w, &cfg, lim, UINT64_MAX / 2, &G, &emu_err))) return rc;
-    out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64;
+    out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64 * G.waves_per_block;
     out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
     out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave;
     out->variant = G.P.lw_shift != 6 ? 8u | 3u : (G.P.heap_spill ? 1u : 0u) | (G.P.lifecycle ? 2u : 0u) | (G.P.rq_in_reg ? 4u : 0u);
