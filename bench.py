@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are spread over. One 65 536-seed batch is 1 024 waves = one per SIMD; "
                          "a second batch in flight on another stream fills the second wave slot the per-seed LDS allows")
-    ap.add_argument("--heap-lds", type=int, default=4, help="timers workload: timer-heap entries kept in LDS")
+    ap.add_argument("--heap-lds", type=int, default=4, help="timer-heap entries kept in LDS (the rest spill to HBM)")
     ap.add_argument("--generic", action="store_true", help="force the generic kernel variant (HBM heap spill enabled)")
     ap.add_argument("--workload", default="pingpong", choices=["pingpong", "raft", "kv", "timers"],
                     help="pingpong = BASELINE configs[1] (the headline); raft / kv = configs[2] / configs[3]-shaped extras")
@@ -74,7 +74,7 @@ def main():
         lim = A.Limits()
         # tight capacities for this workload (high-water marks: 4 timers, 1 pending recv, never a queued message);
         # exceeding one would show up as failed seeds (verdict MADSIM_OVERFLOW), never as a different answer
-        lim.heap_lds_slots, lim.heap_spill_slots = 4, 0
+        lim.heap_lds_slots, lim.heap_spill_slots = args.heap_lds, 4 - args.heap_lds
         lim.mbox_regs, lim.mbox_msgs = 1, A.LIMIT_NONE
     elif args.workload == "raft":
         w, lim = workload.raft_election(), workload.raft_election_limits()

@@ -4,6 +4,7 @@
 #define MADSIM_GEOMETRY_H
 
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -140,12 +141,14 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     uint32_t lw = 64;
     uint32_t sh_bytes = 0;
     for (int pass = 0; pass < 2; pass++) {
-        // the ready queue lives in a register in the (no spill, no extended ops, <= 8 tasks) variant: see madsim_k_launch_sim
-        P.rq_in_reg = !P.lifecycle && P.heap_spill == 0 && P.max_tasks <= 8 && !trace;
+        if (!P.lifecycle && P.max_tasks < P.n_progs) P.max_tasks = P.n_progs;   // handle words live in task slots there
+        // the ready queue lives in a register in the (no extended ops, <= 8 tasks) variants: see madsim_k_launch_sim
+        P.rq_in_reg = !P.lifecycle && P.max_tasks <= 8 && !trace;
         P.off_ready = 0;
         P.off_socks = P.off_ready + (P.rq_in_reg ? 0 : P.max_tasks);
         P.off_handles = P.off_socks + P.n_socks * P.sock_words;
-        P.off_nodes = P.off_handles + P.n_progs;
+        // JoinHandle words: a plane with the extended ops, else unit1.y of task slot p (sim_kernel.hip HW)
+        P.off_nodes = P.off_handles + (P.lifecycle ? P.n_progs : 0);
         // node region (extended ops only): killed / paused / gen0_killed masks, spawn counter, one info_gen byte per node
         P.off_clog = P.off_nodes + (P.lifecycle ? 4 + (P.n_nodes + 4) / 4 : 0);
         P.off_pause = P.off_clog + (P.has_clog ? 2 + (P.has_clog_link ? P.n_nodes + 1 : 0) : 0);
@@ -188,14 +191,16 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // Workgroup = W independent waves.  Measured on MI355X (tools/placement.hip, profiles/r1_placement.txt): the
     // dispatcher spreads the waves of a 256-thread workgroup one per SIMD and keeps three or more such launches
     // co-resident and balanced, while one-wave workgroups stop overlapping beyond two concurrent launches.  So take
-    // the largest W in {4, 2, 1} that does not cost a wave of LDS occupancy.
+    // the largest W in {4, 2, 1} that costs at most one wave of LDS occupancy per CU.
     const uint64_t want = (count + lw - 1) / lw;      // waves this batch needs
-    uint32_t W = 1, waves_cu = 0;
-    for (uint32_t w2 = 4; w2 >= 1; w2 >>= 1) {
+    auto waves_at = [&](uint32_t w2) {
         uint32_t blocks = (uint32_t)(g.lds_per_cu / ((size_t)(P.sh_heap + w2 * P.wave_words) * 4));
-        uint32_t wv = blocks * w2 < 16 ? blocks * w2 : 16;   // VGPR budget admits 4 waves per SIMD
-        if (wv > waves_cu) { waves_cu = wv; W = w2; }
-    }
+        return blocks * w2 < 16 ? blocks * w2 : 16u;         // VGPR budget admits 4 waves per SIMD
+    };
+    const uint32_t best = std::max(waves_at(1), std::max(waves_at(2), waves_at(4)));
+    uint32_t W = 1;
+    for (uint32_t w2 = 4; w2 >= 1; w2 >>= 1)
+        if (waves_at(w2) + 1 >= best && waves_at(w2) > 0) { W = w2; break; }   // the largest W within one wave of the best
     if (want < W) W = want > 1 ? 2 : 1;
     P.waves_per_block = W;
     G->lds_bytes = (P.sh_heap + W * P.wave_words) * 4;

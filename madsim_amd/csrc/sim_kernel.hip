@@ -132,7 +132,9 @@ struct Ctx {
 
 template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { return K::LWS >= 0 ? (uint32_t)K::LWS : c.lws; }
 #define RW(i) SMEM[c.ready0 + ((i) << LWSH<K>(c))]
-#define HW(p) SMEM[c.hand0 + ((p) << LWSH<K>(c))]
+// JoinHandle state of prog p.  Workloads with the extended ops keep a handle plane; the others park the word in the
+// otherwise unused unit1.y of task slot p (max_tasks >= n_progs there, geometry.h) and save the plane's LDS.
+#define HW(p) (*hw_ref<K>(c, (p)))
 #define NODEW(i) SMEM[c.node0 + ((i) << LWSH<K>(c))]
 #define CLOGW(i) SMEM[c.clog0 + ((i) << LWSH<K>(c))]
 #define PAUSEW(i) SMEM[c.pause0 + ((i) << LWSH<K>(c))]   /* [0] = length, [1..] = paused Runnables in pop order */
@@ -145,21 +147,44 @@ template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { retu
 #define SW(c_, s_, f_) SMEM[(c_).sock0 + (((s_) * (c_).P.sock_words + (f_)) << LWSH<K>(c_))]
 #define TU(c_, slot_, u_) LDS128((c_).task0 + (((slot_) * (c_).P.task_units + (u_)) << LWSH<K>(c_)))
 #define TWORD(c_, slot_, u_, k_) SMEM[((c_).task0 + (((slot_) * (c_).P.task_units + (u_)) << LWSH<K>(c_))) * 4 + (k_)]
+template <class K> __device__ __forceinline__ uint32_t* hw_ref(const Ctx& c, uint32_t p) {
+    return K::LIFE ? &SMEM[c.hand0 + (p << LWSH<K>(c))] : &TWORD(c, p, 1, 1);
+}
+// unit1 write-back: x and the deadline only when unit1.y is a handle word (see HW)
+template <class K> __device__ __forceinline__ void tu1_store(const Ctx& c, uint32_t slot, const uint4& u1) {
+    if (K::LIFE) { TU(c, slot, 1) = u1; return; }
+    TWORD(c, slot, 1, 0) = u1.x;
+    LDS64(((c.task0 + ((slot * c.P.task_units + 1) << LWSH<K>(c))) << 1) + 1) = make_uint2(u1.z, u1.w);
+}
 __device__ __forceinline__ uint4 INSN(const Ctx& c, uint32_t pc) { return LDS128(c.insn0 + pc); }
 __device__ __forceinline__ uint32_t PROGW(const Ctx& c, uint32_t p) { return SMEM[c.prog0 + p]; }
 __device__ __forceinline__ uint32_t SOCKW(const Ctx& c, uint32_t s) { return SMEM[c.sockt0 + s]; }
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+// 64-bit rotate as two v_alignbit_b32 (the compiler's shift/or expansion takes 3-4 VALU ops): K is a compile-time constant.
+template <int K_>
+__device__ __forceinline__ uint64_t rotl64(uint64_t x) {
+#ifdef MADSIM_EMU
+    return (x << K_) | (x >> (64 - K_));
+#else
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (K_ >= 32) { uint32_t t = lo; lo = hi; hi = t; }            // rotate by 32 = swap halves
+    constexpr int k = K_ & 31;
+    if (k == 0) return ((uint64_t)hi << 32) | lo;
+    uint32_t nhi = __builtin_amdgcn_alignbit(hi, lo, 32 - k);      // ({hi,lo} >> (32-k))[31:0] = hi<<k | lo>>(32-k)
+    uint32_t nlo = __builtin_amdgcn_alignbit(lo, hi, 32 - k);
+    return ((uint64_t)nhi << 32) | nlo;
+#endif
+}
 __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // ---- GlobalRng ---------------------------------------------------------------------------------
 // Xoshiro256PlusPlus::next_u64 [DEP rand_xoshiro 0.6]
 __device__ __forceinline__ uint64_t rng_next(Lane& L) {
-    uint64_t r = rotl64(L.s0 + L.s3, 23) + L.s0;
+    uint64_t r = rotl64<23>(L.s0 + L.s3) + L.s0;
     uint64_t t = L.s1 << 17;
     L.s2 ^= L.s0; L.s3 ^= L.s1; L.s1 ^= L.s2; L.s0 ^= L.s3;
     L.s2 ^= t;
-    L.s3 = rotl64(L.s3, 45);
+    L.s3 = rotl64<45>(L.s3);
     L.rng_calls++;
     return r;
 }
@@ -170,7 +195,7 @@ __device__ __forceinline__ void rng_log(const Ctx& c, Lane& L) {
 #ifdef EXP_NOLOG
     return;
 #endif
-    uint64_t r = rotl64(L.s0 + L.s3, 23) + L.s0;   // what the clone's next_u64 would return
+    uint64_t r = rotl64<23>(L.s0 + L.s3) + L.s0;   // what the clone's next_u64 would return
     uint32_t v = (uint32_t)(r >> 32);
     uint32_t f = (uint32_t)L.clock ^ (uint32_t)(L.clock >> 32);
     f ^= f >> 16; f ^= f >> 8;
@@ -432,7 +457,7 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
     uint32_t seq = 0;
     if (K::LIFE) { seq = NODEW(3); NODEW(3) = seq + 1; }      // spawn order matters only to NodeInfo::kill
     TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
-    TU(c, slot, 1) = make_uint4(0xffu << 8, (seq & 0xffffff) | (info_gen << 24), 0, 0);   // rxseq 0, no awaiter; spawn order
+    tu1_store<K>(c, slot, make_uint4(0xffu << 8, (seq & 0xffffff) | (info_gen << 24), 0, 0));   // rxseq 0, no awaiter; spawn order
     if (K::LIFE && c.P.uses_chan) TU(c, slot, 3) = make_uint4(0xff, 0, 0, 0);                // no connection held
     ready_push<K>(c, L, slot);
     if (record) HW(prog) = H_RUNNING | (slot << 8) | (gen << 16);
@@ -923,7 +948,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_DONE:
                 u0.y = pc | (sub << 16) | (from << 24);
                 TU(c, slot, 0) = u0;
-                if (u1_dirty) { TU(c, slot, 1) = u1; u1_dirty = false; }
+                if (u1_dirty) { tu1_store<K>(c, slot, u1); u1_dirty = false; }
                 // an init task is `async { future.await; h.exit() }` (runtime/mod.rs:362-370): Spawner::exit =
                 // NodeInfo::kill on the info it was spawned with (task/mod.rs:657-661), before the future drops
                 if (K::LIFE && ((PROGW(c, u0.x >> 24) >> 8) & MADSIM_PROG_INIT) && (u1.y >> 24) == NODE_INFO_GEN(node)) {
@@ -1087,7 +1112,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 pc++;
                 u0.y = pc | (sub << 16) | (from << 24);
                 TU(c, slot, 0) = u0;
-                if (u1_dirty) { TU(c, slot, 1) = u1; u1_dirty = false; }
+                if (u1_dirty) { tu1_store<K>(c, slot, u1); u1_dirty = false; }
                 timer_expire<K>(c, L, L.clock);
                 u0 = TU(c, slot, 0); u1 = TU(c, slot, 1);
                 from = u0.y >> 24;
@@ -1144,7 +1169,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     PROBE(9);
     if (st != ST_FINISHED) {
         u0.y = pc | (sub << 16) | (from << 24);
-        if (u1_dirty) TU(c, slot, 1) = u1;
+        if (u1_dirty) tu1_store<K>(c, slot, u1);
     }
     return st == ST_PANIC;
 }
@@ -1154,7 +1179,7 @@ template <class K>
 __device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     const KParams& P = c.P;
     for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;          // plane 0 is the ready queue: RW spans all planes
-    for (uint32_t t = 0; t < P.max_tasks; t++) TWORD(c, t, 0, 0) = 0;
+    for (uint32_t t = 0; t < P.max_tasks; t++) { TWORD(c, t, 0, 0) = 0; if (!K::LIFE) TWORD(c, t, 1, 1) = 0; }
     // GlobalRng::new_with_seed -> Xoshiro256PlusPlus::seed_from_u64: SplitMix64 [DEP A.1]
     uint64_t x = seed, z;
 #define SPLITMIX(dst) x += 0x9e3779b97f4a7c15ull; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; dst = z ^ (z >> 31)
@@ -1375,6 +1400,7 @@ __global__ void keyflip_kernel(unsigned long long* acc) { acc[0] ^= 0x8000000000
     X(false, true, -1, true)            \
     X(false, false, 6, false)           \
     X(false, false, 6, false, true)     \
+    X(false, true, 6, false, true)      \
     X(false, true, 6, false)            \
     X(false, false, 6, true)            \
     X(false, true, 6, true)
@@ -1389,6 +1415,7 @@ extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, u
     else if (P->lw_shift != 6) LAUNCH(false, true, -1, true);
     else if (!spill && !life && P->rq_in_reg) LAUNCH(false, false, 6, false, true);
     else if (!spill && !life) LAUNCH(false, false, 6, false);
+    else if (spill && !life && P->rq_in_reg) LAUNCH(false, true, 6, false, true);
     else if (spill && !life) LAUNCH(false, true, 6, false);
     else if (!spill && life) LAUNCH(false, false, 6, true);
     else LAUNCH(false, true, 6, true);

@@ -76,6 +76,7 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
             else if (P.lw_shift != 6) sim_kernel<Variant<false, true, -1, true>>(P);
             else if (!spill && !life && P.rq_in_reg) sim_kernel<Variant<false, false, 6, false, true>>(P);
             else if (!spill && !life) sim_kernel<Variant<false, false, 6, false>>(P);
+            else if (spill && !life && P.rq_in_reg) sim_kernel<Variant<false, true, 6, false, true>>(P);
             else if (spill && !life) sim_kernel<Variant<false, true, 6, false>>(P);
             else if (!spill && life) sim_kernel<Variant<false, false, 6, true>>(P);
             else sim_kernel<Variant<false, true, 6, true>>(P);

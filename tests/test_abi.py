@@ -49,7 +49,7 @@ def test_c_twin_of_pingpong_matches_python_assembler():
 
 def test_geometry_and_validation_need_no_gpu():
     g = runtime.geometry(workload.pingpong(4, 64))
-    assert g.block_threads == 64 and g.lanes_per_wave == 64 and g.lds_bytes_per_seed > 0
+    assert g.block_threads in (64, 128, 256) and g.lanes_per_wave == 64 and g.lds_bytes_per_seed > 0
     lim = A.Limits(); lim.lanes_per_wave = 7
     with pytest.raises(runtime.MadsimHipError, match="lanes_per_wave"):
         runtime.geometry(workload.pingpong(4, 64), lim)
