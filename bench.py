@@ -153,7 +153,7 @@ def main():
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
         g = runtime.geometry(w, lim)
         b = lambda x: "true" if x else "false"
-        kname = ("sim_kernel<Variant<false,true,-1,true,false>>" if g.variant & 8 else
+        kname = (f"sim_kernel<Variant<false,true,{g.lanes_per_wave.bit_length() - 1},true,false>>" if g.variant & 8 else
                  f"sim_kernel<Variant<false,{b(g.variant & 1)},6,{b(g.variant & 2)},{b(g.variant & 4)}>>")
         # HBM traffic per launch from the rocprofv3 PMC passes of this same command (tools/prof_pmc.sh ->
         # profiles/r1_traffic.json): FETCH_SIZE (x2, the gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "sim_kernel.h"
@@ -27,12 +28,14 @@ struct State {
     int num_cus = 0;
     size_t lds_per_cu = 160 * 1024;
     size_t max_lds_block = 64 * 1024;
-    // cached device copies of the workload tables
-    uint64_t wl_hash = 0;
-    uint4* d_insns = nullptr; uint32_t* d_progs = nullptr; uint32_t* d_socks = nullptr; uint64_t* d_durs = nullptr;
-    size_t cap_insns = 0, cap_progs = 0, cap_socks = 0, cap_durs = 0;   // capacities in 32-bit (durs: 64-bit) words
-    // scratch
-    uint4* d_spill = nullptr; size_t spill_bytes = 0;
+    // Device copies of workload tables, keyed by content hash.  Entries are immutable once uploaded, so launches that
+    // are still in flight on other streams keep valid pointers when a different workload comes along.
+    struct Tables { uint64_t hash = 0; uint4* insns = nullptr; uint32_t* progs = nullptr; uint32_t* socks = nullptr; uint64_t* durs = nullptr; };
+    std::vector<Tables> tables;
+    // timer-heap spill regions, one per stream: launches on one stream run in order, launches on different streams
+    // may overlap and must not share scratch
+    struct Spill { uint4* p = nullptr; size_t bytes = 0; };
+    std::unordered_map<hipStream_t, Spill> spill;
     unsigned long long* d_acc = nullptr;      // 4 x u64 summary accumulators
     madsim_result_t* d_out = nullptr; size_t out_cap = 0;
     uint8_t* d_tlog = nullptr; size_t tlog_cap = 0; uint64_t* d_tlen = nullptr;
@@ -64,6 +67,14 @@ uint64_t fnv(const void* p, size_t n, uint64_t h) {
 
 using madsim_geo::Geo;
 
+void free_tables(State::Tables& t) {
+    if (t.insns) (void)hipFree(t.insns);
+    if (t.progs) (void)hipFree(t.progs);
+    if (t.socks) (void)hipFree(t.socks);
+    if (t.durs) (void)hipFree(t.durs);
+    t = State::Tables();
+}
+
 int upload_workload(const madsim_workload_t* w, KParams& P) {
     madsim_geo::DeviceTables T;
     int rc = madsim_geo::build_tables(w, &T, &g_err);
@@ -72,29 +83,44 @@ int upload_workload(const madsim_workload_t* w, KParams& P) {
     h = fnv(T.progs.data(), w->n_progs * 4, h);
     h = fnv(T.socks.data(), w->n_socks * 4, h);
     h = fnv(T.durs.data(), T.durs.size() * 8, h);
-    if (h != g.wl_hash || !g.d_insns) {
-        if (g.cap_insns < T.insns.size()) { if (g.d_insns) (void)hipFree(g.d_insns); HIP_TRY(hipMalloc(&g.d_insns, T.insns.size() * 4)); g.cap_insns = T.insns.size(); }
-        if (g.cap_progs < T.progs.size()) { if (g.d_progs) (void)hipFree(g.d_progs); HIP_TRY(hipMalloc(&g.d_progs, T.progs.size() * 4)); g.cap_progs = T.progs.size(); }
-        if (g.cap_socks < T.socks.size()) { if (g.d_socks) (void)hipFree(g.d_socks); HIP_TRY(hipMalloc(&g.d_socks, T.socks.size() * 4)); g.cap_socks = T.socks.size(); }
-        if (g.cap_durs < T.durs.size()) { if (g.d_durs) (void)hipFree(g.d_durs); HIP_TRY(hipMalloc(&g.d_durs, T.durs.size() * 8)); g.cap_durs = T.durs.size(); }
-        HIP_TRY(hipMemcpy(g.d_insns, T.insns.data(), T.insns.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(g.d_progs, T.progs.data(), T.progs.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(g.d_socks, T.socks.data(), T.socks.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(g.d_durs, T.durs.data(), T.durs.size() * 8, hipMemcpyHostToDevice));
-        g.wl_hash = h;
+    h = fnv(&w->n_insns, 4, h);
+    const State::Tables* hit = nullptr;
+    for (auto& t : g.tables) if (t.hash == h) hit = &t;
+    if (!hit) {
+        if (g.tables.size() >= 16) {                       // bounded cache: drop everything once nothing is in flight
+            HIP_TRY(hipDeviceSynchronize());
+            for (auto& t : g.tables) free_tables(t);
+            g.tables.clear();
+        }
+        State::Tables t;
+        t.hash = h;
+        HIP_TRY(hipMalloc(&t.insns, T.insns.size() * 4 + 16));
+        HIP_TRY(hipMalloc(&t.progs, T.progs.size() * 4 + 16));
+        HIP_TRY(hipMalloc(&t.socks, T.socks.size() * 4 + 16));
+        HIP_TRY(hipMalloc(&t.durs, T.durs.size() * 8 + 16));
+        HIP_TRY(hipMemcpy(t.insns, T.insns.data(), T.insns.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t.progs, T.progs.data(), T.progs.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t.socks, T.socks.data(), T.socks.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t.durs, T.durs.data(), T.durs.size() * 8, hipMemcpyHostToDevice));
+        g.tables.push_back(t);
+        hit = &g.tables.back();
     }
-    P.insns = g.d_insns; P.progs = g.d_progs; P.socks = g.d_socks; P.dur_table = g.d_durs;
+    P.insns = hit->insns; P.progs = hit->progs; P.socks = hit->socks; P.dur_table = hit->durs;
     return 0;
 }
 
-int ensure_spill(const KParams& P) {
+int ensure_spill(KParams& P, hipStream_t stream) {
+    P.spill = nullptr;
+    if (!P.heap_spill) return 0;
     size_t need = (size_t)P.heap_spill * P.total_lanes * sizeof(uint4);
-    if (need > g.spill_bytes) {
-        if (g.d_spill) (void)hipFree(g.d_spill);
-        g.d_spill = nullptr; g.spill_bytes = 0;
-        HIP_TRY(hipMalloc(&g.d_spill, need));
-        g.spill_bytes = need;
+    State::Spill& sp = g.spill[stream];
+    if (need > sp.bytes) {
+        if (sp.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(sp.p); }
+        sp.p = nullptr; sp.bytes = 0;
+        HIP_TRY(hipMalloc(&sp.p, need));
+        sp.bytes = need;
     }
+    P.spill = sp.p;
     return 0;
 }
 
@@ -112,8 +138,7 @@ int run_device(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t 
     Geo G;
     if ((rc = madsim_geo::make_geometry(dev(), w, cfg, lim, count, &G, &g_err))) return rc;
     if ((rc = upload_workload(w, G.P))) return rc;
-    if ((rc = ensure_spill(G.P))) return rc;
-    G.P.spill = G.P.heap_spill ? g.d_spill : nullptr;
+    if ((rc = ensure_spill(G.P, stream))) return rc;
     G.P.seed0 = seed0; G.P.count = count; G.P.out = d_out; G.P.prof = g.d_prof;
     if (G.lds_bytes > g.lds_attr) {
         int e = madsim_k_set_max_lds((uint32_t)g.lds_per_cu);
@@ -189,11 +214,8 @@ int madsim_hip_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.inited) return 0;
     (void)hipDeviceSynchronize();
-    if (g.d_insns) (void)hipFree(g.d_insns);
-    if (g.d_progs) (void)hipFree(g.d_progs);
-    if (g.d_socks) (void)hipFree(g.d_socks);
-    if (g.d_durs) (void)hipFree(g.d_durs);
-    if (g.d_spill) (void)hipFree(g.d_spill);
+    for (auto& t : g.tables) free_tables(t);
+    for (auto& kv : g.spill) if (kv.second.p) (void)hipFree(kv.second.p);
     if (g.d_acc) (void)hipFree(g.d_acc);
     if (g.d_out) (void)hipFree(g.d_out);
     if (g.d_tlog) (void)hipFree(g.d_tlog);
@@ -278,7 +300,7 @@ int64_t madsim_hip_trace_seed(const madsim_workload_t* w, const madsim_config_t*
     Geo G;
     if ((rc = madsim_geo::make_geometry(dev(), w, cfg, lim, 1, &G, &g_err, true))) return rc;
     if ((rc = upload_workload(w, G.P))) return rc;
-    if ((rc = ensure_spill(G.P))) return rc;
+    if ((rc = ensure_spill(G.P, nullptr))) return rc;
     if (cap > g.tlog_cap) {
         if (g.d_tlog) (void)hipFree(g.d_tlog);
         g.d_tlog = nullptr; g.tlog_cap = 0;
@@ -286,7 +308,6 @@ int64_t madsim_hip_trace_seed(const madsim_workload_t* w, const madsim_config_t*
         g.tlog_cap = cap;
     }
     if (1 > g.out_cap) { HIP_TRY(hipMalloc(&g.d_out, 64 * sizeof(madsim_result_t))); g.out_cap = 64; }
-    G.P.spill = G.P.heap_spill ? g.d_spill : nullptr;
     G.P.seed0 = seed; G.P.count = 1; G.P.out = g.d_out;
     G.P.trace_log = cap ? g.d_tlog : nullptr; G.P.trace_cap = cap; G.P.trace_len = g.d_tlen;
     if (G.lds_bytes > g.lds_attr) {

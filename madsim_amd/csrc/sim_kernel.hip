@@ -1393,8 +1393,9 @@ __global__ void keyflip_kernel(unsigned long long* acc) { acc[0] ^= 0x8000000000
 }  // namespace madsim_k
 
 #ifndef MADSIM_EMU
-// Kernel variants: the trace build, a fully generic build (runtime lane stride), and for full 64-lane waves
-// one build per (heap spill, extended ops) combination so that workloads only pay for what they use.
+// Kernel variants: the trace build, a fully generic build (runtime lane stride), for full 64-lane waves one build
+// per (heap spill, extended ops) combination so that workloads only pay for what they use, and the full-featured
+// build again for each sub-wave lane stride (32/16/8 seed lanes per wave).
 #define MADSIM_FOR_EACH_VARIANT(X)      \
     X(true, true, -1, true)             \
     X(false, true, -1, true)            \
@@ -1403,7 +1404,10 @@ __global__ void keyflip_kernel(unsigned long long* acc) { acc[0] ^= 0x8000000000
     X(false, true, 6, false, true)      \
     X(false, true, 6, false)            \
     X(false, false, 6, true)            \
-    X(false, true, 6, true)
+    X(false, true, 6, true)             \
+    X(false, true, 5, true)             \
+    X(false, true, 4, true)             \
+    X(false, true, 3, true)
 
 extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace) {
     using namespace madsim_k;
@@ -1412,6 +1416,11 @@ extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, u
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(...) hipLaunchKernelGGL((sim_kernel<Variant<__VA_ARGS__>>), dim3(grid), dim3(64 * P->waves_per_block), lds_bytes, st, *P)
     if (trace) LAUNCH(true, true, -1, true);
+#ifndef EXP_NO_LWS_VARIANTS
+    else if (P->lw_shift == 5) LAUNCH(false, true, 5, true);     // sub-wave occupancy (large per-seed state): the lane
+    else if (P->lw_shift == 4) LAUNCH(false, true, 4, true);     // stride stays a compile-time shift
+    else if (P->lw_shift == 3) LAUNCH(false, true, 3, true);
+#endif
     else if (P->lw_shift != 6) LAUNCH(false, true, -1, true);
     else if (!spill && !life && P->rq_in_reg) LAUNCH(false, false, 6, false, true);
     else if (!spill && !life) LAUNCH(false, false, 6, false);

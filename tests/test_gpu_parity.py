@@ -293,3 +293,37 @@ def test_capacity_verdicts_are_retried_with_larger_limits(hip):
     got, summ = runtime.run_batch_auto(w, 0, 256, None, tight, max_rounds=6)
     want, osumm = oracle.run_batch(w, 0, 256)
     assert (got == want).all() and summ.n_failed == osumm.n_failed == 0
+
+
+def test_concurrent_streams_do_not_share_scratch(hip):
+    """Launches in flight on different HIP streams: each has its own heap-spill region and keeps its own workload
+    tables (two workloads alternate), so overlapping batches stay bit-exact."""
+    import torch
+    wa, la = W.timer_storm(), W.timer_storm_limits(4)          # most of the 24-entry heap spills to HBM
+    wb = W.pingpong(4, 16)
+    n = 16384
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    jobs = []
+    for k in range(6):
+        w, lim = (wa, la) if k % 2 == 0 else (wb, None)
+        buf = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+        rep = torch.zeros(4, dtype=torch.int64, device="cuda")
+        st = streams[k % 3]
+        with torch.cuda.stream(st):
+            hip.run_batch_async(w, 7000 * k, n, buf.data_ptr(), rep.data_ptr(), st.cuda_stream, None, lim)
+        jobs.append((w, lim, 7000 * k, buf))
+    torch.cuda.synchronize()
+    for w, lim, seed0, buf in jobs:
+        got = np.frombuffer(buf.cpu().numpy().tobytes(), dtype=A.RESULT_DTYPE)
+        idx = np.arange(0, n, 37)
+        want = np.concatenate([oracle.run_batch(w, seed0 + int(i), 1, None, lim)[0] for i in idx])
+        assert (got[idx] == want).all()
+        assert (got["verdict"] == A.PASS).all()
+
+
+def test_register_ready_queue_with_heap_spill(hip):
+    """Variant<SPILL, RQ>: 2 LDS heap slots + HBM spill under the register-resident ready queue."""
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots, lim.mbox_regs, lim.mbox_msgs = 2, 6, 1, A.LIMIT_NONE
+    w = W.pingpong(4, 32)
+    assert hip.geometry(w, lim).variant == 5
+    _cmp(hip, w, 424242, 4096, None, lim)
