@@ -96,6 +96,7 @@ def main():
     d_out = d_outs[0]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
     stream = streams[0].cuda_stream
+    report_stream = torch.cuda.Stream() if world > 1 else None
 
     # Fully asynchronous steps: the simulation kernel, the summary reduction and (N > 1) the RCCL all-reduce of the
     # 32-byte report are all queued on the stream; the host never waits inside the timed region.
@@ -109,7 +110,14 @@ def main():
             with torch.cuda.stream(streams[si]):
                 runtime.run_batch_async(w, seed0 + k * total, count, d_outs[si].data_ptr(), ring[k].data_ptr(),
                                         streams[si].cuda_stream, None, lim, timing_slot=(k % 64) if timed else -1)
-                mdist.reduce_report_device(ring[k])
+            if world > 1:
+                # the 32-byte RCCL exchange rides its own stream behind an event: the simulation streams never wait
+                # for a collective kernel to find room on a chip whose LDS the simulation keeps full
+                ev = torch.cuda.Event()
+                ev.record(streams[si])
+                report_stream.wait_event(ev)
+                with torch.cuda.stream(report_stream):
+                    mdist.reduce_report_device(ring[k])
         else:   # functional-test hook (gloo on a 1-GPU box): host-side report
             sm = runtime.run_batch_device(w, seed0 + k * total, count, d_out.data_ptr(), stream, None, lim)
             rep = mdist.reduce_report(sm.first_failing_seed, sm.n_failed, sm.total_steps, sm.total_clock_ns, cdev)
