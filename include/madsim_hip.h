@@ -108,8 +108,26 @@ enum madsim_op {
     MS_OP_CRECV = 49,      /* val = rx.recv().await: in-order delivery, 1 ms -> 10 s backoff while the link
                               is down (net/mod.rs:385-402); MADSIM_VAL_RESET when the channel closed */
     MS_OP_CCLOSE = 50,     /* drop(tx); drop(rx)                                                     */
+    /* -- typed RPC over the datagram Endpoint (net/rpc.rs:96-180) -- */
+    MS_OP_RPC_CALL = 51,   /* a=ep, b=(req_tag<<8)|dst addr, imm=(timeout_ms<<8)|request code:
+                              val = ep.call(dst, req).await (rpc.rs:108-131): rsp_tag = random::<u64>() (one
+                              RngCore draw), send_to_raw(dst, R::ID, (rsp_tag, req)), recv_from_raw(rsp_tag),
+                              assert_eq!(from, dst).  timeout_ms != 0: ep.call_timeout(dst, req, d) (rpc.rs:96-105),
+                              val := MADSIM_VAL_TIMEOUT on Err(TimedOut).  req_tag must be a typed tag (>= 0x80).   */
+    MS_OP_RPC_REPLY = 52,  /* a=ep, imm=response code: net.send_to_raw(from, rsp_tag, rsp) of the request this
+                              task received (or inherited at spawn): the tail of add_rpc_handler (rpc.rs:170-176) */
     MS_OP__COUNT
 };
+
+/* Typed RPC (net/rpc.rs): request tags R::ID are the tag values 0x80..0xFD; a message received on one carries the
+ * caller's response tag besides its 8-bit request code (val), and MS_OP_SPAWN with MADSIM_SPAWN_MOVE_REQUEST hands
+ * (val, from, response tag) to the per-request task like `spawn(async move { .. })` in rpc.rs:170.  Response tags
+ * are u64 draws in the reference; here a response is matched to the caller's pending receive itself, which is
+ * what an unguessable tag means.  Request and response codes are 8 bits in this build. */
+#define MADSIM_TAG_RPC_FIRST 0x80u
+#define MADSIM_TAG_RPC_LAST  0xFDu
+#define MADSIM_SPAWN_MOVE_CONN    2u   /* MS_OP_SPAWN b: the (tx, rx) pair moves into the child               */
+#define MADSIM_SPAWN_MOVE_REQUEST 4u   /* MS_OP_SPAWN b: the received request moves into the child             */
 
 #define MADSIM_VAL_TIMEOUT 0xFFFFFFFFu
 #define MADSIM_VAL_REFUSED 0xFFFFFFFEu

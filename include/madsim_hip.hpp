@@ -105,7 +105,14 @@ class Task {
     Task& chan_send(uint32_t payload) { return emit(MS_OP_CSEND, 0, 0, payload); }
     Task& chan_recv() { return emit(MS_OP_CRECV); }
     Task& chan_close() { return emit(MS_OP_CCLOSE); }
-    Task& spawn_move_conn(const Task& t) { return emit(MS_OP_SPAWN, (uint8_t)t.index_, 2); }
+    Task& spawn_move_conn(const Task& t) { return emit(MS_OP_SPAWN, (uint8_t)t.index_, MADSIM_SPAWN_MOVE_CONN); }
+    // typed RPC (Endpoint::call / call_timeout / add_rpc_handler, net/rpc.rs:96-180): req_id = R::ID - 0x80, 8-bit codes
+    Task& rpc_call(int ep, int dst, uint8_t req_id, uint8_t code, std::chrono::milliseconds timeout = std::chrono::milliseconds(0)) {
+        return emit(MS_OP_RPC_CALL, (uint8_t)ep, (uint16_t)(((MADSIM_TAG_RPC_FIRST + req_id) << 8) | dst), ((uint32_t)timeout.count() << 8) | code);
+    }
+    Task& rpc_recv(int ep, uint8_t req_id) { return emit(MS_OP_RECV, (uint8_t)ep, (uint16_t)((MADSIM_TAG_RPC_FIRST + req_id) << 8)); }
+    Task& rpc_reply(int ep, uint8_t code) { return emit(MS_OP_RPC_REPLY, (uint8_t)ep, 0, code); }
+    Task& spawn_move_request(const Task& t) { return emit(MS_OP_SPAWN, (uint8_t)t.index_, MADSIM_SPAWN_MOVE_REQUEST); }
     // supervisor (Handle::kill / restart / pause / resume / is_exit, JoinHandle::abort)
     Task& kill(int node) { return emit(MS_OP_KILL, (uint8_t)node); }
     Task& restart(int node) { return emit(MS_OP_RESTART, (uint8_t)node); }

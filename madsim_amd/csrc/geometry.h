@@ -68,9 +68,20 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
         case MS_OP_DJNZ: case MS_OP_JMP:
             if (in.b >= w->n_insns) return fail(err, MADSIM_E_WORKLOAD, "jump target out of range"); break;
         case MS_OP_BIND: case MS_OP_REPLY: case MS_OP_RECV: case MS_OP_CLOSE: case MS_OP_RECV_TIMEOUT: case MS_OP_ACCEPT:
-            if (in.a >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range"); break;
+            if (in.a >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range");
+            if ((in.op == MS_OP_REPLY || in.op == MS_OP_RECV || in.op == MS_OP_RECV_TIMEOUT) && (in.b >> 8) > MADSIM_TAG_RPC_LAST)
+                return fail(err, MADSIM_E_WORKLOAD, "tags 0xFE and 0xFF are reserved");
+            break;
         case MS_OP_SEND: case MS_OP_CONNECT:
-            if (in.a >= w->n_socks || (uint32_t)(in.b & 0xff) >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range"); break;
+            if (in.a >= w->n_socks || (uint32_t)(in.b & 0xff) >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range");
+            if (in.op == MS_OP_SEND && (in.b >> 8) > MADSIM_TAG_RPC_LAST) return fail(err, MADSIM_E_WORKLOAD, "tags 0xFE and 0xFF are reserved");
+            break;
+        case MS_OP_RPC_CALL:
+            if (in.a >= w->n_socks || (uint32_t)(in.b & 0xff) >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range");
+            if ((uint32_t)(in.b >> 8) < MADSIM_TAG_RPC_FIRST || (uint32_t)(in.b >> 8) > MADSIM_TAG_RPC_LAST) return fail(err, MADSIM_E_WORKLOAD, "rpc_call needs a typed request tag (0x80..0xFD)");
+            break;
+        case MS_OP_RPC_REPLY:
+            if (in.a >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range"); break;
         case MS_OP_BUILD: case MS_OP_KILL: case MS_OP_RESTART: case MS_OP_PAUSE: case MS_OP_RESUME:
         case MS_OP_CLOG_NODE: case MS_OP_UNCLOG_NODE: case MS_OP_ASSERT_EXIT:
             if (in.a > w->n_nodes) return fail(err, MADSIM_E_WORKLOAD, "node operand out of range"); break;
@@ -101,7 +112,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) restarts |= (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) != 0;
     // request-per-connection servers spawn a handler per accept: leave room for a few concurrent ones
     bool chan = uses_op(w, MS_OP_CONNECT) || uses_op(w, MS_OP_ACCEPT);
-    P.max_tasks = L.max_tasks ? L.max_tasks : w->n_progs + (restarts ? w->n_progs : 0) + (chan ? 8 : 0);
+    P.uses_rpc = uses_op(w, MS_OP_RPC_CALL) || uses_op(w, MS_OP_RPC_REPLY);   // likewise: one task per request in flight
+    P.max_tasks = L.max_tasks ? L.max_tasks : w->n_progs + (restarts ? w->n_progs : 0) + (chan || P.uses_rpc ? 8 : 0);
     if (P.max_tasks > 254) P.max_tasks = 254;
     if (P.max_tasks > 254) return fail(err, MADSIM_E_LIMITS, "max_tasks must be <= 254");
     P.mbox_regs = L.mbox_regs ? L.mbox_regs : 2;
@@ -109,9 +121,10 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     if (P.mbox_regs > 255 || P.mbox_msgs > 255) return fail(err, MADSIM_E_LIMITS, "mailbox capacities must be <= 255");
     P.heap_lds = L.heap_lds_slots ? L.heap_lds_slots : 8;
     P.heap_spill = (L.heap_lds_slots || L.heap_spill_slots) ? L.heap_spill_slots : 56;
-    bool t0 = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_RECV_TIMEOUT);
+    bool t0 = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_RECV_TIMEOUT) || P.uses_rpc;
     P.uses_chan = uses_op(w, MS_OP_CONNECT) || uses_op(w, MS_OP_ACCEPT) || uses_op(w, MS_OP_CSEND) || uses_op(w, MS_OP_CRECV);
     P.task_units = P.uses_chan ? 4 : t0 ? 3 : 2;
+    if (P.uses_rpc) { P.rpc_unit = P.task_units; P.task_units++; }   // {rsp_tag in hand, rsp_tag staged with the oneshot value}
     // per socket: header, owner, registrations, queued messages (+ accept queue, parked acceptor)
     P.sock_words = 2 + P.mbox_regs + 2 * P.mbox_msgs + (P.uses_chan ? 2 : 0);
     P.max_conns = L.max_conns ? L.max_conns : 4;
@@ -130,7 +143,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         if (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) P.restart_nodes |= 1u << i;
     P.has_restart_on_panic = P.restart_nodes != 0;
     P.lifecycle = P.has_restart_on_panic || uses_op(w, MS_OP_KILL) || uses_op(w, MS_OP_RESTART) || uses_op(w, MS_OP_PAUSE) ||
-                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND) || P.uses_chan ||
+                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND) || P.uses_chan || P.uses_rpc ||
                   uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_ADVANCE);
     for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.lifecycle = 1;
     // The generic kernel variants (trace, lanes_per_wave != 64) are compiled with the extended ops, so they need the

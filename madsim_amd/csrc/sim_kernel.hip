@@ -389,11 +389,15 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     uint32_t h = SW(c, s, 0);
     if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;     // that Endpoint object is gone
     uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
+    // Typed RPC (net/rpc.rs): a response (tag 0xff) is addressed to one pending receive — the word of its registration,
+    // tag | slot | rxseq | gen, rides in the payload's upper 24 bits — where the reference matches a random u64 tag.
+    const bool rpc = K::LIFE && c.P.uses_rpc;
+    const bool rsp = rpc && tag == 0xff;
     uint32_t i = 0;
     while (i < nreg) {
         REG(24);
         uint32_t r = SW(c, s, 2 + i);
-        if ((r & 0xff) == tag) {
+        if ((r & 0xff) == tag && (!rsp || (r >> 8) == (val >> 8))) {
             nreg--;
             SW(c, s, 2 + i) = SW(c, s, 2 + nreg);          // swap_remove
             uint32_t slot = (r >> 8) & 0xff, rxseq = (r >> 16) & 0xff, g8 = r >> 24;
@@ -405,6 +409,10 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
                 u0.x |= TF_INBOX | TF_SCHED;
                 u0.y = (u0.y & 0x00ffffffu) | (from << 24);
                 u0.w = val;
+                if (rpc && tag >= MADSIM_TAG_RPC_FIRST) {                  // 8-bit code; a request also carries its rsp_tag
+                    u0.w = val & 0xff;
+                    if (!rsp) TWORD(c, slot, c.P.rpc_unit, 1) = val >> 8;  // staged with the oneshot value
+                }
                 TU(c, slot, 0) = u0;
                 SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);
                 if (!sched && !(u0.x & TF_RUN)) ready_push<K>(c, L, slot);
@@ -415,6 +423,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
         }
     }
     if (nmsg >= c.P.mbox_msgs) { L.ovf = 1; return; }
+    if (rsp) tag = 0xfe;                                   // nobody holds that rsp_tag any more: it can never be received
     SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);
     SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg + 1) = val;
     nmsg++;
@@ -459,6 +468,7 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
     TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
     tu1_store<K>(c, slot, make_uint4(0xffu << 8, (seq & 0xffffff) | (info_gen << 24), 0, 0));   // rxseq 0, no awaiter; spawn order
     if (K::LIFE && c.P.uses_chan) TU(c, slot, 3) = make_uint4(0xff, 0, 0, 0);                // no connection held
+    if (K::LIFE && c.P.uses_rpc) TU(c, slot, c.P.rpc_unit) = make_uint4(0, 0, 0, 0);         // no request in hand
     ready_push<K>(c, L, slot);
     if (record) HW(prog) = H_RUNNING | (slot << 8) | (gen << 16);
     return slot;
@@ -658,6 +668,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (sub == 1 && (u0.x & TF_INBOX)) {                 // oneshot ready -> rand_delay (endpoint.rs:145)
             u0.x &= ~TF_INBOX;
             from = u0.y >> 24;
+            if (P.uses_rpc && (INSN(c, pc).x >> 24) >= MADSIM_TAG_RPC_FIRST) TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
             uint64_t d1 = rand_delay_deadline<K>(c, L);
             u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
             sub = 2;
@@ -677,6 +688,71 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             return true;
         }
         if (!timer_add<K>(c, L, d2, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        st = ST_PENDING;
+        return false;
+    };
+
+    // Endpoint::call / call_timeout (net/rpc.rs:96-131) from its first poll on.  sub 1: send_to_raw's rand_delay;
+    // sub 2: recv_from_raw(rsp_tag)'s oneshot; sub 3: its rand_delay.  With a timeout, the timeout's Sleep is polled after
+    // the call future on every poll and registers ANOTHER timer each time (select_biased!, time/sleep.rs:51-53).
+    // Returns true when the op completed (Ok, Err(TimedOut)) or the task panicked (st).
+    auto rpc_call_poll = [&]() -> bool {
+        const uint4 ci = INSN(c, pc);
+        const uint32_t ca = (ci.x >> 8) & 0xff, cb = ci.x >> 16, cimm = ci.y;
+        const uint32_t dst = cb & 0xff;
+        if (sub == 1) {
+            uint64_t d1 = u64of(u1.z, u1.w);
+            if (L.clock < d1) {
+                if (!timer_add<K>(c, L, d1, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+            } else {
+                // the caller's pending receive doubles as the rsp_tag: registration word >> 8 (see mailbox_deliver)
+                const uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;
+                const uint32_t reg = 0xffu | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                uint64_t lat; int ds;
+                if (try_send_fn<K>(c, L, SOCKW(c, ca) & 0xff, dst, &lat, &ds)) {
+                    uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
+                    uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((cb >> 8) << 12) | (ca << 6) | (uint32_t)ds;
+                    if (!timer_add<K>(c, L, L.clock + lat, meta, (cimm & 0xff) | (reg & 0xffffff00u))) L.ovf = 1;
+                }
+                // recv_from_raw(rsp_tag): Mailbox::recv (endpoint.rs:353-362); no queued message can carry a fresh tag
+                u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
+                u0.x &= ~TF_INBOX;
+                uint32_t h = SW(c, ca, 0);
+                uint32_t nreg = (h >> 9) & 0xff;
+                for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) L.ovf = 1;   // 8-bit rxseq wrapped onto a dead twin
+                if (nreg >= P.mbox_regs) L.ovf = 1;
+                else {
+                    SW(c, ca, 2 + nreg) = reg;
+                    SW(c, ca, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
+                }
+                sub = 2;
+            }
+        }
+        if (sub == 2 && (u0.x & TF_INBOX)) {                 // oneshot ready -> rand_delay (endpoint.rs:145)
+            u0.x &= ~TF_INBOX;
+            from = u0.y >> 24;
+            uint64_t d1 = rand_delay_deadline<K>(c, L);
+            u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
+            sub = 3;
+        }
+        if (sub == 3) {
+            uint64_t d1 = u64of(u1.z, u1.w);
+            if (L.clock >= d1) {
+                if (from != dst) st = ST_PANIC;              // assert_eq!(from, dst) rpc.rs:126
+                return true;
+            }
+            if (!timer_add<K>(c, L, d1, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        }
+        if (cimm >> 8) {
+            uint4 u2 = TU(c, slot, 2);
+            uint64_t d2 = u64of(u2.z, u2.w);
+            if (L.clock >= d2) {                             // Err(Elapsed) -> TimedOut: the call future is dropped
+                if (sub >= 2) { u1.x = (u1.x & ~0xffu) | (((u1.x & 0xff) + 1) & 0xff); u1_dirty = true; u0.x &= ~TF_INBOX; }
+                u0.w = MADSIM_VAL_TIMEOUT;
+                return true;
+            }
+            if (!timer_add<K>(c, L, d2, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        }
         st = ST_PENDING;
         return false;
     };
@@ -721,12 +797,17 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (!(u0.x & TF_INBOX)) { st = ST_PENDING; break; }
                 u0.x &= ~TF_INBOX;
                 from = u0.y >> 24;
+                if (K::LIFE && P.uses_rpc && (b >> 8) >= MADSIM_TAG_RPC_FIRST)   // (rsp_tag, req, data) = *data.downcast()
+                    TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
                 sub = 2;                                   // -> rand_delay, begun in [C]
             } else if (op == MS_OP_YIELD) {
                 completed = true;
             } else if (K::LIFE && op == MS_OP_RECV_TIMEOUT) {
                 completed = recv_timeout_poll();
                 if (!completed) break;
+            } else if (K::LIFE && op == MS_OP_RPC_CALL) {
+                completed = rpc_call_poll();
+                if (!completed || st == ST_PANIC) break;
             } else if (K::LIFE && op == MS_OP_ACCEPT && sub == 2) {
                 completed = accept_check(a);
                 if (!completed) break;
@@ -784,9 +865,13 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);     // bound, gen+1, empty mailbox
                     SW(c, a, 1) = slot | (gen << 16);
                     if (K::LIFE && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
-                } else if (op == MS_OP_SEND || op == MS_OP_REPLY) {        // net/mod.rs:307-331
+                } else if (op == MS_OP_SEND || op == MS_OP_REPLY || (K::LIFE && op == MS_OP_RPC_REPLY)) {   // net/mod.rs:307-331
                     REG(6);
                     uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : from;
+                    if (K::LIFE && op == MS_OP_RPC_REPLY) {    // send_to_raw(from, rsp_tag, rsp): rpc.rs:172-175
+                        b = 0xff00;
+                        imm = (imm & 0xff) | (TWORD(c, slot, P.rpc_unit, 0) << 8);
+                    }
                     uint32_t src_node = SOCKW(c, a) & 0xff;
                     uint32_t dst_node = SOCKW(c, dst) & 0xff;
                     // Network::try_send -> test_link (network.rs:261-269, 296-313)
@@ -880,6 +965,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);        // swap_remove
                     SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
                     u0.w = m1;
+                    if (K::LIFE && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 0) = m1 >> 8; }
                     from = (m0 >> 8) & 0xff;
                     sub = 2;                               // oneshot already holds the value
                     SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
@@ -892,7 +978,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 }
             }
             want_delay = (sub == 2);                       // endpoint.rs:145 rand_delay
-        } else if (op == MS_OP_SEND || op == MS_OP_REPLY || op == MS_OP_BIND || (K::LIFE && (op == MS_OP_CONNECT || op == MS_OP_ACCEPT))) {
+        } else if (op == MS_OP_SEND || op == MS_OP_REPLY || op == MS_OP_BIND || (K::LIFE && (op == MS_OP_CONNECT || op == MS_OP_ACCEPT || op == MS_OP_RPC_REPLY))) {
             want_delay = true;                             // net/mod.rs:306,344,457, endpoint.rs:198: rand_delay first
         } else if (K::LIFE && op == MS_OP_RECV_TIMEOUT) {
             uint32_t tag = b >> 8;
@@ -913,6 +999,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);
                 SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
                 u0.w = m1;
+                if (P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 1) = m1 >> 8; }
                 u0.y = (u0.y & 0x00ffffffu) | (((m0 >> 8) & 0xff) << 24);
                 u0.x |= TF_INBOX;
                 SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
@@ -924,6 +1011,18 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             }
             sub = 1;
             if (recv_timeout_poll()) { sub = 0; pc++; }
+        } else if (K::LIFE && op == MS_OP_RPC_CALL) {          // first poll of timeout(d, ep.call(dst, req)) / ep.call(dst, req)
+            if (imm >> 8) {                                    // timeout()'s Sleep exists before the call is polled
+                uint64_t d2 = sleep_deadline(L, L.clock + (uint64_t)(imm >> 8) * NS_PER_MS);
+                uint4 u2 = TU(c, slot, 2);
+                u2.z = (uint32_t)d2; u2.w = (uint32_t)(d2 >> 32);
+                TU(c, slot, 2) = u2;
+            }
+            (void)rng_next(L); rng_log<K>(c, L);               // rsp_tag = random::<u64>(): one with() (rand.rs:146-148)
+            uint64_t d1 = rand_delay_deadline<K>(c, L);        // send_to_raw -> NetSim::send: rand_delay first
+            u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
+            sub = 1;
+            if (rpc_call_poll()) { sub = 0; pc++; }            // (never on the first poll: 1 ms floor)
         } else if (K::LIFE && op == MS_OP_SLEEP_RAND) {        // sleep(thread_rng().gen_range(lo..hi)): [DEP A.3],
             const uint64_t* dp = P.dur_table + 4 * a;          // host-precomputed UniformDuration {mode, low, range, zone}
             uint64_t mode = dp[0], low = dp[1], range = dp[2], zone = dp[3], d;
@@ -966,6 +1065,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     uint32_t cx = TWORD(c, slot, 3, 0);
                     TWORD(c, child, 3, 0) = cx & 0x1ff;
                     TWORD(c, slot, 3, 0) = cx | 0xff;
+                }
+                if (K::LIFE && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST) && child != 0xffffffffu) {   // rpc.rs:170
+                    TWORD(c, child, 0, 3) = u0.w;
+                    TWORD(c, child, 0, 1) = (TWORD(c, child, 0, 1) & 0x00ffffffu) | (from << 24);
+                    TWORD(c, child, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 0);
                 }
             }
                 pc++;

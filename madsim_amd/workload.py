@@ -44,8 +44,10 @@ class TaskBuilder:
     def done(self):
         return self._emit("DONE")
 
-    def spawn(self, task, move_conn=False):
-        return self._emit("SPAWN", a=task.index, b=2 if move_conn else 0)
+    def spawn(self, task, move_conn=False, move_request=False):
+        """`move_conn`: the child's `async move` block takes this task's (tx, rx); `move_request`: it takes the
+        request just received on a typed tag (value, sender, response tag) — the per-request task of rpc.rs:170."""
+        return self._emit("SPAWN", a=task.index, b=(2 if move_conn else 0) | (4 if move_request else 0))
 
     def join(self, task, expect_err=False):
         return self._emit("JOIN", a=task.index, b=1 if expect_err else 0)
@@ -115,6 +117,21 @@ class TaskBuilder:
 
     def assert_val(self, val):
         return self._emit("ASSERT_VAL", imm=val)
+
+    # -- typed RPC (Endpoint::call / call_timeout / add_rpc_handler, net/rpc.rs:96-180) -------------
+    def rpc_call(self, ep, dst, req_id, code, timeout_ms=0):
+        """val = ep.call(dst, R{code}).await, or call_timeout(.., timeout_ms) -> VAL_TIMEOUT.  `req_id` is R::ID - 0x80."""
+        if not (0 <= code <= 0xFF and 0 <= timeout_ms < (1 << 24) and 0 <= req_id <= 0x7D):
+            raise ValueError("rpc_call: code is 8 bits, timeout_ms 24 bits, req_id 0..125")
+        return self._emit("RPC_CALL", a=ep, b=((0x80 + req_id) << 8) | dst, imm=(timeout_ms << 8) | code)
+
+    def rpc_recv(self, ep, req_id):
+        """(req, from) = recv_from_raw(R::ID) of a handler loop (rpc.rs:161): val = request code."""
+        return self._emit("RECV", a=ep, b=(0x80 + req_id) << 8)
+
+    def rpc_reply(self, ep, code):
+        """send_to_raw(from, rsp_tag, rsp) for the request in hand (rpc.rs:172-175)."""
+        return self._emit("RPC_REPLY", a=ep, imm=code & 0xFF)
 
     # -- reliable channel (Endpoint::connect1 / accept1, net/mod.rs:337-430) -----------------------
     def connect1(self, ep, dst):

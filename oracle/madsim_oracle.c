@@ -80,13 +80,15 @@ typedef struct {           /* naive_timer::Event: deadline + boxed callback     
     uint64_t deadline;
     uint8_t  kind;
     uint16_t slot, gen;    /* EV_WAKE: task instance + generation (a cloned Waker)                   */
-    uint8_t  sock, sockgen, from, tag; /* EV_DELIVER: captured Arc<dyn Socket>, src addr, tag        */
+    uint8_t  sock, sockgen, from;      /* EV_DELIVER: captured Arc<dyn Socket>, src addr              */
+    uint64_t tag;          /* EV_DELIVER tag: u64 in the reference (endpoint.rs:120)                 */
     uint32_t val;          /* EV_DELIVER payload                                                     */
+    uint64_t aux;          /* typed RPC request payload: the caller's rsp_tag (rpc.rs:121-124)       */
     uint8_t  node;         /* EV_RESTART                                                             */
 } event_t;
 
-typedef struct { uint8_t tag; uint16_t slot, gen; uint8_t rxseq; } reg_t;  /* (tag, oneshot::Sender) */
-typedef struct { uint8_t tag, from; uint32_t val; } msg_t;                 /* endpoint.rs:288-292    */
+typedef struct { uint64_t tag; uint16_t slot, gen; uint8_t rxseq; } reg_t; /* (tag, oneshot::Sender) */
+typedef struct { uint64_t tag; uint8_t from; uint32_t val; uint64_t aux; } msg_t;   /* endpoint.rs:288-292 */
 
 typedef struct { uint32_t val; uint8_t has_arrive; uint64_t arrive; } cmsg_t;   /* (Payload, State) net/mod.rs:411-415 */
 typedef struct {                          /* one direction of a connection: net/mod.rs:367-405 channel()            */
@@ -125,7 +127,10 @@ typedef struct {
     uint64_t t0;
     uint16_t cnt[2];
     uint32_t val; uint8_t from;
+    uint64_t aux;          /* rsp_tag of the typed RPC request in hand (rpc.rs:163-165)             */
+    uint64_t rsp_tag;      /* rsp_tag of the call in flight (rpc.rs:121)                            */
     uint8_t  inbox_full; uint8_t rxseq;   /* the oneshot::Receiver currently held                    */
+    uint64_t inbox_aux;
     int32_t  joiner; uint16_t joiner_gen; /* async-task awaiter                                      */
     int8_t   conn; uint8_t side;          /* the (Sender, Receiver) pair this task holds, and which end */
     uint32_t cval; uint8_t chas; uint64_t carrive; uint32_t backoff_ms;   /* receiver stream state (net/mod.rs:386-400) */
@@ -344,7 +349,7 @@ static void mailbox_deliver(sim_t* S, event_t* e) {
             k->registered.p[i] = k->registered.p[--k->registered.n];     /* swap_remove */
             task_t* t = r.slot < S->tasks.n ? &S->tasks.p[r.slot] : NULL;
             if (t && t->alive && t->gen == r.gen && t->rxseq == r.rxseq && !t->inbox_full) {
-                t->inbox_full = 1; t->val = e->val; t->from = e->from;   /* oneshot send Ok */
+                t->inbox_full = 1; t->val = e->val; t->from = e->from; t->inbox_aux = e->aux;   /* oneshot send Ok */
                 wake(S, r.slot, r.gen);                                   /* [DEP tokio oneshot] */
                 return;
             }
@@ -353,7 +358,7 @@ static void mailbox_deliver(sim_t* S, event_t* e) {
             i++;
         }
     }
-    msg_t m = { e->tag, e->from, e->val };
+    msg_t m = { e->tag, e->from, e->val, e->aux };
     vec_push(k->msgs, m);
     if (k->msgs.n > S->st.max_msgs) S->st.max_msgs = (uint32_t)k->msgs.n;
 }
@@ -552,6 +557,9 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 if ((in->b & 2) && child >= 0) {           /* `spawn(async move { .. tx, rx .. })`: the handles move */
                     S->tasks.p[child].conn = t->conn; S->tasks.p[child].side = t->side; t->conn = -1;
                 }
+                if ((in->b & MADSIM_SPAWN_MOVE_REQUEST) && child >= 0) {   /* rpc.rs:170: `spawn(async move { .. from, rsp_tag .. })` */
+                    S->tasks.p[child].val = t->val; S->tasks.p[child].from = t->from; S->tasks.p[child].aux = t->aux;
+                }
             }
             t->pc++;
             break;
@@ -659,6 +667,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
             t->sub = 0; t->pc++;
             break;
         case MS_OP_SEND:
+        case MS_OP_RPC_REPLY:                              /* rpc.rs:172-175: send_to_raw(from, rsp_tag, rsp) */
         case MS_OP_REPLY:                                  /* net/mod.rs:298-333 */
             if (t->sub == 0) { t->deadline = rand_delay_start(S); t->sub = 1; }
             if (!sleep_poll(S, slot, t->deadline)) return 0;
@@ -670,6 +679,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                     e.deadline = S->clock + lat; e.kind = EV_DELIVER; e.sock = (uint8_t)ds;
                     e.sockgen = S->socks[ds].gen; e.from = in->a; e.tag = (uint8_t)(in->b >> 8);
                     e.val = in->imm;
+                    if (in->op == MS_OP_RPC_REPLY) { e.tag = t->aux; e.val = in->imm & 0xff; }
                     timer_add(S, e);
                 }
             }
@@ -685,7 +695,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 if (idx < k->msgs.n) {
                     msg_t m = k->msgs.p[idx];
                     k->msgs.p[idx] = k->msgs.p[--k->msgs.n];            /* swap_remove */
-                    t->inbox_full = 1; t->val = m.val; t->from = m.from;
+                    t->inbox_full = 1; t->val = m.val; t->from = m.from; t->inbox_aux = m.aux;
                 } else {
                     reg_t r = { tag, slot, t->gen, t->rxseq };
                     vec_push(k->registered, r);
@@ -696,6 +706,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (t->sub == 1) {
                 if (!t->inbox_full) return 0;              /* oneshot rx Pending */
                 t->inbox_full = 0;
+                if (tag >= MADSIM_TAG_RPC_FIRST) t->aux = t->inbox_aux;   /* (rsp_tag, req, data) = *data.downcast() */
                 t->deadline = rand_delay_start(S); t->sub = 2;
             }
             if (!sleep_poll(S, slot, t->deadline)) return 0;
@@ -817,7 +828,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 if (idx < k->msgs.n) {
                     msg_t m = k->msgs.p[idx];
                     k->msgs.p[idx] = k->msgs.p[--k->msgs.n];
-                    t->inbox_full = 1; t->val = m.val; t->from = m.from;
+                    t->inbox_full = 1; t->val = m.val; t->from = m.from; t->inbox_aux = m.aux;
                 } else {
                     reg_t r = { tag, slot, t->gen, t->rxseq };
                     vec_push(k->registered, r);
@@ -828,12 +839,71 @@ static int poll_task(sim_t* S, uint16_t slot) {
             int ready = 0;
             if (t->sub == 1 && t->inbox_full) {            /* oneshot ready -> rand_delay (endpoint.rs:145) */
                 t->inbox_full = 0;
+                if (tag >= MADSIM_TAG_RPC_FIRST) t->aux = t->inbox_aux;
                 t->deadline = rand_delay_start(S); t->sub = 2;
             }
             if (t->sub == 2) ready = sleep_poll(S, slot, t->deadline);
             if (ready) { t->sub = 0; t->pc++; break; }     /* Ok((len, from)) */
             if (S->clock >= t->deadline2) {                /* Err(Elapsed): the recv future is dropped */
                 t->rxseq++; t->inbox_full = 0;             /* oneshot::Receiver gone; a message taken in sub 2 is lost */
+                t->val = MADSIM_VAL_TIMEOUT;
+                t->sub = 0; t->pc++;
+                break;
+            }
+            { event_t e; memset(&e, 0, sizeof e);          /* Sleep::poll of the timeout: a NEW timer every time */
+              e.deadline = t->deadline2; e.kind = EV_WAKE; e.slot = slot; e.gen = t->gen; timer_add(S, e); }
+            return 0;
+        }
+        case MS_OP_RPC_CALL: {                             /* Endpoint::call / call_timeout (rpc.rs:96-131) */
+            sock_t* k = &S->socks[in->a];
+            const uint32_t timeout_ms = in->imm >> 8;
+            const unsigned dst = in->b & 0xff;
+            int ready = 0;
+            if (t->sub == 0) {
+                /* timeout(d, self.call(..)) builds its Sleep before the call future is first polled (time/mod.rs:128-133) */
+                if (timeout_ms) t->deadline2 = sleep_deadline(S, S->clock + (uint64_t)timeout_ms * NS_PER_MS);
+                t->rsp_tag = rng_next(S); rng_log(S);      /* random::<u64>() on the GlobalRng: one with() (rand.rs:146-148) */
+                t->deadline = rand_delay_start(S);         /* send_to_raw -> NetSim::send: rand_delay first (net/mod.rs:306) */
+                t->sub = 1;
+            }
+            if (t->sub == 1 && sleep_poll(S, slot, t->deadline)) {
+                uint64_t lat; int ds;
+                if (try_send(S, w->socks[in->a].node, dst, &lat, &ds)) {
+                    event_t e; memset(&e, 0, sizeof e);
+                    e.deadline = S->clock + lat; e.kind = EV_DELIVER; e.sock = (uint8_t)ds;
+                    e.sockgen = S->socks[ds].gen; e.from = in->a; e.tag = (uint8_t)(in->b >> 8);
+                    e.val = in->imm & 0xff; e.aux = t->rsp_tag;            /* Box::new((rsp_tag, request, data)) */
+                    timer_add(S, e);
+                    t = &S->tasks.p[slot];
+                }
+                /* recv_from_raw(rsp_tag): Mailbox::recv (endpoint.rs:353-362) */
+                t->rxseq++; t->inbox_full = 0;
+                size_t idx = 0;
+                while (idx < k->msgs.n && k->msgs.p[idx].tag != t->rsp_tag) idx++;
+                if (idx < k->msgs.n) {
+                    msg_t m = k->msgs.p[idx];
+                    k->msgs.p[idx] = k->msgs.p[--k->msgs.n];
+                    t->inbox_full = 1; t->val = m.val; t->from = m.from; t->inbox_aux = m.aux;
+                } else {
+                    reg_t r = { t->rsp_tag, slot, t->gen, t->rxseq };
+                    vec_push(k->registered, r);
+                    if (k->registered.n > S->st.max_regs) S->st.max_regs = (uint32_t)k->registered.n;
+                }
+                t->sub = 2;
+            }
+            if (t->sub == 2 && t->inbox_full) {            /* oneshot ready -> rand_delay (endpoint.rs:145) */
+                t->inbox_full = 0;
+                t->deadline = rand_delay_start(S); t->sub = 3;
+            }
+            if (t->sub == 3) ready = sleep_poll(S, slot, t->deadline);
+            if (ready) {
+                if (t->from != dst) return 1;              /* assert_eq!(from, dst) rpc.rs:126 */
+                t->sub = 0; t->pc++;
+                break;
+            }
+            if (!timeout_ms) return 0;
+            if (S->clock >= t->deadline2) {                /* Err(Elapsed) -> io::ErrorKind::TimedOut: the call future is dropped */
+                if (t->sub >= 2) { t->rxseq++; t->inbox_full = 0; }     /* its oneshot::Receiver with it */
                 t->val = MADSIM_VAL_TIMEOUT;
                 t->sub = 0; t->pc++;
                 break;

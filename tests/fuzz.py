@@ -230,3 +230,78 @@ def generous_limits():
     lim.lanes_per_wave = 16                    # generous per-seed state: carry fewer seeds per wave so it fits LDS
     lim.mbox_regs, lim.mbox_msgs = 15, 15      # timed-out recv_from leaves dead registrations behind (reference: unbounded Vec)
     return lim
+
+
+def random_rpc_workload(rng: random.Random):
+    """Typed-RPC programs (net/rpc.rs): handler tasks with per-request children, `call` / `call_timeout` loops, slow and
+    silent handlers, lossy links, server kill/restart and clogs.  Returns (BuiltWorkload, Config, description)."""
+    wl = W.WorkloadBuilder()
+    n_srv, n_cl = rng.randint(1, 2), rng.randint(1, 3)
+    desc = []
+    servers = []
+    for i in range(n_srv):
+        n = wl.create_node(); a = wl.addr(n, 1)
+        slow = rng.choice([0, 0, 20, 120]); silent = rng.random() < 0.15
+        h = wl.task(n)
+        if slow:
+            h.sleep(ms=slow)
+        h.trace(300 + i)
+        if not silent:
+            h.rpc_reply(a, 0x40 + i)
+        h.done()
+        is_init = rng.random() < 0.5
+        s = wl.task(n, init=is_init)
+        s.bind(a)
+        if rng.random() < 0.3:                            # a few rounds of timeout(d, recv_from_raw(R::ID)) first
+            s.set(1, rng.randint(1, 8))
+            top = s.label()
+            s.recv_from_timeout(a, 0x80 + i, ms=rng.choice([40, 300]))
+            s.jeq(A.VAL_TIMEOUT, top + 3)
+            s.spawn(h, move_request=True)
+            s.djnz(1, top)
+        top = s.label()
+        s.rpc_recv(a, i); s.spawn(h, move_request=True); s.jmp(top)
+        servers.append((n, a, s, is_init))
+        desc.append(f"srv(slow={slow},silent={int(silent)},init={int(is_init)})")
+    clients = []
+    for j in range(n_cl):
+        n = wl.create_node(); a = wl.addr(n, 1)
+        c = wl.task(n)
+        c.bind(a); c.sleep(ms=rng.randint(0, 30)); c.set(0, rng.randint(1, 6))
+        top = c.label()
+        k = rng.randrange(n_srv)
+        tmo = rng.choice([0, 30, 100, 400])
+        c.rpc_call(a, servers[k][1], k, rng.randrange(256), timeout_ms=tmo)
+        c.trace(500 + j)
+        if rng.random() < 0.5:
+            c.sleep(ms=rng.choice([0, 5, 60]))
+        c.djnz(0, top); c.flag_add(0, 1); c.done()
+        clients.append(c)
+        desc.append(f"cl(->{k},tmo={tmo})")
+    m = wl.main()
+    for n, a, s, is_init in servers:
+        if is_init:
+            m.build_node(n)
+        else:
+            m.spawn(s)
+    for c in clients:
+        m.spawn(c)
+    for _ in range(rng.randint(0, 5)):
+        act = rng.choice(["sleep", "sleep", "kill", "restart", "clog", "unclog"])
+        n = rng.choice(servers)[0]
+        if act == "sleep":
+            m.sleep(ms=rng.choice([3, 25, 150, 900]))
+        elif act == "kill":
+            m.kill(n)
+        elif act == "restart":
+            m.restart(n)
+        elif act == "clog":
+            m.clog_node(n, rng.choice(["in", "out", "both"]))
+        else:
+            m.unclog_node(n, "both")
+    for n, *_ in servers:
+        m.unclog_node(n, "both")
+    m.sleep(ms=rng.choice([100, 3000, 20000]))
+    m.done()
+    cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.1, 0.3]), buggify=rng.random() < 0.1)
+    return wl.build(), cfg, "+".join(desc)

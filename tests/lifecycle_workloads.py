@@ -1,5 +1,6 @@
 """The reference's node-lifecycle unit tests (madsim/src/sim/task/mod.rs:859-1182) restated as workloads.
 Shared by the oracle tests (CPU) and the GPU parity tests."""
+from madsim_amd import _abi as A
 from madsim_amd import workload as W
 
 
@@ -246,3 +247,82 @@ def connect_refused_and_reset():
 
 
 ALL.update(kv_rpc=kv_rpc, channel_backoff=channel_backoff, connect_refused_and_reset=connect_refused_and_reset)
+
+
+def _rpc_server(wl, node, addr, reply_code, handler_sleep_ms=0, **kw):
+    """add_rpc_handler (net/rpc.rs:152-179): `loop { (req, from) = recv_from_raw(R::ID); spawn(async move { rsp = f(req).await;
+    send_to_raw(from, rsp_tag, rsp) }) }`."""
+    h = wl.task(node)
+    if handler_sleep_ms:
+        h.sleep(ms=handler_sleep_ms)
+    h.rpc_reply(addr, reply_code)
+    s = wl.task(node, **kw)
+    s.bind(addr)
+    top = s.label()
+    s.rpc_recv(addr, 0); s.trace(1); s.spawn(h, move_request=True); s.jmp(top)
+    return s
+
+
+def rpc_echo(n_clients=2, n_calls=4):
+    """net/rpc.rs doc example + the shape of its users: typed `call` against a handler task, several callers in flight."""
+    wl = W.WorkloadBuilder()
+    ns = wl.create_node()
+    asv = wl.addr(ns, 1)
+    srv = _rpc_server(wl, ns, asv, 42)
+    m = wl.main(); m.spawn(srv)
+    cls = []
+    for i in range(n_clients):
+        n = wl.create_node(); a = wl.addr(n, 1)
+        c = wl.task(n); c.bind(a); c.sleep(ms=10); c.set(0, n_calls)
+        top = c.label()
+        c.rpc_call(a, asv, 0, 5 + i); c.assert_val(42); c.djnz(0, top)
+        m.spawn(c); cls.append(c)
+    for c in cls:
+        m.join(c)
+    return wl.build()
+
+
+def rpc_call_timeout_then_retry():
+    """call_timeout (rpc.rs:96-105) elapsing while the handler is still working: the late response finds nobody holding
+    its rsp_tag and stays in the caller's mailbox for good; the retry gets its own response."""
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
+    srv = _rpc_server(wl, ns, asv, 42, handler_sleep_ms=80)
+    c = wl.task(nc); c.bind(acl); c.sleep(ms=10)
+    c.rpc_call(acl, asv, 0, 1, timeout_ms=50); c.assert_val(A.VAL_TIMEOUT)
+    c.rpc_call(acl, asv, 0, 2, timeout_ms=500); c.assert_val(42)
+    c.sleep(ms=200)                                   # the first call's response has long arrived by now
+    c.rpc_call(acl, asv, 0, 3); c.assert_val(42)
+    m = wl.main(); m.spawn(srv); m.spawn(c); m.join(c)
+    return wl.build()
+
+
+def rpc_server_restart():
+    """A caller keeps retrying `call_timeout` across a kill + restart of the server node (init task re-registers the handler)."""
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
+    _rpc_server(wl, ns, asv, 7, init=True, pre=True)
+    c = wl.task(nc); c.bind(acl); c.sleep(ms=10); c.set(0, 12)
+    top = c.label()
+    c.rpc_call(acl, asv, 0, 9, timeout_ms=100)
+    ok = c.label() + 3
+    c.jeq(7, ok); c.flag_add(1, 1); c.jmp(ok + 1)
+    assert c.label() == ok
+    c.flag_add(0, 1)
+    c.sleep(ms=50); c.djnz(0, top)
+    c.panic_if_flag_lt(0, 4); c.panic_if_flag_lt(1, 1)    # some calls succeeded on both incarnations, some timed out
+    m = wl.main(); m.spawn(c); m.sleep(ms=300); m.kill(ns); m.sleep(ms=400); m.restart(ns); m.join(c)
+    return wl.build()
+
+
+ALL.update(rpc_echo=rpc_echo, rpc_call_timeout_then_retry=rpc_call_timeout_then_retry, rpc_server_restart=rpc_server_restart)
+
+
+def limits(name):
+    """Device capacities a workload needs beyond the defaults (None = defaults)."""
+    if name == "rpc_server_restart":                  # timed-out calls leave dead registrations behind (rpc.rs:125)
+        lim = A.Limits(); lim.mbox_regs, lim.mbox_msgs = 8, 4
+        return lim
+    return None

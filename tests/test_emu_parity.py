@@ -83,7 +83,7 @@ from tests import lifecycle_workloads as LW  # noqa: E402
 @pytest.mark.parametrize("name", sorted(LW.ALL))
 def test_lifecycle_reference_tests(name):
     """kill / restart / restart_on_panic / pause_resume / exited / join_cancelled ... (task/mod.rs:859-1182)."""
-    o = _same(LW.ALL[name](), 0, 128)
+    o = _same(LW.ALL[name](), 0, 128, None, LW.limits(name))
     assert (o["verdict"] == (A.PANIC if name in LW.EXPECT_PANIC else A.PASS)).all()
 
 
@@ -105,3 +105,16 @@ def test_baseline_config_shaped_workloads():
     o = _same(W.raft_election(), 0, 300, A.Config.default(packet_loss_rate=0.05), W.raft_election_limits())
     o = _same(W.kv_rpc(), 0, 300, None, W.kv_rpc_limits())
     assert (o["verdict"] == A.PASS).all()
+
+
+def test_fuzz_rpc_workloads():
+    """200 random typed-RPC programs (net/rpc.rs): call / call_timeout against handler tasks, slow and silent handlers,
+    loss, server kill/restart."""
+    for k in range(200):
+        w, cfg, desc = fuzz.random_rpc_workload(random.Random(31000 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        o, _ = oracle.run_batch(w, k * 5, 12, cfg, lim)
+        e = emu.run_batch(w, k * 5, 12, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+        assert (e["verdict"] == A.OVERFLOW).mean() < 0.1

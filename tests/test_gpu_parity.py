@@ -219,7 +219,7 @@ from tests import lifecycle_workloads as LW  # noqa: E402
 @pytest.mark.parametrize("name", sorted(LW.ALL))
 def test_lifecycle_reference_tests_gpu(hip, name):
     """The reference's node-lifecycle unit tests (task/mod.rs:859-1182) executed by the kernel, 1024 seeds each."""
-    got, _ = _cmp(hip, LW.ALL[name](), 0, 1024)
+    got, _ = _cmp(hip, LW.ALL[name](), 0, 1024, None, LW.limits(name))
     assert (got["verdict"] == (A.PANIC if name in LW.EXPECT_PANIC else A.PASS)).all()
 
 
@@ -327,3 +327,30 @@ def test_register_ready_queue_with_heap_spill(hip):
     w = W.pingpong(4, 32)
     assert hip.geometry(w, lim).variant == 5
     _cmp(hip, w, 424242, 4096, None, lim)
+
+
+def test_fuzz_rpc_workloads_gpu(hip):
+    """Typed RPC (net/rpc.rs:96-180): 150 random call / call_timeout / handler programs x 64 seeds."""
+    import random
+    from tests import fuzz
+    for k in range(150):
+        w, cfg, desc = fuzz.random_rpc_workload(random.Random(33000 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        got, _ = hip.run_batch(w, k * 19, 64, cfg, lim)
+        want, _ = oracle.run_batch(w, k * 19, 64, cfg, lim)
+        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+        assert (got["verdict"] == A.OVERFLOW).mean() < 0.1
+
+
+def test_rpc_echo_65536_seeds(hip):
+    """Typed RPC at batch size: 2 callers x 4 calls against one handler task, sampled parity + size-independent
+    properties (every call costs one request and one response: 16 messages per seed without loss)."""
+    from tests import lifecycle_workloads as LW
+    w = LW.rpc_echo()
+    n = 65536
+    got, summ = hip.run_batch(w, 9_000_000, n)
+    assert summ.n_failed == 0 and (got["msg_count"] == 16).all()
+    idx = np.arange(0, n, 257)
+    want = np.concatenate([oracle.run_batch(w, 9_000_000 + int(i), 1)[0] for i in idx])
+    assert (got[idx] == want).all()
