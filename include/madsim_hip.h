@@ -116,6 +116,8 @@ enum madsim_op {
                               val := MADSIM_VAL_TIMEOUT on Err(TimedOut).  req_tag must be a typed tag (>= 0x80).   */
     MS_OP_RPC_REPLY = 52,  /* a=ep, imm=response code: net.send_to_raw(from, rsp_tag, rsp) of the request this
                               task received (or inherited at spawn): the tail of add_rpc_handler (rpc.rs:170-176) */
+    MS_OP_RAND_BOOL = 53,  /* a=index into madsim_config_t.loss_table: val = thread_rng().gen_bool(p) as u32 — one
+                              RngCore draw unless p == 1 (madsim-etcd-client/src/service.rs:165-166)        */
     MS_OP__COUNT
 };
 

@@ -98,6 +98,7 @@ class Task {
         uint64_t ns = (uint64_t)hi.count();
         return emit(MS_OP_SLEEP_RAND, (uint8_t)(lo.count() / 50), (uint16_t)(ns / 1000000000ull), (uint32_t)(ns % 1000000000ull));
     }
+    Task& rand_bool(int table_index) { return emit(MS_OP_RAND_BOOL, (uint8_t)table_index); }
     Task& jeq(uint32_t value, int target) { return emit(MS_OP_JEQ, 0, (uint16_t)target, value, true); }
     // reliable channel (Endpoint::connect1 / accept1)
     Task& connect1(int ep, int dst) { return emit(MS_OP_CONNECT, (uint8_t)ep, (uint16_t)dst); }

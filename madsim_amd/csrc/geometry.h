@@ -143,7 +143,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         if (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) P.restart_nodes |= 1u << i;
     P.has_restart_on_panic = P.restart_nodes != 0;
     P.lifecycle = P.has_restart_on_panic || uses_op(w, MS_OP_KILL) || uses_op(w, MS_OP_RESTART) || uses_op(w, MS_OP_PAUSE) ||
-                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND) || P.uses_chan || P.uses_rpc ||
+                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND) || uses_op(w, MS_OP_RAND_BOOL) || P.uses_chan || P.uses_rpc ||
                   uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_ADVANCE);
     for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.lifecycle = 1;
     // The generic kernel variants (trace, lanes_per_wave != 64) are compiled with the extended ops, so they need the

@@ -1246,6 +1246,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 CLOGW(2 + a) &= ~(1u << b);
                 pc++;
                 break;
+            case MS_OP_RAND_BOOL:                           // thread_rng().gen_bool(p) [DEP A.4]
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                u0.w = gen_bool_pint<K>(c, L, P.loss_table_pint[a & 3], P.loss_table_always[a & 3]) ? 1u : 0u;
+                pc++;
+                break;
             case MS_OP_SET_LOSS:
                 L.loss_pint = P.loss_table_pint[a & 3];
                 L.loss_always = P.loss_table_always[a & 3];

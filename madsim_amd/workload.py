@@ -203,6 +203,10 @@ class TaskBuilder:
         b, imm = _dur(**kw)
         return self._emit("SLEEP_RAND", a=lo_ms // 50, b=b, imm=imm)
 
+    def rand_bool(self, table_index):
+        """val = thread_rng().gen_bool(config.loss_table[table_index]) as u32 (one draw unless p == 1)."""
+        return self._emit("RAND_BOOL", a=table_index)
+
     def jeq(self, value, target):
         return self._emit("JEQ", b=target, imm=value, reloc=True)
 
@@ -381,17 +385,28 @@ def raft_election(n_nodes=5, heartbeats=20, partitions=4):
 
 
 def kv_rpc(n_clients=4, n_ops=8):
-    """BASELINE configs[3] shape: an etcd-style KV test.  Every operation is a fresh reliable connection
-    (madsim-etcd-client/src/kv.rs:37-53: connect1 -> send request -> recv response), the server accepts in a loop
-    and spawns one handler task per connection (madsim-etcd-client/src/server.rs:34-40)."""
-    REQ, RSP = 0x11, 0x22
+    """BASELINE configs[3] shape: one etcd-style KV op = one connection (madsim-etcd-client/src/kv.rs:37-53: connect1 ->
+    send request -> recv response).  The server binds, spawns the service's 1 s housekeeping tick task
+    (service.rs:27-33), accepts in a loop and spawns one handler task per connection (server.rs:34-40); the handler
+    receives the request and runs `service.timeout()` (service.rs:164-175): one `gen_bool(timeout_rate)` draw —
+    config.loss_table[1], 0 by default — and on true a `sleep(gen_range(5 s..15 s))` before an error response."""
+    REQ, RSP, ERR = 0x11, 0x22, 0x33
     wl = WorkloadBuilder()
     ns = wl.create_node()
     asv = wl.addr(ns, 2379)
     handler = wl.task(ns)
-    handler.chan_recv(); handler.assert_val(REQ); handler.flag_add(0, 1); handler.chan_send(RSP)
+    handler.chan_recv(); handler.assert_val(REQ); handler.flag_add(0, 1)
+    handler.rand_bool(1)
+    slow = handler.label() + 3
+    handler.jeq(1, slow)
+    handler.chan_send(RSP); handler.done()
+    assert handler.label() == slow
+    handler.sleep_rand(lo_ms=5000, secs=15); handler.chan_send(ERR)
+    tick = wl.task(ns)
+    top = tick.label()
+    tick.flag_add(1, 1); tick.sleep(secs=1); tick.jmp(top)
     srv = wl.task(ns)
-    srv.bind(asv)
+    srv.bind(asv); srv.spawn(tick)
     top = srv.label()
     srv.accept1(asv); srv.spawn(handler, move_conn=True); srv.jmp(top)
     clients = []
@@ -401,7 +416,10 @@ def kv_rpc(n_clients=4, n_ops=8):
         c = wl.task(nc)
         c.bind(acl); c.sleep(ms=10); c.set(0, n_ops)
         top = c.label()
-        c.connect1(acl, asv); c.assert_val(0); c.chan_send(REQ); c.chan_recv(); c.assert_val(RSP); c.chan_close(); c.djnz(0, top)
+        c.connect1(acl, asv); c.assert_val(0); c.chan_send(REQ); c.chan_recv()
+        ok = c.label() + 2
+        c.jeq(RSP, ok); c.assert_val(ERR)
+        c.chan_close(); c.djnz(0, top)
         clients.append(c)
     m = wl.main()
     m.spawn(srv)

@@ -942,6 +942,13 @@ static int poll_task(sim_t* S, uint16_t slot) {
             t->pc++;
             break;
         }
+        case MS_OP_RAND_BOOL: {                            /* thread_rng().gen_bool(p): Bernoulli on the GlobalRng [DEP A.4] */
+            double p = S->cfg->loss_table[in->a & 3];
+            int always = p == 1.0;
+            t->val = (uint32_t)gen_bool_pint(S, always ? 0 : (uint64_t)(p * 18446744073709551616.0), always);
+            t->pc++;
+            break;
+        }
         default:
             return 1;                                      /* unsupported op in this oracle build */
         }

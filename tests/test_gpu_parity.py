@@ -257,6 +257,8 @@ def test_config3_kv_rpc_131072_seeds(hip):
         want, _ = oracle.run_batch(w, s, 1, None, lim)
         assert got[s] == want[0], f"seed {s}"
     _cmp(hip, w, 5_000_000, 2048, A.Config.default(packet_loss_rate=0.02), lim)
+    # service.timeout() firing (timeout_rate 0.2): 5-15 s sleeps and error responses
+    _cmp(hip, w, 6_000_000, 2048, A.Config.default(loss_table=(0.0, 0.2, 1.0)), lim)
 
 
 def test_async_entry_point_device_summary(hip):
