@@ -116,14 +116,16 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.max_tasks = L.max_tasks ? L.max_tasks : w->n_progs + (restarts ? w->n_progs : 0) + (chan || P.uses_rpc ? 8 : 0);
     if (P.max_tasks > 254) P.max_tasks = 254;
     if (P.max_tasks > 254) return fail(err, MADSIM_E_LIMITS, "max_tasks must be <= 254");
-    P.mbox_regs = L.mbox_regs ? L.mbox_regs : 2;
+    P.mbox_regs = L.mbox_regs == MADSIM_LIMIT_NONE ? 0 : L.mbox_regs ? L.mbox_regs : 2;
     P.mbox_msgs = L.mbox_msgs == MADSIM_LIMIT_NONE ? 0 : L.mbox_msgs ? L.mbox_msgs : 2;
     if (P.mbox_regs > 255 || P.mbox_msgs > 255) return fail(err, MADSIM_E_LIMITS, "mailbox capacities must be <= 255");
     P.heap_lds = L.heap_lds_slots ? L.heap_lds_slots : 8;
     P.heap_spill = (L.heap_lds_slots || L.heap_spill_slots) ? L.heap_spill_slots : 56;
     bool t0 = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_RECV_TIMEOUT) || P.uses_rpc;
     P.uses_chan = uses_op(w, MS_OP_CONNECT) || uses_op(w, MS_OP_ACCEPT) || uses_op(w, MS_OP_CSEND) || uses_op(w, MS_OP_CRECV);
-    P.task_units = P.uses_chan ? 4 : t0 ? 3 : 2;
+    // task units: 0-1 always; 2 = {t0, timeout()'s deadline} when used; then the connection unit, then the RPC unit
+    P.task_units = t0 ? 3 : 2;
+    if (P.uses_chan) { P.chan_unit = P.task_units; P.task_units++; }
     if (P.uses_rpc) { P.rpc_unit = P.task_units; P.task_units++; }   // {rsp_tag in hand, rsp_tag staged with the oneshot value}
     // per socket: header, owner, registrations, queued messages (+ accept queue, parked acceptor)
     P.sock_words = 2 + P.mbox_regs + 2 * P.mbox_msgs + (P.uses_chan ? 2 : 0);

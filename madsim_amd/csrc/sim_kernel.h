@@ -36,6 +36,7 @@ struct KParams {
     // per-lane plane offsets (in words)
     uint32_t off_ready, off_socks, off_handles, off_nodes, off_clog, off_pause, off_greg, off_conn;
     uint32_t uses_chan, max_conns, chan_queue, conn_words;   // reliable channel (connect1/accept1) state, if used
+    uint32_t chan_unit;            // index of the task unit holding the (tx, rx) pair state
     uint32_t uses_rpc, rpc_unit;   // typed RPC: index of the task unit holding the response tags
     uint32_t rq_in_reg;        // the ready queue needs no LDS region (register variant)
     uint32_t lifecycle;        // any kill/restart/pause/resume/abort op, init program or restart_on_panic node

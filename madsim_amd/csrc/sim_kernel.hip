@@ -48,7 +48,9 @@ namespace madsim_k {
 // Task state = 16-byte units [unit][lane] (ds_read/write_b128, conflict-free):
 //   unit0 {x: flags:8 | gen:16 | prog:8,  y: pc:16 | sub:8 | from:8,  z: cnt0:16 | cnt1:16,  w: val}
 //   unit1 {x: rxseq:8 | joiner:8 | joiner_gen:16,  y: -,  z: deadline lo,  w: deadline hi}
-//   unit2 {x: t0 lo, y: t0 hi, z/w: -}                       (only when the workload uses MS_OP_MARK)
+//   unit2 {x: t0 lo, y: t0 hi, z/w: timeout()'s deadline}   (only when the workload uses MS_OP_MARK / timeouts)
+//   unit[P.chan_unit] {x: conn:8 | side:1 | backoff ms:16, y: staged payload, z/w: arrive}   (reliable channel)
+//   unit[P.rpc_unit]  {x: rsp_tag in hand, y: rsp_tag staged with the oneshot value}        (typed RPC)
 enum : uint32_t { TF_ALIVE = 1, TF_SCHED = 2, TF_RUN = 4, TF_KILLED = 8, TF_CANCEL = 16, TF_INBOX = 32 };
 enum : uint32_t { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3 };
 enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
@@ -467,7 +469,7 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
     if (K::LIFE) { seq = NODEW(3); NODEW(3) = seq + 1; }      // spawn order matters only to NodeInfo::kill
     TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
     tu1_store<K>(c, slot, make_uint4(0xffu << 8, (seq & 0xffffff) | (info_gen << 24), 0, 0));   // rxseq 0, no awaiter; spawn order
-    if (K::LIFE && c.P.uses_chan) TU(c, slot, 3) = make_uint4(0xff, 0, 0, 0);                // no connection held
+    if (K::LIFE && c.P.uses_chan) TU(c, slot, c.P.chan_unit) = make_uint4(0xff, 0, 0, 0);                // no connection held
     if (K::LIFE && c.P.uses_rpc) TU(c, slot, c.P.rpc_unit) = make_uint4(0, 0, 0, 0);         // no request in hand
     ready_push<K>(c, L, slot);
     if (record) HW(prog) = H_RUNNING | (slot << 8) | (gen << 16);
@@ -483,8 +485,8 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
     uint32_t f = TWORD(c, slot, 0, 0);
     uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
     if (K::LIFE && c.P.uses_chan) {                          // the task's (Sender, Receiver) pair drops with its future
-        uint32_t cx = TWORD(c, slot, 3, 0);
-        if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, 3, 0) = cx | 0xff; }
+        uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+        if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
     }
     {
         uint32_t own = slot | (gen << 16);
@@ -765,15 +767,15 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (n == 0) { SW(c, a, base + 1) = 1u | (slot << 1) | (gen << 9); st = ST_PENDING; return false; }
         uint32_t id = (q >> 4) & 0x7f;
         SW(c, a, base) = (n - 1) | ((q >> 11) << 4);           // pop front
-        uint32_t cx = TWORD(c, slot, 3, 0);
+        uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
         if ((cx & 0xff) != 0xff) conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1);
-        TWORD(c, slot, 3, 0) = id | (1u << 8);                 // server side
+        TWORD(c, slot, c.P.chan_unit, 0) = id | (1u << 8);                 // server side
         return true;
     };
     // the receiver stream of channel() (net/mod.rs:386-400) from "a payload is in hand" (sub 1): either sleep(backoff)
     // while its State is None (sub 2) or sleep_until(arrive_time) (sub 3).  Always ends Pending (1 ms floor).
     auto crecv_arm = [&]() {
-        uint4 u3 = TU(c, slot, 3);
+        uint4 u3 = TU(c, slot, c.P.chan_unit);
         uint64_t arrive = u64of(u3.z, u3.w), d;
         if (arrive != ~0ull) { d = sleep_deadline(L, arrive); sub = 3; }
         else { d = sleep_deadline(L, L.clock + (uint64_t)(u3.x >> 16) * NS_PER_MS); sub = 2; }
@@ -824,20 +826,20 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     sub = 2;
                     if (!accept_check(a)) break;
                 } else if (K::LIFE && op == MS_OP_CRECV) {
-                    uint4 u3 = TU(c, slot, 3);
+                    uint4 u3 = TU(c, slot, c.P.chan_unit);
                     if (sub == 2) {                        // sleep(backoff) done: backoff = min(2 * backoff, 10 s); retry the link
                         uint32_t bo = (u3.x >> 16) * 2; if (bo > 10000) bo = 10000;
                         uint32_t cw = CONNW(u3.x & 0xff, 0);
                         uint64_t arrive = chan_test_link<K>(c, L, cw, 1 - ((u3.x >> 8) & 1));
                         u3.x = (u3.x & 0xffff) | (bo << 16); u3.z = (uint32_t)arrive; u3.w = (uint32_t)(arrive >> 32);
-                        TU(c, slot, 3) = u3;
+                        TU(c, slot, c.P.chan_unit) = u3;
                         crecv_arm();
                         break;
                     }
                     u0.w = u3.y;                           // sub 3: sleep_until(arrive_time) done -> yield value
                 } else if (K::LIFE && op == MS_OP_CONNECT) {   // NetSim::connect1 (net/mod.rs:345-363)
-                    uint32_t cx = TWORD(c, slot, 3, 0);
-                    if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, 3, 0) = cx | 0xff; }
+                    uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                    if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
                     uint64_t lat; int ds;
                     if (!try_send_fn<K>(c, L, SOCKW(c, a) & 0xff, b & 0xff, &lat, &ds)) {
                         u0.w = MADSIM_VAL_REFUSED;
@@ -850,7 +852,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         else {
                             CONNW(id, 0) = 1u | (a << 1) | ((uint32_t)ds << 7) | (0xfu << 13);
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
-                            TWORD(c, slot, 3, 0) = id;             // client side
+                            TWORD(c, slot, c.P.chan_unit, 0) = id;             // client side
                             u0.w = 0;
                             uint32_t n = q & 0xf;                  // socket.new_connection -> conn_tx.try_send
                             SW(c, ds, base) = (q & ~0xfu) | (n + 1) | (id << (4 + 7 * n));
@@ -1062,9 +1064,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_SPAWN: {
                 uint32_t child = spawn_task<K>(c, L, a, true, (PROGW(c, a) & 0xff) != node);
                 if (K::LIFE && P.uses_chan && (b & 2) && child != 0xffffffffu) {   // `async move`: the (tx, rx) pair moves
-                    uint32_t cx = TWORD(c, slot, 3, 0);
-                    TWORD(c, child, 3, 0) = cx & 0x1ff;
-                    TWORD(c, slot, 3, 0) = cx | 0xff;
+                    uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                    TWORD(c, child, c.P.chan_unit, 0) = cx & 0x1ff;
+                    TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff;
                 }
                 if (K::LIFE && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST) && child != 0xffffffffu) {   // rpc.rs:170
                     TWORD(c, child, 0, 3) = u0.w;
@@ -1148,7 +1150,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             case MS_OP_CSEND: {                            // PayloadSender::send (net/mod.rs:417-421)
                 if (!K::LIFE) { st = ST_PANIC; break; }
-                uint32_t cx = TWORD(c, slot, 3, 0);
+                uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                 if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
                 uint32_t id = cx & 0xff, side = (cx >> 8) & 1;
                 uint32_t cw = CONNW(id, 0);
@@ -1166,7 +1168,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             }
             case MS_OP_CRECV: {                            // rx.recv().await (net/mod.rs:386), sub == 0 here
                 if (!K::LIFE) { st = ST_PANIC; break; }
-                uint32_t cx = TWORD(c, slot, 3, 0);
+                uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                 if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
                 uint32_t id = cx & 0xff, dir = 1 - ((cx >> 8) & 1);
                 uint32_t cw = CONNW(id, 0);
@@ -1182,14 +1184,14 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 for (uint32_t i = 1; i < qn; i++)              // VecDeque::pop_front
                     for (uint32_t k = 0; k < 3; k++) CONNW(id, e0 + (i - 1) * 3 + k) = CONNW(id, e0 + i * 3 + k);
                 CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * dir))) | ((qn - 1) << (17 + 4 * dir));
-                TU(c, slot, 3) = u3;
+                TU(c, slot, c.P.chan_unit) = u3;
                 crecv_arm();
                 break;
             }
             case MS_OP_CCLOSE: {
                 if (!K::LIFE) { st = ST_PANIC; break; }
-                uint32_t cx = TWORD(c, slot, 3, 0);
-                if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, 3, 0) = cx | 0xff; }
+                uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
                 pc++;
                 break;
             }

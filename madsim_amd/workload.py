@@ -433,17 +433,22 @@ def kv_rpc(n_clients=4, n_ops=8):
 
 def raft_election_limits():
     """Device capacities the election loop needs (high-water marks over 4 000 seeds on the CPU oracle: timer heap 95
-    — the duplicate timers of timeout() — so most of it lives in the HBM spill region; 67 dead recv registrations)."""
+    — the duplicate timers of timeout() — so most of it lives in the HBM spill region; 43 dead recv registrations
+    per socket, 6 queued messages).  Sized to the high-water marks: per-seed LDS is what bounds seeds per CU."""
     lim = A.Limits()
     lim.heap_lds_slots, lim.heap_spill_slots = 16, 240
-    lim.mbox_regs, lim.mbox_msgs = 96, 12
+    lim.mbox_regs, lim.mbox_msgs = 48, 8
     return lim
 
 
 def kv_rpc_limits():
+    """High-water marks of the KV workload: 11 live tasks, 6 timers, 4 connections with 1 queued payload, datagram
+    mailboxes unused (everything rides the reliable channel)."""
     lim = A.Limits()
-    lim.max_tasks = 16
-    lim.heap_lds_slots, lim.heap_spill_slots = 8, 24
+    lim.max_tasks = 12
+    lim.heap_lds_slots, lim.heap_spill_slots = 8, 0
+    lim.mbox_regs, lim.mbox_msgs = A.LIMIT_NONE, A.LIMIT_NONE
+    lim.max_conns, lim.chan_queue = 4, 1
     return lim
 
 

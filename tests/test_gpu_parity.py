@@ -239,13 +239,20 @@ def test_config2_election_loop_262144_seeds(hip):
     """BASELINE configs[2]: 5-node election loop with NetSim partition injection, 262 144 seeds on one GPU
     (timeout() duplicate timers push most of the timer heap into the HBM spill region)."""
     w, lim = W.raft_election(), W.raft_election_limits()
-    got, summ = hip.run_batch(w, 0, 262144, None, lim)
+    # capacities sized to the common case; the rare seed that outgrows them (dead registrations pile up: the
+    # reference's Vec is unbounded) comes back MADSIM_OVERFLOW and is re-run with doubled capacities
+    first, _ = hip.run_batch(w, 0, 262144, None, lim)
+    n_over = int((first["verdict"] == A.OVERFLOW).sum())
+    assert n_over < 262144 // 100
+    got, summ = hip.run_batch_auto(w, 0, 262144, None, lim)
     assert summ.n_failed == 0 and (got["verdict"] == A.PASS).all()
     assert len(np.unique(got["trace_hash"])) == 262144
-    for s in [(k * 4093) % 262144 for k in range(96)]:
-        want, _ = oracle.run_batch(w, s, 1, None, lim)
+    over = np.nonzero(first["verdict"] == A.OVERFLOW)[0][:16]
+    for s in [(k * 4093) % 262144 for k in range(96)] + [int(i) for i in over]:
+        want, _ = oracle.run_batch(w, s, 1)
         assert got[s] == want[0], f"seed {s}"
-    _cmp(hip, w, 1_000_000, 2048, A.Config.default(packet_loss_rate=0.05), lim)
+    big = hip.grow_limits(lim)
+    _cmp(hip, w, 1_000_000, 2048, A.Config.default(packet_loss_rate=0.05), big)
 
 
 def test_config3_kv_rpc_131072_seeds(hip):
