@@ -260,6 +260,14 @@ int madsim_hip_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg,
                          uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
                          madsim_result_t* out, madsim_summary_t* summary);
 
+/* madsim_hip_run_batch, then every seed that came back MADSIM_OVERFLOW is run again with doubled device capacities,
+ * up to `max_rounds` times, and the summary is recomputed over the final results.  The reference's containers are
+ * unbounded (Vec mailboxes, BinaryHeap timers), so a capacity verdict is never a test verdict: this is the entry
+ * point a Builder::run replacement calls.  `out` must not be NULL. */
+int madsim_hip_run_batch_auto(const madsim_workload_t* w, const madsim_config_t* cfg,
+                              uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
+                              madsim_result_t* out, madsim_summary_t* summary, int max_rounds);
+
 /* Same, results stay resident in HBM: `d_out` is device memory [count] owned by the caller,
  * `stream` is a hipStream_t (NULL = the null stream).  Asynchronous unless `summary` != NULL
  * (the summary needs a device reduction + D2H of 32 bytes, which synchronises `stream`). */

@@ -267,7 +267,7 @@ struct Builder {
         }
         std::vector<madsim_result_t> out(count);
         madsim_summary_t s{};
-        madsim::check(madsim_hip_run_batch(&w, &cfg, seed, count, &lim, out.data(), &s));
+        madsim::check(madsim_hip_run_batch_auto(&w, &cfg, seed, count, &lim, out.data(), &s, 6));   // capacity verdicts are re-run
         if (s.n_failed) {
             panic_with_info(s.first_failing_seed);
             throw SimulationFailure(s.first_failing_seed, out[s.first_failing_seed - seed]);

@@ -291,6 +291,55 @@ int madsim_hip_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg,
     return 0;
 }
 
+int madsim_hip_run_batch_auto(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                              const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary, int max_rounds) {
+    if (!out && count) { std::lock_guard<std::mutex> lk(g_mu); return fail(MADSIM_E_ARG, "run_batch_auto needs the result array"); }
+    auto t0 = std::chrono::steady_clock::now();
+    madsim_summary_t s{};
+    int rc = madsim_hip_run_batch(w, cfg, seed0, count, lim, out, &s);
+    if (rc) return rc;
+    madsim_limits_t L{};
+    if (lim) L = *lim;
+    double kernel_ms = s.kernel_ms;
+    for (int round = 0; round < max_rounds; round++) {
+        bool any = false;
+        for (uint64_t i = 0; i < count; i++) any |= out[i].verdict == MADSIM_OVERFLOW;
+        if (!any) break;
+        // double every capacity (defaults spelled out first); the lane geometry follows the new per-seed footprint
+        auto dbl = [](uint32_t v, uint32_t dflt, uint32_t cap) { uint32_t x = (v == 0 || v == MADSIM_LIMIT_NONE) ? dflt : v; x *= 2; return x > cap ? cap : x; };
+        L.lanes_per_wave = 0;
+        L.heap_lds_slots = L.heap_lds_slots ? L.heap_lds_slots : 8;
+        L.heap_spill_slots = dbl(L.heap_spill_slots, 32, 1u << 20);
+        L.max_tasks = dbl(L.max_tasks, w->n_progs + 8, 254);
+        L.mbox_regs = dbl(L.mbox_regs, 2, 255);
+        L.mbox_msgs = dbl(L.mbox_msgs, 2, 255);
+        L.max_conns = dbl(L.max_conns, 4, 127);
+        L.chan_queue = dbl(L.chan_queue, 2, 15);
+        for (uint64_t i = 0; i < count;) {                  // contiguous runs of overflowed seeds
+            if (out[i].verdict != MADSIM_OVERFLOW) { i++; continue; }
+            uint64_t j = i;
+            while (j + 1 < count && out[j + 1].verdict == MADSIM_OVERFLOW) j++;
+            madsim_summary_t part{};
+            rc = madsim_hip_run_batch(w, cfg, seed0 + i, j - i + 1, &L, out + i, &part);
+            if (rc) return rc;
+            kernel_ms += part.kernel_ms;
+            i = j + 1;
+        }
+    }
+    if (summary) {
+        madsim_summary_t f{};
+        f.first_failing_seed = UINT64_MAX;
+        for (uint64_t i = 0; i < count; i++) {
+            if (out[i].verdict != MADSIM_PASS) { if (!f.n_failed) f.first_failing_seed = seed0 + i; f.n_failed++; }
+            f.total_steps += out[i].steps; f.total_clock_ns += out[i].clock_ns;
+        }
+        f.kernel_ms = kernel_ms;
+        f.wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        *summary = f;
+    }
+    return 0;
+}
+
 int64_t madsim_hip_trace_seed(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
                               const madsim_limits_t* lim, uint8_t* log, uint64_t cap, madsim_result_t* out) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -71,6 +71,8 @@ def lib():
         L.madsim_hip_trace_seed.restype = C.c_int64
         L.madsim_hip_trace_seed.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64,
                                             C.POINTER(A.Limits), C.c_void_p, C.c_uint64, C.POINTER(A.Result)]
+        L.madsim_hip_run_batch_auto.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64, C.c_uint64,
+                                                C.POINTER(A.Limits), C.c_void_p, C.POINTER(A.Summary), C.c_int]
         L.madsim_hip_geometry.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Limits), C.POINTER(A.Geometry)]
         L.madsim_workload_pingpong.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(A.Node), C.POINTER(A.Prog),
                                                C.POINTER(A.Sock), C.POINTER(A.Insn), C.c_uint32,
@@ -133,28 +135,17 @@ def grow_limits(lim):
 
 
 def run_batch_auto(workload, seed0, count, config=None, limits=None, max_rounds=5):
-    """run_batch, then re-run only the seeds that exceeded a device capacity with doubled capacities until none is
-    left (the reference's containers are unbounded; a capacity verdict is never a final answer)."""
+    """madsim_hip_run_batch_auto: run_batch, then only the seeds that exceeded a device capacity are run again with
+    doubled capacities until none is left (the reference's containers are unbounded; a capacity verdict is never a
+    final answer)."""
+    if _inited_device is None:
+        init(0)
+    cfg = config or A.Config.default()
     lim = limits or A.Limits()
-    out, summ = run_batch(workload, seed0, count, config, lim)
-    for _ in range(max_rounds):
-        todo = np.nonzero(out["verdict"] == A.OVERFLOW)[0]
-        if len(todo) == 0:
-            break
-        lim = grow_limits(lim)
-        start = 0
-        while start < len(todo):                       # contiguous runs of overflowed seeds
-            end = start
-            while end + 1 < len(todo) and todo[end + 1] == todo[end] + 1:
-                end += 1
-            part, _ = run_batch(workload, seed0 + int(todo[start]), int(todo[end] - todo[start]) + 1, config, lim)
-            out[todo[start]:todo[end] + 1] = part
-            start = end + 1
-    fails = np.nonzero(out["verdict"] != A.PASS)[0]
-    summ.n_failed = len(fails)
-    summ.first_failing_seed = seed0 + int(fails[0]) if len(fails) else A.U64_MAX
-    summ.total_steps = int(out["steps"].astype(np.int64).sum())
-    summ.total_clock_ns = int(out["clock_ns"].astype(np.int64).sum())
+    out = np.zeros(count, dtype=A.RESULT_DTYPE)
+    summ = A.Summary()
+    _check(lib().madsim_hip_run_batch_auto(workload.ref(), C.byref(cfg), seed0, count, C.byref(lim),
+                                           out.ctypes.data_as(C.c_void_p), C.byref(summ), max_rounds))
     return out, summ
 
 

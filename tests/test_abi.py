@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     L = runtime.lib()
     names = set(re.findall(r"\b(madsim_(?:hip|workload)_[a-z_]+)\s*\(", HEADER))
     assert {"madsim_hip_run_batch", "madsim_hip_run_batch_device", "madsim_hip_trace_seed", "madsim_hip_init",
-            "madsim_hip_shutdown", "madsim_hip_version", "madsim_hip_geometry", "madsim_workload_pingpong",
+            "madsim_hip_shutdown", "madsim_hip_version", "madsim_hip_geometry", "madsim_workload_pingpong", "madsim_hip_run_batch_auto",
             "madsim_hip_strerror", "madsim_hip_last_error"} <= names
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/madsim_hip.h but not exported"

@@ -102,7 +102,8 @@ def test_baseline_config_shaped_workloads():
     """configs[2]-shaped election loop (timeouts, partitions, HBM heap spill) and configs[3]-shaped KV-RPC."""
     o = _same(W.raft_election(), 0, 300, None, W.raft_election_limits())
     assert (o["verdict"] == A.PASS).all()
-    o = _same(W.raft_election(), 0, 300, A.Config.default(packet_loss_rate=0.05), W.raft_election_limits())
+    big = W.raft_election_limits(); big.mbox_regs, big.mbox_msgs = 96, 16      # loss: more timeouts, more dead registrations
+    o = _same(W.raft_election(), 0, 300, A.Config.default(packet_loss_rate=0.05), big)
     o = _same(W.kv_rpc(), 0, 300, None, W.kv_rpc_limits())
     assert (o["verdict"] == A.PASS).all()
 
