@@ -102,6 +102,7 @@ def main():
     # 32-byte report are all queued on the stream; the host never waits inside the timed region.
     use_device_report = world == 1 or backend == "nccl"
     ring = torch.zeros((args.steps + args.warmup, 4), dtype=torch.int64, device=dev)   # one 32-byte report per step
+    gathered = torch.zeros((args.steps + args.warmup, world, 4), dtype=torch.int64, device=dev) if world > 1 else None
 
     def step(k, timed):
         # a fresh block of seeds every step so nothing is cached between steps
@@ -117,7 +118,7 @@ def main():
                 ev.record(streams[si])
                 report_stream.wait_event(ev)
                 with torch.cuda.stream(report_stream):
-                    mdist.reduce_report_device(ring[k])
+                    mdist.gather_report_device(ring[k], gathered[k])     # ONE all-gather of 32 bytes per step
         else:   # functional-test hook (gloo on a 1-GPU box): host-side report
             sm = runtime.run_batch_device(w, seed0 + k * total, count, d_out.data_ptr(), stream, None, lim)
             rep = mdist.reduce_report(sm.first_failing_seed, sm.n_failed, sm.total_steps, sm.total_clock_ns, cdev)
@@ -140,7 +141,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if use_device_report:
-        rows = ring[args.warmup:].cpu()
+        rows = (mdist.combine_gathered(gathered[args.warmup:]) if world > 1 else ring[args.warmup:]).cpu()
         nfail, steps_total, clock_total = (int(x) for x in rows[:, 1:4].sum(dim=0).tolist())
         nslots = min(args.steps, 64)
         kernel_ms = sum(runtime.timing_ms((args.warmup + args.steps - 1 - i) % 64) for i in range(nslots)) * args.steps / nslots

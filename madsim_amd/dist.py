@@ -4,7 +4,8 @@ Seeds are independent (the reference shares nothing between seeds but the read-o
 madsim/src/sim/runtime/builder.rs:129-150), so rank g simply runs the contiguous block
 [seed0 + g*ceil(count/G), ...).  The single exchange is the end-of-batch report: one all-reduce(min) on
 the first failing seed and one all-reduce(sum) on the failure / step / sim-time counters
-(RCCL over xGMI when the backend is "nccl"; "gloo" on CPU for tests).  Payload: 32 bytes.
+(RCCL over xGMI when the backend is "nccl"; "gloo" on CPU for tests), or a single all-gather of the 32-byte
+reports (gather_report_device) folded afterwards.  Payload: 32 bytes.
 """
 import torch
 import torch.distributed as dist
@@ -49,6 +50,22 @@ def reduce_report_device(summary4, group=None):
         dist.all_reduce(summary4[0:1], op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(summary4[1:4], op=dist.ReduceOp.SUM, group=group)
     return summary4
+
+
+def gather_report_device(summary4, gathered, group=None):
+    """The single-collective form: one RCCL all-gather of the 32-byte report into `gathered` (int64[world, 4], same
+    device), no host synchronisation.  `combine_gathered` folds the rows later, on the host or on the device."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_gather_into_tensor(gathered.view(-1), summary4, group=group)
+    else:
+        gathered.view(-1)[:4].copy_(summary4)
+    return gathered
+
+
+def combine_gathered(gathered):
+    """int64[..., world, 4] of gather_report_device -> (first failing seed key, n_failed, total_steps, total_clock_ns)
+    reduced over the world axis: signed MIN of the keys (= unsigned minimum of the seeds), SUM of the counters."""
+    return torch.cat([gathered[..., 0].min(dim=-1, keepdim=True).values, gathered[..., 1:].sum(dim=-2)], dim=-1)
 
 
 def decode_first_fail(key):

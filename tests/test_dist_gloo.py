@@ -44,7 +44,11 @@ def _worker(rank, world, port, q):
     t4 = torch.tensor([key, s.n_failed, s.total_steps, s.total_clock_ns], dtype=torch.int64)
     mdist.reduce_report_device(t4)
     rep3 = (mdist.decode_first_fail(t4[0]), int(t4[1]), int(t4[2]), int(t4[3]))
-    q.put((rank, rep, rep2, rep3))
+    # the single-gather form
+    t4 = torch.tensor([key, s.n_failed, s.total_steps, s.total_clock_ns], dtype=torch.int64)
+    g = mdist.combine_gathered(mdist.gather_report_device(t4, torch.zeros((world, 4), dtype=torch.int64)))
+    rep4 = (mdist.decode_first_fail(g[0]), int(g[1]), int(g[2]), int(g[3]))
+    q.put((rank, rep, rep2, rep3, rep4))
     dist.destroy_process_group()
 
 
@@ -65,7 +69,8 @@ def test_two_rank_first_fail_report():
     out, s = oracle.run_batch(W.pingpong(4, 16), 0, 600, A.Config.default(packet_loss_rate=0.02))
     want = (s.first_failing_seed, s.n_failed, s.total_steps, s.total_clock_ns)
     assert s.n_failed > 0
-    for rank, rep, rep2, rep3 in res:
+    for rank, rep, rep2, rep3, rep4 in res:
         assert rep == want, (rank, rep, want)
         assert rep2[0] == 5
         assert rep3 == want, (rank, rep3, want)
+        assert rep4 == want, (rank, rep4, want)
