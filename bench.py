@@ -39,7 +39,7 @@ def main():
                          "a second batch in flight on another stream fills the second wave slot the per-seed LDS allows")
     ap.add_argument("--heap-lds", type=int, default=4, help="timer-heap entries kept in LDS (the rest spill to HBM)")
     ap.add_argument("--generic", action="store_true", help="force the generic kernel variant (HBM heap spill enabled)")
-    ap.add_argument("--workload", default="pingpong", choices=["pingpong", "raft", "kv", "timers"],
+    ap.add_argument("--workload", default="pingpong", choices=["pingpong", "raft", "kv", "timers", "topo"],
                     help="pingpong = BASELINE configs[1] (the headline); raft / kv = configs[2] / configs[3]-shaped extras")
     args = ap.parse_args()
 
@@ -82,6 +82,9 @@ def main():
     elif args.workload == "timers":
         w, lim = workload.timer_storm(), workload.timer_storm_limits(args.heap_lds)
         wname = f"timer storm: 24 tasks x sleep(gen_range(0..2 s)), heap_lds={args.heap_lds} (HBM heap-spill path)"
+    elif args.workload == "topo":
+        w, lim = workload.streaming_topology(), workload.streaming_topology_limits()
+        wname = "16-node streaming topology: KV meta + typed-RPC brokers + 12 compute nodes (configs[4] shape)"
     else:
         w, lim = workload.kv_rpc(), workload.kv_rpc_limits()
         wname = "etcd-style KV ops over connect1/accept1 (configs[3] shape)"

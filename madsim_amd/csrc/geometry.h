@@ -215,7 +215,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     const uint32_t best = std::max(waves_at(1), std::max(waves_at(2), waves_at(4)));
     uint32_t W = 1;
     for (uint32_t w2 = 4; w2 >= 1; w2 >>= 1)
-        if (waves_at(w2) + 1 >= best && waves_at(w2) > 0) { W = w2; break; }   // the largest W within one wave of the best
+        if (waves_at(w2) + (best >= 8 ? 1u : 0u) >= best && waves_at(w2) > 0) { W = w2; break; }   // largest W within one wave of the best (none to spare below 8)
     if (want < W) W = want > 1 ? 2 : 1;
     P.waves_per_block = W;
     G->lds_bytes = (P.sh_heap + W * P.wave_words) * 4;

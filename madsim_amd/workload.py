@@ -431,6 +431,79 @@ def kv_rpc(n_clients=4, n_ops=8):
     return wl.build()
 
 
+def streaming_topology(n_compute=12, n_brokers=3, rounds=4):
+    """BASELINE configs[4] shape: a 16-node streaming deployment (1 meta + 3 brokers + 12 compute nodes) built from the
+    event shapes of the simulators such a system runs on — meta = etcd-style KV service over connect1/accept1 with its
+    1 s tick task (madsim-etcd-client/src/server.rs:34-40, service.rs:27-33); brokers = typed-RPC handlers, one task per
+    request (net/rpc.rs:152-179, the madsim-rdkafka sim_broker shape); compute nodes register with meta, then loop
+    { produce to a broker with call_timeout; exchange a barrier datagram with the next compute node under timeout() }.
+    A supervisor clogs one broker for a while and restarts another (init task re-binds).  Dozens of concurrent timers
+    (timeouts' duplicate timers, ticks, backoffs) push the event heap into the HBM spill region."""
+    REQ, RSP, ACK = 0x11, 0x22, 0x5A
+    wl = WorkloadBuilder()
+    meta = wl.create_node()
+    a_meta = wl.addr(meta, 2379)
+    h = wl.task(meta)
+    h.chan_recv(); h.assert_val(REQ); h.flag_add(0, 1); h.chan_send(RSP)
+    tick = wl.task(meta)
+    top = tick.label()
+    tick.flag_add(1, 1); tick.sleep(secs=1); tick.jmp(top)
+    ms = wl.task(meta)
+    ms.bind(a_meta); ms.spawn(tick)
+    top = ms.label()
+    ms.accept1(a_meta); ms.spawn(h, move_conn=True); ms.jmp(top)
+    brokers = []
+    for b in range(n_brokers):
+        n = wl.create_node(); a = wl.addr(n, 9092)
+        bh = wl.task(n)
+        bh.sleep(ms=2 + b); bh.flag_add(2, 1); bh.rpc_reply(a, ACK)
+        bs = wl.task(n, init=True)
+        bs.bind(a)
+        top = bs.label()
+        bs.rpc_recv(a, 0); bs.spawn(bh, move_request=True); bs.jmp(top)
+        brokers.append((n, a))
+    nodes = [wl.create_node() for _ in range(n_compute)]
+    addrs = [wl.addr(n, 5688) for n in nodes]
+    computes = []
+    for i in range(n_compute):
+        c = wl.task(nodes[i])
+        c.bind(addrs[i]); c.sleep(ms=5 + 7 * i)
+        c.connect1(addrs[i], a_meta); c.assert_val(0); c.chan_send(REQ); c.chan_recv(); c.assert_val(RSP); c.chan_close()
+        c.set(0, rounds)
+        top = c.label()
+        c.rpc_call(addrs[i], brokers[i % n_brokers][1], 0, i, timeout_ms=200)
+        c.trace(700 + i)                                             # ACK or TIMEOUT: both are fine, both are observed
+        c.send_to(addrs[i], addrs[(i + 1) % n_compute], 1, 0xB0 + i)
+        c.recv_from_timeout(addrs[i], 1, ms=40)
+        c.trace(800 + i)
+        c.sleep_rand(lo_ms=0, ms=30)
+        c.djnz(0, top)
+        computes.append(c)
+    m = wl.main()
+    m.spawn(ms)
+    for n, _ in brokers:
+        m.build_node(n)
+    for c in computes:
+        m.spawn(c)
+    m.sleep(ms=60); m.clog_node(brokers[0][0], "both")
+    m.sleep(ms=150); m.unclog_node(brokers[0][0], "both")
+    m.kill(brokers[1][0]); m.sleep(ms=50); m.restart(brokers[1][0])
+    for c in computes:
+        m.join(c)
+    m.assert_flag(0, n_compute)
+    return wl.build()
+
+
+def streaming_topology_limits():
+    """Capacities for streaming_topology: a small LDS heap quota with the bulk in the HBM spill region."""
+    lim = A.Limits()
+    lim.max_tasks = 28
+    lim.heap_lds_slots, lim.heap_spill_slots = 8, 184
+    lim.mbox_regs, lim.mbox_msgs = 6, 5
+    lim.max_conns, lim.chan_queue = 4, 1
+    return lim
+
+
 def raft_election_limits():
     """Device capacities the election loop needs (high-water marks over 4 000 seeds on the CPU oracle: timer heap 95
     — the duplicate timers of timeout() — so most of it lives in the HBM spill region; 43 dead recv registrations

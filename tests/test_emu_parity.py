@@ -106,6 +106,8 @@ def test_baseline_config_shaped_workloads():
     o = _same(W.raft_election(), 0, 300, A.Config.default(packet_loss_rate=0.05), big)
     o = _same(W.kv_rpc(), 0, 300, None, W.kv_rpc_limits())
     assert (o["verdict"] == A.PASS).all()
+    o = _same(W.streaming_topology(), 0, 96, None, W.streaming_topology_limits())        # configs[4] shape
+    assert (o["verdict"] == A.PASS).all()
 
 
 def test_fuzz_rpc_workloads():

@@ -268,6 +268,23 @@ def test_config3_kv_rpc_131072_seeds(hip):
     _cmp(hip, w, 6_000_000, 2048, A.Config.default(loss_table=(0.0, 0.2, 1.0)), lim)
 
 
+def test_config4_streaming_topology_524288_seeds(hip):
+    """BASELINE configs[4] per-GPU share (4 194 304 seeds / 8 GPUs): 16-node streaming topology (etcd-style meta service,
+    typed-RPC brokers, 12 compute nodes, broker clog + restart), event heap mostly in the HBM spill region."""
+    w, lim = W.streaming_topology(), W.streaming_topology_limits()
+    g = hip.geometry(w, lim)
+    assert g.heap_spill_slots > 8 * g.heap_lds_slots
+    n = 524288
+    got, summ = hip.run_batch_auto(w, 0, n, None, lim)
+    assert summ.n_failed == 0 and (got["verdict"] == A.PASS).all()
+    assert len(np.unique(got["trace_hash"])) == n                      # every seed took its own path
+    assert (got["msg_count"] >= 12 * 2).all()                          # at least the 12 registrations with meta
+    for s in [(k * 8191) % n for k in range(64)]:
+        want, _ = oracle.run_batch(w, s, 1)
+        assert got[s] == want[0], f"seed {s}"
+    _cmp(hip, w, 7_000_000, 1024, A.Config.default(packet_loss_rate=0.03), hip.grow_limits(lim))
+
+
 def test_async_entry_point_device_summary(hip):
     """madsim_hip_run_batch_async: no host copies; the 4-word report lands in HBM in all-reduce-ready form."""
     import torch
