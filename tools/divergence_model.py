@@ -26,19 +26,28 @@ NAMES = {0: "iteration top", 1: "gen_index attempt", 26: "poll (task popped)", 2
          17: "[C] sleep begin (+timer)", 10: "timer_add", 11: "sift_up trip", 18: "advance 50..100 ns draw attempt",
          19: "fire/idle loop trip", 20: "timer_pop", 21: "sift_down trip", 22: "fire: wake", 23: "fire: deliver",
          24: "deliver: registration scan trip", 25: "result write + seed init"}
-w = workload.pingpong(4, 64)
-lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots, lim.mbox_regs, lim.mbox_msgs = 4, 0, 1, A.LIMIT_NONE
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 cus = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+which = sys.argv[3] if len(sys.argv) > 3 else "pingpong"
+if which == "pingpong":
+    w = workload.pingpong(4, 64)
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots, lim.mbox_regs, lim.mbox_msgs = 4, 0, 1, A.LIMIT_NONE
+else:
+    w, lim = {"kv": (workload.kv_rpc, workload.kv_rpc_limits), "raft": (workload.raft_election, workload.raft_election_limits),
+              "topo": (workload.streaming_topology, workload.streaming_topology_limits)}[which]
+    w, lim = w(), lim()
 cfg = A.Config.default()
 out = np.zeros(count, dtype=A.RESULT_DTYPE)
 rc = L.madsim_emu_run_batch(w.ref(), C.byref(cfg), 0, count, C.byref(lim), out.ctypes.data_as(C.c_void_p), cus, None, 0, None)
 assert rc == 0
 trips = (C.c_double * 32)(); visits = (C.c_double * 32)(); iters = C.c_double()
 L.madsim_emu_region_stats(trips, visits, C.byref(iters))
+L.madsim_emu_geometry.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Limits), C.POINTER(A.Geometry)]
+geo = A.Geometry(); L.madsim_emu_geometry(w.ref(), C.byref(lim), C.byref(geo)); LW = geo.lanes_per_wave
 it = iters.value
+print(f"{which}: {LW} seed lanes per wave")
 print(f"{count} seeds, {it:.0f} wave-iterations, executor steps {int(out['steps'].sum())}, lane-steps per wave-iteration {out['steps'].sum() / it:.1f}")
 print(f"{'region':44s} {'wave trips/iter':>16s} {'lane visits/iter':>17s} {'utilisation':>12s}")
 for i in sorted(NAMES, key=lambda k: list(NAMES).index(k)):
     if trips[i] == 0: continue
-    print(f"{NAMES[i]:44s} {trips[i] / it:16.3f} {visits[i] / it / 64:17.3f} {visits[i] / (64 * trips[i]):12.3f}")
+    print(f"{NAMES[i]:44s} {trips[i] / it:16.3f} {visits[i] / it / LW:17.3f} {visits[i] / (LW * trips[i]):12.3f}")
