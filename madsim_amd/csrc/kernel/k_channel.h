@@ -1,0 +1,63 @@
+// k_channel.h — Reliable channel helpers (connect1 / accept1 / channel) and the link test as a function.
+// Part of sim_kernel.hip (included in this order: k_state, k_rng, k_timer, k_net, k_lifecycle, k_channel, k_poll).
+#ifndef MADSIM_K_CHANNEL_H
+#define MADSIM_K_CHANNEL_H
+
+namespace madsim_k {
+
+// ---- reliable channel (NetSim::connect1 / channel, net/mod.rs:337-430) — LIFE variants only ---------------------
+// Network::try_send as a function (the datagram path has it inlined in poll_task's [A] stage).
+template <class K>
+__device__ bool try_send_fn(const Ctx& c, Lane& L, uint32_t src_node, uint32_t dst_addr, uint64_t* latency, int* dst_sock) {
+    const KParams& P = c.P;
+    uint32_t dst_node = SOCKW(c, dst_addr) & 0xff;
+    bool clogged = false;
+    if (P.has_clog) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
+    if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
+    if (clogged) return false;
+    if (gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) return false;
+    L.msg_count++;
+    *latency = sample_latency<K>(c, L);
+    int ds = find_bound<K>(c, dst_addr);
+    if (ds < 0) return false;
+    *dst_sock = ds;
+    return true;
+}
+
+// the `test_link` closure of channel() (net/mod.rs:375-380): Some(now + latency) or None
+template <class K>
+__device__ uint64_t chan_test_link(const Ctx& c, Lane& L, uint32_t cw, uint32_t dir) {
+    uint32_t c_ep = (cw >> 1) & 0x3f, s_ep = (cw >> 7) & 0x3f;
+    uint64_t lat; int ds;
+    if (!try_send_fn<K>(c, L, SOCKW(c, dir == 0 ? c_ep : s_ep) & 0xff, dir == 0 ? s_ep : c_ep, &lat, &ds)) return ~0ull;
+    return L.clock + lat;
+}
+
+// drop the (Sender, Receiver) pair of one end of connection `id`
+template <class K>
+__device__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side) {
+    uint32_t cw = CONNW(id, 0);
+    if (cw & (1u << (13 + 2 * side))) {                       // my PayloadSender: last mpsc sender gone
+        cw &= ~(1u << (13 + 2 * side));
+        uint32_t r = CONNW(id, 1 + side);
+        if (r & 1) { CONNW(id, 1 + side) = 0; CONNW(id, 0) = cw; wake<K>(c, L, (r >> 1) & 0xff, r >> 9); }   // parked receiver sees None
+    }
+    cw &= ~(1u << (14 + 2 * (1 - side)));                     // my PayloadReceiver
+    CONNW(id, 1 + (1 - side)) = 0;
+    if (!(cw & (0xfu << 13))) cw = 0;                          // all four handles gone: slot is free
+    CONNW(id, 0) = cw;
+}
+
+// the listening Endpoint is dropped: connections still queued in conn_rx go with it
+template <class K>
+__device__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s) {
+    uint32_t base = 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs;
+    uint32_t q = SW(c, s, base);
+    SW(c, s, base) = 0; SW(c, s, base + 1) = 0;
+    uint32_t n = q & 0xf;
+    for (uint32_t i = 0; i < n; i++) conn_drop_handles<K>(c, L, (q >> (4 + 7 * i)) & 0x7f, 1);
+}
+
+}  // namespace madsim_k
+
+#endif

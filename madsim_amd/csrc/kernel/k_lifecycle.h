@@ -1,0 +1,134 @@
+// k_lifecycle.h — Task spawn / finish and node lifecycle (kill, restart, pause).
+// Part of sim_kernel.hip (included in this order: k_state, k_rng, k_timer, k_net, k_lifecycle, k_channel, k_poll).
+#ifndef MADSIM_K_LIFECYCLE_H
+#define MADSIM_K_LIFECYCLE_H
+
+namespace madsim_k {
+
+// ---- task lifecycle ----------------------------------------------------------------------------
+// `via_handle`: spawned through a NodeHandle captured at build() (NodeHandle::spawn from another node's task:
+// that Spawner holds the ORIGINAL Arc<NodeInfo>); otherwise task::spawn / init on the node's current info.
+template <class K>
+__device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record, bool via_handle = false) {
+    uint32_t slot = 0;
+    while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
+    if (slot >= c.P.max_tasks) { L.ovf = 1; return 0xffffffffu; }
+    uint32_t gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
+    uint32_t pw = PROGW(c, prog);
+    uint32_t node = pw & 0xff;
+    uint32_t killed = 0, info_gen = 0;
+    if (K::LIFE) {
+        uint32_t cur_gen = NODE_INFO_GEN(node);
+        info_gen = cur_gen;
+        if (via_handle && cur_gen != 0) { killed = 1; info_gen = 0; }             // stale handle: dead info
+        else killed = ((via_handle ? NODEW(2) : NODEW(0)) >> node) & 1;          // task/mod.rs:632-634
+    }
+    uint32_t seq = 0;
+    if (K::LIFE) { seq = NODEW(3); NODEW(3) = seq + 1; }      // spawn order matters only to NodeInfo::kill
+    TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
+    tu1_store<K>(c, slot, make_uint4(0xffu << 8, (seq & 0xffffff) | (info_gen << 24), 0, 0));   // rxseq 0, no awaiter; spawn order
+    if (K::LIFE && c.P.uses_chan) TU(c, slot, c.P.chan_unit) = make_uint4(0xff, 0, 0, 0);                // no connection held
+    if (K::LIFE && c.P.uses_rpc) TU(c, slot, c.P.rpc_unit) = make_uint4(0, 0, 0, 0);         // no request in hand
+    ready_push<K>(c, L, slot);
+    if (record) HW(prog) = H_RUNNING | (slot << 8) | (gen << 16);
+    return slot;
+}
+
+template <class K> __device__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side);
+template <class K> __device__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s);
+
+// The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
+template <class K>
+__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome) {
+    uint32_t f = TWORD(c, slot, 0, 0);
+    uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
+    if (K::LIFE && c.P.uses_chan) {                          // the task's (Sender, Receiver) pair drops with its future
+        uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+        if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
+    }
+    {
+        uint32_t own = slot | (gen << 16);
+        for (uint32_t i = 0; i < c.P.n_socks; i++) {
+            if (SW(c, i, 1) != own) continue;
+            // BindGuard::drop (net/mod.rs:483-493), skipped when the binder's NodeInfo is killed
+            if (!(f & TF_KILLED) && (SW(c, i, 0) & 1)) SW(c, i, 0) &= ~1u;
+            if (K::LIFE && c.P.uses_chan && (SW(c, i, 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, i);
+        }
+    }
+    uint32_t h = HW(prog);
+    if (h == (H_RUNNING | (slot << 8) | (gen << 16))) { HW(prog) = (h & ~3u) | outcome; if (prog == 0) L.main_done = 1; }
+    uint32_t link = TWORD(c, slot, 1, 0);
+    TWORD(c, slot, 0, 0) = f & ~(TF_ALIVE | TF_SCHED | TF_RUN | TF_INBOX);
+    uint32_t j = (link >> 8) & 0xff;
+    if (j != 0xff) wake<K>(c, L, j, link >> 16);              // async-task notifies the awaiter
+}
+
+// NodeInfo::kill (task/mod.rs:133-140): mark + wake every live task holding NodeInfo `info_gen` of `node`, in
+// spawn order (the order of NodeInfo.tasks).  Tasks carry their spawn sequence number, so no list is stored.
+template <class K>
+__device__ void info_kill(const Ctx& c, Lane& L, uint32_t node, uint32_t info_gen) {
+    uint32_t last = 0xffffffffu;                            // "none yet": sequence numbers are < 2^24
+    for (;;) {
+        uint32_t best = 0xffffffffu, best_seq = 0xffffffffu;
+        for (uint32_t t = 0; t < c.P.max_tasks; t++) {
+            uint32_t f = TWORD(c, t, 0, 0);
+            if (!(f & TF_ALIVE) || (PROGW(c, f >> 24) & 0xff) != node) continue;
+            uint32_t sw = TWORD(c, t, 1, 1);
+            uint32_t seq = sw & 0xffffff;
+            if ((sw >> 24) != info_gen) continue;
+            if ((last == 0xffffffffu || seq > last) && seq < best_seq) { best = t; best_seq = seq; }
+        }
+        if (best == 0xffffffffu) break;
+        uint32_t f = TWORD(c, best, 0, 0);
+        TWORD(c, best, 0, 0) = f | TF_KILLED;
+        wake<K>(c, L, best, (f >> 8) & 0xffff);
+        last = best_seq;
+    }
+}
+
+template <class K>
+__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome);
+
+// node.paused.clear() (task/mod.rs:365,392): the parked Runnables of `node` are dropped, in order.
+template <class K>
+__device__ void paused_clear(const Ctx& c, Lane& L, uint32_t node) {
+    if (!c.P.uses_pause) return;
+    uint32_t n = PAUSEW(0), keep = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t slot = PAUSEW(1 + i);
+        if ((PROGW(c, TWORD(c, slot, 0, 0) >> 24) & 0xff) == node) task_finish<K>(c, L, slot, H_CANCELLED);
+        else { PAUSEW(1 + keep) = slot; keep++; }
+    }
+    PAUSEW(0) = keep;
+}
+
+template <class K>
+__device__ void node_kill(const Ctx& c, Lane& L, uint32_t node) {        // TaskHandle::kill_id (task/mod.rs:362-371)
+    paused_clear<K>(c, L, node);
+    uint32_t g = NODE_INFO_GEN(node);
+    NODEW(0) |= 1u << node;
+    if (g == 0) NODEW(2) |= 1u << node;
+    info_kill<K>(c, L, node, g);
+    for (uint32_t i = 0; i < c.P.n_socks; i++)               // NetSim::reset_node (network.rs:142-147)
+        if ((SOCKW(c, i) & 0xff) == node) SW(c, i, 0) &= ~1u;
+}
+
+template <class K>
+__device__ void node_restart(const Ctx& c, Lane& L, uint32_t node) {     // TaskHandle::restart (task/mod.rs:374-401)
+    uint32_t g = NODE_INFO_GEN(node);
+    if (g == 0) NODEW(2) |= 1u << node;
+    uint32_t w = NODEW(4 + (node >> 2)), sh = (node & 3) * 8;
+    NODEW(4 + (node >> 2)) = (w & ~(0xffu << sh)) | (((g + 1) & 0xff) << sh);      // new_info
+    NODEW(0) &= ~(1u << node);
+    NODEW(1) &= ~(1u << node);
+    paused_clear<K>(c, L, node);
+    info_kill<K>(c, L, node, g);                             // old_info.kill()
+    for (uint32_t p = 1; p < c.P.n_progs; p++) {             // init(&Spawner { new info })
+        uint32_t pw = PROGW(c, p);
+        if ((pw & 0xff) == node && ((pw >> 8) & MADSIM_PROG_INIT)) spawn_task<K>(c, L, p, false);
+    }
+}
+
+}  // namespace madsim_k
+
+#endif

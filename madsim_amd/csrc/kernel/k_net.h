@@ -1,0 +1,101 @@
+// k_net.h — async-task wake rules, socket lookup, Mailbox::deliver, Timer::expire.
+// Part of sim_kernel.hip (included in this order: k_state, k_rng, k_timer, k_net, k_lifecycle, k_channel, k_poll).
+#ifndef MADSIM_K_NET_H
+#define MADSIM_K_NET_H
+
+namespace madsim_k {
+
+// ---- async-task wake / schedule [DEP A.7] -------------------------------------------------------
+template <class K>
+__device__ __forceinline__ void ready_push(const Ctx& c, Lane& L, uint32_t slot) {
+    if (K::RQ) L.rq |= (uint64_t)slot << (8 * L.ready_len);
+    else RW(L.ready_len) = slot;
+    L.ready_len++;
+}
+
+template <class K>
+__device__ __forceinline__ void wake(const Ctx& c, Lane& L, uint32_t slot, uint32_t gen) {
+    uint32_t f = TWORD(c, slot, 0, 0);
+    if (!(f & TF_ALIVE) || ((f >> 8) & 0xffff) != gen) return;   // COMPLETED | CLOSED
+    if (f & TF_SCHED) return;
+    TWORD(c, slot, 0, 0) = f | TF_SCHED;
+    if (!(f & TF_RUN)) ready_push<K>(c, L, slot);                   // RUNNING: run() re-queues after the poll
+}
+
+// ---- Network -----------------------------------------------------------------------------------
+// Network::try_send's socket lookup (network.rs:304-306): the bound socket at addr(dst), if any.
+template <class K>
+__device__ __forceinline__ int find_bound(const Ctx& c, uint32_t addr) {
+    if (c.P.uniq_addr) return (SW(c, addr, 0) & 1) ? (int)addr : -1;
+    uint32_t key = SOCKW(c, addr) & 0xffff00ffu;
+    for (uint32_t i = 0; i < c.P.n_socks; i++)
+        if ((SOCKW(c, i) & 0xffff00ffu) == key && (SW(c, i, 0) & 1)) return (int)i;
+    return -1;
+}
+
+// Mailbox::deliver (endpoint.rs:331-351)
+template <class K>
+__device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t meta, uint32_t val) {
+    uint32_t s = meta & 0x3f, from = (meta >> 6) & 0x3f, tag = (meta >> 12) & 0xff, sgen = (meta >> 20) & 0xff;
+    uint32_t h = SW(c, s, 0);
+    if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;     // that Endpoint object is gone
+    uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
+    // Typed RPC (net/rpc.rs): a response (tag 0xff) is addressed to one pending receive — the word of its registration,
+    // tag | slot | rxseq | gen, rides in the payload's upper 24 bits — where the reference matches a random u64 tag.
+    const bool rpc = K::LIFE && c.P.uses_rpc;
+    const bool rsp = rpc && tag == 0xff;
+    uint32_t i = 0;
+    while (i < nreg) {
+        REG(24);
+        uint32_t r = SW(c, s, 2 + i);
+        if ((r & 0xff) == tag && (!rsp || (r >> 8) == (val >> 8))) {
+            nreg--;
+            SW(c, s, 2 + i) = SW(c, s, 2 + nreg);          // swap_remove
+            uint32_t slot = (r >> 8) & 0xff, rxseq = (r >> 16) & 0xff, g8 = r >> 24;
+            uint4 u0 = TU(c, slot, 0);
+            uint32_t link = TWORD(c, slot, 1, 0);
+            if ((u0.x & TF_ALIVE) && ((u0.x >> 8) & 0xff) == g8 && (link & 0xff) == rxseq && !(u0.x & TF_INBOX)) {
+                // oneshot::Sender::send Ok -> value stored, receiver task woken [DEP tokio oneshot]
+                bool sched = u0.x & TF_SCHED;
+                u0.x |= TF_INBOX | TF_SCHED;
+                u0.y = (u0.y & 0x00ffffffu) | (from << 24);
+                u0.w = val;
+                if (rpc && tag >= MADSIM_TAG_RPC_FIRST) {                  // 8-bit code; a request also carries its rsp_tag
+                    u0.w = val & 0xff;
+                    if (!rsp) TWORD(c, slot, c.P.rpc_unit, 1) = val >> 8;  // staged with the oneshot value
+                }
+                TU(c, slot, 0) = u0;
+                SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);
+                if (!sched && !(u0.x & TF_RUN)) ready_push<K>(c, L, slot);
+                return;
+            }
+        } else {
+            i++;
+        }
+    }
+    if (nmsg >= c.P.mbox_msgs) { L.ovf = 1; return; }
+    if (rsp) tag = 0xfe;                                   // nobody holds that rsp_tag any more: it can never be received
+    SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);
+    SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg + 1) = val;
+    nmsg++;
+    SW(c, s, 0) = (h & ~((0xffu << 9) | (0xffu << 17))) | (nreg << 9) | (nmsg << 17);
+}
+
+template <class K> __device__ void node_restart(const Ctx& c, Lane& L, uint32_t node);
+
+// Timer::expire [DEP A.5]: fire every entry with deadline <= now
+template <class K>
+__device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now) {
+    while (L.top_dl <= now) {
+        uint4 e = timer_pop<K>(c, L);
+        L.steps++;
+        uint32_t kind = e.z >> 28;
+        if (kind == EV_WAKE) { REG(22); wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff); }   // time/sleep.rs:52
+        else if (kind == EV_DELIVER) { REG(23); mailbox_deliver<K>(c, L, e.z, e.w); }      // net/mod.rs:323-330
+        else if (K::LIFE && kind == EV_RESTART) node_restart<K>(c, L, e.z & 0xff);   // task/mod.rs:313
+    }
+}
+
+}  // namespace madsim_k
+
+#endif

@@ -1,0 +1,671 @@
+// k_poll.h — poll_task: one poll of a task program (the workload VM).
+// Part of sim_kernel.hip (included in this order: k_state, k_rng, k_timer, k_net, k_lifecycle, k_channel, k_poll).
+#ifndef MADSIM_K_POLL_H
+#define MADSIM_K_POLL_H
+
+namespace madsim_k {
+
+// TimeHandle::sleep_until (time/mod.rs:118-124): 1 ms floor
+__device__ __forceinline__ uint64_t sleep_deadline(const Lane& L, uint64_t deadline) {
+    uint64_t m = L.clock + NS_PER_MS;
+    return deadline > m ? deadline : m;
+}
+
+// NetSim::rand_delay up to the creation of its Sleep (net/mod.rs:287-292): returns the Sleep's deadline.
+template <class K>
+__device__ __forceinline__ uint64_t rand_delay_deadline(const Ctx& c, Lane& L) {
+    uint64_t delay = (uint64_t)gen_range_small<K, 5>(c, L) * 1000ull;
+    if (c.P.buggify) {
+        if (gen_bool_pint<K>(c, L, c.P.bug_pint, 0)) delay = (uint64_t)(1 + gen_range_small<K, 4>(c, L)) * NS_PER_S;
+    }
+    return sleep_deadline(L, L.clock + delay);
+}
+
+__device__ __forceinline__ bool is_light(uint32_t op) {
+    return op == MS_OP_ASSERT_VAL || op == MS_OP_DJNZ || op == MS_OP_SET || op == MS_OP_JMP || op == MS_OP_TRACE || op == MS_OP_JEQ;
+}
+
+// One poll of a task's future (Runnable::run, task/mod.rs:279-283).  `u0` is the task's unit0, held
+// in registers for the whole poll and written back by the caller.  Returns true if the task panicked.
+//
+// A poll is a sequence of rounds; one round = [A] resolve the await the task is parked on and run its
+// completion action, [B] run the cheap straight-line ops that follow, [C] begin the next awaiting op.
+// In steady state every poll is exactly one round, and all lanes walk A -> B -> C together, so the
+// expensive primitives (RNG draws, heap pushes, link test, mailbox scan) sit at fixed points that the
+// whole wave reaches at the same time.
+template <class K>
+__device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t slot, uint4& u0, uint4 u1) {
+    enum : uint32_t { ST_RUN = 0, ST_PENDING = 1, ST_FINISHED = 2, ST_PANIC = 3 };
+    const KParams& P = c.P;
+    bool u1_dirty = false;
+    uint32_t pc = u0.y & 0xffff, sub = (u0.y >> 16) & 0xff, from = u0.y >> 24;
+    const uint32_t gen = (u0.x >> 8) & 0xffff;
+    const uint32_t node = PROGW(c, u0.x >> 24) & 0xff;
+    uint32_t st = ST_RUN;
+
+    // timeout(d, ep.recv_from(tag)) = select_biased! { fut, sleep } (time/mod.rs:128-140): poll the recv future,
+    // then the timeout's Sleep — which registers ANOTHER timer on every not-elapsed poll (time/sleep.rs:51-53).
+    // Returns true when the op completed (Ok or Err(Elapsed)); otherwise the task is Pending.
+    auto recv_timeout_poll = [&]() -> bool {
+        bool fut_ready = false;
+        if (sub == 1 && (u0.x & TF_INBOX)) {                 // oneshot ready -> rand_delay (endpoint.rs:145)
+            u0.x &= ~TF_INBOX;
+            from = u0.y >> 24;
+            if (P.uses_rpc && (INSN(c, pc).x >> 24) >= MADSIM_TAG_RPC_FIRST) TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
+            uint64_t d1 = rand_delay_deadline<K>(c, L);
+            u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
+            sub = 2;
+        }
+        if (sub == 2) {
+            uint64_t d1 = u64of(u1.z, u1.w);
+            if (L.clock >= d1) fut_ready = true;
+            else if (!timer_add<K>(c, L, d1, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        }
+        if (fut_ready) return true;                          // Ok((len, from))
+        uint4 u2 = TU(c, slot, 2);
+        uint64_t d2 = u64of(u2.z, u2.w);
+        if (L.clock >= d2) {                                 // Err(Elapsed): the recv future is dropped
+            u1.x = (u1.x & ~0xffu) | (((u1.x & 0xff) + 1) & 0xff); u1_dirty = true;   // its oneshot::Receiver is gone
+            u0.x &= ~TF_INBOX;
+            u0.w = MADSIM_VAL_TIMEOUT;
+            return true;
+        }
+        if (!timer_add<K>(c, L, d2, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        st = ST_PENDING;
+        return false;
+    };
+
+    // Endpoint::call / call_timeout (net/rpc.rs:96-131) from its first poll on.  sub 1: send_to_raw's rand_delay;
+    // sub 2: recv_from_raw(rsp_tag)'s oneshot; sub 3: its rand_delay.  With a timeout, the timeout's Sleep is polled after
+    // the call future on every poll and registers ANOTHER timer each time (select_biased!, time/sleep.rs:51-53).
+    // Returns true when the op completed (Ok, Err(TimedOut)) or the task panicked (st).
+    auto rpc_call_poll = [&]() -> bool {
+        const uint4 ci = INSN(c, pc);
+        const uint32_t ca = (ci.x >> 8) & 0xff, cb = ci.x >> 16, cimm = ci.y;
+        const uint32_t dst = cb & 0xff;
+        if (sub == 1) {
+            uint64_t d1 = u64of(u1.z, u1.w);
+            if (L.clock < d1) {
+                if (!timer_add<K>(c, L, d1, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+            } else {
+                // the caller's pending receive doubles as the rsp_tag: registration word >> 8 (see mailbox_deliver)
+                const uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;
+                const uint32_t reg = 0xffu | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                uint64_t lat; int ds;
+                if (try_send_fn<K>(c, L, SOCKW(c, ca) & 0xff, dst, &lat, &ds)) {
+                    uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
+                    uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((cb >> 8) << 12) | (ca << 6) | (uint32_t)ds;
+                    if (!timer_add<K>(c, L, L.clock + lat, meta, (cimm & 0xff) | (reg & 0xffffff00u))) L.ovf = 1;
+                }
+                // recv_from_raw(rsp_tag): Mailbox::recv (endpoint.rs:353-362); no queued message can carry a fresh tag
+                u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
+                u0.x &= ~TF_INBOX;
+                uint32_t h = SW(c, ca, 0);
+                uint32_t nreg = (h >> 9) & 0xff;
+                for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) L.ovf = 1;   // 8-bit rxseq wrapped onto a dead twin
+                if (nreg >= P.mbox_regs) L.ovf = 1;
+                else {
+                    SW(c, ca, 2 + nreg) = reg;
+                    SW(c, ca, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
+                }
+                sub = 2;
+            }
+        }
+        if (sub == 2 && (u0.x & TF_INBOX)) {                 // oneshot ready -> rand_delay (endpoint.rs:145)
+            u0.x &= ~TF_INBOX;
+            from = u0.y >> 24;
+            uint64_t d1 = rand_delay_deadline<K>(c, L);
+            u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
+            sub = 3;
+        }
+        if (sub == 3) {
+            uint64_t d1 = u64of(u1.z, u1.w);
+            if (L.clock >= d1) {
+                if (from != dst) st = ST_PANIC;              // assert_eq!(from, dst) rpc.rs:126
+                return true;
+            }
+            if (!timer_add<K>(c, L, d1, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        }
+        if (cimm >> 8) {
+            uint4 u2 = TU(c, slot, 2);
+            uint64_t d2 = u64of(u2.z, u2.w);
+            if (L.clock >= d2) {                             // Err(Elapsed) -> TimedOut: the call future is dropped
+                if (sub >= 2) { u1.x = (u1.x & ~0xffu) | (((u1.x & 0xff) + 1) & 0xff); u1_dirty = true; u0.x &= ~TF_INBOX; }
+                u0.w = MADSIM_VAL_TIMEOUT;
+                return true;
+            }
+            if (!timer_add<K>(c, L, d2, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        }
+        st = ST_PENDING;
+        return false;
+    };
+
+    // accept1's conn_rx.recv() (endpoint.rs:200): take the oldest queued connection or park. true = op completed.
+    auto accept_check = [&](uint32_t a) -> bool {
+        uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
+        uint32_t q = SW(c, a, base);
+        uint32_t n = q & 0xf;
+        if (n == 0) { SW(c, a, base + 1) = 1u | (slot << 1) | (gen << 9); st = ST_PENDING; return false; }
+        uint32_t id = (q >> 4) & 0x7f;
+        SW(c, a, base) = (n - 1) | ((q >> 11) << 4);           // pop front
+        uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+        if ((cx & 0xff) != 0xff) conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1);
+        TWORD(c, slot, c.P.chan_unit, 0) = id | (1u << 8);                 // server side
+        return true;
+    };
+    // the receiver stream of channel() (net/mod.rs:386-400) from "a payload is in hand" (sub 1): either sleep(backoff)
+    // while its State is None (sub 2) or sleep_until(arrive_time) (sub 3).  Always ends Pending (1 ms floor).
+    auto crecv_arm = [&]() {
+        uint4 u3 = TU(c, slot, c.P.chan_unit);
+        uint64_t arrive = u64of(u3.z, u3.w), d;
+        if (arrive != ~0ull) { d = sleep_deadline(L, arrive); sub = 3; }
+        else { d = sleep_deadline(L, L.clock + (uint64_t)(u3.x >> 16) * NS_PER_MS); sub = 2; }
+        u1.z = (uint32_t)d; u1.w = (uint32_t)(d >> 32); u1_dirty = true;
+        if (!timer_add<K>(c, L, d, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        st = ST_PENDING;
+    };
+
+    while (st == ST_RUN) {
+        if (pc >= P.n_insns) { st = ST_PANIC; break; }
+        uint4 in = INSN(c, pc);
+        uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
+
+        PROBE(5);
+        REG(2);
+        // ================= [A] the task is parked on an await of this op =========================
+        if (sub != 0) {
+            bool completed = false;                        // this op is done: step to the next one below
+            if (op == MS_OP_RECV && sub == 1) {            // oneshot::Receiver (endpoint.rs:142-144)
+                REG(4);
+                if (!(u0.x & TF_INBOX)) { st = ST_PENDING; break; }
+                u0.x &= ~TF_INBOX;
+                from = u0.y >> 24;
+                if (K::LIFE && P.uses_rpc && (b >> 8) >= MADSIM_TAG_RPC_FIRST)   // (rsp_tag, req, data) = *data.downcast()
+                    TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
+                sub = 2;                                   // -> rand_delay, begun in [C]
+            } else if (op == MS_OP_YIELD) {
+                completed = true;
+            } else if (K::LIFE && op == MS_OP_RECV_TIMEOUT) {
+                completed = recv_timeout_poll();
+                if (!completed) break;
+            } else if (K::LIFE && op == MS_OP_RPC_CALL) {
+                completed = rpc_call_poll();
+                if (!completed || st == ST_PANIC) break;
+            } else if (K::LIFE && op == MS_OP_ACCEPT && sub == 2) {
+                completed = accept_check(a);
+                if (!completed) break;
+            } else {                                       // a Sleep (time/sleep.rs:47-54)
+                uint64_t deadline = u64of(u1.z, u1.w);
+                REG(3);
+                if (L.clock < deadline) {                  // not elapsed: register ANOTHER timer
+                    REG(5);
+                    if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+                    st = ST_PENDING;
+                    break;
+                }
+                if (K::LIFE && op == MS_OP_ACCEPT) {       // rand_delay done -> conn_rx.recv()
+                    sub = 2;
+                    if (!accept_check(a)) break;
+                } else if (K::LIFE && op == MS_OP_CRECV) {
+                    uint4 u3 = TU(c, slot, c.P.chan_unit);
+                    if (sub == 2) {                        // sleep(backoff) done: backoff = min(2 * backoff, 10 s); retry the link
+                        uint32_t bo = (u3.x >> 16) * 2; if (bo > 10000) bo = 10000;
+                        uint32_t cw = CONNW(u3.x & 0xff, 0);
+                        uint64_t arrive = chan_test_link<K>(c, L, cw, 1 - ((u3.x >> 8) & 1));
+                        u3.x = (u3.x & 0xffff) | (bo << 16); u3.z = (uint32_t)arrive; u3.w = (uint32_t)(arrive >> 32);
+                        TU(c, slot, c.P.chan_unit) = u3;
+                        crecv_arm();
+                        break;
+                    }
+                    u0.w = u3.y;                           // sub 3: sleep_until(arrive_time) done -> yield value
+                } else if (K::LIFE && op == MS_OP_CONNECT) {   // NetSim::connect1 (net/mod.rs:345-363)
+                    uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                    if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
+                    uint64_t lat; int ds;
+                    if (!try_send_fn<K>(c, L, SOCKW(c, a) & 0xff, b & 0xff, &lat, &ds)) {
+                        u0.w = MADSIM_VAL_REFUSED;
+                    } else {
+                        uint32_t id = 0;
+                        while (id < P.max_conns && (CONNW(id, 0) & 1)) id++;
+                        uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
+                        uint32_t q = SW(c, ds, base);
+                        if (id >= P.max_conns || (q & 0xf) >= 4) { L.ovf = 1; }
+                        else {
+                            CONNW(id, 0) = 1u | (a << 1) | ((uint32_t)ds << 7) | (0xfu << 13);
+                            CONNW(id, 1) = 0; CONNW(id, 2) = 0;
+                            TWORD(c, slot, c.P.chan_unit, 0) = id;             // client side
+                            u0.w = 0;
+                            uint32_t n = q & 0xf;                  // socket.new_connection -> conn_tx.try_send
+                            SW(c, ds, base) = (q & ~0xfu) | (n + 1) | (id << (4 + 7 * n));
+                            uint32_t acc = SW(c, ds, base + 1);
+                            if (acc & 1) { SW(c, ds, base + 1) = 0; wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9); }
+                        }
+                    }
+                } else if (op == MS_OP_BIND) {                    // Network::bind (network.rs:206-251)
+                    uint32_t sw = SOCKW(c, a);
+                    if ((sw & 0xff) != node || find_bound<K>(c, a) >= 0) { st = ST_PANIC; break; }
+                    uint32_t h = SW(c, a, 0);
+                    SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);     // bound, gen+1, empty mailbox
+                    SW(c, a, 1) = slot | (gen << 16);
+                    if (K::LIFE && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
+                } else if (op == MS_OP_SEND || op == MS_OP_REPLY || (K::LIFE && op == MS_OP_RPC_REPLY)) {   // net/mod.rs:307-331
+                    REG(6);
+                    uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : from;
+                    if (K::LIFE && op == MS_OP_RPC_REPLY) {    // send_to_raw(from, rsp_tag, rsp): rpc.rs:172-175
+                        b = 0xff00;
+                        imm = (imm & 0xff) | (TWORD(c, slot, P.rpc_unit, 0) << 8);
+                    }
+                    uint32_t src_node = SOCKW(c, a) & 0xff;
+                    uint32_t dst_node = SOCKW(c, dst) & 0xff;
+                    // Network::try_send -> test_link (network.rs:261-269, 296-313)
+                    bool clogged = false;
+                    if (P.has_clog) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
+                    if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
+                    if (!clogged && !gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) {
+                        L.msg_count++;
+                        uint64_t lat = sample_latency<K>(c, L);
+                        int ds = find_bound<K>(c, dst);
+                        if (ds >= 0) {
+                            uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
+                            uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((b >> 8) << 12) | (a << 6) | (uint32_t)ds;
+                            if (!timer_add<K>(c, L, L.clock + lat, meta, imm)) L.ovf = 1;
+                        }
+                    }
+                }
+                completed = true;
+            }
+            if (completed) {                               // fall through to [B]/[C] with the next op: one pass per poll
+                REG(12);
+                sub = 0;
+                // fused post-chain of this op (geometry.h build_tables): assert_eq!(val, ..), then djnz / jmp
+                const uint32_t pf = in.w;
+                if ((pf & 1) && u0.w != in.z) { st = ST_PANIC; break; }
+                pc = (pf >> 4) & 0x3fff;
+                if (pf & 2) {
+                    uint32_t sh = ((pf >> 2) & 1) * 16;
+                    uint32_t v = (((u0.z >> sh) & 0xffff) - 1) & 0xffff;
+                    u0.z = (u0.z & ~(0xffffu << sh)) | (v << sh);
+                    if (v) pc = pf >> 18;
+                } else if (pf & 8) {
+                    pc = pf >> 18;
+                }
+                if (pc >= P.n_insns) { st = ST_PANIC; break; }
+                in = INSN(c, pc);
+                op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
+            }
+        }
+
+        PROBE(6);
+        // ================= [B] cheap ops that never await ========================================
+        while (is_light(op)) {
+            REG(13);
+            if (op == MS_OP_ASSERT_VAL) {
+                if (u0.w != imm) { st = ST_PANIC; break; }
+                pc++;
+            } else if (op == MS_OP_DJNZ) {
+                uint32_t sh = (a & 1) * 16;
+                uint32_t v = (((u0.z >> sh) & 0xffff) - 1) & 0xffff;
+                u0.z = (u0.z & ~(0xffffu << sh)) | (v << sh);
+                pc = v ? b : pc + 1;
+            } else if (op == MS_OP_SET) {
+                u0.z = (a & 1) ? ((u0.z & 0xffffu) | (imm << 16)) : ((u0.z & 0xffff0000u) | (imm & 0xffffu));
+                pc++;
+            } else if (op == MS_OP_JMP) {
+                pc = b;
+            } else if (op == MS_OP_JEQ) {
+                pc = (u0.w == imm) ? b : pc + 1;
+            } else {                                       // MS_OP_TRACE
+                uint64_t v = imm;
+                if (b & 1) v += (u0.z >> ((a & 1) * 16)) & 0xffff;
+                L.obs_hash = (L.obs_hash ^ v) * FNV_PRIME;
+                pc++;
+            }
+            if (pc >= P.n_insns) { st = ST_PANIC; break; }
+            in = INSN(c, pc);
+            op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
+        }
+        if (st != ST_RUN) break;
+
+        PROBE(7);
+        REG(9);
+        // ================= [C] begin the next op =================================================
+        bool want_delay = false, want_sleep = false;
+        uint64_t deadline = 0;
+        if (op == MS_OP_RECV) {
+            if (sub == 0) {                                // Mailbox::recv (endpoint.rs:353-362)
+                REG(14);
+                uint32_t tag = b >> 8;
+                uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;
+                u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
+                u0.x &= ~TF_INBOX;
+                uint32_t h = SW(c, a, 0);
+                uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
+                uint32_t idx = 0, mbase = 2 + P.mbox_regs;
+                while (idx < nmsg && (SW(c, a, mbase + 2 * idx) & 0xff) != tag) idx++;
+                if (idx < nmsg) {
+                    uint32_t m0 = SW(c, a, mbase + 2 * idx), m1 = SW(c, a, mbase + 2 * idx + 1);
+                    nmsg--;
+                    SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);        // swap_remove
+                    SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
+                    u0.w = m1;
+                    if (K::LIFE && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 0) = m1 >> 8; }
+                    from = (m0 >> 8) & 0xff;
+                    sub = 2;                               // oneshot already holds the value
+                    SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
+                } else {
+                    if (nreg >= P.mbox_regs) { L.ovf = 1; st = ST_PENDING; break; }
+                    SW(c, a, 2 + nreg) = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                    SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
+                    sub = 1;
+                    st = ST_PENDING;
+                }
+            }
+            want_delay = (sub == 2);                       // endpoint.rs:145 rand_delay
+        } else if (op == MS_OP_SEND || op == MS_OP_REPLY || op == MS_OP_BIND || (K::LIFE && (op == MS_OP_CONNECT || op == MS_OP_ACCEPT || op == MS_OP_RPC_REPLY))) {
+            want_delay = true;                             // net/mod.rs:306,344,457, endpoint.rs:198: rand_delay first
+        } else if (K::LIFE && op == MS_OP_RECV_TIMEOUT) {
+            uint32_t tag = b >> 8;
+            uint64_t d2 = sleep_deadline(L, L.clock + (uint64_t)(b & 0xff) * NS_PER_S + imm);   // timeout()'s Sleep
+            uint4 u2 = TU(c, slot, 2);
+            u2.z = (uint32_t)d2; u2.w = (uint32_t)(d2 >> 32);
+            TU(c, slot, 2) = u2;
+            uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;       // Mailbox::recv (endpoint.rs:353-362)
+            u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
+            u0.x &= ~TF_INBOX;
+            uint32_t h = SW(c, a, 0);
+            uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
+            uint32_t idx = 0, mbase = 2 + P.mbox_regs;
+            while (idx < nmsg && (SW(c, a, mbase + 2 * idx) & 0xff) != tag) idx++;
+            if (idx < nmsg) {
+                uint32_t m0 = SW(c, a, mbase + 2 * idx), m1 = SW(c, a, mbase + 2 * idx + 1);
+                nmsg--;
+                SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);
+                SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
+                u0.w = m1;
+                if (P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 1) = m1 >> 8; }
+                u0.y = (u0.y & 0x00ffffffu) | (((m0 >> 8) & 0xff) << 24);
+                u0.x |= TF_INBOX;
+                SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
+            } else if (nreg >= P.mbox_regs) {
+                L.ovf = 1;
+            } else {
+                SW(c, a, 2 + nreg) = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
+            }
+            sub = 1;
+            if (recv_timeout_poll()) { sub = 0; pc++; }
+        } else if (K::LIFE && op == MS_OP_RPC_CALL) {          // first poll of timeout(d, ep.call(dst, req)) / ep.call(dst, req)
+            if (imm >> 8) {                                    // timeout()'s Sleep exists before the call is polled
+                uint64_t d2 = sleep_deadline(L, L.clock + (uint64_t)(imm >> 8) * NS_PER_MS);
+                uint4 u2 = TU(c, slot, 2);
+                u2.z = (uint32_t)d2; u2.w = (uint32_t)(d2 >> 32);
+                TU(c, slot, 2) = u2;
+            }
+            (void)rng_next(L); rng_log<K>(c, L);               // rsp_tag = random::<u64>(): one with() (rand.rs:146-148)
+            uint64_t d1 = rand_delay_deadline<K>(c, L);        // send_to_raw -> NetSim::send: rand_delay first
+            u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
+            sub = 1;
+            if (rpc_call_poll()) { sub = 0; pc++; }            // (never on the first poll: 1 ms floor)
+        } else if (K::LIFE && op == MS_OP_SLEEP_RAND) {        // sleep(thread_rng().gen_range(lo..hi)): [DEP A.3],
+            const uint64_t* dp = P.dur_table + 4 * a;          // host-precomputed UniformDuration {mode, low, range, zone}
+            uint64_t mode = dp[0], low = dp[1], range = dp[2], zone = dp[3], d;
+            for (;;) {                                         // on the GlobalRng itself: one with() per attempt
+                uint64_t v = rng_next(L);
+                rng_log<K>(c, L);
+                if (mode == 0) {
+                    uint64_t m = (uint64_t)(uint32_t)(v >> 32) * (uint64_t)(uint32_t)range;
+                    if ((uint32_t)m <= (uint32_t)zone) { d = low + (m >> 32); break; }
+                } else if (v * range <= zone) { d = low + __umul64hi(v, range); break; }
+            }
+            deadline = sleep_deadline(L, L.clock + d);
+            want_sleep = true;
+        } else if (op == MS_OP_SLEEP || op == MS_OP_SLEEP_UNTIL) {
+            uint64_t base = L.clock;
+            if (K::LIFE && op == MS_OP_SLEEP_UNTIL) { uint4 u2 = TU(c, slot, 2); base = u64of(u2.x, u2.y); }
+            deadline = sleep_deadline(L, base + (uint64_t)b * NS_PER_S + imm);
+            want_sleep = true;
+        } else {
+            // ---- everything else: rare, control-plane ops ----
+            switch (op) {
+            case MS_OP_DONE:
+                u0.y = pc | (sub << 16) | (from << 24);
+                TU(c, slot, 0) = u0;
+                if (u1_dirty) { tu1_store<K>(c, slot, u1); u1_dirty = false; }
+                // an init task is `async { future.await; h.exit() }` (runtime/mod.rs:362-370): Spawner::exit =
+                // NodeInfo::kill on the info it was spawned with (task/mod.rs:657-661), before the future drops
+                if (K::LIFE && ((PROGW(c, u0.x >> 24) >> 8) & MADSIM_PROG_INIT) && (u1.y >> 24) == NODE_INFO_GEN(node)) {
+                    NODEW(0) |= 1u << node;
+                    if ((u1.y >> 24) == 0) NODEW(2) |= 1u << node;
+                    info_kill<K>(c, L, node, u1.y >> 24);
+                }
+                task_finish<K>(c, L, slot, H_COMPLETED);
+                u0.x = TWORD(c, slot, 0, 0);
+                st = ST_FINISHED;
+                break;
+            case MS_OP_SPAWN: {
+                uint32_t child = spawn_task<K>(c, L, a, true, (PROGW(c, a) & 0xff) != node);
+                if (K::LIFE && P.uses_chan && (b & 2) && child != 0xffffffffu) {   // `async move`: the (tx, rx) pair moves
+                    uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                    TWORD(c, child, c.P.chan_unit, 0) = cx & 0x1ff;
+                    TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff;
+                }
+                if (K::LIFE && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST) && child != 0xffffffffu) {   // rpc.rs:170
+                    TWORD(c, child, 0, 3) = u0.w;
+                    TWORD(c, child, 0, 1) = (TWORD(c, child, 0, 1) & 0x00ffffffu) | (from << 24);
+                    TWORD(c, child, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 0);
+                }
+            }
+                pc++;
+                break;
+            case MS_OP_BUILD:
+                for (uint32_t p = 1; p < P.n_progs; p++) {
+                    uint32_t pw = PROGW(c, p);
+                    if ((pw & 0xff) == a && ((pw >> 8) & MADSIM_PROG_INIT) && !((pw >> 8) & MADSIM_PROG_PRE)) spawn_task<K>(c, L, p, false);
+                }
+                pc++;
+                break;
+            case MS_OP_JOIN: {                             // task/join.rs:59-72 + async-task poll_task
+                uint32_t h = HW(a);
+                uint32_t hs = h & 3;
+                if (hs == H_RUNNING) {
+                    uint32_t cs = (h >> 8) & 0xff;
+                    uint32_t link = TWORD(c, cs, 1, 0);
+                    TWORD(c, cs, 1, 0) = (link & 0xff) | (slot << 8) | (gen << 16);   // register awaiter
+                    st = ST_PENDING;
+                } else if (hs == H_NONE || ((hs == H_CANCELLED) != ((b & 1) != 0))) {
+                    st = ST_PANIC;
+                } else {
+                    pc++;
+                }
+                break;
+            }
+            case MS_OP_YIELD:                              // [DEP tokio yield_now outside a runtime]
+                sub = 1;
+                u0.x |= TF_SCHED;                          // wake_by_ref while RUNNING
+                st = ST_PENDING;
+                break;
+            case MS_OP_PANIC:
+                st = ST_PANIC;
+                break;
+            case MS_OP_ABORT: {                            // AbortHandle::abort (task/join.rs:158-163)
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint32_t h = HW(a);
+                if ((h & 3) == H_RUNNING) {
+                    uint32_t cs = (h >> 8) & 0xff;
+                    TWORD(c, cs, 0, 0) |= TF_CANCEL;
+                    wake<K>(c, L, cs, h >> 16);
+                }
+                pc++;
+                break;
+            }
+            case MS_OP_KILL: case MS_OP_RESTART:
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                u0.y = pc | (sub << 16) | (from << 24);     // this task may be woken/killed by the call: sync LDS first
+                TU(c, slot, 0) = u0;
+                if (op == MS_OP_KILL) node_kill<K>(c, L, a); else node_restart<K>(c, L, a);
+                u0.x = TWORD(c, slot, 0, 0);
+                pc++;
+                break;
+            case MS_OP_PAUSE:                               // task/mod.rs:404-410
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                NODEW(1) |= 1u << a;
+                pc++;
+                break;
+            case MS_OP_RESUME: {                            // task/mod.rs:413-424: parked Runnables go back, in order
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                NODEW(1) &= ~(1u << a);
+                if (P.uses_pause) {
+                    uint32_t n = PAUSEW(0), keep = 0;
+                    for (uint32_t i = 0; i < n; i++) {
+                        uint32_t ps = PAUSEW(1 + i);
+                        if ((PROGW(c, TWORD(c, ps, 0, 0) >> 24) & 0xff) == a) ready_push<K>(c, L, ps);
+                        else { PAUSEW(1 + keep) = ps; keep++; }
+                    }
+                    PAUSEW(0) = keep;
+                }
+                pc++;
+                break;
+            }
+            case MS_OP_ASSERT_EXIT:                         // Handle::is_exit (task/mod.rs:444-449)
+                if (((NODEW(0) >> a) & 1) != (b & 1)) st = ST_PANIC; else pc++;
+                break;
+            case MS_OP_CSEND: {                            // PayloadSender::send (net/mod.rs:417-421)
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
+                uint32_t id = cx & 0xff, side = (cx >> 8) & 1;
+                uint32_t cw = CONNW(id, 0);
+                uint64_t arrive = chan_test_link<K>(c, L, cw, side);          // draws happen before the closed check
+                if (!(cw & (1u << (14 + 2 * side)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // ConnectionReset
+                uint32_t qn = (cw >> (17 + 4 * side)) & 0xf;
+                if (qn >= P.chan_queue) { L.ovf = 1; pc++; break; }
+                uint32_t e = 3 + (side * P.chan_queue + qn) * 3;
+                CONNW(id, e) = imm; CONNW(id, e + 1) = (uint32_t)arrive; CONNW(id, e + 2) = (uint32_t)(arrive >> 32);
+                CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * side))) | ((qn + 1) << (17 + 4 * side));
+                uint32_t r = CONNW(id, 1 + side);
+                if (r & 1) { CONNW(id, 1 + side) = 0; wake<K>(c, L, (r >> 1) & 0xff, r >> 9); }   // mpsc wakes the parked receiver
+                pc++;
+                break;
+            }
+            case MS_OP_CRECV: {                            // rx.recv().await (net/mod.rs:386), sub == 0 here
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
+                uint32_t id = cx & 0xff, dir = 1 - ((cx >> 8) & 1);
+                uint32_t cw = CONNW(id, 0);
+                uint32_t qn = (cw >> (17 + 4 * dir)) & 0xf;
+                if (qn == 0) {
+                    if (!(cw & (1u << (13 + 2 * dir)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // all senders gone
+                    CONNW(id, 1 + dir) = 1u | (slot << 1) | (gen << 9);
+                    st = ST_PENDING;
+                    break;
+                }
+                uint32_t e0 = 3 + dir * P.chan_queue * 3;
+                uint4 u3 = make_uint4((cx & 0x1ff) | (1u << 16), CONNW(id, e0), CONNW(id, e0 + 1), CONNW(id, e0 + 2));   // backoff = 1 ms
+                for (uint32_t i = 1; i < qn; i++)              // VecDeque::pop_front
+                    for (uint32_t k = 0; k < 3; k++) CONNW(id, e0 + (i - 1) * 3 + k) = CONNW(id, e0 + i * 3 + k);
+                CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * dir))) | ((qn - 1) << (17 + 4 * dir));
+                TU(c, slot, c.P.chan_unit) = u3;
+                crecv_arm();
+                break;
+            }
+            case MS_OP_CCLOSE: {
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
+                pc++;
+                break;
+            }
+            case MS_OP_GSET: GREGW(a & 3) = imm; pc++; break;
+            case MS_OP_GADD: GREGW(a & 3) += imm; pc++; break;
+            case MS_OP_ASSERT_G: if (GREGW(a & 3) != imm) st = ST_PANIC; else pc++; break;
+            case MS_OP_PANIC_IF_G_LT: if (GREGW(a & 3) < imm) st = ST_PANIC; else pc++; break;
+            case MS_OP_MARK:
+                if (!K::LIFE) { st = ST_PANIC; break; }     // t0 family and advance(): extended variant only
+                TU(c, slot, 2) = make_uint4((uint32_t)L.clock, (uint32_t)(L.clock >> 32), 0, 0);
+                pc++;
+                break;
+            case MS_OP_ASSERT_ELAPSED: {
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint4 u2 = TU(c, slot, 2);
+                uint64_t el = L.clock - u64of(u2.x, u2.y), d = (uint64_t)b * NS_PER_S + imm;
+                bool ok = a == 0 ? el == d : a == 1 ? el >= d : el < d;
+                if (!ok) st = ST_PANIC; else pc++;
+                break;
+            }
+            case MS_OP_ADVANCE:                            // time/mod.rs:103-106
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                L.clock += (uint64_t)b * NS_PER_S + imm;
+                pc++;
+                u0.y = pc | (sub << 16) | (from << 24);
+                TU(c, slot, 0) = u0;
+                if (u1_dirty) { tu1_store<K>(c, slot, u1); u1_dirty = false; }
+                timer_expire<K>(c, L, L.clock);
+                u0 = TU(c, slot, 0); u1 = TU(c, slot, 1);
+                from = u0.y >> 24;
+                break;
+            case MS_OP_CLOSE: {
+                uint32_t h = SW(c, a, 0);
+                if ((h & 1) && SW(c, a, 1) == (slot | (gen << 16)) && !(u0.x & TF_KILLED)) SW(c, a, 0) = h & ~1u;
+                if (K::LIFE && P.uses_chan && SW(c, a, 1) == (slot | (gen << 16)) && (SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, a);
+                pc++;
+                break;
+            }
+            case MS_OP_CLOG_NODE:
+                if (b & 1) CLOGW(0) |= 1u << a;
+                if (b & 2) CLOGW(1) |= 1u << a;
+                pc++;
+                break;
+            case MS_OP_UNCLOG_NODE:
+                if (b & 1) CLOGW(0) &= ~(1u << a);
+                if (b & 2) CLOGW(1) &= ~(1u << a);
+                pc++;
+                break;
+            case MS_OP_CLOG_LINK:
+                CLOGW(2 + a) |= 1u << b;
+                pc++;
+                break;
+            case MS_OP_UNCLOG_LINK:
+                CLOGW(2 + a) &= ~(1u << b);
+                pc++;
+                break;
+            case MS_OP_RAND_BOOL:                           // thread_rng().gen_bool(p) [DEP A.4]
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                u0.w = gen_bool_pint<K>(c, L, P.loss_table_pint[a & 3], P.loss_table_always[a & 3]) ? 1u : 0u;
+                pc++;
+                break;
+            case MS_OP_SET_LOSS:
+                L.loss_pint = P.loss_table_pint[a & 3];
+                L.loss_always = P.loss_table_always[a & 3];
+                pc++;
+                break;
+            default:
+                st = ST_PANIC;
+                break;
+            }
+        }
+        PROBE(8);
+        if (want_delay) {                                  // NetSim::rand_delay (net/mod.rs:287-292)
+            REG(15);
+            deadline = rand_delay_deadline<K>(c, L);
+            want_sleep = true;
+        }
+        if (want_sleep) {                                  // first Sleep::poll: never elapsed (1 ms floor)
+            REG(17);
+            u1.z = (uint32_t)deadline; u1.w = (uint32_t)(deadline >> 32); u1_dirty = true;
+            sub = (op == MS_OP_RECV) ? 3 : 1;
+            if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+            st = ST_PENDING;
+        }
+    }
+    PROBE(9);
+    if (st != ST_FINISHED) {
+        u0.y = pc | (sub << 16) | (from << 24);
+        if (u1_dirty) tu1_store<K>(c, slot, u1);
+    }
+    return st == ST_PANIC;
+}
+
+}  // namespace madsim_k
+
+#endif

@@ -1,0 +1,100 @@
+// k_rng.h — GlobalRng: xoshiro256++, rand 0.8 gen_range / gen_bool / UniformDuration, determinism log.
+// Part of sim_kernel.hip (included in this order: k_state, k_rng, k_timer, k_net, k_lifecycle, k_channel, k_poll).
+#ifndef MADSIM_K_RNG_H
+#define MADSIM_K_RNG_H
+
+namespace madsim_k {
+
+// ---- GlobalRng ---------------------------------------------------------------------------------
+// Xoshiro256PlusPlus::next_u64 [DEP rand_xoshiro 0.6]
+__device__ __forceinline__ uint64_t rng_next(Lane& L) {
+    uint64_t r = rotl64<23>(L.s0 + L.s3) + L.s0;
+    uint64_t t = L.s1 << 17;
+    L.s2 ^= L.s0; L.s3 ^= L.s1; L.s1 ^= L.s2; L.s0 ^= L.s3;
+    L.s2 ^= t;
+    L.s3 = rotl64<45>(L.s3);
+    L.rng_calls++;
+    return r;
+}
+
+// One determinism-log byte per GlobalRng::with (rand.rs:64-88): clone.gen::<u8>() ^ xor-fold(elapsed).
+template <class K>
+__device__ __forceinline__ void rng_log(const Ctx& c, Lane& L) {
+#ifdef EXP_NOLOG
+    return;
+#endif
+    uint64_t r = rotl64<23>(L.s0 + L.s3) + L.s0;   // what the clone's next_u64 would return
+    uint32_t v = (uint32_t)(r >> 32);
+    uint32_t f = (uint32_t)L.clock ^ (uint32_t)(L.clock >> 32);
+    f ^= f >> 16; f ^= f >> 8;
+    v = (v ^ f) & 0xff;
+    L.trace_hash = (L.trace_hash ^ v) * FNV_PRIME;
+    if (K::TRACE) { if (L.log_len < c.P.trace_cap) c.tlog[L.log_len] = (uint8_t)v; }
+    L.log_len++;
+}
+
+// gen_range(lo..hi) on u64 [DEP rand 0.8 UniformInt::sample_single_inclusive]; one with() per call.
+template <class K>
+__device__ __forceinline__ uint64_t gen_range_u64(const Ctx& c, Lane& L, uint64_t lo, uint64_t range) {
+    uint64_t zone = (range << __builtin_clzll(range)) - 1;
+    uint64_t v;
+    do { REG(16); v = rng_next(L); } while (v * range > zone);
+    rng_log<K>(c, L);
+    return lo + __umul64hi(v, range);
+}
+
+// ready-queue index draw: range = len <= 255, so the 128-bit product splits into two 32x32 pieces.
+template <class K>
+__device__ __forceinline__ uint32_t gen_index(const Ctx& c, Lane& L, uint32_t len) {
+    uint64_t zone = ((uint64_t)len << __builtin_clzll((uint64_t)len)) - 1;
+    uint64_t v;
+    do { REG(1); v = rng_next(L); } while (EXP_ACCEPT(v * (uint64_t)len > zone));   // accept test on the low 64 bits only
+    rng_log<K>(c, L);
+    uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * len + (((uint64_t)(uint32_t)v * len) >> 32);
+    return (uint32_t)(mid >> 32);                               // high 64 bits of v * len
+}
+
+// gen_range with a compile-time range < 2^32.
+template <class K, uint32_t RANGE>
+__device__ __forceinline__ uint32_t gen_range_small(const Ctx& c, Lane& L) {
+    constexpr uint64_t zone = ((uint64_t)RANGE << __builtin_clzll((uint64_t)RANGE)) - 1;
+    uint64_t v;
+    do { REG(RANGE == 50 ? 18 : 16); v = rng_next(L); } while (EXP_ACCEPT(v * (uint64_t)RANGE > zone));
+    rng_log<K>(c, L);
+    uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * RANGE + (((uint64_t)(uint32_t)v * RANGE) >> 32);
+    return (uint32_t)(mid >> 32);
+}
+
+// gen_bool through GlobalRng's RngCore impl (rand.rs:142-158): one with() per draw [DEP Bernoulli].
+template <class K>
+__device__ __forceinline__ bool gen_bool_pint(const Ctx& c, Lane& L, uint64_t p_int, uint32_t always) {
+    if (always) return true;
+    REG(7);
+    uint64_t v = rng_next(L);
+    rng_log<K>(c, L);
+    return v < p_int;
+}
+
+// UniformDuration sample on the GlobalRng itself (network.rs:267): one with() per attempt [DEP A.3].
+template <class K>
+__device__ __forceinline__ uint64_t sample_latency(const Ctx& c, Lane& L) {
+    const KParams& P = c.P;
+    uint64_t res;
+    for (;;) {
+        REG(8);
+        uint64_t v = rng_next(L);
+        rng_log<K>(c, L);
+        if (P.lat_mode == 0) {
+            uint64_t m = (uint64_t)(uint32_t)(v >> 32) * (uint64_t)(uint32_t)P.lat_range;
+            if ((uint32_t)m <= (uint32_t)P.lat_zone) { res = P.lat_low + (m >> 32); break; }
+        } else {
+            uint64_t mlo = v * P.lat_range;
+            if (mlo <= P.lat_zone) { res = P.lat_low + __umul64hi(v, P.lat_range); break; }
+        }
+    }
+    return res;
+}
+
+}  // namespace madsim_k
+
+#endif

@@ -1,0 +1,97 @@
+// k_timer.h — Timer: the BinaryHeap of naive-timer, LDS-resident with an HBM spill region.
+// Part of sim_kernel.hip (included in this order: k_state, k_rng, k_timer, k_net, k_lifecycle, k_channel, k_poll).
+#ifndef MADSIM_K_TIMER_H
+#define MADSIM_K_TIMER_H
+
+namespace madsim_k {
+
+// ---- Timer = BinaryHeap<Event>, reversed Ord on deadline [DEP naive-timer 0.2 + alloc BinaryHeap] --
+// entry: x = deadline lo, y = deadline hi, z = meta, w = payload value
+__device__ __forceinline__ uint64_t ev_deadline(const uint4& e) { return u64of(e.x, e.y); }
+
+// Entries [0, heap_lds) live in LDS; entries beyond spill to HBM as [slot][global lane] (coalesced
+// across the wave).  Variants without a spill region drop the HBM path.  The LDS load is issued
+// unconditionally (clamped index) and the HBM value selected afterwards, so the two address spaces
+// never merge into a flat_* access.
+template <class K>
+__device__ __forceinline__ uint4 heap_get(const Ctx& c, uint32_t i) {
+    if (!K::SPILL) return LDS128(c.heap0 + (i << LWSH<K>(c)));
+    uint32_t cap = c.P.heap_lds;
+    uint4 v = LDS128(c.heap0 + ((i < cap ? i : cap - 1) << LWSH<K>(c)));
+    if (i >= cap) v = c.spill[(size_t)(i - cap) * c.P.total_lanes];
+    return v;
+}
+template <class K>
+__device__ __forceinline__ void heap_set(const Ctx& c, uint32_t i, const uint4& e) {
+    if (!K::SPILL || i < c.P.heap_lds) LDS128(c.heap0 + (i << LWSH<K>(c))) = e;
+    else c.spill[(size_t)(i - c.P.heap_lds) * c.P.total_lanes] = e;
+}
+
+// BinaryHeap::sift_up(0, pos) with `hole` as the moving element; keeps the root mirror current.
+template <class K>
+__device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos, const uint4& hole) {
+    uint64_t hd = ev_deadline(hole);
+    while (pos > 0) {
+        REG(11);
+        uint32_t parent = (pos - 1) >> 1;
+        if (parent == 0 && hd >= L.top_dl) break;      // root deadline is mirrored in a register
+        uint4 p = heap_get<K>(c, parent);
+        if (hd >= ev_deadline(p)) break;     // hole <= parent in heap order: stop
+        heap_set<K>(c, pos, p);
+        pos = parent;
+    }
+    heap_set<K>(c, pos, hole);
+    if (pos == 0) L.top_dl = hd;
+}
+
+// Timer::add -> BinaryHeap::push.  Returns false on capacity overflow.
+template <class K>
+__device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val) {
+    PROBE2(0);
+    REG(10);
+    if (L.heap_len >= c.P.heap_lds + (K::SPILL ? c.P.heap_spill : 0u)) return false;
+    uint4 e = make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, val);
+    heap_sift_up<K>(c, L, L.heap_len, e);
+    L.heap_len++;
+    PROBE2(10);
+    return true;
+}
+
+// BinaryHeap::pop: swap the last element into the root, sift_down_to_bottom(0), then sift_up.
+template <class K>
+__device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
+    PROBE2(0);
+    REG(20);
+    uint32_t end = --L.heap_len;
+    uint4 item = heap_get<K>(c, end);
+    if (end > 0) {
+        uint4 top = heap_get<K>(c, 0);
+        uint32_t pos = 0, child = 1;
+        while (child + 1 < end) {
+            REG(21);
+            uint4 l = heap_get<K>(c, child), r = heap_get<K>(c, child + 1);
+            bool right = ev_deadline(l) >= ev_deadline(r);   // left <= right in heap order: take right
+            uint4 m = right ? r : l;
+            heap_set<K>(c, pos, m);
+            if (pos == 0) L.top_dl = ev_deadline(m);
+            pos = child + (right ? 1u : 0u);
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1) {
+            uint4 m = heap_get<K>(c, child);
+            heap_set<K>(c, pos, m);
+            if (pos == 0) L.top_dl = ev_deadline(m);
+            pos = child;
+        }
+        heap_sift_up<K>(c, L, pos, item);
+        item = top;
+    } else {
+        L.top_dl = ~0ull;
+    }
+    PROBE2(11);
+    return item;
+}
+
+}  // namespace madsim_k
+
+#endif

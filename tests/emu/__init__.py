@@ -17,6 +17,7 @@ _LIB = os.path.join(_HERE, "libmadsim_emu.so")
 _SRCS = [os.path.join(_HERE, "emu_driver.cpp"), os.path.join(_HERE, "emu_shim.h"),
          os.path.join(_ROOT, "madsim_amd", "csrc", "sim_kernel.hip"),
          os.path.join(_ROOT, "madsim_amd", "csrc", "sim_kernel.h"),
+         *sorted(__import__("glob").glob(os.path.join(_ROOT, "madsim_amd", "csrc", "kernel", "*.h"))),
          os.path.join(_ROOT, "madsim_amd", "csrc", "geometry.h"),
          os.path.join(_ROOT, "include", "madsim_hip.h")]
 
