@@ -182,7 +182,8 @@ def main():
             "config": {"workload": f"{wname}, {per_gpu} seeds per GPU per step"
                                    + (" (BASELINE configs[1])" if args.workload == "pingpong" and args.nodes == N_NODES else ""),
                        "seeds_per_step": total, "parallelism": f"seed-shard x{world}" + (f", {n_streams} concurrent batches per GPU" if n_streams > 1 else "")},
-            "extra": {"seeds_per_sec": seeds_total / dt, "executor_steps_per_sec": steps_total / dt,
+            "extra": {"seeds_per_sec": seeds_total / dt, "first_fail_seeds_per_hour": seeds_total / dt * 3600.0,
+                      "executor_steps_per_sec": steps_total / dt,
                       "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms,
                       "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu * g.block_threads // 64,
                       "lanes_per_wave": g.lanes_per_wave},
