@@ -61,7 +61,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+            try:     # RCCL kernels on a high-priority stream: they take the first CU slot a finishing simulation wave frees
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", gpu), pg_options=opts)
+            except (AttributeError, TypeError):
+                dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
         else:
             dist.init_process_group(backend)
     dev = torch.device("cuda", gpu)
