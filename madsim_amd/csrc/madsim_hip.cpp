@@ -193,8 +193,9 @@ int madsim_hip_init(int device) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(MADSIM_E_HIP, "no HIP device visible (this library has no CPU fallback)");
     if (device < 0 || device >= n) return fail(MADSIM_E_ARG, "device index out of range");
+    if (g.inited && g.device == device) { HIP_TRY(hipSetDevice(device)); return 0; }
+    if (g.inited) return fail(MADSIM_E_ARG, "already bound to another GPU: one process per GPU (call madsim_hip_shutdown first)");
     HIP_TRY(hipSetDevice(device));
-    if (g.inited && g.device == device) return 0;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     g.device = device;
