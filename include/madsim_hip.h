@@ -118,6 +118,11 @@ enum madsim_op {
                               task received (or inherited at spawn): the tail of add_rpc_handler (rpc.rs:170-176) */
     MS_OP_RAND_BOOL = 53,  /* a=index into madsim_config_t.loss_table: val = thread_rng().gen_bool(p) as u32 — one
                               RngCore draw unless p == 1 (madsim-etcd-client/src/service.rs:165-166)        */
+    MS_OP_RANDOM = 54,     /* a=0: val = thread_rng().gen::<u32>() (rand.rs:142-158, one with());
+                              a=1: val = the byte of getrandom(&mut [0u8; 1]) (rand.rs:197-211: with(|r| r.fill_bytes(buf))) */
+    MS_OP_TRACE_TIME = 55, /* a=0: obs_hash <- fold(SystemTime::now() in ns since UNIX_EPOCH): the per-seed base time
+                              (time/mod.rs:26-33) + elapsed; a=1: fold(Instant elapsed ns) (system_time.rs:122-154);
+                              a=2: fold(val): make the last received / drawn value observable                      */
     MS_OP__COUNT
 };
 

@@ -98,6 +98,11 @@ class Task {
         uint64_t ns = (uint64_t)hi.count();
         return emit(MS_OP_SLEEP_RAND, (uint8_t)(lo.count() / 50), (uint16_t)(ns / 1000000000ull), (uint32_t)(ns % 1000000000ull));
     }
+    Task& random_u32() { return emit(MS_OP_RANDOM, 0); }
+    Task& getrandom_byte() { return emit(MS_OP_RANDOM, 1); }
+    Task& trace_system_time() { return emit(MS_OP_TRACE_TIME, 0); }
+    Task& trace_instant() { return emit(MS_OP_TRACE_TIME, 1); }
+    Task& trace_val() { return emit(MS_OP_TRACE_TIME, 2); }
     Task& rand_bool(int table_index) { return emit(MS_OP_RAND_BOOL, (uint8_t)table_index); }
     Task& jeq(uint32_t value, int target) { return emit(MS_OP_JEQ, 0, (uint16_t)target, value, true); }
     // reliable channel (Endpoint::connect1 / accept1)

@@ -145,7 +145,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         if (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) P.restart_nodes |= 1u << i;
     P.has_restart_on_panic = P.restart_nodes != 0;
     P.lifecycle = P.has_restart_on_panic || uses_op(w, MS_OP_KILL) || uses_op(w, MS_OP_RESTART) || uses_op(w, MS_OP_PAUSE) ||
-                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND) || uses_op(w, MS_OP_RAND_BOOL) || P.uses_chan || P.uses_rpc ||
+                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND) || uses_op(w, MS_OP_RAND_BOOL) || uses_op(w, MS_OP_RANDOM) || uses_op(w, MS_OP_TRACE_TIME) || P.uses_chan || P.uses_rpc ||
                   uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_ADVANCE);
     for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.lifecycle = 1;
     // The generic kernel variants (trace, lanes_per_wave != 64) are compiled with the extended ops, so they need the
@@ -165,7 +165,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         // JoinHandle words: a plane with the extended ops, else unit1.y of task slot p (sim_kernel.hip HW)
         P.off_nodes = P.off_handles + (P.lifecycle ? P.n_progs : 0);
         // node region (extended ops only): killed / paused / gen0_killed masks, spawn counter, one info_gen byte per node
-        P.off_clog = P.off_nodes + (P.lifecycle ? 4 + (P.n_nodes + 4) / 4 : 0);
+        P.off_clog = P.off_nodes + (P.lifecycle ? 4 + (P.n_nodes + 4) / 4 + 1 : 0);   // + the base-time word
         P.off_pause = P.off_clog + (P.has_clog ? 2 + (P.has_clog_link ? P.n_nodes + 1 : 0) : 0);
         P.uses_pause = uses_op(w, MS_OP_PAUSE);
         P.off_greg = P.off_pause + (P.uses_pause ? 1 + P.max_tasks : 0);

@@ -629,6 +629,21 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 CLOGW(2 + a) &= ~(1u << b);
                 pc++;
                 break;
+            case MS_OP_RANDOM: {                            // one with() on the GlobalRng's RngCore impl (rand.rs:142-158)
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint64_t v = rng_next(L); rng_log<K>(c, L);
+                u0.w = a == 0 ? (uint32_t)(v >> 32) : (uint32_t)((v >> 32) & 0xff);   // gen::<u32>() / getrandom 1 byte [DEP]
+                pc++;
+                break;
+            }
+            case MS_OP_TRACE_TIME: {                        // SystemTime::now() / Instant elapsed (time/system_time.rs)
+                if (!K::LIFE) { st = ST_PANIC; break; }
+                uint64_t v = a == 2 ? (uint64_t)u0.w : L.clock;
+                if (a == 0) v += (1639872000ull + NODEW(4 + ((P.n_nodes + 4) >> 2))) * NS_PER_S;   // 52 x 365 days + the draw
+                L.obs_hash = (L.obs_hash ^ v) * FNV_PRIME;
+                pc++;
+                break;
+            }
             case MS_OP_RAND_BOOL:                           // thread_rng().gen_bool(p) [DEP A.4]
                 if (!K::LIFE) { st = ST_PANIC; break; }
                 u0.w = gen_bool_pint<K>(c, L, P.loss_table_pint[a & 3], P.loss_table_always[a & 3]) ? 1u : 0u;

@@ -58,7 +58,8 @@ __device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     L.ready_len = 0; L.rq = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING; L.ovf = 0; L.main_done = 0;
     L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
     // TimeRuntime::new (time/mod.rs:26-38): base_time draw, before logging is enabled
-    { uint64_t h = L.trace_hash, n = L.log_len; (void)gen_range_small<Variant<false, false, K::LWS, false, K::RQ>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n; }
+    { uint64_t h = L.trace_hash, n = L.log_len; uint32_t bt = gen_range_small<Variant<false, false, K::LWS, false, K::RQ>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n;
+      if (K::LIFE) NODEW(4 + ((P.n_nodes + 4) >> 2)) = bt; }      // seconds into 2022: SystemTime::now() of MS_OP_TRACE_TIME
     L.trace_hash = FNV_OFFSET; L.obs_hash = FNV_OFFSET; L.log_len = 0;
     // tasks spawned before block_on, then the main task (task/mod.rs:222-235)
     for (uint32_t p = 1; p < P.n_progs; p++) {

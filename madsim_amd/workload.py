@@ -203,6 +203,26 @@ class TaskBuilder:
         b, imm = _dur(**kw)
         return self._emit("SLEEP_RAND", a=lo_ms // 50, b=b, imm=imm)
 
+    def random_u32(self):
+        """val = thread_rng().gen::<u32>()"""
+        return self._emit("RANDOM", a=0)
+
+    def getrandom_byte(self):
+        """val = the byte of getrandom(&mut [0u8; 1]) (the libc interposer routes it to the GlobalRng, rand.rs:197-211)"""
+        return self._emit("RANDOM", a=1)
+
+    def trace_system_time(self):
+        """observe SystemTime::now() (per-seed base time around 2022 + elapsed)"""
+        return self._emit("TRACE_TIME", a=0)
+
+    def trace_val(self):
+        """observe the value last received / drawn"""
+        return self._emit("TRACE_TIME", a=2)
+
+    def trace_instant(self):
+        """observe Instant::now() relative to the runtime's start"""
+        return self._emit("TRACE_TIME", a=1)
+
     def rand_bool(self, table_index):
         """val = thread_rng().gen_bool(config.loss_table[table_index]) as u32 (one draw unless p == 1)."""
         return self._emit("RAND_BOOL", a=table_index)

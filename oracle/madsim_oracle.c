@@ -155,6 +155,7 @@ typedef struct {
     uint64_t trace_hash; uint8_t* log; uint64_t log_len, log_cap;
     /* Clock + Timer */
     uint64_t clock;
+    uint64_t base_time_ns; /* Clock.base_time since UNIX_EPOCH (time/mod.rs:26-33)                      */
     VEC(event_t) heap;
     /* Executor */
     VEC(uint16_t) ready;
@@ -942,6 +943,19 @@ static int poll_task(sim_t* S, uint16_t slot) {
             t->pc++;
             break;
         }
+        case MS_OP_RANDOM: {                               /* one with() on the GlobalRng's RngCore impl (rand.rs:142-158) */
+            uint64_t v = rng_next(S); rng_log(S);
+            /* a=0: gen::<u32>() = next_u32 = upper half [DEP A.1]; a=1: fill_bytes of 1 byte = first LE byte of next_u32
+             * [DEP rand_core 0.6 fill_bytes_via_next: a tail of <= 4 bytes takes next_u32] */
+            t->val = in->a == 0 ? (uint32_t)(v >> 32) : (uint32_t)((v >> 32) & 0xff);
+            t->pc++;
+            break;
+        }
+        case MS_OP_TRACE_TIME: {                           /* SystemTime::now() / Instant::now() (time/system_time.rs) */
+            uint64_t v = in->a == 0 ? S->base_time_ns + S->clock : in->a == 1 ? S->clock : t->val;
+            S->obs_hash = (S->obs_hash ^ v) * FNV_PRIME; t->pc++;
+            break;
+        }
         case MS_OP_RAND_BOOL: {                            /* thread_rng().gen_bool(p): Bernoulli on the GlobalRng [DEP A.4] */
             double p = S->cfg->loss_table[in->a & 3];
             int always = p == 1.0;
@@ -1060,7 +1074,7 @@ static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, cons
      * construction (runtime/mod.rs:185-186), so this draw is not in the determinism log. */
     {
         uint64_t h = S.trace_hash, n = S.log_len;
-        (void)gen_range_u64(&S, 0, 60ull * 60 * 24 * 365);
+        S.base_time_ns = (60ull * 60 * 24 * 365 * (2022 - 1970) + gen_range_u64(&S, 0, 60ull * 60 * 24 * 365)) * NS_PER_S;
         S.trace_hash = h; S.log_len = n;
     }
     /* Tasks spawned BEFORE block_on (the `runtime.create_node()..build(); node.spawn(..);

@@ -320,6 +320,49 @@ def rpc_server_restart():
 ALL.update(rpc_echo=rpc_echo, rpc_call_timeout_then_retry=rpc_call_timeout_then_retry, rpc_server_restart=rpc_server_restart)
 
 
+def std_system_time():
+    """time/system_time.rs:122-154: `t0 = SystemTime::now(); sleep(1 s); assert!(t0.elapsed() >= 1 s); t0` — the observed
+    wall-clock time depends on the seed (base time drawn around 2022), the Instant-based duration does not."""
+    wl = W.WorkloadBuilder()
+    m = wl.main()
+    m.trace_system_time(); m.mark(); m.sleep(secs=1); m.assert_elapsed(">=", secs=1); m.trace_instant()
+    return wl.build()
+
+
+def getrandom_deterministic():
+    """rand.rs:331-354 (issue 201): getrandom inside the simulation is served by the GlobalRng."""
+    wl = W.WorkloadBuilder()
+    m = wl.main()
+    m.getrandom_byte(); m.trace_val(); m.random_u32(); m.trace_val()
+    return wl.build()
+
+
+def buggify_rates():
+    """buggify.rs:36-60: of 1000 `buggify()` draws (gen_bool(0.25), config.loss_table[1]) 200..300 are true, of 1000
+    `buggify_with_prob(0.1)` draws (loss_table[2]) 50..150."""
+    wl = W.WorkloadBuilder()
+    m = wl.main()
+    for idx, flag, lo, hi in ((1, 0, 200, 300), (2, 2, 50, 150)):
+        m.set(0, 1000)
+        top = m.label()
+        m.rand_bool(idx)
+        m.jeq(0, top + 4)
+        m.flag_add(flag, 1); m.jmp(top + 5)
+        m.flag_add(flag + 1, 1)
+        m.djnz(0, top)
+        m.panic_if_flag_lt(flag, lo); m.panic_if_flag_lt(flag + 1, 1000 - hi + 1)
+    return wl.build()
+
+
+ALL.update(std_system_time=std_system_time, getrandom_deterministic=getrandom_deterministic, buggify_rates=buggify_rates)
+CONFIGS = {"buggify_rates": dict(loss_table=(0.0, 0.25, 0.1))}
+
+
+def config(name):
+    """Non-default Config a workload is meant to run under (None = Config::default())."""
+    return A.Config.default(**CONFIGS[name]) if name in CONFIGS else None
+
+
 def limits(name):
     """Device capacities a workload needs beyond the defaults (None = defaults)."""
     if name == "rpc_server_restart":                  # timed-out calls leave dead registrations behind (rpc.rs:125)

@@ -83,7 +83,7 @@ from tests import lifecycle_workloads as LW  # noqa: E402
 @pytest.mark.parametrize("name", sorted(LW.ALL))
 def test_lifecycle_reference_tests(name):
     """kill / restart / restart_on_panic / pause_resume / exited / join_cancelled ... (task/mod.rs:859-1182)."""
-    o = _same(LW.ALL[name](), 0, 128, None, LW.limits(name))
+    o = _same(LW.ALL[name](), 0, 128, LW.config(name), LW.limits(name))
     assert (o["verdict"] == (A.PANIC if name in LW.EXPECT_PANIC else A.PASS)).all()
 
 

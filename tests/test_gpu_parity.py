@@ -219,7 +219,7 @@ from tests import lifecycle_workloads as LW  # noqa: E402
 @pytest.mark.parametrize("name", sorted(LW.ALL))
 def test_lifecycle_reference_tests_gpu(hip, name):
     """The reference's node-lifecycle unit tests (task/mod.rs:859-1182) executed by the kernel, 1024 seeds each."""
-    got, _ = _cmp(hip, LW.ALL[name](), 0, 1024, None, LW.limits(name))
+    got, _ = _cmp(hip, LW.ALL[name](), 0, 1024, LW.config(name), LW.limits(name))
     assert (got["verdict"] == (A.PANIC if name in LW.EXPECT_PANIC else A.PASS)).all()
 
 

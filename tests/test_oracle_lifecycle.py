@@ -9,7 +9,7 @@ from tests import lifecycle_workloads as LW
 
 @pytest.mark.parametrize("name", sorted(LW.ALL))
 def test_reference_lifecycle_test(name):
-    out, summ = oracle.run_batch(LW.ALL[name](), 0, 64)
+    out, summ = oracle.run_batch(LW.ALL[name](), 0, 64, LW.config(name))
     want = A.PANIC if name in LW.EXPECT_PANIC else A.PASS
     assert (out["verdict"] == want).all(), (name, np.bincount(out["verdict"]))
 

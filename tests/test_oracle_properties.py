@@ -153,3 +153,36 @@ def test_loss_produces_deadlocks_and_min_first_fail():
     fails = np.nonzero(out["verdict"] != A.PASS)[0]
     assert len(fails) > 0 and summ.n_failed == len(fails) and summ.first_failing_seed == fails[0]
     assert set(out["verdict"][fails].tolist()) == {A.DEADLOCK}
+
+
+def test_deterministic_std_system_time():
+    """time/system_time.rs:122-137: 9 runs on seeds 0,0,0,1,1,1,2,2,2 observe 3 distinct SystemTime values (the base time
+    is a per-seed draw) — and, deterministic_std_instant (:140-154), one single Instant-based duration."""
+    from tests import lifecycle_workloads as LW
+    w = LW.std_system_time()
+    seen = set()
+    for i in range(9):
+        out, _ = oracle.run_batch(w, i // 3, 1)
+        assert out["verdict"][0] == A.PASS
+        seen.add(int(out["obs_hash"][0]))
+    assert len(seen) == 3
+    out, _ = oracle.run_batch(w, 0, 64)
+    assert len(set(out["obs_hash"].tolist())) == 64                    # 64 seeds, 64 base times
+
+
+def test_getrandom_should_be_deterministic():
+    """rand.rs:331-354: ten runs of one seed draw the same getrandom byte; seeds differ."""
+    from tests import lifecycle_workloads as LW
+    w = LW.getrandom_deterministic()
+    runs = {tuple(oracle.run_batch(w, 42, 1)[0][0].tolist()) for _ in range(10)}
+    assert len(runs) == 1
+    out, _ = oracle.run_batch(w, 0, 256)
+    assert len(set(out["obs_hash"].tolist())) == 256
+
+
+def test_buggify_rate_bounds():
+    """buggify.rs:36-60: 1000 draws at 25 % land in 200..300, at 10 % in 50..150 (asserted inside the workload)."""
+    from tests import lifecycle_workloads as LW
+    out, _ = oracle.run_batch(LW.buggify_rates(), 0, 64, LW.config("buggify_rates"))
+    assert (out["verdict"] == A.PASS).all()
+    assert (out["rng_calls"] >= 2001).all()
