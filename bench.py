@@ -28,8 +28,8 @@ HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s mea
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--seeds", type=int, default=SEEDS_PER_GPU, help="seeds per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lpw", type=int, default=0, help="seed-carrying lanes per wave (0 = library auto)")
