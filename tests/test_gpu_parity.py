@@ -380,3 +380,29 @@ def test_rpc_echo_65536_seeds(hip):
     idx = np.arange(0, n, 257)
     want = np.concatenate([oracle.run_batch(w, 9_000_000 + int(i), 1)[0] for i in idx])
     assert (got[idx] == want).all()
+
+
+@pytest.mark.parametrize("count", [0, 1, 63, 65, 255, 4097])
+def test_ragged_and_empty_batches(hip, count):
+    """Batch sizes that do not fill a wave / a workgroup, and the empty batch."""
+    w = W.pingpong(4, 8)
+    got, summ = hip.run_batch(w, 77, count)
+    want, osumm = oracle.run_batch(w, 77, count)
+    assert len(got) == count and (got == want).all()
+    assert (summ.n_failed, summ.first_failing_seed, summ.total_steps) == (osumm.n_failed, osumm.first_failing_seed, osumm.total_steps)
+
+
+def test_largest_topology(hip):
+    """The largest ping-pong the device tables admit: 30 nodes (31 with the supervisor), 31 programs, 30 sockets."""
+    _cmp(hip, W.pingpong(30, 2), 5, 256)
+
+
+def test_seed_range_extremes(hip):
+    """Seeds near 0 and near 2^64 (seed arithmetic is u64, the first-fail key flips the sign bit)."""
+    w = W.pingpong(2, 4)
+    cfg = A.Config.default(packet_loss_rate=0.3)
+    top = (1 << 64) - 600
+    got, summ = hip.run_batch(w, top, 512, cfg)
+    want, osumm = oracle.run_batch(w, top, 512, cfg)
+    assert (got == want).all() and osumm.n_failed > 0
+    assert summ.first_failing_seed == osumm.first_failing_seed and summ.n_failed == osumm.n_failed
