@@ -168,7 +168,7 @@ struct Workload {
 
 class WorkloadBuilder {
   public:
-    WorkloadBuilder() { nodes_.push_back(madsim_node_t{}); tasks_.push_back(Task(0, 0, 0)); }
+    WorkloadBuilder() { tasks_.reserve(256); nodes_.push_back(madsim_node_t{}); tasks_.push_back(Task(0, 0, 0)); }   // Task& stay valid
     Task& main() { return tasks_[0]; }                                   // the future handed to block_on
     int create_node(bool restart_on_panic = false) {                     // Handle::create_node()[.restart_on_panic()].build()
         madsim_node_t n{}; n.flags = restart_on_panic ? MADSIM_NODE_RESTART_ON_PANIC : 0;
@@ -176,7 +176,7 @@ class WorkloadBuilder {
     }
     int addr(int node, uint16_t port) { socks_.push_back(madsim_sock_t{(uint8_t)node, 0, port}); return (int)socks_.size() - 1; }
     Task& task(int node, bool init = false, bool before_block_on = false) {
-        tasks_.reserve(256);
+        if (tasks_.size() >= 255) throw std::length_error("at most 255 task programs");
         tasks_.push_back(Task((int)tasks_.size(), node, (uint8_t)((init ? MADSIM_PROG_INIT : 0) | (before_block_on ? MADSIM_PROG_PRE : 0))));
         return tasks_.back();
     }
@@ -219,6 +219,7 @@ struct Builder {
     bool check = false;
     bool allow_system_thread = false;
     int device = 0;
+    madsim_limits_t capacities{};            // device capacities to start from (no reference counterpart; 0 = defaults)
 
     // builder.rs:64-118
     static Builder from_env() {
@@ -253,7 +254,7 @@ struct Builder {
         madsim::check(madsim_hip_init(device));
         madsim_workload_t w = wl.raw();
         madsim_config_t cfg = config.raw();
-        madsim_limits_t lim{};
+        madsim_limits_t lim = capacities;
         if (time_limit) lim.time_limit_ns = (uint64_t)(*time_limit * 1e9 + 0.5);
         if (check) {                                   // Runtime::check_determinism (runtime/mod.rs:178-202)
             std::vector<uint8_t> l1(1 << 20), l2(1 << 20);

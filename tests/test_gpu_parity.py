@@ -210,6 +210,11 @@ def test_cpp_host_mirror_runs_like_cargo_test(hip):
     p = subprocess.run([exe], env=dict(os.environ, MADSIM_TEST_SEED="3", MADSIM_TEST_NUM="64", MADSIM_TEST_TIME_LIMIT="1.5"),
                        capture_output=True, text=True)
     assert p.returncode == 101 and "note: run with `MADSIM_TEST_SEED=3` environment variable" in p.stderr
+    # typed RPC + server kill/restart through the same mirror (examples/rpc_restart_test.cpp = lifecycle_workloads.rpc_server_restart)
+    exe2 = os.path.join(root, "examples", "rpc_restart_test")
+    if os.path.exists(exe2):
+        p = subprocess.run([exe2], env=dict(os.environ, MADSIM_TEST_SEED="11", MADSIM_TEST_NUM="2048"), capture_output=True, text=True)
+        assert p.returncode == 0 and "test rpc_survives_restart ... ok (2048 seeds from 11)" in p.stdout, p.stderr
     hip.init(0)
 
 
