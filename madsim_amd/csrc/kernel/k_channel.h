@@ -8,7 +8,7 @@ namespace madsim_k {
 // ---- reliable channel (NetSim::connect1 / channel, net/mod.rs:337-430) — LIFE variants only ---------------------
 // Network::try_send as a function (the datagram path has it inlined in poll_task's [A] stage).
 template <class K>
-__device__ bool try_send_fn(const Ctx& c, Lane& L, uint32_t src_node, uint32_t dst_addr, uint64_t* latency, int* dst_sock) {
+__device__ __forceinline__ bool try_send_fn(const Ctx& c, Lane& L, uint32_t src_node, uint32_t dst_addr, uint64_t* latency, int* dst_sock) {
     const KParams& P = c.P;
     uint32_t dst_node = SOCKW(c, dst_addr) & 0xff;
     bool clogged = false;
@@ -26,7 +26,7 @@ __device__ bool try_send_fn(const Ctx& c, Lane& L, uint32_t src_node, uint32_t d
 
 // the `test_link` closure of channel() (net/mod.rs:375-380): Some(now + latency) or None
 template <class K>
-__device__ uint64_t chan_test_link(const Ctx& c, Lane& L, uint32_t cw, uint32_t dir) {
+__device__ __forceinline__ uint64_t chan_test_link(const Ctx& c, Lane& L, uint32_t cw, uint32_t dir) {
     uint32_t c_ep = (cw >> 1) & 0x3f, s_ep = (cw >> 7) & 0x3f;
     uint64_t lat; int ds;
     if (!try_send_fn<K>(c, L, SOCKW(c, dir == 0 ? c_ep : s_ep) & 0xff, dir == 0 ? s_ep : c_ep, &lat, &ds)) return ~0ull;
@@ -35,7 +35,7 @@ __device__ uint64_t chan_test_link(const Ctx& c, Lane& L, uint32_t cw, uint32_t 
 
 // drop the (Sender, Receiver) pair of one end of connection `id`
 template <class K>
-__device__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side) {
+__device__ __forceinline__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side) {
     uint32_t cw = CONNW(id, 0);
     if (cw & (1u << (13 + 2 * side))) {                       // my PayloadSender: last mpsc sender gone
         cw &= ~(1u << (13 + 2 * side));
@@ -50,7 +50,7 @@ __device__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t s
 
 // the listening Endpoint is dropped: connections still queued in conn_rx go with it
 template <class K>
-__device__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s) {
+__device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s) {
     uint32_t base = 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs;
     uint32_t q = SW(c, s, base);
     SW(c, s, base) = 0; SW(c, s, base + 1) = 0;

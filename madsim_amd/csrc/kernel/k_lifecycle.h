@@ -34,8 +34,8 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
     return slot;
 }
 
-template <class K> __device__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side);
-template <class K> __device__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s);
+template <class K> __device__ __forceinline__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side);
+template <class K> __device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s);
 
 // The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
 template <class K>
@@ -66,7 +66,7 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
 // NodeInfo::kill (task/mod.rs:133-140): mark + wake every live task holding NodeInfo `info_gen` of `node`, in
 // spawn order (the order of NodeInfo.tasks).  Tasks carry their spawn sequence number, so no list is stored.
 template <class K>
-__device__ void info_kill(const Ctx& c, Lane& L, uint32_t node, uint32_t info_gen) {
+__device__ __forceinline__ void info_kill(const Ctx& c, Lane& L, uint32_t node, uint32_t info_gen) {
     uint32_t last = 0xffffffffu;                            // "none yet": sequence numbers are < 2^24
     for (;;) {
         uint32_t best = 0xffffffffu, best_seq = 0xffffffffu;
@@ -91,7 +91,7 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
 
 // node.paused.clear() (task/mod.rs:365,392): the parked Runnables of `node` are dropped, in order.
 template <class K>
-__device__ void paused_clear(const Ctx& c, Lane& L, uint32_t node) {
+__device__ __forceinline__ void paused_clear(const Ctx& c, Lane& L, uint32_t node) {
     if (!c.P.uses_pause) return;
     uint32_t n = PAUSEW(0), keep = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -103,7 +103,7 @@ __device__ void paused_clear(const Ctx& c, Lane& L, uint32_t node) {
 }
 
 template <class K>
-__device__ void node_kill(const Ctx& c, Lane& L, uint32_t node) {        // TaskHandle::kill_id (task/mod.rs:362-371)
+__device__ __forceinline__ void node_kill(const Ctx& c, Lane& L, uint32_t node) {        // TaskHandle::kill_id (task/mod.rs:362-371)
     paused_clear<K>(c, L, node);
     uint32_t g = NODE_INFO_GEN(node);
     NODEW(0) |= 1u << node;
@@ -114,7 +114,7 @@ __device__ void node_kill(const Ctx& c, Lane& L, uint32_t node) {        // Task
 }
 
 template <class K>
-__device__ void node_restart(const Ctx& c, Lane& L, uint32_t node) {     // TaskHandle::restart (task/mod.rs:374-401)
+__device__ __forceinline__ void node_restart(const Ctx& c, Lane& L, uint32_t node) {     // TaskHandle::restart (task/mod.rs:374-401)
     uint32_t g = NODE_INFO_GEN(node);
     if (g == 0) NODEW(2) |= 1u << node;
     uint32_t w = NODEW(4 + (node >> 2)), sh = (node & 3) * 8;

@@ -81,7 +81,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     SW(c, s, 0) = (h & ~((0xffu << 9) | (0xffu << 17))) | (nreg << 9) | (nmsg << 17);
 }
 
-template <class K> __device__ void node_restart(const Ctx& c, Lane& L, uint32_t node);
+template <class K> __device__ __forceinline__ void node_restart(const Ctx& c, Lane& L, uint32_t node);
 
 // Timer::expire [DEP A.5]: fire every entry with deadline <= now
 template <class K>

@@ -45,7 +45,7 @@ namespace madsim_k {
 
 // ---- per-seed init: Runtime::with_seed_and_config (runtime/mod.rs:53-69) ------------------------
 template <class K>
-__device__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
+__device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     const KParams& P = c.P;
     for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;          // plane 0 is the ready queue: RW spans all planes
     for (uint32_t t = 0; t < P.max_tasks; t++) { TWORD(c, t, 0, 0) = 0; if (!K::LIFE) TWORD(c, t, 1, 1) = 0; }
