@@ -210,7 +210,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     const uint64_t want = (count + lw - 1) / lw;      // waves this batch needs
     auto waves_at = [&](uint32_t w2) {
         uint32_t blocks = (uint32_t)(g.lds_per_cu / ((size_t)(P.sh_heap + w2 * P.wave_words) * 4));
-        return blocks * w2 < 16 ? blocks * w2 : 16u;         // VGPR budget admits 4 waves per SIMD
+        const uint32_t cap = P.lifecycle ? 8u : 16u;         // VGPR budget: 4 waves per SIMD, 2 with the extended ops (~186 VGPRs)
+        return blocks * w2 < cap ? blocks * w2 : cap;
     };
     const uint32_t best = std::max(waves_at(1), std::max(waves_at(2), waves_at(4)));
     uint32_t W = 1;
@@ -220,7 +221,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.waves_per_block = W;
     G->lds_bytes = (P.sh_heap + W * P.wave_words) * 4;
     uint32_t bpc = (uint32_t)(g.lds_per_cu / G->lds_bytes);
-    if (bpc * W > 16) bpc = 16 / W;
+    if (bpc * W > (P.lifecycle ? 8u : 16u)) bpc = (P.lifecycle ? 8u : 16u) / W;
     if (bpc == 0) bpc = 1;
     G->blocks_per_cu = bpc;
     G->waves_per_block = W;

@@ -4,7 +4,7 @@ set -u
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_spill; mkdir -p $OUT
 for h in 4 32; do
-  CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload timers --heap-lds $h"
+  CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --workload timers --heap-lds $h"
   $CMD 2>&1 | tail -1 > $OUT/bench_h$h.json
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/h${h}_$c -o p -- $CMD > $OUT/h${h}_$c.log 2>&1
