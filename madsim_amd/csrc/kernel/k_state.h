@@ -88,6 +88,16 @@ extern __shared__ __attribute__((aligned(16))) uint32_t madsim_smem[];
 #define LDS128(i) (reinterpret_cast<uint4*>(SMEM)[(i)])
 #define LDS64(i) (reinterpret_cast<uint2*>(SMEM)[(i)])
 
+// The spill region is reached through a buffer resource (buffer_load/store_dwordx4, byte offsets in a VGPR): with a
+// plain pointer the compiler folds the LDS and HBM alternatives of heap_get/heap_set into one flat_load/flat_store,
+// which is slower for both and waits on both counters.
+#ifdef MADSIM_EMU
+struct SpillRef { uint4* base; };
+#else
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+struct SpillRef { __amdgpu_buffer_rsrc_t rsrc; };
+#endif
+
 struct Ctx {
     const KParams& P;
     uint32_t lws;        // log2(lane stride) (runtime copy; K::LWS overrides when >= 0)
@@ -97,7 +107,8 @@ struct Ctx {
     uint32_t task0;      // uint4 index of task unit 0
     uint32_t insn0;      // uint4 index of the workgroup-shared instruction table
     uint32_t prog0, sockt0;   // word indices of the shared prog / socket-address tables
-    uint4* spill;        // this lane's column of the HBM spill region, stride P.total_lanes
+    SpillRef spill;      // the HBM spill region: entry (slot, this lane) at byte (slot * P.total_lanes) * 16 + spill_off
+    uint32_t spill_off;  // this lane's column: global lane * 16
     uint8_t* tlog;       // trace mode only
     __device__ Ctx(const KParams& p) : P(p) {}
 };

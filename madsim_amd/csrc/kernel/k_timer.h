@@ -13,18 +13,35 @@ __device__ __forceinline__ uint64_t ev_deadline(const uint4& e) { return u64of(e
 // across the wave).  Variants without a spill region drop the HBM path.  The LDS load is issued
 // unconditionally (clamped index) and the HBM value selected afterwards, so the two address spaces
 // never merge into a flat_* access.
+__device__ __forceinline__ uint4 spill_load(const Ctx& c, uint32_t slot) {
+#ifdef MADSIM_EMU
+    return c.spill.base[(size_t)slot * c.P.total_lanes + c.spill_off / 16];
+#else
+    u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(c.spill.rsrc, slot * c.P.total_lanes * 16u + c.spill_off, 0, 0);
+    return make_uint4(t.x, t.y, t.z, t.w);
+#endif
+}
+__device__ __forceinline__ void spill_store(const Ctx& c, uint32_t slot, const uint4& e) {
+#ifdef MADSIM_EMU
+    c.spill.base[(size_t)slot * c.P.total_lanes + c.spill_off / 16] = e;
+#else
+    u32x4_t t = {e.x, e.y, e.z, e.w};
+    __builtin_amdgcn_raw_buffer_store_b128(t, c.spill.rsrc, slot * c.P.total_lanes * 16u + c.spill_off, 0, 0);
+#endif
+}
+
 template <class K>
 __device__ __forceinline__ uint4 heap_get(const Ctx& c, uint32_t i) {
     if (!K::SPILL) return LDS128(c.heap0 + (i << LWSH<K>(c)));
     uint32_t cap = c.P.heap_lds;
     uint4 v = LDS128(c.heap0 + ((i < cap ? i : cap - 1) << LWSH<K>(c)));
-    if (i >= cap) v = c.spill[(size_t)(i - cap) * c.P.total_lanes];
+    if (i >= cap) v = spill_load(c, i - cap);
     return v;
 }
 template <class K>
 __device__ __forceinline__ void heap_set(const Ctx& c, uint32_t i, const uint4& e) {
     if (!K::SPILL || i < c.P.heap_lds) LDS128(c.heap0 + (i << LWSH<K>(c))) = e;
-    else c.spill[(size_t)(i - c.P.heap_lds) * c.P.total_lanes] = e;
+    else spill_store(c, i - c.P.heap_lds, e);
 }
 
 // BinaryHeap::sift_up(0, pos) with `hole` as the moving element; keeps the root mirror current.

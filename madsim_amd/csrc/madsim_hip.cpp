@@ -113,6 +113,7 @@ int ensure_spill(KParams& P, hipStream_t stream) {
     P.spill = nullptr;
     if (!P.heap_spill) return 0;
     size_t need = (size_t)P.heap_spill * P.total_lanes * sizeof(uint4);
+    if (need >= (1ull << 32)) return fail(MADSIM_E_LIMITS, "heap spill region exceeds 4 GiB: lower heap_spill_slots");
     State::Spill& sp = g.spill[stream];
     if (need > sp.bytes) {
         if (sp.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(sp.p); }

@@ -103,7 +103,12 @@ __global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
     c.conn0 = pl + (P.off_conn << P.lw_shift);
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
     const uint32_t glane = ((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane;
-    c.spill = P.spill ? P.spill + glane : nullptr;
+    c.spill_off = glane * 16u;
+#ifdef MADSIM_EMU
+    c.spill.base = P.spill;
+#else   // gfx9 raw buffer, 32-bit data format; num_records in bytes (the host keeps the region below 4 GiB)
+    c.spill.rsrc = __builtin_amdgcn_make_buffer_rsrc(P.spill, 0, (uint32_t)((uint64_t)P.heap_spill * P.total_lanes * 16u), 0x00020000);
+#endif
     c.tlog = P.trace_log;
 
     Lane L;
