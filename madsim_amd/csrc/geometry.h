@@ -208,20 +208,23 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // co-resident and balanced, while one-wave workgroups stop overlapping beyond two concurrent launches.  So take
     // the largest W in {4, 2, 1} that costs at most one wave of LDS occupancy per CU.
     const uint64_t want = (count + lw - 1) / lw;      // waves this batch needs
+    // LDS is handed out in 1 280-byte granules (measured, tools/placement.hip: three 53 688-byte workgroups share a CU,
+    // three 54 000-byte ones do not), so a workgroup costs its size rounded up to that.
+    auto lds_alloc = [&](uint32_t w2) { size_t b = (size_t)(P.sh_heap + w2 * P.wave_words) * 4; return (b + 1279) / 1280 * 1280; };
+    const uint32_t cap = P.lifecycle ? 8u : 16u;      // VGPR budget: 4 waves per SIMD (~105 VGPRs), 2 with the extended ops (~186)
     auto waves_at = [&](uint32_t w2) {
-        uint32_t blocks = (uint32_t)(g.lds_per_cu / ((size_t)(P.sh_heap + w2 * P.wave_words) * 4));
-        const uint32_t cap = P.lifecycle ? 8u : 16u;         // VGPR budget: 4 waves per SIMD, 2 with the extended ops (~186 VGPRs)
+        uint32_t blocks = (uint32_t)(g.lds_per_cu / lds_alloc(w2));
         return blocks * w2 < cap ? blocks * w2 : cap;
     };
     const uint32_t best = std::max(waves_at(1), std::max(waves_at(2), waves_at(4)));
     uint32_t W = 1;
-    for (uint32_t w2 = 4; w2 >= 1; w2 >>= 1)
+    for (uint32_t w2 = 4; w2 >= 1; w2 >>= 1)        // powers of two: a 1 024-wave batch then fills whole workgroups
         if (waves_at(w2) + (best >= 8 ? 1u : 0u) >= best && waves_at(w2) > 0) { W = w2; break; }   // largest W within one wave of the best (none to spare below 8)
     if (want < W) W = want > 1 ? 2 : 1;
     P.waves_per_block = W;
     G->lds_bytes = (P.sh_heap + W * P.wave_words) * 4;
-    uint32_t bpc = (uint32_t)(g.lds_per_cu / G->lds_bytes);
-    if (bpc * W > (P.lifecycle ? 8u : 16u)) bpc = (P.lifecycle ? 8u : 16u) / W;
+    uint32_t bpc = (uint32_t)(g.lds_per_cu / lds_alloc(W));
+    if (bpc * W > cap) bpc = cap / W;
     if (bpc == 0) bpc = 1;
     G->blocks_per_cu = bpc;
     G->waves_per_block = W;
