@@ -126,7 +126,10 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // task units: 0-1 always; 2 = {t0, timeout()'s deadline} when used; then the connection unit, then the RPC unit
     P.task_units = t0 ? 3 : 2;
     if (P.uses_chan) { P.chan_unit = P.task_units; P.task_units++; }
-    if (P.uses_rpc) { P.rpc_unit = P.task_units; P.task_units++; }   // {rsp_tag in hand, rsp_tag staged with the oneshot value}
+    // {rsp_tag in hand, rsp_tag staged with the oneshot value}: the two t0 words of unit 2 when no MARK-family op needs
+    // them (unit 2's other half is the timeout deadline RPC calls use anyway), else a unit of their own
+    const bool mark = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED);
+    if (P.uses_rpc) { if (!mark) P.rpc_unit = 2; else { P.rpc_unit = P.task_units; P.task_units++; } }
     // per socket: header, owner, registrations, queued messages (+ accept queue, parked acceptor)
     P.sock_words = 2 + P.mbox_regs + 2 * P.mbox_msgs + (P.uses_chan ? 2 : 0);
     P.max_conns = L.max_conns ? L.max_conns : 4;
