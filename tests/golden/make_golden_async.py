@@ -1,0 +1,447 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/executor_kat_async.json — known answers for the oracle's await-heavy ops.
+
+A THIRD formulation of the executor, independent of both oracle/madsim_oracle.c (sub-state machine in C) and
+make_golden.py (sub-state machine in Python): here every task body is a Python *generator* — `yield` is
+`Poll::Pending`, `generator.close()` is dropping the future (its `finally:` blocks are the `Drop` impls), a
+`timeout()` is literally `select_biased!` over an inner generator and a Sleep.  Written from the reference
+sources: time/mod.rs:103-140 (sleep, timeout), time/sleep.rs:47-54 (Sleep::poll registers a timer on every
+not-elapsed poll), net/endpoint.rs:120-149,331-362 (send_to_raw / recv_from_raw / Mailbox), net/mod.rs:287-333
+(rand_delay, send), net/network.rs:162-203,261-313 (clog sets, try_send), net/rpc.rs:96-180 (call, call_timeout,
+add_rpc_handler), task/mod.rs:220-323 (executor loop), rand.rs:64-88,142-158 (log, RngCore).  It shares only the
+generator / gen_range / UniformDuration arithmetic with make_golden.py.
+
+Like make_golden.py it cannot be pinned to the Rust reference in this image; what the fixture gives is agreement of
+independently written restatements on timeouts' duplicate timers, dropped receivers, orphaned RPC responses.
+
+Run:  python tests/golden/make_golden_async.py
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+from madsim_amd import _abi as A  # noqa: E402
+from madsim_amd import workload as W  # noqa: E402
+from make_golden import FNV_OFFSET, FNV_PRIME, M64, OPN, Xoshiro, duration_params, gen_range_attempts  # noqa: E402
+
+MS = 1_000_000
+
+
+class Panic(Exception):
+    pass
+
+
+class Oneshot:
+    """tokio::sync::oneshot as the mailbox uses it: one value, a receiver that may be dropped."""
+
+    def __init__(self):
+        self.val, self.rx_alive, self.rx_task = None, True, None
+
+
+class Task:
+    def __init__(self, sim, prog):
+        self.prog, self.node = prog, sim.progs[prog][0]
+        self.alive, self.sched, self.running, self.joiner = True, True, False, None
+        self.cnt, self.val, self.frm, self.aux, self.t0 = [0, 0], 0, 0, 0, 0
+        self.owned = []
+        self.gen = sim.body(self, sim.progs[prog][2])
+
+
+class Sim:
+    def __init__(self, w, cfg, seed):
+        self.insns = [(w.insns[i].op, w.insns[i].a, w.insns[i].b, w.insns[i].imm) for i in range(w.struct.n_insns)]
+        self.progs = [(w.progs[i].node, w.progs[i].flags, w.progs[i].entry) for i in range(w.struct.n_progs)]
+        self.socks = [(w.socks[i].node, w.socks[i].port) for i in range(w.struct.n_socks)]
+        self.cfg, self.rng = cfg, Xoshiro(seed)
+        self.clock, self.log, self.logging = 0, [], False
+        self.heap, self.ready, self.handles, self.bound = [], [], {}, {}
+        self.steps, self.msg_count, self.obs, self.flags = 0, 0, FNV_OFFSET, [0, 0, 0, 0]
+        self.clog_in, self.clog_out = set(), set()
+        self.loss = cfg.packet_loss_rate
+        self.lat = duration_params(cfg.lat_lo_ns, cfg.lat_hi_ns)
+        self.base_ns = 0
+
+    # ---- GlobalRng (rand.rs) ------------------------------------------------------------------------------------
+    def with_log(self):
+        if self.logging:
+            v = (self.rng.peek() >> 32) & 0xFF
+            for i in range(8):
+                v ^= (self.clock >> (8 * i)) & 0xFF
+            self.log.append(v)
+
+    def gen_range(self, lo, hi):                    # rand.with(|r| r.gen_range(lo..hi)): ONE with() per call
+        v, _ = gen_range_attempts(self.rng, lo, hi)
+        self.with_log()
+        return v
+
+    def next_u64(self):                             # RngCore for GlobalRng: one with() per underlying call
+        v = self.rng.next()
+        self.with_log()
+        return v
+
+    def gen_bool(self, p):                          # Bernoulli [DEP A.4]
+        if p == 1.0:
+            return True
+        return self.next_u64() < int(p * 2.0**64)
+
+    def sample_duration(self, params):              # UniformDuration::sample on the GlobalRng itself
+        mode, low, rg, zone = params
+        while True:
+            v = self.next_u64()
+            if mode == 0:
+                m = (v >> 32) * rg
+                if (m & 0xFFFFFFFF) <= zone:
+                    return low + (m >> 32)
+            else:
+                m = v * rg
+                if (m & M64) <= zone:
+                    return low + (m >> 64)
+
+    # ---- Timer: Rust's BinaryHeap with reversed deadline order, by hand --------------------------------------
+    def sift_up(self, pos):
+        h = self.heap
+        hole = h[pos]
+        while pos > 0:
+            parent = (pos - 1) // 2
+            if hole[0] >= h[parent][0]:
+                break
+            h[pos] = h[parent]; pos = parent
+        h[pos] = hole
+
+    def timer_add(self, deadline, cb):
+        self.heap.append([deadline, cb]); self.sift_up(len(self.heap) - 1)
+
+    def timer_pop(self):
+        h = self.heap
+        item = h.pop()
+        if h:
+            item, h[0] = h[0], item
+            end, pos, hole, child = len(h), 0, h[0], 1
+            while child + 1 < end:
+                if h[child][0] >= h[child + 1][0]:
+                    child += 1
+                h[pos] = h[child]; pos = child; child = 2 * pos + 1
+            if child == end - 1:
+                h[pos] = h[child]; pos = child
+            h[pos] = hole
+            self.sift_up(pos)
+        return item
+
+    def expire(self, now):
+        while self.heap and self.heap[0][0] <= now:
+            _, cb = self.timer_pop()
+            self.steps += 1
+            cb()
+
+    # ---- tasks (async-task wake rules) --------------------------------------------------------------------------
+    def spawn(self, prog):
+        t = Task(self, prog)
+        self.ready.append(t); self.handles[prog] = t
+        return t
+
+    def wake(self, t):
+        if not t.alive or t.sched:
+            return
+        t.sched = True
+        if not t.running:
+            self.ready.append(t)
+
+    def finish(self, t):
+        t.gen.close()                               # the future is dropped: `finally:` blocks = Drop impls
+        for a in t.owned:                           # BindGuard::drop
+            if self.bound.get(a) is not None and self.bound[a]["owner"] is t:
+                self.bound[a] = None
+        t.alive = False
+        if t.joiner is not None:
+            self.wake(t.joiner)
+
+    # ---- futures ------------------------------------------------------------------------------------------------
+    def sleep_deadline(self, deadline):             # TimeHandle::sleep_until: 1 ms floor
+        return max(deadline, self.clock + MS)
+
+    def sleep_until(self, t, deadline):             # Sleep::poll
+        while self.clock < deadline:
+            self.timer_add(deadline, lambda: self.wake(t))
+            yield
+
+    def rand_delay(self, t):                        # NetSim::rand_delay (buggify off in the fixtures)
+        delay = self.gen_range(0, 5) * 1000
+        yield from self.sleep_until(t, self.sleep_deadline(self.clock + delay))
+
+    def send_raw(self, t, ep, dst, tag, val, aux=0):   # Endpoint::send_to_raw -> NetSim::send
+        yield from self.rand_delay(t)
+        src_node, dst_node = self.socks[ep][0], self.socks[dst][0]
+        if src_node in self.clog_out or dst_node in self.clog_in:
+            return
+        if self.gen_bool(self.loss):
+            return
+        self.msg_count += 1
+        lat = self.sample_duration(self.lat)
+        mbox = self.bound.get(dst)
+        if mbox is not None:
+            self.timer_add(self.clock + lat, lambda: self.deliver(mbox, tag, val, ep, aux))
+
+    def mailbox_recv(self, t, ep, tag):             # Mailbox::recv
+        mbox, os_ = self.bound[ep], Oneshot()
+        os_.rx_task = t
+        idx = next((i for i, m in enumerate(mbox["msgs"]) if m[0] == tag), None)
+        if idx is not None:
+            m = mbox["msgs"][idx]
+            mbox["msgs"][idx] = mbox["msgs"][-1]; mbox["msgs"].pop()
+            os_.val = m[1:]
+        else:
+            mbox["regs"].append((tag, os_))
+        return os_
+
+    def deliver(self, mbox, tag, val, frm, aux):    # Mailbox::deliver
+        regs, i = mbox["regs"], 0
+        while i < len(regs):
+            if regs[i][0] == tag:
+                os_ = regs[i][1]
+                regs[i] = regs[-1]; regs.pop()
+                if os_.rx_alive:                    # oneshot::Sender::send Ok: value stored, receiver task woken
+                    os_.val = (val, frm, aux); self.wake(os_.rx_task)
+                    return
+            else:
+                i += 1
+        mbox["msgs"].append((tag, val, frm, aux))
+
+    def recv_raw(self, t, ep, tag):                 # Endpoint::recv_from_raw
+        os_ = self.mailbox_recv(t, ep, tag)
+        try:
+            while os_.val is None:
+                yield
+            msg = os_.val
+        finally:
+            os_.rx_alive = False                    # the Receiver is dropped with the future (or consumed)
+        yield from self.rand_delay(t)
+        return msg
+
+    def timeout(self, t, dur_ns, fut):              # time::timeout: select_biased! { fut, sleep }
+        deadline = self.sleep_deadline(self.clock + dur_ns)      # the Sleep exists before the first poll
+        try:
+            while True:
+                try:
+                    next(fut)
+                except StopIteration as e:
+                    return ("ok", e.value)
+                if self.clock >= deadline:
+                    return ("elapsed", None)
+                self.timer_add(deadline, lambda: self.wake(t))   # Sleep::poll: ANOTHER timer on every poll
+                yield
+        finally:
+            fut.close()
+
+    def rpc_call(self, t, ep, dst, req_tag, code):  # Endpoint::call_with_data
+        rsp_tag = self.next_u64()                   # random::<u64>()
+        yield from self.send_raw(t, ep, dst, req_tag, code, rsp_tag)
+        val, frm, _ = yield from self.recv_raw(t, ep, rsp_tag)
+        if frm != dst:
+            raise Panic()
+        return val
+
+    # ---- one task body ---------------------------------------------------------------------------------------
+    def body(self, t, pc):
+        while True:
+            op, a, b, imm = self.insns[pc]
+            name, dur = OPN[op], b * 10**9 + imm
+            nxt = pc + 1
+            if name == "DONE":
+                return
+            elif name == "SPAWN":
+                c = self.spawn(a)
+                if b & 4:
+                    c.val, c.frm, c.aux = t.val, t.frm, t.aux
+            elif name == "JOIN":
+                c = self.handles[a]
+                while c.alive:
+                    c.joiner = t
+                    yield
+                if b & 1:
+                    raise Panic()
+            elif name == "YIELD":
+                self.wake(t)
+                yield
+            elif name == "PANIC":
+                raise Panic()
+            elif name == "SET":
+                t.cnt[a & 1] = imm & 0xFFFF
+            elif name == "DJNZ":
+                t.cnt[a & 1] = (t.cnt[a & 1] - 1) & 0xFFFF
+                if t.cnt[a & 1]:
+                    nxt = b
+            elif name == "JMP":
+                nxt = b
+            elif name == "JEQ":
+                if t.val == imm:
+                    nxt = b
+            elif name == "TRACE":
+                v = imm + (t.cnt[a & 1] if b & 1 else 0)
+                self.obs = ((self.obs ^ v) * FNV_PRIME) & M64
+            elif name == "TRACE_TIME":
+                v = self.base_ns + self.clock if a == 0 else self.clock if a == 1 else t.val
+                self.obs = ((self.obs ^ v) * FNV_PRIME) & M64
+            elif name == "SLEEP":
+                yield from self.sleep_until(t, self.sleep_deadline(self.clock + dur))
+            elif name == "SLEEP_RAND":
+                d = self.sample_duration(duration_params(a * 50 * MS, dur))
+                yield from self.sleep_until(t, self.sleep_deadline(self.clock + d))
+            elif name == "MARK":
+                t.t0 = self.clock
+            elif name == "SLEEP_UNTIL":
+                yield from self.sleep_until(t, self.sleep_deadline(t.t0 + dur))
+            elif name == "ASSERT_ELAPSED":
+                el = self.clock - t.t0
+                if not {0: el == dur, 1: el >= dur, 2: el < dur}[a]:
+                    raise Panic()
+            elif name == "BIND":
+                yield from self.rand_delay(t)
+                if self.socks[a][0] != t.node or self.bound.get(a) is not None:
+                    raise Panic()
+                self.bound[a] = dict(owner=t, regs=[], msgs=[]); t.owned.append(a)
+            elif name == "CLOSE":
+                if self.bound.get(a) is not None and self.bound[a]["owner"] is t:
+                    self.bound[a] = None
+            elif name == "SEND":
+                yield from self.send_raw(t, a, b & 0xFF, b >> 8, imm)
+            elif name == "REPLY":
+                yield from self.send_raw(t, a, t.frm, b >> 8, imm)
+            elif name == "RPC_REPLY":
+                yield from self.send_raw(t, a, t.frm, t.aux, imm & 0xFF)
+            elif name == "RECV":
+                val, frm, aux = yield from self.recv_raw(t, a, b >> 8)
+                t.val, t.frm = val, frm
+                if (b >> 8) >= 0x80:
+                    t.aux = aux
+            elif name == "RECV_TIMEOUT":
+                how, msg = yield from self.timeout(t, (b & 0xFF) * 10**9 + imm, self.recv_raw(t, a, b >> 8))
+                if how == "ok":
+                    t.val, t.frm = msg[0], msg[1]
+                    if (b >> 8) >= 0x80:
+                        t.aux = msg[2]
+                else:
+                    t.val = A.VAL_TIMEOUT
+            elif name == "RPC_CALL":
+                call = self.rpc_call(t, a, b & 0xFF, b >> 8, imm & 0xFF)
+                if imm >> 8:
+                    how, v = yield from self.timeout(t, (imm >> 8) * MS, call)
+                    t.val = v if how == "ok" else A.VAL_TIMEOUT
+                    if how == "ok":
+                        t.frm = b & 0xFF
+                else:
+                    t.val = yield from call
+                    t.frm = b & 0xFF
+            elif name == "ASSERT_VAL":
+                if t.val != imm:
+                    raise Panic()
+            elif name == "RAND_BOOL":
+                t.val = 1 if self.gen_bool(self.cfg.loss_table[a & 3]) else 0
+            elif name == "RANDOM":
+                v = self.next_u64()
+                t.val = (v >> 32) if a == 0 else (v >> 32) & 0xFF
+            elif name == "GSET":
+                self.flags[a & 3] = imm
+            elif name == "GADD":
+                self.flags[a & 3] = (self.flags[a & 3] + imm) & 0xFFFFFFFF
+            elif name == "ASSERT_G":
+                if self.flags[a & 3] != imm:
+                    raise Panic()
+            elif name == "PANIC_IF_G_LT":
+                if self.flags[a & 3] < imm:
+                    raise Panic()
+            elif name == "CLOG_NODE":
+                if b & 1: self.clog_in.add(a)
+                if b & 2: self.clog_out.add(a)
+            elif name == "UNCLOG_NODE":
+                if b & 1: self.clog_in.discard(a)
+                if b & 2: self.clog_out.discard(a)
+            elif name == "SET_LOSS":
+                self.loss = self.cfg.loss_table[a & 3]
+            else:
+                raise NotImplementedError(name)
+            pc = nxt
+
+    # ---- Executor::block_on ---------------------------------------------------------------------------------------
+    def run(self, time_limit=0):
+        self.base_ns = (60 * 60 * 24 * 365 * 52 + self.gen_range(0, 60 * 60 * 24 * 365)) * 10**9   # not logged
+        self.logging = True
+        main = self.spawn(0)
+        verdict = A.PASS
+        while True:
+            panicked = False
+            while self.ready:
+                idx = self.gen_range(0, len(self.ready))
+                t = self.ready[idx]
+                self.ready[idx] = self.ready[-1]; self.ready.pop()
+                self.steps += 1
+                t.sched, t.running = False, True
+                try:
+                    next(t.gen)
+                except StopIteration:
+                    self.finish(t)
+                except Panic:
+                    panicked = True
+                    break
+                if t.alive:
+                    t.running = False
+                    if t.sched:
+                        self.ready.append(t)
+                self.clock += self.gen_range(50, 100)
+                self.expire(self.clock)
+            if panicked:
+                verdict = A.PANIC; break
+            if not main.alive:
+                break
+            if not self.heap:
+                verdict = A.DEADLOCK; break
+            now = self.heap[0][0] + 50
+            self.expire(now)
+            self.clock = now
+            if time_limit and self.clock >= time_limit:
+                verdict = A.TIME_LIMIT; break
+        h = FNV_OFFSET
+        for v in self.log:
+            h = ((h ^ v) * FNV_PRIME) & M64
+        return dict(verdict=verdict, steps=self.steps, clock_ns=self.clock, msg_count=self.msg_count,
+                    rng_calls=self.rng.calls, trace_hash=h, obs_hash=self.obs, log=bytes(self.log).hex())
+
+
+def workloads():
+    from tests import lifecycle_workloads as LW
+    out = {"pingpong_4x2": W.pingpong(4, 2),
+           "receiver_drop": LW.receiver_drop(),
+           "request_timeout_with_stale_timers": LW.request_timeout_with_stale_timers(),
+           "rpc_echo": LW.rpc_echo(),
+           "rpc_call_timeout_then_retry": LW.rpc_call_timeout_then_retry(),
+           "std_system_time": LW.std_system_time(),
+           "getrandom_deterministic": LW.getrandom_deterministic()}
+    # a lossy, clogged RPC retry loop: call_timeout until it succeeds, while the supervisor clogs the server for a while
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
+    h = wl.task(ns); h.sleep(ms=3); h.rpc_reply(asv, 9)
+    s = wl.task(ns); s.bind(asv)
+    top = s.label(); s.rpc_recv(asv, 2); s.spawn(h, move_request=True); s.jmp(top)
+    c = wl.task(nc); c.bind(acl); c.sleep(ms=5); c.set(0, 6)
+    top = c.label(); c.rpc_call(acl, asv, 2, 77, timeout_ms=40); c.trace_val(); c.sleep_rand(lo_ms=0, ms=30); c.djnz(0, top)
+    m = wl.main(); m.spawn(s); m.spawn(c); m.sleep(ms=60); m.clog_node(ns, "in"); m.sleep(ms=90); m.unclog_node(ns, "in"); m.join(c)
+    out["rpc_retry_under_clog"] = wl.build()
+    return out
+
+
+def main():
+    ex = {}
+    for name, w in workloads().items():
+        ex[name] = {}
+        for cfgname, cfg in (("default", A.Config.default()), ("loss20", A.Config.default(packet_loss_rate=0.2))):
+            ex[name][cfgname] = {str(seed): Sim(w, cfg, seed).run() for seed in (0, 1, 2, 3, 99, 123456789)}
+    json.dump(ex, open(os.path.join(HERE, "executor_kat_async.json"), "w"), indent=1)
+    print("wrote executor_kat_async.json")
+
+
+if __name__ == "__main__":
+    main()

@@ -109,3 +109,29 @@ def test_minimal_trace_appendix_b():
     out, _ = oracle.run_batch(w, 0, 3)
     assert [(int(r["clock_ns"]), int(r["rng_calls"])) for r in out] == [(1000000101, 6), (1000000129, 6), (1000000137, 8)]
     assert all(r["verdict"] == A.PASS and r["steps"] == 3 for r in out)
+
+
+ASYNC = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "executor_kat_async.json")))
+ASYNC_CFGS = {"default": lambda: A.Config.default(), "loss20": lambda: A.Config.default(packet_loss_rate=0.2)}
+
+
+def _async_workloads():
+    import importlib.util
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden_async.py")
+    spec = importlib.util.spec_from_file_location("make_golden_async", p)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.workloads()
+
+
+@pytest.mark.parametrize("name", sorted(ASYNC))
+def test_executor_golden_async_formulation(name):
+    """timeout() duplicate timers, dropped receivers, typed RPC with orphaned responses, clogs: every result field and
+    raw log byte vs the generator-based restatement (tests/golden/make_golden_async.py: `yield` = Pending,
+    `close()` = drop)."""
+    w = _async_workloads()[name]
+    for cfgname, seeds in ASYNC[name].items():
+        for seed, want in seeds.items():
+            log, res = oracle.trace_seed(w, int(seed), ASYNC_CFGS[cfgname]())
+            assert dict(zip(FIELDS, res.astuple())) == {k: want[k] for k in FIELDS}, (name, cfgname, seed)
+            assert log.hex() == want["log"], (name, cfgname, seed)
