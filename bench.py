@@ -147,6 +147,16 @@ def main():
         step(args.warmup + k, True)
     sync()
     dt = time.perf_counter() - t0
+    # for reference beside the overlapped figure: the same step with nothing else in flight (one stream), untimed region
+    single_ms = None
+    if use_device_report and n_streams > 1 and world == 1:
+        ns = min(10, args.warmup + args.steps)
+        t1 = time.perf_counter()
+        for k in range(ns):
+            runtime.run_batch_async(w, seed0 + k * total, count, d_outs[0].data_ptr(), ring[k].data_ptr(),
+                                    streams[0].cuda_stream, None, lim, timing_slot=-1)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / ns * 1e3
     if use_device_report:
         rows = (mdist.combine_gathered(gathered[args.warmup:]) if world > 1 else ring[args.warmup:]).cpu()
         nfail, steps_total, clock_total = (int(x) for x in rows[:, 1:4].sum(dim=0).tolist())
@@ -188,7 +198,7 @@ def main():
                        "seeds_per_step": total, "parallelism": f"seed-shard x{world}" + (f", {n_streams} concurrent batches per GPU" if n_streams > 1 else "")},
             "extra": {"seeds_per_sec": seeds_total / dt, "first_fail_seeds_per_hour": seeds_total / dt * 3600.0,
                       "executor_steps_per_sec": steps_total / dt,
-                      "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms,
+                      "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms, "single_stream_ms_per_step": single_ms,
                       "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu * g.block_threads // 64,
                       "lanes_per_wave": g.lanes_per_wave},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
