@@ -4,58 +4,137 @@
 One "step" = one pass of the hot path over one batch: 65 536 seeds of the 4-node ping-pong
 (R = 64 rounds per pair, Config::default()) per GPU, i.e. BASELINE.json configs[1].  With N GPUs each
 rank runs its own contiguous block of 65 536 seeds (weak scaling, no data-path collective) and the
-ranks exchange one first-failing-seed all-reduce per step (RCCL).
+ranks exchange one 64-byte report all-gather per step (RCCL).
+
+`python bench.py --gpus N` with N > 1 and no launcher environment re-executes itself as N ranks under
+torch.distributed.run (one process per GPU); under a launcher, WORLD_SIZE must equal --gpus.  `n_gpus` in the
+output is the size of the process group that actually ran, never the flag.
 
 Prints ONE JSON line (rank 0).  `value` = simulated seconds per wall second summed over every seed of
-every rank; seeds/s and executor-steps/s ride along in `extra`.
+every rank; seeds/s and executor-steps/s ride along in `extra`.  After the timed region (never inside it) the
+line gains `verified_seeds` (sampled seeds of the last batch on every stream compared bit-for-bit with the CPU
+oracle), a first-failing-seed measurement on the packet-loss variant, and the CPU baseline.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SEEDS_PER_GPU = 65536
-N_NODES, ROUNDS = 4, 64
+from madsim_amd import launch  # noqa: E402  (pure host logic, no torch)
+
 ALGO_BYTES_PER_STEP = 120      # SURVEY.md §8d: pop 16 + push 16 + rng 32r+32w + clock 8r+8w + ready 4r+4w
 IO_BYTES_PER_SEED = 8 + 48     # seed in, madsim_result_t out
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+REPORT_WORDS = 8               # int64 per step: 4 from the library's reduction kernel + rank, device, 2 spare
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--seeds", type=int, default=SEEDS_PER_GPU, help="seeds per GPU per step")
+    ap.add_argument("--seeds", type=int, default=0, help="seeds per GPU per step (default 65 536)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of sampled seeds after the timed region")
+    ap.add_argument("--no-first-fail", action="store_true", help="skip the first-failing-seed measurement (loss variant)")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="collect FETCH_SIZE / WRITE_SIZE of this same command with two rocprofv3 --pmc passes (slow)")
+    ap.add_argument("--loss", type=float, default=0.0, help="packet_loss_rate of the timed batches (0 = Config::default())")
+    ap.add_argument("--first-fail-loss", type=float, default=0.01, help="packet_loss_rate of the first-fail leg (SURVEY 8d)")
+    ap.add_argument("--sched", type=int, default=0, help="0 = static seed striding, 1 = per-launch atomic work queue (madsim_limits_t.sched)")
     ap.add_argument("--lpw", type=int, default=0, help="seed-carrying lanes per wave (0 = library auto)")
-    ap.add_argument("--nodes", type=int, default=N_NODES, help="ping-pong nodes (experiments; the bench line is quoted on 4)")
+    ap.add_argument("--nodes", type=int, default=4, help="ping-pong nodes (experiments; the bench line is quoted on 4)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are spread over. One 65 536-seed batch is 1 024 waves = one per SIMD; "
                          "a second batch in flight on another stream fills the second wave slot the per-seed LDS allows")
     ap.add_argument("--heap-lds", type=int, default=4, help="timer-heap entries kept in LDS (the rest spill to HBM)")
     ap.add_argument("--generic", action="store_true", help="force the generic kernel variant (HBM heap spill enabled)")
     ap.add_argument("--workload", default="pingpong", choices=["pingpong", "raft", "kv", "timers", "topo"],
-                    help="pingpong = BASELINE configs[1] (the headline); raft / kv = configs[2] / configs[3]-shaped extras")
-    args = ap.parse_args()
+                    help="pingpong = BASELINE configs[1] (the headline); raft / kv / topo = configs[2] / [3] / [4]-shaped extras")
+    return ap.parse_args(argv)
 
+
+def measure_traffic(argv):
+    """HBM bytes per sim_kernel launch of this same command: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE need
+    separate passes, MI355X_MICROARCH.md §PMC slots), --kernel-trace only.  Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    child = [a for a in argv if a != "--measure-traffic"]
+    for flag, val in (("--steps", "6"), ("--warmup", "2")):
+        if flag in child:
+            child[child.index(flag) + 1] = val
+        else:
+            child += [flag, val]
+    child += ["--no-cpu-baseline", "--no-verify", "--no-first-fail"]
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="madsim_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py")] + child
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return None, f"rocprofv3 {ctr} pass failed: {e}"
+            xs = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "sim_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        xs.append(float(row["Counter_Value"]))
+            if not xs:
+                return None, f"no {ctr} rows for sim_kernel"
+            vals[ctr] = sum(xs) / len(xs)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # rocprofv3 reports both in KB; gfx950 FETCH_SIZE counts 128-B requests as 64 B: x2 (MI355X_MICROARCH.md §HBM)
+    total = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return total, {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+                   "source": "live: rocprofv3 --kernel-trace --pmc, two passes of this command (6 steps), mean per sim_kernel dispatch"}
+
+
+def main():
+    args = parse_args()
+    try:
+        mode, cmd = launch.plan(args.gpus, os.environ, sys.argv[1:], os.path.abspath(__file__))
+    except launch.LaunchError as e:
+        print(f"bench.py: {e}", file=sys.stderr)
+        return 2
+    if mode == "spawn":                      # python bench.py --gpus N: become N ranks, one per GPU
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        return subprocess.call(cmd, env=env)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from madsim_amd import _abi as A
     from madsim_amd import dist as mdist
     from madsim_amd import runtime, workload
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = launch.rank_env(os.environ)
     # MADSIM_BENCH_BACKEND=gloo is a functional-test hook (several ranks sharing one GPU on a 1-GPU box);
     # the real multi-GPU run is one rank per GPU over RCCL ("nccl").
     backend = os.environ.get("MADSIM_BENCH_BACKEND", "nccl")
-    gpu = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        print("bench.py: no GPU visible (there is no CPU path to benchmark)", file=sys.stderr)
+        return 2
+    if world > 1 and backend == "nccl" and n_dev < world:
+        print(f"bench.py: {world} ranks but only {n_dev} GPUs visible", file=sys.stderr)
+        return 2
+    gpu = local_rank % n_dev
     torch.cuda.set_device(gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -68,48 +147,36 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus, world)
+    n_ranks = dist.get_world_size() if world > 1 else 1
     dev = torch.device("cuda", gpu)
-    cdev = dev if backend == "nccl" else torch.device("cpu")     # where the 32-byte report tensors live
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where the report tensors live
     runtime.init(gpu)
 
-    if args.workload == "pingpong":
-        w = workload.pingpong(args.nodes, ROUNDS)
-        wname = f"{args.nodes}-node ping-pong, R={ROUNDS}, Config::default()"
-        lim = A.Limits()
-        # tight capacities for this workload (high-water marks: 4 timers, 1 pending recv, never a queued message);
-        # exceeding one would show up as failed seeds (verdict MADSIM_OVERFLOW), never as a different answer
-        lim.heap_lds_slots, lim.heap_spill_slots = args.heap_lds, 4 - args.heap_lds
-        lim.mbox_regs, lim.mbox_msgs = 1, A.LIMIT_NONE
-    elif args.workload == "raft":
-        w, lim = workload.raft_election(), workload.raft_election_limits()
-        wname = "5-node election loop with partition injection (configs[2] shape)"
-    elif args.workload == "timers":
-        w, lim = workload.timer_storm(), workload.timer_storm_limits(args.heap_lds)
-        wname = f"timer storm: 24 tasks x sleep(gen_range(0..2 s)), heap_lds={args.heap_lds} (HBM heap-spill path)"
-    elif args.workload == "topo":
-        w, lim = workload.streaming_topology(), workload.streaming_topology_limits()
-        wname = "16-node streaming topology: KV meta + typed-RPC brokers + 12 compute nodes (configs[4] shape)"
-    else:
-        w, lim = workload.kv_rpc(), workload.kv_rpc_limits()
-        wname = "etcd-style KV ops over connect1/accept1 (configs[3] shape)"
+    w, lim, wname = workload.bench_case(args.workload, args.nodes, workload.BENCH_ROUNDS, args.heap_lds)
+    headline = args.workload == "pingpong" and args.nodes == workload.BENCH_NODES
     lim.lanes_per_wave = args.lpw
+    lim.sched = int(os.environ.get("MADSIM_BENCH_SCHED", args.sched))     # work distribution inside a launch (experiments)
     if args.generic:
         lim.heap_spill_slots = max(lim.heap_spill_slots, 8)
-    per_gpu = args.seeds
-    total = per_gpu * world
-    seed0, count = mdist.shard_range(0, total, rank, world)
+    cfg = A.Config.default(packet_loss_rate=args.loss) if args.loss else None
+    per_gpu = args.seeds or workload.BENCH_SEEDS_PER_GPU
+    total = per_gpu * n_ranks
+    seed0, count = mdist.shard_range(0, total, rank, n_ranks)
     n_streams = max(1, args.streams)
     d_outs = [torch.empty(count * 48, dtype=torch.uint8, device=dev) for _ in range(n_streams)]   # results stay in HBM
-    d_out = d_outs[0]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
-    stream = streams[0].cuda_stream
     report_stream = torch.cuda.Stream() if world > 1 else None
 
-    # Fully asynchronous steps: the simulation kernel, the summary reduction and (N > 1) the RCCL all-reduce of the
-    # 32-byte report are all queued on the stream; the host never waits inside the timed region.
+    # Fully asynchronous steps: the simulation kernel, the summary reduction and (N > 1) the RCCL all-gather of the
+    # report are all queued on streams; the host never waits inside the timed region.
     use_device_report = world == 1 or backend == "nccl"
-    ring = torch.zeros((args.steps + args.warmup, 4), dtype=torch.int64, device=dev)   # one 32-byte report per step
-    gathered = torch.zeros((args.steps + args.warmup, world, 4), dtype=torch.int64, device=dev) if world > 1 else None
+    n_rows = args.steps + args.warmup
+    ring = torch.zeros((n_rows, REPORT_WORDS), dtype=torch.int64, device=dev)   # one report per step
+    ring[:, 4] = rank                      # identity words: the gathered report must hold one row per rank
+    ring[:, 5] = gpu
+    gathered = torch.zeros((n_rows, n_ranks, REPORT_WORDS), dtype=torch.int64, device=dev) if world > 1 else None
+    last_on_stream = {}
 
     def step(k, timed):
         # a fresh block of seeds every step so nothing is cached between steps
@@ -117,17 +184,19 @@ def main():
             si = k % n_streams
             with torch.cuda.stream(streams[si]):
                 runtime.run_batch_async(w, seed0 + k * total, count, d_outs[si].data_ptr(), ring[k].data_ptr(),
-                                        streams[si].cuda_stream, None, lim, timing_slot=(k % 64) if timed else -1)
+                                        streams[si].cuda_stream, cfg, lim, timing_slot=(k % 64) if timed else -1)
+            last_on_stream[si] = k
             if world > 1:
-                # the 32-byte RCCL exchange rides its own stream behind an event: the simulation streams never wait
+                # the RCCL exchange rides its own stream behind an event: the simulation streams never wait
                 # for a collective kernel to find room on a chip whose LDS the simulation keeps full
                 ev = torch.cuda.Event()
                 ev.record(streams[si])
                 report_stream.wait_event(ev)
                 with torch.cuda.stream(report_stream):
-                    mdist.gather_report_device(ring[k], gathered[k])     # ONE all-gather of 32 bytes per step
+                    mdist.gather_report_device(ring[k], gathered[k])     # ONE all-gather of 64 bytes per step
         else:   # functional-test hook (gloo on a 1-GPU box): host-side report
-            sm = runtime.run_batch_device(w, seed0 + k * total, count, d_out.data_ptr(), stream, None, lim)
+            sm = runtime.run_batch_device(w, seed0 + k * total, count, d_outs[0].data_ptr(), streams[0].cuda_stream, cfg, lim)
+            last_on_stream[0] = k
             rep = mdist.reduce_report(sm.first_failing_seed, sm.n_failed, sm.total_steps, sm.total_clock_ns, cdev)
             if timed:
                 host_tot[0] += rep[1]; host_tot[1] += rep[2]; host_tot[2] += rep[3]; host_tot[3] += sm.kernel_ms
@@ -147,18 +216,28 @@ def main():
         step(args.warmup + k, True)
     sync()
     dt = time.perf_counter() - t0
-    # for reference beside the overlapped figure: the same step with nothing else in flight (one stream), untimed region
+    # ---------------- everything below is outside the timed region ----------------
+    # for reference beside the overlapped figure: the same step with nothing else in flight (one stream)
     single_ms = None
     if use_device_report and n_streams > 1 and world == 1:
-        ns = min(10, args.warmup + args.steps)
+        ns = min(10, n_rows)
+        scratch = torch.empty_like(d_outs[0])
         t1 = time.perf_counter()
         for k in range(ns):
-            runtime.run_batch_async(w, seed0 + k * total, count, d_outs[0].data_ptr(), ring[k].data_ptr(),
-                                    streams[0].cuda_stream, None, lim, timing_slot=-1)
+            runtime.run_batch_async(w, seed0 + k * total, count, scratch.data_ptr(), 0, streams[0].cuda_stream, cfg, lim, timing_slot=-1)
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / ns * 1e3
+    rccl_ranks = None
     if use_device_report:
-        rows = (mdist.combine_gathered(gathered[args.warmup:]) if world > 1 else ring[args.warmup:]).cpu()
+        if world > 1:
+            gath = gathered[args.warmup:].cpu()
+            for row in gath:                       # every step's gathered report holds exactly one row per rank
+                launch.check_ranks([(int(r[4]), int(r[5])) for r in row], n_ranks)
+            devs = {int(r[5]) for r in gath[-1]}
+            rccl_ranks = n_ranks if backend == "nccl" and len(devs) == n_ranks else None
+            rows = mdist.combine_gathered(gath)
+        else:
+            rows = ring[args.warmup:].cpu()
         nfail, steps_total, clock_total = (int(x) for x in rows[:, 1:4].sum(dim=0).tolist())
         nslots = min(args.steps, 64)
         kernel_ms = sum(runtime.timing_ms((args.warmup + args.steps - 1 - i) % 64) for i in range(nslots)) * args.steps / nslots
@@ -169,51 +248,113 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(t[0]), float(t[1])
 
+    # oracle check of the batches that were just timed: the last batch on every stream, sampled k*257 mod count
+    verified = 0
+    if not args.no_verify:
+        import oracle
+        n_samp = min(256, count)
+        for si, k in sorted(last_on_stream.items()):
+            got = np.frombuffer(d_outs[si].cpu().numpy().tobytes(), dtype=A.RESULT_DTYPE)
+            base = seed0 + k * total
+            for j in range(n_samp):
+                i = (j * 257) % count
+                want, _ = oracle.run_batch(w, base + i, 1, cfg, lim)
+                if got[i] != want[0]:
+                    print(f"bench.py: VERIFY FAILED rank {rank} stream {si} seed {base + i}: gpu {got[i]} != oracle {want[0]}", file=sys.stderr)
+                    return 3
+                verified += 1
+        if world > 1:
+            t = torch.tensor([verified], dtype=torch.int64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            verified = int(t[0])
+
+    # first-failing-seed leg (SURVEY 8d fault variant): wall time from launch to the failing seed being known on the host
+    first_fail = None
+    if not args.no_first_fail and world == 1 and args.workload == "pingpong":
+        import oracle
+        fcfg = A.Config.default(packet_loss_rate=args.first_fail_loss)
+        fbuf = d_outs[0]
+        runtime.run_batch_device(w, 1 << 40, count, fbuf.data_ptr(), streams[0].cuda_stream, fcfg, lim)   # warm (tables, variant)
+        torch.cuda.synchronize()
+        reps, wall, ksum, sm = 5, 0.0, 0.0, None
+        for r in range(reps):
+            fs0 = (1 << 41) + r * count
+            t1 = time.perf_counter()
+            sm = runtime.run_batch_device(w, fs0, count, fbuf.data_ptr(), streams[0].cuda_stream, fcfg, lim)   # returns once the 32-byte report is on the host
+            wall += time.perf_counter() - t1
+            ksum += sm.kernel_ms
+        # the last repetition against the oracle: everything up to and including the first failing seed
+        fs0 = (1 << 41) + (reps - 1) * count
+        n_chk = min(count, max(256, int(sm.first_failing_seed - fs0) + 1 if sm.n_failed else 256))
+        want, osm = oracle.run_batch(w, fs0, n_chk, fcfg, lim)
+        got = np.frombuffer(fbuf.cpu().numpy().tobytes(), dtype=A.RESULT_DTYPE)[:n_chk]
+        if (got != want).any() or (sm.n_failed and osm.first_failing_seed != sm.first_failing_seed):
+            print(f"bench.py: FIRST-FAIL VERIFY FAILED: gpu {sm.first_failing_seed} oracle {osm.first_failing_seed}", file=sys.stderr)
+            return 3
+        first_fail = {"packet_loss_rate": args.first_fail_loss, "seeds_per_batch": count,
+                      "time_to_first_fail_ms": wall / reps * 1e3, "kernel_ms": ksum / reps,
+                      "first_failing_seed_offset": int(sm.first_failing_seed - fs0) if sm.n_failed else None,
+                      "failed_fraction": sm.n_failed / count, "oracle_checked_seeds": n_chk,
+                      "seeds_per_hour": count / (wall / reps) * 3600.0,
+                      "note": "launch -> kernel -> device reduction -> 32-byte D2H, host-synchronous, one batch at a time"}
+
     if rank == 0:
         seeds_total = total * args.steps
         sim_s = clock_total / 1e9
-        # roofline of the dominant kernel (sim_kernel), per launch, from the library's HIP events
+        # roofline of the dominant kernel (sim_kernel), per launch, from the library's HIP events on the launch streams
         k_avg_ms = kernel_ms / args.steps
-        steps_per_launch = steps_total / args.steps / world
+        steps_per_launch = steps_total / args.steps / n_ranks
         algo_bytes = steps_per_launch * ALGO_BYTES_PER_STEP + count * IO_BYTES_PER_SEED
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
         g = runtime.geometry(w, lim)
-        b = lambda x: "true" if x else "false"
-        kname = (f"sim_kernel<Variant<false,true,{g.lanes_per_wave.bit_length() - 1},true,false>>" if g.variant & 8 else
-                 f"sim_kernel<Variant<false,{b(g.variant & 1)},6,{b(g.variant & 2)},{b(g.variant & 4)}>>")
-        # HBM traffic per launch from the rocprofv3 PMC passes of this same command (tools/prof_pmc.sh ->
-        # profiles/r1_traffic.json): FETCH_SIZE (x2, the gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if world == 1 and per_gpu == SEEDS_PER_GPU and args.workload == "pingpong" and args.nodes == N_NODES and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = (2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0
+        kname = runtime.variant_name(g)
+        traffic, tdetail = None, None
+        if world == 1 and args.measure_traffic:
+            traffic, tdetail = measure_traffic(sys.argv[1:])
+        if traffic is None and world == 1 and per_gpu == workload.BENCH_SEEDS_PER_GPU and headline and not args.loss:
+            # the committed rocprofv3 PMC passes of this same command (tools/prof_pmc.sh): FETCH_SIZE x2 + WRITE_SIZE
+            for name in ("r2_traffic.json", "r1_traffic.json"):
+                tpath = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(tpath):
+                    tj = json.load(open(tpath))
+                    traffic = (2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0
+                    tdetail = {"FETCH_SIZE_KB": tj["FETCH_SIZE_KB"], "WRITE_SIZE_KB": tj["WRITE_SIZE_KB"],
+                               "source": f"profiles/{name}: rocprofv3 PMC passes of this command, not this run"
+                                         + ("; live attempt: " + str(tdetail) if isinstance(tdetail, str) else "")}
+                    break
         line = {
             "metric": "sim_seconds_per_sec", "value": sim_s / dt, "unit": "sim-s/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"{wname}, {per_gpu} seeds per GPU per step"
-                                   + (" (BASELINE configs[1])" if args.workload == "pingpong" and args.nodes == N_NODES else ""),
-                       "seeds_per_step": total, "parallelism": f"seed-shard x{world}" + (f", {n_streams} concurrent batches per GPU" if n_streams > 1 else "")},
-            "extra": {"seeds_per_sec": seeds_total / dt, "first_fail_seeds_per_hour": seeds_total / dt * 3600.0,
+                                   + (f", packet_loss_rate={args.loss}" if args.loss else "")
+                                   + (" (BASELINE configs[1])" if headline and not args.loss else ""),
+                       "seeds_per_step": total, "parallelism": f"seed-shard x{n_ranks}" + (f", {n_streams} concurrent batches per GPU" if n_streams > 1 else "")},
+            "verified_seeds": verified,
+            "extra": {"seeds_per_sec": seeds_total / dt,
                       "executor_steps_per_sec": steps_total / dt,
                       "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms, "single_stream_ms_per_step": single_ms,
                       "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu * g.block_threads // 64,
-                      "lanes_per_wave": g.lanes_per_wave},
+                      "lanes_per_wave": g.lanes_per_wave, "rccl_ranks": rccl_ranks, "first_fail": first_fail,
+                      "first_fail_seeds_per_hour": first_fail["seeds_per_hour"] if first_fail else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_detail": tdetail,
+                         "measured_hbm_gbps": (traffic / (k_avg_ms * 1e-3) / 1e9) if traffic else None,
                          "kernel": kname, "algorithmic_bytes_per_launch": algo_bytes,
                          "concurrent_launches": n_streams, "chip_achieved": algo_bytes * args.steps / dt / 1e9,
                          "chip_frac": algo_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBPS,
-                         "note": "LDS-resident path: algorithmic bytes (120 B/executor step) never touch HBM; "
-                                 "achieved/frac are per launch, chip_* = all launches' bytes / wall time of the timed region"},
+                         "note": "achieved/frac = ALGORITHMIC bytes (120 B per executor step, SURVEY 8d) / one launch's HIP-event "
+                                 "duration: an LDS-equivalent throughput — on this LDS-resident path those bytes never reach HBM; "
+                                 "measured_hbm_gbps = rocprofv3 FETCH/WRITE bytes over the same duration is the real HBM rate.  "
+                                 f"{n_streams} launches overlap on {n_streams} streams, so kernel_ms_per_step (one launch, start to end) "
+                                 "exceeds ms_per_step (wall time per batch); chip_* = all launches' bytes / wall time"},
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle
-            sample = 4 * SEEDS_PER_GPU          # ~14 s of single-thread CPU work
+            sample = 4 * workload.BENCH_SEEDS_PER_GPU if args.workload == "pingpong" else 16384
             t1 = time.perf_counter()
-            _, osum = oracle.run_batch(w, 0, sample)
+            _, osum = oracle.run_batch(w, 0, sample, cfg, lim)
             cdt = time.perf_counter() - t1
             line["cpu_baseline"] = {"value": osum.total_clock_ns / 1e9 / cdt, "unit": "sim-s/s", "cores": 1,
                                     "kind": "port",
@@ -224,7 +365,8 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     runtime.shutdown()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

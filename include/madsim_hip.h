@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MADSIM_HIP_ABI_VERSION 1u
+#define MADSIM_HIP_ABI_VERSION 2u
 
 /* ------------------------------------------------------------------------------------------------
  * Workload: the actor program (read-only, caller-owned POD).
@@ -205,7 +205,13 @@ typedef struct madsim_limits {
     uint32_t lanes_per_wave;     /* seeds carried per 64-lane wave (8/16/32/64); 0 = auto            */
     uint32_t max_conns;          /* live reliable-channel connections per seed; 0 = auto (4)         */
     uint32_t chan_queue;         /* queued payloads per channel direction; 0 = auto (2)              */
+    uint32_t sched;              /* MADSIM_SCHED_*: how lanes pick up further seeds when a launch holds more
+                                    seeds than resident lanes; 0 = static striding                    */
+    uint32_t reserved;
 } madsim_limits_t;
+
+#define MADSIM_SCHED_STATIC 0u   /* lane g runs seeds g, g+G, g+2G, ...                                */
+#define MADSIM_SCHED_QUEUE  1u   /* a finished lane pulls the next seed from a per-launch atomic counter */
 
 /* ------------------------------------------------------------------------------------------------
  * Outputs.
@@ -232,7 +238,8 @@ typedef struct madsim_result {
 } madsim_result_t;
 
 typedef struct madsim_summary {
-    uint64_t first_failing_seed; /* minimum seed with verdict != PASS, UINT64_MAX if none            */
+    uint64_t first_failing_seed; /* minimum seed with verdict != PASS; UINT64_MAX if none — test n_failed, a
+                                    batch may legitimately contain seed UINT64_MAX itself            */
     uint64_t n_failed;
     uint64_t total_steps;
     uint64_t total_clock_ns;
@@ -252,7 +259,20 @@ typedef struct madsim_summary {
 
 uint32_t    madsim_hip_version(void);
 const char* madsim_hip_strerror(int code);
-const char* madsim_hip_last_error(void);
+const char* madsim_hip_last_error(void);   /* thread-local text of the calling thread's last failure */
+
+/* ---- Per-device contexts -----------------------------------------------------------------------------
+ * "one host thread drives a batch; library is re-entrant per device handle, not thread-safe per
+ * handle".  A context owns everything the runner keeps on one GPU (workload tables, spill regions, events);
+ * distinct contexts share no mutable state, so a process may hold one per GPU and use them from different threads,
+ * or drive all of them from one thread with madsim_hip_run_batch_multi.  Calls on ONE context are serialised.
+ * Every madsim_hip_ctx_* function mirrors the v1 function of the same name below, which runs on the
+ * process-default context created by madsim_hip_init. */
+typedef struct madsim_hip_ctx madsim_hip_ctx_t;
+int madsim_hip_ctx_create(int device, madsim_hip_ctx_t** out);
+int madsim_hip_ctx_destroy(madsim_hip_ctx_t* ctx);
+int madsim_hip_ctx_device(const madsim_hip_ctx_t* ctx);
+madsim_hip_ctx_t* madsim_hip_default_ctx(void);   /* NULL before madsim_hip_init */
 
 /* Bind the calling process to one GPU (one process per GPU; replaces nothing in the reference —
  * the reference's per-seed std::thread::spawn, builder.rs:134, has no device). */
@@ -265,10 +285,12 @@ int madsim_hip_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg,
                          uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
                          madsim_result_t* out, madsim_summary_t* summary);
 
-/* madsim_hip_run_batch, then every seed that came back MADSIM_OVERFLOW is run again with doubled device capacities,
- * up to `max_rounds` times, and the summary is recomputed over the final results.  The reference's containers are
- * unbounded (Vec mailboxes, BinaryHeap timers), so a capacity verdict is never a test verdict: this is the entry
- * point a Builder::run replacement calls.  `out` must not be NULL. */
+/* madsim_hip_run_batch, then every seed that came back with a RUNNER verdict — MADSIM_OVERFLOW (a device capacity)
+ * or MADSIM_STEP_LIMIT (the max_steps safety net) — is run again, all of them gathered into ONE compacted launch per
+ * round, with doubled capacities / a 16x step cap (ceiling UINT32_MAX), up to `max_rounds` times; the summary is
+ * recomputed over the final results.  The reference's containers are unbounded (Vec mailboxes, BinaryHeap timers) and
+ * it has no step cap, so neither is ever a test verdict: this is the entry point a Builder::run replacement calls.
+ * `out` must not be NULL. */
 int madsim_hip_run_batch_auto(const madsim_workload_t* w, const madsim_config_t* cfg,
                               uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
                               madsim_result_t* out, madsim_summary_t* summary, int max_rounds);
@@ -296,6 +318,36 @@ int madsim_hip_timing_ms(int timing_slot, double* ms);
 int64_t madsim_hip_trace_seed(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
                               const madsim_limits_t* lim, uint8_t* log, uint64_t cap,
                               madsim_result_t* out);
+
+/* The same entry points on an explicit context (see "Per-device contexts" above). */
+int madsim_hip_ctx_run_batch(madsim_hip_ctx_t* ctx, const madsim_workload_t* w, const madsim_config_t* cfg,
+                             uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
+                             madsim_result_t* out, madsim_summary_t* summary);
+int madsim_hip_ctx_run_batch_auto(madsim_hip_ctx_t* ctx, const madsim_workload_t* w, const madsim_config_t* cfg,
+                                  uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
+                                  madsim_result_t* out, madsim_summary_t* summary, int max_rounds);
+int madsim_hip_ctx_run_batch_device(madsim_hip_ctx_t* ctx, const madsim_workload_t* w, const madsim_config_t* cfg,
+                                    uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
+                                    void* d_out, void* stream, madsim_summary_t* summary);
+int madsim_hip_ctx_run_batch_async(madsim_hip_ctx_t* ctx, const madsim_workload_t* w, const madsim_config_t* cfg,
+                                   uint64_t seed0, uint64_t count, const madsim_limits_t* lim,
+                                   void* d_out, void* d_summary4, void* stream, int timing_slot);
+int madsim_hip_ctx_timing_ms(madsim_hip_ctx_t* ctx, int timing_slot, double* ms);
+int64_t madsim_hip_ctx_trace_seed(madsim_hip_ctx_t* ctx, const madsim_workload_t* w, const madsim_config_t* cfg,
+                                  uint64_t seed, const madsim_limits_t* lim, uint8_t* log, uint64_t cap,
+                                  madsim_result_t* out);
+
+/* One process, several GPUs: the whole seed loop of Builder::run (builder.rs:129-150, every seed driven from one
+ * process) over `n_ctx` contexts, each on its own GPU (or, for tests on a 1-GPU box, several on the same one).
+ * Seeds are sharded contiguously — context g runs [seed0 + g*ceil(count/n_ctx), ...) —, every device's kernel is
+ * queued from the calling thread before any is waited for, results land in `out[count]` (host), seeds that outgrew a
+ * device capacity or the step cap are re-run in one compacted launch per round (<= max_rounds, as
+ * madsim_hip_run_batch_auto), and the n reports are folded on the host into `summary`.  Bit-identical to
+ * madsim_hip_run_batch_auto on a single context. */
+int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const madsim_workload_t* w,
+                               const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                               const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary,
+                               int max_rounds);
 
 /* Geometry the library picked for a workload (for DESIGN/bench reporting). */
 typedef struct madsim_geometry {

@@ -354,7 +354,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
                 } else {
                     if (nreg >= P.mbox_regs) { L.ovf = 1; st = ST_PENDING; break; }
-                    SW(c, a, 2 + nreg) = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                    const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                    // dead registrations (timed-out / dropped receives, extended ops only) stay in the Vec like the
+                    // reference's; an 8-bit rxseq that wraps onto one of them would make it look live: overflow, never a different answer
+                    if (K::LIFE) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;
+                    SW(c, a, 2 + nreg) = reg;
                     SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
                     sub = 1;
                     st = ST_PENDING;
@@ -389,7 +393,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             } else if (nreg >= P.mbox_regs) {
                 L.ovf = 1;
             } else {
-                SW(c, a, 2 + nreg) = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;   // rxseq wrapped onto a dead twin
+                SW(c, a, 2 + nreg) = reg;
                 SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
             }
             sub = 1;

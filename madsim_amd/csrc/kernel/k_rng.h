@@ -20,9 +20,7 @@ __device__ __forceinline__ uint64_t rng_next(Lane& L) {
 // One determinism-log byte per GlobalRng::with (rand.rs:64-88): clone.gen::<u8>() ^ xor-fold(elapsed).
 template <class K>
 __device__ __forceinline__ void rng_log(const Ctx& c, Lane& L) {
-#ifdef EXP_NOLOG
-    return;
-#endif
+    if (!MADSIM_K_LOG_ENABLED) return;
     uint64_t r = rotl64<23>(L.s0 + L.s3) + L.s0;   // what the clone's next_u64 would return
     uint32_t v = (uint32_t)(r >> 32);
     uint32_t f = (uint32_t)L.clock ^ (uint32_t)(L.clock >> 32);

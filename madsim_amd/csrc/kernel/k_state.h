@@ -5,10 +5,18 @@
 
 namespace madsim_k {
 
-#ifdef EXP_ALWAYS_ACCEPT
-#define EXP_ACCEPT(x) ((x) && false)   /* timing experiment only: breaks parity */
+// Timing-experiment switches live outside the product tree (tools/experiment/k_experiment.h) and are reachable only
+// through tools/build_variant.sh; the product build refuses them.
+#ifdef MADSIM_EXPERIMENT_BUILD
+#include "../../../tools/experiment/k_experiment.h"
 #else
+#if defined(EXP_NOLOG) || defined(EXP_ALWAYS_ACCEPT) || defined(EXP_PROF) || defined(EXP_PROF2) || defined(EXP_NO_LWS_VARIANTS)
+#error "EXP_* switches make a non-bit-exact kernel: build experiment variants with tools/build_variant.sh, never the product Makefile"
+#endif
 #define EXP_ACCEPT(x) (x)
+#define MADSIM_K_LOG_ENABLED 1
+#define PROBE(i) do { } while (0)
+#define PROBE2(i) do { } while (0)
 #endif
 #define FNV_OFFSET 14695981039346656037ull
 #define FNV_PRIME 1099511628211ull
@@ -37,16 +45,6 @@ template <bool TRACE_, bool SPILL_, int LWS_, bool LIFE_, bool RQ_ = false> stru
 #ifndef REG
 #define REG(id) do { } while (0)
 #endif
-#ifdef EXP_PROF2
-#define PROBE2(i) do { uint64_t t_ = __builtin_readcyclecounter(); L.prof_acc[i] += t_ - L.prof_t; L.prof_t = t_; } while (0)
-#else
-#define PROBE2(i) do { } while (0)
-#endif
-#ifdef EXP_PROF
-#define PROBE(i) do { uint64_t t_ = __builtin_readcyclecounter(); L.prof_acc[i] += t_ - L.prof_t; L.prof_t = t_; } while (0)
-#else
-#define PROBE(i) do { } while (0)
-#endif
 
 struct Lane {
     // GlobalRng
@@ -66,7 +64,7 @@ struct Lane {
     uint64_t rq;         // K::RQ variants: the ready queue itself, byte i = i-th queued task slot
     uint32_t heap_len;
     uint32_t verdict;
-#if defined(EXP_PROF) || defined(EXP_PROF2)
+#ifdef MADSIM_K_PROF
     uint64_t prof_acc[12]; uint64_t prof_t;
 #endif
     uint32_t main_done;  // handle[0] left H_RUNNING: block_on's task.is_finished()

@@ -5,8 +5,13 @@
 // launches the gfx950 executor kernel (sim_kernel.hip) with one lane per seed, and reduces the
 // per-seed verdicts to "first failing seed" on the device.  No CPU execution path exists here: when
 // HIP is unavailable every entry point returns MADSIM_E_HIP / MADSIM_E_NOINIT.
+//
+// State lives in per-device contexts (madsim_hip_ctx_t): a process may hold one context per GPU and drive them all from
+// one host thread (madsim_hip_run_batch_multi), which is what a `cargo test` process on an 8-GPU node needs.  The v1
+// entry points (madsim_hip_init / madsim_hip_run_batch ...) are wrappers on a process-default context.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -19,38 +24,12 @@
 #include "geometry.h"
 
 using madsim_k::KParams;
+using madsim_geo::Geo;
 
 namespace {
 
-struct State {
-    bool inited = false;
-    int device = -1;
-    int num_cus = 0;
-    size_t lds_per_cu = 160 * 1024;
-    size_t max_lds_block = 64 * 1024;
-    // Device copies of workload tables, keyed by content hash.  Entries are immutable once uploaded, so launches that
-    // are still in flight on other streams keep valid pointers when a different workload comes along.
-    struct Tables { uint64_t hash = 0; uint4* insns = nullptr; uint32_t* progs = nullptr; uint32_t* socks = nullptr; uint64_t* durs = nullptr; };
-    std::vector<Tables> tables;
-    // timer-heap spill regions, one per stream: launches on one stream run in order, launches on different streams
-    // may overlap and must not share scratch
-    struct Spill { uint4* p = nullptr; size_t bytes = 0; };
-    std::unordered_map<hipStream_t, Spill> spill;
-    unsigned long long* d_acc = nullptr;      // 4 x u64 summary accumulators
-    madsim_result_t* d_out = nullptr; size_t out_cap = 0;
-    uint8_t* d_tlog = nullptr; size_t tlog_cap = 0; uint64_t* d_tlen = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t tev[2 * 64] = {};              // timing slots of madsim_hip_run_batch_async
-    uint32_t lds_attr = 0;
-    uint64_t* d_prof = nullptr;               // debug counters (EXP_PROF kernel builds)
-};
-
-State g;
-std::mutex g_mu;
 thread_local std::string g_err;
-
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
-madsim_geo::Device dev() { madsim_geo::Device d; d.num_cus = g.num_cus > 0 ? g.num_cus : 256; d.lds_per_cu = g.lds_per_cu; return d; }
 
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
@@ -65,108 +44,345 @@ uint64_t fnv(const void* p, size_t n, uint64_t h) {
     return h;
 }
 
-using madsim_geo::Geo;
-
-void free_tables(State::Tables& t) {
-    if (t.insns) (void)hipFree(t.insns);
-    if (t.progs) (void)hipFree(t.progs);
-    if (t.socks) (void)hipFree(t.socks);
-    if (t.durs) (void)hipFree(t.durs);
-    t = State::Tables();
+double since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-int upload_workload(const madsim_workload_t* w, KParams& P) {
+}  // namespace
+
+// One GPU's worth of runner state.  Re-entrant per handle: distinct contexts never share mutable state; one context
+// serialises its callers on `mu`.
+struct madsim_hip_ctx {
+    std::mutex mu;
+    int device = -1;
+    int num_cus = 0;
+    size_t lds_per_cu = 160 * 1024;
+    // Device copies of workload tables.  Looked up by content hash, confirmed by comparing the host bytes kept beside
+    // them; entries are immutable once uploaded, so launches still in flight on other streams keep valid pointers when a
+    // different workload comes along.
+    struct Tables {
+        uint64_t hash = 0;
+        std::vector<uint32_t> host;      // insns | progs | socks | durs (as 32-bit words) | n_insns
+        uint4* insns = nullptr; uint32_t* progs = nullptr; uint32_t* socks = nullptr; uint64_t* durs = nullptr;
+    };
+    std::vector<Tables> tables;
+    // per-stream scratch: launches on one stream run in order, launches on different streams may overlap and must
+    // not share the timer-heap spill region or the work-queue counter
+    struct Scratch { uint4* spill = nullptr; size_t spill_bytes = 0; unsigned long long* work_ctr = nullptr; };
+    std::unordered_map<hipStream_t, Scratch> scratch;
+    hipStream_t own_stream = nullptr;         // madsim_hip_run_batch_multi launches here so devices overlap
+    unsigned long long* d_acc = nullptr;      // 4 x u64 summary accumulators
+    madsim_result_t* d_out = nullptr; size_t out_cap = 0;
+    uint64_t* d_seeds = nullptr; size_t seeds_cap = 0;        // seed list of a compacted re-run
+    uint8_t* d_tlog = nullptr; size_t tlog_cap = 0; uint64_t* d_tlen = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t tev[2 * 64] = {};              // timing slots of madsim_hip_run_batch_async
+    uint32_t lds_attr = 0;
+    uint64_t* d_prof = nullptr;               // debug counters (profiling kernel builds)
+
+    madsim_geo::Device dev() const { madsim_geo::Device d; d.num_cus = num_cus > 0 ? num_cus : 256; d.lds_per_cu = lds_per_cu; return d; }
+    int bind() { HIP_TRY(hipSetDevice(device)); return 0; }
+    static void free_tables(Tables& t) {
+        if (t.insns) (void)hipFree(t.insns);
+        if (t.progs) (void)hipFree(t.progs);
+        if (t.socks) (void)hipFree(t.socks);
+        if (t.durs) (void)hipFree(t.durs);
+        t = Tables();
+    }
+    int open(int dev_index);
+    void close();
+    int upload_workload(const madsim_workload_t* w, KParams& P);
+    int ensure_scratch(KParams& P, hipStream_t stream, bool work_queue);
+    int ensure_out(size_t count);
+    int launch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count, const uint64_t* d_seed_list,
+               const madsim_limits_t* lim, madsim_result_t* d_out, hipStream_t stream);
+    int reduce(const madsim_result_t* d_out, uint64_t count, uint64_t seed0, unsigned long long* d_acc4, hipStream_t stream);
+    int run_device(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                   const madsim_limits_t* lim, madsim_result_t* d_out, hipStream_t stream, madsim_summary_t* summary);
+    int run_host(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                 const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary);
+    int run_list(const madsim_workload_t* w, const madsim_config_t* cfg, const std::vector<uint64_t>& seeds,
+                 const madsim_limits_t* lim, std::vector<madsim_result_t>& res, double* kernel_ms);
+};
+
+int madsim_hip_ctx::open(int dev_index) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(MADSIM_E_HIP, "no HIP device visible (this library has no CPU fallback)");
+    if (dev_index < 0 || dev_index >= n) return fail(MADSIM_E_ARG, "device index out of range");
+    device = dev_index;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    num_cus = prop.multiProcessorCount;
+    lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 160 * 1024;
+    if (lds_per_cu > 160 * 1024) lds_per_cu = 160 * 1024;
+    HIP_TRY(hipMalloc(&d_acc, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&d_tlen, sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&d_prof, 16 * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(d_prof, 0, 16 * sizeof(uint64_t)));
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    return 0;
+}
+
+void madsim_hip_ctx::close() {
+    if (device < 0) return;
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    for (auto& t : tables) free_tables(t);
+    tables.clear();
+    for (auto& kv : scratch) { if (kv.second.spill) (void)hipFree(kv.second.spill); if (kv.second.work_ctr) (void)hipFree(kv.second.work_ctr); }
+    scratch.clear();
+    if (d_acc) (void)hipFree(d_acc);
+    if (d_out) (void)hipFree(d_out);
+    if (d_seeds) (void)hipFree(d_seeds);
+    if (d_tlog) (void)hipFree(d_tlog);
+    if (d_tlen) (void)hipFree(d_tlen);
+    if (d_prof) (void)hipFree(d_prof);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+    for (auto& e : tev) if (e) (void)hipEventDestroy(e);
+    device = -1;
+}
+
+int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
     madsim_geo::DeviceTables T;
     int rc = madsim_geo::build_tables(w, &T, &g_err);
     if (rc) return rc;
-    uint64_t h = fnv(T.insns.data(), T.insns.size() * 4, 14695981039346656037ull);
-    h = fnv(T.progs.data(), w->n_progs * 4, h);
-    h = fnv(T.socks.data(), w->n_socks * 4, h);
-    h = fnv(T.durs.data(), T.durs.size() * 8, h);
-    h = fnv(&w->n_insns, 4, h);
-    const State::Tables* hit = nullptr;
-    for (auto& t : g.tables) if (t.hash == h) hit = &t;
+    std::vector<uint32_t> host;
+    host.reserve(T.insns.size() + w->n_progs + w->n_socks + 2 * T.durs.size() + 1);
+    host.insert(host.end(), T.insns.begin(), T.insns.end());
+    host.insert(host.end(), T.progs.begin(), T.progs.begin() + w->n_progs);
+    host.insert(host.end(), T.socks.begin(), T.socks.begin() + w->n_socks);
+    for (uint64_t d : T.durs) { host.push_back((uint32_t)d); host.push_back((uint32_t)(d >> 32)); }
+    host.push_back(w->n_insns);
+    const uint64_t h = fnv(host.data(), host.size() * 4, 14695981039346656037ull);
+    const Tables* hit = nullptr;
+    for (auto& t : tables) if (t.hash == h && t.host == host) hit = &t;     // hash first, then the bytes themselves
     if (!hit) {
-        if (g.tables.size() >= 16) {                       // bounded cache: drop everything once nothing is in flight
+        if (tables.size() >= 16) {                       // bounded cache: drop everything once nothing is in flight
             HIP_TRY(hipDeviceSynchronize());
-            for (auto& t : g.tables) free_tables(t);
-            g.tables.clear();
+            for (auto& t : tables) free_tables(t);
+            tables.clear();
         }
-        State::Tables t;
+        Tables t;
         t.hash = h;
-        HIP_TRY(hipMalloc(&t.insns, T.insns.size() * 4 + 16));
-        HIP_TRY(hipMalloc(&t.progs, T.progs.size() * 4 + 16));
-        HIP_TRY(hipMalloc(&t.socks, T.socks.size() * 4 + 16));
-        HIP_TRY(hipMalloc(&t.durs, T.durs.size() * 8 + 16));
-        HIP_TRY(hipMemcpy(t.insns, T.insns.data(), T.insns.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(t.progs, T.progs.data(), T.progs.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(t.socks, T.socks.data(), T.socks.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(t.durs, T.durs.data(), T.durs.size() * 8, hipMemcpyHostToDevice));
-        g.tables.push_back(t);
-        hit = &g.tables.back();
+        auto up = [&]() -> int {
+            HIP_TRY(hipMalloc(&t.insns, T.insns.size() * 4 + 16));
+            HIP_TRY(hipMalloc(&t.progs, T.progs.size() * 4 + 16));
+            HIP_TRY(hipMalloc(&t.socks, T.socks.size() * 4 + 16));
+            HIP_TRY(hipMalloc(&t.durs, T.durs.size() * 8 + 16));
+            HIP_TRY(hipMemcpy(t.insns, T.insns.data(), T.insns.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t.progs, T.progs.data(), T.progs.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t.socks, T.socks.data(), T.socks.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t.durs, T.durs.data(), T.durs.size() * 8, hipMemcpyHostToDevice));
+            return 0;
+        };
+        if ((rc = up())) { free_tables(t); return rc; }  // no partial allocation survives an error
+        t.host = std::move(host);
+        tables.push_back(std::move(t));
+        hit = &tables.back();
     }
     P.insns = hit->insns; P.progs = hit->progs; P.socks = hit->socks; P.dur_table = hit->durs;
     return 0;
 }
 
-int ensure_spill(KParams& P, hipStream_t stream) {
-    P.spill = nullptr;
-    if (!P.heap_spill) return 0;
-    size_t need = (size_t)P.heap_spill * P.total_lanes * sizeof(uint4);
-    if (need >= (1ull << 32)) return fail(MADSIM_E_LIMITS, "heap spill region exceeds 4 GiB: lower heap_spill_slots");
-    State::Spill& sp = g.spill[stream];
-    if (need > sp.bytes) {
-        if (sp.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(sp.p); }
-        sp.p = nullptr; sp.bytes = 0;
-        HIP_TRY(hipMalloc(&sp.p, need));
-        sp.bytes = need;
+int madsim_hip_ctx::ensure_scratch(KParams& P, hipStream_t stream, bool work_queue) {
+    P.spill = nullptr; P.work_ctr = nullptr;
+    if (!P.heap_spill && !work_queue) return 0;
+    Scratch& sc = scratch[stream];
+    if (P.heap_spill) {
+        size_t need = (size_t)P.heap_spill * P.total_lanes * sizeof(uint4);
+        if (need >= (1ull << 32)) return fail(MADSIM_E_LIMITS, "heap spill region exceeds 4 GiB: lower heap_spill_slots");
+        if (need > sc.spill_bytes) {
+            if (sc.spill) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(sc.spill); }
+            sc.spill = nullptr; sc.spill_bytes = 0;
+            HIP_TRY(hipMalloc(&sc.spill, need));
+            sc.spill_bytes = need;
+        }
+        P.spill = sc.spill;
     }
-    P.spill = sp.p;
+    if (work_queue) {
+        if (!sc.work_ctr) HIP_TRY(hipMalloc(&sc.work_ctr, sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(sc.work_ctr, 0, sizeof(unsigned long long), stream));
+        P.work_ctr = sc.work_ctr;
+    }
     return 0;
 }
 
-int run_device(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
-               const madsim_limits_t* lim, madsim_result_t* d_out, hipStream_t stream, madsim_summary_t* summary) {
+int madsim_hip_ctx::ensure_out(size_t count) {
+    if (count > out_cap) {
+        if (d_out) (void)hipFree(d_out);
+        d_out = nullptr; out_cap = 0;
+        HIP_TRY(hipMalloc(&d_out, count * sizeof(madsim_result_t)));
+        out_cap = count;
+    }
+    return 0;
+}
+
+// Queue the simulation kernel for `count` units on `stream`: unit i runs seed d_seed_list[i] (device memory) when a list
+// is given, else seed0 + i.  Nothing is synchronised.
+int madsim_hip_ctx::launch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count, const uint64_t* d_seed_list,
+                           const madsim_limits_t* lim, madsim_result_t* d_res, hipStream_t stream) {
+    Geo G;
+    int rc;
+    if ((rc = madsim_geo::make_geometry(dev(), w, cfg, lim, count, &G, &g_err))) return rc;
+    if ((rc = upload_workload(w, G.P))) return rc;
+    // Work distribution: static striding (lane g runs units g, g+G, ...) or a per-launch atomic counter from which a
+    // finished lane pulls its next unit.  They only differ when a launch holds more units than resident lanes.
+    const bool work_queue = lim && lim->sched == MADSIM_SCHED_QUEUE && count > G.P.total_lanes;
+    if ((rc = ensure_scratch(G.P, stream, work_queue))) return rc;
+    G.P.seed0 = seed0; G.P.count = count; G.P.seed_list = d_seed_list; G.P.out = d_res; G.P.prof = d_prof;
+    if (G.lds_bytes > lds_attr) {
+        int e = madsim_k_set_max_lds((uint32_t)lds_per_cu);
+        if (e) return fail(MADSIM_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        lds_attr = (uint32_t)lds_per_cu;
+    }
+    madsim_k_launch_sim(&G.P, G.grid, G.lds_bytes, stream, 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Queue the report reduction of d_out[0..count) into d_acc4 = {first failing seed, n_failed, steps, clock} on `stream`.
+int madsim_hip_ctx::reduce(const madsim_result_t* d_res, uint64_t count, uint64_t seed0, unsigned long long* d_acc4, hipStream_t stream) {
+    HIP_TRY(hipMemsetAsync(d_acc4, 0xff, 8, stream));
+    HIP_TRY(hipMemsetAsync((char*)d_acc4 + 8, 0, 24, stream));
+    madsim_k_launch_summary(d_res, count, seed0, d_acc4, stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int madsim_hip_ctx::run_device(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                               const madsim_limits_t* lim, madsim_result_t* d_res, hipStream_t stream, madsim_summary_t* summary) {
     auto t0 = std::chrono::steady_clock::now();
-    if (!g.inited) return fail(MADSIM_E_NOINIT, "madsim_hip_init has not been called");
     int rc = madsim_geo::validate(w, cfg, &g_err);
     if (rc) return rc;
     if (count == 0) {
         if (summary) { memset(summary, 0, sizeof *summary); summary->first_failing_seed = UINT64_MAX; }
         return 0;
     }
-    if (!d_out) return fail(MADSIM_E_ARG, "null result buffer");
-    Geo G;
-    if ((rc = madsim_geo::make_geometry(dev(), w, cfg, lim, count, &G, &g_err))) return rc;
-    if ((rc = upload_workload(w, G.P))) return rc;
-    if ((rc = ensure_spill(G.P, stream))) return rc;
-    G.P.seed0 = seed0; G.P.count = count; G.P.out = d_out; G.P.prof = g.d_prof;
-    if (G.lds_bytes > g.lds_attr) {
-        int e = madsim_k_set_max_lds((uint32_t)g.lds_per_cu);
-        if (e) return fail(MADSIM_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-        g.lds_attr = (uint32_t)g.lds_per_cu;
-    }
-    if (summary) HIP_TRY(hipEventRecord(g.ev0, stream));
-    madsim_k_launch_sim(&G.P, G.grid, G.lds_bytes, stream, 0);
-    HIP_TRY(hipGetLastError());
+    if (!d_res) return fail(MADSIM_E_ARG, "null result buffer");
+    if (summary) HIP_TRY(hipEventRecord(ev0, stream));
+    if ((rc = launch(w, cfg, seed0, count, nullptr, lim, d_res, stream))) return rc;
     if (summary) {
-        HIP_TRY(hipEventRecord(g.ev1, stream));
-        HIP_TRY(hipMemsetAsync(g.d_acc, 0xff, 8, stream));
-        HIP_TRY(hipMemsetAsync((char*)g.d_acc + 8, 0, 24, stream));
-        madsim_k_launch_summary(d_out, count, seed0, g.d_acc, stream);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev1, stream));
+        if ((rc = reduce(d_res, count, seed0, d_acc, stream))) return rc;
         unsigned long long acc[4];
-        HIP_TRY(hipMemcpyAsync(acc, g.d_acc, sizeof acc, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(acc, d_acc, sizeof acc, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         summary->first_failing_seed = acc[0]; summary->n_failed = acc[1];
         summary->total_steps = acc[2]; summary->total_clock_ns = acc[3];
         summary->kernel_ms = ms;
-        summary->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        summary->wall_s = since(t0);
     }
     return 0;
 }
+
+int madsim_hip_ctx::run_host(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                             const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary) {
+    auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    if ((rc = ensure_out(count))) return rc;
+    madsim_summary_t tmp;
+    if ((rc = run_device(w, cfg, seed0, count, lim, d_out, nullptr, &tmp))) return rc;
+    if (out && count) HIP_TRY(hipMemcpy(out, d_out, count * sizeof(madsim_result_t), hipMemcpyDeviceToHost));
+    if (summary) { *summary = tmp; summary->wall_s = since(t0); }
+    return 0;
+}
+
+// One compacted launch over an arbitrary list of seeds (the re-run of seeds that outgrew a capacity).
+int madsim_hip_ctx::run_list(const madsim_workload_t* w, const madsim_config_t* cfg, const std::vector<uint64_t>& seeds,
+                             const madsim_limits_t* lim, std::vector<madsim_result_t>& res, double* kernel_ms) {
+    const size_t n = seeds.size();
+    res.resize(n);
+    if (!n) return 0;
+    int rc;
+    if ((rc = ensure_out(n))) return rc;
+    if (n > seeds_cap) {
+        if (d_seeds) (void)hipFree(d_seeds);
+        d_seeds = nullptr; seeds_cap = 0;
+        HIP_TRY(hipMalloc(&d_seeds, n * sizeof(uint64_t)));
+        seeds_cap = n;
+    }
+    HIP_TRY(hipMemcpy(d_seeds, seeds.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipEventRecord(ev0, nullptr));
+    if ((rc = launch(w, cfg, 0, n, d_seeds, lim, d_out, nullptr))) return rc;
+    HIP_TRY(hipEventRecord(ev1, nullptr));
+    HIP_TRY(hipMemcpy(res.data(), d_out, n * sizeof(madsim_result_t), hipMemcpyDeviceToHost));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    if (kernel_ms) *kernel_ms += ms;
+    return 0;
+}
+
+namespace {
+
+madsim_hip_ctx* g_default = nullptr;       // the context behind the v1 entry points
+std::mutex g_default_mu;
+
+// Seeds that came back with a RUNNER verdict (a device capacity or the step cap, neither a reference concept) are run
+// again, all of them in ONE compacted launch per round, with doubled capacities / a 16x step cap.
+void grow(madsim_limits_t& L, const madsim_workload_t* w, bool any_ovf, bool any_steps) {
+    auto dbl = [](uint32_t v, uint32_t dflt, uint32_t cap) { uint32_t x = (v == 0 || v == MADSIM_LIMIT_NONE) ? dflt : v; x *= 2; return x > cap ? cap : x; };
+    L.lanes_per_wave = 0;
+    if (any_ovf) {
+        L.heap_lds_slots = L.heap_lds_slots ? L.heap_lds_slots : 8;
+        L.heap_spill_slots = dbl(L.heap_spill_slots, 32, 1u << 20);
+        L.max_tasks = dbl(L.max_tasks, w->n_progs + 8, 254);
+        L.mbox_regs = dbl(L.mbox_regs, 2, 255);
+        L.mbox_msgs = dbl(L.mbox_msgs, 2, 255);
+        L.max_conns = dbl(L.max_conns, 4, 127);
+        L.chan_queue = dbl(L.chan_queue, 2, 15);
+    }
+    if (any_steps) {
+        uint64_t s = L.max_steps ? L.max_steps : (1u << 24);
+        s *= 16;
+        L.max_steps = s > 0xffffffffull ? 0xffffffffu : (uint32_t)s;
+    }
+}
+
+int rerun_runner_verdicts(madsim_hip_ctx* c, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                          const madsim_limits_t* lim, madsim_result_t* out, int max_rounds, double* kernel_ms) {
+    madsim_limits_t L{};
+    if (lim) L = *lim;
+    for (int round = 0; round < max_rounds; round++) {
+        std::vector<uint64_t> idx;
+        bool any_ovf = false, any_steps = false;
+        const bool steps_maxed = L.max_steps == 0xffffffffu;
+        for (uint64_t i = 0; i < count; i++) {
+            if (out[i].verdict == MADSIM_OVERFLOW) { idx.push_back(i); any_ovf = true; }
+            else if (out[i].verdict == MADSIM_STEP_LIMIT && !steps_maxed) { idx.push_back(i); any_steps = true; }
+        }
+        if (idx.empty()) break;
+        grow(L, w, any_ovf, any_steps);
+        std::vector<uint64_t> seeds(idx.size());
+        for (size_t k = 0; k < idx.size(); k++) seeds[k] = seed0 + idx[k];
+        std::vector<madsim_result_t> res;
+        int rc = c->run_list(w, cfg, seeds, &L, res, kernel_ms);
+        if (rc) return rc;
+        for (size_t k = 0; k < idx.size(); k++) out[idx[k]] = res[k];
+    }
+    return 0;
+}
+
+void host_summary(const madsim_result_t* out, uint64_t seed0, uint64_t count, madsim_summary_t* f) {
+    memset(f, 0, sizeof *f);
+    f->first_failing_seed = UINT64_MAX;
+    for (uint64_t i = 0; i < count; i++) {
+        if (out[i].verdict != MADSIM_PASS) { if (!f->n_failed) f->first_failing_seed = seed0 + i; f->n_failed++; }
+        f->total_steps += out[i].steps; f->total_clock_ns += out[i].clock_ns;
+    }
+}
+
+#define CTX_ENTER(c)                                                                              \
+    if (!(c) || (c)->device < 0) return fail(MADSIM_E_NOINIT, "no context (madsim_hip_init / madsim_hip_ctx_create has not been called)"); \
+    std::lock_guard<std::mutex> lk((c)->mu);                                                      \
+    { int brc_ = (c)->bind(); if (brc_) return brc_; }
 
 }  // namespace
 
@@ -188,201 +404,233 @@ const char* madsim_hip_strerror(int code) {
 
 const char* madsim_hip_last_error(void) { return g_err.c_str(); }
 
-int madsim_hip_init(int device) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n == 0) return fail(MADSIM_E_HIP, "no HIP device visible (this library has no CPU fallback)");
-    if (device < 0 || device >= n) return fail(MADSIM_E_ARG, "device index out of range");
-    if (g.inited && g.device == device) { HIP_TRY(hipSetDevice(device)); return 0; }
-    if (g.inited) return fail(MADSIM_E_ARG, "already bound to another GPU: one process per GPU (call madsim_hip_shutdown first)");
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    g.device = device;
-    g.num_cus = prop.multiProcessorCount;
-    g.lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 160 * 1024;
-    if (g.lds_per_cu > 160 * 1024) g.lds_per_cu = 160 * 1024;
-    if (!g.d_acc) HIP_TRY(hipMalloc(&g.d_acc, 4 * sizeof(unsigned long long)));
-    if (!g.d_tlen) HIP_TRY(hipMalloc(&g.d_tlen, sizeof(uint64_t)));
-    if (!g.d_prof) { HIP_TRY(hipMalloc(&g.d_prof, 16 * sizeof(uint64_t))); HIP_TRY(hipMemset(g.d_prof, 0, 16 * sizeof(uint64_t))); }
-    if (!g.ev0) HIP_TRY(hipEventCreate(&g.ev0));
-    if (!g.ev1) HIP_TRY(hipEventCreate(&g.ev1));
-    g.inited = true;
+// ---- per-device contexts ---------------------------------------------------------------------------------------------
+
+int madsim_hip_ctx_create(int device, madsim_hip_ctx_t** out) {
+    if (!out) return fail(MADSIM_E_ARG, "null context pointer");
+    *out = nullptr;
+    madsim_hip_ctx* c = new madsim_hip_ctx();
+    int rc = c->open(device);
+    if (rc) { c->close(); delete c; return rc; }
+    *out = c;
     return 0;
 }
 
-int madsim_hip_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g.inited) return 0;
-    (void)hipDeviceSynchronize();
-    for (auto& t : g.tables) free_tables(t);
-    for (auto& kv : g.spill) if (kv.second.p) (void)hipFree(kv.second.p);
-    if (g.d_acc) (void)hipFree(g.d_acc);
-    if (g.d_out) (void)hipFree(g.d_out);
-    if (g.d_tlog) (void)hipFree(g.d_tlog);
-    if (g.d_tlen) (void)hipFree(g.d_tlen);
-    if (g.d_prof) (void)hipFree(g.d_prof);
-    if (g.ev0) (void)hipEventDestroy(g.ev0);
-    if (g.ev1) (void)hipEventDestroy(g.ev1);
-    for (auto& e : g.tev) if (e) (void)hipEventDestroy(e);
-    g = State();
+int madsim_hip_ctx_destroy(madsim_hip_ctx_t* c) {
+    if (!c) return 0;
+    { std::lock_guard<std::mutex> lk(c->mu); c->close(); }
+    delete c;
     return 0;
 }
 
-int madsim_hip_run_batch_device(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
-                                const madsim_limits_t* lim, void* d_out, void* stream, madsim_summary_t* summary) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    return run_device(w, cfg, seed0, count, lim, (madsim_result_t*)d_out, (hipStream_t)stream, summary);
+int madsim_hip_ctx_device(const madsim_hip_ctx_t* c) { return c ? c->device : -1; }
+
+int madsim_hip_ctx_run_batch(madsim_hip_ctx_t* c, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                             const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary) {
+    CTX_ENTER(c);
+    return c->run_host(w, cfg, seed0, count, lim, out, summary);
 }
 
-int madsim_hip_run_batch_async(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
-                               const madsim_limits_t* lim, void* d_out, void* d_summary4, void* stream, int timing_slot) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g.inited) return fail(MADSIM_E_NOINIT, "madsim_hip_init has not been called");
+int madsim_hip_ctx_run_batch_device(madsim_hip_ctx_t* c, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                                    const madsim_limits_t* lim, void* d_out, void* stream, madsim_summary_t* summary) {
+    CTX_ENTER(c);
+    return c->run_device(w, cfg, seed0, count, lim, (madsim_result_t*)d_out, (hipStream_t)stream, summary);
+}
+
+int madsim_hip_ctx_run_batch_async(madsim_hip_ctx_t* c, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                                   const madsim_limits_t* lim, void* d_out, void* d_summary4, void* stream, int timing_slot) {
+    CTX_ENTER(c);
     if (timing_slot >= 64) return fail(MADSIM_E_ARG, "timing_slot must be < 64");
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t* ev = nullptr;
     if (timing_slot >= 0) {
-        ev = &g.tev[2 * timing_slot];
+        ev = &c->tev[2 * timing_slot];
         if (!ev[0]) { HIP_TRY(hipEventCreate(&ev[0])); HIP_TRY(hipEventCreate(&ev[1])); }
         HIP_TRY(hipEventRecord(ev[0], st));
     }
-    int rc = run_device(w, cfg, seed0, count, lim, (madsim_result_t*)d_out, st, nullptr);
+    int rc = c->run_device(w, cfg, seed0, count, lim, (madsim_result_t*)d_out, st, nullptr);
     if (rc) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     if (d_summary4 && count) {
         // {UINT64_MAX, 0, 0, 0}, accumulated by the reduction kernel, then word 0 is flipped into its
         // order-preserving int64 form (seed ^ 1<<63) so a signed all-reduce(MIN) yields the unsigned minimum
-        HIP_TRY(hipMemsetAsync(d_summary4, 0xff, 8, st));
-        HIP_TRY(hipMemsetAsync((char*)d_summary4 + 8, 0, 24, st));
-        madsim_k_launch_summary((const madsim_result_t*)d_out, count, seed0, (unsigned long long*)d_summary4, st);
-        HIP_TRY(hipGetLastError());
+        if ((rc = c->reduce((const madsim_result_t*)d_out, count, seed0, (unsigned long long*)d_summary4, st))) return rc;
         madsim_k_launch_keyflip((unsigned long long*)d_summary4, st);
         HIP_TRY(hipGetLastError());
     }
     return 0;
 }
 
-int madsim_hip_timing_ms(int timing_slot, double* ms) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (timing_slot < 0 || timing_slot >= 64 || !g.tev[2 * timing_slot] || !ms) return fail(MADSIM_E_ARG, "bad timing slot");
+int madsim_hip_ctx_timing_ms(madsim_hip_ctx_t* c, int timing_slot, double* ms) {
+    CTX_ENTER(c);
+    if (timing_slot < 0 || timing_slot >= 64 || !c->tev[2 * timing_slot] || !ms) return fail(MADSIM_E_ARG, "bad timing slot");
     float f = 0.f;
-    HIP_TRY(hipEventSynchronize(g.tev[2 * timing_slot + 1]));
-    HIP_TRY(hipEventElapsedTime(&f, g.tev[2 * timing_slot], g.tev[2 * timing_slot + 1]));
+    HIP_TRY(hipEventSynchronize(c->tev[2 * timing_slot + 1]));
+    HIP_TRY(hipEventElapsedTime(&f, c->tev[2 * timing_slot], c->tev[2 * timing_slot + 1]));
     *ms = f;
     return 0;
 }
 
-int madsim_hip_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
-                         const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto t0 = std::chrono::steady_clock::now();
-    if (!g.inited) return fail(MADSIM_E_NOINIT, "madsim_hip_init has not been called");
-    if (count > g.out_cap) {
-        if (g.d_out) (void)hipFree(g.d_out);
-        g.d_out = nullptr; g.out_cap = 0;
-        HIP_TRY(hipMalloc(&g.d_out, count * sizeof(madsim_result_t)));
-        g.out_cap = count;
-    }
-    madsim_summary_t tmp;
-    int rc = run_device(w, cfg, seed0, count, lim, g.d_out, nullptr, &tmp);
-    if (rc) return rc;
-    if (out && count) HIP_TRY(hipMemcpy(out, g.d_out, count * sizeof(madsim_result_t), hipMemcpyDeviceToHost));
-    if (summary) { *summary = tmp; summary->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
-    return 0;
-}
-
-int madsim_hip_run_batch_auto(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
-                              const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary, int max_rounds) {
-    if (!out && count) { std::lock_guard<std::mutex> lk(g_mu); return fail(MADSIM_E_ARG, "run_batch_auto needs the result array"); }
+int madsim_hip_ctx_run_batch_auto(madsim_hip_ctx_t* c, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                                  const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary, int max_rounds) {
+    if (!out && count) return fail(MADSIM_E_ARG, "run_batch_auto needs the result array");
+    CTX_ENTER(c);
     auto t0 = std::chrono::steady_clock::now();
     madsim_summary_t s{};
-    int rc = madsim_hip_run_batch(w, cfg, seed0, count, lim, out, &s);
+    int rc = c->run_host(w, cfg, seed0, count, lim, out, &s);
     if (rc) return rc;
-    madsim_limits_t L{};
-    if (lim) L = *lim;
     double kernel_ms = s.kernel_ms;
-    for (int round = 0; round < max_rounds; round++) {
-        bool any = false;
-        for (uint64_t i = 0; i < count; i++) any |= out[i].verdict == MADSIM_OVERFLOW;
-        if (!any) break;
-        // double every capacity (defaults spelled out first); the lane geometry follows the new per-seed footprint
-        auto dbl = [](uint32_t v, uint32_t dflt, uint32_t cap) { uint32_t x = (v == 0 || v == MADSIM_LIMIT_NONE) ? dflt : v; x *= 2; return x > cap ? cap : x; };
-        L.lanes_per_wave = 0;
-        L.heap_lds_slots = L.heap_lds_slots ? L.heap_lds_slots : 8;
-        L.heap_spill_slots = dbl(L.heap_spill_slots, 32, 1u << 20);
-        L.max_tasks = dbl(L.max_tasks, w->n_progs + 8, 254);
-        L.mbox_regs = dbl(L.mbox_regs, 2, 255);
-        L.mbox_msgs = dbl(L.mbox_msgs, 2, 255);
-        L.max_conns = dbl(L.max_conns, 4, 127);
-        L.chan_queue = dbl(L.chan_queue, 2, 15);
-        for (uint64_t i = 0; i < count;) {                  // contiguous runs of overflowed seeds
-            if (out[i].verdict != MADSIM_OVERFLOW) { i++; continue; }
-            uint64_t j = i;
-            while (j + 1 < count && out[j + 1].verdict == MADSIM_OVERFLOW) j++;
-            madsim_summary_t part{};
-            rc = madsim_hip_run_batch(w, cfg, seed0 + i, j - i + 1, &L, out + i, &part);
-            if (rc) return rc;
-            kernel_ms += part.kernel_ms;
-            i = j + 1;
-        }
-    }
-    if (summary) {
-        madsim_summary_t f{};
-        f.first_failing_seed = UINT64_MAX;
-        for (uint64_t i = 0; i < count; i++) {
-            if (out[i].verdict != MADSIM_PASS) { if (!f.n_failed) f.first_failing_seed = seed0 + i; f.n_failed++; }
-            f.total_steps += out[i].steps; f.total_clock_ns += out[i].clock_ns;
-        }
-        f.kernel_ms = kernel_ms;
-        f.wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        *summary = f;
-    }
+    if ((rc = rerun_runner_verdicts(c, w, cfg, seed0, count, lim, out, max_rounds, &kernel_ms))) return rc;
+    if (summary) { host_summary(out, seed0, count, summary); summary->kernel_ms = kernel_ms; summary->wall_s = since(t0); }
     return 0;
 }
 
-int64_t madsim_hip_trace_seed(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
-                              const madsim_limits_t* lim, uint8_t* log, uint64_t cap, madsim_result_t* out) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g.inited) return fail(MADSIM_E_NOINIT, "madsim_hip_init has not been called");
+int64_t madsim_hip_ctx_trace_seed(madsim_hip_ctx_t* c, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
+                                  const madsim_limits_t* lim, uint8_t* log, uint64_t cap, madsim_result_t* out) {
+    CTX_ENTER(c);
     int rc = madsim_geo::validate(w, cfg, &g_err);
     if (rc) return rc;
     Geo G;
-    if ((rc = madsim_geo::make_geometry(dev(), w, cfg, lim, 1, &G, &g_err, true))) return rc;
-    if ((rc = upload_workload(w, G.P))) return rc;
-    if ((rc = ensure_spill(G.P, nullptr))) return rc;
-    if (cap > g.tlog_cap) {
-        if (g.d_tlog) (void)hipFree(g.d_tlog);
-        g.d_tlog = nullptr; g.tlog_cap = 0;
-        HIP_TRY(hipMalloc(&g.d_tlog, cap));
-        g.tlog_cap = cap;
+    if ((rc = madsim_geo::make_geometry(c->dev(), w, cfg, lim, 1, &G, &g_err, true))) return rc;
+    if ((rc = c->upload_workload(w, G.P))) return rc;
+    if ((rc = c->ensure_scratch(G.P, nullptr, false))) return rc;
+    if (cap > c->tlog_cap) {
+        if (c->d_tlog) (void)hipFree(c->d_tlog);
+        c->d_tlog = nullptr; c->tlog_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_tlog, cap));
+        c->tlog_cap = cap;
     }
-    if (1 > g.out_cap) { HIP_TRY(hipMalloc(&g.d_out, 64 * sizeof(madsim_result_t))); g.out_cap = 64; }
-    G.P.seed0 = seed; G.P.count = 1; G.P.out = g.d_out;
-    G.P.trace_log = cap ? g.d_tlog : nullptr; G.P.trace_cap = cap; G.P.trace_len = g.d_tlen;
-    if (G.lds_bytes > g.lds_attr) {
-        if (madsim_k_set_max_lds((uint32_t)g.lds_per_cu)) return fail(MADSIM_E_HIP, "hipFuncSetAttribute failed");
-        g.lds_attr = (uint32_t)g.lds_per_cu;
+    if ((rc = c->ensure_out(64))) return rc;
+    G.P.seed0 = seed; G.P.count = 1; G.P.out = c->d_out;
+    G.P.trace_log = cap ? c->d_tlog : nullptr; G.P.trace_cap = cap; G.P.trace_len = c->d_tlen;
+    if (G.lds_bytes > c->lds_attr) {
+        if (madsim_k_set_max_lds((uint32_t)c->lds_per_cu)) return fail(MADSIM_E_HIP, "hipFuncSetAttribute failed");
+        c->lds_attr = (uint32_t)c->lds_per_cu;
     }
     madsim_k_launch_sim(&G.P, 1, G.lds_bytes, nullptr, 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     uint64_t n = 0;
-    HIP_TRY(hipMemcpy(&n, g.d_tlen, sizeof n, hipMemcpyDeviceToHost));
-    if (log && cap) HIP_TRY(hipMemcpy(log, g.d_tlog, n < cap ? n : cap, hipMemcpyDeviceToHost));
-    if (out) HIP_TRY(hipMemcpy(out, g.d_out, sizeof *out, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&n, c->d_tlen, sizeof n, hipMemcpyDeviceToHost));
+    if (log && cap) HIP_TRY(hipMemcpy(log, c->d_tlog, n < cap ? n : cap, hipMemcpyDeviceToHost));
+    if (out) HIP_TRY(hipMemcpy(out, c->d_out, sizeof *out, hipMemcpyDeviceToHost));
     return (int64_t)n;
 }
 
+// ---- one process, several GPUs -----------------------------------------------------------------------------------------
+// Builder::run drives every seed from one process (builder.rs:129-150): shard [seed0, seed0 + count) contiguously over
+// the contexts (context g gets [g * ceil(count / n), ...), the rule of madsim_amd/dist.py::shard_range), queue every
+// device's kernel from this one host thread before waiting for any of them, then copy the shards back and fold the n
+// reports on the host.  The fold is a host fold on purpose: the per-seed results travel to the caller's host array
+// anyway, and n <= 8 reports of 32 bytes do not justify a single-process RCCL communicator (ncclCommInitAll) and a
+// collective launch per batch.  The one-process-per-GPU form (bench.py, torch.distributed) is where RCCL carries the report.
+int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const madsim_workload_t* w, const madsim_config_t* cfg,
+                               uint64_t seed0, uint64_t count, const madsim_limits_t* lim, madsim_result_t* out,
+                               madsim_summary_t* summary, int max_rounds) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (!ctxs || n_ctx < 1) return fail(MADSIM_E_ARG, "run_batch_multi needs at least one context");
+    if (!out && count) return fail(MADSIM_E_ARG, "run_batch_multi needs the result array");
+    for (int g = 0; g < n_ctx; g++) {
+        if (!ctxs[g] || ctxs[g]->device < 0) return fail(MADSIM_E_NOINIT, "null or closed context");
+        for (int h = 0; h < g; h++) if (ctxs[h] == ctxs[g]) return fail(MADSIM_E_ARG, "the same context appears twice");
+    }
+    int rc = madsim_geo::validate(w, cfg, &g_err);
+    if (rc) return rc;
+    const uint64_t chunk = (count + (uint64_t)n_ctx - 1) / (uint64_t)n_ctx;
+    struct Shard { uint64_t lo = 0, n = 0; };
+    std::vector<Shard> sh(n_ctx);
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (int g = 0; g < n_ctx; g++) locks.emplace_back(ctxs[g]->mu);
+    // 1. every device's kernel is in flight before the host waits for anything
+    for (int g = 0; g < n_ctx; g++) {
+        madsim_hip_ctx* c = ctxs[g];
+        sh[g].lo = std::min((uint64_t)g * chunk, count);
+        sh[g].n = std::min(sh[g].lo + chunk, count) - sh[g].lo;
+        if (!sh[g].n) continue;
+        if ((rc = c->bind())) return rc;
+        if ((rc = c->ensure_out(sh[g].n))) return rc;
+        HIP_TRY(hipEventRecord(c->ev0, c->own_stream));
+        if ((rc = c->launch(w, cfg, seed0 + sh[g].lo, sh[g].n, nullptr, lim, c->d_out, c->own_stream))) return rc;
+        HIP_TRY(hipEventRecord(c->ev1, c->own_stream));
+    }
+    // 2. wait and copy back per device (the others keep running; a D2H copy into pageable memory blocks the host, so
+    //    none is issued before every kernel has been queued)
+    double kernel_ms = 0.0;
+    for (int g = 0; g < n_ctx; g++) {
+        madsim_hip_ctx* c = ctxs[g];
+        if (!sh[g].n) continue;
+        if ((rc = c->bind())) return rc;
+        HIP_TRY(hipStreamSynchronize(c->own_stream));
+        HIP_TRY(hipMemcpy(out + sh[g].lo, c->d_out, sh[g].n * sizeof(madsim_result_t), hipMemcpyDeviceToHost));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        kernel_ms = std::max(kernel_ms, (double)ms);       // devices ran concurrently
+    }
+    // 3. runner verdicts (capacity / step cap) from every shard: one compacted re-launch per round, on the first device
+    if ((rc = ctxs[0]->bind())) return rc;
+    if ((rc = rerun_runner_verdicts(ctxs[0], w, cfg, seed0, count, lim, out, max_rounds, &kernel_ms))) return rc;
+    // 4. fold
+    if (summary) { host_summary(out, seed0, count, summary); summary->kernel_ms = kernel_ms; summary->wall_s = since(t0); }
+    return 0;
+}
+
+// ---- v1 entry points: wrappers on the process-default context ------------------------------------------------------------
+
+int madsim_hip_init(int device) {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (g_default) {
+        if (g_default->device == device) { HIP_TRY(hipSetDevice(device)); return 0; }
+        return fail(MADSIM_E_ARG, "the default context is bound to another GPU: call madsim_hip_shutdown first, or hold one "
+                                  "madsim_hip_ctx_t per GPU (madsim_hip_ctx_create)");
+    }
+    return madsim_hip_ctx_create(device, &g_default);
+}
+
+int madsim_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    madsim_hip_ctx* c = g_default;
+    g_default = nullptr;
+    return madsim_hip_ctx_destroy(c);
+}
+
+madsim_hip_ctx_t* madsim_hip_default_ctx(void) { return g_default; }
+
+int madsim_hip_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                         const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary) {
+    return madsim_hip_ctx_run_batch(g_default, w, cfg, seed0, count, lim, out, summary);
+}
+
+int madsim_hip_run_batch_auto(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                              const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary, int max_rounds) {
+    return madsim_hip_ctx_run_batch_auto(g_default, w, cfg, seed0, count, lim, out, summary, max_rounds);
+}
+
+int madsim_hip_run_batch_device(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                                const madsim_limits_t* lim, void* d_out, void* stream, madsim_summary_t* summary) {
+    return madsim_hip_ctx_run_batch_device(g_default, w, cfg, seed0, count, lim, d_out, stream, summary);
+}
+
+int madsim_hip_run_batch_async(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                               const madsim_limits_t* lim, void* d_out, void* d_summary4, void* stream, int timing_slot) {
+    return madsim_hip_ctx_run_batch_async(g_default, w, cfg, seed0, count, lim, d_out, d_summary4, stream, timing_slot);
+}
+
+int madsim_hip_timing_ms(int timing_slot, double* ms) { return madsim_hip_ctx_timing_ms(g_default, timing_slot, ms); }
+
+int64_t madsim_hip_trace_seed(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
+                              const madsim_limits_t* lim, uint8_t* log, uint64_t cap, madsim_result_t* out) {
+    return madsim_hip_ctx_trace_seed(g_default, w, cfg, seed, lim, log, cap, out);
+}
+
 int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* out) {
-    std::lock_guard<std::mutex> lk(g_mu);
     if (!out) return fail(MADSIM_E_ARG, "null geometry");
     madsim_config_t cfg{}; cfg.lat_lo_ns = 1000000; cfg.lat_hi_ns = 10000000;
     int rc = madsim_geo::validate(w, &cfg, &g_err);
     if (rc) return rc;
     Geo G;
-    if ((rc = madsim_geo::make_geometry(dev(), w, &cfg, lim, UINT64_MAX / 2, &G, &g_err))) return rc;
+    madsim_geo::Device d;
+    { std::lock_guard<std::mutex> lk(g_default_mu); if (g_default) d = g_default->dev(); }
+    if ((rc = madsim_geo::make_geometry(d, w, &cfg, lim, UINT64_MAX / 2, &G, &g_err))) return rc;
     out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64 * G.waves_per_block;
     out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
     out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave;
@@ -390,13 +638,13 @@ int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, 
     return 0;
 }
 
-// Debug: read and clear the per-phase cycle accumulators an EXP_PROF kernel build fills (zeros otherwise).
+// Debug: read and clear the per-phase cycle accumulators a profiling kernel build fills (zeros otherwise).
 int madsim_hip_debug_counters(uint64_t* out16) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g.inited) return fail(MADSIM_E_NOINIT, "madsim_hip_init has not been called");
+    madsim_hip_ctx* c = g_default;
+    CTX_ENTER(c);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out16, g.d_prof, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(g.d_prof, 0, 16 * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(out16, c->d_prof, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->d_prof, 0, 16 * sizeof(uint64_t)));
     return 0;
 }
 

@@ -43,12 +43,14 @@ struct KParams {
     uint32_t uses_pause, has_restart_on_panic, restart_nodes;   // restart_nodes: bit n = NodeBuilder::restart_on_panic
     // batch
     uint64_t seed0, count;
+    const uint64_t* seed_list; // non-null: unit i runs seed_list[i] instead of seed0 + i (compacted re-run of overflowed seeds)
     madsim_result_t* out;
+    unsigned long long* work_ctr; // non-null: a lane that finishes unit i pulls unit total_lanes + atomicAdd(work_ctr, 1) next
     uint4* spill;
     uint32_t total_lanes;
     // trace mode (single seed)
     uint8_t* trace_log; uint64_t trace_cap; uint64_t* trace_len;
-    uint64_t* prof;            // EXP_PROF builds: per-phase cycle accumulators (debug only)
+    uint64_t* prof;            // profiling builds (tools/experiment): per-phase cycle accumulators
 };
 
 }  // namespace madsim_k

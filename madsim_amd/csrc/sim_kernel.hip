@@ -1,7 +1,7 @@
 // sim_kernel.hip — the many-seed executor kernel for gfx950 (MI355X, CDNA4).
 //
-// One wavefront (64 lanes) per workgroup, ONE LANE = ONE SEED.  Each lane runs madsim's whole
-// per-seed executor loop:
+// ONE LANE = ONE SEED.  A workgroup is up to four independent 64-lane wavefronts (one per SIMD of a CU) that share
+// nothing but the read-only workload tables.  Each lane runs madsim's whole per-seed executor loop:
 //     Executor::block_on / run_all_ready       madsim/src/sim/task/mod.rs:220-323
 //     mpsc::Receiver::try_recv_random          madsim/src/sim/utils/mpsc.rs:73-83
 //     TimeRuntime::advance_to_next_event       madsim/src/sim/time/mod.rs:45-60
@@ -112,16 +112,16 @@ __global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
     c.tlog = P.trace_log;
 
     Lane L;
-#if defined(EXP_PROF) || defined(EXP_PROF2)
+#ifdef MADSIM_K_PROF
     for (int i = 0; i < 12; i++) L.prof_acc[i] = 0;
     L.prof_t = __builtin_readcyclecounter(); uint64_t prof_iters = 0;
 #endif
-    uint64_t next = glane;          // static striding: lane g runs seeds g, g+G, g+2G, ...
+    uint64_t next = glane;          // first unit of lane g; then g+G, g+2G, ... or the work queue (below)
     bool have = false;
     for (;;) {
         if (!have) {
             if (next >= P.count) break;
-            seed_init<K>(c, L, P.seed0 + next);
+            seed_init<K>(c, L, P.seed_list ? P.seed_list[next] : P.seed0 + next);
             have = true;
         }
         // One iteration = one pass of the block_on loop body (task/mod.rs:239-259):
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
         //           and advance_to_next_event, firing again — the ONLY place timers fire.
         // A lane that polls and then runs dry fires its next timer in the same pass, so in steady state
         // every lane does one poll and one timer fire per iteration and the wave stays in phase.
-#if defined(EXP_PROF) || defined(EXP_PROF2)
+#ifdef MADSIM_K_PROF
         prof_iters++;
 #endif
         uint64_t now = L.clock;
@@ -225,10 +225,13 @@ __global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
             P.out[next] = r;
             if (K::TRACE) *P.trace_len = L.log_len;
             have = false;
-            next += P.total_lanes;
+            // next unit: static striding, or the per-launch work queue (a lane whose seeds end early — deadlocks under
+            // packet loss — then keeps pulling work instead of idling behind the slowest lane of its stride)
+            if (P.work_ctr) next = P.total_lanes + atomicAdd(P.work_ctr, 1ull);
+            else next += P.total_lanes;
         }
     }
-#if defined(EXP_PROF) || defined(EXP_PROF2)
+#ifdef MADSIM_K_PROF
     PROBE2(0);
     if (lane == 0 && P.prof) { for (int i = 0; i < 12; i++) atomicAdd((unsigned long long*)&P.prof[i], (unsigned long long)L.prof_acc[i]); atomicAdd((unsigned long long*)&P.prof[12], (unsigned long long)prof_iters); atomicAdd((unsigned long long*)&P.prof[13], 1ull); }
 #endif
@@ -291,7 +294,7 @@ extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, u
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(...) hipLaunchKernelGGL((sim_kernel<Variant<__VA_ARGS__>>), dim3(grid), dim3(64 * P->waves_per_block), lds_bytes, st, *P)
     if (trace) LAUNCH(true, true, -1, true);
-#ifndef EXP_NO_LWS_VARIANTS
+#ifndef MADSIM_K_NO_LWS_VARIANTS
     else if (P->lw_shift == 5) LAUNCH(false, true, 5, true);     // sub-wave occupancy (large per-seed state): the lane
     else if (P->lw_shift == 4) LAUNCH(false, true, 4, true);     // stride stays a compile-time shift
     else if (P->lw_shift == 3) LAUNCH(false, true, 3, true);

@@ -53,19 +53,20 @@ def reduce_report_device(summary4, group=None):
 
 
 def gather_report_device(summary4, gathered, group=None):
-    """The single-collective form: one RCCL all-gather of the 32-byte report into `gathered` (int64[world, 4], same
-    device), no host synchronisation.  `combine_gathered` folds the rows later, on the host or on the device."""
+    """The single-collective form: one RCCL all-gather of the per-rank report row into `gathered` (int64[world, W], same
+    device; W >= 4 — words 0-3 are the library's report, further words are the caller's, e.g. bench.py's rank and device
+    identity), no host synchronisation.  `combine_gathered` folds the rows later, on the host or on the device."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_gather_into_tensor(gathered.view(-1), summary4, group=group)
     else:
-        gathered.view(-1)[:4].copy_(summary4)
+        gathered.view(-1)[:summary4.numel()].copy_(summary4)
     return gathered
 
 
 def combine_gathered(gathered):
-    """int64[..., world, 4] of gather_report_device -> (first failing seed key, n_failed, total_steps, total_clock_ns)
+    """int64[..., world, W >= 4] of gather_report_device -> (first failing seed key, n_failed, total_steps, total_clock_ns)
     reduced over the world axis: signed MIN of the keys (= unsigned minimum of the seeds), SUM of the counters."""
-    return torch.cat([gathered[..., 0].min(dim=-1, keepdim=True).values, gathered[..., 1:].sum(dim=-2)], dim=-1)
+    return torch.cat([gathered[..., 0].min(dim=-1, keepdim=True).values, gathered[..., 1:4].sum(dim=-2)], dim=-1)
 
 
 def decode_first_fail(key):

@@ -28,6 +28,16 @@ class MadsimHipError(RuntimeError):
     pass
 
 
+class RunnerLimitExceeded(MadsimHipError):
+    """A seed still carries a RUNNER verdict (device capacity / step cap) after every re-run round.  Neither exists in
+    the reference (unbounded containers, no step cap), so this is NOT a test failure and carries no
+    MADSIM_TEST_SEED reproduction note: raise the limits (madsim_limits_t) instead."""
+
+    def __init__(self, seed, verdict, result):
+        self.seed, self.verdict, self.result = seed, verdict, result
+        super().__init__(f"seed {seed}: {A.VERDICT_NAMES[verdict]} persists after re-runs with larger limits")
+
+
 class SimulationFailure(AssertionError):
     """A seed failed (the reference panics here; cargo test would report the test as failed)."""
 
@@ -77,6 +87,21 @@ def lib():
         L.madsim_workload_pingpong.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(A.Node), C.POINTER(A.Prog),
                                                C.POINTER(A.Sock), C.POINTER(A.Insn), C.c_uint32,
                                                C.POINTER(A.Workload)]
+        ctxp = C.c_void_p
+        L.madsim_hip_ctx_create.argtypes = [C.c_int, C.POINTER(ctxp)]
+        L.madsim_hip_ctx_destroy.argtypes = [ctxp]
+        L.madsim_hip_ctx_device.argtypes = [ctxp]
+        L.madsim_hip_default_ctx.restype = ctxp
+        L.madsim_hip_ctx_run_batch.argtypes = [ctxp] + L.madsim_hip_run_batch.argtypes
+        L.madsim_hip_ctx_run_batch_auto.argtypes = [ctxp] + L.madsim_hip_run_batch_auto.argtypes
+        L.madsim_hip_ctx_run_batch_device.argtypes = [ctxp] + L.madsim_hip_run_batch_device.argtypes
+        L.madsim_hip_ctx_run_batch_async.argtypes = [ctxp] + L.madsim_hip_run_batch_async.argtypes
+        L.madsim_hip_ctx_timing_ms.argtypes = [ctxp] + L.madsim_hip_timing_ms.argtypes
+        L.madsim_hip_ctx_trace_seed.restype = C.c_int64
+        L.madsim_hip_ctx_trace_seed.argtypes = [ctxp] + L.madsim_hip_trace_seed.argtypes
+        L.madsim_hip_run_batch_multi.argtypes = [C.POINTER(ctxp), C.c_int, C.POINTER(A.Workload), C.POINTER(A.Config),
+                                                 C.c_uint64, C.c_uint64, C.POINTER(A.Limits), C.c_void_p,
+                                                 C.POINTER(A.Summary), C.c_int]
         if L.madsim_hip_version() != A.ABI_VERSION:
             raise MadsimHipError("libmadsim_hip.so ABI version mismatch")
         _lib = L
@@ -135,9 +160,9 @@ def grow_limits(lim):
 
 
 def run_batch_auto(workload, seed0, count, config=None, limits=None, max_rounds=5):
-    """madsim_hip_run_batch_auto: run_batch, then only the seeds that exceeded a device capacity are run again with
-    doubled capacities until none is left (the reference's containers are unbounded; a capacity verdict is never a
-    final answer)."""
+    """madsim_hip_run_batch_auto: run_batch, then the seeds that came back with a runner verdict (a device capacity, the
+    step cap) are run again — all of them in one compacted launch per round — with doubled capacities / a 16x step cap
+    (the reference's containers are unbounded and it has no step cap; neither verdict is ever a final answer)."""
     if _inited_device is None:
         init(0)
     cfg = config or A.Config.default()
@@ -174,6 +199,51 @@ def run_batch_async(workload, seed0, count, d_out_ptr, d_summary_ptr=0, stream_p
                                             timing_slot))
 
 
+class Context:
+    """madsim_hip_ctx_t: the runner's state on ONE GPU.  A process may hold several (one per GPU); calls on one
+    context are serialised by the library, distinct contexts share nothing."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().madsim_hip_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().madsim_hip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def run_batch(self, workload, seed0, count, config=None, limits=None, auto_rounds=0):
+        cfg, lim = config or A.Config.default(), limits or A.Limits()
+        out = np.zeros(count, dtype=A.RESULT_DTYPE)
+        summ = A.Summary()
+        if auto_rounds:
+            _check(lib().madsim_hip_ctx_run_batch_auto(self._h, workload.ref(), C.byref(cfg), seed0, count, C.byref(lim),
+                                                       out.ctypes.data_as(C.c_void_p), C.byref(summ), auto_rounds))
+        else:
+            _check(lib().madsim_hip_ctx_run_batch(self._h, workload.ref(), C.byref(cfg), seed0, count, C.byref(lim),
+                                                  out.ctypes.data_as(C.c_void_p), C.byref(summ)))
+        return out, summ
+
+
+def run_batch_multi(contexts, workload, seed0, count, config=None, limits=None, max_rounds=5):
+    """madsim_hip_run_batch_multi: one process, one host thread, the seed range sharded contiguously over `contexts`
+    (all devices' kernels in flight together), runner verdicts re-run compacted, reports folded on the host."""
+    cfg, lim = config or A.Config.default(), limits or A.Limits()
+    out = np.zeros(count, dtype=A.RESULT_DTYPE)
+    summ = A.Summary()
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _check(lib().madsim_hip_run_batch_multi(arr, len(contexts), workload.ref(), C.byref(cfg), seed0, count, C.byref(lim),
+                                            out.ctypes.data_as(C.c_void_p), C.byref(summ), max_rounds))
+    return out, summ
+
+
 def timing_ms(slot):
     ms = C.c_double(0.0)
     _check(lib().madsim_hip_timing_ms(slot, C.byref(ms)))
@@ -199,11 +269,31 @@ def geometry(workload, limits=None):
     return g
 
 
+def variant_name(g):
+    """The sim_kernel specialisation a madsim_geometry_t selects (madsim_k_launch_sim's dispatch), as rocprofv3 names it."""
+    b = lambda x: "true" if x else "false"
+    if g.variant & 8:
+        return f"sim_kernel<Variant<false,true,{g.lanes_per_wave.bit_length() - 1},true,false>>"
+    return f"sim_kernel<Variant<false,{b(g.variant & 1)},6,{b(g.variant & 2)},{b(g.variant & 4)}>>"
+
+
 class Builder:
     """madsim::runtime::Builder (runtime/builder.rs:7-22) over the GPU batch runner."""
 
+    DEFAULT_MAX_STEPS = 1 << 24     # device safety net of the first pass (not a reference concept): seeds that reach it
+                                    # are re-run with a 16x cap per round up to u32::MAX, never reported as failures
+
     def __init__(self, seed=0, count=1, jobs=1, config=None, time_limit=None, check=False,
                  allow_system_thread=False):
+        # Rust's types: seed u64, count u64, jobs u16 (builder.rs:7-22); `seed + i` must not wrap (builder.rs:129)
+        if not (0 <= seed <= A.U64_MAX):
+            raise ValueError("seed must fit u64")
+        if not (0 <= count <= A.U64_MAX) or seed + count > A.U64_MAX + 1:
+            raise ValueError("count must fit u64 and seed + count must not exceed 2^64")
+        if not (0 <= jobs <= 0xFFFF):
+            raise ValueError("jobs must fit u16")
+        if time_limit is not None and not (time_limit >= 0):
+            raise ValueError("time_limit must be a non-negative number of seconds")
         self.seed, self.count, self.jobs = seed, count, jobs
         self.config = config or A.Config.default()
         self.time_limit = time_limit          # seconds (float) or None
@@ -225,11 +315,17 @@ class Builder:
             jobs = int(env.get("MADSIM_TEST_JOBS", "1"))
         except ValueError:
             raise ValueError("MADSIM_TEST_JOBS should be an integer")
+        if not (0 <= seed <= A.U64_MAX):                   # `.parse::<u64>()` (builder.rs:66-69)
+            raise ValueError("MADSIM_TEST_SEED should be an integer")
+        if not (0 <= jobs <= 0xFFFF):                      # `.parse::<u16>()` (builder.rs:75-78)
+            raise ValueError("MADSIM_TEST_JOBS should be an integer")
         config = _parse_config(open(env["MADSIM_TEST_CONFIG"]).read()) if "MADSIM_TEST_CONFIG" in env \
             else A.Config.default()
         try:
             count = int(env.get("MADSIM_TEST_NUM", "1"))
         except ValueError:
+            raise ValueError("MADSIM_TEST_NUM should be an integer")
+        if not (0 <= count <= A.U64_MAX):
             raise ValueError("MADSIM_TEST_NUM should be an integer")
         time_limit = None
         if "MADSIM_TEST_TIME_LIMIT" in env:
@@ -245,7 +341,9 @@ class Builder:
     def limits(self):
         lim = A.Limits()
         if self.time_limit is not None:
-            lim.time_limit_ns = int(round(self.time_limit * 1e9))
+            # time_limit_ns == 0 means None in the C-ABI; Some(Duration::ZERO) panics at the first idle advance
+            # (task/mod.rs:253-258: `elapsed >= limit`), which a 1 ns limit reproduces exactly
+            lim.time_limit_ns = max(1, int(round(self.time_limit * 1e9)))
         return lim
 
     def run(self, workload):
@@ -258,16 +356,20 @@ class Builder:
             return self.check_determinism(workload)
         out, summ = run_batch_auto(workload, self.seed, self.count, self.config, self.limits())
         if summ.n_failed:
-            seed = summ.first_failing_seed
-            r = out[seed - self.seed]
+            bad = np.nonzero(out["verdict"] != A.PASS)[0]
+            i = int(bad[0])
+            seed, r = self.seed + i, out[i]
+            if int(r["verdict"]) in (A.OVERFLOW, A.STEP_LIMIT):      # the runner's limits, not the test's verdict
+                raise RunnerLimitExceeded(seed, int(r["verdict"]), r)
             panic_with_info(seed)
             raise SimulationFailure(seed, int(r["verdict"]), r)
         return out
 
     def check_determinism(self, workload):
         """Runtime::check_determinism (runtime/mod.rs:178-202): run the seed twice, compare the RNG log."""
-        log1, r1 = trace_seed(workload, self.seed, self.config, self.limits())
-        log2, r2 = trace_seed(workload, self.seed, self.config, self.limits())
+        # check_determinism builds its Runtimes without a time limit (runtime/mod.rs:178-202 never calls set_time_limit)
+        log1, r1 = trace_seed(workload, self.seed, self.config, None)
+        log2, r2 = trace_seed(workload, self.seed, self.config, None)
         if log1 != log2 or r1.astuple() != r2.astuple():
             panic_with_info(self.seed)
             raise SimulationFailure(self.seed, A.PANIC, r2)       # "non-determinism detected"

@@ -571,3 +571,37 @@ def timer_storm_limits(lds_slots=4):
     lim = A.Limits()
     lim.heap_lds_slots, lim.heap_spill_slots = lds_slots, 64
     return lim
+
+
+# ---- the workloads bench.py times: ONE definition, shared with the -m gpu parity tests ---------------------------------
+BENCH_SEEDS_PER_GPU = 65536
+BENCH_NODES, BENCH_ROUNDS = 4, 64
+BENCH_WORKLOADS = ("pingpong", "raft", "kv", "timers", "topo")
+
+
+def pingpong_bench_limits(heap_lds=4):
+    """Tight capacities of the 4-node ping-pong (high-water marks on the oracle: 4 timers, 1 pending recv per socket,
+    never a queued message).  Exceeding one shows up as verdict MADSIM_OVERFLOW, never as a different answer."""
+    lim = A.Limits()
+    lim.heap_lds_slots, lim.heap_spill_slots = heap_lds, 4 - heap_lds
+    lim.mbox_regs, lim.mbox_msgs = 1, A.LIMIT_NONE
+    return lim
+
+
+def bench_case(name="pingpong", nodes=BENCH_NODES, rounds=BENCH_ROUNDS, heap_lds=4):
+    """(workload, limits, description) exactly as bench.py runs `--workload name`; tests/test_gpu_parity.py oracle-checks
+    these same objects, so the configuration behind the headline number is the configuration that is verified."""
+    if name == "pingpong":
+        return (pingpong(nodes, rounds), pingpong_bench_limits(heap_lds),
+                f"{nodes}-node ping-pong, R={rounds}, Config::default()")
+    if name == "raft":
+        return raft_election(), raft_election_limits(), "5-node election loop with partition injection (configs[2] shape)"
+    if name == "timers":
+        return (timer_storm(), timer_storm_limits(heap_lds),
+                f"timer storm: 24 tasks x sleep(gen_range(0..2 s)), heap_lds={heap_lds} (HBM heap-spill path)")
+    if name == "topo":
+        return (streaming_topology(), streaming_topology_limits(),
+                "16-node streaming topology: KV meta + typed-RPC brokers + 12 compute nodes (configs[4] shape)")
+    if name == "kv":
+        return kv_rpc(), kv_rpc_limits(), "etcd-style KV ops over connect1/accept1 (configs[3] shape)"
+    raise ValueError(f"unknown bench workload {name!r}")

@@ -1164,3 +1164,10 @@ uint64_t madsim_oracle_gen_range(uint64_t s[4], uint64_t lo, uint64_t hi, uint64
     if (ncalls) *ncalls = n;
     return res;
 }
+
+/* The CPU twin SURVEY.md §8b asks for: the identical signature of madsim_hip_run_batch (include/madsim_hip.h), so a
+ * host can swap one symbol for the other.  Test infrastructure like the rest of this file. */
+int madsim_cpu_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                         const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary) {
+    return madsim_oracle_run_batch(w, cfg, seed0, count, lim, out, summary, NULL);
+}

@@ -26,6 +26,10 @@ int madsim_oracle_run_batch(const madsim_workload_t* w, const madsim_config_t* c
                             uint64_t count, const madsim_limits_t* lim, madsim_result_t* out,
                             madsim_summary_t* summary, madsim_oracle_stats_t* stats);
 
+/* CPU twin of madsim_hip_run_batch with the identical signature. */
+int madsim_cpu_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                         const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary);
+
 int64_t madsim_oracle_trace_seed(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
                                  const madsim_limits_t* lim, uint8_t* log, uint64_t cap,
                                  madsim_result_t* out);

@@ -21,6 +21,7 @@ extern thread_local uint32_t* emu_smem;
 #define __launch_bounds__(...)
 #define __restrict__
 static inline void __syncthreads() {}
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }   // emulated threads run one after another
 static inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 #ifdef MADSIM_EMU_REGIONS   // tools/divergence_model.py: per-iteration code-region visit counts of each emulated lane
 void emu_region(int id);

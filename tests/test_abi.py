@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(A.Insn) == 8 and C.sizeof(A.Result) == 48 and C.sizeof(A.Summary) == 48
-    assert C.sizeof(A.Limits) == 48 and C.sizeof(A.Geometry) == 40
+    assert C.sizeof(A.Limits) == 56 and C.sizeof(A.Geometry) == 40
     assert A.Result.clock_ns.offset == 8 and A.Result.trace_hash.offset == 32 and A.Result.obs_hash.offset == 40
     for name, val in A.OP.items():
         m = re.search(r"MS_OP_%s = (\d+)," % name, HEADER)
@@ -100,3 +100,51 @@ def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu():
         pytest.skip("a GPU is present; the run itself is covered by the gpu test")
     p = subprocess.run([exe], env=dict(os.environ, MADSIM_TEST_SEED="1", MADSIM_TEST_NUM="4"), capture_output=True, text=True)
     assert p.returncode == 2 and "no CPU fallback" in p.stderr
+
+
+def test_oracle_exports_the_cpu_twin_with_the_product_signature():
+    """madsim_cpu_run_batch(...) with the identical signature of madsim_hip_run_batch."""
+    import numpy as np
+    import oracle
+    L = oracle.lib()
+    L.madsim_cpu_run_batch.argtypes = runtime.lib().madsim_hip_run_batch.argtypes
+    w = workload.pingpong(2, 4)
+    cfg, lim, summ = A.Config.default(), A.Limits(), A.Summary()
+    out = np.zeros(16, dtype=A.RESULT_DTYPE)
+    assert L.madsim_cpu_run_batch(w.ref(), C.byref(cfg), 3, 16, C.byref(lim), out.ctypes.data_as(C.c_void_p), C.byref(summ)) == 0
+    want, osm = oracle.run_batch(w, 3, 16)
+    assert (out == want).all() and summ.total_steps == osm.total_steps
+
+
+def test_builder_rejects_what_rust_types_reject():
+    """Builder fields are u64 / u64 / u16 (builder.rs:7-22); seed + i must not wrap (builder.rs:129)."""
+    with pytest.raises(ValueError):
+        runtime.Builder(seed=-1)
+    with pytest.raises(ValueError):
+        runtime.Builder(seed=2**64)
+    with pytest.raises(ValueError):
+        runtime.Builder(seed=2**64 - 2, count=3)
+    runtime.Builder(seed=2**64 - 2, count=2)
+    with pytest.raises(ValueError):
+        runtime.Builder(jobs=70000)
+    with pytest.raises(ValueError, match="MADSIM_TEST_SEED"):
+        runtime.Builder.from_env({"MADSIM_TEST_SEED": "-5"})
+    with pytest.raises(ValueError, match="MADSIM_TEST_JOBS"):
+        runtime.Builder.from_env({"MADSIM_TEST_JOBS": "65536"})
+    # Some(Duration::ZERO) is a limit (panics at the first idle advance), not "no limit"
+    assert runtime.Builder(time_limit=0.0).limits().time_limit_ns == 1
+    assert runtime.Builder().limits().time_limit_ns == 0
+
+
+def test_context_api_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(runtime.MadsimHipError, match="no CPU fallback"):
+        runtime.Context(0)
+    L = runtime.lib()
+    assert L.madsim_hip_default_ctx() is None
+    cfg, lim, summ = A.Config.default(), A.Limits(), A.Summary()
+    w = workload.pingpong(2, 1)
+    arr = (C.c_void_p * 1)(None)
+    assert L.madsim_hip_run_batch_multi(arr, 1, w.ref(), C.byref(cfg), 0, 0, C.byref(lim), None, C.byref(summ), 1) == -3

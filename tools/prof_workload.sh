@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 kernel-trace stats + the PMC passes that give instruction counts, VALU lane utilisation and wait fractions
+# for one bench workload (run on the GPU box).  Usage: prof_workload.sh <outdir under gpurun_out> "<bench args>" [full]
+# PMC passes are separate runs with --kernel-trace only (never combined with sys/hip traces).
+set -u
+cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; mkdir -p $OUT
+CMD="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-verify --no-first-fail ${2:-}"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+SETS=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"
+      "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU")
+if [ "${3:-}" = "full" ]; then
+  SETS+=("SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE")
+fi
+i=0
+for set in "${SETS[@]}"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -o p -- $CMD > $OUT/pmc$i.log 2>&1
+done
+python $R/tools/prof_summary.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
