@@ -47,6 +47,9 @@ def lib():
         L.madsim_oracle_trace_seed.restype = C.c_int64
         L.madsim_oracle_trace_seed.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64,
                                                C.POINTER(A.Limits), C.c_void_p, C.c_uint64, C.POINTER(A.Result)]
+        L.madsim_oracle_observe_seed.restype = C.c_int64
+        L.madsim_oracle_observe_seed.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64,
+                                                 C.POINTER(A.Limits), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(A.Result)]
         L.oracle_seed_from_u64.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
         L.oracle_xoshiro_next.restype = C.c_uint64
         L.oracle_xoshiro_next.argtypes = [C.POINTER(C.c_uint64)]
@@ -83,3 +86,15 @@ def trace_seed(workload, seed, config=None, limits=None, cap=1 << 20):
     if n < 0:
         raise RuntimeError(f"oracle error {n}")
     return bytes(buf[:min(n, cap)]), res
+
+
+def observe_seed(workload, seed, config=None, limits=None, cap=1 << 16):
+    """(list of observed values in execution order — what obs_hash folds —, Result) of one seed."""
+    cfg = config or A.Config.default()
+    lim = limits or A.Limits()
+    buf = (C.c_uint64 * cap)()
+    res = A.Result()
+    n = lib().madsim_oracle_observe_seed(workload.ref(), C.byref(cfg), seed, C.byref(lim), buf, cap, C.byref(res))
+    if n < 0:
+        raise RuntimeError(f"oracle error {n}")
+    return [int(v) for v in buf[:min(n, cap)]], res

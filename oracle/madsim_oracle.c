@@ -45,6 +45,11 @@
 /* ------------------------------------------------------------------------------------------------
  * GlobalRng                                                           rand.rs:27-61, [DEP] A.1
  * ---------------------------------------------------------------------------------------------- */
+/* Optional sink for the values a workload makes observable (MS_OP_TRACE / MS_OP_TRACE_TIME), in execution order:
+ * what obs_hash folds.  Used by tools/ref_twin/compare.py to diff lists against real madsim's output. */
+static __thread uint64_t* g_obs_buf; static __thread uint64_t g_obs_cap, g_obs_len;
+static void obs_record(uint64_t v) { if (g_obs_buf && g_obs_len < g_obs_cap) g_obs_buf[g_obs_len] = v; g_obs_len++; }
+
 typedef struct { uint64_t s[4]; } xoshiro_t;
 
 static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
@@ -625,7 +630,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
             break;
         case MS_OP_TRACE: {
             uint64_t v = in->imm + ((in->b & 1) ? t->cnt[in->a & 1] : 0);
-            S->obs_hash = (S->obs_hash ^ v) * FNV_PRIME; t->pc++;
+            obs_record(v); S->obs_hash = (S->obs_hash ^ v) * FNV_PRIME; t->pc++;
             break;
         }
         case MS_OP_SLEEP:
@@ -953,7 +958,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
         }
         case MS_OP_TRACE_TIME: {                           /* SystemTime::now() / Instant::now() (time/system_time.rs) */
             uint64_t v = in->a == 0 ? S->base_time_ns + S->clock : in->a == 1 ? S->clock : t->val;
-            S->obs_hash = (S->obs_hash ^ v) * FNV_PRIME; t->pc++;
+            obs_record(v); S->obs_hash = (S->obs_hash ^ v) * FNV_PRIME; t->pc++;
             break;
         }
         case MS_OP_RAND_BOOL: {                            /* thread_rng().gen_bool(p): Bernoulli on the GlobalRng [DEP A.4] */
@@ -1170,4 +1175,16 @@ uint64_t madsim_oracle_gen_range(uint64_t s[4], uint64_t lo, uint64_t hi, uint64
 int madsim_cpu_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
                          const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary) {
     return madsim_oracle_run_batch(w, cfg, seed0, count, lim, out, summary, NULL);
+}
+
+/* One seed with its observed-value list (see obs_record).  Returns the number of observations (may exceed cap). */
+int64_t madsim_oracle_observe_seed(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
+                                   const madsim_limits_t* lim, uint64_t* obs, uint64_t cap, madsim_result_t* out) {
+    if (!cfg || validate(w, cfg)) return MADSIM_E_ARG;
+    madsim_result_t r;
+    g_obs_buf = obs; g_obs_cap = cap; g_obs_len = 0;
+    run_one(w, cfg, lim, seed, &r, NULL, 0, NULL, NULL);
+    g_obs_buf = NULL;
+    if (out) *out = r;
+    return (int64_t)g_obs_len;
 }

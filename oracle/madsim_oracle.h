@@ -34,6 +34,10 @@ int64_t madsim_oracle_trace_seed(const madsim_workload_t* w, const madsim_config
                                  const madsim_limits_t* lim, uint8_t* log, uint64_t cap,
                                  madsim_result_t* out);
 
+/* One seed plus the list of values it made observable (MS_OP_TRACE / MS_OP_TRACE_TIME, what obs_hash folds). */
+int64_t madsim_oracle_observe_seed(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
+                                   const madsim_limits_t* lim, uint64_t* obs, uint64_t cap, madsim_result_t* out);
+
 /* Building blocks exposed for the known-answer tests. */
 void     oracle_seed_from_u64(uint64_t seed, uint64_t s[4]);
 uint64_t oracle_xoshiro_next(uint64_t s[4]);

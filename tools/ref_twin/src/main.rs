@@ -1,0 +1,286 @@
+//! madsim-ref-twin — the reference side of the oracle pin.
+//!
+//! Runs REAL madsim on the workloads of SURVEY.md §8d (and the repo's golden / lifecycle workloads) and prints one JSON
+//! line per seed.  Everything printed is observable through madsim's public API:
+//!   * `elapsed_ns`  — `madsim::time::Instant` elapsed since the first poll of the main future (clock 0),
+//!   * `msg_count`   — `NetSim::current().stat().msg_count`            (net/mod.rs:133-135, network.rs:99-105,265),
+//!   * `obs`         — every value the workload made observable, in execution order (the repo's MS_OP_TRACE /
+//!                     MS_OP_TRACE_TIME), ending with ONE trailing `madsim::rand::random::<u32>()` — a draw whose value
+//!                     depends on every RNG call before it, so it pins the draw count and the generator state,
+//!   * `verdict`     — pass / panic / deadlock / time-limit, from the panic message of `block_on` (task/mod.rs:250-258).
+//! With `--features rng-log` (madsim patched with patches/expose_rng_log.patch) `log_hex` carries the raw determinism
+//! log of rand.rs:64-88 for byte-level diffs against `madsim_hip_trace_seed` / the oracle.
+//!
+//! Each workload below is the Rust original of a table in tools/ref_twin/twin_workloads.py (same name); compare.py
+//! runs the oracle on those tables and diffs the two JSONL streams.
+//!
+//! Build (outside this image — it has no rustc):  RUSTFLAGS="--cfg madsim" cargo run --release -- <workload|all> <seed0> <count> [loss]
+
+use madsim::net::{Endpoint, NetSim};
+use madsim::runtime::{Handle, Runtime};
+use madsim::time::{self, Duration, Instant};
+use std::net::SocketAddr;
+use std::panic::{catch_unwind, AssertUnwindSafe};
+use std::sync::atomic::{AtomicUsize, Ordering};
+use std::sync::{Arc, Mutex};
+
+/// Values a workload makes observable, in execution order (the repo folds the same values into `obs_hash`).
+#[derive(Clone, Default)]
+struct Obs(Arc<Mutex<Vec<u64>>>);
+impl Obs {
+    fn push(&self, v: u64) { self.0.lock().unwrap().push(v); }
+    fn take(&self) -> Vec<u64> { std::mem::take(&mut *self.0.lock().unwrap()) }
+}
+
+struct Tail { elapsed_ns: u64, msg_count: u64 }
+
+/// The fingerprint tail every twin's main future ends with:
+/// repo side = `trace_instant(); random_u32(); trace_val()` (tools/ref_twin/twin_workloads.py::fingerprint_tail).
+fn fingerprint_tail(t0: Instant, obs: &Obs) -> Tail {
+    let elapsed_ns = t0.elapsed().as_nanos() as u64;
+    obs.push(elapsed_ns);                                   // MS_OP_TRACE_TIME a=1
+    let msg_count = NetSim::current().stat().msg_count;
+    let r: u32 = madsim::rand::random();                    // MS_OP_RANDOM a=0: one GlobalRng::with, next_u32
+    obs.push(r as u64);                                     // MS_OP_TRACE_TIME a=2
+    Tail { elapsed_ns, msg_count }
+}
+
+fn addr(node: usize, port: u16) -> SocketAddr { format!("10.0.0.{node}:{port}").parse().unwrap() }
+
+const PING: &[u8; 4] = b"ping";
+const PONG: &[u8; 4] = b"pong";
+
+/// N nodes 10.0.0.i, pairs (1,2),(3,4)..; pinger = bind, sleep(1 s), R x {send ping, recv pong};
+/// ponger = bind, R x {recv ping, send pong to `from`}; main spawns in node order and awaits the handles in order.
+async fn pingpong(n_nodes: usize, rounds: usize, obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let mut handles = vec![];
+    for i in 1..=n_nodes {
+        let node = h.create_node().ip(addr(i, 1).ip()).build();
+        let me = addr(i, 1);
+        if i % 2 == 1 {
+            let peer = addr(i + 1, 1);
+            handles.push(node.spawn(async move {
+                let ep = Endpoint::bind(me).await.unwrap();
+                time::sleep(Duration::from_secs(1)).await;
+                let mut buf = [0u8; 16];
+                for _ in 0..rounds {
+                    ep.send_to(peer, 1, PING).await.unwrap();
+                    let (len, _from) = ep.recv_from(1, &mut buf).await.unwrap();
+                    assert_eq!(&buf[..len], PONG);
+                }
+            }));
+        } else {
+            handles.push(node.spawn(async move {
+                let ep = Endpoint::bind(me).await.unwrap();
+                let mut buf = [0u8; 16];
+                for _ in 0..rounds {
+                    let (len, from) = ep.recv_from(1, &mut buf).await.unwrap();
+                    assert_eq!(&buf[..len], PING);
+                    ep.send_to(from, 1, PONG).await.unwrap();
+                }
+            }));
+        }
+    }
+    for jh in handles { jh.await.unwrap(); }
+    fingerprint_tail(t0, &obs)
+}
+
+/// SURVEY Appendix B minimal trace: `block_on(sleep(1 s))` (+ the tail).
+async fn sleep_1s(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    time::sleep(Duration::from_secs(1)).await;
+    fingerprint_tail(t0, &obs)
+}
+
+/// task/mod.rs:1018-1041 with sequential awaits: 3 tasks x 5 x { observe(i*10 + remaining); yield_now() }.
+/// (The repo's loop counter counts DOWN: the observed value is i*10 + (5 - j), j = 0..5.)
+async fn yield_order(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let mut tasks = vec![];
+    for i in 0..3u64 {
+        let obs = obs.clone();
+        tasks.push(madsim::task::spawn(async move {
+            for j in 0..5u64 {
+                obs.push(i * 10 + (5 - j));
+                tokio::task::yield_now().await;
+            }
+        }));
+    }
+    for t in tasks { t.await.unwrap(); }
+    fingerprint_tail(t0, &obs)
+}
+
+/// Equal-deadline timers: 6 tasks all `sleep(10 ms)` from the same instant, each observing its index when it wakes —
+/// pins the BinaryHeap tie order of naive-timer and the ready-queue draw together.
+async fn timer_ties(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let mut tasks = vec![];
+    for i in 0..6u64 {
+        let obs = obs.clone();
+        tasks.push(madsim::task::spawn(async move {
+            for k in 0..3u64 {
+                time::sleep(Duration::from_millis(10)).await;
+                obs.push(i * 100 + k);
+            }
+        }));
+    }
+    for t in tasks { t.await.unwrap(); }
+    fingerprint_tail(t0, &obs)
+}
+
+/// task/mod.rs:859-897 `kill`.
+async fn lifecycle_kill(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let node1 = h.create_node().build();
+    let node2 = h.create_node().build();
+    let (flag1, flag2) = (Arc::new(AtomicUsize::new(0)), Arc::new(AtomicUsize::new(0)));
+    let f = flag1.clone();
+    node1.spawn(async move { loop { time::sleep(Duration::from_secs(2)).await; f.fetch_add(2, Ordering::Relaxed); } });
+    let f = flag2.clone();
+    node2.spawn(async move { loop { time::sleep(Duration::from_secs(2)).await; f.fetch_add(2, Ordering::Relaxed); } });
+    time::sleep_until(t0 + Duration::from_secs(3)).await;
+    assert_eq!(flag1.load(Ordering::Relaxed), 2);
+    assert_eq!(flag2.load(Ordering::Relaxed), 2);
+    h.kill(node1.id());
+    h.kill(node1.id());
+    assert!(h.is_exit(node1.id()));
+    time::sleep_until(t0 + Duration::from_secs(5)).await;
+    assert_eq!(flag1.load(Ordering::Relaxed), 2);
+    assert_eq!(flag2.load(Ordering::Relaxed), 4);
+    fingerprint_tail(t0, &obs)
+}
+
+/// task/mod.rs:899-936 `restart` (an init task; kill + restart; the flag restarts from 0).
+async fn lifecycle_restart(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let flag = Arc::new(AtomicUsize::new(0));
+    let flag_ = flag.clone();
+    let node = h.create_node().init(move || {
+        let flag = flag_.clone();
+        async move {
+            flag.store(0, Ordering::Relaxed);
+            loop { time::sleep(Duration::from_secs(2)).await; flag.fetch_add(2, Ordering::Relaxed); }
+        }
+    }).build();
+    time::sleep_until(t0 + Duration::from_secs(3)).await;
+    assert_eq!(flag.load(Ordering::Relaxed), 2);
+    h.kill(node.id());
+    h.restart(node.id());
+    assert!(!h.is_exit(node.id()));
+    time::sleep_until(t0 + Duration::from_secs(6)).await;
+    assert_eq!(flag.load(Ordering::Relaxed), 2);
+    time::sleep_until(t0 + Duration::from_secs(8)).await;
+    assert_eq!(flag.load(Ordering::Relaxed), 4);
+    fingerprint_tail(t0, &obs)
+}
+
+/// task/mod.rs:938-962 `restart_on_panic`: three panics, restart delays drawn from 1..10 s (UniformDuration, Medium path).
+async fn lifecycle_restart_on_panic(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let flag = Arc::new(AtomicUsize::new(0));
+    let flag_ = flag.clone();
+    h.create_node().init(move || {
+        let flag = flag_.clone();
+        async move { if flag.fetch_add(1, Ordering::Relaxed) < 3 { panic!(); } }
+    }).restart_on_panic().build();
+    time::sleep(Duration::from_secs(60)).await;
+    assert_eq!(flag.load(Ordering::Relaxed), 4);
+    fingerprint_tail(t0, &obs)
+}
+
+/// net/endpoint.rs:409-443 `receiver_drop` without the Barrier (whose wake order would add another dependency):
+/// the sender waits 2 s instead, the receiver times out after 1 s, sleeps 2 s, and receives again.
+async fn receiver_drop(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let (a1, a2) = (addr(1, 1), addr(2, 1));
+    let node1 = h.create_node().ip(a1.ip()).build();
+    let node2 = h.create_node().ip(a2.ip()).build();
+    let s = node1.spawn(async move {
+        let ep = Endpoint::bind(a1).await.unwrap();
+        time::sleep(Duration::from_secs(2)).await;
+        ep.send_to(a2, 1, &[1]).await.unwrap();
+    });
+    let r = node2.spawn(async move {
+        let ep = Endpoint::bind(a2).await.unwrap();
+        let mut buf = vec![0; 0x10];
+        time::timeout(Duration::from_secs(1), ep.recv_from(1, &mut buf)).await.err().unwrap();
+        let (len, from) = ep.recv_from(1, &mut buf).await.unwrap();
+        assert_eq!((len, from), (1, a1));
+    });
+    s.await.unwrap();
+    r.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
+fn run_one(name: &str, seed: u64, loss: f64) -> String {
+    let mut config = madsim::Config::default();
+    config.net.packet_loss_rate = loss;
+    let obs = Obs::default();
+    let o = obs.clone();
+    let name_owned = name.to_string();
+    let mut log_hex = String::new();
+    let res = catch_unwind(AssertUnwindSafe(|| {
+        let rt = Runtime::with_seed_and_config(seed, config);
+        #[cfg(feature = "rng-log")]
+        rt.rng().enable_log();
+        let tail = rt.block_on(async move {
+            match name_owned.as_str() {
+                "pingpong2" => pingpong(2, 64, o).await,
+                "pingpong4" => pingpong(4, 64, o).await,
+                "pingpong16" => pingpong(16, 8, o).await,
+                "sleep_1s" => sleep_1s(o).await,
+                "yield_order" => yield_order(o).await,
+                "timer_ties" => timer_ties(o).await,
+                "kill" => lifecycle_kill(o).await,
+                "restart" => lifecycle_restart(o).await,
+                "restart_on_panic" => lifecycle_restart_on_panic(o).await,
+                "receiver_drop" => receiver_drop(o).await,
+                other => panic!("unknown workload {other}"),
+            }
+        });
+        #[cfg(feature = "rng-log")]
+        { log_hex = rt.rng().take_log().unwrap().into_bytes().iter().map(|b| format!("{b:02x}")).collect(); }
+        tail
+    }));
+    let obs_list = obs.take().iter().map(|v| v.to_string()).collect::<Vec<_>>().join(",");
+    let log_field = if log_hex.is_empty() { String::new() } else { format!(",\"log_hex\":\"{log_hex}\"") };
+    match res {
+        Ok(t) => format!("{{\"workload\":\"{name}\",\"seed\":{seed},\"loss\":{loss},\"verdict\":\"pass\",\"elapsed_ns\":{},\"msg_count\":{},\"obs\":[{obs_list}]{log_field}}}",
+                         t.elapsed_ns, t.msg_count),
+        Err(e) => {
+            let msg = e.downcast_ref::<String>().cloned().or_else(|| e.downcast_ref::<&str>().map(|s| s.to_string())).unwrap_or_default();
+            let verdict = if msg.contains("all tasks will block forever") { "deadlock" }
+                          else if msg.contains("time limit exceeded") { "time-limit" } else { "panic" };
+            format!("{{\"workload\":\"{name}\",\"seed\":{seed},\"loss\":{loss},\"verdict\":\"{verdict}\",\"elapsed_ns\":null,\"msg_count\":null,\"obs\":[{obs_list}]}}")
+        }
+    }
+}
+
+const ALL: &[&str] = &["pingpong2", "pingpong4", "pingpong16", "sleep_1s", "yield_order", "timer_ties", "kill", "restart",
+                       "restart_on_panic", "receiver_drop"];
+
+fn main() {
+    let args: Vec<String> = std::env::args().collect();
+    if args.len() < 4 {
+        eprintln!("usage: madsim-ref-twin <workload|all> <seed0> <count> [packet_loss_rate]\nworkloads: {}", ALL.join(" "));
+        std::process::exit(2);
+    }
+    let (seed0, count): (u64, u64) = (args[2].parse().unwrap(), args[3].parse().unwrap());
+    let loss: f64 = args.get(4).map(|s| s.parse().unwrap()).unwrap_or(0.0);
+    std::panic::set_hook(Box::new(|_| {}));               // verdicts are data here, not noise on stderr
+    let names: Vec<&str> = if args[1] == "all" { ALL.to_vec() } else { vec![args[1].as_str()] };
+    for name in names {
+        for seed in seed0..seed0 + count {
+            // one OS thread per seed like Builder::run (builder.rs:134): madsim's context is thread-local
+            let n = name.to_string();
+            let line = std::thread::spawn(move || run_one(&n, seed, loss)).join().unwrap();
+            println!("{line}");
+        }
+    }
+}

@@ -1,0 +1,162 @@
+"""The repo-side tables of the workloads tools/ref_twin/src/main.rs runs on REAL madsim (same names, same programs).
+
+Every main task ends with the fingerprint tail  `trace_instant(); random_u32(); trace_val()`  — the table form of
+`fingerprint_tail()` in main.rs: the elapsed time of the main future, then one trailing `random::<u32>()` whose value
+depends on every draw before it.  Test infrastructure (used by compare.py and tests/test_ref_twin.py), not product.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from madsim_amd import _abi as A          # noqa: E402
+from madsim_amd import workload as W      # noqa: E402
+
+FNV_OFFSET, FNV_PRIME, M64 = 14695981039346656037, 1099511628211, (1 << 64) - 1
+VERDICTS = ["pass", "panic", "deadlock", "time-limit", "resource-overflow", "step-limit"]
+
+
+def fold_obs(values):
+    """obs_hash of a madsim_result_t from the list of observed values (MS_OP_TRACE / MS_OP_TRACE_TIME order)."""
+    h = FNV_OFFSET
+    for v in values:
+        h = ((h ^ (v & M64)) * FNV_PRIME) & M64
+    return h
+
+
+def fingerprint_tail(m):
+    m.trace_instant()
+    m.random_u32()
+    m.trace_val()
+    m.done()
+
+
+def pingpong(n_nodes, rounds):
+    wl = W.WorkloadBuilder()
+    nodes = [wl.create_node() for _ in range(n_nodes)]
+    addrs = [wl.addr(n, 1) for n in nodes]
+    tasks = []
+    for i, n in enumerate(nodes):
+        t = wl.task(n)
+        t.bind(addrs[i])
+        if i % 2 == 0:
+            t.sleep(secs=1); t.set(0, rounds); top = t.label()
+            t.send_to(addrs[i], addrs[i + 1], 1, W.PING); t.recv_from(addrs[i], 1); t.assert_val(W.PONG); t.djnz(0, top)
+        else:
+            t.set(0, rounds); top = t.label()
+            t.recv_from(addrs[i], 1); t.assert_val(W.PING); t.reply(addrs[i], 1, W.PONG); t.djnz(0, top)
+        t.done()
+        tasks.append(t)
+    m = wl.main()
+    for t in tasks:
+        m.spawn(t)
+    for t in tasks:
+        m.join(t)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def sleep_1s():
+    wl = W.WorkloadBuilder()
+    m = wl.main(); m.sleep(secs=1)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def yield_order():
+    wl = W.WorkloadBuilder()
+    ts = []
+    for i in range(3):
+        t = wl.task(0); t.set(0, 5); top = t.label(); t.trace(i * 10, add_reg=0); t.yield_now(); t.djnz(0, top); t.done()
+        ts.append(t)
+    m = wl.main()
+    for t in ts:
+        m.spawn(t)
+    for t in ts:
+        m.join(t)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def timer_ties():
+    wl = W.WorkloadBuilder()
+    ts = []
+    for i in range(6):
+        t = wl.task(0)
+        for k in range(3):
+            t.sleep(ms=10); t.trace(i * 100 + k)
+        t.done()
+        ts.append(t)
+    m = wl.main()
+    for t in ts:
+        m.spawn(t)
+    for t in ts:
+        m.join(t)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def _ticker(wl, node, flag, **kw):
+    t = wl.task(node, **kw)
+    top = t.label(); t.sleep(secs=2); t.flag_add(flag, 2); t.jmp(top)
+    return t
+
+
+def kill():
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    t1, t2 = _ticker(wl, n1, 0), _ticker(wl, n2, 1)
+    m = wl.main()
+    m.mark(); m.spawn(t1); m.spawn(t2)
+    m.sleep_until(secs=3); m.assert_flag(0, 2); m.assert_flag(1, 2)
+    m.kill(n1); m.kill(n1); m.assert_exit(n1, True)
+    m.sleep_until(secs=5); m.assert_flag(0, 2); m.assert_flag(1, 4)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def restart():
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n, init=True)
+    t.flag_store(0, 0); top = t.label(); t.sleep(secs=2); t.flag_add(0, 2); t.jmp(top)
+    m = wl.main()
+    m.mark(); m.build_node(n)
+    m.sleep_until(secs=3); m.assert_flag(0, 2)
+    m.kill(n); m.restart(n); m.assert_exit(n, False)
+    m.sleep_until(secs=6); m.assert_flag(0, 2)
+    m.sleep_until(secs=8); m.assert_flag(0, 4)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def restart_on_panic():
+    wl = W.WorkloadBuilder()
+    n = wl.create_node(restart_on_panic=True)
+    t = wl.task(n, init=True)
+    t.flag_add(0, 1); t.panic_if_flag_lt(0, 4); t.done()
+    m = wl.main()
+    m.build_node(n); m.sleep(secs=60); m.assert_flag(0, 4)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def receiver_drop():
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+    s = wl.task(n1); s.bind(a1); s.sleep(secs=2); s.send_to(a1, a2, 1, 1); s.done()
+    r = wl.task(n2); r.bind(a2); r.recv_from_timeout(a2, 1, secs=1); r.assert_val(A.VAL_TIMEOUT); r.recv_from(a2, 1); r.assert_val(1); r.done()
+    m = wl.main()
+    m.spawn(s); m.spawn(r); m.join(s); m.join(r)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+ALL = {
+    "pingpong2": lambda: pingpong(2, 64), "pingpong4": lambda: pingpong(4, 64), "pingpong16": lambda: pingpong(16, 8),
+    "sleep_1s": sleep_1s, "yield_order": yield_order, "timer_ties": timer_ties, "kill": kill, "restart": restart,
+    "restart_on_panic": restart_on_panic, "receiver_drop": receiver_drop,
+}
