@@ -259,6 +259,8 @@ def main():
             for j in range(n_samp):
                 i = (j * 257) % count
                 want, _ = oracle.run_batch(w, base + i, 1, cfg, lim)
+                if int(got[i]["verdict"]) == A.OVERFLOW:      # a runner verdict (counted in failed_seeds; Builder::run re-runs
+                    continue                                   # such seeds with larger capacities), not a different answer
                 if got[i] != want[0]:
                     print(f"bench.py: VERIFY FAILED rank {rank} stream {si} seed {base + i}: gpu {got[i]} != oracle {want[0]}", file=sys.stderr)
                     return 3

@@ -207,8 +207,13 @@ typedef struct madsim_limits {
     uint32_t chan_queue;         /* queued payloads per channel direction; 0 = auto (2)              */
     uint32_t sched;              /* MADSIM_SCHED_*: how lanes pick up further seeds when a launch holds more
                                     seeds than resident lanes; 0 = static striding                    */
-    uint32_t reserved;
+    uint32_t state_mem;          /* MADSIM_STATE_*: where a seed's task table and planes live; 0 = auto               */
 } madsim_limits_t;
+
+#define MADSIM_STATE_AUTO   0u   /* LDS unless an extended-op workload's state leaves a CU fewer than 4 full waves       */
+#define MADSIM_STATE_LDS    1u   /* all per-seed state in LDS ([word][lane] planes)                                       */
+#define MADSIM_STATE_GLOBAL 2u   /* extended-op workloads: task table + planes in a per-lane block of global memory
+                                    (L2 / Infinity Cache / HBM), only the timer-heap top and the ready queue in LDS       */
 
 #define MADSIM_SCHED_STATIC 0u   /* lane g runs seeds g, g+G, g+2G, ...                                */
 #define MADSIM_SCHED_QUEUE  1u   /* a finished lane pulls the next seed from a per-launch atomic counter */
@@ -360,8 +365,11 @@ typedef struct madsim_geometry {
     uint32_t heap_spill_slots;
     uint32_t max_tasks;
     uint32_t lanes_per_wave;
-    uint32_t variant;              /* kernel specialisation: bit0 heap spill, bit1 extended (lifecycle/channel) ops,
-                                    * bit2 ready queue in a register, bit3 generic lanes-per-wave form */
+    uint32_t variant;              /* kernel specialisation: bit0 heap spill, bit1 extended ops, bit2 ready queue in a
+                                    * register, bit3 runtime lane stride, bit4 global-state build; bits 8-11 = classes of extended ops compiled in
+                                    * (1 timeouts, 2 channel, 4 RPC, 8 node lifecycle); bits 16-19 = compile-time log2 lane
+                                    * stride (15 = runtime) */
+    uint32_t global_bytes_per_seed; /* size of a lane's state block in global memory (global-state builds), else 0 */
 } madsim_geometry_t;
 int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* g);
 

@@ -10,6 +10,7 @@ ABI_VERSION = 2
 U64_MAX = (1 << 64) - 1
 LIMIT_NONE = 0xFFFFFFFF
 SCHED_STATIC, SCHED_QUEUE = 0, 1
+STATE_AUTO, STATE_LDS, STATE_GLOBAL = 0, 1, 2
 VAL_TIMEOUT = 0xFFFFFFFF
 VAL_REFUSED = 0xFFFFFFFE
 VAL_RESET = 0xFFFFFFFD
@@ -64,7 +65,7 @@ class Limits(C.Structure):
         ("time_limit_ns", C.c_uint64), ("max_steps", C.c_uint32), ("heap_lds_slots", C.c_uint32),
         ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32), ("mbox_regs", C.c_uint32),
         ("mbox_msgs", C.c_uint32), ("lanes_per_wave", C.c_uint32), ("max_conns", C.c_uint32), ("chan_queue", C.c_uint32),
-        ("sched", C.c_uint32), ("reserved", C.c_uint32),
+        ("sched", C.c_uint32), ("state_mem", C.c_uint32),
     ]
 
 
@@ -91,7 +92,7 @@ class Geometry(C.Structure):
         ("lds_bytes_per_seed", C.c_uint32), ("lds_bytes_per_block", C.c_uint32), ("block_threads", C.c_uint32),
         ("blocks_per_cu", C.c_uint32), ("grid_blocks", C.c_uint32), ("heap_lds_slots", C.c_uint32),
         ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32), ("lanes_per_wave", C.c_uint32),
-        ("variant", C.c_uint32),
+        ("variant", C.c_uint32), ("global_bytes_per_seed", C.c_uint32),
     ]
 
 

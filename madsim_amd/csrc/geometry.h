@@ -147,23 +147,32 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
         if (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) P.restart_nodes |= 1u << i;
     P.has_restart_on_panic = P.restart_nodes != 0;
-    P.lifecycle = P.has_restart_on_panic || uses_op(w, MS_OP_KILL) || uses_op(w, MS_OP_RESTART) || uses_op(w, MS_OP_PAUSE) ||
-                  uses_op(w, MS_OP_RESUME) || uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_SLEEP_RAND) || uses_op(w, MS_OP_RAND_BOOL) || uses_op(w, MS_OP_RANDOM) || uses_op(w, MS_OP_TRACE_TIME) || P.uses_chan || P.uses_rpc ||
-                  uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_ADVANCE);
-    for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.lifecycle = 1;
-    // The generic kernel variants (trace, lanes_per_wave != 64) are compiled with the extended ops, so they need the
-    // node region: lay out lean first and redo the layout once with it if the lean form does not end up on a
-    // 64-lane specialised variant (see madsim_k_launch_sim).
-    if (trace) P.lifecycle = 1;
+    // Classes of extended ops the workload needs (sim_kernel.h MADSIM_FEAT_*): the kernel build is picked by this mask
+    // (select_variant), and any of them switches the per-seed LDS layout to its extended form.
+    P.features = 0;
+    if (uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) ||
+        uses_op(w, MS_OP_ADVANCE) || uses_op(w, MS_OP_TRACE_TIME)) P.features |= MADSIM_FEAT_TIME;
+    if (P.uses_chan) P.features |= MADSIM_FEAT_CHAN;
+    if (P.uses_rpc) P.features |= MADSIM_FEAT_RPC | MADSIM_FEAT_TIME;            // call_timeout rides the timeout unit
+    if (P.has_restart_on_panic || uses_op(w, MS_OP_KILL) || uses_op(w, MS_OP_RESTART) || uses_op(w, MS_OP_PAUSE) || uses_op(w, MS_OP_RESUME) ||
+        uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_ASSERT_EXIT) || uses_op(w, MS_OP_BUILD)) P.features |= MADSIM_FEAT_NODE;
+    for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.features |= MADSIM_FEAT_NODE;
+    if (trace) P.features = MADSIM_FEAT_ALL;          // the trace build carries every class
+    P.lifecycle = P.features != 0;
     const uint32_t cus = g.num_cus > 0 ? (uint32_t)g.num_cus : 256u;
     uint32_t lw = 64;
     uint32_t sh_bytes = 0;
-    for (int pass = 0; pass < 2; pass++) {
+    // Where the task table and the planes live (madsim_limits_t.state_mem): LDS, or — extended-op workloads whose state
+    // would leave a CU with fewer than four full waves — a per-lane block of global memory (Variant::G, k_state.h).
+    if (L.state_mem > MADSIM_STATE_GLOBAL) return fail(err, MADSIM_E_LIMITS, "state_mem must be 0 (auto), 1 (LDS) or 2 (global)");
+    P.gstate_mode = 0;
+    for (int pass = 0; pass < 3; pass++) {
         if (!P.lifecycle && P.max_tasks < P.n_progs) P.max_tasks = P.n_progs;   // handle words live in task slots there
-        // the ready queue lives in a register in the (no extended ops, <= 8 tasks) variants: see madsim_k_launch_sim
-        P.rq_in_reg = !P.lifecycle && P.max_tasks <= 8 && !trace;
+        // the ready queue lives in a register in the (base ops, <= 8 tasks, full 64-lane waves) builds: lay out with it
+        // first and once more without it if the lane stride does not come out at 64 (select_variant)
+        P.rq_in_reg = !P.lifecycle && P.max_tasks <= 8 && !trace && pass == 0;
         P.off_ready = 0;
-        P.off_socks = P.off_ready + (P.rq_in_reg ? 0 : P.max_tasks);
+        P.off_socks = P.gstate_mode ? 0 : P.off_ready + (P.rq_in_reg ? 0 : P.max_tasks);     // global planes start at the sockets
         P.off_handles = P.off_socks + P.n_socks * P.sock_words;
         // JoinHandle words: a plane with the extended ops, else unit1.y of task slot p (sim_kernel.hip HW)
         P.off_nodes = P.off_handles + (P.lifecycle ? P.n_progs : 0);
@@ -175,13 +184,19 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         bool gregs = uses_op(w, MS_OP_GSET) || uses_op(w, MS_OP_GADD) || uses_op(w, MS_OP_ASSERT_G) || uses_op(w, MS_OP_PANIC_IF_G_LT);
         P.off_conn = P.off_greg + (gregs ? 4 : 0);
         P.lane_words = P.off_conn + (P.uses_chan ? P.max_conns * P.conn_words : 0);
+        if (P.gstate_mode) {           // the planes just laid out go to the global block; LDS keeps the ready queue only
+            P.gs_plane_words = P.lane_words;
+            P.gs_planes = P.max_tasks * P.task_units * 16;
+            P.gs_stride = (P.gs_planes + P.gs_plane_words * 4 + 63) & ~63u;
+            P.lane_words = P.max_tasks;
+        }
         P.sh_insns = 0;
         P.sh_progs = P.sh_insns + 4 * P.n_insns;
         P.sh_socks = P.sh_progs + P.n_progs;
         P.sh_heap = (P.sh_socks + P.n_socks + 3) & ~3u;
         sh_bytes = P.sh_heap * 4;
-        G->lds_per_seed = P.heap_lds * 16 + P.max_tasks * P.task_units * 16 + P.lane_words * 4;
-        if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
+        G->lds_per_seed = P.heap_lds * 16 + (P.gstate_mode ? 0 : P.max_tasks * P.task_units * 16) + P.lane_words * 4;
+        if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu && (L.state_mem == MADSIM_STATE_LDS || !P.lifecycle || trace || P.gstate_mode)) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
         // Lanes per wave (lw): how many of a wave's 64 lanes carry a seed.  Measured on MI355X (4-node
         // ping-pong, 65 536 seeds, profiles/r1_lanes_per_wave.md): every wave-instruction costs the SIMD
         // ~4 cycles whatever the number of active lanes, and at 16 lanes/wave the VALU pipe is already
@@ -198,12 +213,15 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             auto blocks = [&](uint32_t l) { size_t b = (size_t)sh_bytes + (size_t)l * G->lds_per_seed; return b > g.lds_per_cu ? 0u : (uint32_t)(g.lds_per_cu / b); };
             while (lw > 8 && blocks(lw) < 4) lw >>= 1;
         }
-        if (lw == 64 || P.lifecycle) break;
-        P.lifecycle = 1;
+        if (P.gstate_mode) { if (!L.lanes_per_wave) lw = 64; break; }
+        const bool can_g = P.lifecycle && !trace && L.state_mem != MADSIM_STATE_LDS;
+        if (can_g && (L.state_mem == MADSIM_STATE_GLOBAL || (lw != 64 && !L.lanes_per_wave))) { P.gstate_mode = 1; continue; }
+        if (lw == 64 || !P.rq_in_reg) break;
     }
+    if (P.gstate_mode && lw != 64) return fail(err, MADSIM_E_LIMITS, "global state (state_mem = 2) runs full 64-lane waves only");
     P.lw_shift = lw == 8 ? 3 : lw == 16 ? 4 : lw == 32 ? 5 : 6;
     P.sh_tasks = P.sh_heap + P.heap_lds * lw * 4;
-    P.sh_planes = P.sh_tasks + P.max_tasks * P.task_units * lw * 4;
+    P.sh_planes = P.sh_tasks + (P.gstate_mode ? 0 : P.max_tasks * P.task_units * lw * 4);
     P.wave_words = P.sh_planes + P.lane_words * lw - P.sh_heap;
     if ((size_t)(P.sh_heap + P.wave_words) * 4 > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-wave LDS exceeds 160 KiB: lower heap_lds_slots / mailbox capacities");
     // Workgroup = W independent waves.  Measured on MI355X (tools/placement.hip, profiles/r1_placement.txt): the
@@ -214,7 +232,10 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // LDS is handed out in 1 280-byte granules (measured, tools/placement.hip: three 53 688-byte workgroups share a CU,
     // three 54 000-byte ones do not), so a workgroup costs its size rounded up to that.
     auto lds_alloc = [&](uint32_t w2) { size_t b = (size_t)(P.sh_heap + w2 * P.wave_words) * 4; return (b + 1279) / 1280 * 1280; };
-    const uint32_t cap = P.lifecycle ? 8u : 16u;      // VGPR budget: 4 waves per SIMD (~105 VGPRs), 2 with the extended ops (~186)
+    // VGPR budget (tools/kernel_meta.sh): base builds ~110 VGPRs = 4 waves per SIMD, single-class builds 133 / 151 = 3,
+    // the full extended build ~180 = 2
+    const int vfeat = madsim_k::select_variant(P, trace).feat;
+    const uint32_t cap = vfeat == 0 ? 16u : (vfeat == MADSIM_FEAT_TIME || vfeat == MADSIM_FEAT_CHAN) ? 12u : 8u;
     auto waves_at = [&](uint32_t w2) {
         uint32_t blocks = (uint32_t)(g.lds_per_cu / lds_alloc(w2));
         return blocks * w2 < cap ? blocks * w2 : cap;

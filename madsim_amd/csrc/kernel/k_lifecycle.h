@@ -17,18 +17,18 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
     uint32_t pw = PROGW(c, prog);
     uint32_t node = pw & 0xff;
     uint32_t killed = 0, info_gen = 0;
-    if (K::LIFE) {
+    if (K::FN) {
         uint32_t cur_gen = NODE_INFO_GEN(node);
         info_gen = cur_gen;
         if (via_handle && cur_gen != 0) { killed = 1; info_gen = 0; }             // stale handle: dead info
         else killed = ((via_handle ? NODEW(2) : NODEW(0)) >> node) & 1;          // task/mod.rs:632-634
     }
     uint32_t seq = 0;
-    if (K::LIFE) { seq = NODEW(3); NODEW(3) = seq + 1; }      // spawn order matters only to NodeInfo::kill
+    if (K::FN) { seq = NODEW(3); NODEW(3) = seq + 1; }      // spawn order matters only to NodeInfo::kill
     TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
     tu1_store<K>(c, slot, make_uint4(0xffu << 8, (seq & 0xffffff) | (info_gen << 24), 0, 0));   // rxseq 0, no awaiter; spawn order
-    if (K::LIFE && c.P.uses_chan) TU(c, slot, c.P.chan_unit) = make_uint4(0xff, 0, 0, 0);                // no connection held
-    if (K::LIFE && c.P.uses_rpc) { TWORD(c, slot, c.P.rpc_unit, 0) = 0; TWORD(c, slot, c.P.rpc_unit, 1) = 0; }   // no request in hand
+    if (K::FC && c.P.uses_chan) TU(c, slot, c.P.chan_unit) = make_uint4(0xff, 0, 0, 0);                // no connection held
+    if (K::FR && c.P.uses_rpc) { TWORD(c, slot, c.P.rpc_unit, 0) = 0; TWORD(c, slot, c.P.rpc_unit, 1) = 0; }   // no request in hand
     ready_push<K>(c, L, slot);
     if (record) HW(prog) = H_RUNNING | (slot << 8) | (gen << 16);
     return slot;
@@ -42,7 +42,7 @@ template <class K>
 __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome) {
     uint32_t f = TWORD(c, slot, 0, 0);
     uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
-    if (K::LIFE && c.P.uses_chan) {                          // the task's (Sender, Receiver) pair drops with its future
+    if (K::FC && c.P.uses_chan) {                          // the task's (Sender, Receiver) pair drops with its future
         uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
         if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
     }
@@ -52,7 +52,7 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
             if (SW(c, i, 1) != own) continue;
             // BindGuard::drop (net/mod.rs:483-493), skipped when the binder's NodeInfo is killed
             if (!(f & TF_KILLED) && (SW(c, i, 0) & 1)) SW(c, i, 0) &= ~1u;
-            if (K::LIFE && c.P.uses_chan && (SW(c, i, 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, i);
+            if (K::FC && c.P.uses_chan && (SW(c, i, 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, i);
         }
     }
     uint32_t h = HW(prog);

@@ -42,7 +42,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
     // Typed RPC (net/rpc.rs): a response (tag 0xff) is addressed to one pending receive — the word of its registration,
     // tag | slot | rxseq | gen, rides in the payload's upper 24 bits — where the reference matches a random u64 tag.
-    const bool rpc = K::LIFE && c.P.uses_rpc;
+    const bool rpc = K::FR && c.P.uses_rpc;
     const bool rsp = rpc && tag == 0xff;
     uint32_t i = 0;
     while (i < nreg) {
@@ -92,7 +92,7 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
         uint32_t kind = e.z >> 28;
         if (kind == EV_WAKE) { REG(22); wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff); }   // time/sleep.rs:52
         else if (kind == EV_DELIVER) { REG(23); mailbox_deliver<K>(c, L, e.z, e.w); }      // net/mod.rs:323-330
-        else if (K::LIFE && kind == EV_RESTART) node_restart<K>(c, L, e.z & 0xff);   // task/mod.rs:313
+        else if (K::FN && kind == EV_RESTART) node_restart<K>(c, L, e.z & 0xff);   // task/mod.rs:313
     }
 }
 

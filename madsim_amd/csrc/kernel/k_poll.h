@@ -21,6 +21,17 @@ __device__ __forceinline__ uint64_t rand_delay_deadline(const Ctx& c, Lane& L) {
     return sleep_deadline(L, L.clock + delay);
 }
 
+// madsim_config_t.loss_table[i & 3] as Bernoulli parameters.  A select chain, not P.loss_table_pint[i]: a per-lane index
+// into the by-value kernel-argument block makes the compiler copy the whole block to scratch.
+__device__ __forceinline__ uint64_t loss_pint_at(const KParams& P, uint32_t i) {
+    i &= 3;
+    return i == 0 ? P.loss_table_pint[0] : i == 1 ? P.loss_table_pint[1] : i == 2 ? P.loss_table_pint[2] : P.loss_table_pint[3];
+}
+__device__ __forceinline__ uint32_t loss_always_at(const KParams& P, uint32_t i) {
+    i &= 3;
+    return i == 0 ? P.loss_table_always[0] : i == 1 ? P.loss_table_always[1] : i == 2 ? P.loss_table_always[2] : P.loss_table_always[3];
+}
+
 __device__ __forceinline__ bool is_light(uint32_t op) {
     return op == MS_OP_ASSERT_VAL || op == MS_OP_DJNZ || op == MS_OP_SET || op == MS_OP_JMP || op == MS_OP_TRACE || op == MS_OP_JEQ;
 }
@@ -51,7 +62,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (sub == 1 && (u0.x & TF_INBOX)) {                 // oneshot ready -> rand_delay (endpoint.rs:145)
             u0.x &= ~TF_INBOX;
             from = u0.y >> 24;
-            if (P.uses_rpc && (INSN(c, pc).x >> 24) >= MADSIM_TAG_RPC_FIRST) TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
+            if (K::FR && P.uses_rpc && (INSN(c, pc).x >> 24) >= MADSIM_TAG_RPC_FIRST) TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
             uint64_t d1 = rand_delay_deadline<K>(c, L);
             u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
             sub = 2;
@@ -180,18 +191,18 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (!(u0.x & TF_INBOX)) { st = ST_PENDING; break; }
                 u0.x &= ~TF_INBOX;
                 from = u0.y >> 24;
-                if (K::LIFE && P.uses_rpc && (b >> 8) >= MADSIM_TAG_RPC_FIRST)   // (rsp_tag, req, data) = *data.downcast()
+                if (K::FR && P.uses_rpc && (b >> 8) >= MADSIM_TAG_RPC_FIRST)   // (rsp_tag, req, data) = *data.downcast()
                     TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
                 sub = 2;                                   // -> rand_delay, begun in [C]
             } else if (op == MS_OP_YIELD) {
                 completed = true;
-            } else if (K::LIFE && op == MS_OP_RECV_TIMEOUT) {
+            } else if (K::FT && op == MS_OP_RECV_TIMEOUT) {
                 completed = recv_timeout_poll();
                 if (!completed) break;
-            } else if (K::LIFE && op == MS_OP_RPC_CALL) {
+            } else if (K::FR && op == MS_OP_RPC_CALL) {
                 completed = rpc_call_poll();
                 if (!completed || st == ST_PANIC) break;
-            } else if (K::LIFE && op == MS_OP_ACCEPT && sub == 2) {
+            } else if (K::FC && op == MS_OP_ACCEPT && sub == 2) {
                 completed = accept_check(a);
                 if (!completed) break;
             } else {                                       // a Sleep (time/sleep.rs:47-54)
@@ -203,10 +214,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     st = ST_PENDING;
                     break;
                 }
-                if (K::LIFE && op == MS_OP_ACCEPT) {       // rand_delay done -> conn_rx.recv()
+                if (K::FC && op == MS_OP_ACCEPT) {       // rand_delay done -> conn_rx.recv()
                     sub = 2;
                     if (!accept_check(a)) break;
-                } else if (K::LIFE && op == MS_OP_CRECV) {
+                } else if (K::FC && op == MS_OP_CRECV) {
                     uint4 u3 = TU(c, slot, c.P.chan_unit);
                     if (sub == 2) {                        // sleep(backoff) done: backoff = min(2 * backoff, 10 s); retry the link
                         uint32_t bo = (u3.x >> 16) * 2; if (bo > 10000) bo = 10000;
@@ -218,7 +229,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         break;
                     }
                     u0.w = u3.y;                           // sub 3: sleep_until(arrive_time) done -> yield value
-                } else if (K::LIFE && op == MS_OP_CONNECT) {   // NetSim::connect1 (net/mod.rs:345-363)
+                } else if (K::FC && op == MS_OP_CONNECT) {   // NetSim::connect1 (net/mod.rs:345-363)
                     uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                     if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
                     uint64_t lat; int ds;
@@ -247,11 +258,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     uint32_t h = SW(c, a, 0);
                     SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);     // bound, gen+1, empty mailbox
                     SW(c, a, 1) = slot | (gen << 16);
-                    if (K::LIFE && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
-                } else if (op == MS_OP_SEND || op == MS_OP_REPLY || (K::LIFE && op == MS_OP_RPC_REPLY)) {   // net/mod.rs:307-331
+                    if (K::FC && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
+                } else if (op == MS_OP_SEND || op == MS_OP_REPLY || (K::FR && op == MS_OP_RPC_REPLY)) {   // net/mod.rs:307-331
                     REG(6);
                     uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : from;
-                    if (K::LIFE && op == MS_OP_RPC_REPLY) {    // send_to_raw(from, rsp_tag, rsp): rpc.rs:172-175
+                    if (K::FR && op == MS_OP_RPC_REPLY) {    // send_to_raw(from, rsp_tag, rsp): rpc.rs:172-175
                         b = 0xff00;
                         imm = (imm & 0xff) | (TWORD(c, slot, P.rpc_unit, 0) << 8);
                     }
@@ -348,7 +359,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);        // swap_remove
                     SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
                     u0.w = m1;
-                    if (K::LIFE && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 0) = m1 >> 8; }
+                    if (K::FR && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 0) = m1 >> 8; }
                     from = (m0 >> 8) & 0xff;
                     sub = 2;                               // oneshot already holds the value
                     SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
@@ -357,7 +368,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
                     // dead registrations (timed-out / dropped receives, extended ops only) stay in the Vec like the
                     // reference's; an 8-bit rxseq that wraps onto one of them would make it look live: overflow, never a different answer
-                    if (K::LIFE) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;
+                    if (K::FT || K::FN) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;
                     SW(c, a, 2 + nreg) = reg;
                     SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
                     sub = 1;
@@ -365,9 +376,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 }
             }
             want_delay = (sub == 2);                       // endpoint.rs:145 rand_delay
-        } else if (op == MS_OP_SEND || op == MS_OP_REPLY || op == MS_OP_BIND || (K::LIFE && (op == MS_OP_CONNECT || op == MS_OP_ACCEPT || op == MS_OP_RPC_REPLY))) {
+        } else if (op == MS_OP_SEND || op == MS_OP_REPLY || op == MS_OP_BIND || (K::FC && (op == MS_OP_CONNECT || op == MS_OP_ACCEPT)) || (K::FR && op == MS_OP_RPC_REPLY)) {
             want_delay = true;                             // net/mod.rs:306,344,457, endpoint.rs:198: rand_delay first
-        } else if (K::LIFE && op == MS_OP_RECV_TIMEOUT) {
+        } else if (K::FT && op == MS_OP_RECV_TIMEOUT) {
             uint32_t tag = b >> 8;
             uint64_t d2 = sleep_deadline(L, L.clock + (uint64_t)(b & 0xff) * NS_PER_S + imm);   // timeout()'s Sleep
             uint4 u2 = TU(c, slot, 2);
@@ -386,7 +397,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);
                 SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
                 u0.w = m1;
-                if (P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 1) = m1 >> 8; }
+                if (K::FR && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 1) = m1 >> 8; }
                 u0.y = (u0.y & 0x00ffffffu) | (((m0 >> 8) & 0xff) << 24);
                 u0.x |= TF_INBOX;
                 SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
@@ -400,7 +411,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             }
             sub = 1;
             if (recv_timeout_poll()) { sub = 0; pc++; }
-        } else if (K::LIFE && op == MS_OP_RPC_CALL) {          // first poll of timeout(d, ep.call(dst, req)) / ep.call(dst, req)
+        } else if (K::FR && op == MS_OP_RPC_CALL) {          // first poll of timeout(d, ep.call(dst, req)) / ep.call(dst, req)
             if (imm >> 8) {                                    // timeout()'s Sleep exists before the call is polled
                 uint64_t d2 = sleep_deadline(L, L.clock + (uint64_t)(imm >> 8) * NS_PER_MS);
                 uint4 u2 = TU(c, slot, 2);
@@ -412,7 +423,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
             sub = 1;
             if (rpc_call_poll()) { sub = 0; pc++; }            // (never on the first poll: 1 ms floor)
-        } else if (K::LIFE && op == MS_OP_SLEEP_RAND) {        // sleep(thread_rng().gen_range(lo..hi)): [DEP A.3],
+        } else if (op == MS_OP_SLEEP_RAND) {        // sleep(thread_rng().gen_range(lo..hi)): [DEP A.3],
             const uint64_t* dp = P.dur_table + 4 * a;          // host-precomputed UniformDuration {mode, low, range, zone}
             uint64_t mode = dp[0], low = dp[1], range = dp[2], zone = dp[3], d;
             for (;;) {                                         // on the GlobalRng itself: one with() per attempt
@@ -427,7 +438,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             want_sleep = true;
         } else if (op == MS_OP_SLEEP || op == MS_OP_SLEEP_UNTIL) {
             uint64_t base = L.clock;
-            if (K::LIFE && op == MS_OP_SLEEP_UNTIL) { uint4 u2 = TU(c, slot, 2); base = u64of(u2.x, u2.y); }
+            if (K::FT && op == MS_OP_SLEEP_UNTIL) { uint4 u2 = TU(c, slot, 2); base = u64of(u2.x, u2.y); }
             deadline = sleep_deadline(L, base + (uint64_t)b * NS_PER_S + imm);
             want_sleep = true;
         } else {
@@ -439,7 +450,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (u1_dirty) { tu1_store<K>(c, slot, u1); u1_dirty = false; }
                 // an init task is `async { future.await; h.exit() }` (runtime/mod.rs:362-370): Spawner::exit =
                 // NodeInfo::kill on the info it was spawned with (task/mod.rs:657-661), before the future drops
-                if (K::LIFE && ((PROGW(c, u0.x >> 24) >> 8) & MADSIM_PROG_INIT) && (u1.y >> 24) == NODE_INFO_GEN(node)) {
+                if (K::FN && ((PROGW(c, u0.x >> 24) >> 8) & MADSIM_PROG_INIT) && (u1.y >> 24) == NODE_INFO_GEN(node)) {
                     NODEW(0) |= 1u << node;
                     if ((u1.y >> 24) == 0) NODEW(2) |= 1u << node;
                     info_kill<K>(c, L, node, u1.y >> 24);
@@ -450,12 +461,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             case MS_OP_SPAWN: {
                 uint32_t child = spawn_task<K>(c, L, a, true, (PROGW(c, a) & 0xff) != node);
-                if (K::LIFE && P.uses_chan && (b & 2) && child != 0xffffffffu) {   // `async move`: the (tx, rx) pair moves
+                if (K::FC && P.uses_chan && (b & 2) && child != 0xffffffffu) {   // `async move`: the (tx, rx) pair moves
                     uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                     TWORD(c, child, c.P.chan_unit, 0) = cx & 0x1ff;
                     TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff;
                 }
-                if (K::LIFE && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST) && child != 0xffffffffu) {   // rpc.rs:170
+                if (K::FR && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST) && child != 0xffffffffu) {   // rpc.rs:170
                     TWORD(c, child, 0, 3) = u0.w;
                     TWORD(c, child, 0, 1) = (TWORD(c, child, 0, 1) & 0x00ffffffu) | (from << 24);
                     TWORD(c, child, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 0);
@@ -494,7 +505,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 st = ST_PANIC;
                 break;
             case MS_OP_ABORT: {                            // AbortHandle::abort (task/join.rs:158-163)
-                if (!K::LIFE) { st = ST_PANIC; break; }
+                if (!K::FN) { st = ST_PANIC; break; }
                 uint32_t h = HW(a);
                 if ((h & 3) == H_RUNNING) {
                     uint32_t cs = (h >> 8) & 0xff;
@@ -505,7 +516,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             }
             case MS_OP_KILL: case MS_OP_RESTART:
-                if (!K::LIFE) { st = ST_PANIC; break; }
+                if (!K::FN) { st = ST_PANIC; break; }
                 u0.y = pc | (sub << 16) | (from << 24);     // this task may be woken/killed by the call: sync LDS first
                 TU(c, slot, 0) = u0;
                 if (op == MS_OP_KILL) node_kill<K>(c, L, a); else node_restart<K>(c, L, a);
@@ -513,12 +524,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 pc++;
                 break;
             case MS_OP_PAUSE:                               // task/mod.rs:404-410
-                if (!K::LIFE) { st = ST_PANIC; break; }
+                if (!K::FN) { st = ST_PANIC; break; }
                 NODEW(1) |= 1u << a;
                 pc++;
                 break;
             case MS_OP_RESUME: {                            // task/mod.rs:413-424: parked Runnables go back, in order
-                if (!K::LIFE) { st = ST_PANIC; break; }
+                if (!K::FN) { st = ST_PANIC; break; }
                 NODEW(1) &= ~(1u << a);
                 if (P.uses_pause) {
                     uint32_t n = PAUSEW(0), keep = 0;
@@ -533,10 +544,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             }
             case MS_OP_ASSERT_EXIT:                         // Handle::is_exit (task/mod.rs:444-449)
+                if (!K::FN) { st = ST_PANIC; break; }
                 if (((NODEW(0) >> a) & 1) != (b & 1)) st = ST_PANIC; else pc++;
                 break;
             case MS_OP_CSEND: {                            // PayloadSender::send (net/mod.rs:417-421)
-                if (!K::LIFE) { st = ST_PANIC; break; }
+                if (!K::FC) { st = ST_PANIC; break; }
                 uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                 if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
                 uint32_t id = cx & 0xff, side = (cx >> 8) & 1;
@@ -554,7 +566,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             }
             case MS_OP_CRECV: {                            // rx.recv().await (net/mod.rs:386), sub == 0 here
-                if (!K::LIFE) { st = ST_PANIC; break; }
+                if (!K::FC) { st = ST_PANIC; break; }
                 uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                 if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
                 uint32_t id = cx & 0xff, dir = 1 - ((cx >> 8) & 1);
@@ -576,7 +588,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             }
             case MS_OP_CCLOSE: {
-                if (!K::LIFE) { st = ST_PANIC; break; }
+                if (!K::FC) { st = ST_PANIC; break; }
                 uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                 if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
                 pc++;
@@ -587,12 +599,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_ASSERT_G: if (GREGW(a & 3) != imm) st = ST_PANIC; else pc++; break;
             case MS_OP_PANIC_IF_G_LT: if (GREGW(a & 3) < imm) st = ST_PANIC; else pc++; break;
             case MS_OP_MARK:
-                if (!K::LIFE) { st = ST_PANIC; break; }     // t0 family and advance(): extended variant only
+                if (!K::FT) { st = ST_PANIC; break; }     // t0 family and advance(): extended variant only
                 TU(c, slot, 2) = make_uint4((uint32_t)L.clock, (uint32_t)(L.clock >> 32), 0, 0);
                 pc++;
                 break;
             case MS_OP_ASSERT_ELAPSED: {
-                if (!K::LIFE) { st = ST_PANIC; break; }
+                if (!K::FT) { st = ST_PANIC; break; }
                 uint4 u2 = TU(c, slot, 2);
                 uint64_t el = L.clock - u64of(u2.x, u2.y), d = (uint64_t)b * NS_PER_S + imm;
                 bool ok = a == 0 ? el == d : a == 1 ? el >= d : el < d;
@@ -600,7 +612,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             }
             case MS_OP_ADVANCE:                            // time/mod.rs:103-106
-                if (!K::LIFE) { st = ST_PANIC; break; }
+                if (!K::FT) { st = ST_PANIC; break; }
                 L.clock += (uint64_t)b * NS_PER_S + imm;
                 pc++;
                 u0.y = pc | (sub << 16) | (from << 24);
@@ -613,7 +625,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_CLOSE: {
                 uint32_t h = SW(c, a, 0);
                 if ((h & 1) && SW(c, a, 1) == (slot | (gen << 16)) && !(u0.x & TF_KILLED)) SW(c, a, 0) = h & ~1u;
-                if (K::LIFE && P.uses_chan && SW(c, a, 1) == (slot | (gen << 16)) && (SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, a);
+                if (K::FC && P.uses_chan && SW(c, a, 1) == (slot | (gen << 16)) && (SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, a);
                 pc++;
                 break;
             }
@@ -636,7 +648,6 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 pc++;
                 break;
             case MS_OP_RANDOM: {                            // one with() on the GlobalRng's RngCore impl (rand.rs:142-158)
-                if (!K::LIFE) { st = ST_PANIC; break; }
                 uint64_t v = rng_next(L); rng_log<K>(c, L);
                 u0.w = a == 0 ? (uint32_t)(v >> 32) : (uint32_t)((v >> 32) & 0xff);   // gen::<u32>() / getrandom 1 byte [DEP]
                 pc++;
@@ -651,13 +662,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             }
             case MS_OP_RAND_BOOL:                           // thread_rng().gen_bool(p) [DEP A.4]
-                if (!K::LIFE) { st = ST_PANIC; break; }
-                u0.w = gen_bool_pint<K>(c, L, P.loss_table_pint[a & 3], P.loss_table_always[a & 3]) ? 1u : 0u;
+                u0.w = gen_bool_pint<K>(c, L, loss_pint_at(P, a), loss_always_at(P, a)) ? 1u : 0u;
                 pc++;
                 break;
             case MS_OP_SET_LOSS:
-                L.loss_pint = P.loss_table_pint[a & 3];
-                L.loss_always = P.loss_table_always[a & 3];
+                L.loss_pint = loss_pint_at(P, a);
+                L.loss_always = loss_always_at(P, a);
                 pc++;
                 break;
             default:

@@ -36,10 +36,22 @@ enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 // Compile-time kernel variant: TRACE = also emit the raw determinism log (single-seed trace mode);
 // SPILL = the timer heap may overflow from LDS into the HBM spill region.
 // LWS = log2(lane stride) when known at compile time (6: full 64-lane waves), or -1: read it from KParams.
-// LIFE = the workload uses node lifecycle (kill/restart/pause/abort ops, init programs, restart_on_panic);
-// the fast variant compiles that cold code out of the hot loop.
+// FEAT = which classes of extended ops are compiled in (MADSIM_FEAT_* bits, geometry.h picks the mask from the ops a
+// workload uses): FT timeouts / t0 family / advance, FC reliable channel, FR typed RPC, FN node lifecycle (kill /
+// restart / pause / abort, init programs, restart_on_panic).  0 = the fast variant: none of that cold code in the hot
+// loop.  LIFE = any extended op: selects the extended LDS layout (handle plane, node region, whole-unit task stores).
 // RQ = the ready queue (<= 8 tasks) lives in a 64-bit register, one byte per queued task, instead of LDS.
-template <bool TRACE_, bool SPILL_, int LWS_, bool LIFE_, bool RQ_ = false> struct Variant { static constexpr bool TRACE = TRACE_, SPILL = SPILL_, LIFE = LIFE_, RQ = RQ_; static constexpr int LWS = LWS_; };
+// G = the per-seed task table and planes live in a per-lane block of global memory (L2 / Infinity Cache / HBM) instead of
+// LDS; only the timer-heap top and the ready queue stay in LDS.  Extended-op workloads carry 1-4 KB of state per seed, which
+// in LDS caps a CU at 32-128 seeds; their wave-iterations cost tens of thousands of cycles (the wave executes the union of
+// its lanes' op handlers), so a few hundred cycles of global latency per access are cheap next to 4-16x the seeds in flight.
+template <bool TRACE_, bool SPILL_, int LWS_, int FEAT_, bool RQ_ = false, bool G_ = false> struct Variant {
+    static constexpr bool TRACE = TRACE_, SPILL = SPILL_, RQ = RQ_, G = G_;
+    static constexpr int LWS = LWS_, FEAT = FEAT_;
+    static constexpr bool LIFE = FEAT_ != 0;
+    static constexpr bool FT = (FEAT_ & MADSIM_FEAT_TIME) != 0, FC = (FEAT_ & MADSIM_FEAT_CHAN) != 0,
+                          FR = (FEAT_ & MADSIM_FEAT_RPC) != 0, FN = (FEAT_ & MADSIM_FEAT_NODE) != 0;
+};
 
 // REG(id): divergence-model markers, compiled in only by tools/divergence_model.py's host emulation build
 #ifndef REG
@@ -107,31 +119,124 @@ struct Ctx {
     uint32_t prog0, sockt0;   // word indices of the shared prog / socket-address tables
     SpillRef spill;      // the HBM spill region: entry (slot, this lane) at byte (slot * P.total_lanes) * 16 + spill_off
     uint32_t spill_off;  // this lane's column: global lane * 16
+    // K::G builds: this lane's state block = P.gs_stride bytes at byte gs_off of the state buffer; task0 and the plane
+    // bases (sock0, hand0, node0, clog0, pause0, greg0, conn0) are then BYTE offsets inside that block
+    SpillRef gs;
+    uint32_t gs_off;
     uint8_t* tlog;       // trace mode only
     __device__ Ctx(const KParams& p) : P(p) {}
 };
 
 template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { return K::LWS >= 0 ? (uint32_t)K::LWS : c.lws; }
 #define RW(i) SMEM[c.ready0 + ((i) << LWSH<K>(c))]
-// JoinHandle state of prog p.  Workloads with the extended ops keep a handle plane; the others park the word in the
-// otherwise unused unit1.y of task slot p (max_tasks >= n_progs there, geometry.h) and save the plane's LDS.
-#define HW(p) (*hw_ref<K>(c, (p)))
-#define NODEW(i) SMEM[c.node0 + ((i) << LWSH<K>(c))]
-#define CLOGW(i) SMEM[c.clog0 + ((i) << LWSH<K>(c))]
-#define PAUSEW(i) SMEM[c.pause0 + ((i) << LWSH<K>(c))]   /* [0] = length, [1..] = paused Runnables in pop order */
-#define GREGW(i) SMEM[c.greg0 + ((i) << LWSH<K>(c))]
+
+// ---- the lane's state block in global memory (K::G builds) -----------------------------------------------------------
+// Reached through a buffer resource like the heap spill region (byte offsets in a VGPR): with plain pointers the compiler
+// would fold the LDS and global alternatives into flat_* accesses.  A block belongs to one lane for the whole launch.
+// `off` = byte offset in the state buffer (the lane's gs_off already added).
+__device__ __forceinline__ uint32_t gs_load32(const SpillRef& gs, uint32_t off) {
+#ifdef MADSIM_EMU
+    return *(const uint32_t*)((const uint8_t*)gs.base + off);
+#else
+    return __builtin_amdgcn_raw_buffer_load_b32(gs.rsrc, off, 0, 0);
+#endif
+}
+__device__ __forceinline__ void gs_store32(const SpillRef& gs, uint32_t off, uint32_t v) {
+#ifdef MADSIM_EMU
+    *(uint32_t*)((uint8_t*)gs.base + off) = v;
+#else
+    __builtin_amdgcn_raw_buffer_store_b32(v, gs.rsrc, off, 0, 0);
+#endif
+}
+__device__ __forceinline__ uint4 gs_load128(const SpillRef& gs, uint32_t off) {
+#ifdef MADSIM_EMU
+    return *(const uint4*)((const uint8_t*)gs.base + off);
+#else
+    u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(gs.rsrc, off, 0, 0);
+    return make_uint4(t.x, t.y, t.z, t.w);
+#endif
+}
+__device__ __forceinline__ void gs_store128(const SpillRef& gs, uint32_t off, const uint4& e) {
+#ifdef MADSIM_EMU
+    *(uint4*)((uint8_t*)gs.base + off) = e;
+#else
+    u32x4_t t = {e.x, e.y, e.z, e.w};
+    __builtin_amdgcn_raw_buffer_store_b128(t, gs.rsrc, off, 0, 0);
+#endif
+}
+
+// One 32-bit word / one 16-byte unit of per-seed state, in LDS ([word][lane] planes) or in the lane's global block.
+// The accessor macros below return these, so the executor code reads and writes state the same way in both layouts.
+// They carry the buffer resource by value (no reference back into Ctx / KParams: an escaping address would make the
+// compiler copy the kernel-argument block to scratch).
+template <bool G> struct WRef;
+template <> struct WRef<false> {
+    uint32_t at;                      // LDS word index
+    __device__ __forceinline__ operator uint32_t() const { return SMEM[at]; }
+    __device__ __forceinline__ uint32_t operator=(uint32_t v) const { SMEM[at] = v; return v; }
+    __device__ __forceinline__ uint32_t operator=(const WRef& o) const { return *this = (uint32_t)o; }
+    __device__ __forceinline__ uint32_t operator|=(uint32_t v) const { return *this = (uint32_t)*this | v; }
+    __device__ __forceinline__ uint32_t operator&=(uint32_t v) const { return *this = (uint32_t)*this & v; }
+    __device__ __forceinline__ uint32_t operator+=(uint32_t v) const { return *this = (uint32_t)*this + v; }
+};
+template <> struct WRef<true> {
+    SpillRef gs; uint32_t at;         // byte offset in the state buffer
+    __device__ __forceinline__ operator uint32_t() const { return gs_load32(gs, at); }
+    __device__ __forceinline__ uint32_t operator=(uint32_t v) const { gs_store32(gs, at, v); return v; }
+    __device__ __forceinline__ uint32_t operator=(const WRef& o) const { return *this = (uint32_t)o; }
+    __device__ __forceinline__ uint32_t operator|=(uint32_t v) const { return *this = (uint32_t)*this | v; }
+    __device__ __forceinline__ uint32_t operator&=(uint32_t v) const { return *this = (uint32_t)*this & v; }
+    __device__ __forceinline__ uint32_t operator+=(uint32_t v) const { return *this = (uint32_t)*this + v; }
+};
+template <bool G> struct URef;
+template <> struct URef<false> {
+    uint32_t at;                      // LDS uint4 index
+    __device__ __forceinline__ operator uint4() const { return LDS128(at); }
+    __device__ __forceinline__ void operator=(const uint4& v) const { LDS128(at) = v; }
+    __device__ __forceinline__ void operator=(const URef& o) const { *this = (uint4)o; }
+};
+template <> struct URef<true> {
+    SpillRef gs; uint32_t at;
+    __device__ __forceinline__ operator uint4() const { return gs_load128(gs, at); }
+    __device__ __forceinline__ void operator=(const uint4& v) const { gs_store128(gs, at, v); }
+    __device__ __forceinline__ void operator=(const URef& o) const { *this = (uint4)o; }
+};
+template <bool G> __device__ __forceinline__ WRef<G> make_wref(const Ctx& c, uint32_t lds_at, uint32_t gs_at);
+template <> __device__ __forceinline__ WRef<false> make_wref<false>(const Ctx&, uint32_t lds_at, uint32_t) { return WRef<false>{lds_at}; }
+template <> __device__ __forceinline__ WRef<true> make_wref<true>(const Ctx& c, uint32_t, uint32_t gs_at) { return WRef<true>{c.gs, c.gs_off + gs_at}; }
+template <bool G> __device__ __forceinline__ URef<G> make_uref(const Ctx& c, uint32_t lds_at, uint32_t gs_at);
+template <> __device__ __forceinline__ URef<false> make_uref<false>(const Ctx&, uint32_t lds_at, uint32_t) { return URef<false>{lds_at}; }
+template <> __device__ __forceinline__ URef<true> make_uref<true>(const Ctx& c, uint32_t, uint32_t gs_at) { return URef<true>{c.gs, c.gs_off + gs_at}; }
+// plane word `i` of the region starting at `base`
+template <class K> __device__ __forceinline__ WRef<K::G> plane_ref(const Ctx& c, uint32_t base, uint32_t i) {
+    return make_wref<K::G>(c, base + (i << LWSH<K>(c)), base + i * 4u);
+}
+#define NODEW(i) plane_ref<K>(c, c.node0, (i))
+#define CLOGW(i) plane_ref<K>(c, c.clog0, (i))
+#define PAUSEW(i) plane_ref<K>(c, c.pause0, (i))   /* [0] = length, [1..] = paused Runnables in pop order */
+#define GREGW(i) plane_ref<K>(c, c.greg0, (i))
 // connection id_: [0] alive:1 | c_ep:6<<1 | s_ep:6<<7 | tx0:1<<13 rx0<<14 tx1<<15 rx1<<16 | qn0:4<<17 | qn1:4<<21
 //                 [1 + dir] parked receiver: valid:1 | slot:8<<1 | gen:16<<9;  [3 + (dir * Q + i) * 3 ..] {val, arrive lo, arrive hi}
-#define CONNW(id_, f_) SMEM[c.conn0 + (((id_) * c.P.conn_words + (f_)) << LWSH<K>(c))]
+#define CONNW(id_, f_) plane_ref<K>(c, c.conn0, (id_) * c.P.conn_words + (f_))
 // node region: [0] killed mask, [1] paused mask, [2] gen0_killed mask, [3] spawn counter, [4 + n/4] info_gen bytes,
 //              then one word: the seed's base time in seconds into 2022 (time/mod.rs:26-33)
-#define NODE_INFO_GEN(n_) ((NODEW(4 + ((n_) >> 2)) >> (((n_) & 3) * 8)) & 0xff)
-#define SW(c_, s_, f_) SMEM[(c_).sock0 + (((s_) * (c_).P.sock_words + (f_)) << LWSH<K>(c_))]
-#define TU(c_, slot_, u_) LDS128((c_).task0 + (((slot_) * (c_).P.task_units + (u_)) << LWSH<K>(c_)))
-#define TWORD(c_, slot_, u_, k_) SMEM[((c_).task0 + (((slot_) * (c_).P.task_units + (u_)) << LWSH<K>(c_))) * 4 + (k_)]
-template <class K> __device__ __forceinline__ uint32_t* hw_ref(const Ctx& c, uint32_t p) {
-    return K::LIFE ? &SMEM[c.hand0 + (p << LWSH<K>(c))] : &TWORD(c, p, 1, 1);
+#define NODE_INFO_GEN(n_) (((uint32_t)NODEW(4 + ((n_) >> 2)) >> (((n_) & 3) * 8)) & 0xff)
+#define SW(c_, s_, f_) plane_ref<K>((c_), (c_).sock0, (s_) * (c_).P.sock_words + (f_))
+template <class K> __device__ __forceinline__ URef<K::G> tu_ref(const Ctx& c, uint32_t slot, uint32_t u) {
+    return make_uref<K::G>(c, c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c)), c.task0 + (slot * c.P.task_units + u) * 16u);
 }
+template <class K> __device__ __forceinline__ WRef<K::G> tword_ref(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) {
+    return make_wref<K::G>(c, (c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c))) * 4u + k, c.task0 + (slot * c.P.task_units + u) * 16u + k * 4u);
+}
+#define TU(c_, slot_, u_) tu_ref<K>((c_), (slot_), (u_))
+#define TWORD(c_, slot_, u_, k_) tword_ref<K>((c_), (slot_), (u_), (k_))
+// JoinHandle state of prog p.  Workloads with the extended ops keep a handle plane; the others park the word in the
+// otherwise unused unit1.y of task slot p (max_tasks >= n_progs there, geometry.h) and save the plane's LDS.
+template <class K> __device__ __forceinline__ WRef<K::G> hw_ref(const Ctx& c, uint32_t p) {
+    if (K::LIFE) return plane_ref<K>(c, c.hand0, p);
+    return tword_ref<K>(c, p, 1, 1);
+}
+#define HW(p) hw_ref<K>(c, (p))
 // unit1 write-back: x and the deadline only when unit1.y is a handle word (see HW)
 template <class K> __device__ __forceinline__ void tu1_store(const Ctx& c, uint32_t slot, const uint4& u1) {
     if (K::LIFE) { TU(c, slot, 1) = u1; return; }

@@ -68,7 +68,7 @@ struct madsim_hip_ctx {
     std::vector<Tables> tables;
     // per-stream scratch: launches on one stream run in order, launches on different streams may overlap and must
     // not share the timer-heap spill region or the work-queue counter
-    struct Scratch { uint4* spill = nullptr; size_t spill_bytes = 0; unsigned long long* work_ctr = nullptr; };
+    struct Scratch { uint4* spill = nullptr; size_t spill_bytes = 0; unsigned long long* work_ctr = nullptr; uint8_t* gstate = nullptr; size_t gstate_bytes = 0; };
     std::unordered_map<hipStream_t, Scratch> scratch;
     hipStream_t own_stream = nullptr;         // madsim_hip_run_batch_multi launches here so devices overlap
     unsigned long long* d_acc = nullptr;      // 4 x u64 summary accumulators
@@ -133,7 +133,7 @@ void madsim_hip_ctx::close() {
     (void)hipDeviceSynchronize();
     for (auto& t : tables) free_tables(t);
     tables.clear();
-    for (auto& kv : scratch) { if (kv.second.spill) (void)hipFree(kv.second.spill); if (kv.second.work_ctr) (void)hipFree(kv.second.work_ctr); }
+    for (auto& kv : scratch) { if (kv.second.spill) (void)hipFree(kv.second.spill); if (kv.second.work_ctr) (void)hipFree(kv.second.work_ctr); if (kv.second.gstate) (void)hipFree(kv.second.gstate); }
     scratch.clear();
     if (d_acc) (void)hipFree(d_acc);
     if (d_out) (void)hipFree(d_out);
@@ -191,9 +191,20 @@ int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
 }
 
 int madsim_hip_ctx::ensure_scratch(KParams& P, hipStream_t stream, bool work_queue) {
-    P.spill = nullptr; P.work_ctr = nullptr;
-    if (!P.heap_spill && !work_queue) return 0;
+    P.spill = nullptr; P.work_ctr = nullptr; P.gstate = nullptr;
+    if (!P.heap_spill && !work_queue && !P.gstate_mode) return 0;
     Scratch& sc = scratch[stream];
+    if (P.gstate_mode) {                 // per-lane state blocks of the global-state builds (seed_init clears what it needs)
+        size_t need = (size_t)P.gs_stride * P.total_lanes;
+        if (need >= (1ull << 32)) return fail(MADSIM_E_LIMITS, "global state region exceeds 4 GiB: lower the capacities");
+        if (need > sc.gstate_bytes) {
+            if (sc.gstate) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(sc.gstate); }
+            sc.gstate = nullptr; sc.gstate_bytes = 0;
+            HIP_TRY(hipMalloc(&sc.gstate, need));
+            sc.gstate_bytes = need;
+        }
+        P.gstate = sc.gstate;
+    }
     if (P.heap_spill) {
         size_t need = (size_t)P.heap_spill * P.total_lanes * sizeof(uint4);
         if (need >= (1ull << 32)) return fail(MADSIM_E_LIMITS, "heap spill region exceeds 4 GiB: lower heap_spill_slots");
@@ -241,7 +252,7 @@ int madsim_hip_ctx::launch(const madsim_workload_t* w, const madsim_config_t* cf
         if (e) return fail(MADSIM_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         lds_attr = (uint32_t)lds_per_cu;
     }
-    madsim_k_launch_sim(&G.P, G.grid, G.lds_bytes, stream, 0);
+    if (madsim_k_launch_sim(&G.P, G.grid, G.lds_bytes, stream, 0)) return fail(MADSIM_E_LIMITS, "no kernel build for this geometry (select_variant)");
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -507,7 +518,7 @@ int64_t madsim_hip_ctx_trace_seed(madsim_hip_ctx_t* c, const madsim_workload_t* 
         if (madsim_k_set_max_lds((uint32_t)c->lds_per_cu)) return fail(MADSIM_E_HIP, "hipFuncSetAttribute failed");
         c->lds_attr = (uint32_t)c->lds_per_cu;
     }
-    madsim_k_launch_sim(&G.P, 1, G.lds_bytes, nullptr, 1);
+    if (madsim_k_launch_sim(&G.P, 1, G.lds_bytes, nullptr, 1)) return fail(MADSIM_E_LIMITS, "no trace kernel build");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     uint64_t n = 0;
@@ -634,7 +645,9 @@ int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, 
     out->lds_bytes_per_seed = G.lds_per_seed; out->lds_bytes_per_block = G.lds_bytes; out->block_threads = 64 * G.waves_per_block;
     out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
     out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave;
-    out->variant = G.P.lw_shift != 6 ? 8u | 3u : (G.P.heap_spill ? 1u : 0u) | (G.P.lifecycle ? 2u : 0u) | (G.P.rq_in_reg ? 4u : 0u);
+    const madsim_k::VariantSel v = madsim_k::select_variant(G.P, false);
+    out->variant = (v.spill ? 1u : 0u) | (v.feat ? 2u : 0u) | (v.rq ? 4u : 0u) | (v.lws < 0 ? 8u : 0u) | (v.g ? 16u : 0u) | ((uint32_t)v.feat << 8) | ((uint32_t)(v.lws & 0xf) << 16);
+    out->global_bytes_per_seed = G.P.gstate_mode ? G.P.gs_stride : 0;
     return 0;
 }
 

@@ -8,6 +8,13 @@
 
 #define MADSIM_RUNNING 0xffu /* lane-internal: seed still executing */
 
+/* classes of extended ops a kernel variant may carry (Variant<..., FEAT, ...>, KParams.features) */
+#define MADSIM_FEAT_TIME 1  /* timeout(recv_from), t0 family (mark / sleep_until / assert_elapsed), advance, trace_time */
+#define MADSIM_FEAT_CHAN 2  /* connect1 / accept1 / channel send + recv                                               */
+#define MADSIM_FEAT_RPC  4  /* typed RPC call / reply                                                                   */
+#define MADSIM_FEAT_NODE 8  /* kill / restart / pause / resume / abort / is_exit, init programs, restart_on_panic       */
+#define MADSIM_FEAT_ALL  15
+
 namespace madsim_k {
 
 struct KParams {
@@ -39,7 +46,12 @@ struct KParams {
     uint32_t chan_unit;            // index of the task unit holding the (tx, rx) pair state
     uint32_t uses_rpc, rpc_unit;   // typed RPC: index of the task unit holding the response tags
     uint32_t rq_in_reg;        // the ready queue needs no LDS region (register variant)
-    uint32_t lifecycle;        // any kill/restart/pause/resume/abort op, init program or restart_on_panic node
+    // global-state builds (Variant::G): task table + planes of lane g = gs_stride bytes at gstate + g * gs_stride:
+    // [task units: max_tasks x task_units x 16 B][plane words (off_* count from gs_planes, the ready queue stays in LDS)]
+    uint32_t gstate_mode, gs_stride, gs_planes, gs_plane_words;
+    uint8_t* gstate;
+    uint32_t lifecycle;        // any extended op: the extended LDS layout (features != 0)
+    uint32_t features;         // MADSIM_FEAT_* classes the workload needs
     uint32_t uses_pause, has_restart_on_panic, restart_nodes;   // restart_nodes: bit n = NodeBuilder::restart_on_panic
     // batch
     uint64_t seed0, count;
@@ -53,10 +65,53 @@ struct KParams {
     uint64_t* prof;            // profiling builds (tools/experiment): per-phase cycle accumulators
 };
 
+// Kernel variants (Variant<TRACE, SPILL, LWS, FEAT, RQ>): the trace build; for base-op workloads on full 64-lane waves one
+// build per (heap spill, register ready queue) combination plus a runtime-lane-stride build; single-class builds for
+// workloads that only use timeouts (FEAT_TIME) or only the reliable channel (FEAT_CHAN) — a third of the code and
+// fewer registers than the full build; the full build for every lane stride (64/32/16/8 seed lanes per wave, runtime);
+// and the global-state builds (G: task table + planes in a per-lane block of global memory) of the three extended classes.
+#define MADSIM_FOR_EACH_VARIANT(X)                     \
+    X(true, true, -1, MADSIM_FEAT_ALL, false, false)   \
+    X(false, false, 6, 0, false, false)                \
+    X(false, false, 6, 0, true, false)                 \
+    X(false, true, 6, 0, true, false)                  \
+    X(false, true, 6, 0, false, false)                 \
+    X(false, true, -1, 0, false, false)                \
+    X(false, true, -1, MADSIM_FEAT_TIME, false, false) \
+    X(false, true, -1, MADSIM_FEAT_CHAN, false, false) \
+    X(false, false, 6, MADSIM_FEAT_ALL, false, false)  \
+    X(false, true, 6, MADSIM_FEAT_ALL, false, false)   \
+    X(false, true, 5, MADSIM_FEAT_ALL, false, false)   \
+    X(false, true, 4, MADSIM_FEAT_ALL, false, false)   \
+    X(false, true, 3, MADSIM_FEAT_ALL, false, false)   \
+    X(false, true, -1, MADSIM_FEAT_ALL, false, false)  \
+    X(false, true, 6, MADSIM_FEAT_TIME, false, true)   \
+    X(false, true, 6, MADSIM_FEAT_CHAN, false, true)   \
+    X(false, true, 6, MADSIM_FEAT_ALL, false, true)
+
+// Which compiled specialisation of sim_kernel a parameter block runs on (one rule for the launcher and for
+// madsim_hip_geometry's report).  Compiled set = MADSIM_FOR_EACH_VARIANT in sim_kernel.hip.
+struct VariantSel { int trace, spill, lws, feat, rq, g; };
+inline VariantSel select_variant(const KParams& P, bool trace) {
+    const int spill = P.heap_spill > 0, lw = (int)P.lw_shift, feat = (int)P.features;
+    if (trace) return {1, 1, -1, MADSIM_FEAT_ALL, 0, 0};
+    if (feat == 0) {                                                    // base ops only
+        if (lw == 6) return {0, spill, 6, 0, (int)P.rq_in_reg, 0};
+        return {0, 1, -1, 0, 0, 0};                                     // sub-wave lane stride: runtime-stride build
+    }
+    // single-class workloads: a build without the other classes' code
+    const int cls = (feat & ~MADSIM_FEAT_TIME) == 0 ? MADSIM_FEAT_TIME : (feat & ~MADSIM_FEAT_CHAN) == 0 ? MADSIM_FEAT_CHAN : MADSIM_FEAT_ALL;
+    if (P.gstate_mode) return {0, 1, 6, cls, 0, 1};                      // task table + planes in global memory: full waves
+    if (cls != MADSIM_FEAT_ALL) return {0, 1, -1, cls, 0, 0};
+    if (lw == 6) return {0, spill, 6, MADSIM_FEAT_ALL, 0, 0};
+    if (lw >= 3 && lw <= 5) return {0, 1, lw, MADSIM_FEAT_ALL, 0, 0};
+    return {0, 1, -1, MADSIM_FEAT_ALL, 0, 0};
+}
+
 }  // namespace madsim_k
 
 extern "C" {
-void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace);
+int  madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace);
 void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream);
 int  madsim_k_set_max_lds(uint32_t lds_bytes);
 void madsim_k_launch_keyflip(unsigned long long* acc, void* stream);

@@ -47,7 +47,8 @@ namespace madsim_k {
 template <class K>
 __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     const KParams& P = c.P;
-    for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;          // plane 0 is the ready queue: RW spans all planes
+    if (K::G) { for (uint32_t w = 0; w < P.gs_plane_words; w++) gs_store32(c.gs, c.gs_off + P.gs_planes + w * 4, 0); }
+    else for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;     // plane 0 is the ready queue: RW spans all planes
     for (uint32_t t = 0; t < P.max_tasks; t++) { TWORD(c, t, 0, 0) = 0; if (!K::LIFE) TWORD(c, t, 1, 1) = 0; }
     // GlobalRng::new_with_seed -> Xoshiro256PlusPlus::seed_from_u64: SplitMix64 [DEP A.1]
     uint64_t x = seed, z;
@@ -58,7 +59,7 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
     L.ready_len = 0; L.rq = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING; L.ovf = 0; L.main_done = 0;
     L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
     // TimeRuntime::new (time/mod.rs:26-38): base_time draw, before logging is enabled
-    { uint64_t h = L.trace_hash, n = L.log_len; uint32_t bt = gen_range_small<Variant<false, false, K::LWS, false, K::RQ>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n;
+    { uint64_t h = L.trace_hash, n = L.log_len; uint32_t bt = gen_range_small<Variant<false, false, K::LWS, 0, K::RQ>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n;
       if (K::LIFE) NODEW(4 + ((P.n_nodes + 4) >> 2)) = bt; }      // seconds into 2022: SystemTime::now() of MS_OP_TRACE_TIME
     L.trace_hash = FNV_OFFSET; L.obs_hash = FNV_OFFSET; L.log_len = 0;
     // tasks spawned before block_on, then the main task (task/mod.rs:222-235)
@@ -90,17 +91,24 @@ __global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
     c.sockt0 = P.sh_socks;
     const uint32_t wbase = wv * P.wave_words;       // this wave's slice of the workgroup's LDS
     c.heap0 = (P.sh_heap + wbase) / 4 + lane;
-    c.task0 = (P.sh_tasks + wbase) / 4 + lane;
     c.lws = P.lw_shift;
     const uint32_t pl = P.sh_planes + wbase + lane;
     c.ready0 = pl + (P.off_ready << P.lw_shift);
-    c.sock0 = pl + (P.off_socks << P.lw_shift);
-    c.hand0 = pl + (P.off_handles << P.lw_shift);
-    c.node0 = pl + (P.off_nodes << P.lw_shift);
-    c.clog0 = pl + (P.off_clog << P.lw_shift);
-    c.pause0 = pl + (P.off_pause << P.lw_shift);
-    c.greg0 = pl + (P.off_greg << P.lw_shift);
-    c.conn0 = pl + (P.off_conn << P.lw_shift);
+    if (K::G) {                                      // byte offsets inside the lane's global state block
+        c.task0 = 0;
+        c.sock0 = P.gs_planes + P.off_socks * 4; c.hand0 = P.gs_planes + P.off_handles * 4; c.node0 = P.gs_planes + P.off_nodes * 4;
+        c.clog0 = P.gs_planes + P.off_clog * 4; c.pause0 = P.gs_planes + P.off_pause * 4; c.greg0 = P.gs_planes + P.off_greg * 4;
+        c.conn0 = P.gs_planes + P.off_conn * 4;
+    } else {
+        c.task0 = (P.sh_tasks + wbase) / 4 + lane;
+        c.sock0 = pl + (P.off_socks << P.lw_shift);
+        c.hand0 = pl + (P.off_handles << P.lw_shift);
+        c.node0 = pl + (P.off_nodes << P.lw_shift);
+        c.clog0 = pl + (P.off_clog << P.lw_shift);
+        c.pause0 = pl + (P.off_pause << P.lw_shift);
+        c.greg0 = pl + (P.off_greg << P.lw_shift);
+        c.conn0 = pl + (P.off_conn << P.lw_shift);
+    }
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
     const uint32_t glane = ((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane;
     c.spill_off = glane * 16u;
@@ -108,6 +116,12 @@ __global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
     c.spill.base = P.spill;
 #else   // gfx9 raw buffer, 32-bit data format; num_records in bytes (the host keeps the region below 4 GiB)
     c.spill.rsrc = __builtin_amdgcn_make_buffer_rsrc(P.spill, 0, (uint32_t)((uint64_t)P.heap_spill * P.total_lanes * 16u), 0x00020000);
+#endif
+    c.gs_off = glane * P.gs_stride;
+#ifdef MADSIM_EMU
+    c.gs.base = (uint4*)P.gstate;
+#else
+    c.gs.rsrc = __builtin_amdgcn_make_buffer_rsrc(P.gstate, 0, (uint32_t)((uint64_t)P.gs_stride * P.total_lanes), 0x00020000);
 #endif
     c.tlog = P.trace_log;
 
@@ -160,9 +174,9 @@ __global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
             PROBE(1);
             REG(26);
             bool parked = false;
-            if (K::LIFE && (u0.x & (TF_CANCEL | TF_KILLED))) {   // task/mod.rs:269-273: drop(runnable)
+            if (K::FN && (u0.x & (TF_CANCEL | TF_KILLED))) {   // task/mod.rs:269-273: drop(runnable)
                 task_finish<K>(c, L, slot, H_CANCELLED);
-            } else if (K::LIFE && P.uses_pause && ((NODEW(1) >> (PROGW(c, u0.x >> 24) & 0xff)) & 1)) {
+            } else if (K::FN && P.uses_pause && ((NODEW(1) >> (PROGW(c, u0.x >> 24) & 0xff)) & 1)) {
                 uint32_t n = PAUSEW(0);                       // :274-277: park the Runnable; no poll, no time advance
                 PAUSEW(1 + n) = slot; PAUSEW(0) = n + 1;
                 L.steps--;
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
                 }
             }
             PROBE(2);
-            if (K::LIFE && panicked && P.has_restart_on_panic) {   // task/mod.rs:289-314
+            if (K::FN && panicked && P.has_restart_on_panic) {   // task/mod.rs:289-314
                 uint32_t node = PROGW(c, u0.x >> 24) & 0xff;
                 if ((P.restart_nodes >> node) & 1) {
                     // async-task's panic guard already dropped the future and notified the awaiter
@@ -271,42 +285,19 @@ __global__ void keyflip_kernel(unsigned long long* acc) { acc[0] ^= 0x8000000000
 }  // namespace madsim_k
 
 #ifndef MADSIM_EMU
-// Kernel variants: the trace build, a fully generic build (runtime lane stride), for full 64-lane waves one build
-// per (heap spill, extended ops) combination so that workloads only pay for what they use, and the full-featured
-// build again for each sub-wave lane stride (32/16/8 seed lanes per wave).
-#define MADSIM_FOR_EACH_VARIANT(X)      \
-    X(true, true, -1, true)             \
-    X(false, true, -1, true)            \
-    X(false, false, 6, false)           \
-    X(false, false, 6, false, true)     \
-    X(false, true, 6, false, true)      \
-    X(false, true, 6, false)            \
-    X(false, false, 6, true)            \
-    X(false, true, 6, true)             \
-    X(false, true, 5, true)             \
-    X(false, true, 4, true)             \
-    X(false, true, 3, true)
-
-extern "C" void madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace) {
+extern "C" int madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace) {
     using namespace madsim_k;
-    const bool spill = P->spill != nullptr && P->heap_spill > 0;
-    const bool life = P->lifecycle != 0;
+    const VariantSel v = select_variant(*P, trace != 0);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(...) hipLaunchKernelGGL((sim_kernel<Variant<__VA_ARGS__>>), dim3(grid), dim3(64 * P->waves_per_block), lds_bytes, st, *P)
-    if (trace) LAUNCH(true, true, -1, true);
-#ifndef MADSIM_K_NO_LWS_VARIANTS
-    else if (P->lw_shift == 5) LAUNCH(false, true, 5, true);     // sub-wave occupancy (large per-seed state): the lane
-    else if (P->lw_shift == 4) LAUNCH(false, true, 4, true);     // stride stays a compile-time shift
-    else if (P->lw_shift == 3) LAUNCH(false, true, 3, true);
-#endif
-    else if (P->lw_shift != 6) LAUNCH(false, true, -1, true);
-    else if (!spill && !life && P->rq_in_reg) LAUNCH(false, false, 6, false, true);
-    else if (!spill && !life) LAUNCH(false, false, 6, false);
-    else if (spill && !life && P->rq_in_reg) LAUNCH(false, true, 6, false, true);
-    else if (spill && !life) LAUNCH(false, true, 6, false);
-    else if (!spill && life) LAUNCH(false, false, 6, true);
-    else LAUNCH(false, true, 6, true);
-#undef LAUNCH
+    bool launched = false;
+#define TRY_LAUNCH(T_, S_, L_, F_, R_, G_)                                                                               \
+    if (!launched && v.trace == (int)(T_) && v.spill == (int)(S_) && v.lws == (L_) && v.feat == (F_) && v.rq == (int)(R_) && v.g == (int)(G_)) { \
+        hipLaunchKernelGGL((sim_kernel<Variant<T_, S_, L_, F_, R_, G_>>), dim3(grid), dim3(64 * P->waves_per_block), lds_bytes, st, *P); \
+        launched = true;                                                                                                 \
+    }
+    MADSIM_FOR_EACH_VARIANT(TRY_LAUNCH)
+#undef TRY_LAUNCH
+    return launched ? 0 : -1;      // select_variant named a build that is not compiled: a bug, never a silent substitute
 }
 
 extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream) {

@@ -272,9 +272,9 @@ def geometry(workload, limits=None):
 def variant_name(g):
     """The sim_kernel specialisation a madsim_geometry_t selects (madsim_k_launch_sim's dispatch), as rocprofv3 names it."""
     b = lambda x: "true" if x else "false"
-    if g.variant & 8:
-        return f"sim_kernel<Variant<false,true,{g.lanes_per_wave.bit_length() - 1},true,false>>"
-    return f"sim_kernel<Variant<false,{b(g.variant & 1)},6,{b(g.variant & 2)},{b(g.variant & 4)}>>"
+    lws = (g.variant >> 16) & 0xf
+    return (f"sim_kernel<Variant<false, {b(g.variant & 1)}, {-1 if lws == 15 else lws}, {(g.variant >> 8) & 0xf}, "
+            f"{b(g.variant & 4)}, {b(g.variant & 16)}>>")
 
 
 class Builder:

@@ -51,6 +51,8 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
     P.insns = (const uint4*)T.insns.data(); P.progs = T.progs.data(); P.socks = T.socks.data(); P.dur_table = T.durs.data();
     std::vector<uint4> spill((size_t)P.heap_spill * P.total_lanes + 1);
     P.spill = P.heap_spill ? spill.data() : nullptr;
+    std::vector<uint4> gstate((size_t)P.gs_stride * P.total_lanes / 16 + 4);
+    P.gstate = P.gstate_mode ? (uint8_t*)gstate.data() : nullptr;
     P.seed0 = seed0; P.count = count; P.out = out;
     uint64_t dummy_len = 0;
     P.trace_log = tlog; P.trace_cap = tcap; P.trace_len = tlen ? tlen : &dummy_len;
@@ -71,15 +73,13 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
 #endif
             blockIdx.x = b / G.waves_per_block; threadIdx.x = (b % G.waves_per_block) * 64 + t; emu_smem = base;
             using namespace madsim_k;
-            const bool spill = P.spill != nullptr, life = P.lifecycle != 0;
-            if (tlog) sim_kernel<Variant<true, true, -1, true>>(P);
-            else if (P.lw_shift != 6) sim_kernel<Variant<false, true, -1, true>>(P);
-            else if (!spill && !life && P.rq_in_reg) sim_kernel<Variant<false, false, 6, false, true>>(P);
-            else if (!spill && !life) sim_kernel<Variant<false, false, 6, false>>(P);
-            else if (spill && !life && P.rq_in_reg) sim_kernel<Variant<false, true, 6, false, true>>(P);
-            else if (spill && !life) sim_kernel<Variant<false, true, 6, false>>(P);
-            else if (!spill && life) sim_kernel<Variant<false, false, 6, true>>(P);
-            else sim_kernel<Variant<false, true, 6, true>>(P);
+            const VariantSel v = select_variant(P, tlog != nullptr);      // the same build the GPU launcher would pick
+            bool ran = false;
+#define EMU_TRY(T_, S_, L_, F_, R_, G_) \
+            if (!ran && v.trace == (int)(T_) && v.spill == (int)(S_) && v.lws == (L_) && v.feat == (F_) && v.rq == (int)(R_) && v.g == (int)(G_)) { sim_kernel<Variant<T_, S_, L_, F_, R_, G_>>(P); ran = true; }
+            MADSIM_FOR_EACH_VARIANT(EMU_TRY)
+#undef EMU_TRY
+            if (!ran) { emu_err = "select_variant named a build that is not compiled"; return MADSIM_E_LIMITS; }
         }
 #ifdef MADSIM_EMU_REGIONS
         emu_lane_log = nullptr;

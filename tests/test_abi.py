@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(A.Insn) == 8 and C.sizeof(A.Result) == 48 and C.sizeof(A.Summary) == 48
-    assert C.sizeof(A.Limits) == 56 and C.sizeof(A.Geometry) == 40
+    assert C.sizeof(A.Limits) == 56 and C.sizeof(A.Geometry) == 44
     assert A.Result.clock_ns.offset == 8 and A.Result.trace_hash.offset == 32 and A.Result.obs_hash.offset == 40
     for name, val in A.OP.items():
         m = re.search(r"MS_OP_%s = (\d+)," % name, HEADER)

@@ -108,6 +108,23 @@ def test_baseline_config_shaped_workloads():
     assert (o["verdict"] == A.PASS).all()
     o = _same(W.streaming_topology(), 0, 96, None, W.streaming_topology_limits())        # configs[4] shape
     assert (o["verdict"] == A.PASS).all()
+    o = _same(W.timer_storm(), 0, 200, None, W.timer_storm_limits(4))      # base ops on the runtime-lane-stride build, heap mostly spilled
+    assert (o["verdict"] == A.PASS).all()
+
+
+def test_every_bench_workload_runs_on_the_build_its_ops_need():
+    """select_variant: single-class workloads get the pruned builds (timeouts only / channel only), base-op workloads never
+    pay for extended ops, and only mixed workloads take the full build."""
+    from madsim_amd import runtime
+    want = {"pingpong": (0, 6, 0), "timers": (0, 15, 0), "raft": (1, 6, 16), "kv": (2, 6, 16), "topo": (15, 6, 16)}
+    for name, (feat, lws, glob) in want.items():
+        w, lim, _ = W.bench_case(name)
+        g = runtime.geometry(w, lim)
+        assert ((g.variant >> 8) & 0xf, (g.variant >> 16) & 0xf, g.variant & 16) == (feat, lws, glob), (name, hex(g.variant))
+        assert (g.global_bytes_per_seed > 0) == bool(glob) and (not glob or g.lanes_per_wave == 64)
+        lim.state_mem = A.STATE_LDS                     # the LDS-resident layout stays selectable
+        g = runtime.geometry(w, lim)
+        assert g.variant & 16 == 0 and g.global_bytes_per_seed == 0
 
 
 def test_fuzz_rpc_workloads():
@@ -121,3 +138,43 @@ def test_fuzz_rpc_workloads():
         ok = (o == e) | (e["verdict"] == A.OVERFLOW)
         assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
         assert (e["verdict"] == A.OVERFLOW).mean() < 0.1
+
+
+def _global(lim=None):
+    """The same limits with the task table and planes forced into the per-lane global-memory block (Variant::G)."""
+    g = A.Limits()
+    if lim is not None:
+        for f, _ in A.Limits._fields_:
+            setattr(g, f, getattr(lim, f))
+    g.lanes_per_wave, g.state_mem = 0, A.STATE_GLOBAL
+    return g
+
+
+@pytest.mark.parametrize("name", sorted(LW.ALL))
+def test_global_state_layout_lifecycle(name):
+    """Every reference lifecycle / channel / RPC test again with per-seed state in global memory instead of LDS."""
+    o = _same(LW.ALL[name](), 0, 96, LW.config(name), _global(LW.limits(name)))
+    assert (o["verdict"] == (A.PANIC if name in LW.EXPECT_PANIC else A.PASS)).all()
+
+
+def test_global_state_layout_fuzz():
+    for k in range(120):
+        gen = fuzz.random_lifecycle_workload if k % 2 else fuzz.random_rpc_workload
+        w, cfg, desc = gen(random.Random(47000 + k))
+        lim = _global(fuzz.generous_limits()); lim.max_tasks = 24
+        o, _ = oracle.run_batch(w, k * 7, 12, cfg, lim)
+        e = emu.run_batch(w, k * 7, 12, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+
+
+def test_global_state_is_chosen_by_footprint_and_can_be_forced_either_way():
+    from madsim_amd import runtime
+    small = LW.ALL["kill"]()                       # extended ops, tiny state: stays in LDS on full waves
+    assert runtime.geometry(small).variant & 16 == 0
+    assert runtime.geometry(small, _global()).variant & 16
+    lim = A.Limits(); lim.state_mem = A.STATE_GLOBAL
+    assert runtime.geometry(W.pingpong(4, 4), lim).variant & 16 == 0      # base-op workloads have no global-state build
+    lim = A.Limits(); lim.state_mem = 3
+    with pytest.raises(runtime.MadsimHipError, match="state_mem"):
+        runtime.geometry(small, lim)

@@ -356,7 +356,7 @@ def test_register_ready_queue_with_heap_spill(hip):
     """Variant<SPILL, RQ>: 2 LDS heap slots + HBM spill under the register-resident ready queue."""
     lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots, lim.mbox_regs, lim.mbox_msgs = 2, 6, 1, A.LIMIT_NONE
     w = W.pingpong(4, 32)
-    assert hip.geometry(w, lim).variant == 5
+    assert hip.geometry(w, lim).variant & 0xfff == 5          # heap spill + register ready queue, base ops
     _cmp(hip, w, 424242, 4096, None, lim)
 
 
@@ -421,7 +421,7 @@ def test_bench_configuration_pingpong_is_oracle_checked(hip, n_streams):
     import torch
     w, lim, _ = W.bench_case("pingpong")
     g = hip.geometry(w, lim)
-    assert g.variant == 4 and g.lanes_per_wave == 64 and g.heap_lds_slots == 4 and g.heap_spill_slots == 0
+    assert g.variant & 0xfff == 4 and hip.variant_name(g) == "sim_kernel<Variant<false, false, 6, 0, true, false>>" and g.lanes_per_wave == 64 and g.heap_lds_slots == 4 and g.heap_spill_slots == 0
     n = W.BENCH_SEEDS_PER_GPU
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     bufs = [torch.zeros(n * 48, dtype=torch.uint8, device="cuda") for _ in range(2 * n_streams)]
@@ -548,3 +548,54 @@ def test_ref_twin_workloads_gpu(hip):
     for name in sorted(T.ALL):
         _cmp(hip, T.ALL[name](), 0, 512)
     _cmp(hip, T.ALL["pingpong4"](), 0, 512, A.Config.default(packet_loss_rate=0.01))
+
+
+def _global_limits(lim=None):
+    g = A.Limits()
+    if lim is not None:
+        for f, _ in A.Limits._fields_:
+            setattr(g, f, getattr(lim, f))
+    g.lanes_per_wave, g.state_mem = 0, A.STATE_GLOBAL
+    return g
+
+
+@pytest.mark.parametrize("name", sorted(LW.ALL))
+def test_global_state_lifecycle_reference_tests_gpu(hip, name):
+    """The reference's lifecycle / channel / RPC tests with the task table and planes in the per-lane global-memory block
+    (Variant::G) instead of LDS: same results, bit for bit."""
+    lim = _global_limits(LW.limits(name))
+    assert hip.geometry(LW.ALL[name](), lim).variant & 16
+    got, _ = _cmp(hip, LW.ALL[name](), 0, 2048, LW.config(name), lim)
+    assert (got["verdict"] == (A.PANIC if name in LW.EXPECT_PANIC else A.PASS)).all()
+
+
+def test_global_state_fuzz_gpu(hip):
+    import random
+    from tests import fuzz
+    for k in range(160):
+        gen = fuzz.random_lifecycle_workload if k % 2 else fuzz.random_rpc_workload
+        w, cfg, desc = gen(random.Random(52000 + k))
+        lim = _global_limits(fuzz.generous_limits()); lim.max_tasks = 24
+        got, _ = hip.run_batch(w, k * 23, 128, cfg, lim)
+        want, _ = oracle.run_batch(w, k * 23, 128, cfg, lim)
+        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+
+
+@pytest.mark.parametrize("name", ["raft", "kv", "topo"])
+def test_global_and_lds_state_agree_at_batch_size(hip, name):
+    """configs[2]/[3]/[4]-shaped workloads, 32 768 seeds: the global-state build (what bench.py runs) and the LDS-resident
+    build give identical results; 96 sampled seeds against the oracle."""
+    w, lim, _ = W.bench_case(name)
+    n = 32768
+    assert hip.geometry(w, lim).variant & 16
+    a, sa = hip.run_batch(w, 77_000_000, n, None, lim)
+    lim.state_mem = A.STATE_LDS
+    assert hip.geometry(w, lim).variant & 16 == 0
+    b, sb = hip.run_batch(w, 77_000_000, n, None, lim)
+    both = (a["verdict"] != A.OVERFLOW) & (b["verdict"] != A.OVERFLOW)
+    assert (a[both] == b[both]).all() and both.mean() > 0.99
+    idx = np.arange(0, n, 343)
+    want = np.concatenate([oracle.run_batch(w, 77_000_000 + int(i), 1, None, lim)[0] for i in idx])
+    ok = (a[idx] == want) | (a[idx]["verdict"] == A.OVERFLOW)
+    assert ok.all()
