@@ -47,6 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--loss", type=float, default=0.0, help="packet_loss_rate of the timed batches (0 = Config::default())")
     ap.add_argument("--first-fail-loss", type=float, default=0.01, help="packet_loss_rate of the first-fail leg (SURVEY 8d)")
     ap.add_argument("--sched", type=int, default=0, help="0 = static seed striding, 1 = per-launch atomic work queue (madsim_limits_t.sched)")
+    ap.add_argument("--state-mem", type=int, default=0, help="madsim_limits_t.state_mem: 0 auto, 1 LDS, 2 global-memory state block")
     ap.add_argument("--lpw", type=int, default=0, help="seed-carrying lanes per wave (0 = library auto)")
     ap.add_argument("--nodes", type=int, default=4, help="ping-pong nodes (experiments; the bench line is quoted on 4)")
     ap.add_argument("--streams", type=int, default=2,
@@ -156,6 +157,10 @@ def main():
     w, lim, wname = workload.bench_case(args.workload, args.nodes, workload.BENCH_ROUNDS, args.heap_lds)
     headline = args.workload == "pingpong" and args.nodes == workload.BENCH_NODES
     lim.lanes_per_wave = args.lpw
+    lim.state_mem = args.state_mem
+    if "MADSIM_BENCH_HEAP_LDS" in os.environ:            # experiments: move timer-heap entries between LDS and the HBM spill region
+        n = int(os.environ["MADSIM_BENCH_HEAP_LDS"])
+        lim.heap_spill_slots, lim.heap_lds_slots = lim.heap_spill_slots + max(0, lim.heap_lds_slots - n), n
     lim.sched = int(os.environ.get("MADSIM_BENCH_SCHED", args.sched))     # work distribution inside a launch (experiments)
     if args.generic:
         lim.heap_spill_slots = max(lim.heap_spill_slots, 8)

@@ -14,7 +14,8 @@ namespace madsim_geo {
 
 using madsim_k::KParams;
 
-struct Device { int num_cus = 256; size_t lds_per_cu = 160 * 1024; };
+// vgprs: VGPRs per lane of a kernel build as the loaded code object reports them (null / 0 = unknown: a static estimate)
+struct Device { int num_cus = 256; size_t lds_per_cu = 160 * 1024; int (*vgprs)(const madsim_k::VariantSel*) = nullptr; };
 
 inline int fail(std::string* err, int code, const std::string& msg) { if (err) *err = msg; return code; }
 
@@ -188,7 +189,9 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             P.gs_plane_words = P.lane_words;
             P.gs_planes = P.max_tasks * P.task_units * 16;
             P.gs_stride = (P.gs_planes + P.gs_plane_words * 4 + 63) & ~63u;
-            P.lane_words = P.max_tasks;
+            P.off_amask = P.max_tasks;                         // LDS planes: ready queue, alive-task mask, owned-socket mask
+            P.off_omask = P.off_amask + (P.max_tasks + 31) / 32;
+            P.lane_words = P.off_omask + 2;
         }
         P.sh_insns = 0;
         P.sh_progs = P.sh_insns + 4 * P.n_insns;
@@ -214,8 +217,21 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             while (lw > 8 && blocks(lw) < 4) lw >>= 1;
         }
         if (P.gstate_mode) { if (!L.lanes_per_wave) lw = 64; break; }
+        // extended-op workloads only: a base-op ping-pong iteration is ~11k cycles and 26 G iterations/s would need
+        // > 15 TB/s of 64-byte sector traffic (measured: 3.2 ms per batch against 1.99 ms LDS-resident, profiles/r2_experiments.md)
         const bool can_g = P.lifecycle && !trace && L.state_mem != MADSIM_STATE_LDS;
-        if (can_g && (L.state_mem == MADSIM_STATE_GLOBAL || (lw != 64 && !L.lanes_per_wave))) { P.gstate_mode = 1; continue; }
+        if (can_g && (L.state_mem == MADSIM_STATE_GLOBAL || (lw != 64 && !L.lanes_per_wave))) {
+            P.gstate_mode = 1;
+            // LDS now holds little more than the top of the timer heap.  Keep as much of the requested LDS quota as still
+            // lets eight full waves share a CU (two 4-wave workgroups, each with its copy of the tables): every level that
+            // stays in LDS is one global round trip less per sift (measured on the election loop: 16 -> 8 LDS entries costs
+            // 18 %, a seventh-wave-only geometry as much).  The rest moves to the coalesced spill region, same capacity.
+            const size_t per_seed = (g.lds_per_cu / 2 - sh_bytes) / (4 * 64);
+            const size_t fixed = 4 * ((size_t)P.max_tasks + (P.max_tasks + 31) / 32 + 2);
+            uint32_t fit = per_seed > fixed + 64 ? (uint32_t)((per_seed - fixed) / 16) : 4u;
+            if (P.heap_lds > fit) { P.heap_spill += P.heap_lds - fit; P.heap_lds = fit; }
+            continue;
+        }
         if (lw == 64 || !P.rq_in_reg) break;
     }
     if (P.gstate_mode && lw != 64) return fail(err, MADSIM_E_LIMITS, "global state (state_mem = 2) runs full 64-lane waves only");
@@ -234,8 +250,12 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     auto lds_alloc = [&](uint32_t w2) { size_t b = (size_t)(P.sh_heap + w2 * P.wave_words) * 4; return (b + 1279) / 1280 * 1280; };
     // VGPR budget (tools/kernel_meta.sh): base builds ~110 VGPRs = 4 waves per SIMD, single-class builds 133 / 151 = 3,
     // the full extended build ~180 = 2
-    const int vfeat = madsim_k::select_variant(P, trace).feat;
-    const uint32_t cap = vfeat == 0 ? 16u : (vfeat == MADSIM_FEAT_TIME || vfeat == MADSIM_FEAT_CHAN) ? 12u : 8u;
+    const madsim_k::VariantSel vsel = madsim_k::select_variant(P, trace);
+    uint32_t cap = vsel.feat == 0 ? 16u : (vsel.feat == MADSIM_FEAT_TIME || vsel.feat == MADSIM_FEAT_CHAN) ? 12u : 8u;
+    if (g.vgprs) {                       // 512 VGPRs per SIMD lane, allocated in blocks of 8; at most 8 waves per SIMD
+        int r = g.vgprs(&vsel);
+        if (r > 0) { uint32_t per_simd = 512u / (uint32_t)((r + 7) & ~7); cap = 4u * (per_simd > 8 ? 8u : per_simd < 1 ? 1u : per_simd); }
+    }
     auto waves_at = [&](uint32_t w2) {
         uint32_t blocks = (uint32_t)(g.lds_per_cu / lds_alloc(w2));
         return blocks * w2 < cap ? blocks * w2 : cap;

@@ -11,8 +11,17 @@ namespace madsim_k {
 template <class K>
 __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record, bool via_handle = false) {
     uint32_t slot = 0;
-    while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
+    if (K::G) {                                              // first free slot = first zero bit of the alive mask (LDS)
+        slot = c.P.max_tasks;
+        for (uint32_t wi = 0; wi < (c.P.max_tasks + 31) / 32; wi++) {
+            uint32_t free_bits = ~AMASK(wi);
+            if (free_bits) { slot = wi * 32 + (uint32_t)__builtin_ctz(free_bits); break; }
+        }
+    } else {
+        while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
+    }
     if (slot >= c.P.max_tasks) { L.ovf = 1; return 0xffffffffu; }
+    if (K::G) AMASK(slot >> 5) |= 1u << (slot & 31);
     uint32_t gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
     uint32_t pw = PROGW(c, prog);
     uint32_t node = pw & 0xff;
@@ -46,10 +55,12 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
         uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
         if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
     }
-    {
+    if (f & TF_OWNER) {                                        // BindGuards this task holds drop with its future
         uint32_t own = slot | (gen << 16);
         for (uint32_t i = 0; i < c.P.n_socks; i++) {
+            if (K::G && !((OMASK(i >> 5) >> (i & 31)) & 1)) continue;      // never bound by a task that is still around
             if (SW(c, i, 1) != own) continue;
+            if (K::G) OMASK(i >> 5) &= ~(1u << (i & 31));
             // BindGuard::drop (net/mod.rs:483-493), skipped when the binder's NodeInfo is killed
             if (!(f & TF_KILLED) && (SW(c, i, 0) & 1)) SW(c, i, 0) &= ~1u;
             if (K::FC && c.P.uses_chan && (SW(c, i, 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, i);
@@ -59,6 +70,7 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
     if (h == (H_RUNNING | (slot << 8) | (gen << 16))) { HW(prog) = (h & ~3u) | outcome; if (prog == 0) L.main_done = 1; }
     uint32_t link = TWORD(c, slot, 1, 0);
     TWORD(c, slot, 0, 0) = f & ~(TF_ALIVE | TF_SCHED | TF_RUN | TF_INBOX);
+    if (K::G) AMASK(slot >> 5) &= ~(1u << (slot & 31));
     uint32_t j = (link >> 8) & 0xff;
     if (j != 0xff) wake<K>(c, L, j, link >> 16);              // async-task notifies the awaiter
 }

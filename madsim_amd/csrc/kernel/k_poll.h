@@ -32,6 +32,12 @@ __device__ __forceinline__ uint32_t loss_always_at(const KParams& P, uint32_t i)
     return i == 0 ? P.loss_table_always[0] : i == 1 ? P.loss_table_always[1] : i == 2 ? P.loss_table_always[2] : P.loss_table_always[3];
 }
 
+// A registration word identifies its receiver by 8 bits of receive sequence number and 8 bits of task generation.  A dead
+// registration (timed-out / dropped receive) equal to a NEW word — which would make it look live — can only exist once one
+// of the two has wrapped: this task's rxseq (TF_RXWRAP) or its slot's generation (>= 256 instances).  Only then is the
+// mailbox scanned for a twin (=> MADSIM_OVERFLOW, never a different answer).
+__device__ __forceinline__ bool may_have_twin(uint32_t flags, uint32_t gen) { return (flags & TF_RXWRAP) || gen > 0xff; }
+
 __device__ __forceinline__ bool is_light(uint32_t op) {
     return op == MS_OP_ASSERT_VAL || op == MS_OP_DJNZ || op == MS_OP_SET || op == MS_OP_JMP || op == MS_OP_TRACE || op == MS_OP_JEQ;
 }
@@ -77,6 +83,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         uint64_t d2 = u64of(u2.z, u2.w);
         if (L.clock >= d2) {                                 // Err(Elapsed): the recv future is dropped
             u1.x = (u1.x & ~0xffu) | (((u1.x & 0xff) + 1) & 0xff); u1_dirty = true;   // its oneshot::Receiver is gone
+            if ((u1.x & 0xff) == 0) u0.x |= TF_RXWRAP;
             u0.x &= ~TF_INBOX;
             u0.w = MADSIM_VAL_TIMEOUT;
             return true;
@@ -110,10 +117,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 }
                 // recv_from_raw(rsp_tag): Mailbox::recv (endpoint.rs:353-362); no queued message can carry a fresh tag
                 u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
+                if (rxseq == 0) u0.x |= TF_RXWRAP;
                 u0.x &= ~TF_INBOX;
                 uint32_t h = SW(c, ca, 0);
                 uint32_t nreg = (h >> 9) & 0xff;
-                for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) L.ovf = 1;   // 8-bit rxseq wrapped onto a dead twin
+                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) L.ovf = 1;   // 8-bit rxseq wrapped onto a dead twin
                 if (nreg >= P.mbox_regs) L.ovf = 1;
                 else {
                     SW(c, ca, 2 + nreg) = reg;
@@ -141,7 +149,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             uint4 u2 = TU(c, slot, 2);
             uint64_t d2 = u64of(u2.z, u2.w);
             if (L.clock >= d2) {                             // Err(Elapsed) -> TimedOut: the call future is dropped
-                if (sub >= 2) { u1.x = (u1.x & ~0xffu) | (((u1.x & 0xff) + 1) & 0xff); u1_dirty = true; u0.x &= ~TF_INBOX; }
+                if (sub >= 2) { u1.x = (u1.x & ~0xffu) | (((u1.x & 0xff) + 1) & 0xff); u1_dirty = true; u0.x &= ~TF_INBOX; if ((u1.x & 0xff) == 0) u0.x |= TF_RXWRAP; }
                 u0.w = MADSIM_VAL_TIMEOUT;
                 return true;
             }
@@ -258,6 +266,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     uint32_t h = SW(c, a, 0);
                     SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);     // bound, gen+1, empty mailbox
                     SW(c, a, 1) = slot | (gen << 16);
+                    u0.x |= TF_OWNER;
+                    if (K::G) OMASK(a >> 5) |= 1u << (a & 31);
                     if (K::FC && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
                 } else if (op == MS_OP_SEND || op == MS_OP_REPLY || (K::FR && op == MS_OP_RPC_REPLY)) {   // net/mod.rs:307-331
                     REG(6);
@@ -348,6 +358,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 uint32_t tag = b >> 8;
                 uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;
                 u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
+                if (rxseq == 0) u0.x |= TF_RXWRAP;
                 u0.x &= ~TF_INBOX;
                 uint32_t h = SW(c, a, 0);
                 uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
@@ -368,7 +379,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
                     // dead registrations (timed-out / dropped receives, extended ops only) stay in the Vec like the
                     // reference's; an 8-bit rxseq that wraps onto one of them would make it look live: overflow, never a different answer
-                    if (K::FT || K::FN) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;
+                    if ((K::FT || K::FN) && may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;
                     SW(c, a, 2 + nreg) = reg;
                     SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
                     sub = 1;
@@ -386,6 +397,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             TU(c, slot, 2) = u2;
             uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;       // Mailbox::recv (endpoint.rs:353-362)
             u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
+            if (rxseq == 0) u0.x |= TF_RXWRAP;
             u0.x &= ~TF_INBOX;
             uint32_t h = SW(c, a, 0);
             uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
@@ -405,7 +417,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 L.ovf = 1;
             } else {
                 const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
-                for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;   // rxseq wrapped onto a dead twin
+                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;   // rxseq wrapped onto a dead twin
                 SW(c, a, 2 + nreg) = reg;
                 SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
             }

@@ -29,7 +29,9 @@ namespace madsim_k {
 //   unit2 {x: t0 lo, y: t0 hi, z/w: timeout()'s deadline}   (only when the workload uses MS_OP_MARK / timeouts)
 //   unit[P.chan_unit] {x: conn:8 | side:1 | backoff ms:16, y: staged payload, z/w: arrive}   (reliable channel)
 //   unit[P.rpc_unit]  {x: rsp_tag in hand, y: rsp_tag staged with the oneshot value}        (typed RPC)
-enum : uint32_t { TF_ALIVE = 1, TF_SCHED = 2, TF_RUN = 4, TF_KILLED = 8, TF_CANCEL = 16, TF_INBOX = 32 };
+enum : uint32_t { TF_ALIVE = 1, TF_SCHED = 2, TF_RUN = 4, TF_KILLED = 8, TF_CANCEL = 16, TF_INBOX = 32,
+                  TF_RXWRAP = 64 /* this task's 8-bit receive sequence number has wrapped at least once */,
+                  TF_OWNER = 128 /* this task has bound an Endpoint: its finish must look for sockets to close */ };
 enum : uint32_t { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3 };
 enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 
@@ -123,12 +125,18 @@ struct Ctx {
     // bases (sock0, hand0, node0, clog0, pause0, greg0, conn0) are then BYTE offsets inside that block
     SpillRef gs;
     uint32_t gs_off;
+    // K::G builds keep two small indexes in LDS so the common scans never walk global memory: bit t of the alive mask =
+    // task slot t holds a live task (spawn's free-slot search), bit s of the owner mask = socket s was bound by a task that
+    // has not finished yet (task_finish's "which endpoints did this task own" search)
+    uint32_t amask0, omask0;
     uint8_t* tlog;       // trace mode only
     __device__ Ctx(const KParams& p) : P(p) {}
 };
 
 template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { return K::LWS >= 0 ? (uint32_t)K::LWS : c.lws; }
 #define RW(i) SMEM[c.ready0 + ((i) << LWSH<K>(c))]
+#define AMASK(i) SMEM[c.amask0 + ((i) << LWSH<K>(c))]
+#define OMASK(i) SMEM[c.omask0 + ((i) << LWSH<K>(c))]
 
 // ---- the lane's state block in global memory (K::G builds) -----------------------------------------------------------
 // Reached through a buffer resource like the heap spill region (byte offsets in a VGPR): with plain pointers the compiler
@@ -136,6 +144,7 @@ template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { retu
 // `off` = byte offset in the state buffer (the lane's gs_off already added).
 __device__ __forceinline__ uint32_t gs_load32(const SpillRef& gs, uint32_t off) {
 #ifdef MADSIM_EMU
+    EMU_GSTAT(off, 0);
     return *(const uint32_t*)((const uint8_t*)gs.base + off);
 #else
     return __builtin_amdgcn_raw_buffer_load_b32(gs.rsrc, off, 0, 0);
@@ -143,6 +152,7 @@ __device__ __forceinline__ uint32_t gs_load32(const SpillRef& gs, uint32_t off) 
 }
 __device__ __forceinline__ void gs_store32(const SpillRef& gs, uint32_t off, uint32_t v) {
 #ifdef MADSIM_EMU
+    EMU_GSTAT(off, 1);
     *(uint32_t*)((uint8_t*)gs.base + off) = v;
 #else
     __builtin_amdgcn_raw_buffer_store_b32(v, gs.rsrc, off, 0, 0);
@@ -150,6 +160,7 @@ __device__ __forceinline__ void gs_store32(const SpillRef& gs, uint32_t off, uin
 }
 __device__ __forceinline__ uint4 gs_load128(const SpillRef& gs, uint32_t off) {
 #ifdef MADSIM_EMU
+    EMU_GSTAT(off, 2);
     return *(const uint4*)((const uint8_t*)gs.base + off);
 #else
     u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(gs.rsrc, off, 0, 0);
@@ -158,6 +169,7 @@ __device__ __forceinline__ uint4 gs_load128(const SpillRef& gs, uint32_t off) {
 }
 __device__ __forceinline__ void gs_store128(const SpillRef& gs, uint32_t off, const uint4& e) {
 #ifdef MADSIM_EMU
+    EMU_GSTAT(off, 3);
     *(uint4*)((uint8_t*)gs.base + off) = e;
 #else
     u32x4_t t = {e.x, e.y, e.z, e.w};
@@ -241,6 +253,7 @@ template <class K> __device__ __forceinline__ WRef<K::G> hw_ref(const Ctx& c, ui
 template <class K> __device__ __forceinline__ void tu1_store(const Ctx& c, uint32_t slot, const uint4& u1) {
     if (K::LIFE) { TU(c, slot, 1) = u1; return; }
     TWORD(c, slot, 1, 0) = u1.x;
+    if (K::G) { TWORD(c, slot, 1, 2) = u1.z; TWORD(c, slot, 1, 3) = u1.w; return; }
     LDS64(((c.task0 + ((slot * c.P.task_units + 1) << LWSH<K>(c))) << 1) + 1) = make_uint2(u1.z, u1.w);
 }
 __device__ __forceinline__ uint4 INSN(const Ctx& c, uint32_t pc) { return LDS128(c.insn0 + pc); }

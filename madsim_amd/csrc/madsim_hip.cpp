@@ -44,6 +44,19 @@ uint64_t fnv(const void* p, size_t n, uint64_t h) {
     return h;
 }
 
+// VGPRs of a kernel build, asked of the loaded code object once per build and process (same on every device of a node).
+int variant_vgprs_cached(const madsim_k::VariantSel* v) {
+    static std::mutex mu;
+    static std::unordered_map<uint32_t, int> cache;
+    const uint32_t key = (uint32_t)v->trace | (uint32_t)v->spill << 1 | (uint32_t)v->rq << 2 | (uint32_t)v->g << 3 | (uint32_t)(v->lws & 0xf) << 4 | (uint32_t)v->feat << 8;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int r = madsim_k_variant_vgprs(v);
+    cache[key] = r;
+    return r;
+}
+
 double since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -80,7 +93,7 @@ struct madsim_hip_ctx {
     uint32_t lds_attr = 0;
     uint64_t* d_prof = nullptr;               // debug counters (profiling kernel builds)
 
-    madsim_geo::Device dev() const { madsim_geo::Device d; d.num_cus = num_cus > 0 ? num_cus : 256; d.lds_per_cu = lds_per_cu; return d; }
+    madsim_geo::Device dev() const { madsim_geo::Device d; d.num_cus = num_cus > 0 ? num_cus : 256; d.lds_per_cu = lds_per_cu; d.vgprs = variant_vgprs_cached; return d; }
     int bind() { HIP_TRY(hipSetDevice(device)); return 0; }
     static void free_tables(Tables& t) {
         if (t.insns) (void)hipFree(t.insns);

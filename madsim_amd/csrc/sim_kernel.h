@@ -49,6 +49,7 @@ struct KParams {
     // global-state builds (Variant::G): task table + planes of lane g = gs_stride bytes at gstate + g * gs_stride:
     // [task units: max_tasks x task_units x 16 B][plane words (off_* count from gs_planes, the ready queue stays in LDS)]
     uint32_t gstate_mode, gs_stride, gs_planes, gs_plane_words;
+    uint32_t off_amask, off_omask;     // LDS plane words (after the ready queue) of the alive-task / owned-socket masks
     uint8_t* gstate;
     uint32_t lifecycle;        // any extended op: the extended LDS layout (features != 0)
     uint32_t features;         // MADSIM_FEAT_* classes the workload needs
@@ -114,6 +115,7 @@ extern "C" {
 int  madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace);
 void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream);
 int  madsim_k_set_max_lds(uint32_t lds_bytes);
+int  madsim_k_variant_vgprs(const madsim_k::VariantSel* v);
 void madsim_k_launch_keyflip(unsigned long long* acc, void* stream);
 }
 

@@ -47,7 +47,11 @@ namespace madsim_k {
 template <class K>
 __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     const KParams& P = c.P;
-    if (K::G) { for (uint32_t w = 0; w < P.gs_plane_words; w++) gs_store32(c.gs, c.gs_off + P.gs_planes + w * 4, 0); }
+    if (K::G) {
+        for (uint32_t w = 0; w < P.gs_plane_words; w++) gs_store32(c.gs, c.gs_off + P.gs_planes + w * 4, 0);
+        for (uint32_t w = 0; w < (P.max_tasks + 31) / 32; w++) AMASK(w) = 0;
+        OMASK(0) = 0; OMASK(1) = 0;
+    }
     else for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;     // plane 0 is the ready queue: RW spans all planes
     for (uint32_t t = 0; t < P.max_tasks; t++) { TWORD(c, t, 0, 0) = 0; if (!K::LIFE) TWORD(c, t, 1, 1) = 0; }
     // GlobalRng::new_with_seed -> Xoshiro256PlusPlus::seed_from_u64: SplitMix64 [DEP A.1]
@@ -70,8 +74,13 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
     spawn_task<K>(c, L, 0, true);
 }
 
+// Global-state builds wait on memory most of the time (rocprofv3: 60-70 % of wave cycles), so they trade registers for
+// resident waves: MADSIM_G_WAVES_PER_EU waves per SIMD (the second __launch_bounds__ argument caps the VGPR budget).
+#ifndef MADSIM_G_WAVES_PER_EU
+#define MADSIM_G_WAVES_PER_EU 1
+#endif
 template <class K>
-__global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
+__global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // workgroup-shared tables
     uint32_t* sh = SMEM;
@@ -94,6 +103,8 @@ __global__ __launch_bounds__(256) void sim_kernel(const KParams P) {
     c.lws = P.lw_shift;
     const uint32_t pl = P.sh_planes + wbase + lane;
     c.ready0 = pl + (P.off_ready << P.lw_shift);
+    c.amask0 = pl + (P.off_amask << P.lw_shift);
+    c.omask0 = pl + (P.off_omask << P.lw_shift);
     if (K::G) {                                      // byte offsets inside the lane's global state block
         c.task0 = 0;
         c.sock0 = P.gs_planes + P.off_socks * 4; c.hand0 = P.gs_planes + P.off_handles * 4; c.node0 = P.gs_planes + P.off_nodes * 4;
@@ -309,6 +320,20 @@ extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t cou
 
 extern "C" void madsim_k_launch_keyflip(unsigned long long* acc, void* stream) {
     hipLaunchKernelGGL(madsim_k::keyflip_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc);
+}
+
+// VGPRs per lane of the build select_variant names (0 = not compiled / error): the host sizes waves per CU with it.
+extern "C" int madsim_k_variant_vgprs(const madsim_k::VariantSel* v) {
+    using namespace madsim_k;
+    int regs = 0;
+#define TRY_ATTR(T_, S_, L_, F_, R_, G_)                                                                                 \
+    if (!regs && v->trace == (int)(T_) && v->spill == (int)(S_) && v->lws == (L_) && v->feat == (F_) && v->rq == (int)(R_) && v->g == (int)(G_)) { \
+        hipFuncAttributes a;                                                                                             \
+        if (hipFuncGetAttributes(&a, (const void*)sim_kernel<Variant<T_, S_, L_, F_, R_, G_>>) == hipSuccess) regs = a.numRegs; \
+    }
+    MADSIM_FOR_EACH_VARIANT(TRY_ATTR)
+#undef TRY_ATTR
+    return regs;
 }
 
 extern "C" int madsim_k_set_max_lds(uint32_t lds_bytes) {

@@ -35,6 +35,19 @@ extern "C" void madsim_emu_region_stats(double* trips, double* visits, double* i
 }
 #endif
 
+#ifdef MADSIM_EMU_GSTAT
+// per byte offset WITHIN a lane's state block: access counts by kind, summed over all lanes
+static std::vector<uint64_t> gstat[4];
+static uint32_t gstat_stride = 1;
+void emu_gstat(uint32_t byte_off, int kind) {
+    uint32_t o = byte_off % gstat_stride;
+    if (gstat[kind].size() <= o / 4) gstat[kind].resize(o / 4 + 1);
+    gstat[kind][o / 4]++;
+}
+extern "C" uint64_t madsim_emu_gstat(int kind, uint32_t word) { return word < gstat[kind].size() ? gstat[kind][word] : 0; }
+extern "C" void madsim_emu_gstat_reset(uint32_t stride) { for (auto& g : gstat) g.clear(); gstat_stride = stride ? stride : 1; }
+#endif
+
 extern "C" const char* madsim_emu_last_error(void) { return emu_err.c_str(); }
 
 extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
@@ -116,5 +129,19 @@ extern "C" int madsim_emu_geometry(const madsim_workload_t* w, const madsim_limi
     out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
     out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave;
     out->variant = G.P.lw_shift != 6 ? 8u | 3u : (G.P.heap_spill ? 1u : 0u) | (G.P.lifecycle ? 2u : 0u) | (G.P.rq_in_reg ? 4u : 0u);
+    return 0;
+}
+
+// selected KParams of the geometry a workload gets (tools/gstate_access_model.py)
+extern "C" int madsim_emu_geometry_params(const madsim_workload_t* w, const madsim_limits_t* lim, uint32_t* out32) {
+    madsim_config_t cfg{}; cfg.lat_lo_ns = 1000000; cfg.lat_hi_ns = 10000000;
+    madsim_geo::Device dev; dev.num_cus = 1;
+    madsim_geo::Geo G;
+    int rc = madsim_geo::make_geometry(dev, w, &cfg, lim, 64, &G, &emu_err);
+    if (rc) return rc;
+    const madsim_k::KParams& P = G.P;
+    const uint32_t v[] = {P.gs_stride, P.gs_planes, P.max_tasks, P.task_units, P.n_socks, P.sock_words, P.mbox_regs, P.mbox_msgs, P.off_socks,
+                          P.off_handles, P.off_nodes, P.off_clog, P.off_pause, P.off_greg, P.off_conn, P.gs_plane_words, P.n_progs};
+    for (size_t i = 0; i < sizeof v / sizeof *v; i++) out32[i] = v[i];
     return 0;
 }

@@ -23,6 +23,13 @@ extern thread_local uint32_t* emu_smem;
 static inline void __syncthreads() {}
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }   // emulated threads run one after another
 static inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+// tools/gstate_access_model.py: which words of the per-lane global state block the kernel touches, and how often
+#ifdef MADSIM_EMU_GSTAT
+void emu_gstat(uint32_t byte_off, int kind);      // kind: 0 load32, 1 store32, 2 load128, 3 store128
+#define EMU_GSTAT(off, kind) emu_gstat((off), (kind))
+#else
+#define EMU_GSTAT(off, kind) do { } while (0)
+#endif
 #ifdef MADSIM_EMU_REGIONS   // tools/divergence_model.py: per-iteration code-region visit counts of each emulated lane
 void emu_region(int id);
 #define REG(id) emu_region(id)
