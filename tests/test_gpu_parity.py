@@ -566,7 +566,7 @@ def test_global_state_lifecycle_reference_tests_gpu(hip, name):
     lim = _global_limits(LW.limits(name))
     g = hip.geometry(LW.ALL[name](), lim)
     assert bool(g.variant & 16) == bool(g.variant & 2)        # every extended-op workload takes the global-state build when asked
-    got, _ = _cmp(hip, LW.ALL[name](), 0, 2048, LW.config(name), lim)
+    got, _ = _cmp(hip, LW.ALL[name](), 0, 1024, LW.config(name), lim)
     assert (got["verdict"] == (A.PANIC if name in LW.EXPECT_PANIC else A.PASS)).all()
 
 
