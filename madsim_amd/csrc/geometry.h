@@ -131,8 +131,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // them (unit 2's other half is the timeout deadline RPC calls use anyway), else a unit of their own
     const bool mark = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED);
     if (P.uses_rpc) { if (!mark) P.rpc_unit = 2; else { P.rpc_unit = P.task_units; P.task_units++; } }
-    // per socket: header, owner, registrations, queued messages (+ accept queue, parked acceptor)
-    P.sock_words = 2 + P.mbox_regs + 2 * P.mbox_msgs + (P.uses_chan ? 2 : 0);
+    // per socket: header, owner, registrations, queued messages (+ accept queue, parked acceptor); set once the layout
+    // (base or extended) is known, below
     P.max_conns = L.max_conns ? L.max_conns : 4;
     P.chan_queue = L.chan_queue ? L.chan_queue : 2;
     if (P.max_conns > 127 || P.chan_queue > 15) return fail(err, MADSIM_E_LIMITS, "max_conns <= 127, chan_queue <= 15");
@@ -167,6 +167,11 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // would leave a CU with fewer than four full waves — a per-lane block of global memory (Variant::G, k_state.h).
     if (L.state_mem > MADSIM_STATE_GLOBAL) return fail(err, MADSIM_E_LIMITS, "state_mem must be 0 (auto), 1 (LDS) or 2 (global)");
     P.gstate_mode = 0;
+    // base-op builds: no owner word per socket (the owner's slot rides in the header, k_state.h) and 8-byte unit1
+    P.sock_words = (P.lifecycle ? 2 : 1) + P.mbox_regs + 2 * P.mbox_msgs + (P.uses_chan ? 2 : 0);
+    if (!P.lifecycle && P.mbox_msgs > 127) return fail(err, MADSIM_E_LIMITS, "mbox_msgs must be <= 127 for workloads without extended ops");
+    const uint32_t task_bytes = P.lifecycle ? P.task_units * 16 : 24;
+    const uint32_t heap_bytes = P.lifecycle ? 16 : 12;        // base ops: {deadline 8, meta 4}, no payload word (k_timer.h)
     for (int pass = 0; pass < 3; pass++) {
         if (!P.lifecycle && P.max_tasks < P.n_progs) P.max_tasks = P.n_progs;   // handle words live in task slots there
         // the ready queue lives in a register in the (base ops, <= 8 tasks, full 64-lane waves) builds: lay out with it
@@ -198,7 +203,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         P.sh_socks = P.sh_progs + P.n_progs;
         P.sh_heap = (P.sh_socks + P.n_socks + 3) & ~3u;
         sh_bytes = P.sh_heap * 4;
-        G->lds_per_seed = P.heap_lds * 16 + (P.gstate_mode ? 0 : P.max_tasks * P.task_units * 16) + P.lane_words * 4;
+        G->lds_per_seed = P.heap_lds * heap_bytes + (P.gstate_mode ? 0 : P.max_tasks * task_bytes) + P.lane_words * 4;
         if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu && (L.state_mem == MADSIM_STATE_LDS || !P.lifecycle || trace || P.gstate_mode)) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
         // Lanes per wave (lw): how many of a wave's 64 lanes carry a seed.  Measured on MI355X (4-node
         // ping-pong, 65 536 seeds, profiles/r1_lanes_per_wave.md): every wave-instruction costs the SIMD
@@ -236,8 +241,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     }
     if (P.gstate_mode && lw != 64) return fail(err, MADSIM_E_LIMITS, "global state (state_mem = 2) runs full 64-lane waves only");
     P.lw_shift = lw == 8 ? 3 : lw == 16 ? 4 : lw == 32 ? 5 : 6;
-    P.sh_tasks = P.sh_heap + P.heap_lds * lw * 4;
-    P.sh_planes = P.sh_tasks + (P.gstate_mode ? 0 : P.max_tasks * P.task_units * lw * 4);
+    P.sh_tasks = P.sh_heap + P.heap_lds * lw * (heap_bytes / 4);
+    P.sh_planes = P.sh_tasks + (P.gstate_mode ? 0 : P.max_tasks * (task_bytes / 4) * lw);
     P.wave_words = P.sh_planes + P.lane_words * lw - P.sh_heap;
     if ((size_t)(P.sh_heap + P.wave_words) * 4 > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-wave LDS exceeds 160 KiB: lower heap_lds_slots / mailbox capacities");
     // Workgroup = W independent waves.  Measured on MI355X (tools/placement.hip, profiles/r1_placement.txt): the

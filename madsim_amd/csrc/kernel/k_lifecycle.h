@@ -56,13 +56,13 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
         if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
     }
     if (f & TF_OWNER) {                                        // BindGuards this task holds drop with its future
-        uint32_t own = slot | (gen << 16);
         for (uint32_t i = 0; i < c.P.n_socks; i++) {
             if (K::G && !((OMASK(i >> 5) >> (i & 31)) & 1)) continue;      // never bound by a task that is still around
-            if (SW(c, i, 1) != own) continue;
+            const uint32_t hdr = SW(c, i, 0);
+            if (!sock_owned_by<K>(c, i, hdr, slot, gen)) continue;
             if (K::G) OMASK(i >> 5) &= ~(1u << (i & 31));
             // BindGuard::drop (net/mod.rs:483-493), skipped when the binder's NodeInfo is killed
-            if (!(f & TF_KILLED) && (SW(c, i, 0) & 1)) SW(c, i, 0) &= ~1u;
+            if (!(f & TF_KILLED) && (hdr & 1)) SW(c, i, 0) = hdr & ~1u;
             if (K::FC && c.P.uses_chan && (SW(c, i, 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, i);
         }
     }

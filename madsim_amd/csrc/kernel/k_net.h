@@ -37,9 +37,13 @@ __device__ __forceinline__ int find_bound(const Ctx& c, uint32_t addr) {
 template <class K>
 __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t meta, uint32_t val) {
     uint32_t s = meta & 0x3f, from = (meta >> 6) & 0x3f, tag = (meta >> 12) & 0xff, sgen = (meta >> 20) & 0xff;
+    if (!K::LIFE) {                                        // base ops: the event names its send_to / reply instruction
+        const uint4 in = INSN(c, (meta >> 6) & 0xfff);
+        from = (in.x >> 8) & 0xff; tag = in.x >> 24; val = in.y;
+    }
     uint32_t h = SW(c, s, 0);
     if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;     // that Endpoint object is gone
-    uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
+    uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
     // Typed RPC (net/rpc.rs): a response (tag 0xff) is addressed to one pending receive — the word of its registration,
     // tag | slot | rxseq | gen, rides in the payload's upper 24 bits — where the reference matches a random u64 tag.
     const bool rpc = K::FR && c.P.uses_rpc;
@@ -78,7 +82,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);
     SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg + 1) = val;
     nmsg++;
-    SW(c, s, 0) = (h & ~((0xffu << 9) | (0xffu << 17))) | (nreg << 9) | (nmsg << 17);
+    SW(c, s, 0) = (HDR_SET_NMSG(h, nmsg) & ~(0xffu << 9)) | (nreg << 9);
 }
 
 template <class K> __device__ __forceinline__ void node_restart(const Ctx& c, Lane& L, uint32_t node);

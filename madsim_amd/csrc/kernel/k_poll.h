@@ -216,7 +216,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             } else {                                       // a Sleep (time/sleep.rs:47-54)
                 uint64_t deadline = u64of(u1.z, u1.w);
                 REG(3);
-                if (L.clock < deadline) {                  // not elapsed: register ANOTHER timer
+                // (base-op builds keep no deadline: there a Sleep is only polled again once its own timer has fired)
+                if (K::LIFE && L.clock < deadline) {       // not elapsed: register ANOTHER timer
                     REG(5);
                     if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
                     st = ST_PENDING;
@@ -263,9 +264,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 } else if (op == MS_OP_BIND) {                    // Network::bind (network.rs:206-251)
                     uint32_t sw = SOCKW(c, a);
                     if ((sw & 0xff) != node || find_bound<K>(c, a) >= 0) { st = ST_PANIC; break; }
-                    uint32_t h = SW(c, a, 0);
-                    SW(c, a, 0) = 1u | ((((h >> 1) + 1) & 0xff) << 1);     // bound, gen+1, empty mailbox
-                    SW(c, a, 1) = slot | (gen << 16);
+                    sock_bind<K>(c, a, slot, gen);                         // bound, gen+1, empty mailbox, owned by this task
                     u0.x |= TF_OWNER;
                     if (K::G) OMASK(a >> 5) |= 1u << (a & 31);
                     if (K::FC && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
@@ -288,8 +287,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         int ds = find_bound<K>(c, dst);
                         if (ds >= 0) {
                             uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
-                            uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((b >> 8) << 12) | (a << 6) | (uint32_t)ds;
-                            if (!timer_add<K>(c, L, L.clock + lat, meta, imm)) L.ovf = 1;
+                            const uint2 ev = ev_deliver_meta<K>(sgen, b >> 8, a, (uint32_t)ds, imm, pc);
+                            if (!timer_add<K>(c, L, L.clock + lat, ev.x, ev.y)) L.ovf = 1;
                         }
                     }
                 }
@@ -361,7 +360,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (rxseq == 0) u0.x |= TF_RXWRAP;
                 u0.x &= ~TF_INBOX;
                 uint32_t h = SW(c, a, 0);
-                uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
+                uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
                 uint32_t idx = 0, mbase = 2 + P.mbox_regs;
                 while (idx < nmsg && (SW(c, a, mbase + 2 * idx) & 0xff) != tag) idx++;
                 if (idx < nmsg) {
@@ -373,7 +372,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     if (K::FR && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 0) = m1 >> 8; }
                     from = (m0 >> 8) & 0xff;
                     sub = 2;                               // oneshot already holds the value
-                    SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
+                    SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
                 } else {
                     if (nreg >= P.mbox_regs) { L.ovf = 1; st = ST_PENDING; break; }
                     const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
@@ -400,7 +399,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             if (rxseq == 0) u0.x |= TF_RXWRAP;
             u0.x &= ~TF_INBOX;
             uint32_t h = SW(c, a, 0);
-            uint32_t nreg = (h >> 9) & 0xff, nmsg = (h >> 17) & 0xff;
+            uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
             uint32_t idx = 0, mbase = 2 + P.mbox_regs;
             while (idx < nmsg && (SW(c, a, mbase + 2 * idx) & 0xff) != tag) idx++;
             if (idx < nmsg) {
@@ -412,7 +411,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (K::FR && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 1) = m1 >> 8; }
                 u0.y = (u0.y & 0x00ffffffu) | (((m0 >> 8) & 0xff) << 24);
                 u0.x |= TF_INBOX;
-                SW(c, a, 0) = (h & ~(0xffu << 17)) | (nmsg << 17);
+                SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
             } else if (nreg >= P.mbox_regs) {
                 L.ovf = 1;
             } else {
@@ -631,12 +630,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 TU(c, slot, 0) = u0;
                 if (u1_dirty) { tu1_store<K>(c, slot, u1); u1_dirty = false; }
                 timer_expire<K>(c, L, L.clock);
-                u0 = TU(c, slot, 0); u1 = TU(c, slot, 1);
+                u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot);
                 from = u0.y >> 24;
                 break;
             case MS_OP_CLOSE: {
                 uint32_t h = SW(c, a, 0);
-                if ((h & 1) && SW(c, a, 1) == (slot | (gen << 16)) && !(u0.x & TF_KILLED)) SW(c, a, 0) = h & ~1u;
+                if ((h & 1) && sock_owned_by<K>(c, a, h, slot, gen) && !(u0.x & TF_KILLED)) SW(c, a, 0) = h & ~1u;
                 if (K::FC && P.uses_chan && SW(c, a, 1) == (slot | (gen << 16)) && (SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, a);
                 pc++;
                 break;

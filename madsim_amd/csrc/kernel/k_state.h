@@ -23,7 +23,9 @@ namespace madsim_k {
 #define NS_PER_S 1000000000ull
 #define NS_PER_MS 1000000ull
 
-// Task state = 16-byte units [unit][lane] (ds_read/write_b128, conflict-free):
+// Task state = 16-byte units [unit][lane] (ds_read/write_b128, conflict-free).  Base-op builds (Variant::LIFE false) keep
+// unit1 as 8 bytes {x, y} in its own [slot][lane] array: a task of theirs that awaits a Sleep is only ever polled again by
+// that Sleep's own timer (no timeouts, no kills), so the deadline need not be remembered — 24 bytes per task instead of 32.
 //   unit0 {x: flags:8 | gen:16 | prog:8,  y: pc:16 | sub:8 | from:8,  z: cnt0:16 | cnt1:16,  w: val}
 //   unit1 {x: rxseq:8 | joiner:8 | joiner_gen:16,  y: -,  z: deadline lo,  w: deadline hi}
 //   unit2 {x: t0 lo, y: t0 hi, z/w: timeout()'s deadline}   (only when the workload uses MS_OP_MARK / timeouts)
@@ -115,8 +117,10 @@ struct Ctx {
     uint32_t lws;        // log2(lane stride) (runtime copy; K::LWS overrides when >= 0)
     uint32_t ready0, hand0, node0, clog0, pause0, greg0, conn0;   // word indices of this lane's plane regions
     uint32_t sock0;      // word index of this lane's socket region
-    uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + (i << lws))
+    uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + (i << lws)); base-op builds: uint2 index
+    uint32_t heapm0;     // base-op builds: word index of the meta word of heap entry 0 (k_timer.h)
     uint32_t task0;      // uint4 index of task unit 0
+    uint32_t task1;      // base-op builds: uint2 index of the 8-byte unit1 array (see "Task state")
     uint32_t insn0;      // uint4 index of the workgroup-shared instruction table
     uint32_t prog0, sockt0;   // word indices of the shared prog / socket-address tables
     SpillRef spill;      // the HBM spill region: entry (slot, this lane) at byte (slot * P.total_lanes) * 16 + spill_off
@@ -233,12 +237,40 @@ template <class K> __device__ __forceinline__ WRef<K::G> plane_ref(const Ctx& c,
 // node region: [0] killed mask, [1] paused mask, [2] gen0_killed mask, [3] spawn counter, [4 + n/4] info_gen bytes,
 //              then one word: the seed's base time in seconds into 2022 (time/mod.rs:26-33)
 #define NODE_INFO_GEN(n_) (((uint32_t)NODEW(4 + ((n_) >> 2)) >> (((n_) & 3) * 8)) & 0xff)
-#define SW(c_, s_, f_) plane_ref<K>((c_), (c_).sock0, (s_) * (c_).P.sock_words + (f_))
+// Socket s, field f: [0] header, [1] owner (slot | gen << 16), [2 ..] registrations, then queued messages (2 words each),
+// then (channel users) accept queue + parked acceptor.  Header = bound:1 | gen:8 <<1 | nreg:8 <<9 | nmsg <<17.
+// Base-op builds have no owner word: the owner's task slot rides in header bits 24-31 (nmsg keeps 7 bits) — a bound
+// socket's owner is alive (its finish unbinds it, nothing else can kill it), so the slot alone identifies it.
+template <class K> __device__ __forceinline__ uint32_t sock_field(uint32_t f) { return K::LIFE ? f : (f ? f - 1 : 0); }
+#define SW(c_, s_, f_) plane_ref<K>((c_), (c_).sock0, (s_) * (c_).P.sock_words + sock_field<K>(f_))
+template <class K> struct SockHdr { static constexpr uint32_t NMSG_MASK = K::LIFE ? 0xffu : 0x7fu; };
+#define HDR_NMSG(h_) (((h_) >> 17) & SockHdr<K>::NMSG_MASK)
+#define HDR_SET_NMSG(h_, n_) (((h_) & ~(SockHdr<K>::NMSG_MASK << 17)) | ((n_) << 17))
+// header of a fresh Endpoint bound by task (slot, gen): bound, socket gen + 1, empty mailbox
+template <class K> __device__ __forceinline__ void sock_bind(const Ctx& c, uint32_t s, uint32_t slot, uint32_t gen) {
+    uint32_t h = SW(c, s, 0);
+    uint32_t nh = 1u | ((((h >> 1) + 1) & 0xff) << 1);
+    if (K::LIFE) SW(c, s, 1) = slot | (gen << 16); else nh |= slot << 24;
+    SW(c, s, 0) = nh;
+}
+// is the task (slot, gen) the one whose BindGuard holds socket s?  (base-op builds: of a BOUND socket)
+template <class K> __device__ __forceinline__ bool sock_owned_by(const Ctx& c, uint32_t s, uint32_t h, uint32_t slot, uint32_t gen) {
+    if (K::LIFE) return SW(c, s, 1) == (slot | (gen << 16));
+    return (h & 1) && (h >> 24) == slot;
+}
 template <class K> __device__ __forceinline__ URef<K::G> tu_ref(const Ctx& c, uint32_t slot, uint32_t u) {
+    if (!K::LIFE) return make_uref<K::G>(c, c.task0 + (slot << LWSH<K>(c)), 0);             // unit 0 (unit 1: load_u1 / TWORD)
     return make_uref<K::G>(c, c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c)), c.task0 + (slot * c.P.task_units + u) * 16u);
 }
 template <class K> __device__ __forceinline__ WRef<K::G> tword_ref(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) {
+    if (!K::LIFE) return make_wref<K::G>(c, u == 0 ? (c.task0 + (slot << LWSH<K>(c))) * 4u + k : (c.task1 + (slot << LWSH<K>(c))) * 2u + k, 0);
     return make_wref<K::G>(c, (c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c))) * 4u + k, c.task0 + (slot * c.P.task_units + u) * 16u + k * 4u);
+}
+// unit1 as a uint4 in registers; base-op builds hold {x, y} only
+template <class K> __device__ __forceinline__ uint4 load_u1(const Ctx& c, uint32_t slot) {
+    if (K::LIFE) return tu_ref<K>(c, slot, 1);
+    uint2 t = LDS64(c.task1 + (slot << LWSH<K>(c)));
+    return make_uint4(t.x, t.y, 0, 0);
 }
 #define TU(c_, slot_, u_) tu_ref<K>((c_), (slot_), (u_))
 #define TWORD(c_, slot_, u_, k_) tword_ref<K>((c_), (slot_), (u_), (k_))
@@ -249,12 +281,10 @@ template <class K> __device__ __forceinline__ WRef<K::G> hw_ref(const Ctx& c, ui
     return tword_ref<K>(c, p, 1, 1);
 }
 #define HW(p) hw_ref<K>(c, (p))
-// unit1 write-back: x and the deadline only when unit1.y is a handle word (see HW)
+// unit1 write-back: only x when unit1.y is a handle word (see HW)
 template <class K> __device__ __forceinline__ void tu1_store(const Ctx& c, uint32_t slot, const uint4& u1) {
     if (K::LIFE) { TU(c, slot, 1) = u1; return; }
     TWORD(c, slot, 1, 0) = u1.x;
-    if (K::G) { TWORD(c, slot, 1, 2) = u1.z; TWORD(c, slot, 1, 3) = u1.w; return; }
-    LDS64(((c.task0 + ((slot * c.P.task_units + 1) << LWSH<K>(c))) << 1) + 1) = make_uint2(u1.z, u1.w);
 }
 __device__ __forceinline__ uint4 INSN(const Ctx& c, uint32_t pc) { return LDS128(c.insn0 + pc); }
 __device__ __forceinline__ uint32_t PROGW(const Ctx& c, uint32_t p) { return SMEM[c.prog0 + p]; }

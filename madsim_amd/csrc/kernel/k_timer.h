@@ -30,18 +30,40 @@ __device__ __forceinline__ void spill_store(const Ctx& c, uint32_t slot, const u
 #endif
 }
 
+// LDS entry i of this lane.  Extended builds: one 16-byte unit {deadline, meta, payload}.  Base-op builds: 12 bytes — the
+// deadline in an 8-byte array, meta in a 4-byte one, no payload word: their only events with a payload are datagram
+// deliveries, whose tag / sender / payload are fields of the sending instruction, so meta names that instruction instead
+// (ev_deliver_meta, mailbox_deliver).
+template <class K>
+__device__ __forceinline__ uint4 heap_lds_get(const Ctx& c, uint32_t i) {
+    if (K::LIFE) return LDS128(c.heap0 + (i << LWSH<K>(c)));
+    uint2 d = LDS64(c.heap0 + (i << LWSH<K>(c)));
+    return make_uint4(d.x, d.y, SMEM[c.heapm0 + (i << LWSH<K>(c))], 0);
+}
+template <class K>
+__device__ __forceinline__ void heap_lds_set(const Ctx& c, uint32_t i, const uint4& e) {
+    if (K::LIFE) { LDS128(c.heap0 + (i << LWSH<K>(c))) = e; return; }
+    LDS64(c.heap0 + (i << LWSH<K>(c))) = make_uint2(e.x, e.y);
+    SMEM[c.heapm0 + (i << LWSH<K>(c))] = e.z;
+}
 template <class K>
 __device__ __forceinline__ uint4 heap_get(const Ctx& c, uint32_t i) {
-    if (!K::SPILL) return LDS128(c.heap0 + (i << LWSH<K>(c)));
+    if (!K::SPILL) return heap_lds_get<K>(c, i);
     uint32_t cap = c.P.heap_lds;
-    uint4 v = LDS128(c.heap0 + ((i < cap ? i : cap - 1) << LWSH<K>(c)));
+    uint4 v = heap_lds_get<K>(c, i < cap ? i : cap - 1);
     if (i >= cap) v = spill_load(c, i - cap);
     return v;
 }
 template <class K>
 __device__ __forceinline__ void heap_set(const Ctx& c, uint32_t i, const uint4& e) {
-    if (!K::SPILL || i < c.P.heap_lds) LDS128(c.heap0 + (i << LWSH<K>(c))) = e;
+    if (!K::SPILL || i < c.P.heap_lds) heap_lds_set<K>(c, i, e);
     else spill_store(c, i - c.P.heap_lds, e);
+}
+// meta + payload of a datagram delivery event (net/mod.rs:323-330): destination socket `ds` of incarnation `sgen`.
+template <class K>
+__device__ __forceinline__ uint2 ev_deliver_meta(uint32_t sgen, uint32_t tag, uint32_t from, uint32_t ds, uint32_t val, uint32_t pc) {
+    if (K::LIFE) return make_uint2((EV_DELIVER << 28) | (sgen << 20) | (tag << 12) | (from << 6) | ds, val);
+    return make_uint2((EV_DELIVER << 28) | (sgen << 20) | (pc << 6) | ds, 0);     // base ops: tag, from, payload = fields of insn pc
 }
 
 // BinaryHeap::sift_up(0, pos) with `hole` as the moving element; keeps the root mirror current.

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
     c.prog0 = P.sh_progs;
     c.sockt0 = P.sh_socks;
     const uint32_t wbase = wv * P.wave_words;       // this wave's slice of the workgroup's LDS
-    c.heap0 = (P.sh_heap + wbase) / 4 + lane;
+    if (K::LIFE) c.heap0 = (P.sh_heap + wbase) / 4 + lane;
+    else { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = P.sh_heap + wbase + ((P.heap_lds * 2) << P.lw_shift) + lane; }
     c.lws = P.lw_shift;
     const uint32_t pl = P.sh_planes + wbase + lane;
     c.ready0 = pl + (P.off_ready << P.lw_shift);
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
         c.conn0 = P.gs_planes + P.off_conn * 4;
     } else {
         c.task0 = (P.sh_tasks + wbase) / 4 + lane;
+        c.task1 = (P.sh_tasks + wbase + ((P.max_tasks * 4) << P.lw_shift)) / 2 + lane;      // base-op builds: behind the unit0 array
         c.sock0 = pl + (P.off_socks << P.lw_shift);
         c.hand0 = pl + (P.off_handles << P.lw_shift);
         c.node0 = pl + (P.off_nodes << P.lw_shift);
@@ -165,19 +167,19 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
             // Latency hiding: the queue usually holds exactly one task, so ready[0] and its two state units are
             // loaded BEFORE the draw loop (whose rejection retries take hundreds of cycles) and used if idx == 0.
             const uint32_t slot0 = K::RQ ? (uint32_t)(L.rq & 0xff) : RW(0);
-            const uint4 pu0 = TU(c, slot0, 0), pu1 = TU(c, slot0, 1);
+            const uint4 pu0 = TU(c, slot0, 0), pu1 = load_u1<K>(c, slot0);
             // try_recv_random (utils/mpsc.rs:73-83): idx drawn even when len == 1
             uint32_t idx = gen_index<K>(c, L, L.ready_len);
             L.ready_len--;
             uint32_t slot = slot0;
             uint4 u0 = pu0, u1 = pu1;
             if (K::RQ) {
-                if (idx != 0) { slot = (uint32_t)(L.rq >> (8 * idx)) & 0xff; u0 = TU(c, slot, 0); u1 = TU(c, slot, 1); }
+                if (idx != 0) { slot = (uint32_t)(L.rq >> (8 * idx)) & 0xff; u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot); }
                 uint64_t last = (L.rq >> (8 * L.ready_len)) & 0xff;      // swap_remove on bytes
                 L.rq = (L.rq & ~(0xffull << (8 * idx))) | (last << (8 * idx));
                 L.rq &= ~(0xffull << (8 * L.ready_len));
             } else {
-                if (idx != 0) { slot = RW(idx); u0 = TU(c, slot, 0); u1 = TU(c, slot, 1); }
+                if (idx != 0) { slot = RW(idx); u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot); }
                 if (idx != L.ready_len) RW(idx) = RW(L.ready_len);       // swap_remove
             }
             L.steps++;
