@@ -54,7 +54,10 @@ enum madsim_op {
                               (unwrap_err) else unwrap -> a mismatch panics the polling task         */
     MS_OP_ABORT = 3,       /* a=prog: handle[prog].abort() (task/join.rs:158-163)                    */
     MS_OP_YIELD = 4,       /* tokio::task::yield_now().await (re-export task/mod.rs:30)              */
-    MS_OP_PANIC = 5,       /* panic!()                                                               */
+    MS_OP_PANIC = 5,       /* a=0: panic!() with message code imm (0..254); a=1: panic!("{}", flag[b] + imm): the code
+                              is (flag[b & 3] + imm) & 0xff.  The code is what NodeBuilder::restart_on_panic_matching
+                              patterns are compared with (task/mod.rs:297-300); any other panic (failed assert,
+                              unwrap of an Err) carries code 255, which no pattern names                       */
     MS_OP_SET = 6,         /* a=reg(0..1): cnt[a] = imm (a loop bound; registers are 16 bit)          */
     MS_OP_DJNZ = 7,        /* a=reg, b=target: if (--cnt[a] != 0) goto b                              */
     MS_OP_JMP = 8,         /* b=target                                                               */
@@ -123,6 +126,15 @@ enum madsim_op {
     MS_OP_TRACE_TIME = 55, /* a=0: obs_hash <- fold(SystemTime::now() in ns since UNIX_EPOCH): the per-seed base time
                               (time/mod.rs:26-33) + elapsed; a=1: fold(Instant elapsed ns) (system_time.rs:122-154);
                               a=2: fold(val): make the last received / drawn value observable                      */
+    /* -- NetSim message hooks (net/mod.rs:240-284; consulted by NetSim::send, :307-311 and :323-328) -- */
+    MS_OP_HOOK_REQ = 56,   /* a=node, b=(req_tag<<8)|mode, imm=request code: NetSim::hook_rpc_req::<R>(node, f) — replaces the
+                              node's request hook.  f returns false (the request is dropped after rand_delay, BEFORE the link
+                              test: no loss / latency draws, no delivery timer) for typed-RPC requests of tag req_tag sent FROM
+                              `node` whose code == imm (mode 0) or for all of them (mode 1); every other payload passes.    */
+    MS_OP_HOOK_RSP = 57,   /* a=node, b=mode, imm=response code: NetSim::hook_rpc_rsp::<R>(node, f) — replaces the node's response
+                              hook.  The hook installed when a typed-RPC response is SENT towards `node` judges it when its
+                              delivery timer fires: false (code == imm in mode 0, any response in mode 1) = the timer fires and
+                              nothing is delivered.  Responses carry no type id here: the hook sees every response.           */
     MS_OP__COUNT
 };
 
@@ -163,10 +175,17 @@ typedef struct madsim_sock {
 } madsim_sock_t;
 
 typedef struct madsim_node {
-    uint8_t flags;     /* MADSIM_NODE_* */
-    uint8_t reserved[3];
+    uint8_t flags;       /* MADSIM_NODE_* */
+    uint8_t n_match;     /* MADSIM_NODE_RESTART_MATCHING: number of patterns (0..2)                  */
+    uint8_t match[2];    /* the panic message codes that restart the node                            */
 } madsim_node_t;
 #define MADSIM_NODE_RESTART_ON_PANIC 1u /* NodeBuilder::restart_on_panic (task/mod.rs:298-316)      */
+#define MADSIM_NODE_RESTART_MATCHING 4u /* NodeBuilder::restart_on_panic_matching(msg) (runtime/mod.rs:384-387,
+                                           task/mod.rs:299): restart only when the panic's message code equals one of
+                                           `match[0..n_match)`.  Messages are modelled as 8-bit codes compared for
+                                           equality — exact for single-token messages like the reference test's
+                                           (task/mod.rs:964-982), not a substring search                     */
+#define MADSIM_PANIC_CODE_OTHER 255u
 
 typedef struct madsim_workload {
     uint32_t n_nodes;   /* nodes 1..n_nodes besides node 0                                           */

@@ -83,6 +83,10 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
             break;
         case MS_OP_RPC_REPLY:
             if (in.a >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range"); break;
+        case MS_OP_HOOK_REQ:
+            if ((uint32_t)(in.b >> 8) < MADSIM_TAG_RPC_FIRST || (uint32_t)(in.b >> 8) > MADSIM_TAG_RPC_LAST) return fail(err, MADSIM_E_WORKLOAD, "hook_rpc_req needs a typed request tag (0x80..0xFD)");
+            /* fall through */
+        case MS_OP_HOOK_RSP:
         case MS_OP_BUILD: case MS_OP_KILL: case MS_OP_RESTART: case MS_OP_PAUSE: case MS_OP_RESUME:
         case MS_OP_CLOG_NODE: case MS_OP_UNCLOG_NODE: case MS_OP_ASSERT_EXIT:
             if (in.a > w->n_nodes) return fail(err, MADSIM_E_WORKLOAD, "node operand out of range"); break;
@@ -110,10 +114,11 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.time_limit = L.time_limit_ns;
     P.max_steps = L.max_steps ? L.max_steps : (1u << 24);
     bool restarts = uses_op(w, MS_OP_RESTART);
-    for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) restarts |= (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) != 0;
+    for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) restarts |= (w->nodes[i].flags & (MADSIM_NODE_RESTART_ON_PANIC | MADSIM_NODE_RESTART_MATCHING)) != 0;
     // request-per-connection servers spawn a handler per accept: leave room for a few concurrent ones
     bool chan = uses_op(w, MS_OP_CONNECT) || uses_op(w, MS_OP_ACCEPT);
-    P.uses_rpc = uses_op(w, MS_OP_RPC_CALL) || uses_op(w, MS_OP_RPC_REPLY);   // likewise: one task per request in flight
+    P.uses_hooks = uses_op(w, MS_OP_HOOK_REQ) || uses_op(w, MS_OP_HOOK_RSP);
+    P.uses_rpc = uses_op(w, MS_OP_RPC_CALL) || uses_op(w, MS_OP_RPC_REPLY) || P.uses_hooks;   // likewise: one task per request in flight
     P.max_tasks = L.max_tasks ? L.max_tasks : w->n_progs + (restarts ? w->n_progs : 0) + (chan || P.uses_rpc ? 8 : 0);
     if (P.max_tasks > 254) P.max_tasks = 254;
     if (P.max_tasks > 254) return fail(err, MADSIM_E_LIMITS, "max_tasks must be <= 254");
@@ -146,7 +151,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // ---- which optional per-seed regions exist (LDS diet: a workload only carries what it can touch) ----
     P.restart_nodes = 0;
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
-        if (w->nodes[i].flags & MADSIM_NODE_RESTART_ON_PANIC) P.restart_nodes |= 1u << i;
+        if (w->nodes[i].flags & (MADSIM_NODE_RESTART_ON_PANIC | MADSIM_NODE_RESTART_MATCHING)) P.restart_nodes |= 1u << i;
     P.has_restart_on_panic = P.restart_nodes != 0;
     // Classes of extended ops the workload needs (sim_kernel.h MADSIM_FEAT_*): the kernel build is picked by this mask
     // (select_variant), and any of them switches the per-seed LDS layout to its extended form.
@@ -188,8 +193,10 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         P.uses_pause = uses_op(w, MS_OP_PAUSE);
         P.off_greg = P.off_pause + (P.uses_pause ? 1 + P.max_tasks : 0);
         bool gregs = uses_op(w, MS_OP_GSET) || uses_op(w, MS_OP_GADD) || uses_op(w, MS_OP_ASSERT_G) || uses_op(w, MS_OP_PANIC_IF_G_LT);
+        for (uint32_t i = 0; i < w->n_insns; i++) gregs |= w->insns[i].op == MS_OP_PANIC && (w->insns[i].a & 1);   // panic!("{}", flag)
         P.off_conn = P.off_greg + (gregs ? 4 : 0);
-        P.lane_words = P.off_conn + (P.uses_chan ? P.max_conns * P.conn_words : 0);
+        P.off_hooks = P.off_conn + (P.uses_chan ? P.max_conns * P.conn_words : 0);
+        P.lane_words = P.off_hooks + (P.uses_hooks ? P.n_nodes + 1 : 0);
         if (P.gstate_mode) {           // the planes just laid out go to the global block; LDS keeps the ready queue only
             P.gs_plane_words = P.lane_words;
             P.gs_planes = P.max_tasks * P.task_units * 16;
@@ -201,7 +208,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         P.sh_insns = 0;
         P.sh_progs = P.sh_insns + 4 * P.n_insns;
         P.sh_socks = P.sh_progs + P.n_progs;
-        P.sh_heap = (P.sh_socks + P.n_socks + 3) & ~3u;
+        P.sh_nodes = P.sh_socks + P.n_socks;
+        P.sh_heap = (P.sh_nodes + P.n_nodes + 1 + 3) & ~3u;
         sh_bytes = P.sh_heap * 4;
         G->lds_per_seed = P.heap_lds * heap_bytes + (P.gstate_mode ? 0 : P.max_tasks * task_bytes) + P.lane_words * 4;
         if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu && (L.state_mem == MADSIM_STATE_LDS || !P.lifecycle || trace || P.gstate_mode)) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
@@ -289,7 +297,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
 
 // Device form of the workload tables.  MS_OP_SLEEP_RAND's `a` (lo in 50 ms units) is replaced by an index
 // into `durs` = {mode, low, range, zone} of UniformDuration::new(lo, hi) [DEP rand 0.8, SURVEY A.3].
-struct DeviceTables { std::vector<uint32_t> insns, progs, socks; std::vector<uint64_t> durs; };
+struct DeviceTables { std::vector<uint32_t> insns, progs, socks, nodes; std::vector<uint64_t> durs; };
 inline int build_tables(const madsim_workload_t* w, DeviceTables* T, std::string* err) {
     T->insns.resize(4 * (size_t)w->n_insns); T->progs.resize(w->n_progs); T->socks.resize(w->n_socks ? w->n_socks : 1);
     T->durs.assign(4, 0);
@@ -321,6 +329,10 @@ inline int build_tables(const madsim_workload_t* w, DeviceTables* T, std::string
     }
     for (uint32_t i = 0; i < w->n_progs; i++) T->progs[i] = (uint32_t)w->progs[i].node | ((uint32_t)w->progs[i].flags << 8) | ((uint32_t)w->progs[i].entry << 16);
     for (uint32_t i = 0; i < w->n_socks; i++) T->socks[i] = (uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].port << 16);
+    T->nodes.assign(w->n_nodes + 1, 0);
+    for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
+        T->nodes[i] = (uint32_t)w->nodes[i].flags | ((uint32_t)(w->nodes[i].n_match > 2 ? 2 : w->nodes[i].n_match) << 8) |
+                      ((uint32_t)w->nodes[i].match[0] << 16) | ((uint32_t)w->nodes[i].match[1] << 24);
     return 0;
 }
 

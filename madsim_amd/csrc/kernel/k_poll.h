@@ -110,7 +110,13 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 const uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;
                 const uint32_t reg = 0xffu | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
                 uint64_t lat; int ds;
-                if (try_send_fn<K>(c, L, SOCKW(c, ca) & 0xff, dst, &lat, &ds)) {
+                // hooks_req.get(&node): `if !hook(&msg) { return Ok(()) }` before try_send (net/mod.rs:307-311): no draws
+                bool hooked = false;
+                if (P.uses_hooks) {
+                    const uint32_t hw = HOOKW(SOCKW(c, ca) & 0xff);
+                    hooked = (hw & 1) && ((hw >> 10) & 0xff) == (cb >> 8) && ((hw & 2) || ((hw >> 2) & 0xff) == (cimm & 0xff));
+                }
+                if (!hooked && try_send_fn<K>(c, L, SOCKW(c, ca) & 0xff, dst, &lat, &ds)) {
                     uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
                     uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((cb >> 8) << 12) | (ca << 6) | (uint32_t)ds;
                     if (!timer_add<K>(c, L, L.clock + lat, meta, (cimm & 0xff) | (reg & 0xffffff00u))) L.ovf = 1;
@@ -287,7 +293,14 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         int ds = find_bound<K>(c, dst);
                         if (ds >= 0) {
                             uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
-                            const uint2 ev = ev_deliver_meta<K>(sgen, b >> 8, a, (uint32_t)ds, imm, pc);
+                            uint2 ev = ev_deliver_meta<K>(sgen, b >> 8, a, (uint32_t)ds, imm, pc);
+                            if (K::FR && P.uses_hooks && op == MS_OP_RPC_REPLY) {
+                                // hooks_rsp.get(&dst_node) is cloned now and judges the message when the timer fires
+                                // (net/mod.rs:321-328): the verdict is already fixed, so a dropped response is a timer
+                                // that fires and delivers nothing
+                                const uint32_t hw = HOOKW(SOCKW(c, (uint32_t)ds) & 0xff);
+                                if ((hw & (1u << 18)) && ((hw & (1u << 19)) || ((hw >> 20) & 0xff) == (imm & 0xff))) ev = make_uint2(EV_NOP << 28, 0);
+                            }
                             if (!timer_add<K>(c, L, L.clock + lat, ev.x, ev.y)) L.ovf = 1;
                         }
                     }
@@ -512,7 +525,18 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.x |= TF_SCHED;                          // wake_by_ref while RUNNING
                 st = ST_PENDING;
                 break;
-            case MS_OP_PANIC:
+            case MS_OP_HOOK_REQ:                            // NetSim::hook_rpc_req (net/mod.rs:240-262): HashMap::insert
+                if (!K::FR) { st = ST_PANIC; break; }
+                HOOKW(a) = ((uint32_t)HOOKW(a) & ~0x3ffffu) | 1u | ((b & 1) << 1) | ((imm & 0xff) << 2) | ((b >> 8) << 10);
+                pc++;
+                break;
+            case MS_OP_HOOK_RSP:                            // NetSim::hook_rpc_rsp (net/mod.rs:264-284)
+                if (!K::FR) { st = ST_PANIC; break; }
+                HOOKW(a) = ((uint32_t)HOOKW(a) & 0x3ffffu) | (1u << 18) | ((b & 1) << 19) | ((imm & 0xff) << 20);
+                pc++;
+                break;
+            case MS_OP_PANIC:                               // its message code: what restart_on_panic_matching compares
+                if (K::FN) L.panic_code = ((a & 1) ? (uint32_t)GREGW(b & 3) + imm : imm) & 0xff;
                 st = ST_PANIC;
                 break;
             case MS_OP_ABORT: {                            // AbortHandle::abort (task/join.rs:158-163)

@@ -34,7 +34,8 @@ namespace madsim_k {
 enum : uint32_t { TF_ALIVE = 1, TF_SCHED = 2, TF_RUN = 4, TF_KILLED = 8, TF_CANCEL = 16, TF_INBOX = 32,
                   TF_RXWRAP = 64 /* this task's 8-bit receive sequence number has wrapped at least once */,
                   TF_OWNER = 128 /* this task has bound an Endpoint: its finish must look for sockets to close */ };
-enum : uint32_t { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3 };
+enum : uint32_t { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3,
+                  EV_NOP = 4 /* a delivery timer whose message a response hook drops: fires, delivers nothing */ };
 enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 
 // Compile-time kernel variant: TRACE = also emit the raw determinism log (single-seed trace mode);
@@ -84,6 +85,7 @@ struct Lane {
     uint64_t prof_acc[12]; uint64_t prof_t;
 #endif
     uint32_t main_done;  // handle[0] left H_RUNNING: block_on's task.is_finished()
+    uint32_t panic_code; // message code of the panic being unwound (MS_OP_PANIC), MADSIM_PANIC_CODE_OTHER for the rest
     uint32_t ovf;        // sticky: a device capacity was exceeded this iteration (=> MADSIM_OVERFLOW)
     // runtime-mutable net config (MS_OP_SET_LOSS)
     uint64_t loss_pint;
@@ -115,14 +117,14 @@ struct SpillRef { __amdgpu_buffer_rsrc_t rsrc; };
 struct Ctx {
     const KParams& P;
     uint32_t lws;        // log2(lane stride) (runtime copy; K::LWS overrides when >= 0)
-    uint32_t ready0, hand0, node0, clog0, pause0, greg0, conn0;   // word indices of this lane's plane regions
+    uint32_t ready0, hand0, node0, clog0, pause0, greg0, conn0, hook0;   // word indices of this lane's plane regions
     uint32_t sock0;      // word index of this lane's socket region
     uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + (i << lws)); base-op builds: uint2 index
     uint32_t heapm0;     // base-op builds: word index of the meta word of heap entry 0 (k_timer.h)
     uint32_t task0;      // uint4 index of task unit 0
     uint32_t task1;      // base-op builds: uint2 index of the 8-byte unit1 array (see "Task state")
     uint32_t insn0;      // uint4 index of the workgroup-shared instruction table
-    uint32_t prog0, sockt0;   // word indices of the shared prog / socket-address tables
+    uint32_t prog0, sockt0, nodet0;   // word indices of the shared prog / socket-address / node tables
     SpillRef spill;      // the HBM spill region: entry (slot, this lane) at byte (slot * P.total_lanes) * 16 + spill_off
     uint32_t spill_off;  // this lane's column: global lane * 16
     // K::G builds: this lane's state block = P.gs_stride bytes at byte gs_off of the state buffer; task0 and the plane
@@ -231,6 +233,9 @@ template <class K> __device__ __forceinline__ WRef<K::G> plane_ref(const Ctx& c,
 #define CLOGW(i) plane_ref<K>(c, c.clog0, (i))
 #define PAUSEW(i) plane_ref<K>(c, c.pause0, (i))   /* [0] = length, [1..] = paused Runnables in pop order */
 #define GREGW(i) plane_ref<K>(c, c.greg0, (i))
+// NetSim message hooks of node n (net/mod.rs:250-284): request hook valid:1 | all:1<<1 | code:8<<2 | tag:8<<10,
+//                                                      response hook valid:1<<18 | all:1<<19 | code:8<<20
+#define HOOKW(n_) plane_ref<K>(c, c.hook0, (n_))
 // connection id_: [0] alive:1 | c_ep:6<<1 | s_ep:6<<7 | tx0:1<<13 rx0<<14 tx1<<15 rx1<<16 | qn0:4<<17 | qn1:4<<21
 //                 [1 + dir] parked receiver: valid:1 | slot:8<<1 | gen:16<<9;  [3 + (dir * Q + i) * 3 ..] {val, arrive lo, arrive hi}
 #define CONNW(id_, f_) plane_ref<K>(c, c.conn0, (id_) * c.P.conn_words + (f_))
@@ -289,6 +294,7 @@ template <class K> __device__ __forceinline__ void tu1_store(const Ctx& c, uint3
 __device__ __forceinline__ uint4 INSN(const Ctx& c, uint32_t pc) { return LDS128(c.insn0 + pc); }
 __device__ __forceinline__ uint32_t PROGW(const Ctx& c, uint32_t p) { return SMEM[c.prog0 + p]; }
 __device__ __forceinline__ uint32_t SOCKW(const Ctx& c, uint32_t s) { return SMEM[c.sockt0 + s]; }
+__device__ __forceinline__ uint32_t NODET(const Ctx& c, uint32_t n) { return SMEM[c.nodet0 + n]; }   // flags | n_match<<8 | match0<<16 | match1<<24
 
 // 64-bit rotate as two v_alignbit_b32 (the compiler's shift/or expansion takes 3-4 VALU ops): K is a compile-time constant.
 template <int K_>

@@ -76,7 +76,7 @@ struct madsim_hip_ctx {
     struct Tables {
         uint64_t hash = 0;
         std::vector<uint32_t> host;      // insns | progs | socks | durs (as 32-bit words) | n_insns
-        uint4* insns = nullptr; uint32_t* progs = nullptr; uint32_t* socks = nullptr; uint64_t* durs = nullptr;
+        uint4* insns = nullptr; uint32_t* progs = nullptr; uint32_t* socks = nullptr; uint32_t* nodes = nullptr; uint64_t* durs = nullptr;
     };
     std::vector<Tables> tables;
     // per-stream scratch: launches on one stream run in order, launches on different streams may overlap and must
@@ -99,6 +99,7 @@ struct madsim_hip_ctx {
         if (t.insns) (void)hipFree(t.insns);
         if (t.progs) (void)hipFree(t.progs);
         if (t.socks) (void)hipFree(t.socks);
+        if (t.nodes) (void)hipFree(t.nodes);
         if (t.durs) (void)hipFree(t.durs);
         t = Tables();
     }
@@ -170,6 +171,7 @@ int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
     host.insert(host.end(), T.insns.begin(), T.insns.end());
     host.insert(host.end(), T.progs.begin(), T.progs.begin() + w->n_progs);
     host.insert(host.end(), T.socks.begin(), T.socks.begin() + w->n_socks);
+    host.insert(host.end(), T.nodes.begin(), T.nodes.end());
     for (uint64_t d : T.durs) { host.push_back((uint32_t)d); host.push_back((uint32_t)(d >> 32)); }
     host.push_back(w->n_insns);
     const uint64_t h = fnv(host.data(), host.size() * 4, 14695981039346656037ull);
@@ -188,6 +190,8 @@ int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
             HIP_TRY(hipMalloc(&t.progs, T.progs.size() * 4 + 16));
             HIP_TRY(hipMalloc(&t.socks, T.socks.size() * 4 + 16));
             HIP_TRY(hipMalloc(&t.durs, T.durs.size() * 8 + 16));
+            HIP_TRY(hipMalloc(&t.nodes, T.nodes.size() * 4 + 16));
+            HIP_TRY(hipMemcpy(t.nodes, T.nodes.data(), T.nodes.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(t.insns, T.insns.data(), T.insns.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(t.progs, T.progs.data(), T.progs.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(t.socks, T.socks.data(), T.socks.size() * 4, hipMemcpyHostToDevice));
@@ -199,7 +203,7 @@ int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
         tables.push_back(std::move(t));
         hit = &tables.back();
     }
-    P.insns = hit->insns; P.progs = hit->progs; P.socks = hit->socks; P.dur_table = hit->durs;
+    P.insns = hit->insns; P.progs = hit->progs; P.socks = hit->socks; P.nodes = hit->nodes; P.dur_table = hit->durs;
     return 0;
 }
 

@@ -22,6 +22,7 @@ struct KParams {
     const uint4*    insns;     // {op|a<<8|b<<16, imm, fused assert value, fused post-chain word} (geometry.h build_tables)
     const uint32_t* progs;     // node | flags<<8 | entry<<16
     const uint32_t* socks;     // node | port<<16
+    const uint32_t* nodes;     // per node: flags | n_match<<8 | match[0]<<16 | match[1]<<24 (madsim_node_t as one word)
     const uint64_t* dur_table; // per MS_OP_SLEEP_RAND (its `a` is rewritten to an index): {mode, low, range, zone}
     uint32_t n_insns, n_progs, n_socks, n_nodes;
     // net config (Bernoulli p_int, UniformDuration parameters precomputed on the host)
@@ -36,12 +37,13 @@ struct KParams {
     uint32_t lw_shift;         // log2(seed-carrying lanes per wave): lane stride of every per-lane LDS array
     // LDS layout, in 32-bit words: workgroup-shared tables, heap units and task units (16-byte
     // aligned, [unit][lane]), then the 32-bit planes ([word][lane])
-    uint32_t sh_insns, sh_progs, sh_socks, sh_heap, sh_tasks, sh_planes;
+    uint32_t sh_insns, sh_progs, sh_socks, sh_nodes, sh_heap, sh_tasks, sh_planes;
     // a workgroup is waves_per_block independent waves (one per SIMD): the tables once, then one
     // [heap][tasks][planes] slice of wave_words per wave; sh_heap/sh_tasks/sh_planes are wave 0's
     uint32_t waves_per_block, wave_words;
     // per-lane plane offsets (in words)
-    uint32_t off_ready, off_socks, off_handles, off_nodes, off_clog, off_pause, off_greg, off_conn;
+    uint32_t off_ready, off_socks, off_handles, off_nodes, off_clog, off_pause, off_greg, off_conn, off_hooks;
+    uint32_t uses_hooks;       // MS_OP_HOOK_REQ / MS_OP_HOOK_RSP present: one hook word per node
     uint32_t uses_chan, max_conns, chan_queue, conn_words;   // reliable channel (connect1/accept1) state, if used
     uint32_t chan_unit;            // index of the task unit holding the (tx, rx) pair state
     uint32_t uses_rpc, rpc_unit;   // typed RPC: index of the task unit holding the response tags

@@ -92,12 +92,14 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
     for (uint32_t i = cp0; i < P.n_insns * 4; i += cps) sh[P.sh_insns + i] = ((const uint32_t*)P.insns)[i];
     for (uint32_t i = cp0; i < P.n_progs; i += cps) sh[P.sh_progs + i] = P.progs[i];
     for (uint32_t i = cp0; i < P.n_socks; i += cps) sh[P.sh_socks + i] = P.socks[i];
+    for (uint32_t i = cp0; i <= P.n_nodes; i += cps) sh[P.sh_nodes + i] = P.nodes[i];
     __syncthreads();
 
     Ctx c(P);
     c.insn0 = P.sh_insns / 4;
     c.prog0 = P.sh_progs;
     c.sockt0 = P.sh_socks;
+    c.nodet0 = P.sh_nodes;
     const uint32_t wbase = wv * P.wave_words;       // this wave's slice of the workgroup's LDS
     if (K::LIFE) c.heap0 = (P.sh_heap + wbase) / 4 + lane;
     else { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = P.sh_heap + wbase + ((P.heap_lds * 2) << P.lw_shift) + lane; }
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
         c.task0 = 0;
         c.sock0 = P.gs_planes + P.off_socks * 4; c.hand0 = P.gs_planes + P.off_handles * 4; c.node0 = P.gs_planes + P.off_nodes * 4;
         c.clog0 = P.gs_planes + P.off_clog * 4; c.pause0 = P.gs_planes + P.off_pause * 4; c.greg0 = P.gs_planes + P.off_greg * 4;
-        c.conn0 = P.gs_planes + P.off_conn * 4;
+        c.conn0 = P.gs_planes + P.off_conn * 4; c.hook0 = P.gs_planes + P.off_hooks * 4;
     } else {
         c.task0 = (P.sh_tasks + wbase) / 4 + lane;
         c.task1 = (P.sh_tasks + wbase + ((P.max_tasks * 4) << P.lw_shift)) / 2 + lane;      // base-op builds: behind the unit0 array
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
         c.pause0 = pl + (P.off_pause << P.lw_shift);
         c.greg0 = pl + (P.off_greg << P.lw_shift);
         c.conn0 = pl + (P.off_conn << P.lw_shift);
+        c.hook0 = pl + (P.off_hooks << P.lw_shift);
     }
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
     const uint32_t glane = ((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane;
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
                 parked = true;
             } else {
                 u0.x = (u0.x & ~TF_SCHED) | TF_RUN;          // async-task run(): SCHEDULED -> RUNNING
+                if (K::FN) L.panic_code = MADSIM_PANIC_CODE_OTHER;
                 panicked = poll_task<K>(c, L, slot, u0, u1);
                 if (!panicked && (u0.x & TF_ALIVE)) {
                     if (u0.x & TF_SCHED) ready_push<K>(c, L, slot);   // woken while running: re-queue after the poll
@@ -206,7 +210,11 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
             PROBE(2);
             if (K::FN && panicked && P.has_restart_on_panic) {   // task/mod.rs:289-314
                 uint32_t node = PROGW(c, u0.x >> 24) & 0xff;
-                if ((P.restart_nodes >> node) & 1) {
+                // restart_on_panic || restart_on_panic_matching.iter().any(|s| error_msg.contains(s)) (task/mod.rs:297-300)
+                const uint32_t nw = NODET(c, node), nm = (nw >> 8) & 0xff;
+                const bool matches = (nw & MADSIM_NODE_RESTART_MATCHING) &&
+                                     ((nm >= 1 && ((nw >> 16) & 0xff) == L.panic_code) || (nm >= 2 && (nw >> 24) == L.panic_code));
+                if ((nw & MADSIM_NODE_RESTART_ON_PANIC) || matches) {
                     // async-task's panic guard already dropped the future and notified the awaiter
                     TU(c, slot, 0) = u0;
                     task_finish<K>(c, L, slot, H_CANCELLED);

@@ -58,8 +58,13 @@ class TaskBuilder:
     def yield_now(self):
         return self._emit("YIELD")
 
-    def panic(self):
-        return self._emit("PANIC")
+    def panic(self, code=0):
+        """panic!() with message code `code` (0..254), the thing restart_on_panic_matching patterns name."""
+        return self._emit("PANIC", a=0, imm=code)
+
+    def panic_with_flag(self, flag, offset=0):
+        """panic!("{}", flag.load() + offset): the message code is the flag's value."""
+        return self._emit("PANIC", a=1, b=flag, imm=offset & 0xFFFFFFFF)
 
     def set(self, reg, value):
         return self._emit("SET", a=reg, imm=value)
@@ -124,6 +129,15 @@ class TaskBuilder:
         if not (0 <= code <= 0xFF and 0 <= timeout_ms < (1 << 24) and 0 <= req_id <= 0x7D):
             raise ValueError("rpc_call: code is 8 bits, timeout_ms 24 bits, req_id 0..125")
         return self._emit("RPC_CALL", a=ep, b=((0x80 + req_id) << 8) | dst, imm=(timeout_ms << 8) | code)
+
+    def hook_rpc_req(self, node, req_id, code=None):
+        """NetSim::current().hook_rpc_req::<R>(node, |req| ..): drop requests R sent from `node` — those with request code
+        `code`, or all of them when code is None (net/mod.rs:240-262)."""
+        return self._emit("HOOK_REQ", a=node, b=((0x80 + req_id) << 8) | (1 if code is None else 0), imm=code or 0)
+
+    def hook_rpc_rsp(self, node, code=None):
+        """NetSim::current().hook_rpc_rsp::<R>(node, |rsp| ..): drop responses on their way to `node` (net/mod.rs:264-284)."""
+        return self._emit("HOOK_RSP", a=node, b=1 if code is None else 0, imm=code or 0)
 
     def rpc_recv(self, ep, req_id):
         """(req, from) = recv_from_raw(R::ID) of a handler loop (rpc.rs:161): val = request code."""
@@ -256,9 +270,17 @@ class WorkloadBuilder:
         """The future handed to Runtime::block_on / the #[madsim::test] body."""
         return self.tasks[0]
 
-    def create_node(self, restart_on_panic=False):
+    def create_node(self, restart_on_panic=False, restart_on_panic_matching=()):
+        """create_node()[.restart_on_panic()][.restart_on_panic_matching(code)...] (runtime/mod.rs:377-387)."""
         n = A.Node()
         n.flags = A.NODE_RESTART_ON_PANIC if restart_on_panic else 0
+        if restart_on_panic_matching:
+            if len(restart_on_panic_matching) > 2 or any(not 0 <= c <= 254 for c in restart_on_panic_matching):
+                raise ValueError("at most two patterns, message codes 0..254")
+            n.flags |= A.NODE_RESTART_MATCHING
+            n.n_match = len(restart_on_panic_matching)
+            for i, c in enumerate(restart_on_panic_matching):
+                n.match[i] = c
         self.nodes.append(n)
         return len(self.nodes) - 1
 

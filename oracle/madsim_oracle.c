@@ -90,6 +90,8 @@ typedef struct {           /* naive_timer::Event: deadline + boxed callback     
     uint32_t val;          /* EV_DELIVER payload                                                     */
     uint64_t aux;          /* typed RPC request payload: the caller's rsp_tag (rpc.rs:121-124)       */
     uint8_t  node;         /* EV_RESTART                                                             */
+    uint8_t  is_rsp, hook_valid, hook_all, hook_code;   /* EV_DELIVER: the hooks_rsp entry of the destination node,
+                              cloned when the message was sent and consulted when it arrives (net/mod.rs:321-328) */
 } event_t;
 
 typedef struct { uint64_t tag; uint16_t slot, gen; uint8_t rxseq; } reg_t; /* (tag, oneshot::Sender) */
@@ -149,6 +151,8 @@ typedef struct {
     uint8_t killed, paused;               /* the CURRENT Arc<NodeInfo>'s flags (task/mod.rs:100-103)  */
     uint8_t info_gen;                     /* how many times Handle::restart replaced the NodeInfo     */
     uint8_t gen0_killed;                  /* the NodeInfo captured by NodeHandles at build() is dead  */
+    /* NetSim.hooks_req / hooks_rsp entries of this node (net/mod.rs:250-284): valid, mode (1 = drop all), tag, code */
+    uint8_t hreq_valid, hreq_all, hreq_tag, hreq_code, hrsp_valid, hrsp_all, hrsp_code;
     VEC(uint16_t) paused_list;            /* Node.paused: Vec<Runnable> (task/mod.rs:345-350)        */
     VEC(tref_t) tasks;                    /* NodeInfo.tasks: Vec<Weak<TaskInfo>> in spawn order (:105) */
 } node_t;
@@ -175,6 +179,7 @@ typedef struct {
     int lat_mode; uint64_t lat_low, lat_range, lat_zone; /* UniformDuration               [DEP A.3] */
     const madsim_config_t* cfg;
     /* accounting */
+    uint8_t panic_code;                                  /* message code of the panic being unwound */
     uint64_t msg_count; uint32_t steps; uint64_t obs_hash;
     uint32_t greg[4];                     /* Arc<AtomicUsize> flags shared by the test's tasks       */
     VEC(conn_t) conns;
@@ -617,7 +622,18 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (t->sub == 0) { t->sub = 1; wake(S, slot, t->gen); return 0; }
             t->sub = 0; t->pc++;
             break;
-        case MS_OP_PANIC:
+        case MS_OP_HOOK_REQ: {                             /* NetSim::hook_rpc_req (net/mod.rs:240-262): HashMap::insert */
+            node_t* n = &S->nodes[in->a];
+            n->hreq_valid = 1; n->hreq_all = in->b & 1; n->hreq_tag = (uint8_t)(in->b >> 8); n->hreq_code = (uint8_t)in->imm;
+            t->pc++; break;
+        }
+        case MS_OP_HOOK_RSP: {                             /* NetSim::hook_rpc_rsp (net/mod.rs:264-284) */
+            node_t* n = &S->nodes[in->a];
+            n->hrsp_valid = 1; n->hrsp_all = in->b & 1; n->hrsp_code = (uint8_t)in->imm;
+            t->pc++; break;
+        }
+        case MS_OP_PANIC:                                  /* the message code restart_on_panic_matching looks at */
+            S->panic_code = in->a & 1 ? (uint8_t)(S->greg[in->b & 3] + in->imm) : (uint8_t)in->imm;
             return 1;
         case MS_OP_SET:
             t->cnt[in->a & 1] = (uint16_t)in->imm; t->pc++;
@@ -685,7 +701,11 @@ static int poll_task(sim_t* S, uint16_t slot) {
                     e.deadline = S->clock + lat; e.kind = EV_DELIVER; e.sock = (uint8_t)ds;
                     e.sockgen = S->socks[ds].gen; e.from = in->a; e.tag = (uint8_t)(in->b >> 8);
                     e.val = in->imm;
-                    if (in->op == MS_OP_RPC_REPLY) { e.tag = t->aux; e.val = in->imm & 0xff; }
+                    if (in->op == MS_OP_RPC_REPLY) {
+                        e.tag = t->aux; e.val = in->imm & 0xff;
+                        const node_t* dn = &S->nodes[w->socks[ds].node];   /* hooks_rsp.get(&dst_node).cloned() (:321) */
+                        e.is_rsp = 1; e.hook_valid = dn->hrsp_valid; e.hook_all = dn->hrsp_all; e.hook_code = dn->hrsp_code;
+                    }
                     timer_add(S, e);
                 }
             }
@@ -874,7 +894,10 @@ static int poll_task(sim_t* S, uint16_t slot) {
             }
             if (t->sub == 1 && sleep_poll(S, slot, t->deadline)) {
                 uint64_t lat; int ds;
-                if (try_send(S, w->socks[in->a].node, dst, &lat, &ds)) {
+                /* hooks_req.get(&node): `if !hook(&msg) { return Ok(()) }` before try_send (net/mod.rs:307-311) */
+                const node_t* sn = &S->nodes[w->socks[in->a].node];
+                const int hooked = sn->hreq_valid && sn->hreq_tag == (uint8_t)(in->b >> 8) && (sn->hreq_all || sn->hreq_code == (uint8_t)in->imm);
+                if (!hooked && try_send(S, w->socks[in->a].node, dst, &lat, &ds)) {
                     event_t e; memset(&e, 0, sizeof e);
                     e.deadline = S->clock + lat; e.kind = EV_DELIVER; e.sock = (uint8_t)ds;
                     e.sockgen = S->socks[ds].gen; e.from = in->a; e.tag = (uint8_t)(in->b >> 8);
@@ -983,7 +1006,9 @@ static void timer_expire(sim_t* S, uint64_t now) {
         S->steps++;
         switch (e.kind) {
         case EV_WAKE: wake(S, e.slot, e.gen); break;       /* time/sleep.rs:52 waker.wake() */
-        case EV_DELIVER: mailbox_deliver(S, &e); break;    /* net/mod.rs:323-330 */
+        case EV_DELIVER:                                   /* net/mod.rs:323-330 */
+            if (e.is_rsp && e.hook_valid && (e.hook_all || e.hook_code == (uint8_t)e.val)) break;   /* !hook(&msg): return */
+            mailbox_deliver(S, &e); break;
         case EV_RESTART: node_restart(S, e.node); break;   /* task/mod.rs:313 */
         default: break;
         }
@@ -1009,11 +1034,16 @@ static void run_all_ready(sim_t* S, uint32_t max_steps) {
             continue;
         } else {
             t->scheduled = 0; t->running = 1;              /* async-task run(): clear SCHEDULED, set RUNNING */
+            S->panic_code = MADSIM_PANIC_CODE_OTHER;      /* failed asserts / unwraps: a message no pattern names */
             int panicked = poll_task(S, slot);
             t = &S->tasks.p[slot];
             if (panicked) {                                /* :289-317 */
                 unsigned node = t->node;
-                int restart = (S->w->nodes[node].flags & MADSIM_NODE_RESTART_ON_PANIC) != 0;
+                const madsim_node_t* nb = &S->w->nodes[node];
+                /* restart_on_panic || restart_on_panic_matching.iter().any(|s| error_msg.contains(s)) (:297-300) */
+                int restart = (nb->flags & MADSIM_NODE_RESTART_ON_PANIC) != 0;
+                if (nb->flags & MADSIM_NODE_RESTART_MATCHING)
+                    for (unsigned k = 0; k < nb->n_match && k < 2; k++) restart |= nb->match[k] == S->panic_code;
                 if (!restart) {
                     S->panic = 1;
                     return;                                /* resume_unwind: block_on unwinds */

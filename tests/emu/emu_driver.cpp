@@ -61,7 +61,7 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
     madsim_k::KParams& P = G.P;
     madsim_geo::DeviceTables T;
     if ((rc = madsim_geo::build_tables(w, &T, &emu_err))) return rc;
-    P.insns = (const uint4*)T.insns.data(); P.progs = T.progs.data(); P.socks = T.socks.data(); P.dur_table = T.durs.data();
+    P.insns = (const uint4*)T.insns.data(); P.progs = T.progs.data(); P.socks = T.socks.data(); P.nodes = T.nodes.data(); P.dur_table = T.durs.data();
     std::vector<uint4> spill((size_t)P.heap_spill * P.total_lanes + 1);
     P.spill = P.heap_spill ? spill.data() : nullptr;
     std::vector<uint4> gstate((size_t)P.gs_stride * P.total_lanes / 16 + 4);

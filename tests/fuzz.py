@@ -232,7 +232,7 @@ def generous_limits():
     return lim
 
 
-def random_rpc_workload(rng: random.Random):
+def random_rpc_workload(rng: random.Random, hooks=False):
     """Typed-RPC programs (net/rpc.rs): handler tasks with per-request children, `call` / `call_timeout` loops, slow and
     silent handlers, lossy links, server kill/restart and clogs.  Returns (BuiltWorkload, Config, description)."""
     wl = W.WorkloadBuilder()
@@ -286,10 +286,17 @@ def random_rpc_workload(rng: random.Random):
             m.spawn(s)
     for c in clients:
         m.spawn(c)
-    for _ in range(rng.randint(0, 5)):
-        act = rng.choice(["sleep", "sleep", "kill", "restart", "clog", "unclog"])
+    all_nodes = list(range(1, n_srv + n_cl + 1))
+    for _ in range(rng.randint(0, 5) + (2 if hooks else 0)):
+        act = rng.choice(["sleep", "sleep", "kill", "restart", "clog", "unclog"] + (["hook_req", "hook_rsp", "hook_rsp"] if hooks else []))
         n = rng.choice(servers)[0]
-        if act == "sleep":
+        if act == "hook_req":                              # NetSim::hook_rpc_req / hook_rpc_rsp (net/mod.rs:240-284)
+            m.hook_rpc_req(rng.choice(all_nodes), rng.randrange(n_srv), rng.choice([None, rng.randrange(256)]))
+            desc.append("hook_req")
+        elif act == "hook_rsp":
+            m.hook_rpc_rsp(rng.choice(all_nodes), rng.choice([None, 0x40, 0x41]))
+            desc.append("hook_rsp")
+        elif act == "sleep":
             m.sleep(ms=rng.choice([3, 25, 150, 900]))
         elif act == "kill":
             m.kill(n)

@@ -51,6 +51,27 @@ def restart_on_panic():
     return wl.build()
 
 
+def restart_on_panic_matching():
+    """task/mod.rs:964-982 (#[should_panic(expected = "2")]): the init task panics with its attempt number; the node
+    restarts on messages "0" and "1", so the third panic ("2") unwinds out of block_on."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node(restart_on_panic_matching=(0, 1))
+    t = wl.task(n, init=True, pre=True)
+    t.flag_add(0, 1); t.panic_with_flag(0, offset=-1)          # panic!("{}", flag.fetch_add(1))
+    m = wl.main(); m.sleep(secs=120)                          # block_on(pending()): the panic ends the run long before
+    return wl.build()
+
+
+def restart_on_panic_matching_other_message():
+    """A message no pattern names unwinds at once (no restart, no 1..10 s draw): patterns "5" / "6", panic "0"."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node(restart_on_panic_matching=(5, 6))
+    t = wl.task(n, init=True, pre=True)
+    t.sleep(ms=3); t.panic(code=0)
+    m = wl.main(); m.sleep(secs=120)
+    return wl.build()
+
+
 def panic_without_restart():
     """task/mod.rs:315 resume_unwind: a panic on a node that does not restart fails the run."""
     wl = W.WorkloadBuilder()
@@ -184,7 +205,7 @@ ALL = dict(receiver_drop=receiver_drop, request_timeout_with_stale_timers=reques
            kill=kill, restart=restart, restart_on_panic=restart_on_panic, panic_without_restart=panic_without_restart,
            pause_resume=pause_resume, kill_drop_futures=kill_drop_futures, join_cancelled=join_cancelled,
            exited=exited, spawn_on_killed_node=spawn_on_killed_node, kill_restart_with_traffic=kill_restart_with_traffic)
-EXPECT_PANIC = {"panic_without_restart"}
+EXPECT_PANIC = {"panic_without_restart", "restart_on_panic_matching", "restart_on_panic_matching_other_message"}
 
 
 def kv_rpc(n_clients=2, n_ops=3):
@@ -246,6 +267,8 @@ def connect_refused_and_reset():
     return wl.build()
 
 
+ALL.update(restart_on_panic_matching=restart_on_panic_matching,
+           restart_on_panic_matching_other_message=restart_on_panic_matching_other_message)
 ALL.update(kv_rpc=kv_rpc, channel_backoff=channel_backoff, connect_refused_and_reset=connect_refused_and_reset)
 
 
@@ -317,7 +340,35 @@ def rpc_server_restart():
     return wl.build()
 
 
-ALL.update(rpc_echo=rpc_echo, rpc_call_timeout_then_retry=rpc_call_timeout_then_retry, rpc_server_restart=rpc_server_restart)
+def rpc_hooks():
+    """NetSim::hook_rpc_req / hook_rpc_rsp (net/mod.rs:240-284, consulted in NetSim::send :307-311,321-328): requests R{5}
+    leaving node 1 vanish before the link test (no loss / latency draws), every response on its way to node 2 is judged
+    by the hook that was installed when it was sent and dropped on arrival; replacing a hook takes effect for messages
+    sent afterwards; node 3 is untouched."""
+    wl = W.WorkloadBuilder()
+    ns = wl.create_node(); asv = wl.addr(ns, 1)
+    srv = _rpc_server(wl, ns, asv, 42)
+    n1, n2, n3 = wl.create_node(), wl.create_node(), wl.create_node()
+    a1, a2, a3 = wl.addr(n1, 1), wl.addr(n2, 1), wl.addr(n3, 1)
+    c1 = wl.task(n1); c1.bind(a1); c1.sleep(ms=10)
+    c1.rpc_call(a1, asv, 0, 5, timeout_ms=100); c1.assert_val(A.VAL_TIMEOUT)       # dropped by the request hook
+    c1.rpc_call(a1, asv, 0, 6, timeout_ms=100); c1.assert_val(42)                  # another request value passes
+    c2 = wl.task(n2); c2.bind(a2); c2.sleep(ms=10)
+    c2.rpc_call(a2, asv, 0, 7, timeout_ms=100); c2.assert_val(A.VAL_TIMEOUT)       # the response is dropped on arrival
+    c2.sleep(ms=400)                                                               # main replaces the hook meanwhile
+    c2.rpc_call(a2, asv, 0, 8, timeout_ms=100); c2.assert_val(42)                  # only responses 99 are dropped now
+    c3 = wl.task(n3); c3.bind(a3); c3.sleep(ms=10); c3.set(0, 3); top = c3.label()
+    c3.rpc_call(a3, asv, 0, 9); c3.assert_val(42); c3.djnz(0, top)
+    m = wl.main()
+    m.hook_rpc_req(n1, 0, code=5); m.hook_rpc_rsp(n2)
+    m.spawn(srv); m.spawn(c1); m.spawn(c2); m.spawn(c3)
+    m.sleep(ms=300); m.hook_rpc_rsp(n2, code=99); m.hook_rpc_req(n1, 1)            # (a hook for another request type: R{..} of type 0 pass)
+    m.join(c1); m.join(c2); m.join(c3)
+    return wl.build()
+
+
+ALL.update(rpc_echo=rpc_echo, rpc_call_timeout_then_retry=rpc_call_timeout_then_retry, rpc_server_restart=rpc_server_restart,
+           rpc_hooks=rpc_hooks)
 
 
 def std_system_time():
@@ -365,7 +416,7 @@ def config(name):
 
 def limits(name):
     """Device capacities a workload needs beyond the defaults (None = defaults)."""
-    if name == "rpc_server_restart":                  # timed-out calls leave dead registrations behind (rpc.rs:125)
+    if name in ("rpc_server_restart", "rpc_hooks"):   # timed-out calls leave dead registrations behind (rpc.rs:125)
         lim = A.Limits(); lim.mbox_regs, lim.mbox_msgs = 8, 4
         return lim
     return None

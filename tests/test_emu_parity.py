@@ -140,6 +140,17 @@ def test_fuzz_rpc_workloads():
         assert (e["verdict"] == A.OVERFLOW).mean() < 0.1
 
 
+def test_fuzz_rpc_hooks_and_panic_codes():
+    """Random typed-RPC programs with NetSim request / response hooks installed and replaced at random moments."""
+    for k in range(150):
+        w, cfg, desc = fuzz.random_rpc_workload(random.Random(61000 + k), hooks=True)
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        o, _ = oracle.run_batch(w, k * 5, 12, cfg, lim)
+        e = emu.run_batch(w, k * 5, 12, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+
+
 def _global(lim=None):
     """The same limits with the task table and planes forced into the per-lane global-memory block (Variant::G)."""
     g = A.Limits()

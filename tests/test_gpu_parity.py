@@ -550,6 +550,21 @@ def test_ref_twin_workloads_gpu(hip):
     _cmp(hip, T.ALL["pingpong4"](), 0, 512, A.Config.default(packet_loss_rate=0.01))
 
 
+def test_fuzz_rpc_hooks_gpu(hip):
+    """Random typed-RPC programs with NetSim::hook_rpc_req / hook_rpc_rsp (net/mod.rs:240-284), LDS and global state."""
+    import random
+    from tests import fuzz
+    for k in range(120):
+        w, cfg, desc = fuzz.random_rpc_workload(random.Random(64000 + k), hooks=True)
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        if k % 2:
+            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        got, _ = hip.run_batch(w, k * 19, 96, cfg, lim)
+        want, _ = oracle.run_batch(w, k * 19, 96, cfg, lim)
+        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+
+
 def _global_limits(lim=None):
     g = A.Limits()
     if lim is not None:
