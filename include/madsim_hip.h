@@ -72,7 +72,8 @@ enum madsim_op {
     MS_OP_ASSERT_ELAPSED = 13, /* a=cmp (0 ==, 1 >=, 2 <): assert!(t0.elapsed() cmp b s + imm ns)    */
     MS_OP_ADVANCE = 14,    /* time::advance(b s + imm ns) (time/mod.rs:195-198, 103-106)             */
     /* -- net (datagram Endpoint API, net/endpoint.rs) -- */
-    MS_OP_BIND = 20,       /* a=sock: Endpoint::bind(addr(sock)).await.unwrap() (endpoint.rs:23-36)  */
+    MS_OP_BIND = 20,       /* a=sock: Endpoint::bind(addr(sock)).await.unwrap() (endpoint.rs:23-36, network.rs:206-251).
+                              b&1: without the unwrap — val := 0, MADSIM_VAL_ADDR_NOT_AVAILABLE or MADSIM_VAL_ADDR_IN_USE   */
     MS_OP_SEND = 21,       /* a=src sock, b=(tag<<8)|dst addr, imm=payload:
                               ep.send_to(addr(dst), tag, payload).await (endpoint.rs:69-72,120-133)  */
     MS_OP_REPLY = 22,      /* a=src sock, b=(tag<<8), imm=payload: ep.send_to(from, tag, ..).await   */
@@ -151,6 +152,8 @@ enum madsim_op {
 #define MADSIM_VAL_TIMEOUT 0xFFFFFFFFu
 #define MADSIM_VAL_REFUSED 0xFFFFFFFEu
 #define MADSIM_VAL_RESET   0xFFFFFFFDu
+#define MADSIM_VAL_ADDR_NOT_AVAILABLE 0xFFFFFFFCu
+#define MADSIM_VAL_ADDR_IN_USE        0xFFFFFFFBu
 
 /* A task program: where it runs and where it starts.  Program 0 is the body handed to block_on
  * (the main task on node 0, task/mod.rs:222-235). */
@@ -165,14 +168,22 @@ typedef struct madsim_prog {
 #define MADSIM_PROG_PRE  2u /* spawned before Runtime::block_on pushes the main task, in prog order:
                                `node.spawn(..)` ahead of `runtime.block_on(..)` (task/mod.rs:859-897) */
 
-/* A socket address that an Endpoint may bind: node's IP 10.0.0.<node> and a port.  `addr` operands
- * of SEND name one of these; resolution to a *bound* socket happens at try_send time
- * (network.rs:296-313). */
+/* A socket address an Endpoint may bind or a datagram may be sent to: an IP and a port (never 0: ephemeral ports are
+ * not modelled).  `kind` picks the IP: the node's own 10.0.0.<node>, 0.0.0.0 or 127.0.0.1 as used ON `node` (entries of
+ * the last two kinds are per node: only tasks of `node` may bind them).  Resolution happens at try_send time exactly as
+ * in network.rs:272-313: loopback or an exact match among the sender's own sockets keeps the message on the sender's
+ * node; an IP-less sender or an unknown IP drops it WITHOUT any RNG draw; after the link test (loss + latency draws,
+ * msg_count) the destination node's sockets are searched for the exact address, then for 0.0.0.0:port.  The address a
+ * receiver sees (`from`, what MS_OP_REPLY answers to) is the sender's real IP — or 127.0.0.1 when the datagram was sent
+ * to a loopback address — with the sending socket's port (network.rs:307-311). */
 typedef struct madsim_sock {
     uint8_t  node;
-    uint8_t  reserved;
+    uint8_t  kind;   /* MADSIM_ADDR_* */
     uint16_t port;
 } madsim_sock_t;
+#define MADSIM_ADDR_IP          0u  /* 10.0.0.<node>:port */
+#define MADSIM_ADDR_UNSPECIFIED 1u  /* 0.0.0.0:port       */
+#define MADSIM_ADDR_LOOPBACK    2u  /* 127.0.0.1:port     */
 
 typedef struct madsim_node {
     uint8_t flags;       /* MADSIM_NODE_* */
@@ -186,6 +197,8 @@ typedef struct madsim_node {
                                            equality — exact for single-token messages like the reference test's
                                            (task/mod.rs:964-982), not a substring search                     */
 #define MADSIM_PANIC_CODE_OTHER 255u
+#define MADSIM_NODE_NO_IP 2u /* create_node() without .ip(..): binds any address, cannot send to another node's IP
+                                (network.rs:281-283: "ip not set", no RNG draw)                              */
 
 typedef struct madsim_workload {
     uint32_t n_nodes;   /* nodes 1..n_nodes besides node 0                                           */

@@ -24,8 +24,13 @@ class Prog(C.Structure):
     _fields_ = [("node", C.c_uint8), ("flags", C.c_uint8), ("entry", C.c_uint16)]
 
 
+ADDR_IP, ADDR_UNSPECIFIED, ADDR_LOOPBACK = 0, 1, 2
+VAL_ADDR_NOT_AVAILABLE, VAL_ADDR_IN_USE = 0xFFFFFFFC, 0xFFFFFFFB
+NODE_NO_IP = 2
+
+
 class Sock(C.Structure):
-    _fields_ = [("node", C.c_uint8), ("reserved", C.c_uint8), ("port", C.c_uint16)]
+    _fields_ = [("node", C.c_uint8), ("kind", C.c_uint8), ("port", C.c_uint16)]
 
 
 class Node(C.Structure):

@@ -61,6 +61,8 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
         if (w->progs[i].node > w->n_nodes || w->progs[i].entry >= w->n_insns) return fail(err, MADSIM_E_WORKLOAD, "bad prog entry");
     for (uint32_t i = 0; i < w->n_socks; i++)
         if (w->socks[i].node == 0 || w->socks[i].node > w->n_nodes) return fail(err, MADSIM_E_WORKLOAD, "bad socket node");
+    for (uint32_t i = 0; i < w->n_socks; i++)
+        if (w->socks[i].kind > MADSIM_ADDR_LOOPBACK || w->socks[i].port == 0) return fail(err, MADSIM_E_WORKLOAD, "bad socket address (kind 0..2, port != 0: ephemeral ports are not modelled)");
     for (uint32_t i = 0; i < w->n_insns; i++) {
         const madsim_insn_t& in = w->insns[i];
         switch (in.op) {
@@ -144,10 +146,15 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.conn_words = 3 + 2 * P.chan_queue * 3;
     P.has_clog_link = uses_op(w, MS_OP_CLOG_LINK) || uses_op(w, MS_OP_UNCLOG_LINK);
     P.has_clog = P.has_clog_link || uses_op(w, MS_OP_CLOG_NODE) || uses_op(w, MS_OP_UNCLOG_NODE);
+    // uniq_addr: every table entry is a distinct node-IP address and every node has its IP — then an address resolves to
+    // its node and to its own table entry, and the kernel skips the general resolution of network.rs:272-313
     P.uniq_addr = 1;
-    for (uint32_t i = 0; i < w->n_socks; i++)
+    for (uint32_t i = 0; i < w->n_socks; i++) {
+        if (w->socks[i].kind != MADSIM_ADDR_IP) P.uniq_addr = 0;
         for (uint32_t j = i + 1; j < w->n_socks; j++)
             if (w->socks[i].node == w->socks[j].node && w->socks[i].port == w->socks[j].port) P.uniq_addr = 0;
+    }
+    for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) if (w->nodes[i].flags & MADSIM_NODE_NO_IP) P.uniq_addr = 0;
     // ---- which optional per-seed regions exist (LDS diet: a workload only carries what it can touch) ----
     P.restart_nodes = 0;
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
@@ -328,7 +335,7 @@ inline int build_tables(const madsim_workload_t* w, DeviceTables* T, std::string
         T->insns[4 * i + 3] = flags | ((j & 0x3fffu) << 4) | ((target & 0x3fffu) << 18);
     }
     for (uint32_t i = 0; i < w->n_progs; i++) T->progs[i] = (uint32_t)w->progs[i].node | ((uint32_t)w->progs[i].flags << 8) | ((uint32_t)w->progs[i].entry << 16);
-    for (uint32_t i = 0; i < w->n_socks; i++) T->socks[i] = (uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].port << 16);
+    for (uint32_t i = 0; i < w->n_socks; i++) T->socks[i] = (uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].kind << 8) | ((uint32_t)w->socks[i].port << 16);
     T->nodes.assign(w->n_nodes + 1, 0);
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
         T->nodes[i] = (uint32_t)w->nodes[i].flags | ((uint32_t)(w->nodes[i].n_match > 2 ? 2 : w->nodes[i].n_match) << 8) |

@@ -6,30 +6,46 @@
 namespace madsim_k {
 
 // ---- reliable channel (NetSim::connect1 / channel, net/mod.rs:337-430) — LIFE variants only ---------------------
-// Network::try_send as a function (the datagram path has it inlined in poll_task's [A] stage).
+// Network::try_send (network.rs:296-313) + test_link (:261-269) for a datagram from `src_node` to the address `addr`
+// (node | kind << 8 | port << 16; `idx` = its socket-table entry when it has one, i.e. always for uniq_addr workloads).
+// Returns 1 with the latency, the destination socket and the dst-was-loopback flag of `from` when a delivery must be
+// scheduled, 0 when the message is dropped, -1 when the sender panics (`.ip.unwrap()` of an IP-less node, :309).
 template <class K>
-__device__ __forceinline__ bool try_send_fn(const Ctx& c, Lane& L, uint32_t src_node, uint32_t dst_addr, uint64_t* latency, int* dst_sock) {
+__device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_node, uint32_t addr, uint32_t idx, uint64_t* latency, int* dst_sock, uint32_t* from_lb) {
     const KParams& P = c.P;
-    uint32_t dst_node = SOCKW(c, dst_addr) & 0xff;
+    int dn = (int)(addr & 0xff);                            // resolve_dest_node: plain node IPs resolve to their node
+    if (!P.uniq_addr) { dn = resolve_dest_node<K>(c, src_node, addr); if (dn < 0) return 0; }     // dropped, no draw
+    const uint32_t dst_node = (uint32_t)dn;
     bool clogged = false;
     if (P.has_clog) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
     if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
-    if (clogged) return false;
-    if (gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) return false;
+    if (clogged) return 0;
+    if (gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) return 0;
     L.msg_count++;
     *latency = sample_latency<K>(c, L);
-    int ds = find_bound<K>(c, dst_addr);
-    if (ds < 0) return false;
+    int ds;
+    if (P.uniq_addr) ds = find_bound<K>(c, idx);
+    else {
+        ds = find_exact<K>(c, dst_node, addr);              // sockets.get(&(dst, protocol))
+        if (ds < 0) ds = find_exact<K>(c, dst_node, (addr & 0xffff0000u) | (MADSIM_ADDR_UNSPECIFIED << 8));   // .or_else(0.0.0.0:port)
+    }
+    if (ds < 0) return 0;                                   // draws consumed, silently dropped
+    *from_lb = 0;
+    if (!P.uniq_addr) {
+        *from_lb = ((addr >> 8) & 0xff) == MADSIM_ADDR_LOOPBACK;
+        if (!*from_lb && !node_has_ip(c, src_node)) return -1;
+    }
     *dst_sock = ds;
-    return true;
+    return 1;
 }
 
 // the `test_link` closure of channel() (net/mod.rs:375-380): Some(now + latency) or None
 template <class K>
 __device__ __forceinline__ uint64_t chan_test_link(const Ctx& c, Lane& L, uint32_t cw, uint32_t dir) {
     uint32_t c_ep = (cw >> 1) & 0x3f, s_ep = (cw >> 7) & 0x3f;
-    uint64_t lat; int ds;
-    if (!try_send_fn<K>(c, L, SOCKW(c, dir == 0 ? c_ep : s_ep) & 0xff, dir == 0 ? s_ep : c_ep, &lat, &ds)) return ~0ull;
+    uint64_t lat; int ds; uint32_t lb;
+    const uint32_t dst = dir == 0 ? s_ep : c_ep;
+    if (net_try_send<K>(c, L, SOCKW(c, dir == 0 ? c_ep : s_ep) & 0xff, SOCKW(c, dst), dst, &lat, &ds, &lb) <= 0) return ~0ull;
     return L.clock + lat;
 }
 

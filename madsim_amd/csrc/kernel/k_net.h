@@ -23,23 +23,48 @@ __device__ __forceinline__ void wake(const Ctx& c, Lane& L, uint32_t slot, uint3
 }
 
 // ---- Network -----------------------------------------------------------------------------------
-// Network::try_send's socket lookup (network.rs:304-306): the bound socket at addr(dst), if any.
+// A SocketAddr as one word, the form of the socket table: node | kind << 8 | port << 16 (kind = MADSIM_ADDR_*).
+__device__ __forceinline__ uint32_t addr_of_from(const Ctx& c, uint32_t from) {   // the address a receiver was shown
+    uint32_t w = SOCKW(c, from & 0x3f) & 0xffff00ffu;                             // sender's real IP and socket port,
+    return w | (((from & 0x40) ? MADSIM_ADDR_LOOPBACK : MADSIM_ADDR_IP) << 8);    // or 127.0.0.1 (network.rs:307-311)
+}
+__device__ __forceinline__ bool addr_eq(uint32_t x, uint32_t y) {                 // SocketAddr equality
+    return ((x ^ y) & 0xffffff00u) == 0 && ((x & 0xff00u) != (MADSIM_ADDR_IP << 8) || ((x ^ y) & 0xffu) == 0);
+}
+__device__ __forceinline__ bool node_has_ip(const Ctx& c, uint32_t node) { return !(NODET(c, node) & MADSIM_NODE_NO_IP); }
+
+// node.sockets.get(&(addr, protocol)) on node `on` (network.rs keys a node's sockets by the address they were bound to)
+template <class K>
+__device__ __forceinline__ int find_exact(const Ctx& c, uint32_t on, uint32_t addr) {
+    const uint32_t key = (addr & 0xffffff00u) | on;
+    if (((addr >> 8) & 0xff) == MADSIM_ADDR_IP && (addr & 0xff) != on) return -1;
+    for (uint32_t i = 0; i < c.P.n_socks; i++)
+        if (SOCKW(c, i) == key && (SW(c, i, 0) & 1)) return (int)i;
+    return -1;
+}
+// Network::try_send's socket lookup (network.rs:304-306) for workloads whose addresses are all distinct node IPs
+// (KParams.uniq_addr: the common case): the bound socket at table entry `addr`, if any.
 template <class K>
 __device__ __forceinline__ int find_bound(const Ctx& c, uint32_t addr) {
-    if (c.P.uniq_addr) return (SW(c, addr, 0) & 1) ? (int)addr : -1;
-    uint32_t key = SOCKW(c, addr) & 0xffff00ffu;
-    for (uint32_t i = 0; i < c.P.n_socks; i++)
-        if ((SOCKW(c, i) & 0xffff00ffu) == key && (SW(c, i, 0) & 1)) return (int)i;
-    return -1;
+    return (SW(c, addr, 0) & 1) ? (int)addr : -1;
+}
+// Network::resolve_dest_node (network.rs:272-290): the node a datagram for `addr` goes to, or -1 (dropped, no draws)
+template <class K>
+__device__ __forceinline__ int resolve_dest_node(const Ctx& c, uint32_t node, uint32_t addr) {
+    const uint32_t kind = (addr >> 8) & 0xff, an = addr & 0xff;
+    if (kind == MADSIM_ADDR_LOOPBACK || find_exact<K>(c, node, addr) >= 0) return (int)node;
+    if (!node_has_ip(c, node)) return -1;                                          // "ip not set"
+    if (kind == MADSIM_ADDR_IP && an >= 1 && an <= c.P.n_nodes && node_has_ip(c, an)) return (int)an;   // addr_to_node
+    return -1;                                                                     // "destination not found"
 }
 
 // Mailbox::deliver (endpoint.rs:331-351)
 template <class K>
 __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t meta, uint32_t val) {
-    uint32_t s = meta & 0x3f, from = (meta >> 6) & 0x3f, tag = (meta >> 12) & 0xff, sgen = (meta >> 20) & 0xff;
+    uint32_t s = meta & 0x3f, from = (meta >> 6) & 0x7f, tag = (meta >> 13) & 0xff, sgen = (meta >> 21) & 0xff;
     if (!K::LIFE) {                                        // base ops: the event names its send_to / reply instruction
         const uint4 in = INSN(c, (meta >> 6) & 0xfff);
-        from = (in.x >> 8) & 0xff; tag = in.x >> 24; val = in.y;
+        from = ((in.x >> 8) & 0x3f) | (((meta >> 18) & 1) << 6); tag = in.x >> 24; val = in.y;
     }
     uint32_t h = SW(c, s, 0);
     if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;     // that Endpoint object is gone
@@ -93,7 +118,7 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
     while (L.top_dl <= now) {
         uint4 e = timer_pop<K>(c, L);
         L.steps++;
-        uint32_t kind = e.z >> 28;
+        uint32_t kind = e.z >> EV_SHIFT;
         if (kind == EV_WAKE) { REG(22); wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff); }   // time/sleep.rs:52
         else if (kind == EV_DELIVER) { REG(23); mailbox_deliver<K>(c, L, e.z, e.w); }      // net/mod.rs:323-330
         else if (K::FN && kind == EV_RESTART) node_restart<K>(c, L, e.z & 0xff);   // task/mod.rs:313

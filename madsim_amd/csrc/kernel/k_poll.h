@@ -76,7 +76,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (sub == 2) {
             uint64_t d1 = u64of(u1.z, u1.w);
             if (L.clock >= d1) fut_ready = true;
-            else if (!timer_add<K>(c, L, d1, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+            else if (!timer_add<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
         }
         if (fut_ready) return true;                          // Ok((len, from))
         uint4 u2 = TU(c, slot, 2);
@@ -88,7 +88,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             u0.w = MADSIM_VAL_TIMEOUT;
             return true;
         }
-        if (!timer_add<K>(c, L, d2, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        if (!timer_add<K>(c, L, d2, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
         st = ST_PENDING;
         return false;
     };
@@ -104,7 +104,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (sub == 1) {
             uint64_t d1 = u64of(u1.z, u1.w);
             if (L.clock < d1) {
-                if (!timer_add<K>(c, L, d1, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+                if (!timer_add<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
             } else {
                 // the caller's pending receive doubles as the rsp_tag: registration word >> 8 (see mailbox_deliver)
                 const uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;
@@ -116,9 +116,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     const uint32_t hw = HOOKW(SOCKW(c, ca) & 0xff);
                     hooked = (hw & 1) && ((hw >> 10) & 0xff) == (cb >> 8) && ((hw & 2) || ((hw >> 2) & 0xff) == (cimm & 0xff));
                 }
-                if (!hooked && try_send_fn<K>(c, L, SOCKW(c, ca) & 0xff, dst, &lat, &ds)) {
+                uint32_t lb = 0;
+                const int sent = hooked ? 0 : net_try_send<K>(c, L, SOCKW(c, ca) & 0xff, SOCKW(c, dst), dst, &lat, &ds, &lb);
+                if (sent < 0) { st = ST_PANIC; return true; }
+                if (sent) {
                     uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
-                    uint32_t meta = (EV_DELIVER << 28) | (sgen << 20) | ((cb >> 8) << 12) | (ca << 6) | (uint32_t)ds;
+                    uint32_t meta = (EV_DELIVER << EV_SHIFT) | (sgen << 21) | ((cb >> 8) << 13) | ((ca | (lb << 6)) << 6) | (uint32_t)ds;
                     if (!timer_add<K>(c, L, L.clock + lat, meta, (cimm & 0xff) | (reg & 0xffffff00u))) L.ovf = 1;
                 }
                 // recv_from_raw(rsp_tag): Mailbox::recv (endpoint.rs:353-362); no queued message can carry a fresh tag
@@ -146,10 +149,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (sub == 3) {
             uint64_t d1 = u64of(u1.z, u1.w);
             if (L.clock >= d1) {
-                if (from != dst) st = ST_PANIC;              // assert_eq!(from, dst) rpc.rs:126
+                if (P.uniq_addr ? from != dst : !addr_eq(addr_of_from(c, from), SOCKW(c, dst))) st = ST_PANIC;   // assert_eq!(from, dst) rpc.rs:126
                 return true;
             }
-            if (!timer_add<K>(c, L, d1, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+            if (!timer_add<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
         }
         if (cimm >> 8) {
             uint4 u2 = TU(c, slot, 2);
@@ -159,7 +162,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.w = MADSIM_VAL_TIMEOUT;
                 return true;
             }
-            if (!timer_add<K>(c, L, d2, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+            if (!timer_add<K>(c, L, d2, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
         }
         st = ST_PENDING;
         return false;
@@ -186,7 +189,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (arrive != ~0ull) { d = sleep_deadline(L, arrive); sub = 3; }
         else { d = sleep_deadline(L, L.clock + (uint64_t)(u3.x >> 16) * NS_PER_MS); sub = 2; }
         u1.z = (uint32_t)d; u1.w = (uint32_t)(d >> 32); u1_dirty = true;
-        if (!timer_add<K>(c, L, d, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+        if (!timer_add<K>(c, L, d, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
         st = ST_PENDING;
     };
 
@@ -225,7 +228,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 // (base-op builds keep no deadline: there a Sleep is only polled again once its own timer has fired)
                 if (K::LIFE && L.clock < deadline) {       // not elapsed: register ANOTHER timer
                     REG(5);
-                    if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+                    if (!timer_add<K>(c, L, deadline, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
                     st = ST_PENDING;
                     break;
                 }
@@ -247,8 +250,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 } else if (K::FC && op == MS_OP_CONNECT) {   // NetSim::connect1 (net/mod.rs:345-363)
                     uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                     if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
-                    uint64_t lat; int ds;
-                    if (!try_send_fn<K>(c, L, SOCKW(c, a) & 0xff, b & 0xff, &lat, &ds)) {
+                    uint64_t lat; int ds; uint32_t lb;
+                    const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, SOCKW(c, b & 0xff), b & 0xff, &lat, &ds, &lb);
+                    if (sent < 0) { st = ST_PANIC; break; }
+                    if (!sent) {
                         u0.w = MADSIM_VAL_REFUSED;
                     } else {
                         uint32_t id = 0;
@@ -268,38 +273,45 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         }
                     }
                 } else if (op == MS_OP_BIND) {                    // Network::bind (network.rs:206-251)
-                    uint32_t sw = SOCKW(c, a);
-                    if ((sw & 0xff) != node || find_bound<K>(c, a) >= 0) { st = ST_PANIC; break; }
-                    sock_bind<K>(c, a, slot, gen);                         // bound, gen+1, empty mailbox, owned by this task
-                    u0.x |= TF_OWNER;
-                    if (K::G) OMASK(a >> 5) |= 1u << (a & 31);
-                    if (K::FC && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
+                    // a specified, non-loopback IP must be the node's own (:215-222); table entries are per node for every
+                    // kind, so another node's entry is "not available" too; then the (address, protocol) key must be free (:238-246)
+                    const uint32_t sw = SOCKW(c, a);
+                    uint32_t bind_err = 0;
+                    if ((sw & 0xff) != node) bind_err = MADSIM_VAL_ADDR_NOT_AVAILABLE;
+                    else if ((P.uniq_addr ? find_bound<K>(c, a) : find_exact<K>(c, node, sw)) >= 0) bind_err = MADSIM_VAL_ADDR_IN_USE;
+                    if (bind_err) {
+                        if (!(b & 1)) { st = ST_PANIC; break; }            // .unwrap()
+                        u0.w = bind_err;
+                    } else {
+                        if (b & 1) u0.w = 0;
+                        sock_bind<K>(c, a, slot, gen);                     // bound, gen+1, empty mailbox, owned by this task
+                        u0.x |= TF_OWNER;
+                        if (K::G) OMASK(a >> 5) |= 1u << (a & 31);
+                        if (K::FC && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
+                    }
                 } else if (op == MS_OP_SEND || op == MS_OP_REPLY || (K::FR && op == MS_OP_RPC_REPLY)) {   // net/mod.rs:307-331
                     REG(6);
-                    uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : from;
+                    // the destination: the operand's table entry, or the address the request came from (`from`)
+                    const uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : (from & 0x3f);
+                    const uint32_t dst_addr = (op == MS_OP_SEND || P.uniq_addr) ? SOCKW(c, dst) : addr_of_from(c, from);
                     if (K::FR && op == MS_OP_RPC_REPLY) {    // send_to_raw(from, rsp_tag, rsp): rpc.rs:172-175
                         b = 0xff00;
                         imm = (imm & 0xff) | (TWORD(c, slot, P.rpc_unit, 0) << 8);
                     }
-                    uint32_t src_node = SOCKW(c, a) & 0xff;
-                    uint32_t dst_node = SOCKW(c, dst) & 0xff;
-                    // Network::try_send -> test_link (network.rs:261-269, 296-313)
-                    bool clogged = false;
-                    if (P.has_clog) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
-                    if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
-                    if (!clogged && !gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) {
-                        L.msg_count++;
-                        uint64_t lat = sample_latency<K>(c, L);
-                        int ds = find_bound<K>(c, dst);
-                        if (ds >= 0) {
+                    // Network::try_send -> resolve_dest_node, test_link, socket lookup (network.rs:261-313)
+                    uint64_t lat; int ds; uint32_t lb;
+                    const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dst_addr, dst, &lat, &ds, &lb);
+                    if (sent < 0) { st = ST_PANIC; break; }
+                    if (sent) {
+                        {
                             uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
-                            uint2 ev = ev_deliver_meta<K>(sgen, b >> 8, a, (uint32_t)ds, imm, pc);
+                            uint2 ev = ev_deliver_meta<K>(sgen, b >> 8, a | (lb << 6), (uint32_t)ds, imm, pc);
                             if (K::FR && P.uses_hooks && op == MS_OP_RPC_REPLY) {
                                 // hooks_rsp.get(&dst_node) is cloned now and judges the message when the timer fires
                                 // (net/mod.rs:321-328): the verdict is already fixed, so a dropped response is a timer
                                 // that fires and delivers nothing
                                 const uint32_t hw = HOOKW(SOCKW(c, (uint32_t)ds) & 0xff);
-                                if ((hw & (1u << 18)) && ((hw & (1u << 19)) || ((hw >> 20) & 0xff) == (imm & 0xff))) ev = make_uint2(EV_NOP << 28, 0);
+                                if ((hw & (1u << 18)) && ((hw & (1u << 19)) || ((hw >> 20) & 0xff) == (imm & 0xff))) ev = make_uint2(EV_NOP << EV_SHIFT, 0);
                             }
                             if (!timer_add<K>(c, L, L.clock + lat, ev.x, ev.y)) L.ovf = 1;
                         }
@@ -720,7 +732,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             REG(17);
             u1.z = (uint32_t)deadline; u1.w = (uint32_t)(deadline >> 32); u1_dirty = true;
             sub = (op == MS_OP_RECV) ? 3 : 1;
-            if (!timer_add<K>(c, L, deadline, (EV_WAKE << 28) | (gen << 8) | slot, 0)) L.ovf = 1;
+            if (!timer_add<K>(c, L, deadline, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
             st = ST_PENDING;
         }
     }

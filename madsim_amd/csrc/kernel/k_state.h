@@ -36,6 +36,10 @@ enum : uint32_t { TF_ALIVE = 1, TF_SCHED = 2, TF_RUN = 4, TF_KILLED = 8, TF_CANC
                   TF_OWNER = 128 /* this task has bound an Endpoint: its finish must look for sockets to close */ };
 enum : uint32_t { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3,
                   EV_NOP = 4 /* a delivery timer whose message a response hook drops: fires, delivers nothing */ };
+// timer meta word: kind << 29 | ...;  EV_WAKE: gen << 8 | slot;  EV_RESTART: node;  EV_DELIVER (extended builds):
+// socket gen << 21 | tag << 13 | from (source socket | dst-was-loopback << 6) << 6 | destination socket;  EV_DELIVER (base-op
+// builds): socket gen << 21 | dst-was-loopback << 18 | pc of the sending instruction << 6 | destination socket
+#define EV_SHIFT 29
 enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 
 // Compile-time kernel variant: TRACE = also emit the raw determinism log (single-seed trace mode);

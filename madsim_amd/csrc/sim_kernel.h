@@ -21,7 +21,7 @@ struct KParams {
     // workload tables in device memory (copied into LDS by every workgroup)
     const uint4*    insns;     // {op|a<<8|b<<16, imm, fused assert value, fused post-chain word} (geometry.h build_tables)
     const uint32_t* progs;     // node | flags<<8 | entry<<16
-    const uint32_t* socks;     // node | port<<16
+    const uint32_t* socks;     // node | kind<<8 | port<<16 (a SocketAddr as one word)
     const uint32_t* nodes;     // per node: flags | n_match<<8 | match[0]<<16 | match[1]<<24 (madsim_node_t as one word)
     const uint64_t* dur_table; // per MS_OP_SLEEP_RAND (its `a` is rewritten to an index): {mode, low, range, zone}
     uint32_t n_insns, n_progs, n_socks, n_nodes;

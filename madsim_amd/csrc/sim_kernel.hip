@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
                     rng_log<K>(c, L);
                     uint64_t delay = NS_PER_S + __umul64hi(v, range);
                     node_kill<K>(c, L, node);                 // self.kill(node_id)
-                    if (!timer_add<K>(c, L, L.clock + delay, (EV_RESTART << 28) | node, 0)) L.ovf = 1;
+                    if (!timer_add<K>(c, L, L.clock + delay, (EV_RESTART << EV_SHIFT) | node, 0)) L.ovf = 1;
                     panicked = false;
                 }
             }

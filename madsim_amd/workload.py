@@ -102,6 +102,10 @@ class TaskBuilder:
         return self._emit("ADVANCE", b=b, imm=imm)
 
     # -- net -------------------------------------------------------------------------------------
+    def try_bind(self, addr):
+        """val = match Endpoint::bind(addr).await { Ok(_) => 0, Err(e) => VAL_ADDR_NOT_AVAILABLE / VAL_ADDR_IN_USE }"""
+        return self._emit("BIND", a=addr, b=1)
+
     def bind(self, addr):
         return self._emit("BIND", a=addr)
 
@@ -270,10 +274,11 @@ class WorkloadBuilder:
         """The future handed to Runtime::block_on / the #[madsim::test] body."""
         return self.tasks[0]
 
-    def create_node(self, restart_on_panic=False, restart_on_panic_matching=()):
-        """create_node()[.restart_on_panic()][.restart_on_panic_matching(code)...] (runtime/mod.rs:377-387)."""
+    def create_node(self, restart_on_panic=False, restart_on_panic_matching=(), ip=True):
+        """create_node()[.ip(10.0.0.<id>)][.restart_on_panic()][.restart_on_panic_matching(code)...] (runtime/mod.rs:377-395).
+        ip=False: the node has no address — it can bind anything, but cannot reach other nodes (network.rs:281-283)."""
         n = A.Node()
-        n.flags = A.NODE_RESTART_ON_PANIC if restart_on_panic else 0
+        n.flags = (A.NODE_RESTART_ON_PANIC if restart_on_panic else 0) | (0 if ip else A.NODE_NO_IP)
         if restart_on_panic_matching:
             if len(restart_on_panic_matching) > 2 or any(not 0 <= c <= 254 for c in restart_on_panic_matching):
                 raise ValueError("at most two patterns, message codes 0..254")
@@ -284,9 +289,13 @@ class WorkloadBuilder:
         self.nodes.append(n)
         return len(self.nodes) - 1
 
-    def addr(self, node, port):
-        """SocketAddr 10.0.0.<node>:<port> that an Endpoint may bind or send to."""
-        self.socks.append(A.Sock(node, 0, port))
+    def addr(self, node, port, ip="node"):
+        """A SocketAddr an Endpoint may bind or send to: 10.0.0.<node>:<port> (ip="node"), or — as used on `node` —
+        0.0.0.0:<port> (ip="unspecified") / 127.0.0.1:<port> (ip="loopback").  Resolution as in network.rs:272-313."""
+        kind = {"node": A.ADDR_IP, "unspecified": A.ADDR_UNSPECIFIED, "loopback": A.ADDR_LOOPBACK}[ip]
+        if port == 0:
+            raise ValueError("port 0 (an ephemeral port) is not modelled: name the port")
+        self.socks.append(A.Sock(node, kind, port))
         return len(self.socks) - 1
 
     def task(self, node, init=False, pre=False):

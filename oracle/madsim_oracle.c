@@ -329,22 +329,54 @@ static int link_clogged(sim_t* S, unsigned src, unsigned dst) {        /* networ
     return ((S->clog_out >> src) & 1) || ((S->clog_in >> dst) & 1) || ((S->clog_link[src] >> dst) & 1);
 }
 
-static int find_bound(sim_t* S, unsigned node, unsigned port) {        /* network.rs:304-306 */
-    for (uint32_t i = 0; i < S->w->n_socks; i++)
-        if (S->socks[i].bound && S->w->socks[i].node == node && S->w->socks[i].port == port) return (int)i;
+/* A SocketAddr: `kind` = MADSIM_ADDR_* picks the IP (10.0.0.<node> / 0.0.0.0 / 127.0.0.1). */
+typedef struct { uint8_t kind, node; uint16_t port; } addr_t;
+static addr_t addr_of_sock(const sim_t* S, unsigned idx) {
+    addr_t a = { S->w->socks[idx].kind, S->w->socks[idx].node, S->w->socks[idx].port }; return a;
+}
+/* The source address a receiver was shown, kept as  socket index | dst-was-loopback << 6  (network.rs:307-311):
+ * the sender's real IP, or 127.0.0.1 when the datagram was addressed to a loopback address, with the socket's port. */
+static addr_t addr_of_from(const sim_t* S, unsigned from) {
+    addr_t a = { (uint8_t)((from & 0x40) ? MADSIM_ADDR_LOOPBACK : MADSIM_ADDR_IP), S->w->socks[from & 0x3f].node, S->w->socks[from & 0x3f].port };
+    return a;
+}
+static int addr_eq(addr_t x, addr_t y) {                  /* SocketAddr equality */
+    return x.kind == y.kind && x.port == y.port && (x.kind != MADSIM_ADDR_IP || x.node == y.node);
+}
+static int node_has_ip(const sim_t* S, unsigned node) { return !(S->w->nodes[node].flags & MADSIM_NODE_NO_IP); }
+
+/* node.sockets.get(&(addr, protocol)) on node `on` (network.rs:206-251 keys sockets by the address they were bound to). */
+static int find_exact(sim_t* S, unsigned on, addr_t a) {
+    for (uint32_t i = 0; i < S->w->n_socks; i++) {
+        const madsim_sock_t* e = &S->w->socks[i];
+        if (S->socks[i].bound && e->node == on && e->kind == a.kind && e->port == a.port && (a.kind != MADSIM_ADDR_IP || a.node == on)) return (int)i;
+    }
     return -1;
 }
 
-/* Network::try_send (network.rs:296-313) + test_link (:261-269).  Returns 1 and the latency/socket
- * when a delivery must be scheduled. */
-static int try_send(sim_t* S, unsigned src_node, unsigned dst_addr, uint64_t* latency, int* dst_sock) {
-    unsigned dst_node = S->w->socks[dst_addr].node;       /* resolve_dest_node :272-290 */
-    if (link_clogged(S, src_node, dst_node)) return 0;    /* no draw */
+/* Network::resolve_dest_node (network.rs:272-290): the node a datagram for `dst` goes to, or -1 (dropped, no draws). */
+static int resolve_dest_node(sim_t* S, unsigned node, addr_t dst) {
+    if (dst.kind == MADSIM_ADDR_LOOPBACK || find_exact(S, node, dst) >= 0) return (int)node;
+    if (!node_has_ip(S, node)) return -1;                                  /* "ip not set" */
+    if (dst.kind == MADSIM_ADDR_IP && dst.node >= 1 && dst.node <= S->w->n_nodes && node_has_ip(S, dst.node)) return dst.node;   /* addr_to_node */
+    return -1;                                                             /* "destination not found" */
+}
+
+/* Network::try_send (network.rs:296-313) + test_link (:261-269).  Returns 1 and the latency / socket / the `from`
+ * flag when a delivery must be scheduled, 0 when the message is dropped, -1 when the sender's task panics
+ * (`.ip.unwrap()` of an IP-less node, :309). */
+static int try_send(sim_t* S, unsigned src_node, addr_t dst, uint64_t* latency, int* dst_sock, unsigned* from_lb) {
+    int dst_node = resolve_dest_node(S, src_node, dst);
+    if (dst_node < 0) return 0;                           /* no draw */
+    if (link_clogged(S, src_node, (unsigned)dst_node)) return 0;    /* no draw */
     if (gen_bool_pint(S, S->loss_pint, S->loss_always)) return 0;
     S->msg_count++;
     *latency = sample_duration(S, S->lat_mode, S->lat_low, S->lat_range, S->lat_zone, 1);
-    int s = find_bound(S, dst_node, S->w->socks[dst_addr].port);
+    int s = find_exact(S, (unsigned)dst_node, dst);                        /* sockets.get(&(dst, protocol)) */
+    if (s < 0) { addr_t any = { MADSIM_ADDR_UNSPECIFIED, 0, dst.port }; s = find_exact(S, (unsigned)dst_node, any); }   /* .or_else(0.0.0.0:port) */
     if (s < 0) return 0;                                  /* draws consumed, silently dropped */
+    *from_lb = dst.kind == MADSIM_ADDR_LOOPBACK;
+    if (!*from_lb && !node_has_ip(S, src_node)) return -1;
     *dst_sock = s;
     return 1;
 }
@@ -468,14 +500,12 @@ static void node_restart(sim_t* S, unsigned node) {       /* TaskHandle::restart
 }
 
 /* ---- reliable channel: NetSim::connect1 / channel (net/mod.rs:337-430), Endpoint::accept1 (endpoint.rs:197-211) ---- */
-static int try_send(sim_t* S, unsigned src_node, unsigned dst_addr, uint64_t* latency, int* dst_sock);
-
 /* the `test_link` closure of channel(): try_send(..).map(|latency| now + latency) (net/mod.rs:375-380) */
 static int chan_test_link(sim_t* S, conn_t* c, int dir, uint64_t* arrive) {
     unsigned src_node = S->w->socks[dir == 0 ? c->c_ep : c->s_ep].node;
     unsigned dst_addr = dir == 0 ? c->s_ep : c->c_ep;
-    uint64_t lat; int ds;
-    if (!try_send(S, src_node, dst_addr, &lat, &ds)) return 0;
+    uint64_t lat; int ds; unsigned lb;
+    if (try_send(S, src_node, addr_of_sock(S, dst_addr), &lat, &ds, &lb) <= 0) return 0;
     *arrive = S->clock + lat;
     return 1;
 }
@@ -679,8 +709,17 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (!sleep_poll(S, slot, t->deadline)) return 0;
             {
                 const madsim_sock_t* a = &w->socks[in->a];
-                if (a->node != t->node) return 1;          /* AddrNotAvailable -> unwrap panics */
-                if (find_bound(S, a->node, a->port) >= 0) return 1;   /* AddrInUse */
+                uint32_t bind_err = 0;
+                /* network.rs:215-222: a specified, non-loopback IP must be the node's own (an IP-less node takes any);
+                 * table entries are per node for every kind, so binding another node's entry is "not available" too */
+                if (a->node != t->node) bind_err = MADSIM_VAL_ADDR_NOT_AVAILABLE;
+                else if (find_exact(S, t->node, addr_of_sock(S, in->a)) >= 0) bind_err = MADSIM_VAL_ADDR_IN_USE;   /* :238-246 */
+                if (bind_err) {
+                    if (!(in->b & 1)) return 1;            /* .unwrap() */
+                    t->val = bind_err; t->sub = 0; t->pc++;
+                    break;
+                }
+                if (in->b & 1) t->val = 0;
                 sock_t* k = &S->socks[in->a];
                 k->bound = 1; k->gen++; k->owner_slot = slot; k->owner_gen = t->gen;
                 k->registered.n = 0; k->msgs.n = 0;        /* a fresh Endpoint + Mailbox */
@@ -694,12 +733,14 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (t->sub == 0) { t->deadline = rand_delay_start(S); t->sub = 1; }
             if (!sleep_poll(S, slot, t->deadline)) return 0;
             {
-                unsigned dst = in->op == MS_OP_SEND ? (in->b & 0xff) : t->from;
-                uint64_t lat; int ds;
-                if (try_send(S, w->socks[in->a].node, dst, &lat, &ds)) {
+                const addr_t dst = in->op == MS_OP_SEND ? addr_of_sock(S, in->b & 0xff) : addr_of_from(S, t->from);
+                uint64_t lat; int ds; unsigned lb;
+                const int sent = try_send(S, w->socks[in->a].node, dst, &lat, &ds, &lb);
+                if (sent < 0) return 1;                    /* `.ip.unwrap()` on an IP-less node */
+                if (sent) {
                     event_t e; memset(&e, 0, sizeof e);
                     e.deadline = S->clock + lat; e.kind = EV_DELIVER; e.sock = (uint8_t)ds;
-                    e.sockgen = S->socks[ds].gen; e.from = in->a; e.tag = (uint8_t)(in->b >> 8);
+                    e.sockgen = S->socks[ds].gen; e.from = (uint8_t)(in->a | (lb << 6)); e.tag = (uint8_t)(in->b >> 8);
                     e.val = in->imm;
                     if (in->op == MS_OP_RPC_REPLY) {
                         e.tag = t->aux; e.val = in->imm & 0xff;
@@ -744,8 +785,10 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (!sleep_poll(S, slot, t->deadline)) return 0;
             {
                 if (t->conn >= 0) { conn_drop_handles(S, t->conn, t->side); t->conn = -1; }
-                uint64_t lat; int ds;
-                if (!try_send(S, w->socks[in->a].node, in->b & 0xff, &lat, &ds)) {
+                uint64_t lat; int ds; unsigned lb;
+                const int sent = try_send(S, w->socks[in->a].node, addr_of_sock(S, in->b & 0xff), &lat, &ds, &lb);
+                if (sent < 0) return 1;
+                if (!sent) {
                     t->val = MADSIM_VAL_REFUSED;           /* io::ErrorKind::ConnectionRefused */
                 } else {
                     size_t id = 0;
@@ -897,10 +940,13 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 /* hooks_req.get(&node): `if !hook(&msg) { return Ok(()) }` before try_send (net/mod.rs:307-311) */
                 const node_t* sn = &S->nodes[w->socks[in->a].node];
                 const int hooked = sn->hreq_valid && sn->hreq_tag == (uint8_t)(in->b >> 8) && (sn->hreq_all || sn->hreq_code == (uint8_t)in->imm);
-                if (!hooked && try_send(S, w->socks[in->a].node, dst, &lat, &ds)) {
+                unsigned lb = 0;
+                const int sent = hooked ? 0 : try_send(S, w->socks[in->a].node, addr_of_sock(S, dst), &lat, &ds, &lb);
+                if (sent < 0) return 1;
+                if (sent) {
                     event_t e; memset(&e, 0, sizeof e);
                     e.deadline = S->clock + lat; e.kind = EV_DELIVER; e.sock = (uint8_t)ds;
-                    e.sockgen = S->socks[ds].gen; e.from = in->a; e.tag = (uint8_t)(in->b >> 8);
+                    e.sockgen = S->socks[ds].gen; e.from = (uint8_t)(in->a | (lb << 6)); e.tag = (uint8_t)(in->b >> 8);
                     e.val = in->imm & 0xff; e.aux = t->rsp_tag;            /* Box::new((rsp_tag, request, data)) */
                     timer_add(S, e);
                     t = &S->tasks.p[slot];
@@ -926,7 +972,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
             }
             if (t->sub == 3) ready = sleep_poll(S, slot, t->deadline);
             if (ready) {
-                if (t->from != dst) return 1;              /* assert_eq!(from, dst) rpc.rs:126 */
+                if (!addr_eq(addr_of_from(S, t->from), addr_of_sock(S, dst))) return 1;   /* assert_eq!(from, dst) rpc.rs:126 */
                 t->sub = 0; t->pc++;
                 break;
             }
@@ -1079,6 +1125,7 @@ static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
     if (!w || !w->insns || !w->progs || w->n_progs == 0 || w->n_progs > 255) return -1;
     if (w->n_nodes > 62 || w->n_socks > 63) return -1;
     if (w->n_socks && !w->socks) return -1;
+    for (uint32_t i = 0; i < w->n_socks; i++) if (w->socks[i].kind > MADSIM_ADDR_LOOPBACK || w->socks[i].port == 0) return -1;
     if (cfg->lat_lo_ns >= cfg->lat_hi_ns) return -1;      /* "cannot sample empty range" */
     if (!(cfg->packet_loss_rate >= 0.0 && cfg->packet_loss_rate <= 1.0)) return -1;
     return 0;

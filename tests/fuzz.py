@@ -312,3 +312,52 @@ def random_rpc_workload(rng: random.Random, hooks=False):
     m.done()
     cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.1, 0.3]), buggify=rng.random() < 0.1)
     return wl.build(), cfg, "+".join(desc)
+
+
+def random_addr_workload(rng: random.Random):
+    """Datagram programs over mixed address kinds (network.rs:206-313): node IPs, 0.0.0.0 and 127.0.0.1 entries, IP-less
+    nodes, duplicate table entries naming one address, destinations nobody binds.  Every task binds a few of its node's
+    entries (try_bind: AddrInUse / AddrNotAvailable become values), then sends to random entries, receives with a
+    timeout and sometimes replies to whoever it heard from.  Any verdict is fine; it has to be the oracle's."""
+    wl = W.WorkloadBuilder()
+    n_nodes = rng.randint(2, 3)
+    nodes = [wl.create_node(ip=rng.random() > 0.25) for _ in range(n_nodes)]
+    entries, by_node = [], {n: [] for n in nodes}
+    for n in nodes:
+        for _ in range(rng.randint(1, 3)):
+            kind = rng.choice(["node", "node", "unspecified", "loopback"])
+            a = wl.addr(n, rng.randint(1, 3), ip=kind)
+            entries.append(a); by_node[n].append(a)
+    desc = [f"{n_nodes}n/{len(entries)}a"]
+    tasks = []
+    for n in nodes:
+        t = wl.task(n)
+        mine = by_node[n]
+        bound = []
+        for a in rng.sample(mine, rng.randint(1, len(mine))):
+            t.try_bind(a); t.trace(10 + a, add_reg=None); t.trace_val()
+            bound.append(a)
+        if rng.random() < 0.3:                                     # somebody else's entry: AddrNotAvailable
+            t.try_bind(rng.choice(entries)); t.trace_val()
+        t.sleep(ms=rng.randint(1, 8))
+        t.set(0, rng.randint(1, 4))
+        top = t.label()
+        ep = rng.choice(bound)
+        t.send_to(ep, rng.choice(entries), rng.randint(1, 2), rng.randrange(1000))
+        rx = rng.choice(bound)
+        t.recv_from_timeout(rx, rng.randint(1, 2), ms=rng.choice([3, 20]))
+        t.trace_val()
+        skip = t.label() + 2
+        t.jeq(A.VAL_TIMEOUT, skip)
+        t.reply(rx, rng.randint(1, 2), rng.randrange(1000))
+        assert t.label() == skip
+        t.djnz(0, top)
+        t.done()
+        tasks.append(t)
+    m = wl.main()
+    for t in tasks:
+        m.spawn(t)
+    for t in tasks:
+        m.join(t, expect_err=False)
+    cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.2]))
+    return wl.build(), cfg, "+".join(desc)

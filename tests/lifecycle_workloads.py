@@ -371,6 +371,94 @@ ALL.update(rpc_echo=rpc_echo, rpc_call_timeout_then_retry=rpc_call_timeout_then_
            rpc_hooks=rpc_hooks)
 
 
+def endpoint_localhost():
+    """net/endpoint.rs:516-548 `localhost`, sleeps instead of the Barrier: an Endpoint bound to 127.0.0.1:1 does not
+    receive what another node sends to 10.0.0.1:1 (no exact match, no 0.0.0.0:1 socket: dropped after the draws), the one
+    bound to 10.0.0.1:2 receives its datagram from "10.0.0.2:1" — the sender's real IP although it bound 127.0.0.1:1 —,
+    and a reply to that address finds no socket either (the sender listens on 127.0.0.1 only)."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    lo1, ip1_2, lo2 = wl.addr(n1, 1, ip="loopback"), wl.addr(n1, 2), wl.addr(n2, 1, ip="loopback")
+    ip1_1 = wl.addr(n1, 1)                            # a destination only: nobody binds 10.0.0.1:1
+    f1 = wl.task(n1); f1.bind(lo1); f1.bind(ip1_2)
+    f1.recv_from_timeout(lo1, 1, secs=1); f1.assert_val(A.VAL_TIMEOUT)
+    f1.recv_from(ip1_2, 1); f1.assert_val(1); f1.reply(ip1_2, 1, 7); f1.done()
+    f2 = wl.task(n2); f2.bind(lo2); f2.sleep(ms=5)
+    f2.send_to(lo2, ip1_1, 1, 1); f2.send_to(lo2, ip1_2, 1, 1)
+    f2.recv_from_timeout(lo2, 1, secs=2); f2.assert_val(A.VAL_TIMEOUT); f2.done()
+    m = wl.main(); m.spawn(f1); m.spawn(f2); m.join(f1); m.join(f2)
+    return wl.build()
+
+
+def endpoint_bind():
+    """net/endpoint.rs:470-513 `bind` with named ports (ephemeral port 0 is not modelled): 0.0.0.0 and 127.0.0.1 bind on
+    any node and are different keys, another node's IP is AddrNotAvailable, the node's own IP binds, binding the same
+    address twice is AddrInUse — through the same table entry or through a second one naming the same address —, and a
+    dropped Endpoint frees its port."""
+    wl = W.WorkloadBuilder()
+    n, other = wl.create_node(), wl.create_node()
+    any7, lo7, foreign = wl.addr(n, 7, ip="unspecified"), wl.addr(n, 7, ip="loopback"), wl.addr(other, 9)
+    ip100, ip100b = wl.addr(n, 100), wl.addr(n, 100)
+    t = wl.task(n)
+    t.try_bind(any7); t.assert_val(0); t.try_bind(lo7); t.assert_val(0)
+    t.try_bind(foreign); t.assert_val(A.VAL_ADDR_NOT_AVAILABLE)
+    t.try_bind(ip100); t.assert_val(0)
+    t.try_bind(ip100); t.assert_val(A.VAL_ADDR_IN_USE); t.try_bind(ip100b); t.assert_val(A.VAL_ADDR_IN_USE)
+    t.close(ip100); t.try_bind(ip100b); t.assert_val(0)          # drop and reuse port
+    t.done()
+    m = wl.main(); m.spawn(t); m.join(t)
+    return wl.build()
+
+
+def net_wildcard_and_unbound_port():
+    """network.rs:296-313: the socket lookup happens after the link test — a datagram to a port nobody listens on still
+    costs the loss and latency draws and counts in msg_count —, and falls back from the exact address to 0.0.0.0:port."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a1, any2 = wl.addr(n1, 1), wl.addr(n2, 9, ip="unspecified")
+    ip2_9, ip2_8 = wl.addr(n2, 9), wl.addr(n2, 8)              # destinations only
+    r = wl.task(n2); r.bind(any2); r.recv_from(any2, 1); r.assert_val(5); r.reply(any2, 1, 6); r.done()
+    s = wl.task(n1); s.bind(a1); s.sleep(ms=5)
+    s.send_to(a1, ip2_8, 1, 4)                                  # unbound port: draws, msg_count, no delivery
+    s.send_to(a1, ip2_9, 1, 5)                                  # no socket at 10.0.0.2:9 -> the one at 0.0.0.0:9
+    s.recv_from(a1, 1); s.assert_val(6); s.done()
+    m = wl.main(); m.spawn(r); m.spawn(s); m.join(r); m.join(s)
+    return wl.build()
+
+
+def net_ipless_node():
+    """network.rs:272-290: a node created without .ip(): datagrams to 127.0.0.1 or to one of its own sockets stay on the
+    node, anything else is dropped before any RNG draw ("ip not set"); other nodes cannot reach it ("destination not found")."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(ip=False), wl.create_node()
+    a1, lo1, a2 = wl.addr(n1, 1), wl.addr(n1, 5, ip="loopback"), wl.addr(n2, 1)
+    t1 = wl.task(n1); t1.bind(a1); t1.bind(lo1)
+    t1.send_to(a1, a2, 1, 1)                                    # dropped, no draws
+    t1.send_to(a1, lo1, 1, 2)                                   # loopback: delivered locally, from = 127.0.0.1:1
+    t1.recv_from(lo1, 1); t1.assert_val(2)
+    t1.reply(lo1, 1, 3)                                         # -> 127.0.0.1:1: no socket there (a1 is 10.0.0.1:1): dropped after the draws
+    t1.recv_from_timeout(a1, 1, ms=50); t1.assert_val(A.VAL_TIMEOUT); t1.done()
+    t2 = wl.task(n2); t2.bind(a2); t2.sleep(ms=5); t2.send_to(a2, a1, 1, 9)      # 10.0.0.1 is nobody's registered IP: dropped, no draws
+    t2.recv_from_timeout(a2, 1, ms=50); t2.assert_val(A.VAL_TIMEOUT); t2.done()
+    m = wl.main(); m.spawn(t1); m.spawn(t2); m.join(t1); m.join(t2)
+    return wl.build()
+
+
+def net_ipless_node_own_socket_panics():
+    """network.rs:307-311: an IP-less node sending to one of its own non-loopback sockets gets as far as `.ip.unwrap()`."""
+    wl = W.WorkloadBuilder()
+    n1 = wl.create_node(ip=False)
+    a1, b1 = wl.addr(n1, 1), wl.addr(n1, 2)
+    t1 = wl.task(n1); t1.bind(a1); t1.bind(b1); t1.send_to(a1, b1, 1, 1); t1.done()
+    m = wl.main(); m.spawn(t1); m.join(t1, expect_err=False)
+    return wl.build()
+
+
+ALL.update(endpoint_localhost=endpoint_localhost, endpoint_bind=endpoint_bind, net_wildcard_and_unbound_port=net_wildcard_and_unbound_port,
+           net_ipless_node=net_ipless_node, net_ipless_node_own_socket_panics=net_ipless_node_own_socket_panics)
+EXPECT_PANIC.add("net_ipless_node_own_socket_panics")
+
+
 def std_system_time():
     """time/system_time.rs:122-154: `t0 = SystemTime::now(); sleep(1 s); assert!(t0.elapsed() >= 1 s); t0` — the observed
     wall-clock time depends on the seed (base time drawn around 2022), the Instant-based duration does not."""

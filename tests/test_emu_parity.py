@@ -140,6 +140,20 @@ def test_fuzz_rpc_workloads():
         assert (e["verdict"] == A.OVERFLOW).mean() < 0.1
 
 
+def test_fuzz_address_resolution():
+    """200 random programs over node-IP / 0.0.0.0 / 127.0.0.1 addresses, IP-less nodes, duplicate and unbound entries."""
+    verdicts = set()
+    for k in range(200):
+        w, cfg, desc = fuzz.random_addr_workload(random.Random(73000 + k))
+        lim = fuzz.generous_limits()
+        o, _ = oracle.run_batch(w, k * 9, 12, cfg, lim)
+        e = emu.run_batch(w, k * 9, 12, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+        verdicts |= set(o["verdict"].tolist())
+    assert A.PASS in verdicts and A.PANIC in verdicts
+
+
 def test_fuzz_rpc_hooks_and_panic_codes():
     """Random typed-RPC programs with NetSim request / response hooks installed and replaced at random moments."""
     for k in range(150):

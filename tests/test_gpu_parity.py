@@ -550,6 +550,21 @@ def test_ref_twin_workloads_gpu(hip):
     _cmp(hip, T.ALL["pingpong4"](), 0, 512, A.Config.default(packet_loss_rate=0.01))
 
 
+def test_fuzz_address_resolution_gpu(hip):
+    """Random datagram programs over mixed address kinds (network.rs:206-313: wildcard fallback, loopback, IP-less nodes)."""
+    import random
+    from tests import fuzz
+    for k in range(150):
+        w, cfg, desc = fuzz.random_addr_workload(random.Random(76000 + k))
+        lim = fuzz.generous_limits()
+        if k % 2:
+            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        got, _ = hip.run_batch(w, k * 29, 96, cfg, lim)
+        want, _ = oracle.run_batch(w, k * 29, 96, cfg, lim)
+        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+
+
 def test_fuzz_rpc_hooks_gpu(hip):
     """Random typed-RPC programs with NetSim::hook_rpc_req / hook_rpc_rsp (net/mod.rs:240-284), LDS and global state."""
     import random
