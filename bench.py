@@ -50,10 +50,11 @@ def parse_args(argv=None):
     ap.add_argument("--state-mem", type=int, default=0, help="madsim_limits_t.state_mem: 0 auto, 1 LDS, 2 global-memory state block")
     ap.add_argument("--lpw", type=int, default=0, help="seed-carrying lanes per wave (0 = library auto)")
     ap.add_argument("--nodes", type=int, default=4, help="ping-pong nodes (experiments; the bench line is quoted on 4)")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the steps are spread over. One 65 536-seed batch is 1 024 waves = one per SIMD; the 200 B "
-                         "of LDS per seed admit three waves per SIMD, so three batches are kept in flight (measured: 3.66 / 1.96 / "
-                         "1.47 / 2.03 ms per batch with 1 / 2 / 3 / 4 streams)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams the steps are spread over (0 = pick 3 or 2 by a short trial during warm-up). One 65 536-seed "
+                         "batch is 1 024 waves = one per SIMD; the 200 B of LDS per seed admit three waves per SIMD, so three "
+                         "batches are kept in flight (measured: 3.66 / 1.96 / 1.47 / 2.03 ms per batch with 1 / 2 / 3 / 4 streams); "
+                         "on a box whose HIP streams share hardware queues two can be better, hence the trial")
     ap.add_argument("--heap-lds", type=int, default=4, help="timer-heap entries kept in LDS (the rest spill to HBM)")
     ap.add_argument("--generic", action="store_true", help="force the generic kernel variant (HBM heap spill enabled)")
     ap.add_argument("--workload", default="pingpong", choices=["pingpong", "raft", "kv", "timers", "topo"],
@@ -169,9 +170,10 @@ def main():
     per_gpu = args.seeds or workload.BENCH_SEEDS_PER_GPU
     total = per_gpu * n_ranks
     seed0, count = mdist.shard_range(0, total, rank, n_ranks)
-    n_streams = max(1, args.streams)
-    d_outs = [torch.empty(count * 48, dtype=torch.uint8, device=dev) for _ in range(n_streams)]   # results stay in HBM
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
+    max_streams = args.streams if args.streams > 0 else 3
+    n_streams = max_streams
+    d_outs = [torch.empty(count * 48, dtype=torch.uint8, device=dev) for _ in range(max_streams)]   # results stay in HBM
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max_streams - 1)]
     report_stream = torch.cuda.Stream() if world > 1 else None
 
     # Fully asynchronous steps: the simulation kernel, the summary reduction and (N > 1) the RCCL all-gather of the
@@ -214,6 +216,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    stream_trial = None
+    if args.streams == 0 and args.warmup >= 2:
+        # untimed trial: how many batches in flight does this box reward?  (same kernel, same seeds; only the overlap differs)
+        stream_trial = {}
+        scratch_rep = torch.zeros(REPORT_WORDS, dtype=torch.int64, device=dev)
+        for cand in (3, 2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(12):
+                si = k % cand
+                with torch.cuda.stream(streams[si]):
+                    runtime.run_batch_async(w, seed0 + (1 << 50) + k * total, count, d_outs[si].data_ptr(), scratch_rep.data_ptr(),
+                                            streams[si].cuda_stream, cfg, lim, timing_slot=-1)
+            torch.cuda.synchronize()
+            stream_trial[cand] = (time.perf_counter() - t1) / 12 * 1e3
+        n_streams = min(stream_trial, key=stream_trial.get)
+        if world > 1:            # every rank must use the same count (the report ring is indexed by step)
+            t = torch.tensor([n_streams], dtype=torch.int64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            n_streams = int(t[0])
     for k in range(args.warmup):
         step(k, False)
     sync()
@@ -345,6 +367,7 @@ def main():
                       "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms, "single_stream_ms_per_step": single_ms,
                       "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu * g.block_threads // 64,
                       "lanes_per_wave": g.lanes_per_wave, "rccl_ranks": rccl_ranks, "first_fail": first_fail,
+                      "stream_trial_ms_per_step": stream_trial,
                       "first_fail_seeds_per_hour": first_fail["seeds_per_hour"] if first_fail else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_detail": tdetail,

@@ -398,8 +398,8 @@ typedef struct madsim_geometry {
     uint32_t max_tasks;
     uint32_t lanes_per_wave;
     uint32_t variant;              /* kernel specialisation: bit0 heap spill, bit1 extended ops, bit2 ready queue in a
-                                    * register, bit3 runtime lane stride, bit4 global-state build; bits 8-11 = classes of extended ops compiled in
-                                    * (1 timeouts, 2 channel, 4 RPC, 8 node lifecycle); bits 16-19 = compile-time log2 lane
+                                    * register, bit3 runtime lane stride, bit4 global-state build; bits 8-12 = classes of extended ops compiled in
+                                    * (1 timeouts, 2 channel, 4 RPC, 8 node lifecycle, 16 general address resolution); bits 16-19 = compile-time log2 lane
                                     * stride (15 = runtime) */
     uint32_t global_bytes_per_seed; /* size of a lane's state block in global memory (global-state builds), else 0 */
 } madsim_geometry_t;

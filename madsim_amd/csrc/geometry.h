@@ -170,6 +170,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     if (P.has_restart_on_panic || uses_op(w, MS_OP_KILL) || uses_op(w, MS_OP_RESTART) || uses_op(w, MS_OP_PAUSE) || uses_op(w, MS_OP_RESUME) ||
         uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_ASSERT_EXIT) || uses_op(w, MS_OP_BUILD)) P.features |= MADSIM_FEAT_NODE;
     for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.features |= MADSIM_FEAT_NODE;
+    if (!P.uniq_addr) P.features |= MADSIM_FEAT_ADDR;
     if (trace) P.features = MADSIM_FEAT_ALL;          // the trace build carries every class
     P.lifecycle = P.features != 0;
     const uint32_t cus = g.num_cus > 0 ? (uint32_t)g.num_cus : 256u;

@@ -64,7 +64,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     uint32_t s = meta & 0x3f, from = (meta >> 6) & 0x7f, tag = (meta >> 13) & 0xff, sgen = (meta >> 21) & 0xff;
     if (!K::LIFE) {                                        // base ops: the event names its send_to / reply instruction
         const uint4 in = INSN(c, (meta >> 6) & 0xfff);
-        from = ((in.x >> 8) & 0x3f) | (((meta >> 18) & 1) << 6); tag = in.x >> 24; val = in.y;
+        from = (in.x >> 8) & 0x3f; tag = in.x >> 24; val = in.y;      // (base-op builds: plain addresses, never a loopback flag)
     }
     uint32_t h = SW(c, s, 0);
     if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;     // that Endpoint object is gone

@@ -149,7 +149,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (sub == 3) {
             uint64_t d1 = u64of(u1.z, u1.w);
             if (L.clock >= d1) {
-                if (P.uniq_addr ? from != dst : !addr_eq(addr_of_from(c, from), SOCKW(c, dst))) st = ST_PANIC;   // assert_eq!(from, dst) rpc.rs:126
+                if (PLAIN_ADDR ? from != dst : !addr_eq(addr_of_from(c, from), SOCKW(c, dst))) st = ST_PANIC;   // assert_eq!(from, dst) rpc.rs:126
                 return true;
             }
             if (!timer_add<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
@@ -278,7 +278,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     const uint32_t sw = SOCKW(c, a);
                     uint32_t bind_err = 0;
                     if ((sw & 0xff) != node) bind_err = MADSIM_VAL_ADDR_NOT_AVAILABLE;
-                    else if ((P.uniq_addr ? find_bound<K>(c, a) : find_exact<K>(c, node, sw)) >= 0) bind_err = MADSIM_VAL_ADDR_IN_USE;
+                    else if ((PLAIN_ADDR ? find_bound<K>(c, a) : find_exact<K>(c, node, sw)) >= 0) bind_err = MADSIM_VAL_ADDR_IN_USE;
                     if (bind_err) {
                         if (!(b & 1)) { st = ST_PANIC; break; }            // .unwrap()
                         u0.w = bind_err;
@@ -293,7 +293,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     REG(6);
                     // the destination: the operand's table entry, or the address the request came from (`from`)
                     const uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : (from & 0x3f);
-                    const uint32_t dst_addr = (op == MS_OP_SEND || P.uniq_addr) ? SOCKW(c, dst) : addr_of_from(c, from);
+                    const uint32_t dst_addr = (op == MS_OP_SEND || PLAIN_ADDR) ? SOCKW(c, dst) : addr_of_from(c, from);
                     if (K::FR && op == MS_OP_RPC_REPLY) {    // send_to_raw(from, rsp_tag, rsp): rpc.rs:172-175
                         b = 0xff00;
                         imm = (imm & 0xff) | (TWORD(c, slot, P.rpc_unit, 0) << 8);

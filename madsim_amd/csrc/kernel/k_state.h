@@ -38,7 +38,7 @@ enum : uint32_t { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3,
                   EV_NOP = 4 /* a delivery timer whose message a response hook drops: fires, delivers nothing */ };
 // timer meta word: kind << 29 | ...;  EV_WAKE: gen << 8 | slot;  EV_RESTART: node;  EV_DELIVER (extended builds):
 // socket gen << 21 | tag << 13 | from (source socket | dst-was-loopback << 6) << 6 | destination socket;  EV_DELIVER (base-op
-// builds): socket gen << 21 | dst-was-loopback << 18 | pc of the sending instruction << 6 | destination socket
+// builds): socket gen << 21 | pc of the sending instruction << 6 | destination socket
 #define EV_SHIFT 29
 enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 
@@ -47,7 +47,7 @@ enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 // LWS = log2(lane stride) when known at compile time (6: full 64-lane waves), or -1: read it from KParams.
 // FEAT = which classes of extended ops are compiled in (MADSIM_FEAT_* bits, geometry.h picks the mask from the ops a
 // workload uses): FT timeouts / t0 family / advance, FC reliable channel, FR typed RPC, FN node lifecycle (kill /
-// restart / pause / abort, init programs, restart_on_panic).  0 = the fast variant: none of that cold code in the hot
+// restart / pause / abort, init programs, restart_on_panic), FA general address resolution.  0 = the fast variant: none of that cold code in the hot
 // loop.  LIFE = any extended op: selects the extended LDS layout (handle plane, node region, whole-unit task stores).
 // RQ = the ready queue (<= 8 tasks) lives in a 64-bit register, one byte per queued task, instead of LDS.
 // G = the per-seed task table and planes live in a per-lane block of global memory (L2 / Infinity Cache / HBM) instead of
@@ -59,7 +59,8 @@ template <bool TRACE_, bool SPILL_, int LWS_, int FEAT_, bool RQ_ = false, bool 
     static constexpr int LWS = LWS_, FEAT = FEAT_;
     static constexpr bool LIFE = FEAT_ != 0;
     static constexpr bool FT = (FEAT_ & MADSIM_FEAT_TIME) != 0, FC = (FEAT_ & MADSIM_FEAT_CHAN) != 0,
-                          FR = (FEAT_ & MADSIM_FEAT_RPC) != 0, FN = (FEAT_ & MADSIM_FEAT_NODE) != 0;
+                          FR = (FEAT_ & MADSIM_FEAT_RPC) != 0, FN = (FEAT_ & MADSIM_FEAT_NODE) != 0,
+                          FA = (FEAT_ & MADSIM_FEAT_ADDR) != 0;
 };
 
 // REG(id): divergence-model markers, compiled in only by tools/divergence_model.py's host emulation build
@@ -295,6 +296,8 @@ template <class K> __device__ __forceinline__ void tu1_store(const Ctx& c, uint3
     if (K::LIFE) { TU(c, slot, 1) = u1; return; }
     TWORD(c, slot, 1, 0) = u1.x;
 }
+// every socket-table entry is a distinct node-IP address (always so in builds without general address resolution)
+#define PLAIN_ADDR (!K::FA || c.P.uniq_addr)
 __device__ __forceinline__ uint4 INSN(const Ctx& c, uint32_t pc) { return LDS128(c.insn0 + pc); }
 __device__ __forceinline__ uint32_t PROGW(const Ctx& c, uint32_t p) { return SMEM[c.prog0 + p]; }
 __device__ __forceinline__ uint32_t SOCKW(const Ctx& c, uint32_t s) { return SMEM[c.sockt0 + s]; }

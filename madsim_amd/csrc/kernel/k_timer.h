@@ -63,8 +63,7 @@ __device__ __forceinline__ void heap_set(const Ctx& c, uint32_t i, const uint4& 
 template <class K>
 __device__ __forceinline__ uint2 ev_deliver_meta(uint32_t sgen, uint32_t tag, uint32_t from, uint32_t ds, uint32_t val, uint32_t pc) {
     if (K::LIFE) return make_uint2((EV_DELIVER << EV_SHIFT) | (sgen << 21) | (tag << 13) | (from << 6) | ds, val);
-    // base ops: tag, source socket and payload are fields of insn pc; only the dst-was-loopback bit of `from` rides along
-    return make_uint2((EV_DELIVER << EV_SHIFT) | (sgen << 21) | ((from >> 6) << 18) | (pc << 6) | ds, 0);
+    return make_uint2((EV_DELIVER << EV_SHIFT) | (sgen << 21) | (pc << 6) | ds, 0);     // base ops: tag, from, payload = fields of insn pc
 }
 
 // BinaryHeap::sift_up(0, pos) with `hole` as the moving element; keeps the root mirror current.

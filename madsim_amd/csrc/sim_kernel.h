@@ -13,7 +13,9 @@
 #define MADSIM_FEAT_CHAN 2  /* connect1 / accept1 / channel send + recv                                               */
 #define MADSIM_FEAT_RPC  4  /* typed RPC call / reply                                                                   */
 #define MADSIM_FEAT_NODE 8  /* kill / restart / pause / resume / abort / is_exit, init programs, restart_on_panic       */
-#define MADSIM_FEAT_ALL  15
+#define MADSIM_FEAT_ADDR 16 /* general address resolution (network.rs:272-313): 0.0.0.0 / 127.0.0.1 entries, IP-less nodes, several
+                               table entries naming one address.  Builds without it take every address for a distinct node IP.   */
+#define MADSIM_FEAT_ALL  31
 
 namespace madsim_k {
 
@@ -103,6 +105,7 @@ inline VariantSel select_variant(const KParams& P, bool trace) {
         return {0, 1, -1, 0, 0, 0};                                     // sub-wave lane stride: runtime-stride build
     }
     // single-class workloads: a build without the other classes' code
+    // (general address resolution only exists in the full build: rare, and it would cost the lean builds ~5 %)
     const int cls = (feat & ~MADSIM_FEAT_TIME) == 0 ? MADSIM_FEAT_TIME : (feat & ~MADSIM_FEAT_CHAN) == 0 ? MADSIM_FEAT_CHAN : MADSIM_FEAT_ALL;
     if (P.gstate_mode) return {0, 1, 6, cls, 0, 1};                      // task table + planes in global memory: full waves
     if (cls != MADSIM_FEAT_ALL) return {0, 1, -1, cls, 0, 0};

@@ -116,11 +116,11 @@ def test_every_bench_workload_runs_on_the_build_its_ops_need():
     """select_variant: single-class workloads get the pruned builds (timeouts only / channel only), base-op workloads never
     pay for extended ops, and only mixed workloads take the full build."""
     from madsim_amd import runtime
-    want = {"pingpong": (0, 6, 0), "timers": (0, 15, 0), "raft": (1, 6, 16), "kv": (2, 6, 16), "topo": (15, 6, 16)}
+    want = {"pingpong": (0, 6, 0), "timers": (0, 15, 0), "raft": (1, 6, 16), "kv": (2, 6, 16), "topo": (31, 6, 16)}
     for name, (feat, lws, glob) in want.items():
         w, lim, _ = W.bench_case(name)
         g = runtime.geometry(w, lim)
-        assert ((g.variant >> 8) & 0xf, (g.variant >> 16) & 0xf, g.variant & 16) == (feat, lws, glob), (name, hex(g.variant))
+        assert ((g.variant >> 8) & 0x1f, (g.variant >> 16) & 0xf, g.variant & 16) == (feat, lws, glob), (name, hex(g.variant))
         assert (g.global_bytes_per_seed > 0) == bool(glob) and (not glob or g.lanes_per_wave == 64)
         lim.state_mem = A.STATE_LDS                     # the LDS-resident layout stays selectable
         g = runtime.geometry(w, lim)
