@@ -73,7 +73,8 @@ class Task {
     Task& spawn(const Task& t) { return emit(MS_OP_SPAWN, (uint8_t)t.index_); }
     Task& join(const Task& t, bool expect_err = false) { return emit(MS_OP_JOIN, (uint8_t)t.index_, expect_err ? 1 : 0); }
     Task& yield_now() { return emit(MS_OP_YIELD); }
-    Task& panic() { return emit(MS_OP_PANIC); }
+    Task& panic(uint8_t code = 0) { return emit(MS_OP_PANIC, 0, 0, code); }            // panic!() with message code `code`
+    Task& panic_with_flag(int flag, int32_t offset = 0) { return emit(MS_OP_PANIC, 1, (uint16_t)flag, (uint32_t)offset); }   // panic!("{}", flag + offset)
     Task& set(int reg, uint32_t v) { return emit(MS_OP_SET, (uint8_t)reg, 0, v); }
     Task& djnz(int reg, int target) { return emit(MS_OP_DJNZ, (uint8_t)reg, (uint16_t)target, 0, true); }
     Task& jmp(int target) { return emit(MS_OP_JMP, 0, (uint16_t)target, 0, true); }
@@ -84,6 +85,7 @@ class Task {
     Task& assert_elapsed_eq(std::chrono::nanoseconds d) { return dur(MS_OP_ASSERT_ELAPSED, 0, d); }
     Task& assert_elapsed_ge(std::chrono::nanoseconds d) { return dur(MS_OP_ASSERT_ELAPSED, 1, d); }
     Task& bind(int addr) { return emit(MS_OP_BIND, (uint8_t)addr); }
+    Task& try_bind(int addr) { return emit(MS_OP_BIND, (uint8_t)addr, 1); }            // val = 0 | MADSIM_VAL_ADDR_NOT_AVAILABLE | MADSIM_VAL_ADDR_IN_USE
     Task& send_to(int ep, int dst, uint8_t tag, uint32_t payload) { return emit(MS_OP_SEND, (uint8_t)ep, (uint16_t)((tag << 8) | dst), payload); }
     Task& reply(int ep, uint8_t tag, uint32_t payload) { return emit(MS_OP_REPLY, (uint8_t)ep, (uint16_t)(tag << 8), payload); }
     Task& recv_from(int ep, uint8_t tag) { return emit(MS_OP_RECV, (uint8_t)ep, (uint16_t)(tag << 8)); }
@@ -118,6 +120,11 @@ class Task {
     }
     Task& rpc_recv(int ep, uint8_t req_id) { return emit(MS_OP_RECV, (uint8_t)ep, (uint16_t)((MADSIM_TAG_RPC_FIRST + req_id) << 8)); }
     Task& rpc_reply(int ep, uint8_t code) { return emit(MS_OP_RPC_REPLY, (uint8_t)ep, 0, code); }
+    // NetSim::hook_rpc_req / hook_rpc_rsp (net/mod.rs:240-284): drop requests R leaving `node` / responses on their way to `node`
+    Task& hook_rpc_req(int node, uint8_t req_id, std::optional<uint8_t> code = std::nullopt) {
+        return emit(MS_OP_HOOK_REQ, (uint8_t)node, (uint16_t)(((MADSIM_TAG_RPC_FIRST + req_id) << 8) | (code ? 0 : 1)), code ? *code : 0);
+    }
+    Task& hook_rpc_rsp(int node, std::optional<uint8_t> code = std::nullopt) { return emit(MS_OP_HOOK_RSP, (uint8_t)node, code ? 0 : 1, code ? *code : 0); }
     Task& spawn_move_request(const Task& t) { return emit(MS_OP_SPAWN, (uint8_t)t.index_, MADSIM_SPAWN_MOVE_REQUEST); }
     // supervisor (Handle::kill / restart / pause / resume / is_exit, JoinHandle::abort)
     Task& kill(int node) { return emit(MS_OP_KILL, (uint8_t)node); }
@@ -170,11 +177,21 @@ class WorkloadBuilder {
   public:
     WorkloadBuilder() { tasks_.reserve(256); nodes_.push_back(madsim_node_t{}); tasks_.push_back(Task(0, 0, 0)); }   // Task& stay valid
     Task& main() { return tasks_[0]; }                                   // the future handed to block_on
-    int create_node(bool restart_on_panic = false) {                     // Handle::create_node()[.restart_on_panic()].build()
-        madsim_node_t n{}; n.flags = restart_on_panic ? MADSIM_NODE_RESTART_ON_PANIC : 0;
+    // Handle::create_node()[.ip(10.0.0.<id>)][.restart_on_panic()][.restart_on_panic_matching(code)..].build()
+    int create_node(bool restart_on_panic = false, std::vector<uint8_t> restart_on_panic_matching = {}, bool ip = true) {
+        if (restart_on_panic_matching.size() > 2) throw std::length_error("at most two restart_on_panic_matching patterns");
+        madsim_node_t n{};
+        n.flags = (uint8_t)((restart_on_panic ? MADSIM_NODE_RESTART_ON_PANIC : 0) | (ip ? 0 : MADSIM_NODE_NO_IP) |
+                            (restart_on_panic_matching.empty() ? 0 : MADSIM_NODE_RESTART_MATCHING));
+        n.n_match = (uint8_t)restart_on_panic_matching.size();
+        for (size_t i = 0; i < restart_on_panic_matching.size(); i++) n.match[i] = restart_on_panic_matching[i];
         nodes_.push_back(n); return (int)nodes_.size() - 1;
     }
-    int addr(int node, uint16_t port) { socks_.push_back(madsim_sock_t{(uint8_t)node, 0, port}); return (int)socks_.size() - 1; }
+    // 10.0.0.<node>:port, or 0.0.0.0:port / 127.0.0.1:port as used on `node` (kind = MADSIM_ADDR_*)
+    int addr(int node, uint16_t port, uint8_t kind = MADSIM_ADDR_IP) {
+        if (port == 0) throw std::invalid_argument("port 0 (an ephemeral port) is not modelled");
+        socks_.push_back(madsim_sock_t{(uint8_t)node, kind, port}); return (int)socks_.size() - 1;
+    }
     Task& task(int node, bool init = false, bool before_block_on = false) {
         if (tasks_.size() >= 255) throw std::length_error("at most 255 task programs");
         tasks_.push_back(Task((int)tasks_.size(), node, (uint8_t)((init ? MADSIM_PROG_INIT : 0) | (before_block_on ? MADSIM_PROG_PRE : 0))));
@@ -255,12 +272,14 @@ struct Builder {
         madsim_workload_t w = wl.raw();
         madsim_config_t cfg = config.raw();
         madsim_limits_t lim = capacities;
-        if (time_limit) lim.time_limit_ns = (uint64_t)(*time_limit * 1e9 + 0.5);
+        // Some(Duration::ZERO) is a limit too (panics at the first idle advance); 0 means None in the C-ABI
+        if (time_limit) { lim.time_limit_ns = (uint64_t)(*time_limit * 1e9 + 0.5); if (!lim.time_limit_ns) lim.time_limit_ns = 1; }
         if (check) {                                   // Runtime::check_determinism (runtime/mod.rs:178-202)
             std::vector<uint8_t> l1(1 << 20), l2(1 << 20);
             madsim_result_t r1{}, r2{};
-            int64_t n1 = madsim_hip_trace_seed(&w, &cfg, seed, &lim, l1.data(), l1.size(), &r1);
-            int64_t n2 = madsim_hip_trace_seed(&w, &cfg, seed, &lim, l2.data(), l2.size(), &r2);
+            madsim_limits_t nolim = capacities;           // check_determinism never sets a time limit (runtime/mod.rs:178-202)
+            int64_t n1 = madsim_hip_trace_seed(&w, &cfg, seed, &nolim, l1.data(), l1.size(), &r1);
+            int64_t n2 = madsim_hip_trace_seed(&w, &cfg, seed, &nolim, l2.data(), l2.size(), &r2);
             if (n1 < 0) madsim::check((int)n1);
             if (n2 < 0) madsim::check((int)n2);
             size_t n = (size_t)(n1 < (int64_t)l1.size() ? n1 : (int64_t)l1.size());
@@ -273,10 +292,15 @@ struct Builder {
         }
         std::vector<madsim_result_t> out(count);
         madsim_summary_t s{};
-        madsim::check(madsim_hip_run_batch_auto(&w, &cfg, seed, count, &lim, out.data(), &s, 6));   // capacity verdicts are re-run
+        madsim::check(madsim_hip_run_batch_auto(&w, &cfg, seed, count, &lim, out.data(), &s, 6));   // runner verdicts are re-run
         if (s.n_failed) {
-            panic_with_info(s.first_failing_seed);
-            throw SimulationFailure(s.first_failing_seed, out[s.first_failing_seed - seed]);
+            uint64_t i = 0;
+            while (out[i].verdict == MADSIM_PASS) i++;
+            // a capacity / step-cap verdict that survived the re-runs is the runner's limit, not the test's failure
+            if (out[i].verdict == MADSIM_OVERFLOW || out[i].verdict == MADSIM_STEP_LIMIT)
+                throw Error(MADSIM_E_LIMITS, "seed " + std::to_string(seed + i) + ": runner limit persists after re-runs with larger limits");
+            panic_with_info(seed + i);
+            throw SimulationFailure(seed + i, out[i]);
         }
         return out;
     }

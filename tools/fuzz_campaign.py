@@ -12,13 +12,16 @@ from tests import fuzz
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 base = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 runtime.init(0)
-gens = [("plain", fuzz.random_workload, None), ("lifecycle", fuzz.random_lifecycle_workload, 24), ("rpc", fuzz.random_rpc_workload, 24)]
+gens = [("plain", fuzz.random_workload, None), ("lifecycle", fuzz.random_lifecycle_workload, 24), ("rpc", fuzz.random_rpc_workload, 24),
+        ("rpc+hooks", lambda r: fuzz.random_rpc_workload(r, hooks=True), 24), ("addresses", fuzz.random_addr_workload, None)]
 t0 = time.time(); k = 0; stats = {g[0]: [0, 0, 0] for g in gens}; verdicts = np.zeros(6, dtype=np.int64)
 while time.time() - t0 < budget:
     name, gen, max_tasks = gens[k % len(gens)]
     w, cfg, desc = gen(random.Random(base + k))
     lim = fuzz.generous_limits()
     if max_tasks: lim.max_tasks = max_tasks
+    if (k // len(gens)) % 2:          # every other round: per-seed state in the global-memory block instead of LDS (Variant::G)
+        lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
     n = 96
     got, _ = runtime.run_batch(w, 1000 + 7 * k, n, cfg, lim)
     want, _ = oracle.run_batch(w, 1000 + 7 * k, n, cfg, lim)
