@@ -119,6 +119,10 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         return subprocess.call(cmd, env=env)
 
+    # Three batches in flight need three hardware queues: ROCclr multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4)
+    # of them, and on some boxes two of this process's streams ended up sharing one (3 streams slower than 2).  More queues
+    # make that less likely; the warm-up trial below still decides between 3 and 2 by measurement.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -221,16 +225,22 @@ def main():
         # untimed trial: how many batches in flight does this box reward?  (same kernel, same seeds; only the overlap differs)
         stream_trial = {}
         scratch_rep = torch.zeros(REPORT_WORDS, dtype=torch.int64, device=dev)
-        for cand in (3, 2):
+
+        def trial(cand, n):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for k in range(12):
+            for k in range(n):
                 si = k % cand
                 with torch.cuda.stream(streams[si]):
                     runtime.run_batch_async(w, seed0 + (1 << 50) + k * total, count, d_outs[si].data_ptr(), scratch_rep.data_ptr(),
                                             streams[si].cuda_stream, cfg, lim, timing_slot=-1)
             torch.cuda.synchronize()
-            stream_trial[cand] = (time.perf_counter() - t1) / 12 * 1e3
+            return (time.perf_counter() - t1) / n * 1e3
+
+        trial(3, 6)                                  # first launches pay for table uploads, module load, stream set-up
+        for cand in (2, 3, 2, 3):                    # alternate, keep the better of two rounds each
+            ms = trial(cand, 12)
+            stream_trial[cand] = min(ms, stream_trial.get(cand, ms))
         n_streams = min(stream_trial, key=stream_trial.get)
         if world > 1:            # every rank must use the same count (the report ring is indexed by step)
             t = torch.tensor([n_streams], dtype=torch.int64, device=cdev)
