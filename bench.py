@@ -36,14 +36,16 @@ REPORT_WORDS = 8               # int64 per step: 4 from the library's reduction 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)      # ~1.5 s timed at 1.46 ms per batch (65.5 M seeds)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--seeds", type=int, default=0, help="seeds per GPU per step (default 65 536)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of sampled seeds after the timed region")
     ap.add_argument("--no-first-fail", action="store_true", help="skip the first-failing-seed measurement (loss variant)")
-    ap.add_argument("--measure-traffic", action="store_true",
-                    help="collect FETCH_SIZE / WRITE_SIZE of this same command with two rocprofv3 --pmc passes (slow)")
+    ap.add_argument("--measure-traffic", action="store_true", default=None,
+                    help="collect FETCH_SIZE / WRITE_SIZE of this same command with two short rocprofv3 --pmc passes after the "
+                         "timed region (default at one GPU when rocprofv3 is on PATH; a few seconds)")
+    ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
     ap.add_argument("--loss", type=float, default=0.0, help="packet_loss_rate of the timed batches (0 = Config::default())")
     ap.add_argument("--first-fail-loss", type=float, default=0.01, help="packet_loss_rate of the first-fail leg (SURVEY 8d)")
     ap.add_argument("--sched", type=int, default=0, help="0 = static seed striding, 1 = per-launch atomic work queue (madsim_limits_t.sched)")
@@ -72,7 +74,7 @@ def measure_traffic(argv):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
-    child = [a for a in argv if a != "--measure-traffic"]
+    child = [a for a in argv if a != "--measure-traffic"] + ["--no-measure-traffic"]
     for flag, val in (("--steps", "6"), ("--warmup", "2")):
         if flag in child:
             child[child.index(flag) + 1] = val
@@ -349,7 +351,7 @@ def main():
         g = runtime.geometry(w, lim)
         kname = runtime.variant_name(g)
         traffic, tdetail = None, None
-        if world == 1 and args.measure_traffic:
+        if world == 1 and args.measure_traffic is not False:
             traffic, tdetail = measure_traffic(sys.argv[1:])
         if traffic is None and world == 1 and per_gpu == workload.BENCH_SEEDS_PER_GPU and headline and not args.loss:
             # the committed rocprofv3 PMC passes of this same command (tools/prof_pmc.sh): FETCH_SIZE x2 + WRITE_SIZE

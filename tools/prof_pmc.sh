@@ -4,7 +4,7 @@
 set -u
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; mkdir -p $OUT
-CMD="python $R/bench.py --steps 20 --warmup 4 --no-cpu-baseline ${2:-}"
+CMD="python $R/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-measure-traffic ${2:-}"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" \

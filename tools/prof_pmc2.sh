@@ -3,7 +3,7 @@
 set -u
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; mkdir -p $OUT
-CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${2:-}"
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-measure-traffic ${2:-}"
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU" \
            "SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_IFETCH SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" \
