@@ -1,0 +1,227 @@
+// k_main.h — seed_init and the sim_kernel template: the executor loop of one lane.
+// Part of sim_kernel.hip (included after k_mem, k_state, k_rng, k_timer, k_net, k_lifecycle, k_channel, k_poll).
+#ifndef MADSIM_K_MAIN_H
+#define MADSIM_K_MAIN_H
+
+namespace madsim_k {
+
+// ---- per-seed init: Runtime::with_seed_and_config (runtime/mod.rs:53-69) ------------------------
+template <class K>
+__device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
+    const KParams& P = c.P;
+    if (K::G) {
+        for (uint32_t w = 0; w < P.gs_plane_words; w++) gs_store32(c.gs, c.gs_off + P.gs_planes + w * 4, 0);
+        for (uint32_t w = 0; w < (P.max_tasks + 31) / 32; w++) AMASK(w) = 0;
+        OMASK(0) = 0; OMASK(1) = 0;
+    }
+    else for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;     // plane 0 is the ready queue: RW spans all planes
+    for (uint32_t t = 0; t < P.max_tasks; t++) { TWORD(c, t, 0, 0) = 0; if (!K::LIFE) TWORD(c, t, 1, 1) = 0; }
+    // GlobalRng::new_with_seed -> Xoshiro256PlusPlus::seed_from_u64: SplitMix64 [DEP A.1]
+    uint64_t x = seed, z;
+#define SPLITMIX(dst) x += 0x9e3779b97f4a7c15ull; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; dst = z ^ (z >> 31)
+    SPLITMIX(L.s0); SPLITMIX(L.s1); SPLITMIX(L.s2); SPLITMIX(L.s3);
+#undef SPLITMIX
+    L.rng_calls = 0; L.clock = 0; L.msg_count = 0; L.steps = 0;
+    L.ready_len = 0; L.rq = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING; L.ovf = 0; L.main_done = 0;
+    L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
+    // TimeRuntime::new (time/mod.rs:26-38): base_time draw, before logging is enabled
+    { uint64_t h = L.trace_hash, n = L.log_len; uint32_t bt = gen_range_small<Variant<false, false, K::LWS, 0, K::RQ>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n;
+      if (K::LIFE) NODEW(4 + ((P.n_nodes + 4) >> 2)) = bt; }      // seconds into 2022: SystemTime::now() of MS_OP_TRACE_TIME
+    L.trace_hash = FNV_OFFSET; L.obs_hash = FNV_OFFSET; L.log_len = 0;
+    // tasks spawned before block_on, then the main task (task/mod.rs:222-235)
+    for (uint32_t p = 1; p < P.n_progs; p++) {
+        uint32_t fl = (PROGW(c, p) >> 8) & 0xff;
+        if (fl & MADSIM_PROG_PRE) spawn_task<K>(c, L, p, !(fl & MADSIM_PROG_INIT));
+    }
+    spawn_task<K>(c, L, 0, true);
+}
+
+// Global-state builds wait on memory most of the time (rocprofv3: 60-70 % of wave cycles), so they trade registers for
+// resident waves: MADSIM_G_WAVES_PER_EU waves per SIMD (the second __launch_bounds__ argument caps the VGPR budget).
+#ifndef MADSIM_G_WAVES_PER_EU
+#define MADSIM_G_WAVES_PER_EU 1
+#endif
+template <class K>
+__global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_kernel(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // workgroup-shared tables
+    uint32_t* sh = SMEM;
+    const uint32_t cp0 = table_copy_first(), cps = table_copy_stride(P.waves_per_block);
+    for (uint32_t i = cp0; i < P.n_insns * 4; i += cps) sh[P.sh_insns + i] = ((const uint32_t*)P.insns)[i];
+    for (uint32_t i = cp0; i < P.n_progs; i += cps) sh[P.sh_progs + i] = P.progs[i];
+    for (uint32_t i = cp0; i < P.n_socks; i += cps) sh[P.sh_socks + i] = P.socks[i];
+    for (uint32_t i = cp0; i <= P.n_nodes; i += cps) sh[P.sh_nodes + i] = P.nodes[i];
+    __syncthreads();
+
+    Ctx c(P);
+    c.insn0 = P.sh_insns / 4;
+    c.prog0 = P.sh_progs;
+    c.sockt0 = P.sh_socks;
+    c.nodet0 = P.sh_nodes;
+    const uint32_t wbase = wv * P.wave_words;       // this wave's slice of the workgroup's LDS
+    if (K::LIFE) c.heap0 = (P.sh_heap + wbase) / 4 + lane;
+    else { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = P.sh_heap + wbase + ((P.heap_lds * 2) << P.lw_shift) + lane; }
+    c.lws = P.lw_shift;
+    const uint32_t pl = P.sh_planes + wbase + lane;
+    c.ready0 = pl + (P.off_ready << P.lw_shift);
+    c.amask0 = pl + (P.off_amask << P.lw_shift);
+    c.omask0 = pl + (P.off_omask << P.lw_shift);
+    if (K::G) {                                      // byte offsets inside the lane's global state block
+        c.task0 = 0;
+        c.sock0 = P.gs_planes + P.off_socks * 4; c.hand0 = P.gs_planes + P.off_handles * 4; c.node0 = P.gs_planes + P.off_nodes * 4;
+        c.clog0 = P.gs_planes + P.off_clog * 4; c.pause0 = P.gs_planes + P.off_pause * 4; c.greg0 = P.gs_planes + P.off_greg * 4;
+        c.conn0 = P.gs_planes + P.off_conn * 4; c.hook0 = P.gs_planes + P.off_hooks * 4;
+    } else {
+        c.task0 = (P.sh_tasks + wbase) / 4 + lane;
+        c.task1 = (P.sh_tasks + wbase + ((P.max_tasks * 4) << P.lw_shift)) / 2 + lane;      // base-op builds: behind the unit0 array
+        c.sock0 = pl + (P.off_socks << P.lw_shift);
+        c.hand0 = pl + (P.off_handles << P.lw_shift);
+        c.node0 = pl + (P.off_nodes << P.lw_shift);
+        c.clog0 = pl + (P.off_clog << P.lw_shift);
+        c.pause0 = pl + (P.off_pause << P.lw_shift);
+        c.greg0 = pl + (P.off_greg << P.lw_shift);
+        c.conn0 = pl + (P.off_conn << P.lw_shift);
+        c.hook0 = pl + (P.off_hooks << P.lw_shift);
+    }
+    if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
+    const uint32_t glane = ((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane;
+    c.spill_off = glane * 16u;
+    c.spill = buf_make(P.spill, (uint64_t)P.heap_spill * P.total_lanes * 16u);
+    c.gs_off = glane * P.gs_stride;
+    c.gs = buf_make(P.gstate, (uint64_t)P.gs_stride * P.total_lanes);
+    c.tlog = P.trace_log;
+
+    Lane L;
+#ifdef MADSIM_K_PROF
+    for (int i = 0; i < 12; i++) L.prof_acc[i] = 0;
+    L.prof_t = __builtin_readcyclecounter(); uint64_t prof_iters = 0;
+#endif
+    uint64_t next = glane;          // first unit of lane g; then g+G, g+2G, ... or the work queue (below)
+    bool have = false;
+    for (;;) {
+        if (!have) {
+            if (next >= P.count) break;
+            seed_init<K>(c, L, P.seed_list ? P.seed_list[next] : P.seed0 + next);
+            have = true;
+        }
+        // One iteration = one pass of the block_on loop body (task/mod.rs:239-259):
+        //   [poll]  ready queue non-empty: one run_all_ready iteration (pop, poll, 50..100 ns advance)
+        //   [fire]  Timer::expire up to `now`; while the queue stays empty: is_finished / deadlock checks
+        //           and advance_to_next_event, firing again — the ONLY place timers fire.
+        // A lane that polls and then runs dry fires its next timer in the same pass, so in steady state
+        // every lane does one poll and one timer fire per iteration and the wave stays in phase.
+#ifdef MADSIM_K_PROF
+        prof_iters++;
+#endif
+        uint64_t now = L.clock;
+        PROBE(0);
+        REG(0);
+        if (L.ready_len > 0) {
+            // Latency hiding: the queue usually holds exactly one task, so ready[0] and its two state units are
+            // loaded BEFORE the draw loop (whose rejection retries take hundreds of cycles) and used if idx == 0.
+            const uint32_t slot0 = K::RQ ? (uint32_t)(L.rq & 0xff) : RW(0);
+            const uint4 pu0 = TU(c, slot0, 0), pu1 = load_u1<K>(c, slot0);
+            // try_recv_random (utils/mpsc.rs:73-83): idx drawn even when len == 1
+            uint32_t idx = gen_index<K>(c, L, L.ready_len);
+            L.ready_len--;
+            uint32_t slot = slot0;
+            uint4 u0 = pu0, u1 = pu1;
+            if (K::RQ) {
+                if (idx != 0) { slot = (uint32_t)(L.rq >> (8 * idx)) & 0xff; u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot); }
+                uint64_t last = (L.rq >> (8 * L.ready_len)) & 0xff;      // swap_remove on bytes
+                L.rq = (L.rq & ~(0xffull << (8 * idx))) | (last << (8 * idx));
+                L.rq &= ~(0xffull << (8 * L.ready_len));
+            } else {
+                if (idx != 0) { slot = RW(idx); u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot); }
+                if (idx != L.ready_len) RW(idx) = RW(L.ready_len);       // swap_remove
+            }
+            L.steps++;
+            bool panicked = false;
+            PROBE(1);
+            REG(26);
+            bool parked = false;
+            if (K::FN && (u0.x & (TF_CANCEL | TF_KILLED))) {   // task/mod.rs:269-273: drop(runnable)
+                task_finish<K>(c, L, slot, H_CANCELLED);
+            } else if (K::FN && P.uses_pause && ((NODEW(1) >> (PROGW(c, u0.x >> 24) & 0xff)) & 1)) {
+                uint32_t n = PAUSEW(0);                       // :274-277: park the Runnable; no poll, no time advance
+                PAUSEW(1 + n) = slot; PAUSEW(0) = n + 1;
+                L.steps--;
+                parked = true;
+            } else {
+                u0.x = (u0.x & ~TF_SCHED) | TF_RUN;          // async-task run(): SCHEDULED -> RUNNING
+                if (K::FN) L.panic_code = MADSIM_PANIC_CODE_OTHER;
+                panicked = poll_task<K>(c, L, slot, u0, u1);
+                if (!panicked && (u0.x & TF_ALIVE)) {
+                    if (u0.x & TF_SCHED) ready_push<K>(c, L, slot);   // woken while running: re-queue after the poll
+                    u0.x &= ~TF_RUN;
+                    TU(c, slot, 0) = u0;
+                }
+            }
+            PROBE(2);
+            if (K::FN && panicked && P.has_restart_on_panic) {   // task/mod.rs:289-314
+                uint32_t node = PROGW(c, u0.x >> 24) & 0xff;
+                // restart_on_panic || restart_on_panic_matching.iter().any(|s| error_msg.contains(s)) (task/mod.rs:297-300)
+                const uint32_t nw = NODET(c, node), nm = (nw >> 8) & 0xff;
+                const bool matches = (nw & MADSIM_NODE_RESTART_MATCHING) &&
+                                     ((nm >= 1 && ((nw >> 16) & 0xff) == L.panic_code) || (nm >= 2 && (nw >> 24) == L.panic_code));
+                if ((nw & MADSIM_NODE_RESTART_ON_PANIC) || matches) {
+                    // async-task's panic guard already dropped the future and notified the awaiter
+                    TU(c, slot, 0) = u0;
+                    task_finish<K>(c, L, slot, H_CANCELLED);
+                    // delay = gen_range(1 s..10 s) in ONE with(): UniformDuration Medium path [DEP A.3]
+                    const uint64_t range = 9000000000ull, zone = ~0ull - ((~0ull - range + 1) % range);
+                    uint64_t v;
+                    do { v = rng_next(L); } while (v * range > zone);
+                    rng_log<K>(c, L);
+                    uint64_t delay = NS_PER_S + __umul64hi(v, range);
+                    node_kill<K>(c, L, node);                 // self.kill(node_id)
+                    if (!timer_add<K>(c, L, L.clock + delay, (EV_RESTART << EV_SHIFT) | node, 0)) L.ovf = 1;
+                    panicked = false;
+                }
+            }
+            if (panicked) L.verdict = MADSIM_PANIC;          // resume_unwind (:315): no advance, no expire
+            else if (!parked) L.clock += 50 + gen_range_small<K, 50>(c, L);   // :319-321, then Timer::expire (time/mod.rs:103-106)
+            now = L.clock;
+            PROBE(3);
+        }
+        bool idle_jump = false;
+        while (L.verdict == MADSIM_RUNNING) {
+            REG(19);
+            timer_expire<K>(c, L, now);
+            if (idle_jump) {
+                L.clock = now;                                // time/mod.rs:55: after the callbacks
+                idle_jump = false;
+                if (P.time_limit && L.clock >= P.time_limit) { L.verdict = MADSIM_TIME_LIMIT; break; }   // task/mod.rs:253-258
+            }
+            if (L.steps >= P.max_steps) { L.verdict = MADSIM_STEP_LIMIT; break; }
+            if (L.ready_len > 0) break;                       // back to run_all_ready
+            if (L.main_done) { L.verdict = MADSIM_PASS; break; }                          // :241-243
+            if (L.heap_len == 0) { L.verdict = MADSIM_DEADLOCK; break; }                  // :250
+            now = L.top_dl + 50;                              // advance_to_next_event (time/mod.rs:47-53)
+            idle_jump = true;
+        }
+        PROBE(4);
+        if (L.ovf) L.verdict = MADSIM_OVERFLOW;
+        if (L.verdict != MADSIM_RUNNING) {
+            REG(25);
+            madsim_result_t r;
+            r.verdict = L.verdict; r.steps = L.steps; r.clock_ns = L.clock; r.msg_count = L.msg_count;
+            r.rng_calls = L.rng_calls; r.trace_hash = L.trace_hash; r.obs_hash = L.obs_hash;
+            P.out[next] = r;
+            if (K::TRACE) *P.trace_len = L.log_len;
+            have = false;
+            // next unit: static striding, or the per-launch work queue (a lane whose seeds end early — deadlocks under
+            // packet loss — then keeps pulling work instead of idling behind the slowest lane of its stride)
+            if (P.work_ctr) next = P.total_lanes + atomicAdd(P.work_ctr, 1ull);
+            else next += P.total_lanes;
+        }
+    }
+#ifdef MADSIM_K_PROF
+    PROBE2(0);
+    if (lane == 0 && P.prof) { for (int i = 0; i < 12; i++) atomicAdd((unsigned long long*)&P.prof[i], (unsigned long long)L.prof_acc[i]); atomicAdd((unsigned long long*)&P.prof[12], (unsigned long long)prof_iters); atomicAdd((unsigned long long*)&P.prof[13], 1ull); }
+#endif
+}
+
+}  // namespace madsim_k
+
+#endif

@@ -1,0 +1,63 @@
+// k_mem.h — the memory primitives sim_kernel is written against: the workgroup's LDS array, buffer-resource access to
+// global memory, the 64-bit rotate.  This is the gfx950 implementation; tests/emu/emu_shim.h provides the same names for
+// the host emulation harness (a debugging aid for GPU-less boxes, never part of the product), and nothing else in
+// kernel/*.h or sim_kernel.hip depends on which of the two is in use.
+#ifndef MADSIM_K_MEM_H
+#define MADSIM_K_MEM_H
+
+#ifdef MADSIM_EMU
+#include "emu_shim.h"
+#else
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace madsim_k {
+
+// All LDS traffic goes through the workgroup's one `extern __shared__` array, indexed by per-lane
+// offsets held in VGPRs: the compiler then knows every access is LDS (ds_read/ds_write) — pointer
+// members that may alias global memory degrade to flat_* instructions.
+extern __shared__ __attribute__((aligned(16))) uint32_t madsim_smem[];
+#define SMEM madsim_smem
+
+// Global memory (the timer-heap spill region, the per-lane state blocks) is reached through buffer resources
+// (buffer_load/store, byte offsets in a VGPR): with plain pointers the compiler folds the LDS and global alternatives of an
+// access into one flat_load/flat_store, which is slower for both and waits on both counters.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+struct BufRef { __amdgpu_buffer_rsrc_t rsrc; };
+// gfx9 raw buffer, 32-bit data format; num_records in bytes (the host keeps every region below 4 GiB)
+__device__ __forceinline__ BufRef buf_make(const void* base, uint64_t bytes) {
+    BufRef b; b.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (uint32_t)bytes, 0x00020000); return b;
+}
+__device__ __forceinline__ uint32_t buf_load32(const BufRef& b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(b.rsrc, off, 0, 0); }
+__device__ __forceinline__ void buf_store32(const BufRef& b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b.rsrc, off, 0, 0); }
+__device__ __forceinline__ uint4 buf_load128(const BufRef& b, uint32_t off) {
+    u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, off, 0, 0);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void buf_store128(const BufRef& b, uint32_t off, const uint4& e) {
+    u32x4_t t = {e.x, e.y, e.z, e.w};
+    __builtin_amdgcn_raw_buffer_store_b128(t, b.rsrc, off, 0, 0);
+}
+
+// 64-bit rotate as two v_alignbit_b32 (the compiler's shift/or expansion takes 3-4 VALU ops): K_ is a compile-time constant.
+template <int K_>
+__device__ __forceinline__ uint64_t rotl64(uint64_t x) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (K_ >= 32) { uint32_t t = lo; lo = hi; hi = t; }            // rotate by 32 = swap halves
+    constexpr int k = K_ & 31;
+    if (k == 0) return ((uint64_t)hi << 32) | lo;
+    uint32_t nhi = __builtin_amdgcn_alignbit(hi, lo, 32 - k);      // ({hi,lo} >> (32-k))[31:0] = hi<<k | lo>>(32-k)
+    uint32_t nlo = __builtin_amdgcn_alignbit(lo, hi, 32 - k);
+    return ((uint64_t)nhi << 32) | nlo;
+}
+
+// the threads of a workgroup share the copy of the workload tables into LDS: thread t copies words t, t + stride, ...
+__device__ __forceinline__ uint32_t table_copy_first() { return threadIdx.x; }
+__device__ __forceinline__ uint32_t table_copy_stride(uint32_t waves_per_block) { return 64 * waves_per_block; }
+// per-access statistics hook of the emulation harness (tools/gstate_access_model.py); nothing on the GPU
+#define EMU_GSTAT(off, kind) do { } while (0)
+
+}  // namespace madsim_k
+#endif  // !MADSIM_EMU
+
+#endif

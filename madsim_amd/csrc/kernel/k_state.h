@@ -97,27 +97,8 @@ struct Lane {
     uint32_t loss_always;
 };
 
-// All LDS traffic goes through the workgroup's one `extern __shared__` array, indexed by per-lane
-// offsets held in VGPRs: the compiler then knows every access is LDS (ds_read/ds_write) — pointer
-// members that may alias the HBM spill region degrade to flat_* instructions.
-#ifdef MADSIM_EMU
-#define SMEM emu_smem
-#else
-extern __shared__ __attribute__((aligned(16))) uint32_t madsim_smem[];
-#define SMEM madsim_smem
-#endif
 #define LDS128(i) (reinterpret_cast<uint4*>(SMEM)[(i)])
 #define LDS64(i) (reinterpret_cast<uint2*>(SMEM)[(i)])
-
-// The spill region is reached through a buffer resource (buffer_load/store_dwordx4, byte offsets in a VGPR): with a
-// plain pointer the compiler folds the LDS and HBM alternatives of heap_get/heap_set into one flat_load/flat_store,
-// which is slower for both and waits on both counters.
-#ifdef MADSIM_EMU
-struct SpillRef { uint4* base; };
-#else
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-struct SpillRef { __amdgpu_buffer_rsrc_t rsrc; };
-#endif
 
 struct Ctx {
     const KParams& P;
@@ -130,11 +111,11 @@ struct Ctx {
     uint32_t task1;      // base-op builds: uint2 index of the 8-byte unit1 array (see "Task state")
     uint32_t insn0;      // uint4 index of the workgroup-shared instruction table
     uint32_t prog0, sockt0, nodet0;   // word indices of the shared prog / socket-address / node tables
-    SpillRef spill;      // the HBM spill region: entry (slot, this lane) at byte (slot * P.total_lanes) * 16 + spill_off
+    BufRef spill;      // the HBM spill region: entry (slot, this lane) at byte (slot * P.total_lanes) * 16 + spill_off
     uint32_t spill_off;  // this lane's column: global lane * 16
     // K::G builds: this lane's state block = P.gs_stride bytes at byte gs_off of the state buffer; task0 and the plane
     // bases (sock0, hand0, node0, clog0, pause0, greg0, conn0) are then BYTE offsets inside that block
-    SpillRef gs;
+    BufRef gs;
     uint32_t gs_off;
     // K::G builds keep two small indexes in LDS so the common scans never walk global memory: bit t of the alive mask =
     // task slot t holds a live task (spawn's free-slot search), bit s of the owner mask = socket s was bound by a task that
@@ -150,43 +131,12 @@ template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { retu
 #define OMASK(i) SMEM[c.omask0 + ((i) << LWSH<K>(c))]
 
 // ---- the lane's state block in global memory (K::G builds) -----------------------------------------------------------
-// Reached through a buffer resource like the heap spill region (byte offsets in a VGPR): with plain pointers the compiler
-// would fold the LDS and global alternatives into flat_* accesses.  A block belongs to one lane for the whole launch.
+// Reached through a buffer resource like the heap spill region (k_mem.h).  A block belongs to one lane for the whole launch.
 // `off` = byte offset in the state buffer (the lane's gs_off already added).
-__device__ __forceinline__ uint32_t gs_load32(const SpillRef& gs, uint32_t off) {
-#ifdef MADSIM_EMU
-    EMU_GSTAT(off, 0);
-    return *(const uint32_t*)((const uint8_t*)gs.base + off);
-#else
-    return __builtin_amdgcn_raw_buffer_load_b32(gs.rsrc, off, 0, 0);
-#endif
-}
-__device__ __forceinline__ void gs_store32(const SpillRef& gs, uint32_t off, uint32_t v) {
-#ifdef MADSIM_EMU
-    EMU_GSTAT(off, 1);
-    *(uint32_t*)((uint8_t*)gs.base + off) = v;
-#else
-    __builtin_amdgcn_raw_buffer_store_b32(v, gs.rsrc, off, 0, 0);
-#endif
-}
-__device__ __forceinline__ uint4 gs_load128(const SpillRef& gs, uint32_t off) {
-#ifdef MADSIM_EMU
-    EMU_GSTAT(off, 2);
-    return *(const uint4*)((const uint8_t*)gs.base + off);
-#else
-    u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(gs.rsrc, off, 0, 0);
-    return make_uint4(t.x, t.y, t.z, t.w);
-#endif
-}
-__device__ __forceinline__ void gs_store128(const SpillRef& gs, uint32_t off, const uint4& e) {
-#ifdef MADSIM_EMU
-    EMU_GSTAT(off, 3);
-    *(uint4*)((uint8_t*)gs.base + off) = e;
-#else
-    u32x4_t t = {e.x, e.y, e.z, e.w};
-    __builtin_amdgcn_raw_buffer_store_b128(t, gs.rsrc, off, 0, 0);
-#endif
-}
+__device__ __forceinline__ uint32_t gs_load32(const BufRef& gs, uint32_t off) { EMU_GSTAT(off, 0); return buf_load32(gs, off); }
+__device__ __forceinline__ void gs_store32(const BufRef& gs, uint32_t off, uint32_t v) { EMU_GSTAT(off, 1); buf_store32(gs, off, v); }
+__device__ __forceinline__ uint4 gs_load128(const BufRef& gs, uint32_t off) { EMU_GSTAT(off, 2); return buf_load128(gs, off); }
+__device__ __forceinline__ void gs_store128(const BufRef& gs, uint32_t off, const uint4& e) { EMU_GSTAT(off, 3); buf_store128(gs, off, e); }
 
 // One 32-bit word / one 16-byte unit of per-seed state, in LDS ([word][lane] planes) or in the lane's global block.
 // The accessor macros below return these, so the executor code reads and writes state the same way in both layouts.
@@ -203,7 +153,7 @@ template <> struct WRef<false> {
     __device__ __forceinline__ uint32_t operator+=(uint32_t v) const { return *this = (uint32_t)*this + v; }
 };
 template <> struct WRef<true> {
-    SpillRef gs; uint32_t at;         // byte offset in the state buffer
+    BufRef gs; uint32_t at;         // byte offset in the state buffer
     __device__ __forceinline__ operator uint32_t() const { return gs_load32(gs, at); }
     __device__ __forceinline__ uint32_t operator=(uint32_t v) const { gs_store32(gs, at, v); return v; }
     __device__ __forceinline__ uint32_t operator=(const WRef& o) const { return *this = (uint32_t)o; }
@@ -219,7 +169,7 @@ template <> struct URef<false> {
     __device__ __forceinline__ void operator=(const URef& o) const { *this = (uint4)o; }
 };
 template <> struct URef<true> {
-    SpillRef gs; uint32_t at;
+    BufRef gs; uint32_t at;
     __device__ __forceinline__ operator uint4() const { return gs_load128(gs, at); }
     __device__ __forceinline__ void operator=(const uint4& v) const { gs_store128(gs, at, v); }
     __device__ __forceinline__ void operator=(const URef& o) const { *this = (uint4)o; }
@@ -303,21 +253,6 @@ __device__ __forceinline__ uint32_t PROGW(const Ctx& c, uint32_t p) { return SME
 __device__ __forceinline__ uint32_t SOCKW(const Ctx& c, uint32_t s) { return SMEM[c.sockt0 + s]; }
 __device__ __forceinline__ uint32_t NODET(const Ctx& c, uint32_t n) { return SMEM[c.nodet0 + n]; }   // flags | n_match<<8 | match0<<16 | match1<<24
 
-// 64-bit rotate as two v_alignbit_b32 (the compiler's shift/or expansion takes 3-4 VALU ops): K is a compile-time constant.
-template <int K_>
-__device__ __forceinline__ uint64_t rotl64(uint64_t x) {
-#ifdef MADSIM_EMU
-    return (x << K_) | (x >> (64 - K_));
-#else
-    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    if (K_ >= 32) { uint32_t t = lo; lo = hi; hi = t; }            // rotate by 32 = swap halves
-    constexpr int k = K_ & 31;
-    if (k == 0) return ((uint64_t)hi << 32) | lo;
-    uint32_t nhi = __builtin_amdgcn_alignbit(hi, lo, 32 - k);      // ({hi,lo} >> (32-k))[31:0] = hi<<k | lo>>(32-k)
-    uint32_t nlo = __builtin_amdgcn_alignbit(lo, hi, 32 - k);
-    return ((uint64_t)nhi << 32) | nlo;
-#endif
-}
 __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 }  // namespace madsim_k

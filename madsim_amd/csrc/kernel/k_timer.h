@@ -14,20 +14,10 @@ __device__ __forceinline__ uint64_t ev_deadline(const uint4& e) { return u64of(e
 // unconditionally (clamped index) and the HBM value selected afterwards, so the two address spaces
 // never merge into a flat_* access.
 __device__ __forceinline__ uint4 spill_load(const Ctx& c, uint32_t slot) {
-#ifdef MADSIM_EMU
-    return c.spill.base[(size_t)slot * c.P.total_lanes + c.spill_off / 16];
-#else
-    u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(c.spill.rsrc, slot * c.P.total_lanes * 16u + c.spill_off, 0, 0);
-    return make_uint4(t.x, t.y, t.z, t.w);
-#endif
+    return buf_load128(c.spill, slot * c.P.total_lanes * 16u + c.spill_off);
 }
 __device__ __forceinline__ void spill_store(const Ctx& c, uint32_t slot, const uint4& e) {
-#ifdef MADSIM_EMU
-    c.spill.base[(size_t)slot * c.P.total_lanes + c.spill_off / 16] = e;
-#else
-    u32x4_t t = {e.x, e.y, e.z, e.w};
-    __builtin_amdgcn_raw_buffer_store_b128(t, c.spill.rsrc, slot * c.P.total_lanes * 16u + c.spill_off, 0, 0);
-#endif
+    buf_store128(c.spill, slot * c.P.total_lanes * 16u + c.spill_off, e);
 }
 
 // LDS entry i of this lane.  Extended builds: one 16-byte unit {deadline, meta, payload}.  Base-op builds: 12 bytes — the

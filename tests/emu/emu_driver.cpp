@@ -8,7 +8,17 @@ thread_local uint32_t* emu_smem;
 #include <vector>
 #include <cstring>
 
-#include "../../madsim_amd/csrc/sim_kernel.hip"
+// the device code, host-compiled: the same headers sim_kernel.hip includes (k_mem.h picks emu_shim.h under MADSIM_EMU)
+#include "../../madsim_amd/csrc/kernel/k_mem.h"
+#include "../../madsim_amd/csrc/sim_kernel.h"
+#include "../../madsim_amd/csrc/kernel/k_state.h"
+#include "../../madsim_amd/csrc/kernel/k_rng.h"
+#include "../../madsim_amd/csrc/kernel/k_timer.h"
+#include "../../madsim_amd/csrc/kernel/k_net.h"
+#include "../../madsim_amd/csrc/kernel/k_lifecycle.h"
+#include "../../madsim_amd/csrc/kernel/k_channel.h"
+#include "../../madsim_amd/csrc/kernel/k_poll.h"
+#include "../../madsim_amd/csrc/kernel/k_main.h"
 #include "../../madsim_amd/csrc/geometry.h"
 
 static thread_local std::string emu_err;

@@ -30,6 +30,19 @@ void emu_gstat(uint32_t byte_off, int kind);      // kind: 0 load32, 1 store32, 
 #else
 #define EMU_GSTAT(off, kind) do { } while (0)
 #endif
+// ---- the memory primitives of madsim_amd/csrc/kernel/k_mem.h, host form ---------------------------------------------------
+namespace madsim_k {
+#define SMEM emu_smem
+struct BufRef { uint8_t* base; };
+static inline BufRef buf_make(const void* base, uint64_t) { return BufRef{(uint8_t*)base}; }
+static inline uint32_t buf_load32(const BufRef& b, uint32_t off) { return *(const uint32_t*)(b.base + off); }
+static inline void buf_store32(const BufRef& b, uint32_t off, uint32_t v) { *(uint32_t*)(b.base + off) = v; }
+static inline uint4 buf_load128(const BufRef& b, uint32_t off) { return *(const uint4*)(b.base + off); }
+static inline void buf_store128(const BufRef& b, uint32_t off, const uint4& e) { *(uint4*)(b.base + off) = e; }
+template <int K_> static inline uint64_t rotl64(uint64_t x) { return (x << K_) | (x >> (64 - K_)); }
+static inline uint32_t table_copy_first() { return 0; }                   // emulated threads run one after another:
+static inline uint32_t table_copy_stride(uint32_t) { return 1; }          // each copies everything
+}
 #ifdef MADSIM_EMU_REGIONS   // tools/divergence_model.py: per-iteration code-region visit counts of each emulated lane
 void emu_region(int id);
 #define REG(id) emu_region(id)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Divergence model of sim_kernel on CPU (no GPU needed).
 
-Builds the host emulation of the device code (tests/emu) with region markers (REG(id) in sim_kernel.hip),
+Builds the host emulation of the device code (tests/emu) with region markers (REG(id) in kernel/k_*.h),
 runs a batch, and for each marked region reports how often a 64-lane wave executes it per main-loop
 iteration (max over lanes: lanes re-converge at the loop top) and what fraction of the lanes are active
 in it.  Regions with many trips and low utilisation are where the wave's VALU time goes.
