@@ -322,23 +322,27 @@ def random_addr_workload(rng: random.Random):
     wl = W.WorkloadBuilder()
     n_nodes = rng.randint(2, 3)
     nodes = [wl.create_node(ip=rng.random() > 0.25) for _ in range(n_nodes)]
-    entries, by_node = [], {n: [] for n in nodes}
+    entries, by_node, keys = [], {n: [] for n in nodes}, {}
     for n in nodes:
         for _ in range(rng.randint(1, 3)):
             kind = rng.choice(["node", "node", "unspecified", "loopback"])
-            a = wl.addr(n, rng.randint(1, 3), ip=kind)
-            entries.append(a); by_node[n].append(a)
+            port = rng.randint(1, 3)
+            a = wl.addr(n, port, ip=kind)
+            entries.append(a); by_node[n].append(a); keys[a] = (n, kind, port)
     desc = [f"{n_nodes}n/{len(entries)}a"]
     tasks = []
     for n in nodes:
         t = wl.task(n)
         mine = by_node[n]
-        bound = []
+        bound, seen = [], set()
         for a in rng.sample(mine, rng.randint(1, len(mine))):
-            t.try_bind(a); t.trace(10 + a, add_reg=None); t.trace_val()
-            bound.append(a)
-        if rng.random() < 0.3:                                     # somebody else's entry: AddrNotAvailable
-            t.try_bind(rng.choice(entries)); t.trace_val()
+            if keys[a] in seen:                                        # a second entry naming a bound address: AddrInUse
+                t.try_bind(a); t.trace(10 + a); t.trace_val()
+            else:                                                      # (only entries that do get bound serve as Endpoints)
+                t.bind(a); seen.add(keys[a]); bound.append(a)
+        if rng.random() < 0.3:                                         # somebody else's entry: AddrNotAvailable (or in use)
+            t.try_bind(rng.choice([e for e in entries if e not in bound])) if len(entries) > len(bound) else None
+            t.trace_val()
         t.sleep(ms=rng.randint(1, 8))
         t.set(0, rng.randint(1, 4))
         top = t.label()

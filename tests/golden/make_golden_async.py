@@ -9,7 +9,10 @@ sources: time/mod.rs:103-140 (sleep, timeout), time/sleep.rs:47-54 (Sleep::poll 
 not-elapsed poll), net/endpoint.rs:120-149,331-362 (send_to_raw / recv_from_raw / Mailbox), net/mod.rs:287-333
 (rand_delay, send), net/network.rs:162-203,261-313 (clog sets, try_send), net/rpc.rs:96-180 (call, call_timeout,
 add_rpc_handler), task/mod.rs:220-323 (executor loop), rand.rs:64-88,142-158 (log, RngCore).  It shares only the
-generator / gen_range / UniformDuration arithmetic with make_golden.py.
+generator / gen_range / UniformDuration arithmetic with make_golden.py.  Round 2 added the network's address handling —
+sockets live in a literal per-node `HashMap<(ip, port), socket>`, `Network::bind` / `resolve_dest_node` / `try_send`
+(net/network.rs:206-313) are restated over it with addresses as (ip string, port) tuples, the receiver's `from` is the
+tuple the reference builds (:307-311) — and the NetSim request / response hooks (net/mod.rs:240-284,307-328).
 
 Like make_golden.py it cannot be pinned to the Rust reference in this image; what the fixture gives is agreement of
 independently written restatements on timeouts' duplicate timers, dropped receivers, orphaned RPC responses.
@@ -56,6 +59,14 @@ class Sim:
         self.insns = [(w.insns[i].op, w.insns[i].a, w.insns[i].b, w.insns[i].imm) for i in range(w.struct.n_insns)]
         self.progs = [(w.progs[i].node, w.progs[i].flags, w.progs[i].entry) for i in range(w.struct.n_progs)]
         self.socks = [(w.socks[i].node, w.socks[i].port) for i in range(w.struct.n_socks)]
+        # SocketAddr of table entry i, and the network's view of the nodes (network.rs:19-37)
+        self.addr = [({0: "10.0.0.%d" % w.socks[i].node, 1: "0.0.0.0", 2: "127.0.0.1"}[w.socks[i].kind], w.socks[i].port)
+                     for i in range(w.struct.n_socks)]
+        n_nodes = w.struct.n_nodes
+        self.node_ip = {n: (None if w.nodes[n].flags & A.NODE_NO_IP else "10.0.0.%d" % n) for n in range(1, n_nodes + 1)}
+        self.addr_to_node = {ip: n for n, ip in self.node_ip.items() if ip is not None}
+        self.node_sockets = {n: {} for n in range(0, n_nodes + 1)}        # HashMap<(SocketAddr, protocol), Arc<dyn Socket>>
+        self.hooks_req, self.hooks_rsp = {}, {}                            # NetSim.hooks_req / hooks_rsp: HashMap<NodeId, hook>
         self.cfg, self.rng = cfg, Xoshiro(seed)
         self.clock, self.log, self.logging = 0, [], False
         self.heap, self.ready, self.handles, self.bound = [], [], {}, {}
@@ -152,9 +163,9 @@ class Sim:
 
     def finish(self, t):
         t.gen.close()                               # the future is dropped: `finally:` blocks = Drop impls
-        for a in t.owned:                           # BindGuard::drop
+        for a in t.owned:                           # BindGuard::drop -> Network::close(node, addr)
             if self.bound.get(a) is not None and self.bound[a]["owner"] is t:
-                self.bound[a] = None
+                self.close_sock(a)
         t.alive = False
         if t.joiner is not None:
             self.wake(t.joiner)
@@ -172,18 +183,56 @@ class Sim:
         delay = self.gen_range(0, 5) * 1000
         yield from self.sleep_until(t, self.sleep_deadline(self.clock + delay))
 
-    def send_raw(self, t, ep, dst, tag, val, aux=0):   # Endpoint::send_to_raw -> NetSim::send
-        yield from self.rand_delay(t)
-        src_node, dst_node = self.socks[ep][0], self.socks[dst][0]
-        if src_node in self.clog_out or dst_node in self.clog_in:
-            return
+    def close_sock(self, a):                        # Network::close (network.rs:253-258)
+        self.node_sockets[self.socks[a][0]].pop(self.addr[a], None)
+        self.bound[a] = None
+
+    def resolve_dest_node(self, node, dst):         # network.rs:272-290
+        if dst[0] == "127.0.0.1" or dst in self.node_sockets[node]:
+            return node
+        if self.node_ip[node] is None:
+            return None                             # "ip not set"
+        return self.addr_to_node.get(dst[0])        # or "destination not found"
+
+    def try_send(self, node, dst):                  # network.rs:296-313 -> (src_ip, socket, latency) or None
+        dst_node = self.resolve_dest_node(node, dst)
+        if dst_node is None:
+            return None
+        if node in self.clog_out or dst_node in self.clog_in:         # test_link (:261-269)
+            return None
         if self.gen_bool(self.loss):
-            return
+            return None
         self.msg_count += 1
         lat = self.sample_duration(self.lat)
-        mbox = self.bound.get(dst)
-        if mbox is not None:
-            self.timer_add(self.clock + lat, lambda: self.deliver(mbox, tag, val, ep, aux))
+        sockets = self.node_sockets[dst_node]
+        ep = sockets.get(dst) or sockets.get(("0.0.0.0", dst[1]))
+        if ep is None:
+            return None
+        if dst[0] == "127.0.0.1":
+            src_ip = "127.0.0.1"
+        else:
+            if self.node_ip[node] is None:
+                raise Panic()                       # `.ip.unwrap()`
+            src_ip = self.node_ip[node]
+        return src_ip, dst_node, ep, lat
+
+    def send_raw(self, t, ep, dst, tag, val, aux=0, kind="datagram"):   # Endpoint::send_to_raw -> NetSim::send (net/mod.rs:298-333)
+        yield from self.rand_delay(t)
+        node = self.socks[ep][0]
+        hook = self.hooks_req.get(node)
+        if hook is not None and kind == "request" and not hook(tag, val):
+            return                                  # `if !hook(&msg) { return Ok(()) }`
+        sent = self.try_send(node, dst)
+        if sent is not None:
+            src_ip, dst_node, mbox, lat = sent
+            frm = (src_ip, self.addr[ep][1])
+            rsp_hook = self.hooks_rsp.get(dst_node)     # cloned now, consulted when the timer fires
+
+            def arrive():
+                if rsp_hook is not None and kind == "response" and not rsp_hook(val):
+                    return
+                self.deliver(mbox, tag, val, frm, aux)
+            self.timer_add(self.clock + lat, arrive)
 
     def mailbox_recv(self, t, ep, tag):             # Mailbox::recv
         mbox, os_ = self.bound[ep], Oneshot()
@@ -238,7 +287,7 @@ class Sim:
 
     def rpc_call(self, t, ep, dst, req_tag, code):  # Endpoint::call_with_data
         rsp_tag = self.next_u64()                   # random::<u64>()
-        yield from self.send_raw(t, ep, dst, req_tag, code, rsp_tag)
+        yield from self.send_raw(t, ep, dst, req_tag, code, rsp_tag, kind="request")
         val, frm, _ = yield from self.recv_raw(t, ep, rsp_tag)
         if frm != dst:
             raise Panic()
@@ -268,6 +317,11 @@ class Sim:
                 yield
             elif name == "PANIC":
                 raise Panic()
+            elif name == "HOOK_REQ":                # NetSim::hook_rpc_req::<R>(node, f): HashMap::insert
+                self.hooks_req[a] = (lambda tag, code, want_tag=b >> 8, all_=b & 1, want=imm & 0xFF:
+                                     not (tag == want_tag and (all_ or code == want)))
+            elif name == "HOOK_RSP":
+                self.hooks_rsp[a] = (lambda code, all_=b & 1, want=imm & 0xFF: not (all_ or code == want))
             elif name == "SET":
                 t.cnt[a & 1] = imm & 0xFFFF
             elif name == "DJNZ":
@@ -298,20 +352,36 @@ class Sim:
                 el = self.clock - t.t0
                 if not {0: el == dur, 1: el >= dur, 2: el < dur}[a]:
                     raise Panic()
-            elif name == "BIND":
+            elif name == "BIND":                    # Endpoint::bind -> Network::bind (network.rs:206-251)
                 yield from self.rand_delay(t)
-                if self.socks[a][0] != t.node or self.bound.get(a) is not None:
-                    raise Panic()
-                self.bound[a] = dict(owner=t, regs=[], msgs=[]); t.owned.append(a)
+                ip, port = self.addr[a]
+                err = 0
+                # (a table entry is one node's: the workload VM's rule, not the reference's)
+                if self.socks[a][0] != t.node:
+                    err = A.VAL_ADDR_NOT_AVAILABLE
+                elif ip not in ("0.0.0.0", "127.0.0.1") and self.node_ip[t.node] is not None and ip != self.node_ip[t.node]:
+                    err = A.VAL_ADDR_NOT_AVAILABLE
+                elif (ip, port) in self.node_sockets[t.node]:
+                    err = A.VAL_ADDR_IN_USE
+                if err:
+                    if not (b & 1):
+                        raise Panic()               # .unwrap()
+                    t.val = err
+                else:
+                    mbox = dict(owner=t, regs=[], msgs=[])
+                    self.node_sockets[t.node][(ip, port)] = mbox
+                    self.bound[a] = mbox; t.owned.append(a)
+                    if b & 1:
+                        t.val = 0
             elif name == "CLOSE":
                 if self.bound.get(a) is not None and self.bound[a]["owner"] is t:
-                    self.bound[a] = None
+                    self.close_sock(a)
             elif name == "SEND":
-                yield from self.send_raw(t, a, b & 0xFF, b >> 8, imm)
+                yield from self.send_raw(t, a, self.addr[b & 0xFF], b >> 8, imm)
             elif name == "REPLY":
                 yield from self.send_raw(t, a, t.frm, b >> 8, imm)
             elif name == "RPC_REPLY":
-                yield from self.send_raw(t, a, t.frm, t.aux, imm & 0xFF)
+                yield from self.send_raw(t, a, t.frm, t.aux, imm & 0xFF, kind="response")
             elif name == "RECV":
                 val, frm, aux = yield from self.recv_raw(t, a, b >> 8)
                 t.val, t.frm = val, frm
@@ -326,15 +396,15 @@ class Sim:
                 else:
                     t.val = A.VAL_TIMEOUT
             elif name == "RPC_CALL":
-                call = self.rpc_call(t, a, b & 0xFF, b >> 8, imm & 0xFF)
+                call = self.rpc_call(t, a, self.addr[b & 0xFF], b >> 8, imm & 0xFF)
                 if imm >> 8:
                     how, v = yield from self.timeout(t, (imm >> 8) * MS, call)
                     t.val = v if how == "ok" else A.VAL_TIMEOUT
                     if how == "ok":
-                        t.frm = b & 0xFF
+                        t.frm = self.addr[b & 0xFF]
                 else:
                     t.val = yield from call
-                    t.frm = b & 0xFF
+                    t.frm = self.addr[b & 0xFF]
             elif name == "ASSERT_VAL":
                 if t.val != imm:
                     raise Panic()
@@ -430,6 +500,19 @@ def workloads():
     top = c.label(); c.rpc_call(acl, asv, 2, 77, timeout_ms=40); c.trace_val(); c.sleep_rand(lo_ms=0, ms=30); c.djnz(0, top)
     m = wl.main(); m.spawn(s); m.spawn(c); m.sleep(ms=60); m.clog_node(ns, "in"); m.sleep(ms=90); m.unclog_node(ns, "in"); m.join(c)
     out["rpc_retry_under_clog"] = wl.build()
+    # round 2: address resolution (network.rs:206-313) and NetSim hooks (net/mod.rs:240-284)
+    for name in ("endpoint_localhost", "endpoint_bind", "net_wildcard_and_unbound_port", "net_ipless_node",
+                 "net_ipless_node_own_socket_panics", "rpc_hooks"):
+        out[name] = LW.ALL[name]()
+    import random
+    from tests import fuzz
+    for k in range(24):                             # random programs over mixed address kinds / IP-less nodes
+        out["addr_fuzz_%02d" % k] = fuzz.random_addr_workload(random.Random(880000 + k))[0]
+    for k in range(12):                             # random typed-RPC programs with hooks — those without node lifecycle
+        w, _, _ = fuzz.random_rpc_workload(random.Random(890000 + k), hooks=True)
+        ops = {OPN[w.insns[i].op] for i in range(w.struct.n_insns)}
+        if not ops & {"KILL", "RESTART", "BUILD"} and not any(w.progs[i].flags for i in range(w.struct.n_progs)):
+            out["rpc_hook_fuzz_%02d" % k] = w
     return out
 
 
