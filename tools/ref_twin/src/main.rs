@@ -218,6 +218,46 @@ async fn receiver_drop(obs: Obs) -> Tail {
     fingerprint_tail(t0, &obs)
 }
 
+/// net/endpoint.rs:516-548 `localhost`, sleeps instead of the Barrier: 127.0.0.1-bound endpoints, a datagram to an address
+/// nobody listens on (dropped after the draws), the receiver seeing the sender's real IP, a reply that finds no socket.
+async fn localhost(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let node1 = h.create_node().ip("10.0.0.1".parse().unwrap()).build();
+    let node2 = h.create_node().ip("10.0.0.2".parse().unwrap()).build();
+    let f1 = node1.spawn(async move {
+        let ep1 = Endpoint::bind("127.0.0.1:1").await.unwrap();
+        let ep2 = Endpoint::bind("10.0.0.1:2").await.unwrap();
+        time::timeout(Duration::from_secs(1), ep1.recv_from(1, &mut [])).await.expect_err("localhost endpoint should not receive from other nodes");
+        let mut buf = [0u8; 4];
+        let (_, from) = ep2.recv_from(1, &mut buf).await.unwrap();
+        assert_eq!(from.to_string(), "10.0.0.2:1");
+        ep2.send_to(from, 1, &[7]).await.unwrap();
+    });
+    let f2 = node2.spawn(async move {
+        let ep = Endpoint::bind("127.0.0.1:1").await.unwrap();
+        time::sleep(Duration::from_millis(5)).await;
+        ep.send_to("10.0.0.1:1", 1, &[1]).await.unwrap();
+        ep.send_to("10.0.0.1:2", 1, &[1]).await.unwrap();
+        time::timeout(Duration::from_secs(2), ep.recv_from(1, &mut [])).await.expect_err("the reply went to 10.0.0.2:1");
+    });
+    f1.await.unwrap();
+    f2.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
+/// task/mod.rs:964-982 `restart_on_panic_matching`: panics "0" and "1" restart the node, "2" unwinds out of block_on.
+async fn restart_on_panic_matching(_obs: Obs) -> Tail {
+    let h = Handle::current();
+    let flag = Arc::new(AtomicUsize::new(0));
+    h.create_node().init(move || {
+        let flag = flag.clone();
+        async move { panic!("{}", flag.fetch_add(1, Ordering::Relaxed)); }
+    }).restart_on_panic_matching("0").restart_on_panic_matching("1").build();
+    time::sleep(Duration::from_secs(120)).await;
+    unreachable!("the third panic ends the run")
+}
+
 fn run_one(name: &str, seed: u64, loss: f64) -> String {
     let mut config = madsim::Config::default();
     config.net.packet_loss_rate = loss;
@@ -241,6 +281,8 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
                 "restart" => lifecycle_restart(o).await,
                 "restart_on_panic" => lifecycle_restart_on_panic(o).await,
                 "receiver_drop" => receiver_drop(o).await,
+                "localhost" => localhost(o).await,
+                "restart_on_panic_matching" => restart_on_panic_matching(o).await,
                 other => panic!("unknown workload {other}"),
             }
         });
@@ -263,7 +305,7 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
 }
 
 const ALL: &[&str] = &["pingpong2", "pingpong4", "pingpong16", "sleep_1s", "yield_order", "timer_ties", "kill", "restart",
-                       "restart_on_panic", "receiver_drop"];
+                       "restart_on_panic", "receiver_drop", "localhost", "restart_on_panic_matching"];
 
 fn main() {
     let args: Vec<String> = std::env::args().collect();

@@ -155,8 +155,38 @@ def receiver_drop():
     return wl.build()
 
 
+def localhost():
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    lo1, ip1_2, lo2 = wl.addr(n1, 1, ip="loopback"), wl.addr(n1, 2), wl.addr(n2, 1, ip="loopback")
+    ip1_1 = wl.addr(n1, 1)                            # a destination only
+    f1 = wl.task(n1); f1.bind(lo1); f1.bind(ip1_2)
+    f1.recv_from_timeout(lo1, 1, secs=1); f1.assert_val(A.VAL_TIMEOUT)
+    f1.recv_from(ip1_2, 1); f1.assert_val(1); f1.reply(ip1_2, 1, 7); f1.done()
+    f2 = wl.task(n2); f2.bind(lo2); f2.sleep(ms=5)
+    f2.send_to(lo2, ip1_1, 1, 1); f2.send_to(lo2, ip1_2, 1, 1)
+    f2.recv_from_timeout(lo2, 1, secs=2); f2.assert_val(A.VAL_TIMEOUT); f2.done()
+    m = wl.main(); m.spawn(f1); m.spawn(f2); m.join(f1); m.join(f2)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def restart_on_panic_matching():
+    wl = W.WorkloadBuilder()
+    n = wl.create_node(restart_on_panic_matching=(0, 1))
+    t = wl.task(n, init=True)
+    t.flag_add(0, 1); t.panic_with_flag(0, offset=-1)
+    m = wl.main(); m.build_node(n); m.sleep(secs=120)
+    fingerprint_tail(m)                                # never reached: the third panic ends the run
+    return wl.build()
+
+
+# workloads that end in a panic by design (the reference test is #[should_panic])
+EXPECT_PANIC = {"restart_on_panic_matching"}
+
 ALL = {
     "pingpong2": lambda: pingpong(2, 64), "pingpong4": lambda: pingpong(4, 64), "pingpong16": lambda: pingpong(16, 8),
     "sleep_1s": sleep_1s, "yield_order": yield_order, "timer_ties": timer_ties, "kill": kill, "restart": restart,
     "restart_on_panic": restart_on_panic, "receiver_drop": receiver_drop,
+    "localhost": localhost, "restart_on_panic_matching": restart_on_panic_matching,
 }
