@@ -404,6 +404,25 @@ def main():
                                     "sample": f"{sample} seeds of the same workload, single thread, "
                                               f"{cdt:.1f} s ({sample / cdt:.0f} seeds/s, "
                                               f"{osum.total_steps / cdt / 1e6:.1f} M steps/s)"}
+            # the whole host beside it: one oracle thread per core, disjoint seed blocks (ctypes releases the GIL)
+            import threading
+            n_thr = min(os.cpu_count() or 1, 64)
+            per = max(2048, sample // 4)
+            res = [None] * n_thr
+
+            def work(i):
+                res[i] = oracle.run_batch(w, (1 << 45) + i * per, per, cfg, lim)[1]
+            thr = [threading.Thread(target=work, args=(i,)) for i in range(n_thr)]
+            t1 = time.perf_counter()
+            for t in thr:
+                t.start()
+            for t in thr:
+                t.join()
+            hdt = time.perf_counter() - t1
+            line["cpu_baseline_host"] = {"value": sum(r.total_clock_ns for r in res) / 1e9 / hdt, "unit": "sim-s/s", "cores": n_thr,
+                                         "kind": "port",
+                                         "sample": f"{n_thr} threads x {per} seeds, {hdt:.1f} s ({n_thr * per / hdt:.0f} seeds/s, "
+                                                   f"{sum(r.total_steps for r in res) / hdt / 1e6:.0f} M steps/s)"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
