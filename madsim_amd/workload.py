@@ -556,12 +556,13 @@ def streaming_topology_limits():
 
 
 def raft_election_limits():
-    """Device capacities the election loop needs (high-water marks over 4 000 seeds on the CPU oracle: timer heap 95
-    — the duplicate timers of timeout() — so most of it lives in the HBM spill region; 43 dead recv registrations
-    per socket, 6 queued messages).  Sized to the high-water marks: per-seed LDS is what bounds seeds per CU."""
+    """Device capacities the election loop needs (high-water marks over 40 000 seeds on the CPU oracle: timer heap 99
+    — the duplicate timers of timeout() — so most of it lives in the HBM spill region; 67 dead recv registrations
+    per socket, 8 queued messages).  The mailboxes live in the per-lane global-memory block (Variant::G), so their
+    capacity costs no LDS; rarer seeds still come back MADSIM_OVERFLOW and are re-run by run_batch_auto."""
     lim = A.Limits()
     lim.heap_lds_slots, lim.heap_spill_slots = 16, 240
-    lim.mbox_regs, lim.mbox_msgs = 48, 8
+    lim.mbox_regs, lim.mbox_msgs = 80, 10
     return lim
 
 
