@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from madsim_amd import runtime, workload, _abi as A
 import torch
 runtime.init(0)
-w = workload.pingpong(4, 64)
-lim = A.Limits(); lim.heap_lds_slots = 8; lim.mbox_regs = lim.mbox_msgs = 1
+which = sys.argv[1] if len(sys.argv) > 1 else "pingpong"       # any bench.py --workload name
+w, lim, _ = workload.bench_case(which)
 buf = torch.empty(65536 * 48, dtype=torch.uint8, device="cuda")
 out = (C.c_uint64 * 16)()
 L = runtime.lib()
