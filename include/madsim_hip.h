@@ -73,7 +73,8 @@ enum madsim_op {
     MS_OP_ADVANCE = 14,    /* time::advance(b s + imm ns) (time/mod.rs:195-198, 103-106)             */
     /* -- net (datagram Endpoint API, net/endpoint.rs) -- */
     MS_OP_BIND = 20,       /* a=sock: Endpoint::bind(addr(sock)).await.unwrap() (endpoint.rs:23-36, network.rs:206-251).
-                              b&1: without the unwrap — val := 0, MADSIM_VAL_ADDR_NOT_AVAILABLE or MADSIM_VAL_ADDR_IN_USE   */
+                              b&1: without the unwrap — val := 0, MADSIM_VAL_ADDR_NOT_AVAILABLE or MADSIM_VAL_ADDR_IN_USE;
+                              b&2: on success val := ep.local_addr().unwrap().port() (what a port-0 entry was given)        */
     MS_OP_SEND = 21,       /* a=src sock, b=(tag<<8)|dst addr, imm=payload:
                               ep.send_to(addr(dst), tag, payload).await (endpoint.rs:69-72,120-133)  */
     MS_OP_REPLY = 22,      /* a=src sock, b=(tag<<8), imm=payload: ep.send_to(from, tag, ..).await   */
@@ -168,14 +169,22 @@ typedef struct madsim_prog {
 #define MADSIM_PROG_PRE  2u /* spawned before Runtime::block_on pushes the main task, in prog order:
                                `node.spawn(..)` ahead of `runtime.block_on(..)` (task/mod.rs:859-897) */
 
-/* A socket address an Endpoint may bind or a datagram may be sent to: an IP and a port (never 0: ephemeral ports are
- * not modelled).  `kind` picks the IP: the node's own 10.0.0.<node>, 0.0.0.0 or 127.0.0.1 as used ON `node` (entries of
- * the last two kinds are per node: only tasks of `node` may bind them).  Resolution happens at try_send time exactly as
+/* A socket address an Endpoint may bind or a datagram may be sent to: an IP and a port.  `kind` picks the IP: the node's
+ * own 10.0.0.<node>, 0.0.0.0 or 127.0.0.1 as used ON `node` (entries of the last two kinds are per node: only tasks of
+ * `node` may bind them).  Resolution happens at try_send time exactly as
  * in network.rs:272-313: loopback or an exact match among the sender's own sockets keeps the message on the sender's
  * node; an IP-less sender or an unknown IP drops it WITHOUT any RNG draw; after the link test (loss + latency draws,
  * msg_count) the destination node's sockets are searched for the exact address, then for 0.0.0.0:port.  The address a
  * receiver sees (`from`, what MS_OP_REPLY answers to) is the sender's real IP — or 127.0.0.1 when the datagram was sent
- * to a loopback address — with the sending socket's port (network.rs:307-311). */
+ * to a loopback address — with the sending socket's port (network.rs:307-311).
+ * port == 0 is an EPHEMERAL Endpoint (`Endpoint::bind("0.0.0.0:0")`): every MS_OP_BIND of the entry takes the lowest port
+ * from 1 up that no socket of the node holds for that IP (network.rs:224-236) and every other op on the entry works on the
+ * Endpoint its last bind made.  Such an entry is not an address anybody can name: it cannot be a destination operand
+ * (MS_OP_SEND / MS_OP_CONNECT / MS_OP_RPC_CALL `b`) — peers reach it by replying to `from`, or through a named entry that
+ * happens to carry the port it was given.
+ * The device table holds one candidate entry per port such an Endpoint can get — as many as the node has entries for that
+ * IP — and the total, candidates included, is limited to 63 entries; a workload that keeps more Endpoints of one entry
+ * alive than that gets the resource-overflow verdict. */
 typedef struct madsim_sock {
     uint8_t  node;
     uint8_t  kind;   /* MADSIM_ADDR_* */

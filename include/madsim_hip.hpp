@@ -84,7 +84,7 @@ class Task {
     Task& sleep_until(std::chrono::nanoseconds after_mark) { return dur(MS_OP_SLEEP_UNTIL, 0, after_mark); }
     Task& assert_elapsed_eq(std::chrono::nanoseconds d) { return dur(MS_OP_ASSERT_ELAPSED, 0, d); }
     Task& assert_elapsed_ge(std::chrono::nanoseconds d) { return dur(MS_OP_ASSERT_ELAPSED, 1, d); }
-    Task& bind(int addr) { return emit(MS_OP_BIND, (uint8_t)addr); }
+    Task& bind(int addr, bool port_to_val = false) { return emit(MS_OP_BIND, (uint8_t)addr, port_to_val ? 2 : 0); }   // val = local_addr().port()
     Task& try_bind(int addr) { return emit(MS_OP_BIND, (uint8_t)addr, 1); }            // val = 0 | MADSIM_VAL_ADDR_NOT_AVAILABLE | MADSIM_VAL_ADDR_IN_USE
     Task& send_to(int ep, int dst, uint8_t tag, uint32_t payload) { return emit(MS_OP_SEND, (uint8_t)ep, (uint16_t)((tag << 8) | dst), payload); }
     Task& reply(int ep, uint8_t tag, uint32_t payload) { return emit(MS_OP_REPLY, (uint8_t)ep, (uint16_t)(tag << 8), payload); }
@@ -187,9 +187,9 @@ class WorkloadBuilder {
         for (size_t i = 0; i < restart_on_panic_matching.size(); i++) n.match[i] = restart_on_panic_matching[i];
         nodes_.push_back(n); return (int)nodes_.size() - 1;
     }
-    // 10.0.0.<node>:port, or 0.0.0.0:port / 127.0.0.1:port as used on `node` (kind = MADSIM_ADDR_*)
+    // 10.0.0.<node>:port, or 0.0.0.0:port / 127.0.0.1:port as used on `node` (kind = MADSIM_ADDR_*).  port 0 = an ephemeral
+    // Endpoint (network.rs:224-236): each bind gets the node's lowest free port for that IP; not a destination operand.
     int addr(int node, uint16_t port, uint8_t kind = MADSIM_ADDR_IP) {
-        if (port == 0) throw std::invalid_argument("port 0 (an ephemeral port) is not modelled");
         socks_.push_back(madsim_sock_t{(uint8_t)node, kind, port}); return (int)socks_.size() - 1;
     }
     Task& task(int node, bool init = false, bool before_block_on = false) {

@@ -51,6 +51,32 @@ inline void bernoulli(double p, uint64_t* p_int, uint32_t* always) {   // [DEP r
     *p_int = *always ? 0 : (uint64_t)(p * 18446744073709551616.0);
 }
 
+// The device socket table.  A caller's entry is one word, node | kind << 8 | port << 16.  An entry with port 0 is an
+// EPHEMERAL Endpoint (`Endpoint::bind("0.0.0.0:0")`): Network::bind gives it the lowest port from 1 up that no socket of
+// the node holds for the same IP (network.rs:224-236).  On the device such an entry is a HANDLE, node | (kind | 0x80) << 8
+// | base << 16 | K << 24, over K candidate entries base .. base+K-1 that this function appends for its (node, IP):
+// ordinary entries with the ports 1 .. K, where K = the number of entries of that (node, IP) — at most K-1 other sockets
+// can be bound when the handle binds, so a free candidate always exists, as it does among 65 535 ports.  Binding a
+// handle binds the candidate with the lowest free port (every other op on the handle is redirected to the candidate
+// bound last, k_state.h sock_resolve), so the socket a message comes from or goes to is always an ordinary entry with a
+// fixed address and nothing else in the kernel knows about ephemeral ports.
+inline std::vector<uint32_t> device_socks(const madsim_workload_t* w) {
+    std::vector<uint32_t> t(w->n_socks);
+    for (uint32_t i = 0; i < w->n_socks; i++) t[i] = (uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].kind << 8) | ((uint32_t)w->socks[i].port << 16);
+    for (uint32_t i = 0; i < w->n_socks; i++) {
+        if (w->socks[i].port != 0 || (t[i] & 0x8000u)) continue;
+        uint32_t K = 0;
+        for (uint32_t j = 0; j < w->n_socks; j++) K += w->socks[j].node == w->socks[i].node && w->socks[j].kind == w->socks[i].kind;
+        const uint32_t base = (uint32_t)t.size();
+        if (base + K > 255) { t.resize(256); return t; }                         // far too many: validate() rejects it
+        for (uint32_t p = 1; p <= K; p++) t.push_back((uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].kind << 8) | (p << 16));
+        for (uint32_t j = i; j < w->n_socks; j++)
+            if (w->socks[j].port == 0 && w->socks[j].node == w->socks[i].node && w->socks[j].kind == w->socks[i].kind)
+                t[j] = (uint32_t)w->socks[j].node | (((uint32_t)w->socks[j].kind | 0x80u) << 8) | (base << 16) | (K << 24);
+    }
+    return t;
+}
+
 inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std::string* err) {
     if (!w || !cfg) return fail(err, MADSIM_E_ARG, "null workload/config");
     if (!w->insns || !w->progs || w->n_progs == 0 || w->n_progs > 255 || w->n_insns == 0 || w->n_insns > 4096)   /* the table is copied into LDS, 16 B per instruction */
@@ -62,7 +88,8 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
     for (uint32_t i = 0; i < w->n_socks; i++)
         if (w->socks[i].node == 0 || w->socks[i].node > w->n_nodes) return fail(err, MADSIM_E_WORKLOAD, "bad socket node");
     for (uint32_t i = 0; i < w->n_socks; i++)
-        if (w->socks[i].kind > MADSIM_ADDR_LOOPBACK || w->socks[i].port == 0) return fail(err, MADSIM_E_WORKLOAD, "bad socket address (kind 0..2, port != 0: ephemeral ports are not modelled)");
+        if (w->socks[i].kind > MADSIM_ADDR_LOOPBACK) return fail(err, MADSIM_E_WORKLOAD, "bad socket address (kind 0..2)");
+    if (device_socks(w).size() > 63) return fail(err, MADSIM_E_WORKLOAD, "at most 63 socket addresses, counting the candidate ports of ephemeral endpoints");
     for (uint32_t i = 0; i < w->n_insns; i++) {
         const madsim_insn_t& in = w->insns[i];
         switch (in.op) {
@@ -78,10 +105,12 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
         case MS_OP_SEND: case MS_OP_CONNECT:
             if (in.a >= w->n_socks || (uint32_t)(in.b & 0xff) >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range");
             if (in.op == MS_OP_SEND && (in.b >> 8) > MADSIM_TAG_RPC_LAST) return fail(err, MADSIM_E_WORKLOAD, "tags 0xFE and 0xFF are reserved");
+            if (w->socks[in.b & 0xff].port == 0) return fail(err, MADSIM_E_WORKLOAD, "an ephemeral Endpoint (port 0) has no address a peer can name: reply to `from` or dial a named entry");
             break;
         case MS_OP_RPC_CALL:
             if (in.a >= w->n_socks || (uint32_t)(in.b & 0xff) >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range");
             if ((uint32_t)(in.b >> 8) < MADSIM_TAG_RPC_FIRST || (uint32_t)(in.b >> 8) > MADSIM_TAG_RPC_LAST) return fail(err, MADSIM_E_WORKLOAD, "rpc_call needs a typed request tag (0x80..0xFD)");
+            if (w->socks[in.b & 0xff].port == 0) return fail(err, MADSIM_E_WORKLOAD, "an ephemeral Endpoint (port 0) has no address a peer can name: reply to `from` or dial a named entry");
             break;
         case MS_OP_RPC_REPLY:
             if (in.a >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range"); break;
@@ -107,7 +136,9 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     memset(&P, 0, sizeof P);
     madsim_limits_t L{};
     if (lim) L = *lim;
-    P.n_insns = w->n_insns; P.n_progs = w->n_progs; P.n_socks = w->n_socks; P.n_nodes = w->n_nodes;
+    P.n_insns = w->n_insns; P.n_progs = w->n_progs; P.n_nodes = w->n_nodes;
+    P.n_socks = (uint32_t)device_socks(w).size();        // the caller's entries + the candidate ports of ephemeral endpoints
+    P.uses_eph = P.n_socks != w->n_socks;
     bernoulli(cfg->packet_loss_rate, &P.loss_pint, &P.loss_always);
     P.buggify = cfg->buggify != 0;
     uint32_t dummy; bernoulli(0.1, &P.bug_pint, &dummy);
@@ -150,7 +181,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // its node and to its own table entry, and the kernel skips the general resolution of network.rs:272-313
     P.uniq_addr = 1;
     for (uint32_t i = 0; i < w->n_socks; i++) {
-        if (w->socks[i].kind != MADSIM_ADDR_IP) P.uniq_addr = 0;
+        if (w->socks[i].kind != MADSIM_ADDR_IP || w->socks[i].port == 0) P.uniq_addr = 0;
         for (uint32_t j = i + 1; j < w->n_socks; j++)
             if (w->socks[i].node == w->socks[j].node && w->socks[i].port == w->socks[j].port) P.uniq_addr = 0;
     }
@@ -307,7 +338,9 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
 // into `durs` = {mode, low, range, zone} of UniformDuration::new(lo, hi) [DEP rand 0.8, SURVEY A.3].
 struct DeviceTables { std::vector<uint32_t> insns, progs, socks, nodes; std::vector<uint64_t> durs; };
 inline int build_tables(const madsim_workload_t* w, DeviceTables* T, std::string* err) {
-    T->insns.resize(4 * (size_t)w->n_insns); T->progs.resize(w->n_progs); T->socks.resize(w->n_socks ? w->n_socks : 1);
+    T->insns.resize(4 * (size_t)w->n_insns); T->progs.resize(w->n_progs);
+    T->socks = device_socks(w);
+    if (T->socks.empty()) T->socks.push_back(0);
     T->durs.assign(4, 0);
     for (uint32_t i = 0; i < w->n_insns; i++) {
         madsim_insn_t in = w->insns[i];
@@ -336,7 +369,6 @@ inline int build_tables(const madsim_workload_t* w, DeviceTables* T, std::string
         T->insns[4 * i + 3] = flags | ((j & 0x3fffu) << 4) | ((target & 0x3fffu) << 18);
     }
     for (uint32_t i = 0; i < w->n_progs; i++) T->progs[i] = (uint32_t)w->progs[i].node | ((uint32_t)w->progs[i].flags << 8) | ((uint32_t)w->progs[i].entry << 16);
-    for (uint32_t i = 0; i < w->n_socks; i++) T->socks[i] = (uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].kind << 8) | ((uint32_t)w->socks[i].port << 16);
     T->nodes.assign(w->n_nodes + 1, 0);
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
         T->nodes[i] = (uint32_t)w->nodes[i].flags | ((uint32_t)(w->nodes[i].n_match > 2 ? 2 : w->nodes[i].n_match) << 8) |

@@ -42,10 +42,20 @@ __device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_
 // the `test_link` closure of channel() (net/mod.rs:375-380): Some(now + latency) or None
 template <class K>
 __device__ __forceinline__ uint64_t chan_test_link(const Ctx& c, Lane& L, uint32_t cw, uint32_t dir) {
-    uint32_t c_ep = (cw >> 1) & 0x3f, s_ep = (cw >> 7) & 0x3f;
+    // connect1 makes channel(node, dst) and channel(dst_node, src) (net/mod.rs:356-357): `dst` is the address connect1 was
+    // GIVEN (entry d_ep — not the address of the socket that answered, which may be 0.0.0.0:port), `src` is what the
+    // listener saw: the client's IP — 127.0.0.1 if dst is a loopback address — with the client Endpoint's port.
+    const uint32_t c_ep = (cw >> 1) & 0x3f, d_ep = (cw >> 7) & 0x3f;
+    const uint32_t cw_addr = SOCKW(c, c_ep), dw_addr = SOCKW(c, d_ep), dkind = (dw_addr >> 8) & 0xff;
+    uint32_t src_node = cw_addr & 0xff, addr = dw_addr, idx = d_ep;
+    if (dir) {
+        if (!PLAIN_ADDR) src_node = dkind == MADSIM_ADDR_IP ? (dw_addr & 0xff) : src_node;   // dst_node (resolve_dest_node)
+        else src_node = dw_addr & 0xff;
+        addr = PLAIN_ADDR ? cw_addr : addr_of_from(c, c_ep | ((dkind == MADSIM_ADDR_LOOPBACK ? 1u : 0u) << 6));
+        idx = c_ep;
+    }
     uint64_t lat; int ds; uint32_t lb;
-    const uint32_t dst = dir == 0 ? s_ep : c_ep;
-    if (net_try_send<K>(c, L, SOCKW(c, dir == 0 ? c_ep : s_ep) & 0xff, SOCKW(c, dst), dst, &lat, &ds, &lb) <= 0) return ~0ull;
+    if (net_try_send<K>(c, L, src_node, addr, idx, &lat, &ds, &lb) <= 0) return ~0ull;
     return L.clock + lat;
 }
 

@@ -38,6 +38,21 @@ __device__ __forceinline__ uint32_t loss_always_at(const KParams& P, uint32_t i)
 // mailbox scanned for a twin (=> MADSIM_OVERFLOW, never a different answer).
 __device__ __forceinline__ bool may_have_twin(uint32_t flags, uint32_t gen) { return (flags & TF_RXWRAP) || gen > 0xff; }
 
+// Instruction fetch.  Workloads with ephemeral Endpoints (full-address builds only): an Endpoint operand naming a handle
+// is replaced by the candidate entry the handle's last bind took (k_state.h sock_resolve) — except MS_OP_BIND's own.
+// (Destination operands never name a handle: validate().)
+template <class K>
+__device__ __forceinline__ uint4 insn_fetch(const Ctx& c, uint32_t pc) {
+    uint4 in = INSN(c, pc);
+    if (!PLAIN_ADDR && c.P.uses_eph) {
+        const uint32_t op = in.x & 0xff;
+        const bool own = op == MS_OP_SEND || op == MS_OP_CONNECT || op == MS_OP_RPC_CALL || op == MS_OP_REPLY || op == MS_OP_RECV ||
+                         op == MS_OP_RECV_TIMEOUT || op == MS_OP_CLOSE || op == MS_OP_ACCEPT || op == MS_OP_RPC_REPLY;   // a names an Endpoint
+        if (own) in.x = (in.x & ~0xff00u) | (sock_resolve<K>(c, (in.x >> 8) & 0xff) << 8);
+    }
+    return in;
+}
+
 __device__ __forceinline__ bool is_light(uint32_t op) {
     return op == MS_OP_ASSERT_VAL || op == MS_OP_DJNZ || op == MS_OP_SET || op == MS_OP_JMP || op == MS_OP_TRACE || op == MS_OP_JEQ;
 }
@@ -98,7 +113,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     // the call future on every poll and registers ANOTHER timer each time (select_biased!, time/sleep.rs:51-53).
     // Returns true when the op completed (Ok, Err(TimedOut)) or the task panicked (st).
     auto rpc_call_poll = [&]() -> bool {
-        const uint4 ci = INSN(c, pc);
+        const uint4 ci = insn_fetch<K>(c, pc);
         const uint32_t ca = (ci.x >> 8) & 0xff, cb = ci.x >> 16, cimm = ci.y;
         const uint32_t dst = cb & 0xff;
         if (sub == 1) {
@@ -195,7 +210,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
 
     while (st == ST_RUN) {
         if (pc >= P.n_insns) { st = ST_PANIC; break; }
-        uint4 in = INSN(c, pc);
+        uint4 in = insn_fetch<K>(c, pc);
         uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
 
         PROBE(5);
@@ -262,7 +277,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         uint32_t q = SW(c, ds, base);
                         if (id >= P.max_conns || (q & 0xf) >= 4) { L.ovf = 1; }
                         else {
-                            CONNW(id, 0) = 1u | (a << 1) | ((uint32_t)ds << 7) | (0xfu << 13);
+                            CONNW(id, 0) = 1u | (a << 1) | ((b & 0xff) << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
                             TWORD(c, slot, c.P.chan_unit, 0) = id;             // client side
                             u0.w = 0;
@@ -275,15 +290,27 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 } else if (op == MS_OP_BIND) {                    // Network::bind (network.rs:206-251)
                     // a specified, non-loopback IP must be the node's own (:215-222); table entries are per node for every
                     // kind, so another node's entry is "not available" too; then the (address, protocol) key must be free (:238-246)
-                    const uint32_t sw = SOCKW(c, a);
+                    uint32_t sw = SOCKW(c, a);
                     uint32_t bind_err = 0;
                     if ((sw & 0xff) != node) bind_err = MADSIM_VAL_ADDR_NOT_AVAILABLE;
+                    else if (!PLAIN_ADDR && (sw & 0x8000u)) {
+                        // port 0: the lowest port from 1 up that no socket of the node holds for this IP (:224-236) = the
+                        // first free candidate entry of the handle; none left means the caller kept more Endpoints of this
+                        // handle alive than the table has entries for (a capacity verdict, not an error of the workload)
+                        const uint32_t base = (sw >> 16) & 0xff, nk = sw >> 24;
+                        uint32_t p = 0;
+                        while (p < nk && find_exact<K>(c, node, (sw & 0x7fffu) | ((p + 1) << 16)) >= 0) p++;
+                        if (p == nk) { L.ovf = 1; p = 0; }
+                        SW(c, a, 0) = p << 25;
+                        a = base + p;
+                    }
                     else if ((PLAIN_ADDR ? find_bound<K>(c, a) : find_exact<K>(c, node, sw)) >= 0) bind_err = MADSIM_VAL_ADDR_IN_USE;
                     if (bind_err) {
                         if (!(b & 1)) { st = ST_PANIC; break; }            // .unwrap()
                         u0.w = bind_err;
                     } else {
                         if (b & 1) u0.w = 0;
+                        if (b & 2) u0.w = SOCKW(c, a) >> 16;                // ep.local_addr().unwrap().port()
                         sock_bind<K>(c, a, slot, gen);                     // bound, gen+1, empty mailbox, owned by this task
                         u0.x |= TF_OWNER;
                         if (K::G) OMASK(a >> 5) |= 1u << (a & 31);
@@ -335,7 +362,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     pc = pf >> 18;
                 }
                 if (pc >= P.n_insns) { st = ST_PANIC; break; }
-                in = INSN(c, pc);
+                in = insn_fetch<K>(c, pc);
                 op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
             }
         }
@@ -366,7 +393,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 pc++;
             }
             if (pc >= P.n_insns) { st = ST_PANIC; break; }
-            in = INSN(c, pc);
+            in = insn_fetch<K>(c, pc);
             op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
         }
         if (st != ST_RUN) break;

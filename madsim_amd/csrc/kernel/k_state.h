@@ -191,7 +191,7 @@ template <class K> __device__ __forceinline__ WRef<K::G> plane_ref(const Ctx& c,
 // NetSim message hooks of node n (net/mod.rs:250-284): request hook valid:1 | all:1<<1 | code:8<<2 | tag:8<<10,
 //                                                      response hook valid:1<<18 | all:1<<19 | code:8<<20
 #define HOOKW(n_) plane_ref<K>(c, c.hook0, (n_))
-// connection id_: [0] alive:1 | c_ep:6<<1 | s_ep:6<<7 | tx0:1<<13 rx0<<14 tx1<<15 rx1<<16 | qn0:4<<17 | qn1:4<<21
+// connection id_: [0] alive:1 | c_ep:6<<1 | d_ep:6<<7 (the address dialled) | tx0:1<<13 rx0<<14 tx1<<15 rx1<<16 | qn0:4<<17 | qn1:4<<21
 //                 [1 + dir] parked receiver: valid:1 | slot:8<<1 | gen:16<<9;  [3 + (dir * Q + i) * 3 ..] {val, arrive lo, arrive hi}
 #define CONNW(id_, f_) plane_ref<K>(c, c.conn0, (id_) * c.P.conn_words + (f_))
 // node region: [0] killed mask, [1] paused mask, [2] gen0_killed mask, [3] spawn counter, [4 + n/4] info_gen bytes,
@@ -251,6 +251,13 @@ template <class K> __device__ __forceinline__ void tu1_store(const Ctx& c, uint3
 __device__ __forceinline__ uint4 INSN(const Ctx& c, uint32_t pc) { return LDS128(c.insn0 + pc); }
 __device__ __forceinline__ uint32_t PROGW(const Ctx& c, uint32_t p) { return SMEM[c.prog0 + p]; }
 __device__ __forceinline__ uint32_t SOCKW(const Ctx& c, uint32_t s) { return SMEM[c.sockt0 + s]; }
+// Ephemeral Endpoints (network.rs:224-236; geometry.h device_socks): a table entry with kind bit 7 is a handle over the
+// candidate entries base .. base+K-1 (ports 1 .. K of its node and IP); bits 25-31 of its header word remember which
+// candidate its last bind took.  Every op but MS_OP_BIND works on that candidate.
+template <class K> __device__ __forceinline__ uint32_t sock_resolve(const Ctx& c, uint32_t s) {
+    const uint32_t w = SOCKW(c, s);
+    return (w & 0x8000u) ? ((w >> 16) & 0xff) + (SW(c, s, 0) >> 25) : s;
+}
 __device__ __forceinline__ uint32_t NODET(const Ctx& c, uint32_t n) { return SMEM[c.nodet0 + n]; }   // flags | n_match<<8 | match0<<16 | match1<<24
 
 __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }

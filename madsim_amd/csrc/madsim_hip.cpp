@@ -167,10 +167,10 @@ int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
     int rc = madsim_geo::build_tables(w, &T, &g_err);
     if (rc) return rc;
     std::vector<uint32_t> host;
-    host.reserve(T.insns.size() + w->n_progs + w->n_socks + 2 * T.durs.size() + 1);
+    host.reserve(T.insns.size() + w->n_progs + T.socks.size() + T.nodes.size() + 2 * T.durs.size() + 1);
     host.insert(host.end(), T.insns.begin(), T.insns.end());
     host.insert(host.end(), T.progs.begin(), T.progs.begin() + w->n_progs);
-    host.insert(host.end(), T.socks.begin(), T.socks.begin() + w->n_socks);
+    host.insert(host.end(), T.socks.begin(), T.socks.end());
     host.insert(host.end(), T.nodes.begin(), T.nodes.end());
     for (uint64_t d : T.durs) { host.push_back((uint32_t)d); host.push_back((uint32_t)(d >> 32)); }
     host.push_back(w->n_insns);

@@ -45,6 +45,7 @@ struct KParams {
     uint32_t waves_per_block, wave_words;
     // per-lane plane offsets (in words)
     uint32_t off_ready, off_socks, off_handles, off_nodes, off_clog, off_pause, off_greg, off_conn, off_hooks;
+    uint32_t uses_eph;         // ephemeral Endpoint handles in the socket table (geometry.h device_socks)
     uint32_t uses_hooks;       // MS_OP_HOOK_REQ / MS_OP_HOOK_RSP present: one hook word per node
     uint32_t uses_chan, max_conns, chan_queue, conn_words;   // reliable channel (connect1/accept1) state, if used
     uint32_t chan_unit;            // index of the task unit holding the (tx, rx) pair state

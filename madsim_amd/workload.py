@@ -106,8 +106,9 @@ class TaskBuilder:
         """val = match Endpoint::bind(addr).await { Ok(_) => 0, Err(e) => VAL_ADDR_NOT_AVAILABLE / VAL_ADDR_IN_USE }"""
         return self._emit("BIND", a=addr, b=1)
 
-    def bind(self, addr):
-        return self._emit("BIND", a=addr)
+    def bind(self, addr, port_to_val=False):
+        """Endpoint::bind(addr).await.unwrap(); port_to_val: val = ep.local_addr().unwrap().port() (what an ephemeral bind got)"""
+        return self._emit("BIND", a=addr, b=2 if port_to_val else 0)
 
     def send_to(self, ep, dst, tag, val):
         return self._emit("SEND", a=ep, b=(tag << 8) | dst, imm=val)
@@ -291,10 +292,13 @@ class WorkloadBuilder:
 
     def addr(self, node, port, ip="node"):
         """A SocketAddr an Endpoint may bind or send to: 10.0.0.<node>:<port> (ip="node"), or — as used on `node` —
-        0.0.0.0:<port> (ip="unspecified") / 127.0.0.1:<port> (ip="loopback").  Resolution as in network.rs:272-313."""
+        0.0.0.0:<port> (ip="unspecified") / 127.0.0.1:<port> (ip="loopback").  Resolution as in network.rs:272-313.
+        port=0 is an ephemeral Endpoint (`Endpoint::bind("0.0.0.0:0")`): each bind takes the lowest port from 1 up that no
+        socket of the node holds for that IP (network.rs:224-236).  Such an entry cannot be a destination operand: peers
+        reply to `from`, or dial a named entry that carries the port it was given."""
         kind = {"node": A.ADDR_IP, "unspecified": A.ADDR_UNSPECIFIED, "loopback": A.ADDR_LOOPBACK}[ip]
-        if port == 0:
-            raise ValueError("port 0 (an ephemeral port) is not modelled: name the port")
+        if not 0 <= port <= 0xFFFF:
+            raise ValueError("port out of range")
         self.socks.append(A.Sock(node, kind, port))
         return len(self.socks) - 1
 

@@ -85,7 +85,8 @@ typedef struct {           /* naive_timer::Event: deadline + boxed callback     
     uint64_t deadline;
     uint8_t  kind;
     uint16_t slot, gen;    /* EV_WAKE: task instance + generation (a cloned Waker)                   */
-    uint8_t  sock, sockgen, from;      /* EV_DELIVER: captured Arc<dyn Socket>, src addr              */
+    uint8_t  sock, sockgen;            /* EV_DELIVER: captured Arc<dyn Socket>                        */
+    uint32_t from;                     /* EV_DELIVER: src addr (mk_from)                              */
     uint64_t tag;          /* EV_DELIVER tag: u64 in the reference (endpoint.rs:120)                 */
     uint32_t val;          /* EV_DELIVER payload                                                     */
     uint64_t aux;          /* typed RPC request payload: the caller's rsp_tag (rpc.rs:121-124)       */
@@ -95,7 +96,7 @@ typedef struct {           /* naive_timer::Event: deadline + boxed callback     
 } event_t;
 
 typedef struct { uint64_t tag; uint16_t slot, gen; uint8_t rxseq; } reg_t; /* (tag, oneshot::Sender) */
-typedef struct { uint64_t tag; uint8_t from; uint32_t val; uint64_t aux; } msg_t;   /* endpoint.rs:288-292 */
+typedef struct { uint64_t tag; uint32_t from; uint32_t val; uint64_t aux; } msg_t;   /* endpoint.rs:288-292 */
 
 typedef struct { uint32_t val; uint8_t has_arrive; uint64_t arrive; } cmsg_t;   /* (Payload, State) net/mod.rs:411-415 */
 typedef struct {                          /* one direction of a connection: net/mod.rs:367-405 channel()            */
@@ -105,12 +106,15 @@ typedef struct {                          /* one direction of a connection: net/
 } cdir_t;
 typedef struct {
     uint8_t alive;
-    uint8_t c_ep, s_ep;                   /* client endpoint address, listening endpoint address                    */
+    uint8_t c_node, s_node;               /* connect1's `node` and `dst_node`                                        */
+    uint8_t dst_kind, dst_ipnode, src_kind; uint16_t dst_port, src_port;   /* its `dst` and `src` SocketAddrs (addr_t fields) */
     cdir_t d[2];                          /* [0] client -> server, [1] server -> client                             */
 } conn_t;
 
 typedef struct {
     uint8_t bound; uint8_t gen;           /* gen: which Endpoint object currently owns the address   */
+    uint16_t port;                        /* the port it is (or was last) bound to: the table entry's, or — entry port 0 —
+                                             the ephemeral port Network::bind picked (network.rs:224-236)             */
     uint16_t owner_slot, owner_gen;
     VEC(reg_t) registered;                /* endpoint.rs:298-303 Mailbox                             */
     VEC(msg_t) msgs;
@@ -133,7 +137,7 @@ typedef struct {
     uint64_t deadline2;    /* the Sleep inside timeout()                                             */
     uint64_t t0;
     uint16_t cnt[2];
-    uint32_t val; uint8_t from;
+    uint32_t val; uint32_t from;
     uint64_t aux;          /* rsp_tag of the typed RPC request in hand (rpc.rs:163-165)             */
     uint64_t rsp_tag;      /* rsp_tag of the call in flight (rpc.rs:121)                            */
     uint8_t  inbox_full; uint8_t rxseq;   /* the oneshot::Receiver currently held                    */
@@ -331,13 +335,15 @@ static int link_clogged(sim_t* S, unsigned src, unsigned dst) {        /* networ
 
 /* A SocketAddr: `kind` = MADSIM_ADDR_* picks the IP (10.0.0.<node> / 0.0.0.0 / 127.0.0.1). */
 typedef struct { uint8_t kind, node; uint16_t port; } addr_t;
-static addr_t addr_of_sock(const sim_t* S, unsigned idx) {
-    addr_t a = { S->w->socks[idx].kind, S->w->socks[idx].node, S->w->socks[idx].port }; return a;
+static addr_t addr_of_sock(const sim_t* S, unsigned idx) {       /* local_addr() of the Endpoint entry idx stands for */
+    addr_t a = { S->w->socks[idx].kind, S->w->socks[idx].node, S->socks[idx].port }; return a;
 }
-/* The source address a receiver was shown, kept as  socket index | dst-was-loopback << 6  (network.rs:307-311):
- * the sender's real IP, or 127.0.0.1 when the datagram was addressed to a loopback address, with the socket's port. */
-static addr_t addr_of_from(const sim_t* S, unsigned from) {
-    addr_t a = { (uint8_t)((from & 0x40) ? MADSIM_ADDR_LOOPBACK : MADSIM_ADDR_IP), S->w->socks[from & 0x3f].node, S->w->socks[from & 0x3f].port };
+/* The source address a receiver was shown, kept as  socket index | dst-was-loopback << 6 | port << 8  (network.rs:307-311):
+ * the sender's real IP, or 127.0.0.1 when the datagram was addressed to a loopback address, with the port the sending
+ * socket had at that moment. */
+static uint32_t mk_from(const sim_t* S, unsigned idx, unsigned lb) { return idx | (lb << 6) | ((uint32_t)S->socks[idx].port << 8); }
+static addr_t addr_of_from(const sim_t* S, uint32_t from) {
+    addr_t a = { (uint8_t)((from & 0x40) ? MADSIM_ADDR_LOOPBACK : MADSIM_ADDR_IP), S->w->socks[from & 0x3f].node, (uint16_t)(from >> 8) };
     return a;
 }
 static int addr_eq(addr_t x, addr_t y) {                  /* SocketAddr equality */
@@ -349,7 +355,7 @@ static int node_has_ip(const sim_t* S, unsigned node) { return !(S->w->nodes[nod
 static int find_exact(sim_t* S, unsigned on, addr_t a) {
     for (uint32_t i = 0; i < S->w->n_socks; i++) {
         const madsim_sock_t* e = &S->w->socks[i];
-        if (S->socks[i].bound && e->node == on && e->kind == a.kind && e->port == a.port && (a.kind != MADSIM_ADDR_IP || a.node == on)) return (int)i;
+        if (S->socks[i].bound && e->node == on && e->kind == a.kind && S->socks[i].port == a.port && (a.kind != MADSIM_ADDR_IP || a.node == on)) return (int)i;
     }
     return -1;
 }
@@ -502,10 +508,11 @@ static void node_restart(sim_t* S, unsigned node) {       /* TaskHandle::restart
 /* ---- reliable channel: NetSim::connect1 / channel (net/mod.rs:337-430), Endpoint::accept1 (endpoint.rs:197-211) ---- */
 /* the `test_link` closure of channel(): try_send(..).map(|latency| now + latency) (net/mod.rs:375-380) */
 static int chan_test_link(sim_t* S, conn_t* c, int dir, uint64_t* arrive) {
-    unsigned src_node = S->w->socks[dir == 0 ? c->c_ep : c->s_ep].node;
-    unsigned dst_addr = dir == 0 ? c->s_ep : c->c_ep;
+    /* (tx1, rx1) = channel(node, dst), (tx2, rx2) = channel(dst_node, src)  (net/mod.rs:356-357) */
+    unsigned src_node = dir == 0 ? c->c_node : c->s_node;
+    addr_t to = { dir == 0 ? c->dst_kind : c->src_kind, dir == 0 ? c->dst_ipnode : c->c_node, dir == 0 ? c->dst_port : c->src_port };
     uint64_t lat; int ds; unsigned lb;
-    if (try_send(S, src_node, addr_of_sock(S, dst_addr), &lat, &ds, &lb) <= 0) return 0;
+    if (try_send(S, src_node, to, &lat, &ds, &lb) <= 0) return 0;
     *arrive = S->clock + lat;
     return 1;
 }
@@ -712,16 +719,25 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 uint32_t bind_err = 0;
                 /* network.rs:215-222: a specified, non-loopback IP must be the node's own (an IP-less node takes any);
                  * table entries are per node for every kind, so binding another node's entry is "not available" too */
+                uint16_t port = a->port;
                 if (a->node != t->node) bind_err = MADSIM_VAL_ADDR_NOT_AVAILABLE;
-                else if (find_exact(S, t->node, addr_of_sock(S, in->a)) >= 0) bind_err = MADSIM_VAL_ADDR_IN_USE;   /* :238-246 */
+                else if (port == 0) {                      /* :224-236 "resolve port if unspecified": the first free one */
+                    addr_t cand = { a->kind, a->node, 0 };
+                    for (uint32_t p = 1; p <= 65535 && port == 0; p++) { cand.port = (uint16_t)p; if (find_exact(S, t->node, cand) < 0) port = (uint16_t)p; }
+                    if (port == 0) bind_err = MADSIM_VAL_ADDR_IN_USE;      /* "no available ephemeral port" */
+                } else {
+                    addr_t want = { a->kind, a->node, port };
+                    if (find_exact(S, t->node, want) >= 0) bind_err = MADSIM_VAL_ADDR_IN_USE;   /* :238-246 */
+                }
                 if (bind_err) {
                     if (!(in->b & 1)) return 1;            /* .unwrap() */
                     t->val = bind_err; t->sub = 0; t->pc++;
                     break;
                 }
                 if (in->b & 1) t->val = 0;
+                if (in->b & 2) t->val = port;              /* ep.local_addr().unwrap().port() */
                 sock_t* k = &S->socks[in->a];
-                k->bound = 1; k->gen++; k->owner_slot = slot; k->owner_gen = t->gen;
+                k->bound = 1; k->gen++; k->owner_slot = slot; k->owner_gen = t->gen; k->port = port;
                 k->registered.n = 0; k->msgs.n = 0;        /* a fresh Endpoint + Mailbox */
                 k->acceptq.n = 0; k->acc_task = -1;
             }
@@ -740,7 +756,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 if (sent) {
                     event_t e; memset(&e, 0, sizeof e);
                     e.deadline = S->clock + lat; e.kind = EV_DELIVER; e.sock = (uint8_t)ds;
-                    e.sockgen = S->socks[ds].gen; e.from = (uint8_t)(in->a | (lb << 6)); e.tag = (uint8_t)(in->b >> 8);
+                    e.sockgen = S->socks[ds].gen; e.from = mk_from(S, in->a, lb); e.tag = (uint8_t)(in->b >> 8);
                     e.val = in->imm;
                     if (in->op == MS_OP_RPC_REPLY) {
                         e.tag = t->aux; e.val = in->imm & 0xff;
@@ -786,7 +802,8 @@ static int poll_task(sim_t* S, uint16_t slot) {
             {
                 if (t->conn >= 0) { conn_drop_handles(S, t->conn, t->side); t->conn = -1; }
                 uint64_t lat; int ds; unsigned lb;
-                const int sent = try_send(S, w->socks[in->a].node, addr_of_sock(S, in->b & 0xff), &lat, &ds, &lb);
+                const addr_t dial = addr_of_sock(S, in->b & 0xff);
+                const int sent = try_send(S, w->socks[in->a].node, dial, &lat, &ds, &lb);
                 if (sent < 0) return 1;
                 if (!sent) {
                     t->val = MADSIM_VAL_REFUSED;           /* io::ErrorKind::ConnectionRefused */
@@ -795,7 +812,9 @@ static int poll_task(sim_t* S, uint16_t slot) {
                     while (id < S->conns.n && S->conns.p[id].alive) id++;
                     if (id == S->conns.n) { conn_t z; memset(&z, 0, sizeof z); vec_push(S->conns, z); }
                     conn_t* c = &S->conns.p[id];
-                    c->alive = 1; c->c_ep = in->a; c->s_ep = (uint8_t)ds;
+                    c->alive = 1; c->c_node = w->socks[in->a].node; c->s_node = w->socks[ds].node;
+                    c->dst_kind = dial.kind; c->dst_ipnode = dial.node; c->dst_port = dial.port;
+                    c->src_kind = lb ? MADSIM_ADDR_LOOPBACK : MADSIM_ADDR_IP; c->src_port = S->socks[in->a].port;   /* src = (ip, port) :355 */
                     for (int d = 0; d < 2; d++) { c->d[d].tx_alive = c->d[d].rx_alive = 1; c->d[d].q.n = 0; c->d[d].rx_task = -1; }
                     t->conn = (int8_t)id; t->side = 0; t->val = 0;
                     sock_t* k = &S->socks[ds];             /* socket.new_connection -> conn_tx.try_send (endpoint.rs:320-328) */
@@ -946,7 +965,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 if (sent) {
                     event_t e; memset(&e, 0, sizeof e);
                     e.deadline = S->clock + lat; e.kind = EV_DELIVER; e.sock = (uint8_t)ds;
-                    e.sockgen = S->socks[ds].gen; e.from = (uint8_t)(in->a | (lb << 6)); e.tag = (uint8_t)(in->b >> 8);
+                    e.sockgen = S->socks[ds].gen; e.from = mk_from(S, in->a, lb); e.tag = (uint8_t)(in->b >> 8);
                     e.val = in->imm & 0xff; e.aux = t->rsp_tag;            /* Box::new((rsp_tag, request, data)) */
                     timer_add(S, e);
                     t = &S->tasks.p[slot];
@@ -1125,7 +1144,12 @@ static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
     if (!w || !w->insns || !w->progs || w->n_progs == 0 || w->n_progs > 255) return -1;
     if (w->n_nodes > 62 || w->n_socks > 63) return -1;
     if (w->n_socks && !w->socks) return -1;
-    for (uint32_t i = 0; i < w->n_socks; i++) if (w->socks[i].kind > MADSIM_ADDR_LOOPBACK || w->socks[i].port == 0) return -1;
+    for (uint32_t i = 0; i < w->n_socks; i++) if (w->socks[i].kind > MADSIM_ADDR_LOOPBACK) return -1;
+    for (uint32_t i = 0; i < w->n_insns; i++) {           /* an ephemeral Endpoint has no address a peer could name */
+        const madsim_insn_t* in = &w->insns[i];
+        if ((in->op == MS_OP_SEND || in->op == MS_OP_CONNECT || in->op == MS_OP_RPC_CALL) &&
+            (uint32_t)(in->b & 0xff) < w->n_socks && w->socks[in->b & 0xff].port == 0) return -1;
+    }
     if (cfg->lat_lo_ns >= cfg->lat_hi_ns) return -1;      /* "cannot sample empty range" */
     if (!(cfg->packet_loss_rate >= 0.0 && cfg->packet_loss_rate <= 1.0)) return -1;
     return 0;
@@ -1140,7 +1164,10 @@ static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, cons
     S.nodes = calloc(w->n_nodes + 1, sizeof *S.nodes);
     S.socks = calloc(w->n_socks ? w->n_socks : 1, sizeof *S.socks);
     S.clog_link = calloc(w->n_nodes + 1, sizeof *S.clog_link);
-    for (uint32_t i = 0; i < w->n_socks; i++) S.socks[i].acc_task = -1;
+    for (uint32_t i = 0; i < w->n_socks; i++) {
+        S.socks[i].acc_task = -1;
+        S.socks[i].port = w->socks[i].port;               /* 0: ephemeral, set by its bind (never a destination: validate) */
+    }
     S.trace_hash = FNV_OFFSET; S.obs_hash = FNV_OFFSET;
     S.log = log; S.log_cap = log_cap;
     S.buggify = cfg->buggify != 0;

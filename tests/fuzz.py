@@ -365,3 +365,62 @@ def random_addr_workload(rng: random.Random):
         m.join(t, expect_err=False)
     cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.2]))
     return wl.build(), cfg, "+".join(desc)
+
+
+def random_ephemeral_workload(rng: random.Random):
+    """Datagram programs whose Endpoints bind port 0 (network.rs:224-236): several tasks per node bind, drop and re-bind
+    ephemeral Endpoints on 0.0.0.0 / 127.0.0.1 / the node's IP next to named ports in the range the ephemeral ones are
+    handed out from, so which port a bind gets depends on the order the seed runs the tasks in; ports are observed
+    (local_addr), used as reply addresses while their Endpoint may already be gone, and the named entries everybody sends
+    to (an ephemeral Endpoint has no address a peer could name) carry ports an ephemeral Endpoint sometimes holds.  Every entry has one live Endpoint at a time."""
+    wl = W.WorkloadBuilder()
+    n_nodes = rng.randint(2, 3)
+    nodes = [wl.create_node(ip=rng.random() > 0.2) for _ in range(n_nodes)]
+    named, by_node = [], {n: [] for n in nodes}
+    for n in nodes:
+        for _ in range(rng.randint(1, 2)):
+            a = wl.addr(n, rng.randint(1, 3), ip=rng.choice(["node", "unspecified", "unspecified", "loopback"]))
+            named.append(a); by_node[n].append(a)
+    tasks, taken, dests, n_eph = [], set(), list(named), 0
+    plans = []
+    for n in nodes:
+        for _ in range(rng.randint(1, 2)):
+            ephs = [wl.addr(n, 0, ip=rng.choice(["unspecified", "unspecified", "loopback", "node"])) for _ in range(rng.randint(1, 2))]
+            n_eph += len(ephs)
+            plans.append((n, ephs))
+    for n, ephs in plans:
+        t = wl.task(n)
+        free_named = [a for a in by_node[n] if a not in taken]
+        own = None
+        if free_named and rng.random() < 0.6:
+            own = rng.choice(free_named); taken.add(own)
+            t.try_bind(own); t.trace_val()                               # may be AddrInUse: an ephemeral bind got there first
+        t.sleep(ms=rng.randint(0, 6))
+        t.set(0, rng.randint(2, 4))
+        top = t.label()
+        for e in ephs:
+            t.bind(e, port_to_val=True); t.trace_val()
+        ep = rng.choice(ephs)
+        t.send_to(ep, rng.choice(dests), 1, rng.randrange(1000))
+        rx = rng.choice(ephs)
+        t.recv_from_timeout(rx, 1, ms=rng.choice([4, 15, 30]))
+        t.trace_val()
+        skip = t.label() + 2
+        t.jeq(A.VAL_TIMEOUT, skip)
+        t.reply(rx, 1, rng.randrange(1000))
+        assert t.label() == skip
+        for e in ephs:
+            t.close(e)
+        if rng.random() < 0.5:
+            t.sleep_rand(lo_ms=0, ms=rng.randint(1, 5))
+        t.djnz(0, top)
+        t.done()
+        tasks.append(t)
+    m = wl.main()
+    for t in tasks:
+        m.spawn(t)
+    for t in tasks:
+        m.join(t, expect_err=False)
+    cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.2]))
+    return wl.build(), cfg, f"{n_nodes}n/{len(named)}a/{n_eph}e"
+

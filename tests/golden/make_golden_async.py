@@ -62,6 +62,8 @@ class Sim:
         # SocketAddr of table entry i, and the network's view of the nodes (network.rs:19-37)
         self.addr = [({0: "10.0.0.%d" % w.socks[i].node, 1: "0.0.0.0", 2: "127.0.0.1"}[w.socks[i].kind], w.socks[i].port)
                      for i in range(w.struct.n_socks)]
+        # port 0 = an ephemeral Endpoint: its address is whatever its last bind was given (never a destination operand)
+        self.ephemeral = [w.socks[i].port == 0 for i in range(w.struct.n_socks)]
         n_nodes = w.struct.n_nodes
         self.node_ip = {n: (None if w.nodes[n].flags & A.NODE_NO_IP else "10.0.0.%d" % n) for n in range(1, n_nodes + 1)}
         self.addr_to_node = {ip: n for n, ip in self.node_ip.items() if ip is not None}
@@ -72,6 +74,7 @@ class Sim:
         self.heap, self.ready, self.handles, self.bound = [], [], {}, {}
         self.steps, self.msg_count, self.obs, self.flags = 0, 0, FNV_OFFSET, [0, 0, 0, 0]
         self.clog_in, self.clog_out = set(), set()
+        self.obs_list = []                                                 # what obs folds, in order (debugging aid)
         self.loss = cfg.packet_loss_rate
         self.lat = duration_params(cfg.lat_lo_ns, cfg.lat_hi_ns)
         self.base_ns = 0
@@ -184,7 +187,7 @@ class Sim:
         yield from self.sleep_until(t, self.sleep_deadline(self.clock + delay))
 
     def close_sock(self, a):                        # Network::close (network.rs:253-258)
-        self.node_sockets[self.socks[a][0]].pop(self.addr[a], None)
+        self.node_sockets[self.socks[a][0]].pop(self.bound[a]["addr"], None)
         self.bound[a] = None
 
     def resolve_dest_node(self, node, dst):         # network.rs:272-290
@@ -335,9 +338,11 @@ class Sim:
                     nxt = b
             elif name == "TRACE":
                 v = imm + (t.cnt[a & 1] if b & 1 else 0)
+                self.obs_list.append(v)
                 self.obs = ((self.obs ^ v) * FNV_PRIME) & M64
             elif name == "TRACE_TIME":
                 v = self.base_ns + self.clock if a == 0 else self.clock if a == 1 else t.val
+                self.obs_list.append(v)
                 self.obs = ((self.obs ^ v) * FNV_PRIME) & M64
             elif name == "SLEEP":
                 yield from self.sleep_until(t, self.sleep_deadline(self.clock + dur))
@@ -361,6 +366,10 @@ class Sim:
                     err = A.VAL_ADDR_NOT_AVAILABLE
                 elif ip not in ("0.0.0.0", "127.0.0.1") and self.node_ip[t.node] is not None and ip != self.node_ip[t.node]:
                     err = A.VAL_ADDR_NOT_AVAILABLE
+                elif self.ephemeral[a]:             # "resolve port if unspecified" (:224-236)
+                    port = next((p for p in range(1, 65536) if (ip, p) not in self.node_sockets[t.node]), None)
+                    if port is None:
+                        err = A.VAL_ADDR_IN_USE
                 elif (ip, port) in self.node_sockets[t.node]:
                     err = A.VAL_ADDR_IN_USE
                 if err:
@@ -368,11 +377,14 @@ class Sim:
                         raise Panic()               # .unwrap()
                     t.val = err
                 else:
-                    mbox = dict(owner=t, regs=[], msgs=[])
+                    mbox = dict(owner=t, regs=[], msgs=[], addr=(ip, port))
                     self.node_sockets[t.node][(ip, port)] = mbox
                     self.bound[a] = mbox; t.owned.append(a)
+                    self.addr[a] = (ip, port)       # ep.local_addr()
                     if b & 1:
                         t.val = 0
+                    if b & 2:
+                        t.val = port
             elif name == "CLOSE":
                 if self.bound.get(a) is not None and self.bound[a]["owner"] is t:
                     self.close_sock(a)
@@ -508,6 +520,10 @@ def workloads():
     from tests import fuzz
     for k in range(24):                             # random programs over mixed address kinds / IP-less nodes
         out["addr_fuzz_%02d" % k] = fuzz.random_addr_workload(random.Random(880000 + k))[0]
+    for name in ("endpoint_bind_ephemeral", "ephemeral_clients"):     # port 0 (network.rs:224-236), literally
+        out[name] = LW.ALL[name]()
+    for k in range(16):
+        out["ephemeral_fuzz_%02d" % k] = fuzz.random_ephemeral_workload(random.Random(870000 + k))[0]
     for k in range(12):                             # random typed-RPC programs with hooks — those without node lifecycle
         w, _, _ = fuzz.random_rpc_workload(random.Random(890000 + k), hooks=True)
         ops = {OPN[w.insns[i].op] for i in range(w.struct.n_insns)}

@@ -459,6 +459,94 @@ ALL.update(endpoint_localhost=endpoint_localhost, endpoint_bind=endpoint_bind, n
 EXPECT_PANIC.add("net_ipless_node_own_socket_panics")
 
 
+def endpoint_bind_ephemeral():
+    """net/endpoint.rs:470-513 `bind`, literally (v4 cases): 0.0.0.0:0 and 127.0.0.1:0 get a non-zero port — port 1 each,
+    they are different IPs —, 10.0.0.2:0 on node 1 is AddrNotAvailable, the node's own 10.0.0.1:100 binds, is dropped and
+    binds again.  Then network.rs:224-236 in detail: a second 0.0.0.0:0 gets port 2, 0.0.0.0:3 named explicitly makes the
+    third one skip to 4, and a dropped Endpoint's port is the next one handed out."""
+    wl = W.WorkloadBuilder()
+    n, other = wl.create_node(), wl.create_node()
+    any_a, any_b, any_c = (wl.addr(n, 0, ip="unspecified") for _ in range(3))
+    lo_a, foreign, ip100, any3 = wl.addr(n, 0, ip="loopback"), wl.addr(other, 0), wl.addr(n, 100), wl.addr(n, 3, ip="unspecified")
+    t = wl.task(n)
+    t.bind(any_a, port_to_val=True); t.assert_val(1)
+    t.bind(lo_a, port_to_val=True); t.assert_val(1)
+    t.try_bind(foreign); t.assert_val(A.VAL_ADDR_NOT_AVAILABLE)
+    t.bind(ip100, port_to_val=True); t.assert_val(100); t.close(ip100); t.bind(ip100)
+    t.bind(any_b, port_to_val=True); t.assert_val(2)
+    t.bind(any3); t.bind(any_c, port_to_val=True); t.assert_val(4)
+    t.close(any_a); t.close(any_c)
+    t.bind(any_c, port_to_val=True); t.assert_val(1)            # the lowest free port again
+    t.bind(any_a, port_to_val=True); t.assert_val(4)
+    t.done()
+    m = wl.main(); m.spawn(t); m.join(t)
+    return wl.build()
+
+
+def ephemeral_clients():
+    """The usual client shape: `Endpoint::bind("0.0.0.0:0")`, send to the server's address, wait for the reply the server
+    sends to `from` = 10.0.0.<client>:<ephemeral port> — found through the 0.0.0.0:<port> fallback of the socket lookup
+    (network.rs:304-306).  Two clients share node 2 (ports 1 and 2 in the order their binds complete, which the seed
+    decides); each drops its Endpoint and binds again between requests, so ports are handed back and re-issued while
+    replies to the old address are still in flight (those find nobody, or the other client's new Endpoint)."""
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv = wl.addr(ns, 700, ip="unspecified")
+    asv_ip = wl.addr(ns, 700)                                         # what the clients dial: 10.0.0.1:700
+    srv = wl.task(ns); srv.bind(asv)
+    top = srv.label(); srv.recv_from(asv, 1); srv.trace_val(); srv.sleep_rand(lo_ms=0, ms=12); srv.reply(asv, 2, 0x50); srv.jmp(top)
+    clients = []
+    for i in range(2):
+        ep = wl.addr(nc, 0, ip="unspecified")
+        c = wl.task(nc); c.set(0, 4)
+        top = c.label()
+        c.bind(ep, port_to_val=True); c.trace_val()
+        c.send_to(ep, asv_ip, 1, 0x10 + i); c.recv_from_timeout(ep, 2, ms=25); c.trace_val()
+        c.close(ep); c.sleep_rand(lo_ms=0, ms=4); c.djnz(0, top); c.done()
+        clients.append(c)
+    m = wl.main(); m.spawn(srv)
+    for c in clients:
+        m.spawn(c)
+    for c in clients:
+        m.join(c)
+    return wl.build()
+
+
+def channel_wildcard_listener():
+    """connect1 over general addresses (net/mod.rs:337-364): the server listens on 0.0.0.0:2379, the client binds
+    0.0.0.0:0 and dials 10.0.0.1:2379.  channel(node, dst) keeps testing the link towards the DIALLED address and
+    channel(dst_node, src) towards src = (client IP, client port) — both reach their sockets through the 0.0.0.0 fallback —
+    so payloads flow in both directions; after the listener is dropped the client's next payload is stamped None and the
+    receiver side backs off for good (the server task is gone: RESET on the client's recv)."""
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, dial, acl = wl.addr(ns, 2379, ip="unspecified"), wl.addr(ns, 2379), wl.addr(nc, 0, ip="unspecified")
+    srv = wl.task(ns); srv.bind(asv); srv.accept1(asv); srv.set(0, 3)
+    top = srv.label(); srv.chan_recv(); srv.trace_val(); srv.chan_send(0x22); srv.djnz(0, top); srv.done()
+    cl = wl.task(nc); cl.bind(acl); cl.sleep(ms=10); cl.connect1(acl, dial); cl.assert_val(0); cl.set(0, 3)
+    top = cl.label(); cl.chan_send(0x11); cl.chan_recv(); cl.assert_val(0x22); cl.djnz(0, top)
+    cl.chan_recv(); cl.assert_val(A.VAL_RESET); cl.done()
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.join(cl)
+    return wl.build()
+
+
+def channel_loopback():
+    """connect1 to 127.0.0.1:<port> on the client's own node: src is 127.0.0.1:<client port> (net/mod.rs:355,
+    network.rs:307-311), so the server-to-client channel tests the link to a loopback address; the client Endpoint is bound
+    to 0.0.0.0:0 and is found through the fallback."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    asv, dial, acl = wl.addr(n, 9, ip="unspecified"), wl.addr(n, 9, ip="loopback"), wl.addr(n, 0, ip="unspecified")
+    srv = wl.task(n); srv.bind(asv); srv.accept1(asv); srv.chan_recv(); srv.assert_val(5); srv.chan_send(6); srv.sleep(ms=50); srv.done()
+    cl = wl.task(n); cl.sleep(ms=5); cl.bind(acl); cl.connect1(acl, dial); cl.assert_val(0); cl.chan_send(5); cl.chan_recv(); cl.assert_val(6); cl.done()
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.join(cl); m.join(srv)
+    return wl.build()
+
+
+ALL.update(endpoint_bind_ephemeral=endpoint_bind_ephemeral, ephemeral_clients=ephemeral_clients,
+           channel_wildcard_listener=channel_wildcard_listener, channel_loopback=channel_loopback)
+
+
 def std_system_time():
     """time/system_time.rs:122-154: `t0 = SystemTime::now(); sleep(1 s); assert!(t0.elapsed() >= 1 s); t0` — the observed
     wall-clock time depends on the seed (base time drawn around 2022), the Instant-based duration does not."""

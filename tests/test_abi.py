@@ -58,6 +58,38 @@ def test_geometry_and_validation_need_no_gpu():
         runtime.geometry(bad.build())
 
 
+def test_ephemeral_endpoints_validation():
+    """port 0 = an ephemeral Endpoint (network.rs:224-236): accepted, picks the full-address build, counts its candidate
+    ports against the 63-entry table, and cannot be named as a destination — by the library and by the oracle alike."""
+    import oracle
+    wl = workload.WorkloadBuilder()
+    n = wl.create_node(); eph, named = wl.addr(n, 0, ip="unspecified"), wl.addr(n, 7)
+    t = wl.task(n); t.bind(eph, port_to_val=True); t.assert_val(1); t.send_to(eph, named, 1, 5); t.done()
+    m = wl.main(); m.spawn(t); m.join(t)
+    g = runtime.geometry(wl.build())
+    assert "ALL" in runtime.variant_name(g) or (g.variant >> 8) & 0x1f == 31
+    bad = workload.WorkloadBuilder()
+    n = bad.create_node(); eph, named = bad.addr(n, 0), bad.addr(n, 7)
+    t = bad.task(n); t.bind(named); t.send_to(named, eph, 1, 5); t.done()
+    bad.main().spawn(t)
+    with pytest.raises(runtime.MadsimHipError, match="ephemeral"):
+        runtime.geometry(bad.build())
+    with pytest.raises(RuntimeError):
+        oracle.run_batch(bad.build(), 0, 1)
+    many = workload.WorkloadBuilder()
+    n = many.create_node()
+    ephs = [many.addr(n, 0, ip="unspecified") for _ in range(8)]      # 8 handles + 8 candidate ports each group = 16: fine
+    t = many.task(n)
+    for e in ephs:
+        t.bind(e)
+    t.done(); many.main().spawn(t)
+    runtime.geometry(many.build())
+    for _ in range(24):                                                 # 32 handles + 32 candidates > 63
+        many.addr(n, 0, ip="unspecified")
+    with pytest.raises(runtime.MadsimHipError, match="63 socket addresses"):
+        runtime.geometry(many.build())
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():

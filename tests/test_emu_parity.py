@@ -154,6 +154,24 @@ def test_fuzz_address_resolution():
     assert A.PASS in verdicts and A.PANIC in verdicts
 
 
+def test_fuzz_ephemeral_ports():
+    """200 random programs binding port 0 (network.rs:224-236): the oracle hands out ports literally (lowest free port of
+    the node for that IP, the sender's port captured in `from`), the kernel binds the first free candidate entry of the
+    handle (geometry.h device_socks) — they have to agree on every port observed and on everything downstream."""
+    n_overflow = 0
+    for k in range(200):
+        w, cfg, desc = fuzz.random_ephemeral_workload(random.Random(74000 + k))
+        lim = fuzz.generous_limits()
+        if k % 2:
+            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        o, _ = oracle.run_batch(w, k * 7, 12, cfg, lim)
+        e = emu.run_batch(w, k * 7, 12, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+        n_overflow += int((e["verdict"] == A.OVERFLOW).sum())
+    assert n_overflow == 0                          # one live Endpoint per entry: a candidate is always free
+
+
 def test_fuzz_rpc_hooks_and_panic_codes():
     """Random typed-RPC programs with NetSim request / response hooks installed and replaced at random moments."""
     for k in range(150):

@@ -565,6 +565,20 @@ def test_fuzz_address_resolution_gpu(hip):
         assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
 
 
+def test_fuzz_ephemeral_ports_gpu(hip):
+    """Random programs binding port 0 (network.rs:224-236): literal port hand-out in the oracle, candidate entries on the GPU."""
+    import random
+    from tests import fuzz
+    for k in range(150):
+        w, cfg, desc = fuzz.random_ephemeral_workload(random.Random(77000 + k))
+        lim = fuzz.generous_limits()
+        if k % 2:
+            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        got, _ = hip.run_batch(w, k * 31, 96, cfg, lim)
+        want, _ = oracle.run_batch(w, k * 31, 96, cfg, lim)
+        assert (got == want).all(), (k, desc, got[got != want][0], want[got != want][0])
+
+
 def test_fuzz_rpc_hooks_gpu(hip):
     """Random typed-RPC programs with NetSim::hook_rpc_req / hook_rpc_rsp (net/mod.rs:240-284), LDS and global state."""
     import random
