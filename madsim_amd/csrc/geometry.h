@@ -56,7 +56,9 @@ inline void bernoulli(double p, uint64_t* p_int, uint32_t* always) {   // [DEP r
 // the node holds for the same IP (network.rs:224-236).  On the device such an entry is a HANDLE, node | (kind | 0x80) << 8
 // | base << 16 | K << 24, over K candidate entries base .. base+K-1 that this function appends for its (node, IP):
 // ordinary entries with the ports 1 .. K, where K = the number of entries of that (node, IP) — at most K-1 other sockets
-// can be bound when the handle binds, so a free candidate always exists, as it does among 65 535 ports.  Binding a
+// can be bound when the handle binds, so a free candidate always exists, as it does among 65 535 ports — and twice that in
+// workloads with connections: an address outlives its Endpoint while a Sender / Receiver made from it is alive
+// (k_channel.h guard_release), so each entry may have one such predecessor still in the table.  Binding a
 // handle binds the candidate with the lowest free port (every other op on the handle is redirected to the candidate
 // bound last, k_state.h sock_resolve), so the socket a message comes from or goes to is always an ordinary entry with a
 // fixed address and nothing else in the kernel knows about ephemeral ports.
@@ -67,6 +69,7 @@ inline std::vector<uint32_t> device_socks(const madsim_workload_t* w) {
         if (w->socks[i].port != 0 || (t[i] & 0x8000u)) continue;
         uint32_t K = 0;
         for (uint32_t j = 0; j < w->n_socks; j++) K += w->socks[j].node == w->socks[i].node && w->socks[j].kind == w->socks[i].kind;
+        if (uses_op(w, MS_OP_CONNECT)) K *= 2;
         const uint32_t base = (uint32_t)t.size();
         if (base + K > 255) { t.resize(256); return t; }                         // far too many: validate() rejects it
         for (uint32_t p = 1; p <= K; p++) t.push_back((uint32_t)w->socks[i].node | ((uint32_t)w->socks[i].kind << 8) | (p << 16));

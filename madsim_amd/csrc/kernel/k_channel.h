@@ -39,7 +39,8 @@ __device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_
     return 1;
 }
 
-// the `test_link` closure of channel() (net/mod.rs:375-380): Some(now + latency) or None
+// the `test_link` closure of channel() (net/mod.rs:375-380): Some(now + latency), None (~0) or a panic of the caller
+constexpr uint64_t CHAN_LINK_PANIC = ~0ull - 1;
 template <class K>
 __device__ __forceinline__ uint64_t chan_test_link(const Ctx& c, Lane& L, uint32_t cw, uint32_t dir) {
     // connect1 makes channel(node, dst) and channel(dst_node, src) (net/mod.rs:356-357): `dst` is the address connect1 was
@@ -55,13 +56,15 @@ __device__ __forceinline__ uint64_t chan_test_link(const Ctx& c, Lane& L, uint32
         idx = c_ep;
     }
     uint64_t lat; int ds; uint32_t lb;
-    if (net_try_send<K>(c, L, src_node, addr, idx, &lat, &ds, &lb) <= 0) return ~0ull;
+    const int sent = net_try_send<K>(c, L, src_node, addr, idx, &lat, &ds, &lb);
+    if (sent < 0) return CHAN_LINK_PANIC;                   // `.ip.unwrap()` inside try_send (network.rs:309)
+    if (sent == 0) return ~0ull;
     return L.clock + lat;
 }
 
-// drop the (Sender, Receiver) pair of one end of connection `id`
+// drop the raw (PayloadSender, PayloadReceiver) pair of one end of connection `id`
 template <class K>
-__device__ __forceinline__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side) {
+__device__ __forceinline__ void conn_drop_raw(const Ctx& c, Lane& L, uint32_t id, uint32_t side) {
     uint32_t cw = CONNW(id, 0);
     if (cw & (1u << (13 + 2 * side))) {                       // my PayloadSender: last mpsc sender gone
         cw &= ~(1u << (13 + 2 * side));
@@ -71,17 +74,64 @@ __device__ __forceinline__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_
     cw &= ~(1u << (14 + 2 * (1 - side)));                     // my PayloadReceiver
     CONNW(id, 1 + (1 - side)) = 0;
     if (!(cw & (0xfu << 13))) cw = 0;                          // all four handles gone: slot is free
+    if (side) cw &= ~(0x7fu << 25);                            // (the listener-side guard reference goes with the handles)
     CONNW(id, 0) = cw;
 }
 
-// the listening Endpoint is dropped: connections still queued in conn_rx go with it
+// the EndpointSocket is freed: the connections still queued in conn_tx go with it (nobody accepted them, so their
+// server-side handles are the raw pair: no BindGuard clones)
 template <class K>
 __device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s) {
     uint32_t base = 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs;
     uint32_t q = SW(c, s, base);
     SW(c, s, base) = 0; SW(c, s, base + 1) = 0;
     uint32_t n = q & 0xf;
-    for (uint32_t i = 0; i < n; i++) conn_drop_handles<K>(c, L, (q >> (4 + 7 * i)) & 0x7f, 1);
+    for (uint32_t i = 0; i < n; i++) conn_drop_raw<K>(c, L, (q >> (4 + 7 * i)) & 0x7f, 1);
+}
+
+// Every Sender / Receiver holds a clone of its Endpoint's Arc<BindGuard> (endpoint.rs:181-190,203-210), so an address stays
+// in the node's socket table until the Endpoint AND every connection end made from it are gone.  Socket header bits 25-31
+// count the live (Sender, Receiver) pairs of a socket; an Endpoint dropped while that count is non-zero leaves the marker
+// ~0 in the owner word instead of unbinding.  BindGuard::drop runs with the last owner and does nothing when the binder's
+// NodeInfo is killed (net/mod.rs:483-493): reset_node has emptied the table — and the counts — by then.
+template <class K>
+__device__ __forceinline__ void guard_release(const Ctx& c, Lane& L, uint32_t s, bool node_killed) {
+    if (node_killed) return;
+    uint32_t h = SW(c, s, 0);
+    if (!(h >> 25)) return;
+    h -= 1u << 25;
+    if (!(h >> 25) && (h & 1) && SW(c, s, 1) == ~0u) {       // the last owner: Network::close, and the socket dies
+        SW(c, s, 0) = h & ~1u;
+        if (SW(c, s, 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs) & 0xf) sock_drop_acceptq<K>(c, L, s);
+    } else {
+        SW(c, s, 0) = h;
+    }
+}
+
+// drop(tx); drop(rx) of one end of connection `id`, by a task whose NodeInfo is killed or not
+template <class K>
+__device__ __forceinline__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side, bool node_killed) {
+    const uint32_t cw = CONNW(id, 0);
+    const bool held = side ? (cw >> 31) != 0 : (cw & (1u << 13)) != 0;       // accepted / the client's handles exist
+    const uint32_t gs = side ? (cw >> 25) & 0x3f : (cw >> 1) & 0x3f;
+    conn_drop_raw<K>(c, L, id, side);
+    if (held) guard_release<K>(c, L, gs, node_killed);
+}
+
+// drop(Endpoint) of socket s by its owner: conn_rx goes (later connections are dropped on arrival, endpoint.rs:320-328) and
+// the Arc<BindGuard> loses one owner
+template <class K>
+__device__ __forceinline__ void endpoint_drop(const Ctx& c, Lane& L, uint32_t s, bool node_killed) {
+    const uint32_t h = SW(c, s, 0);
+    const bool chan = K::FC && c.P.uses_chan;
+    const uint32_t base = 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs;
+    if (chan) SW(c, s, base + 1) = 0;                          // the parked acceptor was the owner
+    bool bound = h & 1;
+    // BindGuard::drop -> Network::close, unless connections hold clones of the guard or the binder's NodeInfo is killed
+    // (after Handle::kill reset_node has emptied the table already; after an init task's exit the address just stays)
+    if (bound && !node_killed && !(chan && (h >> 25))) { SW(c, s, 0) = h & ~1u; bound = false; }
+    if (bound) { if (K::LIFE) SW(c, s, 1) = ~0u; }             // the table keeps the EndpointSocket (and its queue) alive
+    else if (chan && (SW(c, s, base) & 0xf)) sock_drop_acceptq<K>(c, L, s);
 }
 
 }  // namespace madsim_k

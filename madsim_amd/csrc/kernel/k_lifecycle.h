@@ -43,7 +43,8 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
     return slot;
 }
 
-template <class K> __device__ __forceinline__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side);
+template <class K> __device__ __forceinline__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side, bool node_killed);
+template <class K> __device__ __forceinline__ void endpoint_drop(const Ctx& c, Lane& L, uint32_t s, bool node_killed);
 template <class K> __device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s);
 
 // The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
@@ -53,17 +54,15 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
     uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
     if (K::FC && c.P.uses_chan) {                          // the task's (Sender, Receiver) pair drops with its future
         uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
-        if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
+        if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (f & TF_KILLED) != 0); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
     }
-    if (f & TF_OWNER) {                                        // BindGuards this task holds drop with its future
+    if (f & TF_OWNER) {                                        // the Endpoints this task holds drop with its future
         for (uint32_t i = 0; i < c.P.n_socks; i++) {
             if (K::G && !((OMASK(i >> 5) >> (i & 31)) & 1)) continue;      // never bound by a task that is still around
             const uint32_t hdr = SW(c, i, 0);
             if (!sock_owned_by<K>(c, i, hdr, slot, gen)) continue;
             if (K::G) OMASK(i >> 5) &= ~(1u << (i & 31));
-            // BindGuard::drop (net/mod.rs:483-493), skipped when the binder's NodeInfo is killed
-            if (!(f & TF_KILLED) && (hdr & 1)) SW(c, i, 0) = hdr & ~1u;
-            if (K::FC && c.P.uses_chan && (SW(c, i, 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, i);
+            endpoint_drop<K>(c, L, i, (f & TF_KILLED) != 0);
         }
     }
     uint32_t h = HW(prog);
@@ -122,7 +121,11 @@ __device__ __forceinline__ void node_kill(const Ctx& c, Lane& L, uint32_t node) 
     if (g == 0) NODEW(2) |= 1u << node;
     info_kill<K>(c, L, node, g);
     for (uint32_t i = 0; i < c.P.n_socks; i++)               // NetSim::reset_node (network.rs:142-147)
-        if ((SOCKW(c, i) & 0xff) == node) SW(c, i, 0) &= ~1u;
+        if ((SOCKW(c, i) & 0xff) == node) {
+            SW(c, i, 0) &= ~(1u | (0x7fu << 25));              // (and nobody's guard matters any more)
+            // a socket whose Endpoint is already gone dies with its table entry: so do the connections queued there
+            if (K::FC && c.P.uses_chan && SW(c, i, 1) == ~0u && (SW(c, i, 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, i);
+        }
 }
 
 template <class K>

@@ -68,6 +68,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     }
     uint32_t h = SW(c, s, 0);
     if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;     // that Endpoint object is gone
+    if (K::FC && c.P.uses_chan && SW(c, s, 1) == ~0u) return;     // ... only its connections still hold the address
     uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
     // Typed RPC (net/rpc.rs): a response (tag 0xff) is addressed to one pending receive — the word of its registration,
     // tag | slot | rxseq | gen, rides in the payload's upper 24 bits — where the reference matches a random u64 tag.

@@ -192,8 +192,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         uint32_t id = (q >> 4) & 0x7f;
         SW(c, a, base) = (n - 1) | ((q >> 11) << 4);           // pop front
         uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
-        if ((cx & 0xff) != 0xff) conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1);
+        if ((cx & 0xff) != 0xff) conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0);
         TWORD(c, slot, c.P.chan_unit, 0) = id | (1u << 8);                 // server side
+        // Sender { _guard: self.guard.clone(), tx }, Receiver { _guard: self.guard.clone(), rx } (endpoint.rs:203-210)
+        CONNW(id, 0) = (CONNW(id, 0) & ~(0x7fu << 25)) | (a << 25) | (1u << 31);
+        SW(c, a, 0) += 1u << 25;
         return true;
     };
     // the receiver stream of channel() (net/mod.rs:386-400) from "a payload is in hand" (sub 1): either sleep(backoff)
@@ -256,6 +259,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         uint32_t bo = (u3.x >> 16) * 2; if (bo > 10000) bo = 10000;
                         uint32_t cw = CONNW(u3.x & 0xff, 0);
                         uint64_t arrive = chan_test_link<K>(c, L, cw, 1 - ((u3.x >> 8) & 1));
+                        if (arrive == CHAN_LINK_PANIC) { st = ST_PANIC; break; }
                         u3.x = (u3.x & 0xffff) | (bo << 16); u3.z = (uint32_t)arrive; u3.w = (uint32_t)(arrive >> 32);
                         TU(c, slot, c.P.chan_unit) = u3;
                         crecv_arm();
@@ -264,7 +268,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     u0.w = u3.y;                           // sub 3: sleep_until(arrive_time) done -> yield value
                 } else if (K::FC && op == MS_OP_CONNECT) {   // NetSim::connect1 (net/mod.rs:345-363)
                     uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
-                    if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
+                    if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
                     uint64_t lat; int ds; uint32_t lb;
                     const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, SOCKW(c, b & 0xff), b & 0xff, &lat, &ds, &lb);
                     if (sent < 0) { st = ST_PANIC; break; }
@@ -280,11 +284,16 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                             CONNW(id, 0) = 1u | (a << 1) | ((b & 0xff) << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
                             TWORD(c, slot, c.P.chan_unit, 0) = id;             // client side
+                            SW(c, a, 0) += 1u << 25;               // Sender / Receiver { _guard: self.guard.clone(), .. } (endpoint.rs:181-190)
                             u0.w = 0;
-                            uint32_t n = q & 0xf;                  // socket.new_connection -> conn_tx.try_send
-                            SW(c, ds, base) = (q & ~0xfu) | (n + 1) | (id << (4 + 7 * n));
-                            uint32_t acc = SW(c, ds, base + 1);
-                            if (acc & 1) { SW(c, ds, base + 1) = 0; wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9); }
+                            if (SW(c, ds, 1) == ~0u) {             // the listener's Endpoint is gone (connections it accepted hold the
+                                conn_drop_raw<K>(c, L, id, 1);     // address): `let _ = conn_tx.try_send(..)` drops (tx2, rx1) here
+                            } else {
+                                uint32_t n = q & 0xf;              // socket.new_connection -> conn_tx.try_send
+                                SW(c, ds, base) = (q & ~0xfu) | (n + 1) | (id << (4 + 7 * n));
+                                uint32_t acc = SW(c, ds, base + 1);
+                                if (acc & 1) { SW(c, ds, base + 1) = 0; wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9); }
+                            }
                         }
                     }
                 } else if (op == MS_OP_BIND) {                    // Network::bind (network.rs:206-251)
@@ -628,6 +637,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 uint32_t id = cx & 0xff, side = (cx >> 8) & 1;
                 uint32_t cw = CONNW(id, 0);
                 uint64_t arrive = chan_test_link<K>(c, L, cw, side);          // draws happen before the closed check
+                if (arrive == CHAN_LINK_PANIC) { st = ST_PANIC; break; }
                 if (!(cw & (1u << (14 + 2 * side)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // ConnectionReset
                 uint32_t qn = (cw >> (17 + 4 * side)) & 0xf;
                 if (qn >= P.chan_queue) { L.ovf = 1; pc++; break; }
@@ -664,7 +674,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_CCLOSE: {
                 if (!K::FC) { st = ST_PANIC; break; }
                 uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
-                if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
+                if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
                 pc++;
                 break;
             }
@@ -698,8 +708,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             case MS_OP_CLOSE: {
                 uint32_t h = SW(c, a, 0);
-                if ((h & 1) && sock_owned_by<K>(c, a, h, slot, gen) && !(u0.x & TF_KILLED)) SW(c, a, 0) = h & ~1u;
-                if (K::FC && P.uses_chan && SW(c, a, 1) == (slot | (gen << 16)) && (SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) & 0xf)) sock_drop_acceptq<K>(c, L, a);
+                if (K::LIFE) {
+                    if (sock_owned_by<K>(c, a, h, slot, gen)) endpoint_drop<K>(c, L, a, (u0.x & TF_KILLED) != 0);
+                } else if ((h & 1) && sock_owned_by<K>(c, a, h, slot, gen)) SW(c, a, 0) = h & ~1u;
                 pc++;
                 break;
             }

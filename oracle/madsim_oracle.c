@@ -107,6 +107,9 @@ typedef struct {                          /* one direction of a connection: net/
 typedef struct {
     uint8_t alive;
     uint8_t c_node, s_node;               /* connect1's `node` and `dst_node`                                        */
+    int16_t guard_sock[2];                /* the Endpoint whose Arc<BindGuard> this end's Sender + Receiver hold clones of
+                                             (endpoint.rs:181-190,203-210): [0] the client's, from connect1 on; [1] the
+                                             listener's, from accept1 on; -1 = none (a connection nobody accepted yet)  */
     uint8_t dst_kind, dst_ipnode, src_kind; uint16_t dst_port, src_port;   /* its `dst` and `src` SocketAddrs (addr_t fields) */
     cdir_t d[2];                          /* [0] client -> server, [1] server -> client                             */
 } conn_t;
@@ -116,6 +119,9 @@ typedef struct {
     uint16_t port;                        /* the port it is (or was last) bound to: the table entry's, or — entry port 0 —
                                              the ephemeral port Network::bind picked (network.rs:224-236)             */
     uint16_t owner_slot, owner_gen;
+    uint8_t ep_alive;                     /* the Endpoint object exists (its task has not dropped it)                */
+    uint16_t guards;                      /* live (Sender, Receiver) pairs holding clones of its Arc<BindGuard>: the address
+                                             stays in the node's socket table until the Endpoint AND all of them are gone */
     VEC(reg_t) registered;                /* endpoint.rs:298-303 Mailbox                             */
     VEC(msg_t) msgs;
     VEC(uint8_t) acceptq;                 /* conn_tx/conn_rx: pending connections (endpoint.rs:18,307) */
@@ -390,7 +396,7 @@ static int try_send(sim_t* S, unsigned src_node, addr_t dst, uint64_t* latency, 
 /* Mailbox::deliver (endpoint.rs:331-351) through EndpointSocket::deliver (:311-318). */
 static void mailbox_deliver(sim_t* S, event_t* e) {
     sock_t* k = &S->socks[e->sock];
-    if (!k->bound || k->gen != e->sockgen) return;        /* Endpoint object gone: unobservable */
+    if (!k->bound || !k->ep_alive || k->gen != e->sockgen) return;   /* Endpoint object gone: nobody can read the mailbox */
     size_t i = 0;
     while (i < k->registered.n) {
         if (k->registered.p[i].tag == e->tag) {
@@ -416,15 +422,35 @@ static void mailbox_deliver(sim_t* S, event_t* e) {
  * task lifecycle
  * ---------------------------------------------------------------------------------------------- */
 static void sock_drop_acceptq(sim_t* S, sock_t* k);
+/* An EndpointSocket lives while the node's socket table (`bound`) or its Endpoint (`ep_alive`) holds an Arc of it (in-flight
+ * delivery closures are not counted); when it dies conn_tx dies, and with it the connections nobody accepted. */
+static void sock_maybe_free(sim_t* S, sock_t* k) {
+    if (!k->bound && !k->ep_alive && k->acceptq.n) sock_drop_acceptq(S, k);
+}
+/* The address leaves the node's socket table — Network::close (network.rs:253-258) from BindGuard::drop. */
+static void sock_release(sim_t* S, sock_t* k) {
+    k->bound = 0;
+    sock_maybe_free(S, k);
+}
+/* drop(Endpoint): conn_rx goes (the async_channel is closed: later connections are dropped on arrival, endpoint.rs:320-328)
+ * and the Arc<BindGuard> loses one owner.  BindGuard::drop (net/mod.rs:483-493) runs with the LAST owner and does nothing
+ * when the binder's NodeInfo is killed: after Handle::kill reset_node has emptied the socket table already, after the init
+ * task's exit (Spawner::exit is info.kill() alone, task/mod.rs:657-661) the address simply stays in the table. */
+static void endpoint_drop(sim_t* S, sock_t* k, int node_killed) {
+    k->ep_alive = 0; k->acc_task = -1;
+    if (!node_killed && k->guards == 0) k->bound = 0;
+    sock_maybe_free(S, k);
+}
+/* one end's Sender and Receiver are dropped: their two clones of the Endpoint's Arc<BindGuard> */
+static void guard_release(sim_t* S, int sock, int node_killed) {
+    if (sock < 0 || node_killed) return;                  /* killed: reset_node forgot the counts, drop() would return early */
+    sock_t* k = &S->socks[sock];
+    if (k->guards && --k->guards == 0 && !k->ep_alive && k->bound) sock_release(S, k);
+}
 static void sock_close_owned(sim_t* S, uint16_t slot, uint16_t gen, int node_killed) {
-    /* BindGuard::drop (net/mod.rs:483-493): skipped when the binder's NodeInfo is killed */
     for (uint32_t i = 0; i < S->w->n_socks; i++) {
         sock_t* k = &S->socks[i];
-        if (k->owner_slot == slot && k->owner_gen == gen && k->bound) {
-            if (!node_killed) { k->bound = 0; }
-            /* the Endpoint (and its mailbox) is unreachable from now on either way */
-        }
-        if (k->owner_slot == slot && k->owner_gen == gen && k->acceptq.n) sock_drop_acceptq(S, k);
+        if (k->ep_alive && k->owner_slot == slot && k->owner_gen == gen) endpoint_drop(S, k, node_killed);
     }
 }
 
@@ -486,7 +512,7 @@ static void node_kill(sim_t* S, unsigned node) {          /* TaskHandle::kill_id
     paused_clear(S, node);
     info_kill(S, node);
     for (uint32_t i = 0; i < S->w->n_socks; i++)          /* NetSim::reset_node -> sockets.clear() (network.rs:142-147) */
-        if (S->w->socks[i].node == node) S->socks[i].bound = 0;
+        if (S->w->socks[i].node == node) { S->socks[i].bound = 0; S->socks[i].guards = 0; sock_maybe_free(S, &S->socks[i]); }
 }
 
 static void node_restart(sim_t* S, unsigned node) {       /* TaskHandle::restart (task/mod.rs:374-401) */
@@ -512,21 +538,21 @@ static int chan_test_link(sim_t* S, conn_t* c, int dir, uint64_t* arrive) {
     unsigned src_node = dir == 0 ? c->c_node : c->s_node;
     addr_t to = { dir == 0 ? c->dst_kind : c->src_kind, dir == 0 ? c->dst_ipnode : c->c_node, dir == 0 ? c->dst_port : c->src_port };
     uint64_t lat; int ds; unsigned lb;
-    if (try_send(S, src_node, to, &lat, &ds, &lb) <= 0) return 0;
+    const int sent = try_send(S, src_node, to, &lat, &ds, &lb);
+    if (sent <= 0) return sent;
     *arrive = S->clock + lat;
     return 1;
 }
 
-static void conn_drop_handles(sim_t* S, int id, int side);
-/* the listening Endpoint is dropped: connections still queued in conn_rx go with it (their server-side handles).
- * Modelling note: the reference frees them when the last Arc<EndpointSocket> dies, which an in-flight
- * datagram closure can postpone; here it happens with the Endpoint. */
+static void conn_drop_handles(sim_t* S, int id, int side, int node_killed);
+/* the EndpointSocket is freed: the connections still queued in conn_tx go with it (their server-side raw handles) */
 static void sock_drop_acceptq(sim_t* S, sock_t* k) {
     size_t n = k->acceptq.n; k->acceptq.n = 0; k->acc_task = -1;
-    for (size_t i = 0; i < n; i++) conn_drop_handles(S, k->acceptq.p[i], 1);
+    for (size_t i = 0; i < n; i++) conn_drop_handles(S, k->acceptq.p[i], 1, 0);
 }
 
-static void conn_drop_handles(sim_t* S, int id, int side) {   /* drop (Sender, Receiver) of one end */
+/* drop(tx); drop(rx) of one end, by a task whose NodeInfo is killed or not */
+static void conn_drop_handles(sim_t* S, int id, int side, int node_killed) {
     if (id < 0) return;
     conn_t* c = &S->conns.p[id];
     cdir_t* out = &c->d[side], *in = &c->d[1 - side];
@@ -535,15 +561,18 @@ static void conn_drop_handles(sim_t* S, int id, int side) {   /* drop (Sender, R
         if (out->rx_task >= 0) { int32_t r = out->rx_task; out->rx_task = -1; wake(S, (uint16_t)r, out->rx_gen); }
     }
     in->rx_alive = 0; in->rx_task = -1;
+    const int gs = c->guard_sock[side];
+    c->guard_sock[side] = -1;
     if (!c->d[0].tx_alive && !c->d[0].rx_alive && !c->d[1].tx_alive && !c->d[1].rx_alive) {
         c->alive = 0; c->d[0].q.n = 0; c->d[1].q.n = 0;
     }
+    guard_release(S, gs, node_killed);                    /* may free a socket and, with it, connections queued there */
 }
 
 /* The future is gone (completed, or dropped by the executor).  outcome: H_COMPLETED / H_CANCELLED. */
 static void task_finish(sim_t* S, uint16_t slot, int outcome) {
     task_t* t = &S->tasks.p[slot];
-    if (t->conn >= 0) { conn_drop_handles(S, t->conn, t->side); t->conn = -1; }
+    if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, t->killed); t = &S->tasks.p[slot]; }
     sock_close_owned(S, slot, t->gen, t->killed);
     handle_t* h = &S->handles[t->prog];
     if (h->state == H_RUNNING && h->slot == slot && h->gen == t->gen) h->state = (uint8_t)outcome;
@@ -738,6 +767,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 if (in->b & 2) t->val = port;              /* ep.local_addr().unwrap().port() */
                 sock_t* k = &S->socks[in->a];
                 k->bound = 1; k->gen++; k->owner_slot = slot; k->owner_gen = t->gen; k->port = port;
+                k->ep_alive = 1; k->guards = 0;
                 k->registered.n = 0; k->msgs.n = 0;        /* a fresh Endpoint + Mailbox */
                 k->acceptq.n = 0; k->acc_task = -1;
             }
@@ -800,7 +830,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (t->sub == 0) { t->deadline = rand_delay_start(S); t->sub = 1; }
             if (!sleep_poll(S, slot, t->deadline)) return 0;
             {
-                if (t->conn >= 0) { conn_drop_handles(S, t->conn, t->side); t->conn = -1; }
+                if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, t->killed); t = &S->tasks.p[slot]; }
                 uint64_t lat; int ds; unsigned lb;
                 const addr_t dial = addr_of_sock(S, in->b & 0xff);
                 const int sent = try_send(S, w->socks[in->a].node, dial, &lat, &ds, &lb);
@@ -816,11 +846,18 @@ static int poll_task(sim_t* S, uint16_t slot) {
                     c->dst_kind = dial.kind; c->dst_ipnode = dial.node; c->dst_port = dial.port;
                     c->src_kind = lb ? MADSIM_ADDR_LOOPBACK : MADSIM_ADDR_IP; c->src_port = S->socks[in->a].port;   /* src = (ip, port) :355 */
                     for (int d = 0; d < 2; d++) { c->d[d].tx_alive = c->d[d].rx_alive = 1; c->d[d].q.n = 0; c->d[d].rx_task = -1; }
+                    c->guard_sock[0] = in->a; c->guard_sock[1] = -1;
+                    S->socks[in->a].guards++;              /* Sender { _guard: self.guard.clone(), .. }, Receiver { .. } (endpoint.rs:181-190) */
                     t->conn = (int8_t)id; t->side = 0; t->val = 0;
-                    sock_t* k = &S->socks[ds];             /* socket.new_connection -> conn_tx.try_send (endpoint.rs:320-328) */
-                    vec_push(k->acceptq, (uint8_t)id);
-                    if (k->acc_task >= 0) { int32_t a = k->acc_task; k->acc_task = -1; wake(S, (uint16_t)a, k->acc_gen); }
                     if (S->conns.n > S->st.max_conns) S->st.max_conns = (uint32_t)S->conns.n;
+                    sock_t* k = &S->socks[ds];             /* socket.new_connection -> `let _ = conn_tx.try_send(..)` (endpoint.rs:320-328) */
+                    if (!k->ep_alive) {
+                        conn_drop_handles(S, (int)id, 1, 0);   /* the listener's Endpoint is gone (its address is held by connections
+                                                                  it accepted): the channel is closed, (tx2, rx1) are dropped here */
+                    } else {
+                        vec_push(k->acceptq, (uint8_t)id);
+                        if (k->acc_task >= 0) { int32_t a = k->acc_task; k->acc_task = -1; wake(S, (uint16_t)a, k->acc_gen); }
+                    }
                 }
             }
             t = &S->tasks.p[slot]; t->sub = 0; t->pc++;
@@ -830,9 +867,10 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (t->sub == 1) { if (!sleep_poll(S, slot, t->deadline)) return 0; t->sub = 2; }
             sock_t* k = &S->socks[in->a];
             if (k->acceptq.n == 0) { k->acc_task = slot; k->acc_gen = t->gen; return 0; }   /* conn_rx.recv() pending */
-            if (t->conn >= 0) { conn_drop_handles(S, t->conn, t->side); t->conn = -1; }
+            if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, t->killed); t = &S->tasks.p[slot]; k = &S->socks[in->a]; }
             t->conn = (int8_t)k->acceptq.p[0];
             memmove(k->acceptq.p, k->acceptq.p + 1, --k->acceptq.n);
+            S->conns.p[t->conn].guard_sock[1] = in->a; k->guards++;   /* Sender / Receiver { _guard: self.guard.clone() } (endpoint.rs:203-210) */
             t->side = 1; t->sub = 0; t->pc++;
             break;
         }
@@ -841,7 +879,9 @@ static int poll_task(sim_t* S, uint16_t slot) {
             conn_t* c = &S->conns.p[t->conn];
             cdir_t* d = &c->d[t->side];
             cmsg_t m; m.val = in->imm; m.arrive = 0;
-            m.has_arrive = (uint8_t)chan_test_link(S, c, t->side, &m.arrive);      /* draws happen before the closed check */
+            const int link = chan_test_link(S, c, t->side, &m.arrive);             /* draws happen before the closed check */
+            if (link < 0) return 1;                        /* `.ip.unwrap()` inside try_send (network.rs:309) */
+            m.has_arrive = (uint8_t)link;
             if (!d->rx_alive) { t->val = MADSIM_VAL_RESET; t->pc++; break; }        /* ConnectionReset */
             vec_push(d->q, m);
             if (d->q.n > S->st.max_cq) S->st.max_cq = (uint32_t)d->q.n;
@@ -872,14 +912,16 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 if (!sleep_poll(S, slot, t->deadline)) return 0;
                 if (t->sub == 3) break;
                 t->backoff_ms = t->backoff_ms * 2 > 10000 ? 10000 : t->backoff_ms * 2;               /* min(backoff * 2, 10 s) */
-                t->chas = (uint8_t)chan_test_link(S, c, 1 - t->side, &t->carrive);                   /* retry */
+                const int link = chan_test_link(S, c, 1 - t->side, &t->carrive);                     /* retry */
+                if (link < 0) return 1;
+                t->chas = (uint8_t)link;
                 t->sub = 1;
             }
             t->val = t->cval; t->sub = 0; t->pc++;
             break;
         }
         case MS_OP_CCLOSE:
-            if (t->conn >= 0) { conn_drop_handles(S, t->conn, t->side); t = &S->tasks.p[slot]; t->conn = -1; }
+            if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, t->killed); t = &S->tasks.p[slot]; }
             t->pc++;
             break;
         case MS_OP_ASSERT_VAL:
@@ -1008,8 +1050,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
         }
         case MS_OP_CLOSE: {
             sock_t* k = &S->socks[in->a];
-            if (k->bound && k->owner_slot == slot && k->owner_gen == t->gen && !t->killed) k->bound = 0;
-            if (k->owner_slot == slot && k->owner_gen == t->gen && k->acceptq.n) { sock_drop_acceptq(S, k); t = &S->tasks.p[slot]; }
+            if (k->ep_alive && k->owner_slot == slot && k->owner_gen == t->gen) { endpoint_drop(S, k, t->killed); t = &S->tasks.p[slot]; }
             t->pc++;
             break;
         }

@@ -424,3 +424,121 @@ def random_ephemeral_workload(rng: random.Random):
     cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.2]))
     return wl.build(), cfg, f"{n_nodes}n/{len(named)}a/{n_eph}e"
 
+
+
+def random_channel_workload(rng: random.Random):
+    """Reliable-channel programs (net/mod.rs:337-430, endpoint.rs:178-262) without node lifecycle, aimed at who keeps an
+    address bound: every Sender / Receiver holds a clone of its Endpoint's Arc<BindGuard>, so a listener dropped while
+    connections it accepted are alive stays in the node's socket table (bind: AddrInUse, connect1: Ok but the connection is
+    dropped on the floor), and the connections nobody accepted die only when the last clone goes.  Servers accept a few
+    connections (inline or through `async move` handler tasks), drop the listener early or late and sometimes bind it
+    again; clients sit on named or ephemeral Endpoints, dial node-IP / wildcard-reached / loopback addresses, drop their
+    Endpoint before their connection; probers try_bind the listening addresses; the supervisor clogs links."""
+    wl = W.WorkloadBuilder()
+    n_srv = rng.randint(1, 2)
+    srv_nodes = [wl.create_node() for _ in range(n_srv)]
+    cli_nodes = [wl.create_node() for _ in range(rng.randint(1, 2))]
+    tasks, dials = [], []
+    for i, n in enumerate(srv_nodes):
+        port = rng.randint(1, 3)
+        lkind = rng.choice(["node", "unspecified"])
+        listen = wl.addr(n, port, ip=lkind)
+        dials.append((n, wl.addr(n, port)))                                   # what clients dial: 10.0.0.<n>:<port>
+        handler = None
+        if rng.random() < 0.5:
+            handler = wl.task(n)
+            handler.chan_recv(); handler.trace_val()
+            if rng.random() < 0.8:
+                handler.chan_send(0x70 + i)
+            if rng.random() < 0.5:
+                handler.sleep(ms=rng.choice([1, 8, 40]))
+            if rng.random() < 0.4:
+                handler.chan_recv(); handler.trace_val()
+            handler.done()
+        srv = wl.task(n)
+        srv.bind(listen)
+        srv.set(0, rng.randint(1, 3))
+        top = srv.label()
+        srv.accept1(listen)
+        if handler is not None:
+            srv.spawn(handler, move_conn=True)
+        else:
+            srv.chan_recv(); srv.trace_val()
+            if rng.random() < 0.7:
+                srv.chan_send(0x50 + i)
+        srv.djnz(0, top)
+        r = rng.random()
+        if r < 0.4:                                                            # drop the listener, maybe while connections live
+            srv.close(listen)
+            if rng.random() < 0.6:
+                srv.sleep(ms=rng.choice([1, 5, 30])); srv.try_bind(listen); srv.trace_val()
+                if rng.random() < 0.5:                                         # only an Endpoint that exists can accept
+                    end = srv.label() + 4
+                    srv.jeq(A.VAL_ADDR_IN_USE, end)
+                    srv.accept1(listen); srv.chan_recv(); srv.trace_val()
+                    assert srv.label() == end
+        elif r < 0.7:
+            srv.sleep(ms=rng.choice([5, 50]))
+        srv.done()
+        tasks.append(srv)
+        if rng.random() < 0.6:                                                 # a second Endpoint for the same address
+            twin = wl.addr(n, port, ip=lkind)
+            pr = wl.task(n)
+            pr.set(0, rng.randint(1, 3))
+            top = pr.label()
+            pr.sleep(ms=rng.choice([2, 9, 25, 60])); pr.try_bind(twin); pr.trace_val()
+            skip = pr.label() + 3
+            pr.jeq(A.VAL_ADDR_IN_USE, skip)
+            pr.sleep(ms=rng.choice([1, 10])); pr.close(twin)
+            assert pr.label() == skip
+            pr.djnz(0, top); pr.done()
+            tasks.append(pr)
+    for j, n in enumerate(cli_nodes):
+        for _ in range(rng.randint(1, 2)):
+            ep = wl.addr(n, rng.choice([0, 0, 5, 6]), ip=rng.choice(["unspecified", "node"]))
+            c = wl.task(n)
+            c.bind(ep); c.sleep(ms=rng.randint(0, 12)); c.set(0, rng.randint(1, 4))
+            top = c.label()
+            dn, dial = rng.choice(dials)
+            c.connect1(ep, dial); c.trace_val()
+            body_end = None
+            skip_at = c.label()
+            c.jeq(A.VAL_REFUSED, 0)                                            # target patched below
+            drop_ep_first = rng.random() < 0.3
+            if drop_ep_first:
+                c.close(ep)                                                    # the connection keeps the address
+            for _ in range(rng.randint(1, 2)):
+                c.chan_send(0x10 + j)
+            if rng.random() < 0.8:
+                c.chan_recv(); c.trace_val()
+            if rng.random() < 0.5:
+                c.sleep(ms=rng.choice([1, 6, 20]))
+            if rng.random() < 0.7:
+                c.chan_close()
+            if drop_ep_first:
+                c.try_bind(ep); c.trace_val()                                  # AddrInUse while (tx, rx) live (named ports)
+                fix = c.label() + 3
+                c.jeq(0, fix)
+                c.chan_close(); c.bind(ep)
+                assert c.label() == fix
+            body_end = c.label()
+            c.code[skip_at] = (c.code[skip_at][0], c.code[skip_at][1], body_end, c.code[skip_at][3], c.code[skip_at][4])
+            c.sleep(ms=rng.choice([0, 3, 15])); c.djnz(0, top); c.done()
+            tasks.append(c)
+    m = wl.main()
+    order = list(range(len(tasks)))
+    rng.shuffle(order)
+    for i in order:
+        m.spawn(tasks[i])
+    for _ in range(rng.randint(0, 2)):
+        m.sleep(ms=rng.randint(1, 30))
+        a, b = rng.choice(srv_nodes), rng.choice(cli_nodes)
+        if rng.random() < 0.5:
+            a, b = b, a
+        m.clog_link(a, b); m.sleep(ms=rng.randint(1, 40)); m.unclog_link(a, b)
+    m.sleep(ms=rng.choice([100, 400]))
+    for i in order:
+        if rng.random() < 0.5:
+            m.join(tasks[i], expect_err=False)
+    cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.1]))
+    return wl.build(), cfg, f"{n_srv}s/{len(cli_nodes)}c/{len(tasks)}t"

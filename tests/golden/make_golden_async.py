@@ -12,7 +12,9 @@ add_rpc_handler), task/mod.rs:220-323 (executor loop), rand.rs:64-88,142-158 (lo
 generator / gen_range / UniformDuration arithmetic with make_golden.py.  Round 2 added the network's address handling —
 sockets live in a literal per-node `HashMap<(ip, port), socket>`, `Network::bind` / `resolve_dest_node` / `try_send`
 (net/network.rs:206-313) are restated over it with addresses as (ip string, port) tuples, the receiver's `from` is the
-tuple the reference builds (:307-311) — and the NetSim request / response hooks (net/mod.rs:240-284,307-328).
+tuple the reference builds (:307-311) — the NetSim request / response hooks (net/mod.rs:240-284,307-328), ephemeral ports
+(network.rs:224-236) and the reliable channel (net/mod.rs:337-430, endpoint.rs:178-262): connect1 / accept1 / Sender / Receiver
+with explicit Arc<BindGuard> counts, the async_channel accept queue and the receiver's backoff stream.
 
 Like make_golden.py it cannot be pinned to the Rust reference in this image; what the fixture gives is agreement of
 independently written restatements on timeouts' duplicate timers, dropped receivers, orphaned RPC responses.
@@ -45,12 +47,36 @@ class Oneshot:
         self.val, self.rx_alive, self.rx_task = None, True, None
 
 
+class Arc:
+    """Arc<T> with an explicit strong count; `on_zero` is T's Drop impl."""
+
+    def __init__(self, on_zero):
+        self.n, self.on_zero = 1, on_zero
+
+    def clone(self):
+        self.n += 1
+        return self
+
+    def drop(self):
+        self.n -= 1
+        if self.n == 0:
+            self.on_zero()
+
+
+class Mpsc:
+    """tokio::sync::mpsc::unbounded_channel as channel() uses it: one sender, one receiver."""
+
+    def __init__(self):
+        self.q, self.tx_alive, self.rx_alive, self.rx_task = [], True, True, None
+
+
 class Task:
     def __init__(self, sim, prog):
         self.prog, self.node = prog, sim.progs[prog][0]
         self.alive, self.sched, self.running, self.joiner = True, True, False, None
         self.cnt, self.val, self.frm, self.aux, self.t0 = [0, 0], 0, 0, 0, 0
         self.owned = []
+        self.conn = None                            # the (Sender, Receiver) pair this task holds (one at a time: the VM's rule)
         self.gen = sim.body(self, sim.progs[prog][2])
 
 
@@ -73,7 +99,7 @@ class Sim:
         self.clock, self.log, self.logging = 0, [], False
         self.heap, self.ready, self.handles, self.bound = [], [], {}, {}
         self.steps, self.msg_count, self.obs, self.flags = 0, 0, FNV_OFFSET, [0, 0, 0, 0]
-        self.clog_in, self.clog_out = set(), set()
+        self.clog_in, self.clog_out, self.clog_link = set(), set(), set()
         self.obs_list = []                                                 # what obs folds, in order (debugging aid)
         self.loss = cfg.packet_loss_rate
         self.lat = duration_params(cfg.lat_lo_ns, cfg.lat_hi_ns)
@@ -166,7 +192,8 @@ class Sim:
 
     def finish(self, t):
         t.gen.close()                               # the future is dropped: `finally:` blocks = Drop impls
-        for a in t.owned:                           # BindGuard::drop -> Network::close(node, addr)
+        self.conn_drop(t)                           # the task's locals: its (tx, rx) first, then its Endpoints (table order)
+        for a in sorted(set(t.owned)):
             if self.bound.get(a) is not None and self.bound[a]["owner"] is t:
                 self.close_sock(a)
         t.alive = False
@@ -186,9 +213,109 @@ class Sim:
         delay = self.gen_range(0, 5) * 1000
         yield from self.sleep_until(t, self.sleep_deadline(self.clock + delay))
 
-    def close_sock(self, a):                        # Network::close (network.rs:253-258)
-        self.node_sockets[self.socks[a][0]].pop(self.bound[a]["addr"], None)
+    def close_sock(self, a):                        # drop(Endpoint): conn_rx goes (the async_channel is closed), the guard
+        sock = self.bound[a]                        # loses one of its owners; Sender / Receiver clones may keep it alive
         self.bound[a] = None
+        sock["conn_closed"], sock["acceptor"] = True, None
+        sock["guard"].drop()
+
+    def guard_drop(self, node, sock):               # BindGuard::drop (net/mod.rs:483-493; nothing is ever killed here)
+        self.node_sockets[node].pop(sock["addr"], None)        # Network::close (network.rs:253-258)
+        # the map held the last Arc<EndpointSocket> (the Endpoint is gone, in-flight delivery closures are not counted —
+        # DESIGN.md): conn_tx dies, and with it the connections nobody accepted
+        q, sock["connq"] = sock["connq"], []
+        for tx, rx in q:
+            self.tx_drop(tx); self.rx_drop(rx)
+
+    # ---- reliable channel (net/mod.rs:337-430, endpoint.rs:178-262) ---------------------------------------------
+    def channel(self, node, dst):                   # NetSim::channel: an mpsc + the test_link closure both ends share
+        ch = Mpsc()
+
+        def test_link():
+            sent = self.try_send(node, dst)
+            return None if sent is None else self.clock + sent[3]
+        return (ch, test_link), (ch, test_link)
+
+    def tx_drop(self, tx):                          # PayloadSender dropped: the last mpsc sender -> a parked receiver wakes
+        ch = tx[0]
+        ch.tx_alive = False
+        if ch.rx_task is not None:
+            r, ch.rx_task = ch.rx_task, None
+            self.wake(r)
+
+    def rx_drop(self, rx):                          # PayloadReceiver dropped: tx.send() fails from now on
+        rx[0].rx_alive, rx[0].rx_task = False, None
+
+    def conn_drop(self, t):                         # drop(tx); drop(rx) — each is {_guard, channel end}, fields in that order
+        if t.conn is None:
+            return
+        tx, rx, guard = t.conn
+        t.conn = None
+        guard.drop(); self.tx_drop(tx)
+        guard.drop(); self.rx_drop(rx)
+
+    def connect1(self, t, a, dst):                  # Endpoint::connect1 -> NetSim::connect1
+        yield from self.rand_delay(t)
+        self.conn_drop(t)                           # (the VM's rule: a task holds one pair; the old one goes here)
+        node = self.socks[a][0]
+        sent = self.try_send(node, dst)
+        if sent is None:
+            return A.VAL_REFUSED
+        src_ip, dst_node, sock, _lat = sent         # "FIXME: delay": the latency is discarded
+        src = (src_ip, self.bound[a]["addr"][1])
+        tx1, rx1 = self.channel(node, dst)
+        tx2, rx2 = self.channel(dst_node, src)
+        if sock["conn_closed"]:                     # socket.new_connection: `let _ = conn_tx.try_send(..)`
+            self.tx_drop(tx2); self.rx_drop(rx1)
+        else:
+            sock["connq"].append((tx2, rx1))
+            if sock["acceptor"] is not None:
+                acc, sock["acceptor"] = sock["acceptor"], None
+                self.wake(acc)
+        guard = self.bound[a]["guard"]
+        t.conn = (tx1, rx2, guard.clone().clone())  # Sender { _guard: guard.clone(), tx } + Receiver { _guard: guard.clone(), rx }
+        return 0
+
+    def accept1(self, t, a):                        # Endpoint::accept1
+        yield from self.rand_delay(t)
+        sock = self.bound[a]
+        while not sock["connq"]:                    # conn_rx.recv().await
+            sock["acceptor"] = t
+            yield
+        self.conn_drop(t)
+        tx, rx = sock["connq"].pop(0)
+        t.conn = (tx, rx, sock["guard"].clone().clone())
+
+    def chan_send(self, t, val):                    # Sender::send -> PayloadSender::send (net/mod.rs:417-421)
+        if t.conn is None:
+            return A.VAL_RESET
+        ch, test_link = t.conn[0]
+        state = test_link()                         # the draws come before the closed check
+        if not ch.rx_alive:
+            return A.VAL_RESET
+        ch.q.append((val, state))
+        if ch.rx_task is not None:
+            r, ch.rx_task = ch.rx_task, None
+            self.wake(r)
+        return None
+
+    def chan_recv(self, t):                         # Receiver::recv -> the stream of channel() (net/mod.rs:385-402)
+        if t.conn is None:
+            return A.VAL_RESET
+        ch, test_link = t.conn[1]
+        while not ch.q:
+            if not ch.tx_alive:
+                return A.VAL_RESET                  # the stream ended
+            ch.rx_task = t
+            yield
+        val, state = ch.q.pop(0)
+        backoff = MS
+        while state is None:
+            yield from self.sleep_until(t, self.sleep_deadline(self.clock + backoff))
+            backoff = min(backoff * 2, 10 * 1000 * MS)
+            state = test_link()
+        yield from self.sleep_until(t, self.sleep_deadline(state))
+        return val
 
     def resolve_dest_node(self, node, dst):         # network.rs:272-290
         if dst[0] == "127.0.0.1" or dst in self.node_sockets[node]:
@@ -201,7 +328,7 @@ class Sim:
         dst_node = self.resolve_dest_node(node, dst)
         if dst_node is None:
             return None
-        if node in self.clog_out or dst_node in self.clog_in:         # test_link (:261-269)
+        if node in self.clog_out or dst_node in self.clog_in or (node, dst_node) in self.clog_link:   # test_link (:261-269)
             return None
         if self.gen_bool(self.loss):
             return None
@@ -306,6 +433,8 @@ class Sim:
                 return
             elif name == "SPAWN":
                 c = self.spawn(a)
+                if b & 2:                           # `async move`: the child takes (tx, rx)
+                    c.conn, t.conn = t.conn, None
                 if b & 4:
                     c.val, c.frm, c.aux = t.val, t.frm, t.aux
             elif name == "JOIN":
@@ -377,7 +506,8 @@ class Sim:
                         raise Panic()               # .unwrap()
                     t.val = err
                 else:
-                    mbox = dict(owner=t, regs=[], msgs=[], addr=(ip, port))
+                    mbox = dict(owner=t, regs=[], msgs=[], addr=(ip, port), connq=[], conn_closed=False, acceptor=None)
+                    mbox["guard"] = Arc(lambda node=t.node, sock=mbox: self.guard_drop(node, sock))
                     self.node_sockets[t.node][(ip, port)] = mbox
                     self.bound[a] = mbox; t.owned.append(a)
                     self.addr[a] = (ip, port)       # ep.local_addr()
@@ -388,6 +518,22 @@ class Sim:
             elif name == "CLOSE":
                 if self.bound.get(a) is not None and self.bound[a]["owner"] is t:
                     self.close_sock(a)
+            elif name == "CONNECT":
+                t.val = yield from self.connect1(t, a, self.addr[b & 0xFF])
+            elif name == "ACCEPT":
+                yield from self.accept1(t, a)
+            elif name == "CSEND":
+                r = self.chan_send(t, imm)
+                if r is not None:
+                    t.val = r
+            elif name == "CRECV":
+                t.val = yield from self.chan_recv(t)
+            elif name == "CCLOSE":
+                self.conn_drop(t)
+            elif name == "CLOG_LINK":
+                self.clog_link.add((a, b))
+            elif name == "UNCLOG_LINK":
+                self.clog_link.discard((a, b))
             elif name == "SEND":
                 yield from self.send_raw(t, a, self.addr[b & 0xFF], b >> 8, imm)
             elif name == "REPLY":
@@ -524,6 +670,12 @@ def workloads():
         out[name] = LW.ALL[name]()
     for k in range(16):
         out["ephemeral_fuzz_%02d" % k] = fuzz.random_ephemeral_workload(random.Random(870000 + k))[0]
+    # the reliable channel, literally (Arc<BindGuard> clones in every Sender / Receiver, async_channel accept queue,
+    # the backoff stream): the reference-shaped workloads and random programs about who keeps an address bound
+    for name in ("kv_rpc", "channel_backoff", "connect_refused_and_reset", "channel_wildcard_listener", "channel_loopback"):
+        out[name] = LW.ALL[name]()
+    for k in range(24):
+        out["channel_fuzz_%02d" % k] = fuzz.random_channel_workload(random.Random(860000 + k))[0]
     for k in range(12):                             # random typed-RPC programs with hooks — those without node lifecycle
         w, _, _ = fuzz.random_rpc_workload(random.Random(890000 + k), hooks=True)
         ops = {OPN[w.insns[i].op] for i in range(w.struct.n_insns)}

@@ -172,6 +172,26 @@ def test_fuzz_ephemeral_ports():
     assert n_overflow == 0                          # one live Endpoint per entry: a candidate is always free
 
 
+def test_fuzz_channel_guards():
+    """250 random reliable-channel programs about who keeps an address bound (every Sender / Receiver holds a clone of its
+    Endpoint's Arc<BindGuard>, endpoint.rs:181-210): listeners dropped under live connections, clients dropping their
+    Endpoint before their connection, probers binding the same address, ephemeral and wildcard addresses, clogged links."""
+    seen, n_ovf = set(), 0
+    for k in range(250):
+        w, cfg, desc = fuzz.random_channel_workload(random.Random(75000 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        if k % 2:
+            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        o, _ = oracle.run_batch(w, k * 5, 10, cfg, lim)
+        e = emu.run_batch(w, k * 5, 10, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+        n_ovf += int((e["verdict"] == A.OVERFLOW).sum())
+        seen |= set(o["verdict"].tolist())
+    assert A.PASS in seen and A.DEADLOCK in seen
+    assert n_ovf < 0.15 * 250 * 10, n_ovf            # (more than four connections waiting in one accept queue: a device capacity)
+
+
 def test_fuzz_rpc_hooks_and_panic_codes():
     """Random typed-RPC programs with NetSim request / response hooks installed and replaced at random moments."""
     for k in range(150):

@@ -579,6 +579,21 @@ def test_fuzz_ephemeral_ports_gpu(hip):
         assert (got == want).all(), (k, desc, got[got != want][0], want[got != want][0])
 
 
+def test_fuzz_channel_guards_gpu(hip):
+    """Random reliable-channel programs about who keeps an address bound (Arc<BindGuard> clones in Sender / Receiver)."""
+    import random
+    from tests import fuzz
+    for k in range(150):
+        w, cfg, desc = fuzz.random_channel_workload(random.Random(78000 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        if k % 2:
+            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        got, _ = hip.run_batch(w, k * 37, 96, cfg, lim)
+        want, _ = oracle.run_batch(w, k * 37, 96, cfg, lim)
+        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+
+
 def test_fuzz_rpc_hooks_gpu(hip):
     """Random typed-RPC programs with NetSim::hook_rpc_req / hook_rpc_rsp (net/mod.rs:240-284), LDS and global state."""
     import random

@@ -1,4 +1,4 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2g
-for wl in raft kv topo pingpong; do echo "== $wl"; MADSIM_HIP_LIB=$PWD/madsim_amd/libmadsim_hip_prof.so timeout 200 python tools/phase_prof.py $wl 2>&1 | grep -v amdgpu.ids; done > gpurun_out/r2g/phase.txt
-cat gpurun_out/r2g/phase.txt | head -3
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2h
+python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r2h/gputest.txt; cat gpurun_out/r2h/gputest.txt
+bash tools/gpu_exp.sh gpurun_exp.txt
