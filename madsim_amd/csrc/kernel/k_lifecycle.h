@@ -47,24 +47,32 @@ template <class K> __device__ __forceinline__ void conn_drop_handles(const Ctx& 
 template <class K> __device__ __forceinline__ void endpoint_drop(const Ctx& c, Lane& L, uint32_t s, bool node_killed);
 template <class K> __device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s);
 
-// The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
+// The locals of a task body drop: its (Sender, Receiver) pair, then the Endpoints it holds (table order).  `f` = its flag word.
 template <class K>
-__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome) {
-    uint32_t f = TWORD(c, slot, 0, 0);
-    uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
-    if (K::FC && c.P.uses_chan) {                          // the task's (Sender, Receiver) pair drops with its future
+__device__ __forceinline__ void task_drop_locals(const Ctx& c, Lane& L, uint32_t slot, uint32_t f) {
+    const uint32_t gen = (f >> 8) & 0xffff;
+    if (K::FC && c.P.uses_chan) {
         uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
         if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (f & TF_KILLED) != 0); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
     }
-    if (f & TF_OWNER) {                                        // the Endpoints this task holds drop with its future
+    if (f & TF_OWNER) {
         for (uint32_t i = 0; i < c.P.n_socks; i++) {
             if (K::G && !((OMASK(i >> 5) >> (i & 31)) & 1)) continue;      // never bound by a task that is still around
             const uint32_t hdr = SW(c, i, 0);
             if (!sock_owned_by<K>(c, i, hdr, slot, gen)) continue;
             if (K::G) OMASK(i >> 5) &= ~(1u << (i & 31));
             endpoint_drop<K>(c, L, i, (f & TF_KILLED) != 0);
+            if (K::LIFE && SW(c, i, 1) != ~0u) SW(c, i, 1) = 0x0000ff00u;    // nobody's: no owner word has bits 8-15 set
         }
     }
+}
+
+// The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
+template <class K>
+__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome) {
+    uint32_t f = TWORD(c, slot, 0, 0);
+    uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
+    task_drop_locals<K>(c, L, slot, f);
     uint32_t h = HW(prog);
     if (h == (H_RUNNING | (slot << 8) | (gen << 16))) { HW(prog) = (h & ~3u) | outcome; if (prog == 0) L.main_done = 1; }
     uint32_t link = TWORD(c, slot, 1, 0);

@@ -520,9 +520,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.y = pc | (sub << 16) | (from << 24);
                 TU(c, slot, 0) = u0;
                 if (u1_dirty) { tu1_store<K>(c, slot, u1); u1_dirty = false; }
-                // an init task is `async { future.await; h.exit() }` (runtime/mod.rs:362-370): Spawner::exit =
-                // NodeInfo::kill on the info it was spawned with (task/mod.rs:657-661), before the future drops
+                // an init task is `async move { future.await; h.exit() }` (runtime/mod.rs:362-370): the body's locals are gone
+                // when `future.await` returns, on a node that is not killed yet; then Spawner::exit = NodeInfo::kill on the
+                // info it was spawned with (task/mod.rs:657-661)
                 if (K::FN && ((PROGW(c, u0.x >> 24) >> 8) & MADSIM_PROG_INIT) && (u1.y >> 24) == NODE_INFO_GEN(node)) {
+                    task_drop_locals<K>(c, L, slot, u0.x);
                     NODEW(0) |= 1u << node;
                     if ((u1.y >> 24) == 0) NODEW(2) |= 1u << node;
                     info_kill<K>(c, L, node, u1.y >> 24);

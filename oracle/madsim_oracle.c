@@ -619,9 +619,12 @@ static int poll_task(sim_t* S, uint16_t slot) {
         const madsim_insn_t* in = &w->insns[t->pc];
         switch (in->op) {
         case MS_OP_DONE:
-            /* an init task is `async { future.await; h.exit() }` (runtime/mod.rs:362-370): Spawner::exit =
-             * info.kill() on the NodeInfo it was spawned with (task/mod.rs:657-661), before the future drops */
+            /* an init task is `async move { future.await; h.exit() }` (runtime/mod.rs:362-370): the body's locals — its
+             * (tx, rx), its Endpoints — are gone when `future.await` returns, on a node that is not killed yet; then
+             * Spawner::exit = info.kill() on the NodeInfo it was spawned with (task/mod.rs:657-661) */
             if ((w->progs[t->prog].flags & MADSIM_PROG_INIT) && t->info_gen == S->nodes[t->node].info_gen) {
+                if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, 0); t = &S->tasks.p[slot]; }
+                sock_close_owned(S, slot, t->gen, 0);
                 info_kill(S, t->node);
                 t = &S->tasks.p[slot];
             }

@@ -37,7 +37,25 @@ MS = 1_000_000
 
 
 class Panic(Exception):
-    pass
+    """panic!(..): `code` is what NodeBuilder::restart_on_panic_matching patterns are compared with (255 = any other message)."""
+
+    def __init__(self, code=255):
+        super().__init__(code)
+        self.code = code
+
+
+class NodeInfo:
+    """task/mod.rs:86-110: one per node incarnation; Handle::restart replaces it."""
+
+    def __init__(self, node):
+        self.node, self.killed, self.paused, self.tasks = node, False, False, []
+
+    def kill(self, sim):                            # NodeInfo::kill (:133-140)
+        self.killed = True
+        tasks, self.tasks = self.tasks, []          # drain(..)
+        for t in tasks:
+            if t.alive:                             # Weak<TaskInfo>::upgrade: the TaskInfo lives as long as the future
+                sim.wake(t)
 
 
 class Oneshot:
@@ -71,8 +89,9 @@ class Mpsc:
 
 
 class Task:
-    def __init__(self, sim, prog):
-        self.prog, self.node = prog, sim.progs[prog][0]
+    def __init__(self, sim, prog, info):
+        self.prog, self.node, self.info = prog, sim.progs[prog][0], info
+        self.cancelled, self.outcome = False, None  # TaskInfo.cancelled; "completed" / "cancelled" once the future is gone
         self.alive, self.sched, self.running, self.joiner = True, True, False, None
         self.cnt, self.val, self.frm, self.aux, self.t0 = [0, 0], 0, 0, 0, 0
         self.owned = []
@@ -94,6 +113,14 @@ class Sim:
         self.node_ip = {n: (None if w.nodes[n].flags & A.NODE_NO_IP else "10.0.0.%d" % n) for n in range(1, n_nodes + 1)}
         self.addr_to_node = {ip: n for n, ip in self.node_ip.items() if ip is not None}
         self.node_sockets = {n: {} for n in range(0, n_nodes + 1)}        # HashMap<(SocketAddr, protocol), Arc<dyn Socket>>
+        # task/mod.rs: TaskHandle.nodes (the current NodeInfo, the paused Runnables, the init fns) and the NodeHandles the test
+        # body holds — Spawners over the ORIGINAL NodeInfo (runtime/mod.rs:405-418)
+        self.node_info = {n: NodeInfo(n) for n in range(0, n_nodes + 1)}
+        self.handle_info = dict(self.node_info)
+        self.paused = {n: [] for n in range(0, n_nodes + 1)}
+        self.node_flags = {n: (w.nodes[n].flags, [w.nodes[n].match[i] for i in range(min(2, w.nodes[n].n_match))])
+                           for n in range(0, n_nodes + 1)}
+        self.all_socks = []                                                # every EndpointSocket ever made (reset_node's sweep)
         self.hooks_req, self.hooks_rsp = {}, {}                            # NetSim.hooks_req / hooks_rsp: HashMap<NodeId, hook>
         self.cfg, self.rng = cfg, Xoshiro(seed)
         self.clock, self.log, self.logging = 0, [], False
@@ -127,6 +154,20 @@ class Sim:
         if p == 1.0:
             return True
         return self.next_u64() < int(p * 2.0**64)
+
+    def gen_duration_once(self, lo, hi):            # rand.with(|rng| rng.gen_range(lo..hi)) on Durations: ONE with() however many
+        mode, low, rg, zone = duration_params(lo, hi)       # attempts the rejection loop takes (task/mod.rs:302-304)
+        while True:
+            v = self.rng.next()
+            if mode == 0:
+                m = (v >> 32) * rg
+                ok, r = (m & 0xFFFFFFFF) <= zone, low + (m >> 32)
+            else:
+                m = v * rg
+                ok, r = (m & M64) <= zone, low + (m >> 64)
+            if ok:
+                self.with_log()
+                return r
 
     def sample_duration(self, params):              # UniformDuration::sample on the GlobalRng itself
         mode, low, rg, zone = params
@@ -178,10 +219,47 @@ class Sim:
             cb()
 
     # ---- tasks (async-task wake rules) --------------------------------------------------------------------------
-    def spawn(self, prog):
-        t = Task(self, prog)
-        self.ready.append(t); self.handles[prog] = t
+    def spawn(self, prog, info, record=True):         # Spawner::spawn_inner (:627-654) on the Spawner's NodeInfo
+        t = Task(self, prog, info)
+        info.tasks.append(t)                        # new_task
+        self.ready.append(t)                        # runnable.schedule()
+        if record:
+            self.handles[prog] = t                  # the JoinHandle the spawning code keeps
         return t
+
+    def spawn_init(self, node):                     # the init closure(s) of a node on its current NodeInfo
+        for p in range(1, len(self.progs)):
+            if self.progs[p][0] == node and self.progs[p][1] & A.PROG_INIT:
+                self.spawn(p, self.node_info[node], record=False)
+
+    # ---- TaskHandle (task/mod.rs:354-424) -----------------------------------------------------------------------
+    def paused_clear(self, node):                   # node.paused.clear(): the Runnables drop, their futures with them
+        lst, self.paused[node] = self.paused[node], []
+        for t in lst:
+            self.finish(t, "cancelled")
+
+    def kill(self, node):                           # kill_id
+        self.paused_clear(node)
+        self.node_info[node].kill(self)
+        self.reset_node(node)                       # for sim in sims: sim.reset_node(id)
+
+    def restart(self, node):
+        old, self.node_info[node] = self.node_info[node], NodeInfo(node)
+        self.paused_clear(node)
+        old.kill(self)
+        self.spawn_init(node)
+
+    def resume(self, node):
+        self.node_info[node].paused = False
+        lst, self.paused[node] = self.paused[node], []
+        for t in lst:
+            self.ready.append(t)                    # sender.send(runnable)
+
+    def reset_node(self, node):                     # Network::reset_node (network.rs:142-147): sockets.clear()
+        self.node_sockets[node].clear()
+        for sock in self.all_socks:                 # EndpointSockets only the table kept alive die now (table order of the
+            if sock["node"] == node and not sock["in_table_or_ep"]():     # entries: the HashMap's own order is not modelled)
+                self.sock_free(sock)
 
     def wake(self, t):
         if not t.alive or t.sched:
@@ -190,14 +268,17 @@ class Sim:
         if not t.running:
             self.ready.append(t)
 
-    def finish(self, t):
-        t.gen.close()                               # the future is dropped: `finally:` blocks = Drop impls
-        self.conn_drop(t)                           # the task's locals: its (tx, rx) first, then its Endpoints (table order)
+    def drop_locals(self, t):                       # the task body's locals: its (tx, rx) first, then its Endpoints (table order)
+        self.conn_drop(t)
         for a in sorted(set(t.owned)):
             if self.bound.get(a) is not None and self.bound[a]["owner"] is t:
                 self.close_sock(a)
-        t.alive = False
-        if t.joiner is not None:
+
+    def finish(self, t, outcome):
+        t.gen.close()                               # the future is dropped: `finally:` blocks = Drop impls
+        self.drop_locals(t)
+        t.alive, t.outcome = False, outcome
+        if t.joiner is not None:                    # async-task notifies the awaiter
             self.wake(t.joiner)
 
     # ---- futures ------------------------------------------------------------------------------------------------
@@ -209,19 +290,30 @@ class Sim:
             self.timer_add(deadline, lambda: self.wake(t))
             yield
 
-    def rand_delay(self, t):                        # NetSim::rand_delay (buggify off in the fixtures)
+    def rand_delay(self, t):                        # NetSim::rand_delay (net/mod.rs:287-295)
         delay = self.gen_range(0, 5) * 1000
+        if self.cfg.buggify and self.gen_bool(0.1):         # buggify_with_prob(0.1): enabled && with(|rng| rng.gen_bool(p))
+            delay = self.gen_range(1, 5) * 10**9
         yield from self.sleep_until(t, self.sleep_deadline(self.clock + delay))
 
     def close_sock(self, a):                        # drop(Endpoint): conn_rx goes (the async_channel is closed), the guard
         sock = self.bound[a]                        # loses one of its owners; Sender / Receiver clones may keep it alive
         self.bound[a] = None
-        sock["conn_closed"], sock["acceptor"] = True, None
+        sock["conn_closed"], sock["acceptor"], sock["ep_alive"] = True, None, False
         sock["guard"].drop()
+        if not sock["in_table_or_ep"]():            # (the table entry went with the guard, or reset_node took it earlier)
+            self.sock_free(sock)
 
-    def guard_drop(self, node, sock):               # BindGuard::drop (net/mod.rs:483-493; nothing is ever killed here)
-        self.node_sockets[node].pop(sock["addr"], None)        # Network::close (network.rs:253-258)
-        # the map held the last Arc<EndpointSocket> (the Endpoint is gone, in-flight delivery closures are not counted —
+    def guard_drop(self, info, node, sock):         # BindGuard::drop (net/mod.rs:483-493)
+        if info.killed:                             # "avoid interfering with restarted node"
+            return
+        if self.node_sockets[node].get(sock["addr"]) is sock:
+            del self.node_sockets[node][sock["addr"]]          # Network::close (network.rs:253-258)
+        if not sock["in_table_or_ep"]():
+            self.sock_free(sock)
+
+    def sock_free(self, sock):
+        # the last Arc<EndpointSocket> is gone (table entry and Endpoint; in-flight delivery closures are not counted —
         # DESIGN.md): conn_tx dies, and with it the connections nobody accepted
         q, sock["connq"] = sock["connq"], []
         for tx, rx in q:
@@ -430,25 +522,54 @@ class Sim:
             name, dur = OPN[op], b * 10**9 + imm
             nxt = pc + 1
             if name == "DONE":
+                if self.progs[t.prog][1] & A.PROG_INIT:   # `async move { future.await; h.exit() }` (runtime/mod.rs:362-370): the
+                    self.drop_locals(t)                   # body's locals are gone when `future.await` returns; then Spawner::exit
+                    t.info.kill(self)                     # = info.kill() on the NodeInfo this init task was spawned with
                 return
             elif name == "SPAWN":
-                c = self.spawn(a)
+                # NodeHandle::spawn for another node's program (the handle's ORIGINAL NodeInfo), task::spawn otherwise
+                c = self.spawn(a, self.handle_info[self.progs[a][0]] if self.progs[a][0] != t.node else t.info)
                 if b & 2:                           # `async move`: the child takes (tx, rx)
                     c.conn, t.conn = t.conn, None
                 if b & 4:
                     c.val, c.frm, c.aux = t.val, t.frm, t.aux
             elif name == "JOIN":
-                c = self.handles[a]
+                c = self.handles.get(a)
+                if c is None:
+                    raise Panic()
                 while c.alive:
                     c.joiner = t
                     yield
-                if b & 1:
+                if (c.outcome == "cancelled") != bool(b & 1):      # .unwrap() / .unwrap_err()
                     raise Panic()
+            elif name == "ABORT":                   # AbortHandle::abort (task/join.rs:158-163)
+                c = self.handles.get(a)
+                if c is not None and c.alive:
+                    c.cancelled = True
+                    self.wake(c)
+            elif name == "KILL":
+                self.kill(a)
+            elif name == "RESTART":
+                self.restart(a)
+            elif name == "PAUSE":
+                self.node_info[a].paused = True
+            elif name == "RESUME":
+                self.resume(a)
+            elif name == "ASSERT_EXIT":             # Handle::is_exit
+                if self.node_info[a].killed != bool(b & 1):
+                    raise Panic()
+            elif name == "BUILD":                   # create_node().init(..).build() inside a task body
+                for p in range(1, len(self.progs)):
+                    if self.progs[p][0] == a and (self.progs[p][1] & A.PROG_INIT) and not (self.progs[p][1] & A.PROG_PRE):
+                        self.spawn(p, self.node_info[a], record=False)
+            elif name == "ADVANCE":                 # time::advance (time/mod.rs:103-106)
+                self.clock += dur
+                self.expire(self.clock)
             elif name == "YIELD":
                 self.wake(t)
                 yield
             elif name == "PANIC":
-                raise Panic()
+                raise Panic(imm & 0xFF if a == 0 else (self.flags[b & 3] + imm) & 0xFF)
             elif name == "HOOK_REQ":                # NetSim::hook_rpc_req::<R>(node, f): HashMap::insert
                 self.hooks_req[a] = (lambda tag, code, want_tag=b >> 8, all_=b & 1, want=imm & 0xFF:
                                      not (tag == want_tag and (all_ or code == want)))
@@ -506,8 +627,12 @@ class Sim:
                         raise Panic()               # .unwrap()
                     t.val = err
                 else:
-                    mbox = dict(owner=t, regs=[], msgs=[], addr=(ip, port), connq=[], conn_closed=False, acceptor=None)
-                    mbox["guard"] = Arc(lambda node=t.node, sock=mbox: self.guard_drop(node, sock))
+                    mbox = dict(owner=t, regs=[], msgs=[], addr=(ip, port), connq=[], conn_closed=False, acceptor=None,
+                                node=t.node, ep_alive=True)
+                    mbox["in_table_or_ep"] = (lambda sock=mbox, node=t.node:
+                                              sock["ep_alive"] or self.node_sockets[node].get(sock["addr"]) is sock)
+                    mbox["guard"] = Arc(lambda info=t.info, node=t.node, sock=mbox: self.guard_drop(info, node, sock))
+                    self.all_socks.append(mbox)
                     self.node_sockets[t.node][(ip, port)] = mbox
                     self.bound[a] = mbox; t.owned.append(a)
                     self.addr[a] = (ip, port)       # ep.local_addr()
@@ -597,7 +722,10 @@ class Sim:
     def run(self, time_limit=0):
         self.base_ns = (60 * 60 * 24 * 365 * 52 + self.gen_range(0, 60 * 60 * 24 * 365)) * 10**9   # not logged
         self.logging = True
-        main = self.spawn(0)
+        for p in range(1, len(self.progs)):         # `node.spawn(..)` / init tasks of nodes built ahead of block_on, in order
+            if self.progs[p][1] & A.PROG_PRE:
+                self.spawn(p, self.node_info[self.progs[p][0]], record=not (self.progs[p][1] & A.PROG_INIT))
+        main = self.spawn(0, self.node_info[0], record=False)
         verdict = A.PASS
         while True:
             panicked = False
@@ -605,19 +733,34 @@ class Sim:
                 idx = self.gen_range(0, len(self.ready))
                 t = self.ready[idx]
                 self.ready[idx] = self.ready[-1]; self.ready.pop()
-                self.steps += 1
-                t.sched, t.running = False, True
-                try:
-                    next(t.gen)
-                except StopIteration:
-                    self.finish(t)
-                except Panic:
-                    panicked = True
-                    break
-                if t.alive:
-                    t.running = False
-                    if t.sched:
-                        self.ready.append(t)
+                if t.cancelled or t.info.killed:    # cancelled task or killed node: drop the future (:269-273)
+                    self.steps += 1
+                    self.finish(t, "cancelled")
+                elif t.info.paused:                 # paused task: push to the node's waiting list, no poll, no time advance
+                    self.paused[t.info.node].append(t)
+                    continue
+                else:
+                    self.steps += 1
+                    t.sched, t.running = False, True
+                    try:
+                        next(t.gen)
+                    except StopIteration:
+                        self.finish(t, "completed")
+                    except Panic as e:
+                        flags, match = self.node_flags[t.info.node]
+                        if not (flags & A.NODE_RESTART_ON_PANIC or (flags & A.NODE_RESTART_MATCHING and e.code in match)):
+                            panicked = True         # resume_unwind
+                            break
+                        # async-task's guard drops the future while unwinding (the node is not killed yet), then (:301-313)
+                        self.finish(t, "cancelled")
+                        delay = self.gen_duration_once(1 * 10**9, 10 * 10**9)
+                        node = t.info.node
+                        self.kill(node)
+                        self.timer_add(self.clock + delay, lambda node=node: self.restart(node))
+                    if t.alive:
+                        t.running = False
+                        if t.sched:
+                            self.ready.append(t)
                 self.clock += self.gen_range(50, 100)
                 self.expire(self.clock)
             if panicked:
@@ -639,14 +782,17 @@ class Sim:
 
 
 def workloads():
+    """name -> (workload, the Config it was generated for or None).  Every entry runs under Config::default() and 20 % loss;
+    entries with a Config of their own (non-default latency ranges, buggify, loss tables) under that one too."""
+    import random
+    from tests import fuzz
     from tests import lifecycle_workloads as LW
-    out = {"pingpong_4x2": W.pingpong(4, 2),
-           "receiver_drop": LW.receiver_drop(),
-           "request_timeout_with_stale_timers": LW.request_timeout_with_stale_timers(),
-           "rpc_echo": LW.rpc_echo(),
-           "rpc_call_timeout_then_retry": LW.rpc_call_timeout_then_retry(),
-           "std_system_time": LW.std_system_time(),
-           "getrandom_deterministic": LW.getrandom_deterministic()}
+    out = {"pingpong_4x2": (W.pingpong(4, 2), None)}
+    # every reference-shaped workload of tests/lifecycle_workloads.py: timeouts, dropped receivers, typed RPC, hooks, address
+    # resolution, ephemeral ports, the reliable channel, and the node lifecycle (kill / restart / pause / resume / abort /
+    # init + exit / restart_on_panic[_matching]) restated literally in this file
+    for name in sorted(LW.ALL):
+        out[name] = (LW.ALL[name](), LW.config(name))
     # a lossy, clogged RPC retry loop: call_timeout until it succeeds, while the supervisor clogs the server for a while
     wl = W.WorkloadBuilder()
     ns, nc = wl.create_node(), wl.create_node()
@@ -657,41 +803,51 @@ def workloads():
     c = wl.task(nc); c.bind(acl); c.sleep(ms=5); c.set(0, 6)
     top = c.label(); c.rpc_call(acl, asv, 2, 77, timeout_ms=40); c.trace_val(); c.sleep_rand(lo_ms=0, ms=30); c.djnz(0, top)
     m = wl.main(); m.spawn(s); m.spawn(c); m.sleep(ms=60); m.clog_node(ns, "in"); m.sleep(ms=90); m.unclog_node(ns, "in"); m.join(c)
-    out["rpc_retry_under_clog"] = wl.build()
-    # round 2: address resolution (network.rs:206-313) and NetSim hooks (net/mod.rs:240-284)
-    for name in ("endpoint_localhost", "endpoint_bind", "net_wildcard_and_unbound_port", "net_ipless_node",
-                 "net_ipless_node_own_socket_panics", "rpc_hooks"):
-        out[name] = LW.ALL[name]()
-    import random
-    from tests import fuzz
-    for k in range(24):                             # random programs over mixed address kinds / IP-less nodes
-        out["addr_fuzz_%02d" % k] = fuzz.random_addr_workload(random.Random(880000 + k))[0]
-    for name in ("endpoint_bind_ephemeral", "ephemeral_clients"):     # port 0 (network.rs:224-236), literally
-        out[name] = LW.ALL[name]()
-    for k in range(16):
-        out["ephemeral_fuzz_%02d" % k] = fuzz.random_ephemeral_workload(random.Random(870000 + k))[0]
-    # the reliable channel, literally (Arc<BindGuard> clones in every Sender / Receiver, async_channel accept queue,
-    # the backoff stream): the reference-shaped workloads and random programs about who keeps an address bound
-    for name in ("kv_rpc", "channel_backoff", "connect_refused_and_reset", "channel_wildcard_listener", "channel_loopback"):
-        out[name] = LW.ALL[name]()
-    for k in range(24):
-        out["channel_fuzz_%02d" % k] = fuzz.random_channel_workload(random.Random(860000 + k))[0]
-    for k in range(12):                             # random typed-RPC programs with hooks — those without node lifecycle
-        w, _, _ = fuzz.random_rpc_workload(random.Random(890000 + k), hooks=True)
-        ops = {OPN[w.insns[i].op] for i in range(w.struct.n_insns)}
-        if not ops & {"KILL", "RESTART", "BUILD"} and not any(w.progs[i].flags for i in range(w.struct.n_progs)):
-            out["rpc_hook_fuzz_%02d" % k] = w
+    out["rpc_retry_under_clog"] = (wl.build(), None)
+    # random programs of every generator in tests/fuzz.py (fixed seeds)
+    for gen, base, n in (("random_workload", 810000, 16), ("random_lifecycle_workload", 820000, 24), ("random_rpc_workload", 830000, 16),
+                         ("random_addr_workload", 880000, 24), ("random_ephemeral_workload", 870000, 16),
+                         ("random_channel_workload", 860000, 24)):
+        for k in range(n):
+            r = getattr(fuzz, gen)(random.Random(base + k))
+            out["%s_%02d" % (gen.replace("random_", "fuzz_").replace("_workload", ""), k)] = (r[0], r[1])
+    for k in range(12):                             # random typed-RPC programs with hooks
+        r = fuzz.random_rpc_workload(random.Random(890000 + k), hooks=True)
+        out["fuzz_rpc_hooks_%02d" % k] = (r[0], r[1])
     return out
 
 
+CFG_FIELDS = ("packet_loss_rate", "lat_lo_ns", "lat_hi_ns", "buggify")
+
+
+def cfg_to_json(cfg):
+    return dict({f: getattr(cfg, f) for f in CFG_FIELDS}, loss_table=[cfg.loss_table[i] for i in range(4)])
+
+
+def cfg_from_json(d):
+    return A.Config.default(packet_loss_rate=d["packet_loss_rate"], lat_lo_ns=d["lat_lo_ns"], lat_hi_ns=d["lat_hi_ns"],
+                            buggify=bool(d["buggify"]), loss_table=tuple(d["loss_table"]))
+
+
 def main():
+    import hashlib
     ex = {}
-    for name, w in workloads().items():
+    for name, (w, own) in workloads().items():
         ex[name] = {}
-        for cfgname, cfg in (("default", A.Config.default()), ("loss20", A.Config.default(packet_loss_rate=0.2))):
-            ex[name][cfgname] = {str(seed): Sim(w, cfg, seed).run() for seed in (0, 1, 2, 3, 99, 123456789)}
-    json.dump(ex, open(os.path.join(HERE, "executor_kat_async.json"), "w"), indent=1)
-    print("wrote executor_kat_async.json")
+        cfgs = [("default", A.Config.default()), ("loss20", A.Config.default(packet_loss_rate=0.2))]
+        if own is not None:
+            cfgs.append(("own", own))
+            ex[name]["_own_config"] = cfg_to_json(own)
+        fuzzed = name.startswith("fuzz_")
+        for cfgname, cfg in cfgs:
+            ex[name][cfgname] = {}
+            for seed in ((0, 1, 99) if fuzzed else (0, 1, 2, 3, 99, 123456789)):
+                r = Sim(w, cfg, seed).run()
+                if fuzzed:                          # random programs: the log's digest instead of its bytes
+                    r["log_sha256"] = hashlib.sha256(bytes.fromhex(r.pop("log"))).hexdigest()[:32]
+                ex[name][cfgname][str(seed)] = r
+    json.dump(ex, open(os.path.join(HERE, "executor_kat_async.json"), "w"), indent=0, separators=(",", ":"))
+    print("wrote executor_kat_async.json", len(ex), "workloads")
 
 
 if __name__ == "__main__":
