@@ -258,6 +258,121 @@ async fn restart_on_panic_matching(_obs: Obs) -> Tail {
     unreachable!("the third panic ends the run")
 }
 
+/// net/endpoint.rs:470-513 `bind` (v4 cases) + network.rs:224-236 in detail; repo side: twin_workloads.py::bind_ephemeral.
+async fn bind_ephemeral(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let node = h.create_node().ip("10.0.0.1".parse().unwrap()).build();
+    let _other = h.create_node().ip("10.0.0.2".parse().unwrap()).build();
+    let o = obs.clone();
+    let f = node.spawn(async move {
+        let port = |ep: &Endpoint| ep.local_addr().unwrap().port() as u64;
+        let any_a = Endpoint::bind("0.0.0.0:0").await.unwrap();
+        o.push(port(&any_a));
+        let lo_a = Endpoint::bind("127.0.0.1:0").await.unwrap();
+        o.push(port(&lo_a));
+        let err = Endpoint::bind("10.0.0.2:0").await.err().unwrap();
+        assert_eq!(err.kind(), std::io::ErrorKind::AddrNotAvailable);
+        let ip100 = Endpoint::bind("10.0.0.1:100").await.unwrap();
+        o.push(port(&ip100));
+        drop(ip100);
+        let _ip100 = Endpoint::bind("10.0.0.1:100").await.unwrap();
+        let any_b = Endpoint::bind("0.0.0.0:0").await.unwrap();
+        o.push(port(&any_b));
+        let _any3 = Endpoint::bind("0.0.0.0:3").await.unwrap();
+        let any_c = Endpoint::bind("0.0.0.0:0").await.unwrap();
+        o.push(port(&any_c));
+        drop(any_a);
+        drop(any_c);
+        let any_c = Endpoint::bind("0.0.0.0:0").await.unwrap();
+        o.push(port(&any_c));
+        let any_a = Endpoint::bind("0.0.0.0:0").await.unwrap();
+        o.push(port(&any_a));
+        drop((lo_a, any_b, any_c, any_a));
+    });
+    f.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
+fn payload(v: u32) -> Box<dyn std::any::Any + Send + Sync> { Box::new(v) }
+fn value(p: Box<dyn std::any::Any + Send + Sync>) -> u64 { *p.downcast::<u32>().unwrap() as u64 }
+
+/// connect1 through general addresses (net/mod.rs:337-364): a 0.0.0.0:2379 listener, a client on 0.0.0.0:0 dialling
+/// 10.0.0.1:2379, three request / response pairs, then the server side is gone; repo side: twin_workloads.py::channel_wildcard.
+async fn channel_wildcard(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let ns = h.create_node().ip("10.0.0.1".parse().unwrap()).build();
+    let nc = h.create_node().ip("10.0.0.2".parse().unwrap()).build();
+    let o = obs.clone();
+    let _srv = ns.spawn(async move {
+        let ep = Endpoint::bind("0.0.0.0:2379").await.unwrap();
+        let (tx, mut rx, _) = ep.accept1().await.unwrap();
+        for _ in 0..3 {
+            o.push(value(rx.recv().await.unwrap()));
+            tx.send(payload(0x22)).await.unwrap();
+        }
+    });
+    let cl = nc.spawn(async move {
+        let ep = Endpoint::bind("0.0.0.0:0").await.unwrap();
+        time::sleep(Duration::from_millis(10)).await;
+        let (tx, mut rx) = ep.connect1("10.0.0.1:2379".parse().unwrap()).await.unwrap();
+        for _ in 0..3 {
+            tx.send(payload(0x11)).await.unwrap();
+            assert_eq!(value(rx.recv().await.unwrap()), 0x22);
+        }
+        assert_eq!(rx.recv().await.err().unwrap().kind(), std::io::ErrorKind::ConnectionReset);
+    });
+    cl.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
+/// Sender / Receiver keep their Endpoint's Arc<BindGuard> (endpoint.rs:181-210): the listener is dropped while the connection
+/// it accepted lives on in a handler task; binding the address again fails until the handler is done.  The client's second
+/// connect1 succeeds (the address is in the table) but nobody can accept it: its first recv is a ConnectionReset.
+/// repo side: twin_workloads.py::guard_keeps_address.
+async fn guard_keeps_address(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let ns = h.create_node().ip("10.0.0.1".parse().unwrap()).build();
+    let nc = h.create_node().ip("10.0.0.2".parse().unwrap()).build();
+    let o = obs.clone();
+    let srv = ns.spawn(async move {
+        let ep = Endpoint::bind("10.0.0.1:7").await.unwrap();
+        let (tx, mut rx, _) = ep.accept1().await.unwrap();
+        let handler = madsim::task::spawn(async move {
+            assert_eq!(value(rx.recv().await.unwrap()), 1);
+            time::sleep(Duration::from_millis(50)).await;
+            tx.send(payload(2)).await.unwrap();
+        });
+        drop(ep);
+        time::sleep(Duration::from_millis(5)).await;
+        o.push(match Endpoint::bind("10.0.0.1:7").await { Ok(_) => 0, Err(e) => { assert_eq!(e.kind(), std::io::ErrorKind::AddrInUse); 1 } });
+        handler.await.unwrap();
+        time::sleep(Duration::from_millis(5)).await;
+        o.push(match Endpoint::bind("10.0.0.1:7").await { Ok(_) => 0, Err(_) => 1 });
+    });
+    let o = obs.clone();
+    let cl = nc.spawn(async move {
+        let ep = Endpoint::bind("10.0.0.2:1").await.unwrap();
+        time::sleep(Duration::from_millis(10)).await;
+        let (tx, mut rx) = ep.connect1("10.0.0.1:7".parse().unwrap()).await.unwrap();
+        tx.send(payload(1)).await.unwrap();
+        time::sleep(Duration::from_millis(20)).await;
+        let o2 = o.clone();
+        let second = madsim::task::spawn(async move {     // (a task of its own, as in the table form: one (tx, rx) pair per task)
+            let ep2 = Endpoint::bind("10.0.0.2:2").await.unwrap();
+            let (_tx2, mut rx2) = ep2.connect1("10.0.0.1:7".parse().unwrap()).await.unwrap();
+            o2.push(match rx2.recv().await { Ok(_) => 0, Err(e) => { assert_eq!(e.kind(), std::io::ErrorKind::ConnectionReset); 1 } });
+        });
+        second.await.unwrap();
+        o.push(value(rx.recv().await.unwrap()));
+    });
+    srv.await.unwrap();
+    cl.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
 fn run_one(name: &str, seed: u64, loss: f64) -> String {
     let mut config = madsim::Config::default();
     config.net.packet_loss_rate = loss;
@@ -283,6 +398,9 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
                 "receiver_drop" => receiver_drop(o).await,
                 "localhost" => localhost(o).await,
                 "restart_on_panic_matching" => restart_on_panic_matching(o).await,
+                "bind_ephemeral" => bind_ephemeral(o).await,
+                "channel_wildcard" => channel_wildcard(o).await,
+                "guard_keeps_address" => guard_keeps_address(o).await,
                 other => panic!("unknown workload {other}"),
             }
         });

@@ -181,6 +181,73 @@ def restart_on_panic_matching():
     return wl.build()
 
 
+def bind_ephemeral():
+    wl = W.WorkloadBuilder()
+    n, other = wl.create_node(), wl.create_node()
+    any_a, any_b, any_c = (wl.addr(n, 0, ip="unspecified") for _ in range(3))
+    lo_a, foreign, ip100, any3 = wl.addr(n, 0, ip="loopback"), wl.addr(other, 0), wl.addr(n, 100), wl.addr(n, 3, ip="unspecified")
+    t = wl.task(n)
+    t.bind(any_a, port_to_val=True); t.trace_val()
+    t.bind(lo_a, port_to_val=True); t.trace_val()
+    t.try_bind(foreign); t.assert_val(A.VAL_ADDR_NOT_AVAILABLE)
+    t.bind(ip100, port_to_val=True); t.trace_val(); t.close(ip100); t.bind(ip100)
+    t.bind(any_b, port_to_val=True); t.trace_val()
+    t.bind(any3); t.bind(any_c, port_to_val=True); t.trace_val()
+    t.close(any_a); t.close(any_c)
+    t.bind(any_c, port_to_val=True); t.trace_val()
+    t.bind(any_a, port_to_val=True); t.trace_val()
+    t.done()
+    m = wl.main(); m.spawn(t); m.join(t)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def channel_wildcard():
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, dial, acl = wl.addr(ns, 2379, ip="unspecified"), wl.addr(ns, 2379), wl.addr(nc, 0, ip="unspecified")
+    srv = wl.task(ns); srv.bind(asv); srv.accept1(asv); srv.set(0, 3)
+    top = srv.label(); srv.chan_recv(); srv.trace_val(); srv.chan_send(0x22); srv.djnz(0, top); srv.done()
+    cl = wl.task(nc); cl.bind(acl); cl.sleep(ms=10); cl.connect1(acl, dial); cl.assert_val(0); cl.set(0, 3)
+    top = cl.label(); cl.chan_send(0x11); cl.chan_recv(); cl.assert_val(0x22); cl.djnz(0, top)
+    cl.chan_recv(); cl.assert_val(A.VAL_RESET); cl.done()
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.join(cl)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def guard_keeps_address():
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    a7, c1, c2 = wl.addr(ns, 7), wl.addr(nc, 1), wl.addr(nc, 2)
+    handler = wl.task(ns); handler.chan_recv(); handler.assert_val(1); handler.sleep(ms=50); handler.chan_send(2); handler.done()
+    srv = wl.task(ns); srv.bind(a7); srv.accept1(a7); srv.spawn(handler, move_conn=True)
+    srv.close(a7); srv.sleep(ms=5)
+    def trace_bind_outcome(t):                    # obs <- 1 if Err(AddrInUse) else 0
+        t.try_bind(a7)
+        ok = t.label() + 4
+        t.jeq(0, ok); t.assert_val(A.VAL_ADDR_IN_USE); t.trace(1); t.jmp(ok + 1)
+        assert t.label() == ok
+        t.trace(0)
+    trace_bind_outcome(srv)
+    srv.join(handler); srv.sleep(ms=5)
+    trace_bind_outcome(srv)
+    srv.done()
+    cl = wl.task(nc); cl.bind(c1); cl.sleep(ms=10); cl.connect1(c1, a7); cl.assert_val(0); cl.chan_send(1); cl.sleep(ms=20)
+    # the second connection rides on a helper task: one (tx, rx) pair per task in the table form
+    second = wl.task(nc); second.bind(c2); second.connect1(c2, a7); second.assert_val(0); second.chan_recv()
+    rst = second.label() + 3
+    second.jeq(A.VAL_RESET, rst); second.trace(0); second.jmp(rst + 1)
+    assert second.label() == rst
+    second.trace(1)
+    second.done()
+    cl.spawn(second); cl.join(second)
+    cl.chan_recv(); cl.trace_val(); cl.done()
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.join(srv); m.join(cl)
+    fingerprint_tail(m)
+    return wl.build()
+
+
 # workloads that end in a panic by design (the reference test is #[should_panic])
 EXPECT_PANIC = {"restart_on_panic_matching"}
 
@@ -189,4 +256,5 @@ ALL = {
     "sleep_1s": sleep_1s, "yield_order": yield_order, "timer_ties": timer_ties, "kill": kill, "restart": restart,
     "restart_on_panic": restart_on_panic, "receiver_drop": receiver_drop,
     "localhost": localhost, "restart_on_panic_matching": restart_on_panic_matching,
+    "bind_ephemeral": bind_ephemeral, "channel_wildcard": channel_wildcard, "guard_keeps_address": guard_keeps_address,
 }
