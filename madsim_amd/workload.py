@@ -265,11 +265,36 @@ class BuiltWorkload:
         return C.byref(self.struct)
 
 
+PAYLOAD_BASE = 0x40000000
+
+
 class WorkloadBuilder:
     def __init__(self):
         self.nodes = [A.Node()]  # node 0 = "madsim-main"
         self.socks = []
         self.tasks = [TaskBuilder(self, 0, 0)]
+        self.payloads = []       # interned byte strings: see payload()
+
+    def payload(self, data: bytes):
+        """The 32-bit value standing for the byte string `data` on the wire.  Payload bytes never steer the simulation
+        (a Payload is a Box<dyn Any> the network moves around, endpoint.rs:69-94): only the test body looks at them, and all
+        it can do in this VM is compare.  So byte strings are interned here — equal bytes <=> equal value — and
+        `assert_eq!(&buf[..len], b"..")` becomes assert_val(payload(b"..")).  Four-byte strings stand for themselves
+        (little-endian, like PING / PONG) unless they would look like an id or an error value; every other string gets
+        PAYLOAD_BASE + its index in the pool.  BuiltWorkload.payloads maps back."""
+        data = bytes(data)
+        v = int.from_bytes(data, "little")
+        if len(data) == 4 and not PAYLOAD_BASE <= v < PAYLOAD_BASE + 0x10000 and v < 0xFFFFFF00:
+            return v
+        if data not in self.payloads:
+            self.payloads.append(data)
+        return PAYLOAD_BASE + self.payloads.index(data)
+
+    def received(self, data: bytes, buf_len: int):
+        """What `recv_from(tag, &mut buf)` with a `buf_len`-byte buffer leaves of a message `data` (endpoint.rs:87-94):
+        (the value of &buf[..len], len) with len = min(buf.len(), data.len()) — a host-side computation, like the copy."""
+        n = min(buf_len, len(data))
+        return self.payload(bytes(data)[:n]), n
 
     def main(self):
         """The future handed to Runtime::block_on / the #[madsim::test] body."""
@@ -319,7 +344,9 @@ class WorkloadBuilder:
                 insns.append(A.Insn(op, a, (b + base) if reloc else b, imm))
         if len(insns) > 0xFFFF:
             raise ValueError("program too long")
-        return BuiltWorkload(self.nodes, progs, self.socks, insns)
+        built = BuiltWorkload(self.nodes, progs, self.socks, insns)
+        built.payloads = list(self.payloads)
+        return built
 
 
 def pingpong(n_nodes=4, rounds=64):

@@ -106,6 +106,30 @@ def test_send_recv_out_of_order_tags():
     assert summ.n_failed == 0 and (out["msg_count"] == 2).all()
 
 
+def test_send_recv_bytes_and_truncation():
+    """net/endpoint.rs:372-408 send_recv with its byte strings: `send_to(addr2, 1, &[1])`, a 16-byte receive buffer, and
+    `assert_eq!(len, 1); assert_eq!(buf[0], 1)`; then a long message into a short buffer (len = min(buf.len(), data.len()),
+    endpoint.rs:91-92).  Payloads are interned by the builder: the bytes never steer the simulation."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+    long_msg = b"a message longer than the receive buffer"
+    assert wl.payload(b"ping") == W.PING and wl.payload(long_msg) == wl.payload(bytes(long_msg)) >= W.PAYLOAD_BASE
+    s = wl.task(n1); s.bind(a1); s.sleep(ms=100); s.send_to(a1, a2, 1, wl.payload(bytes([1])))
+    s.sleep(secs=1); s.send_to(a1, a2, 2, wl.payload(long_msg))
+    r = wl.task(n2); r.bind(a2)
+    r.recv_from(a2, 2); r.assert_val(wl.payload(long_msg))                 # the raw payload; what a 16-byte buffer keeps of it:
+    got, n = wl.received(long_msg, 16)
+    assert n == 16 and got == wl.payload(long_msg[:16]) != wl.payload(long_msg)
+    r.recv_from(a2, 1); r.assert_val(wl.payload(bytes([1])))
+    assert wl.received(bytes([1]), 16) == (wl.payload(bytes([1])), 1)
+    m = wl.main(); m.spawn(s); m.spawn(r); m.join(r)
+    w = wl.build()
+    assert w.payloads == [long_msg, bytes([1]), long_msg[:16]]
+    out, summ = oracle.run_batch(w, 0, 32)
+    assert summ.n_failed == 0 and (out["msg_count"] == 2).all()
+
+
 def test_connect_send_recv_pingpong():
     """net/endpoint.rs:549-584 connect_send_recv: the literal ping/pong, one round."""
     out, summ = oracle.run_batch(W.pingpong(2, 1), 0, 32)
