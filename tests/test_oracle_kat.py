@@ -149,3 +149,24 @@ def test_executor_golden_async_formulation(name):
                 assert log.hex() == want["log"], (name, cfgname, seed)
             else:
                 assert hashlib.sha256(log).hexdigest()[:32] == want["log_sha256"], (name, cfgname, seed)
+
+
+def test_time_limit_verdicts_match_the_generator_restatement():
+    """Runtime::set_time_limit (task/mod.rs:253-258: checked after every advance_to_next_event) on random programs of three
+    generators, limits from 1 ns to 1 s: verdict, step count, clock and RNG position vs tests/golden/make_golden_async.py."""
+    import random
+    from tests import fuzz
+    mod = _async_mod()
+    n_limit = 0
+    for k in range(90):
+        gen = [fuzz.random_workload, fuzz.random_lifecycle_workload, fuzz.random_channel_workload][k % 3]
+        r = gen(random.Random(123000 + k))
+        w, cfg = r[0], r[1]
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        lim.time_limit_ns = random.Random(k).choice([1, 1_000_000, 5_000_000, 50_000_000, 1_000_000_000])
+        got, _ = oracle.run_batch(w, 0, 3, cfg, lim)
+        for s in range(3):
+            want = mod.Sim(w, cfg, s).run(lim.time_limit_ns)
+            assert {f: int(got[s][f]) for f in FIELDS} == {f: want[f] for f in FIELDS}, (k, s)
+            n_limit += want["verdict"] == A.TIME_LIMIT
+    assert n_limit > 100
