@@ -80,6 +80,18 @@ def test_fuzz_random_workloads():
 from tests import lifecycle_workloads as LW  # noqa: E402
 
 
+def test_trace_build_on_extended_workloads():
+    """The trace build (every op class, general addresses): raw log bytes + result on lifecycle / channel / RPC / address workloads."""
+    for name in ("kill_restart_with_traffic", "exited", "kv_rpc", "channel_wildcard_listener", "ephemeral_clients",
+                 "endpoint_bind_ephemeral", "rpc_hooks", "restart_on_panic_matching", "net_ipless_node"):
+        w, cfg, lim = LW.ALL[name](), LW.config(name), LW.limits(name)
+        for seed in (0, 3):
+            elog, eres = emu.trace_seed(w, seed, cfg, lim)
+            olog, ores = oracle.trace_seed(w, seed, cfg, lim)
+            assert tuple(eres) == ores.astuple(), (name, seed)
+            assert elog == olog, (name, seed)
+
+
 @pytest.mark.parametrize("name", sorted(LW.ALL))
 def test_lifecycle_reference_tests(name):
     """kill / restart / restart_on_panic / pause_resume / exited / join_cancelled ... (task/mod.rs:859-1182)."""

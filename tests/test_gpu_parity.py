@@ -58,6 +58,19 @@ def test_trace_log_bytes(hip):
         assert gres.astuple() == ores.astuple()
 
 
+def test_trace_log_bytes_extended_workloads(hip):
+    """The trace build (every op class, general addresses) on the lifecycle / channel / RPC / address workloads: raw log bytes
+    and result of a few seeds each, byte for byte — the log the golden fixture holds for the same workloads."""
+    for name in ("kill_restart_with_traffic", "exited", "kv_rpc", "channel_wildcard_listener", "ephemeral_clients",
+                 "endpoint_bind_ephemeral", "rpc_hooks", "restart_on_panic_matching", "net_ipless_node"):
+        w, cfg, lim = LW.ALL[name](), LW.config(name), LW.limits(name)
+        for seed in (0, 3):
+            glog, gres = hip.trace_seed(w, seed, cfg, lim)
+            olog, ores = oracle.trace_seed(w, seed, cfg, lim)
+            assert gres.astuple() == ores.astuple(), (name, seed)
+            assert glog == olog, (name, seed)
+
+
 def test_fuzz_random_workloads_gpu(hip):
     """Random actor programs (every verdict, clog/set_loss/close/yield, HBM spill path) through the C-ABI."""
     import random
