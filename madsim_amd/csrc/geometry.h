@@ -215,7 +215,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     if (L.state_mem > MADSIM_STATE_GLOBAL) return fail(err, MADSIM_E_LIMITS, "state_mem must be 0 (auto), 1 (LDS) or 2 (global)");
     P.gstate_mode = 0;
     // base-op builds: no owner word per socket (the owner's slot rides in the header, k_state.h) and 8-byte unit1
-    P.sock_words = (P.lifecycle ? 2 : 1) + P.mbox_regs + 2 * P.mbox_msgs + (P.uses_chan ? 2 : 0);
+    P.sock_words = (P.lifecycle ? 2 : 1) + P.mbox_regs + 2 * P.mbox_msgs + (P.uses_chan ? 3 : 0);   // + accept queue (2 words), parked acceptor
     if (!P.lifecycle && P.mbox_msgs > 127) return fail(err, MADSIM_E_LIMITS, "mbox_msgs must be <= 127 for workloads without extended ops");
     const uint32_t task_bytes = P.lifecycle ? P.task_units * 16 : 24;
     const uint32_t heap_bytes = P.lifecycle ? 16 : 12;        // base ops: {deadline 8, meta 4}, no payload word (k_timer.h)

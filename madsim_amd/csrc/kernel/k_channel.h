@@ -78,15 +78,28 @@ __device__ __forceinline__ void conn_drop_raw(const Ctx& c, Lane& L, uint32_t id
     CONNW(id, 0) = cw;
 }
 
+// conn_tx / conn_rx of an Endpoint (endpoint.rs:18,307): up to MADSIM_ACCEPTQ connection ids waiting for accept1, as one
+// 64-bit word — count in bits 0-3, 7-bit ids from bit 4 — in socket fields base (low half; its low 4 bits are the count, so
+// "is anything queued" needs one load) and base + 2; field base + 1 is the parked acceptor.
+constexpr uint32_t MADSIM_ACCEPTQ = 8;
+template <class K> __device__ __forceinline__ uint64_t acceptq_load(const Ctx& c, uint32_t s) {
+    const uint32_t base = 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs;
+    return u64of(SW(c, s, base), SW(c, s, base + 2));
+}
+template <class K> __device__ __forceinline__ void acceptq_store(const Ctx& c, uint32_t s, uint64_t q) {
+    const uint32_t base = 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs;
+    SW(c, s, base) = (uint32_t)q; SW(c, s, base + 2) = (uint32_t)(q >> 32);
+}
+
 // the EndpointSocket is freed: the connections still queued in conn_tx go with it (nobody accepted them, so their
 // server-side handles are the raw pair: no BindGuard clones)
 template <class K>
 __device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s) {
     uint32_t base = 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs;
-    uint32_t q = SW(c, s, base);
-    SW(c, s, base) = 0; SW(c, s, base + 1) = 0;
-    uint32_t n = q & 0xf;
-    for (uint32_t i = 0; i < n; i++) conn_drop_raw<K>(c, L, (q >> (4 + 7 * i)) & 0x7f, 1);
+    uint64_t q = acceptq_load<K>(c, s);
+    acceptq_store<K>(c, s, 0); SW(c, s, base + 1) = 0;
+    uint32_t n = (uint32_t)q & 0xf;
+    for (uint32_t i = 0; i < n; i++) conn_drop_raw<K>(c, L, (uint32_t)(q >> (4 + 7 * i)) & 0x7f, 1);
 }
 
 // Every Sender / Receiver holds a clone of its Endpoint's Arc<BindGuard> (endpoint.rs:181-190,203-210), so an address stays

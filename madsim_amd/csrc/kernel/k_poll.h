@@ -186,11 +186,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     // accept1's conn_rx.recv() (endpoint.rs:200): take the oldest queued connection or park. true = op completed.
     auto accept_check = [&](uint32_t a) -> bool {
         uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
-        uint32_t q = SW(c, a, base);
-        uint32_t n = q & 0xf;
+        uint32_t n = SW(c, a, base) & 0xf;
         if (n == 0) { SW(c, a, base + 1) = 1u | (slot << 1) | (gen << 9); st = ST_PENDING; return false; }
-        uint32_t id = (q >> 4) & 0x7f;
-        SW(c, a, base) = (n - 1) | ((q >> 11) << 4);           // pop front
+        uint64_t q = acceptq_load<K>(c, a);
+        uint32_t id = (uint32_t)(q >> 4) & 0x7f;
+        acceptq_store<K>(c, a, (uint64_t)(n - 1) | ((q >> 11) << 4));           // pop front
         uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
         if ((cx & 0xff) != 0xff) conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0);
         TWORD(c, slot, c.P.chan_unit, 0) = id | (1u << 8);                 // server side
@@ -278,8 +278,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         uint32_t id = 0;
                         while (id < P.max_conns && (CONNW(id, 0) & 1)) id++;
                         uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
-                        uint32_t q = SW(c, ds, base);
-                        if (id >= P.max_conns || (q & 0xf) >= 4) { L.ovf = 1; }
+                        uint64_t q = acceptq_load<K>(c, (uint32_t)ds);
+                        if (id >= P.max_conns || ((uint32_t)q & 0xf) >= MADSIM_ACCEPTQ) { L.ovf = 1; }
                         else {
                             CONNW(id, 0) = 1u | (a << 1) | ((b & 0xff) << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
@@ -289,8 +289,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                             if (SW(c, ds, 1) == ~0u) {             // the listener's Endpoint is gone (connections it accepted hold the
                                 conn_drop_raw<K>(c, L, id, 1);     // address): `let _ = conn_tx.try_send(..)` drops (tx2, rx1) here
                             } else {
-                                uint32_t n = q & 0xf;              // socket.new_connection -> conn_tx.try_send
-                                SW(c, ds, base) = (q & ~0xfu) | (n + 1) | (id << (4 + 7 * n));
+                                uint32_t n = (uint32_t)q & 0xf;    // socket.new_connection -> conn_tx.try_send
+                                acceptq_store<K>(c, (uint32_t)ds, (q & ~0xfull) | (n + 1) | ((uint64_t)id << (4 + 7 * n)));
                                 uint32_t acc = SW(c, ds, base + 1);
                                 if (acc & 1) { SW(c, ds, base + 1) = 0; wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9); }
                             }
@@ -323,7 +323,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         sock_bind<K>(c, a, slot, gen);                     // bound, gen+1, empty mailbox, owned by this task
                         u0.x |= TF_OWNER;
                         if (K::G) OMASK(a >> 5) |= 1u << (a & 31);
-                        if (K::FC && P.uses_chan) { SW(c, a, 2 + P.mbox_regs + 2 * P.mbox_msgs) = 0; SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
+                        if (K::FC && P.uses_chan) { acceptq_store<K>(c, a, 0); SW(c, a, 3 + P.mbox_regs + 2 * P.mbox_msgs) = 0; }
                     }
                 } else if (op == MS_OP_SEND || op == MS_OP_REPLY || (K::FR && op == MS_OP_RPC_REPLY)) {   // net/mod.rs:307-331
                     REG(6);
