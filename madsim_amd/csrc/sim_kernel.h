@@ -93,6 +93,7 @@ struct KParams {
     X(false, true, -1, MADSIM_FEAT_ALL, false, false)  \
     X(false, true, 6, MADSIM_FEAT_TIME, false, true)   \
     X(false, true, 6, MADSIM_FEAT_CHAN, false, true)   \
+    X(false, true, 6, MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR, false, true) \
     X(false, true, 6, MADSIM_FEAT_ALL, false, true)
 
 // Which compiled specialisation of sim_kernel a parameter block runs on (one rule for the launcher and for
@@ -108,7 +109,10 @@ inline VariantSel select_variant(const KParams& P, bool trace) {
     // single-class workloads: a build without the other classes' code
     // (general address resolution only exists in the full build: rare, and it would cost the lean builds ~5 %)
     const int cls = (feat & ~MADSIM_FEAT_TIME) == 0 ? MADSIM_FEAT_TIME : (feat & ~MADSIM_FEAT_CHAN) == 0 ? MADSIM_FEAT_CHAN : MADSIM_FEAT_ALL;
-    if (P.gstate_mode) return {0, 1, 6, cls, 0, 1};                      // task table + planes in global memory: full waves
+    if (P.gstate_mode) {                                                // task table + planes in global memory: full waves
+        if (cls == MADSIM_FEAT_ALL && !(feat & MADSIM_FEAT_ADDR)) return {0, 1, 6, MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR, 0, 1};   // plain addresses
+        return {0, 1, 6, cls, 0, 1};
+    }
     if (cls != MADSIM_FEAT_ALL) return {0, 1, -1, cls, 0, 0};
     if (lw == 6) return {0, spill, 6, MADSIM_FEAT_ALL, 0, 0};
     if (lw >= 3 && lw <= 5) return {0, 1, lw, MADSIM_FEAT_ALL, 0, 0};

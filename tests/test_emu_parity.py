@@ -126,9 +126,10 @@ def test_baseline_config_shaped_workloads():
 
 def test_every_bench_workload_runs_on_the_build_its_ops_need():
     """select_variant: single-class workloads get the pruned builds (timeouts only / channel only), base-op workloads never
-    pay for extended ops, and only mixed workloads take the full build."""
+    pay for extended ops, mixed workloads take the full build — without general address resolution (FEAT 15) when every
+    address is a plain node IP and the state lives in global memory."""
     from madsim_amd import runtime
-    want = {"pingpong": (0, 6, 0), "timers": (0, 15, 0), "raft": (1, 6, 16), "kv": (2, 6, 16), "topo": (31, 6, 16)}
+    want = {"pingpong": (0, 6, 0), "timers": (0, 15, 0), "raft": (1, 6, 16), "kv": (2, 6, 16), "topo": (15, 6, 16)}
     for name, (feat, lws, glob) in want.items():
         w, lim, _ = W.bench_case(name)
         g = runtime.geometry(w, lim)
