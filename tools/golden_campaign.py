@@ -14,12 +14,13 @@ import make_golden_async as G
 FIELDS = ("verdict", "steps", "clock_ns", "msg_count", "rng_calls", "trace_hash", "obs_hash")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 base = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
-gens = ["random_workload", "random_lifecycle_workload", "random_rpc_workload", "random_addr_workload",
+gens = ["random_workload", "random_lifecycle_workload", "random_rpc_workload", "random_rpc_workload+hooks", "random_addr_workload",
         "random_ephemeral_workload", "random_channel_workload"]
 t0 = time.time(); total = 0; verdicts = collections.Counter()
 for gi, gname in enumerate(gens):
     for k in range(n):
-        r = getattr(fuzz, gname)(random.Random(base + 100_000 * gi + k))
+        rng = random.Random(base + 100_000 * gi + k)
+        r = fuzz.random_rpc_workload(rng, hooks=True) if gname.endswith("+hooks") else getattr(fuzz, gname)(rng)
         w, cfg, desc = r[0], r[1], r[2]
         lim = fuzz.generous_limits(); lim.max_tasks = 24
         seeds = (0, 1, 2, 3, 7)
