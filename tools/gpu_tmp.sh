@@ -1,4 +1,6 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2h
-python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r2h/gputest.txt; cat gpurun_out/r2h/gputest.txt
-bash tools/gpu_exp.sh gpurun_exp.txt
+cd $GRAFT_REPO_ROOT
+bash tools/prof_workload.sh r2j_pp "" full
+bash tools/prof_workload.sh r2j_kv "--workload kv"
+bash tools/prof_workload.sh r2j_topo "--workload topo"
+for d in r2j_pp r2j_kv r2j_topo; do echo "== $d"; head -12 gpurun_out/$d/summary.txt; done
