@@ -243,7 +243,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             P.gs_plane_words = P.lane_words;
             P.gs_planes = P.max_tasks * P.task_units * 16;
             P.gs_stride = (P.gs_planes + P.gs_plane_words * 4 + 63) & ~63u;
-            P.off_amask = P.max_tasks;                         // LDS planes: ready queue, alive-task mask, owned-socket mask
+            P.off_amask = (P.max_tasks + 3) / 4;               // LDS planes: ready queue (a byte per entry), alive-task mask, owned-socket mask
             P.off_omask = P.off_amask + (P.max_tasks + 31) / 32;
             P.lane_words = P.off_omask + 2;
         }
@@ -278,11 +278,16 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         if (can_g && (L.state_mem == MADSIM_STATE_GLOBAL || (lw != 64 && !L.lanes_per_wave))) {
             P.gstate_mode = 1;
             // LDS now holds little more than the top of the timer heap.  Keep as much of the requested LDS quota as still
-            // lets eight full waves share a CU (two 4-wave workgroups, each with its copy of the tables): every level that
-            // stays in LDS is one global round trip less per sift (measured on the election loop: 16 -> 8 LDS entries costs
-            // 18 %, a seventh-wave-only geometry as much).  The rest moves to the coalesced spill region, same capacity.
-            const size_t per_seed = (g.lds_per_cu / 2 - sh_bytes) / (4 * 64);
-            const size_t fixed = 4 * ((size_t)P.max_tasks + (P.max_tasks + 31) / 32 + 2);
+            // lets the build's register budget decide the occupancy — three 4-wave workgroups per CU for builds that fit
+            // three waves per SIMD (<= 168 VGPRs), two otherwise — each workgroup with its copy of the tables.  Every level
+            // that stays in LDS is one global round trip less per sift, but with the [unit][lane] state layout a third wave
+            // per SIMD is worth more (election loop: 8 entries x 12 waves 6.5 G steps/s, 15 x 8 6.1).  The rest of the
+            // quota moves to the coalesced spill region, same capacity.
+            const madsim_k::VariantSel gsel = madsim_k::select_variant(P, trace);
+            const int gv = g.vgprs ? g.vgprs(&gsel) : -1;
+            const bool three = gv > 0 ? 512 / ((gv + 7) & ~7) >= 3 : gsel.feat != MADSIM_FEAT_ALL;
+            const size_t per_seed = (g.lds_per_cu / (three ? 3 : 2) - sh_bytes - 1280) / (4 * 64);
+            const size_t fixed = 4 * (((size_t)P.max_tasks + 3) / 4 + (P.max_tasks + 31) / 32 + 2);
             uint32_t fit = per_seed > fixed + 64 ? (uint32_t)((per_seed - fixed) / 16) : 4u;
             if (P.heap_lds > fit) { P.heap_spill += P.heap_lds - fit; P.heap_lds = fit; }
             continue;
@@ -306,7 +311,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // VGPR budget (tools/kernel_meta.sh): base builds ~110 VGPRs = 4 waves per SIMD, single-class builds 133 / 151 = 3,
     // the full extended build ~180 = 2
     const madsim_k::VariantSel vsel = madsim_k::select_variant(P, trace);
-    uint32_t cap = vsel.feat == 0 ? 16u : (vsel.feat == MADSIM_FEAT_TIME || vsel.feat == MADSIM_FEAT_CHAN) ? 12u : 8u;
+    uint32_t cap = vsel.feat == 0 ? 16u : (vsel.feat == MADSIM_FEAT_TIME || vsel.feat == MADSIM_FEAT_CHAN || (vsel.g && vsel.feat != MADSIM_FEAT_ALL)) ? 12u : 8u;
     if (g.vgprs) {                       // 512 VGPRs per SIMD lane, allocated in blocks of 8; at most 8 waves per SIMD
         int r = g.vgprs(&vsel);
         if (r > 0) { uint32_t per_simd = 512u / (uint32_t)((r + 7) & ~7); cap = 4u * (per_simd > 8 ? 8u : per_simd < 1 ? 1u : per_simd); }

@@ -10,7 +10,7 @@ template <class K>
 __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) {
     const KParams& P = c.P;
     if (K::G) {
-        for (uint32_t w = 0; w < P.gs_plane_words; w++) gs_store32(c.gs, c.gs_off + P.gs_planes + w * 4, 0);
+        for (uint32_t w = 0; w < P.gs_plane_words; w++) gs_store32(c.gs, gs_addr_word(c, P.gs_planes + w * 4), 0);
         for (uint32_t w = 0; w < (P.max_tasks + 31) / 32; w++) AMASK(w) = 0;
         OMASK(0) = 0; OMASK(1) = 0;
     }
@@ -39,10 +39,10 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
 // Global-state builds wait on memory most of the time (rocprofv3: 60-70 % of wave cycles), so they trade registers for
 // resident waves: MADSIM_G_WAVES_PER_EU waves per SIMD (the second __launch_bounds__ argument caps the VGPR budget).
 #ifndef MADSIM_G_WAVES_PER_EU
-#define MADSIM_G_WAVES_PER_EU 1
+#define MADSIM_G_WAVES_PER_EU 3
 #endif
 template <class K>
-__global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_kernel(const KParams P) {
+__global__ __launch_bounds__(256, !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : MADSIM_G_WAVES_PER_EU) void sim_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // workgroup-shared tables
     uint32_t* sh = SMEM;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
     const uint32_t glane = ((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane;
     c.spill_off = glane * 16u;
     c.spill = buf_make(P.spill, (uint64_t)P.heap_spill * P.total_lanes * 16u);
-    c.gs_off = glane * P.gs_stride;
+    c.gs_lane = glane;
     c.gs = buf_make(P.gstate, (uint64_t)P.gs_stride * P.total_lanes);
     c.tlog = P.trace_log;
 
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
         if (L.ready_len > 0) {
             // Latency hiding: the queue usually holds exactly one task, so ready[0] and its two state units are
             // loaded BEFORE the draw loop (whose rejection retries take hundreds of cycles) and used if idx == 0.
-            const uint32_t slot0 = K::RQ ? (uint32_t)(L.rq & 0xff) : RW(0);
+            const uint32_t slot0 = K::RQ ? (uint32_t)(L.rq & 0xff) : rq_get<K>(c, 0);
             const uint4 pu0 = TU(c, slot0, 0), pu1 = load_u1<K>(c, slot0);
             // try_recv_random (utils/mpsc.rs:73-83): idx drawn even when len == 1
             uint32_t idx = gen_index<K>(c, L, L.ready_len);
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256, K::G ? MADSIM_G_WAVES_PER_EU : 1) void sim_ker
                 L.rq = (L.rq & ~(0xffull << (8 * idx))) | (last << (8 * idx));
                 L.rq &= ~(0xffull << (8 * L.ready_len));
             } else {
-                if (idx != 0) { slot = RW(idx); u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot); }
-                if (idx != L.ready_len) RW(idx) = RW(L.ready_len);       // swap_remove
+                if (idx != 0) { slot = rq_get<K>(c, idx); u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot); }
+                if (idx != L.ready_len) rq_set<K>(c, idx, rq_get<K>(c, L.ready_len));       // swap_remove
             }
             L.steps++;
             bool panicked = false;

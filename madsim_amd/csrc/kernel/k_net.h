@@ -9,7 +9,7 @@ namespace madsim_k {
 template <class K>
 __device__ __forceinline__ void ready_push(const Ctx& c, Lane& L, uint32_t slot) {
     if (K::RQ) L.rq |= (uint64_t)slot << (8 * L.ready_len);
-    else RW(L.ready_len) = slot;
+    else rq_set<K>(c, L.ready_len, slot);
     L.ready_len++;
 }
 

@@ -113,10 +113,12 @@ struct Ctx {
     uint32_t prog0, sockt0, nodet0;   // word indices of the shared prog / socket-address / node tables
     BufRef spill;      // the HBM spill region: entry (slot, this lane) at byte (slot * P.total_lanes) * 16 + spill_off
     uint32_t spill_off;  // this lane's column: global lane * 16
-    // K::G builds: this lane's state block = P.gs_stride bytes at byte gs_off of the state buffer; task0 and the plane
-    // bases (sock0, hand0, node0, clog0, pause0, greg0, conn0) are then BYTE offsets inside that block
+    // K::G builds: the lane's state is P.gs_stride bytes — task units, then the plane words — laid out across the launch as
+    // [unit][global lane] (16-byte units) followed by [word][global lane] (4-byte words), so lanes that touch the same unit
+    // or word share cache lines.  task0 and the plane bases (sock0, hand0, node0, clog0, pause0, greg0, conn0) are BYTE
+    // offsets inside the lane's logical block; gs_addr_* turn such an offset into a byte offset in the buffer.
     BufRef gs;
-    uint32_t gs_off;
+    uint32_t gs_lane;   // global lane index
     // K::G builds keep two small indexes in LDS so the common scans never walk global memory: bit t of the alive mask =
     // task slot t holds a live task (spawn's free-slot search), bit s of the owner mask = socket s was bound by a task that
     // has not finished yet (task_finish's "which endpoints did this task own" search)
@@ -127,6 +129,17 @@ struct Ctx {
 
 template <class K> __device__ __forceinline__ uint32_t LWSH(const Ctx& c) { return K::LWS >= 0 ? (uint32_t)K::LWS : c.lws; }
 #define RW(i) SMEM[c.ready0 + ((i) << LWSH<K>(c))]
+// Entry i of the ready Vec (a task slot).  LDS-resident builds: one plane word per entry.  Global-state builds, where the
+// ready queue is most of what is left in LDS: four entries per word.
+template <class K> __device__ __forceinline__ uint32_t rq_get(const Ctx& c, uint32_t i) {
+    if (!K::G) return RW(i);
+    return (RW(i >> 2) >> ((i & 3u) * 8u)) & 0xffu;
+}
+template <class K> __device__ __forceinline__ void rq_set(const Ctx& c, uint32_t i, uint32_t slot) {
+    if (!K::G) { RW(i) = slot; return; }
+    const uint32_t sh = (i & 3u) * 8u, w = RW(i >> 2);
+    RW(i >> 2) = (w & ~(0xffu << sh)) | (slot << sh);
+}
 #define AMASK(i) SMEM[c.amask0 + ((i) << LWSH<K>(c))]
 #define OMASK(i) SMEM[c.omask0 + ((i) << LWSH<K>(c))]
 
@@ -176,10 +189,15 @@ template <> struct URef<true> {
 };
 template <bool G> __device__ __forceinline__ WRef<G> make_wref(const Ctx& c, uint32_t lds_at, uint32_t gs_at);
 template <> __device__ __forceinline__ WRef<false> make_wref<false>(const Ctx&, uint32_t lds_at, uint32_t) { return WRef<false>{lds_at}; }
-template <> __device__ __forceinline__ WRef<true> make_wref<true>(const Ctx& c, uint32_t, uint32_t gs_at) { return WRef<true>{c.gs, c.gs_off + gs_at}; }
+// logical offset `at` inside the lane's block -> byte offset in the state buffer (both regions: at * total_lanes + this lane)
+__device__ __forceinline__ uint32_t gs_addr_unit(const Ctx& c, uint32_t at) { return __umul24(at, c.P.total_lanes) + c.gs_lane * 16u; }            // at % 16 == 0
+__device__ __forceinline__ uint32_t gs_addr_uword(const Ctx& c, uint32_t at) { return __umul24(at & ~15u, c.P.total_lanes) + c.gs_lane * 16u + (at & 15u); }   // a word of a unit
+__device__ __forceinline__ uint32_t gs_addr_word(const Ctx& c, uint32_t at) { return __umul24(at, c.P.total_lanes) + c.gs_lane * 4u; }              // a plane word
+template <> __device__ __forceinline__ WRef<true> make_wref<true>(const Ctx& c, uint32_t, uint32_t gs_at) { return WRef<true>{c.gs, gs_addr_word(c, gs_at)}; }
+__device__ __forceinline__ WRef<true> make_uword_ref(const Ctx& c, uint32_t gs_at) { return WRef<true>{c.gs, gs_addr_uword(c, gs_at)}; }
 template <bool G> __device__ __forceinline__ URef<G> make_uref(const Ctx& c, uint32_t lds_at, uint32_t gs_at);
 template <> __device__ __forceinline__ URef<false> make_uref<false>(const Ctx&, uint32_t lds_at, uint32_t) { return URef<false>{lds_at}; }
-template <> __device__ __forceinline__ URef<true> make_uref<true>(const Ctx& c, uint32_t, uint32_t gs_at) { return URef<true>{c.gs, c.gs_off + gs_at}; }
+template <> __device__ __forceinline__ URef<true> make_uref<true>(const Ctx& c, uint32_t, uint32_t gs_at) { return URef<true>{c.gs, gs_addr_unit(c, gs_at)}; }
 // plane word `i` of the region starting at `base`
 template <class K> __device__ __forceinline__ WRef<K::G> plane_ref(const Ctx& c, uint32_t base, uint32_t i) {
     return make_wref<K::G>(c, base + (i << LWSH<K>(c)), base + i * 4u);
@@ -218,13 +236,17 @@ template <class K> __device__ __forceinline__ bool sock_owned_by(const Ctx& c, u
     if (K::LIFE) return SW(c, s, 1) == (slot | (gen << 16));
     return (h & 1) && (h >> 24) == slot;
 }
+template <bool G> __device__ __forceinline__ WRef<G> tword_gs(const Ctx& c, uint32_t gs_at);       // (K::G builds only)
+template <> __device__ __forceinline__ WRef<false> tword_gs<false>(const Ctx&, uint32_t) { return WRef<false>{0}; }
+template <> __device__ __forceinline__ WRef<true> tword_gs<true>(const Ctx& c, uint32_t gs_at) { return make_uword_ref(c, gs_at); }
 template <class K> __device__ __forceinline__ URef<K::G> tu_ref(const Ctx& c, uint32_t slot, uint32_t u) {
     if (!K::LIFE) return make_uref<K::G>(c, c.task0 + (slot << LWSH<K>(c)), 0);             // unit 0 (unit 1: load_u1 / TWORD)
     return make_uref<K::G>(c, c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c)), c.task0 + (slot * c.P.task_units + u) * 16u);
 }
 template <class K> __device__ __forceinline__ WRef<K::G> tword_ref(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) {
     if (!K::LIFE) return make_wref<K::G>(c, u == 0 ? (c.task0 + (slot << LWSH<K>(c))) * 4u + k : (c.task1 + (slot << LWSH<K>(c))) * 2u + k, 0);
-    return make_wref<K::G>(c, (c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c))) * 4u + k, c.task0 + (slot * c.P.task_units + u) * 16u + k * 4u);
+    if (K::G) return tword_gs<K::G>(c, c.task0 + (slot * c.P.task_units + u) * 16u + k * 4u);
+    return make_wref<K::G>(c, (c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c))) * 4u + k, 0);
 }
 // unit1 as a uint4 in registers; base-op builds hold {x, y} only
 template <class K> __device__ __forceinline__ uint4 load_u1(const Ctx& c, uint32_t slot) {

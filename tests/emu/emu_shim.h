@@ -21,6 +21,7 @@ extern thread_local uint32_t* emu_smem;
 #define __launch_bounds__(...)
 #define __restrict__
 static inline void __syncthreads() {}
+static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }   // emulated threads run one after another
 static inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 // tools/gstate_access_model.py: which words of the per-lane global state block the kernel touches, and how often
