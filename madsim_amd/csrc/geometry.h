@@ -278,15 +278,16 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         if (can_g && (L.state_mem == MADSIM_STATE_GLOBAL || (lw != 64 && !L.lanes_per_wave))) {
             P.gstate_mode = 1;
             // LDS now holds little more than the top of the timer heap.  Keep as much of the requested LDS quota as still
-            // lets the build's register budget decide the occupancy — three 4-wave workgroups per CU for builds that fit
-            // three waves per SIMD (<= 168 VGPRs), two otherwise — each workgroup with its copy of the tables.  Every level
+            // lets the build's register budget decide the occupancy — as many 4-wave workgroups per CU as the build fits waves
+            // per SIMD (three at <= 168 VGPRs, two above) — each workgroup with its copy of the tables.  Every level
             // that stays in LDS is one global round trip less per sift, but with the [unit][lane] state layout a third wave
             // per SIMD is worth more (election loop: 8 entries x 12 waves 6.5 G steps/s, 15 x 8 6.1).  The rest of the
             // quota moves to the coalesced spill region, same capacity.
             const madsim_k::VariantSel gsel = madsim_k::select_variant(P, trace);
             const int gv = g.vgprs ? g.vgprs(&gsel) : -1;
-            const bool three = gv > 0 ? 512 / ((gv + 7) & ~7) >= 3 : gsel.feat != MADSIM_FEAT_ALL;
-            const size_t per_seed = (g.lds_per_cu / (three ? 3 : 2) - sh_bytes - 1280) / (4 * 64);
+            uint32_t per_simd = gv > 0 ? 512u / (uint32_t)((gv + 7) & ~7) : gsel.feat != MADSIM_FEAT_ALL ? 3u : 2u;
+            per_simd = per_simd < 2 ? 2u : per_simd > 4 ? 4u : per_simd;         // workgroups of four waves, one wave per SIMD each
+            const size_t per_seed = (g.lds_per_cu / per_simd - sh_bytes - 1280) / (4 * 64);
             const size_t fixed = 4 * (((size_t)P.max_tasks + 3) / 4 + (P.max_tasks + 31) / 32 + 2);
             uint32_t fit = per_seed > fixed + 64 ? (uint32_t)((per_seed - fixed) / 16) : 4u;
             if (P.heap_lds > fit) { P.heap_spill += P.heap_lds - fit; P.heap_lds = fit; }
