@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-bash tools/prof_workload.sh r2j_pp "" full
-bash tools/prof_workload.sh r2j_kv "--workload kv"
-bash tools/prof_workload.sh r2j_topo "--workload topo"
-for d in r2j_pp r2j_kv r2j_topo; do echo "== $d"; head -12 gpurun_out/$d/summary.txt; done
+bash tools/prof_workload.sh r2k_raft "--workload raft"
+bash tools/prof_workload.sh r2k_topo "--workload topo"
+bash tools/prof_workload.sh r2k_kv "--workload kv"
+for d in r2k_raft r2k_topo r2k_kv; do echo "== $d"; grep -v "at::native\|rocclr\|summary_kernel\|keyflip" gpurun_out/$d/summary.txt | head -40; done
