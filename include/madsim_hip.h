@@ -253,8 +253,8 @@ typedef struct madsim_limits {
 
 #define MADSIM_STATE_AUTO   0u   /* LDS unless an extended-op workload's state leaves a CU fewer than 4 full waves       */
 #define MADSIM_STATE_LDS    1u   /* all per-seed state in LDS ([word][lane] planes)                                       */
-#define MADSIM_STATE_GLOBAL 2u   /* extended-op workloads: task table + planes in a per-lane block of global memory
-                                    (L2 / Infinity Cache / HBM), only the timer-heap top and the ready queue in LDS       */
+#define MADSIM_STATE_GLOBAL 2u   /* extended-op workloads: task table + planes in global memory ([unit][lane] across the launch:
+                                    L2 / Infinity Cache / HBM), only the timer-heap top and the ready queue in LDS       */
 
 #define MADSIM_SCHED_STATIC 0u   /* lane g runs seeds g, g+G, g+2G, ...                                */
 #define MADSIM_SCHED_QUEUE  1u   /* a finished lane pulls the next seed from a per-launch atomic counter */

@@ -211,7 +211,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     uint32_t lw = 64;
     uint32_t sh_bytes = 0;
     // Where the task table and the planes live (madsim_limits_t.state_mem): LDS, or — extended-op workloads whose state
-    // would leave a CU with fewer than four full waves — a per-lane block of global memory (Variant::G, k_state.h).
+    // would leave a CU with fewer than four full waves — global memory, [unit][lane] across the launch (Variant::G, k_state.h).
     if (L.state_mem > MADSIM_STATE_GLOBAL) return fail(err, MADSIM_E_LIMITS, "state_mem must be 0 (auto), 1 (LDS) or 2 (global)");
     P.gstate_mode = 0;
     // base-op builds: no owner word per socket (the owner's slot rides in the header, k_state.h) and 8-byte unit1

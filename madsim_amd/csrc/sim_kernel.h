@@ -51,8 +51,10 @@ struct KParams {
     uint32_t chan_unit;            // index of the task unit holding the (tx, rx) pair state
     uint32_t uses_rpc, rpc_unit;   // typed RPC: index of the task unit holding the response tags
     uint32_t rq_in_reg;        // the ready queue needs no LDS region (register variant)
-    // global-state builds (Variant::G): task table + planes of lane g = gs_stride bytes at gstate + g * gs_stride:
-    // [task units: max_tasks x task_units x 16 B][plane words (off_* count from gs_planes, the ready queue stays in LDS)]
+    // global-state builds (Variant::G): a lane's task table + planes are gs_stride logical bytes — [task units: max_tasks x
+    // task_units x 16 B][plane words (off_* count from gs_planes, the ready queue stays in LDS)] — stored across the launch
+    // as [unit][global lane] then [word][global lane] (k_state.h gs_addr_*): logical byte `at` of lane g lives at
+    // at * total_lanes + g * 16 (units) or + g * 4 (words)
     uint32_t gstate_mode, gs_stride, gs_planes, gs_plane_words;
     uint32_t off_amask, off_omask;     // LDS plane words (after the ready queue) of the alive-task / owned-socket masks
     uint8_t* gstate;
@@ -75,7 +77,7 @@ struct KParams {
 // build per (heap spill, register ready queue) combination plus a runtime-lane-stride build; single-class builds for
 // workloads that only use timeouts (FEAT_TIME) or only the reliable channel (FEAT_CHAN) — a third of the code and
 // fewer registers than the full build; the full build for every lane stride (64/32/16/8 seed lanes per wave, runtime);
-// and the global-state builds (G: task table + planes in a per-lane block of global memory) of the three extended classes.
+// and the global-state builds (G: task table + planes in global memory) of the three extended classes.
 #define MADSIM_FOR_EACH_VARIANT(X)                     \
     X(true, true, -1, MADSIM_FEAT_ALL, false, false)   \
     X(false, false, 6, 0, false, false)                \

@@ -589,7 +589,7 @@ def streaming_topology_limits():
 def raft_election_limits():
     """Device capacities the election loop needs (high-water marks over 40 000 seeds on the CPU oracle: timer heap 99
     — the duplicate timers of timeout() — so most of it lives in the HBM spill region; 67 dead recv registrations
-    per socket, 8 queued messages).  The mailboxes live in the per-lane global-memory block (Variant::G), so their
+    per socket, 8 queued messages).  The mailboxes live in global memory (Variant::G), so their
     capacity costs no LDS; rarer seeds still come back MADSIM_OVERFLOW and are re-run by run_batch_auto."""
     lim = A.Limits()
     lim.heap_lds_slots, lim.heap_spill_slots = 16, 240
