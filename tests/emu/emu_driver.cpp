@@ -48,9 +48,13 @@ extern "C" void madsim_emu_region_stats(double* trips, double* visits, double* i
 #ifdef MADSIM_EMU_GSTAT
 // per byte offset WITHIN a lane's state block: access counts by kind, summed over all lanes
 static std::vector<uint64_t> gstat[4];
-static uint32_t gstat_stride = 1;
+static uint32_t gstat_stride = 1, gstat_planes = 0, gstat_lanes = 1;
 void emu_gstat(uint32_t byte_off, int kind) {
-    uint32_t o = byte_off % gstat_stride;
+    // buffer offset -> logical offset inside the lane's state ([unit][lane] then [word][lane], k_state.h gs_addr_*)
+    uint32_t o;
+    if (byte_off < gstat_planes * gstat_lanes) o = byte_off / (gstat_lanes * 16u) * 16u + byte_off % 16u;
+    else o = gstat_planes + (byte_off - gstat_planes * gstat_lanes) / (gstat_lanes * 4u) * 4u;
+    o %= gstat_stride;
     if (gstat[kind].size() <= o / 4) gstat[kind].resize(o / 4 + 1);
     gstat[kind][o / 4]++;
 }
@@ -76,6 +80,9 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
     P.spill = P.heap_spill ? spill.data() : nullptr;
     std::vector<uint4> gstate((size_t)P.gs_stride * P.total_lanes / 16 + 4);
     P.gstate = P.gstate_mode ? (uint8_t*)gstate.data() : nullptr;
+#ifdef MADSIM_EMU_GSTAT
+    gstat_planes = P.gs_planes; gstat_lanes = P.total_lanes ? P.total_lanes : 1;
+#endif
     P.seed0 = seed0; P.count = count; P.out = out;
     uint64_t dummy_len = 0;
     P.trace_log = tlog; P.trace_cap = tcap; P.trace_len = tlen ? tlen : &dummy_len;
