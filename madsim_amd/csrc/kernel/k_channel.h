@@ -108,6 +108,12 @@ __device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_
 // ~0 in the owner word instead of unbinding.  BindGuard::drop runs with the last owner and does nothing when the binder's
 // NodeInfo is killed (net/mod.rs:483-493): reset_node has emptied the table — and the counts — by then.
 template <class K>
+__device__ __forceinline__ void guard_acquire(const Ctx& c, Lane& L, uint32_t s) {
+    const uint32_t h = SW(c, s, 0);
+    if ((h >> 25) == 0x7fu) { L.ovf = 1; return; }            // (a seven-bit count: 127 connection ends per socket)
+    SW(c, s, 0) = h + (1u << 25);
+}
+template <class K>
 __device__ __forceinline__ void guard_release(const Ctx& c, Lane& L, uint32_t s, bool node_killed) {
     if (node_killed) return;
     uint32_t h = SW(c, s, 0);

@@ -196,7 +196,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         TWORD(c, slot, c.P.chan_unit, 0) = id | (1u << 8);                 // server side
         // Sender { _guard: self.guard.clone(), tx }, Receiver { _guard: self.guard.clone(), rx } (endpoint.rs:203-210)
         CONNW(id, 0) = (CONNW(id, 0) & ~(0x7fu << 25)) | (a << 25) | (1u << 31);
-        SW(c, a, 0) += 1u << 25;
+        guard_acquire<K>(c, L, a);
         return true;
     };
     // the receiver stream of channel() (net/mod.rs:386-400) from "a payload is in hand" (sub 1): either sleep(backoff)
@@ -284,7 +284,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                             CONNW(id, 0) = 1u | (a << 1) | ((b & 0xff) << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
                             TWORD(c, slot, c.P.chan_unit, 0) = id;             // client side
-                            SW(c, a, 0) += 1u << 25;               // Sender / Receiver { _guard: self.guard.clone(), .. } (endpoint.rs:181-190)
+                            guard_acquire<K>(c, L, a);             // Sender / Receiver { _guard: self.guard.clone(), .. } (endpoint.rs:181-190)
                             u0.w = 0;
                             if (SW(c, ds, 1) == ~0u) {             // the listener's Endpoint is gone (connections it accepted hold the
                                 conn_drop_raw<K>(c, L, id, 1);     // address): `let _ = conn_tx.try_send(..)` drops (tx2, rx1) here
