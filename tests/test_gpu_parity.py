@@ -228,6 +228,11 @@ def test_cpp_host_mirror_runs_like_cargo_test(hip):
     if os.path.exists(exe2):
         p = subprocess.run([exe2], env=dict(os.environ, MADSIM_TEST_SEED="11", MADSIM_TEST_NUM="2048"), capture_output=True, text=True)
         assert p.returncode == 0 and "test rpc_survives_restart ... ok (2048 seeds from 11)" in p.stdout, p.stderr
+    # reliable connections from ephemeral ports to a 0.0.0.0 listener (examples/kv_client_test.cpp): under 5 % loss some seeds fail
+    exe3 = os.path.join(root, "examples", "kv_client_test")
+    if os.path.exists(exe3):
+        p = subprocess.run([exe3], env=dict(os.environ, MADSIM_TEST_SEED="5", MADSIM_TEST_NUM="2048"), capture_output=True, text=True)
+        assert p.returncode == 0 and "test kv_requests ... ok (2048 seeds from 5)" in p.stdout, p.stderr
     hip.init(0)
 
 
