@@ -51,6 +51,21 @@ __device__ __forceinline__ uint64_t rotl64(uint64_t x) {
     return ((uint64_t)nhi << 32) | nlo;
 }
 
+// a ^ b ^ c on 64 bits as one v_bitop3_b32 (truth table 0x96) per half: the compiler does not form it from two xors
+__device__ __forceinline__ uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) {
+    uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0x96);
+    uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0x96);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// a + b as ONE v_lshl_add_u64: when `a` was just assembled from two 32-bit halves the compiler reassociates the sum into a
+// 64-bit add of the low half plus a 32-bit add of the high half (three instructions with the zero-extension)
+__device__ __forceinline__ uint64_t add64_1(uint64_t a, uint64_t b) {
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // the threads of a workgroup share the copy of the workload tables into LDS: thread t copies words t, t + stride, ...
 __device__ __forceinline__ uint32_t table_copy_first() { return threadIdx.x; }
 __device__ __forceinline__ uint32_t table_copy_stride(uint32_t waves_per_block) { return 64 * waves_per_block; }

@@ -8,20 +8,29 @@ namespace madsim_k {
 // ---- GlobalRng ---------------------------------------------------------------------------------
 // Xoshiro256PlusPlus::next_u64 [DEP rand_xoshiro 0.6]
 __device__ __forceinline__ uint64_t rng_next(Lane& L) {
-    uint64_t r = rotl64<23>(L.s0 + L.s3) + L.s0;
-    uint64_t t = L.s1 << 17;
-    L.s2 ^= L.s0; L.s3 ^= L.s1; L.s1 ^= L.s2; L.s0 ^= L.s3;
-    L.s2 ^= t;
-    L.s3 = rotl64<45>(L.s3);
+    uint64_t r = add64_1(rotl64<23>(L.s0 + L.s3), L.s0);
+    // s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= s1 << 17 with the two three-input xors as one v_bitop3_b32 per half
+    const uint64_t t = L.s1 << 17;
+    const uint64_t d1 = L.s3 ^ L.s1;
+    const uint64_t b1 = xor3_64(L.s1, L.s2, L.s0);
+    const uint64_t c2 = xor3_64(L.s2, L.s0, t);
+    L.s0 ^= d1; L.s1 = b1; L.s2 = c2;
+    L.s3 = rotl64<45>(d1);
     L.rng_calls++;
     return r;
+}
+
+// rand 0.8's accept test `lo64(v * range) <= zone` for a range below 2^32: zone = (range << lz) - 1 has its low word all
+// ones, so only the high word of the low 64 product bits is compared: (v.hi * range + mulhi(v.lo, range)) mod 2^32.
+__device__ __forceinline__ bool reject32(uint64_t v, uint32_t range, uint32_t zone_hi) {
+    return (uint32_t)(v >> 32) * range + __umulhi((uint32_t)v, range) > zone_hi;
 }
 
 // One determinism-log byte per GlobalRng::with (rand.rs:64-88): clone.gen::<u8>() ^ xor-fold(elapsed).
 template <class K>
 __device__ __forceinline__ void rng_log(const Ctx& c, Lane& L) {
     if (!MADSIM_K_LOG_ENABLED) return;
-    uint64_t r = rotl64<23>(L.s0 + L.s3) + L.s0;   // what the clone's next_u64 would return
+    uint64_t r = add64_1(rotl64<23>(L.s0 + L.s3), L.s0);   // what the clone's next_u64 would return
     uint32_t v = (uint32_t)(r >> 32);
     uint32_t f = (uint32_t)L.clock ^ (uint32_t)(L.clock >> 32);
     f ^= f >> 16; f ^= f >> 8;
@@ -44,9 +53,9 @@ __device__ __forceinline__ uint64_t gen_range_u64(const Ctx& c, Lane& L, uint64_
 // ready-queue index draw: range = len <= 255, so the 128-bit product splits into two 32x32 pieces.
 template <class K>
 __device__ __forceinline__ uint32_t gen_index(const Ctx& c, Lane& L, uint32_t len) {
-    uint64_t zone = ((uint64_t)len << __builtin_clzll((uint64_t)len)) - 1;
     uint64_t v;
-    do { REG(1); v = rng_next(L); } while (EXP_ACCEPT(v * (uint64_t)len > zone));   // accept test on the low 64 bits only
+    const uint32_t zone_hi = (len << (__builtin_clz(len))) - 1;
+    do { REG(1); v = rng_next(L); } while (EXP_ACCEPT(reject32(v, len, zone_hi)));
     rng_log<K>(c, L);
     uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * len + (((uint64_t)(uint32_t)v * len) >> 32);
     return (uint32_t)(mid >> 32);                               // high 64 bits of v * len
@@ -56,8 +65,9 @@ __device__ __forceinline__ uint32_t gen_index(const Ctx& c, Lane& L, uint32_t le
 template <class K, uint32_t RANGE>
 __device__ __forceinline__ uint32_t gen_range_small(const Ctx& c, Lane& L) {
     constexpr uint64_t zone = ((uint64_t)RANGE << __builtin_clzll((uint64_t)RANGE)) - 1;
+    static_assert((uint32_t)zone == 0xffffffffu, "reject32 compares the high word only");
     uint64_t v;
-    do { REG(RANGE == 50 ? 18 : 16); v = rng_next(L); } while (EXP_ACCEPT(v * (uint64_t)RANGE > zone));
+    do { REG(RANGE == 50 ? 18 : 16); v = rng_next(L); } while (EXP_ACCEPT(reject32(v, RANGE, (uint32_t)(zone >> 32))));
     rng_log<K>(c, L);
     uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * RANGE + (((uint64_t)(uint32_t)v * RANGE) >> 32);
     return (uint32_t)(mid >> 32);

@@ -23,6 +23,7 @@ extern thread_local uint32_t* emu_smem;
 static inline void __syncthreads() {}
 static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }   // emulated threads run one after another
+static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 static inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 // tools/gstate_access_model.py: which words of the per-lane global state block the kernel touches, and how often
 #ifdef MADSIM_EMU_GSTAT
@@ -41,6 +42,8 @@ static inline void buf_store32(const BufRef& b, uint32_t off, uint32_t v) { *(ui
 static inline uint4 buf_load128(const BufRef& b, uint32_t off) { return *(const uint4*)(b.base + off); }
 static inline void buf_store128(const BufRef& b, uint32_t off, const uint4& e) { *(uint4*)(b.base + off) = e; }
 template <int K_> static inline uint64_t rotl64(uint64_t x) { return (x << K_) | (x >> (64 - K_)); }
+static inline uint64_t add64_1(uint64_t a, uint64_t b) { return a + b; }
+static inline uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) { return a ^ b ^ c; }
 static inline uint32_t table_copy_first() { return 0; }                   // emulated threads run one after another:
 static inline uint32_t table_copy_stride(uint32_t) { return 1; }          // each copies everything
 }
