@@ -78,6 +78,7 @@ struct KParams {
 // workloads that only use timeouts (FEAT_TIME) or only the reliable channel (FEAT_CHAN) — a third of the code and
 // fewer registers than the full build; the full build for every lane stride (64/32/16/8 seed lanes per wave, runtime);
 // and the global-state builds (G: task table + planes in global memory) of the three extended classes.
+#ifndef MADSIM_FOR_EACH_VARIANT      // (tools/ may compile a subset: -D'MADSIM_FOR_EACH_VARIANT(X)=X(false,false,6,0,true,false)')
 #define MADSIM_FOR_EACH_VARIANT(X)                     \
     X(true, true, -1, MADSIM_FEAT_ALL, false, false)   \
     X(false, false, 6, 0, false, false)                \
@@ -97,6 +98,7 @@ struct KParams {
     X(false, true, 6, MADSIM_FEAT_CHAN, false, true)   \
     X(false, true, 6, MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR, false, true) \
     X(false, true, 6, MADSIM_FEAT_ALL, false, true)
+#endif
 
 // Which compiled specialisation of sim_kernel a parameter block runs on (one rule for the launcher and for
 // madsim_hip_geometry's report).  Compiled set = MADSIM_FOR_EACH_VARIANT in sim_kernel.hip.
