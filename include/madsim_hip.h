@@ -168,6 +168,15 @@ typedef struct madsim_prog {
                                (runtime/mod.rs:405-418, task/mod.rs:395-400,472-474)                 */
 #define MADSIM_PROG_PRE  2u /* spawned before Runtime::block_on pushes the main task, in prog order:
                                `node.spawn(..)` ahead of `runtime.block_on(..)` (task/mod.rs:859-897) */
+#define MADSIM_PROG_DROP_SPAWN 4u /* the body owns a guard moved into it whose Drop calls task::spawn(program p + 1)
+                               (the reference tests spawn_in_future_drop_by_aborting_task / _by_killing_node,
+                               task/mod.rs:1185-1253): whenever an instance finishes — returns, or its future is
+                               dropped because it was aborted, its node killed or it panicked — after its other locals
+                               have dropped and before its JoinHandle awaiter is notified.  The child is spawned in the
+                               dying task's context (run_all_ready enters it for `drop` as for `run`, :284-287): same
+                               node, same NodeInfo incarnation, so a guard dropped by a kill spawns a task that is
+                               scheduled once and dropped unpolled.  Program p + 1 must run on the same node; not
+                               combined with MS_OP_PAUSE (a parked Runnable is dropped in the KILLER's context).    */
 
 /* A socket address an Endpoint may bind or a datagram may be sent to: an IP and a port.  `kind` picks the IP: the node's
  * own 10.0.0.<node>, 0.0.0.0 or 127.0.0.1 as used ON `node` (entries of the last two kinds are per node: only tasks of

@@ -192,9 +192,11 @@ class WorkloadBuilder {
     int addr(int node, uint16_t port, uint8_t kind = MADSIM_ADDR_IP) {
         socks_.push_back(madsim_sock_t{(uint8_t)node, kind, port}); return (int)socks_.size() - 1;
     }
-    Task& task(int node, bool init = false, bool before_block_on = false) {
+    // spawn_on_drop: the body owns a guard whose Drop calls task::spawn(<the NEXT task declared>) (MADSIM_PROG_DROP_SPAWN)
+    Task& task(int node, bool init = false, bool before_block_on = false, bool spawn_on_drop = false) {
         if (tasks_.size() >= 255) throw std::length_error("at most 255 task programs");
-        tasks_.push_back(Task((int)tasks_.size(), node, (uint8_t)((init ? MADSIM_PROG_INIT : 0) | (before_block_on ? MADSIM_PROG_PRE : 0))));
+        tasks_.push_back(Task((int)tasks_.size(), node, (uint8_t)((init ? MADSIM_PROG_INIT : 0) | (before_block_on ? MADSIM_PROG_PRE : 0) |
+                                                                 (spawn_on_drop ? MADSIM_PROG_DROP_SPAWN : 0))));
         return tasks_.back();
     }
     Workload build() {

@@ -119,6 +119,6 @@ OP = dict(
     KILL=30, RESTART=31, PAUSE=32, RESUME=33, CLOG_NODE=34, UNCLOG_NODE=35, CLOG_LINK=36,
     UNCLOG_LINK=37, ASSERT_EXIT=38, SET_LOSS=39, SLEEP_RAND=40, GSET=41, GADD=42, ASSERT_G=43, PANIC_IF_G_LT=44, JEQ=45, CONNECT=46, ACCEPT=47, CSEND=48, CRECV=49, CCLOSE=50, RPC_CALL=51, RPC_REPLY=52, RAND_BOOL=53, RANDOM=54, TRACE_TIME=55, HOOK_REQ=56, HOOK_RSP=57,
 )
-PROG_INIT, PROG_PRE = 1, 2
+PROG_INIT, PROG_PRE, PROG_DROP_SPAWN = 1, 2, 4
 NODE_RESTART_ON_PANIC = 1
 NODE_RESTART_MATCHING = 4

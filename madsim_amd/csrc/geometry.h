@@ -129,6 +129,13 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
         default: break;
         }
     }
+    for (uint32_t p = 0; p < w->n_progs; p++) {
+        if (!(w->progs[p].flags & MADSIM_PROG_DROP_SPAWN)) continue;
+        if (p + 1 >= w->n_progs || w->progs[p + 1].node != w->progs[p].node)
+            return fail(err, MADSIM_E_WORKLOAD, "MADSIM_PROG_DROP_SPAWN: the guard spawns program p + 1, which must exist and run on the same node");
+        if (uses_op(w, MS_OP_PAUSE))
+            return fail(err, MADSIM_E_WORKLOAD, "MADSIM_PROG_DROP_SPAWN cannot be combined with MS_OP_PAUSE (a parked Runnable is dropped in the killer's context)");
+    }
     if (cfg->lat_lo_ns >= cfg->lat_hi_ns) return fail(err, MADSIM_E_ARG, "send_latency: cannot sample empty range");
     if (!(cfg->packet_loss_rate >= 0.0 && cfg->packet_loss_rate <= 1.0)) return fail(err, MADSIM_E_ARG, "packet_loss_rate not in [0,1]");
     return 0;
@@ -205,6 +212,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         uses_op(w, MS_OP_ABORT) || uses_op(w, MS_OP_ASSERT_EXIT) || uses_op(w, MS_OP_BUILD)) P.features |= MADSIM_FEAT_NODE;
     for (uint32_t i = 0; i < w->n_progs; i++) if (w->progs[i].flags & MADSIM_PROG_INIT) P.features |= MADSIM_FEAT_NODE;
     if (!P.uniq_addr) P.features |= MADSIM_FEAT_ADDR;
+    for (uint32_t i = 0; i < w->n_progs; i++)          // guards that spawn in Drop: compiled into the full builds only
+        if (w->progs[i].flags & MADSIM_PROG_DROP_SPAWN) P.features |= MADSIM_FEAT_NODE | MADSIM_FEAT_ADDR;
     if (trace) P.features = MADSIM_FEAT_ALL;          // the trace build carries every class
     P.lifecycle = P.features != 0;
     const uint32_t cus = g.num_cus > 0 ? (uint32_t)g.num_cus : 256u;

@@ -9,7 +9,7 @@ namespace madsim_k {
 // `via_handle`: spawned through a NodeHandle captured at build() (NodeHandle::spawn from another node's task:
 // that Spawner holds the ORIGINAL Arc<NodeInfo>); otherwise task::spawn / init on the node's current info.
 template <class K>
-__device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record, bool via_handle = false) {
+__device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record, bool via_handle = false, int parent = -1) {
     uint32_t slot = 0;
     if (K::G) {                                              // first free slot = first zero bit of the alive mask (LDS)
         slot = c.P.max_tasks;
@@ -29,7 +29,11 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
     if (K::FN) {
         uint32_t cur_gen = NODE_INFO_GEN(node);
         info_gen = cur_gen;
-        if (via_handle && cur_gen != 0) { killed = 1; info_gen = 0; }             // stale handle: dead info
+        if (parent >= 0) {           // task::spawn inside that task's context: its own Arc<NodeInfo>, whatever became of the node
+            killed = (TWORD(c, (uint32_t)parent, 0, 0) & TF_KILLED) ? 1u : 0u;
+            info_gen = TWORD(c, (uint32_t)parent, 1, 1) >> 24;
+        }
+        else if (via_handle && cur_gen != 0) { killed = 1; info_gen = 0; }        // stale handle: dead info
         else killed = ((via_handle ? NODEW(2) : NODEW(0)) >> node) & 1;          // task/mod.rs:632-634
     }
     uint32_t seq = 0;
@@ -67,12 +71,20 @@ __device__ __forceinline__ void task_drop_locals(const Ctx& c, Lane& L, uint32_t
     }
 }
 
+// MADSIM_PROG_DROP_SPAWN: the guard moved into the body drops after its other locals, and its Drop spawns program prog + 1 in
+// this task's context (task/mod.rs:1185-1253).  Full builds only (geometry.h routes such workloads there, like address resolution).
+template <class K>
+__device__ __forceinline__ void task_drop_guard(const Ctx& c, Lane& L, uint32_t slot, uint32_t prog) {
+    if (K::FN && K::FA && ((PROGW(c, prog) >> 8) & MADSIM_PROG_DROP_SPAWN)) spawn_task<K>(c, L, prog + 1, false, false, (int)slot);
+}
+
 // The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
 template <class K>
-__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome) {
+__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome, bool guard = true) {
     uint32_t f = TWORD(c, slot, 0, 0);
     uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
     task_drop_locals<K>(c, L, slot, f);
+    if (guard) task_drop_guard<K>(c, L, slot, prog);
     uint32_t h = HW(prog);
     if (h == (H_RUNNING | (slot << 8) | (gen << 16))) { HW(prog) = (h & ~3u) | outcome; if (prog == 0) L.main_done = 1; }
     uint32_t link = TWORD(c, slot, 1, 0);
@@ -106,7 +118,7 @@ __device__ __forceinline__ void info_kill(const Ctx& c, Lane& L, uint32_t node, 
 }
 
 template <class K>
-__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome);
+__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome, bool guard);
 
 // node.paused.clear() (task/mod.rs:365,392): the parked Runnables of `node` are dropped, in order.
 template <class K>

@@ -515,6 +515,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             want_sleep = true;
         } else {
             // ---- everything else: rare, control-plane ops ----
+            bool done_guard = true;                    // MS_OP_DONE: an init task's guard drops before its exit() (below)
             switch (op) {
             case MS_OP_DONE:
                 u0.y = pc | (sub << 16) | (from << 24);
@@ -525,11 +526,13 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 // info it was spawned with (task/mod.rs:657-661)
                 if (K::FN && ((PROGW(c, u0.x >> 24) >> 8) & MADSIM_PROG_INIT) && (u1.y >> 24) == NODE_INFO_GEN(node)) {
                     task_drop_locals<K>(c, L, slot, u0.x);
+                    task_drop_guard<K>(c, L, slot, u0.x >> 24);
                     NODEW(0) |= 1u << node;
                     if ((u1.y >> 24) == 0) NODEW(2) |= 1u << node;
                     info_kill<K>(c, L, node, u1.y >> 24);
+                    done_guard = false;
                 }
-                task_finish<K>(c, L, slot, H_COMPLETED);
+                task_finish<K>(c, L, slot, H_COMPLETED, done_guard);
                 u0.x = TWORD(c, slot, 0, 0);
                 st = ST_FINISHED;
                 break;

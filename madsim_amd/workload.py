@@ -327,9 +327,11 @@ class WorkloadBuilder:
         self.socks.append(A.Sock(node, kind, port))
         return len(self.socks) - 1
 
-    def task(self, node, init=False, pre=False):
+    def task(self, node, init=False, pre=False, spawn_on_drop=False):
+        """A task body.  spawn_on_drop: the body owns a guard whose Drop calls task::spawn(<the NEXT task declared>) — it
+        runs whenever an instance returns or is dropped (abort, kill, panic), in that instance's context (task/mod.rs:1185-1253)."""
         t = TaskBuilder(self, len(self.tasks), node,
-                        (A.PROG_INIT if init else 0) | (A.PROG_PRE if pre else 0))
+                        (A.PROG_INIT if init else 0) | (A.PROG_PRE if pre else 0) | (A.PROG_DROP_SPAWN if spawn_on_drop else 0))
         self.tasks.append(t)
         return t
 

@@ -456,9 +456,12 @@ static void sock_close_owned(sim_t* S, uint16_t slot, uint16_t gen, int node_kil
 
 /* `via_handle`: spawned through a NodeHandle captured at build() (NodeHandle::spawn from another node's
  * task: the Spawner holds the ORIGINAL Arc<NodeInfo>); otherwise task::spawn / init on the current info. */
-static int spawn_task_on(sim_t* S, unsigned prog, int record_handle, int via_handle);
-static int spawn_task(sim_t* S, unsigned prog, int record_handle) { return spawn_task_on(S, prog, record_handle, 0); }
-static int spawn_task_on(sim_t* S, unsigned prog, int record_handle, int via_handle) {   /* task/mod.rs:627-654 */
+static int spawn_task_from(sim_t* S, unsigned prog, int record_handle, int via_handle, int parent);
+static int spawn_task_on(sim_t* S, unsigned prog, int record_handle, int via_handle) { return spawn_task_from(S, prog, record_handle, via_handle, -1); }
+static int spawn_task(sim_t* S, unsigned prog, int record_handle) { return spawn_task_from(S, prog, record_handle, 0, -1); }
+/* parent >= 0: task::spawn from inside that task's context — its own Arc<NodeInfo>, whatever became of the node since
+ * (Spawner::current -> context::current_task().node: a guard's Drop running while its killed task is dropped) */
+static int spawn_task_from(sim_t* S, unsigned prog, int record_handle, int via_handle, int parent) {   /* task/mod.rs:627-654 */
     size_t slot = 0;
     while (slot < S->tasks.n && S->tasks.p[slot].alive) slot++;
     if (slot == S->tasks.n) { task_t z; memset(&z, 0, sizeof z); vec_push(S->tasks, z); }
@@ -468,7 +471,8 @@ static int spawn_task_on(sim_t* S, unsigned prog, int record_handle, int via_han
     t->alive = 1; t->gen = gen; t->prog = (uint8_t)prog; t->node = S->w->progs[prog].node;
     {
         node_t* n = &S->nodes[t->node];
-        if (via_handle && n->info_gen != 0) { t->killed = 1; t->info_gen = 0; }        /* stale handle: dead info */
+        if (parent >= 0) { t->killed = S->tasks.p[parent].killed; t->info_gen = S->tasks.p[parent].info_gen; }
+        else if (via_handle && n->info_gen != 0) { t->killed = 1; t->info_gen = 0; }        /* stale handle: dead info */
         else { t->killed = via_handle ? n->gen0_killed : n->killed; t->info_gen = n->info_gen; }  /* :632-634 */
         if (t->info_gen == n->info_gen) { tref_t r = { (uint16_t)slot, gen }; vec_push(n->tasks, r); }
     }
@@ -498,6 +502,7 @@ static void info_kill(sim_t* S, unsigned node) {
 }
 
 static void task_finish(sim_t* S, uint16_t slot, int outcome);
+static void task_finish_opt(sim_t* S, uint16_t slot, int outcome, int guard);
 
 static void paused_clear(sim_t* S, unsigned node) {       /* node.paused.clear(): drops the Runnables */
     node_t* n = &S->nodes[node];
@@ -570,10 +575,18 @@ static void conn_drop_handles(sim_t* S, int id, int side, int node_killed) {
 }
 
 /* The future is gone (completed, or dropped by the executor).  outcome: H_COMPLETED / H_CANCELLED. */
-static void task_finish(sim_t* S, uint16_t slot, int outcome) {
+/* MADSIM_PROG_DROP_SPAWN: the guard moved into the body drops after its other locals: A::drop -> task::spawn in this task's
+ * context (task/mod.rs:1190-1196, 1227-1233) */
+static void task_drop_guard(sim_t* S, uint16_t slot) {
+    const unsigned prog = S->tasks.p[slot].prog;
+    if (S->w->progs[prog].flags & MADSIM_PROG_DROP_SPAWN) spawn_task_from(S, prog + 1u, 0, 0, slot);
+}
+static void task_finish(sim_t* S, uint16_t slot, int outcome) { task_finish_opt(S, slot, outcome, 1); }
+static void task_finish_opt(sim_t* S, uint16_t slot, int outcome, int guard) {
     task_t* t = &S->tasks.p[slot];
     if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, t->killed); t = &S->tasks.p[slot]; }
     sock_close_owned(S, slot, t->gen, t->killed);
+    if (guard) { task_drop_guard(S, slot); t = &S->tasks.p[slot]; }
     handle_t* h = &S->handles[t->prog];
     if (h->state == H_RUNNING && h->slot == slot && h->gen == t->gen) h->state = (uint8_t)outcome;
     int32_t j = t->joiner; uint16_t jg = t->joiner_gen;
@@ -625,8 +638,11 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if ((w->progs[t->prog].flags & MADSIM_PROG_INIT) && t->info_gen == S->nodes[t->node].info_gen) {
                 if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, 0); t = &S->tasks.p[slot]; }
                 sock_close_owned(S, slot, t->gen, 0);
-                info_kill(S, t->node);
+                task_drop_guard(S, slot);
                 t = &S->tasks.p[slot];
+                info_kill(S, t->node);
+                task_finish_opt(S, slot, H_COMPLETED, 0);
+                return 0;
             }
             task_finish(S, slot, H_COMPLETED);
             return 0;
@@ -1193,6 +1209,11 @@ static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
         const madsim_insn_t* in = &w->insns[i];
         if ((in->op == MS_OP_SEND || in->op == MS_OP_CONNECT || in->op == MS_OP_RPC_CALL) &&
             (uint32_t)(in->b & 0xff) < w->n_socks && w->socks[in->b & 0xff].port == 0) return -1;
+    }
+    for (uint32_t p = 0; p < w->n_progs; p++) {           /* a guard's Drop spawns the next program, on the same node */
+        if (!(w->progs[p].flags & MADSIM_PROG_DROP_SPAWN)) continue;
+        if (p + 1 >= w->n_progs || w->progs[p + 1].node != w->progs[p].node) return -1;
+        for (uint32_t i = 0; i < w->n_insns; i++) if (w->insns[i].op == MS_OP_PAUSE) return -1;
     }
     if (cfg->lat_lo_ns >= cfg->lat_hi_ns) return -1;      /* "cannot sample empty range" */
     if (!(cfg->packet_loss_rate >= 0.0 && cfg->packet_loss_rate <= 1.0)) return -1;

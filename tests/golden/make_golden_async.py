@@ -95,6 +95,7 @@ class Task:
         self.alive, self.sched, self.running, self.joiner = True, True, False, None
         self.cnt, self.val, self.frm, self.aux, self.t0 = [0, 0], 0, 0, 0, 0
         self.owned = []
+        self.guard_gone = False
         self.conn = None                            # the (Sender, Receiver) pair this task holds (one at a time: the VM's rule)
         self.gen = sim.body(self, sim.progs[prog][2])
 
@@ -274,9 +275,15 @@ class Sim:
             if self.bound.get(a) is not None and self.bound[a]["owner"] is t:
                 self.close_sock(a)
 
+    def drop_guard(self, t):                        # the guard moved into the body drops last: `impl Drop for A { spawn(..) }`
+        if self.progs[t.prog][1] & A.PROG_DROP_SPAWN and not t.guard_gone:
+            t.guard_gone = True
+            self.spawn(t.prog + 1, t.info, record=False)    # Spawner::current(): this task's own Arc<NodeInfo> (task/mod.rs:1185-1253)
+
     def finish(self, t, outcome):
         t.gen.close()                               # the future is dropped: `finally:` blocks = Drop impls
         self.drop_locals(t)
+        self.drop_guard(t)
         t.alive, t.outcome = False, outcome
         if t.joiner is not None:                    # async-task notifies the awaiter
             self.wake(t.joiner)
@@ -524,6 +531,7 @@ class Sim:
             if name == "DONE":
                 if self.progs[t.prog][1] & A.PROG_INIT:   # `async move { future.await; h.exit() }` (runtime/mod.rs:362-370): the
                     self.drop_locals(t)                   # body's locals are gone when `future.await` returns; then Spawner::exit
+                    self.drop_guard(t)
                     t.info.kill(self)                     # = info.kill() on the NodeInfo this init task was spawned with
                 return
             elif name == "SPAWN":

@@ -582,6 +582,61 @@ def buggify_rates():
 
 
 ALL.update(std_system_time=std_system_time, getrandom_deterministic=getrandom_deterministic, buggify_rates=buggify_rates)
+
+
+def spawn_in_future_drop_by_aborting_task():
+    """task/mod.rs:1184-1216: `impl Drop for A { spawn(..) }` moved into a task that is aborted before it ever runs — the task
+    spawned in A::drop belongs to the same node and does run."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n, spawn_on_drop=True)                      # async move { drop(a) }
+    c = wl.task(n); c.flag_add(0, 1)                        # the task A::drop spawns: records that it ran (on node n)
+    m = wl.main(); m.spawn(t); m.abort(t); m.join(t, expect_err=True)
+    m.sleep(secs=57257); m.sleep(secs=57257); m.assert_flag(0, 1)      # 114514 s
+    return wl.build()
+
+
+def spawn_in_future_drop_by_killing_node():
+    """task/mod.rs:1219-1253: the same guard dropped because the node was killed — spawning on the killed node succeeds, the
+    new task never runs (`unreachable!()`)."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n, spawn_on_drop=True)
+    c = wl.task(n); c.panic(7)                              # unreachable!()
+    m = wl.main(); m.spawn(t); m.kill(n); m.join(t, expect_err=True); m.sleep(secs=57257); m.sleep(secs=57257)
+    return wl.build()
+
+
+def spawn_in_future_drop_by_completion():
+    """The guard of a body that runs to its end (`drop(a)` executed, task/mod.rs:1207): the spawned task is queued before the
+    JoinHandle's awaiter is woken, so it is there when the awaiter looks."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    a = wl.addr(n, 1)
+    t = wl.task(n, spawn_on_drop=True); t.bind(a); t.sleep(ms=3)
+    c = wl.task(n); c.bind(a); c.flag_add(0, 1); c.sleep(ms=1); c.flag_add(0, 1)      # binds the address its parent's locals freed
+    m = wl.main(); m.spawn(t); m.join(t); m.sleep(ms=10); m.assert_flag(0, 2)
+    return wl.build()
+
+
+def spawn_in_future_drop_across_restart():
+    """A guard in an init task across a restart: the old incarnation's task is dropped under its own (killed) NodeInfo, so the
+    task its guard spawns never runs; the new incarnation's init task returns, its guard spawns, and exit() kills that too."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n, init=True, spawn_on_drop=True); t.flag_add(0, 1); t.sleep(secs=2)
+    c = wl.task(n); c.flag_add(1, 1)
+    m = wl.main(); m.build_node(n); m.sleep(secs=1); m.restart(n); m.sleep(secs=5)
+    # both incarnations started; neither guard's task ever ran: the first was spawned under the killed NodeInfo, the second just
+    # before its init task's exit() killed the node (runtime/mod.rs:362-370)
+    m.assert_flag(0, 2); m.assert_flag(1, 0); m.assert_exit(n, True)
+    return wl.build()
+
+
+ALL.update(spawn_in_future_drop_by_aborting_task=spawn_in_future_drop_by_aborting_task,
+           spawn_in_future_drop_by_killing_node=spawn_in_future_drop_by_killing_node,
+           spawn_in_future_drop_by_completion=spawn_in_future_drop_by_completion,
+           spawn_in_future_drop_across_restart=spawn_in_future_drop_across_restart)
 CONFIGS = {"buggify_rates": dict(loss_table=(0.0, 0.25, 0.1))}
 
 

@@ -373,6 +373,49 @@ async fn guard_keeps_address(obs: Obs) -> Tail {
     fingerprint_tail(t0, &obs)
 }
 
+/// A value whose Drop runs a closure: `impl Drop for A { fn drop(&mut self) { spawn(..) } }` of task/mod.rs:1188-1196.
+struct OnDrop<F: FnOnce() + Send + 'static>(Option<F>);
+impl<F: FnOnce() + Send + 'static> Drop for OnDrop<F> {
+    fn drop(&mut self) { if let Some(f) = self.0.take() { f() } }
+}
+
+/// task/mod.rs:1184-1216 `spawn_in_future_drop_by_aborting_task`: the task spawned in A::drop runs, on the aborted task's node.
+async fn spawn_in_drop_abort(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let node = h.create_node().build();
+    let node_id = node.id();
+    let ran_on = Arc::new(Mutex::new(None));
+    let r = ran_on.clone();
+    let a = OnDrop(Some(move || { madsim::task::spawn(async move { *r.lock().unwrap() = Some(madsim::plugin::node()); }); }));
+    let jh = node.spawn(async move { drop(a) });
+    jh.abort();
+    assert!(jh.await.unwrap_err().is_cancelled());
+    time::sleep(Duration::from_secs(57257)).await;
+    time::sleep(Duration::from_secs(57257)).await;
+    assert_eq!(*ran_on.lock().unwrap(), Some(node_id));
+    obs.push(1);
+    fingerprint_tail(t0, &obs)
+}
+
+/// task/mod.rs:1219-1253 `spawn_in_future_drop_by_killing_node`: spawning on the killed node succeeds, the task never runs.
+async fn spawn_in_drop_kill(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let node = h.create_node().build();
+    let dropped = Arc::new(AtomicUsize::new(0));
+    let d = dropped.clone();
+    let a = OnDrop(Some(move || { madsim::task::spawn(async move { unreachable!() }); d.store(1, Ordering::Relaxed); }));
+    let jh = node.spawn(async move { drop(a) });
+    h.kill(node.id());
+    assert!(jh.await.unwrap_err().is_cancelled());
+    assert_eq!(dropped.load(Ordering::Relaxed), 1);
+    time::sleep(Duration::from_secs(57257)).await;
+    time::sleep(Duration::from_secs(57257)).await;
+    obs.push(dropped.load(Ordering::Relaxed) as u64);
+    fingerprint_tail(t0, &obs)
+}
+
 fn run_one(name: &str, seed: u64, loss: f64) -> String {
     let mut config = madsim::Config::default();
     config.net.packet_loss_rate = loss;
@@ -401,6 +444,8 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
                 "bind_ephemeral" => bind_ephemeral(o).await,
                 "channel_wildcard" => channel_wildcard(o).await,
                 "guard_keeps_address" => guard_keeps_address(o).await,
+                "spawn_in_drop_abort" => spawn_in_drop_abort(o).await,
+                "spawn_in_drop_kill" => spawn_in_drop_kill(o).await,
                 other => panic!("unknown workload {other}"),
             }
         });
@@ -423,7 +468,8 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
 }
 
 const ALL: &[&str] = &["pingpong2", "pingpong4", "pingpong16", "sleep_1s", "yield_order", "timer_ties", "kill", "restart",
-                       "restart_on_panic", "receiver_drop", "localhost", "restart_on_panic_matching"];
+                       "restart_on_panic", "receiver_drop", "localhost", "restart_on_panic_matching", "bind_ephemeral",
+                       "channel_wildcard", "guard_keeps_address", "spawn_in_drop_abort", "spawn_in_drop_kill"];
 
 fn main() {
     let args: Vec<String> = std::env::args().collect();

@@ -248,6 +248,32 @@ def guard_keeps_address():
     return wl.build()
 
 
+def spawn_in_drop_abort():
+    """task/mod.rs:1184-1216: the guard of an aborted task spawns a task that runs on the same node (obs <- 1)."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n, spawn_on_drop=True)
+    c = wl.task(n); c.flag_add(0, 1)
+    m = wl.main()
+    m.spawn(t); m.abort(t); m.join(t, expect_err=True)
+    m.sleep(secs=57257); m.sleep(secs=57257); m.assert_flag(0, 1); m.trace(1)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def spawn_in_drop_kill():
+    """task/mod.rs:1219-1253: the guard of a killed node's task spawns a task that never runs (obs <- 1: the guard did drop)."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n, spawn_on_drop=True)
+    c = wl.task(n); c.panic(7)
+    m = wl.main()
+    m.spawn(t); m.kill(n); m.join(t, expect_err=True)
+    m.sleep(secs=57257); m.sleep(secs=57257); m.trace(1)
+    fingerprint_tail(m)
+    return wl.build()
+
+
 # workloads that end in a panic by design (the reference test is #[should_panic])
 EXPECT_PANIC = {"restart_on_panic_matching"}
 
@@ -257,4 +283,5 @@ ALL = {
     "restart_on_panic": restart_on_panic, "receiver_drop": receiver_drop,
     "localhost": localhost, "restart_on_panic_matching": restart_on_panic_matching,
     "bind_ephemeral": bind_ephemeral, "channel_wildcard": channel_wildcard, "guard_keeps_address": guard_keeps_address,
+    "spawn_in_drop_abort": spawn_in_drop_abort, "spawn_in_drop_kill": spawn_in_drop_kill,
 }
