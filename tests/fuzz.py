@@ -112,9 +112,11 @@ def random_workload(rng: random.Random, max_nodes=4, max_rounds=6):
     return wl.build(), cfg, "+".join(desc)
 
 
-def random_lifecycle_workload(rng: random.Random, max_nodes=4):
+def random_lifecycle_workload(rng: random.Random, max_nodes=4, guards=False):
     """Programs that also exercise node lifecycle: init tasks, kill / restart / pause / resume / abort,
-    restart_on_panic nodes, spawns on dead nodes, shared flags.  Returns (BuiltWorkload, Config, description)."""
+    restart_on_panic nodes, spawns on dead nodes, shared flags.  Returns (BuiltWorkload, Config, description).
+    guards=True (random_guard_workload): about half of the task bodies own a guard whose Drop spawns a small task
+    (MADSIM_PROG_DROP_SPAWN, task/mod.rs:1184-1253); pause / resume are left out (the ABI's rule for guards)."""
     n_nodes = rng.randint(1, max_nodes)
     wl = W.WorkloadBuilder()
     nodes = [wl.create_node(restart_on_panic=rng.random() < 0.3) for _ in range(n_nodes)]
@@ -122,11 +124,17 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4):
     tasks, inits, desc = [], {}, []
     for i, n in enumerate(nodes):
         is_init = rng.random() < 0.6
-        t = wl.task(n, init=is_init)
+        guard = guards and rng.random() < 0.5
+        t = wl.task(n, init=is_init, spawn_on_drop=guard)
+        if guard:                                           # the task A::drop spawns: the program right behind its owner
+            c = wl.task(n); c.flag_add(3, 1)
+            if rng.random() < 0.5:
+                c.sleep(ms=rng.choice([0, 2, 40])); c.trace(800 + i)
+            c.done()
         kind = rng.choice(["server", "client", "ticker", "crasher", "short", "rpc_server", "rpc_client", "rpc_client"])
         if n_nodes == 1 and kind in ("server", "client", "rpc_server", "rpc_client"):
             kind = "ticker"
-        desc.append(("i:" if is_init else "") + kind)
+        desc.append(("i:" if is_init else "") + ("g:" if guard else "") + kind)
         if kind == "server":
             t.bind(addrs[i])
             top = t.label()
@@ -187,6 +195,8 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4):
     for _ in range(rng.randint(1, 8)):
         act = rng.choice(["sleep", "sleep", "kill", "restart", "pause", "resume", "abort", "spawn", "yield", "clog", "unclog"])
         n = rng.choice(nodes)
+        if guards and act in ("pause", "resume"):
+            act = "sleep"
         if act == "sleep":
             m.sleep(ms=rng.choice([0, 3, 25, 150, 2500]))
         elif act == "kill":
@@ -212,7 +222,7 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4):
         elif act == "unclog":
             m.unclog_node(n, "both")
     for n in nodes:
-        if rng.random() < 0.3:
+        if rng.random() < 0.3 and not guards:
             m.resume(n)
         if rng.random() < 0.5:
             m.unclog_node(n, "both")
@@ -220,6 +230,10 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4):
     m.done()
     cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.1]), buggify=rng.random() < 0.15)
     return wl.build(), cfg, "+".join(desc)
+
+
+def random_guard_workload(rng: random.Random):
+    return random_lifecycle_workload(rng, guards=True)
 
 
 def generous_limits():

@@ -258,6 +258,22 @@ def test_fuzz_lifecycle_workloads_gpu(hip):
         assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
 
 
+def test_fuzz_guard_workloads_gpu(hip):
+    """Random lifecycle programs whose task bodies own guards that spawn in Drop (MADSIM_PROG_DROP_SPAWN, task/mod.rs:1184-1253);
+    odd rounds with the per-seed state in the global-memory block."""
+    import random
+    from tests import fuzz
+    for k in range(150):
+        w, cfg, desc = fuzz.random_guard_workload(random.Random(7600 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        if k % 2:
+            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        got, _ = hip.run_batch(w, k * 17, 64, cfg, lim)
+        want, _ = oracle.run_batch(w, k * 17, 64, cfg, lim)
+        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+
+
 def test_config2_election_loop_262144_seeds(hip):
     """BASELINE configs[2]: 5-node election loop with NetSim partition injection, 262 144 seeds on one GPU
     (timeout() duplicate timers push most of the timer heap into the HBM spill region)."""

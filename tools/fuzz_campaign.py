@@ -14,7 +14,8 @@ base = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 runtime.init(0)
 gens = [("plain", fuzz.random_workload, None), ("lifecycle", fuzz.random_lifecycle_workload, 24), ("rpc", fuzz.random_rpc_workload, 24),
         ("rpc+hooks", lambda r: fuzz.random_rpc_workload(r, hooks=True), 24), ("addresses", fuzz.random_addr_workload, None),
-        ("ephemeral", fuzz.random_ephemeral_workload, None), ("channel", fuzz.random_channel_workload, 24)]
+        ("ephemeral", fuzz.random_ephemeral_workload, None), ("channel", fuzz.random_channel_workload, 24),
+        ("guards", fuzz.random_guard_workload, 24)]
 t0 = time.time(); k = 0; stats = {g[0]: [0, 0, 0] for g in gens}; verdicts = np.zeros(6, dtype=np.int64)
 while time.time() - t0 < budget:
     name, gen, max_tasks = gens[k % len(gens)]
