@@ -537,7 +537,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 st = ST_FINISHED;
                 break;
             case MS_OP_SPAWN: {
-                uint32_t child = spawn_task<K>(c, L, a, true, (PROGW(c, a) & 0xff) != node);
+                // another node's program: NodeHandle::spawn; this node's: task::spawn under this task's OWN NodeInfo (task/mod.rs:592-599)
+                const bool via = (PROGW(c, a) & 0xff) != node;
+                uint32_t child = spawn_task<K>(c, L, a, true, via, via ? -1 : (int)slot);
                 if (K::FC && P.uses_chan && (b & 2) && child != 0xffffffffu) {   // `async move`: the (tx, rx) pair moves
                     uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                     TWORD(c, child, c.P.chan_unit, 0) = cx & 0x1ff;

@@ -457,7 +457,6 @@ static void sock_close_owned(sim_t* S, uint16_t slot, uint16_t gen, int node_kil
 /* `via_handle`: spawned through a NodeHandle captured at build() (NodeHandle::spawn from another node's
  * task: the Spawner holds the ORIGINAL Arc<NodeInfo>); otherwise task::spawn / init on the current info. */
 static int spawn_task_from(sim_t* S, unsigned prog, int record_handle, int via_handle, int parent);
-static int spawn_task_on(sim_t* S, unsigned prog, int record_handle, int via_handle) { return spawn_task_from(S, prog, record_handle, via_handle, -1); }
 static int spawn_task(sim_t* S, unsigned prog, int record_handle) { return spawn_task_from(S, prog, record_handle, 0, -1); }
 /* parent >= 0: task::spawn from inside that task's context — its own Arc<NodeInfo>, whatever became of the node since
  * (Spawner::current -> context::current_task().node: a guard's Drop running while its killed task is dropped) */
@@ -648,7 +647,11 @@ static int poll_task(sim_t* S, uint16_t slot) {
             return 0;
         case MS_OP_SPAWN:
             {
-                int child = spawn_task_on(S, in->a, 1, w->progs[in->a].node != t->node);
+                /* another node's program: NodeHandle::spawn (the handle's ORIGINAL NodeInfo); this node's: task::spawn =
+                 * Spawner::current() = this task's OWN Arc<NodeInfo> (task/mod.rs:592-599) — not the node's current one: a
+                 * task that restarted its own node spawns under the dead incarnation */
+                const int via = w->progs[in->a].node != t->node;
+                int child = spawn_task_from(S, in->a, 1, via, via ? -1 : (int)slot);
                 t = &S->tasks.p[slot];
                 if ((in->b & 2) && child >= 0) {           /* `spawn(async move { .. tx, rx .. })`: the handles move */
                     S->tasks.p[child].conn = t->conn; S->tasks.p[child].side = t->side; t->conn = -1;

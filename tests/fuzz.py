@@ -131,7 +131,10 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4, guards=False):
             if rng.random() < 0.5:
                 c.sleep(ms=rng.choice([0, 2, 40])); c.trace(800 + i)
             c.done()
-        kind = rng.choice(["server", "client", "ticker", "crasher", "short", "rpc_server", "rpc_client", "rpc_client"])
+        kinds = ["server", "client", "ticker", "crasher", "short", "rpc_server", "rpc_client", "rpc_client"]
+        if guards:
+            kinds += ["saboteur", "saboteur"]
+        kind = rng.choice(kinds)
         if n_nodes == 1 and kind in ("server", "client", "rpc_server", "rpc_client"):
             kind = "ticker"
         desc.append(("i:" if is_init else "") + ("g:" if guard else "") + kind)
@@ -173,6 +176,15 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4, guards=False):
                 t.sleep(ms=1)
             t.chan_recv(); t.trace(950 + i)
             t.sleep(ms=rng.choice([0, 5, 60])); t.djnz(0, top)
+        elif kind == "saboteur":
+            # kills or restarts its OWN node and keeps going until it yields: what it spawns meanwhile (task::spawn, its own
+            # NodeInfo: task/mod.rs:592-599) belongs to the dead incarnation
+            helper = wl.task(n); helper.flag_add(3, 2); helper.sleep(ms=rng.choice([0, 4])); helper.trace(850 + i); helper.done()
+            t.sleep(ms=rng.choice([0, 2, 30]))
+            (t.kill if rng.random() < 0.4 else t.restart)(n)
+            t.spawn(helper); t.flag_add(2, 1)
+            if rng.random() < 0.5:
+                t.sleep(ms=1); t.flag_add(2, 16)
         elif kind == "ticker":
             top = t.label()
             t.sleep(ms=rng.choice([1, 7, 30, 100])); t.flag_add(1, 1); t.trace(7, add_reg=0)

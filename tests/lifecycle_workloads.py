@@ -633,6 +633,31 @@ def spawn_in_future_drop_across_restart():
     return wl.build()
 
 
+def spawn_after_restarting_own_node():
+    """task::spawn = Spawner::current() = the calling task's OWN Arc<NodeInfo> (task/mod.rs:592-599): a task that restarts its
+    own node keeps running until it yields, and what it spawns meanwhile belongs to the dead incarnation — it never runs.
+    The new incarnation's init task does."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    i = wl.task(n, init=True); i.flag_add(2, 1); i.sleep(secs=10)
+    c = wl.task(n); c.flag_add(0, 1)
+    t = wl.task(n); t.restart(n); t.spawn(c); t.flag_add(1, 1); t.sleep(ms=1); t.flag_add(1, 10)
+    m = wl.main(); m.build_node(n); m.sleep(ms=5); m.spawn(t); m.sleep(secs=1)
+    m.assert_flag(0, 0); m.assert_flag(1, 1); m.assert_flag(2, 2)
+    return wl.build()
+
+
+def spawn_after_killing_own_node():
+    """The same with Handle::kill: the spawned task is created under the killed NodeInfo and dropped unpolled."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    c = wl.task(n); c.flag_add(0, 1)
+    t = wl.task(n); t.kill(n); t.spawn(c); t.flag_add(1, 1); t.sleep(ms=1); t.flag_add(1, 10)
+    m = wl.main(); m.spawn(t); m.sleep(secs=1); m.assert_flag(0, 0); m.assert_flag(1, 1); m.assert_exit(n, True)
+    return wl.build()
+
+
+ALL.update(spawn_after_restarting_own_node=spawn_after_restarting_own_node, spawn_after_killing_own_node=spawn_after_killing_own_node)
 ALL.update(spawn_in_future_drop_by_aborting_task=spawn_in_future_drop_by_aborting_task,
            spawn_in_future_drop_by_killing_node=spawn_in_future_drop_by_killing_node,
            spawn_in_future_drop_by_completion=spawn_in_future_drop_by_completion,
