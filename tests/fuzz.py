@@ -133,7 +133,7 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4, guards=False):
             c.done()
         kinds = ["server", "client", "ticker", "crasher", "short", "rpc_server", "rpc_client", "rpc_client"]
         if guards:
-            kinds += ["saboteur", "saboteur"]
+            kinds += ["saboteur", "saboteur", "meddler"]
         kind = rng.choice(kinds)
         if n_nodes == 1 and kind in ("server", "client", "rpc_server", "rpc_client"):
             kind = "ticker"
@@ -185,7 +185,22 @@ def random_lifecycle_workload(rng: random.Random, max_nodes=4, guards=False):
             t.spawn(helper); t.flag_add(2, 1)
             if rng.random() < 0.5:
                 t.sleep(ms=1); t.flag_add(2, 16)
-        elif kind == "ticker":
+        elif kind == "meddler" and i > 0:
+            # supervisor calls from an ordinary task: kill / restart ANOTHER node, NodeHandle::spawn there (the handle's original
+            # NodeInfo), abort and join that node's first task
+            j = rng.randrange(i)
+            helper = wl.task(nodes[j]); helper.flag_add(3, 4); helper.sleep(ms=rng.choice([0, 3])); helper.trace(870 + i); helper.done()
+            t.sleep(ms=rng.choice([0, 1, 20, 200]))
+            for _ in range(rng.randint(1, 4)):
+                act = rng.choice(["kill", "restart", "spawn", "abort", "join", "sleep"])
+                if act == "kill": t.kill(nodes[j])
+                elif act == "restart": t.restart(nodes[j])
+                elif act == "spawn": t.spawn(helper)
+                elif act == "abort": t.abort(tasks[j])
+                elif act == "join": t.join(tasks[j], expect_err=rng.random() < 0.5)
+                else: t.sleep(ms=rng.choice([0, 2, 50]))
+            t.flag_add(2, 1)
+        elif kind == "ticker" or kind == "meddler":
             top = t.label()
             t.sleep(ms=rng.choice([1, 7, 30, 100])); t.flag_add(1, 1); t.trace(7, add_reg=0)
             if rng.random() < 0.5:

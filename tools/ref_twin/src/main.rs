@@ -416,6 +416,34 @@ async fn spawn_in_drop_kill(obs: Obs) -> Tail {
     fingerprint_tail(t0, &obs)
 }
 
+/// task::spawn from a task that has just restarted its own node: Spawner::current() is the caller's own Arc<NodeInfo>
+/// (task/mod.rs:592-599), so the spawned task belongs to the dead incarnation and never runs; obs <- the three counters.
+async fn spawn_after_own_restart(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let (child_ran, saboteur, inits) = (Arc::new(AtomicUsize::new(0)), Arc::new(AtomicUsize::new(0)), Arc::new(AtomicUsize::new(0)));
+    let i = inits.clone();
+    let node = h.create_node().init(move || {
+        let i = i.clone();
+        async move { i.fetch_add(1, Ordering::Relaxed); time::sleep(Duration::from_secs(10)).await; }
+    }).build();
+    time::sleep(Duration::from_millis(5)).await;
+    let id = node.id();
+    let (c, s) = (child_ran.clone(), saboteur.clone());
+    node.spawn(async move {
+        Handle::current().restart(id);
+        madsim::task::spawn(async move { c.fetch_add(1, Ordering::Relaxed); });
+        s.fetch_add(1, Ordering::Relaxed);
+        time::sleep(Duration::from_millis(1)).await;
+        s.fetch_add(10, Ordering::Relaxed);
+    });
+    time::sleep(Duration::from_secs(1)).await;
+    obs.push(child_ran.load(Ordering::Relaxed) as u64);
+    obs.push(saboteur.load(Ordering::Relaxed) as u64);
+    obs.push(inits.load(Ordering::Relaxed) as u64);
+    fingerprint_tail(t0, &obs)
+}
+
 fn run_one(name: &str, seed: u64, loss: f64) -> String {
     let mut config = madsim::Config::default();
     config.net.packet_loss_rate = loss;
@@ -446,6 +474,7 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
                 "guard_keeps_address" => guard_keeps_address(o).await,
                 "spawn_in_drop_abort" => spawn_in_drop_abort(o).await,
                 "spawn_in_drop_kill" => spawn_in_drop_kill(o).await,
+                "spawn_after_own_restart" => spawn_after_own_restart(o).await,
                 other => panic!("unknown workload {other}"),
             }
         });
@@ -469,7 +498,8 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
 
 const ALL: &[&str] = &["pingpong2", "pingpong4", "pingpong16", "sleep_1s", "yield_order", "timer_ties", "kill", "restart",
                        "restart_on_panic", "receiver_drop", "localhost", "restart_on_panic_matching", "bind_ephemeral",
-                       "channel_wildcard", "guard_keeps_address", "spawn_in_drop_abort", "spawn_in_drop_kill"];
+                       "channel_wildcard", "guard_keeps_address", "spawn_in_drop_abort", "spawn_in_drop_kill",
+                       "spawn_after_own_restart"];
 
 fn main() {
     let args: Vec<String> = std::env::args().collect();

@@ -274,6 +274,19 @@ def spawn_in_drop_kill():
     return wl.build()
 
 
+def spawn_after_own_restart():
+    """Spawner::current() = the caller's own NodeInfo (task/mod.rs:592-599): obs <- child ran 0, saboteur 1, init tasks 2."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    i = wl.task(n, init=True); i.flag_add(2, 1); i.sleep(secs=10)
+    c = wl.task(n); c.flag_add(0, 1)
+    t = wl.task(n); t.restart(n); t.spawn(c); t.flag_add(1, 1); t.sleep(ms=1); t.flag_add(1, 10)
+    m = wl.main(); m.build_node(n); m.sleep(ms=5); m.spawn(t); m.sleep(secs=1)
+    m.assert_flag(0, 0); m.trace(0); m.assert_flag(1, 1); m.trace(1); m.assert_flag(2, 2); m.trace(2)
+    fingerprint_tail(m)
+    return wl.build()
+
+
 # workloads that end in a panic by design (the reference test is #[should_panic])
 EXPECT_PANIC = {"restart_on_panic_matching"}
 
@@ -284,4 +297,5 @@ ALL = {
     "localhost": localhost, "restart_on_panic_matching": restart_on_panic_matching,
     "bind_ephemeral": bind_ephemeral, "channel_wildcard": channel_wildcard, "guard_keeps_address": guard_keeps_address,
     "spawn_in_drop_abort": spawn_in_drop_abort, "spawn_in_drop_kill": spawn_in_drop_kill,
+    "spawn_after_own_restart": spawn_after_own_restart,
 }
