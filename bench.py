@@ -333,12 +333,35 @@ def main():
         if (got != want).any() or (sm.n_failed and osm.first_failing_seed != sm.first_failing_seed):
             print(f"bench.py: FIRST-FAIL VERIFY FAILED: gpu {sm.first_failing_seed} oracle {osm.first_failing_seed}", file=sys.stderr)
             return 3
+        # the same search with batches kept in flight (what a campaign does: the report of batch k is read while k + 1 .. run):
+        # n_streams streams, one device report row per batch, the host looks at the rows once at the end
+        n_search = 10 * n_streams
+        srows = torch.zeros((n_search, REPORT_WORDS), dtype=torch.int64, device=dev)
+        fs1 = 1 << 42
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(n_search):
+            si = k % n_streams
+            with torch.cuda.stream(streams[si]):
+                runtime.run_batch_async(w, fs1 + k * count, count, d_outs[si].data_ptr(), srows[k].data_ptr(),
+                                        streams[si].cuda_stream, fcfg, lim, timing_slot=-1)
+        torch.cuda.synchronize()
+        search_dt = time.perf_counter() - t1
+        srows_h = srows.cpu()
+        found = mdist.decode_first_fail(int(srows_h[:, 0].min()))
+        _, osm1 = oracle.run_batch(w, fs1, 64, fcfg, lim)            # the first batch's first failing seed is the search's answer
+        if osm1.n_failed and found != osm1.first_failing_seed:
+            print(f"bench.py: FIRST-FAIL SEARCH VERIFY FAILED: gpu {found} oracle {osm1.first_failing_seed}", file=sys.stderr)
+            return 3
         first_fail = {"packet_loss_rate": args.first_fail_loss, "seeds_per_batch": count,
+                      "search_batches_in_flight": n_streams, "search_seeds_per_hour": n_search * count / search_dt * 3600.0,
+                      "search_ms_per_batch": search_dt / n_search * 1e3,
                       "time_to_first_fail_ms": wall / reps * 1e3, "kernel_ms": ksum / reps,
                       "first_failing_seed_offset": int(sm.first_failing_seed - fs0) if sm.n_failed else None,
                       "failed_fraction": sm.n_failed / count, "oracle_checked_seeds": n_chk,
                       "seeds_per_hour": count / (wall / reps) * 3600.0,
-                      "note": "launch -> kernel -> device reduction -> 32-byte D2H, host-synchronous, one batch at a time"}
+                      "note": "time_to_first_fail_ms / seeds_per_hour: launch -> kernel -> device reduction -> 32-byte D2H, "
+                              "host-synchronous, one batch at a time; search_*: the same batches kept in flight on the bench's streams"}
 
     if rank == 0:
         seeds_total = total * args.steps
