@@ -177,6 +177,20 @@ class WorkloadBuilder {
   public:
     WorkloadBuilder() { tasks_.reserve(256); nodes_.push_back(madsim_node_t{}); tasks_.push_back(Task(0, 0, 0)); }   // Task& stay valid
     Task& main() { return tasks_[0]; }                                   // the future handed to block_on
+    // Byte strings on the wire never steer the simulation (a Payload is a Box<dyn Any>, endpoint.rs:69-94): the test body can
+    // only compare them, so they are interned — equal bytes <=> equal value.  payload(): the 32-bit value of a datagram /
+    // channel payload; rpc_message(): the 8-bit code of a typed-RPC message together with its call_with_data bytes
+    // (net/rpc.rs:114-131), at most 256 distinct pairs per workload.
+    uint32_t payload(const std::string& data) {
+        for (size_t i = 0; i < payloads_.size(); i++) if (payloads_[i] == data) return 0x40000000u + (uint32_t)i;
+        payloads_.push_back(data); return 0x40000000u + (uint32_t)payloads_.size() - 1;
+    }
+    uint8_t rpc_message(const std::string& msg, const std::string& data = std::string()) {
+        const std::string key = std::to_string(msg.size()) + ":" + msg + data;
+        for (size_t i = 0; i < rpc_messages_.size(); i++) if (rpc_messages_[i] == key) return (uint8_t)i;
+        if (rpc_messages_.size() >= 256) throw std::length_error("at most 256 distinct typed-RPC (message, data) pairs");
+        rpc_messages_.push_back(key); return (uint8_t)(rpc_messages_.size() - 1);
+    }
     // Handle::create_node()[.ip(10.0.0.<id>)][.restart_on_panic()][.restart_on_panic_matching(code)..].build()
     int create_node(bool restart_on_panic = false, std::vector<uint8_t> restart_on_panic_matching = {}, bool ip = true) {
         if (restart_on_panic_matching.size() > 2) throw std::length_error("at most two restart_on_panic_matching patterns");
@@ -219,6 +233,7 @@ class WorkloadBuilder {
     std::vector<madsim_node_t> nodes_;
     std::vector<madsim_sock_t> socks_;
     std::vector<Task> tasks_;
+    std::vector<std::string> payloads_, rpc_messages_;
 };
 
 namespace runtime {

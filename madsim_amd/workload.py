@@ -274,6 +274,7 @@ class WorkloadBuilder:
         self.socks = []
         self.tasks = [TaskBuilder(self, 0, 0)]
         self.payloads = []       # interned byte strings: see payload()
+        self.rpc_messages = []   # interned typed-RPC (message, data) pairs: see rpc_message()
 
     def payload(self, data: bytes):
         """The 32-bit value standing for the byte string `data` on the wire.  Payload bytes never steer the simulation
@@ -289,6 +290,20 @@ class WorkloadBuilder:
         if data not in self.payloads:
             self.payloads.append(data)
         return PAYLOAD_BASE + self.payloads.index(data)
+
+    def rpc_message(self, msg, data: bytes = b""):
+        """The 8-bit code standing for a typed-RPC message on the wire: the request (or response) value `msg` together with the
+        bytes of `call_with_data` / `add_rpc_handler_with_data` (net/rpc.rs:114-131,143-180).  Like payload(): neither the
+        value nor the bytes steer the simulation, the test body only compares them — so (msg, data) pairs are interned, equal
+        pairs <=> equal codes, at most 256 distinct pairs per workload.  Use the code as `code` of rpc_call / rpc_reply /
+        hook_rpc_*, and assert_val(rpc_message(..)) for `assert_eq!((rsp, &data[..]), (.., b".."))`.
+        BuiltWorkload.rpc_messages maps back."""
+        key = (msg, bytes(data))
+        if key not in self.rpc_messages:
+            if len(self.rpc_messages) >= 256:
+                raise ValueError("at most 256 distinct typed-RPC (message, data) pairs per workload")
+            self.rpc_messages.append(key)
+        return self.rpc_messages.index(key)
 
     def received(self, data: bytes, buf_len: int):
         """What `recv_from(tag, &mut buf)` with a `buf_len`-byte buffer leaves of a message `data` (endpoint.rs:87-94):
@@ -348,6 +363,7 @@ class WorkloadBuilder:
             raise ValueError("program too long")
         built = BuiltWorkload(self.nodes, progs, self.socks, insns)
         built.payloads = list(self.payloads)
+        built.rpc_messages = list(self.rpc_messages)
         return built
 
 

@@ -305,6 +305,31 @@ def rpc_echo(n_clients=2, n_calls=4):
     return wl.build()
 
 
+def rpc_echo_with_data():
+    """madsim/examples/rpc.rs (`Echo("hello")` -> "echo: hello") and the benches' `call_with_data` (benches/rpc.rs:28-52, net/rpc.rs:
+    114-131): the request / response values and their byte payloads travel as interned (message, data) codes; the handler checks
+    what it received, the caller what came back."""
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
+    hello, echoed = wl.rpc_message(("Echo", "hello")), wl.rpc_message("echo: hello")
+    blob = bytes(range(256)) * 4
+    put, ack = wl.rpc_message(("Put", 7), blob), wl.rpc_message("ok", blob[::-1])
+    h = wl.task(ns)                                           # the per-request task: f(req, data) -> (rsp, data)
+    skip = h.label() + 4
+    h.jeq(put, skip); h.assert_val(hello); h.rpc_reply(asv, echoed); h.done()
+    h.rpc_reply(asv, ack)
+    s = wl.task(ns); s.bind(asv)
+    top = s.label(); s.rpc_recv(asv, 0); s.spawn(h, move_request=True); s.jmp(top)
+    c = wl.task(nc); c.bind(acl); c.sleep(ms=5)
+    c.rpc_call(acl, asv, 0, hello); c.assert_val(echoed)
+    c.rpc_call(acl, asv, 0, put); c.assert_val(ack)
+    m = wl.main(); m.spawn(s); m.spawn(c); m.join(c)
+    built = wl.build()
+    assert built.rpc_messages[ack] == ("ok", blob[::-1]) and len(built.rpc_messages) == 4
+    return built
+
+
 def rpc_call_timeout_then_retry():
     """call_timeout (rpc.rs:96-105) elapsing while the handler is still working: the late response finds nobody holding
     its rsp_tag and stays in the caller's mailbox for good; the retry gets its own response."""
@@ -367,6 +392,7 @@ def rpc_hooks():
     return wl.build()
 
 
+ALL.update(rpc_echo_with_data=rpc_echo_with_data)
 ALL.update(rpc_echo=rpc_echo, rpc_call_timeout_then_retry=rpc_call_timeout_then_retry, rpc_server_restart=rpc_server_restart,
            rpc_hooks=rpc_hooks)
 
