@@ -59,7 +59,13 @@ class TaskBuilder:
         return self._emit("YIELD")
 
     def panic(self, code=0):
-        """panic!() with message code `code` (0..254), the thing restart_on_panic_matching patterns name."""
+        """panic!() with message code `code` (0..254), the thing restart_on_panic_matching patterns name — or panic!("<text>")
+        with a literal message: WorkloadBuilder.build() then gives every message the code of its class under the nodes'
+        string patterns (`error_msg.contains(pattern)`, task/mod.rs:297-300)."""
+        if isinstance(code, str):
+            self.wl.panic_texts.append(code)
+            self.code.append([A.OP["PANIC"], 0, 0, ("panic_text", code), False])      # the code is assigned in build()
+            return self
         return self._emit("PANIC", a=0, imm=code)
 
     def panic_with_flag(self, flag, offset=0):
@@ -275,6 +281,8 @@ class WorkloadBuilder:
         self.tasks = [TaskBuilder(self, 0, 0)]
         self.payloads = []       # interned byte strings: see payload()
         self.rpc_messages = []   # interned typed-RPC (message, data) pairs: see rpc_message()
+        self.panic_texts = []    # literal panic messages (TaskBuilder.panic("..")) and, per node, string patterns
+        self.panic_patterns = {}
 
     def payload(self, data: bytes):
         """The 32-bit value standing for the byte string `data` on the wire.  Payload bytes never steer the simulation
@@ -320,7 +328,11 @@ class WorkloadBuilder:
         ip=False: the node has no address — it can bind anything, but cannot reach other nodes (network.rs:281-283)."""
         n = A.Node()
         n.flags = (A.NODE_RESTART_ON_PANIC if restart_on_panic else 0) | (0 if ip else A.NODE_NO_IP)
-        if restart_on_panic_matching:
+        if restart_on_panic_matching and all(isinstance(p, str) for p in restart_on_panic_matching):
+            # string patterns, any number of them: resolved against the workload's literal panic messages in build()
+            self.panic_patterns[len(self.nodes)] = tuple(restart_on_panic_matching)
+            n.flags |= A.NODE_RESTART_MATCHING
+        elif restart_on_panic_matching:
             if len(restart_on_panic_matching) > 2 or any(not 0 <= c <= 254 for c in restart_on_panic_matching):
                 raise ValueError("at most two patterns, message codes 0..254")
             n.flags |= A.NODE_RESTART_MATCHING
@@ -350,8 +362,33 @@ class WorkloadBuilder:
         self.tasks.append(t)
         return t
 
+    def _panic_codes(self):
+        """Literal panic messages -> message codes.  A code only ever meets the nodes' patterns, so messages that the same
+        set of nodes restarts on are one class and share a code; a node then names the classes it restarts on (the device has
+        two pattern slots per node: more classes than that is refused)."""
+        texts = sorted(set(self.panic_texts))
+        cls = {}
+        for m in texts:
+            key = tuple(sorted(n for n, pats in self.panic_patterns.items() if any(p in m for p in pats)))
+            cls.setdefault(key, len(cls))
+        codes = {m: cls[tuple(sorted(n for n, pats in self.panic_patterns.items() if any(p in m for p in pats)))] for m in texts}
+        for n in self.panic_patterns:
+            mine = sorted({c for key, c in cls.items() if n in key})
+            if len(mine) > 2:
+                raise ValueError("node %d restarts on %d classes of panic messages; the device holds two per node" % (n, len(mine)))
+            self.nodes[n].n_match = len(mine)
+            for i, c in enumerate(mine):
+                self.nodes[n].match[i] = c
+        return codes
+
     def build(self):
         insns, progs = [], []
+        if self.panic_texts or self.panic_patterns:
+            if any(n.flags & A.NODE_RESTART_MATCHING and i not in self.panic_patterns for i, n in enumerate(self.nodes)):
+                raise ValueError("string and numeric restart_on_panic_matching patterns cannot be mixed in one workload")
+            codes = self._panic_codes()
+            for t in self.tasks:
+                t.code = [(op, a, b, codes[imm[1]] if isinstance(imm, tuple) else imm, reloc) for op, a, b, imm, reloc in t.code]
         for t in self.tasks:
             base = len(insns)
             if not t.code or t.code[-1][0] not in (A.OP["DONE"], A.OP["JMP"], A.OP["PANIC"]):

@@ -72,6 +72,25 @@ def restart_on_panic_matching_other_message():
     return wl.build()
 
 
+def restart_on_panic_matching_substrings():
+    """`restart_on_panic_matching.iter().any(|s| error_msg.contains(s))` (task/mod.rs:297-300) with literal messages and
+    substring patterns: nodes A ("disk" | "net") and B ("reset") keep restarting on the messages that contain one of their
+    patterns — "network reset" matches both — until node C's "out of memory", which its pattern "timeout" does not match,
+    unwinds out of block_on at 100 s."""
+    wl = W.WorkloadBuilder()
+    a = wl.create_node(restart_on_panic_matching=("disk", "net"))
+    b = wl.create_node(restart_on_panic_matching=("reset",))
+    c = wl.create_node(restart_on_panic_matching=("timeout",))
+    ta = wl.task(a, init=True, pre=True); ta.flag_add(0, 1); ta.sleep(secs=3); ta.panic("disk full")
+    ta2 = wl.task(a, init=True, pre=True); ta2.sleep(secs=7); ta2.panic("network reset")
+    tb = wl.task(b, init=True, pre=True); tb.flag_add(1, 1); tb.sleep(secs=20); tb.panic("network reset")
+    tc = wl.task(c, init=True, pre=True); tc.sleep(secs=100); tc.panic("out of memory")
+    m = wl.main(); m.sleep(secs=50); m.panic_if_flag_lt(0, 3); m.panic_if_flag_lt(1, 2); m.sleep(secs=100)
+    built = wl.build()
+    assert built.nodes[a].n_match == 2 and built.nodes[b].n_match == 1 and built.nodes[c].n_match == 0
+    return built
+
+
 def panic_without_restart():
     """task/mod.rs:315 resume_unwind: a panic on a node that does not restart fails the run."""
     wl = W.WorkloadBuilder()
@@ -205,7 +224,8 @@ ALL = dict(receiver_drop=receiver_drop, request_timeout_with_stale_timers=reques
            kill=kill, restart=restart, restart_on_panic=restart_on_panic, panic_without_restart=panic_without_restart,
            pause_resume=pause_resume, kill_drop_futures=kill_drop_futures, join_cancelled=join_cancelled,
            exited=exited, spawn_on_killed_node=spawn_on_killed_node, kill_restart_with_traffic=kill_restart_with_traffic)
-EXPECT_PANIC = {"panic_without_restart", "restart_on_panic_matching", "restart_on_panic_matching_other_message"}
+EXPECT_PANIC = {"panic_without_restart", "restart_on_panic_matching", "restart_on_panic_matching_other_message",
+                "restart_on_panic_matching_substrings"}
 
 
 def kv_rpc(n_clients=2, n_ops=3):
@@ -267,6 +287,7 @@ def connect_refused_and_reset():
     return wl.build()
 
 
+ALL.update(restart_on_panic_matching_substrings=restart_on_panic_matching_substrings)
 ALL.update(restart_on_panic_matching=restart_on_panic_matching,
            restart_on_panic_matching_other_message=restart_on_panic_matching_other_message)
 ALL.update(kv_rpc=kv_rpc, channel_backoff=channel_backoff, connect_refused_and_reset=connect_refused_and_reset)
