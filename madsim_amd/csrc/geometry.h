@@ -88,6 +88,11 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
     if (w->n_socks > 63 || (w->n_socks && !w->socks)) return fail(err, MADSIM_E_WORKLOAD, "at most 63 socket addresses");
     for (uint32_t i = 0; i < w->n_progs; i++)
         if (w->progs[i].node > w->n_nodes || w->progs[i].entry >= w->n_insns) return fail(err, MADSIM_E_WORKLOAD, "bad prog entry");
+    {   // no body may run off the end of the table: the kernel fetches insns[pc] without a range check (jump targets are checked below)
+        const uint8_t last = w->insns[w->n_insns - 1].op;
+        if (last != MS_OP_DONE && last != MS_OP_JMP && last != MS_OP_PANIC)
+            return fail(err, MADSIM_E_WORKLOAD, "the instruction table must end in MS_OP_DONE, MS_OP_JMP or MS_OP_PANIC");
+    }
     for (uint32_t i = 0; i < w->n_socks; i++)
         if (w->socks[i].node == 0 || w->socks[i].node > w->n_nodes) return fail(err, MADSIM_E_WORKLOAD, "bad socket node");
     for (uint32_t i = 0; i < w->n_socks; i++)
@@ -98,7 +103,7 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
         switch (in.op) {
         case MS_OP_SPAWN: case MS_OP_JOIN: case MS_OP_ABORT:
             if (in.a >= w->n_progs) return fail(err, MADSIM_E_WORKLOAD, "prog operand out of range"); break;
-        case MS_OP_DJNZ: case MS_OP_JMP:
+        case MS_OP_DJNZ: case MS_OP_JMP: case MS_OP_JEQ:
             if (in.b >= w->n_insns) return fail(err, MADSIM_E_WORKLOAD, "jump target out of range"); break;
         case MS_OP_BIND: case MS_OP_REPLY: case MS_OP_RECV: case MS_OP_CLOSE: case MS_OP_RECV_TIMEOUT: case MS_OP_ACCEPT:
             if (in.a >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range");

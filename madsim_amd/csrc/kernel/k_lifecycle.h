@@ -91,7 +91,14 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
     TWORD(c, slot, 0, 0) = f & ~(TF_ALIVE | TF_SCHED | TF_RUN | TF_INBOX);
     if (K::G) AMASK(slot >> 5) &= ~(1u << (slot & 31));
     uint32_t j = (link >> 8) & 0xff;
-    if (j != 0xff) wake<K>(c, L, j, link >> 16);              // async-task notifies the awaiter
+    if (j != 0xff) {                                          // async-task hands the output over and notifies the awaiter
+        const uint32_t jf = TWORD(c, j, 0, 0);
+        if ((jf & TF_ALIVE) && ((jf >> 8) & 0xffff) == (link >> 16)) {     // still that task: it is parked in its MS_OP_JOIN
+            const uint32_t jy = TWORD(c, j, 0, 1);
+            if (((jy >> 16) & 0xff) == SUB_JOIN_WAIT) TWORD(c, j, 0, 1) = (jy & ~0x00ff0000u) | ((outcome == H_CANCELLED ? SUB_JOIN_CANCELLED : SUB_JOIN_COMPLETED) << 16);
+        }
+        wake<K>(c, L, j, link >> 16);
+    }
 }
 
 // NodeInfo::kill (task/mod.rs:133-140): mark + wake every live task holding NodeInfo `info_gen` of `node`, in

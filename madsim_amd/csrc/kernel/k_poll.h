@@ -212,23 +212,25 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     };
 
     while (st == ST_RUN) {
-        if (pc >= P.n_insns) { st = ST_PANIC; break; }
+        // (pc < n_insns always: validate() checks jump targets and that the table ends in DONE / JMP / PANIC)
         uint4 in = insn_fetch<K>(c, pc);
         uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
 
         PROBE(5);
         REG(2);
         // ================= [A] the task is parked on an await of this op =========================
-        if (sub != 0) {
+        if (sub != 0 && sub < SUB_JOIN_WAIT) {
             bool completed = false;                        // this op is done: step to the next one below
             if (op == MS_OP_RECV && sub == 1) {            // oneshot::Receiver (endpoint.rs:142-144)
                 REG(4);
-                if (!(u0.x & TF_INBOX)) { st = ST_PENDING; break; }
-                u0.x &= ~TF_INBOX;
-                from = u0.y >> 24;
-                if (K::FR && P.uses_rpc && (b >> 8) >= MADSIM_TAG_RPC_FIRST)   // (rsp_tag, req, data) = *data.downcast()
-                    TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
-                sub = 2;                                   // -> rand_delay, begun in [C]
+                if (!(u0.x & TF_INBOX)) st = ST_PENDING;       // (no `break`: leaves at the check behind [B], like every Pending)
+                else {
+                    u0.x &= ~TF_INBOX;
+                    from = u0.y >> 24;
+                    if (K::FR && P.uses_rpc && (b >> 8) >= MADSIM_TAG_RPC_FIRST)   // (rsp_tag, req, data) = *data.downcast()
+                        TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
+                    sub = 2;                               // -> rand_delay, begun in [C]
+                }
             } else if (op == MS_OP_YIELD) {
                 completed = true;
             } else if (K::FT && op == MS_OP_RECV_TIMEOUT) {
@@ -360,19 +362,20 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 sub = 0;
                 // fused post-chain of this op (geometry.h build_tables): assert_eq!(val, ..), then djnz / jmp
                 const uint32_t pf = in.w;
-                if ((pf & 1) && u0.w != in.z) { st = ST_PANIC; break; }
-                pc = (pf >> 4) & 0x3fff;
-                if (pf & 2) {
-                    uint32_t sh = ((pf >> 2) & 1) * 16;
-                    uint32_t v = (((u0.z >> sh) & 0xffff) - 1) & 0xffff;
-                    u0.z = (u0.z & ~(0xffffu << sh)) | (v << sh);
-                    if (v) pc = pf >> 18;
-                } else if (pf & 8) {
-                    pc = pf >> 18;
+                if ((pf & 1) && u0.w != in.z) st = ST_PANIC;   // (no `break`: `op` stays this awaiting op, so [B] is skipped too)
+                else {
+                    pc = (pf >> 4) & 0x3fff;
+                    if (pf & 2) {
+                        uint32_t sh = ((pf >> 2) & 1) * 16;
+                        uint32_t v = (((u0.z >> sh) & 0xffff) - 1) & 0xffff;
+                        u0.z = (u0.z & ~(0xffffu << sh)) | (v << sh);
+                        if (v) pc = pf >> 18;
+                    } else if (pf & 8) {
+                        pc = pf >> 18;
+                    }
+                    in = insn_fetch<K>(c, pc);
+                    op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
                 }
-                if (pc >= P.n_insns) { st = ST_PANIC; break; }
-                in = insn_fetch<K>(c, pc);
-                op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
             }
         }
 
@@ -401,7 +404,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 L.obs_hash = (L.obs_hash ^ v) * FNV_PRIME;
                 pc++;
             }
-            if (pc >= P.n_insns) { st = ST_PANIC; break; }
+
             in = insn_fetch<K>(c, pc);
             op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
         }
@@ -561,18 +564,26 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 pc++;
                 break;
             case MS_OP_JOIN: {                             // task/join.rs:59-72 + async-task poll_task
-                uint32_t h = HW(a);
-                uint32_t hs = h & 3;
-                if (hs == H_RUNNING) {
-                    uint32_t cs = (h >> 8) & 0xff;
-                    uint32_t link = TWORD(c, cs, 1, 0);
-                    TWORD(c, cs, 1, 0) = (link & 0xff) | (slot << 8) | (gen << 16);   // register awaiter
-                    st = ST_PENDING;
-                } else if (hs == H_NONE || ((hs == H_CANCELLED) != ((b & 1) != 0))) {
-                    st = ST_PANIC;
-                } else {
-                    pc++;
+                // `handle.await` moves the JoinHandle into the await: the task it names NOW is the one awaited, whatever a later
+                // spawn stores in handle[prog]; task_finish hands its outcome to this task.  The await's state lives in `sub`
+                // with bit 7 set (SUB_JOIN_*), which keeps it out of stage [A]: that chain is hot, this op is rare.
+                uint32_t hs;
+                if (sub == SUB_JOIN_WAIT) { st = ST_PENDING; break; }        // woken for another reason (a stale timer)
+                if (sub != 0) { hs = sub == SUB_JOIN_CANCELLED ? H_CANCELLED : H_COMPLETED; sub = 0; }
+                else {
+                    const uint32_t h = HW(a);
+                    hs = h & 3;
+                    if (hs == H_RUNNING) {
+                        const uint32_t cs = (h >> 8) & 0xff;
+                        const uint32_t link = TWORD(c, cs, 1, 0);
+                        TWORD(c, cs, 1, 0) = (link & 0xff) | (slot << 8) | (gen << 16);   // register awaiter
+                        sub = SUB_JOIN_WAIT;
+                        st = ST_PENDING;
+                        break;
+                    }
                 }
+                if (hs == H_NONE || ((hs == H_CANCELLED) != ((b & 1) != 0))) st = ST_PANIC;     // .unwrap() / .unwrap_err()
+                else pc++;
                 break;
             }
             case MS_OP_YIELD:                              // [DEP tokio yield_now outside a runtime]

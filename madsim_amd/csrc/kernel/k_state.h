@@ -34,6 +34,8 @@ namespace madsim_k {
 enum : uint32_t { TF_ALIVE = 1, TF_SCHED = 2, TF_RUN = 4, TF_KILLED = 8, TF_CANCEL = 16, TF_INBOX = 32,
                   TF_RXWRAP = 64 /* this task's 8-bit receive sequence number has wrapped at least once */,
                   TF_OWNER = 128 /* this task has bound an Endpoint: its finish must look for sockets to close */ };
+// `sub` values of a task parked in MS_OP_JOIN (bit 7 set: stage [A] of poll_task ignores them, stage [C] owns them)
+enum : uint32_t { SUB_JOIN_WAIT = 0x80, SUB_JOIN_COMPLETED = 0x81, SUB_JOIN_CANCELLED = 0x82 };
 enum : uint32_t { EV_WAKE = 1, EV_DELIVER = 2, EV_RESTART = 3,
                   EV_NOP = 4 /* a delivery timer whose message a response hook drops: fires, delivers nothing */ };
 // timer meta word: kind << 29 | ...;  EV_WAKE: gen << 8 | slot;  EV_RESTART: node;  EV_DELIVER (extended builds):

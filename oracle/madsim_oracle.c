@@ -149,6 +149,7 @@ typedef struct {
     uint8_t  inbox_full; uint8_t rxseq;   /* the oneshot::Receiver currently held                    */
     uint64_t inbox_aux;
     int32_t  joiner; uint16_t joiner_gen; /* async-task awaiter                                      */
+    uint8_t  join_state;                  /* parked in MS_OP_JOIN: 1 awaiting, 2 / 3 the awaited task completed / was cancelled */
     int8_t   conn; uint8_t side;          /* the (Sender, Receiver) pair this task holds, and which end */
     uint32_t cval; uint8_t chas; uint64_t carrive; uint32_t backoff_ms;   /* receiver stream state (net/mod.rs:386-400) */
 } task_t;
@@ -590,7 +591,11 @@ static void task_finish_opt(sim_t* S, uint16_t slot, int outcome, int guard) {
     if (h->state == H_RUNNING && h->slot == slot && h->gen == t->gen) h->state = (uint8_t)outcome;
     int32_t j = t->joiner; uint16_t jg = t->joiner_gen;
     t->alive = 0; t->scheduled = 0; t->running = 0;
-    if (j >= 0) wake(S, (uint16_t)j, jg);                 /* async-task notifies the awaiter */
+    if (j >= 0) {                                         /* async-task hands the output over and notifies the awaiter */
+        task_t* jt = (size_t)j < S->tasks.n ? &S->tasks.p[j] : NULL;
+        if (jt && jt->alive && jt->gen == jg && jt->join_state == 1) jt->join_state = outcome == H_CANCELLED ? 3 : 2;
+        wake(S, (uint16_t)j, jg);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -669,15 +674,24 @@ static int poll_task(sim_t* S, uint16_t slot) {
             t = &S->tasks.p[slot]; t->pc++;
             break;
         case MS_OP_JOIN: {                                 /* task/join.rs:59-72 + async-task poll_task */
-            handle_t* h = &S->handles[in->a];
-            if (h->state == H_RUNNING) {
-                task_t* c = &S->tasks.p[h->slot];
-                c->joiner = slot; c->joiner_gen = t->gen;  /* header.register(cx.waker()) */
-                return 0;
+            /* `handle.await` moves the JoinHandle into the await: the task it names when the await begins is the one awaited,
+             * whatever a later spawn stores in handle[prog]; its outcome reaches the awaiter when it finishes (task_finish) */
+            const int want_err = in->b & 1;
+            int outcome;
+            if (t->join_state == 1) return 0;                  /* woken for another reason (a stale timer): still pending */
+            if (t->join_state) { outcome = t->join_state == 3 ? H_CANCELLED : H_COMPLETED; t->join_state = 0; }
+            else {
+                handle_t* h = &S->handles[in->a];
+                if (h->state == H_RUNNING) {
+                    task_t* c = &S->tasks.p[h->slot];
+                    c->joiner = slot; c->joiner_gen = t->gen;  /* header.register(cx.waker()) */
+                    t->join_state = 1;
+                    return 0;
+                }
+                if (h->state == H_NONE) return 1;
+                outcome = h->state;
             }
-            int want_err = in->b & 1;
-            if (h->state == H_NONE) return 1;
-            if ((h->state == H_CANCELLED) != want_err) return 1;   /* unwrap()/unwrap_err() */
+            if ((outcome == H_CANCELLED) != want_err) return 1;   /* unwrap()/unwrap_err() */
             t->pc++;
             break;
         }
@@ -1212,6 +1226,14 @@ static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
         const madsim_insn_t* in = &w->insns[i];
         if ((in->op == MS_OP_SEND || in->op == MS_OP_CONNECT || in->op == MS_OP_RPC_CALL) &&
             (uint32_t)(in->b & 0xff) < w->n_socks && w->socks[in->b & 0xff].port == 0) return -1;
+    }
+    if (w->n_insns == 0) return -1;
+    {                                                     /* no body may run off the end of the table (the kernel does not check) */
+        const uint8_t last = w->insns[w->n_insns - 1].op;
+        if (last != MS_OP_DONE && last != MS_OP_JMP && last != MS_OP_PANIC) return -1;
+        for (uint32_t i = 0; i < w->n_insns; i++)
+            if ((w->insns[i].op == MS_OP_DJNZ || w->insns[i].op == MS_OP_JMP || w->insns[i].op == MS_OP_JEQ) && w->insns[i].b >= w->n_insns) return -1;
+        for (uint32_t p = 0; p < w->n_progs; p++) if (w->progs[p].entry >= w->n_insns) return -1;
     }
     for (uint32_t p = 0; p < w->n_progs; p++) {           /* a guard's Drop spawns the next program, on the same node */
         if (!(w->progs[p].flags & MADSIM_PROG_DROP_SPAWN)) continue;

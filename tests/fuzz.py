@@ -263,6 +263,64 @@ def random_guard_workload(rng: random.Random):
     return random_lifecycle_workload(rng, guards=True)
 
 
+def random_supervisor_workload(rng: random.Random):
+    """Supervisor calls from everywhere: every task — not only the test body — may spawn, abort and join other tasks (its own
+    handle included), kill / restart / build any node (its own included), yield and panic.  What this reaches that the other
+    generators do not: task::spawn under the caller's own NodeInfo after it killed or restarted its node, a JoinHandle awaited
+    while its program is spawned again, init tasks spawned by hand, builds of a built node.  Every task body starts with a
+    sleep of at least 1 ms and spawns only programs declared after it, so every respawn loop is bounded by the main task's
+    few simulated seconds.  Returns (BuiltWorkload, Config, description)."""
+    wl = W.WorkloadBuilder()
+    nodes = [wl.create_node(restart_on_panic=rng.random() < 0.3) for _ in range(rng.randint(1, 3))]
+    tasks = []
+    for n in nodes:
+        for j in range(2):
+            tasks.append(wl.task(n, init=(j == 0 and rng.random() < 0.5)))
+    desc = []
+
+    def act(t, me):
+        k = rng.choice(["sleep", "sleep", "spawn", "abort", "join", "kill", "restart", "build", "yield", "flag", "abort_self", "join_self", "panic"])
+        later = [x for i, x in enumerate(tasks) if me is None or i > me]
+        if k == "sleep":
+            t.sleep(ms=rng.choice([0, 1, 5, 40, 700]))
+        elif k == "spawn" and later:
+            t.spawn(rng.choice(later))
+        elif k == "abort":
+            t.abort(rng.choice(tasks))
+        elif k == "join":
+            t.join(rng.choice(tasks), expect_err=rng.random() < 0.5)
+        elif k == "kill":
+            t.kill(rng.choice(nodes))
+        elif k == "restart":
+            t.restart(rng.choice(nodes))
+        elif k == "build" and me is None:
+            t.build_node(rng.choice(nodes))
+        elif k == "yield":
+            t.yield_now()
+        elif k == "flag":
+            t.flag_add(rng.randrange(4), 1)
+        elif k == "abort_self" and me is not None:
+            t.abort(tasks[me])
+        elif k == "join_self" and me is not None and rng.random() < 0.3:
+            t.join(tasks[me], expect_err=rng.random() < 0.5)
+        elif k == "panic" and rng.random() < 0.3:
+            t.panic(rng.randrange(3))
+        else:
+            return
+        desc.append(k)
+
+    for i, t in enumerate(tasks):
+        t.sleep(ms=rng.choice([1, 2, 9, 60]))
+        for _ in range(rng.randint(1, 5)):
+            act(t, i)
+        t.trace(100 + i); t.done()
+    m = wl.main()
+    for _ in range(rng.randint(2, 8)):
+        act(m, None)
+    m.sleep(ms=rng.choice([10, 2000])); m.done()
+    return wl.build(), A.Config.default(), "+".join(desc)
+
+
 def generous_limits():
     lim = A.Limits()
     lim.max_steps = 200_000

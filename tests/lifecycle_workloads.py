@@ -680,6 +680,21 @@ def spawn_in_future_drop_across_restart():
     return wl.build()
 
 
+def join_handle_awaits_the_task_it_named():
+    """`handle.await` moves the JoinHandle into the await (task/join.rs:59-72): the awaiter gets the outcome of the task the
+    handle named when the await began — here the first worker, done after 5 ms — although another task has since spawned the
+    same program again (10 ms of work left) and aborted it."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    worker = wl.task(n); worker.sleep(ms=5); worker.flag_add(0, 1)
+    other = wl.task(n); other.sleep(ms=1); other.spawn(worker); other.sleep(ms=1); other.abort(worker); other.sleep(ms=20)
+    m = wl.main(); m.mark(); m.spawn(worker); m.spawn(other)
+    m.join(worker)                                           # Ok(()): the first worker completed; the second one was cancelled
+    m.assert_elapsed(">=", ms=5); m.assert_elapsed("<", ms=7); m.assert_flag(0, 1)
+    m.join(worker, expect_err=True)                          # the handle variable itself now names the aborted second worker
+    return wl.build()
+
+
 def spawn_after_restarting_own_node():
     """task::spawn = Spawner::current() = the calling task's OWN Arc<NodeInfo> (task/mod.rs:592-599): a task that restarts its
     own node keeps running until it yields, and what it spawns meanwhile belongs to the dead incarnation — it never runs.
@@ -704,6 +719,7 @@ def spawn_after_killing_own_node():
     return wl.build()
 
 
+ALL.update(join_handle_awaits_the_task_it_named=join_handle_awaits_the_task_it_named)
 ALL.update(spawn_after_restarting_own_node=spawn_after_restarting_own_node, spawn_after_killing_own_node=spawn_after_killing_own_node)
 ALL.update(spawn_in_future_drop_by_aborting_task=spawn_in_future_drop_by_aborting_task,
            spawn_in_future_drop_by_killing_node=spawn_in_future_drop_by_killing_node,
@@ -721,5 +737,8 @@ def limits(name):
     """Device capacities a workload needs beyond the defaults (None = defaults)."""
     if name in ("rpc_server_restart", "rpc_hooks"):   # timed-out calls leave dead registrations behind (rpc.rs:125)
         lim = A.Limits(); lim.mbox_regs, lim.mbox_msgs = 8, 4
+        return lim
+    if name == "join_handle_awaits_the_task_it_named":   # two instances of one program alive at once
+        lim = A.Limits(); lim.max_tasks = 6
         return lim
     return None

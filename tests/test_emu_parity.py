@@ -123,6 +123,19 @@ def test_fuzz_guard_workloads():
         assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
 
 
+def test_fuzz_supervisor_workloads():
+    """Supervisor calls from every task (spawn / abort / join / kill / restart of own and other nodes), in both state layouts."""
+    for k in range(160):
+        w, cfg, desc = fuzz.random_supervisor_workload(random.Random(9700 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 48
+        if k % 2:
+            lim = _global(lim)
+        o, _ = oracle.run_batch(w, k * 3, 12, cfg, lim)
+        e = emu.run_batch(w, k * 3, 12, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+
+
 def test_baseline_config_shaped_workloads():
     """configs[2]-shaped election loop (timeouts, partitions, HBM heap spill) and configs[3]-shaped KV-RPC."""
     o = _same(W.raft_election(), 0, 300, None, W.raft_election_limits())

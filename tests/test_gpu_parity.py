@@ -274,6 +274,22 @@ def test_fuzz_guard_workloads_gpu(hip):
         assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
 
 
+def test_fuzz_supervisor_workloads_gpu(hip):
+    """Supervisor calls from every task: task::spawn after killing / restarting the own node, JoinHandles awaited across a
+    respawn of their program, init tasks spawned by hand; odd rounds with the per-seed state in the global-memory block."""
+    import random
+    from tests import fuzz
+    for k in range(200):
+        w, cfg, desc = fuzz.random_supervisor_workload(random.Random(7800 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 48
+        if k % 2:
+            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        got, _ = hip.run_batch(w, k * 17, 64, cfg, lim)
+        want, _ = oracle.run_batch(w, k * 17, 64, cfg, lim)
+        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+
+
 def test_config2_election_loop_262144_seeds(hip):
     """BASELINE configs[2]: 5-node election loop with NetSim partition injection, 262 144 seeds on one GPU
     (timeout() duplicate timers push most of the timer heap into the HBM spill region)."""
