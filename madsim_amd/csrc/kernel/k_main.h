@@ -184,19 +184,27 @@ __global__ __launch_bounds__(256, !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : M
             now = L.clock;
             PROBE(3);
         }
+        // One exit (every `break` out of a hot loop is an exit edge whose phis cost register copies): the checks decide a
+        // verdict — or that the run queue has work again — in the reference's order, the loop leaves when anything was decided.
         bool idle_jump = false;
         while (L.verdict == MADSIM_RUNNING) {
             REG(19);
             timer_expire<K>(c, L, now);
+            uint32_t v = MADSIM_RUNNING;
             if (idle_jump) {
                 L.clock = now;                                // time/mod.rs:55: after the callbacks
                 idle_jump = false;
-                if (P.time_limit && L.clock >= P.time_limit) { L.verdict = MADSIM_TIME_LIMIT; break; }   // task/mod.rs:253-258
+                if (P.time_limit && L.clock >= P.time_limit) v = MADSIM_TIME_LIMIT;     // task/mod.rs:253-258
             }
-            if (L.steps >= P.max_steps) { L.verdict = MADSIM_STEP_LIMIT; break; }
-            if (L.ready_len > 0) break;                       // back to run_all_ready
-            if (L.main_done) { L.verdict = MADSIM_PASS; break; }                          // :241-243
-            if (L.heap_len == 0) { L.verdict = MADSIM_DEADLOCK; break; }                  // :250
+            const bool more = L.ready_len > 0;                // back to run_all_ready
+            if (v == MADSIM_RUNNING) {
+                if (L.steps >= P.max_steps) v = MADSIM_STEP_LIMIT;
+                else if (more) { }
+                else if (L.main_done) v = MADSIM_PASS;                                   // :241-243
+                else if (L.heap_len == 0) v = MADSIM_DEADLOCK;                           // :250
+            }
+            L.verdict = v;
+            if (v != MADSIM_RUNNING || more) break;
             now = L.top_dl + 50;                              // advance_to_next_event (time/mod.rs:47-53)
             idle_jump = true;
         }

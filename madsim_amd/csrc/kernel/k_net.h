@@ -15,11 +15,12 @@ __device__ __forceinline__ void ready_push(const Ctx& c, Lane& L, uint32_t slot)
 
 template <class K>
 __device__ __forceinline__ void wake(const Ctx& c, Lane& L, uint32_t slot, uint32_t gen) {
-    uint32_t f = TWORD(c, slot, 0, 0);
-    if (!(f & TF_ALIVE) || ((f >> 8) & 0xffff) != gen) return;   // COMPLETED | CLOSED
-    if (f & TF_SCHED) return;
-    TWORD(c, slot, 0, 0) = f | TF_SCHED;
-    if (!(f & TF_RUN)) ready_push<K>(c, L, slot);                   // RUNNING: run() re-queues after the poll
+    const uint32_t f = TWORD(c, slot, 0, 0);
+    // not COMPLETED | CLOSED (a stale waker), not SCHEDULED already
+    if ((f & (TF_ALIVE | TF_SCHED)) == TF_ALIVE && ((f >> 8) & 0xffff) == gen) {
+        TWORD(c, slot, 0, 0) = f | TF_SCHED;
+        if (!(f & TF_RUN)) ready_push<K>(c, L, slot);               // RUNNING: run() re-queues after the poll
+    }
 }
 
 // ---- Network -----------------------------------------------------------------------------------
@@ -66,49 +67,56 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
         const uint4 in = INSN(c, (meta >> 6) & 0xfff);
         from = (in.x >> 8) & 0x3f; tag = in.x >> 24; val = in.y;      // (base-op builds: plain addresses, never a loopback flag)
     }
-    uint32_t h = SW(c, s, 0);
-    if (!(h & 1) || ((h >> 1) & 0xff) != sgen) return;     // that Endpoint object is gone
-    if (K::FC && c.P.uses_chan && SW(c, s, 1) == ~0u) return;     // ... only its connections still hold the address
-    uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
-    // Typed RPC (net/rpc.rs): a response (tag 0xff) is addressed to one pending receive — the word of its registration,
-    // tag | slot | rxseq | gen, rides in the payload's upper 24 bits — where the reference matches a random u64 tag.
-    const bool rpc = K::FR && c.P.uses_rpc;
-    const bool rsp = rpc && tag == 0xff;
-    uint32_t i = 0;
-    while (i < nreg) {
-        REG(24);
-        uint32_t r = SW(c, s, 2 + i);
-        if ((r & 0xff) == tag && (!rsp || (r >> 8) == (val >> 8))) {
-            nreg--;
-            SW(c, s, 2 + i) = SW(c, s, 2 + nreg);          // swap_remove
-            uint32_t slot = (r >> 8) & 0xff, rxseq = (r >> 16) & 0xff, g8 = r >> 24;
-            uint4 u0 = TU(c, slot, 0);
-            uint32_t link = TWORD(c, slot, 1, 0);
-            if ((u0.x & TF_ALIVE) && ((u0.x >> 8) & 0xff) == g8 && (link & 0xff) == rxseq && !(u0.x & TF_INBOX)) {
-                // oneshot::Sender::send Ok -> value stored, receiver task woken [DEP tokio oneshot]
-                bool sched = u0.x & TF_SCHED;
-                u0.x |= TF_INBOX | TF_SCHED;
-                u0.y = (u0.y & 0x00ffffffu) | (from << 24);
-                u0.w = val;
-                if (rpc && tag >= MADSIM_TAG_RPC_FIRST) {                  // 8-bit code; a request also carries its rsp_tag
-                    u0.w = val & 0xff;
-                    if (!rsp) TWORD(c, slot, c.P.rpc_unit, 1) = val >> 8;  // staged with the oneshot value
+    const uint32_t h = SW(c, s, 0);
+    bool live = (h & 1) && ((h >> 1) & 0xff) == sgen;      // else: that Endpoint object is gone
+    if (K::FC && c.P.uses_chan && live && SW(c, s, 1) == ~0u) live = false;     // ... only its connections still hold the address
+    if (live) {
+        uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
+        // Typed RPC (net/rpc.rs): a response (tag 0xff) is addressed to one pending receive — the word of its registration,
+        // tag | slot | rxseq | gen, rides in the payload's upper 24 bits — where the reference matches a random u64 tag.
+        const bool rpc = K::FR && c.P.uses_rpc;
+        const bool rsp = rpc && tag == 0xff;
+        uint32_t i = 0;
+        bool taken = false;                                // (one loop exit, no early returns: see k_main.h)
+        while (i < nreg && !taken) {
+            REG(24);
+            uint32_t r = SW(c, s, 2 + i);
+            if ((r & 0xff) == tag && (!rsp || (r >> 8) == (val >> 8))) {
+                nreg--;
+                SW(c, s, 2 + i) = SW(c, s, 2 + nreg);      // swap_remove
+                uint32_t slot = (r >> 8) & 0xff, rxseq = (r >> 16) & 0xff, g8 = r >> 24;
+                uint4 u0 = TU(c, slot, 0);
+                uint32_t link = TWORD(c, slot, 1, 0);
+                if ((u0.x & TF_ALIVE) && ((u0.x >> 8) & 0xff) == g8 && (link & 0xff) == rxseq && !(u0.x & TF_INBOX)) {
+                    // oneshot::Sender::send Ok -> value stored, receiver task woken [DEP tokio oneshot]
+                    bool sched = u0.x & TF_SCHED;
+                    u0.x |= TF_INBOX | TF_SCHED;
+                    u0.y = (u0.y & 0x00ffffffu) | (from << 24);
+                    u0.w = val;
+                    if (rpc && tag >= MADSIM_TAG_RPC_FIRST) {                  // 8-bit code; a request also carries its rsp_tag
+                        u0.w = val & 0xff;
+                        if (!rsp) TWORD(c, slot, c.P.rpc_unit, 1) = val >> 8;  // staged with the oneshot value
+                    }
+                    TU(c, slot, 0) = u0;
+                    if (!sched && !(u0.x & TF_RUN)) ready_push<K>(c, L, slot);
+                    taken = true;
                 }
-                TU(c, slot, 0) = u0;
-                SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);
-                if (!sched && !(u0.x & TF_RUN)) ready_push<K>(c, L, slot);
-                return;
+            } else {
+                i++;
             }
+        }
+        if (taken) {
+            SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);
+        } else if (nmsg >= c.P.mbox_msgs) {
+            L.ovf = 1;
         } else {
-            i++;
+            if (rsp) tag = 0xfe;                           // nobody holds that rsp_tag any more: it can never be received
+            SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);
+            SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg + 1) = val;
+            nmsg++;
+            SW(c, s, 0) = (HDR_SET_NMSG(h, nmsg) & ~(0xffu << 9)) | (nreg << 9);
         }
     }
-    if (nmsg >= c.P.mbox_msgs) { L.ovf = 1; return; }
-    if (rsp) tag = 0xfe;                                   // nobody holds that rsp_tag any more: it can never be received
-    SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);
-    SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg + 1) = val;
-    nmsg++;
-    SW(c, s, 0) = (HDR_SET_NMSG(h, nmsg) & ~(0xffu << 9)) | (nreg << 9);
 }
 
 template <class K> __device__ __forceinline__ void node_restart(const Ctx& c, Lane& L, uint32_t node);

@@ -317,7 +317,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     }
                     else if ((PLAIN_ADDR ? find_bound<K>(c, a) : find_exact<K>(c, node, sw)) >= 0) bind_err = MADSIM_VAL_ADDR_IN_USE;
                     if (bind_err) {
-                        if (!(b & 1)) { st = ST_PANIC; break; }            // .unwrap()
+                        if (!(b & 1)) st = ST_PANIC;                        // .unwrap()  (leaves below: `completed` stays false)
                         u0.w = bind_err;
                     } else {
                         if (b & 1) u0.w = 0;
@@ -339,8 +339,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     // Network::try_send -> resolve_dest_node, test_link, socket lookup (network.rs:261-313)
                     uint64_t lat; int ds; uint32_t lb;
                     const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dst_addr, dst, &lat, &ds, &lb);
-                    if (sent < 0) { st = ST_PANIC; break; }
-                    if (sent) {
+                    if (sent < 0) st = ST_PANIC;
+                    else if (sent) {
                         {
                             uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
                             uint2 ev = ev_deliver_meta<K>(sgen, b >> 8, a | (lb << 6), (uint32_t)ds, imm, pc);
@@ -355,7 +355,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         }
                     }
                 }
-                completed = true;
+                completed = st == ST_RUN;                  // (a panic above leaves at the check behind [B]: no `break` in this chain)
             }
             if (completed) {                               // fall through to [B]/[C] with the next op: one pass per poll
                 REG(12);
@@ -438,14 +438,16 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     sub = 2;                               // oneshot already holds the value
                     SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
                 } else {
-                    if (nreg >= P.mbox_regs) { L.ovf = 1; st = ST_PENDING; break; }
-                    const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
-                    // dead registrations (timed-out / dropped receives, extended ops only) stay in the Vec like the
-                    // reference's; an 8-bit rxseq that wraps onto one of them would make it look live: overflow, never a different answer
-                    if ((K::FT || K::FN) && may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;
-                    SW(c, a, 2 + nreg) = reg;
-                    SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
-                    sub = 1;
+                    if (nreg >= P.mbox_regs) L.ovf = 1;            // (a capacity verdict: the state no longer matters)
+                    else {
+                        const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
+                        // dead registrations (timed-out / dropped receives, extended ops only) stay in the Vec like the
+                        // reference's; an 8-bit rxseq that wraps onto one of them would make it look live: overflow, never a different answer
+                        if ((K::FT || K::FN) && may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;
+                        SW(c, a, 2 + nreg) = reg;
+                        SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
+                        sub = 1;
+                    }
                     st = ST_PENDING;
                 }
             }

@@ -60,14 +60,14 @@ __device__ __forceinline__ uint2 ev_deliver_meta(uint32_t sgen, uint32_t tag, ui
 template <class K>
 __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos, const uint4& hole) {
     uint64_t hd = ev_deadline(hole);
-    while (pos > 0) {
+    bool up = pos > 0;
+    while (up) {                                       // (one exit: see k_main.h)
         REG(11);
-        uint32_t parent = (pos - 1) >> 1;
-        if (parent == 0 && hd >= L.top_dl) break;      // root deadline is mirrored in a register
-        uint4 p = heap_get<K>(c, parent);
-        if (hd >= ev_deadline(p)) break;     // hole <= parent in heap order: stop
-        heap_set<K>(c, pos, p);
-        pos = parent;
+        const uint32_t parent = (pos - 1) >> 1;
+        const uint4 p = heap_get<K>(c, parent);
+        // hole <= parent in heap order: stop (the root's deadline is mirrored in a register)
+        up = hd < (parent == 0 ? L.top_dl : ev_deadline(p));
+        if (up) { heap_set<K>(c, pos, p); pos = parent; up = pos > 0; }
     }
     heap_set<K>(c, pos, hole);
     if (pos == 0) L.top_dl = hd;
