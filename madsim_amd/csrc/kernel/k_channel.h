@@ -13,30 +13,36 @@ namespace madsim_k {
 template <class K>
 __device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_node, uint32_t addr, uint32_t idx, uint64_t* latency, int* dst_sock, uint32_t* from_lb) {
     const KParams& P = c.P;
+    // (one result variable, no early returns: every extra way out of an inlined body costs phi copies where it is used)
+    int res = 0;
     int dn = (int)(addr & 0xff);                            // resolve_dest_node: plain node IPs resolve to their node
-    if (!PLAIN_ADDR) { dn = resolve_dest_node<K>(c, src_node, addr); if (dn < 0) return 0; }     // dropped, no draw
-    const uint32_t dst_node = (uint32_t)dn;
-    bool clogged = false;
-    if (P.has_clog) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
-    if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
-    if (clogged) return 0;
-    if (gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) return 0;
-    L.msg_count++;
-    *latency = sample_latency<K>(c, L);
-    int ds;
-    if (PLAIN_ADDR) ds = find_bound<K>(c, idx);
-    else {
-        ds = find_exact<K>(c, dst_node, addr);              // sockets.get(&(dst, protocol))
-        if (ds < 0) ds = find_exact<K>(c, dst_node, (addr & 0xffff0000u) | (MADSIM_ADDR_UNSPECIFIED << 8));   // .or_else(0.0.0.0:port)
+    if (!PLAIN_ADDR) dn = resolve_dest_node<K>(c, src_node, addr);          // < 0: dropped, no draw
+    if (dn >= 0) {
+        const uint32_t dst_node = (uint32_t)dn;
+        bool clogged = false;
+        if (P.has_clog) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
+        if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
+        if (!clogged && !gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) {
+            L.msg_count++;
+            *latency = sample_latency<K>(c, L);
+            int ds;
+            if (PLAIN_ADDR) ds = find_bound<K>(c, idx);
+            else {
+                ds = find_exact<K>(c, dst_node, addr);              // sockets.get(&(dst, protocol))
+                if (ds < 0) ds = find_exact<K>(c, dst_node, (addr & 0xffff0000u) | (MADSIM_ADDR_UNSPECIFIED << 8));   // .or_else(0.0.0.0:port)
+            }
+            if (ds >= 0) {                                  // else: draws consumed, silently dropped
+                *from_lb = 0;
+                res = 1;
+                if (!PLAIN_ADDR) {
+                    *from_lb = ((addr >> 8) & 0xff) == MADSIM_ADDR_LOOPBACK;
+                    if (!*from_lb && !node_has_ip(c, src_node)) res = -1;
+                }
+                *dst_sock = ds;
+            }
+        }
     }
-    if (ds < 0) return 0;                                   // draws consumed, silently dropped
-    *from_lb = 0;
-    if (!PLAIN_ADDR) {
-        *from_lb = ((addr >> 8) & 0xff) == MADSIM_ADDR_LOOPBACK;
-        if (!*from_lb && !node_has_ip(c, src_node)) return -1;
-    }
-    *dst_sock = ds;
-    return 1;
+    return res;
 }
 
 // the `test_link` closure of channel() (net/mod.rs:375-380): Some(now + latency), None (~0) or a panic of the caller

@@ -234,14 +234,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             } else if (op == MS_OP_YIELD) {
                 completed = true;
             } else if (K::FT && op == MS_OP_RECV_TIMEOUT) {
-                completed = recv_timeout_poll();
-                if (!completed) break;
+                completed = recv_timeout_poll();            // (false: st is Pending — the round leaves behind [B], no `break` here)
             } else if (K::FR && op == MS_OP_RPC_CALL) {
-                completed = rpc_call_poll();
-                if (!completed || st == ST_PANIC) break;
+                completed = rpc_call_poll() && st == ST_RUN;
             } else if (K::FC && op == MS_OP_ACCEPT && sub == 2) {
                 completed = accept_check(a);
-                if (!completed) break;
             } else {                                       // a Sleep (time/sleep.rs:47-54)
                 uint64_t deadline = u64of(u1.z, u1.w);
                 REG(3);
@@ -250,31 +247,31 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     REG(5);
                     if (!timer_add<K>(c, L, deadline, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
                     st = ST_PENDING;
-                    break;
                 }
-                if (K::FC && op == MS_OP_ACCEPT) {       // rand_delay done -> conn_rx.recv()
+                else if (K::FC && op == MS_OP_ACCEPT) {    // rand_delay done -> conn_rx.recv()
                     sub = 2;
-                    if (!accept_check(a)) break;
+                    accept_check(a);                       // (false: st is Pending)
                 } else if (K::FC && op == MS_OP_CRECV) {
                     uint4 u3 = TU(c, slot, c.P.chan_unit);
                     if (sub == 2) {                        // sleep(backoff) done: backoff = min(2 * backoff, 10 s); retry the link
                         uint32_t bo = (u3.x >> 16) * 2; if (bo > 10000) bo = 10000;
                         uint32_t cw = CONNW(u3.x & 0xff, 0);
                         uint64_t arrive = chan_test_link<K>(c, L, cw, 1 - ((u3.x >> 8) & 1));
-                        if (arrive == CHAN_LINK_PANIC) { st = ST_PANIC; break; }
-                        u3.x = (u3.x & 0xffff) | (bo << 16); u3.z = (uint32_t)arrive; u3.w = (uint32_t)(arrive >> 32);
-                        TU(c, slot, c.P.chan_unit) = u3;
-                        crecv_arm();
-                        break;
+                        if (arrive == CHAN_LINK_PANIC) st = ST_PANIC;
+                        else {
+                            u3.x = (u3.x & 0xffff) | (bo << 16); u3.z = (uint32_t)arrive; u3.w = (uint32_t)(arrive >> 32);
+                            TU(c, slot, c.P.chan_unit) = u3;
+                            crecv_arm();                   // (always ends Pending)
+                        }
                     }
-                    u0.w = u3.y;                           // sub 3: sleep_until(arrive_time) done -> yield value
+                    else u0.w = u3.y;                      // sub 3: sleep_until(arrive_time) done -> yield value
                 } else if (K::FC && op == MS_OP_CONNECT) {   // NetSim::connect1 (net/mod.rs:345-363)
                     uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                     if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
                     uint64_t lat; int ds; uint32_t lb;
                     const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, SOCKW(c, b & 0xff), b & 0xff, &lat, &ds, &lb);
-                    if (sent < 0) { st = ST_PANIC; break; }
-                    if (!sent) {
+                    if (sent < 0) st = ST_PANIC;
+                    else if (!sent) {
                         u0.w = MADSIM_VAL_REFUSED;
                     } else {
                         uint32_t id = 0;

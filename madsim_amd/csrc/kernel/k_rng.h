@@ -88,18 +88,20 @@ template <class K>
 __device__ __forceinline__ uint64_t sample_latency(const Ctx& c, Lane& L) {
     const KParams& P = c.P;
     uint64_t res;
-    for (;;) {
+    bool ok;
+    do {                                                // (one exit: see k_main.h on exit edges)
         REG(8);
         uint64_t v = rng_next(L);
         rng_log<K>(c, L);
         if (P.lat_mode == 0) {
             uint64_t m = (uint64_t)(uint32_t)(v >> 32) * (uint64_t)(uint32_t)P.lat_range;
-            if ((uint32_t)m <= (uint32_t)P.lat_zone) { res = P.lat_low + (m >> 32); break; }
+            ok = (uint32_t)m <= (uint32_t)P.lat_zone;
+            res = P.lat_low + (m >> 32);
         } else {
-            uint64_t mlo = v * P.lat_range;
-            if (mlo <= P.lat_zone) { res = P.lat_low + __umul64hi(v, P.lat_range); break; }
+            ok = v * P.lat_range <= P.lat_zone;
+            res = P.lat_low + __umul64hi(v, P.lat_range);
         }
-    }
+    } while (!ok);
     return res;
 }
 

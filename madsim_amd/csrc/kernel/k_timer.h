@@ -78,12 +78,14 @@ template <class K>
 __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val) {
     PROBE2(0);
     REG(10);
-    if (L.heap_len >= c.P.heap_lds + (K::SPILL ? c.P.heap_spill : 0u)) return false;
-    uint4 e = make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, val);
-    heap_sift_up<K>(c, L, L.heap_len, e);
-    L.heap_len++;
+    const bool room = L.heap_len < c.P.heap_lds + (K::SPILL ? c.P.heap_spill : 0u);
+    if (room) {                                        // (no early return: see k_main.h on exit edges)
+        uint4 e = make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, val);
+        heap_sift_up<K>(c, L, L.heap_len, e);
+        L.heap_len++;
+    }
     PROBE2(10);
-    return true;
+    return room;
 }
 
 // BinaryHeap::pop: swap the last element into the root, sift_down_to_bottom(0), then sift_up.
