@@ -609,8 +609,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 uint32_t h = HW(a);
                 if ((h & 3) == H_RUNNING) {
                     uint32_t cs = (h >> 8) & 0xff;
-                    TWORD(c, cs, 0, 0) |= TF_CANCEL;
-                    wake<K>(c, L, cs, h >> 16);
+                    if (cs == slot) u0.x |= TF_CANCEL | TF_SCHED;   // its OWN handle: this task's unit0 lives in registers during the
+                    else {                                          // poll; woken while RUNNING = re-queued after it (and dropped)
+                        TWORD(c, cs, 0, 0) |= TF_CANCEL;
+                        wake<K>(c, L, cs, h >> 16);
+                    }
                 }
                 pc++;
                 break;

@@ -695,6 +695,17 @@ def join_handle_awaits_the_task_it_named():
     return wl.build()
 
 
+def abort_own_handle():
+    """A task that aborts its own JoinHandle (task/join.rs:158-163) keeps running until it yields — it is cancelled and woken while
+    RUNNING — and is dropped when the executor pops it again: the work behind its next await never happens."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n)
+    t.sleep(ms=1); t.abort(t); t.flag_add(0, 1); t.sleep(ms=5); t.flag_add(0, 10)
+    m = wl.main(); m.spawn(t); m.join(t, expect_err=True); m.sleep(ms=20); m.assert_flag(0, 1)
+    return wl.build()
+
+
 def spawn_after_restarting_own_node():
     """task::spawn = Spawner::current() = the calling task's OWN Arc<NodeInfo> (task/mod.rs:592-599): a task that restarts its
     own node keeps running until it yields, and what it spawns meanwhile belongs to the dead incarnation — it never runs.
@@ -720,6 +731,7 @@ def spawn_after_killing_own_node():
 
 
 ALL.update(join_handle_awaits_the_task_it_named=join_handle_awaits_the_task_it_named)
+ALL.update(abort_own_handle=abort_own_handle)
 ALL.update(spawn_after_restarting_own_node=spawn_after_restarting_own_node, spawn_after_killing_own_node=spawn_after_killing_own_node)
 ALL.update(spawn_in_future_drop_by_aborting_task=spawn_in_future_drop_by_aborting_task,
            spawn_in_future_drop_by_killing_node=spawn_in_future_drop_by_killing_node,
