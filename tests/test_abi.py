@@ -58,6 +58,48 @@ def test_geometry_and_validation_need_no_gpu():
         runtime.geometry(bad.build())
 
 
+def test_program_table_validation():
+    """What the kernel relies on instead of checking at run time: the instruction table ends in a terminator (no body can run off
+    its end), every jump target is inside it; and the rules of MADSIM_PROG_DROP_SPAWN (the guard spawns the NEXT program, on the
+    same node, never together with pause) — refused by the library and by the oracle alike."""
+    import oracle
+    def raw(insns, progs, nodes=1):
+        w = workload.WorkloadBuilder()
+        for _ in range(nodes):
+            w.create_node()
+        return workload.BuiltWorkload(w.nodes, progs, [], insns)
+    off_end = raw([A.Insn(A.OP["SLEEP"], 0, 0, 5)], [A.Prog(0, 0, 0)])                      # ... and then what?
+    with pytest.raises(runtime.MadsimHipError, match="must end in"):
+        runtime.geometry(off_end)
+    with pytest.raises(RuntimeError):
+        oracle.run_batch(off_end, 0, 1)
+    bad_jeq = raw([A.Insn(A.OP["JEQ"], 0, 9, 0), A.Insn(A.OP["DONE"], 0, 0, 0)], [A.Prog(0, 0, 0)])
+    with pytest.raises(runtime.MadsimHipError, match="jump target"):
+        runtime.geometry(bad_jeq)
+    with pytest.raises(RuntimeError):
+        oracle.run_batch(bad_jeq, 0, 1)
+    # a guard must have a next program, on the guard's node ...
+    last = workload.WorkloadBuilder(); n = last.create_node(); last.task(n, spawn_on_drop=True)
+    with pytest.raises(runtime.MadsimHipError, match="DROP_SPAWN"):
+        runtime.geometry(last.build())
+    with pytest.raises(RuntimeError):
+        oracle.run_batch(last.build(), 0, 1)
+    other = workload.WorkloadBuilder(); n1, n2 = other.create_node(), other.create_node()
+    other.task(n1, spawn_on_drop=True); other.task(n2)
+    with pytest.raises(runtime.MadsimHipError, match="same node"):
+        runtime.geometry(other.build())
+    # ... and no pause anywhere in the workload (a parked Runnable is dropped in the KILLER's context)
+    paused = workload.WorkloadBuilder(); n = paused.create_node()
+    paused.task(n, spawn_on_drop=True); paused.task(n); paused.main().pause(n)
+    with pytest.raises(runtime.MadsimHipError, match="MS_OP_PAUSE"):
+        runtime.geometry(paused.build())
+    with pytest.raises(RuntimeError):
+        oracle.run_batch(paused.build(), 0, 1)
+    ok = workload.WorkloadBuilder(); n = ok.create_node(); ok.task(n, spawn_on_drop=True); ok.task(n)
+    g = runtime.geometry(ok.build())
+    assert (g.variant >> 8) & 0x1f == 31 or "ALL" in runtime.variant_name(g)           # guards live in the full builds
+
+
 def test_ephemeral_endpoints_validation():
     """port 0 = an ephemeral Endpoint (network.rs:224-236): accepted, picks the full-address build, counts its candidate
     ports against the 63-entry table, and cannot be named as a destination — by the library and by the oracle alike."""
