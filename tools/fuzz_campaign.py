@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extended parity fuzzing on a GPU box: fresh random workloads (tests/fuzz.py generators, new generator seeds) through the
-C-ABI vs the CPU oracle, bit-exact on all 48 result bytes.  Usage: fuzz_campaign.py [seconds] [base_seed]"""
+C-ABI vs the CPU oracle, bit-exact on all 48 result bytes.  Usage: fuzz_campaign.py [seconds] [base_seed] [generators]"""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +16,8 @@ gens = [("plain", fuzz.random_workload, None), ("lifecycle", fuzz.random_lifecyc
         ("rpc+hooks", lambda r: fuzz.random_rpc_workload(r, hooks=True), 24), ("addresses", fuzz.random_addr_workload, None),
         ("ephemeral", fuzz.random_ephemeral_workload, None), ("channel", fuzz.random_channel_workload, 24),
         ("guards", fuzz.random_guard_workload, 24), ("supervisor", fuzz.random_supervisor_workload, 48)]
+if len(sys.argv) > 3:                              # optional: only the generators whose name contains one of these (comma-separated)
+    gens = [g for g in gens if any(x in g[0] for x in sys.argv[3].split(","))]
 t0 = time.time(); k = 0; stats = {g[0]: [0, 0, 0] for g in gens}; verdicts = np.zeros(6, dtype=np.int64)
 while time.time() - t0 < budget:
     name, gen, max_tasks = gens[k % len(gens)]
