@@ -321,6 +321,94 @@ def random_supervisor_workload(rng: random.Random):
     return wl.build(), A.Config.default(), "+".join(desc)
 
 
+def random_mixed_workload(rng: random.Random):
+    """Everything from everywhere: like random_supervisor_workload (supervisor calls, spawn / abort / join from every task), and
+    every task also owns an Endpoint and mixes in datagrams with timeouts, connect1 / accept1 exchanges, typed RPC calls and
+    handlers, clogs and (in half of the programs) pause / resume.  Returns (BuiltWorkload, Config, description)."""
+    wl = W.WorkloadBuilder()
+    nodes = [wl.create_node(restart_on_panic=rng.random() < 0.3) for _ in range(rng.randint(2, 3))]
+    tasks = []
+    for n in nodes:
+        for j in range(2):
+            tasks.append((wl.task(n, init=(j == 0 and rng.random() < 0.4)), wl.addr(n, 1 + j)))
+    addrs = [x[1] for x in tasks]
+    use_pause = rng.random() < 0.5
+    desc = []
+
+    def act(t, me, a):
+        ks = ["sleep", "sleep", "spawn", "abort", "join", "kill", "restart", "yield", "flag", "abort_self", "panic",
+              "send", "recv", "recv_to", "clog", "unclog", "connect", "accept", "rpc_call", "rpc_srv"]
+        if use_pause:
+            ks += ["pause", "resume"]
+        k = rng.choice(ks)
+        later = [x[0] for i, x in enumerate(tasks) if me is None or i > me]
+        peer = rng.choice(addrs)
+        if k == "sleep":
+            t.sleep(ms=rng.choice([0, 1, 5, 40, 700]))
+        elif k == "spawn" and later:
+            t.spawn(rng.choice(later))
+        elif k == "abort":
+            t.abort(rng.choice(tasks)[0])
+        elif k == "join":
+            t.join(rng.choice(tasks)[0], expect_err=rng.random() < 0.5)
+        elif k == "kill":
+            t.kill(rng.choice(nodes))
+        elif k == "restart":
+            t.restart(rng.choice(nodes))
+        elif k == "pause":
+            t.pause(rng.choice(nodes))
+        elif k == "resume":
+            t.resume(rng.choice(nodes))
+        elif k == "yield":
+            t.yield_now()
+        elif k == "flag":
+            t.flag_add(rng.randrange(4), 1)
+        elif k == "abort_self" and me is not None:
+            t.abort(tasks[me][0])
+        elif k == "panic" and rng.random() < 0.3:
+            t.panic(rng.randrange(3))
+        elif k == "clog":
+            t.clog_node(rng.choice(nodes), rng.choice(["in", "out", "both"]))
+        elif k == "unclog":
+            t.unclog_node(rng.choice(nodes), "both")
+        elif a is None:
+            return
+        elif k == "send":
+            t.send_to(a, peer, 1, 7)
+        elif k == "recv":
+            t.recv_from_timeout(a, 1, ms=rng.choice([1, 20, 300]))
+        elif k == "recv_to":
+            t.recv_from_timeout(a, 2, ms=5)
+        elif k == "connect" and peer != a:
+            t.connect1(a, peer); skip = t.label() + 4; t.jeq(A.VAL_REFUSED, skip); t.chan_send(9); t.chan_recv(); t.chan_close()
+        elif k == "accept":
+            t.accept1(a); t.chan_recv(); t.chan_send(8)
+        elif k == "rpc_call" and peer != a:
+            t.rpc_call(a, peer, 0, 5, timeout_ms=rng.choice([10, 30, 200]))
+        elif k == "rpc_srv":
+            t.rpc_recv(a, 0); t.rpc_reply(a, 6)
+        else:
+            return
+        desc.append(k)
+
+    for i, (t, a) in enumerate(tasks):
+        t.sleep(ms=rng.choice([1, 2, 9, 60])); t.bind(a)
+        for _ in range(rng.randint(1, 6)):
+            act(t, i, a)
+        t.trace(100 + i); t.done()
+    m = wl.main()
+    for _ in range(rng.randint(2, 8)):
+        act(m, None, None)
+    m.sleep(ms=rng.choice([10, 2000])); m.done()
+    return wl.build(), A.Config.default(), "+".join(desc)
+
+
+def mixed_limits():
+    lim = generous_limits()
+    lim.max_tasks, lim.max_steps = 60, 20000
+    return lim
+
+
 def generous_limits():
     lim = A.Limits()
     lim.max_steps = 200_000

@@ -816,7 +816,7 @@ def workloads():
     for gen, base, n in (("random_workload", 810000, 16), ("random_lifecycle_workload", 820000, 24), ("random_rpc_workload", 830000, 16),
                          ("random_addr_workload", 880000, 24), ("random_ephemeral_workload", 870000, 16),
                          ("random_channel_workload", 860000, 24), ("random_guard_workload", 850000, 16),
-                         ("random_supervisor_workload", 840000, 16)):
+                         ("random_supervisor_workload", 840000, 16), ("random_mixed_workload", 845000, 16)):
         for k in range(n):
             r = getattr(fuzz, gen)(random.Random(base + k))
             out["%s_%02d" % (gen.replace("random_", "fuzz_").replace("_workload", ""), k)] = (r[0], r[1])

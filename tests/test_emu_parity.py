@@ -136,6 +136,19 @@ def test_fuzz_supervisor_workloads():
         assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
 
 
+def test_fuzz_mixed_workloads():
+    """Everything from everywhere: supervisor calls, datagrams, channel and RPC exchanges from every task, both state layouts."""
+    for k in range(160):
+        w, cfg, desc = fuzz.random_mixed_workload(random.Random(9900 + k))
+        lim = fuzz.mixed_limits()
+        if k % 2:
+            lim = _global(lim)
+        o, _ = oracle.run_batch(w, k * 3, 8, cfg, lim)
+        e = emu.run_batch(w, k * 3, 8, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+
+
 def test_baseline_config_shaped_workloads():
     """configs[2]-shaped election loop (timeouts, partitions, HBM heap spill) and configs[3]-shaped KV-RPC."""
     o = _same(W.raft_election(), 0, 300, None, W.raft_election_limits())

@@ -15,7 +15,7 @@ FIELDS = ("verdict", "steps", "clock_ns", "msg_count", "rng_calls", "trace_hash"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 base = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
 gens = ["random_workload", "random_lifecycle_workload", "random_rpc_workload", "random_rpc_workload+hooks", "random_addr_workload",
-        "random_ephemeral_workload", "random_channel_workload", "random_guard_workload", "random_supervisor_workload"]
+        "random_ephemeral_workload", "random_channel_workload", "random_guard_workload", "random_supervisor_workload", "random_mixed_workload"]
 if len(sys.argv) > 3:                              # optional: only the generators whose name contains this
     gens = [g for g in gens if sys.argv[3] in g]
 t0 = time.time(); total = 0; verdicts = collections.Counter()
@@ -25,9 +25,13 @@ for gi, gname in enumerate(gens):
         r = fuzz.random_rpc_workload(rng, hooks=True) if gname.endswith("+hooks") else getattr(fuzz, gname)(rng)
         w, cfg, desc = r[0], r[1], r[2]
         lim = fuzz.generous_limits(); lim.max_tasks = 24
+        if gname in ("random_supervisor_workload", "random_mixed_workload"):
+            lim = fuzz.mixed_limits()
         seeds = (0, 1, 2, 3, 7)
         want, _ = oracle.run_batch(w, 0, max(seeds) + 1, config=cfg, limits=lim)
         for s in seeds:
+            if int(want[s]["verdict"]) in (A.OVERFLOW, A.STEP_LIMIT):      # the runner's limits, not a verdict of the simulation
+                continue
             g = G.Sim(w, cfg, s).run()
             o = {f: int(want[s][f]) for f in FIELDS}
             if o != {f: g[f] for f in FIELDS}:
