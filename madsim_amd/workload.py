@@ -371,6 +371,8 @@ class WorkloadBuilder:
         for m in texts:
             key = tuple(sorted(n for n, pats in self.panic_patterns.items() if any(p in m for p in pats)))
             cls.setdefault(key, len(cls))
+        if len(cls) > 255:                                  # 255 itself is MADSIM_PANIC_CODE_OTHER (asserts, unwraps)
+            raise ValueError("too many classes of panic messages")
         codes = {m: cls[tuple(sorted(n for n, pats in self.panic_patterns.items() if any(p in m for p in pats)))] for m in texts}
         for n in self.panic_patterns:
             mine = sorted({c for key, c in cls.items() if n in key})
