@@ -596,7 +596,7 @@ def test_ref_twin_workloads_gpu(hip):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ref_twin"))
     import twin_workloads as T
     for name in sorted(T.ALL):
-        _cmp(hip, T.ALL[name](), 0, 512)
+        _cmp(hip, T.ALL[name](), 0, 512, None, T.limits(name))
     _cmp(hip, T.ALL["pingpong4"](), 0, 512, A.Config.default(packet_loss_rate=0.01))
 
 

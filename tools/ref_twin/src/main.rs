@@ -444,6 +444,60 @@ async fn spawn_after_own_restart(obs: Obs) -> Tail {
     fingerprint_tail(t0, &obs)
 }
 
+/// `handle.await` moves the JoinHandle into the await: the awaiter gets the first worker's outcome (Ok after 5 ms) although the
+/// same closure was spawned again meanwhile into the variable it came from, and that second worker aborted.
+async fn join_names_its_task(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let node = h.create_node().build();
+    let done = Arc::new(AtomicUsize::new(0));
+    let worker = {
+        let done = done.clone();
+        move || { let done = done.clone(); async move { time::sleep(Duration::from_millis(5)).await; done.fetch_add(1, Ordering::Relaxed); } }
+    };
+    let slot: Arc<Mutex<Option<madsim::task::JoinHandle<()>>>> = Arc::new(Mutex::new(None));
+    let first = node.spawn(worker());
+    let (slot2, worker2) = (slot.clone(), worker.clone());
+    node.spawn(async move {
+        time::sleep(Duration::from_millis(1)).await;
+        let second = madsim::task::spawn(worker2());
+        time::sleep(Duration::from_millis(1)).await;
+        second.abort();
+        *slot2.lock().unwrap() = Some(second);
+        time::sleep(Duration::from_millis(20)).await;
+    });
+    first.await.unwrap();
+    let waited = t0.elapsed();
+    assert!(waited >= Duration::from_millis(5) && waited < Duration::from_millis(7));
+    obs.push(done.load(Ordering::Relaxed) as u64);
+    let second = slot.lock().unwrap().take().unwrap();
+    assert!(second.await.unwrap_err().is_cancelled());
+    fingerprint_tail(t0, &obs)
+}
+
+/// A task that aborts its own JoinHandle keeps running until it yields, then is dropped: obs <- 1 (the work before its next
+/// await happened, the work behind it did not).
+async fn abort_own_handle(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let node = h.create_node().build();
+    let flag = Arc::new(AtomicUsize::new(0));
+    let own: Arc<Mutex<Option<madsim::task::AbortHandle>>> = Arc::new(Mutex::new(None));
+    let (f, o) = (flag.clone(), own.clone());
+    let jh = node.spawn(async move {
+        time::sleep(Duration::from_millis(1)).await;
+        o.lock().unwrap().as_ref().unwrap().abort();
+        f.fetch_add(1, Ordering::Relaxed);
+        time::sleep(Duration::from_millis(5)).await;
+        f.fetch_add(10, Ordering::Relaxed);
+    });
+    *own.lock().unwrap() = Some(jh.abort_handle());
+    assert!(jh.await.unwrap_err().is_cancelled());
+    time::sleep(Duration::from_millis(20)).await;
+    obs.push(flag.load(Ordering::Relaxed) as u64);
+    fingerprint_tail(t0, &obs)
+}
+
 fn run_one(name: &str, seed: u64, loss: f64) -> String {
     let mut config = madsim::Config::default();
     config.net.packet_loss_rate = loss;
@@ -475,6 +529,8 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
                 "spawn_in_drop_abort" => spawn_in_drop_abort(o).await,
                 "spawn_in_drop_kill" => spawn_in_drop_kill(o).await,
                 "spawn_after_own_restart" => spawn_after_own_restart(o).await,
+                "join_names_its_task" => join_names_its_task(o).await,
+                "abort_own_handle" => abort_own_handle(o).await,
                 other => panic!("unknown workload {other}"),
             }
         });
@@ -499,7 +555,7 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
 const ALL: &[&str] = &["pingpong2", "pingpong4", "pingpong16", "sleep_1s", "yield_order", "timer_ties", "kill", "restart",
                        "restart_on_panic", "receiver_drop", "localhost", "restart_on_panic_matching", "bind_ephemeral",
                        "channel_wildcard", "guard_keeps_address", "spawn_in_drop_abort", "spawn_in_drop_kill",
-                       "spawn_after_own_restart"];
+                       "spawn_after_own_restart", "join_names_its_task", "abort_own_handle"];
 
 fn main() {
     let args: Vec<String> = std::env::args().collect();

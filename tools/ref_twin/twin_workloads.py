@@ -287,6 +287,37 @@ def spawn_after_own_restart():
     return wl.build()
 
 
+def join_names_its_task():
+    """`handle.await` awaits the task the handle named when the await began (task/join.rs:59-72): obs <- 1 worker done."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    worker = wl.task(n); worker.sleep(ms=5); worker.flag_add(0, 1)
+    other = wl.task(n); other.sleep(ms=1); other.spawn(worker); other.sleep(ms=1); other.abort(worker); other.sleep(ms=20)
+    m = wl.main(); m.mark(); m.spawn(worker); m.spawn(other)
+    m.join(worker); m.assert_elapsed(">=", ms=5); m.assert_elapsed("<", ms=7); m.assert_flag(0, 1); m.trace(1)
+    m.join(worker, expect_err=True)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def abort_own_handle():
+    """A task aborting its own JoinHandle runs on until it yields, then is dropped: obs <- 1."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    t = wl.task(n); t.sleep(ms=1); t.abort(t); t.flag_add(0, 1); t.sleep(ms=5); t.flag_add(0, 10)
+    m = wl.main(); m.spawn(t); m.join(t, expect_err=True); m.sleep(ms=20); m.assert_flag(0, 1); m.trace(1)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def limits(name):
+    """Device capacities a table needs beyond the defaults (None = defaults); the oracle has none."""
+    if name == "join_names_its_task":                     # two instances of one program alive at once
+        lim = A.Limits(); lim.max_tasks = 6
+        return lim
+    return None
+
+
 # workloads that end in a panic by design (the reference test is #[should_panic])
 EXPECT_PANIC = {"restart_on_panic_matching"}
 
@@ -298,4 +329,5 @@ ALL = {
     "bind_ephemeral": bind_ephemeral, "channel_wildcard": channel_wildcard, "guard_keeps_address": guard_keeps_address,
     "spawn_in_drop_abort": spawn_in_drop_abort, "spawn_in_drop_kill": spawn_in_drop_kill,
     "spawn_after_own_restart": spawn_after_own_restart,
+    "join_names_its_task": join_names_its_task, "abort_own_handle": abort_own_handle,
 }
