@@ -337,10 +337,14 @@ def random_mixed_workload(rng: random.Random):
 
     def act(t, me, a):
         ks = ["sleep", "sleep", "spawn", "abort", "join", "kill", "restart", "yield", "flag", "abort_self", "panic",
-              "send", "recv", "recv_to", "clog", "unclog", "connect", "accept", "rpc_call", "rpc_srv"]
+              "send", "recv", "recv_to", "clog", "unclog", "connect", "accept", "rpc_call", "rpc_srv",
+              "close_rebind", "advance", "hook_req", "hook_rsp", "clog_link", "sleep_rand", "rand_bool", "connect_keep", "accept_keep",
+              "crecv", "csend"]
         if use_pause:
             ks += ["pause", "resume"]
         k = rng.choice(ks)
+        if k in ("crecv", "csend") and not have_conn[0]:      # only with a (Sender, Receiver) pair in hand
+            return
         later = [x[0] for i, x in enumerate(tasks) if me is None or i > me]
         peer = rng.choice(addrs)
         if k == "sleep":
@@ -387,20 +391,50 @@ def random_mixed_workload(rng: random.Random):
             t.rpc_call(a, peer, 0, 5, timeout_ms=rng.choice([10, 30, 200]))
         elif k == "rpc_srv":
             t.rpc_recv(a, 0); t.rpc_reply(a, 6)
+        elif k == "close_rebind":                           # drop(Endpoint) with whatever still holds its address, then bind again
+            t.close(a); t.sleep(ms=rng.choice([0, 3])); t.try_bind(a)
+        elif k == "advance":
+            t.advance(ms=rng.choice([1, 30]))
+        elif k == "hook_req":
+            t.hook_rpc_req(rng.choice(nodes), 0, code=rng.choice([None, 5]))
+        elif k == "hook_rsp":
+            t.hook_rpc_rsp(rng.choice(nodes), code=rng.choice([None, 6]))
+        elif k == "clog_link":
+            t.clog_link(rng.choice(nodes), rng.choice(nodes))
+        elif k == "sleep_rand":
+            t.sleep_rand(lo_ms=0, ms=rng.choice([2, 50]))
+        elif k == "rand_bool":
+            t.rand_bool(0)
+        elif k == "connect_keep" and peer != a:             # keeps the connection: later chan ops, or dropped with the task
+            t.connect1(a, peer); skip = t.label() + 2; t.jeq(A.VAL_REFUSED, skip); t.chan_send(11)
+        elif k == "accept_keep":
+            t.accept1(a)
+        elif k == "crecv":
+            t.chan_recv()
+        elif k == "csend":
+            t.chan_send(12)
         else:
             return
         desc.append(k)
+        if k in ("connect_keep", "accept_keep"):
+            have_conn[0] = True
+        elif k in ("connect", "accept"):
+            have_conn[0] = k == "accept"                    # the connect unit closes its pair, the accept unit keeps it
 
+    have_conn = [False]
     for i, (t, a) in enumerate(tasks):
         t.sleep(ms=rng.choice([1, 2, 9, 60])); t.bind(a)
-        for _ in range(rng.randint(1, 6)):
+        have_conn[0] = False
+        for _ in range(rng.randint(1, 7)):
             act(t, i, a)
         t.trace(100 + i); t.done()
+    have_conn[0] = False
     m = wl.main()
     for _ in range(rng.randint(2, 8)):
         act(m, None, None)
     m.sleep(ms=rng.choice([10, 2000])); m.done()
-    return wl.build(), A.Config.default(), "+".join(desc)
+    cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.1]), buggify=rng.random() < 0.15, loss_table=(0.5,))
+    return wl.build(), cfg, "+".join(desc)
 
 
 def mixed_limits():
