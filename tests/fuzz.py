@@ -392,7 +392,7 @@ def random_mixed_workload(rng: random.Random):
         elif k == "rpc_srv":
             t.rpc_recv(a, 0); t.rpc_reply(a, 6)
         elif k == "close_rebind":                           # drop(Endpoint) with whatever still holds its address, then bind again
-            t.close(a); t.sleep(ms=rng.choice([0, 3])); t.try_bind(a)
+            t.close(a); t.sleep(ms=rng.choice([0, 3])); t.bind(a)      # .unwrap(): AddrInUse (a live connection's guard) panics
         elif k == "advance":
             t.advance(ms=rng.choice([1, 30]))
         elif k == "hook_req":
