@@ -263,6 +263,17 @@ def random_guard_workload(rng: random.Random):
     return random_lifecycle_workload(rng, guards=True)
 
 
+def _start_everything(wl, m, tasks):
+    """The test body's prologue: build the nodes that have init tasks, spawn the other tasks (`node.spawn(..)`)."""
+    built = set()
+    for t, node in tasks:
+        if t.flags & A.PROG_INIT:
+            if node not in built:
+                built.add(node); m.build_node(node)
+        else:
+            m.spawn(t)
+
+
 def random_supervisor_workload(rng: random.Random):
     """Supervisor calls from everywhere: every task — not only the test body — may spawn, abort and join other tasks (its own
     handle included), kill / restart / build any node (its own included), yield and panic.  What this reaches that the other
@@ -287,7 +298,7 @@ def random_supervisor_workload(rng: random.Random):
             t.spawn(rng.choice(later))
         elif k == "abort":
             t.abort(rng.choice(tasks))
-        elif k == "join":
+        elif k == "join" and (me is not None or rng.random() < 0.25):      # (the test body: rarely — a wrong guess ends the run)
             t.join(rng.choice(tasks), expect_err=rng.random() < 0.5)
         elif k == "kill":
             t.kill(rng.choice(nodes))
@@ -303,7 +314,7 @@ def random_supervisor_workload(rng: random.Random):
             t.abort(tasks[me])
         elif k == "join_self" and me is not None and rng.random() < 0.3:
             t.join(tasks[me], expect_err=rng.random() < 0.5)
-        elif k == "panic" and rng.random() < 0.3:
+        elif k == "panic" and me is not None and rng.random() < 0.3:
             t.panic(rng.randrange(3))
         else:
             return
@@ -315,9 +326,10 @@ def random_supervisor_workload(rng: random.Random):
             act(t, i)
         t.trace(100 + i); t.done()
     m = wl.main()
+    _start_everything(wl, m, [(t, t.node) for t in tasks])
     for _ in range(rng.randint(2, 8)):
         act(m, None)
-    m.sleep(ms=rng.choice([10, 2000])); m.done()
+    m.sleep(ms=rng.choice([10, 300, 2000])); m.done()
     return wl.build(), A.Config.default(), "+".join(desc)
 
 
@@ -353,7 +365,7 @@ def random_mixed_workload(rng: random.Random):
             t.spawn(rng.choice(later))
         elif k == "abort":
             t.abort(rng.choice(tasks)[0])
-        elif k == "join":
+        elif k == "join" and (me is not None or rng.random() < 0.25):
             t.join(rng.choice(tasks)[0], expect_err=rng.random() < 0.5)
         elif k == "kill":
             t.kill(rng.choice(nodes))
@@ -369,7 +381,7 @@ def random_mixed_workload(rng: random.Random):
             t.flag_add(rng.randrange(4), 1)
         elif k == "abort_self" and me is not None:
             t.abort(tasks[me][0])
-        elif k == "panic" and rng.random() < 0.3:
+        elif k == "panic" and me is not None and rng.random() < 0.3:
             t.panic(rng.randrange(3))
         elif k == "clog":
             t.clog_node(rng.choice(nodes), rng.choice(["in", "out", "both"]))
@@ -425,14 +437,21 @@ def random_mixed_workload(rng: random.Random):
     for i, (t, a) in enumerate(tasks):
         t.sleep(ms=rng.choice([1, 2, 9, 60])); t.bind(a)
         have_conn[0] = False
+        loop = rng.random() < 0.5                           # half of the bodies repeat their actions a few times
+        if loop:
+            t.set(0, rng.randint(2, 4))
+        top = t.label()
         for _ in range(rng.randint(1, 7)):
             act(t, i, a)
+        if loop:
+            t.sleep(ms=rng.choice([1, 7, 50])); t.djnz(0, top)
         t.trace(100 + i); t.done()
     have_conn[0] = False
     m = wl.main()
+    _start_everything(wl, m, [(t, t.node) for t, _ in tasks])
     for _ in range(rng.randint(2, 8)):
         act(m, None, None)
-    m.sleep(ms=rng.choice([10, 2000])); m.done()
+    m.sleep(ms=rng.choice([10, 300, 2000])); m.done()
     cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.1]), buggify=rng.random() < 0.15, loss_table=(0.5,))
     return wl.build(), cfg, "+".join(desc)
 
