@@ -263,6 +263,16 @@ def random_guard_workload(rng: random.Random):
     return random_lifecycle_workload(rng, guards=True)
 
 
+def _supervised_node(wl, rng):
+    """create_node() that restarts on every panic (30 %), on panics with one or two of the message codes 0..2 (30 %), or never."""
+    r = rng.random()
+    if r < 0.3:
+        return wl.create_node(restart_on_panic=True)
+    if r < 0.6:
+        return wl.create_node(restart_on_panic_matching=tuple(rng.sample(range(3), rng.randint(1, 2))))
+    return wl.create_node()
+
+
 def _start_everything(wl, m, tasks):
     """The test body's prologue: build the nodes that have init tasks, spawn the other tasks (`node.spawn(..)`)."""
     built = set()
@@ -282,7 +292,7 @@ def random_supervisor_workload(rng: random.Random):
     sleep of at least 1 ms and spawns only programs declared after it, so every respawn loop is bounded by the main task's
     few simulated seconds.  Returns (BuiltWorkload, Config, description)."""
     wl = W.WorkloadBuilder()
-    nodes = [wl.create_node(restart_on_panic=rng.random() < 0.3) for _ in range(rng.randint(1, 3))]
+    nodes = [_supervised_node(wl, rng) for _ in range(rng.randint(1, 3))]
     tasks = []
     for n in nodes:
         for j in range(2):
@@ -338,7 +348,7 @@ def random_mixed_workload(rng: random.Random):
     every task also owns an Endpoint and mixes in datagrams with timeouts, connect1 / accept1 exchanges, typed RPC calls and
     handlers, clogs and (in half of the programs) pause / resume.  Returns (BuiltWorkload, Config, description)."""
     wl = W.WorkloadBuilder()
-    nodes = [wl.create_node(restart_on_panic=rng.random() < 0.3) for _ in range(rng.randint(2, 3))]
+    nodes = [_supervised_node(wl, rng) for _ in range(rng.randint(2, 3))]
     tasks = []
     for n in nodes:
         for j in range(2):
