@@ -2,7 +2,9 @@
 """CPU campaign: the kernel sources compiled for the host (tests/emu — a debugging aid, never the product path) against the oracle on fresh
 random programs of every generator in tests/fuzz.py, odd programs with the per-seed state in the global-memory block.  What it is for:
 kernel *logic* (the workload VM, the executor loop) checked at scale without GPU time; what it cannot see: anything the hardware or the
-device compiler adds.  Usage: emu_campaign.py [programs per generator] [base seed]"""
+device compiler adds.  Usage: emu_campaign.py [programs per generator] [base seed] [tight]
+`tight`: random stingy capacities (tasks, registrations, queued messages, heap slots, connections) instead of generous ones — the kernel
+must then give the oracle's answer or the capacity verdict, never a different answer."""
 import os, sys, random, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, oracle
@@ -11,7 +13,7 @@ from madsim_amd import _abi as A
 gens = [("random_workload", None, None), ("random_lifecycle_workload", 24, None), ("random_rpc_workload", 24, None), ("random_rpc_workload", 24, "hooks"),
         ("random_addr_workload", None, None), ("random_ephemeral_workload", None, None), ("random_channel_workload", 24, None),
         ("random_guard_workload", 24, None), ("random_supervisor_workload", 48, None), ("random_mixed_workload", 60, None)]
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 200; base = int(sys.argv[2]) if len(sys.argv) > 2 else 3_000_000; t0=time.time(); total=0; bad=0; ovf=0
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200; base = int(sys.argv[2]) if len(sys.argv) > 2 else 3_000_000; TIGHT = len(sys.argv) > 3 and sys.argv[3] == 'tight'; t0=time.time(); total=0; bad=0; ovf=0
 for gi,(g,mt,opt) in enumerate(gens):
     for k in range(N):
         rng = random.Random(base + 100000*gi + k)
@@ -19,6 +21,14 @@ for gi,(g,mt,opt) in enumerate(gens):
         w, cfg, desc = r[0], r[1], r[2]
         lim = fuzz.mixed_limits() if mt == 60 else fuzz.generous_limits()
         if mt and mt != 60: lim.max_tasks = mt
+        if TIGHT:
+            lr = random.Random(k)
+            lim = A.Limits(); lim.max_steps = 200000
+            lim.max_tasks = lr.choice([0, w.struct.n_progs, w.struct.n_progs + 2, 12])
+            lim.mbox_regs, lim.mbox_msgs = lr.choice([1, 2, 4]), lr.choice([1, 2, 4])
+            lim.heap_lds_slots, lim.heap_spill_slots = lr.choice([2, 4, 8]), lr.choice([0, 4, 16])
+            lim.max_conns, lim.chan_queue = lr.choice([1, 2, 4]), lr.choice([1, 2])
+            lim.lanes_per_wave = lr.choice([0, 16, 64])
         if k % 2: lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
         o, _ = oracle.run_batch(w, k * 5, 8, cfg, lim)
         e = emu.run_batch(w, k * 5, 8, cfg, lim)
