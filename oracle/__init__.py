@@ -39,7 +39,8 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB):
             build()
-        L = C.CDLL(_LIB)
+        # MADSIM_ORACLE_LIB: another build of this same oracle (tools/sanitize_check.sh loads an ASan / UBSan one)
+        L = C.CDLL(os.environ.get("MADSIM_ORACLE_LIB", _LIB))
         L.madsim_oracle_run_batch.restype = C.c_int
         L.madsim_oracle_run_batch.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64, C.c_uint64,
                                               C.POINTER(A.Limits), C.c_void_p, C.POINTER(A.Summary),

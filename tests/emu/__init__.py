@@ -35,7 +35,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(build())
+        L = C.CDLL(os.environ.get("MADSIM_EMU_LIB") or build())      # MADSIM_EMU_LIB: a sanitizer build (tools/sanitize_check.sh)
         L.madsim_emu_run_batch.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64, C.c_uint64,
                                            C.POINTER(A.Limits), C.c_void_p, C.c_int, C.c_void_p, C.c_uint64,
                                            C.POINTER(C.c_uint64)]
