@@ -364,6 +364,8 @@ def random_mixed_workload(rng: random.Random):
               "crecv", "csend"]
         if use_pause:
             ks += ["pause", "resume"]
+        if me is not None:                                  # the tasks talk more than they supervise
+            ks += ["send", "send", "send", "rpc_call", "rpc_call", "connect", "connect", "connect_keep", "recv"]
         k = rng.choice(ks)
         if k in ("crecv", "csend") and not have_conn[0]:      # only with a (Sender, Receiver) pair in hand
             return
@@ -444,8 +446,25 @@ def random_mixed_workload(rng: random.Random):
             have_conn[0] = k == "accept"                    # the connect unit closes its pair, the accept unit keeps it
 
     have_conn = [False]
+    services = {}                                           # task index -> the kind of server loop it runs instead of random actions
+    for i in range(len(tasks)):
+        if rng.random() < 0.4:
+            services[i] = rng.choice(["echo", "rpc", "accept"])
+    if services:                                            # clients aim at the services most of the time
+        addrs = addrs + [tasks[i][1] for i in services] * 3
     for i, (t, a) in enumerate(tasks):
         t.sleep(ms=rng.choice([1, 2, 9, 60])); t.bind(a)
+        if i in services:
+            kind = services[i]; desc.append("svc:" + kind)
+            top = t.label()
+            if kind == "echo":
+                t.recv_from(a, 1); t.reply(a, 1, 8)
+            elif kind == "rpc":
+                t.rpc_recv(a, 0); t.sleep(ms=rng.choice([0, 2, 25])); t.rpc_reply(a, 6)
+            else:
+                t.accept1(a); t.chan_recv(); t.chan_send(8)
+            t.jmp(top)
+            continue
         have_conn[0] = False
         loop = rng.random() < 0.5                           # half of the bodies repeat their actions a few times
         if loop:
