@@ -41,7 +41,13 @@ def parse_args(argv=None):
     ap.add_argument("--seeds", type=int, default=0, help="seeds per GPU per step (default 65 536)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of sampled seeds after the timed region")
-    ap.add_argument("--no-first-fail", action="store_true", help="skip the first-failing-seed measurement (loss variant)")
+    ap.add_argument("--no-first-fail", action="store_true", help="skip the first-failing-seed measurements (loss variants)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip extra.workloads (3 timed steps each of the raft / kv / topo / timers workloads after the headline)")
+    ap.add_argument("--rare-loss", type=float, default=1.2e-6,
+                    help="packet_loss_rate of the rare-failure search: 256 datagrams per seed => ~3e-4 of the seeds deadlock")
+    ap.add_argument("--very-rare-loss", type=float, default=2e-8,
+                    help="packet_loss_rate of the very-rare-failure search: ~5e-6 of the seeds deadlock, i.e. one per ~3 batches")
     ap.add_argument("--measure-traffic", action="store_true", default=None,
                     help="collect FETCH_SIZE / WRITE_SIZE of this same command with two short rocprofv3 --pmc passes after the "
                          "timed region (default at one GPU when rocprofv3 is on PATH; a few seconds)")
@@ -64,9 +70,14 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def measure_traffic(argv):
-    """HBM bytes per sim_kernel launch of this same command: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE need
-    separate passes, MI355X_MICROARCH.md §PMC slots), --kernel-trace only.  Returns (bytes, detail) or (None, reason)."""
+PMC_ISSUE = "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"
+
+
+def measure_counters(argv):
+    """Per-launch hardware counters of sim_kernel for this same command, from three short rocprofv3 --pmc passes
+    (--kernel-trace only, never combined with other traces): FETCH_SIZE and WRITE_SIZE (separate passes,
+    MI355X_MICROARCH.md §PMC slots) give the HBM bytes; one pass of SQ counters gives the instruction counts and the
+    VALU lane utilisation the issue roofline needs.  Returns (dict, None) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -80,33 +91,55 @@ def measure_traffic(argv):
             child[child.index(flag) + 1] = val
         else:
             child += [flag, val]
-    child += ["--no-cpu-baseline", "--no-verify", "--no-first-fail"]
+    child += ["--no-cpu-baseline", "--no-verify", "--no-first-fail", "--no-extras"]
     vals = {}
     tmp = tempfile.mkdtemp(prefix="madsim_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr)
-            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
+        for i, ctrs in enumerate(("FETCH_SIZE", "WRITE_SIZE", PMC_ISSUE)):
+            d = os.path.join(tmp, f"pass{i}")
+            cmd = [exe, "--kernel-trace", "--pmc", *ctrs.split(), "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.join(ROOT, "bench.py")] + child
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
             except (OSError, subprocess.TimeoutExpired) as e:
-                return None, f"rocprofv3 {ctr} pass failed: {e}"
-            xs = []
+                return None, f"rocprofv3 pass {i} ({ctrs}) failed: {e}"
+            xs = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "sim_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
-                        xs.append(float(row["Counter_Value"]))
-            if not xs:
-                return None, f"no {ctr} rows for sim_kernel"
-            vals[ctr] = sum(xs) / len(xs)
+                    if "sim_kernel" in row.get("Kernel_Name", ""):
+                        xs.setdefault(row.get("Counter_Name"), []).append(float(row["Counter_Value"]))
+            for c in ctrs.split():
+                if c not in xs:
+                    if i < 2:
+                        return None, f"no {c} rows for sim_kernel"
+                    continue                      # an SQ counter this rocprofv3 does not know: the issue roofline degrades, traffic stays
+                vals[c] = sum(xs[c]) / len(xs[c])
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    # rocprofv3 reports both in KB; gfx950 FETCH_SIZE counts 128-B requests as 64 B: x2 (MI355X_MICROARCH.md §HBM)
-    total = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    return total, {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
-                   "source": "live: rocprofv3 --kernel-trace --pmc, two passes of this command (6 steps), mean per sim_kernel dispatch"}
+    vals["source"] = ("live: rocprofv3 --kernel-trace --pmc, three passes of this command (6 steps), mean per sim_kernel dispatch")
+    return vals, None
+
+
+def issue_ceiling():
+    """The chip's sustained VALU issue rate for the executor's instruction mix (wave-instructions per second by wall time):
+    tools/ubench_issue --quick run live when the binary is there (build() compiles it), else the committed measurement
+    (profiles/r3_issue_ceiling.json)."""
+    exe = os.path.join(ROOT, "tools", "ubench_issue")
+    if os.path.exists(exe):
+        try:
+            out = subprocess.run([exe, "--quick"], capture_output=True, text=True, timeout=60)
+            j = json.loads(out.stdout.strip().splitlines()[-1])
+            j["source"] = "live: tools/ubench_issue --quick on this GPU"
+            return j
+        except (OSError, subprocess.TimeoutExpired, ValueError, IndexError):
+            pass
+    path = os.path.join(ROOT, "profiles", "r3_issue_ceiling.json")
+    if os.path.exists(path):
+        j = json.load(open(path))
+        j["source"] = "profiles/r3_issue_ceiling.json (tools/ubench_issue on an MI355X, not this run)"
+        return j
+    return None
 
 
 def main():
@@ -363,33 +396,213 @@ def main():
                       "note": "time_to_first_fail_ms / seeds_per_hour: launch -> kernel -> device reduction -> 32-byte D2H, "
                               "host-synchronous, one batch at a time; search_*: the same batches kept in flight on the bench's streams"}
 
+
+    # Rare-failure searches: time-to-first-failure only means something when failures are rare.  Batches of `count` seeds are
+    # kept in flight on the bench's streams; the host reads each batch's 32-byte device report as it completes and stops
+    # launching as soon as one reports a failure (seeds are contiguous, so the first failing batch holds the minimum failing
+    # seed).  Afterwards — outside the measured time — EVERY seed from the start of the search up to and including the one
+    # found is run through the oracle: all before it must pass, and the failing batch's GPU results are compared bit for bit.
+    def rare_search(loss, fs, max_batches=96):
+        import threading
+        import oracle
+        fcfg = A.Config.default(packet_loss_rate=loss)
+        nb = max_batches
+        srows = torch.zeros((nb, REPORT_WORDS), dtype=torch.int64, device=dev)
+        copy_stream = torch.cuda.Stream()
+        events, found, launched = [], None, 0
+        runtime.run_batch_device(w, fs - count, count, d_outs[0].data_ptr(), streams[0].cuda_stream, fcfg, lim)   # warm (tables)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(nb):
+            si = k % n_streams
+            with torch.cuda.stream(streams[si]):
+                runtime.run_batch_async(w, fs + k * count, count, d_outs[si].data_ptr(), srows[k].data_ptr(),
+                                        streams[si].cuda_stream, fcfg, lim, timing_slot=-1)
+                ev = torch.cuda.Event(); ev.record(streams[si]); events.append(ev)
+            launched = k + 1
+            j = k - (n_streams - 1)                     # the oldest batch still unread: its stream gets the NEXT launch
+            if j >= 0:
+                events[j].synchronize()
+                with torch.cuda.stream(copy_stream):
+                    row = srows[j].cpu()
+                if int(row[1]) > 0:
+                    found = (j, mdist.decode_first_fail(int(row[0])), int(row[1]))
+                    break
+        if found is None:
+            for j in range(max(0, launched - (n_streams - 1)), launched):
+                events[j].synchronize()
+                with torch.cuda.stream(copy_stream):
+                    row = srows[j].cpu()
+                if int(row[1]) > 0:
+                    found = (j, mdist.decode_first_fail(int(row[0])), int(row[1]))
+                    break
+        t_found = time.perf_counter() - t1
+        torch.cuda.synchronize()
+        res = {"packet_loss_rate": loss, "seeds_per_batch": count, "batches_in_flight": n_streams,
+               "batches_launched": launched, "found": found is not None}
+        if found is None:
+            res["note"] = f"no failing seed in {launched} batches"
+            return res
+        j, seed, nf = found
+        offset = seed - fs
+        got = np.frombuffer(d_outs[j % n_streams].cpu().numpy().tobytes(), dtype=A.RESULT_DTYPE)   # batch j: not overwritten yet
+        # oracle: every seed of [fs, seed], threads over disjoint blocks (ctypes releases the GIL)
+        n_chk = offset + 1
+        n_thr = max(1, min(os.cpu_count() or 1, 32, (n_chk + 4095) // 4096))
+        per = (n_chk + n_thr - 1) // n_thr
+        parts = [None] * n_thr
+
+        def work(i):
+            lo = i * per
+            n = max(0, min(per, n_chk - lo))
+            parts[i] = oracle.run_batch(w, fs + lo, n, fcfg, lim)[0] if n else np.zeros(0, dtype=A.RESULT_DTYPE)
+        thr = [threading.Thread(target=work, args=(i,)) for i in range(n_thr)]
+        t2 = time.perf_counter()
+        for t in thr:
+            t.start()
+        for t in thr:
+            t.join()
+        want = np.concatenate(parts)
+        o_first = np.nonzero(want["verdict"] != A.PASS)[0]
+        in_batch = want[j * count:]
+        ok = len(o_first) == 1 and int(o_first[0]) == offset and (got[:len(in_batch)] == in_batch).all()
+        res.update({"batches_until_found": j + 1, "first_failing_seed_offset": offset, "failed_in_that_batch": nf,
+                    "failed_fraction_of_that_batch": nf / count, "time_to_first_fail_ms": t_found * 1e3,
+                    "seeds_searched": (j + 1) * count, "seeds_per_hour": (j + 1) * count / t_found * 3600.0,
+                    "oracle_checked_seeds": n_chk, "oracle_check_s": time.perf_counter() - t2, "oracle_agrees": bool(ok),
+                    "note": "wall time from the first launch to the failing seed being known on the host; every seed up to and "
+                            "including it then oracle-checked (all earlier ones pass, the failing batch bit for bit)"})
+        return res
+
+    first_fail_rare = first_fail_very_rare = None
+    if not args.no_first_fail and world == 1 and args.workload == "pingpong":
+        first_fail_rare = rare_search(args.rare_loss, 1 << 43)
+        first_fail_very_rare = rare_search(args.very_rare_loss, 1 << 44)
+        for ff in (first_fail_rare, first_fail_very_rare):
+            if ff.get("found") and not ff["oracle_agrees"]:
+                print(f"bench.py: RARE FIRST-FAIL VERIFY FAILED: {ff}", file=sys.stderr)
+                return 3
+
+    # extra.workloads: the configs[2] / [3] / [4]-shaped workloads and the timer storm, 3 timed steps each on the same streams,
+    # every line with sampled seeds of its timed batches checked against the oracle
+    extras = None
+    if not args.no_extras and world == 1 and headline and not args.loss:
+        import oracle
+        extras = {}
+        for name in ("raft", "kv", "topo", "timers"):
+            xw, xlim, xname = workload.bench_case(name)
+            xs, xwu = 3, 3
+            xring = torch.zeros((xs + xwu, REPORT_WORDS), dtype=torch.int64, device=dev)
+            last = {}
+
+            def xstep(k, timed):
+                si = k % n_streams
+                with torch.cuda.stream(streams[si]):
+                    runtime.run_batch_async(xw, (1 << 46) + k * count, count, d_outs[si].data_ptr(), xring[k].data_ptr(),
+                                            streams[si].cuda_stream, None, xlim, timing_slot=(k % 64) if timed else -1)
+                last[si] = k
+            for k in range(xwu):
+                xstep(k, False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(xs):
+                xstep(xwu + k, True)
+            torch.cuda.synchronize()
+            xdt = time.perf_counter() - t1
+            rows = xring[xwu:].cpu()
+            xfail, xsteps, xclock = (int(x) for x in rows[:, 1:4].sum(dim=0).tolist())
+            xk_ms = sum(runtime.timing_ms((xwu + i) % 64) for i in range(xs)) / xs
+            xver = 0
+            for si, k in sorted(last.items()):
+                got = np.frombuffer(d_outs[si].cpu().numpy().tobytes(), dtype=A.RESULT_DTYPE)
+                for jj in range(64):
+                    i = (jj * 1021) % count
+                    want, _ = oracle.run_batch(xw, (1 << 46) + k * count + i, 1, None, xlim)
+                    if int(got[i]["verdict"]) == A.OVERFLOW:
+                        continue
+                    if got[i] != want[0]:
+                        print(f"bench.py: VERIFY FAILED workload {name} seed {(1 << 46) + k * count + i}: gpu {got[i]} != oracle {want[0]}", file=sys.stderr)
+                        return 3
+                    xver += 1
+            xg = runtime.geometry(xw, xlim)
+            xalgo = xsteps / xs * ALGO_BYTES_PER_STEP + count * IO_BYTES_PER_SEED
+            extras[name] = {"workload": xname, "seeds_per_step": count, "steps": xs, "warmup": xwu, "concurrent_batches": n_streams,
+                            "ms_per_step": xdt / xs * 1e3, "kernel_ms_per_step": xk_ms,
+                            "steps_per_sec": xsteps / xdt, "seeds_per_sec": xs * count / xdt, "sim_seconds_per_sec": xclock / 1e9 / xdt,
+                            "failed_seeds": xfail, "verified_seeds": xver, "kernel": runtime.variant_name(xg),
+                            "lds_bytes_per_seed": xg.lds_bytes_per_seed, "global_bytes_per_seed": xg.global_bytes_per_seed,
+                            "frac": xalgo / (xk_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "chip_frac": xalgo * xs / xdt / 1e9 / HBM_PEAK_GBPS,
+                            "frac_note": "nominal SURVEY 8d yardstick (120 B per executor step / 8 TB/s): frac per launch, chip_frac over wall time"}
+
     if rank == 0:
         seeds_total = total * args.steps
         sim_s = clock_total / 1e9
-        # roofline of the dominant kernel (sim_kernel), per launch, from the library's HIP events on the launch streams
+        # Roofline of the dominant kernel (sim_kernel).  The executor state lives in registers and LDS, so the kernel's binding
+        # bound is VALU instruction issue, not HBM: `roofline` prices the VALU wave-instructions the launches executed (PMC,
+        # live) against the chip's sustained issue rate for the same instruction mix (tools/ubench_issue, live); the nominal
+        # SURVEY 8d HBM yardstick (120 algorithmic bytes per executor step) rides along in roofline.hbm_nominal.
         k_avg_ms = kernel_ms / args.steps
+        ms_step = dt / args.steps * 1e3
         steps_per_launch = steps_total / args.steps / n_ranks
         algo_bytes = steps_per_launch * ALGO_BYTES_PER_STEP + count * IO_BYTES_PER_SEED
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
         g = runtime.geometry(w, lim)
         kname = runtime.variant_name(g)
-        traffic, tdetail = None, None
+        pmc, pmc_note = None, None
         if world == 1 and args.measure_traffic is not False:
-            traffic, tdetail = measure_traffic(sys.argv[1:])
-        if traffic is None and world == 1 and per_gpu == workload.BENCH_SEEDS_PER_GPU and headline and not args.loss:
-            # the committed rocprofv3 PMC passes of this same command (tools/prof_pmc.sh): FETCH_SIZE x2 + WRITE_SIZE
-            for name in ("r2_traffic.json", "r1_traffic.json"):
+            pmc, pmc_note = measure_counters(sys.argv[1:])
+        traffic, tdetail = None, pmc_note
+        if pmc:
+            # rocprofv3 reports both in KB; gfx950 FETCH_SIZE counts 128-B requests as 64 B: x2 (MI355X_MICROARCH.md §HBM)
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            tdetail = {"FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"], "source": pmc["source"]}
+        elif world == 1 and per_gpu == workload.BENCH_SEEDS_PER_GPU and headline and not args.loss:
+            # the committed rocprofv3 PMC passes of this same command (tools/prof_workload.sh): FETCH_SIZE x2 + WRITE_SIZE
+            for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tpath):
                     tj = json.load(open(tpath))
                     traffic = (2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0
                     tdetail = {"FETCH_SIZE_KB": tj["FETCH_SIZE_KB"], "WRITE_SIZE_KB": tj["WRITE_SIZE_KB"],
                                "source": f"profiles/{name}: rocprofv3 PMC passes of this command, not this run"
-                                         + ("; live attempt: " + str(tdetail) if isinstance(tdetail, str) else "")}
+                                         + ("; live attempt: " + str(pmc_note) if pmc_note else "")}
                     break
+        hbm_nominal = {"bound": "hbm (nominal yardstick, NOT the binding bound)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": algo_bytes,
+                       "chip_achieved": algo_bytes / (ms_step * 1e-3) / 1e9,
+                       "chip_frac": algo_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                       "measured_hbm_gbps": (traffic / (k_avg_ms * 1e-3) / 1e9) if traffic else None,
+                       "note": "ALGORITHMIC bytes (120 B per executor step, SURVEY 8d) / one launch's HIP-event duration: an LDS-equivalent "
+                               "rate — those bytes never reach HBM on this LDS-resident path (measured_hbm_gbps is the real HBM rate from "
+                               "FETCH/WRITE_SIZE).  chip_* = all overlapping launches / wall time; chip_frac > 1 means exactly that: "
+                               "HBM is not a bound for this kernel"}
+        ceil = issue_ceiling() if world == 1 else None
+        roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G wave-inst/s", "frac": None, "traffic": traffic,
+                "traffic_detail": tdetail, "kernel": kname, "concurrent_launches": n_streams, "hbm_nominal": hbm_nominal}
+        if pmc and "SQ_INSTS_VALU" in pmc:
+            valu = pmc["SQ_INSTS_VALU"]
+            roof.update({"valu_inst_per_launch": valu, "salu_inst_per_launch": pmc.get("SQ_INSTS_SALU"),
+                         "lds_inst_per_launch": pmc.get("SQ_INSTS_LDS"), "waves_per_launch": pmc.get("SQ_WAVES"),
+                         "achieved_ginst_s": valu / (ms_step * 1e-3) / 1e9,
+                         "per_launch_ginst_s": valu / (k_avg_ms * 1e-3) / 1e9})
+            roof["achieved"] = roof["achieved_ginst_s"]
+            if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_THREAD_CYCLES_VALU"):
+                roof["lane_util"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
+        if ceil:
+            roof.update({"ceiling_ginst_s": ceil["valu_mix_ceiling_ginst_s"], "peak": ceil["valu_mix_ceiling_ginst_s"],
+                         "ceiling_detail": ceil})
+            if roof["achieved"]:
+                roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["note"] = ("achieved = VALU wave-instructions per sim_kernel launch (rocprofv3 SQ_INSTS_VALU, live) / wall time per batch "
+                        f"({n_streams} launches overlap, so this is the chip-level rate; per_launch_ginst_s divides by one launch's own "
+                        "HIP-event duration instead); peak = the chip's sustained issue rate for the executor's VALU mix measured by wall "
+                        "time (tools/ubench_issue, best over 1-8 waves per SIMD); lane_util = active lanes per issued VALU instruction "
+                        "(divergence: rejection-sampling retries and op-kind branches issue for the whole wave); kernel_ms_per_step "
+                        "(one launch, start to end) exceeds ms_per_step (wall time per batch) because launches overlap")
         line = {
             "metric": "sim_seconds_per_sec", "value": sim_s / dt, "unit": "sim-s/s",
-            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"{wname}, {per_gpu} seeds per GPU per step"
@@ -402,19 +615,11 @@ def main():
                       "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms, "single_stream_ms_per_step": single_ms,
                       "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu * g.block_threads // 64,
                       "lanes_per_wave": g.lanes_per_wave, "rccl_ranks": rccl_ranks, "first_fail": first_fail,
+                      "first_fail_rare": first_fail_rare, "first_fail_very_rare": first_fail_very_rare,
+                      "workloads": extras,
                       "stream_trial_ms_per_step": stream_trial,
-                      "first_fail_seeds_per_hour": first_fail["seeds_per_hour"] if first_fail else None},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_detail": tdetail,
-                         "measured_hbm_gbps": (traffic / (k_avg_ms * 1e-3) / 1e9) if traffic else None,
-                         "kernel": kname, "algorithmic_bytes_per_launch": algo_bytes,
-                         "concurrent_launches": n_streams, "chip_achieved": algo_bytes * args.steps / dt / 1e9,
-                         "chip_frac": algo_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBPS,
-                         "note": "achieved/frac = ALGORITHMIC bytes (120 B per executor step, SURVEY 8d) / one launch's HIP-event "
-                                 "duration: an LDS-equivalent throughput — on this LDS-resident path those bytes never reach HBM; "
-                                 "measured_hbm_gbps = rocprofv3 FETCH/WRITE bytes over the same duration is the real HBM rate.  "
-                                 f"{n_streams} launches overlap on {n_streams} streams, so kernel_ms_per_step (one launch, start to end) "
-                                 "exceeds ms_per_step (wall time per batch); chip_* = all launches' bytes / wall time"},
+                      "first_fail_seeds_per_hour": (first_fail_rare or {}).get("seeds_per_hour") or (first_fail["seeds_per_hour"] if first_fail else None)},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle

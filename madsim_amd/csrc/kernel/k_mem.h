@@ -1,13 +1,10 @@
 // k_mem.h — the memory primitives sim_kernel is written against: the workgroup's LDS array, buffer-resource access to
-// global memory, the 64-bit rotate.  This is the gfx950 implementation; tests/emu/emu_shim.h provides the same names for
-// the host emulation harness (a debugging aid for GPU-less boxes, never part of the product), and nothing else in
-// kernel/*.h or sim_kernel.hip depends on which of the two is in use.
+// global memory, the 64-bit rotate — for gfx950, the only target.  Nothing else in kernel/*.h or sim_kernel.hip touches a
+// HIP built-in directly, so a test harness can compile the executor text against its own definitions of these names
+// (tests/emu does, by defining this header's include guard before it is reached); the product build has one path.
 #ifndef MADSIM_K_MEM_H
 #define MADSIM_K_MEM_H
 
-#ifdef MADSIM_EMU
-#include "emu_shim.h"
-#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -73,6 +70,5 @@ __device__ __forceinline__ uint32_t table_copy_stride(uint32_t waves_per_block) 
 #define EMU_GSTAT(off, kind) do { } while (0)
 
 }  // namespace madsim_k
-#endif  // !MADSIM_EMU
 
 #endif

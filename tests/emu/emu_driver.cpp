@@ -8,7 +8,7 @@ thread_local uint32_t* emu_smem;
 #include <vector>
 #include <cstring>
 
-// the device code, host-compiled: the same headers sim_kernel.hip includes (k_mem.h picks emu_shim.h under MADSIM_EMU)
+// the device code, host-compiled: the same headers sim_kernel.hip includes (emu_shim.h, included first, replaces k_mem.h's body)
 #include "../../madsim_amd/csrc/kernel/k_mem.h"
 #include "../../madsim_amd/csrc/sim_kernel.h"
 #include "../../madsim_amd/csrc/kernel/k_state.h"

@@ -5,6 +5,7 @@
 // about the GPU build — the -m gpu tests do that.
 #ifndef MADSIM_EMU_SHIM_H
 #define MADSIM_EMU_SHIM_H
+#define MADSIM_K_MEM_H      // this header stands in for madsim_amd/csrc/kernel/k_mem.h: its body is skipped when included later
 #include <stdint.h>
 #include <stddef.h>
 

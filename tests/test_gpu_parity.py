@@ -20,6 +20,52 @@ def _cmp(hip, w, seed0, count, config=None, limits=None):
     return got, summ
 
 
+# ---- fuzz blocks --------------------------------------------------------------------------------------------------------
+# Every test_fuzz_*_gpu runs two blocks of random programs: a FIXED block (the same programs on every run: a regression
+# anchor) and a FRESH block whose program seeds derive from MADSIM_FUZZ_SEED — by default the wall clock, so every driver
+# run covers programs no earlier run has seen.  A failure message names the generator seed: re-run with
+# MADSIM_FUZZ_SEED=<printed value> to reproduce.
+def _fuzz_seed():
+    import os
+    import time
+    v = os.environ.get("MADSIM_FUZZ_SEED")
+    return int(v, 0) if v else int(time.time())
+
+
+FUZZ_SEED = _fuzz_seed()
+
+
+def _fuzz_block(hip, gen, base, n, count, seed_mul, limits, alt_global=False, strict=False, gen_kw=None, tally=None):
+    """Programs gen(Random(base + k)), k < n, `count` seeds each, GPU vs oracle on all 48 result bytes.  A device capacity
+    verdict (MADSIM_OVERFLOW) is allowed unless `strict`; a different answer never is."""
+    import random
+    for k in range(n):
+        w, cfg, desc = gen(random.Random(base + k), **(gen_kw or {}))
+        lim = limits()
+        if alt_global and k % 2:
+            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        got, _ = hip.run_batch(w, k * seed_mul, count, cfg, lim)
+        want, _ = oracle.run_batch(w, k * seed_mul, count, cfg, lim)
+        ovf = got["verdict"] == A.OVERFLOW
+        ok = (got == want) if strict else ((got == want) | ovf)
+        assert ok.all(), (f"{gen.__name__}(Random({base + k})) [MADSIM_FUZZ_SEED={FUZZ_SEED}]", desc, got[~ok][0], want[~ok][0])
+        if tally is not None:
+            tally["ovf"] += int(ovf.sum()); tally["n"] += count; tally["verdicts"] |= set(got["verdict"].tolist())
+
+
+def _fuzz_two_blocks(hip, gen, fixed_base, n_fixed, n_fresh, salt, **kw):
+    _fuzz_block(hip, gen, fixed_base, n_fixed, **kw)
+    _fuzz_block(hip, gen, (FUZZ_SEED * 1_000_003 + salt * 7919) & 0x7fffffffffff, n_fresh, **kw)
+
+
+def _lim_tasks(n):
+    def f():
+        from tests import fuzz
+        lim = fuzz.generous_limits(); lim.max_tasks = n
+        return lim
+    return f
+
+
 def test_pingpong_2node_one_seed(hip):
     """BASELINE config 0: 2-node ping-pong, 1 seed, plumbing + bit-exact baseline."""
     _cmp(hip, W.pingpong(2, 64), 0, 1)
@@ -73,20 +119,10 @@ def test_trace_log_bytes_extended_workloads(hip):
 
 def test_fuzz_random_workloads_gpu(hip):
     """Random actor programs (every verdict, clog/set_loss/close/yield, HBM spill path) through the C-ABI."""
-    import random
     from tests import fuzz
-    verdicts, n_ovf = set(), 0
-    for k in range(120):
-        w, cfg, desc = fuzz.random_workload(random.Random(5000 + k))
-        lim = fuzz.generous_limits()
-        got, _ = hip.run_batch(w, k * 13, 96, cfg, lim)
-        want, _ = oracle.run_batch(w, k * 13, 96, cfg, lim)
-        ovf = got["verdict"] == A.OVERFLOW               # a device capacity verdict is allowed, a different answer is not
-        ok = (got == want) | ovf
-        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
-        n_ovf += int(ovf.sum())
-        verdicts |= set(got["verdict"].tolist())
-    assert {A.PASS, A.DEADLOCK, A.PANIC} <= verdicts and n_ovf < 0.02 * 120 * 96
+    t = {"ovf": 0, "n": 0, "verdicts": set()}
+    _fuzz_two_blocks(hip, fuzz.random_workload, 5000, 120, 60, 1, count=96, seed_mul=13, limits=fuzz.generous_limits, tally=t)
+    assert {A.PASS, A.DEADLOCK, A.PANIC} <= t["verdicts"] and t["ovf"] < 0.02 * t["n"]
 
 
 @pytest.mark.parametrize("nodes,rounds,count", [(2, 64, 1024), (8, 8, 1024), (16, 4, 512)])
@@ -247,47 +283,29 @@ def test_lifecycle_reference_tests_gpu(hip, name):
 
 
 def test_fuzz_lifecycle_workloads_gpu(hip):
-    import random
     from tests import fuzz
-    for k in range(150):
-        w, cfg, desc = fuzz.random_lifecycle_workload(random.Random(7000 + k))
-        lim = fuzz.generous_limits(); lim.max_tasks = 24
-        got, _ = hip.run_batch(w, k * 17, 64, cfg, lim)
-        want, _ = oracle.run_batch(w, k * 17, 64, cfg, lim)
-        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
-        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+    _fuzz_two_blocks(hip, fuzz.random_lifecycle_workload, 7000, 150, 75, 2, count=64, seed_mul=17, limits=_lim_tasks(24))
 
 
 def test_fuzz_guard_workloads_gpu(hip):
     """Random lifecycle programs whose task bodies own guards that spawn in Drop (MADSIM_PROG_DROP_SPAWN, task/mod.rs:1184-1253);
     odd rounds with the per-seed state in the global-memory block."""
-    import random
     from tests import fuzz
-    for k in range(150):
-        w, cfg, desc = fuzz.random_guard_workload(random.Random(7600 + k))
-        lim = fuzz.generous_limits(); lim.max_tasks = 24
-        if k % 2:
-            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
-        got, _ = hip.run_batch(w, k * 17, 64, cfg, lim)
-        want, _ = oracle.run_batch(w, k * 17, 64, cfg, lim)
-        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
-        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+    _fuzz_two_blocks(hip, fuzz.random_guard_workload, 7600, 150, 75, 3, count=64, seed_mul=17, limits=_lim_tasks(24), alt_global=True)
 
 
 def test_fuzz_supervisor_workloads_gpu(hip):
     """Supervisor calls from every task: task::spawn after killing / restarting the own node, JoinHandles awaited across a
     respawn of their program, init tasks spawned by hand; odd rounds with the per-seed state in the global-memory block."""
-    import random
     from tests import fuzz
-    for k in range(200):
-        w, cfg, desc = fuzz.random_supervisor_workload(random.Random(7800 + k))
-        lim = fuzz.generous_limits(); lim.max_tasks = 48
-        if k % 2:
-            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
-        got, _ = hip.run_batch(w, k * 17, 64, cfg, lim)
-        want, _ = oracle.run_batch(w, k * 17, 64, cfg, lim)
-        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
-        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+    _fuzz_two_blocks(hip, fuzz.random_supervisor_workload, 7800, 200, 100, 4, count=64, seed_mul=17, limits=_lim_tasks(48), alt_global=True)
+
+
+def test_fuzz_mixed_workloads_gpu(hip):
+    """Everything from everywhere — supervisor calls, datagrams, channel and RPC exchanges, service tasks (echo, RPC handler,
+    accept loop) — from every task: the deepest generator, LDS-resident (even rounds) and global-state (odd rounds) builds."""
+    from tests import fuzz
+    _fuzz_two_blocks(hip, fuzz.random_mixed_workload, 9900, 200, 100, 5, count=64, seed_mul=3, limits=fuzz.mixed_limits, alt_global=True)
 
 
 def test_config2_election_loop_262144_seeds(hip):
@@ -411,17 +429,8 @@ def test_register_ready_queue_with_heap_spill(hip):
 
 
 def test_fuzz_rpc_workloads_gpu(hip):
-    """Typed RPC (net/rpc.rs:96-180): 150 random call / call_timeout / handler programs x 64 seeds."""
-    import random
     from tests import fuzz
-    for k in range(150):
-        w, cfg, desc = fuzz.random_rpc_workload(random.Random(33000 + k))
-        lim = fuzz.generous_limits(); lim.max_tasks = 24
-        got, _ = hip.run_batch(w, k * 19, 64, cfg, lim)
-        want, _ = oracle.run_batch(w, k * 19, 64, cfg, lim)
-        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
-        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
-        assert (got["verdict"] == A.OVERFLOW).mean() < 0.1
+    _fuzz_two_blocks(hip, fuzz.random_rpc_workload, 33000, 120, 60, 6, count=96, seed_mul=19, limits=_lim_tasks(24))
 
 
 def test_rpc_echo_65536_seeds(hip):
@@ -602,61 +611,26 @@ def test_ref_twin_workloads_gpu(hip):
 
 def test_fuzz_address_resolution_gpu(hip):
     """Random datagram programs over mixed address kinds (network.rs:206-313: wildcard fallback, loopback, IP-less nodes)."""
-    import random
     from tests import fuzz
-    for k in range(150):
-        w, cfg, desc = fuzz.random_addr_workload(random.Random(76000 + k))
-        lim = fuzz.generous_limits()
-        if k % 2:
-            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
-        got, _ = hip.run_batch(w, k * 29, 96, cfg, lim)
-        want, _ = oracle.run_batch(w, k * 29, 96, cfg, lim)
-        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
-        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+    _fuzz_two_blocks(hip, fuzz.random_addr_workload, 76000, 150, 75, 7, count=96, seed_mul=29, limits=fuzz.generous_limits, alt_global=True)
 
 
 def test_fuzz_ephemeral_ports_gpu(hip):
     """Random programs binding port 0 (network.rs:224-236): literal port hand-out in the oracle, candidate entries on the GPU."""
-    import random
     from tests import fuzz
-    for k in range(150):
-        w, cfg, desc = fuzz.random_ephemeral_workload(random.Random(77000 + k))
-        lim = fuzz.generous_limits()
-        if k % 2:
-            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
-        got, _ = hip.run_batch(w, k * 31, 96, cfg, lim)
-        want, _ = oracle.run_batch(w, k * 31, 96, cfg, lim)
-        assert (got == want).all(), (k, desc, got[got != want][0], want[got != want][0])
+    _fuzz_two_blocks(hip, fuzz.random_ephemeral_workload, 77000, 150, 75, 8, count=96, seed_mul=31, limits=fuzz.generous_limits, alt_global=True, strict=True)
 
 
 def test_fuzz_channel_guards_gpu(hip):
     """Random reliable-channel programs about who keeps an address bound (Arc<BindGuard> clones in Sender / Receiver)."""
-    import random
     from tests import fuzz
-    for k in range(150):
-        w, cfg, desc = fuzz.random_channel_workload(random.Random(78000 + k))
-        lim = fuzz.generous_limits(); lim.max_tasks = 24
-        if k % 2:
-            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
-        got, _ = hip.run_batch(w, k * 37, 96, cfg, lim)
-        want, _ = oracle.run_batch(w, k * 37, 96, cfg, lim)
-        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
-        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+    _fuzz_two_blocks(hip, fuzz.random_channel_workload, 78000, 150, 75, 9, count=96, seed_mul=37, limits=_lim_tasks(24), alt_global=True)
 
 
 def test_fuzz_rpc_hooks_gpu(hip):
     """Random typed-RPC programs with NetSim::hook_rpc_req / hook_rpc_rsp (net/mod.rs:240-284), LDS and global state."""
-    import random
     from tests import fuzz
-    for k in range(120):
-        w, cfg, desc = fuzz.random_rpc_workload(random.Random(64000 + k), hooks=True)
-        lim = fuzz.generous_limits(); lim.max_tasks = 24
-        if k % 2:
-            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
-        got, _ = hip.run_batch(w, k * 19, 96, cfg, lim)
-        want, _ = oracle.run_batch(w, k * 19, 96, cfg, lim)
-        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
-        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+    _fuzz_two_blocks(hip, fuzz.random_rpc_workload, 64000, 120, 60, 10, count=96, seed_mul=19, limits=_lim_tasks(24), alt_global=True, gen_kw={"hooks": True})
 
 
 def _global_limits(lim=None):
@@ -680,16 +654,13 @@ def test_global_state_lifecycle_reference_tests_gpu(hip, name):
 
 
 def test_global_state_fuzz_gpu(hip):
-    import random
     from tests import fuzz
-    for k in range(160):
-        gen = fuzz.random_lifecycle_workload if k % 2 else fuzz.random_rpc_workload
-        w, cfg, desc = gen(random.Random(52000 + k))
-        lim = _global_limits(fuzz.generous_limits()); lim.max_tasks = 24
-        got, _ = hip.run_batch(w, k * 23, 128, cfg, lim)
-        want, _ = oracle.run_batch(w, k * 23, 128, cfg, lim)
-        ok = (got == want) | (got["verdict"] == A.OVERFLOW)
-        assert ok.all(), (k, desc, got[~ok][0], want[~ok][0])
+
+    def lim():
+        g = _global_limits(fuzz.generous_limits()); g.max_tasks = 24
+        return g
+    for gen, base, salt in ((fuzz.random_rpc_workload, 52000, 11), (fuzz.random_lifecycle_workload, 52500, 12)):
+        _fuzz_two_blocks(hip, gen, base, 80, 40, salt, count=128, seed_mul=23, limits=lim)
 
 
 @pytest.mark.parametrize("name", ["raft", "kv", "topo"])
