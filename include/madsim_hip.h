@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MADSIM_HIP_ABI_VERSION 2u
+#define MADSIM_HIP_ABI_VERSION 3u
 
 /* ------------------------------------------------------------------------------------------------
  * Workload: the actor program (read-only, caller-owned POD).
@@ -258,6 +258,11 @@ typedef struct madsim_limits {
     uint32_t sched;              /* MADSIM_SCHED_*: how lanes pick up further seeds when a launch holds more
                                     seeds than resident lanes; 0 = static striding                    */
     uint32_t state_mem;          /* MADSIM_STATE_*: where a seed's task table and planes live; 0 = auto               */
+    uint32_t max_steps_ceiling;  /* the largest step cap a re-run of MADSIM_STEP_LIMIT seeds (madsim_hip_run_batch_auto / _multi)
+                                    may use; 0 = default (1 << 28: the first pass's 1 << 24, then ONE 16x round).  A seed that
+                                    still hits the cap keeps the MADSIM_STEP_LIMIT verdict: a livelocked workload (a yield or
+                                    1 ms timer loop without a time limit) costs seconds, not one hour-long kernel              */
+    uint32_t reserved;           /* 0 */
 } madsim_limits_t;
 
 #define MADSIM_STATE_AUTO   0u   /* LDS unless an extended-op workload's state leaves a CU fewer than 4 full waves       */
@@ -313,6 +318,10 @@ typedef struct madsim_summary {
 #define MADSIM_E_LIMITS   (-5)
 
 uint32_t    madsim_hip_version(void);
+/* Identity of the loaded library: "madsim_hip abi=<MADSIM_HIP_ABI_VERSION> arch=gfx950 kernels=<builds> ..." — the product is
+ * the gfx950 HIP build and nothing else; a host mirror that lets the library path be overridden (A/B builds) checks this
+ * string so that no other object exporting the same symbols can stand in for it. */
+const char* madsim_hip_build_info(void);
 const char* madsim_hip_strerror(int code);
 const char* madsim_hip_last_error(void);   /* thread-local text of the calling thread's last failure */
 
@@ -342,7 +351,7 @@ int madsim_hip_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg,
 
 /* madsim_hip_run_batch, then every seed that came back with a RUNNER verdict — MADSIM_OVERFLOW (a device capacity)
  * or MADSIM_STEP_LIMIT (the max_steps safety net) — is run again, all of them gathered into ONE compacted launch per
- * round, with doubled capacities / a 16x step cap (ceiling UINT32_MAX), up to `max_rounds` times; the summary is
+ * round, with doubled capacities / a 16x step cap (never above madsim_limits_t.max_steps_ceiling), up to `max_rounds` times; the summary is
  * recomputed over the final results.  The reference's containers are unbounded (Vec mailboxes, BinaryHeap timers) and
  * it has no step cap, so neither is ever a test verdict: this is the entry point a Builder::run replacement calls.
  * `out` must not be NULL. */

@@ -6,7 +6,7 @@ same structs, so a parity test hands identical bytes to both sides.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 U64_MAX = (1 << 64) - 1
 LIMIT_NONE = 0xFFFFFFFF
 SCHED_STATIC, SCHED_QUEUE = 0, 1
@@ -70,7 +70,7 @@ class Limits(C.Structure):
         ("time_limit_ns", C.c_uint64), ("max_steps", C.c_uint32), ("heap_lds_slots", C.c_uint32),
         ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32), ("mbox_regs", C.c_uint32),
         ("mbox_msgs", C.c_uint32), ("lanes_per_wave", C.c_uint32), ("max_conns", C.c_uint32), ("chan_queue", C.c_uint32),
-        ("sched", C.c_uint32), ("state_mem", C.c_uint32),
+        ("sched", C.c_uint32), ("state_mem", C.c_uint32), ("max_steps_ceiling", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -102,7 +102,7 @@ class Geometry(C.Structure):
 
 
 assert C.sizeof(Insn) == 8 and C.sizeof(Prog) == 4 and C.sizeof(Sock) == 4 and C.sizeof(Node) == 4
-assert C.sizeof(Result) == 48 and C.sizeof(Summary) == 48 and C.sizeof(Limits) == 56
+assert C.sizeof(Result) == 48 and C.sizeof(Summary) == 48 and C.sizeof(Limits) == 64
 
 # numpy view of a result array: one record per seed, same layout as madsim_result_t
 RESULT_DTYPE = [("verdict", "<u4"), ("steps", "<u4"), ("clock_ns", "<u8"), ("msg_count", "<u8"),

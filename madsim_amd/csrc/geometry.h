@@ -301,7 +301,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             const int gv = g.vgprs ? g.vgprs(&gsel) : -1;
             uint32_t per_simd = gv > 0 ? 512u / (uint32_t)((gv + 7) & ~7) : gsel.feat != MADSIM_FEAT_ALL ? 3u : 2u;
             per_simd = per_simd < 2 ? 2u : per_simd > 4 ? 4u : per_simd;         // workgroups of four waves, one wave per SIMD each
-            const size_t per_seed = (g.lds_per_cu / per_simd - sh_bytes - 1280) / (4 * 64);
+            const size_t quota = g.lds_per_cu / per_simd;                    // (a large instruction table can eat a workgroup's whole share:
+            const size_t per_seed = quota > (size_t)sh_bytes + 1280 ? (quota - sh_bytes - 1280) / (4 * 64) : 0;   // no size_t underflow)
             const size_t fixed = 4 * (((size_t)P.max_tasks + 3) / 4 + (P.max_tasks + 31) / 32 + 2);
             uint32_t fit = per_seed > fixed + 64 ? (uint32_t)((per_seed - fixed) / 16) : 4u;
             if (P.heap_lds > fit) { P.heap_spill += P.heap_lds - fit; P.heap_lds = fit; }

@@ -13,14 +13,18 @@ __device__ __forceinline__ void ready_push(const Ctx& c, Lane& L, uint32_t slot)
     L.ready_len++;
 }
 
+// (`f` = the task's flag word when the caller has loaded it already: timer_expire's prefetch)
 template <class K>
-__device__ __forceinline__ void wake(const Ctx& c, Lane& L, uint32_t slot, uint32_t gen) {
-    const uint32_t f = TWORD(c, slot, 0, 0);
+__device__ __forceinline__ void wake_with(const Ctx& c, Lane& L, uint32_t slot, uint32_t gen, const uint32_t f) {
     // not COMPLETED | CLOSED (a stale waker), not SCHEDULED already
     if ((f & (TF_ALIVE | TF_SCHED)) == TF_ALIVE && ((f >> 8) & 0xffff) == gen) {
         TWORD(c, slot, 0, 0) = f | TF_SCHED;
         if (!(f & TF_RUN)) ready_push<K>(c, L, slot);               // RUNNING: run() re-queues after the poll
     }
+}
+template <class K>
+__device__ __forceinline__ void wake(const Ctx& c, Lane& L, uint32_t slot, uint32_t gen) {
+    wake_with<K>(c, L, slot, gen, TWORD(c, slot, 0, 0));
 }
 
 // ---- Network -----------------------------------------------------------------------------------
@@ -60,14 +64,16 @@ __device__ __forceinline__ int resolve_dest_node(const Ctx& c, uint32_t node, ui
 }
 
 // Mailbox::deliver (endpoint.rs:331-351)
+// `pf` (global-state builds): the socket's header word and first registration, loaded by timer_expire before the pop's sift
+struct DeliverPrefetch { uint32_t hdr, reg0; };
 template <class K>
-__device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t meta, uint32_t val) {
+__device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t meta, uint32_t val, const DeliverPrefetch* pf = nullptr) {
     uint32_t s = meta & 0x3f, from = (meta >> 6) & 0x7f, tag = (meta >> 13) & 0xff, sgen = (meta >> 21) & 0xff;
     if (!K::LIFE) {                                        // base ops: the event names its send_to / reply instruction
         const uint4 in = INSN(c, (meta >> 6) & 0xfff);
         from = (in.x >> 8) & 0x3f; tag = in.x >> 24; val = in.y;      // (base-op builds: plain addresses, never a loopback flag)
     }
-    const uint32_t h = SW(c, s, 0);
+    const uint32_t h = pf ? pf->hdr : (uint32_t)SW(c, s, 0);
     bool live = (h & 1) && ((h >> 1) & 0xff) == sgen;      // else: that Endpoint object is gone
     if (K::FC && c.P.uses_chan && live && SW(c, s, 1) == ~0u) live = false;     // ... only its connections still hold the address
     if (live) {
@@ -78,9 +84,11 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
         const bool rsp = rpc && tag == 0xff;
         uint32_t i = 0;
         bool taken = false;                                // (one loop exit, no early returns: see k_main.h)
+        bool first = pf != nullptr;                        // the prefetched registration is entry 0 as it was before any removal
         while (i < nreg && !taken) {
             REG(24);
-            uint32_t r = SW(c, s, 2 + i);
+            uint32_t r = first ? pf->reg0 : (uint32_t)SW(c, s, 2 + i);
+            first = false;
             if ((r & 0xff) == tag && (!rsp || (r >> 8) == (val >> 8))) {
                 nreg--;
                 SW(c, s, 2 + i) = SW(c, s, 2 + nreg);      // swap_remove
@@ -125,11 +133,26 @@ template <class K> __device__ __forceinline__ void node_restart(const Ctx& c, La
 template <class K>
 __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now) {
     while (L.top_dl <= now) {
+        // Global-state builds: the callback's first loads (the woken task's flag word; the destination socket's header and
+        // first registration) depend only on the ROOT entry, which sits in LDS — issue them before the pop, whose sift-down
+        // walks the spilled heap levels one dependent round trip at a time, so they arrive with its first level instead of
+        // costing a round trip of their own afterwards.  The pop touches neither task nor socket state.
+        uint32_t pf_flags = 0;
+        DeliverPrefetch pf = {0, 0};
+        if (K::G) {
+            const uint32_t rz = heap_lds_get<K>(c, 0).z, rk = rz >> EV_SHIFT;
+            if (rk == EV_WAKE) pf_flags = TWORD(c, rz & 0xff, 0, 0);
+            else if (rk == EV_DELIVER) { pf.hdr = SW(c, rz & 0x3f, 0); pf.reg0 = SW(c, rz & 0x3f, 2); }
+        }
         uint4 e = timer_pop<K>(c, L);
         L.steps++;
         uint32_t kind = e.z >> EV_SHIFT;
-        if (kind == EV_WAKE) { REG(22); wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff); }   // time/sleep.rs:52
-        else if (kind == EV_DELIVER) { REG(23); mailbox_deliver<K>(c, L, e.z, e.w); }      // net/mod.rs:323-330
+        if (kind == EV_WAKE) {                                                              // time/sleep.rs:52
+            REG(22);
+            if (K::G) wake_with<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff, pf_flags);
+            else wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff);
+        }
+        else if (kind == EV_DELIVER) { REG(23); mailbox_deliver<K>(c, L, e.z, e.w, K::G ? &pf : nullptr); }      // net/mod.rs:323-330
         else if (K::FN && kind == EV_RESTART) node_restart<K>(c, L, e.z & 0xff);   // task/mod.rs:313
     }
 }

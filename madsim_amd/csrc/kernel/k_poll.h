@@ -91,7 +91,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (sub == 2) {
             uint64_t d1 = u64of(u1.z, u1.w);
             if (L.clock >= d1) fut_ready = true;
-            else if (!timer_add<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
+            else timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
         }
         if (fut_ready) return true;                          // Ok((len, from))
         uint4 u2 = TU(c, slot, 2);
@@ -103,7 +103,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             u0.w = MADSIM_VAL_TIMEOUT;
             return true;
         }
-        if (!timer_add<K>(c, L, d2, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
+        timer_schedule<K>(c, L, d2, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
         st = ST_PENDING;
         return false;
     };
@@ -119,7 +119,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (sub == 1) {
             uint64_t d1 = u64of(u1.z, u1.w);
             if (L.clock < d1) {
-                if (!timer_add<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
+                timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
             } else {
                 // the caller's pending receive doubles as the rsp_tag: registration word >> 8 (see mailbox_deliver)
                 const uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;
@@ -137,7 +137,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (sent) {
                     uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
                     uint32_t meta = (EV_DELIVER << EV_SHIFT) | (sgen << 21) | ((cb >> 8) << 13) | ((ca | (lb << 6)) << 6) | (uint32_t)ds;
-                    if (!timer_add<K>(c, L, L.clock + lat, meta, (cimm & 0xff) | (reg & 0xffffff00u))) L.ovf = 1;
+                    timer_schedule<K>(c, L, L.clock + lat, meta, (cimm & 0xff) | (reg & 0xffffff00u), false);
                 }
                 // recv_from_raw(rsp_tag): Mailbox::recv (endpoint.rs:353-362); no queued message can carry a fresh tag
                 u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
@@ -167,7 +167,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (PLAIN_ADDR ? from != dst : !addr_eq(addr_of_from(c, from), SOCKW(c, dst))) st = ST_PANIC;   // assert_eq!(from, dst) rpc.rs:126
                 return true;
             }
-            if (!timer_add<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
+            timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
         }
         if (cimm >> 8) {
             uint4 u2 = TU(c, slot, 2);
@@ -177,7 +177,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.w = MADSIM_VAL_TIMEOUT;
                 return true;
             }
-            if (!timer_add<K>(c, L, d2, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
+            timer_schedule<K>(c, L, d2, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
         }
         st = ST_PENDING;
         return false;
@@ -207,11 +207,14 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (arrive != ~0ull) { d = sleep_deadline(L, arrive); sub = 3; }
         else { d = sleep_deadline(L, L.clock + (uint64_t)(u3.x >> 16) * NS_PER_MS); sub = 2; }
         u1.z = (uint32_t)d; u1.w = (uint32_t)(d >> 32); u1_dirty = true;
-        if (!timer_add<K>(c, L, d, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
+        timer_schedule<K>(c, L, d, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
         st = ST_PENDING;
     };
 
-    while (st == ST_RUN) {
+    for (;;) {
+        // global-state builds: the Timer::add calls of the previous round happen here, at one site for the whole wave
+        timer_flush<K>(c, L, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot);
+        if (st != ST_RUN) break;
         // (pc < n_insns always: validate() checks jump targets and that the table ends in DONE / JMP / PANIC)
         uint4 in = insn_fetch<K>(c, pc);
         uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
@@ -245,7 +248,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 // (base-op builds keep no deadline: there a Sleep is only polled again once its own timer has fired)
                 if (K::LIFE && L.clock < deadline) {       // not elapsed: register ANOTHER timer
                     REG(5);
-                    if (!timer_add<K>(c, L, deadline, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
+                    timer_schedule<K>(c, L, deadline, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
                     st = ST_PENDING;
                 }
                 else if (K::FC && op == MS_OP_ACCEPT) {    // rand_delay done -> conn_rx.recv()
@@ -348,7 +351,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                                 const uint32_t hw = HOOKW(SOCKW(c, (uint32_t)ds) & 0xff);
                                 if ((hw & (1u << 18)) && ((hw & (1u << 19)) || ((hw >> 20) & 0xff) == (imm & 0xff))) ev = make_uint2(EV_NOP << EV_SHIFT, 0);
                             }
-                            if (!timer_add<K>(c, L, L.clock + lat, ev.x, ev.y)) L.ovf = 1;
+                            timer_schedule<K>(c, L, L.clock + lat, ev.x, ev.y, false);
                         }
                     }
                 }
@@ -405,7 +408,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             in = insn_fetch<K>(c, pc);
             op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
         }
-        if (st != ST_RUN) break;
+        if (st != ST_RUN) { if (K::G) continue; else break; }      // (global-state builds leave through the flush at the head)
 
         PROBE(7);
         REG(9);
@@ -717,6 +720,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             }
             case MS_OP_ADVANCE:                            // time/mod.rs:103-106
                 if (!K::FT) { st = ST_PANIC; break; }
+                if (K::G && L.pq_n) break;                 // pushes of this round are still queued: flush at the head, then come back here
                 L.clock += (uint64_t)b * NS_PER_S + imm;
                 pc++;
                 u0.y = pc | (sub << 16) | (from << 24);
@@ -790,7 +794,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             REG(17);
             u1.z = (uint32_t)deadline; u1.w = (uint32_t)(deadline >> 32); u1_dirty = true;
             sub = (op == MS_OP_RECV) ? 3 : 1;
-            if (!timer_add<K>(c, L, deadline, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0)) L.ovf = 1;
+            timer_schedule<K>(c, L, deadline, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
             st = ST_PENDING;
         }
     }

@@ -97,6 +97,13 @@ struct Lane {
     // runtime-mutable net config (MS_OP_SET_LOSS)
     uint64_t loss_pint;
     uint32_t loss_always;
+    // Global-state builds: the Timer::add calls of one poll round, held back and performed at ONE site (poll_task's round
+    // head, k_timer.h timer_flush) in their original order: at most one delivery event, then up to three wake-ups of the
+    // polled task.  Inlined at each of its ~20 call sites the push's sift-up ran once per site, for the few lanes that
+    // were there, every spilled level a round trip to global memory; at one site all lanes of the wave share those trips.
+    uint64_t pq_deliv_dl, pq_w0, pq_w1, pq_w2;
+    uint32_t pq_deliv_meta, pq_deliv_val;
+    uint32_t pq_n;       // bit 7: a delivery is pending; bits 0-2: pending wake-ups
 };
 
 #define LDS128(i) (reinterpret_cast<uint4*>(SMEM)[(i)])

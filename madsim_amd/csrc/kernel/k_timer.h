@@ -13,6 +13,8 @@ __device__ __forceinline__ uint64_t ev_deadline(const uint4& e) { return u64of(e
 // across the wave).  Variants without a spill region drop the HBM path.  The LDS load is issued
 // unconditionally (clamped index) and the HBM value selected afterwards, so the two address spaces
 // never merge into a flat_* access.
+// (Tried in round 3: [sibling pair][lane][2] — both children of a sift-down level in one 32-byte granule, one sector per
+// lane and level instead of two.  A/B on one box: election loop +2 %, topology 0, timer storm -2 %: not kept.)
 __device__ __forceinline__ uint4 spill_load(const Ctx& c, uint32_t slot) {
     return buf_load128(c.spill, slot * c.P.total_lanes * 16u + c.spill_off);
 }
@@ -57,6 +59,9 @@ __device__ __forceinline__ uint2 ev_deliver_meta(uint32_t sgen, uint32_t tag, ui
 }
 
 // BinaryHeap::sift_up(0, pos) with `hole` as the moving element; keeps the root mirror current.
+// Builds with a spill region walk two levels per trip: parent and grandparent are loaded together (their indices depend on
+// `pos` alone), so a sift through the spilled levels costs one global round trip per TWO levels; the comparisons and stores
+// are those of the one-level loop, in the same order.
 template <class K>
 __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos, const uint4& hole) {
     uint64_t hd = ev_deadline(hole);
@@ -65,9 +70,20 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos
         REG(11);
         const uint32_t parent = (pos - 1) >> 1;
         const uint4 p = heap_get<K>(c, parent);
-        // hole <= parent in heap order: stop (the root's deadline is mirrored in a register)
-        up = hd < (parent == 0 ? L.top_dl : ev_deadline(p));
-        if (up) { heap_set<K>(c, pos, p); pos = parent; up = pos > 0; }
+        if (K::SPILL) {
+            const uint32_t gp = parent > 0 ? (parent - 1) >> 1 : 0;
+            const uint4 g = heap_get<K>(c, gp);
+            up = hd < (parent == 0 ? L.top_dl : ev_deadline(p));
+            if (up) {
+                heap_set<K>(c, pos, p); pos = parent;
+                up = pos > 0 && hd < (gp == 0 ? L.top_dl : ev_deadline(g));
+                if (up) { heap_set<K>(c, pos, g); pos = gp; up = pos > 0; }
+            }
+        } else {
+            // hole <= parent in heap order: stop (the root's deadline is mirrored in a register)
+            up = hd < (parent == 0 ? L.top_dl : ev_deadline(p));
+            if (up) { heap_set<K>(c, pos, p); pos = parent; up = pos > 0; }
+        }
     }
     heap_set<K>(c, pos, hole);
     if (pos == 0) L.top_dl = hd;
@@ -88,6 +104,37 @@ __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadli
     return room;
 }
 
+// Timer::add as the executor code calls it.  Every build but the global-state ones pushes at once; those queue the call in
+// the lane (k_state.h Lane::pq_*) until timer_flush.  `wake` = the event is a wake-up of the task being polled (meta is the
+// same for all of them, so only the deadline is kept); a delivery always precedes the wake-ups of its round (k_poll.h).
+template <class K>
+__device__ __forceinline__ void timer_schedule(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val, bool wake) {
+    if (!K::G) { if (!timer_add<K>(c, L, deadline, meta, val)) L.ovf = 1; return; }
+    if (wake) {
+        const uint32_t n = L.pq_n & 7u;
+        if (n >= 3) L.ovf = 1;                            // (cannot happen: a round makes at most three; never a lost timer)
+        else {
+            // (value selects, not `if (n == 0) L.pq_w0 = ..`: a store through a selected field address keeps the whole Lane in scratch)
+            L.pq_w0 = n == 0 ? deadline : L.pq_w0; L.pq_w1 = n == 1 ? deadline : L.pq_w1; L.pq_w2 = n == 2 ? deadline : L.pq_w2;
+            L.pq_n++;
+        }
+    } else {
+        if (L.pq_n) L.ovf = 1;                            // (cannot happen: one delivery per round, before its wake-ups)
+        L.pq_deliv_dl = deadline; L.pq_deliv_meta = meta; L.pq_deliv_val = val; L.pq_n |= 0x80u;
+    }
+}
+// Perform the queued pushes, oldest first.  `wake_meta` = the wake-up event of the task being polled.
+template <class K>
+__device__ __forceinline__ void timer_flush(const Ctx& c, Lane& L, uint32_t wake_meta) {
+    if (!K::G) return;
+    while (L.pq_n) {
+        uint64_t dl; uint32_t meta, val;
+        if (L.pq_n & 0x80u) { dl = L.pq_deliv_dl; meta = L.pq_deliv_meta; val = L.pq_deliv_val; L.pq_n &= 0x7fu; }
+        else { dl = L.pq_w0; meta = wake_meta; val = 0; L.pq_w0 = L.pq_w1; L.pq_w1 = L.pq_w2; L.pq_n--; }
+        if (!timer_add<K>(c, L, dl, meta, val)) L.ovf = 1;
+    }
+}
+
 // BinaryHeap::pop: swap the last element into the root, sift_down_to_bottom(0), then sift_up.
 template <class K>
 __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
@@ -98,23 +145,33 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
     if (end > 0) {
         uint4 top = heap_get<K>(c, 0);
         uint32_t pos = 0, child = 1;
+        uint4 m = item;                                     // the entry last moved up: it now sits at parent(pos)
         while (child + 1 < end) {
             REG(21);
             uint4 l = heap_get<K>(c, child), r = heap_get<K>(c, child + 1);
             bool right = ev_deadline(l) >= ev_deadline(r);   // left <= right in heap order: take right
-            uint4 m = right ? r : l;
+            m = right ? r : l;
             heap_set<K>(c, pos, m);
             if (pos == 0) L.top_dl = ev_deadline(m);
             pos = child + (right ? 1u : 0u);
             child = 2 * pos + 1;
         }
         if (child == end - 1) {
-            uint4 m = heap_get<K>(c, child);
+            m = heap_get<K>(c, child);
             heap_set<K>(c, pos, m);
             if (pos == 0) L.top_dl = ev_deadline(m);
             pos = child;
         }
-        heap_sift_up<K>(c, L, pos, item);
+        // sift_up(0, pos) of `item`.  Its first comparison is with the entry at parent(pos) — the one just moved there, still
+        // in registers — so the common outcome (the old bottom element belongs at the bottom again) costs no load: on the
+        // spill levels that is one dependent global round trip less per pop.  (Same comparisons, same stores as
+        // heap_sift_up from `pos`: only where the parent's value comes from differs.)
+        if (K::SPILL && pos > 0) {
+            if (ev_deadline(item) < ev_deadline(m)) { heap_set<K>(c, pos, m); pos = (pos - 1) >> 1; heap_sift_up<K>(c, L, pos, item); }
+            else heap_set<K>(c, pos, item);
+        } else {
+            heap_sift_up<K>(c, L, pos, item);
+        }
         item = top;
     } else {
         L.top_dl = ~0ull;

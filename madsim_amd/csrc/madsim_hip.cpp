@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -86,6 +88,7 @@ struct madsim_hip_ctx {
     hipStream_t own_stream = nullptr;         // madsim_hip_run_batch_multi launches here so devices overlap
     unsigned long long* d_acc = nullptr;      // 4 x u64 summary accumulators
     madsim_result_t* d_out = nullptr; size_t out_cap = 0;
+    madsim_result_t* h_pinned = nullptr; size_t pinned_cap = 0;   // host staging of madsim_hip_run_batch_multi (page-locked: async D2H)
     uint64_t* d_seeds = nullptr; size_t seeds_cap = 0;        // seed list of a compacted re-run
     uint8_t* d_tlog = nullptr; size_t tlog_cap = 0; uint64_t* d_tlen = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -108,6 +111,7 @@ struct madsim_hip_ctx {
     int upload_workload(const madsim_workload_t* w, KParams& P);
     int ensure_scratch(KParams& P, hipStream_t stream, bool work_queue);
     int ensure_out(size_t count);
+    int ensure_pinned(size_t count);
     int launch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count, const uint64_t* d_seed_list,
                const madsim_limits_t* lim, madsim_result_t* d_out, hipStream_t stream);
     int reduce(const madsim_result_t* d_out, uint64_t count, uint64_t seed0, unsigned long long* d_acc4, hipStream_t stream);
@@ -151,6 +155,7 @@ void madsim_hip_ctx::close() {
     scratch.clear();
     if (d_acc) (void)hipFree(d_acc);
     if (d_out) (void)hipFree(d_out);
+    if (h_pinned) (void)hipHostFree(h_pinned);
     if (d_seeds) (void)hipFree(d_seeds);
     if (d_tlog) (void)hipFree(d_tlog);
     if (d_tlen) (void)hipFree(d_tlen);
@@ -159,6 +164,9 @@ void madsim_hip_ctx::close() {
     if (ev1) (void)hipEventDestroy(ev1);
     if (own_stream) (void)hipStreamDestroy(own_stream);
     for (auto& e : tev) if (e) (void)hipEventDestroy(e);
+    d_acc = nullptr; d_out = nullptr; h_pinned = nullptr; d_seeds = nullptr; d_tlog = nullptr; d_tlen = nullptr; d_prof = nullptr;
+    ev0 = ev1 = nullptr; own_stream = nullptr; out_cap = pinned_cap = seeds_cap = tlog_cap = 0;
+    for (auto& e : tev) e = nullptr;
     device = -1;
 }
 
@@ -247,6 +255,16 @@ int madsim_hip_ctx::ensure_out(size_t count) {
         d_out = nullptr; out_cap = 0;
         HIP_TRY(hipMalloc(&d_out, count * sizeof(madsim_result_t)));
         out_cap = count;
+    }
+    return 0;
+}
+
+int madsim_hip_ctx::ensure_pinned(size_t count) {
+    if (count > pinned_cap) {
+        if (h_pinned) (void)hipHostFree(h_pinned);
+        h_pinned = nullptr; pinned_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&h_pinned, count * sizeof(madsim_result_t), hipHostMallocDefault));
+        pinned_cap = count;
     }
     return 0;
 }
@@ -355,6 +373,14 @@ std::mutex g_default_mu;
 
 // Seeds that came back with a RUNNER verdict (a device capacity or the step cap, neither a reference concept) are run
 // again, all of them in ONE compacted launch per round, with doubled capacities / a 16x step cap.
+// The step cap never grows beyond madsim_limits_t.max_steps_ceiling (default 1 << 28 = the first pass's 1 << 24 and one 16x
+// round): a livelocked workload — a yield loop, a 1 ms timer loop without a time limit — must come back as MADSIM_STEP_LIMIT
+// after seconds, not hold the GPU (and the context mutex) in one non-preemptible kernel for an hour.
+uint64_t step_ceiling(const madsim_limits_t& L) {
+    uint64_t c = L.max_steps_ceiling ? L.max_steps_ceiling : (1u << 28);
+    const uint64_t first = L.max_steps ? L.max_steps : (1u << 24);
+    return c < first ? first : c;
+}
 void grow(madsim_limits_t& L, const madsim_workload_t* w, bool any_ovf, bool any_steps) {
     auto dbl = [](uint32_t v, uint32_t dflt, uint32_t cap) { uint32_t x = (v == 0 || v == MADSIM_LIMIT_NONE) ? dflt : v; x *= 2; return x > cap ? cap : x; };
     L.lanes_per_wave = 0;
@@ -370,18 +396,21 @@ void grow(madsim_limits_t& L, const madsim_workload_t* w, bool any_ovf, bool any
     if (any_steps) {
         uint64_t s = L.max_steps ? L.max_steps : (1u << 24);
         s *= 16;
-        L.max_steps = s > 0xffffffffull ? 0xffffffffu : (uint32_t)s;
+        const uint64_t ceil = step_ceiling(L);
+        L.max_steps = s > ceil ? (uint32_t)ceil : (uint32_t)s;
     }
 }
 
-int rerun_runner_verdicts(madsim_hip_ctx* c, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+// `ctxs` = the contexts whose locks the caller holds: round r runs on ctxs[r % n] (the shards' overflow is spread, not piled
+// on the first device).
+int rerun_runner_verdicts(madsim_hip_ctx* const* ctxs, int n_ctx, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
                           const madsim_limits_t* lim, madsim_result_t* out, int max_rounds, double* kernel_ms) {
     madsim_limits_t L{};
     if (lim) L = *lim;
     for (int round = 0; round < max_rounds; round++) {
         std::vector<uint64_t> idx;
         bool any_ovf = false, any_steps = false;
-        const bool steps_maxed = L.max_steps == 0xffffffffu;
+        const bool steps_maxed = (L.max_steps ? L.max_steps : (1u << 24)) >= step_ceiling(L);
         for (uint64_t i = 0; i < count; i++) {
             if (out[i].verdict == MADSIM_OVERFLOW) { idx.push_back(i); any_ovf = true; }
             else if (out[i].verdict == MADSIM_STEP_LIMIT && !steps_maxed) { idx.push_back(i); any_steps = true; }
@@ -391,8 +420,10 @@ int rerun_runner_verdicts(madsim_hip_ctx* c, const madsim_workload_t* w, const m
         std::vector<uint64_t> seeds(idx.size());
         for (size_t k = 0; k < idx.size(); k++) seeds[k] = seed0 + idx[k];
         std::vector<madsim_result_t> res;
-        int rc = c->run_list(w, cfg, seeds, &L, res, kernel_ms);
+        madsim_hip_ctx* c = ctxs[round % n_ctx];
+        int rc = c->bind();
         if (rc) return rc;
+        if ((rc = c->run_list(w, cfg, seeds, &L, res, kernel_ms))) return rc;
         for (size_t k = 0; k < idx.size(); k++) out[idx[k]] = res[k];
     }
     return 0;
@@ -417,6 +448,19 @@ void host_summary(const madsim_result_t* out, uint64_t seed0, uint64_t count, ma
 extern "C" {
 
 uint32_t madsim_hip_version(void) { return MADSIM_HIP_ABI_VERSION; }
+
+#define MADSIM_STR2(x) #x
+#define MADSIM_STR(x) MADSIM_STR2(x)
+#define MADSIM_COUNT_VARIANT(...) +1
+const char* madsim_hip_build_info(void) {
+    static const std::string info = std::string("madsim_hip abi=") + MADSIM_STR(MADSIM_HIP_ABI_VERSION) + " arch=gfx950 kernels="
+        + std::to_string(0 MADSIM_FOR_EACH_VARIANT(MADSIM_COUNT_VARIANT)) + " backend=hip-rocm"
+#ifdef MADSIM_EXPERIMENT_BUILD
+        + " experiment-build"
+#endif
+        ;
+    return info.c_str();
+}
 
 const char* madsim_hip_strerror(int code) {
     switch (code) {
@@ -508,7 +552,8 @@ int madsim_hip_ctx_run_batch_auto(madsim_hip_ctx_t* c, const madsim_workload_t* 
     int rc = c->run_host(w, cfg, seed0, count, lim, out, &s);
     if (rc) return rc;
     double kernel_ms = s.kernel_ms;
-    if ((rc = rerun_runner_verdicts(c, w, cfg, seed0, count, lim, out, max_rounds, &kernel_ms))) return rc;
+    madsim_hip_ctx* one[1] = {c};
+    if ((rc = rerun_runner_verdicts(one, 1, w, cfg, seed0, count, lim, out, max_rounds, &kernel_ms))) return rc;
     if (summary) { host_summary(out, seed0, count, summary); summary->kernel_ms = kernel_ms; summary->wall_s = since(t0); }
     return 0;
 }
@@ -548,10 +593,16 @@ int64_t madsim_hip_ctx_trace_seed(madsim_hip_ctx_t* c, const madsim_workload_t* 
 // ---- one process, several GPUs -----------------------------------------------------------------------------------------
 // Builder::run drives every seed from one process (builder.rs:129-150): shard [seed0, seed0 + count) contiguously over
 // the contexts (context g gets [g * ceil(count / n), ...), the rule of madsim_amd/dist.py::shard_range), queue every
-// device's kernel from this one host thread before waiting for any of them, then copy the shards back and fold the n
-// reports on the host.  The fold is a host fold on purpose: the per-seed results travel to the caller's host array
-// anyway, and n <= 8 reports of 32 bytes do not justify a single-process RCCL communicator (ncclCommInitAll) and a
-// collective launch per batch.  The one-process-per-GPU form (bench.py, torch.distributed) is where RCCL carries the report.
+// device's kernel AND its device-to-host copy (into pinned staging memory, so the copies of different devices overlap)
+// from this one host thread before waiting for any of them, then fold the n reports on the host.
+// Why a host fold and not the RCCL gather BASELINE.json's north_star names: the per-seed results travel to the caller's host
+// array anyway (Builder::run needs the failing seed's result), so the only thing a collective could carry is n <= 8 reports
+// of 32 bytes that the host already holds; a single-process communicator (ncclCommInitAll) plus one collective launch per
+// batch would add a dependency and a synchronisation, not remove one.  The RCCL gather lives where ranks really are
+// separate processes: bench.py / madsim_amd/dist.py (one process per GPU, one 64-byte all-gather per batch).
+// Robustness: context locks are taken in address order (two threads passing the same contexts in different orders cannot
+// deadlock); once the first kernel is in flight no error returns before EVERY launched stream has been synchronised; the
+// compacted re-runs of runner verdicts go round-robin over the contexts.
 int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const madsim_workload_t* w, const madsim_config_t* cfg,
                                uint64_t seed0, uint64_t count, const madsim_limits_t* lim, madsim_result_t* out,
                                madsim_summary_t* summary, int max_rounds) {
@@ -559,50 +610,79 @@ int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const m
     if (!ctxs || n_ctx < 1) return fail(MADSIM_E_ARG, "run_batch_multi needs at least one context");
     if (!out && count) return fail(MADSIM_E_ARG, "run_batch_multi needs the result array");
     for (int g = 0; g < n_ctx; g++) {
-        if (!ctxs[g] || ctxs[g]->device < 0) return fail(MADSIM_E_NOINIT, "null or closed context");
+        if (!ctxs[g]) return fail(MADSIM_E_NOINIT, "null context");
         for (int h = 0; h < g; h++) if (ctxs[h] == ctxs[g]) return fail(MADSIM_E_ARG, "the same context appears twice");
     }
     int rc = madsim_geo::validate(w, cfg, &g_err);
     if (rc) return rc;
-    const uint64_t chunk = (count + (uint64_t)n_ctx - 1) / (uint64_t)n_ctx;
-    struct Shard { uint64_t lo = 0, n = 0; };
-    std::vector<Shard> sh(n_ctx);
+    std::vector<madsim_hip_ctx*> order(ctxs, ctxs + n_ctx);
+    std::sort(order.begin(), order.end(), [](madsim_hip_ctx* a, madsim_hip_ctx* b) { return std::less<madsim_hip_ctx*>()(a, b); });
     std::vector<std::unique_lock<std::mutex>> locks;
-    for (int g = 0; g < n_ctx; g++) locks.emplace_back(ctxs[g]->mu);
-    // 1. every device's kernel is in flight before the host waits for anything
-    for (int g = 0; g < n_ctx; g++) {
+    for (madsim_hip_ctx* c : order) locks.emplace_back(c->mu);
+    for (int g = 0; g < n_ctx; g++) if (ctxs[g]->device < 0) return fail(MADSIM_E_NOINIT, "closed context");
+    const uint64_t chunk = (count + (uint64_t)n_ctx - 1) / (uint64_t)n_ctx;
+    struct Shard { uint64_t lo = 0, n = 0; bool launched = false; };
+    std::vector<Shard> sh(n_ctx);
+    // 1. every device's kernel and its D2H copy are in flight before the host waits for anything
+    int first_err = 0;
+    std::string first_msg;
+    auto note = [&](int e) { if (e && !first_err) { first_err = e; first_msg = g_err; } return e; };
+    auto queue_shard = [&](int g) -> int {
         madsim_hip_ctx* c = ctxs[g];
+        int e;
+        if ((e = c->bind())) return e;
+        if ((e = c->ensure_out(sh[g].n))) return e;
+        if ((e = c->ensure_pinned(sh[g].n))) return e;
+        HIP_TRY(hipEventRecord(c->ev0, c->own_stream));
+        sh[g].launched = true;                                  // from here on the stream must be drained before returning
+        if ((e = c->launch(w, cfg, seed0 + sh[g].lo, sh[g].n, nullptr, lim, c->d_out, c->own_stream))) return e;
+        HIP_TRY(hipEventRecord(c->ev1, c->own_stream));
+        HIP_TRY(hipMemcpyAsync(c->h_pinned, c->d_out, sh[g].n * sizeof(madsim_result_t), hipMemcpyDeviceToHost, c->own_stream));
+        return 0;
+    };
+    for (int g = 0; g < n_ctx && !first_err; g++) {
         sh[g].lo = std::min((uint64_t)g * chunk, count);
         sh[g].n = std::min(sh[g].lo + chunk, count) - sh[g].lo;
-        if (!sh[g].n) continue;
-        if ((rc = c->bind())) return rc;
-        if ((rc = c->ensure_out(sh[g].n))) return rc;
-        HIP_TRY(hipEventRecord(c->ev0, c->own_stream));
-        if ((rc = c->launch(w, cfg, seed0 + sh[g].lo, sh[g].n, nullptr, lim, c->d_out, c->own_stream))) return rc;
-        HIP_TRY(hipEventRecord(c->ev1, c->own_stream));
+        if (sh[g].n) note(queue_shard(g));
     }
-    // 2. wait and copy back per device (the others keep running; a D2H copy into pageable memory blocks the host, so
-    //    none is issued before every kernel has been queued)
+    // 2. drain EVERY launched stream — also when something failed above: no kernel of this call stays in flight behind an
+    //    error return — and move the staged results into the caller's array
     double kernel_ms = 0.0;
-    for (int g = 0; g < n_ctx; g++) {
+    auto drain_shard = [&](int g) -> int {
         madsim_hip_ctx* c = ctxs[g];
-        if (!sh[g].n) continue;
-        if ((rc = c->bind())) return rc;
+        int e;
+        if ((e = c->bind())) return e;
         HIP_TRY(hipStreamSynchronize(c->own_stream));
-        HIP_TRY(hipMemcpy(out + sh[g].lo, c->d_out, sh[g].n * sizeof(madsim_result_t), hipMemcpyDeviceToHost));
+        if (first_err) return 0;
+        memcpy(out + sh[g].lo, c->h_pinned, sh[g].n * sizeof(madsim_result_t));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         kernel_ms = std::max(kernel_ms, (double)ms);       // devices ran concurrently
-    }
-    // 3. runner verdicts (capacity / step cap) from every shard: one compacted re-launch per round, on the first device
-    if ((rc = ctxs[0]->bind())) return rc;
-    if ((rc = rerun_runner_verdicts(ctxs[0], w, cfg, seed0, count, lim, out, max_rounds, &kernel_ms))) return rc;
+        return 0;
+    };
+    for (int g = 0; g < n_ctx; g++) if (sh[g].launched) note(drain_shard(g));
+    if (first_err) return fail(first_err, first_msg);
+    // 3. runner verdicts (capacity / step cap) from every shard: one compacted re-launch per round, round-robin over the devices
+    if ((rc = rerun_runner_verdicts(ctxs, n_ctx, w, cfg, seed0, count, lim, out, max_rounds, &kernel_ms))) return rc;
     // 4. fold
     if (summary) { host_summary(out, seed0, count, summary); summary->kernel_ms = kernel_ms; summary->wall_s = since(t0); }
     return 0;
 }
 
 // ---- v1 entry points: wrappers on the process-default context ------------------------------------------------------------
+// The default context is reference-counted by its users: a wrapper pins it under g_default_mu for the duration of its call,
+// and madsim_hip_shutdown waits until no call is inside before destroying it — a concurrent run_batch and shutdown is a
+// clean "not initialised" for whichever comes second, never a use-after-free.
+
+namespace {
+int g_default_users = 0;
+std::condition_variable g_default_cv;
+struct DefaultPin {
+    madsim_hip_ctx* c;
+    DefaultPin() { std::lock_guard<std::mutex> lk(g_default_mu); c = g_default; if (c) g_default_users++; }
+    ~DefaultPin() { if (c) { std::lock_guard<std::mutex> lk(g_default_mu); if (--g_default_users == 0) g_default_cv.notify_all(); } }
+};
+}  // namespace
 
 int madsim_hip_init(int device) {
     std::lock_guard<std::mutex> lk(g_default_mu);
@@ -615,39 +695,48 @@ int madsim_hip_init(int device) {
 }
 
 int madsim_hip_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_default_mu);
-    madsim_hip_ctx* c = g_default;
-    g_default = nullptr;
+    madsim_hip_ctx* c;
+    {
+        std::unique_lock<std::mutex> lk(g_default_mu);
+        c = g_default;
+        g_default = nullptr;                                   // later calls see "not initialised"
+        g_default_cv.wait(lk, [] { return g_default_users == 0; });
+    }
     return madsim_hip_ctx_destroy(c);
 }
 
-madsim_hip_ctx_t* madsim_hip_default_ctx(void) { return g_default; }
+madsim_hip_ctx_t* madsim_hip_default_ctx(void) { std::lock_guard<std::mutex> lk(g_default_mu); return g_default; }
 
 int madsim_hip_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
                          const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary) {
-    return madsim_hip_ctx_run_batch(g_default, w, cfg, seed0, count, lim, out, summary);
+    DefaultPin p;
+    return madsim_hip_ctx_run_batch(p.c, w, cfg, seed0, count, lim, out, summary);
 }
 
 int madsim_hip_run_batch_auto(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
                               const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary, int max_rounds) {
-    return madsim_hip_ctx_run_batch_auto(g_default, w, cfg, seed0, count, lim, out, summary, max_rounds);
+    DefaultPin p;
+    return madsim_hip_ctx_run_batch_auto(p.c, w, cfg, seed0, count, lim, out, summary, max_rounds);
 }
 
 int madsim_hip_run_batch_device(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
                                 const madsim_limits_t* lim, void* d_out, void* stream, madsim_summary_t* summary) {
-    return madsim_hip_ctx_run_batch_device(g_default, w, cfg, seed0, count, lim, d_out, stream, summary);
+    DefaultPin p;
+    return madsim_hip_ctx_run_batch_device(p.c, w, cfg, seed0, count, lim, d_out, stream, summary);
 }
 
 int madsim_hip_run_batch_async(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
                                const madsim_limits_t* lim, void* d_out, void* d_summary4, void* stream, int timing_slot) {
-    return madsim_hip_ctx_run_batch_async(g_default, w, cfg, seed0, count, lim, d_out, d_summary4, stream, timing_slot);
+    DefaultPin p;
+    return madsim_hip_ctx_run_batch_async(p.c, w, cfg, seed0, count, lim, d_out, d_summary4, stream, timing_slot);
 }
 
-int madsim_hip_timing_ms(int timing_slot, double* ms) { return madsim_hip_ctx_timing_ms(g_default, timing_slot, ms); }
+int madsim_hip_timing_ms(int timing_slot, double* ms) { DefaultPin p; return madsim_hip_ctx_timing_ms(p.c, timing_slot, ms); }
 
 int64_t madsim_hip_trace_seed(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed,
                               const madsim_limits_t* lim, uint8_t* log, uint64_t cap, madsim_result_t* out) {
-    return madsim_hip_ctx_trace_seed(g_default, w, cfg, seed, lim, log, cap, out);
+    DefaultPin p;
+    return madsim_hip_ctx_trace_seed(p.c, w, cfg, seed, lim, log, cap, out);
 }
 
 int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* out) {
@@ -670,7 +759,8 @@ int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, 
 
 // Debug: read and clear the per-phase cycle accumulators a profiling kernel build fills (zeros otherwise).
 int madsim_hip_debug_counters(uint64_t* out16) {
-    madsim_hip_ctx* c = g_default;
+    DefaultPin pin;
+    madsim_hip_ctx* c = pin.c;
     CTX_ENTER(c);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out16, c->d_prof, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));

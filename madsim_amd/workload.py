@@ -388,6 +388,13 @@ class WorkloadBuilder:
         if self.panic_texts or self.panic_patterns:
             if any(n.flags & A.NODE_RESTART_MATCHING and i not in self.panic_patterns for i, n in enumerate(self.nodes)):
                 raise ValueError("string and numeric restart_on_panic_matching patterns cannot be mixed in one workload")
+            # literal messages get class codes 0, 1, ..: a numeric panic(code) / panic_with_flag in the same workload could
+            # collide with a class a node restarts on (a spurious restart instead of a test failure), so the two do not mix
+            for t in self.tasks:
+                for op, a, b, imm, reloc in t.code:
+                    if op == A.OP["PANIC"] and not isinstance(imm, tuple):
+                        raise ValueError("numeric panic codes (panic(code), panic_with_flag) cannot be mixed with literal panic "
+                                         "messages / string patterns in one workload")
             codes = self._panic_codes()
             for t in self.tasks:
                 t.code = [(op, a, b, codes[imm[1]] if isinstance(imm, tuple) else imm, reloc) for op, a, b, imm, reloc in t.code]

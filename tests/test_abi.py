@@ -25,12 +25,29 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(A.Insn) == 8 and C.sizeof(A.Result) == 48 and C.sizeof(A.Summary) == 48
-    assert C.sizeof(A.Limits) == 56 and C.sizeof(A.Geometry) == 44
-    assert A.Result.clock_ns.offset == 8 and A.Result.trace_hash.offset == 32 and A.Result.obs_hash.offset == 40
+    """The ctypes mirror against the header itself: every struct's field names, order, offsets and size (parsed from
+    include/madsim_hip.h by tests/cheader.py), every op code."""
+    from tests import cheader as H
+    S = H.structs()
+    mirror = {"madsim_insn_t": A.Insn, "madsim_prog_t": A.Prog, "madsim_sock_t": A.Sock, "madsim_node_t": A.Node,
+              "madsim_workload_t": A.Workload, "madsim_config_t": A.Config, "madsim_limits_t": A.Limits,
+              "madsim_result_t": A.Result, "madsim_summary_t": A.Summary, "madsim_geometry_t": A.Geometry}
+    for name in S:
+        if name in mirror:
+            continue
+        assert hasattr(A, "HEADER_STRUCTS") and name in A.HEADER_STRUCTS, f"{name} has no ctypes mirror in madsim_amd/_abi.py"
+    mirror.update(getattr(A, "HEADER_STRUCTS", {}))
+    for name, cls in mirror.items():
+        offs, size = H.layout(S[name])
+        assert [f[0] for f in cls._fields_] == [f[0] for f in S[name]], name
+        assert C.sizeof(cls) == size, (name, C.sizeof(cls), size)
+        for fname, _, _, _ in S[name]:
+            assert getattr(cls, fname).offset == offs[fname], (name, fname)
+    assert C.sizeof(A.Result) == 48 and A.Result.trace_hash.offset == 32 and A.Result.obs_hash.offset == 40
     for name, val in A.OP.items():
         m = re.search(r"MS_OP_%s = (\d+)," % name, HEADER)
         assert m and int(m.group(1)) == val, name
+    assert len(A.OP) == len(re.findall(r"MS_OP_\w+ = \d+,", HEADER))
 
 
 def test_c_twin_of_pingpong_matches_python_assembler():

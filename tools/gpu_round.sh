@@ -3,12 +3,14 @@
 #   gpurun --timeout 900 -- 'bash tools/gpu_round.sh <out-tag> <stage>...'
 # Stages run in the order given; each writes under gpurun_out/<out-tag>/ and prints a one-line summary.
 #   ubench            tools/ubench_issue (VALU / SALU issue ceilings by wall time, attainable HBM copy bandwidth)
+#   vmem              tools/ubench_vmem (cost of divergent global-memory instructions, round-trip latency)
 #   tests             python -m pytest tests -m gpu -x -q
 #   smoke             __graft_entry__.smoke()
 #   bench             python bench.py (the default line: headline + extra.workloads + first-fail legs)
 #   bench:<args>      python bench.py <args with ',' for spaces>, e.g. bench:--workload,raft,--steps,12
 #   line:<wl>[:<steps>]  one bench line of workload <wl> without the extra legs (fast A/B)
 #   prof:<wl>[:full]  tools/prof_workload.sh on workload <wl> (kernel-trace --stats + PMC passes; full adds FETCH/WRITE)
+#   phase:<wl>        tools/phase_prof.py on workload <wl> (in-kernel s_memtime probes of an EXP_PROF build)
 #   fuzz[:<seconds>[:<generators>]]  tools/fuzz_campaign.py with a clock-derived base seed
 #   ab:<wl>:<steps>   every madsim_amd/libmadsim_hip*.so back to back on workload <wl> (A/B builds from tools/build_variant.sh)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -32,6 +34,9 @@ for st in "$@"; do
     ubench)
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/ubench_issue.hip -o tools/ubench_issue 2> "$O/ubench_build.err" \
         && timeout 300 tools/ubench_issue > "$O/ubench_issue.txt" 2> "$O/ubench_issue.err"; tail -8 "$O/ubench_issue.txt";;
+    vmem)
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/ubench_vmem.hip -o tools/ubench_vmem 2> "$O/vmem_build.err" \
+        && timeout 400 tools/ubench_vmem > "$O/ubench_vmem.txt" 2> "$O/ubench_vmem.err"; tail -12 "$O/ubench_vmem.txt";;
     tests)
       timeout 1500 python -m pytest tests -m gpu -x -q > "$O/pytest.txt" 2>&1; tail -3 "$O/pytest.txt";;
     smoke)
@@ -46,6 +51,8 @@ for st in "$@"; do
     prof)
       args=""; [ "$a1" != pingpong ] && args="--workload $a1"
       bash tools/prof_workload.sh "$TAG/prof_$a1" "$args" "$a2"; tail -14 "$O/prof_$a1/summary.txt";;
+    phase)   # needs madsim_amd/libmadsim_hip_prof.so (tools/build_variant.sh prof -DEXP_PROF), built before the call
+      MADSIM_HIP_LIB=$PWD/madsim_amd/libmadsim_hip_prof.so timeout 300 python tools/phase_prof.py "$a1" > "$O/phase_$a1.txt" 2>&1; cat "$O/phase_$a1.txt";;
     fuzz)
       timeout $(( ${a1:-90} + 120 )) python tools/fuzz_campaign.py "${a1:-90}" "$(( $(date +%s) * 1000 ))" $a2 > "$O/fuzz.txt" 2>&1; tail -2 "$O/fuzz.txt";;
     ab)

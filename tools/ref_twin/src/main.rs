@@ -498,6 +498,131 @@ async fn abort_own_handle(obs: Obs) -> Tail {
     fingerprint_tail(t0, &obs)
 }
 
+// ---- round 3: rpc hooks, substring panic patterns, a datagram in flight across a re-bind, the DSL-built ping-pong ------------
+
+#[derive(madsim::net::rpc::Serialize, madsim::net::rpc::Deserialize, madsim::Request)]
+#[rtype("u32")]
+struct Echo(u32);
+#[derive(madsim::net::rpc::Serialize, madsim::net::rpc::Deserialize, madsim::Request)]
+#[rtype("u32")]
+struct Other(u32);
+
+/// NetSim::hook_rpc_req / hook_rpc_rsp (net/mod.rs:240-284; consulted by NetSim::send, :307-311 and :321-328).
+/// Table: twin_workloads.py::rpc_hooks (the handler's `obs.push(1)` is its MS_OP_TRACE 1).
+async fn rpc_hooks(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let net = NetSim::current();
+    let ns = h.create_node().ip(addr(1, 1).ip()).build();
+    let (n1, n2, n3) = (h.create_node().ip(addr(2, 1).ip()).build(), h.create_node().ip(addr(3, 1).ip()).build(),
+                        h.create_node().ip(addr(4, 1).ip()).build());
+    let asv = addr(1, 1);
+    net.hook_rpc_req(n1.id(), |req: &Echo| req.0 != 5);                 // m.hook_rpc_req(n1, 0, code=5)
+    net.hook_rpc_rsp(n2.id(), |_rsp: &u32| false);                      // m.hook_rpc_rsp(n2): every response is dropped
+    let o = obs.clone();
+    let _srv = ns.spawn(async move {
+        let ep = Endpoint::bind(asv).await.unwrap();
+        ep.add_rpc_handler(move |_req: Echo| { o.push(1); async move { 42u32 } });
+        std::future::pending::<()>().await;
+    });
+    let timeout = Duration::from_millis(100);
+    let c1 = n1.spawn(async move {
+        let ep = Endpoint::bind(addr(2, 1)).await.unwrap();
+        time::sleep(Duration::from_millis(10)).await;
+        assert_eq!(ep.call_timeout(asv, Echo(5), timeout).await.unwrap_err().kind(), std::io::ErrorKind::TimedOut);
+        assert_eq!(ep.call_timeout(asv, Echo(6), timeout).await.unwrap(), 42);
+    });
+    let c2 = n2.spawn(async move {
+        let ep = Endpoint::bind(addr(3, 1)).await.unwrap();
+        time::sleep(Duration::from_millis(10)).await;
+        assert_eq!(ep.call_timeout(asv, Echo(7), timeout).await.unwrap_err().kind(), std::io::ErrorKind::TimedOut);
+        time::sleep(Duration::from_millis(400)).await;
+        assert_eq!(ep.call_timeout(asv, Echo(8), timeout).await.unwrap(), 42);
+    });
+    let c3 = n3.spawn(async move {
+        let ep = Endpoint::bind(addr(4, 1)).await.unwrap();
+        time::sleep(Duration::from_millis(10)).await;
+        for _ in 0..3 { assert_eq!(ep.call(asv, Echo(9)).await.unwrap(), 42); }
+    });
+    time::sleep(Duration::from_millis(300)).await;
+    net.hook_rpc_rsp(n2.id(), |rsp: &u32| *rsp != 99);                  // m.hook_rpc_rsp(n2, code=99): replaces the hook
+    c1.await.unwrap(); c2.await.unwrap(); c3.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
+/// task/mod.rs:297-300 `error_msg.contains(pattern)` with literal messages.  Table: twin_workloads.py::panic_substrings.
+/// Ends in the panic "out of memory" at 100 s (verdict "panic", like the #[should_panic] test it generalises).
+async fn panic_substrings(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let (fa, fb) = (Arc::new(AtomicUsize::new(0)), Arc::new(AtomicUsize::new(0)));
+    let f = fa.clone();
+    // two init tasks on node A: NodeBuilder::init takes ONE closure, so the node's init spawns the second body beside the first
+    let _a = h.create_node().restart_on_panic_matching("disk").restart_on_panic_matching("net").init(move || {
+        let f = f.clone();
+        async move {
+            let second = madsim::task::spawn(async move { time::sleep(Duration::from_secs(7)).await; panic!("network reset"); });
+            f.fetch_add(1, Ordering::Relaxed);
+            time::sleep(Duration::from_secs(3)).await;
+            let _keep = second;
+            panic!("disk full");
+        }
+    }).build();
+    let f = fb.clone();
+    let _b = h.create_node().restart_on_panic_matching("reset").init(move || {
+        let f = f.clone();
+        async move { f.fetch_add(1, Ordering::Relaxed); time::sleep(Duration::from_secs(20)).await; panic!("network reset"); }
+    }).build();
+    let _c = h.create_node().restart_on_panic_matching("timeout").init(|| async {
+        time::sleep(Duration::from_secs(100)).await; panic!("out of memory");
+    }).build();
+    time::sleep(Duration::from_secs(50)).await;
+    assert!(fa.load(Ordering::Relaxed) >= 3 && fb.load(Ordering::Relaxed) >= 2);
+    obs.push(1);
+    time::sleep(Duration::from_secs(100)).await;
+    fingerprint_tail(t0, &obs)
+}
+
+/// A datagram in flight to a socket that is closed and re-bound before it lands: the delivery closure holds the OLD
+/// `Arc<dyn Socket>` (net/mod.rs:318-330).  Table: twin_workloads.py::rebind_in_flight; 0xFFFF_FFFF = Err(Elapsed).
+async fn rebind_in_flight(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let (n1, n2) = (h.create_node().ip(addr(1, 1).ip()).build(), h.create_node().ip(addr(2, 1).ip()).build());
+    let o = obs.clone();
+    let rx = n2.spawn(async move {
+        let ep = Endpoint::bind(addr(2, 1)).await.unwrap();
+        time::sleep(Duration::from_millis(14)).await;
+        drop(ep);
+        let ep = Endpoint::bind(addr(2, 1)).await.unwrap();
+        let mut buf = [0u8; 16];
+        for (tag, ms) in [(1u64, 200u64), (2, 400)] {
+            match time::timeout(Duration::from_millis(ms), ep.recv_from(tag, &mut buf)).await {
+                Ok(r) => { let (len, _) = r.unwrap(); let mut w = [0u8; 4]; w[..len].copy_from_slice(&buf[..len]); o.push(u32::from_le_bytes(w) as u64) }
+                Err(_) => o.push(0xFFFF_FFFF),
+            }
+        }
+    });
+    let tx = n1.spawn(async move {
+        let ep = Endpoint::bind(addr(1, 1)).await.unwrap();
+        time::sleep(Duration::from_millis(10)).await;
+        ep.send_to(addr(2, 1), 1, &5u32.to_le_bytes()).await.unwrap();
+        time::sleep(Duration::from_millis(100)).await;
+        ep.send_to(addr(2, 1), 2, &7u32.to_le_bytes()).await.unwrap();
+    });
+    rx.await.unwrap(); tx.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
+/// The 4-node ping-pong built ONCE with the Rust workload DSL (bindings/rust/madsim-hip, `pingpong_twin`) and interpreted on
+/// real madsim by `madsim_hip::interp` — the table `Builder::run_workload` hands to the GPU runner, run here by the reference.
+async fn pingpong4_dsl(obs: Obs) -> Tail {
+    let w = madsim_hip::pingpong_twin(4, 64);
+    let seen = madsim_hip::interp::main_future(&w, Vec::new()).await;
+    for v in &seen.obs { obs.push(*v); }
+    Tail { elapsed_ns: seen.obs[seen.obs.len() - 2], msg_count: seen.msg_count }
+}
+
 fn run_one(name: &str, seed: u64, loss: f64) -> String {
     let mut config = madsim::Config::default();
     config.net.packet_loss_rate = loss;
@@ -531,6 +656,10 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
                 "spawn_after_own_restart" => spawn_after_own_restart(o).await,
                 "join_names_its_task" => join_names_its_task(o).await,
                 "abort_own_handle" => abort_own_handle(o).await,
+                "rpc_hooks" => rpc_hooks(o).await,
+                "panic_substrings" => panic_substrings(o).await,
+                "rebind_in_flight" => rebind_in_flight(o).await,
+                "pingpong4_dsl" => pingpong4_dsl(o).await,
                 other => panic!("unknown workload {other}"),
             }
         });
@@ -555,7 +684,8 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
 const ALL: &[&str] = &["pingpong2", "pingpong4", "pingpong16", "sleep_1s", "yield_order", "timer_ties", "kill", "restart",
                        "restart_on_panic", "receiver_drop", "localhost", "restart_on_panic_matching", "bind_ephemeral",
                        "channel_wildcard", "guard_keeps_address", "spawn_in_drop_abort", "spawn_in_drop_kill",
-                       "spawn_after_own_restart", "join_names_its_task", "abort_own_handle"];
+                       "spawn_after_own_restart", "join_names_its_task", "abort_own_handle", "rpc_hooks", "panic_substrings",
+                       "rebind_in_flight", "pingpong4_dsl"];
 
 fn main() {
     let args: Vec<String> = std::env::args().collect();

@@ -310,6 +310,75 @@ def abort_own_handle():
     return wl.build()
 
 
+def rpc_hooks():
+    """NetSim::hook_rpc_req / hook_rpc_rsp (net/mod.rs:240-284; consulted by NetSim::send, :307-311 and :321-328): requests
+    Echo(5) leaving node 2 vanish before the link test (no loss / latency draws); every response on its way to node 3 is
+    judged by the hook installed when it was SENT and dropped when its timer fires; a replaced hook only judges messages sent
+    afterwards; node 4 is untouched.  The handler observes 1 per request it receives."""
+    wl = W.WorkloadBuilder()
+    ns = wl.create_node(); asv = wl.addr(ns, 1)
+    h = wl.task(ns); h.rpc_reply(asv, 42)
+    srv = wl.task(ns); srv.bind(asv); top = srv.label()
+    srv.rpc_recv(asv, 0); srv.trace(1); srv.spawn(h, move_request=True); srv.jmp(top)
+    n1, n2, n3 = wl.create_node(), wl.create_node(), wl.create_node()
+    a1, a2, a3 = wl.addr(n1, 1), wl.addr(n2, 1), wl.addr(n3, 1)
+    c1 = wl.task(n1); c1.bind(a1); c1.sleep(ms=10)
+    c1.rpc_call(a1, asv, 0, 5, timeout_ms=100); c1.assert_val(A.VAL_TIMEOUT)
+    c1.rpc_call(a1, asv, 0, 6, timeout_ms=100); c1.assert_val(42)
+    c2 = wl.task(n2); c2.bind(a2); c2.sleep(ms=10)
+    c2.rpc_call(a2, asv, 0, 7, timeout_ms=100); c2.assert_val(A.VAL_TIMEOUT)
+    c2.sleep(ms=400)
+    c2.rpc_call(a2, asv, 0, 8, timeout_ms=100); c2.assert_val(42)
+    c3 = wl.task(n3); c3.bind(a3); c3.sleep(ms=10); c3.set(0, 3); top = c3.label()
+    c3.rpc_call(a3, asv, 0, 9); c3.assert_val(42); c3.djnz(0, top)
+    m = wl.main()
+    m.hook_rpc_req(n1, 0, code=5); m.hook_rpc_rsp(n2)
+    m.spawn(srv); m.spawn(c1); m.spawn(c2); m.spawn(c3)
+    m.sleep(ms=300); m.hook_rpc_rsp(n2, code=99)
+    m.join(c1); m.join(c2); m.join(c3)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def panic_substrings():
+    """`restart_on_panic_matching.iter().any(|s| error_msg.contains(s))` (task/mod.rs:297-300) with literal messages and
+    substring patterns: node A ("disk" | "net") and node B ("reset") keep restarting — "network reset" matches both — until
+    node C's "out of memory", which its pattern "timeout" does not match, unwinds out of block_on at 100 s."""
+    wl = W.WorkloadBuilder()
+    a = wl.create_node(restart_on_panic_matching=("disk", "net"))
+    b = wl.create_node(restart_on_panic_matching=("reset",))
+    c = wl.create_node(restart_on_panic_matching=("timeout",))
+    ta2 = wl.task(a); ta2.sleep(secs=7); ta2.panic("network reset")            # task::spawn-ed by A's init task (one init closure per node)
+    ta = wl.task(a, init=True); ta.spawn(ta2); ta.flag_add(0, 1); ta.sleep(secs=3); ta.panic("disk full")
+    tb = wl.task(b, init=True); tb.flag_add(1, 1); tb.sleep(secs=20); tb.panic("network reset")
+    tc = wl.task(c, init=True); tc.sleep(secs=100); tc.panic("out of memory")
+    m = wl.main(); m.build_node(a); m.build_node(b); m.build_node(c)
+    m.sleep(secs=50); m.panic_if_flag_lt(0, 3); m.panic_if_flag_lt(1, 2); m.trace(1); m.sleep(secs=100)
+    fingerprint_tail(m)                                # never reached: "out of memory" ends the run at 100 s
+    return wl.build()
+
+
+def rebind_in_flight():
+    """A datagram in flight to a socket that is closed and re-bound before it lands: the delivery closure holds the OLD
+    `Arc<dyn Socket>` (net/mod.rs:318-330), so the message lands in the dropped Endpoint's mailbox and the new Endpoint at the
+    same address never sees it — its `timeout(recv_from)` elapses (observed value MADSIM_VAL_TIMEOUT) — while a datagram
+    sent after the re-bind arrives (observed value 7)."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+    rx = wl.task(n2)
+    rx.bind(a2); rx.sleep(ms=14)                        # the first datagram is sent at ~12 ms and lands at 13-22 ms;
+    rx.close(a2); rx.bind(a2)                           # the drop + re-bind happens at ~15-16 ms: most seeds have it in flight then.
+    rx.recv_from_timeout(a2, 1, ms=200); rx.trace_val() # Either way it is lost: landed early = queued in the Endpoint that was dropped
+    rx.recv_from_timeout(a2, 2, ms=400); rx.trace_val()
+    tx = wl.task(n1)
+    tx.bind(a1); tx.sleep(ms=10); tx.send_to(a1, a2, 1, 5)
+    tx.sleep(ms=100); tx.send_to(a1, a2, 2, 7)
+    m = wl.main(); m.spawn(rx); m.spawn(tx); m.join(rx); m.join(tx)
+    fingerprint_tail(m)
+    return wl.build()
+
+
 def limits(name):
     """Device capacities a table needs beyond the defaults (None = defaults); the oracle has none."""
     if name == "join_names_its_task":                     # two instances of one program alive at once
@@ -319,7 +388,7 @@ def limits(name):
 
 
 # workloads that end in a panic by design (the reference test is #[should_panic])
-EXPECT_PANIC = {"restart_on_panic_matching"}
+EXPECT_PANIC = {"restart_on_panic_matching", "panic_substrings"}
 
 ALL = {
     "pingpong2": lambda: pingpong(2, 64), "pingpong4": lambda: pingpong(4, 64), "pingpong16": lambda: pingpong(16, 8),
@@ -330,4 +399,7 @@ ALL = {
     "spawn_in_drop_abort": spawn_in_drop_abort, "spawn_in_drop_kill": spawn_in_drop_kill,
     "spawn_after_own_restart": spawn_after_own_restart,
     "join_names_its_task": join_names_its_task, "abort_own_handle": abort_own_handle,
+    # round 3: the semantics added since the first kit, and the table built by the Rust DSL (bindings/rust/madsim-hip)
+    "rpc_hooks": rpc_hooks, "panic_substrings": panic_substrings, "rebind_in_flight": rebind_in_flight,
+    "pingpong4_dsl": lambda: pingpong(4, 64),          # the same table, built by madsim_hip::pingpong_twin and run by madsim_hip::interp
 }

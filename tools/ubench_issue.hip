@@ -50,6 +50,29 @@ VALU_KERNEL(lshl_add_u64, 4, "v_lshl_add_u64 %4, %5, 2, %4\n v_lshl_add_u64 %6, 
 VALU_KERNEL(cndmask, 4, "v_cndmask_b32 %0, %1, %0, s[20:21]\n v_cndmask_b32 %2, %3, %2, s[20:21]\n v_cndmask_b32 %1, %0, %1, s[20:21]\n v_cndmask_b32 %3, %2, %3, s[20:21]\n")
 VALU_KERNEL(cmp_u32, 4, "v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 s[22:23], %2, %3\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 s[22:23], %3, %0\n")
 VALU_KERNEL(cmp_u64, 4, "v_cmp_lt_u64 vcc, %4, %5\n v_cmp_lt_u64 s[22:23], %6, %7\n v_cmp_lt_u64 vcc, %5, %6\n v_cmp_lt_u64 s[22:23], %7, %4\n")
+// more instruction kinds (which VALU ops issue at the full rate?)
+VALU_KERNEL(mov_b32, 4, "v_mov_b32 %0, %1\n v_mov_b32 %2, %3\n v_mov_b32 %1, %0\n v_mov_b32 %3, %2\n")
+VALU_KERNEL(mov_b64, 4, "v_mov_b64 %4, %5\n v_mov_b64 %6, %7\n v_mov_b64 %5, %4\n v_mov_b64 %7, %6\n")
+VALU_KERNEL(lshlrev_b32, 4, "v_lshlrev_b32 %0, 3, %1\n v_lshlrev_b32 %2, 5, %3\n v_lshrrev_b32 %1, 3, %0\n v_lshrrev_b32 %3, 5, %2\n")
+VALU_KERNEL(lshlrev_b64, 4, "v_lshlrev_b64 %4, 5, %5\n v_lshlrev_b64 %6, 5, %7\n v_lshrrev_b64 %5, 3, %4\n v_lshrrev_b64 %7, 3, %6\n")
+VALU_KERNEL(lshl_add_u32, 4, "v_lshl_add_u32 %0, %1, 2, %0\n v_lshl_add_u32 %2, %3, 2, %2\n v_lshl_add_u32 %1, %0, 1, %1\n v_lshl_add_u32 %3, %2, 1, %3\n")
+VALU_KERNEL(lshl_or_b32, 4, "v_lshl_or_b32 %0, %1, 2, %0\n v_lshl_or_b32 %2, %3, 2, %2\n v_lshl_or_b32 %1, %0, 1, %1\n v_lshl_or_b32 %3, %2, 1, %3\n")
+VALU_KERNEL(add3_u32, 4, "v_add3_u32 %0, %1, %2, %0\n v_add3_u32 %3, %1, %2, %3\n v_add3_u32 %1, %0, %3, %1\n v_add3_u32 %2, %0, %3, %2\n")
+VALU_KERNEL(and_or_b32, 4, "v_and_or_b32 %0, %1, %2, %0\n v_and_or_b32 %3, %1, %2, %3\n v_and_or_b32 %1, %0, %3, %1\n v_and_or_b32 %2, %0, %3, %2\n")
+VALU_KERNEL(bfe_u32, 4, "v_bfe_u32 %0, %1, 3, 8\n v_bfe_u32 %2, %3, 5, 8\n v_bfe_u32 %1, %0, 1, 9\n v_bfe_u32 %3, %2, 1, 9\n")
+VALU_KERNEL(perm_b32, 4, "v_perm_b32 %0, %1, %0, %2\n v_perm_b32 %3, %1, %3, %2\n v_perm_b32 %1, %0, %1, %3\n v_perm_b32 %2, %0, %2, %3\n")
+VALU_KERNEL(add_co, 4, "v_add_co_u32 %0, vcc, %1, %0\n v_addc_co_u32 %2, vcc, %3, %2, vcc\n v_add_co_u32 %1, vcc, %0, %1\n v_addc_co_u32 %3, vcc, %2, %3, vcc\n")
+VALU_KERNEL(mul_u24, 4, "v_mul_u32_u24 %0, %1, %0\n v_mul_u32_u24 %2, %3, %2\n v_mul_u32_u24 %1, %0, %1\n v_mul_u32_u24 %3, %2, %3\n")
+VALU_KERNEL(mad_u32_u24, 4, "v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %3, %1, %2, %3\n v_mad_u32_u24 %1, %0, %3, %1\n v_mad_u32_u24 %2, %0, %3, %2\n")
+VALU_KERNEL(cndmask_vcc, 4, "v_cndmask_b32 %0, %1, %0, vcc\n v_cndmask_b32 %2, %3, %2, vcc\n v_cndmask_b32 %1, %0, %1, vcc\n v_cndmask_b32 %3, %2, %3, vcc\n")
+VALU_KERNEL(cmp_vcc, 4, "v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_eq_u32 vcc, %1, %2\n v_cmp_ne_u32 vcc, %3, %0\n")
+VALU_KERNEL(min_u32, 4, "v_min_u32 %0, %1, %0\n v_max_u32 %2, %3, %2\n v_min_u32 %1, %0, %1\n v_max_u32 %3, %2, %3\n")
+VALU_KERNEL(sub_u32, 4, "v_sub_u32 %0, %1, %0\n v_subrev_u32 %2, %3, %2\n v_sub_u32 %1, %0, %1\n v_subrev_u32 %3, %2, %3\n")
+VALU_KERNEL(alignbyte, 4, "v_alignbyte_b32 %0, %1, %0, 1\n v_alignbyte_b32 %2, %3, %2, 1\n v_alignbyte_b32 %1, %0, %1, 3\n v_alignbyte_b32 %3, %2, %3, 3\n")
+VALU_KERNEL(xad_u32, 4, "v_xad_u32 %0, %1, %2, %0\n v_xad_u32 %3, %1, %2, %3\n v_xad_u32 %1, %0, %3, %1\n v_xad_u32 %2, %0, %3, %2\n")
+VALU_KERNEL(or3_b32, 4, "v_or3_b32 %0, %1, %2, %0\n v_or3_b32 %3, %1, %2, %3\n v_or3_b32 %1, %0, %3, %1\n v_or3_b32 %2, %0, %3, %2\n")
+VALU_KERNEL(xor_sgpr, 4, "v_xor_b32 %0, s20, %0\n v_xor_b32 %2, s21, %2\n v_xor_b32 %1, s20, %1\n v_xor_b32 %3, s21, %3\n")
+VALU_KERNEL(readlane, 4, "v_readlane_b32 s22, %0, 3\n v_readlane_b32 s23, %1, 5\n v_readfirstlane_b32 s24, %2\n v_readfirstlane_b32 s25, %3\n")
 // the executor kernel's mix (static count of its hot loop: ~40 % logic/add, 15 % alignbit + bitop3, 12 % multiplies,
 // 8 % 64-bit adds, 15 % cndmask, 10 % compares): 20 instructions
 VALU_KERNEL(mix, 20,
@@ -175,6 +198,9 @@ int main(int argc, char** argv) {
 #define RUN(name) run_issue(#name, k_##name, insts_##name, T, 1.0)
     RUN(add_u32); RUN(xor_b32); RUN(alignbit); RUN(bitop3); RUN(mul_lo); RUN(mul_hi); RUN(mad_u64_u32); RUN(lshl_add_u64);
     RUN(cndmask); RUN(cmp_u32); RUN(cmp_u64); RUN(mix); RUN(salu); RUN(valu_salu);
+    RUN(mov_b32); RUN(mov_b64); RUN(lshlrev_b32); RUN(lshlrev_b64); RUN(lshl_add_u32); RUN(lshl_or_b32); RUN(add3_u32); RUN(and_or_b32);
+    RUN(bfe_u32); RUN(perm_b32); RUN(add_co); RUN(mul_u24); RUN(mad_u32_u24); RUN(cndmask_vcc); RUN(cmp_vcc); RUN(min_u32); RUN(sub_u32);
+    RUN(alignbyte); RUN(xad_u32); RUN(or3_b32); RUN(xor_sgpr); RUN(readlane);
     printf("# xoshiro: draws (one rejection-loop trip of kernel/k_rng.h: next_u64 + accept test) per second per chip, G draws/s\n");
     {
         CK(hipFuncSetAttribute((const void*)k_xoshiro, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
