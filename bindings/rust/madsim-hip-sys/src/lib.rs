@@ -41,6 +41,14 @@ pub struct madsim_sock_t {
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
+pub struct madsim_service_t {
+    pub vaddr: u8,
+    pub n_servers: u8,
+    pub servers: [u8; 6],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
 pub struct madsim_node_t {
     pub flags: u8,
     pub n_match: u8,
@@ -58,6 +66,10 @@ pub struct madsim_workload_t {
     pub progs: *const madsim_prog_t,
     pub socks: *const madsim_sock_t,
     pub insns: *const madsim_insn_t,
+    pub n_services: u32,
+    pub panic_dyn_max: u32,
+    pub services: *const madsim_service_t,
+    pub panic_match: *const u32,
 }
 
 #[repr(C)]
@@ -205,6 +217,8 @@ pub const MADSIM_PROG_DROP_SPAWN: u32 = 4;
 pub const MADSIM_ADDR_IP: u32 = 0;
 pub const MADSIM_ADDR_UNSPECIFIED: u32 = 1;
 pub const MADSIM_ADDR_LOOPBACK: u32 = 2;
+pub const MADSIM_ADDR_VIRTUAL: u32 = 3;
+pub const MADSIM_MAX_SERVICES: u32 = 8;
 pub const MADSIM_NODE_RESTART_ON_PANIC: u32 = 1;
 pub const MADSIM_NODE_RESTART_MATCHING: u32 = 4;
 pub const MADSIM_PANIC_CODE_OTHER: u32 = 255;

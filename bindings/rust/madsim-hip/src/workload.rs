@@ -127,6 +127,8 @@ pub struct Workload {
     pub progs: Vec<sys::madsim_prog_t>,
     pub socks: Vec<sys::madsim_sock_t>,
     pub insns: Vec<sys::madsim_insn_t>,
+    /// IPVS virtual services (net/ipvs.rs): address entry + real servers in add_server order
+    pub services: Vec<sys::madsim_service_t>,
 }
 
 impl Workload {
@@ -141,6 +143,10 @@ impl Workload {
             progs: self.progs.as_ptr(),
             socks: self.socks.as_ptr(),
             insns: self.insns.as_ptr(),
+            n_services: self.services.len() as u32,
+            panic_dyn_max: 0,
+            services: if self.services.is_empty() { std::ptr::null() } else { self.services.as_ptr() },
+            panic_match: std::ptr::null(),
         }
     }
 }
@@ -150,6 +156,7 @@ pub struct WorkloadBuilder {
     socks: Vec<sys::madsim_sock_t>,
     tasks: Vec<TaskBuilder>,
     payloads: Vec<Vec<u8>>,
+    services: Vec<sys::madsim_service_t>,
 }
 
 impl Default for WorkloadBuilder {
@@ -165,6 +172,7 @@ impl WorkloadBuilder {
             socks: Vec::new(),
             tasks: vec![TaskBuilder { index: 0, node: 0, flags: 0, code: Vec::new() }],
             payloads: Vec::new(),
+            services: Vec::new(),
         }
     }
     /// The future handed to `block_on` (program 0, on node 0).
@@ -186,6 +194,21 @@ impl WorkloadBuilder {
         self.socks.push(sys::madsim_sock_t { node, kind: sys::MADSIM_ADDR_IP as u8, port });
         Addr((self.socks.len() - 1) as u8)
     }
+    /// A virtual service address that belongs to no node ("1.1.1.<ip_id>:<port>"): a destination only.
+    pub fn virtual_addr(&mut self, ip_id: u8, port: u16) -> Addr {
+        assert!(ip_id >= 1 && port >= 1);
+        self.socks.push(sys::madsim_sock_t { node: ip_id, kind: sys::MADSIM_ADDR_VIRTUAL as u8, port });
+        Addr((self.socks.len() - 1) as u8)
+    }
+    /// `ipvs.add_service(ServiceAddr::Tcp(vaddr), RoundRobin)` + one `add_server` per entry (net/ipvs.rs:50-85), before any task runs
+    pub fn ipvs_service(&mut self, vaddr: Addr, servers: &[Addr]) {
+        assert!(self.services.len() < sys::MADSIM_MAX_SERVICES as usize && servers.len() <= 6);
+        let mut s = sys::madsim_service_t { vaddr: vaddr.0, n_servers: servers.len() as u8, servers: [0; 6] };
+        for (i, a) in servers.iter().enumerate() {
+            s.servers[i] = a.0;
+        }
+        self.services.push(s);
+    }
     /// A new task program on `node` (`node.spawn(async move { .. })` once a `spawn` instruction names it).
     pub fn task(&mut self, node: u8) -> TaskId {
         assert!(self.tasks.len() < 255, "at most 255 task programs");
@@ -206,7 +229,7 @@ impl WorkloadBuilder {
         self.payloads.clone()
     }
     pub fn build(mut self) -> Workload {
-        let mut w = Workload { nodes: self.nodes, progs: Vec::new(), socks: self.socks, insns: Vec::new() };
+        let mut w = Workload { nodes: self.nodes, progs: Vec::new(), socks: self.socks, insns: Vec::new(), services: self.services };
         for t in self.tasks.iter_mut() {
             let base = w.insns.len() as u16;
             let ends = t.code.last().map_or(false, |i| i.insn.op == sys::MS_OP_DONE || i.insn.op == sys::MS_OP_JMP || i.insn.op == sys::MS_OP_PANIC);

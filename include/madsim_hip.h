@@ -54,10 +54,11 @@ enum madsim_op {
                               (unwrap_err) else unwrap -> a mismatch panics the polling task         */
     MS_OP_ABORT = 3,       /* a=prog: handle[prog].abort() (task/join.rs:158-163)                    */
     MS_OP_YIELD = 4,       /* tokio::task::yield_now().await (re-export task/mod.rs:30)              */
-    MS_OP_PANIC = 5,       /* a=0: panic!() with message code imm (0..254); a=1: panic!("{}", flag[b] + imm): the code
-                              is (flag[b & 3] + imm) & 0xff.  The code is what NodeBuilder::restart_on_panic_matching
-                              patterns are compared with (task/mod.rs:297-300); any other panic (failed assert,
-                              unwrap of an Err) carries code 255, which no pattern names                       */
+    MS_OP_PANIC = 5,       /* a=0: panic!() with message code imm (0..254); a=1: panic!("{}", flag[b & 3] + imm): the message is
+                              the decimal text of that value, which is also its code — values above
+                              madsim_workload_t.panic_dyn_max yield MADSIM_OVERFLOW.  The code is what
+                              NodeBuilder::restart_on_panic_matching looks at (task/mod.rs:297-300; madsim_workload_t.panic_match);
+                              any other panic (failed assert, unwrap of an Err) carries code 255, which no pattern names */
     MS_OP_SET = 6,         /* a=reg(0..1): cnt[a] = imm (a loop bound; registers are 16 bit)          */
     MS_OP_DJNZ = 7,        /* a=reg, b=target: if (--cnt[a] != 0) goto b                              */
     MS_OP_JMP = 8,         /* b=target                                                               */
@@ -202,6 +203,26 @@ typedef struct madsim_sock {
 #define MADSIM_ADDR_IP          0u  /* 10.0.0.<node>:port */
 #define MADSIM_ADDR_UNSPECIFIED 1u  /* 0.0.0.0:port       */
 #define MADSIM_ADDR_LOOPBACK    2u  /* 127.0.0.1:port     */
+#define MADSIM_ADDR_VIRTUAL     3u  /* a virtual IP that belongs to no node ("1.1.1.1:80"): `node` is an id of the IP (1..255), not a
+                                       node.  Only a destination: a workload that binds it is refused (MADSIM_E_WORKLOAD), and a
+                                       datagram sent to it is dropped without any draw ("destination not found", :285-289) unless an
+                                       IPVS service rewrites the destination first (madsim_service_t)                                */
+
+/* IP Virtual Server (net/ipvs.rs): `NetSim::global_ipvs().add_service(ServiceAddr::Tcp(vaddr), RoundRobin)` plus one
+ * `add_server` per entry of `servers`, done before the first task runs (as the reference's own test does,
+ * net/tcp/mod.rs:254-315).  NetSim::send and connect1 ask `ipvs.get_server(dst)` after rand_delay and the request hook and
+ * before Network::try_send (net/mod.rs:312-317, :345-350): when `dst` equals a service's virtual address and the service has
+ * servers, the destination becomes servers[rr_index] and the per-seed rr_index advances (ipvs.rs:88-105) — also when the
+ * message is then lost, clogged or finds no socket.  Everything downstream sees the rewritten address: the link test, the
+ * socket lookup, the `dst` a connection's channel() halves are built from.  (An RPC caller still asserts `from == dst` with
+ * the address it was GIVEN, rpc.rs:126: a typed call through a virtual address panics when the real server answers, as in
+ * the reference.)  The service table is static: add_server / del_server at run time are not modelled. */
+typedef struct madsim_service {
+    uint8_t vaddr;       /* socket-table entry holding the service address (any kind; typically MADSIM_ADDR_VIRTUAL) */
+    uint8_t n_servers;   /* 0..6 real servers, in add_server order; 0 = get_server() returns None: no rewrite        */
+    uint8_t servers[6];  /* socket-table entries of the real server addresses                                       */
+} madsim_service_t;
+#define MADSIM_MAX_SERVICES 8u
 
 typedef struct madsim_node {
     uint8_t flags;       /* MADSIM_NODE_* */
@@ -210,10 +231,10 @@ typedef struct madsim_node {
 } madsim_node_t;
 #define MADSIM_NODE_RESTART_ON_PANIC 1u /* NodeBuilder::restart_on_panic (task/mod.rs:298-316)      */
 #define MADSIM_NODE_RESTART_MATCHING 4u /* NodeBuilder::restart_on_panic_matching(msg) (runtime/mod.rs:384-387,
-                                           task/mod.rs:299): restart only when the panic's message code equals one of
-                                           `match[0..n_match)`.  Messages are modelled as 8-bit codes compared for
-                                           equality — exact for single-token messages like the reference test's
-                                           (task/mod.rs:964-982), not a substring search                     */
+                                           task/mod.rs:299): restart when the panic's message code is one of
+                                           `match[0..n_match)` — or, with madsim_workload_t.panic_match, when the node's
+                                           256-bit row has the code's bit set (the host evaluates `contains(pattern)` per code:
+                                           substring patterns against literal AND run-time formatted messages)            */
 #define MADSIM_PANIC_CODE_OTHER 255u
 #define MADSIM_NODE_NO_IP 2u /* create_node() without .ip(..): binds any address, cannot send to another node's IP
                                 (network.rs:281-283: "ip not set", no RNG draw)                              */
@@ -227,6 +248,17 @@ typedef struct madsim_workload {
     const madsim_prog_t* progs;  /* [n_progs]                                                        */
     const madsim_sock_t* socks;  /* [n_socks]                                                        */
     const madsim_insn_t* insns;  /* [n_insns]                                                        */
+    /* -- ABI v3 -- */
+    uint32_t n_services;         /* IPVS virtual services (<= MADSIM_MAX_SERVICES); their use selects the general-address build */
+    uint32_t panic_dyn_max;      /* largest message code a run-time formatted panic (MS_OP_PANIC a=1) may produce; 0 = 254.
+                                    A workload that also uses literal messages gives those the codes above it; a formatted value
+                                    beyond it yields MADSIM_OVERFLOW for the seed (never a silently different answer)          */
+    const madsim_service_t* services;   /* [n_services] or NULL                                                       */
+    const uint32_t* panic_match; /* NULL, or [n_nodes+1][8]: bit c of row n = "a panic whose message code is c restarts node n"
+                                    (NodeBuilder::restart_on_panic_matching, `error_msg.contains(pattern)` task/mod.rs:297-300,
+                                    evaluated by the host for every code: literal messages are interned as codes, a formatted
+                                    message is the decimal text of its code).  Rows of nodes without MADSIM_NODE_RESTART_MATCHING
+                                    are ignored.  NULL: the rows are built from madsim_node_t.match[] (equality on the code).   */
 } madsim_workload_t;
 
 /* ------------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@
 #ifndef MADSIM_HIP_HPP
 #define MADSIM_HIP_HPP
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -73,7 +74,8 @@ class Task {
     Task& spawn(const Task& t) { return emit(MS_OP_SPAWN, (uint8_t)t.index_); }
     Task& join(const Task& t, bool expect_err = false) { return emit(MS_OP_JOIN, (uint8_t)t.index_, expect_err ? 1 : 0); }
     Task& yield_now() { return emit(MS_OP_YIELD); }
-    Task& panic(uint8_t code = 0) { return emit(MS_OP_PANIC, 0, 0, code); }            // panic!() with message code `code`
+    Task& panic(uint8_t code = 0) { return emit(MS_OP_PANIC, 0, 0, code); }            // panic!("<code>"): the message is the decimal text of `code`
+    Task& panic(const std::string& message);                                           // panic!("<message>"): interned by WorkloadBuilder::build()
     Task& panic_with_flag(int flag, int32_t offset = 0) { return emit(MS_OP_PANIC, 1, (uint16_t)flag, (uint32_t)offset); }   // panic!("{}", flag + offset)
     Task& set(int reg, uint32_t v) { return emit(MS_OP_SET, (uint8_t)reg, 0, v); }
     Task& djnz(int reg, int target) { return emit(MS_OP_DJNZ, (uint8_t)reg, (uint16_t)target, 0, true); }
@@ -146,10 +148,10 @@ class Task {
 
   private:
     friend class WorkloadBuilder;
-    struct Ins { madsim_insn_t in; bool reloc; };
+    struct Ins { madsim_insn_t in; bool reloc; std::string text; };     // text: the literal message of a panic("..")
     Task(int index, int node, uint8_t flags) : index_(index), node_(node), flags_(flags) {}
     Task& emit(uint8_t op, uint8_t a = 0, uint16_t b = 0, uint32_t imm = 0, bool reloc = false) {
-        code_.push_back({madsim_insn_t{op, a, b, imm}, reloc});
+        code_.push_back({madsim_insn_t{op, a, b, imm}, reloc, std::string()});
         return *this;
     }
     Task& dur(uint8_t op, uint8_t a, std::chrono::nanoseconds d) {
@@ -167,9 +169,16 @@ struct Workload {
     std::vector<madsim_prog_t> progs;
     std::vector<madsim_sock_t> socks;
     std::vector<madsim_insn_t> insns;
+    std::vector<madsim_service_t> services;   // IPVS virtual services (net/ipvs.rs)
+    std::vector<uint32_t> panic_match;        // empty, or 8 words per node: which message codes restart it (madsim_workload_t.panic_match)
+    uint32_t panic_dyn_max = 0;
     madsim_workload_t raw() const {
-        return madsim_workload_t{(uint32_t)nodes.size() - 1, (uint32_t)progs.size(), (uint32_t)socks.size(),
-                                 (uint32_t)insns.size(), nodes.data(), progs.data(), socks.data(), insns.data()};
+        madsim_workload_t w{};
+        w.n_nodes = (uint32_t)nodes.size() - 1; w.n_progs = (uint32_t)progs.size(); w.n_socks = (uint32_t)socks.size();
+        w.n_insns = (uint32_t)insns.size(); w.nodes = nodes.data(); w.progs = progs.data(); w.socks = socks.data(); w.insns = insns.data();
+        w.n_services = (uint32_t)services.size(); w.services = services.empty() ? nullptr : services.data();
+        w.panic_dyn_max = panic_dyn_max; w.panic_match = panic_match.empty() ? nullptr : panic_match.data();
+        return w;
     }
 };
 
@@ -201,6 +210,26 @@ class WorkloadBuilder {
         for (size_t i = 0; i < restart_on_panic_matching.size(); i++) n.match[i] = restart_on_panic_matching[i];
         nodes_.push_back(n); return (int)nodes_.size() - 1;
     }
+    // ...restart_on_panic_matching("pattern")...: substrings of the panic message (`error_msg.contains(s)`, task/mod.rs:297-300),
+    // any number of them; build() evaluates them against every message code (literal messages, decimal texts of numbers)
+    int create_node_matching(std::vector<std::string> patterns, bool ip = true) {
+        madsim_node_t n{};
+        n.flags = (uint8_t)(MADSIM_NODE_RESTART_MATCHING | (ip ? 0 : MADSIM_NODE_NO_IP));
+        nodes_.push_back(n);
+        patterns_.resize(nodes_.size());
+        patterns_.back() = std::move(patterns);
+        return (int)nodes_.size() - 1;
+    }
+    // a virtual service address that belongs to no node ("1.1.1.<ip_id>:port"): a destination only
+    int virtual_addr(uint8_t ip_id, uint16_t port) { socks_.push_back(madsim_sock_t{ip_id, MADSIM_ADDR_VIRTUAL, port}); return (int)socks_.size() - 1; }
+    // ipvs.add_service(ServiceAddr::Tcp(vaddr), RoundRobin) + add_server per entry (net/ipvs.rs:50-85), before any task runs
+    void ipvs_service(int vaddr, const std::vector<int>& servers) {
+        if (services_.size() >= MADSIM_MAX_SERVICES || servers.size() > 6) throw std::length_error("at most 8 services of at most 6 servers");
+        madsim_service_t s{};
+        s.vaddr = (uint8_t)vaddr; s.n_servers = (uint8_t)servers.size();
+        for (size_t i = 0; i < servers.size(); i++) s.servers[i] = (uint8_t)servers[i];
+        services_.push_back(s);
+    }
     // 10.0.0.<node>:port, or 0.0.0.0:port / 127.0.0.1:port as used on `node` (kind = MADSIM_ADDR_*).  port 0 = an ephemeral
     // Endpoint (network.rs:224-236): each bind gets the node's lowest free port for that IP; not a destination operand.
     int addr(int node, uint16_t port, uint8_t kind = MADSIM_ADDR_IP) {
@@ -215,13 +244,36 @@ class WorkloadBuilder {
     }
     Workload build() {
         Workload w;
-        w.nodes = nodes_; w.socks = socks_;
+        w.nodes = nodes_; w.socks = socks_; w.services = services_;
+        // message codes: literal messages are interned from 254 downwards, a number is its decimal text; a node's row has bit c
+        // set when one of its patterns is a substring of the text of code c (the rule of madsim_amd/workload.py::_panic_rows)
+        std::vector<std::string> literals;
+        for (auto& t : tasks_) for (auto& i : t.code_) if (!i.text.empty() && std::find(literals.begin(), literals.end(), i.text) == literals.end()) literals.push_back(i.text);
+        std::sort(literals.begin(), literals.end());
+        if (literals.size() > 200) throw std::length_error("at most 200 distinct literal panic messages");
+        const uint32_t dyn_max = 254 - (uint32_t)literals.size();
+        auto text_of = [&](uint32_t c) { return c > dyn_max ? literals[254 - c] : std::to_string(c); };
+        bool any_patterns = false;
+        for (auto& p : patterns_) any_patterns |= !p.empty();
+        if (any_patterns || !literals.empty()) {
+            w.panic_dyn_max = dyn_max;
+            w.panic_match.assign(8 * nodes_.size(), 0);
+            for (size_t n = 0; n < patterns_.size(); n++)
+                for (uint32_t c = 0; c <= 254; c++)
+                    for (auto& p : patterns_[n]) if (text_of(c).find(p) != std::string::npos) w.panic_match[8 * n + (c >> 5)] |= 1u << (c & 31);
+            for (size_t n = 0; n < nodes_.size(); n++)          // numeric patterns given to create_node(): their decimal text
+                for (uint32_t k = 0; k < nodes_[n].n_match && k < 2; k++)
+                    for (uint32_t c = 0; c <= 254; c++)
+                        if (text_of(c).find(std::to_string(nodes_[n].match[k])) != std::string::npos) w.panic_match[8 * n + (c >> 5)] |= 1u << (c & 31);
+        }
         for (auto& t : tasks_) {
             uint16_t base = (uint16_t)w.insns.size();
             if (t.code_.empty() || (t.code_.back().in.op != MS_OP_DONE && t.code_.back().in.op != MS_OP_JMP)) t.done();
             w.progs.push_back(madsim_prog_t{(uint8_t)t.node_, t.flags_, base});
             for (auto& i : t.code_) {
                 madsim_insn_t in = i.in;
+                if (!i.text.empty()) in.imm = 254 - (uint32_t)(std::find(literals.begin(), literals.end(), i.text) - literals.begin());
+                else if (in.op == MS_OP_PANIC && in.a == 0 && in.imm > dyn_max) throw std::invalid_argument("numeric panic code collides with a literal message");
                 if (i.reloc) in.b = (uint16_t)(in.b + base);
                 w.insns.push_back(in);
             }
@@ -234,7 +286,15 @@ class WorkloadBuilder {
     std::vector<madsim_sock_t> socks_;
     std::vector<Task> tasks_;
     std::vector<std::string> payloads_, rpc_messages_;
+    std::vector<std::vector<std::string>> patterns_;      // per node: restart_on_panic_matching strings
+    std::vector<madsim_service_t> services_;
 };
+
+inline Task& Task::panic(const std::string& message) {
+    if (message.empty()) throw std::invalid_argument("empty panic message");
+    code_.push_back({madsim_insn_t{MS_OP_PANIC, 0, 0, 0}, false, message});
+    return *this;
+}
 
 namespace runtime {
 
@@ -311,13 +371,14 @@ struct Builder {
         madsim_summary_t s{};
         madsim::check(madsim_hip_run_batch_auto(&w, &cfg, seed, count, &lim, out.data(), &s, 6));   // runner verdicts are re-run
         if (s.n_failed) {
+            auto runner = [](uint32_t v) { return v == MADSIM_OVERFLOW || v == MADSIM_STEP_LIMIT; };
+            // a genuine test failure wins over unresolved runner limits: the first failing seed and its note are never hidden
+            for (uint64_t i = 0; i < count; i++)
+                if (out[i].verdict != MADSIM_PASS && !runner(out[i].verdict)) { panic_with_info(seed + i); throw SimulationFailure(seed + i, out[i]); }
             uint64_t i = 0;
-            while (out[i].verdict == MADSIM_PASS) i++;
+            while (!runner(out[i].verdict)) i++;
             // a capacity / step-cap verdict that survived the re-runs is the runner's limit, not the test's failure
-            if (out[i].verdict == MADSIM_OVERFLOW || out[i].verdict == MADSIM_STEP_LIMIT)
-                throw Error(MADSIM_E_LIMITS, "seed " + std::to_string(seed + i) + ": runner limit persists after re-runs with larger limits");
-            panic_with_info(seed + i);
-            throw SimulationFailure(seed + i, out[i]);
+            throw Error(MADSIM_E_LIMITS, "seed " + std::to_string(seed + i) + ": runner limit persists after re-runs with larger limits");
         }
         return out;
     }

@@ -24,7 +24,8 @@ class Prog(C.Structure):
     _fields_ = [("node", C.c_uint8), ("flags", C.c_uint8), ("entry", C.c_uint16)]
 
 
-ADDR_IP, ADDR_UNSPECIFIED, ADDR_LOOPBACK = 0, 1, 2
+ADDR_IP, ADDR_UNSPECIFIED, ADDR_LOOPBACK, ADDR_VIRTUAL = 0, 1, 2, 3
+MAX_SERVICES = 8
 VAL_ADDR_NOT_AVAILABLE, VAL_ADDR_IN_USE = 0xFFFFFFFC, 0xFFFFFFFB
 NODE_NO_IP = 2
 
@@ -37,12 +38,22 @@ class Node(C.Structure):
     _fields_ = [("flags", C.c_uint8), ("n_match", C.c_uint8), ("match", C.c_uint8 * 2)]
 
 
+class Service(C.Structure):
+    """madsim_service_t: one IPVS virtual service (net/ipvs.rs) — address entry + real servers in add_server order."""
+    _fields_ = [("vaddr", C.c_uint8), ("n_servers", C.c_uint8), ("servers", C.c_uint8 * 6)]
+
+
 class Workload(C.Structure):
     _fields_ = [
         ("n_nodes", C.c_uint32), ("n_progs", C.c_uint32), ("n_socks", C.c_uint32), ("n_insns", C.c_uint32),
         ("nodes", C.POINTER(Node)), ("progs", C.POINTER(Prog)), ("socks", C.POINTER(Sock)),
         ("insns", C.POINTER(Insn)),
+        ("n_services", C.c_uint32), ("panic_dyn_max", C.c_uint32), ("services", C.POINTER(Service)),
+        ("panic_match", C.POINTER(C.c_uint32)),
     ]
+
+
+HEADER_STRUCTS = {"madsim_service_t": Service}
 
 
 class Config(C.Structure):

@@ -94,9 +94,25 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
             return fail(err, MADSIM_E_WORKLOAD, "the instruction table must end in MS_OP_DONE, MS_OP_JMP or MS_OP_PANIC");
     }
     for (uint32_t i = 0; i < w->n_socks; i++)
-        if (w->socks[i].node == 0 || w->socks[i].node > w->n_nodes) return fail(err, MADSIM_E_WORKLOAD, "bad socket node");
-    for (uint32_t i = 0; i < w->n_socks; i++)
-        if (w->socks[i].kind > MADSIM_ADDR_LOOPBACK) return fail(err, MADSIM_E_WORKLOAD, "bad socket address (kind 0..2)");
+        if (w->socks[i].node == 0 || (w->socks[i].kind != MADSIM_ADDR_VIRTUAL && w->socks[i].node > w->n_nodes)) return fail(err, MADSIM_E_WORKLOAD, "bad socket node");
+    for (uint32_t i = 0; i < w->n_socks; i++) {
+        if (w->socks[i].kind > MADSIM_ADDR_VIRTUAL) return fail(err, MADSIM_E_WORKLOAD, "bad socket address (kind 0..3)");
+        if (w->socks[i].kind == MADSIM_ADDR_VIRTUAL && w->socks[i].port == 0) return fail(err, MADSIM_E_WORKLOAD, "a virtual address needs a port");
+    }
+    if (w->n_services > MADSIM_MAX_SERVICES || (w->n_services && !w->services)) return fail(err, MADSIM_E_WORKLOAD, "at most 8 IPVS services");
+    for (uint32_t k = 0; k < w->n_services; k++) {
+        const madsim_service_t& sv = w->services[k];
+        if (sv.vaddr >= w->n_socks || sv.n_servers > 6) return fail(err, MADSIM_E_WORKLOAD, "IPVS service: bad address entry or more than 6 servers");
+        if (w->socks[sv.vaddr].port == 0) return fail(err, MADSIM_E_WORKLOAD, "IPVS service: the service address needs a port");
+        for (uint32_t j = 0; j < sv.n_servers; j++)
+            if (sv.servers[j] >= w->n_socks || w->socks[sv.servers[j]].port == 0) return fail(err, MADSIM_E_WORKLOAD, "IPVS service: a server must be a named address entry");
+        for (uint32_t j = 0; j < k; j++) {               // a HashMap keyed by the address: one service per address
+            const madsim_sock_t &x = w->socks[sv.vaddr], &y = w->socks[w->services[j].vaddr];
+            if (x.kind == y.kind && x.port == y.port && ((x.kind != MADSIM_ADDR_IP && x.kind != MADSIM_ADDR_VIRTUAL) || x.node == y.node))
+                return fail(err, MADSIM_E_WORKLOAD, "IPVS service: two services with one address");
+        }
+    }
+    if (w->panic_dyn_max > 254) return fail(err, MADSIM_E_WORKLOAD, "panic_dyn_max must be <= 254");
     if (device_socks(w).size() > 63) return fail(err, MADSIM_E_WORKLOAD, "at most 63 socket addresses, counting the candidate ports of ephemeral endpoints");
     for (uint32_t i = 0; i < w->n_insns; i++) {
         const madsim_insn_t& in = w->insns[i];
@@ -107,11 +123,14 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
             if (in.b >= w->n_insns) return fail(err, MADSIM_E_WORKLOAD, "jump target out of range"); break;
         case MS_OP_BIND: case MS_OP_REPLY: case MS_OP_RECV: case MS_OP_CLOSE: case MS_OP_RECV_TIMEOUT: case MS_OP_ACCEPT:
             if (in.a >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range");
+            // (the reference would let an IP-less node bind it and answer AddrNotAvailable to every other: not modelled, refused)
+            if (w->socks[in.a].kind == MADSIM_ADDR_VIRTUAL) return fail(err, MADSIM_E_WORKLOAD, "a virtual address is a destination only: it cannot be bound or used as an Endpoint");
             if ((in.op == MS_OP_REPLY || in.op == MS_OP_RECV || in.op == MS_OP_RECV_TIMEOUT) && (in.b >> 8) > MADSIM_TAG_RPC_LAST)
                 return fail(err, MADSIM_E_WORKLOAD, "tags 0xFE and 0xFF are reserved");
             break;
         case MS_OP_SEND: case MS_OP_CONNECT:
             if (in.a >= w->n_socks || (uint32_t)(in.b & 0xff) >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range");
+            if (w->socks[in.a].kind == MADSIM_ADDR_VIRTUAL) return fail(err, MADSIM_E_WORKLOAD, "a virtual address is never an Endpoint");
             if (in.op == MS_OP_SEND && (in.b >> 8) > MADSIM_TAG_RPC_LAST) return fail(err, MADSIM_E_WORKLOAD, "tags 0xFE and 0xFF are reserved");
             if (w->socks[in.b & 0xff].port == 0) return fail(err, MADSIM_E_WORKLOAD, "an ephemeral Endpoint (port 0) has no address a peer can name: reply to `from` or dial a named entry");
             break;
@@ -196,11 +215,24 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // its node and to its own table entry, and the kernel skips the general resolution of network.rs:272-313
     P.uniq_addr = 1;
     for (uint32_t i = 0; i < w->n_socks; i++) {
-        if (w->socks[i].kind != MADSIM_ADDR_IP || w->socks[i].port == 0) P.uniq_addr = 0;
+        if (w->socks[i].kind != MADSIM_ADDR_IP || w->socks[i].port == 0) P.uniq_addr = 0;      // (virtual addresses included)
         for (uint32_t j = i + 1; j < w->n_socks; j++)
             if (w->socks[i].node == w->socks[j].node && w->socks[i].port == w->socks[j].port) P.uniq_addr = 0;
     }
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) if (w->nodes[i].flags & MADSIM_NODE_NO_IP) P.uniq_addr = 0;
+    if (w->n_services) P.uniq_addr = 0;                // IPVS rewrites destinations: general address resolution
+    // the node table: a flags word per node, then the restart rows (when a node restarts on matching panics), then the services
+    {
+        bool rows = false;
+        for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) rows |= (w->nodes[i].flags & MADSIM_NODE_RESTART_MATCHING) != 0;
+        P.n_nodetab = w->n_nodes + 1;
+        P.pm_off = rows ? P.n_nodetab : 0;
+        if (rows) P.n_nodetab += 8 * (w->n_nodes + 1);
+        P.n_services = w->n_services;
+        P.svc_off = w->n_services ? P.n_nodetab : 0;
+        P.n_nodetab += 2 * w->n_services;
+        P.panic_dyn_max = w->panic_dyn_max ? w->panic_dyn_max : 254u;
+    }
     // ---- which optional per-seed regions exist (LDS diet: a workload only carries what it can touch) ----
     P.restart_nodes = 0;
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
@@ -252,7 +284,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         for (uint32_t i = 0; i < w->n_insns; i++) gregs |= w->insns[i].op == MS_OP_PANIC && (w->insns[i].a & 1);   // panic!("{}", flag)
         P.off_conn = P.off_greg + (gregs ? 4 : 0);
         P.off_hooks = P.off_conn + (P.uses_chan ? P.max_conns * P.conn_words : 0);
-        P.lane_words = P.off_hooks + (P.uses_hooks ? P.n_nodes + 1 : 0);
+        P.off_ipvs = P.off_hooks + (P.uses_hooks ? P.n_nodes + 1 : 0);
+        P.lane_words = P.off_ipvs + P.n_services;
         if (P.gstate_mode) {           // the planes just laid out go to the global block; LDS keeps the ready queue only
             P.gs_plane_words = P.lane_words;
             P.gs_planes = P.max_tasks * P.task_units * 16;
@@ -265,7 +298,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         P.sh_progs = P.sh_insns + 4 * P.n_insns;
         P.sh_socks = P.sh_progs + P.n_progs;
         P.sh_nodes = P.sh_socks + P.n_socks;
-        P.sh_heap = (P.sh_nodes + P.n_nodes + 1 + 3) & ~3u;
+        P.sh_heap = (P.sh_nodes + P.n_nodetab + 3) & ~3u;
         sh_bytes = P.sh_heap * 4;
         G->lds_per_seed = P.heap_lds * heap_bytes + (P.gstate_mode ? 0 : P.max_tasks * task_bytes) + P.lane_words * 4;
         if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu && (L.state_mem == MADSIM_STATE_LDS || !P.lifecycle || trace || P.gstate_mode)) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
@@ -393,10 +426,28 @@ inline int build_tables(const madsim_workload_t* w, DeviceTables* T, std::string
         T->insns[4 * i + 3] = flags | ((j & 0x3fffu) << 4) | ((target & 0x3fffu) << 18);
     }
     for (uint32_t i = 0; i < w->n_progs; i++) T->progs[i] = (uint32_t)w->progs[i].node | ((uint32_t)w->progs[i].flags << 8) | ((uint32_t)w->progs[i].entry << 16);
+    // node table (sim_kernel.h KParams::nodes): flags words, restart rows, services — the layout make_geometry announced
     T->nodes.assign(w->n_nodes + 1, 0);
-    for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++)
-        T->nodes[i] = (uint32_t)w->nodes[i].flags | ((uint32_t)(w->nodes[i].n_match > 2 ? 2 : w->nodes[i].n_match) << 8) |
-                      ((uint32_t)w->nodes[i].match[0] << 16) | ((uint32_t)w->nodes[i].match[1] << 24);
+    bool rows = false;
+    for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) { T->nodes[i] = (uint32_t)w->nodes[i].flags; rows |= (w->nodes[i].flags & MADSIM_NODE_RESTART_MATCHING) != 0; }
+    if (rows) {
+        // bit c of row n: a panic with message code c restarts node n.  The caller's rows (madsim_workload_t.panic_match), or
+        // equality on madsim_node_t.match[]; code 255 (failed asserts, unwraps: a message no pattern names) never matches.
+        for (uint32_t i = 0; i <= w->n_nodes; i++) {
+            uint32_t row[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (w->nodes[i].flags & MADSIM_NODE_RESTART_MATCHING) {
+                if (w->panic_match) for (int k = 0; k < 8; k++) row[k] = w->panic_match[8 * i + k];
+                else for (uint32_t k = 0; k < w->nodes[i].n_match && k < 2; k++) row[w->nodes[i].match[k] >> 5] |= 1u << (w->nodes[i].match[k] & 31);
+                row[7] &= 0x7fffffffu;
+            }
+            T->nodes.insert(T->nodes.end(), row, row + 8);
+        }
+    }
+    for (uint32_t k = 0; k < w->n_services; k++) {
+        const madsim_service_t& sv = w->services[k];
+        T->nodes.push_back((uint32_t)sv.vaddr | ((uint32_t)sv.n_servers << 8) | ((uint32_t)sv.servers[0] << 16) | ((uint32_t)sv.servers[1] << 24));
+        T->nodes.push_back((uint32_t)sv.servers[2] | ((uint32_t)sv.servers[3] << 8) | ((uint32_t)sv.servers[4] << 16) | ((uint32_t)sv.servers[5] << 24));
+    }
     return 0;
 }
 

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : M
     for (uint32_t i = cp0; i < P.n_insns * 4; i += cps) sh[P.sh_insns + i] = ((const uint32_t*)P.insns)[i];
     for (uint32_t i = cp0; i < P.n_progs; i += cps) sh[P.sh_progs + i] = P.progs[i];
     for (uint32_t i = cp0; i < P.n_socks; i += cps) sh[P.sh_socks + i] = P.socks[i];
-    for (uint32_t i = cp0; i <= P.n_nodes; i += cps) sh[P.sh_nodes + i] = P.nodes[i];
+    for (uint32_t i = cp0; i < P.n_nodetab; i += cps) sh[P.sh_nodes + i] = P.nodes[i];
     __syncthreads();
 
     Ctx c(P);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : M
         c.task0 = 0;
         c.sock0 = P.gs_planes + P.off_socks * 4; c.hand0 = P.gs_planes + P.off_handles * 4; c.node0 = P.gs_planes + P.off_nodes * 4;
         c.clog0 = P.gs_planes + P.off_clog * 4; c.pause0 = P.gs_planes + P.off_pause * 4; c.greg0 = P.gs_planes + P.off_greg * 4;
-        c.conn0 = P.gs_planes + P.off_conn * 4; c.hook0 = P.gs_planes + P.off_hooks * 4;
+        c.conn0 = P.gs_planes + P.off_conn * 4; c.hook0 = P.gs_planes + P.off_hooks * 4; c.ipvs0 = P.gs_planes + P.off_ipvs * 4;
     } else {
         c.task0 = (P.sh_tasks + wbase) / 4 + lane;
         c.task1 = (P.sh_tasks + wbase + ((P.max_tasks * 4) << P.lw_shift)) / 2 + lane;      // base-op builds: behind the unit0 array
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256, !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : M
         c.greg0 = pl + (P.off_greg << P.lw_shift);
         c.conn0 = pl + (P.off_conn << P.lw_shift);
         c.hook0 = pl + (P.off_hooks << P.lw_shift);
+        c.ipvs0 = pl + (P.off_ipvs << P.lw_shift);
     }
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
     const uint32_t glane = ((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane;
@@ -161,9 +162,10 @@ __global__ __launch_bounds__(256, !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : M
             if (K::FN && panicked && P.has_restart_on_panic) {   // task/mod.rs:289-314
                 uint32_t node = PROGW(c, u0.x >> 24) & 0xff;
                 // restart_on_panic || restart_on_panic_matching.iter().any(|s| error_msg.contains(s)) (task/mod.rs:297-300)
-                const uint32_t nw = NODET(c, node), nm = (nw >> 8) & 0xff;
+                // (the host evaluated `contains` for every message code: one bit of the node's 256-bit row, geometry.h build_tables)
+                const uint32_t nw = NODET(c, node);
                 const bool matches = (nw & MADSIM_NODE_RESTART_MATCHING) &&
-                                     ((nm >= 1 && ((nw >> 16) & 0xff) == L.panic_code) || (nm >= 2 && (nw >> 24) == L.panic_code));
+                                     ((SMEM[c.nodet0 + P.pm_off + node * 8 + (L.panic_code >> 5)] >> (L.panic_code & 31)) & 1);
                 if ((nw & MADSIM_NODE_RESTART_ON_PANIC) || matches) {
                     // async-task's panic guard already dropped the future and notified the awaiter
                     TU(c, slot, 0) = u0;

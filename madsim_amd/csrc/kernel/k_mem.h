@@ -63,6 +63,24 @@ __device__ __forceinline__ uint64_t add64_1(uint64_t a, uint64_t b) {
     return r;
 }
 
+// x << K_ as ONE v_lshlrev_b64 (half rate, 4.3 cycles): left alone the compiler splits a 64-bit shift by a constant into
+// v_lshlrev_b32 + v_alignbit_b32 — two half-rate instructions (tools/ubench_issue.hip: only add / sub / xor / mov / bitop3 are
+// full rate on gfx950, every shift is half rate whatever its width)
+template <int K_>
+__device__ __forceinline__ uint64_t shl64(uint64_t x) {
+    uint64_t r;
+    asm("v_lshlrev_b64 %0, %1, %2" : "=v"(r) : "n"(K_), "v"(x));
+    return r;
+}
+
+// (v << K_) + v as ONE v_lshl_add_u64: the low 64 bits of v * (2^K_ + 1), K_ <= 4
+template <int K_>
+__device__ __forceinline__ uint64_t mul_pow2p1(uint64_t v) {
+    uint64_t p;
+    asm("v_lshl_add_u64 %0, %1, %2, %1" : "=v"(p) : "v"(v), "n"(K_));
+    return p;
+}
+
 // the threads of a workgroup share the copy of the workload tables into LDS: thread t copies words t, t + stride, ...
 __device__ __forceinline__ uint32_t table_copy_first() { return threadIdx.x; }
 __device__ __forceinline__ uint32_t table_copy_stride(uint32_t waves_per_block) { return 64 * waves_per_block; }

@@ -34,7 +34,8 @@ __device__ __forceinline__ uint32_t addr_of_from(const Ctx& c, uint32_t from) { 
     return w | (((from & 0x40) ? MADSIM_ADDR_LOOPBACK : MADSIM_ADDR_IP) << 8);    // or 127.0.0.1 (network.rs:307-311)
 }
 __device__ __forceinline__ bool addr_eq(uint32_t x, uint32_t y) {                 // SocketAddr equality
-    return ((x ^ y) & 0xffffff00u) == 0 && ((x & 0xff00u) != (MADSIM_ADDR_IP << 8) || ((x ^ y) & 0xffu) == 0);
+    const uint32_t kind = (x >> 8) & 0xff;                                         // (0.0.0.0 and 127.0.0.1 are the same address on every node)
+    return ((x ^ y) & 0xffffff00u) == 0 && ((kind != MADSIM_ADDR_IP && kind != MADSIM_ADDR_VIRTUAL) || ((x ^ y) & 0xffu) == 0);
 }
 __device__ __forceinline__ bool node_has_ip(const Ctx& c, uint32_t node) { return !(NODET(c, node) & MADSIM_NODE_NO_IP); }
 
@@ -61,6 +62,29 @@ __device__ __forceinline__ int resolve_dest_node(const Ctx& c, uint32_t node, ui
     if (!node_has_ip(c, node)) return -1;                                          // "ip not set"
     if (kind == MADSIM_ADDR_IP && an >= 1 && an <= c.P.n_nodes && node_has_ip(c, an)) return (int)an;   // addr_to_node
     return -1;                                                                     // "destination not found"
+}
+
+// `if let Some(addr) = ipvs.get_server(dst) { dst = addr }` of NetSim::send / connect1 (net/mod.rs:312-317,345-350) with
+// IpVirtualServer::get_server (net/ipvs.rs:88-105): the service whose address equals `addr`; no servers -> no rewrite;
+// `if *i >= len { *i = 0 }; server = servers[*i]; *i += 1`.  `idx` = the table entry `addr` came from, rewritten with it.
+template <class K>
+__device__ __forceinline__ void ipvs_rewrite(const Ctx& c, uint32_t& idx, uint32_t& addr) {
+    if (!K::FA || !c.P.n_services) return;
+    bool found = false;
+    for (uint32_t k = 0; k < c.P.n_services && !found; k++) {
+        const uint32_t w0 = SMEM[c.nodet0 + c.P.svc_off + 2 * k], w1 = SMEM[c.nodet0 + c.P.svc_off + 2 * k + 1];
+        if (addr_eq(SOCKW(c, w0 & 0xff), addr)) {
+            found = true;
+            const uint32_t n = (w0 >> 8) & 0xff;
+            if (n) {
+                uint32_t i = IPVSW(k);
+                if (i >= n) i = 0;
+                IPVSW(k) = i + 1;
+                const uint32_t lo = w0 >> 16, srv = i < 2 ? (lo >> (8 * i)) & 0xff : (w1 >> (8 * (i - 2))) & 0xff;
+                idx = srv; addr = SOCKW(c, srv);
+            }
+        }
+    }
 }
 
 // Mailbox::deliver (endpoint.rs:331-351)

@@ -131,8 +131,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     const uint32_t hw = HOOKW(SOCKW(c, ca) & 0xff);
                     hooked = (hw & 1) && ((hw >> 10) & 0xff) == (cb >> 8) && ((hw & 2) || ((hw >> 2) & 0xff) == (cimm & 0xff));
                 }
-                uint32_t lb = 0;
-                const int sent = hooked ? 0 : net_try_send<K>(c, L, SOCKW(c, ca) & 0xff, SOCKW(c, dst), dst, &lat, &ds, &lb);
+                uint32_t lb = 0, to_idx = dst, to_addr = SOCKW(c, dst);
+                if (!hooked) ipvs_rewrite<K>(c, to_idx, to_addr);          // after the hook, before try_send (net/mod.rs:312-317)
+                const int sent = hooked ? 0 : net_try_send<K>(c, L, SOCKW(c, ca) & 0xff, to_addr, to_idx, &lat, &ds, &lb);
                 if (sent < 0) { st = ST_PANIC; return true; }
                 if (sent) {
                     uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
@@ -272,7 +273,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
                     if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
                     uint64_t lat; int ds; uint32_t lb;
-                    const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, SOCKW(c, b & 0xff), b & 0xff, &lat, &ds, &lb);
+                    uint32_t dial = b & 0xff, dial_addr = SOCKW(c, dial);
+                    ipvs_rewrite<K>(c, dial, dial_addr);          // channel() below is built from the rewritten dst (net/mod.rs:345-357)
+                    const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dial_addr, dial, &lat, &ds, &lb);
                     if (sent < 0) st = ST_PANIC;
                     else if (!sent) {
                         u0.w = MADSIM_VAL_REFUSED;
@@ -283,7 +286,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         uint64_t q = acceptq_load<K>(c, (uint32_t)ds);
                         if (id >= P.max_conns || ((uint32_t)q & 0xf) >= MADSIM_ACCEPTQ) { L.ovf = 1; }
                         else {
-                            CONNW(id, 0) = 1u | (a << 1) | ((b & 0xff) << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
+                            CONNW(id, 0) = 1u | (a << 1) | (dial << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
                             TWORD(c, slot, c.P.chan_unit, 0) = id;             // client side
                             guard_acquire<K>(c, L, a);             // Sender / Receiver { _guard: self.guard.clone(), .. } (endpoint.rs:181-190)
@@ -330,8 +333,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 } else if (op == MS_OP_SEND || op == MS_OP_REPLY || (K::FR && op == MS_OP_RPC_REPLY)) {   // net/mod.rs:307-331
                     REG(6);
                     // the destination: the operand's table entry, or the address the request came from (`from`)
-                    const uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : (from & 0x3f);
-                    const uint32_t dst_addr = (op == MS_OP_SEND || PLAIN_ADDR) ? SOCKW(c, dst) : addr_of_from(c, from);
+                    uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : (from & 0x3f);
+                    uint32_t dst_addr = (op == MS_OP_SEND || PLAIN_ADDR) ? SOCKW(c, dst) : addr_of_from(c, from);
+                    ipvs_rewrite<K>(c, dst, dst_addr);
                     if (K::FR && op == MS_OP_RPC_REPLY) {    // send_to_raw(from, rsp_tag, rsp): rpc.rs:172-175
                         b = 0xff00;
                         imm = (imm & 0xff) | (TWORD(c, slot, P.rpc_unit, 0) << 8);
@@ -604,7 +608,14 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 pc++;
                 break;
             case MS_OP_PANIC:                               // its message code: what restart_on_panic_matching compares
-                if (K::FN) L.panic_code = ((a & 1) ? (uint32_t)GREGW(b & 3) + imm : imm) & 0xff;
+                if (K::FN) {
+                    uint32_t code = imm & 0xff;
+                    if (a & 1) {       // panic!("{}", flag + imm): the message is the decimal text of the value, and the nodes' rows were
+                        code = (uint32_t)GREGW(b & 3) + imm;     // evaluated for values up to panic_dyn_max only
+                        if (code > P.panic_dyn_max) { L.ovf = 1; code = MADSIM_PANIC_CODE_OTHER; }
+                    }
+                    L.panic_code = code;
+                }
                 st = ST_PANIC;
                 break;
             case MS_OP_ABORT: {                            // AbortHandle::abort (task/join.rs:158-163)

@@ -6,24 +6,36 @@
 namespace madsim_k {
 
 // ---- GlobalRng ---------------------------------------------------------------------------------
-// Xoshiro256PlusPlus::next_u64 [DEP rand_xoshiro 0.6]
-__device__ __forceinline__ uint64_t rng_next(Lane& L) {
+// Xoshiro256PlusPlus::next_u64 [DEP rand_xoshiro 0.6] without the call counter (rng_next below counts; the rejection loops
+// count their trips in a 32-bit register — a full-rate v_add_u32 per trip — and add once per draw)
+__device__ __forceinline__ uint64_t rng_step(Lane& L) {
     uint64_t r = add64_1(rotl64<23>(L.s0 + L.s3), L.s0);
     // s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= s1 << 17 with the two three-input xors as one v_bitop3_b32 per half
-    const uint64_t t = L.s1 << 17;
+    const uint64_t t = shl64<17>(L.s1);
     const uint64_t d1 = L.s3 ^ L.s1;
     const uint64_t b1 = xor3_64(L.s1, L.s2, L.s0);
     const uint64_t c2 = xor3_64(L.s2, L.s0, t);
     L.s0 ^= d1; L.s1 = b1; L.s2 = c2;
     L.s3 = rotl64<45>(d1);
-    L.rng_calls++;
     return r;
+}
+__device__ __forceinline__ uint64_t rng_next(Lane& L) {
+    L.rng_calls++;
+    return rng_step(L);
 }
 
 // rand 0.8's accept test `lo64(v * range) <= zone` for a range below 2^32: zone = (range << lz) - 1 has its low word all
 // ones, so only the high word of the low 64 product bits is compared: (v.hi * range + mulhi(v.lo, range)) mod 2^32.
 __device__ __forceinline__ bool reject32(uint64_t v, uint32_t range, uint32_t zone_hi) {
     return (uint32_t)(v >> 32) * range + __umulhi((uint32_t)v, range) > zone_hi;
+}
+// ... and for a compile-time range of the form 2^k + 1 (k <= 4) the low 64 product bits are ONE v_lshl_add_u64, (v << k) + v,
+// instead of a v_mul_hi_u32 and a v_mad_u64_u32: NetSim::rand_delay's gen_range(0..5) runs ~5 trips per executor iteration
+template <uint32_t RANGE>
+__device__ __forceinline__ bool reject_const(uint64_t v, uint32_t zone_hi) {
+    if (RANGE == 3 || RANGE == 5 || RANGE == 9 || RANGE == 17)
+        return (uint32_t)(mul_pow2p1<RANGE == 3 ? 1 : RANGE == 5 ? 2 : RANGE == 9 ? 3 : 4>(v) >> 32) > zone_hi;
+    return reject32(v, RANGE, zone_hi);
 }
 
 // One determinism-log byte per GlobalRng::with (rand.rs:64-88): clone.gen::<u8>() ^ xor-fold(elapsed).
@@ -54,8 +66,10 @@ __device__ __forceinline__ uint64_t gen_range_u64(const Ctx& c, Lane& L, uint64_
 template <class K>
 __device__ __forceinline__ uint32_t gen_index(const Ctx& c, Lane& L, uint32_t len) {
     uint64_t v;
+    uint32_t trips = 0;
     const uint32_t zone_hi = (len << (__builtin_clz(len))) - 1;
-    do { REG(1); v = rng_next(L); } while (EXP_ACCEPT(reject32(v, len, zone_hi)));
+    do { REG(1); v = rng_step(L); trips++; } while (EXP_ACCEPT(reject32(v, len, zone_hi)));
+    L.rng_calls += trips;
     rng_log<K>(c, L);
     uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * len + (((uint64_t)(uint32_t)v * len) >> 32);
     return (uint32_t)(mid >> 32);                               // high 64 bits of v * len
@@ -67,7 +81,9 @@ __device__ __forceinline__ uint32_t gen_range_small(const Ctx& c, Lane& L) {
     constexpr uint64_t zone = ((uint64_t)RANGE << __builtin_clzll((uint64_t)RANGE)) - 1;
     static_assert((uint32_t)zone == 0xffffffffu, "reject32 compares the high word only");
     uint64_t v;
-    do { REG(RANGE == 50 ? 18 : 16); v = rng_next(L); } while (EXP_ACCEPT(reject32(v, RANGE, (uint32_t)(zone >> 32))));
+    uint32_t trips = 0;
+    do { REG(RANGE == 50 ? 18 : 16); v = rng_step(L); trips++; } while (EXP_ACCEPT(reject_const<RANGE>(v, (uint32_t)(zone >> 32))));
+    L.rng_calls += trips;
     rng_log<K>(c, L);
     uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * RANGE + (((uint64_t)(uint32_t)v * RANGE) >> 32);
     return (uint32_t)(mid >> 32);

@@ -112,7 +112,7 @@ struct Lane {
 struct Ctx {
     const KParams& P;
     uint32_t lws;        // log2(lane stride) (runtime copy; K::LWS overrides when >= 0)
-    uint32_t ready0, hand0, node0, clog0, pause0, greg0, conn0, hook0;   // word indices of this lane's plane regions
+    uint32_t ready0, hand0, node0, clog0, pause0, greg0, conn0, hook0, ipvs0;   // word indices of this lane's plane regions
     uint32_t sock0;      // word index of this lane's socket region
     uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + (i << lws)); base-op builds: uint2 index
     uint32_t heapm0;     // base-op builds: word index of the meta word of heap entry 0 (k_timer.h)
@@ -218,6 +218,8 @@ template <class K> __device__ __forceinline__ WRef<K::G> plane_ref(const Ctx& c,
 // NetSim message hooks of node n (net/mod.rs:250-284): request hook valid:1 | all:1<<1 | code:8<<2 | tag:8<<10,
 //                                                      response hook valid:1<<18 | all:1<<19 | code:8<<20
 #define HOOKW(n_) plane_ref<K>(c, c.hook0, (n_))
+// round-robin counter of IPVS service k (net/ipvs.rs Service::rr_index)
+#define IPVSW(k_) plane_ref<K>(c, c.ipvs0, (k_))
 // connection id_: [0] alive:1 | c_ep:6<<1 | d_ep:6<<7 (the address dialled) | tx0:1<<13 rx0<<14 tx1<<15 rx1<<16 | qn0:4<<17 | qn1:4<<21
 //                 [1 + dir] parked receiver: valid:1 | slot:8<<1 | gen:16<<9;  [3 + (dir * Q + i) * 3 ..] {val, arrive lo, arrive hi}
 #define CONNW(id_, f_) plane_ref<K>(c, c.conn0, (id_) * c.P.conn_words + (f_))
@@ -289,7 +291,7 @@ template <class K> __device__ __forceinline__ uint32_t sock_resolve(const Ctx& c
     const uint32_t w = SOCKW(c, s);
     return (w & 0x8000u) ? ((w >> 16) & 0xff) + (SW(c, s, 0) >> 25) : s;
 }
-__device__ __forceinline__ uint32_t NODET(const Ctx& c, uint32_t n) { return SMEM[c.nodet0 + n]; }   // flags | n_match<<8 | match0<<16 | match1<<24
+__device__ __forceinline__ uint32_t NODET(const Ctx& c, uint32_t n) { return SMEM[c.nodet0 + n]; }   // the node's flags (MADSIM_NODE_*)
 
 __device__ __forceinline__ uint64_t u64of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 

@@ -24,7 +24,9 @@ struct KParams {
     const uint4*    insns;     // {op|a<<8|b<<16, imm, fused assert value, fused post-chain word} (geometry.h build_tables)
     const uint32_t* progs;     // node | flags<<8 | entry<<16
     const uint32_t* socks;     // node | kind<<8 | port<<16 (a SocketAddr as one word)
-    const uint32_t* nodes;     // per node: flags | n_match<<8 | match[0]<<16 | match[1]<<24 (madsim_node_t as one word)
+    const uint32_t* nodes;     // n_nodetab words: per node its flags word; then (pm_off != 0) 8 words per node: the 256-bit row "a panic
+                               // with message code c restarts this node"; then (n_services != 0) 2 words per IPVS service:
+                               // vaddr | n_servers<<8 | servers[0]<<16 | servers[1]<<24, servers[2..5]
     const uint64_t* dur_table; // per MS_OP_SLEEP_RAND (its `a` is rewritten to an index): {mode, low, range, zone}
     uint32_t n_insns, n_progs, n_socks, n_nodes;
     // net config (Bernoulli p_int, UniformDuration parameters precomputed on the host)
@@ -45,6 +47,9 @@ struct KParams {
     uint32_t waves_per_block, wave_words;
     // per-lane plane offsets (in words)
     uint32_t off_ready, off_socks, off_handles, off_nodes, off_clog, off_pause, off_greg, off_conn, off_hooks;
+    uint32_t n_nodetab, pm_off, svc_off, n_services;   // layout of the node table (word offsets from its start; 0 = absent)
+    uint32_t panic_dyn_max;    // largest code a run-time formatted panic message may have (madsim_workload_t.panic_dyn_max)
+    uint32_t off_ipvs;         // per-seed plane: one round-robin counter per IPVS service (net/ipvs.rs rr_index)
     uint32_t uses_eph;         // ephemeral Endpoint handles in the socket table (geometry.h device_socks)
     uint32_t uses_hooks;       // MS_OP_HOOK_REQ / MS_OP_HOOK_RSP present: one hook word per node
     uint32_t uses_chan, max_conns, chan_queue, conn_words;   // reliable channel (connect1/accept1) state, if used

@@ -259,13 +259,18 @@ class TaskBuilder:
 class BuiltWorkload:
     """Owns the ctypes arrays a `madsim_workload_t` points into."""
 
-    def __init__(self, nodes, progs, socks, insns):
+    def __init__(self, nodes, progs, socks, insns, services=(), panic_match=None, panic_dyn_max=0):
         self.nodes = (A.Node * len(nodes))(*nodes)
         self.progs = (A.Prog * len(progs))(*progs)
         self.socks = (A.Sock * max(1, len(socks)))(*socks)
         self.insns = (A.Insn * len(insns))(*insns)
+        self.services = (A.Service * max(1, len(services)))(*services)
+        # rows of 8 words per node: bit c = "a panic with message code c restarts the node" (madsim_workload_t.panic_match)
+        self.panic_match = (C.c_uint32 * (8 * len(nodes)))(*panic_match) if panic_match is not None else None
         self.struct = A.Workload(len(nodes) - 1, len(progs), len(socks), len(insns), self.nodes, self.progs,
-                                 self.socks, self.insns)
+                                 self.socks, self.insns, len(services), panic_dyn_max,
+                                 self.services if services else None,
+                                 self.panic_match if panic_match is not None else None)
 
     def ref(self):
         return C.byref(self.struct)
@@ -281,8 +286,9 @@ class WorkloadBuilder:
         self.tasks = [TaskBuilder(self, 0, 0)]
         self.payloads = []       # interned byte strings: see payload()
         self.rpc_messages = []   # interned typed-RPC (message, data) pairs: see rpc_message()
-        self.panic_texts = []    # literal panic messages (TaskBuilder.panic("..")) and, per node, string patterns
-        self.panic_patterns = {}
+        self.panic_texts = []    # literal panic messages (TaskBuilder.panic(".."))
+        self.panic_patterns = {} # node -> its restart_on_panic_matching patterns, as strings
+        self.services = []       # IPVS virtual services: see ipvs_service()
 
     def payload(self, data: bytes):
         """The 32-bit value standing for the byte string `data` on the wire.  Payload bytes never steer the simulation
@@ -328,17 +334,15 @@ class WorkloadBuilder:
         ip=False: the node has no address — it can bind anything, but cannot reach other nodes (network.rs:281-283)."""
         n = A.Node()
         n.flags = (A.NODE_RESTART_ON_PANIC if restart_on_panic else 0) | (0 if ip else A.NODE_NO_IP)
-        if restart_on_panic_matching and all(isinstance(p, str) for p in restart_on_panic_matching):
-            # string patterns, any number of them: resolved against the workload's literal panic messages in build()
-            self.panic_patterns[len(self.nodes)] = tuple(restart_on_panic_matching)
+        if restart_on_panic_matching:
+            # Patterns are substrings of the panic message (`error_msg.contains(s)`, task/mod.rs:297-300).  A number stands for
+            # its decimal text — the reference's own test panics with `panic!("{}", n)` and matches "0" and "1" — so any
+            # number of patterns, strings and numbers alike; build() evaluates them against every message code.
+            pats = tuple(p if isinstance(p, str) else str(int(p)) for p in restart_on_panic_matching)
+            if any(p == "" for p in pats):
+                raise ValueError("an empty pattern matches every message: use restart_on_panic")
+            self.panic_patterns[len(self.nodes)] = pats
             n.flags |= A.NODE_RESTART_MATCHING
-        elif restart_on_panic_matching:
-            if len(restart_on_panic_matching) > 2 or any(not 0 <= c <= 254 for c in restart_on_panic_matching):
-                raise ValueError("at most two patterns, message codes 0..254")
-            n.flags |= A.NODE_RESTART_MATCHING
-            n.n_match = len(restart_on_panic_matching)
-            for i, c in enumerate(restart_on_panic_matching):
-                n.match[i] = c
         self.nodes.append(n)
         return len(self.nodes) - 1
 
@@ -354,6 +358,27 @@ class WorkloadBuilder:
         self.socks.append(A.Sock(node, kind, port))
         return len(self.socks) - 1
 
+    def virtual_addr(self, ip_id, port):
+        """A virtual service address that belongs to no node ("1.1.1.<ip_id>:<port>"): a destination only.  Without an IPVS
+        service a datagram sent there is dropped before any draw ("destination not found", network.rs:285-289)."""
+        if not 1 <= ip_id <= 255 or not 1 <= port <= 0xFFFF:
+            raise ValueError("virtual address: ip id 1..255, port 1..65535")
+        self.socks.append(A.Sock(ip_id, A.ADDR_VIRTUAL, port))
+        return len(self.socks) - 1
+
+    def ipvs_service(self, vaddr, servers):
+        """`ipvs.add_service(ServiceAddr::Tcp(vaddr), Scheduler::RoundRobin)` + one `add_server` per entry of `servers`, before
+        any task runs (net/ipvs.rs:50-85; the reference test net/tcp/mod.rs:254-315): send_to / call / connect1 towards `vaddr`
+        go to the servers in turn (net/mod.rs:312-317,345-350)."""
+        servers = list(servers)
+        if len(self.services) >= A.MAX_SERVICES or len(servers) > 6:
+            raise ValueError("at most 8 services with at most 6 servers each")
+        sv = A.Service(vaddr, len(servers))
+        for i, e in enumerate(servers):
+            sv.servers[i] = e
+        self.services.append(sv)
+        return len(self.services) - 1
+
     def task(self, node, init=False, pre=False, spawn_on_drop=False):
         """A task body.  spawn_on_drop: the body owns a guard whose Drop calls task::spawn(<the NEXT task declared>) — it
         runs whenever an instance returns or is dropped (abort, kill, panic), in that instance's context (task/mod.rs:1185-1253)."""
@@ -362,41 +387,36 @@ class WorkloadBuilder:
         self.tasks.append(t)
         return t
 
-    def _panic_codes(self):
-        """Literal panic messages -> message codes.  A code only ever meets the nodes' patterns, so messages that the same
-        set of nodes restarts on are one class and share a code; a node then names the classes it restarts on (the device has
-        two pattern slots per node: more classes than that is refused)."""
+    def _panic_rows(self):
+        """Message codes and the nodes' restart rows.  Every message a task can panic with gets an 8-bit code: a run-time
+        formatted `panic!("{}", n)` (panic_with_flag) and a numeric panic(code) ARE their value, whose text is its decimal
+        form; literal messages are interned from 254 downwards, and formatted values may not reach into that range
+        (panic_dyn_max: the device answers MADSIM_OVERFLOW beyond it).  A node's row has bit c set when one of its patterns
+        is a substring of the text of code c — `restart_on_panic_matching.iter().any(|s| error_msg.contains(s))`
+        (task/mod.rs:297-300) evaluated once per code on the host."""
         texts = sorted(set(self.panic_texts))
-        cls = {}
-        for m in texts:
-            key = tuple(sorted(n for n, pats in self.panic_patterns.items() if any(p in m for p in pats)))
-            cls.setdefault(key, len(cls))
-        if len(cls) > 255:                                  # 255 itself is MADSIM_PANIC_CODE_OTHER (asserts, unwraps)
-            raise ValueError("too many classes of panic messages")
-        codes = {m: cls[tuple(sorted(n for n, pats in self.panic_patterns.items() if any(p in m for p in pats)))] for m in texts}
-        for n in self.panic_patterns:
-            mine = sorted({c for key, c in cls.items() if n in key})
-            if len(mine) > 2:
-                raise ValueError("node %d restarts on %d classes of panic messages; the device holds two per node" % (n, len(mine)))
-            self.nodes[n].n_match = len(mine)
-            for i, c in enumerate(mine):
-                self.nodes[n].match[i] = c
-        return codes
+        if len(texts) > 200:
+            raise ValueError("too many distinct literal panic messages (at most 200)")
+        codes = {m: 254 - i for i, m in enumerate(texts)}
+        dyn_max = 254 - len(texts)
+        text_of = {c: str(c) for c in range(dyn_max + 1)}
+        text_of.update({c: m for m, c in codes.items()})
+        rows = [0] * (8 * len(self.nodes))
+        for n, pats in self.panic_patterns.items():
+            for c, text in text_of.items():
+                if any(p in text for p in pats):
+                    rows[8 * n + (c >> 5)] |= 1 << (c & 31)
+        return codes, rows, dyn_max
 
     def build(self):
         insns, progs = [], []
+        rows, dyn_max = None, 0
         if self.panic_texts or self.panic_patterns:
-            if any(n.flags & A.NODE_RESTART_MATCHING and i not in self.panic_patterns for i, n in enumerate(self.nodes)):
-                raise ValueError("string and numeric restart_on_panic_matching patterns cannot be mixed in one workload")
-            # literal messages get class codes 0, 1, ..: a numeric panic(code) / panic_with_flag in the same workload could
-            # collide with a class a node restarts on (a spurious restart instead of a test failure), so the two do not mix
+            codes, rows, dyn_max = self._panic_rows()
             for t in self.tasks:
                 for op, a, b, imm, reloc in t.code:
-                    if op == A.OP["PANIC"] and not isinstance(imm, tuple):
-                        raise ValueError("numeric panic codes (panic(code), panic_with_flag) cannot be mixed with literal panic "
-                                         "messages / string patterns in one workload")
-            codes = self._panic_codes()
-            for t in self.tasks:
+                    if op == A.OP["PANIC"] and a == 0 and not isinstance(imm, tuple) and imm > dyn_max:
+                        raise ValueError(f"panic({imm}): numeric message codes above {dyn_max} are taken by this workload's literal messages")
                 t.code = [(op, a, b, codes[imm[1]] if isinstance(imm, tuple) else imm, reloc) for op, a, b, imm, reloc in t.code]
         for t in self.tasks:
             base = len(insns)
@@ -407,9 +427,12 @@ class WorkloadBuilder:
                 insns.append(A.Insn(op, a, (b + base) if reloc else b, imm))
         if len(insns) > 0xFFFF:
             raise ValueError("program too long")
-        built = BuiltWorkload(self.nodes, progs, self.socks, insns)
+        built = BuiltWorkload(self.nodes, progs, self.socks, insns, self.services, rows, dyn_max if rows is not None else 0)
         built.payloads = list(self.payloads)
         built.rpc_messages = list(self.rpc_messages)
+        # what the rows were evaluated from (tests/golden/make_golden_async.py re-evaluates `contains` literally from these)
+        built.panic_patterns = dict(self.panic_patterns)
+        built.panic_text_of = {c: m for m, c in (codes.items() if rows is not None else ())}
         return built
 
 

@@ -191,6 +191,7 @@ typedef struct {
     const madsim_config_t* cfg;
     /* accounting */
     uint8_t panic_code;                                  /* message code of the panic being unwound */
+    uint32_t ipvs_rr[MADSIM_MAX_SERVICES];               /* Service.rr_index of every virtual service (net/ipvs.rs:37-41) */
     uint64_t msg_count; uint32_t steps; uint64_t obs_hash;
     uint32_t greg[4];                     /* Arc<AtomicUsize> flags shared by the test's tasks       */
     VEC(conn_t) conns;
@@ -354,7 +355,7 @@ static addr_t addr_of_from(const sim_t* S, uint32_t from) {
     return a;
 }
 static int addr_eq(addr_t x, addr_t y) {                  /* SocketAddr equality */
-    return x.kind == y.kind && x.port == y.port && (x.kind != MADSIM_ADDR_IP || x.node == y.node);
+    return x.kind == y.kind && x.port == y.port && ((x.kind != MADSIM_ADDR_IP && x.kind != MADSIM_ADDR_VIRTUAL) || x.node == y.node);
 }
 static int node_has_ip(const sim_t* S, unsigned node) { return !(S->w->nodes[node].flags & MADSIM_NODE_NO_IP); }
 
@@ -373,6 +374,26 @@ static int resolve_dest_node(sim_t* S, unsigned node, addr_t dst) {
     if (!node_has_ip(S, node)) return -1;                                  /* "ip not set" */
     if (dst.kind == MADSIM_ADDR_IP && dst.node >= 1 && dst.node <= S->w->n_nodes && node_has_ip(S, dst.node)) return dst.node;   /* addr_to_node */
     return -1;                                                             /* "destination not found" */
+}
+
+/* `if let Some(addr) = self.ipvs.get_server(ServiceAddr::from_addr_proto(dst, protocol)) { dst = addr.parse() }`
+ * (net/mod.rs:312-317 in send, :345-350 in connect1) with IpVirtualServer::get_server (net/ipvs.rs:88-105): the service whose
+ * address equals `dst`; no servers -> None; `if *i >= len { *i = 0 }; server = servers[*i]; *i += 1`. */
+static addr_t ipvs_rewrite(sim_t* S, addr_t dst) {
+    const madsim_workload_t* w = S->w;
+    for (uint32_t k = 0; k < w->n_services; k++) {
+        const madsim_service_t* sv = &w->services[k];
+        const addr_t va = { w->socks[sv->vaddr].kind, w->socks[sv->vaddr].node, w->socks[sv->vaddr].port };
+        if (!addr_eq(va, dst)) continue;
+        if (sv->n_servers == 0) return dst;               /* Some(service) with no servers: None */
+        uint32_t* i = &S->ipvs_rr[k];
+        if (*i >= sv->n_servers) *i = 0;
+        const madsim_sock_t* e = &w->socks[sv->servers[*i]];
+        *i += 1;
+        addr_t real = { e->kind, e->node, e->port };
+        return real;
+    }
+    return dst;
 }
 
 /* Network::try_send (network.rs:296-313) + test_link (:261-269).  Returns 1 and the latency / socket / the `from`
@@ -735,7 +756,12 @@ static int poll_task(sim_t* S, uint16_t slot) {
             t->pc++; break;
         }
         case MS_OP_PANIC:                                  /* the message code restart_on_panic_matching looks at */
-            S->panic_code = in->a & 1 ? (uint8_t)(S->greg[in->b & 3] + in->imm) : (uint8_t)in->imm;
+            /* a run-time formatted message is the decimal text of its value: values beyond the workload's panic_dyn_max are outside
+             * what the patterns were evaluated for (the device reports MADSIM_OVERFLOW there; here: a message no pattern names) */
+            if (in->a & 1) {
+                const uint32_t v = S->greg[in->b & 3] + in->imm, dyn_max = w->panic_dyn_max ? w->panic_dyn_max : 254u;
+                S->panic_code = v > dyn_max ? MADSIM_PANIC_CODE_OTHER : (uint8_t)v;
+            } else S->panic_code = (uint8_t)in->imm;
             return 1;
         case MS_OP_SET:
             t->cnt[in->a & 1] = (uint16_t)in->imm; t->pc++;
@@ -815,7 +841,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (t->sub == 0) { t->deadline = rand_delay_start(S); t->sub = 1; }
             if (!sleep_poll(S, slot, t->deadline)) return 0;
             {
-                const addr_t dst = in->op == MS_OP_SEND ? addr_of_sock(S, in->b & 0xff) : addr_of_from(S, t->from);
+                const addr_t dst = ipvs_rewrite(S, in->op == MS_OP_SEND ? addr_of_sock(S, in->b & 0xff) : addr_of_from(S, t->from));
                 uint64_t lat; int ds; unsigned lb;
                 const int sent = try_send(S, w->socks[in->a].node, dst, &lat, &ds, &lb);
                 if (sent < 0) return 1;                    /* `.ip.unwrap()` on an IP-less node */
@@ -868,7 +894,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
             {
                 if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, t->killed); t = &S->tasks.p[slot]; }
                 uint64_t lat; int ds; unsigned lb;
-                const addr_t dial = addr_of_sock(S, in->b & 0xff);
+                const addr_t dial = ipvs_rewrite(S, addr_of_sock(S, in->b & 0xff));    /* channel() is built from the rewritten dst */
                 const int sent = try_send(S, w->socks[in->a].node, dial, &lat, &ds, &lb);
                 if (sent < 0) return 1;
                 if (!sent) {
@@ -1038,7 +1064,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 const node_t* sn = &S->nodes[w->socks[in->a].node];
                 const int hooked = sn->hreq_valid && sn->hreq_tag == (uint8_t)(in->b >> 8) && (sn->hreq_all || sn->hreq_code == (uint8_t)in->imm);
                 unsigned lb = 0;
-                const int sent = hooked ? 0 : try_send(S, w->socks[in->a].node, addr_of_sock(S, dst), &lat, &ds, &lb);
+                const int sent = hooked ? 0 : try_send(S, w->socks[in->a].node, ipvs_rewrite(S, addr_of_sock(S, dst)), &lat, &ds, &lb);
                 if (sent < 0) return 1;
                 if (sent) {
                     event_t e; memset(&e, 0, sizeof e);
@@ -1184,8 +1210,11 @@ static void run_all_ready(sim_t* S, uint32_t max_steps) {
                 const madsim_node_t* nb = &S->w->nodes[node];
                 /* restart_on_panic || restart_on_panic_matching.iter().any(|s| error_msg.contains(s)) (:297-300) */
                 int restart = (nb->flags & MADSIM_NODE_RESTART_ON_PANIC) != 0;
-                if (nb->flags & MADSIM_NODE_RESTART_MATCHING)
-                    for (unsigned k = 0; k < nb->n_match && k < 2; k++) restart |= nb->match[k] == S->panic_code;
+                if (nb->flags & MADSIM_NODE_RESTART_MATCHING) {
+                    if (S->w->panic_match)                 /* the host evaluated `error_msg.contains(pattern)` for every message code */
+                        restart |= (S->w->panic_match[node * 8 + (S->panic_code >> 5)] >> (S->panic_code & 31)) & 1;
+                    else for (unsigned k = 0; k < nb->n_match && k < 2; k++) restart |= nb->match[k] == S->panic_code;
+                }
                 if (!restart) {
                     S->panic = 1;
                     return;                                /* resume_unwind: block_on unwinds */
@@ -1221,9 +1250,15 @@ static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
     if (!w || !w->insns || !w->progs || w->n_progs == 0 || w->n_progs > 255) return -1;
     if (w->n_nodes > 62 || w->n_socks > 63) return -1;
     if (w->n_socks && !w->socks) return -1;
-    for (uint32_t i = 0; i < w->n_socks; i++) if (w->socks[i].kind > MADSIM_ADDR_LOOPBACK) return -1;
+    for (uint32_t i = 0; i < w->n_socks; i++) if (w->socks[i].kind > MADSIM_ADDR_VIRTUAL) return -1;
+    if (w->n_services > MADSIM_MAX_SERVICES || (w->n_services && !w->services)) return -1;
+    for (uint32_t k = 0; k < w->n_services; k++) {
+        if (w->services[k].vaddr >= w->n_socks || w->services[k].n_servers > 6) return -1;
+        for (uint32_t j = 0; j < w->services[k].n_servers; j++) if (w->services[k].servers[j] >= w->n_socks) return -1;
+    }
     for (uint32_t i = 0; i < w->n_insns; i++) {           /* an ephemeral Endpoint has no address a peer could name */
         const madsim_insn_t* in = &w->insns[i];
+        if (in->op == MS_OP_BIND && in->a < w->n_socks && w->socks[in->a].kind == MADSIM_ADDR_VIRTUAL) return -1;   /* a destination only */
         if ((in->op == MS_OP_SEND || in->op == MS_OP_CONNECT || in->op == MS_OP_RPC_CALL) &&
             (uint32_t)(in->b & 0xff) < w->n_socks && w->socks[in->b & 0xff].port == 0) return -1;
     }

@@ -44,6 +44,8 @@ static inline uint4 buf_load128(const BufRef& b, uint32_t off) { return *(const 
 static inline void buf_store128(const BufRef& b, uint32_t off, const uint4& e) { *(uint4*)(b.base + off) = e; }
 template <int K_> static inline uint64_t rotl64(uint64_t x) { return (x << K_) | (x >> (64 - K_)); }
 static inline uint64_t add64_1(uint64_t a, uint64_t b) { return a + b; }
+template <int K_> static inline uint64_t shl64(uint64_t x) { return x << K_; }
+template <int K_> static inline uint64_t mul_pow2p1(uint64_t v) { return (v << K_) + v; }
 static inline uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) { return a ^ b ^ c; }
 static inline uint32_t table_copy_first() { return 0; }                   // emulated threads run one after another:
 static inline uint32_t table_copy_stride(uint32_t) { return 1; }          // each copies everything

@@ -811,3 +811,79 @@ def random_channel_workload(rng: random.Random):
             m.join(tasks[i], expect_err=False)
     cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.1]))
     return wl.build(), cfg, f"{n_srv}s/{len(cli_nodes)}c/{len(tasks)}t"
+
+
+def random_ipvs_workload(rng: random.Random):
+    """Programs over IP Virtual Server rewriting (net/ipvs.rs; NetSim::send / connect1, net/mod.rs:312-317,345-350): one to
+    three services — on virtual addresses and sometimes on a real one — with zero to three servers each (bound listeners,
+    addresses nobody binds, 0.0.0.0 listeners reached through the node IP), virtual addresses without a service; clients send
+    datagrams, dial connect1, and now and then make a typed call (which panics when a real server answers for a virtual
+    address, rpc.rs:126).  Round-robin counters advance per seed whatever becomes of the message.  Any verdict is fine; it
+    has to be the oracle's."""
+    wl = W.WorkloadBuilder()
+    n_srv, n_cli = rng.randint(2, 3), rng.randint(1, 2)
+    srv_nodes = [wl.create_node() for _ in range(n_srv)]
+    cli_nodes = [wl.create_node() for _ in range(n_cli)]
+    named, tasks = [], []
+    chan = rng.random() < 0.5
+    for i, n in enumerate(srv_nodes):
+        port = rng.randint(1, 2)
+        listen = wl.addr(n, port, ip=rng.choice(["node", "node", "unspecified"]))
+        name = wl.addr(n, port)                                                  # what add_server / clients name
+        named.append(name)
+        if rng.random() < 0.2:
+            named.append(wl.addr(n, 3))                                          # a server address nobody binds
+        s = wl.task(n)
+        s.bind(listen); s.set(0, rng.randint(2, 5)); top = s.label()
+        if chan and rng.random() < 0.7:
+            s.accept1(listen); s.chan_recv(); s.trace_val(); s.chan_send(0x100 + i)
+        else:
+            s.recv_from_timeout(listen, 1, ms=rng.choice([30, 80])); s.trace_val()
+            skip = s.label() + 2
+            s.jeq(A.VAL_TIMEOUT, skip); s.reply(listen, 2, 0x200 + i)
+            assert s.label() == skip
+        s.djnz(0, top)
+        tasks.append(s)
+    vips = [wl.virtual_addr(rng.randint(1, 3), rng.choice([80, 81])) for _ in range(rng.randint(1, 3))]
+    targets = list(vips)
+    seen = set()
+    for v in vips:
+        key = (wl.socks[v].node, wl.socks[v].port)
+        if key in seen or rng.random() < 0.25:                                   # a virtual address without a service (or a twin of one)
+            continue
+        seen.add(key)
+        wl.ipvs_service(v, [rng.choice(named) for _ in range(rng.randint(0, 3))])
+    if rng.random() < 0.3 and len(wl.services) < 3:                              # a service keyed by a REAL address
+        real = rng.choice(named)
+        wl.ipvs_service(real, [rng.choice(named) for _ in range(rng.randint(1, 2))])
+        targets.append(real)
+    targets += [rng.choice(named)]
+    desc = [f"{n_srv}s/{n_cli}c/{len(wl.services)}svc/{'chan' if chan else 'dgram'}"]
+    for j, n in enumerate(cli_nodes):
+        me = wl.addr(n, 1)
+        c = wl.task(n)
+        c.bind(me); c.sleep(ms=rng.randint(5, 12)); c.set(0, rng.randint(2, 5)); top = c.label()
+        r = rng.random()
+        dst = rng.choice(targets)
+        if chan and r < 0.5:
+            c.connect1(me, dst); c.trace_val()
+            skip = c.label() + 4
+            c.jeq(A.VAL_REFUSED, skip); c.chan_send(0x300 + j); c.chan_recv(); c.trace_val()
+            assert c.label() == skip
+        elif r < 0.8:
+            c.send_to(me, dst, 1, 0x400 + j)
+            c.recv_from_timeout(me, 2, ms=rng.choice([15, 40])); c.trace_val()
+        else:
+            c.rpc_call(me, dst, 0, 7, timeout_ms=30); c.trace_val()
+        c.sleep(ms=rng.choice([1, 3, 9]))
+        c.djnz(0, top)
+        tasks.append(c)
+    m = wl.main()
+    for t in tasks:
+        m.spawn(t)
+    if rng.random() < 0.4:
+        m.sleep(ms=rng.randint(10, 40)); m.clog_node(rng.choice(srv_nodes), "both"); m.sleep(ms=20); m.unclog_node(srv_nodes[0], "both")
+    for t in tasks[n_srv:]:
+        m.join(t, expect_err=False)
+    cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.15]))
+    return wl.build(), cfg, "+".join(desc)

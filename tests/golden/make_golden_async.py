@@ -106,8 +106,13 @@ class Sim:
         self.progs = [(w.progs[i].node, w.progs[i].flags, w.progs[i].entry) for i in range(w.struct.n_progs)]
         self.socks = [(w.socks[i].node, w.socks[i].port) for i in range(w.struct.n_socks)]
         # SocketAddr of table entry i, and the network's view of the nodes (network.rs:19-37)
-        self.addr = [({0: "10.0.0.%d" % w.socks[i].node, 1: "0.0.0.0", 2: "127.0.0.1"}[w.socks[i].kind], w.socks[i].port)
-                     for i in range(w.struct.n_socks)]
+        self.addr = [({0: "10.0.0.%d" % w.socks[i].node, 1: "0.0.0.0", 2: "127.0.0.1", 3: "1.1.1.%d" % w.socks[i].node}[w.socks[i].kind],
+                      w.socks[i].port) for i in range(w.struct.n_socks)]
+        # IpVirtualServer (net/ipvs.rs): HashMap<ServiceAddr, Service { servers: Vec<String>, rr_index }>, filled before block_on
+        self.ipvs = {}
+        for k in range(w.struct.n_services):
+            sv = w.services[k]
+            self.ipvs[self.addr[sv.vaddr]] = {"servers": [self.addr[sv.servers[j]] for j in range(sv.n_servers)], "rr_index": 0}
         # port 0 = an ephemeral Endpoint: its address is whatever its last bind was given (never a destination operand)
         self.ephemeral = [w.socks[i].port == 0 for i in range(w.struct.n_socks)]
         n_nodes = w.struct.n_nodes
@@ -119,8 +124,15 @@ class Sim:
         self.node_info = {n: NodeInfo(n) for n in range(0, n_nodes + 1)}
         self.handle_info = dict(self.node_info)
         self.paused = {n: [] for n in range(0, n_nodes + 1)}
-        self.node_flags = {n: (w.nodes[n].flags, [w.nodes[n].match[i] for i in range(min(2, w.nodes[n].n_match))])
+        # NodeBuilder::restart_on_panic_matching: the patterns as STRINGS, and the text of every message code (a literal
+        # message the builder interned, else the decimal form of the value `panic!("{}", n)` formats) — the builder's own
+        # records, not the 256-bit rows it derived from them for the device and the oracle
+        pats, texts = getattr(w, "panic_patterns", {}), getattr(w, "panic_text_of", {})
+        self.node_flags = {n: (w.nodes[n].flags, tuple(pats.get(n, ())) if n in pats else
+                               tuple(str(w.nodes[n].match[i]) for i in range(min(2, w.nodes[n].n_match))), n in pats)
                            for n in range(0, n_nodes + 1)}
+        self.panic_text = lambda code: None if code is None or code == 255 else texts.get(code, str(code))
+        self.panic_dyn_max = w.struct.panic_dyn_max or 254
         self.all_socks = []                                                # every EndpointSocket ever made (reset_node's sweep)
         self.hooks_req, self.hooks_rsp = {}, {}                            # NetSim.hooks_req / hooks_rsp: HashMap<NodeId, hook>
         self.cfg, self.rng = cfg, Xoshiro(seed)
@@ -357,6 +369,7 @@ class Sim:
         yield from self.rand_delay(t)
         self.conn_drop(t)                           # (the VM's rule: a task holds one pair; the old one goes here)
         node = self.socks[a][0]
+        dst = self.ipvs_get_server(dst) or dst      # net/mod.rs:345-350
         sent = self.try_send(node, dst)
         if sent is None:
             return A.VAL_REFUSED
@@ -416,6 +429,16 @@ class Sim:
         yield from self.sleep_until(t, self.sleep_deadline(state))
         return val
 
+    def ipvs_get_server(self, dst):                 # IpVirtualServer::get_server (net/ipvs.rs:88-105), RoundRobin
+        service = self.ipvs.get(dst)
+        if service is None or not service["servers"]:
+            return None
+        if service["rr_index"] >= len(service["servers"]):
+            service["rr_index"] = 0
+        server = service["servers"][service["rr_index"]]
+        service["rr_index"] += 1
+        return server
+
     def resolve_dest_node(self, node, dst):         # network.rs:272-290
         if dst[0] == "127.0.0.1" or dst in self.node_sockets[node]:
             return node
@@ -451,6 +474,7 @@ class Sim:
         hook = self.hooks_req.get(node)
         if hook is not None and kind == "request" and not hook(tag, val):
             return                                  # `if !hook(&msg) { return Ok(()) }`
+        dst = self.ipvs_get_server(dst) or dst      # net/mod.rs:312-317
         sent = self.try_send(node, dst)
         if sent is not None:
             src_ip, dst_node, mbox, lat = sent
@@ -577,7 +601,10 @@ class Sim:
                 self.wake(t)
                 yield
             elif name == "PANIC":
-                raise Panic(imm & 0xFF if a == 0 else (self.flags[b & 3] + imm) & 0xFF)
+                if a == 0:
+                    raise Panic(imm & 0xFF)
+                v = (self.flags[b & 3] + imm) & 0xFFFFFFFF      # panic!("{}", flag + imm): values past panic_dyn_max are outside the model
+                raise Panic(v if v <= self.panic_dyn_max else 255)
             elif name == "HOOK_REQ":                # NetSim::hook_rpc_req::<R>(node, f): HashMap::insert
                 self.hooks_req[a] = (lambda tag, code, want_tag=b >> 8, all_=b & 1, want=imm & 0xFF:
                                      not (tag == want_tag and (all_ or code == want)))
@@ -755,8 +782,12 @@ class Sim:
                     except StopIteration:
                         self.finish(t, "completed")
                     except Panic as e:
-                        flags, match = self.node_flags[t.info.node]
-                        if not (flags & A.NODE_RESTART_ON_PANIC or (flags & A.NODE_RESTART_MATCHING and e.code in match)):
+                        flags, patterns, substr = self.node_flags[t.info.node]
+                        error_msg = self.panic_text(e.code)         # None: a failed assert / unwrap — a message no pattern names
+                        # restart_on_panic || restart_on_panic_matching.iter().any(|s| error_msg.contains(s))  (task/mod.rs:297-300);
+                        # raw C-ABI tables without the builder's records carry codes, compared for equality
+                        hit = error_msg is not None and any((p in error_msg) if substr else (p == error_msg) for p in patterns)
+                        if not (flags & A.NODE_RESTART_ON_PANIC or (flags & A.NODE_RESTART_MATCHING and hit)):
                             panicked = True         # resume_unwind
                             break
                         # async-task's guard drops the future while unwinding (the node is not killed yet), then (:301-313)
@@ -816,7 +847,8 @@ def workloads():
     for gen, base, n in (("random_workload", 810000, 16), ("random_lifecycle_workload", 820000, 24), ("random_rpc_workload", 830000, 16),
                          ("random_addr_workload", 880000, 24), ("random_ephemeral_workload", 870000, 16),
                          ("random_channel_workload", 860000, 24), ("random_guard_workload", 850000, 16),
-                         ("random_supervisor_workload", 840000, 16), ("random_mixed_workload", 845000, 16)):
+                         ("random_supervisor_workload", 840000, 16), ("random_mixed_workload", 845000, 16),
+                         ("random_ipvs_workload", 895000, 16)):
         for k in range(n):
             r = getattr(fuzz, gen)(random.Random(base + k))
             out["%s_%02d" % (gen.replace("random_", "fuzz_").replace("_workload", ""), k)] = (r[0], r[1])

@@ -87,7 +87,7 @@ def restart_on_panic_matching_substrings():
     tc = wl.task(c, init=True, pre=True); tc.sleep(secs=100); tc.panic("out of memory")
     m = wl.main(); m.sleep(secs=50); m.panic_if_flag_lt(0, 3); m.panic_if_flag_lt(1, 2); m.sleep(secs=100)
     built = wl.build()
-    assert built.nodes[a].n_match == 2 and built.nodes[b].n_match == 1 and built.nodes[c].n_match == 0
+    assert built.struct.panic_dyn_max == 254 - 3 and built.panic_match is not None     # three literal messages, one row per node
     return built
 
 
@@ -750,7 +750,75 @@ def limits(name):
     if name in ("rpc_server_restart", "rpc_hooks"):   # timed-out calls leave dead registrations behind (rpc.rs:125)
         lim = A.Limits(); lim.mbox_regs, lim.mbox_msgs = 8, 4
         return lim
+    if name == "ipvs_round_robin_datagrams":             # four replies may queue up before the sender starts receiving
+        lim = A.Limits(); lim.mbox_msgs = 6
+        return lim
     if name == "join_handle_awaits_the_task_it_named":   # two instances of one program alive at once
         lim = A.Limits(); lim.max_tasks = 6
         return lim
     return None
+
+
+# ---- IP Virtual Server (net/ipvs.rs; consulted by NetSim::send and connect1, net/mod.rs:312-317,345-350) --------------------
+
+def ipvs_load_balance():
+    """net/tcp/mod.rs:254-315 `ipvs_load_balance` over the Endpoint layer the TCP sim rides on (connect1 / accept1): service
+    1.1.1.1:80 -> [10.0.0.1:1, 10.0.0.2:1], listeners on 0.0.0.0:1 of nodes 1 and 2, node 3 connects to 1.1.1.1:80 twice —
+    the first connection reaches node 1, the second node 2 — and writes "1" / "2"; each listener asserts what it reads.
+    (sleeps order the set-up where the reference uses a tokio Barrier.)"""
+    wl = W.WorkloadBuilder()
+    n1, n2, n3 = wl.create_node(), wl.create_node(), wl.create_node()
+    l1, l2 = wl.addr(n1, 1, ip="unspecified"), wl.addr(n2, 1, ip="unspecified")
+    s1, s2 = wl.addr(n1, 1), wl.addr(n2, 1)                       # the real servers' addresses, as add_server names them
+    vip = wl.virtual_addr(1, 80)
+    wl.ipvs_service(vip, [s1, s2])
+    c = wl.addr(n3, 0, ip="unspecified")                          # TcpStream::connect binds an ephemeral Endpoint
+    f1 = wl.task(n1); f1.bind(l1); f1.accept1(l1); f1.chan_recv(); f1.assert_val(wl.payload(b"1"))
+    f2 = wl.task(n2); f2.bind(l2); f2.accept1(l2); f2.chan_recv(); f2.assert_val(wl.payload(b"2"))
+    hold = wl.task(n3); hold.chan_send(wl.payload(b"1")); hold.sleep(ms=200)       # stream1 lives on in its own task
+    f3 = wl.task(n3); f3.sleep(ms=50); f3.bind(c)
+    f3.connect1(c, vip); f3.assert_val(0); f3.spawn(hold, move_conn=True)          # go to node 1
+    f3.connect1(c, vip); f3.assert_val(0); f3.chan_send(wl.payload(b"2")); f3.sleep(ms=200)   # go to node 2
+    m = wl.main(); m.spawn(f1); m.spawn(f2); m.spawn(f3); m.join(f1); m.join(f2); m.join(f3)
+    return wl.build()
+
+
+def ipvs_round_robin_datagrams():
+    """ipvs.rs:88-105 get_server over datagrams: five send_to(1.1.1.1:80) go to the three servers in turn and wrap
+    (a, b, c, a, b); rr_index advances also when the chosen server has no socket (server c: nobody listens — the datagram is
+    lost after its draws); a datagram to a virtual address WITHOUT a service (1.1.1.2:80) is dropped before any draw; one to
+    a service with no servers likewise; replies go back to the sender's real address."""
+    wl = W.WorkloadBuilder()
+    n1, n2, n3, n4 = wl.create_node(), wl.create_node(), wl.create_node(), wl.create_node()
+    a, b, cdead = wl.addr(n1, 1), wl.addr(n2, 1), wl.addr(n3, 1)
+    vip, lonely, empty = wl.virtual_addr(1, 80), wl.virtual_addr(2, 80), wl.virtual_addr(3, 80)
+    wl.ipvs_service(vip, [a, b, cdead]); wl.ipvs_service(empty, [])
+    me = wl.addr(n4, 1)
+    ra = wl.task(n1); ra.bind(a); ra.set(0, 2); top = ra.label(); ra.recv_from(a, 1); ra.trace_val(); ra.reply(a, 2, 100); ra.djnz(0, top)
+    rb = wl.task(n2); rb.bind(b); rb.set(0, 2); top = rb.label(); rb.recv_from(b, 1); rb.trace_val(); rb.reply(b, 2, 200); rb.djnz(0, top)
+    tx = wl.task(n4); tx.bind(me); tx.sleep(ms=20)
+    for k in range(5):
+        tx.send_to(me, vip, 1, 10 + k); tx.sleep(ms=15)
+    tx.send_to(me, lonely, 1, 77); tx.send_to(me, empty, 1, 78)
+    tx.set(0, 4); top = tx.label(); tx.recv_from(me, 2); tx.trace_val(); tx.djnz(0, top)
+    tx.recv_from_timeout(me, 2, ms=100); tx.assert_val(A.VAL_TIMEOUT)
+    m = wl.main(); m.spawn(ra); m.spawn(rb); m.spawn(tx); m.join(ra); m.join(rb); m.join(tx)
+    return wl.build()
+
+
+def ipvs_rpc_call_asserts_given_address():
+    """rpc.rs:126 `assert_eq!(from, dst)`: a typed call through a virtual address reaches the real server, whose response
+    comes from ITS address, not from the one the caller was given — the caller panics, as in the reference."""
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, vip, me = wl.addr(ns, 1), wl.virtual_addr(1, 80), wl.addr(nc, 1)
+    wl.ipvs_service(vip, [asv])
+    srv = _rpc_server(wl, ns, asv, 42)
+    cl = wl.task(nc); cl.bind(me); cl.sleep(ms=10); cl.rpc_call(me, vip, 0, 5); cl.assert_val(42)
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.join(cl)
+    return wl.build()
+
+
+ALL.update(ipvs_load_balance=ipvs_load_balance, ipvs_round_robin_datagrams=ipvs_round_robin_datagrams,
+           ipvs_rpc_call_asserts_given_address=ipvs_rpc_call_asserts_given_address)
+EXPECT_PANIC.add("ipvs_rpc_call_asserts_given_address")

@@ -26,29 +26,52 @@ def test_rpc_message_interning():
     assert wl.build().rpc_messages[x] == (("Echo", "hi"), b"")
 
 
-def test_panic_message_classes():
-    """Literal panic messages get the code of their class under the nodes' substring patterns (task/mod.rs:297-300)."""
+def test_panic_message_rows():
+    """`restart_on_panic_matching.iter().any(|s| error_msg.contains(s))` (task/mod.rs:297-300) evaluated per message code: literal
+    messages are interned from 254 down, numbers stand for their decimal text, and each node gets a 256-bit row."""
     wl = W.WorkloadBuilder()
     a = wl.create_node(restart_on_panic_matching=("disk", "net"))
     b = wl.create_node(restart_on_panic_matching=("reset",))
+    c = wl.create_node(restart_on_panic_matching=(0, "1"))          # numbers and strings mix: both are substrings
     t = wl.task(a)
-    t.panic("disk full"); t.panic("bad disk"); t.panic("network reset"); t.panic("out of memory")
+    t.panic("disk full"); t.panic("bad disk"); t.panic("network reset"); t.panic("out of memory"); t.panic_with_flag(0)
     built = wl.build()
-    codes = [built.insns[i].imm for i in range(built.struct.n_insns) if built.insns[i].op == A.OP["PANIC"]]
-    assert codes[0] == codes[1]                                  # same class: only node a restarts on them
-    assert len({codes[0], codes[2], codes[3]}) == 3
-    na, nb = built.nodes[a], built.nodes[b]
-    assert sorted(na.match[i] for i in range(na.n_match)) == sorted({codes[0], codes[2]})
-    assert [nb.match[i] for i in range(nb.n_match)] == [codes[2]]
-    # three classes for one node do not fit its two pattern slots
+    codes = [built.insns[i].imm for i in range(built.struct.n_insns) if built.insns[i].op == A.OP["PANIC"]][:4]
+    assert len(set(codes)) == 4 and min(codes) == 251 and built.struct.panic_dyn_max == 250
+
+    def bit(n, code):
+        return (built.panic_match[8 * n + (code >> 5)] >> (code & 31)) & 1
+    assert [bit(a, x) for x in codes] == [1, 1, 1, 0] and [bit(b, x) for x in codes] == [0, 0, 1, 0]
+    assert [x for x in range(251) if bit(c, x)] == [x for x in range(251) if "0" in str(x) or "1" in str(x)]      # "10", "21", "100" ...
+    assert not any(bit(c, x) for x in codes) and not bit(a, 7) and not bit(a, 255)
+    # a numeric message code may not reach into the literal range
     wl = W.WorkloadBuilder()
-    a = wl.create_node(restart_on_panic_matching=("x",)); b = wl.create_node(restart_on_panic_matching=("xy",)); c = wl.create_node(restart_on_panic_matching=("xyz",))
-    t = wl.task(a); t.panic("x"); t.panic("xy"); t.panic("xyz")
-    with pytest.raises(ValueError, match="classes"):
+    n = wl.create_node(restart_on_panic_matching=("boom",))
+    t = wl.task(n); t.panic("boom"); t.panic(254)
+    with pytest.raises(ValueError, match="numeric message codes"):
         wl.build()
-    # numeric and literal forms do not mix in one workload
+    with pytest.raises(ValueError, match="empty pattern"):
+        W.WorkloadBuilder().create_node(restart_on_panic_matching=("",))
+
+
+def test_ipvs_service_table():
     wl = W.WorkloadBuilder()
-    wl.create_node(restart_on_panic_matching=(1,)); n = wl.create_node(restart_on_panic_matching=("boom",))
-    wl.task(n).panic("boom")
-    with pytest.raises(ValueError, match="mixed"):
-        wl.build()
+    n1, n2 = wl.create_node(), wl.create_node()
+    v = wl.virtual_addr(1, 80)
+    s = wl.ipvs_service(v, [wl.addr(n1, 1), wl.addr(n2, 1)])
+    built = wl.build()
+    assert s == 0 and built.struct.n_services == 1 and built.services[0].vaddr == v and built.services[0].n_servers == 2
+    assert built.socks[v].kind == A.ADDR_VIRTUAL
+
+
+def test_cpp_mirror_builds_the_ipvs_example_for_the_oracle(tmp_path):
+    """examples/ipvs_workload.hpp (the C++ DSL: IPVS service, virtual address, substring panic patterns) run through the oracle's
+    C twin of the batch entry point — no GPU involved: the table is valid, every seed passes, one literal message interned."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "hpp_oracle_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(root, "tests", "cpp", "hpp_oracle_check.cpp"), "-o", exe,
+                           "-L" + os.path.join(root, "oracle"), "-lmadsim_oracle", "-Wl,-rpath," + os.path.join(root, "oracle")])
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 0 and "failed 0 dyn_max 253 services 1" in p.stdout, p.stdout + p.stderr

@@ -149,6 +149,19 @@ def test_fuzz_mixed_workloads():
         assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
 
 
+def test_fuzz_ipvs_workloads():
+    """IP Virtual Server rewriting in NetSim::send / connect1 (net/mod.rs:312-317,345-350; net/ipvs.rs), both state layouts."""
+    for k in range(160):
+        w, cfg, desc = fuzz.random_ipvs_workload(random.Random(9950 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        if k % 2:
+            lim = _global(lim)
+        o, _ = oracle.run_batch(w, k * 3, 12, cfg, lim)
+        e = emu.run_batch(w, k * 3, 12, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+
+
 def test_baseline_config_shaped_workloads():
     """configs[2]-shaped election loop (timeouts, partitions, HBM heap spill) and configs[3]-shaped KV-RPC."""
     o = _same(W.raft_election(), 0, 300, None, W.raft_election_limits())

@@ -269,6 +269,11 @@ def test_cpp_host_mirror_runs_like_cargo_test(hip):
     if os.path.exists(exe3):
         p = subprocess.run([exe3], env=dict(os.environ, MADSIM_TEST_SEED="5", MADSIM_TEST_NUM="2048"), capture_output=True, text=True)
         assert p.returncode == 0 and "test kv_requests ... ok (2048 seeds from 5)" in p.stdout, p.stderr
+    # IPVS round robin over connect1 + a node restarting on substring panic patterns (examples/ipvs_test.cpp)
+    exe4 = os.path.join(root, "examples", "ipvs_test")
+    if os.path.exists(exe4):
+        p = subprocess.run([exe4], env=dict(os.environ, MADSIM_TEST_SEED="7", MADSIM_TEST_NUM="2048"), capture_output=True, text=True)
+        assert p.returncode == 0 and "test ipvs_load_balance ... ok (2048 seeds from 7)" in p.stdout, p.stderr
     hip.init(0)
 
 
@@ -619,6 +624,12 @@ def test_fuzz_ephemeral_ports_gpu(hip):
     """Random programs binding port 0 (network.rs:224-236): literal port hand-out in the oracle, candidate entries on the GPU."""
     from tests import fuzz
     _fuzz_two_blocks(hip, fuzz.random_ephemeral_workload, 77000, 150, 75, 8, count=96, seed_mul=31, limits=fuzz.generous_limits, alt_global=True, strict=True)
+
+
+def test_fuzz_ipvs_gpu(hip):
+    """Random programs over IP Virtual Server rewriting (net/ipvs.rs; NetSim::send / connect1, net/mod.rs:312-317,345-350)."""
+    from tests import fuzz
+    _fuzz_two_blocks(hip, fuzz.random_ipvs_workload, 79000, 150, 75, 13, count=96, seed_mul=41, limits=_lim_tasks(24), alt_global=True)
 
 
 def test_fuzz_channel_guards_gpu(hip):
