@@ -160,6 +160,32 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
         if (uses_op(w, MS_OP_PAUSE))
             return fail(err, MADSIM_E_WORKLOAD, "MADSIM_PROG_DROP_SPAWN cannot be combined with MS_OP_PAUSE (a parked Runnable is dropped in the killer's context)");
     }
+    {   // NetSim::reset_node (network.rs:142-147) drops a killed node's sockets in the iteration order of a HashMap hashed with
+        // the seed's SipHash keys (rand.rs:176-180) — observable only when two of them hold un-accepted connections at that moment
+        // (each drop closes queued connection ends and wakes their peers: the wake order feeds the ready queue).  That order is
+        // not modelled, so a workload where it COULD matter is refused rather than answered differently: a node that can be
+        // reset (kill / restart / restart_on_panic / an init task, whose return exits the node) with two or more listening entries.
+        uint32_t resettable = 0;
+        for (uint32_t i = 0; i < w->n_insns; i++) {
+            const madsim_insn_t& in = w->insns[i];
+            if (in.op == MS_OP_KILL || in.op == MS_OP_RESTART) resettable |= 1u << in.a;
+        }
+        for (uint32_t n = 0; n <= w->n_nodes && w->nodes; n++) if (w->nodes[n].flags & (MADSIM_NODE_RESTART_ON_PANIC | MADSIM_NODE_RESTART_MATCHING)) resettable |= 1u << n;
+        for (uint32_t p = 0; p < w->n_progs; p++) if (w->progs[p].flags & MADSIM_PROG_INIT) resettable |= 1u << w->progs[p].node;
+        for (uint32_t n = 1; n <= w->n_nodes; n++) {
+            uint32_t cnt = 0;
+            for (uint32_t i = 0; i < w->n_insns; i++) {
+                const madsim_insn_t& in = w->insns[i];
+                if (in.op != MS_OP_ACCEPT || w->socks[in.a].node != n) continue;
+                bool seen = false;
+                for (uint32_t j = 0; j < i; j++) seen |= w->insns[j].op == MS_OP_ACCEPT && w->insns[j].a == in.a;
+                cnt += !seen;
+            }
+            if (((resettable >> n) & 1) && cnt >= 2)
+                return fail(err, MADSIM_E_WORKLOAD, "a node that can be killed or restarted has two listening (accept1) Endpoints: the order in which "
+                                                    "reset_node drops their queued connections (a seeded HashMap, network.rs:142-147) is not modelled");
+        }
+    }
     if (cfg->lat_lo_ns >= cfg->lat_hi_ns) return fail(err, MADSIM_E_ARG, "send_latency: cannot sample empty range");
     if (!(cfg->packet_loss_rate >= 0.0 && cfg->packet_loss_rate <= 1.0)) return fail(err, MADSIM_E_ARG, "packet_loss_rate not in [0,1]");
     return 0;

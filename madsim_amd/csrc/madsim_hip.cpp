@@ -806,6 +806,7 @@ int madsim_workload_pingpong(uint32_t n_nodes, uint32_t rounds, madsim_node_t* n
         }
         emit(MS_OP_DONE, 0, 0, 0);
     }
+    memset(w, 0, sizeof *w);              // no services, no restart rows: every field of the struct is defined
     w->n_nodes = n_nodes; w->n_progs = n_nodes + 1; w->n_socks = n_nodes; w->n_insns = n;
     w->nodes = nodes; w->progs = progs; w->socks = socks; w->insns = insns;
     return (int)n;

@@ -1275,6 +1275,23 @@ static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
         if (p + 1 >= w->n_progs || w->progs[p + 1].node != w->progs[p].node) return -1;
         for (uint32_t i = 0; i < w->n_insns; i++) if (w->insns[i].op == MS_OP_PAUSE) return -1;
     }
+    {   /* reset_node's socket drop order (network.rs:142-147: a HashMap under the seed's SipHash keys) is not restated: workloads
+         * where it could be observed — a resettable node with two listening Endpoints — are refused, here as in the library */
+        uint32_t resettable = 0;
+        for (uint32_t i = 0; i < w->n_insns; i++) if (w->insns[i].op == MS_OP_KILL || w->insns[i].op == MS_OP_RESTART) resettable |= 1u << w->insns[i].a;
+        for (uint32_t n = 0; n <= w->n_nodes && w->nodes; n++) if (w->nodes[n].flags & (MADSIM_NODE_RESTART_ON_PANIC | MADSIM_NODE_RESTART_MATCHING)) resettable |= 1u << n;
+        for (uint32_t p = 0; p < w->n_progs; p++) if (w->progs[p].flags & MADSIM_PROG_INIT) resettable |= 1u << w->progs[p].node;
+        for (uint32_t n = 1; n <= w->n_nodes && n < 32; n++) {
+            uint32_t cnt = 0;
+            for (uint32_t i = 0; i < w->n_insns; i++) {
+                if (w->insns[i].op != MS_OP_ACCEPT || w->insns[i].a >= w->n_socks || w->socks[w->insns[i].a].node != n) continue;
+                int seen = 0;
+                for (uint32_t j = 0; j < i; j++) seen |= w->insns[j].op == MS_OP_ACCEPT && w->insns[j].a == w->insns[i].a;
+                cnt += !seen;
+            }
+            if (((resettable >> n) & 1) && cnt >= 2) return -1;
+        }
+    }
     if (cfg->lat_lo_ns >= cfg->lat_hi_ns) return -1;      /* "cannot sample empty range" */
     if (!(cfg->packet_loss_rate >= 0.0 && cfg->packet_loss_rate <= 1.0)) return -1;
     return 0;

@@ -369,6 +369,10 @@ def random_mixed_workload(rng: random.Random):
         k = rng.choice(ks)
         if k in ("crecv", "csend") and not have_conn[0]:      # only with a (Sender, Receiver) pair in hand
             return
+        # one listening Endpoint per node: a node that can be killed while TWO of its sockets hold un-accepted connections is
+        # refused by validate() (reset_node drops them in the order of a seeded HashMap, network.rs:142-147: not modelled)
+        if k in ("accept", "accept_keep") and me is not None and me % 2:
+            return
         later = [x[0] for i, x in enumerate(tasks) if me is None or i > me]
         peer = rng.choice(addrs)
         if k == "sleep":
@@ -450,6 +454,8 @@ def random_mixed_workload(rng: random.Random):
     for i in range(len(tasks)):
         if rng.random() < 0.4:
             services[i] = rng.choice(["echo", "rpc", "accept"])
+            if services[i] == "accept" and i % 2:           # (one listening Endpoint per node, see act())
+                services[i] = "echo"
     if services:                                            # clients aim at the services most of the time
         addrs = addrs + [tasks[i][1] for i in services] * 3
     for i, (t, a) in enumerate(tasks):

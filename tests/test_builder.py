@@ -75,3 +75,34 @@ def test_cpp_mirror_builds_the_ipvs_example_for_the_oracle(tmp_path):
                            "-L" + os.path.join(root, "oracle"), "-lmadsim_oracle", "-Wl,-rpath," + os.path.join(root, "oracle")])
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 0 and "failed 0 dyn_max 253 services 1" in p.stdout, p.stdout + p.stderr
+
+
+def test_reset_node_drop_order_is_refused_not_guessed():
+    """NetSim::reset_node drops a killed node's sockets in the order of a seeded HashMap (network.rs:142-147, rand.rs:176-180):
+    observable when two of them hold un-accepted connections.  Oracle and library refuse such workloads alike."""
+    import oracle
+    from tests import emu
+
+    def build(two_listeners, kill):
+        wl = W.WorkloadBuilder()
+        n, c = wl.create_node(), wl.create_node()
+        a, b, me = wl.addr(n, 1), wl.addr(n, 2), wl.addr(c, 1)
+        t1 = wl.task(n); t1.bind(a); t1.accept1(a)
+        t2 = wl.task(n); t2.bind(b)
+        if two_listeners:
+            t2.accept1(b)
+        cl = wl.task(c); cl.bind(me); cl.connect1(me, a); cl.connect1(me, b)
+        m = wl.main(); m.spawn(t1); m.spawn(t2); m.spawn(cl); m.sleep(ms=50)
+        if kill:
+            m.kill(n)
+        m.sleep(ms=50)
+        return wl.build()
+    for two, kill, ok in ((True, True, False), (True, False, True), (False, True, True)):
+        w = build(two, kill)
+        if ok:
+            oracle.run_batch(w, 0, 4); emu.run_batch(w, 0, 4)
+        else:
+            with pytest.raises(Exception):
+                oracle.run_batch(w, 0, 4)
+            with pytest.raises(RuntimeError, match="reset_node"):
+                emu.run_batch(w, 0, 4)

@@ -691,3 +691,26 @@ def test_global_and_lds_state_agree_at_batch_size(hip, name):
     want = np.concatenate([oracle.run_batch(w, 77_000_000 + int(i), 1, None, lim)[0] for i in idx])
     ok = (a[idx] == want) | (a[idx]["verdict"] == A.OVERFLOW)
     assert ok.all()
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo(hip):
+    """The N > 1 path of bench.py end to end on a 1-GPU box: `--gpus 2` re-executes itself as two ranks
+    (torch.distributed.run), both on this GPU, reports reduced over gloo (the functional-test hook; a real node runs one
+    rank per GPU over RCCL).  The line must say n_gpus 2, cover both ranks' seed blocks and carry oracle-verified seeds."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hip.shutdown()
+    env = dict(os.environ, MADSIM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-measure-traffic"], env=env, capture_output=True, text=True, timeout=600)
+    hip.init(0)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
+    assert line["config"]["seeds_per_step"] == 2 * 65536 and line["verified_seeds"] >= 2 * 256
+    assert line["extra"]["failed_seeds"] == 0 and line["extra"]["seeds_per_sec"] > 0

@@ -614,6 +614,56 @@ async fn rebind_in_flight(obs: Obs) -> Tail {
     fingerprint_tail(t0, &obs)
 }
 
+/// IpVirtualServer (net/ipvs.rs) consulted by NetSim::send and connect1 (net/mod.rs:312-317,345-350).
+/// Table: twin_workloads.py::ipvs_round_robin.  0xFFFF_FFFF = Err(Elapsed).
+async fn ipvs_round_robin(obs: Obs) -> Tail {
+    use madsim::net::ipvs::{Scheduler, ServiceAddr};
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let ipvs = NetSim::current().global_ipvs();
+    ipvs.add_service(ServiceAddr::Tcp("1.1.1.1:80".into()), Scheduler::RoundRobin);
+    ipvs.add_server(ServiceAddr::Tcp("1.1.1.1:80".into()), "10.0.0.1:1");
+    ipvs.add_server(ServiceAddr::Tcp("1.1.1.1:80".into()), "10.0.0.2:1");
+    let nodes = [h.create_node().ip(addr(1, 1).ip()).build(), h.create_node().ip(addr(2, 1).ip()).build(),
+                 h.create_node().ip(addr(3, 1).ip()).build()];
+    let mut servers = vec![];
+    for i in 0..2 {
+        let o = obs.clone();
+        servers.push(nodes[i].spawn(async move {
+            let ep = Endpoint::bind("0.0.0.0:1").await.unwrap();
+            let (_tx, mut rx, _) = ep.accept1().await.unwrap();
+            o.push(value(rx.recv().await.unwrap()));
+            let mut buf = [0u8; 16];
+            for _ in 0..2 {
+                match time::timeout(Duration::from_millis(300), ep.recv_from(1, &mut buf)).await {
+                    Ok(r) => { let (len, _) = r.unwrap(); let mut w = [0u8; 4]; w[..len].copy_from_slice(&buf[..len]); o.push(u32::from_le_bytes(w) as u64) }
+                    Err(_) => o.push(0xFFFF_FFFF),
+                }
+            }
+        }));
+    }
+    let f3 = nodes[2].spawn(async move {
+        time::sleep(Duration::from_millis(50)).await;
+        let ep = Endpoint::bind(addr(3, 7)).await.unwrap();
+        let vip: SocketAddr = "1.1.1.1:80".parse().unwrap();
+        let mut held = None;                                         // the table's task holds one (tx, rx) pair at a time: its
+        for v in [1u32, 2] {                                         // second connect1 lets go of the first (nobody is parked on it)
+            drop(held.take());
+            let (tx, rx) = ep.connect1(vip).await.unwrap();
+            tx.send(payload(v)).await.unwrap();
+            held = Some((tx, rx));
+            time::sleep(Duration::from_millis(30)).await;
+        }
+        for k in 0..3u32 {
+            ep.send_to(vip, 1, &(10 + k).to_le_bytes()).await.unwrap();
+            time::sleep(Duration::from_millis(20)).await;
+        }
+    });
+    for s in servers { s.await.unwrap(); }
+    f3.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
 /// The 4-node ping-pong built ONCE with the Rust workload DSL (bindings/rust/madsim-hip, `pingpong_twin`) and interpreted on
 /// real madsim by `madsim_hip::interp` — the table `Builder::run_workload` hands to the GPU runner, run here by the reference.
 async fn pingpong4_dsl(obs: Obs) -> Tail {
@@ -659,6 +709,7 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
                 "rpc_hooks" => rpc_hooks(o).await,
                 "panic_substrings" => panic_substrings(o).await,
                 "rebind_in_flight" => rebind_in_flight(o).await,
+                "ipvs_round_robin" => ipvs_round_robin(o).await,
                 "pingpong4_dsl" => pingpong4_dsl(o).await,
                 other => panic!("unknown workload {other}"),
             }
@@ -685,7 +736,7 @@ const ALL: &[&str] = &["pingpong2", "pingpong4", "pingpong16", "sleep_1s", "yiel
                        "restart_on_panic", "receiver_drop", "localhost", "restart_on_panic_matching", "bind_ephemeral",
                        "channel_wildcard", "guard_keeps_address", "spawn_in_drop_abort", "spawn_in_drop_kill",
                        "spawn_after_own_restart", "join_names_its_task", "abort_own_handle", "rpc_hooks", "panic_substrings",
-                       "rebind_in_flight", "pingpong4_dsl"];
+                       "rebind_in_flight", "ipvs_round_robin", "pingpong4_dsl"];
 
 fn main() {
     let args: Vec<String> = std::env::args().collect();

@@ -379,6 +379,37 @@ def rebind_in_flight():
     return wl.build()
 
 
+def ipvs_round_robin():
+    """IpVirtualServer (net/ipvs.rs) consulted by NetSim::send and connect1 (net/mod.rs:312-317,345-350): service 1.1.1.1:80 ->
+    [10.0.0.1:1, 10.0.0.2:1].  Two connect1("1.1.1.1:80") from node 3 reach node 1 then node 2 (each listener observes what it
+    reads), then three datagrams to the same virtual address go 1, 2, 1 — the round-robin index is shared by both paths and
+    advances per call (each echo server observes the payloads it sees)."""
+    wl = W.WorkloadBuilder()
+    n1, n2, n3 = wl.create_node(), wl.create_node(), wl.create_node()
+    l1, l2 = wl.addr(n1, 1, ip="unspecified"), wl.addr(n2, 1, ip="unspecified")
+    s1, s2 = wl.addr(n1, 1), wl.addr(n2, 1)
+    vip = wl.virtual_addr(1, 80)
+    wl.ipvs_service(vip, [s1, s2])
+    c = wl.addr(n3, 7)
+    tasks = []
+    for (n, l, base) in ((n1, l1, 100), (n2, l2, 200)):
+        t = wl.task(n); t.bind(l); t.accept1(l); t.chan_recv(); t.trace_val()
+        t.set(0, 2); top = t.label()
+        t.recv_from_timeout(l, 1, ms=300); t.trace_val(); t.djnz(0, top)
+        tasks.append(t)
+    f3 = wl.task(n3); f3.sleep(ms=50); f3.bind(c)
+    f3.connect1(c, vip); f3.assert_val(0); f3.chan_send(1); f3.sleep(ms=30)           # -> node 1
+    f3.connect1(c, vip); f3.assert_val(0); f3.chan_send(2); f3.sleep(ms=30)           # -> node 2
+    for k in range(3):
+        f3.send_to(c, vip, 1, 10 + k); f3.sleep(ms=20)                                # -> node 1, node 2, node 1
+    m = wl.main()
+    for t in tasks:
+        m.spawn(t)
+    m.spawn(f3); m.join(tasks[0]); m.join(tasks[1]); m.join(f3)
+    fingerprint_tail(m)
+    return wl.build()
+
+
 def limits(name):
     """Device capacities a table needs beyond the defaults (None = defaults); the oracle has none."""
     if name == "join_names_its_task":                     # two instances of one program alive at once
@@ -401,5 +432,6 @@ ALL = {
     "join_names_its_task": join_names_its_task, "abort_own_handle": abort_own_handle,
     # round 3: the semantics added since the first kit, and the table built by the Rust DSL (bindings/rust/madsim-hip)
     "rpc_hooks": rpc_hooks, "panic_substrings": panic_substrings, "rebind_in_flight": rebind_in_flight,
+    "ipvs_round_robin": ipvs_round_robin,
     "pingpong4_dsl": lambda: pingpong(4, 64),          # the same table, built by madsim_hip::pingpong_twin and run by madsim_hip::interp
 }
