@@ -403,49 +403,23 @@ def main():
     # seed).  Afterwards — outside the measured time — EVERY seed from the start of the search up to and including the one
     # found is run through the oracle: all before it must pass, and the failing batch's GPU results are compared bit for bit.
     def rare_search(loss, fs, max_batches=96):
+        """One madsim_hip_run_campaign call: the LIBRARY keeps the batches in flight on its own streams and stops launching at the
+        first batch that reports a genuine failure — what a Rust / C host gets, no torch streams involved."""
         import threading
         import oracle
         fcfg = A.Config.default(packet_loss_rate=loss)
-        nb = max_batches
-        srows = torch.zeros((nb, REPORT_WORDS), dtype=torch.int64, device=dev)
-        copy_stream = torch.cuda.Stream()
-        events, found, launched = [], None, 0
-        runtime.run_batch_device(w, fs - count, count, d_outs[0].data_ptr(), streams[0].cuda_stream, fcfg, lim)   # warm (tables)
+        runtime.run_campaign(w, fs - 4 * count, 4 * count, count, n_streams, False, fcfg, lim)      # warm (streams, buffers, tables)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for k in range(nb):
-            si = k % n_streams
-            with torch.cuda.stream(streams[si]):
-                runtime.run_batch_async(w, fs + k * count, count, d_outs[si].data_ptr(), srows[k].data_ptr(),
-                                        streams[si].cuda_stream, fcfg, lim, timing_slot=-1)
-                ev = torch.cuda.Event(); ev.record(streams[si]); events.append(ev)
-            launched = k + 1
-            j = k - (n_streams - 1)                     # the oldest batch still unread: its stream gets the NEXT launch
-            if j >= 0:
-                events[j].synchronize()
-                with torch.cuda.stream(copy_stream):
-                    row = srows[j].cpu()
-                if int(row[1]) > 0:
-                    found = (j, mdist.decode_first_fail(int(row[0])), int(row[1]))
-                    break
-        if found is None:
-            for j in range(max(0, launched - (n_streams - 1)), launched):
-                events[j].synchronize()
-                with torch.cuda.stream(copy_stream):
-                    row = srows[j].cpu()
-                if int(row[1]) > 0:
-                    found = (j, mdist.decode_first_fail(int(row[0])), int(row[1]))
-                    break
-        t_found = time.perf_counter() - t1
-        torch.cuda.synchronize()
+        rep = runtime.run_campaign(w, fs, max_batches * count, count, n_streams, True, fcfg, lim)
+        found = rep.first_failing_seed != (1 << 64) - 1
         res = {"packet_loss_rate": loss, "seeds_per_batch": count, "batches_in_flight": n_streams,
-               "batches_launched": launched, "found": found is not None}
-        if found is None:
-            res["note"] = f"no failing seed in {launched} batches"
+               "batches_launched": int(rep.batches_launched), "found": found, "entry_point": "madsim_hip_run_campaign(STOP_AT_FAILURE)"}
+        if not found:
+            res["note"] = f"no failing seed in {int(rep.batches_run)} batches"
             return res
-        j, seed, nf = found
-        offset = seed - fs
-        got = np.frombuffer(d_outs[j % n_streams].cpu().numpy().tobytes(), dtype=A.RESULT_DTYPE)   # batch j: not overwritten yet
+        seed = int(rep.first_failing_seed)
+        offset, j = seed - fs, int(rep.batches_run) - 1
+        got, _ = runtime.run_batch(w, fs + j * count, count, fcfg, lim)          # the failing batch again, per-seed results this time
         # oracle: every seed of [fs, seed], threads over disjoint blocks (ctypes releases the GIL)
         n_chk = offset + 1
         n_thr = max(1, min(os.cpu_count() or 1, 32, (n_chk + 4095) // 4096))
@@ -466,12 +440,12 @@ def main():
         o_first = np.nonzero(want["verdict"] != A.PASS)[0]
         in_batch = want[j * count:]
         ok = len(o_first) == 1 and int(o_first[0]) == offset and (got[:len(in_batch)] == in_batch).all()
-        res.update({"batches_until_found": j + 1, "first_failing_seed_offset": offset, "failed_in_that_batch": nf,
-                    "failed_fraction_of_that_batch": nf / count, "time_to_first_fail_ms": t_found * 1e3,
-                    "seeds_searched": (j + 1) * count, "seeds_per_hour": (j + 1) * count / t_found * 3600.0,
+        res.update({"batches_until_found": j + 1, "first_failing_seed_offset": offset, "failed_in_that_batch": int(rep.n_failed),
+                    "time_to_first_fail_ms": rep.wall_s * 1e3, "seeds_searched": int(rep.seeds_run),
+                    "seeds_per_hour": rep.seeds_run / rep.wall_s * 3600.0,
                     "oracle_checked_seeds": n_chk, "oracle_check_s": time.perf_counter() - t2, "oracle_agrees": bool(ok),
-                    "note": "wall time from the first launch to the failing seed being known on the host; every seed up to and "
-                            "including it then oracle-checked (all earlier ones pass, the failing batch bit for bit)"})
+                    "note": "wall time of the call: first launch to the failing seed known on the host; then every seed up to and including "
+                            "it oracle-checked (all earlier ones pass, the failing batch re-run and compared bit for bit)"})
         return res
 
     first_fail_rare = first_fail_very_rare = None

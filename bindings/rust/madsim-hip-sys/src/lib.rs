@@ -127,6 +127,21 @@ pub struct madsim_summary_t {
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
+pub struct madsim_campaign_t {
+    pub seeds_run: u64,
+    pub batches_run: u64,
+    pub batches_launched: u64,
+    pub first_failing_seed: u64,
+    pub n_failed: u64,
+    pub n_runner: u64,
+    pub total_steps: u64,
+    pub total_clock_ns: u64,
+    pub kernel_ms: f64,
+    pub wall_s: f64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
 pub struct madsim_geometry_t {
     pub lds_bytes_per_seed: u32,
     pub lds_bytes_per_block: u32,
@@ -234,6 +249,7 @@ pub const MADSIM_E_HIP: c_int = -2;
 pub const MADSIM_E_NOINIT: c_int = -3;
 pub const MADSIM_E_WORKLOAD: c_int = -4;
 pub const MADSIM_E_LIMITS: c_int = -5;
+pub const MADSIM_CAMPAIGN_STOP_AT_FAILURE: u32 = 1;
 
 #[link(name = "madsim_hip")]
 extern "C" {
@@ -260,6 +276,8 @@ extern "C" {
     pub fn madsim_hip_ctx_timing_ms(ctx: *mut madsim_hip_ctx_t, timing_slot: c_int, ms: *mut f64) -> c_int;
     pub fn madsim_hip_ctx_trace_seed(ctx: *mut madsim_hip_ctx_t, w: *const madsim_workload_t, cfg: *const madsim_config_t, seed: u64, lim: *const madsim_limits_t, log: *mut u8, cap: u64, out: *mut madsim_result_t) -> i64;
     pub fn madsim_hip_run_batch_multi(ctxs: *const *mut madsim_hip_ctx_t, n_ctx: c_int, w: *const madsim_workload_t, cfg: *const madsim_config_t, seed0: u64, count: u64, lim: *const madsim_limits_t, out: *mut madsim_result_t, summary: *mut madsim_summary_t, max_rounds: c_int) -> c_int;
+    pub fn madsim_hip_ctx_run_campaign(ctx: *mut madsim_hip_ctx_t, w: *const madsim_workload_t, cfg: *const madsim_config_t, seed0: u64, total: u64, batch: u64, in_flight: u32, flags: u32, lim: *const madsim_limits_t, out: *mut madsim_campaign_t) -> define MADSIM_CAMPAIGN_STOP_AT_FAILURE 1u int;
+    pub fn madsim_hip_run_campaign(w: *const madsim_workload_t, cfg: *const madsim_config_t, seed0: u64, total: u64, batch: u64, in_flight: u32, flags: u32, lim: *const madsim_limits_t, out: *mut madsim_campaign_t) -> c_int;
     pub fn madsim_hip_geometry(w: *const madsim_workload_t, lim: *const madsim_limits_t, g: *mut madsim_geometry_t) -> c_int;
     pub fn madsim_hip_debug_counters(out16: *mut u64) -> c_int;
     pub fn madsim_workload_pingpong(n_nodes: u32, rounds: u32, nodes: *mut madsim_node_t, progs: *mut madsim_prog_t, socks: *mut madsim_sock_t, insns: *mut madsim_insn_t, cap_insns: u32, w: *mut madsim_workload_t) -> c_int;

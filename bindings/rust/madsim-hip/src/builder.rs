@@ -189,6 +189,29 @@ impl Builder {
         Ok((log, res))
     }
 
+    /// Seed search: seeds `self.seed .. self.seed + self.count` as batches the LIBRARY keeps in flight on its own streams
+    /// (`madsim_hip_run_campaign`), stopping at the first batch that holds a failing seed.  Returns the campaign report — the
+    /// smallest failing seed, how many seeds were searched — without per-seed results: re-run the reported seed for details
+    /// (`MADSIM_TEST_SEED=<seed>`).  This is the "first failing seed per hour" use of `MADSIM_TEST_NUM` at its full rate: one
+    /// 65 536-seed batch alone leaves two thirds of the GPU's issue slots idle.
+    pub fn search_first_failure(&self, workload: &Workload) -> Result<sys::madsim_campaign_t, RunError> {
+        let w = workload.raw();
+        let cfg = self.config.raw();
+        let lim = self.raw_limits(true);
+        let ctx = contexts()?.0[0];
+        let mut rep: sys::madsim_campaign_t = unsafe { std::mem::zeroed() };
+        let rc = unsafe {
+            sys::madsim_hip_ctx_run_campaign(ctx, &w, &cfg, self.seed, self.count, 0, 0, sys::MADSIM_CAMPAIGN_STOP_AT_FAILURE, &lim, &mut rep)
+        };
+        if rc != 0 {
+            return Err(last_error(rc));
+        }
+        if rep.first_failing_seed != u64::MAX {
+            note_seed(rep.first_failing_seed);
+        }
+        Ok(rep)
+    }
+
     /// Same contract as `Builder::run` (builder.rs:121-162) for a test body registered as a workload: returns the per-seed
     /// results when every seed passes, panics (after the reproduction note) on the smallest failing seed.  Library errors
     /// and runner limits that survive the re-runs come back as `Err`, never as a test failure.

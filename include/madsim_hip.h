@@ -445,6 +445,38 @@ int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const m
                                const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary,
                                int max_rounds);
 
+/* ---- Campaigns: many batches, kept in flight by the library -------------------------------------------------------------
+ * One 65 536-seed batch is one wave per SIMD: alone it leaves two thirds of the issue slots idle (a base-op launch takes ~3.2 ms
+ * alone, ~1.3 ms per batch with three in flight).  madsim_hip_run_batch cannot overlap anything — it returns the results —, so
+ * the overlap lives here: `total` seeds from `seed0` run as batches of `batch` seeds (0 = 65 536) on the context's own HIP
+ * streams, `in_flight` at a time (0 = 3; more streams than hardware queues are pointless: GPU_MAX_HW_QUEUES), each followed by a
+ * device reduction whose 48-byte report is the only thing copied to the host.  Per-seed results are NOT returned: a campaign
+ * answers "which is the first failing seed, how many fail" — the seed-search use of `MADSIM_TEST_NUM` — and the caller re-runs
+ * the seed it is told about (madsim_hip_run_batch / madsim_hip_trace_seed) for details.
+ * MADSIM_CAMPAIGN_STOP_AT_FAILURE: stop launching as soon as a completed batch reports a seed with a GENUINE verdict (panic /
+ * deadlock / time limit); batches are contiguous and reports are read in order, so `first_failing_seed` is then the smallest
+ * failing seed of [seed0, seed0 + seeds_run): at most `in_flight - 1` batches beyond the failing one have been started.
+ * Runner verdicts (MADSIM_OVERFLOW / MADSIM_STEP_LIMIT) never stop a campaign and are counted apart (`n_runner`): re-run those
+ * ranges with madsim_hip_run_batch_auto. */
+#define MADSIM_CAMPAIGN_STOP_AT_FAILURE 1u
+typedef struct madsim_campaign {
+    uint64_t seeds_run;           /* seeds whose batch ran to completion and was read (a prefix of the range)                 */
+    uint64_t batches_run;
+    uint64_t batches_launched;    /* >= batches_run: with STOP_AT_FAILURE the batches in flight when the failure was read      */
+    uint64_t first_failing_seed;  /* smallest seed with a genuine verdict among seeds_run; UINT64_MAX if none                  */
+    uint64_t n_failed;            /* genuine failures among seeds_run                                                          */
+    uint64_t n_runner;            /* seeds that came back with a runner verdict (not failures; to be re-run)                   */
+    uint64_t total_steps, total_clock_ns;
+    double   kernel_ms;           /* sum of the simulation kernels' HIP-event durations (they overlap: > wall time)            */
+    double   wall_s;
+} madsim_campaign_t;
+int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* ctx, const madsim_workload_t* w, const madsim_config_t* cfg,
+                                uint64_t seed0, uint64_t total, uint64_t batch, uint32_t in_flight, uint32_t flags,
+                                const madsim_limits_t* lim, madsim_campaign_t* out);
+int madsim_hip_run_campaign(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t total,
+                            uint64_t batch, uint32_t in_flight, uint32_t flags, const madsim_limits_t* lim,
+                            madsim_campaign_t* out);
+
 /* Geometry the library picked for a workload (for DESIGN/bench reporting). */
 typedef struct madsim_geometry {
     uint32_t lds_bytes_per_seed;

@@ -342,6 +342,21 @@ struct Builder {
         return b;
     }
 
+    // Seed search: seed .. seed + count as batches the LIBRARY keeps in flight on its own streams (madsim_hip_run_campaign),
+    // stopping at the first batch that holds a failing seed; prints the reproduction note for the seed it found.  No per-seed
+    // results: re-run the reported seed for details.
+    madsim_campaign_t search_first_failure(const Workload& wl) const {
+        madsim::check(madsim_hip_init(device));
+        madsim_workload_t w = wl.raw();
+        madsim_config_t cfg = config.raw();
+        madsim_limits_t lim = capacities;
+        if (time_limit) { lim.time_limit_ns = (uint64_t)(*time_limit * 1e9 + 0.5); if (!lim.time_limit_ns) lim.time_limit_ns = 1; }
+        madsim_campaign_t rep{};
+        madsim::check(madsim_hip_run_campaign(&w, &cfg, seed, count, 0, 0, MADSIM_CAMPAIGN_STOP_AT_FAILURE, &lim, &rep));
+        if (rep.first_failing_seed != UINT64_MAX) panic_with_info(rep.first_failing_seed);
+        return rep;
+    }
+
     // builder.rs:121-162: run seeds seed..seed+count; return on success, "panic" on the first failing seed.
     // Reports the numerically smallest failing seed (the reference reports the first to complete).
     std::vector<madsim_result_t> run(const Workload& wl) const {

@@ -53,7 +53,7 @@ class Workload(C.Structure):
     ]
 
 
-HEADER_STRUCTS = {"madsim_service_t": Service}
+HEADER_STRUCTS = {"madsim_service_t": Service}          # + madsim_campaign_t, registered below its definition
 
 
 class Config(C.Structure):
@@ -103,6 +103,18 @@ class Summary(C.Structure):
     ]
 
 
+class Campaign(C.Structure):
+    """madsim_campaign_t: the report of madsim_hip_run_campaign (batches kept in flight by the library)."""
+    _fields_ = [
+        ("seeds_run", C.c_uint64), ("batches_run", C.c_uint64), ("batches_launched", C.c_uint64),
+        ("first_failing_seed", C.c_uint64), ("n_failed", C.c_uint64), ("n_runner", C.c_uint64),
+        ("total_steps", C.c_uint64), ("total_clock_ns", C.c_uint64), ("kernel_ms", C.c_double), ("wall_s", C.c_double),
+    ]
+
+
+CAMPAIGN_STOP_AT_FAILURE = 1
+
+
 class Geometry(C.Structure):
     _fields_ = [
         ("lds_bytes_per_seed", C.c_uint32), ("lds_bytes_per_block", C.c_uint32), ("block_threads", C.c_uint32),
@@ -112,6 +124,7 @@ class Geometry(C.Structure):
     ]
 
 
+HEADER_STRUCTS["madsim_campaign_t"] = Campaign
 assert C.sizeof(Insn) == 8 and C.sizeof(Prog) == 4 and C.sizeof(Sock) == 4 and C.sizeof(Node) == 4
 assert C.sizeof(Result) == 48 and C.sizeof(Summary) == 48 and C.sizeof(Limits) == 64
 

@@ -86,6 +86,11 @@ struct madsim_hip_ctx {
     struct Scratch { uint4* spill = nullptr; size_t spill_bytes = 0; unsigned long long* work_ctr = nullptr; uint8_t* gstate = nullptr; size_t gstate_bytes = 0; };
     std::unordered_map<hipStream_t, Scratch> scratch;
     hipStream_t own_stream = nullptr;         // madsim_hip_run_batch_multi launches here so devices overlap
+    // madsim_hip_ctx_run_campaign: batches in flight on the context's own streams
+    static constexpr int CAMPAIGN_MAX = 8;
+    struct Flight { hipStream_t stream = nullptr; madsim_result_t* d_out = nullptr; size_t cap = 0; unsigned long long* d_acc6 = nullptr;
+                    unsigned long long* h_acc6 = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr; };
+    Flight flights[CAMPAIGN_MAX];
     unsigned long long* d_acc = nullptr;      // 4 x u64 summary accumulators
     madsim_result_t* d_out = nullptr; size_t out_cap = 0;
     madsim_result_t* h_pinned = nullptr; size_t pinned_cap = 0;   // host staging of madsim_hip_run_batch_multi (page-locked: async D2H)
@@ -163,6 +168,16 @@ void madsim_hip_ctx::close() {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (own_stream) (void)hipStreamDestroy(own_stream);
+    for (auto& f : flights) {
+        if (f.stream) (void)hipStreamDestroy(f.stream);
+        if (f.d_out) (void)hipFree(f.d_out);
+        if (f.d_acc6) (void)hipFree(f.d_acc6);
+        if (f.h_acc6) (void)hipHostFree(f.h_acc6);
+        if (f.e0) (void)hipEventDestroy(f.e0);
+        if (f.e1) (void)hipEventDestroy(f.e1);
+        if (f.done) (void)hipEventDestroy(f.done);
+        f = Flight();
+    }
     for (auto& e : tev) if (e) (void)hipEventDestroy(e);
     d_acc = nullptr; d_out = nullptr; h_pinned = nullptr; d_seeds = nullptr; d_tlog = nullptr; d_tlen = nullptr; d_prof = nullptr;
     ev0 = ev1 = nullptr; own_stream = nullptr; out_cap = pinned_cap = seeds_cap = tlog_cap = 0;
@@ -669,6 +684,89 @@ int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const m
     return 0;
 }
 
+// ---- campaigns -------------------------------------------------------------------------------------------------------------
+int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* c, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t total,
+                                uint64_t batch, uint32_t in_flight, uint32_t flags, const madsim_limits_t* lim, madsim_campaign_t* out) {
+    if (!out) return fail(MADSIM_E_ARG, "null campaign report");
+    CTX_ENTER(c);
+    auto t0 = std::chrono::steady_clock::now();
+    memset(out, 0, sizeof *out);
+    out->first_failing_seed = UINT64_MAX;
+    int rc = madsim_geo::validate(w, cfg, &g_err);
+    if (rc) return rc;
+    if (batch == 0) batch = 65536;
+    if (in_flight == 0) in_flight = 3;
+    if (in_flight > (uint32_t)madsim_hip_ctx::CAMPAIGN_MAX) return fail(MADSIM_E_ARG, "at most 8 batches in flight");
+    if (seed0 + total < seed0) return fail(MADSIM_E_ARG, "seed0 + total wraps");
+    if (total == 0) return 0;
+    const uint64_t n_batches = (total + batch - 1) / batch;
+    if (n_batches < in_flight) in_flight = (uint32_t)n_batches;
+    for (uint32_t i = 0; i < in_flight; i++) {
+        madsim_hip_ctx::Flight& f = c->flights[i];
+        if (!f.stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+            HIP_TRY(hipMalloc(&f.d_acc6, 6 * sizeof(unsigned long long)));
+            HIP_TRY(hipHostMalloc((void**)&f.h_acc6, 6 * sizeof(unsigned long long), hipHostMallocDefault));
+            HIP_TRY(hipEventCreate(&f.e0)); HIP_TRY(hipEventCreate(&f.e1)); HIP_TRY(hipEventCreate(&f.done));
+        }
+        if (batch > f.cap) {
+            if (f.d_out) { HIP_TRY(hipStreamSynchronize(f.stream)); (void)hipFree(f.d_out); }
+            f.d_out = nullptr; f.cap = 0;
+            HIP_TRY(hipMalloc(&f.d_out, batch * sizeof(madsim_result_t)));
+            f.cap = batch;
+        }
+    }
+    int first_err = 0;
+    std::string first_msg;
+    auto queue = [&](uint64_t k) -> int {                       // batch k on flight k % in_flight
+        madsim_hip_ctx::Flight& f = c->flights[k % in_flight];
+        const uint64_t lo = k * batch, n = std::min(batch, total - lo);
+        int e;
+        HIP_TRY(hipMemsetAsync(f.d_acc6, 0xff, 8, f.stream));
+        HIP_TRY(hipMemsetAsync((char*)f.d_acc6 + 8, 0, 24, f.stream));
+        HIP_TRY(hipMemsetAsync((char*)f.d_acc6 + 32, 0xff, 8, f.stream));
+        HIP_TRY(hipMemsetAsync((char*)f.d_acc6 + 40, 0, 8, f.stream));
+        HIP_TRY(hipEventRecord(f.e0, f.stream));
+        if ((e = c->launch(w, cfg, seed0 + lo, n, nullptr, lim, f.d_out, f.stream))) return e;
+        HIP_TRY(hipEventRecord(f.e1, f.stream));
+        madsim_k_launch_summary6(f.d_out, n, seed0 + lo, f.d_acc6, f.stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(f.h_acc6, f.d_acc6, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, f.stream));
+        HIP_TRY(hipEventRecord(f.done, f.stream));
+        return 0;
+    };
+    bool stop = false;
+    auto harvest = [&](uint64_t k) -> int {                     // wait for batch k, fold its report (batches are read in order)
+        madsim_hip_ctx::Flight& f = c->flights[k % in_flight];
+        HIP_TRY(hipEventSynchronize(f.done));
+        if (first_err) return 0;                                // (draining after an error: nothing is folded any more)
+        const uint64_t lo = k * batch, n = std::min(batch, total - lo);
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, f.e0, f.e1));
+        if (!stop) {                                            // batches launched beyond the failing one are not part of the answer
+            out->kernel_ms += ms;
+            out->batches_run++; out->seeds_run += n;
+            out->n_runner += f.h_acc6[5];
+            out->n_failed += f.h_acc6[1] - f.h_acc6[5];
+            out->total_steps += f.h_acc6[2]; out->total_clock_ns += f.h_acc6[3];
+            if (f.h_acc6[4] < out->first_failing_seed) out->first_failing_seed = f.h_acc6[4];
+            if ((flags & MADSIM_CAMPAIGN_STOP_AT_FAILURE) && f.h_acc6[4] != UINT64_MAX) stop = true;
+        }
+        return 0;
+    };
+    auto note = [&](int e) { if (e && !first_err) { first_err = e; first_msg = g_err; } };
+    uint64_t launched = 0, harvested = 0;
+    while (harvested < launched || (launched < n_batches && !stop && !first_err)) {
+        if (launched < n_batches && !stop && !first_err && launched - harvested < in_flight) { note(queue(launched)); launched++; continue; }
+        note(harvest(harvested)); harvested++;                  // the oldest batch in flight: its stream takes the next launch
+    }
+    out->batches_launched = launched;
+    out->wall_s = since(t0);
+    if (first_err) return fail(first_err, first_msg);
+    return 0;
+}
+
+
 // ---- v1 entry points: wrappers on the process-default context ------------------------------------------------------------
 // The default context is reference-counted by its users: a wrapper pins it under g_default_mu for the duration of its call,
 // and madsim_hip_shutdown waits until no call is inside before destroying it — a concurrent run_batch and shutdown is a
@@ -737,6 +835,12 @@ int64_t madsim_hip_trace_seed(const madsim_workload_t* w, const madsim_config_t*
                               const madsim_limits_t* lim, uint8_t* log, uint64_t cap, madsim_result_t* out) {
     DefaultPin p;
     return madsim_hip_ctx_trace_seed(p.c, w, cfg, seed, lim, log, cap, out);
+}
+
+int madsim_hip_run_campaign(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t total, uint64_t batch,
+                            uint32_t in_flight, uint32_t flags, const madsim_limits_t* lim, madsim_campaign_t* out) {
+    DefaultPin p;
+    return madsim_hip_ctx_run_campaign(p.c, w, cfg, seed0, total, batch, in_flight, flags, lim, out);
 }
 
 int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* out) {

@@ -133,6 +133,7 @@ inline VariantSel select_variant(const KParams& P, bool trace) {
 extern "C" {
 int  madsim_k_launch_sim(const madsim_k::KParams* P, uint32_t grid, uint32_t lds_bytes, void* stream, int trace);
 void madsim_k_launch_summary(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc, void* stream);
+void madsim_k_launch_summary6(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc6, void* stream);
 int  madsim_k_set_max_lds(uint32_t lds_bytes);
 int  madsim_k_variant_vgprs(const madsim_k::VariantSel* v);
 void madsim_k_launch_keyflip(unsigned long long* acc, void* stream);

@@ -64,6 +64,31 @@ __global__ __launch_bounds__(256) void summary_kernel(const madsim_result_t* __r
     }
 }
 
+// the campaign form: also tells the RUNNER verdicts (device capacity, step cap: not reference verdicts) from genuine failures —
+// acc6 = {first failing seed, n_failed, steps, clock, first seed with a GENUINE verdict (panic / deadlock / time limit), n runner verdicts}
+__global__ __launch_bounds__(256) void summary6_kernel(const madsim_result_t* __restrict__ out, uint64_t count,
+                                                       uint64_t seed0, unsigned long long* __restrict__ acc) {
+    unsigned long long first = ~0ull, nfail = 0, steps = 0, clk = 0, gfirst = ~0ull, nrun = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 r = reinterpret_cast<const uint4*>(out + i)[0];
+        if (r.x != MADSIM_PASS) {
+            const unsigned long long s = seed0 + i;
+            nfail++; first = s < first ? s : first;
+            if (r.x == MADSIM_OVERFLOW || r.x == MADSIM_STEP_LIMIT) nrun++; else gfirst = s < gfirst ? s : gfirst;
+        }
+        steps += r.y; clk += ((unsigned long long)r.w << 32) | r.z;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long f2 = __shfl_xor(first, o), g2 = __shfl_xor(gfirst, o);
+        first = f2 < first ? f2 : first; gfirst = g2 < gfirst ? g2 : gfirst;
+        nfail += __shfl_xor(nfail, o); steps += __shfl_xor(steps, o); clk += __shfl_xor(clk, o); nrun += __shfl_xor(nrun, o);
+    }
+    if ((threadIdx.x & 63) == 0) {                                      // one set of atomics per wave (<= 1 024 per launch)
+        atomicMin(&acc[0], first); atomicAdd(&acc[1], nfail); atomicAdd(&acc[2], steps); atomicAdd(&acc[3], clk);
+        atomicMin(&acc[4], gfirst); atomicAdd(&acc[5], nrun);
+    }
+}
+
 __global__ void keyflip_kernel(unsigned long long* acc) { acc[0] ^= 0x8000000000000000ull; }
 
 }  // namespace madsim_k
@@ -88,6 +113,13 @@ extern "C" void madsim_k_launch_summary(const madsim_result_t* out, uint64_t cou
     if (grid > 256) grid = 256;
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(madsim_k::summary_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, count, seed0, acc);
+}
+
+extern "C" void madsim_k_launch_summary6(const madsim_result_t* out, uint64_t count, uint64_t seed0, unsigned long long* acc6, void* stream) {
+    uint32_t grid = (uint32_t)((count + 1023) / 1024);
+    if (grid > 256) grid = 256;
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(madsim_k::summary6_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, count, seed0, acc6);
 }
 
 extern "C" void madsim_k_launch_keyflip(unsigned long long* acc, void* stream) {

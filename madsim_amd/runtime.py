@@ -102,6 +102,9 @@ def lib():
         L.madsim_hip_run_batch_multi.argtypes = [C.POINTER(ctxp), C.c_int, C.POINTER(A.Workload), C.POINTER(A.Config),
                                                  C.c_uint64, C.c_uint64, C.POINTER(A.Limits), C.c_void_p,
                                                  C.POINTER(A.Summary), C.c_int]
+        L.madsim_hip_run_campaign.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64, C.c_uint64, C.c_uint64,
+                                              C.c_uint32, C.c_uint32, C.POINTER(A.Limits), C.POINTER(A.Campaign)]
+        L.madsim_hip_ctx_run_campaign.argtypes = [ctxp] + L.madsim_hip_run_campaign.argtypes
         if L.madsim_hip_version() != A.ABI_VERSION:
             raise MadsimHipError("libmadsim_hip.so ABI version mismatch")
         # build identity: MADSIM_HIP_LIB may name an A/B build of THIS library (tools/build_variant.sh), nothing else — an
@@ -183,6 +186,20 @@ def run_batch_auto(workload, seed0, count, config=None, limits=None, max_rounds=
     _check(lib().madsim_hip_run_batch_auto(workload.ref(), C.byref(cfg), seed0, count, C.byref(lim),
                                            out.ctypes.data_as(C.c_void_p), C.byref(summ), max_rounds))
     return out, summ
+
+
+def run_campaign(workload, seed0, total, batch=0, in_flight=0, stop_at_failure=False, config=None, limits=None):
+    """madsim_hip_run_campaign: `total` seeds as batches kept in flight on the library's own streams; returns the Campaign
+    report (first failing seed, counts) — no per-seed results.  stop_at_failure: stop launching once a completed batch holds a
+    seed with a genuine verdict."""
+    if _inited_device is None:
+        init(0)
+    cfg = config or A.Config.default()
+    lim = limits or A.Limits()
+    rep = A.Campaign()
+    _check(lib().madsim_hip_run_campaign(workload.ref(), C.byref(cfg), seed0, total, batch, in_flight,
+                                         A.CAMPAIGN_STOP_AT_FAILURE if stop_at_failure else 0, C.byref(lim), C.byref(rep)))
+    return rep
 
 
 def run_batch_device(workload, seed0, count, d_out_ptr, stream_ptr=0, config=None, limits=None, want_summary=True):

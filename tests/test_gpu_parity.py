@@ -714,3 +714,30 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(hip):
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
     assert line["config"]["seeds_per_step"] == 2 * 65536 and line["verified_seeds"] >= 2 * 256
     assert line["extra"]["failed_seeds"] == 0 and line["extra"]["seeds_per_sec"] > 0
+
+
+def test_campaign_keeps_batches_in_flight_and_reports_like_the_oracle(hip):
+    """madsim_hip_run_campaign: batches on the library's own streams, reports folded in order.  Without STOP the report is the
+    oracle's over the whole range; with STOP_AT_FAILURE it is the oracle's first failing seed, found after reading exactly the
+    batches up to it, at most in_flight - 1 launched beyond; runner verdicts are counted apart and never stop a campaign."""
+    w = W.pingpong(4, 16)
+    cfg = A.Config.default(packet_loss_rate=0.002)
+    total, batch = 40_000, 4096                                     # ragged last batch
+    rep = hip.run_campaign(w, 5_000_000, total, batch, 3, False, cfg)
+    want, osum = oracle.run_batch(w, 5_000_000, total, cfg)
+    assert (rep.seeds_run, rep.batches_run, rep.batches_launched) == (total, 10, 10)
+    assert (rep.n_failed, rep.first_failing_seed, rep.total_steps, rep.n_runner) == (osum.n_failed, osum.first_failing_seed, osum.total_steps, 0)
+    assert rep.n_failed > 0 and rep.total_clock_ns == int(want["clock_ns"].sum())
+    # rare failures: stop at the first batch that has one
+    cfg = A.Config.default(packet_loss_rate=0.000002)
+    rep = hip.run_campaign(w, 9_000_000, 64 * batch, batch, 3, True, cfg)
+    assert rep.first_failing_seed != (1 << 64) - 1
+    off = rep.first_failing_seed - 9_000_000
+    j = off // batch
+    assert rep.batches_run == j + 1 and rep.seeds_run == (j + 1) * batch and j + 1 <= rep.batches_launched <= j + 3
+    want, _ = oracle.run_batch(w, 9_000_000, off + 1, cfg)
+    assert (want["verdict"][:-1] == A.PASS).all() and want["verdict"][-1] != A.PASS
+    # a capacity nobody fits: runner verdicts only
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 2, 0
+    rep = hip.run_campaign(w, 0, 3 * batch, batch, 2, True, None, lim)
+    assert (rep.n_runner, rep.n_failed, rep.batches_run) == (3 * batch, 0, 3) and rep.first_failing_seed == (1 << 64) - 1
