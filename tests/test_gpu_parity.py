@@ -741,3 +741,34 @@ def test_campaign_keeps_batches_in_flight_and_reports_like_the_oracle(hip):
     lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 2, 0
     rep = hip.run_campaign(w, 0, 3 * batch, batch, 2, True, None, lim)
     assert (rep.n_runner, rep.n_failed, rep.batches_run) == (3 * batch, 0, 3) and rep.first_failing_seed == (1 << 64) - 1
+
+
+def test_run_batch_multi_from_two_threads_with_permuted_context_lists(hip):
+    """madsim_hip_run_batch_multi takes its context locks in address order: two host threads handing it the same contexts in
+    opposite orders must both finish (no lock-order deadlock) with the single-context answer; an error after the first
+    launch (a workload the second validation refuses is impossible to stage, so: a capacity the device cannot fit) comes back
+    as an error code with nothing left in flight — the next call on the same contexts works."""
+    import threading
+    w = W.pingpong(4, 8)
+    ref, rsum = hip.run_batch(w, 1234, 6000)
+    with hip.Context(0) as c0, hip.Context(0) as c1:
+        outs, errs = {}, []
+
+        def work(tag, ctxs):
+            try:
+                for _ in range(6):
+                    outs[tag] = hip.run_batch_multi(ctxs, w, 1234, 6000)
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        ta = threading.Thread(target=work, args=("a", [c0, c1])); tb = threading.Thread(target=work, args=("b", [c1, c0]))
+        ta.start(); tb.start(); ta.join(120); tb.join(120)
+        assert not ta.is_alive() and not tb.is_alive(), "deadlock: the two calls never returned"
+        assert not errs, errs
+        for tag in ("a", "b"):
+            got, summ = outs[tag]
+            assert (got == ref).all() and summ.first_failing_seed == rsum.first_failing_seed and summ.total_steps == rsum.total_steps
+        bad = A.Limits(); bad.heap_lds_slots = 100000                    # per-seed LDS far beyond a CU: make_geometry refuses it
+        with pytest.raises(hip.MadsimHipError):
+            hip.run_batch_multi([c0, c1], w, 1234, 6000, None, bad)
+        got, _ = hip.run_batch_multi([c0, c1], w, 1234, 6000)            # the contexts are intact
+        assert (got == ref).all()
