@@ -23,6 +23,43 @@ thread_local uint32_t* emu_smem;
 
 static thread_local std::string emu_err;
 
+#ifdef MADSIM_EMU_SITES
+// Memory-site model (tools/mem_site_model.py; needs MADSIM_EMU_REGIONS for the iteration marks and a -O0 -fno-omit-frame-pointer
+// build): every global access is keyed by the chain of return addresses above it — on the GPU everything is inlined, so one
+// chain = one machine instruction site — and counted per lane and main-loop iteration; a wave issues the site's instruction
+// max-over-lanes times per iteration.
+#include <unordered_map>
+#include <map>
+static constexpr int SITE_DEPTH = 7;
+struct SiteKey { uintptr_t ra[SITE_DEPTH]; int kind; bool operator<(const SiteKey& o) const { return memcmp(this, &o, sizeof *this) < 0; } };
+static std::map<SiteKey, uint32_t> site_ids;
+static std::vector<SiteKey> site_keys;
+static thread_local std::vector<std::unordered_map<uint32_t, uint16_t>>* emu_site_log = nullptr;
+static std::vector<double> site_trips, site_visits;
+__attribute__((noinline)) void madsim_k::emu_site(int kind, const void*, uint32_t) {
+    if (!emu_site_log || emu_site_log->empty()) return;
+    SiteKey k; memset(&k, 0, sizeof k); k.kind = kind;
+    void** fp = (void**)__builtin_frame_address(0);
+    fp = (void**)fp[0];                                     // skip emu_site's caller frame (buf_load/store itself)
+    for (int i = 0; i < SITE_DEPTH && fp; i++) {
+        k.ra[i] = (uintptr_t)fp[1];
+        void** up = (void**)fp[0];
+        if (up <= fp || (uintptr_t)up - (uintptr_t)fp > (1u << 20) || ((uintptr_t)up & 7)) break;      // left the frames built with frame pointers
+        fp = up;
+    }
+    auto it = site_ids.find(k);
+    uint32_t id;
+    if (it == site_ids.end()) { id = (uint32_t)site_keys.size(); site_ids.emplace(k, id); site_keys.push_back(k); } else id = it->second;
+    (*emu_site_log).back()[id]++;
+}
+extern "C" uint32_t madsim_emu_site_count(void) { return (uint32_t)site_keys.size(); }
+extern "C" void madsim_emu_site(uint32_t id, uintptr_t* ra, int* kind, double* trips, double* visits) {
+    for (int i = 0; i < SITE_DEPTH; i++) ra[i] = site_keys[id].ra[i];
+    *kind = site_keys[id].kind; *trips = id < site_trips.size() ? site_trips[id] : 0; *visits = id < site_visits.size() ? site_visits[id] : 0;
+}
+extern "C" void madsim_emu_anchor(void) {}
+#endif
+
 #ifdef MADSIM_EMU_REGIONS
 // Divergence model: every lane logs how often it visits each marked code region in each main-loop iteration; a
 // wave executes a region max-over-lanes times per iteration (lanes re-converge at the loop top), so
@@ -34,7 +71,12 @@ static constexpr int NREG = 32;
 static thread_local std::vector<std::array<uint16_t, NREG>>* emu_lane_log = nullptr;
 void emu_region(int id) {
     if (!emu_lane_log) return;
-    if (id == 0) emu_lane_log->push_back({});
+    if (id == 0) {
+        emu_lane_log->push_back({});
+#ifdef MADSIM_EMU_SITES
+        if (emu_site_log) emu_site_log->push_back({});
+#endif
+    }
     if (emu_lane_log->empty()) return;
     emu_lane_log->back()[id]++;
 }
@@ -97,9 +139,15 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
 #ifdef MADSIM_EMU_REGIONS
         std::vector<std::vector<std::array<uint16_t, NREG>>> logs(G.lanes_per_wave);
 #endif
+#ifdef MADSIM_EMU_SITES
+        std::vector<std::vector<std::unordered_map<uint32_t, uint16_t>>> slogs(G.lanes_per_wave);
+#endif
         for (uint32_t t = 0; t < G.lanes_per_wave; t++) {
 #ifdef MADSIM_EMU_REGIONS
             emu_lane_log = &logs[t];
+#endif
+#ifdef MADSIM_EMU_SITES
+            emu_site_log = &slogs[t];
 #endif
             blockIdx.x = b / G.waves_per_block; threadIdx.x = (b % G.waves_per_block) * 64 + t; emu_smem = base;
             using namespace madsim_k;
@@ -111,6 +159,23 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
 #undef EMU_TRY
             if (!ran) { emu_err = "select_variant named a build that is not compiled"; return MADSIM_E_LIMITS; }
         }
+#ifdef MADSIM_EMU_SITES
+        emu_site_log = nullptr;
+        {
+            size_t its = 0;
+            for (auto& l : slogs) its = l.size() > its ? l.size() : its;
+            std::unordered_map<uint32_t, uint32_t> mx;
+            for (size_t i = 0; i < its; i++) {
+                mx.clear();
+                for (auto& l : slogs) if (i < l.size()) for (auto& kv : l[i]) {
+                    if (site_visits.size() <= kv.first) { site_visits.resize(kv.first + 1); site_trips.resize(kv.first + 1); }
+                    site_visits[kv.first] += kv.second;
+                    uint32_t& m = mx[kv.first]; if (kv.second > m) m = kv.second;
+                }
+                for (auto& kv : mx) site_trips[kv.first] += kv.second;
+            }
+        }
+#endif
 #ifdef MADSIM_EMU_REGIONS
         emu_lane_log = nullptr;
         size_t iters = 0;

@@ -38,10 +38,16 @@ namespace madsim_k {
 #define SMEM emu_smem
 struct BufRef { uint8_t* base; };
 static inline BufRef buf_make(const void* base, uint64_t) { return BufRef{(uint8_t*)base}; }
-static inline uint32_t buf_load32(const BufRef& b, uint32_t off) { return *(const uint32_t*)(b.base + off); }
-static inline void buf_store32(const BufRef& b, uint32_t off, uint32_t v) { *(uint32_t*)(b.base + off) = v; }
-static inline uint4 buf_load128(const BufRef& b, uint32_t off) { return *(const uint4*)(b.base + off); }
-static inline void buf_store128(const BufRef& b, uint32_t off, const uint4& e) { *(uint4*)(b.base + off) = e; }
+#ifdef MADSIM_EMU_SITES     // tools/mem_site_model.py: which machine-level site (= inlining context) issues each global access
+void emu_site(int kind, const void* base, uint32_t off);
+#define EMU_SITE(kind, b, off) emu_site((kind), (b).base, (off))
+#else
+#define EMU_SITE(kind, b, off) do { } while (0)
+#endif
+static inline uint32_t buf_load32(const BufRef& b, uint32_t off) { EMU_SITE(0, b, off); return *(const uint32_t*)(b.base + off); }
+static inline void buf_store32(const BufRef& b, uint32_t off, uint32_t v) { EMU_SITE(1, b, off); *(uint32_t*)(b.base + off) = v; }
+static inline uint4 buf_load128(const BufRef& b, uint32_t off) { EMU_SITE(2, b, off); return *(const uint4*)(b.base + off); }
+static inline void buf_store128(const BufRef& b, uint32_t off, const uint4& e) { EMU_SITE(3, b, off); *(uint4*)(b.base + off) = e; }
 template <int K_> static inline uint64_t rotl64(uint64_t x) { return (x << K_) | (x >> (64 - K_)); }
 static inline uint64_t add64_1(uint64_t a, uint64_t b) { return a + b; }
 template <int K_> static inline uint64_t shl64(uint64_t x) { return x << K_; }
