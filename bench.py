@@ -459,6 +459,54 @@ def main():
                     "ms_per_batch": rep.wall_s / nb * 1e3, "seeds_per_sec": rep.seeds_run / rep.wall_s,
                     "executor_steps_per_sec": rep.total_steps / rep.wall_s, "failed_seeds": int(rep.n_failed), "runner_verdicts": int(rep.n_runner)}
 
+    # extra.plain_run: the same step without the per-seed fingerprint of the determinism log (madsim_limits_t.no_trace_hash) — the
+    # reference's own Builder::run computes log bytes only under check_determinism (rand.rs:67), so this is the mode a drop-in test
+    # run needs; the headline keeps the fingerprint (all 48 result bytes oracle-checked).  Same streams, same batch size, its own
+    # timed region and its own oracle check (the oracle honours the same flag).
+    plain = None
+    if not args.no_extras and world == 1 and headline and not args.loss and use_device_report:
+        import copy
+        plim = copy.copy(lim); plim.no_trace_hash = 1
+        psteps, pwu = max(args.steps, 12), 4
+        pring = torch.zeros((psteps + pwu, REPORT_WORDS), dtype=torch.int64, device=dev)
+        plast = {}
+
+        def pstep(k, timed):
+            si = k % n_streams
+            with torch.cuda.stream(streams[si]):
+                runtime.run_batch_async(w, (1 << 45) + k * count, count, d_outs[si].data_ptr(), pring[k].data_ptr(),
+                                        streams[si].cuda_stream, cfg, plim, timing_slot=(k % 64) if timed else -1)
+            plast[si] = k
+        for k in range(pwu):
+            pstep(k, False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(psteps):
+            pstep(pwu + k, True)
+        torch.cuda.synchronize()
+        pdt = time.perf_counter() - t1
+        prows = pring[pwu:].cpu()
+        pfail, psteps_total, pclock = (int(x) for x in prows[:, 1:4].sum(dim=0).tolist())
+        pver = 0
+        if not args.no_verify:
+            import oracle
+            for si, k in sorted(plast.items()):
+                got = np.frombuffer(d_outs[si].cpu().numpy().tobytes(), dtype=A.RESULT_DTYPE)
+                for jj in range(128):
+                    i = (jj * 509) % count
+                    want, _ = oracle.run_batch(w, (1 << 45) + k * count + i, 1, cfg, plim)
+                    if got[i] != want[0] or int(got[i]["trace_hash"]) != 0:
+                        print(f"bench.py: VERIFY FAILED plain run seed {(1 << 45) + k * count + i}: gpu {got[i]} != oracle {want[0]}", file=sys.stderr)
+                        return 3
+                    pver += 1
+        pg = runtime.geometry(w, plim)
+        plain = {"what": "madsim_limits_t.no_trace_hash = 1: results without the determinism-log fingerprint (the reference logs only under "
+                         "check_determinism, rand.rs:67); every other result field as in the headline run",
+                 "steps": psteps, "warmup": pwu, "concurrent_batches": n_streams, "ms_per_step": pdt / psteps * 1e3,
+                 "seeds_per_sec": psteps * count / pdt, "executor_steps_per_sec": psteps_total / pdt,
+                 "sim_seconds_per_sec": pclock / 1e9 / pdt, "failed_seeds": pfail, "verified_seeds": pver,
+                 "kernel": runtime.variant_name(pg)}
+
     first_fail_rare = first_fail_very_rare = None
     if not args.no_first_fail and world == 1 and args.workload == "pingpong":
         first_fail_rare = rare_search(args.rare_loss, 1 << 43)
@@ -612,7 +660,7 @@ def main():
                       "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu * g.block_threads // 64,
                       "lanes_per_wave": g.lanes_per_wave, "rccl_ranks": rccl_ranks, "first_fail": first_fail,
                       "first_fail_rare": first_fail_rare, "first_fail_very_rare": first_fail_very_rare,
-                      "workloads": extras, "campaign": campaign,
+                      "workloads": extras, "campaign": campaign, "plain_run": plain,
                       "stream_trial_ms_per_step": stream_trial,
                       "first_fail_seeds_per_hour": (first_fail_rare or {}).get("seeds_per_hour") or (first_fail["seeds_per_hour"] if first_fail else None)},
             "roofline": roof,

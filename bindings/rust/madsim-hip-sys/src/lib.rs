@@ -99,7 +99,7 @@ pub struct madsim_limits_t {
     pub sched: u32,
     pub state_mem: u32,
     pub max_steps_ceiling: u32,
-    pub reserved: u32,
+    pub no_trace_hash: u32,
 }
 
 #[repr(C)]

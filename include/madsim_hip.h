@@ -294,7 +294,11 @@ typedef struct madsim_limits {
                                     may use; 0 = default (1 << 28: the first pass's 1 << 24, then ONE 16x round).  A seed that
                                     still hits the cap keeps the MADSIM_STEP_LIMIT verdict: a livelocked workload (a yield or
                                     1 ms timer loop without a time limit) costs seconds, not one hour-long kernel              */
-    uint32_t reserved;           /* 0 */
+    uint32_t no_trace_hash;      /* non-zero: do not fold the determinism log into madsim_result_t.trace_hash (it comes back 0).
+                                    The reference computes a log byte per RNG call only while check_determinism logs or checks
+                                    (rand.rs:67 `if lock.log.is_some() || lock.check.is_some()`); the per-seed fingerprint of
+                                    that log in every result is an extra of this runner — 0 keeps it (default), a plain
+                                    Builder::run needs none of it (measured: 4 % faster on the ping-pong kernel; madsim_hip_trace_seed always logs) */
 } madsim_limits_t;
 
 #define MADSIM_STATE_AUTO   0u   /* LDS unless an extended-op workload's state leaves a CU fewer than 4 full waves       */
@@ -490,7 +494,8 @@ typedef struct madsim_geometry {
     uint32_t lanes_per_wave;
     uint32_t variant;              /* kernel specialisation: bit0 heap spill, bit1 extended ops, bit2 ready queue in a
                                     * register, bit3 runtime lane stride, bit4 global-state build; bits 8-12 = classes of extended ops compiled in
-                                    * (1 timeouts, 2 channel, 4 RPC, 8 node lifecycle, 16 general address resolution); bits 16-19 = compile-time log2 lane
+                                    * (1 timeouts, 2 channel, 4 RPC, 8 node lifecycle, 16 general address resolution), bit 13 = built without the determinism-log
+                                    * fold (madsim_limits_t.no_trace_hash on a base-op workload); bits 16-19 = compile-time log2 lane
                                     * stride (15 = runtime) */
     uint32_t global_bytes_per_seed; /* size of a lane's state block in global memory (global-state builds), else 0 */
 } madsim_geometry_t;

@@ -81,7 +81,7 @@ class Limits(C.Structure):
         ("time_limit_ns", C.c_uint64), ("max_steps", C.c_uint32), ("heap_lds_slots", C.c_uint32),
         ("heap_spill_slots", C.c_uint32), ("max_tasks", C.c_uint32), ("mbox_regs", C.c_uint32),
         ("mbox_msgs", C.c_uint32), ("lanes_per_wave", C.c_uint32), ("max_conns", C.c_uint32), ("chan_queue", C.c_uint32),
-        ("sched", C.c_uint32), ("state_mem", C.c_uint32), ("max_steps_ceiling", C.c_uint32), ("reserved", C.c_uint32),
+        ("sched", C.c_uint32), ("state_mem", C.c_uint32), ("max_steps_ceiling", C.c_uint32), ("no_trace_hash", C.c_uint32),
     ]
 
 

@@ -206,6 +206,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     for (int i = 0; i < 4; i++) bernoulli(i < (int)cfg->n_loss_table ? cfg->loss_table[i] : 0.0, &P.loss_table_pint[i], &P.loss_table_always[i]);
     P.time_limit = L.time_limit_ns;
     P.max_steps = L.max_steps ? L.max_steps : (1u << 24);
+    P.no_log = L.no_trace_hash ? 1u : 0u;
     bool restarts = uses_op(w, MS_OP_RESTART);
     for (uint32_t i = 0; i <= w->n_nodes && w->nodes; i++) restarts |= (w->nodes[i].flags & (MADSIM_NODE_RESTART_ON_PANIC | MADSIM_NODE_RESTART_MATCHING)) != 0;
     // request-per-connection servers spawn a handler per accept: leave room for a few concurrent ones

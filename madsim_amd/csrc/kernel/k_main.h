@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : M
             REG(25);
             madsim_result_t r;
             r.verdict = L.verdict; r.steps = L.steps; r.clock_ns = L.clock; r.msg_count = L.msg_count;
-            r.rng_calls = L.rng_calls; r.trace_hash = L.trace_hash; r.obs_hash = L.obs_hash;
+            r.rng_calls = L.rng_calls; r.trace_hash = (K::NOLOG || (K::LOGSW && P.no_log)) ? 0 : L.trace_hash; r.obs_hash = L.obs_hash;
             P.out[next] = r;
             if (K::TRACE) *P.trace_len = L.log_len;
             have = false;

@@ -41,7 +41,8 @@ __device__ __forceinline__ bool reject_const(uint64_t v, uint32_t zone_hi) {
 // One determinism-log byte per GlobalRng::with (rand.rs:64-88): clone.gen::<u8>() ^ xor-fold(elapsed).
 template <class K>
 __device__ __forceinline__ void rng_log(const Ctx& c, Lane& L) {
-    if (!MADSIM_K_LOG_ENABLED) return;
+    if (!MADSIM_K_LOG_ENABLED || K::NOLOG) return;
+    if (K::LOGSW && c.P.no_log) return;                    // (wave-uniform)
     uint64_t r = add64_1(rotl64<23>(L.s0 + L.s3), L.s0);   // what the clone's next_u64 would return
     uint32_t v = (uint32_t)(r >> 32);
     uint32_t f = (uint32_t)L.clock ^ (uint32_t)(L.clock >> 32);

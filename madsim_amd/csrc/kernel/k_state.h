@@ -58,8 +58,12 @@ enum : uint32_t { H_NONE = 0, H_RUNNING = 1, H_COMPLETED = 2, H_CANCELLED = 3 };
 // its lanes' op handlers), so a few hundred cycles of global latency per access are cheap next to 4-16x the seeds in flight.
 template <bool TRACE_, bool SPILL_, int LWS_, int FEAT_, bool RQ_ = false, bool G_ = false> struct Variant {
     static constexpr bool TRACE = TRACE_, SPILL = SPILL_, RQ = RQ_, G = G_;
-    static constexpr int LWS = LWS_, FEAT = FEAT_;
-    static constexpr bool LIFE = FEAT_ != 0;
+    static constexpr int LWS = LWS_, FEAT = FEAT_ & MADSIM_FEAT_ALL;
+    static constexpr bool LIFE = FEAT != 0;
+    // the determinism-log fold (rng_log): compiled out (a base-op twin selected by KParams.no_log), or compiled in behind a run-time
+    // test of KParams.no_log — every build except the base-op full-wave ones without a spill region, whose twin takes those launches
+    static constexpr bool NOLOG = (FEAT_ & MADSIM_FEAT_NOLOG) != 0;
+    static constexpr bool LOGSW = !NOLOG && !TRACE_ && (LIFE || SPILL_ || LWS_ != 6);
     static constexpr bool FT = (FEAT_ & MADSIM_FEAT_TIME) != 0, FC = (FEAT_ & MADSIM_FEAT_CHAN) != 0,
                           FR = (FEAT_ & MADSIM_FEAT_RPC) != 0, FN = (FEAT_ & MADSIM_FEAT_NODE) != 0,
                           FA = (FEAT_ & MADSIM_FEAT_ADDR) != 0;

@@ -856,7 +856,7 @@ int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, 
     out->blocks_per_cu = G.blocks_per_cu; out->grid_blocks = G.grid; out->heap_lds_slots = G.P.heap_lds;
     out->heap_spill_slots = G.P.heap_spill; out->max_tasks = G.P.max_tasks; out->lanes_per_wave = G.lanes_per_wave;
     const madsim_k::VariantSel v = madsim_k::select_variant(G.P, false);
-    out->variant = (v.spill ? 1u : 0u) | (v.feat ? 2u : 0u) | (v.rq ? 4u : 0u) | (v.lws < 0 ? 8u : 0u) | (v.g ? 16u : 0u) | ((uint32_t)v.feat << 8) | ((uint32_t)(v.lws & 0xf) << 16);
+    out->variant = (v.spill ? 1u : 0u) | ((v.feat & MADSIM_FEAT_ALL) ? 2u : 0u) | (v.rq ? 4u : 0u) | (v.lws < 0 ? 8u : 0u) | (v.g ? 16u : 0u) | ((uint32_t)v.feat << 8) | ((uint32_t)(v.lws & 0xf) << 16);
     out->global_bytes_per_seed = G.P.gstate_mode ? G.P.gs_stride : 0;
     return 0;
 }

@@ -16,6 +16,10 @@
 #define MADSIM_FEAT_ADDR 16 /* general address resolution (network.rs:272-313): 0.0.0.0 / 127.0.0.1 entries, IP-less nodes, several
                                table entries naming one address.  Builds without it take every address for a distinct node IP.   */
 #define MADSIM_FEAT_ALL  31
+/* Variant<..., FEAT, ...> only, never in KParams.features: a base-op build without the determinism-log fold (rng_log), selected
+   by KParams.no_log.  The other builds test KParams.no_log at run time (a wave-uniform branch); the base-op builds on full waves
+   are issue-bound, so they get a twin compiled without the code instead. */
+#define MADSIM_FEAT_NOLOG 32
 
 namespace madsim_k {
 
@@ -75,6 +79,7 @@ struct KParams {
     uint32_t total_lanes;
     // trace mode (single seed)
     uint8_t* trace_log; uint64_t trace_cap; uint64_t* trace_len;
+    uint32_t no_log;           // madsim_limits_t.no_trace_hash: skip rng_log, report trace_hash = 0 (trace launches ignore it)
     uint64_t* prof;            // profiling builds (tools/experiment): per-phase cycle accumulators
 };
 
@@ -88,6 +93,8 @@ struct KParams {
     X(true, true, -1, MADSIM_FEAT_ALL, false, false)   \
     X(false, false, 6, 0, false, false)                \
     X(false, false, 6, 0, true, false)                 \
+    X(false, false, 6, MADSIM_FEAT_NOLOG, false, false) \
+    X(false, false, 6, MADSIM_FEAT_NOLOG, true, false)  \
     X(false, true, 6, 0, true, false)                  \
     X(false, true, 6, 0, false, false)                 \
     X(false, true, -1, 0, false, false)                \
@@ -112,7 +119,7 @@ inline VariantSel select_variant(const KParams& P, bool trace) {
     const int spill = P.heap_spill > 0, lw = (int)P.lw_shift, feat = (int)P.features;
     if (trace) return {1, 1, -1, MADSIM_FEAT_ALL, 0, 0};
     if (feat == 0) {                                                    // base ops only
-        if (lw == 6) return {0, spill, 6, 0, (int)P.rq_in_reg, 0};
+        if (lw == 6) return {0, spill, 6, P.no_log && !spill ? MADSIM_FEAT_NOLOG : 0, (int)P.rq_in_reg, 0};
         return {0, 1, -1, 0, 0, 0};                                     // sub-wave lane stride: runtime-stride build
     }
     // single-class workloads: a build without the other classes' code

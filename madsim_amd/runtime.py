@@ -301,7 +301,7 @@ def variant_name(g):
     """The sim_kernel specialisation a madsim_geometry_t selects (madsim_k_launch_sim's dispatch), as rocprofv3 names it."""
     b = lambda x: "true" if x else "false"
     lws = (g.variant >> 16) & 0xf
-    return (f"sim_kernel<Variant<false, {b(g.variant & 1)}, {-1 if lws == 15 else lws}, {(g.variant >> 8) & 0x1f}, "
+    return (f"sim_kernel<Variant<false, {b(g.variant & 1)}, {-1 if lws == 15 else lws}, {(g.variant >> 8) & 0x3f}, "
             f"{b(g.variant & 4)}, {b(g.variant & 16)}>>")
 
 
@@ -330,6 +330,8 @@ class Builder:
         self.check = check
         self.allow_system_thread = allow_system_thread
         self.max_steps_ceiling = 0            # 0 = the library's default (1 << 28); not a reference field
+        self.trace_hash = True                # False: madsim_limits_t.no_trace_hash — results carry no fingerprint of the determinism
+                                              # log (the reference computes log bytes only under check_determinism, rand.rs:67)
 
     @classmethod
     def from_env(cls, env=None):
@@ -376,6 +378,7 @@ class Builder:
             # (task/mod.rs:253-258: `elapsed >= limit`), which a 1 ns limit reproduces exactly
             lim.time_limit_ns = max(1, int(round(self.time_limit * 1e9)))
         lim.max_steps_ceiling = self.max_steps_ceiling
+        lim.no_trace_hash = 0 if self.trace_hash else 1
         return lim
 
     def run(self, workload):

@@ -173,6 +173,7 @@ typedef struct {
     /* GlobalRng */
     xoshiro_t rng; uint64_t rng_calls; int buggify;
     uint64_t trace_hash; uint8_t* log; uint64_t log_len, log_cap;
+    int no_log;                          /* madsim_limits_t.no_trace_hash: the reference's plain run — `log` and `check` both None (rand.rs:67) */
     /* Clock + Timer */
     uint64_t clock;
     uint64_t base_time_ns; /* Clock.base_time since UNIX_EPOCH (time/mod.rs:26-33)                      */
@@ -207,6 +208,7 @@ static inline uint64_t rng_next(sim_t* S) { S->rng_calls++; return oracle_xoshir
 /* One call per GlobalRng::with(): v = clone.gen::<u8>() ^ xor-fold(elapsed.as_nanos() as u128).
  * gen::<u8>() = next_u32() as u8 [DEP rand 0.8 Standard]; next_u32 = (next_u64 >> 32) [DEP xoshiro]. */
 static void rng_log(sim_t* S) {
+    if (S->no_log) return;                                  /* rand.rs:67: neither logging nor checking */
     xoshiro_t c = S->rng;
     uint8_t v = (uint8_t)(oracle_xoshiro_next(c.s) >> 32);
     uint64_t t = S->clock;
@@ -1312,6 +1314,7 @@ static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, cons
     }
     S.trace_hash = FNV_OFFSET; S.obs_hash = FNV_OFFSET;
     S.log = log; S.log_cap = log_cap;
+    S.no_log = lim && lim->no_trace_hash && !log;          /* a trace request always logs, like madsim_hip_trace_seed */
     S.buggify = cfg->buggify != 0;
     S.loss_always = cfg->packet_loss_rate == 1.0;
     S.loss_pint = S.loss_always ? 0 : (uint64_t)(cfg->packet_loss_rate * 18446744073709551616.0);
@@ -1349,7 +1352,7 @@ static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, cons
         if (time_limit && !(S.clock < time_limit)) { verdict = MADSIM_TIME_LIMIT; break; }  /* :253-258 */
     }
     out->verdict = (uint32_t)verdict; out->steps = S.steps; out->clock_ns = S.clock;
-    out->msg_count = S.msg_count; out->rng_calls = S.rng_calls; out->trace_hash = S.trace_hash;
+    out->msg_count = S.msg_count; out->rng_calls = S.rng_calls; out->trace_hash = S.no_log ? 0 : S.trace_hash;
     out->obs_hash = S.obs_hash;
     if (log_len) *log_len = S.log_len;
     if (stats) {

@@ -306,3 +306,38 @@ def test_global_state_is_chosen_by_footprint_and_can_be_forced_either_way():
     lim = A.Limits(); lim.state_mem = 3
     with pytest.raises(runtime.MadsimHipError, match="state_mem"):
         runtime.geometry(small, lim)
+
+
+def _without_trace_hash(lim):
+    lim = lim or A.Limits()
+    lim.no_trace_hash = 1
+    return lim
+
+
+@pytest.mark.parametrize("case", ["pingpong", "pingpong_rq", "spill", "lanes16", "raft", "kv", "topo", "timers"])
+def test_no_trace_hash_drops_only_the_fingerprint(case):
+    """madsim_limits_t.no_trace_hash: the reference's plain run (rand.rs:67: no log, no check).  trace_hash comes back 0, every
+    other field is what the logging run reports — on the build compiled without the fold (base ops, full waves) and on the
+    builds that test the flag at run time; a trace request logs regardless."""
+    lim = None
+    if case == "pingpong":
+        w = W.pingpong(4, 16)
+    elif case == "pingpong_rq":
+        w, lim, _ = W.bench_case("pingpong", 4, 16, 4)
+    elif case == "spill":
+        w = W.pingpong(8, 4); lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 2, 30
+    elif case == "lanes16":
+        w = W.pingpong(4, 8); lim = A.Limits(); lim.lanes_per_wave = 16
+    else:
+        w, lim, _ = W.bench_case(case, 4, 8, 4)
+    n = 64 if case in ("raft", "topo") else 192
+    with_log = _same(w, 3, n, None, lim)
+    lim2 = _without_trace_hash(lim)
+    without = _same(w, 3, n, None, lim2)
+    assert (without["trace_hash"] == 0).all() and (with_log["trace_hash"] != 0).all()
+    for f in ("verdict", "steps", "clock_ns", "msg_count", "rng_calls", "obs_hash"):
+        assert (without[f] == with_log[f]).all(), f
+    elog, eres = emu.trace_seed(w, 3, None, lim2)
+    olog, ores = oracle.trace_seed(w, 3, None, lim2)
+    assert bytes(elog) == bytes(olog) and len(olog) > 0
+    assert tuple(eres) == ores.astuple() and ores.trace_hash == with_log["trace_hash"][0]

@@ -772,3 +772,33 @@ def test_run_batch_multi_from_two_threads_with_permuted_context_lists(hip):
             hip.run_batch_multi([c0, c1], w, 1234, 6000, None, bad)
         got, _ = hip.run_batch_multi([c0, c1], w, 1234, 6000)            # the contexts are intact
         assert (got == ref).all()
+
+
+@pytest.mark.parametrize("case", ["pingpong", "spill", "lanes16", "raft", "kv", "topo", "timers"])
+def test_no_trace_hash_drops_only_the_fingerprint(hip, case):
+    """madsim_limits_t.no_trace_hash = the reference's plain run (rand.rs:67: log and check both None): trace_hash comes back 0
+    and every other field is what the logging run reports, GPU == oracle in both modes — on the base-op build compiled
+    without the fold (geometry reports it) and on the builds that test the flag at run time; a trace request logs anyway."""
+    lim = None
+    if case == "pingpong":
+        w, lim, _ = W.bench_case("pingpong", 4, 64, 4)
+    elif case == "spill":
+        w = W.pingpong(8, 4); lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 2, 30
+    elif case == "lanes16":
+        w = W.pingpong(4, 8); lim = A.Limits(); lim.lanes_per_wave = 16
+    else:
+        w, lim, _ = W.bench_case(case, 4, 64, 4)
+    n = 256 if case in ("raft", "topo") else 4096
+    with_log, _ = _cmp(hip, w, 11, n, None, lim)
+    lim = lim or A.Limits()
+    lim.no_trace_hash = 1
+    without, _ = _cmp(hip, w, 11, n, None, lim)
+    assert (without["trace_hash"] == 0).all() and (with_log["trace_hash"] != 0).all()
+    for f in ("verdict", "steps", "clock_ns", "msg_count", "rng_calls", "obs_hash"):
+        assert (without[f] == with_log[f]).all(), f
+    g = hip.geometry(w, lim)
+    assert bool((g.variant >> 13) & 1) == (case == "pingpong"), hip.variant_name(g)
+    glog, gres = hip.trace_seed(w, 11, None, lim)
+    olog, ores = oracle.trace_seed(w, 11, None, lim)
+    assert bytes(glog) == bytes(olog) and len(olog) > 0 and gres.astuple() == ores.astuple()
+    assert ores.trace_hash == with_log["trace_hash"][0]
