@@ -15,11 +15,15 @@
 #define MADSIM_HIP_HPP
 
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <functional>
 #include <optional>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -55,6 +59,87 @@ struct Config {
     double packet_loss_rate = 0.0;
     uint64_t send_latency_start_ns = 1000000, send_latency_end_ns = 10000000;
     bool buggify = false;
+
+    // `content.parse::<Config>()` of MADSIM_TEST_CONFIG (builder.rs:81-88; config.rs:29-35 = toml::from_str): the [net] table —
+    // packet_loss_rate and send_latency = { start = { secs, nanos }, end = { secs, nanos } } — in either TOML spelling (inline
+    // tables as in config.rs:52-56, or [net.send_latency.start] sections as Display prints them); [tcp] is an empty struct.
+    // A TOML subset on purpose: tables, inline tables, numbers, strings and booleans — what a Config file can hold.
+    static Config from_toml(const std::string& text) {
+        Config c;
+        std::optional<uint64_t> s_secs, s_nanos, e_secs, e_nanos;
+        auto set = [&](const std::string& path, const std::string& v) {
+            auto num = [&]() -> double {
+                char* end = nullptr; double x = std::strtod(v.c_str(), &end);
+                if (v.empty() || *end) throw std::invalid_argument("failed to parse config file: `" + path + "` is not a number");
+                return x;
+            };
+            if (path == "net.packet_loss_rate") c.packet_loss_rate = num();
+            else if (path == "net.send_latency.start.secs") s_secs = (uint64_t)num();
+            else if (path == "net.send_latency.start.nanos") s_nanos = (uint64_t)num();
+            else if (path == "net.send_latency.end.secs") e_secs = (uint64_t)num();
+            else if (path == "net.send_latency.end.nanos") e_nanos = (uint64_t)num();
+            else if (path.rfind("net.", 0) == 0) throw std::invalid_argument("failed to parse config file: unknown field `" + path + "`");
+            // (other tables — [tcp] — carry no fields this path reads)
+        };
+        size_t i = 0; const size_t n = text.size();
+        auto ws = [&](bool newlines) {
+            while (i < n) {
+                if (text[i] == '#') { while (i < n && text[i] != '\n') i++; }
+                else if (text[i] == ' ' || text[i] == '\t' || text[i] == '\r' || (newlines && text[i] == '\n')) i++;
+                else break;
+            }
+        };
+        auto key = [&]() -> std::string {              // bare or quoted key, dotted: a.b."c"
+            std::string k;
+            for (;;) {
+                ws(false);
+                if (i < n && (text[i] == '"' || text[i] == '\'')) { const char q = text[i++]; while (i < n && text[i] != q) k += text[i++]; if (i < n) i++; }
+                else { const size_t b = i; while (i < n && (std::isalnum((unsigned char)text[i]) || text[i] == '_' || text[i] == '-')) i++; if (i == b) throw std::invalid_argument("failed to parse config file: key expected"); k.append(text, b, i - b); }
+                ws(false);
+                if (i < n && text[i] == '.') { k += '.'; i++; } else return k;
+            }
+        };
+        std::function<void(const std::string&)> value = [&](const std::string& path) {
+            ws(false);
+            if (i < n && text[i] == '{') {               // inline table
+                i++; ws(true);
+                while (i < n && text[i] != '}') {
+                    const std::string k = key();
+                    if (i >= n || text[i] != '=') throw std::invalid_argument("failed to parse config file: `=` expected");
+                    i++; value(path + "." + k); ws(true);
+                    if (i < n && text[i] == ',') { i++; ws(true); }
+                }
+                if (i >= n) throw std::invalid_argument("failed to parse config file: unterminated inline table");
+                i++;
+            } else if (i < n && (text[i] == '"' || text[i] == '\'')) {
+                const char q = text[i++]; std::string v; while (i < n && text[i] != q) v += text[i++]; if (i < n) i++;
+                set(path, v);
+            } else {
+                const size_t b = i;
+                while (i < n && text[i] != ',' && text[i] != '}' && text[i] != '\n' && text[i] != '#' && text[i] != ' ' && text[i] != '\t' && text[i] != '\r') i++;
+                std::string v(text, b, i - b);
+                v.erase(std::remove(v.begin(), v.end(), '_'), v.end());       // 1_000_000
+                set(path, v);
+            }
+        };
+        std::string table;
+        for (ws(true); i < n; ws(true)) {
+            if (text[i] == '[') {
+                i++; table = key();
+                if (i >= n || text[i] != ']') throw std::invalid_argument("failed to parse config file: `]` expected");
+                i++;
+            } else {
+                const std::string k = key();
+                if (i >= n || text[i] != '=') throw std::invalid_argument("failed to parse config file: `=` expected");
+                i++; value(table.empty() ? k : table + "." + k);
+            }
+        }
+        if (s_secs || s_nanos || e_secs || e_nanos) {
+            if (!(s_secs && s_nanos && e_secs && e_nanos)) throw std::invalid_argument("failed to parse config file: send_latency needs start and end, secs and nanos");
+            c.send_latency_start_ns = *s_secs * 1000000000ull + *s_nanos; c.send_latency_end_ns = *e_secs * 1000000000ull + *e_nanos;
+        }
+        return c;
+    }
     madsim_config_t raw() const {
         madsim_config_t c{};
         c.packet_loss_rate = packet_loss_rate; c.lat_lo_ns = send_latency_start_ns; c.lat_hi_ns = send_latency_end_ns;
@@ -330,6 +415,12 @@ struct Builder {
         else b.seed = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
                           std::chrono::system_clock::now().time_since_epoch()).count();
         if (auto s = env("MADSIM_TEST_JOBS")) b.jobs = (uint16_t)parse_u64(s, "MADSIM_TEST_JOBS");
+        if (auto s = env("MADSIM_TEST_CONFIG")) {
+            std::ifstream f(s);
+            if (!f) throw std::invalid_argument("failed to read config file");
+            std::stringstream ss; ss << f.rdbuf();
+            b.config = Config::from_toml(ss.str());
+        }
         if (auto s = env("MADSIM_TEST_NUM")) b.count = parse_u64(s, "MADSIM_TEST_NUM");
         if (auto s = env("MADSIM_TEST_TIME_LIMIT")) {
             char* end = nullptr;

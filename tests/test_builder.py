@@ -106,3 +106,37 @@ def test_reset_node_drop_order_is_refused_not_guessed():
                 oracle.run_batch(w, 0, 4)
             with pytest.raises(RuntimeError, match="reset_node"):
                 emu.run_batch(w, 0, 4)
+
+
+def test_cpp_mirror_parses_madsim_test_config_like_the_python_mirror(tmp_path):
+    """MADSIM_TEST_CONFIG (builder.rs:81-88): the C++ mirror's TOML subset against the Python mirror's tomli parse, on the
+    reference's own test text (config.rs:52-56), on what `Display` prints (sub-table sections), on defaults, and on junk."""
+    import os
+    import subprocess
+    from madsim_amd import runtime
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = {
+        "reference_test": '\n        [net]\n        packet_loss_rate = 0.1\n        send_latency = { start = { secs = 0, nanos = 1000000 }, end = { secs = 0, nanos = 10000000 } }\n        \n        [tcp]\n        ',
+        "display_form": '[net]\npacket_loss_rate = 0.25\n\n[net.send_latency.start]\nsecs = 1\nnanos = 500_000_000\n\n[net.send_latency.end]\nsecs = 2\nnanos = 0\n\n[tcp]\n',
+        "defaults": "# nothing set\n[tcp]\n",
+        "loss_only": "[net]\npacket_loss_rate = 1.0 # everything\n",
+        "dotted_keys": 'net.packet_loss_rate = 0.5\nnet.send_latency.start = { secs = 0, nanos = 2_000_000 }\nnet.send_latency.end = { "secs" = 0, nanos = 3000000 }\n',
+        "unknown_field": "[net]\npacket_loss = 0.1\n",
+        "half_range": "[net]\nsend_latency = { start = { secs = 0, nanos = 1 } }\n",
+        "not_a_number": "[net]\npacket_loss_rate = lots\n",
+    }
+    exe = str(tmp_path / "hpp_config_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(root, "tests", "cpp", "hpp_config_check.cpp"), "-o", exe])
+    argv = [exe]
+    for name, text in cases.items():
+        path = tmp_path / (name + ".toml"); path.write_text(text); argv += [name, str(path)]
+    env = dict(os.environ, MADSIM_TEST_CONFIG=str(tmp_path / "display_form.toml"), MADSIM_TEST_SEED="1")
+    lines = dict(l.split(" ", 1) for l in subprocess.run(argv, capture_output=True, text=True, env=env, check=True).stdout.splitlines())
+    for name, text in cases.items():
+        if name in ("unknown_field", "half_range", "not_a_number"):
+            assert lines[name].startswith("ERROR failed to parse config file"), (name, lines[name])
+            continue
+        c = runtime._parse_config(text)
+        loss, lo, hi = lines[name].split()
+        assert (float(loss), int(lo), int(hi)) == (c.packet_loss_rate, c.lat_lo_ns, c.lat_hi_ns), (name, lines[name])
+    assert lines["from_env"] == lines["display_form"] and lines["display_form"].split()[1:] == ["1500000000", "2000000000"]
