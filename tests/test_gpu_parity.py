@@ -44,6 +44,8 @@ def _fuzz_block(hip, gen, base, n, count, seed_mul, limits, alt_global=False, st
         lim = limits()
         if alt_global and k % 2:
             lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        if k % 4 == 3:
+            lim.no_trace_hash = 1                      # the reference's plain mode: no determinism-log fingerprint (rand.rs:67)
         got, _ = hip.run_batch(w, k * seed_mul, count, cfg, lim)
         want, _ = oracle.run_batch(w, k * seed_mul, count, cfg, lim)
         ovf = got["verdict"] == A.OVERFLOW
