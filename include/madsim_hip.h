@@ -306,6 +306,10 @@ typedef struct madsim_limits {
 #define MADSIM_STATE_GLOBAL 2u   /* extended-op workloads: task table + planes in global memory ([unit][lane] across the launch:
                                     L2 / Infinity Cache / HBM), only the timer-heap top and the ready queue in LDS       */
 
+#define MADSIM_STATE_COMPACT 3u  /* base-op workloads on full waves, <= 8 tasks, no heap spill, sleeps < 2.1 s: 8-byte timer-heap entries (low
+                                    deadline word: exact inside that horizon), heap root in registers, the main task in global memory —
+                                    a fourth wave per SIMD for the 4-node ping-pong.  AUTO takes it when it gains a workgroup per CU  */
+
 #define MADSIM_SCHED_STATIC 0u   /* lane g runs seeds g, g+G, g+2G, ...                                */
 #define MADSIM_SCHED_QUEUE  1u   /* a finished lane pulls the next seed from a per-launch atomic counter */
 
@@ -453,7 +457,7 @@ int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const m
  * One 65 536-seed batch is one wave per SIMD: alone it leaves two thirds of the issue slots idle (a base-op launch takes ~3.2 ms
  * alone, ~1.3 ms per batch with three in flight).  madsim_hip_run_batch cannot overlap anything — it returns the results —, so
  * the overlap lives here: `total` seeds from `seed0` run as batches of `batch` seeds (0 = 65 536) on the context's own HIP
- * streams, `in_flight` at a time (0 = 3; more streams than hardware queues are pointless: GPU_MAX_HW_QUEUES), each followed by a
+ * streams, `in_flight` at a time (0 = auto: 3, or 5 when the workload's LDS admits four waves per SIMD; more streams than hardware queues are pointless: GPU_MAX_HW_QUEUES), each followed by a
  * device reduction whose 48-byte report is the only thing copied to the host.  Per-seed results are NOT returned: a campaign
  * answers "which is the first failing seed, how many fail" — the seed-search use of `MADSIM_TEST_NUM` — and the caller re-runs
  * the seed it is told about (madsim_hip_run_batch / madsim_hip_trace_seed) for details.
@@ -495,7 +499,7 @@ typedef struct madsim_geometry {
     uint32_t variant;              /* kernel specialisation: bit0 heap spill, bit1 extended ops, bit2 ready queue in a
                                     * register, bit3 runtime lane stride, bit4 global-state build; bits 8-12 = classes of extended ops compiled in
                                     * (1 timeouts, 2 channel, 4 RPC, 8 node lifecycle, 16 general address resolution), bit 13 = built without the determinism-log
-                                    * fold (madsim_limits_t.no_trace_hash on a base-op workload); bits 16-19 = compile-time log2 lane
+                                    * fold (madsim_limits_t.no_trace_hash on a base-op workload), bit 14 = the compact base-op layout (MADSIM_STATE_COMPACT); bits 16-19 = compile-time log2 lane
                                     * stride (15 = runtime) */
     uint32_t global_bytes_per_seed; /* size of a lane's state block in global memory (global-state builds), else 0 */
 } madsim_geometry_t;

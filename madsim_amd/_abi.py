@@ -10,7 +10,7 @@ ABI_VERSION = 3
 U64_MAX = (1 << 64) - 1
 LIMIT_NONE = 0xFFFFFFFF
 SCHED_STATIC, SCHED_QUEUE = 0, 1
-STATE_AUTO, STATE_LDS, STATE_GLOBAL = 0, 1, 2
+STATE_AUTO, STATE_LDS, STATE_GLOBAL, STATE_COMPACT = 0, 1, 2, 3
 VAL_TIMEOUT = 0xFFFFFFFF
 VAL_REFUSED = 0xFFFFFFFE
 VAL_RESET = 0xFFFFFFFD

@@ -285,7 +285,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     uint32_t sh_bytes = 0;
     // Where the task table and the planes live (madsim_limits_t.state_mem): LDS, or — extended-op workloads whose state
     // would leave a CU with fewer than four full waves — global memory, [unit][lane] across the launch (Variant::G, k_state.h).
-    if (L.state_mem > MADSIM_STATE_GLOBAL) return fail(err, MADSIM_E_LIMITS, "state_mem must be 0 (auto), 1 (LDS) or 2 (global)");
+    if (L.state_mem > MADSIM_STATE_COMPACT) return fail(err, MADSIM_E_LIMITS, "state_mem must be 0 (auto), 1 (LDS), 2 (global) or 3 (compact)");
     P.gstate_mode = 0;
     // base-op builds: no owner word per socket (the owner's slot rides in the header, k_state.h) and 8-byte unit1
     P.sock_words = (P.lifecycle ? 2 : 1) + P.mbox_regs + 2 * P.mbox_msgs + (P.uses_chan ? 3 : 0);   // + accept queue (2 words), parked acceptor
@@ -372,8 +372,36 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     }
     if (P.gstate_mode && lw != 64) return fail(err, MADSIM_E_LIMITS, "global state (state_mem = 2) runs full 64-lane waves only");
     P.lw_shift = lw == 8 ? 3 : lw == 16 ? 4 : lw == 32 ? 5 : 6;
-    P.sh_tasks = P.sh_heap + P.heap_lds * lw * (heap_bytes / 4);
-    P.sh_planes = P.sh_tasks + (P.gstate_mode ? 0 : P.max_tasks * (task_bytes / 4) * lw);
+    // The compact base-op layout (sim_kernel.h MADSIM_FEAT_COMPACT): 8-byte heap entries with the root in registers, the main
+    // task's 24 bytes in global memory.  Taken when it buys a CU another 4-wave workgroup (the 4-node ping-pong: 200 -> 152 bytes
+    // per seed, three -> four waves per SIMD) and every live deadline provably stays within 2^31 ns of the clock: the longest
+    // sleep of the program, the latency range, rand_delay's 1 ms floor — or buggify's 1..5 s, which rules it out.
+    P.compact = 0;
+    uint32_t heap_n = P.heap_lds, heap_b = heap_bytes, task_n = P.max_tasks;
+    {
+        uint64_t horizon = std::max<uint64_t>(cfg->lat_hi_ns, 1000000ull);
+        if (cfg->buggify) horizon = ~0ull;
+        for (uint32_t i = 0; i < w->n_insns; i++) {
+            const madsim_insn_t& in = w->insns[i];
+            if (in.op == MS_OP_SLEEP || in.op == MS_OP_SLEEP_RAND)
+                horizon = std::max<uint64_t>(horizon, (uint64_t)in.b * 1000000000ull + in.imm);
+        }
+        const bool can = !P.lifecycle && !trace && !P.gstate_mode && lw == 64 && P.rq_in_reg && P.heap_spill == 0 && P.heap_lds >= 2 &&
+                         P.max_tasks >= 2 && horizon < (1ull << 31) - (1ull << 24) && !L.lanes_per_wave;
+        if (L.state_mem == MADSIM_STATE_COMPACT && !can)
+            return fail(err, MADSIM_E_LIMITS, "state_mem = 3 (compact): base-op workloads on full waves with <= 8 tasks, no heap spill, no buggify and sleeps below 2.1 s only");
+        if (can && L.state_mem != MADSIM_STATE_LDS) {
+            const size_t per_seed_c = (size_t)(P.heap_lds - 1) * 8 + (size_t)(P.max_tasks - 1) * task_bytes + (size_t)P.lane_words * 4;
+            auto groups = [&](size_t per_seed) { size_t b = ((size_t)sh_bytes + 256 * per_seed + 1279) / 1280 * 1280; return g.lds_per_cu / b; };
+            if (L.state_mem == MADSIM_STATE_COMPACT || (groups(per_seed_c) > groups(G->lds_per_seed) && groups(per_seed_c) <= 4)) {
+                P.compact = 1; heap_n = P.heap_lds - 1; heap_b = 8; task_n = P.max_tasks - 1;
+                G->lds_per_seed = (uint32_t)per_seed_c;
+                P.gs_stride = 24;                      // the main task's record: unit0 (16 bytes) + unit1 {x, y}
+            }
+        }
+    }
+    P.sh_tasks = P.sh_heap + heap_n * lw * (heap_b / 4);
+    P.sh_planes = P.sh_tasks + (P.gstate_mode ? 0 : task_n * (task_bytes / 4) * lw);
     P.wave_words = P.sh_planes + P.lane_words * lw - P.sh_heap;
     if ((size_t)(P.sh_heap + P.wave_words) * 4 > g.lds_per_cu) return fail(err, MADSIM_E_LIMITS, "per-wave LDS exceeds 160 KiB: lower heap_lds_slots / mailbox capacities");
     // Workgroup = W independent waves.  Measured on MI355X (tools/placement.hip, profiles/r1_placement.txt): the

@@ -22,7 +22,7 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
     SPLITMIX(L.s0); SPLITMIX(L.s1); SPLITMIX(L.s2); SPLITMIX(L.s3);
 #undef SPLITMIX
     L.rng_calls = 0; L.clock = 0; L.msg_count = 0; L.steps = 0;
-    L.pq_n = 0; L.ready_len = 0; L.rq = 0; L.heap_len = 0; L.top_dl = ~0ull; L.verdict = MADSIM_RUNNING; L.ovf = 0; L.main_done = 0;
+    L.pq_n = 0; L.ready_len = 0; L.rq = 0; L.heap_len = 0; L.top_dl = ~0ull; L.top_meta = 0; L.verdict = MADSIM_RUNNING; L.ovf = 0; L.main_done = 0;
     L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
     // TimeRuntime::new (time/mod.rs:26-38): base_time draw, before logging is enabled
     { uint64_t h = L.trace_hash, n = L.log_len; uint32_t bt = gen_range_small<Variant<false, false, K::LWS, 0, K::RQ>, 31536000u>(c, L); L.trace_hash = h; L.log_len = n;
@@ -42,7 +42,7 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
 #define MADSIM_G_WAVES_PER_EU 3
 #endif
 template <class K>
-__global__ __launch_bounds__(256, !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : MADSIM_G_WAVES_PER_EU) void sim_kernel(const KParams P) {
+__global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : MADSIM_G_WAVES_PER_EU) void sim_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // workgroup-shared tables
     uint32_t* sh = SMEM;
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256, !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : M
     c.nodet0 = P.sh_nodes;
     const uint32_t wbase = wv * P.wave_words;       // this wave's slice of the workgroup's LDS
     if (K::LIFE) c.heap0 = (P.sh_heap + wbase) / 4 + lane;
+    else if (K::CMP) { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = 0; }        // 8-byte entries 1 .. heap_lds - 1 (entry 0: registers)
     else { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = P.sh_heap + wbase + ((P.heap_lds * 2) << P.lw_shift) + lane; }
     c.lws = P.lw_shift;
     const uint32_t pl = P.sh_planes + wbase + lane;
@@ -74,6 +75,10 @@ __global__ __launch_bounds__(256, !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : M
     } else {
         c.task0 = (P.sh_tasks + wbase) / 4 + lane;
         c.task1 = (P.sh_tasks + wbase + ((P.max_tasks * 4) << P.lw_shift)) / 2 + lane;      // base-op builds: behind the unit0 array
+        if (K::CMP) {          // slots 1 .. max_tasks - 1 in LDS (slot 0 = the main task: global memory), the arrays indexed by slot - 1
+            c.task1 = (P.sh_tasks + wbase + (((P.max_tasks - 1) * 4) << P.lw_shift)) / 2 + lane - (1u << P.lw_shift);
+            c.task0 -= 1u << P.lw_shift;
+        }
         c.sock0 = pl + (P.off_socks << P.lw_shift);
         c.hand0 = pl + (P.off_handles << P.lw_shift);
         c.node0 = pl + (P.off_nodes << P.lw_shift);

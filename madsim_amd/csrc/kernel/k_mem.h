@@ -27,6 +27,11 @@ __device__ __forceinline__ BufRef buf_make(const void* base, uint64_t bytes) {
 }
 __device__ __forceinline__ uint32_t buf_load32(const BufRef& b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(b.rsrc, off, 0, 0); }
 __device__ __forceinline__ void buf_store32(const BufRef& b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b.rsrc, off, 0, 0); }
+__device__ __forceinline__ uint2 buf_load64(const BufRef& b, uint32_t off) {
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(b.rsrc, off, 0, 0);
+    return make_uint2(t.x, t.y);
+}
 __device__ __forceinline__ uint4 buf_load128(const BufRef& b, uint32_t off) {
     u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, off, 0, 0);
     return make_uint4(t.x, t.y, t.z, t.w);

@@ -8,6 +8,7 @@ namespace madsim_k {
 // Timing-experiment switches live outside the product tree (tools/experiment/k_experiment.h) and are reachable only
 // through tools/build_variant.sh; the product build refuses them.
 #ifdef MADSIM_EXPERIMENT_BUILD
+#include <type_traits>
 #include "../../../tools/experiment/k_experiment.h"
 #else
 #if defined(EXP_NOLOG) || defined(EXP_ALWAYS_ACCEPT) || defined(EXP_PROF) || defined(EXP_PROF2) || defined(EXP_NO_LWS_VARIANTS)
@@ -62,6 +63,8 @@ template <bool TRACE_, bool SPILL_, int LWS_, int FEAT_, bool RQ_ = false, bool 
     static constexpr bool LIFE = FEAT != 0;
     // the determinism-log fold (rng_log): compiled out (a base-op twin selected by KParams.no_log), or compiled in behind a run-time
     // test of KParams.no_log — every build except the base-op full-wave ones without a spill region, whose twin takes those launches
+    // the compact base-op layout (sim_kernel.h MADSIM_FEAT_COMPACT): 8-byte heap entries + root in registers + main task in global memory
+    static constexpr bool CMP = (FEAT_ & MADSIM_FEAT_COMPACT) != 0;
     static constexpr bool NOLOG = (FEAT_ & MADSIM_FEAT_NOLOG) != 0;
     static constexpr bool LOGSW = !NOLOG && !TRACE_ && (LIFE || SPILL_ || LWS_ != 6);
     static constexpr bool FT = (FEAT_ & MADSIM_FEAT_TIME) != 0, FC = (FEAT_ & MADSIM_FEAT_CHAN) != 0,
@@ -84,6 +87,7 @@ struct Lane {
     uint64_t clock;
     // Timer: write-through mirror of heap[0]'s deadline (UINT64_MAX when empty)
     uint64_t top_dl;
+    uint32_t top_meta;   // compact builds: the meta word of heap[0] (the root entry lives in registers)
     // accounting
     uint64_t obs_hash;
     uint32_t msg_count;
@@ -200,6 +204,27 @@ template <> struct URef<true> {
     __device__ __forceinline__ void operator=(const uint4& v) const { gs_store128(gs, at, v); }
     __device__ __forceinline__ void operator=(const URef& o) const { *this = (uint4)o; }
 };
+// Compact base-op builds: task slot 0 (the main task) lives in global memory, the other slots in LDS.  `glob` is rarely true
+// (the main task is polled a handful of times per run), so the global side sits behind a branch that whole waves skip.
+struct HWRef {
+    BufRef gs; uint32_t at; bool glob;   // at: LDS word index, or byte offset in the main-task buffer
+    __device__ __forceinline__ operator uint32_t() const { uint32_t v; if (glob) v = gs_load32(gs, at); else v = SMEM[at]; return v; }
+    __device__ __forceinline__ uint32_t operator=(uint32_t v) const { if (glob) gs_store32(gs, at, v); else SMEM[at] = v; return v; }
+    __device__ __forceinline__ uint32_t operator=(const HWRef& o) const { return *this = (uint32_t)o; }
+    __device__ __forceinline__ uint32_t operator|=(uint32_t v) const { return *this = (uint32_t)*this | v; }
+    __device__ __forceinline__ uint32_t operator&=(uint32_t v) const { return *this = (uint32_t)*this & v; }
+    __device__ __forceinline__ uint32_t operator+=(uint32_t v) const { return *this = (uint32_t)*this + v; }
+};
+struct HURef {
+    BufRef gs; uint32_t at; bool glob;   // at: LDS uint4 index, or byte offset in the main-task buffer
+    __device__ __forceinline__ operator uint4() const { uint4 v; if (glob) v = gs_load128(gs, at); else v = LDS128(at); return v; }
+    __device__ __forceinline__ void operator=(const uint4& v) const { if (glob) gs_store128(gs, at, v); else LDS128(at) = v; }
+    __device__ __forceinline__ void operator=(const HURef& o) const { *this = (uint4)o; }
+};
+template <class K> struct TaskRef {      // what TU / TWORD / HW hand out
+    typedef typename std::conditional<K::CMP, HURef, URef<K::G>>::type U;
+    typedef typename std::conditional<K::CMP, HWRef, WRef<K::G>>::type W;
+};
 template <bool G> __device__ __forceinline__ WRef<G> make_wref(const Ctx& c, uint32_t lds_at, uint32_t gs_at);
 template <> __device__ __forceinline__ WRef<false> make_wref<false>(const Ctx&, uint32_t lds_at, uint32_t) { return WRef<false>{lds_at}; }
 // logical offset `at` inside the lane's block -> byte offset in the state buffer (both regions: at * total_lanes + this lane)
@@ -254,28 +279,47 @@ template <class K> __device__ __forceinline__ bool sock_owned_by(const Ctx& c, u
 template <bool G> __device__ __forceinline__ WRef<G> tword_gs(const Ctx& c, uint32_t gs_at);       // (K::G builds only)
 template <> __device__ __forceinline__ WRef<false> tword_gs<false>(const Ctx&, uint32_t) { return WRef<false>{0}; }
 template <> __device__ __forceinline__ WRef<true> tword_gs<true>(const Ctx& c, uint32_t gs_at) { return make_uword_ref(c, gs_at); }
-template <class K> __device__ __forceinline__ URef<K::G> tu_ref(const Ctx& c, uint32_t slot, uint32_t u) {
+template <class K> __device__ __forceinline__ URef<K::G> tu_ref_plain(const Ctx& c, uint32_t slot, uint32_t u) {
     if (!K::LIFE) return make_uref<K::G>(c, c.task0 + (slot << LWSH<K>(c)), 0);             // unit 0 (unit 1: load_u1 / TWORD)
     return make_uref<K::G>(c, c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c)), c.task0 + (slot * c.P.task_units + u) * 16u);
 }
-template <class K> __device__ __forceinline__ WRef<K::G> tword_ref(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) {
+template <class K> __device__ __forceinline__ WRef<K::G> tword_ref_plain(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) {
     if (!K::LIFE) return make_wref<K::G>(c, u == 0 ? (c.task0 + (slot << LWSH<K>(c))) * 4u + k : (c.task1 + (slot << LWSH<K>(c))) * 2u + k, 0);
     if (K::G) return tword_gs<K::G>(c, c.task0 + (slot * c.P.task_units + u) * 16u + k * 4u);
     return make_wref<K::G>(c, (c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c))) * 4u + k, 0);
 }
+// Compact builds: the main task's record in the global buffer is unit0 at [lane * 16], then unit1 {x, y} at
+// [total_lanes * 16 + lane * 8]; c.task0 / c.task1 are biased so that slot s >= 1 indexes LDS entry s - 1.
+template <class K> __device__ __forceinline__ typename TaskRef<K>::U tu_ref(const Ctx& c, uint32_t slot, uint32_t u) {
+    if constexpr (K::CMP) return HURef{c.gs, slot == 0 ? c.gs_lane * 16u : c.task0 + (slot << LWSH<K>(c)), slot == 0};
+    else return tu_ref_plain<K>(c, slot, u);
+}
+template <class K> __device__ __forceinline__ typename TaskRef<K>::W tword_ref(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) {
+    if constexpr (K::CMP) {
+        const uint32_t lds = u == 0 ? (c.task0 + (slot << LWSH<K>(c))) * 4u + k : (c.task1 + (slot << LWSH<K>(c))) * 2u + k;
+        const uint32_t glb = u == 0 ? c.gs_lane * 16u + k * 4u : c.P.total_lanes * 16u + c.gs_lane * 8u + k * 4u;
+        return HWRef{c.gs, slot == 0 ? glb : lds, slot == 0};
+    } else return tword_ref_plain<K>(c, slot, u, k);
+}
 // unit1 as a uint4 in registers; base-op builds hold {x, y} only
 template <class K> __device__ __forceinline__ uint4 load_u1(const Ctx& c, uint32_t slot) {
     if (K::LIFE) return tu_ref<K>(c, slot, 1);
-    uint2 t = LDS64(c.task1 + (slot << LWSH<K>(c)));
+    uint2 t;
+    if (K::CMP && slot == 0) t = buf_load64(c.gs, c.P.total_lanes * 16u + c.gs_lane * 8u);
+    else t = LDS64(c.task1 + (slot << LWSH<K>(c)));
     return make_uint4(t.x, t.y, 0, 0);
 }
 #define TU(c_, slot_, u_) tu_ref<K>((c_), (slot_), (u_))
 #define TWORD(c_, slot_, u_, k_) tword_ref<K>((c_), (slot_), (u_), (k_))
+template <class K> __device__ __forceinline__ WRef<K::G> hw_ref_plain(const Ctx& c, uint32_t p) {
+    if (K::LIFE) return plane_ref<K>(c, c.hand0, p);
+    return tword_ref_plain<K>(c, p, 1, 1);
+}
 // JoinHandle state of prog p.  Workloads with the extended ops keep a handle plane; the others park the word in the
 // otherwise unused unit1.y of task slot p (max_tasks >= n_progs there, geometry.h) and save the plane's LDS.
-template <class K> __device__ __forceinline__ WRef<K::G> hw_ref(const Ctx& c, uint32_t p) {
-    if (K::LIFE) return plane_ref<K>(c, c.hand0, p);
-    return tword_ref<K>(c, p, 1, 1);
+template <class K> __device__ __forceinline__ typename TaskRef<K>::W hw_ref(const Ctx& c, uint32_t p) {
+    if constexpr (K::CMP) return tword_ref<K>(c, p, 1, 1);
+    else return hw_ref_plain<K>(c, p);
 }
 #define HW(p) hw_ref<K>(c, (p))
 // unit1 write-back: only x when unit1.y is a handle word (see HW)

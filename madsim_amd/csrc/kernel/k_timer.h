@@ -38,8 +38,17 @@ __device__ __forceinline__ void heap_lds_set(const Ctx& c, uint32_t i, const uin
     LDS64(c.heap0 + (i << LWSH<K>(c))) = make_uint2(e.x, e.y);
     SMEM[c.heapm0 + (i << LWSH<K>(c))] = e.z;
 }
+// Compact base-op builds (sim_kernel.h MADSIM_FEAT_COMPACT): entry 0 lives in registers (Lane::top_dl, top_meta), entry
+// i >= 1 is 8 bytes in LDS — the low 32 bits of its deadline and its meta word.  The host admits the layout only when every
+// live deadline lies within 2^31 ns of the clock (geometry.h: the workload's longest sleep), so clock + sign-extended
+// (low word - low word of the clock) IS the deadline: the comparisons below run on the same 64-bit values as everywhere else.
 template <class K>
-__device__ __forceinline__ uint4 heap_get(const Ctx& c, uint32_t i) {
+__device__ __forceinline__ uint4 heap_get(const Ctx& c, const Lane& L, uint32_t i) {
+    if (K::CMP) {
+        const uint2 e = LDS64(c.heap0 + ((i ? i - 1 : 0) << LWSH<K>(c)));
+        const uint64_t d = L.clock + (uint64_t)(int64_t)(int32_t)(e.x - (uint32_t)L.clock);
+        return i == 0 ? make_uint4((uint32_t)L.top_dl, (uint32_t)(L.top_dl >> 32), L.top_meta, 0) : make_uint4((uint32_t)d, (uint32_t)(d >> 32), e.y, 0);
+    }
     if (!K::SPILL) return heap_lds_get<K>(c, i);
     uint32_t cap = c.P.heap_lds;
     uint4 v = heap_lds_get<K>(c, i < cap ? i : cap - 1);
@@ -47,7 +56,12 @@ __device__ __forceinline__ uint4 heap_get(const Ctx& c, uint32_t i) {
     return v;
 }
 template <class K>
-__device__ __forceinline__ void heap_set(const Ctx& c, uint32_t i, const uint4& e) {
+__device__ __forceinline__ void heap_set(const Ctx& c, Lane& L, uint32_t i, const uint4& e) {
+    if (K::CMP) {
+        if (i == 0) { L.top_dl = u64of(e.x, e.y); L.top_meta = e.z; }
+        else LDS64(c.heap0 + ((i - 1) << LWSH<K>(c))) = make_uint2(e.x, e.z);
+        return;
+    }
     if (!K::SPILL || i < c.P.heap_lds) heap_lds_set<K>(c, i, e);
     else spill_store(c, i - c.P.heap_lds, e);
 }
@@ -69,23 +83,23 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos
     while (up) {                                       // (one exit: see k_main.h)
         REG(11);
         const uint32_t parent = (pos - 1) >> 1;
-        const uint4 p = heap_get<K>(c, parent);
+        const uint4 p = heap_get<K>(c, L, parent);
         if (K::SPILL) {
             const uint32_t gp = parent > 0 ? (parent - 1) >> 1 : 0;
-            const uint4 g = heap_get<K>(c, gp);
+            const uint4 g = heap_get<K>(c, L, gp);
             up = hd < (parent == 0 ? L.top_dl : ev_deadline(p));
             if (up) {
-                heap_set<K>(c, pos, p); pos = parent;
+                heap_set<K>(c, L, pos, p); pos = parent;
                 up = pos > 0 && hd < (gp == 0 ? L.top_dl : ev_deadline(g));
-                if (up) { heap_set<K>(c, pos, g); pos = gp; up = pos > 0; }
+                if (up) { heap_set<K>(c, L, pos, g); pos = gp; up = pos > 0; }
             }
         } else {
             // hole <= parent in heap order: stop (the root's deadline is mirrored in a register)
             up = hd < (parent == 0 ? L.top_dl : ev_deadline(p));
-            if (up) { heap_set<K>(c, pos, p); pos = parent; up = pos > 0; }
+            if (up) { heap_set<K>(c, L, pos, p); pos = parent; up = pos > 0; }
         }
     }
-    heap_set<K>(c, pos, hole);
+    heap_set<K>(c, L, pos, hole);
     if (pos == 0) L.top_dl = hd;
 }
 
@@ -141,24 +155,24 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
     PROBE2(0);
     REG(20);
     uint32_t end = --L.heap_len;
-    uint4 item = heap_get<K>(c, end);
+    uint4 item = heap_get<K>(c, L, end);
     if (end > 0) {
-        uint4 top = heap_get<K>(c, 0);
+        uint4 top = heap_get<K>(c, L, 0);
         uint32_t pos = 0, child = 1;
         uint4 m = item;                                     // the entry last moved up: it now sits at parent(pos)
         while (child + 1 < end) {
             REG(21);
-            uint4 l = heap_get<K>(c, child), r = heap_get<K>(c, child + 1);
+            uint4 l = heap_get<K>(c, L, child), r = heap_get<K>(c, L, child + 1);
             bool right = ev_deadline(l) >= ev_deadline(r);   // left <= right in heap order: take right
             m = right ? r : l;
-            heap_set<K>(c, pos, m);
+            heap_set<K>(c, L, pos, m);
             if (pos == 0) L.top_dl = ev_deadline(m);
             pos = child + (right ? 1u : 0u);
             child = 2 * pos + 1;
         }
         if (child == end - 1) {
-            m = heap_get<K>(c, child);
-            heap_set<K>(c, pos, m);
+            m = heap_get<K>(c, L, child);
+            heap_set<K>(c, L, pos, m);
             if (pos == 0) L.top_dl = ev_deadline(m);
             pos = child;
         }
@@ -167,8 +181,8 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
         // spill levels that is one dependent global round trip less per pop.  (Same comparisons, same stores as
         // heap_sift_up from `pos`: only where the parent's value comes from differs.)
         if (K::SPILL && pos > 0) {
-            if (ev_deadline(item) < ev_deadline(m)) { heap_set<K>(c, pos, m); pos = (pos - 1) >> 1; heap_sift_up<K>(c, L, pos, item); }
-            else heap_set<K>(c, pos, item);
+            if (ev_deadline(item) < ev_deadline(m)) { heap_set<K>(c, L, pos, m); pos = (pos - 1) >> 1; heap_sift_up<K>(c, L, pos, item); }
+            else heap_set<K>(c, L, pos, item);
         } else {
             heap_sift_up<K>(c, L, pos, item);
         }

@@ -232,9 +232,9 @@ int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
 
 int madsim_hip_ctx::ensure_scratch(KParams& P, hipStream_t stream, bool work_queue) {
     P.spill = nullptr; P.work_ctr = nullptr; P.gstate = nullptr;
-    if (!P.heap_spill && !work_queue && !P.gstate_mode) return 0;
+    if (!P.heap_spill && !work_queue && !P.gstate_mode && !P.compact) return 0;
     Scratch& sc = scratch[stream];
-    if (P.gstate_mode) {                 // per-lane state blocks of the global-state builds (seed_init clears what it needs)
+    if (P.gstate_mode || P.compact) {    // per-lane state blocks of the global-state builds / main-task records of the compact ones (seed_init writes what it reads)
         size_t need = (size_t)P.gs_stride * P.total_lanes;
         if (need >= (1ull << 32)) return fail(MADSIM_E_LIMITS, "global state region exceeds 4 GiB: lower the capacities");
         if (need > sc.gstate_bytes) {
@@ -695,7 +695,13 @@ int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* c, const madsim_workload_t* w,
     int rc = madsim_geo::validate(w, cfg, &g_err);
     if (rc) return rc;
     if (batch == 0) batch = 65536;
-    if (in_flight == 0) in_flight = 3;
+    if (in_flight == 0) {
+        // one wave per SIMD and batch of 65 536 seeds: as many batches as the workload's LDS admits waves per SIMD, and — when that is
+        // four (the compact base-op layout) — a fifth, whose launch queues behind them and fills the gaps their tails leave
+        madsim_geo::Geo G;
+        in_flight = 3;
+        if (!madsim_geo::make_geometry(c->dev(), w, cfg, lim, batch, &G, &g_err) && G.blocks_per_cu * G.waves_per_block >= 16) in_flight = 5;
+    }
     if (in_flight > (uint32_t)madsim_hip_ctx::CAMPAIGN_MAX) return fail(MADSIM_E_ARG, "at most 8 batches in flight");
     if (seed0 + total < seed0) return fail(MADSIM_E_ARG, "seed0 + total wraps");
     if (total == 0) return 0;

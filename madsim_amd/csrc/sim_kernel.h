@@ -20,6 +20,12 @@
    by KParams.no_log.  The other builds test KParams.no_log at run time (a wave-uniform branch); the base-op builds on full waves
    are issue-bound, so they get a twin compiled without the code instead. */
 #define MADSIM_FEAT_NOLOG 32
+/* Variant<..., FEAT, ...> only: the COMPACT base-op build (KParams.compact) — a fourth wave per SIMD for small workloads.
+   A 4-wave workgroup may hold 40 960 bytes of LDS if four are to share a CU; the 4-node ping-pong's 200 bytes per seed make
+   it 51 200.  The compact layout gets it to 152: timer-heap entries of 8 bytes (the low 32 bits of the deadline + meta: exact
+   while every live deadline lies within 2^31 ns of the clock, which the host checks against the workload's longest sleep), the
+   heap's root in registers, and the main task's state — polled a handful of times per run — in global memory. */
+#define MADSIM_FEAT_COMPACT 64
 
 namespace madsim_k {
 
@@ -79,6 +85,7 @@ struct KParams {
     uint32_t total_lanes;
     // trace mode (single seed)
     uint8_t* trace_log; uint64_t trace_cap; uint64_t* trace_len;
+    uint32_t compact;          // base-op builds: the compact LDS layout (MADSIM_FEAT_COMPACT); gstate then holds the main tasks' records
     uint32_t no_log;           // madsim_limits_t.no_trace_hash: skip rng_log, report trace_hash = 0 (trace launches ignore it)
     uint64_t* prof;            // profiling builds (tools/experiment): per-phase cycle accumulators
 };
@@ -95,6 +102,8 @@ struct KParams {
     X(false, false, 6, 0, true, false)                 \
     X(false, false, 6, MADSIM_FEAT_NOLOG, false, false) \
     X(false, false, 6, MADSIM_FEAT_NOLOG, true, false)  \
+    X(false, false, 6, MADSIM_FEAT_COMPACT, true, false) \
+    X(false, false, 6, MADSIM_FEAT_COMPACT | MADSIM_FEAT_NOLOG, true, false) \
     X(false, true, 6, 0, true, false)                  \
     X(false, true, 6, 0, false, false)                 \
     X(false, true, -1, 0, false, false)                \
@@ -119,6 +128,7 @@ inline VariantSel select_variant(const KParams& P, bool trace) {
     const int spill = P.heap_spill > 0, lw = (int)P.lw_shift, feat = (int)P.features;
     if (trace) return {1, 1, -1, MADSIM_FEAT_ALL, 0, 0};
     if (feat == 0) {                                                    // base ops only
+        if (lw == 6 && P.compact) return {0, 0, 6, MADSIM_FEAT_COMPACT | (P.no_log ? MADSIM_FEAT_NOLOG : 0), 1, 0};
         if (lw == 6) return {0, spill, 6, P.no_log && !spill ? MADSIM_FEAT_NOLOG : 0, (int)P.rq_in_reg, 0};
         return {0, 1, -1, 0, 0, 0};                                     // sub-wave lane stride: runtime-stride build
     }

@@ -20,6 +20,13 @@ def hip():
     # plain `pytest tests` is green; on a GPU box (or with MADSIM_REQUIRE_GPU=1) a missing device is a loud failure.
     if not os.path.exists("/dev/kfd") and os.environ.get("MADSIM_REQUIRE_GPU", "0") != "1":
         pytest.skip("no GPU device node (/dev/kfd): gpu tests need a real MI355X")
+    # Some gpu tests hand torch buffers / streams to the library.  torch's wheel bundles its own ROCm runtime; a process that
+    # loads /opt/rocm's first (through libmadsim_hip.so) and torch's second ends up with two, and the second finds "No HIP GPUs".
+    # Importing torch first makes both resolve to one copy — the order bench.py has anyway.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     runtime.init(0)
     yield runtime
     runtime.shutdown()

@@ -121,7 +121,7 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
     std::vector<uint4> spill((size_t)P.heap_spill * P.total_lanes + 1);
     P.spill = P.heap_spill ? spill.data() : nullptr;
     std::vector<uint4> gstate((size_t)P.gs_stride * P.total_lanes / 16 + 4);
-    P.gstate = P.gstate_mode ? (uint8_t*)gstate.data() : nullptr;
+    P.gstate = (P.gstate_mode || P.compact) ? (uint8_t*)gstate.data() : nullptr;
 #ifdef MADSIM_EMU_GSTAT
     gstat_planes = P.gs_planes; gstat_lanes = P.total_lanes ? P.total_lanes : 1;
 #endif

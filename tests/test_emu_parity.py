@@ -343,3 +343,65 @@ def test_no_trace_hash_drops_only_the_fingerprint(case):
     olog, ores = oracle.trace_seed(w, 3, None, lim2)
     assert bytes(elog) == bytes(olog) and len(olog) > 0
     assert tuple(eres) == ores.astuple() and ores.trace_hash == with_log["trace_hash"][0]
+
+
+def _compact(lim):
+    lim.state_mem = A.STATE_COMPACT
+    return lim
+
+
+@pytest.mark.parametrize("nodes,rounds,loss", [(4, 64, 0.0), (2, 64, 0.0), (6, 9, 0.0), (4, 16, 0.05), (4, 16, 1.0)])
+def test_compact_layout_pingpong(nodes, rounds, loss):
+    """MADSIM_STATE_COMPACT: 8-byte heap entries (low deadline word), heap root in registers, main task in global memory — the
+    same answers as the oracle on every field, with and without the determinism-log fold."""
+    w, lim, _ = W.bench_case("pingpong", nodes, rounds, 4)
+    lim.heap_lds_slots = max(4, nodes)
+    cfg = A.Config.default(packet_loss_rate=loss) if loss else None
+    _same(w, 5, 320, cfg, _compact(lim))
+    lim.no_trace_hash = 1
+    _same(w, 5, 320, cfg, lim)
+    g = emu.geometry(w, lim)
+    assert g.lds_bytes_per_seed == (lim.heap_lds_slots - 1) * 8 + nodes * 24 + nodes * 8
+
+
+def test_compact_layout_is_automatic_when_it_gains_a_workgroup_and_refused_outside_its_horizon():
+    w, lim, _ = W.bench_case("pingpong", 4, 64, 4)
+    assert emu.geometry(w, lim).lds_bytes_per_seed == 152          # auto: 200 -> 152 bytes, four workgroups per CU instead of three
+    lim.state_mem = A.STATE_LDS
+    assert emu.geometry(w, lim).lds_bytes_per_seed == 200          # the plain layout stays selectable
+    # a sleep beyond the 2^31 ns horizon: forced compact is refused, auto falls back to the plain layout
+    wl = W.WorkloadBuilder()
+    n1 = wl.create_node()
+    t = wl.task(n1); t.sleep(secs=3)
+    m = wl.main(); m.spawn(t); m.join(t)
+    far = wl.build()
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 4, 0
+    _same(far, 0, 64, None, lim)
+    with pytest.raises(RuntimeError):
+        emu.run_batch(far, 0, 64, None, _compact(lim))
+    # buggify's 1..5 s delays rule it out as well
+    w, lim, _ = W.bench_case("pingpong", 4, 8, 4)
+    with pytest.raises(RuntimeError):
+        emu.run_batch(w, 0, 64, A.Config.default(buggify=True), _compact(lim))
+    lim.state_mem = A.STATE_AUTO
+    _same(w, 0, 192, A.Config.default(buggify=True), lim)
+    assert emu.geometry(w, lim).lds_bytes_per_seed == 152          # (geometry alone does not know the config: the run decides)
+
+
+def test_compact_layout_fuzz():
+    """Random base-op programs small enough for the compact layout (<= 8 tasks, sleeps below 2.1 s), compact vs oracle."""
+    ran = 0
+    for k in range(400):
+        w, cfg, desc = fuzz.random_workload(random.Random(31000 + k))
+        lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 24, 0
+        lim.mbox_regs, lim.mbox_msgs = 4, 6
+        _compact(lim)
+        try:
+            e = emu.run_batch(w, k * 5, 24, cfg, lim)
+        except RuntimeError:
+            continue                                               # not a compact candidate (tasks, horizon, buggify)
+        o, _ = oracle.run_batch(w, k * 5, 24, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+        ran += 1
+    assert ran >= 60, ran

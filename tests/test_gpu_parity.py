@@ -479,15 +479,21 @@ def test_seed_range_extremes(hip):
     assert summ.first_failing_seed == osumm.first_failing_seed and summ.n_failed == osumm.n_failed
 
 
-@pytest.mark.parametrize("n_streams", [1, 2])
-def test_bench_configuration_pingpong_is_oracle_checked(hip, n_streams):
-    """The exact configuration bench.py times (workload.bench_case: heap 4 LDS / 0 spill, mbox_regs 1, mbox_msgs NONE,
-    Variant<false,false,6,false,true>, 65 536 seeds per launch, 1 and 2 launches in flight through the async entry
-    point): 256 sampled seeds k*257 mod 65 536 and 4 096 contiguous seeds of every launch against the oracle."""
+@pytest.mark.parametrize("n_streams,state_mem", [(1, 0), (2, 0), (5, 0), (2, 1)])
+def test_bench_configuration_pingpong_is_oracle_checked(hip, n_streams, state_mem):
+    """The exact configuration bench.py times (workload.bench_case: heap 4 LDS / 0 spill, mbox_regs 1, mbox_msgs NONE; the
+    compact layout by AUTO: Variant<false,false,6,COMPACT,true>, 152 B per seed, four waves per SIMD — and the plain layout
+    it replaced, state_mem = LDS), 65 536 seeds per launch, 1, 2 and 5 launches in flight through the async entry point:
+    256 sampled seeds k*257 mod 65 536 and 4 096 contiguous seeds of every launch against the oracle."""
     import torch
     w, lim, _ = W.bench_case("pingpong")
+    lim.state_mem = state_mem
     g = hip.geometry(w, lim)
-    assert g.variant & 0xfff == 4 and hip.variant_name(g) == "sim_kernel<Variant<false, false, 6, 0, true, false>>" and g.lanes_per_wave == 64 and g.heap_lds_slots == 4 and g.heap_spill_slots == 0
+    if state_mem == 0:
+        assert g.variant & 0xff == 4 and (g.variant >> 14) & 1 and hip.variant_name(g) == "sim_kernel<Variant<false, false, 6, 64, true, false>>" and g.lds_bytes_per_seed == 152
+    else:
+        assert g.variant & 0xfff == 4 and hip.variant_name(g) == "sim_kernel<Variant<false, false, 6, 0, true, false>>" and g.lds_bytes_per_seed == 200
+    assert g.lanes_per_wave == 64 and g.heap_lds_slots == 4 and g.heap_spill_slots == 0
     n = W.BENCH_SEEDS_PER_GPU
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     bufs = [torch.zeros(n * 48, dtype=torch.uint8, device="cuda") for _ in range(2 * n_streams)]
@@ -804,3 +810,75 @@ def test_no_trace_hash_drops_only_the_fingerprint(hip, case):
     olog, ores = oracle.trace_seed(w, 11, None, lim)
     assert bytes(glog) == bytes(olog) and len(olog) > 0 and gres.astuple() == ores.astuple()
     assert ores.trace_hash == with_log["trace_hash"][0]
+
+
+def _compact(lim):
+    lim.state_mem = A.STATE_COMPACT
+    return lim
+
+
+@pytest.mark.parametrize("nodes,rounds,loss,n", [(4, 64, 0.0, 65536), (2, 64, 0.0, 4096), (6, 9, 0.0, 4096), (4, 16, 0.05, 4096), (4, 16, 1.0, 1024)])
+def test_compact_layout_pingpong(hip, nodes, rounds, loss, n):
+    """MADSIM_STATE_COMPACT (8-byte heap entries on the low deadline word, heap root in registers, main task in global memory):
+    the oracle's answers on every field, with and without the determinism-log fold; 4-node / 65 536 seeds = the bench batch."""
+    w, lim, _ = W.bench_case("pingpong", nodes, rounds, 4)
+    lim.heap_lds_slots = max(4, nodes)
+    cfg = A.Config.default(packet_loss_rate=loss) if loss else None
+    _compact(lim)
+    g = hip.geometry(w, lim)
+    assert g.lds_bytes_per_seed == (lim.heap_lds_slots - 1) * 8 + nodes * 24 + nodes * 8 and (g.variant >> 14) & 1
+    if n > 8192:                                    # the whole batch on the GPU, 512 sampled seeds on the oracle
+        got, _ = hip.run_batch(w, 1 << 33, n, cfg, lim)
+        for j in range(512):
+            i = (j * 257) % n
+            want, _ = oracle.run_batch(w, (1 << 33) + i, 1, cfg, lim)
+            assert got[i] == want[0], (i, got[i], want[0])
+    else:
+        _cmp(hip, w, 5, n, cfg, lim)
+    lim.no_trace_hash = 1
+    _cmp(hip, w, 5, min(n, 4096), cfg, lim)
+
+
+def test_compact_layout_selection_and_horizon(hip):
+    w, lim, _ = W.bench_case("pingpong", 4, 64, 4)
+    g = hip.geometry(w, lim)
+    assert g.lds_bytes_per_seed == 152 and g.blocks_per_cu * g.block_threads // 64 == 16     # auto: four waves per SIMD
+    lim.state_mem = A.STATE_LDS
+    g = hip.geometry(w, lim)
+    assert g.lds_bytes_per_seed == 200 and g.blocks_per_cu * g.block_threads // 64 == 12     # the plain layout stays selectable
+    wl = W.WorkloadBuilder()
+    n1 = wl.create_node()
+    t = wl.task(n1); t.sleep(secs=3)
+    m = wl.main(); m.spawn(t); m.join(t)
+    far = wl.build()
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 4, 0
+    _cmp(hip, far, 0, 256, None, lim)                    # auto: outside the 2^31 ns horizon, the plain layout runs it
+    with pytest.raises(RuntimeError):
+        hip.run_batch(far, 0, 256, None, _compact(lim))
+    w, lim, _ = W.bench_case("pingpong", 4, 8, 4)
+    with pytest.raises(RuntimeError):
+        hip.run_batch(w, 0, 256, A.Config.default(buggify=True), _compact(lim))
+    lim.state_mem = A.STATE_AUTO
+    _cmp(hip, w, 0, 1024, A.Config.default(buggify=True), lim)
+
+
+def test_compact_layout_fuzz_gpu(hip):
+    """Random base-op programs small enough for the compact layout, compact vs oracle; fixed block + fresh block."""
+    import random
+    from tests import fuzz
+    ran = 0
+    for base, n in ((31000, 120), ((FUZZ_SEED * 1_000_003 + 77 * 7919) & 0x7fffffffffff, 120)):
+        for k in range(n):
+            w, cfg, desc = fuzz.random_workload(random.Random(base + k))
+            lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 24, 0
+            lim.mbox_regs, lim.mbox_msgs = 4, 6
+            _compact(lim)
+            try:
+                got, _ = hip.run_batch(w, k * 5, 96, cfg, lim)
+            except RuntimeError:
+                continue                                 # not a compact candidate (tasks, horizon, buggify)
+            want, _ = oracle.run_batch(w, k * 5, 96, cfg, lim)
+            ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+            assert ok.all(), (f"random_workload(Random({base + k})) [MADSIM_FUZZ_SEED={FUZZ_SEED}]", desc, got[~ok][0], want[~ok][0])
+            ran += 1
+    assert ran >= 30, ran
