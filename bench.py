@@ -157,7 +157,7 @@ def main():
     # Three batches in flight need three hardware queues: ROCclr multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4)
     # of them, and on some boxes two of this process's streams ended up sharing one (3 streams slower than 2).  More queues
     # make that less likely; the warm-up trial below still decides between 3 and 2 by measurement.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # torch's streams of the timed loop (up to 5) + the library's own of the campaign legs (up to 5)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -412,11 +412,14 @@ def main():
         import threading
         import oracle
         fcfg = A.Config.default(packet_loss_rate=loss)
-        runtime.run_campaign(w, fs - 4 * count, 4 * count, count, n_streams, False, fcfg, lim)      # warm (streams, buffers, tables)
+        # time to the first failure is a latency: a batch among five in flight takes 5.6 ms, among three 4.1 ms — the search keeps
+        # three in flight whatever the throughput legs use
+        n_search_flights = min(n_streams, 3)
+        runtime.run_campaign(w, fs - 4 * count, 4 * count, count, n_search_flights, False, fcfg, lim)      # warm (streams, buffers, tables)
         torch.cuda.synchronize()
-        rep = runtime.run_campaign(w, fs, max_batches * count, count, n_streams, True, fcfg, lim)
+        rep = runtime.run_campaign(w, fs, max_batches * count, count, n_search_flights, True, fcfg, lim)
         found = rep.first_failing_seed != (1 << 64) - 1
-        res = {"packet_loss_rate": loss, "seeds_per_batch": count, "batches_in_flight": n_streams,
+        res = {"packet_loss_rate": loss, "seeds_per_batch": count, "batches_in_flight": n_search_flights,
                "batches_launched": int(rep.batches_launched), "found": found, "entry_point": "madsim_hip_run_campaign(STOP_AT_FAILURE)"}
         if not found:
             res["note"] = f"no failing seed in {int(rep.batches_run)} batches"
@@ -528,12 +531,16 @@ def main():
         extras = {}
         for name in ("raft", "kv", "topo", "timers"):
             xw, xlim, xname = workload.bench_case(name)
+            xg0 = runtime.geometry(xw, xlim)
+            # batches in flight by THIS workload's occupancy: more than three only where four waves per SIMD fit — a fourth or
+            # fifth batch of a global-state build only pushes its working set out of the Infinity Cache
+            xn = n_streams if xg0.blocks_per_cu * xg0.block_threads // 64 >= 16 else min(n_streams, 3)
             xs, xwu = 3, 3
             xring = torch.zeros((xs + xwu, REPORT_WORDS), dtype=torch.int64, device=dev)
             last = {}
 
             def xstep(k, timed):
-                si = k % n_streams
+                si = k % xn
                 with torch.cuda.stream(streams[si]):
                     runtime.run_batch_async(xw, (1 << 46) + k * count, count, d_outs[si].data_ptr(), xring[k].data_ptr(),
                                             streams[si].cuda_stream, None, xlim, timing_slot=(k % 64) if timed else -1)
@@ -563,7 +570,7 @@ def main():
                     xver += 1
             xg = runtime.geometry(xw, xlim)
             xalgo = xsteps / xs * ALGO_BYTES_PER_STEP + count * IO_BYTES_PER_SEED
-            extras[name] = {"workload": xname, "seeds_per_step": count, "steps": xs, "warmup": xwu, "concurrent_batches": n_streams,
+            extras[name] = {"workload": xname, "seeds_per_step": count, "steps": xs, "warmup": xwu, "concurrent_batches": xn,
                             "ms_per_step": xdt / xs * 1e3, "kernel_ms_per_step": xk_ms,
                             "steps_per_sec": xsteps / xdt, "seeds_per_sec": xs * count / xdt, "sim_seconds_per_sec": xclock / 1e9 / xdt,
                             "failed_seeds": xfail, "verified_seeds": xver, "kernel": runtime.variant_name(xg),
