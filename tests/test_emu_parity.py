@@ -405,3 +405,14 @@ def test_compact_layout_fuzz():
         assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
         ran += 1
     assert ran >= 60, ran
+
+
+@pytest.mark.parametrize("sched", [A.SCHED_STATIC, A.SCHED_QUEUE])
+def test_compact_layout_lane_reuse(sched):
+    """More seeds than lanes: a lane runs several seeds in turn — the main task's global record, the register-resident heap
+    root and the biased LDS task arrays are all re-initialised by seed_init."""
+    w, lim, _ = W.bench_case("pingpong", 4, 8, 4)
+    lim.sched = sched
+    o, _ = oracle.run_batch(w, 9, 2600, A.Config.default(packet_loss_rate=0.02), lim)
+    e = emu.run_batch(w, 9, 2600, A.Config.default(packet_loss_rate=0.02), lim, num_cus=1)
+    assert emu.geometry(w, lim).lds_bytes_per_seed == 152 and (o == e).all()
