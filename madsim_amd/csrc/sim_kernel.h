@@ -117,6 +117,7 @@ struct KParams {
     X(false, true, -1, MADSIM_FEAT_ALL, false, false)  \
     X(false, true, 6, MADSIM_FEAT_TIME, false, true)   \
     X(false, true, 6, MADSIM_FEAT_CHAN, false, true)   \
+    X(false, false, 6, MADSIM_FEAT_CHAN, false, true)  \
     X(false, true, 6, MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR, false, true) \
     X(false, true, 6, MADSIM_FEAT_ALL, false, true)
 #endif
@@ -137,7 +138,9 @@ inline VariantSel select_variant(const KParams& P, bool trace) {
     const int cls = (feat & ~MADSIM_FEAT_TIME) == 0 ? MADSIM_FEAT_TIME : (feat & ~MADSIM_FEAT_CHAN) == 0 ? MADSIM_FEAT_CHAN : MADSIM_FEAT_ALL;
     if (P.gstate_mode) {                                                // task table + planes in global memory: full waves
         if (cls == MADSIM_FEAT_ALL && !(feat & MADSIM_FEAT_ADDR)) return {0, 1, 6, MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR, 0, 1};   // plain addresses
-        return {0, 1, 6, cls, 0, 1};
+        // (connection workloads keep short heaps — a handful of backoff / timeout timers — that sit in LDS whole: a build
+        // without the spill path, like the base-op builds have)
+        return {0, cls == MADSIM_FEAT_CHAN ? spill : 1, 6, cls, 0, 1};
     }
     if (cls != MADSIM_FEAT_ALL) return {0, 1, -1, cls, 0, 0};
     if (lw == 6) return {0, spill, 6, MADSIM_FEAT_ALL, 0, 0};
