@@ -208,6 +208,7 @@ pub const MS_OP_RANDOM: u8 = 54;
 pub const MS_OP_TRACE_TIME: u8 = 55;
 pub const MS_OP_HOOK_REQ: u8 = 56;
 pub const MS_OP_HOOK_RSP: u8 = 57;
+pub const MS_OP_IPVS: u8 = 58;
 pub const MADSIM_PASS: u32 = 0;
 pub const MADSIM_PANIC: u32 = 1;
 pub const MADSIM_DEADLOCK: u32 = 2;
@@ -217,6 +218,10 @@ pub const MADSIM_STEP_LIMIT: u32 = 5;
 
 // ---- #define constants -------------------------------------------------------------------------------------------
 pub const MADSIM_HIP_ABI_VERSION: u32 = 3;
+pub const MADSIM_IPVS_ADD_SERVICE: u32 = 0;
+pub const MADSIM_IPVS_DEL_SERVICE: u32 = 1;
+pub const MADSIM_IPVS_ADD_SERVER: u32 = 2;
+pub const MADSIM_IPVS_DEL_SERVER: u32 = 3;
 pub const MADSIM_TAG_RPC_FIRST: u32 = 0x80;
 pub const MADSIM_TAG_RPC_LAST: u32 = 0xFD;
 pub const MADSIM_SPAWN_MOVE_CONN: u32 = 2;
@@ -234,6 +239,7 @@ pub const MADSIM_ADDR_UNSPECIFIED: u32 = 1;
 pub const MADSIM_ADDR_LOOPBACK: u32 = 2;
 pub const MADSIM_ADDR_VIRTUAL: u32 = 3;
 pub const MADSIM_MAX_SERVICES: u32 = 8;
+pub const MADSIM_SERVICE_ABSENT: u32 = 0x80;
 pub const MADSIM_NODE_RESTART_ON_PANIC: u32 = 1;
 pub const MADSIM_NODE_RESTART_MATCHING: u32 = 4;
 pub const MADSIM_PANIC_CODE_OTHER: u32 = 255;

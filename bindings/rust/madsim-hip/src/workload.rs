@@ -119,6 +119,11 @@ impl TaskBuilder {
     }
     pub fn rpc_recv(&mut self, ep: Addr, req_id: u8) -> &mut Self { self.emit(sys::MS_OP_RECV, ep.0, ((sys::MADSIM_TAG_RPC_FIRST as u16) + req_id as u16) << 8, 0, false) }
     pub fn rpc_reply(&mut self, ep: Addr, code: u8) -> &mut Self { self.emit(sys::MS_OP_RPC_REPLY, ep.0, 0, code as u32, false) }
+    // ---- NetSim::global_ipvs() at run time (net/ipvs.rs:50-85); `service` = the index `ipvs_service` returned -------------------
+    pub fn ipvs_add_service(&mut self, service: u8) -> &mut Self { self.emit(sys::MS_OP_IPVS, sys::MADSIM_IPVS_ADD_SERVICE as u8, service as u16, 0, false) }
+    pub fn ipvs_del_service(&mut self, service: u8) -> &mut Self { self.emit(sys::MS_OP_IPVS, sys::MADSIM_IPVS_DEL_SERVICE as u8, service as u16, 0, false) }
+    pub fn ipvs_add_server(&mut self, service: u8, server: Addr) -> &mut Self { self.emit(sys::MS_OP_IPVS, sys::MADSIM_IPVS_ADD_SERVER as u8, service as u16, server.0 as u32, false) }
+    pub fn ipvs_del_server(&mut self, service: u8, server: Addr) -> &mut Self { self.emit(sys::MS_OP_IPVS, sys::MADSIM_IPVS_DEL_SERVER as u8, service as u16, server.0 as u32, false) }
 }
 
 /// Owns the tables a `madsim_workload_t` points into.
@@ -201,13 +206,16 @@ impl WorkloadBuilder {
         Addr((self.socks.len() - 1) as u8)
     }
     /// `ipvs.add_service(ServiceAddr::Tcp(vaddr), RoundRobin)` + one `add_server` per entry (net/ipvs.rs:50-85), before any task runs
-    pub fn ipvs_service(&mut self, vaddr: Addr, servers: &[Addr]) {
-        assert!(self.services.len() < sys::MADSIM_MAX_SERVICES as usize && servers.len() <= 6);
-        let mut s = sys::madsim_service_t { vaddr: vaddr.0, n_servers: servers.len() as u8, servers: [0; 6] };
+    /// (`absent`: only the address is declared — the service exists once a task calls `ipvs_add_service`).  Returns the service index.
+    pub fn ipvs_service(&mut self, vaddr: Addr, servers: &[Addr], absent: bool) -> u8 {
+        assert!(self.services.len() < sys::MADSIM_MAX_SERVICES as usize && servers.len() <= 6 && !(absent && !servers.is_empty()));
+        let n = if absent { sys::MADSIM_SERVICE_ABSENT as u8 } else { servers.len() as u8 };
+        let mut s = sys::madsim_service_t { vaddr: vaddr.0, n_servers: n, servers: [0; 6] };
         for (i, a) in servers.iter().enumerate() {
             s.servers[i] = a.0;
         }
         self.services.push(s);
+        (self.services.len() - 1) as u8
     }
     /// A new task program on `node` (`node.spawn(async move { .. })` once a `spawn` instruction names it).
     pub fn task(&mut self, node: u8) -> TaskId {

@@ -138,8 +138,19 @@ enum madsim_op {
                               hook.  The hook installed when a typed-RPC response is SENT towards `node` judges it when its
                               delivery timer fires: false (code == imm in mode 0, any response in mode 1) = the timer fires and
                               nothing is delivered.  Responses carry no type id here: the hook sees every response.           */
+    /* -- IP Virtual Server at run time (net/ipvs.rs:50-85): the calls a test makes on NetSim::global_ipvs() -- */
+    MS_OP_IPVS = 58,       /* a=MADSIM_IPVS_*, b=service (index into madsim_workload_t.services), imm=socket-table entry of a
+                              server address (ADD_SERVER / DEL_SERVER).  ADD_SERVICE = HashMap::insert of a fresh Service (no
+                              servers, rr_index 0: also when the service exists); DEL_SERVICE removes it; ADD_SERVER pushes
+                              (`.expect("service not found")`: the calling task panics when the service is absent);
+                              DEL_SERVER = servers.retain(|a| a != server_addr), rr_index untouched — get_server resets an
+                              index that ran off the end (ipvs.rs:96-98).  No draw, no await.                              */
     MS_OP__COUNT
 };
+#define MADSIM_IPVS_ADD_SERVICE 0u
+#define MADSIM_IPVS_DEL_SERVICE 1u
+#define MADSIM_IPVS_ADD_SERVER  2u
+#define MADSIM_IPVS_DEL_SERVER  3u
 
 /* Typed RPC (net/rpc.rs): request tags R::ID are the tag values 0x80..0xFD; a message received on one carries the
  * caller's response tag besides its 8-bit request code (val), and MS_OP_SPAWN with MADSIM_SPAWN_MOVE_REQUEST hands
@@ -216,13 +227,18 @@ typedef struct madsim_sock {
  * message is then lost, clogged or finds no socket.  Everything downstream sees the rewritten address: the link test, the
  * socket lookup, the `dst` a connection's channel() halves are built from.  (An RPC caller still asserts `from == dst` with
  * the address it was GIVEN, rpc.rs:126: a typed call through a virtual address panics when the real server answers, as in
- * the reference.)  The service table is static: add_server / del_server at run time are not modelled. */
+ * the reference.)  The table gives every service's address and its state before the first task runs; MS_OP_IPVS changes
+ * that state at run time (add_service / del_service / add_server / del_server, ipvs.rs:50-85), per seed, at most 6 servers
+ * per service at any time (a seventh add_server yields MADSIM_OVERFLOW). */
 typedef struct madsim_service {
     uint8_t vaddr;       /* socket-table entry holding the service address (any kind; typically MADSIM_ADDR_VIRTUAL) */
-    uint8_t n_servers;   /* 0..6 real servers, in add_server order; 0 = get_server() returns None: no rewrite        */
+    uint8_t n_servers;   /* 0..6 real servers, in add_server order; 0 = get_server() returns None: no rewrite.
+                            | MADSIM_SERVICE_ABSENT: only the address is declared — the service does not exist until a task
+                            runs MS_OP_IPVS ADD_SERVICE on it (n_servers & 7 must be 0 then)                          */
     uint8_t servers[6];  /* socket-table entries of the real server addresses                                       */
 } madsim_service_t;
 #define MADSIM_MAX_SERVICES 8u
+#define MADSIM_SERVICE_ABSENT 0x80u
 
 typedef struct madsim_node {
     uint8_t flags;       /* MADSIM_NODE_* */

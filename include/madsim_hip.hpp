@@ -212,6 +212,11 @@ class Task {
         return emit(MS_OP_HOOK_REQ, (uint8_t)node, (uint16_t)(((MADSIM_TAG_RPC_FIRST + req_id) << 8) | (code ? 0 : 1)), code ? *code : 0);
     }
     Task& hook_rpc_rsp(int node, std::optional<uint8_t> code = std::nullopt) { return emit(MS_OP_HOOK_RSP, (uint8_t)node, code ? 0 : 1, code ? *code : 0); }
+    // NetSim::global_ipvs() at run time (net/ipvs.rs:50-85); `service` = the index ipvs_service returned
+    Task& ipvs_add_service(int service) { return emit(MS_OP_IPVS, MADSIM_IPVS_ADD_SERVICE, (uint16_t)service); }
+    Task& ipvs_del_service(int service) { return emit(MS_OP_IPVS, MADSIM_IPVS_DEL_SERVICE, (uint16_t)service); }
+    Task& ipvs_add_server(int service, int server) { return emit(MS_OP_IPVS, MADSIM_IPVS_ADD_SERVER, (uint16_t)service, (uint32_t)server); }
+    Task& ipvs_del_server(int service, int server) { return emit(MS_OP_IPVS, MADSIM_IPVS_DEL_SERVER, (uint16_t)service, (uint32_t)server); }
     Task& spawn_move_request(const Task& t) { return emit(MS_OP_SPAWN, (uint8_t)t.index_, MADSIM_SPAWN_MOVE_REQUEST); }
     // supervisor (Handle::kill / restart / pause / resume / is_exit, JoinHandle::abort)
     Task& kill(int node) { return emit(MS_OP_KILL, (uint8_t)node); }
@@ -308,12 +313,14 @@ class WorkloadBuilder {
     // a virtual service address that belongs to no node ("1.1.1.<ip_id>:port"): a destination only
     int virtual_addr(uint8_t ip_id, uint16_t port) { socks_.push_back(madsim_sock_t{ip_id, MADSIM_ADDR_VIRTUAL, port}); return (int)socks_.size() - 1; }
     // ipvs.add_service(ServiceAddr::Tcp(vaddr), RoundRobin) + add_server per entry (net/ipvs.rs:50-85), before any task runs
-    void ipvs_service(int vaddr, const std::vector<int>& servers) {
-        if (services_.size() >= MADSIM_MAX_SERVICES || servers.size() > 6) throw std::length_error("at most 8 services of at most 6 servers");
+    // (absent = only the address is declared: the service exists once a task calls ipvs_add_service).  Returns the service index.
+    int ipvs_service(int vaddr, const std::vector<int>& servers = {}, bool absent = false) {
+        if (services_.size() >= MADSIM_MAX_SERVICES || servers.size() > 6 || (absent && !servers.empty())) throw std::length_error("at most 8 services of at most 6 servers");
         madsim_service_t s{};
-        s.vaddr = (uint8_t)vaddr; s.n_servers = (uint8_t)servers.size();
+        s.vaddr = (uint8_t)vaddr; s.n_servers = absent ? (uint8_t)MADSIM_SERVICE_ABSENT : (uint8_t)servers.size();
         for (size_t i = 0; i < servers.size(); i++) s.servers[i] = (uint8_t)servers[i];
         services_.push_back(s);
+        return (int)services_.size() - 1;
     }
     // 10.0.0.<node>:port, or 0.0.0.0:port / 127.0.0.1:port as used on `node` (kind = MADSIM_ADDR_*).  port 0 = an ephemeral
     // Endpoint (network.rs:224-236): each bind gets the node's lowest free port for that IP; not a destination operand.

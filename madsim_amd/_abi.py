@@ -26,6 +26,8 @@ class Prog(C.Structure):
 
 ADDR_IP, ADDR_UNSPECIFIED, ADDR_LOOPBACK, ADDR_VIRTUAL = 0, 1, 2, 3
 MAX_SERVICES = 8
+SERVICE_ABSENT = 0x80       # madsim_service_t.n_servers: the address is declared, the service added by a task (MS_OP_IPVS)
+IPVS_ADD_SERVICE, IPVS_DEL_SERVICE, IPVS_ADD_SERVER, IPVS_DEL_SERVER = 0, 1, 2, 3
 VAL_ADDR_NOT_AVAILABLE, VAL_ADDR_IN_USE = 0xFFFFFFFC, 0xFFFFFFFB
 NODE_NO_IP = 2
 
@@ -141,7 +143,7 @@ OP = dict(
     SLEEP=10, MARK=11, SLEEP_UNTIL=12, ASSERT_ELAPSED=13, ADVANCE=14, BUILD=15,
     BIND=20, SEND=21, REPLY=22, RECV=23, ASSERT_VAL=24, RECV_TIMEOUT=25, CLOSE=26,
     KILL=30, RESTART=31, PAUSE=32, RESUME=33, CLOG_NODE=34, UNCLOG_NODE=35, CLOG_LINK=36,
-    UNCLOG_LINK=37, ASSERT_EXIT=38, SET_LOSS=39, SLEEP_RAND=40, GSET=41, GADD=42, ASSERT_G=43, PANIC_IF_G_LT=44, JEQ=45, CONNECT=46, ACCEPT=47, CSEND=48, CRECV=49, CCLOSE=50, RPC_CALL=51, RPC_REPLY=52, RAND_BOOL=53, RANDOM=54, TRACE_TIME=55, HOOK_REQ=56, HOOK_RSP=57,
+    UNCLOG_LINK=37, ASSERT_EXIT=38, SET_LOSS=39, SLEEP_RAND=40, GSET=41, GADD=42, ASSERT_G=43, PANIC_IF_G_LT=44, JEQ=45, CONNECT=46, ACCEPT=47, CSEND=48, CRECV=49, CCLOSE=50, RPC_CALL=51, RPC_REPLY=52, RAND_BOOL=53, RANDOM=54, TRACE_TIME=55, HOOK_REQ=56, HOOK_RSP=57, IPVS=58,
 )
 PROG_INIT, PROG_PRE, PROG_DROP_SPAWN = 1, 2, 4
 NODE_RESTART_ON_PANIC = 1

@@ -102,9 +102,9 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
     if (w->n_services > MADSIM_MAX_SERVICES || (w->n_services && !w->services)) return fail(err, MADSIM_E_WORKLOAD, "at most 8 IPVS services");
     for (uint32_t k = 0; k < w->n_services; k++) {
         const madsim_service_t& sv = w->services[k];
-        if (sv.vaddr >= w->n_socks || sv.n_servers > 6) return fail(err, MADSIM_E_WORKLOAD, "IPVS service: bad address entry or more than 6 servers");
+        if (sv.vaddr >= w->n_socks || (sv.n_servers > 6 && sv.n_servers != MADSIM_SERVICE_ABSENT)) return fail(err, MADSIM_E_WORKLOAD, "IPVS service: bad address entry, more than 6 servers, or servers on a service declared absent");
         if (w->socks[sv.vaddr].port == 0) return fail(err, MADSIM_E_WORKLOAD, "IPVS service: the service address needs a port");
-        for (uint32_t j = 0; j < sv.n_servers; j++)
+        for (uint32_t j = 0; j < (sv.n_servers & 7u); j++)
             if (sv.servers[j] >= w->n_socks || w->socks[sv.servers[j]].port == 0) return fail(err, MADSIM_E_WORKLOAD, "IPVS service: a server must be a named address entry");
         for (uint32_t j = 0; j < k; j++) {               // a HashMap keyed by the address: one service per address
             const madsim_sock_t &x = w->socks[sv.vaddr], &y = w->socks[w->services[j].vaddr];
@@ -141,6 +141,10 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
             break;
         case MS_OP_RPC_REPLY:
             if (in.a >= w->n_socks) return fail(err, MADSIM_E_WORKLOAD, "socket operand out of range"); break;
+        case MS_OP_IPVS:
+            if (in.a > MADSIM_IPVS_DEL_SERVER || in.b >= w->n_services) return fail(err, MADSIM_E_WORKLOAD, "ipvs: bad call or service index");
+            if (in.a >= MADSIM_IPVS_ADD_SERVER && (in.imm >= w->n_socks || w->socks[in.imm].port == 0)) return fail(err, MADSIM_E_WORKLOAD, "ipvs: a server must be a named address entry");
+            break;
         case MS_OP_HOOK_REQ:
             if ((uint32_t)(in.b >> 8) < MADSIM_TAG_RPC_FIRST || (uint32_t)(in.b >> 8) > MADSIM_TAG_RPC_LAST) return fail(err, MADSIM_E_WORKLOAD, "hook_rpc_req needs a typed request tag (0x80..0xFD)");
             /* fall through */
@@ -312,7 +316,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         P.off_conn = P.off_greg + (gregs ? 4 : 0);
         P.off_hooks = P.off_conn + (P.uses_chan ? P.max_conns * P.conn_words : 0);
         P.off_ipvs = P.off_hooks + (P.uses_hooks ? P.n_nodes + 1 : 0);
-        P.lane_words = P.off_ipvs + P.n_services;
+        P.ipvs_dyn = uses_op(w, MS_OP_IPVS);
+        P.lane_words = P.off_ipvs + P.n_services * (P.ipvs_dyn ? 2 : 1);
         if (P.gstate_mode) {           // the planes just laid out go to the global block; LDS keeps the ready queue only
             P.gs_plane_words = P.lane_words;
             P.gs_planes = P.max_tasks * P.task_units * 16;

@@ -16,6 +16,12 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
     }
     else for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;     // plane 0 is the ready queue: RW spans all planes
     for (uint32_t t = 0; t < P.max_tasks; t++) { TWORD(c, t, 0, 0) = 0; if (!K::LIFE) TWORD(c, t, 1, 1) = 0; }
+    if (K::FA && P.ipvs_dyn)                               // the services as the table declares them: the ipvs calls made before the first task runs
+        for (uint32_t k = 0; k < P.n_services; k++) {
+            const uint32_t w0 = SMEM[c.nodet0 + P.svc_off + 2 * k], w1 = SMEM[c.nodet0 + P.svc_off + 2 * k + 1];
+            IPVSW(2 * k) = (w0 >> 16) | (w1 << 16);
+            IPVSW(2 * k + 1) = (w1 >> 16) | (((w0 >> 8) & 7u) << 16) | ((w0 & 0x8000u) ? 0u : 1u << 24);
+        }
     // GlobalRng::new_with_seed -> Xoshiro256PlusPlus::seed_from_u64: SplitMix64 [DEP A.1]
     uint64_t x = seed, z;
 #define SPLITMIX(dst) x += 0x9e3779b97f4a7c15ull; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; dst = z ^ (z >> 31)

@@ -75,7 +75,18 @@ __device__ __forceinline__ void ipvs_rewrite(const Ctx& c, uint32_t& idx, uint32
         const uint32_t w0 = SMEM[c.nodet0 + c.P.svc_off + 2 * k], w1 = SMEM[c.nodet0 + c.P.svc_off + 2 * k + 1];
         if (addr_eq(SOCKW(c, w0 & 0xff), addr)) {
             found = true;
-            const uint32_t n = (w0 >> 8) & 0xff;
+            if (c.P.ipvs_dyn) {                 // the service's state is the seed's own (MS_OP_IPVS, k_poll.h): {servers[0..3]}, {servers[4..5], n, rr, present}
+                const uint32_t d0 = IPVSW(2 * k), d1 = IPVSW(2 * k + 1), n = (d1 >> 16) & 0xf;
+                if ((d1 >> 24) & 1u && n) {
+                    uint32_t i = (d1 >> 20) & 0xf;
+                    if (i >= n) i = 0;
+                    IPVSW(2 * k + 1) = (d1 & ~(0xfu << 20)) | ((i + 1) << 20);
+                    const uint32_t srv = i < 4 ? (d0 >> (8 * i)) & 0xff : (d1 >> (8 * (i - 4))) & 0xff;
+                    idx = srv; addr = SOCKW(c, srv);
+                }
+                continue;
+            }
+            const uint32_t n = (w0 >> 8) & 0x7;      // (bit 7: declared absent — no servers either)
             if (n) {
                 uint32_t i = IPVSW(k);
                 if (i >= n) i = 0;

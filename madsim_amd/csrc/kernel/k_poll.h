@@ -597,6 +597,37 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.x |= TF_SCHED;                          // wake_by_ref while RUNNING
                 st = ST_PENDING;
                 break;
+            case MS_OP_IPVS: {                              // IpVirtualServer::{add,del}_{service,server} (net/ipvs.rs:50-85)
+                if (!K::FA) { st = ST_PANIC; break; }
+                const uint32_t k = b & 7u;
+                uint32_t d0 = IPVSW(2 * k), d1 = IPVSW(2 * k + 1), n = (d1 >> 16) & 0xf;
+                bool ok = true;
+                if (a == MADSIM_IPVS_ADD_SERVICE) { d0 = 0; d1 = 1u << 24; }                 // insert(addr, Service { servers: [], rr_index: 0 })
+                else if (a == MADSIM_IPVS_DEL_SERVICE) d1 &= ~(1u << 24);                    // remove
+                else if (!((d1 >> 24) & 1u)) ok = false;                                     // .expect("service not found")
+                else if (a == MADSIM_IPVS_ADD_SERVER) {                                      // servers.push
+                    if (n >= 6) L.ovf = 1;
+                    else {
+                        if (n < 4) d0 |= (imm & 0xff) << (8 * n); else d1 |= (imm & 0xff) << (8 * (n - 4));
+                        d1 += 1u << 16;
+                    }
+                } else {                                                                     // servers.retain(|addr| addr != server_addr)
+                    const uint32_t gone = SOCKW(c, imm & 0xff);
+                    uint32_t e0 = 0, e1 = d1 & 0xfff00000u, m = 0;
+                    for (uint32_t j = 0; j < n; j++) {
+                        const uint32_t sj = j < 4 ? (d0 >> (8 * j)) & 0xff : (d1 >> (8 * (j - 4))) & 0xff;
+                        if (!addr_eq(SOCKW(c, sj), gone)) {
+                            if (m < 4) e0 |= sj << (8 * m); else e1 |= sj << (8 * (m - 4));
+                            m++;
+                        }
+                    }
+                    d0 = e0; d1 = e1 | (m << 16);
+                }
+                if (!ok) { st = ST_PANIC; break; }
+                IPVSW(2 * k) = d0; IPVSW(2 * k + 1) = d1;
+                pc++;
+                break;
+            }
             case MS_OP_HOOK_REQ:                            // NetSim::hook_rpc_req (net/mod.rs:240-262): HashMap::insert
                 if (!K::FR) { st = ST_PANIC; break; }
                 HOOKW(a) = ((uint32_t)HOOKW(a) & ~0x3ffffu) | 1u | ((b & 1) << 1) | ((imm & 0xff) << 2) | ((b >> 8) << 10);

@@ -247,7 +247,9 @@ template <class K> __device__ __forceinline__ WRef<K::G> plane_ref(const Ctx& c,
 // NetSim message hooks of node n (net/mod.rs:250-284): request hook valid:1 | all:1<<1 | code:8<<2 | tag:8<<10,
 //                                                      response hook valid:1<<18 | all:1<<19 | code:8<<20
 #define HOOKW(n_) plane_ref<K>(c, c.hook0, (n_))
-// round-robin counter of IPVS service k (net/ipvs.rs Service::rr_index)
+// round-robin counter of IPVS service k (net/ipvs.rs Service::rr_index); workloads that change services at run time
+// (KParams.ipvs_dyn): two words per service — [2k] servers[0..3], a socket-table entry per byte; [2k + 1] servers[4] |
+// servers[5] << 8 | n << 16 | rr_index << 20 | present << 24
 #define IPVSW(k_) plane_ref<K>(c, c.ipvs0, (k_))
 // connection id_: [0] alive:1 | c_ep:6<<1 | d_ep:6<<7 (the address dialled) | tx0:1<<13 rx0<<14 tx1<<15 rx1<<16 | qn0:4<<17 | qn1:4<<21
 //                 [1 + dir] parked receiver: valid:1 | slot:8<<1 | gen:16<<9;  [3 + (dir * Q + i) * 3 ..] {val, arrive lo, arrive hi}

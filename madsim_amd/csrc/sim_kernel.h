@@ -36,7 +36,7 @@ struct KParams {
     const uint32_t* socks;     // node | kind<<8 | port<<16 (a SocketAddr as one word)
     const uint32_t* nodes;     // n_nodetab words: per node its flags word; then (pm_off != 0) 8 words per node: the 256-bit row "a panic
                                // with message code c restarts this node"; then (n_services != 0) 2 words per IPVS service:
-                               // vaddr | n_servers<<8 | servers[0]<<16 | servers[1]<<24, servers[2..5]
+                               // vaddr | n_servers<<8 (| 0x80<<8: declared absent) | servers[0]<<16 | servers[1]<<24, servers[2..5]
     const uint64_t* dur_table; // per MS_OP_SLEEP_RAND (its `a` is rewritten to an index): {mode, low, range, zone}
     uint32_t n_insns, n_progs, n_socks, n_nodes;
     // net config (Bernoulli p_int, UniformDuration parameters precomputed on the host)
@@ -58,6 +58,7 @@ struct KParams {
     // per-lane plane offsets (in words)
     uint32_t off_ready, off_socks, off_handles, off_nodes, off_clog, off_pause, off_greg, off_conn, off_hooks;
     uint32_t n_nodetab, pm_off, svc_off, n_services;   // layout of the node table (word offsets from its start; 0 = absent)
+    uint32_t ipvs_dyn;         // MS_OP_IPVS present: the services' server lists are per-seed state (k_state.h IPVSW), initialised from the table
     uint32_t panic_dyn_max;    // largest code a run-time formatted panic message may have (madsim_workload_t.panic_dyn_max)
     uint32_t off_ipvs;         // per-seed plane: one round-robin counter per IPVS service (net/ipvs.rs rr_index)
     uint32_t uses_eph;         // ephemeral Endpoint handles in the socket table (geometry.h device_socks)

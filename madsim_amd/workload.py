@@ -150,6 +150,23 @@ class TaskBuilder:
         """NetSim::current().hook_rpc_rsp::<R>(node, |rsp| ..): drop responses on their way to `node` (net/mod.rs:264-284)."""
         return self._emit("HOOK_RSP", a=node, b=1 if code is None else 0, imm=code or 0)
 
+    # -- IP Virtual Server at run time (NetSim::global_ipvs(), net/ipvs.rs:50-85) ---------------------
+    def ipvs_add_service(self, service):
+        """ipvs.add_service(addr, RoundRobin): HashMap::insert of a fresh Service — no servers, rr_index 0, also when it exists."""
+        return self._emit("IPVS", a=A.IPVS_ADD_SERVICE, b=service)
+
+    def ipvs_del_service(self, service):
+        """ipvs.del_service(addr): the service and its servers are gone; sends to its address are no longer rewritten."""
+        return self._emit("IPVS", a=A.IPVS_DEL_SERVICE, b=service)
+
+    def ipvs_add_server(self, service, server):
+        """ipvs.add_server(addr, server): servers.push; panics ("service not found") when the service is absent."""
+        return self._emit("IPVS", a=A.IPVS_ADD_SERVER, b=service, imm=server)
+
+    def ipvs_del_server(self, service, server):
+        """ipvs.del_server(addr, server): servers.retain(|a| a != server); rr_index stays (get_server wraps it, ipvs.rs:96-98)."""
+        return self._emit("IPVS", a=A.IPVS_DEL_SERVER, b=service, imm=server)
+
     def rpc_recv(self, ep, req_id):
         """(req, from) = recv_from_raw(R::ID) of a handler loop (rpc.rs:161): val = request code."""
         return self._emit("RECV", a=ep, b=(0x80 + req_id) << 8)
@@ -366,14 +383,16 @@ class WorkloadBuilder:
         self.socks.append(A.Sock(ip_id, A.ADDR_VIRTUAL, port))
         return len(self.socks) - 1
 
-    def ipvs_service(self, vaddr, servers):
+    def ipvs_service(self, vaddr, servers=(), absent=False):
         """`ipvs.add_service(ServiceAddr::Tcp(vaddr), Scheduler::RoundRobin)` + one `add_server` per entry of `servers`, before
         any task runs (net/ipvs.rs:50-85; the reference test net/tcp/mod.rs:254-315): send_to / call / connect1 towards `vaddr`
-        go to the servers in turn (net/mod.rs:312-317,345-350)."""
+        go to the servers in turn (net/mod.rs:312-317,345-350).  absent=True only declares the address: the service does not
+        exist until a task calls ipvs_add_service.  Tasks change services at run time with ipvs_add_service / ipvs_del_service /
+        ipvs_add_server / ipvs_del_server."""
         servers = list(servers)
-        if len(self.services) >= A.MAX_SERVICES or len(servers) > 6:
-            raise ValueError("at most 8 services with at most 6 servers each")
-        sv = A.Service(vaddr, len(servers))
+        if len(self.services) >= A.MAX_SERVICES or len(servers) > 6 or (absent and servers):
+            raise ValueError("at most 8 services with at most 6 servers each; a service declared absent has none")
+        sv = A.Service(vaddr, A.SERVICE_ABSENT if absent else len(servers))
         for i, e in enumerate(servers):
             sv.servers[i] = e
         self.services.append(sv)

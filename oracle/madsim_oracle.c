@@ -193,6 +193,9 @@ typedef struct {
     /* accounting */
     uint8_t panic_code;                                  /* message code of the panic being unwound */
     uint32_t ipvs_rr[MADSIM_MAX_SERVICES];               /* Service.rr_index of every virtual service (net/ipvs.rs:37-41) */
+    uint8_t ipvs_present[MADSIM_MAX_SERVICES];           /* the service is in the HashMap (ipvs.rs:11-13) */
+    uint16_t ipvs_n[MADSIM_MAX_SERVICES];                /* Service.servers: Vec<String>, as socket-table entries of the addresses */
+    uint8_t ipvs_srv[MADSIM_MAX_SERVICES][256];          /* (a Vec: the device's six-server capacity is not the oracle's concern) */
     uint64_t msg_count; uint32_t steps; uint64_t obs_hash;
     uint32_t greg[4];                     /* Arc<AtomicUsize> flags shared by the test's tasks       */
     VEC(conn_t) conns;
@@ -387,10 +390,11 @@ static addr_t ipvs_rewrite(sim_t* S, addr_t dst) {
         const madsim_service_t* sv = &w->services[k];
         const addr_t va = { w->socks[sv->vaddr].kind, w->socks[sv->vaddr].node, w->socks[sv->vaddr].port };
         if (!addr_eq(va, dst)) continue;
-        if (sv->n_servers == 0) return dst;               /* Some(service) with no servers: None */
+        if (!S->ipvs_present[k]) return dst;              /* services.get_mut(..)? : None */
+        if (S->ipvs_n[k] == 0) return dst;                /* Some(service) with no servers: None */
         uint32_t* i = &S->ipvs_rr[k];
-        if (*i >= sv->n_servers) *i = 0;
-        const madsim_sock_t* e = &w->socks[sv->servers[*i]];
+        if (*i >= S->ipvs_n[k]) *i = 0;
+        const madsim_sock_t* e = &w->socks[S->ipvs_srv[k][*i]];
         *i += 1;
         addr_t real = { e->kind, e->node, e->port };
         return real;
@@ -747,6 +751,25 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (t->sub == 0) { t->sub = 1; wake(S, slot, t->gen); return 0; }
             t->sub = 0; t->pc++;
             break;
+        case MS_OP_IPVS: {                                 /* IpVirtualServer::{add,del}_{service,server} (net/ipvs.rs:50-85) */
+            const uint32_t k = in->b;
+            if (in->a == MADSIM_IPVS_ADD_SERVICE) { S->ipvs_present[k] = 1; S->ipvs_n[k] = 0; S->ipvs_rr[k] = 0; }   /* insert: replaces */
+            else if (in->a == MADSIM_IPVS_DEL_SERVICE) S->ipvs_present[k] = 0;
+            else {
+                if (!S->ipvs_present[k]) return 1;         /* .expect("service not found") */
+                if (in->a == MADSIM_IPVS_ADD_SERVER) {
+                    if (S->ipvs_n[k] >= 256) return 1;      /* (this restatement's own bound; the device gives MADSIM_OVERFLOW beyond six) */
+                    S->ipvs_srv[k][S->ipvs_n[k]++] = (uint8_t)in->imm;      /* servers.push */
+                } else {                                    /* servers.retain(|addr| addr != server_addr): equal address strings */
+                    const addr_t gone = addr_of_sock(S, in->imm);
+                    uint32_t n = 0;
+                    for (uint32_t j = 0; j < S->ipvs_n[k]; j++)
+                        if (!addr_eq(addr_of_sock(S, S->ipvs_srv[k][j]), gone)) S->ipvs_srv[k][n++] = S->ipvs_srv[k][j];
+                    S->ipvs_n[k] = (uint16_t)n;
+                }
+            }
+            t->pc++; break;
+        }
         case MS_OP_HOOK_REQ: {                             /* NetSim::hook_rpc_req (net/mod.rs:240-262): HashMap::insert */
             node_t* n = &S->nodes[in->a];
             n->hreq_valid = 1; n->hreq_all = in->b & 1; n->hreq_tag = (uint8_t)(in->b >> 8); n->hreq_code = (uint8_t)in->imm;
@@ -1255,12 +1278,15 @@ static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
     for (uint32_t i = 0; i < w->n_socks; i++) if (w->socks[i].kind > MADSIM_ADDR_VIRTUAL) return -1;
     if (w->n_services > MADSIM_MAX_SERVICES || (w->n_services && !w->services)) return -1;
     for (uint32_t k = 0; k < w->n_services; k++) {
-        if (w->services[k].vaddr >= w->n_socks || w->services[k].n_servers > 6) return -1;
-        for (uint32_t j = 0; j < w->services[k].n_servers; j++) if (w->services[k].servers[j] >= w->n_socks) return -1;
+        const uint32_t ns = w->services[k].n_servers;
+        if (w->services[k].vaddr >= w->n_socks || (ns > 6 && ns != MADSIM_SERVICE_ABSENT)) return -1;
+        for (uint32_t j = 0; j < (ns & 7u); j++) if (w->services[k].servers[j] >= w->n_socks) return -1;
     }
     for (uint32_t i = 0; i < w->n_insns; i++) {           /* an ephemeral Endpoint has no address a peer could name */
         const madsim_insn_t* in = &w->insns[i];
         if (in->op == MS_OP_BIND && in->a < w->n_socks && w->socks[in->a].kind == MADSIM_ADDR_VIRTUAL) return -1;   /* a destination only */
+        if (in->op == MS_OP_IPVS && (in->a > MADSIM_IPVS_DEL_SERVER || in->b >= w->n_services ||
+                                     (in->a >= MADSIM_IPVS_ADD_SERVER && (in->imm >= w->n_socks || w->socks[in->imm].port == 0)))) return -1;
         if ((in->op == MS_OP_SEND || in->op == MS_OP_CONNECT || in->op == MS_OP_RPC_CALL) &&
             (uint32_t)(in->b & 0xff) < w->n_socks && w->socks[in->b & 0xff].port == 0) return -1;
     }
@@ -1311,6 +1337,12 @@ static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, cons
     for (uint32_t i = 0; i < w->n_socks; i++) {
         S.socks[i].acc_task = -1;
         S.socks[i].port = w->socks[i].port;               /* 0: ephemeral, set by its bind (never a destination: validate) */
+    }
+    for (uint32_t k = 0; k < w->n_services; k++) {        /* the table = the ipvs calls made before the first task runs */
+        const madsim_service_t* sv = &w->services[k];
+        S.ipvs_present[k] = !(sv->n_servers & MADSIM_SERVICE_ABSENT);
+        S.ipvs_n[k] = sv->n_servers & 7u;
+        for (uint32_t j = 0; j < S.ipvs_n[k]; j++) S.ipvs_srv[k][j] = sv->servers[j];
     }
     S.trace_hash = FNV_OFFSET; S.obs_hash = FNV_OFFSET;
     S.log = log; S.log_cap = log_cap;

@@ -819,13 +819,16 @@ def random_channel_workload(rng: random.Random):
     return wl.build(), cfg, f"{n_srv}s/{len(cli_nodes)}c/{len(tasks)}t"
 
 
-def random_ipvs_workload(rng: random.Random):
+def random_ipvs_workload(rng: random.Random, runtime_ops=False):
     """Programs over IP Virtual Server rewriting (net/ipvs.rs; NetSim::send / connect1, net/mod.rs:312-317,345-350): one to
     three services — on virtual addresses and sometimes on a real one — with zero to three servers each (bound listeners,
     addresses nobody binds, 0.0.0.0 listeners reached through the node IP), virtual addresses without a service; clients send
     datagrams, dial connect1, and now and then make a typed call (which panics when a real server answers for a virtual
     address, rpc.rs:126).  Round-robin counters advance per seed whatever becomes of the message.  Any verdict is fine; it
-    has to be the oracle's."""
+    has to be the oracle's.  runtime_ops (random_ipvs_runtime_workload): some services are only declared, and one or two operator
+    tasks call add_service / del_service / add_server / del_server (net/ipvs.rs:50-85) between sleeps while the clients
+    run — mostly on services that exist at that point (each operator's calls are straight-line, so the generator tracks the
+    server lists and keeps them within the device's six), now and then on one that does not (the operator panics)."""
     wl = W.WorkloadBuilder()
     n_srv, n_cli = rng.randint(2, 3), rng.randint(1, 2)
     srv_nodes = [wl.create_node() for _ in range(n_srv)]
@@ -858,6 +861,9 @@ def random_ipvs_workload(rng: random.Random):
         if key in seen or rng.random() < 0.25:                                   # a virtual address without a service (or a twin of one)
             continue
         seen.add(key)
+        if runtime_ops and rng.random() < 0.35:
+            wl.ipvs_service(v, absent=True)
+            continue
         wl.ipvs_service(v, [rng.choice(named) for _ in range(rng.randint(0, 3))])
     if rng.random() < 0.3 and len(wl.services) < 3:                              # a service keyed by a REAL address
         real = rng.choice(named)
@@ -884,8 +890,41 @@ def random_ipvs_workload(rng: random.Random):
         c.sleep(ms=rng.choice([1, 3, 9]))
         c.djnz(0, top)
         tasks.append(c)
+    operators = []
+    if runtime_ops and wl.services:
+        # what each service holds when an operator's next call runs, were it alone: with two operators the lists interleave, so
+        # the second one only deletes (a capacity verdict must not depend on timing) and may find a service gone (a panic: fine)
+        state = [None if sv.n_servers & A.SERVICE_ABSENT else [sv.servers[j] for j in range(sv.n_servers)] for sv in wl.services]
+        for o in range(rng.randint(1, 2)):
+            op = wl.task(rng.choice(cli_nodes + srv_nodes))
+            op.sleep(ms=rng.randint(1, 12))
+            for _ in range(rng.randint(3, 9)):
+                k = rng.randrange(len(wl.services))
+                r = rng.random()
+                reckless = rng.random() < 0.06
+                if o == 0 and r < 0.2:
+                    op.ipvs_add_service(k); state[k] = []
+                elif r < 0.3:
+                    op.ipvs_del_service(k)
+                    if o == 0:
+                        state[k] = None
+                elif o == 0 and r < 0.7:
+                    if (state[k] is not None and len(state[k]) < 6) or (state[k] is None and reckless):
+                        srv = rng.choice(named)
+                        op.ipvs_add_server(k, srv)
+                        if state[k] is not None:
+                            state[k].append(srv)
+                elif state[k] is not None or reckless:
+                    srv = rng.choice(named)
+                    op.ipvs_del_server(k, srv)
+                    if state[k] is not None and o == 0:
+                        gone = (wl.socks[srv].node, wl.socks[srv].kind, wl.socks[srv].port)
+                        state[k] = [x for x in state[k] if (wl.socks[x].node, wl.socks[x].kind, wl.socks[x].port) != gone]
+                op.sleep(ms=rng.choice([1, 4, 9, 15]))
+            operators.append(op)
+        desc.append(f"{len(operators)}op")
     m = wl.main()
-    for t in tasks:
+    for t in tasks + operators:
         m.spawn(t)
     if rng.random() < 0.4:
         m.sleep(ms=rng.randint(10, 40)); m.clog_node(rng.choice(srv_nodes), "both"); m.sleep(ms=20); m.unclog_node(srv_nodes[0], "both")
@@ -893,3 +932,8 @@ def random_ipvs_workload(rng: random.Random):
         m.join(t, expect_err=False)
     cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.15]))
     return wl.build(), cfg, "+".join(desc)
+
+
+def random_ipvs_runtime_workload(rng: random.Random):
+    """random_ipvs_workload with services changed at run time (MS_OP_IPVS)."""
+    return random_ipvs_workload(rng, runtime_ops=True)

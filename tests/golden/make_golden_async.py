@@ -112,7 +112,10 @@ class Sim:
         self.ipvs = {}
         for k in range(w.struct.n_services):
             sv = w.services[k]
+            if sv.n_servers & 0x80:                 # declared only: a task adds the service (MS_OP_IPVS)
+                continue
             self.ipvs[self.addr[sv.vaddr]] = {"servers": [self.addr[sv.servers[j]] for j in range(sv.n_servers)], "rr_index": 0}
+        self.service_addr = [self.addr[w.services[k].vaddr] for k in range(w.struct.n_services)]
         # port 0 = an ephemeral Endpoint: its address is whatever its last bind was given (never a destination operand)
         self.ephemeral = [w.socks[i].port == 0 for i in range(w.struct.n_socks)]
         n_nodes = w.struct.n_nodes
@@ -605,6 +608,20 @@ class Sim:
                     raise Panic(imm & 0xFF)
                 v = (self.flags[b & 3] + imm) & 0xFFFFFFFF      # panic!("{}", flag + imm): values past panic_dyn_max are outside the model
                 raise Panic(v if v <= self.panic_dyn_max else 255)
+            elif name == "IPVS":                    # NetSim::global_ipvs().{add,del}_{service,server} (net/ipvs.rs:50-85)
+                key = self.service_addr[b]
+                if a == 0:
+                    self.ipvs[key] = {"servers": [], "rr_index": 0}             # HashMap::insert: a fresh Service
+                elif a == 1:
+                    self.ipvs.pop(key, None)
+                else:
+                    service = self.ipvs.get(key)
+                    if service is None:
+                        raise Panic(255)                                         # .expect("service not found")
+                    if a == 2:
+                        service["servers"].append(self.addr[imm])
+                    else:
+                        service["servers"] = [x for x in service["servers"] if x != self.addr[imm]]     # retain
             elif name == "HOOK_REQ":                # NetSim::hook_rpc_req::<R>(node, f): HashMap::insert
                 self.hooks_req[a] = (lambda tag, code, want_tag=b >> 8, all_=b & 1, want=imm & 0xFF:
                                      not (tag == want_tag and (all_ or code == want)))
@@ -848,7 +865,7 @@ def workloads():
                          ("random_addr_workload", 880000, 24), ("random_ephemeral_workload", 870000, 16),
                          ("random_channel_workload", 860000, 24), ("random_guard_workload", 850000, 16),
                          ("random_supervisor_workload", 840000, 16), ("random_mixed_workload", 845000, 16),
-                         ("random_ipvs_workload", 895000, 16)):
+                         ("random_ipvs_workload", 895000, 16), ("random_ipvs_runtime_workload", 897000, 16)):
         for k in range(n):
             r = getattr(fuzz, gen)(random.Random(base + k))
             out["%s_%02d" % (gen.replace("random_", "fuzz_").replace("_workload", ""), k)] = (r[0], r[1])

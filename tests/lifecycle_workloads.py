@@ -747,7 +747,7 @@ def config(name):
 
 def limits(name):
     """Device capacities a workload needs beyond the defaults (None = defaults)."""
-    if name in ("rpc_server_restart", "rpc_hooks"):   # timed-out calls leave dead registrations behind (rpc.rs:125)
+    if name in ("rpc_server_restart", "rpc_hooks", "ipvs_service_lifecycle"):   # timed-out calls / receives leave dead registrations behind (rpc.rs:125)
         lim = A.Limits(); lim.mbox_regs, lim.mbox_msgs = 8, 4
         return lim
     if name == "ipvs_round_robin_datagrams":             # four replies may queue up before the sender starts receiving
@@ -819,6 +819,114 @@ def ipvs_rpc_call_asserts_given_address():
     return wl.build()
 
 
+def _ipvs_receivers(wl, nodes, counts, reply=False):
+    """One listener per node on 10.0.0.<node>:1 that receives `counts[i]` datagrams of tag 1 and folds each payload into the
+    observation hash (so WHO received WHAT is part of the result)."""
+    addrs, tasks = [], []
+    for n, cnt in zip(nodes, counts):
+        a = wl.addr(n, 1)
+        t = wl.task(n); t.bind(a)
+        if cnt:
+            t.set(0, cnt); top = t.label(); t.recv_from(a, 1); t.trace_val()
+            if reply:
+                t.reply(a, 2, 0x500 + n)
+            t.djnz(0, top)
+        addrs.append(a); tasks.append(t)
+    return addrs, tasks
+
+
+def ipvs_round_robin_unit_test():
+    """net/ipvs.rs:113-131 `round_robin`, call for call, with get_server observed through NetSim::send (net/mod.rs:312-317):
+    add_service; get_server -> None (the datagram keeps its virtual destination and is dropped before any draw); three
+    add_server; three get_server -> servers 1, 2, 3; del_server(server 1); get_server -> server 2 (rr_index 3 >= len 2 wraps to
+    0, ipvs.rs:96-98).  Receiver 1 asserts it got datagram 1 only, receiver 2 datagrams 2 and 4, receiver 3 datagram 3."""
+    wl = W.WorkloadBuilder()
+    n1, n2, n3, n4 = (wl.create_node() for _ in range(4))
+    vip = wl.virtual_addr(1, 80)
+    svc = wl.ipvs_service(vip, absent=True)
+    s1, s2, s3 = wl.addr(n1, 1), wl.addr(n2, 1), wl.addr(n3, 1)
+    r1 = wl.task(n1); r1.bind(s1); r1.recv_from(s1, 1); r1.assert_val(1); r1.recv_from_timeout(s1, 1, ms=200); r1.assert_val(A.VAL_TIMEOUT)
+    r2 = wl.task(n2); r2.bind(s2); r2.recv_from(s2, 1); r2.assert_val(2); r2.recv_from(s2, 1); r2.assert_val(4)
+    r3 = wl.task(n3); r3.bind(s3); r3.recv_from(s3, 1); r3.assert_val(3); r3.recv_from_timeout(s3, 1, ms=200); r3.assert_val(A.VAL_TIMEOUT)
+    me = wl.addr(n4, 1)
+    op = wl.task(n4); op.bind(me); op.sleep(ms=10)
+    op.ipvs_add_service(svc)
+    op.send_to(me, vip, 1, 99); op.sleep(ms=20)                   # get_server -> None
+    op.ipvs_add_server(svc, s1); op.ipvs_add_server(svc, s2); op.ipvs_add_server(svc, s3)
+    for k in (1, 2, 3):
+        op.send_to(me, vip, 1, k); op.sleep(ms=20)
+    op.ipvs_del_server(svc, s1)
+    op.send_to(me, vip, 1, 4); op.sleep(ms=20)
+    m = wl.main()
+    for t in (r1, r2, r3, op):
+        m.spawn(t)
+    for t in (r1, r2, r3, op):
+        m.join(t)
+    return wl.build()
+
+
+def ipvs_add_server_without_service():
+    """ipvs.rs:67-75 `.expect("service not found")`: add_server on a service nobody added panics the calling task."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    vip = wl.virtual_addr(1, 80)
+    svc = wl.ipvs_service(vip, absent=True)
+    s1 = wl.addr(n1, 1)
+    op = wl.task(n2); op.sleep(ms=1); op.ipvs_add_server(svc, s1)
+    m = wl.main(); m.spawn(op); m.join(op)
+    return wl.build()
+
+
+def ipvs_del_server_without_service():
+    """ipvs.rs:78-85: del_server after del_service panics too (the service left the HashMap with its servers)."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    vip = wl.virtual_addr(1, 80)
+    s1 = wl.addr(n1, 1)
+    svc = wl.ipvs_service(vip, [s1])
+    op = wl.task(n2); op.sleep(ms=1); op.ipvs_del_service(svc); op.ipvs_del_server(svc, s1)
+    m = wl.main(); m.spawn(op); m.join(op)
+    return wl.build()
+
+
+def ipvs_service_lifecycle():
+    """del_service stops the rewrite (the datagram is dropped: nobody owns the virtual address); add_service on an EXISTING
+    service is HashMap::insert of a fresh one — servers gone, rr_index 0; del_server removes every equal address (retain);
+    an rr_index left beyond the shorter list wraps to its head.  Three receivers reply with their own code, the operator
+    traces each reply (or the timeout)."""
+    wl = W.WorkloadBuilder()
+    n1, n2, n3, n4 = (wl.create_node() for _ in range(4))
+    vip = wl.virtual_addr(1, 80)
+    (a, b, c), rx = _ipvs_receivers(wl, (n1, n2, n3), (0, 0, 0))
+    for t, addr, code in zip(rx, (a, b, c), (0xA, 0xB, 0xC)):      # serve until the operator is done
+        top = t.label(); t.recv_from_timeout(addr, 1, ms=400)
+        done = t.label() + 3
+        t.jeq(A.VAL_TIMEOUT, done); t.reply(addr, 2, code); t.jmp(top)
+        assert t.label() == done
+    svc = wl.ipvs_service(vip, [a, b, c])
+    me = wl.addr(n4, 1)
+    op = wl.task(n4); op.bind(me); op.sleep(ms=5)
+
+    def probe():
+        op.send_to(me, vip, 1, 7); op.recv_from_timeout(me, 2, ms=30); op.trace_val()
+    probe(); probe(); probe()                                     # a b c: rr_index = 3
+    op.ipvs_del_server(svc, c); probe()                            # [a, b], 3 >= 2 -> a
+    op.ipvs_add_server(svc, a); op.ipvs_add_server(svc, c)         # [a, b, a, c], rr_index 1
+    probe(); probe(); probe()                                     # b a c
+    op.ipvs_del_server(svc, a); probe()                            # retain: [b, c]; rr_index 4 -> b
+    op.ipvs_del_service(svc); probe()                              # no service: timeout
+    op.ipvs_add_service(svc); probe()                              # a fresh service without servers: timeout
+    op.ipvs_add_server(svc, c); probe(); probe()                   # c c
+    op.ipvs_add_service(svc); probe()                              # insert again: servers gone
+    m = wl.main()
+    for t in rx + [op]:
+        m.spawn(t)
+    m.join(op)
+    return wl.build()
+
+
 ALL.update(ipvs_load_balance=ipvs_load_balance, ipvs_round_robin_datagrams=ipvs_round_robin_datagrams,
-           ipvs_rpc_call_asserts_given_address=ipvs_rpc_call_asserts_given_address)
-EXPECT_PANIC.add("ipvs_rpc_call_asserts_given_address")
+           ipvs_rpc_call_asserts_given_address=ipvs_rpc_call_asserts_given_address,
+           ipvs_round_robin_unit_test=ipvs_round_robin_unit_test, ipvs_add_server_without_service=ipvs_add_server_without_service,
+           ipvs_del_server_without_service=ipvs_del_server_without_service, ipvs_service_lifecycle=ipvs_service_lifecycle)
+EXPECT_PANIC.update(("ipvs_rpc_call_asserts_given_address", "ipvs_add_server_without_service", "ipvs_del_server_without_service"))

@@ -64,6 +64,34 @@ def test_ipvs_service_table():
     assert built.socks[v].kind == A.ADDR_VIRTUAL
 
 
+def test_ipvs_runtime_calls():
+    """MS_OP_IPVS as the builder emits it, a service that is only declared, and what validation refuses (library and oracle alike)."""
+    import oracle
+    from madsim_amd import runtime
+    wl = W.WorkloadBuilder()
+    n1 = wl.create_node()
+    v, a = wl.virtual_addr(1, 80), wl.addr(n1, 1)
+    s = wl.ipvs_service(v, absent=True)
+    t = wl.main(); t.ipvs_add_service(s); t.ipvs_add_server(s, a); t.ipvs_del_server(s, a); t.ipvs_del_service(s)
+    built = wl.build()
+    assert built.services[0].n_servers == A.SERVICE_ABSENT
+    ins = [(i.op, i.a, i.b, i.imm) for i in built.insns[:4]]
+    assert ins == [(A.OP["IPVS"], A.IPVS_ADD_SERVICE, s, 0), (A.OP["IPVS"], A.IPVS_ADD_SERVER, s, a),
+                   (A.OP["IPVS"], A.IPVS_DEL_SERVER, s, a), (A.OP["IPVS"], A.IPVS_DEL_SERVICE, s, 0)]
+    runtime.geometry(built)
+    with pytest.raises(ValueError, match="declared absent"):
+        wl.ipvs_service(wl.virtual_addr(2, 80), [a], absent=True)
+    for bad_call in (lambda t: t.ipvs_add_service(3), lambda t: t.ipvs_add_server(0, 99), lambda t: t._emit("IPVS", a=7, b=0)):
+        wl = W.WorkloadBuilder(); n1 = wl.create_node()
+        wl.ipvs_service(wl.virtual_addr(1, 80), [wl.addr(n1, 1)])
+        bad_call(wl.main())
+        w = wl.build()
+        with pytest.raises(runtime.MadsimHipError, match="ipvs"):
+            runtime.geometry(w)
+        with pytest.raises(RuntimeError):
+            oracle.run_batch(w, 0, 1)
+
+
 def test_cpp_mirror_builds_the_ipvs_example_for_the_oracle(tmp_path):
     """examples/ipvs_workload.hpp (the C++ DSL: IPVS service, virtual address, substring panic patterns) run through the oracle's
     C twin of the batch entry point — no GPU involved: the table is valid, every seed passes, one literal message interned."""

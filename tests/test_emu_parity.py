@@ -164,6 +164,36 @@ def test_fuzz_ipvs_workloads():
         assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
 
 
+def test_fuzz_ipvs_runtime_workloads():
+    """Services changed while the clients run: add_service / del_service / add_server / del_server (net/ipvs.rs:50-85) from
+    operator tasks, services that are only declared, calls on a service that is gone (panic) — both state layouts."""
+    for k in range(200):
+        w, cfg, desc = fuzz.random_ipvs_runtime_workload(random.Random(9975000 + k))
+        lim = fuzz.generous_limits(); lim.max_tasks = 24
+        if k % 2:
+            lim = _global(lim)
+        o, _ = oracle.run_batch(w, k * 3, 12, cfg, lim)
+        e = emu.run_batch(w, k * 3, 12, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+
+
+def test_ipvs_seventh_server_is_a_capacity_verdict():
+    """Six servers per service fit the seed's two state words; a seventh add_server yields MADSIM_OVERFLOW, never a shorter list."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    v = wl.virtual_addr(1, 80); a = wl.addr(n, 1)
+    svc = wl.ipvs_service(v, [a] * 6)
+    t = wl.task(n); t.sleep(ms=1); t.ipvs_add_server(svc, a)
+    m = wl.main(); m.spawn(t); m.join(t)
+    w = wl.build()
+    for lim in (None, _global(A.Limits())):
+        e = emu.run_batch(w, 0, 4, None, lim)
+        assert (e["verdict"] == A.OVERFLOW).all()
+    o, _ = oracle.run_batch(w, 0, 4)                  # (the oracle's Vec has no such bound)
+    assert (o["verdict"] == A.PASS).all()
+
+
 def test_baseline_config_shaped_workloads():
     """configs[2]-shaped election loop (timeouts, partitions, HBM heap spill) and configs[3]-shaped KV-RPC."""
     o = _same(W.raft_election(), 0, 300, None, W.raft_election_limits())

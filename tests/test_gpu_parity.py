@@ -640,6 +640,13 @@ def test_fuzz_ipvs_gpu(hip):
     _fuzz_two_blocks(hip, fuzz.random_ipvs_workload, 79000, 150, 75, 13, count=96, seed_mul=41, limits=_lim_tasks(24), alt_global=True)
 
 
+def test_fuzz_ipvs_runtime_gpu(hip):
+    """Random programs whose operator tasks change IPVS services at run time (MS_OP_IPVS: add_service / del_service /
+    add_server / del_server, net/ipvs.rs:50-85), both state layouts."""
+    from tests import fuzz
+    _fuzz_two_blocks(hip, fuzz.random_ipvs_runtime_workload, 79500, 150, 75, 14, count=96, seed_mul=43, limits=_lim_tasks(24), alt_global=True)
+
+
 def test_fuzz_channel_guards_gpu(hip):
     """Random reliable-channel programs about who keeps an address bound (Arc<BindGuard> clones in Sender / Receiver)."""
     from tests import fuzz

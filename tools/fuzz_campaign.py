@@ -16,7 +16,7 @@ gens = [("plain", fuzz.random_workload, None), ("lifecycle", fuzz.random_lifecyc
         ("rpc+hooks", lambda r: fuzz.random_rpc_workload(r, hooks=True), 24), ("addresses", fuzz.random_addr_workload, None),
         ("ephemeral", fuzz.random_ephemeral_workload, None), ("channel", fuzz.random_channel_workload, 24),
         ("guards", fuzz.random_guard_workload, 24), ("supervisor", fuzz.random_supervisor_workload, 48),
-        ("mixed", fuzz.random_mixed_workload, 60), ("ipvs", fuzz.random_ipvs_workload, 24)]
+        ("mixed", fuzz.random_mixed_workload, 60), ("ipvs", fuzz.random_ipvs_workload, 24), ("ipvs_rt", fuzz.random_ipvs_runtime_workload, 24)]
 if len(sys.argv) > 3:                              # optional: only the generators whose name contains one of these (comma-separated)
     gens = [g for g in gens if any(x in g[0] for x in sys.argv[3].split(","))]
 t0 = time.time(); k = 0; stats = {g[0]: [0, 0, 0] for g in gens}; verdicts = np.zeros(6, dtype=np.int64)
