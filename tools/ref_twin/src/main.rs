@@ -614,6 +614,54 @@ async fn rebind_in_flight(obs: Obs) -> Tail {
     fingerprint_tail(t0, &obs)
 }
 
+/// IpVirtualServer changed while datagrams flow (net/ipvs.rs:50-105: add_service / add_server / del_server / del_service from a
+/// task; the wrap of an index left beyond a shortened list; retain; insert over an existing service).
+/// Table: twin_workloads.py::ipvs_runtime.  0xFFFF_FFFF = Err(Elapsed).
+async fn ipvs_runtime(obs: Obs) -> Tail {
+    use madsim::net::ipvs::{Scheduler, ServiceAddr};
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let nodes: Vec<_> = (1..=4u8).map(|i| h.create_node().ip(addr(i, 1).ip()).build()).collect();
+    for (i, code) in [(1u8, 0xAu32), (2, 0xB), (3, 0xC)] {
+        nodes[i as usize - 1].spawn(async move {
+            let ep = Endpoint::bind(addr(i, 1)).await.unwrap();
+            let mut buf = [0u8; 16];
+            while let Ok(r) = time::timeout(Duration::from_millis(400), ep.recv_from(1, &mut buf)).await {
+                let (_, from) = r.unwrap();
+                ep.send_to(from, 2, &code.to_le_bytes()).await.unwrap();
+            }
+        });
+    }
+    let o = obs.clone();
+    let op = nodes[3].spawn(async move {
+        let ep = Endpoint::bind(addr(4, 1)).await.unwrap();
+        time::sleep(Duration::from_millis(5)).await;
+        let ipvs = NetSim::current().global_ipvs();
+        let svc = || ServiceAddr::Tcp("1.1.1.1:80".into());
+        let vip: SocketAddr = "1.1.1.1:80".parse().unwrap();
+        let (a, b, c) = ("10.0.0.1:1", "10.0.0.2:1", "10.0.0.3:1");
+        let _ = b;
+        macro_rules! probe { ($n:expr) => { for _ in 0..$n {
+            ep.send_to(vip, 1, &7u32.to_le_bytes()).await.unwrap();
+            let mut buf = [0u8; 16];
+            match time::timeout(Duration::from_millis(30), ep.recv_from(2, &mut buf)).await {
+                Ok(r) => { let (len, _) = r.unwrap(); let mut w = [0u8; 4]; w[..len].copy_from_slice(&buf[..len]); o.push(u32::from_le_bytes(w) as u64) }
+                Err(_) => o.push(0xFFFF_FFFF),
+            }
+        } } }
+        ipvs.add_service(svc(), Scheduler::RoundRobin); probe!(1);
+        ipvs.add_server(svc(), a); ipvs.add_server(svc(), "10.0.0.2:1"); ipvs.add_server(svc(), c); probe!(3);
+        ipvs.del_server(svc(), c); probe!(1);
+        ipvs.add_server(svc(), a); ipvs.add_server(svc(), c); probe!(3);
+        ipvs.del_server(svc(), a); probe!(1);
+        ipvs.del_service(svc()); probe!(1);
+        ipvs.add_service(svc(), Scheduler::RoundRobin); probe!(1);
+        ipvs.add_server(svc(), c); probe!(2);
+    });
+    op.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
 /// IpVirtualServer (net/ipvs.rs) consulted by NetSim::send and connect1 (net/mod.rs:312-317,345-350).
 /// Table: twin_workloads.py::ipvs_round_robin.  0xFFFF_FFFF = Err(Elapsed).
 async fn ipvs_round_robin(obs: Obs) -> Tail {
@@ -710,6 +758,7 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
                 "panic_substrings" => panic_substrings(o).await,
                 "rebind_in_flight" => rebind_in_flight(o).await,
                 "ipvs_round_robin" => ipvs_round_robin(o).await,
+                "ipvs_runtime" => ipvs_runtime(o).await,
                 "pingpong4_dsl" => pingpong4_dsl(o).await,
                 other => panic!("unknown workload {other}"),
             }
@@ -736,7 +785,7 @@ const ALL: &[&str] = &["pingpong2", "pingpong4", "pingpong16", "sleep_1s", "yiel
                        "restart_on_panic", "receiver_drop", "localhost", "restart_on_panic_matching", "bind_ephemeral",
                        "channel_wildcard", "guard_keeps_address", "spawn_in_drop_abort", "spawn_in_drop_kill",
                        "spawn_after_own_restart", "join_names_its_task", "abort_own_handle", "rpc_hooks", "panic_substrings",
-                       "rebind_in_flight", "ipvs_round_robin", "pingpong4_dsl"];
+                       "rebind_in_flight", "ipvs_round_robin", "ipvs_runtime", "pingpong4_dsl"];
 
 fn main() {
     let args: Vec<String> = std::env::args().collect();

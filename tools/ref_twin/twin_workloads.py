@@ -410,8 +410,53 @@ def ipvs_round_robin():
     return wl.build()
 
 
+def ipvs_runtime():
+    """IpVirtualServer changed while datagrams flow (net/ipvs.rs:50-105): add_service on a fresh address, add_server x3, three
+    sends go a, b, c; del_server(c) and the index left at 3 wraps to a; duplicates ([a, b, a, c]) and retain (del_server(a)
+    removes both); del_service stops the rewrite (timeout); add_service on an existing service starts it over.  Every probe =
+    send_to(1.1.1.1:80) + timeout(30 ms, recv_from(reply)): the operator observes which server answered (0xA / 0xB / 0xC) or
+    0xFFFF_FFFF."""
+    wl = W.WorkloadBuilder()
+    n1, n2, n3, n4 = (wl.create_node() for _ in range(4))
+    vip = wl.virtual_addr(1, 80)
+    svc = wl.ipvs_service(vip, absent=True)
+    rx, addrs = [], []
+    for n, code in ((n1, 0xA), (n2, 0xB), (n3, 0xC)):
+        a = wl.addr(n, 1)
+        t = wl.task(n); t.bind(a)
+        top = t.label(); t.recv_from_timeout(a, 1, ms=400)
+        done = t.label() + 3
+        t.jeq(A.VAL_TIMEOUT, done); t.reply(a, 2, code); t.jmp(top)
+        assert t.label() == done
+        rx.append(t); addrs.append(a)
+    a, b, c = addrs
+    me = wl.addr(n4, 1)
+    op = wl.task(n4); op.bind(me); op.sleep(ms=5)
+
+    def probe(times=1):
+        for _ in range(times):
+            op.send_to(me, vip, 1, 7); op.recv_from_timeout(me, 2, ms=30); op.trace_val()
+    op.ipvs_add_service(svc); probe()                              # no servers yet: None
+    op.ipvs_add_server(svc, a); op.ipvs_add_server(svc, b); op.ipvs_add_server(svc, c); probe(3)      # a b c
+    op.ipvs_del_server(svc, c); probe()                            # [a, b], rr_index 3 -> a
+    op.ipvs_add_server(svc, a); op.ipvs_add_server(svc, c); probe(3)                                  # [a, b, a, c] from index 1: b a c
+    op.ipvs_del_server(svc, a); probe()                            # [b, c], rr_index 4 -> b
+    op.ipvs_del_service(svc); probe()                              # None
+    op.ipvs_add_service(svc); probe()                              # fresh, empty
+    op.ipvs_add_server(svc, c); probe(2)                           # c c
+    m = wl.main()
+    for t in rx:
+        m.spawn(t)
+    m.spawn(op); m.join(op)
+    fingerprint_tail(m)
+    return wl.build()
+
+
 def limits(name):
     """Device capacities a table needs beyond the defaults (None = defaults); the oracle has none."""
+    if name == "ipvs_runtime":                            # timed-out receives leave dead registrations behind until the next delivery
+        lim = A.Limits(); lim.mbox_regs, lim.mbox_msgs = 8, 4
+        return lim
     if name == "join_names_its_task":                     # two instances of one program alive at once
         lim = A.Limits(); lim.max_tasks = 6
         return lim
@@ -432,6 +477,6 @@ ALL = {
     "join_names_its_task": join_names_its_task, "abort_own_handle": abort_own_handle,
     # round 3: the semantics added since the first kit, and the table built by the Rust DSL (bindings/rust/madsim-hip)
     "rpc_hooks": rpc_hooks, "panic_substrings": panic_substrings, "rebind_in_flight": rebind_in_flight,
-    "ipvs_round_robin": ipvs_round_robin,
+    "ipvs_round_robin": ipvs_round_robin, "ipvs_runtime": ipvs_runtime,
     "pingpong4_dsl": lambda: pingpong(4, 64),          # the same table, built by madsim_hip::pingpong_twin and run by madsim_hip::interp
 }
