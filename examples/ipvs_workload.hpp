@@ -11,7 +11,7 @@ inline madsim::Workload ipvs_example_workload() {
     const int l1 = wl.addr(n1, 1, MADSIM_ADDR_UNSPECIFIED), l2 = wl.addr(n2, 1, MADSIM_ADDR_UNSPECIFIED);
     const int s1 = wl.addr(n1, 1), s2 = wl.addr(n2, 1);                 // the real servers, as add_server names them
     const int vip = wl.virtual_addr(1, 80);                             // "1.1.1.1:80"
-    wl.ipvs_service(vip, {s1, s2});
+    const int svc = wl.ipvs_service(vip, {s1});                         // add_service + add_server(s1) before the run; s2 joins at run time
     const int c = wl.addr(n3, 0, MADSIM_ADDR_UNSPECIFIED);              // TcpStream::connect binds an ephemeral Endpoint
     const uint32_t one = wl.payload("1"), two = wl.payload("2");
     madsim::Task& f1 = wl.task(n1); f1.bind(l1).accept1(l1).chan_recv().assert_val(one);
@@ -20,7 +20,8 @@ inline madsim::Workload ipvs_example_workload() {
     madsim::Task& f3 = wl.task(n3);
     f3.sleep(50ms).bind(c);
     f3.connect1(c, vip).assert_val(0).spawn_move_conn(hold);                          // go to node1
-    f3.connect1(c, vip).assert_val(0).chan_send(two).sleep(200ms);                    // go to node2
+    f3.ipvs_add_server(svc, s2);                                                      // NetSim::global_ipvs().add_server(.., "10.0.0.2:1")
+    f3.connect1(c, vip).assert_val(0).chan_send(two).sleep(200ms);                    // go to node2 (rr_index 1 of [s1, s2])
     // a supervised node: restarts on "disk full" (pattern "disk"), three times within ten seconds at most
     const int nd = wl.create_node_matching({"disk", "net"});
     madsim::Task& flaky = wl.task(nd, /*init=*/true, /*before_block_on=*/true);
