@@ -198,7 +198,10 @@ def main():
     w, lim, wname = workload.bench_case(args.workload, args.nodes, workload.BENCH_ROUNDS, args.heap_lds)
     headline = args.workload == "pingpong" and args.nodes == workload.BENCH_NODES
     lim.lanes_per_wave = args.lpw
-    lim.state_mem = args.state_mem
+    lim.state_mem = args.state_mem or lim.state_mem
+    if "MADSIM_BENCH_STATE_FLAGS" in os.environ:         # experiments: OR into / clear from state_mem (e.g. 0x100 = MADSIM_STATE_DEDUP_TIMERS; "-0x100" clears it)
+        v = os.environ["MADSIM_BENCH_STATE_FLAGS"]
+        lim.state_mem = (lim.state_mem & ~int(v[1:], 0)) if v.startswith("-") else (lim.state_mem | int(v, 0))
     if "MADSIM_BENCH_HEAP_LDS" in os.environ:            # experiments: move timer-heap entries between LDS and the HBM spill region
         n = int(os.environ["MADSIM_BENCH_HEAP_LDS"])
         lim.heap_spill_slots, lim.heap_lds_slots = lim.heap_spill_slots + max(0, lim.heap_lds_slots - n), n

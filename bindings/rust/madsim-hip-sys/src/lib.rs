@@ -249,6 +249,7 @@ pub const MADSIM_STATE_AUTO: u32 = 0;
 pub const MADSIM_STATE_LDS: u32 = 1;
 pub const MADSIM_STATE_GLOBAL: u32 = 2;
 pub const MADSIM_STATE_COMPACT: u32 = 3;
+pub const MADSIM_STATE_DEDUP_TIMERS: u32 = 0x100;
 pub const MADSIM_SCHED_STATIC: u32 = 0;
 pub const MADSIM_SCHED_QUEUE: u32 = 1;
 pub const MADSIM_E_ARG: c_int = -1;

@@ -326,6 +326,16 @@ typedef struct madsim_limits {
                                     deadline word: exact inside that horizon), heap root in registers, the main task in global memory —
                                     a fourth wave per SIMD for the 4-node ping-pong.  AUTO takes it when it gains a workgroup per CU  */
 
+/* OR-ed into madsim_limits_t.state_mem (the low byte keeps MADSIM_STATE_*): global-state builds of timeout-only workloads keep the
+   re-registrations of a pending Sleep — time/sleep.rs:51-53 registers ANOTHER timer with the same deadline and waker on every
+   not-elapsed poll — as a COUNT beside the first entry instead of as further heap entries (k_timer.h dedup_note).  Identical
+   entries fire back to back and every one after the first is a no-op wake-up, so the result is the same bit for bit unless two
+   DIFFERENT events tie on a deadline (their order depends on the heap's shape): the kernel notices such a tie when it pops it and
+   runs that seed again from the start with the literal heap, so callers never see a difference — only time.  Ignored by the other
+   builds.  Worth it where timeouts dominate and ties are rare (the election loop: 34 % of its timer pushes are such duplicates,
+   5e-4 of its seeds meet a tie). */
+#define MADSIM_STATE_DEDUP_TIMERS 0x100u
+
 #define MADSIM_SCHED_STATIC 0u   /* lane g runs seeds g, g+G, g+2G, ...                                */
 #define MADSIM_SCHED_QUEUE  1u   /* a finished lane pulls the next seed from a per-launch atomic counter */
 

@@ -289,8 +289,12 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     uint32_t sh_bytes = 0;
     // Where the task table and the planes live (madsim_limits_t.state_mem): LDS, or — extended-op workloads whose state
     // would leave a CU with fewer than four full waves — global memory, [unit][lane] across the launch (Variant::G, k_state.h).
-    if (L.state_mem > MADSIM_STATE_COMPACT) return fail(err, MADSIM_E_LIMITS, "state_mem must be 0 (auto), 1 (LDS), 2 (global) or 3 (compact)");
+    // (its low byte; MADSIM_STATE_DEDUP_TIMERS rides above it)
+    const uint32_t state_mem = L.state_mem & 0xffu;
+    if (state_mem > MADSIM_STATE_COMPACT || (L.state_mem & ~(0xffu | MADSIM_STATE_DEDUP_TIMERS)))
+        return fail(err, MADSIM_E_LIMITS, "state_mem must be 0 (auto), 1 (LDS), 2 (global) or 3 (compact), optionally | MADSIM_STATE_DEDUP_TIMERS");
     P.gstate_mode = 0;
+    P.dedup_n = 0; P.dedup_off = 0;
     // base-op builds: no owner word per socket (the owner's slot rides in the header, k_state.h) and 8-byte unit1
     P.sock_words = (P.lifecycle ? 2 : 1) + P.mbox_regs + 2 * P.mbox_msgs + (P.uses_chan ? 3 : 0);   // + accept queue (2 words), parked acceptor
     if (!P.lifecycle && P.mbox_msgs > 127) return fail(err, MADSIM_E_LIMITS, "mbox_msgs must be <= 127 for workloads without extended ops");
@@ -320,7 +324,11 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         P.lane_words = P.off_ipvs + P.n_services * (P.ipvs_dyn ? 2 : 1);
         if (P.gstate_mode) {           // the planes just laid out go to the global block; LDS keeps the ready queue only
             P.gs_plane_words = P.lane_words;
-            P.gs_planes = P.max_tasks * P.task_units * 16;
+            // MADSIM_STATE_DEDUP_TIMERS: 64 buckets of 16 bytes behind the task units — the one build that carries the code is
+            // the global-state build of timeout-only workloads (k_state.h Variant::DEDUP, k_timer.h dedup_note)
+            P.dedup_off = P.max_tasks * P.task_units * 16;
+            P.dedup_n = ((L.state_mem & MADSIM_STATE_DEDUP_TIMERS) && P.features == MADSIM_FEAT_TIME && !trace) ? 64u : 0u;
+            P.gs_planes = P.dedup_off + P.dedup_n * 16;
             P.gs_stride = (P.gs_planes + P.gs_plane_words * 4 + 63) & ~63u;
             P.off_amask = (P.max_tasks + 3) / 4;               // LDS planes: ready queue (a byte per entry), alive-task mask, owned-socket mask
             P.off_omask = P.off_amask + (P.max_tasks + 31) / 32;
@@ -333,7 +341,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         P.sh_heap = (P.sh_nodes + P.n_nodetab + 3) & ~3u;
         sh_bytes = P.sh_heap * 4;
         G->lds_per_seed = P.heap_lds * heap_bytes + (P.gstate_mode ? 0 : P.max_tasks * task_bytes) + P.lane_words * 4;
-        if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu && (L.state_mem == MADSIM_STATE_LDS || !P.lifecycle || trace || P.gstate_mode)) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
+        if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu && (state_mem == MADSIM_STATE_LDS || !P.lifecycle || trace || P.gstate_mode)) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
         // Lanes per wave (lw): how many of a wave's 64 lanes carry a seed.  Measured on MI355X (4-node
         // ping-pong, 65 536 seeds, profiles/r1_lanes_per_wave.md): every wave-instruction costs the SIMD
         // ~4 cycles whatever the number of active lanes, and at 16 lanes/wave the VALU pipe is already
@@ -353,8 +361,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         if (P.gstate_mode) { if (!L.lanes_per_wave) lw = 64; break; }
         // extended-op workloads only: a base-op ping-pong iteration is ~11k cycles and 26 G iterations/s would need
         // > 15 TB/s of 64-byte sector traffic (measured: 3.2 ms per batch against 1.99 ms LDS-resident, profiles/r2_experiments.md)
-        const bool can_g = P.lifecycle && !trace && L.state_mem != MADSIM_STATE_LDS;
-        if (can_g && (L.state_mem == MADSIM_STATE_GLOBAL || (lw != 64 && !L.lanes_per_wave))) {
+        const bool can_g = P.lifecycle && !trace && state_mem != MADSIM_STATE_LDS;
+        if (can_g && (state_mem == MADSIM_STATE_GLOBAL || (lw != 64 && !L.lanes_per_wave))) {
             P.gstate_mode = 1;
             // LDS now holds little more than the top of the timer heap.  Keep as much of the requested LDS quota as still
             // lets the build's register budget decide the occupancy — as many 4-wave workgroups per CU as the build fits waves
@@ -393,12 +401,12 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         }
         const bool can = !P.lifecycle && !trace && !P.gstate_mode && lw == 64 && P.rq_in_reg && P.heap_spill == 0 && P.heap_lds >= 2 &&
                          P.max_tasks >= 2 && horizon < (1ull << 31) - (1ull << 24) && !L.lanes_per_wave;
-        if (L.state_mem == MADSIM_STATE_COMPACT && !can)
+        if (state_mem == MADSIM_STATE_COMPACT && !can)
             return fail(err, MADSIM_E_LIMITS, "state_mem = 3 (compact): base-op workloads on full waves with <= 8 tasks, no heap spill, no buggify and sleeps below 2.1 s only");
-        if (can && L.state_mem != MADSIM_STATE_LDS) {
+        if (can && state_mem != MADSIM_STATE_LDS) {
             const size_t per_seed_c = (size_t)(P.heap_lds - 1) * 8 + (size_t)(P.max_tasks - 1) * task_bytes + (size_t)P.lane_words * 4;
             auto groups = [&](size_t per_seed) { size_t b = ((size_t)sh_bytes + 256 * per_seed + 1279) / 1280 * 1280; return g.lds_per_cu / b; };
-            if (L.state_mem == MADSIM_STATE_COMPACT || (groups(per_seed_c) > groups(G->lds_per_seed) && groups(per_seed_c) <= 4)) {
+            if (state_mem == MADSIM_STATE_COMPACT || (groups(per_seed_c) > groups(G->lds_per_seed) && groups(per_seed_c) <= 4)) {
                 P.compact = 1; heap_n = P.heap_lds - 1; heap_b = 8; task_n = P.max_tasks - 1;
                 G->lds_per_seed = (uint32_t)per_seed_c;
                 P.gs_stride = 24;                      // the main task's record: unit0 (16 bytes) + unit1 {x, y}

@@ -15,6 +15,7 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
         OMASK(0) = 0; OMASK(1) = 0;
     }
     else for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;     // plane 0 is the ready queue: RW spans all planes
+    if (K::DEDUP) { for (uint32_t b = 0; b < P.dedup_n; b++) gs_store32(c.gs, gs_addr_uword(c, P.dedup_off + b * 16u + 12u), 0); L.hazard = 0; }   // empty buckets
     for (uint32_t t = 0; t < P.max_tasks; t++) { TWORD(c, t, 0, 0) = 0; if (!K::LIFE) TWORD(c, t, 1, 1) = 0; }
     if (K::FA && P.ipvs_dyn)                               // the services as the table declares them: the ipvs calls made before the first task runs
         for (uint32_t k = 0; k < P.n_services; k++) {
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEA
     for (int i = 0; i < 12; i++) L.prof_acc[i] = 0;
     L.prof_t = __builtin_readcyclecounter(); uint64_t prof_iters = 0;
 #endif
+    L.exact = 0; L.hazard = 0;
     uint64_t next = glane;          // first unit of lane g; then g+G, g+2G, ... or the work queue (below)
     bool have = false;
     for (;;) {
@@ -222,6 +224,9 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEA
             idle_jump = true;
         }
         PROBE(4);
+        // MADSIM_STATE_DEDUP_TIMERS: two different events tied on a deadline — this seed once more from the start, every timer a
+        // heap entry (k_timer.h dedup_note); nothing of the abandoned attempt is reported
+        if (K::DEDUP && L.hazard) { L.exact = 1; have = false; continue; }
         if (L.ovf) L.verdict = MADSIM_OVERFLOW;
         if (L.verdict != MADSIM_RUNNING) {
             REG(25);
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEA
             P.out[next] = r;
             if (K::TRACE) *P.trace_len = L.log_len;
             have = false;
+            if (K::DEDUP) L.exact = 0;
             // next unit: static striding, or the per-launch work queue (a lane whose seeds end early — deadlocks under
             // packet loss — then keeps pulling work instead of idling behind the slowest lane of its stride)
             if (P.work_ctr) next = P.total_lanes + atomicAdd(P.work_ctr, 1ull);

@@ -179,9 +179,24 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
             if (rk == EV_WAKE) pf_flags = TWORD(c, rz & 0xff, 0, 0);
             else if (rk == EV_DELIVER) { pf.hdr = SW(c, rz & 0x3f, 0); pf.reg0 = SW(c, rz & 0x3f, 2); }
         }
+        // DEDUP builds: the bucket that may hold repeats of the root wake-up (k_timer.h dedup_note) — like the loads above it
+        // depends on the root entry alone
+        const bool dd = K::DEDUP && c.P.dedup_n && !L.exact;
+        uint32_t dd_at = 0;
+        uint4 dd_u = make_uint4(0, 0, 0, 0);
+        if (K::DEDUP && dd) {
+            const uint32_t rz = heap_lds_get<K>(c, 0).z;
+            if ((rz >> EV_SHIFT) == EV_WAKE) { dd_at = dedup_bucket(c, L.top_dl, rz); dd_u = gs_load128(c.gs, gs_addr_unit(c, dd_at)); }
+        }
         uint4 e = timer_pop<K>(c, L);
         L.steps++;
         uint32_t kind = e.z >> EV_SHIFT;
+        if (K::DEDUP && dd) {
+            // the repeats of this wake-up fire with it: a step each, their task is SCHEDULED by the first already
+            if (dd_u.w != 0 && dd_u.x == e.x && dd_u.y == e.y && dd_u.z == e.z) { L.steps += dd_u.w; gs_store32(c.gs, gs_addr_uword(c, dd_at + 12u), 0); }
+            // two DIFFERENT events with one deadline: which fires first is a matter of the heap's shape (restart the seed exactly)
+            if (L.heap_len > 0 && L.top_dl == ev_deadline(e)) { const uint4 r = heap_lds_get<K>(c, 0); if (r.z != e.z || r.w != e.w) L.hazard = 1; }
+        }
         if (kind == EV_WAKE) {                                                              // time/sleep.rs:52
             REG(22);
             if (K::G) wake_with<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff, pf_flags);

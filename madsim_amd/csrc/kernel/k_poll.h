@@ -78,8 +78,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     // timeout(d, ep.recv_from(tag)) = select_biased! { fut, sleep } (time/mod.rs:128-140): poll the recv future,
     // then the timeout's Sleep — which registers ANOTHER timer on every not-elapsed poll (time/sleep.rs:51-53).
     // Returns true when the op completed (Ok or Err(Elapsed)); otherwise the task is Pending.
+    // (`first_poll`: the call is the op's first poll, from [C] — every Sleep it registers is new; on later polls a Sleep that
+    // was pending before registers its timer AGAIN: the `again` argument of timer_schedule, k_timer.h dedup_note)
+    bool first_poll = false;
     auto recv_timeout_poll = [&]() -> bool {
         bool fut_ready = false;
+        bool d1_new = false;
         if (sub == 1 && (u0.x & TF_INBOX)) {                 // oneshot ready -> rand_delay (endpoint.rs:145)
             u0.x &= ~TF_INBOX;
             from = u0.y >> 24;
@@ -87,11 +91,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             uint64_t d1 = rand_delay_deadline<K>(c, L);
             u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
             sub = 2;
+            d1_new = true;
         }
         if (sub == 2) {
             uint64_t d1 = u64of(u1.z, u1.w);
             if (L.clock >= d1) fut_ready = true;
-            else timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
+            else timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true, !d1_new);
         }
         if (fut_ready) return true;                          // Ok((len, from))
         uint4 u2 = TU(c, slot, 2);
@@ -103,7 +108,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             u0.w = MADSIM_VAL_TIMEOUT;
             return true;
         }
-        timer_schedule<K>(c, L, d2, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
+        timer_schedule<K>(c, L, d2, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true, !first_poll);
         st = ST_PENDING;
         return false;
     };
@@ -119,7 +124,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (sub == 1) {
             uint64_t d1 = u64of(u1.z, u1.w);
             if (L.clock < d1) {
-                timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
+                timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true, !first_poll);
             } else {
                 // the caller's pending receive doubles as the rsp_tag: registration word >> 8 (see mailbox_deliver)
                 const uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;
@@ -155,12 +160,14 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 sub = 2;
             }
         }
+        bool d1_new = false;
         if (sub == 2 && (u0.x & TF_INBOX)) {                 // oneshot ready -> rand_delay (endpoint.rs:145)
             u0.x &= ~TF_INBOX;
             from = u0.y >> 24;
             uint64_t d1 = rand_delay_deadline<K>(c, L);
             u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
             sub = 3;
+            d1_new = true;
         }
         if (sub == 3) {
             uint64_t d1 = u64of(u1.z, u1.w);
@@ -168,7 +175,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (PLAIN_ADDR ? from != dst : !addr_eq(addr_of_from(c, from), SOCKW(c, dst))) st = ST_PANIC;   // assert_eq!(from, dst) rpc.rs:126
                 return true;
             }
-            timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
+            timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true, !d1_new);
         }
         if (cimm >> 8) {
             uint4 u2 = TU(c, slot, 2);
@@ -178,7 +185,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.w = MADSIM_VAL_TIMEOUT;
                 return true;
             }
-            timer_schedule<K>(c, L, d2, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
+            timer_schedule<K>(c, L, d2, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true, !first_poll);
         }
         st = ST_PENDING;
         return false;
@@ -249,7 +256,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 // (base-op builds keep no deadline: there a Sleep is only polled again once its own timer has fired)
                 if (K::LIFE && L.clock < deadline) {       // not elapsed: register ANOTHER timer
                     REG(5);
-                    timer_schedule<K>(c, L, deadline, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true);
+                    timer_schedule<K>(c, L, deadline, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true, true);
                     st = ST_PENDING;
                 }
                 else if (K::FC && op == MS_OP_ACCEPT) {    // rand_delay done -> conn_rx.recv()
@@ -491,7 +498,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
             }
             sub = 1;
+            first_poll = true;
             if (recv_timeout_poll()) { sub = 0; pc++; }
+            first_poll = false;
         } else if (K::FR && op == MS_OP_RPC_CALL) {          // first poll of timeout(d, ep.call(dst, req)) / ep.call(dst, req)
             if (imm >> 8) {                                    // timeout()'s Sleep exists before the call is polled
                 uint64_t d2 = sleep_deadline(L, L.clock + (uint64_t)(imm >> 8) * NS_PER_MS);
@@ -503,7 +512,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             uint64_t d1 = rand_delay_deadline<K>(c, L);        // send_to_raw -> NetSim::send: rand_delay first
             u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
             sub = 1;
+            first_poll = true;
             if (rpc_call_poll()) { sub = 0; pc++; }            // (never on the first poll: 1 ms floor)
+            first_poll = false;
         } else if (op == MS_OP_SLEEP_RAND) {        // sleep(thread_rng().gen_range(lo..hi)): [DEP A.3],
             const uint64_t* dp = P.dur_table + 4 * a;          // host-precomputed UniformDuration {mode, low, range, zone}
             uint64_t mode = dp[0], low = dp[1], range = dp[2], zone = dp[3], d;

@@ -67,6 +67,8 @@ template <bool TRACE_, bool SPILL_, int LWS_, int FEAT_, bool RQ_ = false, bool 
     static constexpr bool CMP = (FEAT_ & MADSIM_FEAT_COMPACT) != 0;
     static constexpr bool NOLOG = (FEAT_ & MADSIM_FEAT_NOLOG) != 0;
     static constexpr bool LOGSW = !NOLOG && !TRACE_ && (LIFE || SPILL_ || LWS_ != 6);
+    // MADSIM_STATE_DEDUP_TIMERS (KParams.dedup_n): only the global-state build of timeout-only workloads carries the code
+    static constexpr bool DEDUP = G_ && !TRACE_ && (FEAT_ & MADSIM_FEAT_ALL) == MADSIM_FEAT_TIME;
     static constexpr bool FT = (FEAT_ & MADSIM_FEAT_TIME) != 0, FC = (FEAT_ & MADSIM_FEAT_CHAN) != 0,
                           FR = (FEAT_ & MADSIM_FEAT_RPC) != 0, FN = (FEAT_ & MADSIM_FEAT_NODE) != 0,
                           FA = (FEAT_ & MADSIM_FEAT_ADDR) != 0;
@@ -111,7 +113,11 @@ struct Lane {
     // were there, every spilled level a round trip to global memory; at one site all lanes of the wave share those trips.
     uint64_t pq_deliv_dl, pq_w0, pq_w1, pq_w2;
     uint32_t pq_deliv_meta, pq_deliv_val;
-    uint32_t pq_n;       // bit 7: a delivery is pending; bits 0-2: pending wake-ups
+    uint32_t pq_n;       // bit 7: a delivery is pending; bits 0-2: pending wake-ups; bits 3-5: wake-up i re-registers a pending Sleep (DEDUP)
+    // MADSIM_STATE_DEDUP_TIMERS: `hazard` = this iteration popped two different events with one deadline (their order is the
+    // heap shape's, which the de-duplicated heap does not share with the reference's): the seed starts over with `exact` set —
+    // every timer a heap entry, as everywhere else
+    uint32_t exact, hazard;
 };
 
 #define LDS128(i) (reinterpret_cast<uint4*>(SMEM)[(i)])

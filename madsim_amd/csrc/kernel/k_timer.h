@@ -118,11 +118,39 @@ __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadli
     return room;
 }
 
+// ---- MADSIM_STATE_DEDUP_TIMERS (Variant::DEDUP builds, KParams.dedup_n != 0) ------------------------------------------------
+// Sleep::poll registers ANOTHER timer with the same deadline and the same waker on every not-elapsed poll (time/sleep.rs:51-53);
+// the first one is still in the heap then (it fires once deadline <= now, and the poll saw now < deadline), and when the
+// deadline comes all of them fire back to back, every one after the first finding its task SCHEDULED already: one executor step
+// each, nothing else.  In the election loop a third of all Timer::add calls are such repeats and they make up half of the heap,
+// most of it in the HBM spill region.  Here a repeat becomes a count in a small per-seed hash table — dedup_n 16-byte buckets
+// {deadline lo, hi, wake meta, count} behind the task units — and the pop of the first entry with that (deadline, meta) adds
+// the count to the step counter.  A bucket held by another key: the repeat is pushed like everywhere else (always right).
+// What the shorter heap cannot reproduce is the order of two DIFFERENT entries with equal deadlines (the array algorithm's tie
+// order depends on the heap's shape): timer_expire notices every such tie as it pops it (Lane::hazard) and the seed starts over
+// with Lane::exact set (k_main.h) — results never differ.
+__device__ __forceinline__ uint32_t dedup_bucket(const Ctx& c, uint64_t deadline, uint32_t meta) {
+    const uint32_t lo = (uint32_t)deadline;
+    const uint32_t h = lo ^ (lo >> 7) ^ (lo >> 15) ^ ((uint32_t)(deadline >> 32) * 0x9e3779b1u) ^ ((meta & 0xffu) * 0x85ebca6bu);
+    return c.P.dedup_off + ((h ^ (h >> 11)) & (c.P.dedup_n - 1u)) * 16u;        // logical byte offset of the bucket's unit
+}
+// A re-registration of (deadline, meta): true = it now lives in the table; false = push it.
+__device__ __forceinline__ bool dedup_note(const Ctx& c, uint64_t deadline, uint32_t meta) {
+    const uint32_t at = dedup_bucket(c, deadline, meta);
+    const uint4 u = gs_load128(c.gs, gs_addr_unit(c, at));
+    const bool same = u.x == (uint32_t)deadline && u.y == (uint32_t)(deadline >> 32) && u.z == meta;
+    bool noted = false;
+    if (u.w == 0) { gs_store128(c.gs, gs_addr_unit(c, at), make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, 1u)); noted = true; }
+    else if (same && u.w != ~0u) { gs_store32(c.gs, gs_addr_uword(c, at + 12u), u.w + 1u); noted = true; }
+    return noted;
+}
+
 // Timer::add as the executor code calls it.  Every build but the global-state ones pushes at once; those queue the call in
 // the lane (k_state.h Lane::pq_*) until timer_flush.  `wake` = the event is a wake-up of the task being polled (meta is the
 // same for all of them, so only the deadline is kept); a delivery always precedes the wake-ups of its round (k_poll.h).
 template <class K>
-__device__ __forceinline__ void timer_schedule(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val, bool wake) {
+// `again` = the call re-registers a Sleep whose first timer is still in the heap (DEDUP builds: see dedup_note).
+__device__ __forceinline__ void timer_schedule(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val, bool wake, bool again = false) {
     if (!K::G) { if (!timer_add<K>(c, L, deadline, meta, val)) L.ovf = 1; return; }
     if (wake) {
         const uint32_t n = L.pq_n & 7u;
@@ -131,6 +159,7 @@ __device__ __forceinline__ void timer_schedule(const Ctx& c, Lane& L, uint64_t d
             // (value selects, not `if (n == 0) L.pq_w0 = ..`: a store through a selected field address keeps the whole Lane in scratch)
             L.pq_w0 = n == 0 ? deadline : L.pq_w0; L.pq_w1 = n == 1 ? deadline : L.pq_w1; L.pq_w2 = n == 2 ? deadline : L.pq_w2;
             L.pq_n++;
+            if (K::DEDUP && again) L.pq_n |= 8u << n;
         }
     } else {
         if (L.pq_n) L.ovf = 1;                            // (cannot happen: one delivery per round, before its wake-ups)
@@ -144,7 +173,13 @@ __device__ __forceinline__ void timer_flush(const Ctx& c, Lane& L, uint32_t wake
     while (L.pq_n) {
         uint64_t dl; uint32_t meta, val;
         if (L.pq_n & 0x80u) { dl = L.pq_deliv_dl; meta = L.pq_deliv_meta; val = L.pq_deliv_val; L.pq_n &= 0x7fu; }
-        else { dl = L.pq_w0; meta = wake_meta; val = 0; L.pq_w0 = L.pq_w1; L.pq_w1 = L.pq_w2; L.pq_n--; }
+        else if (!K::DEDUP) { dl = L.pq_w0; meta = wake_meta; val = 0; L.pq_w0 = L.pq_w1; L.pq_w1 = L.pq_w2; L.pq_n--; }
+        else {
+            dl = L.pq_w0; meta = wake_meta; val = 0; L.pq_w0 = L.pq_w1; L.pq_w1 = L.pq_w2;
+            const bool again = (L.pq_n & 8u) != 0;
+            L.pq_n = ((L.pq_n & 7u) - 1u) | ((L.pq_n >> 1) & 0x18u);        // one wake-up less; the repeat flags move down with their deadlines
+            if (again && c.P.dedup_n && !L.exact && dedup_note(c, dl, meta)) continue;
+        }
         if (!timer_add<K>(c, L, dl, meta, val)) L.ovf = 1;
     }
 }

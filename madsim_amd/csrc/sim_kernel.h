@@ -88,6 +88,9 @@ struct KParams {
     uint8_t* trace_log; uint64_t trace_cap; uint64_t* trace_len;
     uint32_t compact;          // base-op builds: the compact LDS layout (MADSIM_FEAT_COMPACT); gstate then holds the main tasks' records
     uint32_t no_log;           // madsim_limits_t.no_trace_hash: skip rng_log, report trace_hash = 0 (trace launches ignore it)
+    // MADSIM_STATE_DEDUP_TIMERS (global-state timeout-only build): dedup_n (a power of two, 0 = off) 16-byte buckets
+    // {deadline lo, hi, wake meta, count} behind the task units, at logical byte dedup_off of the lane's block (k_timer.h dedup_note)
+    uint32_t dedup_n, dedup_off;
     uint64_t* prof;            // profiling builds (tools/experiment): per-phase cycle accumulators
 };
 

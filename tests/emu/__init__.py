@@ -56,6 +56,21 @@ def run_batch(workload, seed0, count, config=None, limits=None, num_cus=2):
     return out
 
 
+def geometry_params(workload, limits=None):
+    """Selected KParams of the geometry a workload gets: the layout words tools/gstate_access_model.py reads, then the op classes
+    (MADSIM_FEAT_* mask), whether the state lives in global memory, and the de-duplication table (buckets, byte offset)."""
+    names = ["gs_stride", "gs_planes", "max_tasks", "task_units", "n_socks", "sock_words", "mbox_regs", "mbox_msgs", "off_socks",
+             "off_handles", "off_nodes", "off_clog", "off_pause", "off_greg", "off_conn", "gs_plane_words", "n_progs",
+             "features", "gstate_mode", "dedup_n", "dedup_off"]
+    kp = (C.c_uint32 * 32)()
+    L = lib()
+    L.madsim_emu_geometry_params.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Limits), C.POINTER(C.c_uint32)]
+    rc = L.madsim_emu_geometry_params(workload.ref(), C.byref(limits or A.Limits()), kp)
+    if rc:
+        raise RuntimeError(L.madsim_emu_last_error().decode())
+    return dict(zip(names, kp))
+
+
 def trace_seed(workload, seed, config=None, limits=None, cap=1 << 20):
     cfg = config or A.Config.default()
     lim = limits or A.Limits()

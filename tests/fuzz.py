@@ -937,3 +937,91 @@ def random_ipvs_workload(rng: random.Random, runtime_ops=False):
 def random_ipvs_runtime_workload(rng: random.Random):
     """random_ipvs_workload with services changed at run time (MS_OP_IPVS)."""
     return random_ipvs_workload(rng, runtime_ops=True)
+
+
+def random_timeout_workload(rng: random.Random):
+    """Timeout-only programs for MADSIM_STATE_DEDUP_TIMERS (the global-state build of FEAT_TIME workloads): receivers in
+    `timeout(d, recv_from)` loops fed by senders (a message that completes a timeout re-registers its Sleep, and the stale pair
+    later wakes a task that has moved on, whose spurious poll re-registers the Sleep it is in by then: time/sleep.rs:51-53),
+    sleepers whose deadlines collide with other tasks' to the nanosecond (1 ms + 50..99 ns against 1 ms: the poll cost in
+    between decides), sleep_until / mark / advance users, and a supervisor partitioning nodes.  Only base and time ops — any
+    other class of op would select a build the switch does not apply to."""
+    n_nodes = rng.randint(2, 4)
+    wl = W.WorkloadBuilder()
+    nodes = [wl.create_node() for _ in range(n_nodes)]
+    addrs = [wl.addr(n, 1) for n in nodes]
+    tasks, desc = [], []
+    for i, n in enumerate(nodes):
+        kind = rng.choice(["rx", "rx", "tx", "pair", "until"])
+        desc.append(kind)
+        t = wl.task(n); t.bind(addrs[i])
+        if kind == "rx":
+            t.set(0, rng.randint(3, 14))
+            top = t.label()
+            if rng.random() < 0.15:
+                t.recv_from(addrs[i], 1)                  # (may wait for ever: a deadlock verdict is as good a comparison as any)
+            t.recv_from_timeout(addrs[i], rng.choice([1, 1, 2]), ms=rng.choice([1, 4, 12, 25, 60]))
+            t.trace_val()
+            if rng.random() < 0.1:
+                t.assert_val(0xB0 + rng.randrange(n_nodes))  # (panics on a timeout or another sender)
+            if rng.random() < 0.3:
+                t.sleep(us=rng.choice([0, 300, 2500]))
+            if rng.random() < 0.3:                       # answer what was received (`from` only exists after an Ok)
+                t.jeq(A.VAL_TIMEOUT, t.label() + 2)
+                t.reply(addrs[i], 1, 0xC0 + i)
+            t.djnz(0, top)
+        elif kind == "tx":
+            t.set(0, rng.randint(3, 12))
+            top = t.label()
+            t.sleep(ms=rng.choice([0, 1, 2, 5]), ns=rng.choice([0, 0, 60, 75, 90]))
+            for _ in range(rng.randint(1, 2)):
+                t.send_to(addrs[i], addrs[rng.choice([j for j in range(n_nodes) if j != i])], rng.choice([1, 1, 2]), 0xB0 + i)
+            t.trace(0x200 + i, add_reg=0)
+            t.djnz(0, top)
+        elif kind == "pair":
+            t.set(0, rng.randint(5, 30))
+            top = t.label()
+            t.sleep(ms=1, ns=rng.choice([0, 0, 55, 64, 75, 88, 99]))
+            t.trace(0x300 + i, add_reg=0)
+            t.djnz(0, top)
+        else:
+            t.mark()
+            t.set(0, rng.randint(2, 8))
+            top = t.label()
+            t.sleep_until(ms=rng.choice([1, 2, 3, 10]))
+            if rng.random() < 0.4:
+                t.recv_from_timeout(addrs[i], 1, ms=rng.choice([2, 8])); t.trace_val()
+            if rng.random() < 0.25:
+                t.advance(ms=rng.choice([1, 3]))
+            t.trace_instant()
+            t.djnz(0, top)
+        t.done()
+        tasks.append(t)
+    # a twin for every sleeper so that ties have someone to tie with
+    for i, n in enumerate(nodes):
+        if desc[i] == "pair" or rng.random() < 0.3:
+            t = wl.task(n); t.set(0, rng.randint(5, 30)); top = t.label()
+            t.sleep(ms=1, ns=rng.choice([0, 0, 0, 70])); t.trace(0x400 + i, add_reg=0); t.djnz(0, top); t.done()
+            tasks.append(t); desc.append("twin")
+    m = wl.main()
+    order = list(range(len(tasks))); rng.shuffle(order)
+    for k in order:
+        m.spawn(tasks[k])
+    for _ in range(rng.randint(0, 3)):
+        act = rng.choice(["sleep", "clog", "unclog", "loss"])
+        if act == "sleep":
+            m.sleep(ms=rng.randint(0, 20))
+        elif act == "clog":
+            m.clog_node(rng.choice(nodes), rng.choice(["in", "out", "both"]))
+        elif act == "unclog":
+            m.unclog_node(rng.choice(nodes), rng.choice(["in", "out", "both"]))
+        else:
+            m.set_loss(rng.randint(0, 2))
+    for k in order:
+        if rng.random() < 0.85:
+            m.join(tasks[k])
+    m.done()
+    cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.05]),
+                           lat_lo_ns=rng.choice([1_000_000, 1, 2_000_000]), lat_hi_ns=rng.choice([10_000_000, 3_000_000]),
+                           loss_table=(0.0, rng.choice([0.0, 0.3]), 1.0))
+    return wl.build(), cfg, "+".join(desc)

@@ -930,3 +930,42 @@ ALL.update(ipvs_load_balance=ipvs_load_balance, ipvs_round_robin_datagrams=ipvs_
            ipvs_round_robin_unit_test=ipvs_round_robin_unit_test, ipvs_add_server_without_service=ipvs_add_server_without_service,
            ipvs_del_server_without_service=ipvs_del_server_without_service, ipvs_service_lifecycle=ipvs_service_lifecycle)
 EXPECT_PANIC.update(("ipvs_rpc_call_asserts_given_address", "ipvs_add_server_without_service", "ipvs_del_server_without_service"))
+
+
+# ---- MADSIM_STATE_DEDUP_TIMERS (k_timer.h dedup_note): not in ALL — these two exist to exercise that switch ------------------
+
+def timeout_repeats_and_ties(pairs=5, rounds=40, chatter=30):
+    """A timeout-only workload (the build the switch applies to) with both things the de-duplicated timer heap must get right:
+    * repeats — `timeout(20 ms, ep.recv_from(tag))` completing through a message: the poll that takes the message registers the
+      timeout's Sleep AGAIN (time/sleep.rs:51-53), both copies fire 20 ms later as wake-ups of a task that has moved on, whose
+      spurious poll re-registers whatever Sleep it is in by then;
+    * ties between DIFFERENT events — pairs of tasks looping `sleep(1 ms + 75 ns)` / `sleep(1 ms)`: polled back to back the two
+      deadlines coincide whenever the 50..100 ns poll cost in between (task/mod.rs:319-321) comes out at 75, and which of them
+      fires first is decided by the BinaryHeap's array order; each traces its id after waking, so the order is observable."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a_rx, a_tx = wl.addr(n1, 1), wl.addr(n2, 1)
+    rx = wl.task(n1); rx.bind(a_rx); rx.set(0, chatter)
+    top = rx.label(); rx.recv_from_timeout(a_rx, 7, ms=20); rx.trace_val(); rx.djnz(0, top); rx.done()
+    tx = wl.task(n2); tx.bind(a_tx); tx.set(0, chatter - 2)
+    top = tx.label(); tx.sleep(ms=3); tx.send_to(a_tx, a_rx, 7, 0x55); tx.djnz(0, top); tx.done()
+    tasks = [rx, tx]
+    for p in range(pairs):
+        a = wl.task(n1); a.set(0, rounds); top = a.label(); a.sleep(ms=1, ns=75); a.trace(0x100 + 2 * p); a.djnz(0, top); a.done()
+        b = wl.task(n2); b.set(0, rounds); top = b.label(); b.sleep(ms=1); b.trace(0x101 + 2 * p); b.djnz(0, top); b.done()
+        tasks += [a, b]
+    m = wl.main()
+    for t in tasks:
+        m.spawn(t)
+    for t in tasks:
+        m.join(t)
+    return wl.build()
+
+
+def dedup_limits(base=None):
+    """Global-state layout with the re-registered Sleep timers kept as counts (MADSIM_STATE_DEDUP_TIMERS)."""
+    import copy
+    lim = copy.copy(base) if base is not None else A.Limits()
+    lim.lanes_per_wave = 0
+    lim.state_mem = A.STATE_GLOBAL | A.STATE_DEDUP_TIMERS
+    return lim

@@ -446,3 +446,69 @@ def test_compact_layout_lane_reuse(sched):
     o, _ = oracle.run_batch(w, 9, 2600, A.Config.default(packet_loss_rate=0.02), lim)
     e = emu.run_batch(w, 9, 2600, A.Config.default(packet_loss_rate=0.02), lim, num_cus=1)
     assert emu.geometry(w, lim).lds_bytes_per_seed == 152 and (o == e).all()
+
+
+# ---- MADSIM_STATE_DEDUP_TIMERS: re-registered Sleep timers as counts (k_timer.h dedup_note) ---------------------------------
+
+def test_dedup_timers_switch_selects_the_timeout_only_global_build_and_nothing_else():
+    raft = W.raft_election()
+    on = emu.geometry_params(raft, LW.dedup_limits(W.raft_election_limits()))
+    assert on["features"] == 1 and on["gstate_mode"] == 1 and on["dedup_n"] == 64          # MADSIM_FEAT_TIME only, global state
+    assert on["dedup_off"] == on["max_tasks"] * on["task_units"] * 16 and on["gs_planes"] == on["dedup_off"] + 64 * 16
+    lim = W.raft_election_limits(); lim.state_mem = A.STATE_GLOBAL
+    off = emu.geometry_params(raft, lim)
+    assert off["dedup_n"] == 0 and off["gs_planes"] == on["gs_planes"] - 64 * 16
+    lim = W.raft_election_limits(); lim.state_mem = A.STATE_LDS | A.STATE_DEDUP_TIMERS        # LDS-resident: ignored
+    assert emu.geometry_params(raft, lim)["dedup_n"] == 0
+    for w, base in ((W.kv_rpc(), W.kv_rpc_limits()), (W.streaming_topology(), W.streaming_topology_limits()), (W.pingpong(4, 8), None)):
+        assert emu.geometry_params(w, LW.dedup_limits(base))["dedup_n"] == 0                  # other op classes / base ops: ignored
+    lim = A.Limits(); lim.state_mem = 0x200
+    with pytest.raises(RuntimeError, match="state_mem"):
+        emu.geometry_params(raft, lim)
+
+
+def test_dedup_timers_election_loop():
+    """The election loop (a third of its Timer::add calls re-register a pending Sleep) with those calls kept as counts:
+    every result byte as the oracle has it, in static striding and through the work queue (several seeds per lane)."""
+    w, lim = W.raft_election(), LW.dedup_limits(W.raft_election_limits())
+    o = _same(w, 5000, 192, None, lim)
+    assert (o["verdict"] == A.PASS).mean() > 0.9
+    want, _ = oracle.run_batch(w, 0, 2000, None, lim)
+    for sched in (A.SCHED_STATIC, A.SCHED_QUEUE):               # one CU: 768 lanes, so a lane runs two or three seeds in turn
+        lim.sched = sched
+        assert (emu.run_batch(w, 0, 2000, None, lim, num_cus=1) == want).all()
+
+
+def test_dedup_timers_ties_restart_the_seed_with_the_literal_heap():
+    """Two DIFFERENT events on one deadline fire in the order of the BinaryHeap's array, which a heap without the repeats does
+    not share: timeout_repeats_and_ties has such ties in a seventh of its seeds (with the tie check compiled out 9 of these
+    512 seeds differ from the oracle — tried once by hand); the kernel notices each as it pops it and runs the seed again
+    with every timer a heap entry."""
+    w = LW.timeout_repeats_and_ties()
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 4, 60; lim.mbox_regs, lim.mbox_msgs = 8, 8
+    o = _same(w, 0, 512, None, LW.dedup_limits(lim))
+    assert (o["verdict"] == A.PASS).all()
+    assert emu.geometry_params(w, LW.dedup_limits(lim))["dedup_n"] == 64
+    _same(w, 0, 128, A.Config.default(packet_loss_rate=0.1), LW.dedup_limits(lim))
+    # a lane that ran a seed twice goes back to counting for its next seed (one CU, several seeds per lane, both work distributions)
+    want, _ = oracle.run_batch(w, 700, 2400, None, lim)
+    for sched in (A.SCHED_STATIC, A.SCHED_QUEUE):
+        l2 = LW.dedup_limits(lim); l2.sched = sched
+        assert (emu.run_batch(w, 700, 2400, None, l2, num_cus=1) == want).all()
+
+
+def test_dedup_timers_fuzz():
+    """Random timeout-only programs (repeats, nanosecond ties, sleep_until / advance, partitions) on the de-duplicating build."""
+    seen, active = set(), 0
+    for k in range(250):
+        w, cfg, desc = fuzz.random_timeout_workload(random.Random(92000 + k))
+        lim = LW.dedup_limits(fuzz.generous_limits())
+        if k % 3 == 2:
+            lim.no_trace_hash = 1
+        o, _ = oracle.run_batch(w, k * 7, 12, cfg, lim)
+        e = emu.run_batch(w, k * 7, 12, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+        seen |= set(o["verdict"].tolist())
+        active += emu.geometry_params(w, lim)["dedup_n"] != 0
+    assert {A.PASS, A.PANIC, A.DEADLOCK} <= seen and active > 200

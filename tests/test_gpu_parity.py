@@ -889,3 +889,62 @@ def test_compact_layout_fuzz_gpu(hip):
             assert ok.all(), (f"random_workload(Random({base + k})) [MADSIM_FUZZ_SEED={FUZZ_SEED}]", desc, got[~ok][0], want[~ok][0])
             ran += 1
     assert ran >= 30, ran
+
+
+# ---- MADSIM_STATE_DEDUP_TIMERS: re-registered Sleep timers as counts (k_timer.h dedup_note) ---------------------------------
+
+def test_dedup_timers_election_loop_gpu(hip):
+    """The election loop at batch size with the repeats of a pending Sleep's timer kept as counts: the same 48 bytes per seed
+    as without the switch (131 072 seeds compared with each other), sampled and contiguous seeds against the oracle."""
+    from tests import lifecycle_workloads as LW
+    w, lim = W.raft_election(), W.raft_election_limits()
+    lim.state_mem = A.STATE_GLOBAL
+    g0, g1 = hip.geometry(w, lim), hip.geometry(w, LW.dedup_limits(lim))
+    assert g0.variant == g1.variant and g1.global_bytes_per_seed == g0.global_bytes_per_seed + 64 * 16
+    plain, _ = hip.run_batch(w, 0, 131072, None, lim)
+    got, _ = hip.run_batch(w, 0, 131072, None, LW.dedup_limits(lim))
+    assert (got == plain).all()
+    want, _ = oracle.run_batch(w, 40000, 1024, None, lim)
+    assert (got[40000:41024] == want).all()
+    for s in [(k * 4093) % 131072 for k in range(128)]:
+        want, _ = oracle.run_batch(w, s, 1, None, lim)
+        assert got[s] == want[0], f"seed {s}"
+
+
+def test_dedup_timers_ties_and_lane_reuse_gpu(hip):
+    """Ties between different events (a seventh of these seeds): the kernel restarts such a seed with the literal heap — also
+    when the lane has more seeds to run afterwards (the per-launch work queue and static striding, more seeds than lanes)."""
+    from tests import lifecycle_workloads as LW
+    w = LW.timeout_repeats_and_ties()
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 4, 60; lim.mbox_regs, lim.mbox_msgs = 8, 8
+    want, _ = oracle.run_batch(w, 0, 8192, None, lim)
+    got, _ = hip.run_batch(w, 0, 8192, None, LW.dedup_limits(lim))
+    assert (got == want).all() and (got["verdict"] == A.PASS).all()
+    n = 3 * hip.geometry(w, LW.dedup_limits(lim)).grid_blocks * 256 // 2 + 777       # one and a half seeds per resident lane ... and a few
+    n = min(n, 400000)
+    plain = copy_limits(lim); plain.lanes_per_wave, plain.state_mem = 0, A.STATE_GLOBAL
+    ref, _ = hip.run_batch(w, 1 << 20, n, None, plain)
+    for sched in (A.SCHED_STATIC, A.SCHED_QUEUE):
+        l2 = LW.dedup_limits(lim); l2.sched = sched
+        got, _ = hip.run_batch(w, 1 << 20, n, None, l2)
+        assert (got == ref).all(), sched
+    want, _ = oracle.run_batch(w, (1 << 20) + n - 2048, 2048, None, lim)
+    assert (ref[n - 2048:] == want).all()
+
+
+def copy_limits(lim):
+    import copy
+    return copy.copy(lim)
+
+
+def test_fuzz_timeout_workloads_gpu(hip):
+    """Random timeout-only programs (repeats of pending Sleeps, nanosecond ties, sleep_until / advance, partitions) on the
+    de-duplicating global-state build — and, every other program, on the builds the switch does not touch."""
+    from tests import fuzz, lifecycle_workloads as LW
+
+    def limits():
+        limits.k += 1
+        lim = fuzz.generous_limits()
+        return LW.dedup_limits(lim) if limits.k % 2 else lim
+    limits.k = 0
+    _fuzz_two_blocks(hip, fuzz.random_timeout_workload, 12100, 240, 120, 11, count=64, seed_mul=13, limits=limits)

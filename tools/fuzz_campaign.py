@@ -16,7 +16,8 @@ gens = [("plain", fuzz.random_workload, None), ("lifecycle", fuzz.random_lifecyc
         ("rpc+hooks", lambda r: fuzz.random_rpc_workload(r, hooks=True), 24), ("addresses", fuzz.random_addr_workload, None),
         ("ephemeral", fuzz.random_ephemeral_workload, None), ("channel", fuzz.random_channel_workload, 24),
         ("guards", fuzz.random_guard_workload, 24), ("supervisor", fuzz.random_supervisor_workload, 48),
-        ("mixed", fuzz.random_mixed_workload, 60), ("ipvs", fuzz.random_ipvs_workload, 24), ("ipvs_rt", fuzz.random_ipvs_runtime_workload, 24)]
+        ("mixed", fuzz.random_mixed_workload, 60), ("ipvs", fuzz.random_ipvs_workload, 24), ("ipvs_rt", fuzz.random_ipvs_runtime_workload, 24),
+        ("timeouts", fuzz.random_timeout_workload, None)]
 if len(sys.argv) > 3:                              # optional: only the generators whose name contains one of these (comma-separated)
     gens = [g for g in gens if any(x in g[0] for x in sys.argv[3].split(","))]
 t0 = time.time(); k = 0; stats = {g[0]: [0, 0, 0] for g in gens}; verdicts = np.zeros(6, dtype=np.int64)
@@ -27,6 +28,7 @@ while time.time() - t0 < budget:
     if max_tasks: lim.max_tasks = max_tasks
     if (k // len(gens)) % 2:          # every other round: per-seed state in the global-memory block instead of LDS (Variant::G)
         lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        if name == "timeouts": lim.state_mem |= A.STATE_DEDUP_TIMERS      # re-registered Sleep timers as counts (k_timer.h dedup_note)
     if k % 5 == 4:                    # every fifth program in the reference's plain mode: no determinism-log fingerprint (rand.rs:67)
         lim.no_trace_hash = 1
     n = 96

@@ -28,6 +28,7 @@ top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 w, lim = {"kv": (workload.kv_rpc, workload.kv_rpc_limits), "raft": (workload.raft_election, workload.raft_election_limits),
           "topo": (workload.streaming_topology, workload.streaming_topology_limits)}[which]
 w, lim = w(), lim()
+lim.state_mem |= int(os.environ.get("MADSIM_MODEL_STATE_FLAGS", "0"), 0)      # e.g. 0x100 = MADSIM_STATE_DEDUP_TIMERS
 cfg = A.Config.default()
 out = np.zeros(count, dtype=A.RESULT_DTYPE)
 rc = L.madsim_emu_run_batch(w.ref(), C.byref(cfg), 0, count, C.byref(lim), out.ctypes.data_as(C.c_void_p), 1, None, 0, None)

@@ -7,6 +7,7 @@ import torch
 runtime.init(0)
 which = sys.argv[1] if len(sys.argv) > 1 else "pingpong"       # any bench.py --workload name
 w, lim, _ = workload.bench_case(which)
+lim.state_mem |= int(os.environ.get("MADSIM_BENCH_STATE_FLAGS", "0"), 0)      # e.g. 0x100 = MADSIM_STATE_DEDUP_TIMERS
 buf = torch.empty(65536 * 48, dtype=torch.uint8, device="cuda")
 out = (C.c_uint64 * 16)()
 L = runtime.lib()
