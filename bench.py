@@ -43,7 +43,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of sampled seeds after the timed region")
     ap.add_argument("--no-first-fail", action="store_true", help="skip the first-failing-seed measurements (loss variants)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip extra.workloads (3 timed steps each of the raft / kv / topo / timers workloads after the headline)")
+                    help="skip extra.workloads (a few timed steps each of the raft / kv / topo / timers workloads after the headline)")
     ap.add_argument("--rare-loss", type=float, default=1.2e-6,
                     help="packet_loss_rate of the rare-failure search: 256 datagrams per seed => ~3e-4 of the seeds deadlock")
     ap.add_argument("--very-rare-loss", type=float, default=2e-8,
@@ -216,7 +216,12 @@ def main():
     waves_cu = g0.blocks_per_cu * g0.block_threads // 64
     # batches in flight: one wave per SIMD each, so as many as the workload's LDS admits waves per SIMD — and one more, whose
     # launch queues behind them and fills the gaps their tails leave (measured: tools/experiment/exp_compact.sh)
-    max_streams = args.streams if args.streams > 0 else (5 if waves_cu >= 16 else 3)
+    # (global-state builds with a heap-spill region — long launches that end with their slowest wave: three resident and a fourth
+    # behind them, +5 % on the election loop and the topology; the KV build, whose heap sits in LDS, gains nothing from it:
+    # tools/experiment/exp_gstreams.sh)
+    def flights(g):
+        return 5 if g.blocks_per_cu * g.block_threads // 64 >= 16 else 4 if (g.variant & 16) and g.heap_spill_slots else 3
+    max_streams = args.streams if args.streams > 0 else flights(g0)
     n_streams = max_streams
     d_outs = [torch.empty(count * 48, dtype=torch.uint8, device=dev) for _ in range(max_streams)]   # results stay in HBM
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max_streams - 1)]
@@ -280,7 +285,7 @@ def main():
             return (time.perf_counter() - t1) / n * 1e3
 
         trial(min(3, max_streams), 6)                # first launches pay for table uploads, module load, stream set-up
-        for cand in ((3, 4, 5, 3, 4, 5) if max_streams >= 5 else (2, 3, 2, 3)):      # alternate, keep the better of two rounds each
+        for cand in ((3, 4, 5, 3, 4, 5) if max_streams >= 5 else (3, 4, 3, 4) if max_streams == 4 else (2, 3, 2, 3)):      # alternate, keep the better of two rounds each
             ms = trial(cand, 12)
             stream_trial[cand] = min(ms, stream_trial.get(cand, ms))
         n_streams = min(stream_trial, key=stream_trial.get)
@@ -526,7 +531,7 @@ def main():
                 print(f"bench.py: RARE FIRST-FAIL VERIFY FAILED: {ff}", file=sys.stderr)
                 return 3
 
-    # extra.workloads: the configs[2] / [3] / [4]-shaped workloads and the timer storm, 3 timed steps each on the same streams,
+    # extra.workloads: the configs[2] / [3] / [4]-shaped workloads and the timer storm, two timed steps per stream each on the same streams,
     # every line with sampled seeds of its timed batches checked against the oracle
     extras = None
     if not args.no_extras and world == 1 and headline and not args.loss:
@@ -535,10 +540,10 @@ def main():
         for name in ("raft", "kv", "topo", "timers"):
             xw, xlim, xname = workload.bench_case(name)
             xg0 = runtime.geometry(xw, xlim)
-            # batches in flight by THIS workload's occupancy: more than three only where four waves per SIMD fit — a fourth or
-            # fifth batch of a global-state build only pushes its working set out of the Infinity Cache
-            xn = n_streams if xg0.blocks_per_cu * xg0.block_threads // 64 >= 16 else min(n_streams, 3)
-            xs, xwu = 3, 3
+            # batches in flight by THIS workload's occupancy (flights(), above): five only where four waves per SIMD fit, four for
+            # the global-state builds with a heap-spill region, else three
+            xn = min(n_streams, flights(xg0))
+            xs, xwu = 2 * xn, xn          # two timed batches per stream after one untimed: the second launch of a stream starts into a busy chip
             xring = torch.zeros((xs + xwu, REPORT_WORDS), dtype=torch.int64, device=dev)
             last = {}
 

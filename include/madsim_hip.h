@@ -483,7 +483,7 @@ int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const m
  * One 65 536-seed batch is one wave per SIMD: alone it leaves two thirds of the issue slots idle (a base-op launch takes ~3.2 ms
  * alone, ~1.3 ms per batch with three in flight).  madsim_hip_run_batch cannot overlap anything — it returns the results —, so
  * the overlap lives here: `total` seeds from `seed0` run as batches of `batch` seeds (0 = 65 536) on the context's own HIP
- * streams, `in_flight` at a time (0 = auto: 3, or 5 when the workload's LDS admits four waves per SIMD; more streams than hardware queues are pointless: GPU_MAX_HW_QUEUES), each followed by a
+ * streams, `in_flight` at a time (0 = auto: 3; 5 when the workload's LDS admits four waves per SIMD; 4 for a global-state build with a heap-spill region; more streams than hardware queues are pointless: GPU_MAX_HW_QUEUES), each followed by a
  * device reduction whose 48-byte report is the only thing copied to the host.  Per-seed results are NOT returned: a campaign
  * answers "which is the first failing seed, how many fail" — the seed-search use of `MADSIM_TEST_NUM` — and the caller re-runs
  * the seed it is told about (madsim_hip_run_batch / madsim_hip_trace_seed) for details.

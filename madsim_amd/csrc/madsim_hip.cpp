@@ -700,7 +700,10 @@ int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* c, const madsim_workload_t* w,
         // four (the compact base-op layout) — a fifth, whose launch queues behind them and fills the gaps their tails leave
         madsim_geo::Geo G;
         in_flight = 3;
-        if (!madsim_geo::make_geometry(c->dev(), w, cfg, lim, batch, &G, &g_err) && G.blocks_per_cu * G.waves_per_block >= 16) in_flight = 5;
+        if (!madsim_geo::make_geometry(c->dev(), w, cfg, lim, batch, &G, &g_err)) {
+            if (G.blocks_per_cu * G.waves_per_block >= 16) in_flight = 5;
+            else if (G.P.gstate_mode && G.P.heap_spill) in_flight = 4;      // long launches that end with their slowest wave: one more behind them
+        }
     }
     if (in_flight > (uint32_t)madsim_hip_ctx::CAMPAIGN_MAX) return fail(MADSIM_E_ARG, "at most 8 batches in flight");
     if (seed0 + total < seed0) return fail(MADSIM_E_ARG, "seed0 + total wraps");
