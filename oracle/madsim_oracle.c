@@ -504,6 +504,9 @@ static int spawn_task_from(sim_t* S, unsigned prog, int record_handle, int via_h
         if (t->info_gen == n->info_gen) { tref_t r = { (uint16_t)slot, gen }; vec_push(n->tasks, r); }
     }
     t->pc = S->w->progs[prog].entry; t->joiner = -1; t->conn = -1;
+    /* `from` before the task has received anything: no Rust program can name it (the binding does not exist yet); the workload VM
+     * can (MS_OP_REPLY after a timed-out receive), and then both this oracle and the kernel read it as socket-table entry 0 */
+    if (S->w->n_socks) t->from = (uint32_t)S->w->socks[0].port << 8;
     t->scheduled = 1;                                     /* runnable.schedule() :651 */
     ready_push(S, (uint16_t)slot);
     if (record_handle) { S->handles[prog].state = H_RUNNING; S->handles[prog].slot = (uint16_t)slot; S->handles[prog].gen = gen; }

@@ -1025,3 +1025,30 @@ def random_timeout_workload(rng: random.Random):
                            lat_lo_ns=rng.choice([1_000_000, 1, 2_000_000]), lat_hi_ns=rng.choice([10_000_000, 3_000_000]),
                            loss_table=(0.0, rng.choice([0.0, 0.3]), 1.0))
     return wl.build(), cfg, "+".join(desc)
+
+
+def random_reply_without_receive_workload(rng: random.Random):
+    """Programs that `reply` with whatever `from` holds — nothing yet, or the sender of an earlier message after a receive that
+    timed out.  No Rust program can do the former (the binding does not exist before the first Ok), the workload VM can: oracle
+    and kernel both read an unset `from` as socket-table entry 0 (oracle/madsim_oracle.c spawn_task_from)."""
+    wl = W.WorkloadBuilder()
+    n = rng.randint(2, 4)
+    nodes = [wl.create_node() for _ in range(n)]
+    addrs = [wl.addr(x, rng.choice([1, 1, 7])) for x in nodes]
+    tasks = []
+    for i in range(n):
+        t = wl.task(nodes[i]); t.bind(addrs[i]); t.set(0, rng.randint(2, 8)); top = t.label()
+        if rng.random() < 0.5:
+            t.recv_from_timeout(addrs[i], rng.choice([1, 2]), ms=rng.choice([1, 5, 20]))
+        else:
+            t.sleep(ms=rng.choice([1, 3]))
+        t.reply(addrs[i], rng.choice([1, 2]), 0xC0 + i)
+        if rng.random() < 0.5:
+            t.send_to(addrs[i], addrs[rng.randrange(n)], rng.choice([1, 2]), 0xB0 + i)
+        t.trace_val(); t.djnz(0, top); t.done(); tasks.append(t)
+    m = wl.main()
+    for t in tasks:
+        m.spawn(t)
+    for t in tasks:
+        m.join(t)
+    return wl.build(), A.Config.default(packet_loss_rate=rng.choice([0.0, 0.1])), f"{n} repliers"

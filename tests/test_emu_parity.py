@@ -512,3 +512,17 @@ def test_dedup_timers_fuzz():
         seen |= set(o["verdict"].tolist())
         active += emu.geometry_params(w, lim)["dedup_n"] != 0
     assert {A.PASS, A.PANIC, A.DEADLOCK} <= seen and active > 200
+
+
+def test_fuzz_reply_without_receive():
+    """`reply` before anything was received / after a timed-out receive: an unset `from` is socket-table entry 0 on both sides
+    (found by the timeout generator's first version: the oracle had sent such a reply to port 0, the kernel to entry 0's port)."""
+    for k in range(150):
+        w, cfg, desc = fuzz.random_reply_without_receive_workload(random.Random(96000 + k))
+        lim = fuzz.generous_limits()
+        if k % 2:
+            lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        o, _ = oracle.run_batch(w, k * 3, 8, cfg, lim)
+        e = emu.run_batch(w, k * 3, 8, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])

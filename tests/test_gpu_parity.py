@@ -948,3 +948,9 @@ def test_fuzz_timeout_workloads_gpu(hip):
         return LW.dedup_limits(lim) if limits.k % 2 else lim
     limits.k = 0
     _fuzz_two_blocks(hip, fuzz.random_timeout_workload, 12100, 240, 120, 11, count=64, seed_mul=13, limits=limits)
+
+
+def test_fuzz_reply_without_receive_gpu(hip):
+    """`reply` with an unset or stale `from` (tests/fuzz.py random_reply_without_receive_workload): entry 0 on both sides."""
+    from tests import fuzz
+    _fuzz_two_blocks(hip, fuzz.random_reply_without_receive_workload, 13300, 120, 60, 12, count=32, seed_mul=3, limits=fuzz.generous_limits, alt_global=True)

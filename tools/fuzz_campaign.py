@@ -17,7 +17,7 @@ gens = [("plain", fuzz.random_workload, None), ("lifecycle", fuzz.random_lifecyc
         ("ephemeral", fuzz.random_ephemeral_workload, None), ("channel", fuzz.random_channel_workload, 24),
         ("guards", fuzz.random_guard_workload, 24), ("supervisor", fuzz.random_supervisor_workload, 48),
         ("mixed", fuzz.random_mixed_workload, 60), ("ipvs", fuzz.random_ipvs_workload, 24), ("ipvs_rt", fuzz.random_ipvs_runtime_workload, 24),
-        ("timeouts", fuzz.random_timeout_workload, None)]
+        ("timeouts", fuzz.random_timeout_workload, None), ("stale_from", fuzz.random_reply_without_receive_workload, None)]
 if len(sys.argv) > 3:                              # optional: only the generators whose name contains one of these (comma-separated)
     gens = [g for g in gens if any(x in g[0] for x in sys.argv[3].split(","))]
 t0 = time.time(); k = 0; stats = {g[0]: [0, 0, 0] for g in gens}; verdicts = np.zeros(6, dtype=np.int64)
