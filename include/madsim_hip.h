@@ -68,7 +68,8 @@ enum madsim_op {
                               MADSIM_PROG_INIT program(s) now (task/mod.rs:472-474)                  */
     /* -- time -- */
     MS_OP_SLEEP = 10,      /* time::sleep(b s + imm ns).await  (time/sleep.rs:5-8, mod.rs:111-124)   */
-    MS_OP_MARK = 11,       /* t0 = Instant::now()                                                    */
+    MS_OP_MARK = 11,       /* t0 = Instant::now().  A program's SLEEP_UNTIL / ASSERT_ELAPSED must have a MARK at a lower pc: t0
+                              is a local of the task body, and a use before its assignment is refused (MADSIM_E_WORKLOAD) as Rust would */
     MS_OP_SLEEP_UNTIL = 12,/* time::sleep_until(t0 + b s + imm ns).await (time/mod.rs:118-124)       */
     MS_OP_ASSERT_ELAPSED = 13, /* a=cmp (0 ==, 1 >=, 2 <): assert!(t0.elapsed() cmp b s + imm ns)    */
     MS_OP_ADVANCE = 14,    /* time::advance(b s + imm ns) (time/mod.rs:195-198, 103-106)             */

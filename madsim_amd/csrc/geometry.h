@@ -157,6 +157,20 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
         default: break;
         }
     }
+    {   // `t0` is a local of the task body (`let t0 = Instant::now()`): Rust refuses a use before its assignment, and so does this —
+        // a task slot's t0 words are whatever its previous occupant left there.  Rule: in the program that owns it (the one with the
+        // largest entry <= pc) a MS_OP_MARK stands at a lower pc than every MS_OP_SLEEP_UNTIL / MS_OP_ASSERT_ELAPSED.
+        std::vector<uint8_t> is_entry(w->n_insns, 0);
+        for (uint32_t p = 0; p < w->n_progs; p++) is_entry[w->progs[p].entry] = 1;
+        bool marked = false;
+        for (uint32_t i = 0; i < w->n_insns; i++) {
+            if (is_entry[i]) marked = false;
+            const uint8_t op = w->insns[i].op;
+            if (op == MS_OP_MARK) marked = true;
+            else if ((op == MS_OP_SLEEP_UNTIL || op == MS_OP_ASSERT_ELAPSED) && !marked)
+                return fail(err, MADSIM_E_WORKLOAD, "sleep_until / assert_elapsed before the program's first mark: t0 is not assigned yet");
+        }
+    }
     for (uint32_t p = 0; p < w->n_progs; p++) {
         if (!(w->progs[p].flags & MADSIM_PROG_DROP_SPAWN)) continue;
         if (p + 1 >= w->n_progs || w->progs[p + 1].node != w->progs[p].node)
@@ -226,7 +240,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     P.heap_lds = L.heap_lds_slots ? L.heap_lds_slots : 8;
     P.heap_spill = (L.heap_lds_slots || L.heap_spill_slots) ? L.heap_spill_slots : 56;
     bool t0 = uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) || uses_op(w, MS_OP_RECV_TIMEOUT) || P.uses_rpc;
-    P.uses_chan = uses_op(w, MS_OP_CONNECT) || uses_op(w, MS_OP_ACCEPT) || uses_op(w, MS_OP_CSEND) || uses_op(w, MS_OP_CRECV);
+    // (MS_OP_CCLOSE alone counts too: without the connection unit a stray `drop((tx, rx))` read the task's flag word as a connection id)
+    P.uses_chan = uses_op(w, MS_OP_CONNECT) || uses_op(w, MS_OP_ACCEPT) || uses_op(w, MS_OP_CSEND) || uses_op(w, MS_OP_CRECV) || uses_op(w, MS_OP_CCLOSE);
     // task units: 0-1 always; 2 = {t0, timeout()'s deadline} when used; then the connection unit, then the RPC unit
     P.task_units = t0 ? 3 : 2;
     if (P.uses_chan) { P.chan_unit = P.task_units; P.task_units++; }

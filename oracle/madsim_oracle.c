@@ -957,9 +957,13 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (t->sub == 1) { if (!sleep_poll(S, slot, t->deadline)) return 0; t->sub = 2; }
             sock_t* k = &S->socks[in->a];
             if (k->acceptq.n == 0) { k->acc_task = slot; k->acc_gen = t->gen; return 0; }   /* conn_rx.recv() pending */
-            if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, t->killed); t = &S->tasks.p[slot]; k = &S->socks[in->a]; }
-            t->conn = (int8_t)k->acceptq.p[0];
+            /* `(tx, rx, _) = ep.accept1().await` over a pair already in hand: the right-hand side is evaluated first — the connection
+             * leaves the queue — and the old pair drops on assignment.  (The other order also mis-sized the memmove when the drop
+             * emptied this very queue: an Endpoint that was closed and is kept bound by that old pair alone.) */
+            const int8_t taken = (int8_t)k->acceptq.p[0];
             memmove(k->acceptq.p, k->acceptq.p + 1, --k->acceptq.n);
+            if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, t->killed); t = &S->tasks.p[slot]; k = &S->socks[in->a]; }
+            t->conn = taken;
             S->conns.p[t->conn].guard_sock[1] = in->a; k->guards++;   /* Sender / Receiver { _guard: self.guard.clone() } (endpoint.rs:203-210) */
             t->side = 1; t->sub = 0; t->pc++;
             break;

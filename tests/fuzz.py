@@ -1052,3 +1052,68 @@ def random_reply_without_receive_workload(rng: random.Random):
     for t in tasks:
         m.join(t)
     return wl.build(), A.Config.default(packet_loss_rate=rng.choice([0.0, 0.1])), f"{n} repliers"
+
+
+UNSTRUCTURED_OPS = ("try_bind,try_bind,close,send,send,reply,recv_t,recv_t,recv,sleep,sleep_until,mark,advance,yield,trace,tinst,loss,clog,unclog,"
+                    "spawn,spawn,join,bind,connect,connect,accept,csend,crecv,cclose,kill,restart,pause,resume,abort").split(",")
+
+
+def random_unstructured_workload(rng: random.Random, ops=UNSTRUCTURED_OPS):
+    """Op soup: every task a short loop of randomly chosen ops on randomly chosen operands — Endpoints the task never bound or has
+    closed, connections it does not hold, programs spawned twice or joined before they were spawned, nodes killed under their own
+    supervisor.  Most of it no Rust program could say; the table format can, and whatever passes validate() must get the oracle's
+    answer from the kernel (this generator's first runs found an oracle crash — accept1 over a pair in hand whose drop emptied the
+    queue —, a stray `drop((tx, rx))` in a workload without any other connection op reading the flag word as a connection id, and
+    t0 read before its first mark: now refused)."""
+    wl = W.WorkloadBuilder()
+    n = rng.randint(1, 3)
+    nodes = [wl.create_node() for _ in range(n)]
+    addrs = [wl.addr(nodes[rng.randrange(n)], rng.choice([1, 2])) for _ in range(rng.randint(1, 4))]
+    tasks = [wl.task(nodes[rng.randrange(n)]) for _ in range(rng.randint(1, 4))]
+    for ti, t in enumerate(tasks):
+        t.mark(); t.set(0, rng.randint(1, 3)); top = t.label()
+        for _ in range(rng.randint(2, 9)):
+            op = rng.choice(ops)
+            a = rng.choice(addrs)
+            later = ti + 1 < len(tasks)
+            if op == "bind": t.bind(a)
+            elif op == "try_bind": t.try_bind(a); t.trace_val()
+            elif op == "close": t.close(a)
+            elif op == "send": t.send_to(a, rng.choice(addrs), rng.choice([1, 2]), rng.randrange(256))
+            elif op == "reply": t.reply(a, rng.choice([1, 2]), rng.randrange(256))
+            elif op == "recv": t.recv_from(a, rng.choice([1, 2])); t.trace_val()
+            elif op == "recv_t": t.recv_from_timeout(a, rng.choice([1, 2]), ms=rng.choice([0, 1, 3, 10])); t.trace_val()
+            elif op == "sleep": t.sleep(us=rng.choice([0, 10, 1000, 1500]))
+            elif op == "sleep_until": t.sleep_until(ms=rng.choice([0, 1, 4]))
+            elif op == "mark": t.mark()
+            elif op == "advance": t.advance(us=rng.choice([0, 500, 2000]))
+            elif op == "yield": t.yield_now()
+            elif op == "trace": t.trace(rng.randrange(1000))
+            elif op == "tinst": t.trace_instant()
+            elif op == "loss": t.set_loss(rng.randrange(3))
+            elif op == "clog": t.clog_node(rng.choice(nodes), rng.choice(["in", "out", "both"]))
+            elif op == "unclog": t.unclog_node(rng.choice(nodes), rng.choice(["in", "out", "both"]))
+            elif op == "connect": t.connect1(a, rng.choice(addrs)); t.trace_val()
+            elif op == "accept": t.accept1(a)
+            elif op == "csend": t.chan_send(rng.randrange(256)); t.trace_val()
+            elif op == "crecv": t.chan_recv(); t.trace_val()
+            elif op == "cclose": t.chan_close()
+            elif op == "kill": t.kill(rng.choice(nodes))
+            elif op == "restart": t.restart(rng.choice(nodes))
+            elif op == "pause": t.pause(rng.choice(nodes))
+            elif op == "resume": t.resume(rng.choice(nodes))
+            elif op == "abort" and later: t.abort(tasks[rng.randrange(ti + 1, len(tasks))])
+            elif op == "spawn" and later: t.spawn(tasks[rng.randrange(ti + 1, len(tasks))])
+            elif op == "join" and later: t.join(tasks[rng.randrange(ti + 1, len(tasks))], expect_err=rng.random() < 0.2)
+        t.djnz(0, top); t.done()
+    m = wl.main()
+    for t in tasks:
+        if rng.random() < 0.8:
+            m.spawn(t)
+    if rng.random() < 0.5:
+        m.sleep(ms=rng.randint(0, 5))
+    for t in tasks:
+        if rng.random() < 0.7:
+            m.join(t, expect_err=rng.random() < 0.1)
+    m.done()
+    return wl.build(), A.Config.default(packet_loss_rate=rng.choice([0.0, 0.1]), loss_table=(0.0, 0.5, 1.0)), f"{len(tasks)} tasks of op soup"

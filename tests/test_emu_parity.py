@@ -526,3 +526,42 @@ def test_fuzz_reply_without_receive():
         e = emu.run_batch(w, k * 3, 8, cfg, lim)
         ok = (o == e) | (e["verdict"] == A.OVERFLOW)
         assert ok.all(), (k, desc, o[~ok][0], e[~ok][0])
+
+
+def test_fuzz_unstructured_workloads():
+    """Op soup (tests/fuzz.py random_unstructured_workload): whatever validate() lets through gets the oracle's answer — or is
+    refused by both layouts alike."""
+    from madsim_amd import runtime
+    seen, refused = set(), 0
+    for k in range(400):
+        w, cfg, desc = fuzz.random_unstructured_workload(random.Random(97000 + k))
+        for glob in (0, 1):
+            lim = fuzz.generous_limits(); lim.max_tasks = 16
+            if glob:
+                lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL | A.STATE_DEDUP_TIMERS
+            try:
+                e = emu.run_batch(w, k * 3, 6, cfg, lim)
+            except RuntimeError as ex:                     # a validate() rule (e.g. two listening Endpoints on a node that can be killed)
+                assert "emu error" in str(ex), ex
+                refused += 1
+                continue
+            o, _ = oracle.run_batch(w, k * 3, 6, cfg, lim)
+            ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+            assert ok.all(), (k, glob, desc, o[~ok][0], e[~ok][0])
+            seen |= set(o["verdict"].tolist())
+    assert {A.PASS, A.PANIC, A.DEADLOCK} <= seen and refused < 40
+
+
+def test_t0_must_be_marked_before_it_is_read_and_cclose_alone_lays_out_the_connection_unit():
+    wl = W.WorkloadBuilder(); n = wl.create_node()
+    t = wl.task(n); t.sleep_until(ms=1); t.mark(); t.done()
+    m = wl.main(); m.spawn(t); m.join(t)
+    with pytest.raises(RuntimeError, match="t0 is not assigned"):
+        emu.run_batch(wl.build(), 0, 1)
+    wl = W.WorkloadBuilder(); n = wl.create_node()
+    t = wl.task(n); t.mark(); t.assert_elapsed("<", ms=1); t.chan_close(); t.done()      # a stray drop((tx, rx)): no connection in hand
+    m = wl.main(); m.spawn(t); m.join(t)
+    w = wl.build()
+    assert emu.geometry_params(w)["features"] & 2                                      # MADSIM_FEAT_CHAN: the connection unit exists
+    o = _same(w, 0, 8)
+    assert (o["verdict"] == A.PASS).all()

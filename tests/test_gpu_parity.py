@@ -954,3 +954,23 @@ def test_fuzz_reply_without_receive_gpu(hip):
     """`reply` with an unset or stale `from` (tests/fuzz.py random_reply_without_receive_workload): entry 0 on both sides."""
     from tests import fuzz
     _fuzz_two_blocks(hip, fuzz.random_reply_without_receive_workload, 13300, 120, 60, 12, count=32, seed_mul=3, limits=fuzz.generous_limits, alt_global=True)
+
+
+def test_fuzz_unstructured_workloads_gpu(hip):
+    """Op soup (tests/fuzz.py random_unstructured_workload) on the GPU: the oracle's answer or a refusal, in both state layouts."""
+    import random
+    from tests import fuzz
+    from madsim_amd import runtime
+    for base, n in ((14400, 200), ((FUZZ_SEED * 1_000_003 + 13 * 7919) & 0x7fffffffffff, 100)):
+        for k in range(n):
+            w, cfg, desc = fuzz.random_unstructured_workload(random.Random(base + k))
+            lim = fuzz.generous_limits(); lim.max_tasks = 16
+            if k % 2:
+                lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL | A.STATE_DEDUP_TIMERS
+            try:
+                got, _ = hip.run_batch(w, k * 3, 24, cfg, lim)
+            except runtime.MadsimHipError:                  # refused by validate()
+                continue
+            want, _ = oracle.run_batch(w, k * 3, 24, cfg, lim)
+            ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+            assert ok.all(), (f"random_unstructured_workload(Random({base + k})) [MADSIM_FUZZ_SEED={FUZZ_SEED}]", desc, got[~ok][0], want[~ok][0])
