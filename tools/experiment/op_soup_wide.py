@@ -1,6 +1,6 @@
 # Throw-away script behind DESIGN.md section 2 ("a wider soup"): random ops incl. address kinds, IP-less nodes, typed RPC, hooks, IPVS calls and panics on
 # restarting nodes, host-compiled kernel vs oracle in both layouts.  Usage: PYTHONPATH=. python tools/experiment/op_soup_wide.py <programs> <base seed>
-# Known open difference: program 1507471 of `... 8000 1500000`.
+# Known open difference: program 1507471 of `... 8000 1500000` — a socket left bound by a restarted node's dead task, a receive registered on it by another task.
 import random, sys, collections
 import numpy as np
 import oracle
