@@ -565,3 +565,33 @@ def test_t0_must_be_marked_before_it_is_read_and_cclose_alone_lays_out_the_conne
     assert emu.geometry_params(w)["features"] & 2                                      # MADSIM_FEAT_CHAN: the connection unit exists
     o = _same(w, 0, 8)
     assert (o["verdict"] == A.PASS).all()
+
+
+def test_fuzz_unstructured_workloads_under_varied_configs_and_limits():
+    """The op soup again with what a run can be given besides the program: buggify, second-scale and nanosecond latency ranges,
+    heavy loss; sub-wave lane strides, the global-state layout with the timer switch, a two-entry LDS heap (everything else in
+    the spill region), time limits, step caps, no log fingerprint — verdicts TIME_LIMIT and STEP_LIMIT included."""
+    seen = set()
+    for k in range(600):
+        w, _, desc = fuzz.random_unstructured_workload(random.Random(98000 + k))
+        lr = random.Random(k * 7 + 1)
+        lo, hi = lr.choice([(1_000_000, 10_000_000), (1, 2), (0, 10_000_000), (900_000_000, 2_100_000_000), (5_000_000, 5_000_001)])
+        cfg = A.Config.default(packet_loss_rate=lr.choice([0.0, 0.05, 0.5]), lat_lo_ns=lo, lat_hi_ns=hi, buggify=lr.random() < 0.3,
+                               loss_table=(0.0, 0.5, 1.0))
+        lim = fuzz.generous_limits(); lim.max_tasks = 16
+        mode = lr.randrange(6)
+        if mode == 0: lim.lanes_per_wave = lr.choice([8, 16, 32])
+        elif mode == 1: lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL | A.STATE_DEDUP_TIMERS
+        elif mode == 2: lim.heap_lds_slots, lim.heap_spill_slots = 2, 62
+        elif mode == 3: lim.time_limit_ns = lr.choice([1, 1_000_000, 5_000_000, 2_000_000_000])
+        elif mode == 4: lim.max_steps = lr.choice([1, 7, 40, 200])
+        else: lim.no_trace_hash = 1; lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
+        try:
+            e = emu.run_batch(w, k * 3, 6, cfg, lim)
+        except RuntimeError:                               # refused by validate()
+            continue
+        o, _ = oracle.run_batch(w, k * 3, 6, cfg, lim)
+        ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+        assert ok.all(), (k, mode, desc, o[~ok][0], e[~ok][0])
+        seen |= set(o["verdict"].tolist())
+    assert {A.PASS, A.PANIC, A.DEADLOCK, A.TIME_LIMIT, A.STEP_LIMIT} <= seen
