@@ -130,6 +130,32 @@ async fn timer_ties(obs: Obs) -> Tail {
     fingerprint_tail(t0, &obs)
 }
 
+/// Deadlines equal to the nanosecond: five pairs of tasks looping `sleep(1 ms + 75 ns)` / `sleep(1 ms)` — polled back to back with a
+/// poll cost of exactly 75 ns in between (task/mod.rs:319-321: 50..100 ns) the two timers tie, and the BinaryHeap's array order decides
+/// who wakes first (about every seventh seed).  `timer_ties` above only gets deadlines 50..100 ns apart.
+async fn ns_ties(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let mut tasks = vec![];
+    for p in 0..5u64 {
+        let o = obs.clone();
+        tasks.push(madsim::task::spawn(async move {
+            for _ in 0..40 {
+                time::sleep(Duration::from_nanos(1_000_075)).await;
+                o.push(0x100 + 2 * p);
+            }
+        }));
+        let o = obs.clone();
+        tasks.push(madsim::task::spawn(async move {
+            for _ in 0..40 {
+                time::sleep(Duration::from_millis(1)).await;
+                o.push(0x101 + 2 * p);
+            }
+        }));
+    }
+    for t in tasks { t.await.unwrap(); }
+    fingerprint_tail(t0, &obs)
+}
+
 /// task/mod.rs:859-897 `kill`.
 async fn lifecycle_kill(obs: Obs) -> Tail {
     let t0 = Instant::now();
@@ -760,6 +786,7 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
                 "ipvs_round_robin" => ipvs_round_robin(o).await,
                 "ipvs_runtime" => ipvs_runtime(o).await,
                 "pingpong4_dsl" => pingpong4_dsl(o).await,
+                "ns_ties" => ns_ties(o).await,
                 other => panic!("unknown workload {other}"),
             }
         });
@@ -785,7 +812,7 @@ const ALL: &[&str] = &["pingpong2", "pingpong4", "pingpong16", "sleep_1s", "yiel
                        "restart_on_panic", "receiver_drop", "localhost", "restart_on_panic_matching", "bind_ephemeral",
                        "channel_wildcard", "guard_keeps_address", "spawn_in_drop_abort", "spawn_in_drop_kill",
                        "spawn_after_own_restart", "join_names_its_task", "abort_own_handle", "rpc_hooks", "panic_substrings",
-                       "rebind_in_flight", "ipvs_round_robin", "ipvs_runtime", "pingpong4_dsl"];
+                       "rebind_in_flight", "ipvs_round_robin", "ipvs_runtime", "pingpong4_dsl", "ns_ties"];
 
 fn main() {
     let args: Vec<String> = std::env::args().collect();

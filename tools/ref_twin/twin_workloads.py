@@ -463,6 +463,26 @@ def limits(name):
     return None
 
 
+def ns_ties():
+    """Timers that REALLY tie: five pairs of tasks looping `sleep(1 ms + 75 ns)` / `sleep(1 ms)`.  Whenever the two of a pair are
+    polled back to back and the 50..100 ns poll cost in between (task/mod.rs:319-321) comes out at 75, their deadlines coincide to
+    the nanosecond, and which fires first is the BinaryHeap's array order (naive-timer) — about every seventh seed has
+    such a tie.  (`timer_ties` sleeps 10 ms in six tasks whose polls are 50..100 ns apart: close deadlines, no equal ones.)"""
+    wl = W.WorkloadBuilder()
+    ts = []
+    for p in range(5):
+        a = wl.task(0); a.set(0, 40); top = a.label(); a.sleep(ms=1, ns=75); a.trace(0x100 + 2 * p); a.djnz(0, top); a.done()
+        b = wl.task(0); b.set(0, 40); top = b.label(); b.sleep(ms=1); b.trace(0x101 + 2 * p); b.djnz(0, top); b.done()
+        ts += [a, b]
+    m = wl.main()
+    for t in ts:
+        m.spawn(t)
+    for t in ts:
+        m.join(t)
+    fingerprint_tail(m)
+    return wl.build()
+
+
 # workloads that end in a panic by design (the reference test is #[should_panic])
 EXPECT_PANIC = {"restart_on_panic_matching", "panic_substrings"}
 
@@ -479,4 +499,5 @@ ALL = {
     "rpc_hooks": rpc_hooks, "panic_substrings": panic_substrings, "rebind_in_flight": rebind_in_flight,
     "ipvs_round_robin": ipvs_round_robin, "ipvs_runtime": ipvs_runtime,
     "pingpong4_dsl": lambda: pingpong(4, 64),          # the same table, built by madsim_hip::pingpong_twin and run by madsim_hip::interp
+    "ns_ties": ns_ties,                                # deadlines equal to the nanosecond: the heap's tie order for real
 }
