@@ -215,6 +215,8 @@ pub const MADSIM_DEADLOCK: u32 = 2;
 pub const MADSIM_TIME_LIMIT: u32 = 3;
 pub const MADSIM_OVERFLOW: u32 = 4;
 pub const MADSIM_STEP_LIMIT: u32 = 5;
+pub const MADSIM_UNSUPPORTED: u32 = 6;
+pub const MADSIM_INTERNAL: u32 = 7;
 
 // ---- #define constants -------------------------------------------------------------------------------------------
 pub const MADSIM_HIP_ABI_VERSION: u32 = 3;

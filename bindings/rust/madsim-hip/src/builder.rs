@@ -100,6 +100,8 @@ pub fn verdict_message(verdict: u32) -> &'static str {
         sys::MADSIM_TIME_LIMIT => "time limit exceeded",
         sys::MADSIM_OVERFLOW => "device capacity exceeded (runner limit, not a test verdict)",
         sys::MADSIM_STEP_LIMIT => "step cap reached (runner limit, not a test verdict)",
+        sys::MADSIM_UNSUPPORTED => "the seed left the workload model (runner verdict, not a test verdict)",
+        sys::MADSIM_INTERNAL => "internal invariant of the device code broke (runner verdict, not a test verdict)",
         _ => "pass",
     }
 }
@@ -223,7 +225,7 @@ impl Builder {
             // Runtime::check_determinism (runtime/mod.rs:178-202): run the seed twice, compare the RNG log; no time limit there
             let lim = self.raw_limits(false);
             let (l1, r1) = self.trace(&w, &cfg, &lim)?;
-            if r1.verdict == sys::MADSIM_OVERFLOW || r1.verdict == sys::MADSIM_STEP_LIMIT {
+            if r1.verdict >= sys::MADSIM_OVERFLOW {
                 return Err(RunError { code: sys::MADSIM_E_LIMITS, message: format!("seed {}: {}", self.seed, verdict_message(r1.verdict)) });
             }
             let (l2, r2) = self.trace(&w, &cfg, &lim)?;
@@ -251,7 +253,7 @@ impl Builder {
             return Err(last_error(rc));
         }
         if summary.n_failed > 0 {
-            let runner = |v: u32| v == sys::MADSIM_OVERFLOW || v == sys::MADSIM_STEP_LIMIT;
+            let runner = |v: u32| v >= sys::MADSIM_OVERFLOW;
             // a genuine test failure wins over unresolved runner limits: its seed and repro note are never hidden
             if let Some(i) = out.iter().position(|r| r.verdict != sys::MADSIM_PASS && !runner(r.verdict)) {
                 note_seed(self.seed + i as u64);

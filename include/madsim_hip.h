@@ -350,8 +350,16 @@ enum madsim_verdict {
     MADSIM_TIME_LIMIT = 3,  /* "time limit exceeded" (task/mod.rs:253-258)                           */
     MADSIM_OVERFLOW = 4,    /* a device capacity in madsim_limits_t was exceeded: re-run the seed with
                                larger limits (not a reference verdict; never silently wrong)         */
-    MADSIM_STEP_LIMIT = 5   /* max_steps reached (not a reference verdict)                           */
+    MADSIM_STEP_LIMIT = 5,  /* max_steps reached (not a reference verdict)                           */
+    MADSIM_UNSUPPORTED = 6, /* the seed left the workload MODEL (not a reference verdict, and larger limits do not help:
+                               never re-run): a port-0 table entry bound again while the Endpoint of its previous bind is
+                               alive — an entry names one Endpoint at a time, `close` it first.  The oracle reports the
+                               same verdict for the same seed; every other result field is 0                            */
+    MADSIM_INTERNAL = 7     /* an invariant of the device code broke (a bug in this library, never a property of the
+                               workload): the parity tests assert that no seed ever carries it; other fields 0        */
 };
+/* verdicts >= MADSIM_OVERFLOW are RUNNER verdicts: statements about this runner, never a test's failure */
+#define MADSIM_IS_RUNNER_VERDICT(v) ((v) >= MADSIM_OVERFLOW)
 
 /* 48 bytes per seed.  Everything here is compared bit-for-bit against the oracle. */
 typedef struct madsim_result {

@@ -45,8 +45,8 @@ struct SimulationFailure : std::runtime_error {
         : std::runtime_error("seed " + std::to_string(s) + ": " + verdict_name(r.verdict)), seed(s), result(r) {}
     static const char* verdict_name(uint32_t v) {
         static const char* n[] = {"pass", "panic", "no events, all tasks will block forever", "time limit exceeded",
-                                  "device capacity overflow", "step limit"};
-        return v < 6 ? n[v] : "?";
+                                  "device capacity overflow", "step limit", "outside the workload model", "internal invariant"};
+        return v < 8 ? n[v] : "?";
     }
 };
 
@@ -485,14 +485,14 @@ struct Builder {
         madsim_summary_t s{};
         madsim::check(madsim_hip_run_batch_auto(&w, &cfg, seed, count, &lim, out.data(), &s, 6));   // runner verdicts are re-run
         if (s.n_failed) {
-            auto runner = [](uint32_t v) { return v == MADSIM_OVERFLOW || v == MADSIM_STEP_LIMIT; };
+            auto runner = [](uint32_t v) { return MADSIM_IS_RUNNER_VERDICT(v); };
             // a genuine test failure wins over unresolved runner limits: the first failing seed and its note are never hidden
             for (uint64_t i = 0; i < count; i++)
                 if (out[i].verdict != MADSIM_PASS && !runner(out[i].verdict)) { panic_with_info(seed + i); throw SimulationFailure(seed + i, out[i]); }
             uint64_t i = 0;
             while (!runner(out[i].verdict)) i++;
             // a capacity / step-cap verdict that survived the re-runs is the runner's limit, not the test's failure
-            throw Error(MADSIM_E_LIMITS, "seed " + std::to_string(seed + i) + ": runner limit persists after re-runs with larger limits");
+            throw Error(MADSIM_E_LIMITS, "seed " + std::to_string(seed + i) + ": " + SimulationFailure::verdict_name(out[i].verdict) + " (a runner verdict, not a test failure) persists after re-runs with larger limits");
         }
         return out;
     }

@@ -135,8 +135,13 @@ assert C.sizeof(Result) == 48 and C.sizeof(Summary) == 48 and C.sizeof(Limits) =
 RESULT_DTYPE = [("verdict", "<u4"), ("steps", "<u4"), ("clock_ns", "<u8"), ("msg_count", "<u8"),
                 ("rng_calls", "<u8"), ("trace_hash", "<u8"), ("obs_hash", "<u8")]
 
-PASS, PANIC, DEADLOCK, TIME_LIMIT, OVERFLOW, STEP_LIMIT = range(6)
-VERDICT_NAMES = ["pass", "panic", "deadlock", "time-limit", "resource-overflow", "step-limit"]
+PASS, PANIC, DEADLOCK, TIME_LIMIT, OVERFLOW, STEP_LIMIT, UNSUPPORTED, INTERNAL = range(8)
+VERDICT_NAMES = ["pass", "panic", "deadlock", "time-limit", "resource-overflow", "step-limit", "outside-the-workload-model", "internal-invariant"]
+
+
+def is_runner_verdict(v):
+    """MADSIM_IS_RUNNER_VERDICT: a statement about this runner (capacity, step cap, model frontier, internal), never a test failure."""
+    return v >= OVERFLOW
 
 # enum madsim_op
 OP = dict(

@@ -116,7 +116,7 @@ __device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_
 template <class K>
 __device__ __forceinline__ void guard_acquire(const Ctx& c, Lane& L, uint32_t s) {
     const uint32_t h = SW(c, s, 0);
-    if ((h >> 25) == 0x7fu) { L.ovf = 1; return; }            // (a seven-bit count: 127 connection ends per socket)
+    if ((h >> 25) == 0x7fu) { L.ovf |= OVF_CAP; return; }            // (a seven-bit count: 127 connection ends per socket)
     SW(c, s, 0) = h + (1u << 25);
 }
 template <class K>

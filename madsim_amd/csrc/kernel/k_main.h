@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEA
                     rng_log<K>(c, L);
                     uint64_t delay = NS_PER_S + __umul64hi(v, range);
                     node_kill<K>(c, L, node);                 // self.kill(node_id)
-                    if (!timer_add<K>(c, L, L.clock + delay, (EV_RESTART << EV_SHIFT) | node, 0)) L.ovf = 1;
+                    if (!timer_add<K>(c, L, L.clock + delay, (EV_RESTART << EV_SHIFT) | node, 0)) L.ovf |= OVF_CAP;
                     panicked = false;
                 }
             }
@@ -227,12 +227,13 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEA
         // MADSIM_STATE_DEDUP_TIMERS: two different events tied on a deadline — this seed once more from the start, every timer a
         // heap entry (k_timer.h dedup_note); nothing of the abandoned attempt is reported
         if (K::DEDUP && L.hazard) { L.exact = 1; have = false; continue; }
-        if (L.ovf) L.verdict = MADSIM_OVERFLOW;
+        if (L.ovf) L.verdict = (L.ovf & OVF_CAP) ? MADSIM_OVERFLOW : (L.ovf & OVF_BUG) ? MADSIM_INTERNAL : MADSIM_UNSUPPORTED;
         if (L.verdict != MADSIM_RUNNING) {
             REG(25);
             madsim_result_t r;
             r.verdict = L.verdict; r.steps = L.steps; r.clock_ns = L.clock; r.msg_count = L.msg_count;
             r.rng_calls = L.rng_calls; r.trace_hash = (K::NOLOG || (K::LOGSW && P.no_log)) ? 0 : L.trace_hash; r.obs_hash = L.obs_hash;
+            if (r.verdict >= MADSIM_UNSUPPORTED) { r.steps = 0; r.clock_ns = 0; r.msg_count = 0; r.rng_calls = 0; r.trace_hash = 0; r.obs_hash = 0; }   // the verdict is the whole answer
             P.out[next] = r;
             if (K::TRACE) *P.trace_len = L.log_len;
             have = false;

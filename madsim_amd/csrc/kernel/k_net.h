@@ -110,7 +110,11 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     }
     const uint32_t h = pf ? pf->hdr : (uint32_t)SW(c, s, 0);
     bool live = (h & 1) && ((h >> 1) & 0xff) == sgen;      // else: that Endpoint object is gone
-    if (K::FC && c.P.uses_chan && live && SW(c, s, 1) == ~0u) live = false;     // ... only its connections still hold the address
+    // The Endpoint object is gone (its address is still held: by connections made from it, or because its node was killed before the
+    // BindGuard dropped — `if self.node.is_killed() { return }`, net/mod.rs:483-493 — and TaskHandle::restart resets no sockets): the
+    // EndpointSocket stays in the table and its mailbox still takes a message for a receive that some OTHER holder of the Endpoint
+    // registered; with nobody left to register one, a message is dropped instead of queued for ever.
+    const bool orphan = K::LIFE && live && SW(c, s, 1) == ~0u;
     if (live) {
         uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
         // Typed RPC (net/rpc.rs): a response (tag 0xff) is addressed to one pending receive — the word of its registration,
@@ -150,8 +154,10 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
         }
         if (taken) {
             SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);
+        } else if (orphan) {
+            SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);      // (dead registrations swept on the way stay swept)
         } else if (nmsg >= c.P.mbox_msgs) {
-            L.ovf = 1;
+            L.ovf |= OVF_CAP;
         } else {
             if (rsp) tag = 0xfe;                           // nobody holds that rsp_tag any more: it can never be received
             SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);
@@ -167,6 +173,12 @@ template <class K> __device__ __forceinline__ void node_restart(const Ctx& c, La
 // Timer::expire [DEP A.5]: fire every entry with deadline <= now
 template <class K>
 __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now) {
+#ifdef MADSIM_EMU
+    // Global-state builds queue a round's Timer::add calls in the lane (k_timer.h timer_schedule): whoever reads the heap — top_dl, a
+    // pop — must come after timer_flush.  Checked in the host-compiled kernel on every call (the emulation suite asserts that no
+    // seed ends MADSIM_INTERNAL); a new op that fires timers inside a round without flushing first shows up there.
+    if (K::G && L.pq_n) L.ovf |= OVF_BUG;
+#endif
     while (L.top_dl <= now) {
         // Global-state builds: the callback's first loads (the woken task's flag word; the destination socket's header and
         // first registration) depend only on the ROOT entry, which sits in LDS — issue them before the pop, whose sift-down

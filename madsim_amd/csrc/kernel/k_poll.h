@@ -41,14 +41,23 @@ __device__ __forceinline__ bool may_have_twin(uint32_t flags, uint32_t gen) { re
 // Instruction fetch.  Workloads with ephemeral Endpoints (full-address builds only): an Endpoint operand naming a handle
 // is replaced by the candidate entry the handle's last bind took (k_state.h sock_resolve) — except MS_OP_BIND's own.
 // (Destination operands never name a handle: validate().)
+// The fetch is also where a handle that no longer names its socket is caught (k_state.h handle_names_its_socket): every fetch is
+// followed by the instruction's execution — or its next poll — in the same task poll with no socket state changing in between
+// (the callers fetch after the previous op's effects and never while the task is panicking), which is exactly when the oracle
+// enters the op's case.  `drop(ep)` of such a name is a no-op, as in the oracle: the fetch hands back `jmp pc + 1`.
 template <class K>
-__device__ __forceinline__ uint4 insn_fetch(const Ctx& c, uint32_t pc) {
+__device__ __forceinline__ uint4 insn_fetch(const Ctx& c, Lane& L, uint32_t pc) {
     uint4 in = INSN(c, pc);
     if (!PLAIN_ADDR && c.P.uses_eph) {
         const uint32_t op = in.x & 0xff;
         const bool own = op == MS_OP_SEND || op == MS_OP_CONNECT || op == MS_OP_RPC_CALL || op == MS_OP_REPLY || op == MS_OP_RECV ||
                          op == MS_OP_RECV_TIMEOUT || op == MS_OP_CLOSE || op == MS_OP_ACCEPT || op == MS_OP_RPC_REPLY;   // a names an Endpoint
-        if (own) in.x = (in.x & ~0xff00u) | (sock_resolve<K>(c, (in.x >> 8) & 0xff) << 8);
+        const uint32_t s = (in.x >> 8) & 0xff;
+        if (own && (SOCKW(c, s) & 0x8000u)) {
+            if (handle_names_its_socket<K>(c, s)) in.x = (in.x & ~0xff00u) | (sock_resolve<K>(c, s) << 8);
+            else if (op == MS_OP_CLOSE) in = make_uint4(MS_OP_JMP | ((pc + 1) << 16), 0, 0, 0);
+            else { L.ovf |= OVF_MODEL; in.x = (in.x & ~0xff00u) | (sock_resolve<K>(c, s) << 8); }
+        }
     }
     return in;
 }
@@ -118,7 +127,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     // the call future on every poll and registers ANOTHER timer each time (select_biased!, time/sleep.rs:51-53).
     // Returns true when the op completed (Ok, Err(TimedOut)) or the task panicked (st).
     auto rpc_call_poll = [&]() -> bool {
-        const uint4 ci = insn_fetch<K>(c, pc);
+        const uint4 ci = insn_fetch<K>(c, L, pc);
         const uint32_t ca = (ci.x >> 8) & 0xff, cb = ci.x >> 16, cimm = ci.y;
         const uint32_t dst = cb & 0xff;
         if (sub == 1) {
@@ -151,8 +160,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.x &= ~TF_INBOX;
                 uint32_t h = SW(c, ca, 0);
                 uint32_t nreg = (h >> 9) & 0xff;
-                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) L.ovf = 1;   // 8-bit rxseq wrapped onto a dead twin
-                if (nreg >= P.mbox_regs) L.ovf = 1;
+                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) L.ovf |= OVF_CAP;   // 8-bit rxseq wrapped onto a dead twin
+                if (nreg >= P.mbox_regs) L.ovf |= OVF_CAP;
                 else {
                     SW(c, ca, 2 + nreg) = reg;
                     SW(c, ca, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
@@ -224,7 +233,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         timer_flush<K>(c, L, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot);
         if (st != ST_RUN) break;
         // (pc < n_insns always: validate() checks jump targets and that the table ends in DONE / JMP / PANIC)
-        uint4 in = insn_fetch<K>(c, pc);
+        uint4 in = insn_fetch<K>(c, L, pc);
         uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
 
         PROBE(5);
@@ -291,7 +300,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         while (id < P.max_conns && (CONNW(id, 0) & 1)) id++;
                         uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
                         uint64_t q = acceptq_load<K>(c, (uint32_t)ds);
-                        if (id >= P.max_conns || ((uint32_t)q & 0xf) >= MADSIM_ACCEPTQ) { L.ovf = 1; }
+                        if (id >= P.max_conns || ((uint32_t)q & 0xf) >= MADSIM_ACCEPTQ) { L.ovf |= OVF_CAP; }
                         else {
                             CONNW(id, 0) = 1u | (a << 1) | (dial << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
@@ -319,10 +328,15 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         // first free candidate entry of the handle; none left means the caller kept more Endpoints of this
                         // handle alive than the table has entries for (a capacity verdict, not an error of the workload)
                         const uint32_t base = (sw >> 16) & 0xff, nk = sw >> 24;
+                        // An entry names ONE Endpoint at a time.  Bound again while the Endpoint of its previous bind is alive (in
+                        // Rust: a second `Endpoint::bind("0.0.0.0:0")` beside the first) the two would have to coexist under one
+                        // name: outside the model — the verdict says so, the oracle says the same (include/madsim_hip.h).  The
+                        // handle word keeps {candidate, valid, the candidate's socket gen after that bind} to know.
+                        if (handle_names_its_socket<K>(c, a) && SW(c, base + ((uint32_t)SW(c, a, 0) >> 25), 1) != ~0u) L.ovf |= OVF_MODEL;
                         uint32_t p = 0;
                         while (p < nk && find_exact<K>(c, node, (sw & 0x7fffu) | ((p + 1) << 16)) >= 0) p++;
-                        if (p == nk) { L.ovf = 1; p = 0; }
-                        SW(c, a, 0) = p << 25;
+                        if (p == nk) { if (!(L.ovf & OVF_MODEL)) L.ovf |= OVF_CAP; p = 0; }    // (beside its own live Endpoint the handle has no candidate left by construction)
+                        SW(c, a, 0) = (p << 25) | (1u << 24) | (((((uint32_t)SW(c, base + p, 0) >> 1) + 1) & 0xff) << 16);
                         a = base + p;
                     }
                     else if ((PLAIN_ADDR ? find_bound<K>(c, a) : find_exact<K>(c, node, sw)) >= 0) bind_err = MADSIM_VAL_ADDR_IN_USE;
@@ -384,7 +398,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     } else if (pf & 8) {
                         pc = pf >> 18;
                     }
-                    in = insn_fetch<K>(c, pc);
+                    in = insn_fetch<K>(c, L, pc);
                     op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
                 }
             }
@@ -416,7 +430,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 pc++;
             }
 
-            in = insn_fetch<K>(c, pc);
+            in = insn_fetch<K>(c, L, pc);
             op = in.x & 0xff; a = (in.x >> 8) & 0xff; b = in.x >> 16; imm = in.y;
         }
         if (st != ST_RUN) { if (K::G) continue; else break; }      // (global-state builds leave through the flush at the head)
@@ -449,12 +463,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     sub = 2;                               // oneshot already holds the value
                     SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
                 } else {
-                    if (nreg >= P.mbox_regs) L.ovf = 1;            // (a capacity verdict: the state no longer matters)
+                    if (nreg >= P.mbox_regs) L.ovf |= OVF_CAP;            // (a capacity verdict: the state no longer matters)
                     else {
                         const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
                         // dead registrations (timed-out / dropped receives, extended ops only) stay in the Vec like the
                         // reference's; an 8-bit rxseq that wraps onto one of them would make it look live: overflow, never a different answer
-                        if ((K::FT || K::FN) && may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;
+                        if ((K::FT || K::FN) && may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf |= OVF_CAP;
                         SW(c, a, 2 + nreg) = reg;
                         SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
                         sub = 1;
@@ -490,10 +504,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.x |= TF_INBOX;
                 SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
             } else if (nreg >= P.mbox_regs) {
-                L.ovf = 1;
+                L.ovf |= OVF_CAP;
             } else {
                 const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
-                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf = 1;   // rxseq wrapped onto a dead twin
+                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf |= OVF_CAP;   // rxseq wrapped onto a dead twin
                 SW(c, a, 2 + nreg) = reg;
                 SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
             }
@@ -617,7 +631,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 else if (a == MADSIM_IPVS_DEL_SERVICE) d1 &= ~(1u << 24);                    // remove
                 else if (!((d1 >> 24) & 1u)) ok = false;                                     // .expect("service not found")
                 else if (a == MADSIM_IPVS_ADD_SERVER) {                                      // servers.push
-                    if (n >= 6) L.ovf = 1;
+                    if (n >= 6) L.ovf |= OVF_CAP;
                     else {
                         if (n < 4) d0 |= (imm & 0xff) << (8 * n); else d1 |= (imm & 0xff) << (8 * (n - 4));
                         d1 += 1u << 16;
@@ -654,7 +668,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     uint32_t code = imm & 0xff;
                     if (a & 1) {       // panic!("{}", flag + imm): the message is the decimal text of the value, and the nodes' rows were
                         code = (uint32_t)GREGW(b & 3) + imm;     // evaluated for values up to panic_dyn_max only
-                        if (code > P.panic_dyn_max) { L.ovf = 1; code = MADSIM_PANIC_CODE_OTHER; }
+                        if (code > P.panic_dyn_max) { L.ovf |= OVF_CAP; code = MADSIM_PANIC_CODE_OTHER; }
                     }
                     L.panic_code = code;
                 }
@@ -716,7 +730,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (arrive == CHAN_LINK_PANIC) { st = ST_PANIC; break; }
                 if (!(cw & (1u << (14 + 2 * side)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // ConnectionReset
                 uint32_t qn = (cw >> (17 + 4 * side)) & 0xf;
-                if (qn >= P.chan_queue) { L.ovf = 1; pc++; break; }
+                if (qn >= P.chan_queue) { L.ovf |= OVF_CAP; pc++; break; }
                 uint32_t e = 3 + (side * P.chan_queue + qn) * 3;
                 CONNW(id, e) = imm; CONNW(id, e + 1) = (uint32_t)arrive; CONNW(id, e + 2) = (uint32_t)(arrive >> 32);
                 CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * side))) | ((qn + 1) << (17 + 4 * side));

@@ -79,6 +79,10 @@ template <bool TRACE_, bool SPILL_, int LWS_, int FEAT_, bool RQ_ = false, bool 
 #define REG(id) do { } while (0)
 #endif
 
+// Lane::ovf: OVF_CAP = a device capacity was exceeded (MADSIM_OVERFLOW: run again with larger limits); OVF_MODEL = the seed
+// did what the workload model cannot say (MADSIM_UNSUPPORTED; the oracle reports the same); OVF_BUG = an invariant of this code
+// broke (MADSIM_INTERNAL: the parity tests assert it never shows).  A capacity verdict wins: the re-run decides the rest.
+enum : uint32_t { OVF_CAP = 1, OVF_MODEL = 2, OVF_BUG = 4 };
 struct Lane {
     // GlobalRng
     uint64_t s0, s1, s2, s3;
@@ -103,7 +107,7 @@ struct Lane {
 #endif
     uint32_t main_done;  // handle[0] left H_RUNNING: block_on's task.is_finished()
     uint32_t panic_code; // message code of the panic being unwound (MS_OP_PANIC), MADSIM_PANIC_CODE_OTHER for the rest
-    uint32_t ovf;        // sticky: a device capacity was exceeded this iteration (=> MADSIM_OVERFLOW)
+    uint32_t ovf;        // sticky OVF_* bits: the seed ends with a runner verdict (k_main.h), whatever its state says by then
     // runtime-mutable net config (MS_OP_SET_LOSS)
     uint64_t loss_pint;
     uint32_t loss_always;
@@ -346,6 +350,15 @@ __device__ __forceinline__ uint32_t SOCKW(const Ctx& c, uint32_t s) { return SME
 template <class K> __device__ __forceinline__ uint32_t sock_resolve(const Ctx& c, uint32_t s) {
     const uint32_t w = SOCKW(c, s);
     return (w & 0x8000u) ? ((w >> 16) & 0xff) + (SW(c, s, 0) >> 25) : s;
+}
+// The handle word of entry s (a handle: SOCKW & 0x8000): candidate << 25 | valid << 24 | the candidate's socket gen after the
+// handle's last bind << 16.  Does the handle still NAME that socket — is it in the table (bound) with the same gen?  The candidates
+// of a (node, IP) are shared by its handles, so once the socket is gone the candidate may carry another handle's Endpoint: an
+// op through the stale name would read or write a stranger's mailbox, where the oracle's entry keeps its own dead one.  No Rust
+// program uses an Endpoint it never bound or has dropped, so such an op is MADSIM_UNSUPPORTED on both sides (k_poll.h insn_fetch).
+template <class K> __device__ __forceinline__ bool handle_names_its_socket(const Ctx& c, uint32_t s) {
+    const uint32_t hw = SW(c, s, 0), ch = SW(c, ((SOCKW(c, s) >> 16) & 0xff) + (hw >> 25), 0);
+    return (hw & (1u << 24)) && (ch & 1) && ((ch >> 1) & 0xff) == ((hw >> 16) & 0xff);
 }
 __device__ __forceinline__ uint32_t NODET(const Ctx& c, uint32_t n) { return SMEM[c.nodet0 + n]; }   // the node's flags (MADSIM_NODE_*)
 

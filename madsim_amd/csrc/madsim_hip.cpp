@@ -400,6 +400,9 @@ void grow(madsim_limits_t& L, const madsim_workload_t* w, bool any_ovf, bool any
     auto dbl = [](uint32_t v, uint32_t dflt, uint32_t cap) { uint32_t x = (v == 0 || v == MADSIM_LIMIT_NONE) ? dflt : v; x *= 2; return x > cap ? cap : x; };
     L.lanes_per_wave = 0;
     if (any_ovf) {
+        // the compact base-op layout admits no heap spill and at most eight task slots: a grown re-run must be free to leave
+        // it (an explicit MADSIM_STATE_COMPACT would fail make_geometry with MADSIM_E_LIMITS and take the whole call with it)
+        if ((L.state_mem & 0xffu) == MADSIM_STATE_COMPACT) L.state_mem = (L.state_mem & ~0xffu) | MADSIM_STATE_AUTO;
         L.heap_lds_slots = L.heap_lds_slots ? L.heap_lds_slots : 8;
         L.heap_spill_slots = dbl(L.heap_spill_slots, 32, 1u << 20);
         L.max_tasks = dbl(L.max_tasks, w->n_progs + 8, 254);

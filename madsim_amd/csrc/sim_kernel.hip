@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void summary6_kernel(const madsim_result_t* __
         if (r.x != MADSIM_PASS) {
             const unsigned long long s = seed0 + i;
             nfail++; first = s < first ? s : first;
-            if (r.x == MADSIM_OVERFLOW || r.x == MADSIM_STEP_LIMIT) nrun++; else gfirst = s < gfirst ? s : gfirst;
+            if (MADSIM_IS_RUNNER_VERDICT(r.x)) nrun++; else gfirst = s < gfirst ? s : gfirst;
         }
         steps += r.y; clk += ((unsigned long long)r.w << 32) | r.z;
     }

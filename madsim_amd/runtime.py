@@ -392,7 +392,7 @@ class Builder:
         out, summ = run_batch_auto(workload, self.seed, self.count, self.config, self.limits())
         if summ.n_failed:
             v = out["verdict"]
-            runner = (v == A.OVERFLOW) | (v == A.STEP_LIMIT)          # the runner's limits, not the test's verdict
+            runner = v >= A.OVERFLOW          # the runner's limits, not the test's verdict
             genuine = np.nonzero((v != A.PASS) & ~runner)[0]
             if len(genuine):                                          # a real test failure wins over unresolved runner limits:
                 i = int(genuine[0])                                   # the first failing seed and its repro note are never hidden
@@ -413,11 +413,11 @@ class Builder:
         lim = A.Limits()
         for _ in range(4):                                  # a runner verdict says nothing about determinism: grow the limits
             log1, r1 = trace_seed(workload, self.seed, self.config, lim)
-            if r1.verdict not in (A.OVERFLOW, A.STEP_LIMIT):
+            if r1.verdict not in (A.OVERFLOW, A.STEP_LIMIT):      # (UNSUPPORTED / INTERNAL: larger limits change nothing)
                 break
             lim = grow_limits(lim)
             lim.max_steps = min((lim.max_steps or self.DEFAULT_MAX_STEPS) * 16, 1 << 28)
-        if r1.verdict in (A.OVERFLOW, A.STEP_LIMIT):
+        if A.is_runner_verdict(r1.verdict):
             raise RunnerLimitExceeded(self.seed, r1.verdict, r1)
         log2, r2 = trace_seed(workload, self.seed, self.config, lim)
         if log1 != log2 or r1.astuple() != r2.astuple():

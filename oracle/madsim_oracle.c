@@ -200,6 +200,7 @@ typedef struct {
     uint32_t greg[4];                     /* Arc<AtomicUsize> flags shared by the test's tasks       */
     VEC(conn_t) conns;
     uint32_t panic; int main_slot;
+    int unsupported;                                     /* the seed left the workload model (MADSIM_UNSUPPORTED): stop at once */
     madsim_oracle_stats_t st;
 } sim_t;
 
@@ -424,7 +425,7 @@ static int try_send(sim_t* S, unsigned src_node, addr_t dst, uint64_t* latency, 
 /* Mailbox::deliver (endpoint.rs:331-351) through EndpointSocket::deliver (:311-318). */
 static void mailbox_deliver(sim_t* S, event_t* e) {
     sock_t* k = &S->socks[e->sock];
-    if (!k->bound || !k->ep_alive || k->gen != e->sockgen) return;   /* Endpoint object gone: nobody can read the mailbox */
+    if (!k->bound || k->gen != e->sockgen) return;        /* that EndpointSocket has left the table */
     size_t i = 0;
     while (i < k->registered.n) {
         if (k->registered.p[i].tag == e->tag) {
@@ -441,6 +442,9 @@ static void mailbox_deliver(sim_t* S, event_t* e) {
             i++;
         }
     }
+    if (!k->ep_alive) return;     /* the Endpoint object is gone (the address is held by its connections, or its node was killed before the
+                                     guard dropped: net/mod.rs:483-493): a receive registered by another holder was served above; with
+                                     none, nobody is left to read what would be queued here */
     msg_t m = { e->tag, e->from, e->val, e->aux };
     vec_push(k->msgs, m);
     if (k->msgs.n > S->st.max_msgs) S->st.max_msgs = (uint32_t)k->msgs.n;
@@ -664,6 +668,17 @@ static int poll_task(sim_t* S, uint16_t slot) {
         task_t* t = &S->tasks.p[slot];
         if (t->pc >= w->n_insns) return 1;
         const madsim_insn_t* in = &w->insns[t->pc];
+        switch (in->op) {                                  /* ops whose `a` names an Endpoint, through a port-0 table entry: */
+        case MS_OP_SEND: case MS_OP_CONNECT: case MS_OP_RPC_CALL: case MS_OP_REPLY: case MS_OP_RECV:
+        case MS_OP_RECV_TIMEOUT: case MS_OP_ACCEPT: case MS_OP_RPC_REPLY:
+            /* the entry must still name the socket its last bind put in the table.  No Rust program uses an Endpoint it never
+             * bound or has dropped; the table format can say it, and the device (whose port-0 entries of one (node, IP) share
+             * their candidate sockets, geometry.h) could only answer with a stranger's mailbox: outside the model, on both sides
+             * (`drop(ep)` of such a name stays a no-op: MS_OP_CLOSE below) */
+            if (in->a < w->n_socks && w->socks[in->a].port == 0 && !S->socks[in->a].bound) { S->unsupported = 1; return 1; }
+            break;
+        default: break;
+        }
         switch (in->op) {
         case MS_OP_DONE:
             /* an init task is `async move { future.await; h.exit() }` (runtime/mod.rs:362-370): the body's locals — its
@@ -841,6 +856,9 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 uint16_t port = a->port;
                 if (a->node != t->node) bind_err = MADSIM_VAL_ADDR_NOT_AVAILABLE;
                 else if (port == 0) {                      /* :224-236 "resolve port if unspecified": the first free one */
+                    /* a table entry names ONE Endpoint at a time: bound again while the Endpoint of its previous bind is alive, the
+                     * two would coexist under one name — outside the workload model, and the verdict says so (MADSIM_UNSUPPORTED) */
+                    if (S->socks[in->a].bound && S->socks[in->a].ep_alive) { S->unsupported = 1; return 1; }
                     addr_t cand = { a->kind, a->node, 0 };
                     for (uint32_t p = 1; p <= 65535 && port == 0; p++) { cand.port = (uint16_t)p; if (find_exact(S, t->node, cand) < 0) port = (uint16_t)p; }
                     if (port == 0) bind_err = MADSIM_VAL_ADDR_IN_USE;      /* "no available ephemeral port" */
@@ -1247,7 +1265,7 @@ static void run_all_ready(sim_t* S, uint32_t max_steps) {
                         restart |= (S->w->panic_match[node * 8 + (S->panic_code >> 5)] >> (S->panic_code & 31)) & 1;
                     else for (unsigned k = 0; k < nb->n_match && k < 2; k++) restart |= nb->match[k] == S->panic_code;
                 }
-                if (!restart) {
+                if (!restart || S->unsupported) {
                     S->panic = 1;
                     return;                                /* resume_unwind: block_on unwinds */
                 }
@@ -1312,11 +1330,11 @@ static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
     }
     {   /* reset_node's socket drop order (network.rs:142-147: a HashMap under the seed's SipHash keys) is not restated: workloads
          * where it could be observed — a resettable node with two listening Endpoints — are refused, here as in the library */
-        uint32_t resettable = 0;
-        for (uint32_t i = 0; i < w->n_insns; i++) if (w->insns[i].op == MS_OP_KILL || w->insns[i].op == MS_OP_RESTART) resettable |= 1u << w->insns[i].a;
-        for (uint32_t n = 0; n <= w->n_nodes && w->nodes; n++) if (w->nodes[n].flags & (MADSIM_NODE_RESTART_ON_PANIC | MADSIM_NODE_RESTART_MATCHING)) resettable |= 1u << n;
-        for (uint32_t p = 0; p < w->n_progs; p++) if (w->progs[p].flags & MADSIM_PROG_INIT) resettable |= 1u << w->progs[p].node;
-        for (uint32_t n = 1; n <= w->n_nodes && n < 32; n++) {
+        uint64_t resettable = 0;
+        for (uint32_t i = 0; i < w->n_insns; i++) if (w->insns[i].op == MS_OP_KILL || w->insns[i].op == MS_OP_RESTART) resettable |= 1ull << (w->insns[i].a & 63);
+        for (uint32_t n = 0; n <= w->n_nodes && w->nodes; n++) if (w->nodes[n].flags & (MADSIM_NODE_RESTART_ON_PANIC | MADSIM_NODE_RESTART_MATCHING)) resettable |= 1ull << n;
+        for (uint32_t p = 0; p < w->n_progs; p++) if (w->progs[p].flags & MADSIM_PROG_INIT) resettable |= 1ull << (w->progs[p].node & 63);
+        for (uint32_t n = 1; n <= w->n_nodes && n < 64; n++) {
             uint32_t cnt = 0;
             for (uint32_t i = 0; i < w->n_insns; i++) {
                 if (w->insns[i].op != MS_OP_ACCEPT || w->insns[i].a >= w->n_socks || w->socks[w->insns[i].a].node != n) continue;
@@ -1393,6 +1411,7 @@ static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, cons
     out->verdict = (uint32_t)verdict; out->steps = S.steps; out->clock_ns = S.clock;
     out->msg_count = S.msg_count; out->rng_calls = S.rng_calls; out->trace_hash = S.no_log ? 0 : S.trace_hash;
     out->obs_hash = S.obs_hash;
+    if (S.unsupported) { memset(out, 0, sizeof *out); out->verdict = MADSIM_UNSUPPORTED; }   /* the verdict is the whole answer */
     if (log_len) *log_len = S.log_len;
     if (stats) {
         if (S.st.max_heap > stats->max_heap) stats->max_heap = S.st.max_heap;

@@ -595,3 +595,86 @@ def test_fuzz_unstructured_workloads_under_varied_configs_and_limits():
         assert ok.all(), (k, mode, desc, o[~ok][0], e[~ok][0])
         seen |= set(o["verdict"].tolist())
     assert {A.PASS, A.PANIC, A.DEADLOCK, A.TIME_LIMIT, A.STEP_LIMIT} <= seen
+
+
+def test_fuzz_unstructured_wide_workloads():
+    """The op soup over the whole table format (tests/fuzz.py random_unstructured_wide_workload), both state layouts: the oracle's
+    answer on all 48 bytes, a capacity verdict, or a refusal by validate() — and MADSIM_UNSUPPORTED exactly where the oracle says
+    it (a port-0 entry bound again beside its live Endpoint).  No seed ends MADSIM_INTERNAL."""
+    seen, refused = set(), 0
+    for k in range(500):
+        w, cfg, desc = fuzz.random_unstructured_wide_workload(random.Random(1_500_000 + k))
+        for glob in (0, 1):
+            lim = fuzz.wide_limits(glob)
+            try:
+                e = emu.run_batch(w, k * 3, 6, cfg, lim)
+            except RuntimeError as ex:
+                assert "emu error" in str(ex), ex
+                refused += 1
+                break
+            o, _ = oracle.run_batch(w, k * 3, 6, cfg, lim)
+            ok = (o == e) | (e["verdict"] == A.OVERFLOW)
+            assert ok.all(), (k, glob, desc, o[~ok][0], e[~ok][0])
+            assert not (e["verdict"] == A.INTERNAL).any()
+            seen |= set(o["verdict"].tolist())
+    assert {A.PASS, A.PANIC, A.DEADLOCK, A.UNSUPPORTED} <= seen and refused < 25
+
+
+def test_port0_entry_bound_again_beside_its_live_endpoint_is_unsupported():
+    """An entry names one Endpoint at a time.  `bind; bind` on a port-0 entry = two Endpoints under one name: MADSIM_UNSUPPORTED
+    with every other field 0, from the oracle and the kernel alike; `bind; close; bind` is the reference's `bind` test shape and passes."""
+    for glob in (0, 1):
+        wl = W.WorkloadBuilder(); n = wl.create_node()
+        a = wl.addr(n, 0, ip="unspecified")
+        t = wl.task(n); t.bind(a); t.bind(a); t.done()
+        m = wl.main(); m.spawn(t); m.join(t); m.done()
+        w = wl.build()
+        lim = fuzz.wide_limits(glob)
+        o, _ = oracle.run_batch(w, 0, 8, None, lim)
+        e = emu.run_batch(w, 0, 8, None, lim)
+        assert (o == e).all() and (o["verdict"] == A.UNSUPPORTED).all()
+        assert not o["steps"].any() and not o["clock_ns"].any() and not o["trace_hash"].any() and not o["rng_calls"].any()
+        wl = W.WorkloadBuilder(); n = wl.create_node()
+        a = wl.addr(n, 0, ip="unspecified")
+        t = wl.task(n); t.bind(a); t.close(a); t.bind(a); t.done()
+        m = wl.main(); m.spawn(t); m.join(t); m.done()
+        w = wl.build()
+        o, _ = oracle.run_batch(w, 0, 8, None, lim)
+        e = emu.run_batch(w, 0, 8, None, lim)
+        assert (o == e).all() and (o["verdict"] == A.PASS).all()
+
+
+def test_socket_of_a_restarted_nodes_dead_task_serves_a_receive_another_holder_registered():
+    """TaskHandle::restart resets no sockets and BindGuard::drop returns early on a killed node (net/mod.rs:483-493,
+    task/mod.rs:374-401): the dead task's socket stays in the table.  A datagram for it wakes a receive that a task of ANOTHER node
+    registered on that entry before the restart (an Endpoint clone held across it) and is dropped when nobody did — in kernel
+    builds with and without connection ops alike (round 3: they disagreed with each other)."""
+    outs = []
+    for with_conn in (False, True):
+        wl = W.WorkloadBuilder()
+        n1, n2 = wl.create_node(), wl.create_node()
+        a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+        binder = wl.task(n1); binder.bind(a1); binder.sleep(ms=100); binder.done()
+        holder = wl.task(n2); holder.mark(); holder.sleep(ms=2); holder.recv_from_timeout(a1, 1, ms=50); holder.trace_val(); holder.done()
+        sender = wl.task(n2); sender.bind(a2); sender.sleep(ms=10); sender.send_to(a2, a1, 1, 77); sender.sleep(ms=20)
+        sender.send_to(a2, a1, 1, 78); sender.sleep(ms=20)
+        if with_conn:
+            sender.chan_close()
+        sender.done()
+        sup = wl.task(n2); sup.sleep(ms=5); sup.restart(n1); sup.done()
+        m = wl.main()
+        for t in (binder, holder, sender, sup):
+            m.spawn(t)
+        for t in (holder, sender, sup):
+            m.join(t)
+        m.done()
+        w = wl.build()
+        for glob in (0, 1):
+            lim = fuzz.wide_limits(glob)
+            o, _ = oracle.run_batch(w, 0, 16, None, lim)
+            e = emu.run_batch(w, 0, 16, None, lim)
+            assert (o == e).all(), (with_conn, glob, o[o != e][0], e[o != e][0])
+            outs.append(o)
+    # the connection op changes the kernel build, not the run: same verdicts, clocks and observations
+    for f in ("verdict", "steps", "clock_ns", "msg_count", "rng_calls", "trace_hash", "obs_hash"):
+        assert (outs[0][f] == outs[2][f]).all(), f

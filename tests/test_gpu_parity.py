@@ -974,3 +974,83 @@ def test_fuzz_unstructured_workloads_gpu(hip):
             want, _ = oracle.run_batch(w, k * 3, 24, cfg, lim)
             ok = (got == want) | (got["verdict"] == A.OVERFLOW)
             assert ok.all(), (f"random_unstructured_workload(Random({base + k})) [MADSIM_FUZZ_SEED={FUZZ_SEED}]", desc, got[~ok][0], want[~ok][0])
+
+
+def test_fuzz_unstructured_wide_gpu(hip):
+    """The op soup over the whole table format (tests/fuzz.py random_unstructured_wide_workload: address kinds, port-0 entries,
+    IP-less nodes, typed RPC, hooks, IPVS calls, panics on restarting nodes) on the GPU, both state layouts, a fixed block and a
+    fresh one: the oracle's 48 bytes, a capacity verdict or a refusal; MADSIM_UNSUPPORTED exactly where the oracle says it; never
+    MADSIM_INTERNAL."""
+    import random
+    from tests import fuzz
+    from madsim_amd import runtime
+    n_unsup = 0
+    for base, n in ((1_500_000, 300), ((FUZZ_SEED * 1_000_003 + 17 * 7919) & 0x7fffffffffff, 150)):
+        for k in range(n):
+            w, cfg, desc = fuzz.random_unstructured_wide_workload(random.Random(base + k))
+            lim = fuzz.wide_limits(k % 2)
+            try:
+                got, _ = hip.run_batch(w, k * 3, 24, cfg, lim)
+            except runtime.MadsimHipError:                  # refused by validate()
+                continue
+            want, _ = oracle.run_batch(w, k * 3, 24, cfg, lim)
+            ok = (got == want) | (got["verdict"] == A.OVERFLOW)
+            assert ok.all(), (f"random_unstructured_wide_workload(Random({base + k})) [MADSIM_FUZZ_SEED={FUZZ_SEED}]", desc, got[~ok][0], want[~ok][0])
+            assert not (got["verdict"] == A.INTERNAL).any()
+            n_unsup += int((got["verdict"] == A.UNSUPPORTED).sum())
+    assert n_unsup > 0
+
+
+def test_restarted_nodes_leftover_socket_same_bytes_with_and_without_connection_ops_gpu(hip):
+    """kernel builds with and without connection ops disagreed on a datagram for the socket a restarted node's
+    dead task left in the table (net/mod.rs:483-493, task/mod.rs:374-401).  Same program, once with a stray `drop((tx, rx))` that
+    selects the connection build: identical bytes from both builds, both layouts, and the oracle's."""
+    from tests import fuzz
+    from madsim_amd import workload as W
+    outs = []
+    for with_conn in (False, True):
+        wl = W.WorkloadBuilder()
+        n1, n2 = wl.create_node(), wl.create_node()
+        a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+        binder = wl.task(n1); binder.bind(a1); binder.sleep(ms=100); binder.done()
+        holder = wl.task(n2); holder.mark(); holder.sleep(ms=2); holder.recv_from_timeout(a1, 1, ms=50); holder.trace_val(); holder.done()
+        sender = wl.task(n2); sender.bind(a2); sender.sleep(ms=10); sender.send_to(a2, a1, 1, 77); sender.sleep(ms=20)
+        sender.send_to(a2, a1, 1, 78); sender.sleep(ms=20)
+        if with_conn:
+            sender.chan_close()
+        sender.done()
+        sup = wl.task(n2); sup.sleep(ms=5); sup.restart(n1); sup.done()
+        m = wl.main()
+        for t in (binder, holder, sender, sup):
+            m.spawn(t)
+        for t in (holder, sender, sup):
+            m.join(t)
+        m.done()
+        w = wl.build()
+        for glob in (0, 1):
+            lim = fuzz.wide_limits(glob)
+            want, _ = oracle.run_batch(w, 0, 256, None, lim)
+            got, _ = hip.run_batch(w, 0, 256, None, lim)
+            assert (got == want).all(), (with_conn, glob)
+            outs.append(got)
+    for f in ("verdict", "steps", "clock_ns", "msg_count", "rng_calls", "trace_hash", "obs_hash"):
+        assert (outs[0][f] == outs[2][f]).all() and (outs[1][f] == outs[3][f]).all(), f
+
+
+def test_port0_rebind_is_unsupported_and_never_rerun_gpu(hip):
+    """`bind; bind` on a port-0 entry: MADSIM_UNSUPPORTED from kernel and oracle, every other field 0; run_batch_auto does not
+    re-run it (larger limits change nothing) and counts it as a runner verdict, not a genuine failure."""
+    from tests import fuzz
+    from madsim_amd import workload as W
+    wl = W.WorkloadBuilder(); n = wl.create_node()
+    a = wl.addr(n, 0, ip="unspecified")
+    t = wl.task(n); t.bind(a); t.bind(a); t.done()
+    m = wl.main(); m.spawn(t); m.join(t); m.done()
+    w = wl.build()
+    for glob in (0, 1):
+        lim = fuzz.wide_limits(glob)
+        want, _ = oracle.run_batch(w, 0, 64, None, lim)
+        got, _ = hip.run_batch(w, 0, 64, None, lim)
+        assert (got == want).all() and (got["verdict"] == A.UNSUPPORTED).all() and not got["steps"].any()
+        got2, _ = hip.run_batch_auto(w, 0, 64, None, lim)
+        assert (got2 == want).all()

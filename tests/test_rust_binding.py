@@ -80,10 +80,10 @@ def test_constants_match_header():
     raw = open(H.HEADER_PATH).read()
     rconst = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"pub const (\w+): \w+ = (-?(?:0x[0-9a-fA-F]+|\d+));", SYS)}
     n = 0
-    for m in re.finditer(r"\b(MS_OP_\w+|MADSIM_(?:PASS|PANIC|DEADLOCK|TIME_LIMIT|OVERFLOW|STEP_LIMIT))\s*=\s*(\d+)", H.header_text()):
+    for m in re.finditer(r"\b(MS_OP_\w+|MADSIM_(?:PASS|PANIC|DEADLOCK|TIME_LIMIT|OVERFLOW|STEP_LIMIT|UNSUPPORTED|INTERNAL))\s*=\s*(\d+)", H.header_text()):
         assert rconst[m.group(1)] == int(m.group(2)), m.group(1)
         n += 1
-    assert n >= 57 + 6 - 6 and n == len(re.findall(r"pub const (?:MS_OP_\w+|MADSIM_(?:PASS|PANIC|DEADLOCK|TIME_LIMIT|OVERFLOW|STEP_LIMIT)): ", SYS))
+    assert n >= 57 + 6 - 6 and n == len(re.findall(r"pub const (?:MS_OP_\w+|MADSIM_(?:PASS|PANIC|DEADLOCK|TIME_LIMIT|OVERFLOW|STEP_LIMIT|UNSUPPORTED|INTERNAL)): ", SYS))
     for m in re.finditer(r"#define\s+(MADSIM_\w+)\s+\(?(0x[0-9a-fA-F]+|-?\d+)[uU]?\)?", raw):
         if m.group(1) == "MADSIM_HIP_H":
             continue

@@ -64,7 +64,7 @@ def main():
         w("}")
     w("")
     w("// ---- enum madsim_op / enum madsim_verdict -------------------------------------------------------------------------")
-    for m in re.finditer(r"\b(MS_OP_\w+|MADSIM_(?:PASS|PANIC|DEADLOCK|TIME_LIMIT|OVERFLOW|STEP_LIMIT))\s*=\s*(\d+)", text):
+    for m in re.finditer(r"\b(MS_OP_\w+|MADSIM_(?:PASS|PANIC|DEADLOCK|TIME_LIMIT|OVERFLOW|STEP_LIMIT|UNSUPPORTED|INTERNAL))\s*=\s*(\d+)", text):
         ty = "u8" if m.group(1).startswith("MS_OP_") else "u32"
         w(f"pub const {m.group(1)}: {ty} = {m.group(2)};")
     w("")
