@@ -39,6 +39,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=1000)      # ~1.5 s timed at 1.46 ms per batch (65.5 M seeds)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--seeds", type=int, default=0, help="seeds per GPU per step (default 65 536)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed regions of exactly --steps steps each, back to back, every one bracketed by barrier + synchronize; the "
+                         "line's ms_per_step / value are those of the MEDIAN region, all of them are listed in extra.regions "
+                         "(default: 21 for short regions, fewer for long ones — about 2 000 steps in total, at least 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of sampled seeds after the timed region")
     ap.add_argument("--no-first-fail", action="store_true", help="skip the first-failing-seed measurements (loss variants)")
@@ -230,7 +234,8 @@ def main():
     # Fully asynchronous steps: the simulation kernel, the summary reduction and (N > 1) the RCCL all-gather of the
     # report are all queued on streams; the host never waits inside the timed region.
     use_device_report = world == 1 or backend == "nccl"
-    n_rows = args.steps + args.warmup
+    repeats = args.repeats if args.repeats > 0 else max(3, min(21, 2000 // max(1, args.steps)))
+    n_rows = args.steps * repeats + args.warmup
     ring = torch.zeros((n_rows, REPORT_WORDS), dtype=torch.int64, device=dev)   # one report per step
     ring[:, 4] = rank                      # identity words: the gathered report must hold one row per rank
     ring[:, 5] = gpu
@@ -295,12 +300,30 @@ def main():
             n_streams = int(t[0])
     for k in range(args.warmup):
         step(k, False)
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k, True)
-    sync()
-    dt = time.perf_counter() - t0
+    # `repeats` timed regions of EXACTLY args.steps steps each (a 20-step region is 24 ms: one of them is not a measurement).
+    # Every region is bracketed by barrier + synchronize on both sides; fresh seeds throughout.  The line reports the median region.
+    regions = []
+    for r in range(repeats):
+        base = args.warmup + r * args.steps
+        sync()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(base + k, True)
+        sync()
+        rdt = time.perf_counter() - t0
+        rk_ms = None
+        if use_device_report:                 # (outside the region) this region's launches, start to end, from their HIP events
+            nslots = min(args.steps, 64)
+            rk_ms = sum(runtime.timing_ms((base + args.steps - 1 - i) % 64) for i in range(nslots)) * args.steps / nslots
+        if world > 1:
+            t = torch.tensor([rdt, rk_ms or 0.0], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rdt, rk_ms = float(t[0]), float(t[1])
+        regions.append({"first_row": base, "dt": rdt, "kernel_ms": rk_ms})
+    order = sorted(range(repeats), key=lambda i: regions[i]["dt"])
+    med = regions[order[(repeats - 1) // 2]]        # the median region (the lower one of an even count)
+    dt = med["dt"]
+    row0 = med["first_row"]
     # ---------------- everything below is outside the timed region ----------------
     # for reference beside the overlapped figure: the same step with nothing else in flight (one stream)
     single_ms = None
@@ -315,23 +338,25 @@ def main():
     rccl_ranks = None
     if use_device_report:
         if world > 1:
-            gath = gathered[args.warmup:].cpu()
-            for row in gath:                       # every step's gathered report holds exactly one row per rank
+            gath_all = gathered[args.warmup:].cpu()
+            for row in gath_all:                   # every step's gathered report holds exactly one row per rank
                 launch.check_ranks([(int(r[4]), int(r[5])) for r in row], n_ranks)
-            devs = {int(r[5]) for r in gath[-1]}
+            devs = {int(r[5]) for r in gath_all[-1]}
             rccl_ranks = n_ranks if backend == "nccl" and len(devs) == n_ranks else None
-            rows = mdist.combine_gathered(gath)
+            rows = mdist.combine_gathered(gath_all[row0 - args.warmup: row0 - args.warmup + args.steps])
         else:
-            rows = ring[args.warmup:].cpu()
+            rows = ring[row0: row0 + args.steps].cpu()
         nfail, steps_total, clock_total = (int(x) for x in rows[:, 1:4].sum(dim=0).tolist())
-        nslots = min(args.steps, 64)
-        kernel_ms = sum(runtime.timing_ms((args.warmup + args.steps - 1 - i) % 64) for i in range(nslots)) * args.steps / nslots
-    else:
+        kernel_ms = med["kernel_ms"]
+    else:       # functional-test hook (host-side reports): totals over ALL regions, scaled to one
         nfail, steps_total, clock_total, kernel_ms = host_tot
-    if world > 1:
-        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, kernel_ms = float(t[0]), float(t[1])
+        steps_total //= repeats; clock_total //= repeats; kernel_ms /= repeats; nfail //= repeats
+    ms_list = [r["dt"] / args.steps * 1e3 for r in regions]
+    region_stats = {"n": repeats, "steps_each": args.steps, "ms_per_step_median": med["dt"] / args.steps * 1e3,
+                    "ms_per_step_min": min(ms_list), "ms_per_step_max": max(ms_list), "ms_per_step_first": ms_list[0],
+                    "ms_per_step_all": [round(x, 5) for x in ms_list],
+                    "note": "each region = exactly `steps` steps between barrier + synchronize; the line's ms_per_step / value / "
+                            "kernel_ms_per_step are the median region's"}
 
     # oracle check of the batches that were just timed: the last batch on every stream, sampled k*257 mod count
     verified = 0
@@ -474,6 +499,38 @@ def main():
                     "ms_per_batch": rep.wall_s / nb * 1e3, "seeds_per_sec": rep.seeds_run / rep.wall_s,
                     "executor_steps_per_sec": rep.total_steps / rep.wall_s, "failed_seeds": int(rep.n_failed), "runner_verdicts": int(rep.n_runner)}
 
+    # extra.run_batch_262144: the SURVEY 8b entry point itself — one plain madsim_hip_run_batch call with host buffers for four batches
+    # of seeds (Builder::run hands over all its seeds at once, runtime/builder.rs:121-162).  The library cuts the call into sub-launches
+    # it keeps in flight and overlaps their device-to-host copies (run_pipelined); the figure includes the copy of all 12.6 MB of
+    # per-seed results into pageable host memory.  Sampled seeds are compared with the oracle, the whole array with the summary.
+    run_batch_big = None
+    if not args.no_first_fail and world == 1 and headline and not args.loss:
+        import oracle
+        nbig = 4 * count
+        runtime.run_batch(w, 1 << 48, nbig, cfg, lim)                                   # warm (flights, staging buffers)
+        walls = []
+        for r in range(7):
+            t1 = time.perf_counter()
+            big, bsum = runtime.run_batch(w, (1 << 48) + (r + 1) * nbig, nbig, cfg, lim)
+            walls.append(time.perf_counter() - t1)
+        bbase = (1 << 48) + 7 * nbig
+        bver = 0
+        for jj in range(256):
+            i = (jj * 1031) % nbig
+            want, _ = oracle.run_batch(w, bbase + i, 1, cfg, lim)
+            if big[i] != want[0]:
+                print(f"bench.py: VERIFY FAILED run_batch({nbig}) seed {bbase + i}: gpu {big[i]} != oracle {want[0]}", file=sys.stderr)
+                return 3
+            bver += 1
+        if int(big["steps"].sum()) != bsum.total_steps or int((big["verdict"] != A.PASS).sum()) != bsum.n_failed:
+            print("bench.py: VERIFY FAILED run_batch summary does not match its own per-seed array", file=sys.stderr)
+            return 3
+        walls.sort()
+        run_batch_big = {"entry_point": "madsim_hip_run_batch (host result array, PCIe-inclusive)", "seeds": nbig, "calls": len(walls),
+                         "wall_ms_median": walls[len(walls) // 2] * 1e3, "wall_ms_min": walls[0] * 1e3, "wall_ms_max": walls[-1] * 1e3,
+                         "seeds_per_sec": nbig / walls[len(walls) // 2], "kernel_ms": bsum.kernel_ms, "verified_seeds": bver,
+                         "failed_seeds": int(bsum.n_failed)}
+
     # extra.plain_run: the same step without the per-seed fingerprint of the determinism log (madsim_limits_t.no_trace_hash) — the
     # reference's own Builder::run computes log bytes only under check_determinism (rand.rs:67), so this is the mode a drop-in test
     # run needs; the headline keeps the fingerprint (all 48 result bytes oracle-checked).  Same streams, same batch size, its own
@@ -537,13 +594,18 @@ def main():
     if not args.no_extras and world == 1 and headline and not args.loss:
         import oracle
         extras = {}
+        # a step of these = the per-GPU batch BASELINE.json quotes the config on (configs[2]: 262 144 seeds on one GPU; configs[3]:
+        # 1 048 576 over 8 GPUs; configs[4]: 4 194 304 over 8 GPUs), issued as sub-launches of `count` seeds kept in flight on the streams
+        baseline_batch = {"raft": 262144, "kv": 131072, "topo": 524288, "timers": count}
         for name in ("raft", "kv", "topo", "timers"):
             xw, xlim, xname = workload.bench_case(name)
             xg0 = runtime.geometry(xw, xlim)
             # batches in flight by THIS workload's occupancy (flights(), above): five only where four waves per SIMD fit, four for
             # the global-state builds with a heap-spill region, else three
             xn = min(n_streams, flights(xg0))
-            xs, xwu = 2 * xn, xn          # two timed batches per stream after one untimed: the second launch of a stream starts into a busy chip
+            nsub = max(1, baseline_batch[name] // count)
+            xsteps = max(2, -(-3 * xn // nsub))      # timed steps: at least three sub-launches per stream
+            xs, xwu = xsteps * nsub, xn   # timed sub-launches after one untimed per stream: the timed ones start into a busy chip
             xring = torch.zeros((xs + xwu, REPORT_WORDS), dtype=torch.int64, device=dev)
             last = {}
 
@@ -563,7 +625,7 @@ def main():
             xdt = time.perf_counter() - t1
             rows = xring[xwu:].cpu()
             xfail, xsteps, xclock = (int(x) for x in rows[:, 1:4].sum(dim=0).tolist())
-            xk_ms = sum(runtime.timing_ms((xwu + i) % 64) for i in range(xs)) / xs
+            xk_ms = sum(runtime.timing_ms((xwu + xs - 1 - i) % 64) for i in range(min(xs, 48))) / min(xs, 48)
             xver = 0
             for si, k in sorted(last.items()):
                 got = np.frombuffer(d_outs[si].cpu().numpy().tobytes(), dtype=A.RESULT_DTYPE)
@@ -578,8 +640,9 @@ def main():
                     xver += 1
             xg = runtime.geometry(xw, xlim)
             xalgo = xsteps / xs * ALGO_BYTES_PER_STEP + count * IO_BYTES_PER_SEED
-            extras[name] = {"workload": xname, "seeds_per_step": count, "steps": xs, "warmup": xwu, "concurrent_batches": xn,
-                            "ms_per_step": xdt / xs * 1e3, "kernel_ms_per_step": xk_ms,
+            extras[name] = {"workload": xname, "seeds_per_step": nsub * count, "steps": xsteps, "sub_launches_per_step": nsub,
+                            "seeds_per_sub_launch": count, "warmup_sub_launches": xwu, "concurrent_batches": xn,
+                            "ms_per_step": xdt / xsteps * 1e3, "ms_per_sub_launch": xdt / xs * 1e3, "kernel_ms_per_sub_launch": xk_ms,
                             "steps_per_sec": xsteps / xdt, "seeds_per_sec": xs * count / xdt, "sim_seconds_per_sec": xclock / 1e9 / xdt,
                             "failed_seeds": xfail, "verified_seeds": xver, "kernel": runtime.variant_name(xg),
                             "lds_bytes_per_seed": xg.lds_bytes_per_seed, "global_bytes_per_seed": xg.global_bytes_per_seed,
@@ -630,7 +693,15 @@ def main():
                                "FETCH/WRITE_SIZE).  chip_* = all overlapping launches / wall time; chip_frac > 1 means exactly that: "
                                "HBM is not a bound for this kernel"}
         ceil = issue_ceiling() if world == 1 else None
+        # `bound` keeps round 3's definition (valu-issue against the measured ceiling of the kernel's own instruction mix); the earlier
+        # definitions ride beside it as TOP-LEVEL keys so no round's number is lost to a redefinition: hbm_* = round 1/2's nominal
+        # SURVEY 8d yardstick (algorithmic bytes per launch / that launch's duration / 8 TB/s), peak_hw / frac_hw = the hardware
+        # issue rate of the guide (a wave64 VALU instruction every 2 cycles x 1 024 SIMDs x 2.4 GHz), whatever the mix.
+        PEAK_HW_GINST = 1228.8
         roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G wave-inst/s", "frac": None, "traffic": traffic,
+                "peak_hw": PEAK_HW_GINST, "frac_hw": None, "frac_hw_useful_lanes": None,
+                "hbm_frac": hbm_nominal["frac"], "hbm_chip_frac": hbm_nominal["chip_frac"],
+                "hbm_measured_gbps": hbm_nominal["measured_hbm_gbps"], "hbm_algorithmic_bytes_per_launch": algo_bytes,
                 "traffic_detail": tdetail, "kernel": kname, "concurrent_launches": n_streams, "hbm_nominal": hbm_nominal}
         if pmc and "SQ_INSTS_VALU" in pmc:
             valu = pmc["SQ_INSTS_VALU"]
@@ -657,6 +728,10 @@ def main():
                          "ceiling_detail": ceil})
             if roof["achieved"]:
                 roof["frac"] = roof["achieved"] / roof["peak"]
+        if roof["achieved"]:
+            roof["frac_hw"] = roof["achieved"] / PEAK_HW_GINST
+            if roof.get("lane_util"):
+                roof["frac_hw_useful_lanes"] = roof["frac_hw"] * roof["lane_util"]      # lane-operations that do simulation work
         roof["note"] = ("achieved = VALU wave-instructions per sim_kernel launch (rocprofv3 SQ_INSTS_VALU, live) / wall time per batch "
                         f"({n_streams} launches overlap, so this is the chip-level rate; per_launch_ginst_s divides by one launch's own "
                         "HIP-event duration instead); peak = the chip's sustained issue rate for the executor's VALU mix measured by wall "
@@ -679,7 +754,8 @@ def main():
                       "lds_bytes_per_seed": g.lds_bytes_per_seed, "waves_per_cu": g.blocks_per_cu * g.block_threads // 64,
                       "lanes_per_wave": g.lanes_per_wave, "rccl_ranks": rccl_ranks, "first_fail": first_fail,
                       "first_fail_rare": first_fail_rare, "first_fail_very_rare": first_fail_very_rare,
-                      "workloads": extras, "campaign": campaign, "plain_run": plain,
+                      "workloads": extras, "campaign": campaign, "plain_run": plain, "run_batch_262144": run_batch_big,
+                      "regions": region_stats,
                       "stream_trial_ms_per_step": stream_trial,
                       "first_fail_seeds_per_hour": (first_fail_rare or {}).get("seeds_per_hour") or (first_fail["seeds_per_hour"] if first_fail else None)},
             "roofline": roof,

@@ -85,18 +85,18 @@ struct madsim_hip_ctx {
     // not share the timer-heap spill region or the work-queue counter
     struct Scratch { uint4* spill = nullptr; size_t spill_bytes = 0; unsigned long long* work_ctr = nullptr; uint8_t* gstate = nullptr; size_t gstate_bytes = 0; };
     std::unordered_map<hipStream_t, Scratch> scratch;
-    hipStream_t own_stream = nullptr;         // madsim_hip_run_batch_multi launches here so devices overlap
     // madsim_hip_ctx_run_campaign: batches in flight on the context's own streams
     static constexpr int CAMPAIGN_MAX = 8;
     struct Flight { hipStream_t stream = nullptr; madsim_result_t* d_out = nullptr; size_t cap = 0; unsigned long long* d_acc6 = nullptr;
-                    unsigned long long* h_acc6 = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr; };
+                    unsigned long long* h_acc6 = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr;
+                    madsim_result_t* h_out = nullptr; size_t h_cap = 0; };      // h_out: page-locked staging of run_pipelined
     Flight flights[CAMPAIGN_MAX];
     unsigned long long* d_acc = nullptr;      // 4 x u64 summary accumulators
     madsim_result_t* d_out = nullptr; size_t out_cap = 0;
-    madsim_result_t* h_pinned = nullptr; size_t pinned_cap = 0;   // host staging of madsim_hip_run_batch_multi (page-locked: async D2H)
     uint64_t* d_seeds = nullptr; size_t seeds_cap = 0;        // seed list of a compacted re-run
     uint8_t* d_tlog = nullptr; size_t tlog_cap = 0; uint64_t* d_tlen = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t pipe_begin = nullptr;          // run_pipelined: before the first sub-batch of a call
     hipEvent_t tev[2 * 64] = {};              // timing slots of madsim_hip_run_batch_async
     uint32_t lds_attr = 0;
     uint64_t* d_prof = nullptr;               // debug counters (profiling kernel builds)
@@ -116,7 +116,6 @@ struct madsim_hip_ctx {
     int upload_workload(const madsim_workload_t* w, KParams& P);
     int ensure_scratch(KParams& P, hipStream_t stream, bool work_queue);
     int ensure_out(size_t count);
-    int ensure_pinned(size_t count);
     int launch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count, const uint64_t* d_seed_list,
                const madsim_limits_t* lim, madsim_result_t* d_out, hipStream_t stream);
     int reduce(const madsim_result_t* d_out, uint64_t count, uint64_t seed0, unsigned long long* d_acc4, hipStream_t stream);
@@ -126,6 +125,8 @@ struct madsim_hip_ctx {
                  const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary);
     int run_list(const madsim_workload_t* w, const madsim_config_t* cfg, const std::vector<uint64_t>& seeds,
                  const madsim_limits_t* lim, std::vector<madsim_result_t>& res, double* kernel_ms);
+    int ensure_flights(uint32_t n, uint64_t batch, bool staging);
+    uint32_t flights_for(const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim, uint64_t batch);
 };
 
 int madsim_hip_ctx::open(int dev_index) {
@@ -146,7 +147,7 @@ int madsim_hip_ctx::open(int dev_index) {
     HIP_TRY(hipMemset(d_prof, 0, 16 * sizeof(uint64_t)));
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&pipe_begin));
     return 0;
 }
 
@@ -160,27 +161,27 @@ void madsim_hip_ctx::close() {
     scratch.clear();
     if (d_acc) (void)hipFree(d_acc);
     if (d_out) (void)hipFree(d_out);
-    if (h_pinned) (void)hipHostFree(h_pinned);
     if (d_seeds) (void)hipFree(d_seeds);
     if (d_tlog) (void)hipFree(d_tlog);
     if (d_tlen) (void)hipFree(d_tlen);
     if (d_prof) (void)hipFree(d_prof);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
-    if (own_stream) (void)hipStreamDestroy(own_stream);
+    if (pipe_begin) (void)hipEventDestroy(pipe_begin);
     for (auto& f : flights) {
         if (f.stream) (void)hipStreamDestroy(f.stream);
         if (f.d_out) (void)hipFree(f.d_out);
         if (f.d_acc6) (void)hipFree(f.d_acc6);
         if (f.h_acc6) (void)hipHostFree(f.h_acc6);
+        if (f.h_out) (void)hipHostFree(f.h_out);
         if (f.e0) (void)hipEventDestroy(f.e0);
         if (f.e1) (void)hipEventDestroy(f.e1);
         if (f.done) (void)hipEventDestroy(f.done);
         f = Flight();
     }
     for (auto& e : tev) if (e) (void)hipEventDestroy(e);
-    d_acc = nullptr; d_out = nullptr; h_pinned = nullptr; d_seeds = nullptr; d_tlog = nullptr; d_tlen = nullptr; d_prof = nullptr;
-    ev0 = ev1 = nullptr; own_stream = nullptr; out_cap = pinned_cap = seeds_cap = tlog_cap = 0;
+    d_acc = nullptr; d_out = nullptr; d_seeds = nullptr; d_tlog = nullptr; d_tlen = nullptr; d_prof = nullptr;
+    ev0 = ev1 = nullptr; pipe_begin = nullptr; out_cap = seeds_cap = tlog_cap = 0;
     for (auto& e : tev) e = nullptr;
     device = -1;
 }
@@ -274,16 +275,6 @@ int madsim_hip_ctx::ensure_out(size_t count) {
     return 0;
 }
 
-int madsim_hip_ctx::ensure_pinned(size_t count) {
-    if (count > pinned_cap) {
-        if (h_pinned) (void)hipHostFree(h_pinned);
-        h_pinned = nullptr; pinned_cap = 0;
-        HIP_TRY(hipHostMalloc((void**)&h_pinned, count * sizeof(madsim_result_t), hipHostMallocDefault));
-        pinned_cap = count;
-    }
-    return 0;
-}
-
 // Queue the simulation kernel for `count` units on `stream`: unit i runs seed d_seed_list[i] (device memory) when a list
 // is given, else seed0 + i.  Nothing is synchronised.
 int madsim_hip_ctx::launch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count, const uint64_t* d_seed_list,
@@ -344,10 +335,26 @@ int madsim_hip_ctx::run_device(const madsim_workload_t* w, const madsim_config_t
     return 0;
 }
 
+constexpr uint64_t PIPE_BATCH_HOST = 65536 + 32768;     // up to one and a half batches stay one launch
+int run_pipelined_fwd(madsim_hip_ctx* const* ctxs, int n_ctx, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                      const madsim_limits_t* lim, madsim_result_t* out, unsigned long long* acc6, double* kernel_ms);
 int madsim_hip_ctx::run_host(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
                              const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary) {
     auto t0 = std::chrono::steady_clock::now();
     int rc;
+    if (count > PIPE_BATCH_HOST) {             // more than one batch: sub-launches kept in flight, copies overlapped (run_pipelined)
+        if ((rc = madsim_geo::validate(w, cfg, &g_err))) return rc;
+        if (!out) return fail(MADSIM_E_ARG, "null result buffer");
+        unsigned long long a[6];
+        double ms = 0.0;
+        madsim_hip_ctx* one[1] = {this};
+        if ((rc = run_pipelined_fwd(one, 1, w, cfg, seed0, count, lim, out, a, &ms))) return rc;
+        if (summary) {
+            summary->first_failing_seed = a[0]; summary->n_failed = a[1]; summary->total_steps = a[2]; summary->total_clock_ns = a[3];
+            summary->kernel_ms = ms; summary->wall_s = since(t0);
+        }
+        return 0;
+    }
     if ((rc = ensure_out(count))) return rc;
     madsim_summary_t tmp;
     if ((rc = run_device(w, cfg, seed0, count, lim, d_out, nullptr, &tmp))) return rc;
@@ -379,6 +386,39 @@ int madsim_hip_ctx::run_list(const madsim_workload_t* w, const madsim_config_t* 
     HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
     if (kernel_ms) *kernel_ms += ms;
     return 0;
+}
+
+// Streams, report words, events and result buffers of the first n flights (campaigns and run_pipelined share them; the
+// context's mutex serialises the two).  `staging`: also a page-locked host buffer of `batch` results per flight.
+int madsim_hip_ctx::ensure_flights(uint32_t n, uint64_t batch, bool staging) {
+    if (n > (uint32_t)CAMPAIGN_MAX) return fail(MADSIM_E_ARG, "at most 8 batches in flight");
+    for (uint32_t i = 0; i < n; i++) {
+        Flight& f = flights[i];
+        if (!f.stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+            HIP_TRY(hipMalloc(&f.d_acc6, 6 * sizeof(unsigned long long)));
+            HIP_TRY(hipHostMalloc((void**)&f.h_acc6, 6 * sizeof(unsigned long long), hipHostMallocDefault));
+            HIP_TRY(hipEventCreate(&f.e0)); HIP_TRY(hipEventCreate(&f.e1)); HIP_TRY(hipEventCreate(&f.done));
+        }
+        if (batch > f.cap) {
+            if (f.d_out) { HIP_TRY(hipStreamSynchronize(f.stream)); (void)hipFree(f.d_out); }
+            f.d_out = nullptr; f.cap = 0;
+            HIP_TRY(hipMalloc(&f.d_out, batch * sizeof(madsim_result_t)));
+            f.cap = batch;
+        }
+        if (staging && batch > f.h_cap) {
+            if (f.h_out) { HIP_TRY(hipStreamSynchronize(f.stream)); (void)hipHostFree(f.h_out); }
+            f.h_out = nullptr; f.h_cap = 0;
+            HIP_TRY(hipHostMalloc((void**)&f.h_out, batch * sizeof(madsim_result_t), hipHostMallocDefault));
+            f.h_cap = batch;
+        }
+    }
+    return 0;
+}
+
+namespace { uint32_t flights_of(madsim_hip_ctx* c, const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim, uint64_t batch); }
+uint32_t madsim_hip_ctx::flights_for(const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim, uint64_t batch) {
+    return flights_of(this, w, cfg, lim, batch);
 }
 
 namespace {
@@ -455,6 +495,121 @@ void host_summary(const madsim_result_t* out, uint64_t seed0, uint64_t count, ma
         f->total_steps += out[i].steps; f->total_clock_ns += out[i].clock_ns;
     }
 }
+
+// Batches in flight by the workload's occupancy: a batch of 65 536 seeds is one wave per SIMD, so as many batches as the
+// workload's LDS admits waves per SIMD, and — when that is four (the compact base-op layout) — a fifth, whose launch queues behind
+// them and fills the gaps their tails leave.
+uint32_t flights_of(madsim_hip_ctx* c, const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim, uint64_t batch) {
+    madsim_geo::Geo G;
+    uint32_t n = 3;
+    if (!madsim_geo::make_geometry(c->dev(), w, cfg, lim, batch, &G, &g_err)) {
+        if (G.blocks_per_cu * G.waves_per_block >= 16) n = 5;
+        else if (G.P.gstate_mode && G.P.heap_spill) n = 4;      // long launches that end with their slowest wave: one more behind them
+    }
+    return n;
+}
+
+// Per-seed results at the overlapped rate (one launch of 65 536 seeds is one wave per SIMD and leaves two
+// thirds of the issue slots idle).  Builder::run hands over ALL its seeds in one call (runtime/builder.rs:121-162), so the call
+// itself cuts [seed0, seed0 + count) into sub-batches: every context runs its contiguous share (context g: the block
+// g * ceil(count / n) — the rule of madsim_amd/dist.py shard_range), keeping `flights` sub-batches in flight on its own streams;
+// each sub-batch is kernel -> report reduction (accumulating in the flight's six words) -> device-to-host copy into the flight's
+// page-locked staging buffer, and the host moves a finished sub-batch into the caller's array while the next ones run.  Every
+// launch is queued from the calling thread; once the first kernel is in flight no error returns before every launched stream
+// has been drained.  `acc6` (optional): the folded device reports {first failing seed, failed, steps, clock, first genuine, runner}.
+constexpr uint64_t PIPE_BATCH = 65536;
+int run_pipelined(madsim_hip_ctx* const* ctxs, int n_ctx, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                  const madsim_limits_t* lim, madsim_result_t* out, unsigned long long* acc6, double* kernel_ms) {
+    struct Pipe { madsim_hip_ctx* c; uint64_t lo = 0, n = 0, nb = 0, launched = 0, harvested = 0; uint32_t F = 0; double ms = 0.0; };
+    std::vector<Pipe> pp(n_ctx);
+    const uint64_t chunk = (count + (uint64_t)n_ctx - 1) / (uint64_t)n_ctx;
+    int first_err = 0;
+    std::string first_msg;
+    auto note = [&](int e) { if (e && !first_err) { first_err = e; first_msg = g_err; } return e; };
+    for (int g = 0; g < n_ctx; g++) {
+        Pipe& p = pp[g];
+        p.c = ctxs[g];
+        p.lo = std::min((uint64_t)g * chunk, count);
+        p.n = std::min(p.lo + chunk, count) - p.lo;
+        p.nb = (p.n + PIPE_BATCH - 1) / PIPE_BATCH;
+        if (!p.nb) continue;
+        int e;
+        if (note(e = p.c->bind())) break;
+        p.F = (uint32_t)std::min<uint64_t>(p.nb, p.c->flights_for(w, cfg, lim, std::min(p.n, PIPE_BATCH)));
+        if (note(e = p.c->ensure_flights(p.F, std::min(p.n, PIPE_BATCH), true))) break;
+    }
+    if (first_err) return fail(first_err, first_msg);
+    auto queue = [&](Pipe& p) -> int {
+        const uint64_t k = p.launched;
+        madsim_hip_ctx::Flight& f = p.c->flights[k % p.F];
+        const uint64_t lo = p.lo + k * PIPE_BATCH, n = std::min(PIPE_BATCH, p.lo + p.n - lo);
+        int e;
+        if ((e = p.c->bind())) return e;
+        if (k < p.F) {                                           // the flight's first sub-batch of this call: a fresh report
+            HIP_TRY(hipMemsetAsync(f.d_acc6, 0xff, 8, f.stream));
+            HIP_TRY(hipMemsetAsync((char*)f.d_acc6 + 8, 0, 24, f.stream));
+            HIP_TRY(hipMemsetAsync((char*)f.d_acc6 + 32, 0xff, 8, f.stream));
+            HIP_TRY(hipMemsetAsync((char*)f.d_acc6 + 40, 0, 8, f.stream));
+        }
+        if (k == 0) HIP_TRY(hipEventRecord(p.c->pipe_begin, f.stream));
+        p.launched++;                                            // from here on the flight must be drained before returning
+        if ((e = p.c->launch(w, cfg, seed0 + lo, n, nullptr, lim, f.d_out, f.stream))) return e;
+        HIP_TRY(hipEventRecord(f.e1, f.stream));
+        madsim_k_launch_summary6(f.d_out, n, seed0 + lo, f.d_acc6, f.stream);
+        HIP_TRY(hipGetLastError());
+        if (out) HIP_TRY(hipMemcpyAsync(f.h_out, f.d_out, n * sizeof(madsim_result_t), hipMemcpyDeviceToHost, f.stream));
+        HIP_TRY(hipEventRecord(f.done, f.stream));
+        return 0;
+    };
+    auto harvest = [&](Pipe& p) -> int {
+        const uint64_t k = p.harvested++;
+        madsim_hip_ctx::Flight& f = p.c->flights[k % p.F];
+        int e;
+        if ((e = p.c->bind())) return e;
+        HIP_TRY(hipEventSynchronize(f.done));
+        if (first_err) return 0;                                 // (draining after an error: nothing is moved any more)
+        const uint64_t lo = p.lo + k * PIPE_BATCH, n = std::min(PIPE_BATCH, p.lo + p.n - lo);
+        if (out) memcpy(out + lo, f.h_out, n * sizeof(madsim_result_t));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.c->pipe_begin, f.e1));
+        p.ms = std::max(p.ms, (double)ms);
+        return 0;
+    };
+    for (;;) {
+        bool any = false;
+        for (Pipe& p : pp)                                       // 1. fill every device's flights before waiting for any of them
+            while (!first_err && p.launched < p.nb && p.launched - p.harvested < p.F) { note(queue(p)); any = true; }
+        for (Pipe& p : pp)                                       // 2. then the oldest sub-batch of every device
+            if (p.harvested < p.launched) { note(harvest(p)); any = true; }
+        if (!any) break;
+    }
+    if (first_err) return fail(first_err, first_msg);
+    unsigned long long a[6] = {~0ull, 0, 0, 0, ~0ull, 0};
+    double ms = 0.0;
+    for (Pipe& p : pp) {
+        if (!p.nb) continue;
+        int e;
+        if ((e = p.c->bind())) return e;
+        for (uint32_t i = 0; i < p.F; i++) {
+            madsim_hip_ctx::Flight& f = p.c->flights[i];
+            HIP_TRY(hipMemcpyAsync(f.h_acc6, f.d_acc6, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, f.stream));
+            HIP_TRY(hipStreamSynchronize(f.stream));
+            a[0] = std::min(a[0], f.h_acc6[0]); a[4] = std::min(a[4], f.h_acc6[4]);
+            a[1] += f.h_acc6[1]; a[2] += f.h_acc6[2]; a[3] += f.h_acc6[3]; a[5] += f.h_acc6[5];
+        }
+        ms = std::max(ms, p.ms);                                 // devices ran concurrently
+    }
+    if (acc6) memcpy(acc6, a, sizeof a);
+    if (kernel_ms) *kernel_ms += ms;
+    return 0;
+}
+
+}  // namespace
+int run_pipelined_fwd(madsim_hip_ctx* const* ctxs, int n_ctx, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                      const madsim_limits_t* lim, madsim_result_t* out, unsigned long long* acc6, double* kernel_ms) {
+    return run_pipelined(ctxs, n_ctx, w, cfg, seed0, count, lim, out, acc6, kernel_ms);
+}
+namespace {
 
 #define CTX_ENTER(c)                                                                              \
     if (!(c) || (c)->device < 0) return fail(MADSIM_E_NOINIT, "no context (madsim_hip_init / madsim_hip_ctx_create has not been called)"); \
@@ -610,9 +765,9 @@ int64_t madsim_hip_ctx_trace_seed(madsim_hip_ctx_t* c, const madsim_workload_t* 
 
 // ---- one process, several GPUs -----------------------------------------------------------------------------------------
 // Builder::run drives every seed from one process (builder.rs:129-150): shard [seed0, seed0 + count) contiguously over
-// the contexts (context g gets [g * ceil(count / n), ...), the rule of madsim_amd/dist.py::shard_range), queue every
-// device's kernel AND its device-to-host copy (into pinned staging memory, so the copies of different devices overlap)
-// from this one host thread before waiting for any of them, then fold the n reports on the host.
+// the contexts (context g gets [g * ceil(count / n), ...), the rule of madsim_amd/dist.py::shard_range) and run every share
+// as sub-batches kept in flight on that device's own streams (run_pipelined: kernels and device-to-host copies of all devices
+// queued from this one host thread, page-locked staging so the copies overlap), then fold the reports on the host.
 // Why a host fold and not the RCCL gather BASELINE.json's north_star names: the per-seed results travel to the caller's host
 // array anyway (Builder::run needs the failing seed's result), so the only thing a collective could carry is n <= 8 reports
 // of 32 bytes that the host already holds; a single-process communicator (ncclCommInitAll) plus one collective launch per
@@ -638,48 +793,10 @@ int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const m
     std::vector<std::unique_lock<std::mutex>> locks;
     for (madsim_hip_ctx* c : order) locks.emplace_back(c->mu);
     for (int g = 0; g < n_ctx; g++) if (ctxs[g]->device < 0) return fail(MADSIM_E_NOINIT, "closed context");
-    const uint64_t chunk = (count + (uint64_t)n_ctx - 1) / (uint64_t)n_ctx;
-    struct Shard { uint64_t lo = 0, n = 0; bool launched = false; };
-    std::vector<Shard> sh(n_ctx);
-    // 1. every device's kernel and its D2H copy are in flight before the host waits for anything
-    int first_err = 0;
-    std::string first_msg;
-    auto note = [&](int e) { if (e && !first_err) { first_err = e; first_msg = g_err; } return e; };
-    auto queue_shard = [&](int g) -> int {
-        madsim_hip_ctx* c = ctxs[g];
-        int e;
-        if ((e = c->bind())) return e;
-        if ((e = c->ensure_out(sh[g].n))) return e;
-        if ((e = c->ensure_pinned(sh[g].n))) return e;
-        HIP_TRY(hipEventRecord(c->ev0, c->own_stream));
-        sh[g].launched = true;                                  // from here on the stream must be drained before returning
-        if ((e = c->launch(w, cfg, seed0 + sh[g].lo, sh[g].n, nullptr, lim, c->d_out, c->own_stream))) return e;
-        HIP_TRY(hipEventRecord(c->ev1, c->own_stream));
-        HIP_TRY(hipMemcpyAsync(c->h_pinned, c->d_out, sh[g].n * sizeof(madsim_result_t), hipMemcpyDeviceToHost, c->own_stream));
-        return 0;
-    };
-    for (int g = 0; g < n_ctx && !first_err; g++) {
-        sh[g].lo = std::min((uint64_t)g * chunk, count);
-        sh[g].n = std::min(sh[g].lo + chunk, count) - sh[g].lo;
-        if (sh[g].n) note(queue_shard(g));
-    }
-    // 2. drain EVERY launched stream — also when something failed above: no kernel of this call stays in flight behind an
-    //    error return — and move the staged results into the caller's array
+    // 1 + 2. every device's sub-batches and their device-to-host copies are queued from this thread, each device keeping as many
+    //        in flight as the workload's occupancy rewards; finished sub-batches move into the caller's array while the rest run
     double kernel_ms = 0.0;
-    auto drain_shard = [&](int g) -> int {
-        madsim_hip_ctx* c = ctxs[g];
-        int e;
-        if ((e = c->bind())) return e;
-        HIP_TRY(hipStreamSynchronize(c->own_stream));
-        if (first_err) return 0;
-        memcpy(out + sh[g].lo, c->h_pinned, sh[g].n * sizeof(madsim_result_t));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        kernel_ms = std::max(kernel_ms, (double)ms);       // devices ran concurrently
-        return 0;
-    };
-    for (int g = 0; g < n_ctx; g++) if (sh[g].launched) note(drain_shard(g));
-    if (first_err) return fail(first_err, first_msg);
+    if ((rc = run_pipelined(ctxs, n_ctx, w, cfg, seed0, count, lim, out, nullptr, &kernel_ms))) return rc;
     // 3. runner verdicts (capacity / step cap) from every shard: one compacted re-launch per round, round-robin over the devices
     if ((rc = rerun_runner_verdicts(ctxs, n_ctx, w, cfg, seed0, count, lim, out, max_rounds, &kernel_ms))) return rc;
     // 4. fold
@@ -698,36 +815,13 @@ int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* c, const madsim_workload_t* w,
     int rc = madsim_geo::validate(w, cfg, &g_err);
     if (rc) return rc;
     if (batch == 0) batch = 65536;
-    if (in_flight == 0) {
-        // one wave per SIMD and batch of 65 536 seeds: as many batches as the workload's LDS admits waves per SIMD, and — when that is
-        // four (the compact base-op layout) — a fifth, whose launch queues behind them and fills the gaps their tails leave
-        madsim_geo::Geo G;
-        in_flight = 3;
-        if (!madsim_geo::make_geometry(c->dev(), w, cfg, lim, batch, &G, &g_err)) {
-            if (G.blocks_per_cu * G.waves_per_block >= 16) in_flight = 5;
-            else if (G.P.gstate_mode && G.P.heap_spill) in_flight = 4;      // long launches that end with their slowest wave: one more behind them
-        }
-    }
+    if (in_flight == 0) in_flight = c->flights_for(w, cfg, lim, batch);
     if (in_flight > (uint32_t)madsim_hip_ctx::CAMPAIGN_MAX) return fail(MADSIM_E_ARG, "at most 8 batches in flight");
     if (seed0 + total < seed0) return fail(MADSIM_E_ARG, "seed0 + total wraps");
     if (total == 0) return 0;
     const uint64_t n_batches = (total + batch - 1) / batch;
     if (n_batches < in_flight) in_flight = (uint32_t)n_batches;
-    for (uint32_t i = 0; i < in_flight; i++) {
-        madsim_hip_ctx::Flight& f = c->flights[i];
-        if (!f.stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
-            HIP_TRY(hipMalloc(&f.d_acc6, 6 * sizeof(unsigned long long)));
-            HIP_TRY(hipHostMalloc((void**)&f.h_acc6, 6 * sizeof(unsigned long long), hipHostMallocDefault));
-            HIP_TRY(hipEventCreate(&f.e0)); HIP_TRY(hipEventCreate(&f.e1)); HIP_TRY(hipEventCreate(&f.done));
-        }
-        if (batch > f.cap) {
-            if (f.d_out) { HIP_TRY(hipStreamSynchronize(f.stream)); (void)hipFree(f.d_out); }
-            f.d_out = nullptr; f.cap = 0;
-            HIP_TRY(hipMalloc(&f.d_out, batch * sizeof(madsim_result_t)));
-            f.cap = batch;
-        }
-    }
+    if ((rc = c->ensure_flights(in_flight, batch, false))) return rc;
     int first_err = 0;
     std::string first_msg;
     auto queue = [&](uint64_t k) -> int {                       // batch k on flight k % in_flight

@@ -74,3 +74,83 @@ def test_two_rank_first_fail_report():
         assert rep2[0] == 5
         assert rep3 == want, (rank, rep3, want)
         assert rep4 == want, (rank, rep4, want)
+
+
+# ---- world size 8: bench.py's launcher path end to end on CPU ------------------------------------------------------------
+# What `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` does around the kernel, with the oracle standing in
+# for the GPU: the launcher environment -> launch.plan / rank_env, the rank -> seed-block map (uneven: count % 8 != 0), one
+# 8-word report row per rank and step ({first-fail key, failed, steps, clock, rank, device, 0, 0}), ONE all-gather per step,
+# launch.check_ranks on every gathered step and dist.combine_gathered over the steps (runtime/builder.rs:129-150: the seeds are
+# seed0 .. seed0 + count whoever runs them).
+REPORT_WORDS = 8
+
+
+def _worker8(rank, world, port, count, n_steps, q):
+    env = {"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    os.environ.update(env)
+    import torch
+    import oracle
+    from madsim_amd import _abi as A, launch
+    from madsim_amd import workload as W
+    assert launch.plan(world, env, ["--gpus", str(world)], "bench.py") == ("inline", None)
+    assert launch.rank_env(env) == (rank, rank, world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = W.pingpong(4, 8)
+    cfg = A.Config.default(packet_loss_rate=0.01)
+    gathered = torch.zeros((n_steps, world, REPORT_WORDS), dtype=torch.int64)
+    blocks = []
+    for k in range(n_steps):
+        seed0, n = mdist.shard_range(k * count, count, rank, world)        # a fresh block of seeds every step
+        blocks.append((seed0, n))
+        _, s = oracle.run_batch(w, seed0, n, cfg)
+        key = s.first_failing_seed ^ (1 << 63)
+        key = key - (1 << 64) if key >= (1 << 63) else key
+        row = torch.tensor([key, s.n_failed, s.total_steps, s.total_clock_ns, rank, rank % 8, 0, 0], dtype=torch.int64)
+        mdist.gather_report_device(row, gathered[k])
+    for row in gathered:
+        assert launch.check_ranks([(int(r[4]), int(r[5])) for r in row], world) == world
+    rows = mdist.combine_gathered(gathered)
+    q.put((rank, blocks, [(mdist.decode_first_fail(r[0]), int(r[1]), int(r[2]), int(r[3])) for r in rows]))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_launcher_path_uneven_count():
+    world, count, n_steps = 8, 203, 3                      # 203 = 8 * 25 + 3: blocks of 26 seeds, the last one of 21
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, count, n_steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    import oracle
+    from madsim_amd import _abi as A
+    from madsim_amd import workload as W
+    w, cfg = W.pingpong(4, 8), A.Config.default(packet_loss_rate=0.01)
+    want = []
+    for k in range(n_steps):
+        _, sm = oracle.run_batch(w, k * count, count, cfg)
+        want.append((sm.first_failing_seed, sm.n_failed, sm.total_steps, sm.total_clock_ns))
+    assert any(wf[1] for wf in want)
+    res.sort()
+    for k in range(n_steps):                               # the ranks' blocks tile the step's seed range, in rank order
+        nxt = k * count
+        for rank, blocks, _ in res:
+            s0, n = blocks[k]
+            assert n in (26, 21) and (n == 0 or s0 == nxt)
+            nxt += n
+        assert nxt == (k + 1) * count
+    for rank, _, rows in res:
+        assert rows == want, (rank, rows, want)
+
+
+def test_check_ranks_refuses_a_missing_or_doubled_rank():
+    import pytest
+    from madsim_amd import launch
+    assert launch.check_ranks([(r, r) for r in range(8)], 8) == 8
+    for bad in ([(r, r) for r in range(7)] + [(6, 6)], [(r, r) for r in range(7)], [(r, r) for r in range(9)]):
+        with pytest.raises(launch.LaunchError):
+            launch.check_ranks(bad, 8)

@@ -1054,3 +1054,66 @@ def test_port0_rebind_is_unsupported_and_never_rerun_gpu(hip):
         assert (got == want).all() and (got["verdict"] == A.UNSUPPORTED).all() and not got["steps"].any()
         got2, _ = hip.run_batch_auto(w, 0, 64, None, lim)
         assert (got2 == want).all()
+
+
+def test_run_batch_of_262144_seeds_is_pipelined_and_bit_exact(hip):
+    """VERDICT r3 weak #5 / Builder::run (runtime/builder.rs:121-162: one call runs all seeds): a plain madsim_hip_run_batch with
+    more than one batch of seeds is cut into sub-launches kept in flight inside the library and still fills the caller's
+    per-seed array — identical to four separate one-batch calls, to the oracle on sampled seeds (all 48 bytes) and in its
+    summary; a ragged tail, loss-induced failures (first failing seed), and the compact / plain / global layouts."""
+    from madsim_amd import workload
+    w, lim, _ = workload.bench_case("pingpong")
+    for cfg, count in ((None, 262144), (A.Config.default(packet_loss_rate=2e-6), 200_001)):
+        got, summ = hip.run_batch(w, 77_000_000, count, cfg, lim)
+        parts, nf, steps, first = [], 0, 0, (1 << 64) - 1
+        for lo in range(0, count, 65536):
+            g1, s1 = hip.run_batch(w, 77_000_000 + lo, min(65536, count - lo), cfg, lim)
+            parts.append(g1); nf += s1.n_failed; steps += s1.total_steps; first = min(first, s1.first_failing_seed)
+        assert (got == np.concatenate(parts)).all()
+        assert (summ.n_failed, summ.total_steps, summ.first_failing_seed) == (nf, steps, first)
+        idx = (np.arange(768) * 341) % count
+        want = np.concatenate([oracle.run_batch(w, 77_000_000 + int(i), 1, cfg, lim)[0] for i in idx])
+        assert (got[idx] == want).all()
+        if cfg is not None:
+            assert summ.n_failed > 0 and got[summ.first_failing_seed - 77_000_000]["verdict"] == A.DEADLOCK
+    # an extended-op workload in the global layout with a heap-spill region (scratch per stream), 3 sub-batches + a tail
+    xw, xlim, _ = workload.bench_case("kv")
+    got, summ = hip.run_batch(xw, 5_000_000, 150_000, None, xlim)
+    one, _ = hip.run_batch(xw, 5_000_000 + 131072, 150_000 - 131072, None, xlim)
+    assert (got[131072:] == one).all()
+    idx = (np.arange(256) * 577) % 150_000
+    want = np.concatenate([oracle.run_batch(xw, 5_000_000 + int(i), 1, None, xlim)[0] for i in idx])
+    assert ((got[idx] == want) | (got[idx]["verdict"] == A.OVERFLOW)).all()
+
+
+def test_run_batch_multi_over_k_contexts_equals_k_independent_calls(hip):
+    """madsim_hip_run_batch_multi over k contexts == k independent run_batch calls on the blocks of madsim_amd/dist.py
+    shard_range, for counts k does not divide and counts large enough that every context pipelines several sub-batches
+    (runtime/builder.rs:129-150: the seeds are seed0 .. seed0 + count whatever runs them)."""
+    from madsim_amd import dist as mdist
+    w = W.pingpong(4, 8)
+    cfg = A.Config.default(packet_loss_rate=0.002)
+    for k, count in ((3, 10_007), (5, 65_537), (2, 300_001), (4, 3)):
+        ctxs = [hip.Context(0) for _ in range(k)]
+        try:
+            got, summ = hip.run_batch_multi(ctxs, w, 900, count, cfg)
+            parts, nf, first = [], 0, (1 << 64) - 1
+            for g in range(k):
+                lo, n = mdist.shard_range(900, count, g, k)
+                g1, s1 = ctxs[g].run_batch(w, lo, n, cfg)
+                parts.append(g1); nf += s1.n_failed
+                if s1.n_failed:
+                    first = min(first, s1.first_failing_seed)
+            assert (got == np.concatenate(parts)).all(), (k, count)
+            assert (summ.n_failed, summ.first_failing_seed) == (nf, first)
+        finally:
+            for c in ctxs:
+                c.close()
+    want, _ = oracle.run_batch(w, 900, 3000, cfg)
+    ctxs = [hip.Context(0) for _ in range(3)]
+    try:
+        got, _ = hip.run_batch_multi(ctxs, w, 900, 3000, cfg)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert (got == want).all()
