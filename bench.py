@@ -604,8 +604,8 @@ def main():
             # the global-state builds with a heap-spill region, else three
             xn = min(n_streams, flights(xg0))
             nsub = max(1, baseline_batch[name] // count)
-            xsteps = max(2, -(-3 * xn // nsub))      # timed steps: at least three sub-launches per stream
-            xs, xwu = xsteps * nsub, xn   # timed sub-launches after one untimed per stream: the timed ones start into a busy chip
+            xtimed = max(2, -(-3 * xn // nsub))      # timed steps: at least three sub-launches per stream
+            xs, xwu = xtimed * nsub, xn   # timed sub-launches after one untimed per stream: the timed ones start into a busy chip
             xring = torch.zeros((xs + xwu, REPORT_WORDS), dtype=torch.int64, device=dev)
             last = {}
 
@@ -640,9 +640,9 @@ def main():
                     xver += 1
             xg = runtime.geometry(xw, xlim)
             xalgo = xsteps / xs * ALGO_BYTES_PER_STEP + count * IO_BYTES_PER_SEED
-            extras[name] = {"workload": xname, "seeds_per_step": nsub * count, "steps": xsteps, "sub_launches_per_step": nsub,
+            extras[name] = {"workload": xname, "seeds_per_step": nsub * count, "steps": xtimed, "sub_launches_per_step": nsub,
                             "seeds_per_sub_launch": count, "warmup_sub_launches": xwu, "concurrent_batches": xn,
-                            "ms_per_step": xdt / xsteps * 1e3, "ms_per_sub_launch": xdt / xs * 1e3, "kernel_ms_per_sub_launch": xk_ms,
+                            "ms_per_step": xdt / xtimed * 1e3, "ms_per_sub_launch": xdt / xs * 1e3, "kernel_ms_per_sub_launch": xk_ms,
                             "steps_per_sec": xsteps / xdt, "seeds_per_sec": xs * count / xdt, "sim_seconds_per_sec": xclock / 1e9 / xdt,
                             "failed_seeds": xfail, "verified_seeds": xver, "kernel": runtime.variant_name(xg),
                             "lds_bytes_per_seed": xg.lds_bytes_per_seed, "global_bytes_per_seed": xg.global_bytes_per_seed,

@@ -114,7 +114,6 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
     // BindGuard dropped — `if self.node.is_killed() { return }`, net/mod.rs:483-493 — and TaskHandle::restart resets no sockets): the
     // EndpointSocket stays in the table and its mailbox still takes a message for a receive that some OTHER holder of the Endpoint
     // registered; with nobody left to register one, a message is dropped instead of queued for ever.
-    const bool orphan = K::LIFE && live && SW(c, s, 1) == ~0u;
     if (live) {
         uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
         // Typed RPC (net/rpc.rs): a response (tag 0xff) is addressed to one pending receive — the word of its registration,
@@ -154,7 +153,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
         }
         if (taken) {
             SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);
-        } else if (orphan) {
+        } else if (K::LIFE && SW(c, s, 1) == ~0u) {              // (the owner word is read only when nobody took the message)
             SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);      // (dead registrations swept on the way stay swept)
         } else if (nmsg >= c.P.mbox_msgs) {
             L.ovf |= OVF_CAP;

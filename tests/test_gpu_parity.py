@@ -193,6 +193,7 @@ def test_device_resident_entry_point_on_torch_stream(hip):
     w = W.pingpong(4, 8)
     n = 4096
     buf = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()        # (the fill ran on torch's current stream, the kernel runs on another)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         summ = hip.run_batch_device(w, 77, n, buf.data_ptr(), st.cuda_stream)
@@ -410,10 +411,12 @@ def test_concurrent_streams_do_not_share_scratch(hip):
     n = 16384
     streams = [torch.cuda.Stream() for _ in range(3)]
     jobs = []
+    bufs = [torch.zeros(n * 48, dtype=torch.uint8, device="cuda") for _ in range(6)]
+    reps = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in range(6)]
+    torch.cuda.synchronize()        # the fills run on torch's current stream: they must not land after a kernel on another stream
     for k in range(6):
         w, lim = (wa, la) if k % 2 == 0 else (wb, None)
-        buf = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
-        rep = torch.zeros(4, dtype=torch.int64, device="cuda")
+        buf, rep = bufs[k], reps[k]
         st = streams[k % 3]
         with torch.cuda.stream(st):
             hip.run_batch_async(w, 7000 * k, n, buf.data_ptr(), rep.data_ptr(), st.cuda_stream, None, lim)
@@ -498,6 +501,7 @@ def test_bench_configuration_pingpong_is_oracle_checked(hip, n_streams, state_me
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     bufs = [torch.zeros(n * 48, dtype=torch.uint8, device="cuda") for _ in range(2 * n_streams)]
     reps = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in range(2 * n_streams)]
+    torch.cuda.synchronize()        # (the fills ran on torch's current stream, the kernels run on others)
     for k in range(2 * n_streams):                     # two rounds per stream, all queued before any finishes
         st = streams[k % n_streams]
         with torch.cuda.stream(st):
