@@ -341,7 +341,9 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             P.gs_plane_words = P.lane_words;
             // MADSIM_STATE_DEDUP_TIMERS: 64 buckets of 16 bytes behind the task units — the one build that carries the code is
             // the global-state build of timeout-only workloads (k_state.h Variant::DEDUP, k_timer.h dedup_note)
-            P.dedup_off = P.max_tasks * P.task_units * 16;
+            // the task region: one granule per (slot, lane), the slot's units side by side (k_state.h gs_addr_task)
+            P.gs_gran_sh = 5; while ((1u << P.gs_gran_sh) < P.task_units * 16) P.gs_gran_sh++;
+            P.dedup_off = P.max_tasks << P.gs_gran_sh;
             P.dedup_n = ((L.state_mem & MADSIM_STATE_DEDUP_TIMERS) && P.features == MADSIM_FEAT_TIME && !trace) ? 64u : 0u;
             P.gs_planes = P.dedup_off + P.dedup_n * 16;
             P.gs_stride = (P.gs_planes + P.gs_plane_words * 4 + 63) & ~63u;

@@ -288,16 +288,27 @@ template <class K> __device__ __forceinline__ bool sock_owned_by(const Ctx& c, u
     if (K::LIFE) return SW(c, s, 1) == (slot | (gen << 16));
     return (h & 1) && (h >> 24) == slot;
 }
-template <bool G> __device__ __forceinline__ WRef<G> tword_gs(const Ctx& c, uint32_t gs_at);       // (K::G builds only)
-template <> __device__ __forceinline__ WRef<false> tword_gs<false>(const Ctx&, uint32_t) { return WRef<false>{0}; }
-template <> __device__ __forceinline__ WRef<true> tword_gs<true>(const Ctx& c, uint32_t gs_at) { return make_uword_ref(c, gs_at); }
+// Global-state builds: a task slot's units sit together in ONE granule per lane — [slot][global lane][unit 0 .. task_units - 1], the
+// granule padded to a power of two (32 / 64 / 128 bytes) — so the two or three units a poll reads and writes back share a
+// 32- or 64-byte sector instead of a sector each.  (The plane words stay [word][lane]: lanes that read the same word share lines.)
+// byte offset in the state buffer of byte `b` of slot's granule:
+__device__ __forceinline__ uint32_t gs_addr_task(const Ctx& c, uint32_t slot, uint32_t b) {
+    return __umul24(slot << c.P.gs_gran_sh, c.P.total_lanes) + (c.gs_lane << c.P.gs_gran_sh) + b;
+}
+template <bool G> __device__ __forceinline__ URef<G> tu_gs(const Ctx& c, uint32_t slot, uint32_t u);
+template <> __device__ __forceinline__ URef<false> tu_gs<false>(const Ctx&, uint32_t, uint32_t) { return URef<false>{0}; }
+template <> __device__ __forceinline__ URef<true> tu_gs<true>(const Ctx& c, uint32_t slot, uint32_t u) { return URef<true>{c.gs, gs_addr_task(c, slot, u * 16u)}; }
+template <bool G> __device__ __forceinline__ WRef<G> tword_gs2(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k);
+template <> __device__ __forceinline__ WRef<false> tword_gs2<false>(const Ctx&, uint32_t, uint32_t, uint32_t) { return WRef<false>{0}; }
+template <> __device__ __forceinline__ WRef<true> tword_gs2<true>(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) { return WRef<true>{c.gs, gs_addr_task(c, slot, u * 16u + k * 4u)}; }
 template <class K> __device__ __forceinline__ URef<K::G> tu_ref_plain(const Ctx& c, uint32_t slot, uint32_t u) {
     if (!K::LIFE) return make_uref<K::G>(c, c.task0 + (slot << LWSH<K>(c)), 0);             // unit 0 (unit 1: load_u1 / TWORD)
-    return make_uref<K::G>(c, c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c)), c.task0 + (slot * c.P.task_units + u) * 16u);
+    if (K::G) return tu_gs<K::G>(c, slot, u);
+    return make_uref<K::G>(c, c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c)), 0);
 }
 template <class K> __device__ __forceinline__ WRef<K::G> tword_ref_plain(const Ctx& c, uint32_t slot, uint32_t u, uint32_t k) {
     if (!K::LIFE) return make_wref<K::G>(c, u == 0 ? (c.task0 + (slot << LWSH<K>(c))) * 4u + k : (c.task1 + (slot << LWSH<K>(c))) * 2u + k, 0);
-    if (K::G) return tword_gs<K::G>(c, c.task0 + (slot * c.P.task_units + u) * 16u + k * 4u);
+    if (K::G) return tword_gs2<K::G>(c, slot, u, k);
     return make_wref<K::G>(c, (c.task0 + ((slot * c.P.task_units + u) << LWSH<K>(c))) * 4u + k, 0);
 }
 // Compact builds: the main task's record in the global buffer is unit0 at [lane * 16], then unit1 {x, y} at

@@ -72,6 +72,7 @@ struct KParams {
     // as [unit][global lane] then [word][global lane] (k_state.h gs_addr_*): logical byte `at` of lane g lives at
     // at * total_lanes + g * 16 (units) or + g * 4 (words)
     uint32_t gstate_mode, gs_stride, gs_planes, gs_plane_words;
+    uint32_t gs_gran_sh;         // log2 of a task slot's granule in the global block: [slot][lane][task_units x 16 bytes, padded to 2^gs_gran_sh]
     uint32_t off_amask, off_omask;     // LDS plane words (after the ready queue) of the alive-task / owned-socket masks
     uint8_t* gstate;
     uint32_t lifecycle;        // any extended op: the extended LDS layout (features != 0)

@@ -454,7 +454,10 @@ def test_dedup_timers_switch_selects_the_timeout_only_global_build_and_nothing_e
     raft = W.raft_election()
     on = emu.geometry_params(raft, LW.dedup_limits(W.raft_election_limits()))
     assert on["features"] == 1 and on["gstate_mode"] == 1 and on["dedup_n"] == 64          # MADSIM_FEAT_TIME only, global state
-    assert on["dedup_off"] == on["max_tasks"] * on["task_units"] * 16 and on["gs_planes"] == on["dedup_off"] + 64 * 16
+    gran = 32
+    while gran < on["task_units"] * 16:
+        gran *= 2                    # a task slot's units share one power-of-two granule per lane (k_state.h gs_addr_task)
+    assert on["dedup_off"] == on["max_tasks"] * gran and on["gs_planes"] == on["dedup_off"] + 64 * 16
     lim = W.raft_election_limits(); lim.state_mem = A.STATE_GLOBAL
     off = emu.geometry_params(raft, lim)
     assert off["dedup_n"] == 0 and off["gs_planes"] == on["gs_planes"] - 64 * 16
