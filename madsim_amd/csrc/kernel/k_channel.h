@@ -11,10 +11,16 @@ namespace madsim_k {
 // Returns 1 with the latency, the destination socket and the dst-was-loopback flag of `from` when a delivery must be
 // scheduled, 0 when the message is dropped, -1 when the sender panics (`.ip.unwrap()` of an IP-less node, :309).
 template <class K>
-__device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_node, uint32_t addr, uint32_t idx, uint64_t* latency, int* dst_sock, uint32_t* from_lb) {
+// `dst_hdr` receives the destination socket's header word (valid when the result is 1).
+__device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_node, uint32_t addr, uint32_t idx, uint64_t* latency, int* dst_sock, uint32_t* from_lb, uint32_t* dst_hdr) {
     const KParams& P = c.P;
     // (one result variable, no early returns: every extra way out of an inlined body costs phi copies where it is used)
     int res = 0;
+    // Global-state builds, plain addresses: the destination's table entry is known before the draws, so its header word is
+    // requested here — with the clog words — and has arrived when the loss and latency draws are done, instead of costing a round
+    // trip after them.  (Nothing is stored in between.)
+    uint32_t hdr = 0;
+    if (K::G && PLAIN_ADDR) hdr = SW(c, idx, 0);
     int dn = (int)(addr & 0xff);                            // resolve_dest_node: plain node IPs resolve to their node
     if (!PLAIN_ADDR) dn = resolve_dest_node<K>(c, src_node, addr);          // < 0: dropped, no draw
     if (dn >= 0) {
@@ -26,10 +32,11 @@ __device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_
             L.msg_count++;
             *latency = sample_latency<K>(c, L);
             int ds;
-            if (PLAIN_ADDR) ds = find_bound<K>(c, idx);
+            if (PLAIN_ADDR) { if (!K::G) hdr = SW(c, idx, 0); ds = (hdr & 1) ? (int)idx : -1; }     // (k_net.h find_bound)
             else {
                 ds = find_exact<K>(c, dst_node, addr);              // sockets.get(&(dst, protocol))
                 if (ds < 0) ds = find_exact<K>(c, dst_node, (addr & 0xffff0000u) | (MADSIM_ADDR_UNSPECIFIED << 8));   // .or_else(0.0.0.0:port)
+                if (ds >= 0) hdr = SW(c, (uint32_t)ds, 0);
             }
             if (ds >= 0) {                                  // else: draws consumed, silently dropped
                 *from_lb = 0;
@@ -39,6 +46,7 @@ __device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_
                     if (!*from_lb && !node_has_ip(c, src_node)) res = -1;
                 }
                 *dst_sock = ds;
+                *dst_hdr = hdr;
             }
         }
     }
@@ -61,20 +69,19 @@ __device__ __forceinline__ uint64_t chan_test_link(const Ctx& c, Lane& L, uint32
         addr = PLAIN_ADDR ? cw_addr : addr_of_from(c, c_ep | ((dkind == MADSIM_ADDR_LOOPBACK ? 1u : 0u) << 6));
         idx = c_ep;
     }
-    uint64_t lat; int ds; uint32_t lb;
-    const int sent = net_try_send<K>(c, L, src_node, addr, idx, &lat, &ds, &lb);
+    uint64_t lat; int ds; uint32_t lb, dh;
+    const int sent = net_try_send<K>(c, L, src_node, addr, idx, &lat, &ds, &lb, &dh);
     if (sent < 0) return CHAN_LINK_PANIC;                   // `.ip.unwrap()` inside try_send (network.rs:309)
     if (sent == 0) return ~0ull;
     return L.clock + lat;
 }
 
 // drop the raw (PayloadSender, PayloadReceiver) pair of one end of connection `id`
+// (`cw`, `r` = the connection's header word and the parked-receiver word of this end's direction, when the caller holds them)
 template <class K>
-__device__ __forceinline__ void conn_drop_raw(const Ctx& c, Lane& L, uint32_t id, uint32_t side) {
-    uint32_t cw = CONNW(id, 0);
+__device__ __forceinline__ void conn_drop_raw_with(const Ctx& c, Lane& L, uint32_t id, uint32_t side, uint32_t cw, uint32_t r) {
     if (cw & (1u << (13 + 2 * side))) {                       // my PayloadSender: last mpsc sender gone
         cw &= ~(1u << (13 + 2 * side));
-        uint32_t r = CONNW(id, 1 + side);
         if (r & 1) { CONNW(id, 1 + side) = 0; CONNW(id, 0) = cw; wake<K>(c, L, (r >> 1) & 0xff, r >> 9); }   // parked receiver sees None
     }
     cw &= ~(1u << (14 + 2 * (1 - side)));                     // my PayloadReceiver
@@ -82,6 +89,13 @@ __device__ __forceinline__ void conn_drop_raw(const Ctx& c, Lane& L, uint32_t id
     if (!(cw & (0xfu << 13))) cw = 0;                          // all four handles gone: slot is free
     if (side) cw &= ~(0x7fu << 25);                            // (the listener-side guard reference goes with the handles)
     CONNW(id, 0) = cw;
+}
+template <class K>
+__device__ __forceinline__ void conn_drop_raw(const Ctx& c, Lane& L, uint32_t id, uint32_t side) {
+    const uint32_t cw = CONNW(id, 0);
+    // (global-state builds: both words in one round trip; the LDS builds read the second one only when it is wanted)
+    const uint32_t r = (Hoist<K>::CHAN || (cw & (1u << (13 + 2 * side)))) ? (uint32_t)CONNW(id, 1 + side) : 0u;
+    conn_drop_raw_with<K>(c, L, id, side, cw, r);
 }
 
 // conn_tx / conn_rx of an Endpoint (endpoint.rs:18,307): up to MADSIM_ACCEPTQ connection ids waiting for accept1, as one
@@ -123,9 +137,10 @@ template <class K>
 __device__ __forceinline__ void guard_release(const Ctx& c, Lane& L, uint32_t s, bool node_killed) {
     if (node_killed) return;
     uint32_t h = SW(c, s, 0);
+    const uint32_t own_pre = Hoist<K>::CHAN ? (uint32_t)SW(c, s, 1) : 0u;      // (global-state builds: the owner word with the header)
     if (!(h >> 25)) return;
     h -= 1u << 25;
-    if (!(h >> 25) && (h & 1) && SW(c, s, 1) == ~0u) {       // the last owner: Network::close, and the socket dies
+    if (!(h >> 25) && (h & 1) && (Hoist<K>::CHAN ? own_pre : (uint32_t)SW(c, s, 1)) == ~0u) {       // the last owner: Network::close, and the socket dies
         SW(c, s, 0) = h & ~1u;
         if (SW(c, s, 2 + c.P.mbox_regs + 2 * c.P.mbox_msgs) & 0xf) sock_drop_acceptq<K>(c, L, s);
     } else {
@@ -137,9 +152,10 @@ __device__ __forceinline__ void guard_release(const Ctx& c, Lane& L, uint32_t s,
 template <class K>
 __device__ __forceinline__ void conn_drop_handles(const Ctx& c, Lane& L, uint32_t id, uint32_t side, bool node_killed) {
     const uint32_t cw = CONNW(id, 0);
+    const uint32_t r = (Hoist<K>::CHAN || (cw & (1u << (13 + 2 * side)))) ? (uint32_t)CONNW(id, 1 + side) : 0u;
     const bool held = side ? (cw >> 31) != 0 : (cw & (1u << 13)) != 0;       // accepted / the client's handles exist
     const uint32_t gs = side ? (cw >> 25) & 0x3f : (cw >> 1) & 0x3f;
-    conn_drop_raw<K>(c, L, id, side);
+    conn_drop_raw_with<K>(c, L, id, side, cw, r);
     if (held) guard_release<K>(c, L, gs, node_killed);
 }
 

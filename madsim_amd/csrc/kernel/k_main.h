@@ -135,18 +135,19 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEA
             // loaded BEFORE the draw loop (whose rejection retries take hundreds of cycles) and used if idx == 0.
             const uint32_t slot0 = K::RQ ? (uint32_t)(L.rq & 0xff) : rq_get<K>(c, 0);
             const uint4 pu0 = TU(c, slot0, 0), pu1 = load_u1<K>(c, slot0);
+            PollPrefetch pp = poll_prefetch<K>(c, slot0);     // (global-state builds: more of the slot's granule, same cache line)
             // try_recv_random (utils/mpsc.rs:73-83): idx drawn even when len == 1
             uint32_t idx = gen_index<K>(c, L, L.ready_len);
             L.ready_len--;
             uint32_t slot = slot0;
             uint4 u0 = pu0, u1 = pu1;
             if (K::RQ) {
-                if (idx != 0) { slot = (uint32_t)(L.rq >> (8 * idx)) & 0xff; u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot); }
+                if (idx != 0) { slot = (uint32_t)(L.rq >> (8 * idx)) & 0xff; u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot); pp = poll_prefetch<K>(c, slot); }
                 uint64_t last = (L.rq >> (8 * L.ready_len)) & 0xff;      // swap_remove on bytes
                 L.rq = (L.rq & ~(0xffull << (8 * idx))) | (last << (8 * idx));
                 L.rq &= ~(0xffull << (8 * L.ready_len));
             } else {
-                if (idx != 0) { slot = rq_get<K>(c, idx); u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot); }
+                if (idx != 0) { slot = rq_get<K>(c, idx); u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot); pp = poll_prefetch<K>(c, slot); }
                 if (idx != L.ready_len) rq_set<K>(c, idx, rq_get<K>(c, L.ready_len));       // swap_remove
             }
             L.steps++;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEA
             } else {
                 u0.x = (u0.x & ~TF_SCHED) | TF_RUN;          // async-task run(): SCHEDULED -> RUNNING
                 if (K::FN) L.panic_code = MADSIM_PANIC_CODE_OTHER;
-                panicked = poll_task<K>(c, L, slot, u0, u1);
+                panicked = poll_task<K>(c, L, slot, u0, u1, pp);
                 if (!panicked && (u0.x & TF_ALIVE)) {
                     if (u0.x & TF_SCHED) ready_push<K>(c, L, slot);   // woken while running: re-queue after the poll
                     u0.x &= ~TF_RUN;

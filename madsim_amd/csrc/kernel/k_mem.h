@@ -32,6 +32,11 @@ __device__ __forceinline__ uint2 buf_load64(const BufRef& b, uint32_t off) {
     u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(b.rsrc, off, 0, 0);
     return make_uint2(t.x, t.y);
 }
+__device__ __forceinline__ void buf_store64(const BufRef& b, uint32_t off, const uint2& e) {
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t t = {e.x, e.y};
+    __builtin_amdgcn_raw_buffer_store_b64(t, b.rsrc, off, 0, 0);
+}
 __device__ __forceinline__ uint4 buf_load128(const BufRef& b, uint32_t off) {
     u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, off, 0, 0);
     return make_uint4(t.x, t.y, t.z, t.w);
@@ -85,6 +90,9 @@ __device__ __forceinline__ uint64_t mul_pow2p1(uint64_t v) {
     asm("v_lshl_add_u64 %0, %1, %2, %1" : "=v"(p) : "v"(v), "n"(K_));
     return p;
 }
+
+// true when `p` holds in every active lane of the wave (a scalar: branches on it are uniform)
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
 
 // the threads of a workgroup share the copy of the workload tables into LDS: thread t copies words t, t + stride, ...
 __device__ __forceinline__ uint32_t table_copy_first() { return threadIdx.x; }

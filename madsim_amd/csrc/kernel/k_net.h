@@ -122,17 +122,24 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
         const bool rsp = rpc && tag == 0xff;
         uint32_t i = 0;
         bool taken = false;                                // (one loop exit, no early returns: see k_main.h)
-        bool first = pf != nullptr;                        // the prefetched registration is entry 0 as it was before any removal
+        // Global-state builds: `known` = the value of entry i is in `r_known` — the prefetched entry 0 before any removal, and after a
+        // swap_remove the entry just moved into position i.  A dead registration (a timed-out receive: the election loop's mailboxes
+        // are full of them) then costs ONE round trip — its task's words and the entry to move, requested together — not three
+        // (entry, entry to move, task words, each waiting for the one before).
+        bool known = pf != nullptr;
+        uint32_t r_known = pf ? pf->reg0 : 0u;
         while (i < nreg && !taken) {
             REG(24);
-            uint32_t r = first ? pf->reg0 : (uint32_t)SW(c, s, 2 + i);
-            first = false;
+            uint32_t r = known ? r_known : (uint32_t)SW(c, s, 2 + i);
+            known = false;
             if ((r & 0xff) == tag && (!rsp || (r >> 8) == (val >> 8))) {
                 nreg--;
-                SW(c, s, 2 + i) = SW(c, s, 2 + nreg);      // swap_remove
                 uint32_t slot = (r >> 8) & 0xff, rxseq = (r >> 16) & 0xff, g8 = r >> 24;
+                const uint32_t moved = SW(c, s, 2 + nreg);  // swap_remove: the three loads first, then the store
                 uint4 u0 = TU(c, slot, 0);
                 uint32_t link = TWORD(c, slot, 1, 0);
+                SW(c, s, 2 + i) = moved;
+                if (K::G) { known = true; r_known = moved; }
                 if ((u0.x & TF_ALIVE) && ((u0.x >> 8) & 0xff) == g8 && (link & 0xff) == rxseq && !(u0.x & TF_INBOX)) {
                     // oneshot::Sender::send Ok -> value stored, receiver task woken [DEP tokio oneshot]
                     bool sched = u0.x & TF_SCHED;

@@ -75,7 +75,7 @@ __device__ __forceinline__ bool is_light(uint32_t op) {
 // expensive primitives (RNG draws, heap pushes, link test, mailbox scan) sit at fixed points that the
 // whole wave reaches at the same time.
 template <class K>
-__device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t slot, uint4& u0, uint4 u1) {
+__device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t slot, uint4& u0, uint4 u1, PollPrefetch pp) {
     enum : uint32_t { ST_RUN = 0, ST_PENDING = 1, ST_FINISHED = 2, ST_PANIC = 3 };
     const KParams& P = c.P;
     bool u1_dirty = false;
@@ -90,6 +90,13 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     // (`first_poll`: the call is the op's first poll, from [C] — every Sleep it registers is new; on later polls a Sleep that
     // was pending before registers its timer AGAIN: the `again` argument of timer_schedule, k_timer.h dedup_note)
     bool first_poll = false;
+    // this task's connection unit: global-state builds hold it in registers for the poll (it came with unit 0: k_state.h
+    // PollPrefetch) and write through; the other builds read LDS as before
+    constexpr bool CU_FULL = K::G && K::FEAT == MADSIM_FEAT_CHAN;      // (else word 0 only: k_state.h poll_prefetch)
+    auto cu_get = [&]() -> uint4 { if (CU_FULL) return pp.cu; return (uint4)TU(c, slot, c.P.chan_unit); };
+    auto cu0_get = [&]() -> uint32_t { if (K::G) return pp.cu.x; return (uint32_t)TWORD(c, slot, c.P.chan_unit, 0); };
+    auto cu0_set = [&](uint32_t v) { if (K::G) pp.cu.x = v; TWORD(c, slot, c.P.chan_unit, 0) = v; };
+    auto cu_set = [&](const uint4& v) { if (CU_FULL) pp.cu = v; else if (K::G) pp.cu.x = v.x; TU(c, slot, c.P.chan_unit) = v; };
     auto recv_timeout_poll = [&]() -> bool {
         bool fut_ready = false;
         bool d1_new = false;
@@ -108,8 +115,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             else timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true, !d1_new);
         }
         if (fut_ready) return true;                          // Ok((len, from))
-        uint4 u2 = TU(c, slot, 2);
-        uint64_t d2 = u64of(u2.z, u2.w);
+        uint64_t d2;
+        if (K::G) d2 = u64of(pp.d2lo, pp.d2hi);              // (came with unit 0: k_state.h PollPrefetch)
+        else { uint4 u2 = TU(c, slot, 2); d2 = u64of(u2.z, u2.w); }
         if (L.clock >= d2) {                                 // Err(Elapsed): the recv future is dropped
             u1.x = (u1.x & ~0xffu) | (((u1.x & 0xff) + 1) & 0xff); u1_dirty = true;   // its oneshot::Receiver is gone
             if ((u1.x & 0xff) == 0) u0.x |= TF_RXWRAP;
@@ -147,10 +155,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 }
                 uint32_t lb = 0, to_idx = dst, to_addr = SOCKW(c, dst);
                 if (!hooked) ipvs_rewrite<K>(c, to_idx, to_addr);          // after the hook, before try_send (net/mod.rs:312-317)
-                const int sent = hooked ? 0 : net_try_send<K>(c, L, SOCKW(c, ca) & 0xff, to_addr, to_idx, &lat, &ds, &lb);
+                uint32_t dh = 0;
+                const int sent = hooked ? 0 : net_try_send<K>(c, L, SOCKW(c, ca) & 0xff, to_addr, to_idx, &lat, &ds, &lb, &dh);
                 if (sent < 0) { st = ST_PANIC; return true; }
                 if (sent) {
-                    uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
+                    uint32_t sgen = (dh >> 1) & 0xff;
                     uint32_t meta = (EV_DELIVER << EV_SHIFT) | (sgen << 21) | ((cb >> 8) << 13) | ((ca | (lb << 6)) << 6) | (uint32_t)ds;
                     timer_schedule<K>(c, L, L.clock + lat, meta, (cimm & 0xff) | (reg & 0xffffff00u), false);
                 }
@@ -187,8 +196,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             timer_schedule<K>(c, L, d1, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, 0, true, !d1_new);
         }
         if (cimm >> 8) {
-            uint4 u2 = TU(c, slot, 2);
-            uint64_t d2 = u64of(u2.z, u2.w);
+            uint64_t d2;
+            if (K::G) d2 = u64of(pp.d2lo, pp.d2hi);
+            else { uint4 u2 = TU(c, slot, 2); d2 = u64of(u2.z, u2.w); }
             if (L.clock >= d2) {                             // Err(Elapsed) -> TimedOut: the call future is dropped
                 if (sub >= 2) { u1.x = (u1.x & ~0xffu) | (((u1.x & 0xff) + 1) & 0xff); u1_dirty = true; u0.x &= ~TF_INBOX; if ((u1.x & 0xff) == 0) u0.x |= TF_RXWRAP; }
                 u0.w = MADSIM_VAL_TIMEOUT;
@@ -203,14 +213,16 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     // accept1's conn_rx.recv() (endpoint.rs:200): take the oldest queued connection or park. true = op completed.
     auto accept_check = [&](uint32_t a) -> bool {
         uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
-        uint32_t n = SW(c, a, base) & 0xf;
+        const uint32_t q_lo = SW(c, a, base);
+        const uint32_t q_hi = Hoist<K>::CHAN ? (uint32_t)SW(c, a, base + 2) : 0u;      // (global-state builds: both halves of the queue word at once)
+        uint32_t n = q_lo & 0xf;
         if (n == 0) { SW(c, a, base + 1) = 1u | (slot << 1) | (gen << 9); st = ST_PENDING; return false; }
-        uint64_t q = acceptq_load<K>(c, a);
+        uint64_t q = Hoist<K>::CHAN ? u64of(q_lo, q_hi) : acceptq_load<K>(c, a);
         uint32_t id = (uint32_t)(q >> 4) & 0x7f;
         acceptq_store<K>(c, a, (uint64_t)(n - 1) | ((q >> 11) << 4));           // pop front
-        uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+        uint32_t cx = cu0_get();
         if ((cx & 0xff) != 0xff) conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0);
-        TWORD(c, slot, c.P.chan_unit, 0) = id | (1u << 8);                 // server side
+        cu0_set(id | (1u << 8));                                           // server side
         // Sender { _guard: self.guard.clone(), tx }, Receiver { _guard: self.guard.clone(), rx } (endpoint.rs:203-210)
         CONNW(id, 0) = (CONNW(id, 0) & ~(0x7fu << 25)) | (a << 25) | (1u << 31);
         guard_acquire<K>(c, L, a);
@@ -218,8 +230,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     };
     // the receiver stream of channel() (net/mod.rs:386-400) from "a payload is in hand" (sub 1): either sleep(backoff)
     // while its State is None (sub 2) or sleep_until(arrive_time) (sub 3).  Always ends Pending (1 ms floor).
-    auto crecv_arm = [&]() {
-        uint4 u3 = TU(c, slot, c.P.chan_unit);
+    auto crecv_arm = [&](const uint4& u3) {
         uint64_t arrive = u64of(u3.z, u3.w), d;
         if (arrive != ~0ull) { d = sleep_deadline(L, arrive); sub = 3; }
         else { d = sleep_deadline(L, L.clock + (uint64_t)(u3.x >> 16) * NS_PER_MS); sub = 2; }
@@ -272,7 +283,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     sub = 2;
                     accept_check(a);                       // (false: st is Pending)
                 } else if (K::FC && op == MS_OP_CRECV) {
-                    uint4 u3 = TU(c, slot, c.P.chan_unit);
+                    uint4 u3 = cu_get();
                     if (sub == 2) {                        // sleep(backoff) done: backoff = min(2 * backoff, 10 s); retry the link
                         uint32_t bo = (u3.x >> 16) * 2; if (bo > 10000) bo = 10000;
                         uint32_t cw = CONNW(u3.x & 0xff, 0);
@@ -280,18 +291,19 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         if (arrive == CHAN_LINK_PANIC) st = ST_PANIC;
                         else {
                             u3.x = (u3.x & 0xffff) | (bo << 16); u3.z = (uint32_t)arrive; u3.w = (uint32_t)(arrive >> 32);
-                            TU(c, slot, c.P.chan_unit) = u3;
-                            crecv_arm();                   // (always ends Pending)
+                            cu_set(u3);
+                            crecv_arm(u3);                 // (always ends Pending)
                         }
                     }
                     else u0.w = u3.y;                      // sub 3: sleep_until(arrive_time) done -> yield value
                 } else if (K::FC && op == MS_OP_CONNECT) {   // NetSim::connect1 (net/mod.rs:345-363)
-                    uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
-                    if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
+                    uint32_t cx = cu0_get();
+                    if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0); cu0_set(cx | 0xff); }
                     uint64_t lat; int ds; uint32_t lb;
                     uint32_t dial = b & 0xff, dial_addr = SOCKW(c, dial);
                     ipvs_rewrite<K>(c, dial, dial_addr);          // channel() below is built from the rewritten dst (net/mod.rs:345-357)
-                    const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dial_addr, dial, &lat, &ds, &lb);
+                    uint32_t dh;
+                    const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dial_addr, dial, &lat, &ds, &lb, &dh);
                     if (sent < 0) st = ST_PANIC;
                     else if (!sent) {
                         u0.w = MADSIM_VAL_REFUSED;
@@ -304,7 +316,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         else {
                             CONNW(id, 0) = 1u | (a << 1) | (dial << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
-                            TWORD(c, slot, c.P.chan_unit, 0) = id;             // client side
+                            cu0_set(id);                                        // client side
                             guard_acquire<K>(c, L, a);             // Sender / Receiver { _guard: self.guard.clone(), .. } (endpoint.rs:181-190)
                             u0.w = 0;
                             if (SW(c, ds, 1) == ~0u) {             // the listener's Endpoint is gone (connections it accepted hold the
@@ -363,11 +375,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     }
                     // Network::try_send -> resolve_dest_node, test_link, socket lookup (network.rs:261-313)
                     uint64_t lat; int ds; uint32_t lb;
-                    const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dst_addr, dst, &lat, &ds, &lb);
+                    uint32_t dh = 0;
+                    const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dst_addr, dst, &lat, &ds, &lb, &dh);
                     if (sent < 0) st = ST_PANIC;
                     else if (sent) {
                         {
-                            uint32_t sgen = (SW(c, ds, 0) >> 1) & 0xff;
+                            uint32_t sgen = (dh >> 1) & 0xff;
                             uint2 ev = ev_deliver_meta<K>(sgen, b >> 8, a | (lb << 6), (uint32_t)ds, imm, pc);
                             if (K::FR && P.uses_hooks && op == MS_OP_RPC_REPLY) {
                                 // hooks_rsp.get(&dst_node) is cloned now and judges the message when the timer fires
@@ -482,9 +495,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         } else if (K::FT && op == MS_OP_RECV_TIMEOUT) {
             uint32_t tag = b >> 8;
             uint64_t d2 = sleep_deadline(L, L.clock + (uint64_t)(b & 0xff) * NS_PER_S + imm);   // timeout()'s Sleep
-            uint4 u2 = TU(c, slot, 2);
-            u2.z = (uint32_t)d2; u2.w = (uint32_t)(d2 >> 32);
-            TU(c, slot, 2) = u2;
+            if (K::G) { buf_store64(c.gs, gs_addr_task(c, slot, 2 * 16u + 8u), make_uint2((uint32_t)d2, (uint32_t)(d2 >> 32))); pp.d2lo = (uint32_t)d2; pp.d2hi = (uint32_t)(d2 >> 32); }
+            else { uint4 u2 = TU(c, slot, 2); u2.z = (uint32_t)d2; u2.w = (uint32_t)(d2 >> 32); TU(c, slot, 2) = u2; }
             uint32_t rxseq = ((u1.x & 0xff) + 1) & 0xff;       // Mailbox::recv (endpoint.rs:353-362)
             u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
             if (rxseq == 0) u0.x |= TF_RXWRAP;
@@ -518,9 +530,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         } else if (K::FR && op == MS_OP_RPC_CALL) {          // first poll of timeout(d, ep.call(dst, req)) / ep.call(dst, req)
             if (imm >> 8) {                                    // timeout()'s Sleep exists before the call is polled
                 uint64_t d2 = sleep_deadline(L, L.clock + (uint64_t)(imm >> 8) * NS_PER_MS);
-                uint4 u2 = TU(c, slot, 2);
-                u2.z = (uint32_t)d2; u2.w = (uint32_t)(d2 >> 32);
-                TU(c, slot, 2) = u2;
+                if (K::G) { buf_store64(c.gs, gs_addr_task(c, slot, 2 * 16u + 8u), make_uint2((uint32_t)d2, (uint32_t)(d2 >> 32))); pp.d2lo = (uint32_t)d2; pp.d2hi = (uint32_t)(d2 >> 32); }
+                else { uint4 u2 = TU(c, slot, 2); u2.z = (uint32_t)d2; u2.w = (uint32_t)(d2 >> 32); TU(c, slot, 2) = u2; }
             }
             (void)rng_next(L); rng_log<K>(c, L);               // rsp_tag = random::<u64>(): one with() (rand.rs:146-148)
             uint64_t d1 = rand_delay_deadline<K>(c, L);        // send_to_raw -> NetSim::send: rand_delay first
@@ -575,9 +586,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 const bool via = (PROGW(c, a) & 0xff) != node;
                 uint32_t child = spawn_task<K>(c, L, a, true, via, via ? -1 : (int)slot);
                 if (K::FC && P.uses_chan && (b & 2) && child != 0xffffffffu) {   // `async move`: the (tx, rx) pair moves
-                    uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                    uint32_t cx = cu0_get();
                     TWORD(c, child, c.P.chan_unit, 0) = cx & 0x1ff;
-                    TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff;
+                    cu0_set(cx | 0xff);
                 }
                 if (K::FR && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST) && child != 0xffffffffu) {   // rpc.rs:170
                     TWORD(c, child, 0, 3) = u0.w;
@@ -722,10 +733,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             case MS_OP_CSEND: {                            // PayloadSender::send (net/mod.rs:417-421)
                 if (!K::FC) { st = ST_PANIC; break; }
-                uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                uint32_t cx = cu0_get();
                 if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
                 uint32_t id = cx & 0xff, side = (cx >> 8) & 1;
                 uint32_t cw = CONNW(id, 0);
+                const uint32_t r_pre = Hoist<K>::CHAN ? (uint32_t)CONNW(id, 1 + side) : 0;   // (global-state builds: the parked receiver's word with the header, not after the link test)
                 uint64_t arrive = chan_test_link<K>(c, L, cw, side);          // draws happen before the closed check
                 if (arrive == CHAN_LINK_PANIC) { st = ST_PANIC; break; }
                 if (!(cw & (1u << (14 + 2 * side)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // ConnectionReset
@@ -734,17 +746,21 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 uint32_t e = 3 + (side * P.chan_queue + qn) * 3;
                 CONNW(id, e) = imm; CONNW(id, e + 1) = (uint32_t)arrive; CONNW(id, e + 2) = (uint32_t)(arrive >> 32);
                 CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * side))) | ((qn + 1) << (17 + 4 * side));
-                uint32_t r = CONNW(id, 1 + side);
+                uint32_t r = Hoist<K>::CHAN ? r_pre : (uint32_t)CONNW(id, 1 + side);
                 if (r & 1) { CONNW(id, 1 + side) = 0; wake<K>(c, L, (r >> 1) & 0xff, r >> 9); }   // mpsc wakes the parked receiver
                 pc++;
                 break;
             }
             case MS_OP_CRECV: {                            // rx.recv().await (net/mod.rs:386), sub == 0 here
                 if (!K::FC) { st = ST_PANIC; break; }
-                uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+                uint32_t cx = cu0_get();
                 if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
                 uint32_t id = cx & 0xff, dir = 1 - ((cx >> 8) & 1);
                 uint32_t cw = CONNW(id, 0);
+                // (global-state builds: the oldest queued payload's three words go out with the header — one round trip, not two)
+                const uint32_t e0 = 3 + dir * P.chan_queue * 3;
+                uint32_t h0 = 0, h1 = 0, h2 = 0;
+                if (Hoist<K>::CHAN) { h0 = CONNW(id, e0); h1 = CONNW(id, e0 + 1); h2 = CONNW(id, e0 + 2); }
                 uint32_t qn = (cw >> (17 + 4 * dir)) & 0xf;
                 if (qn == 0) {
                     if (!(cw & (1u << (13 + 2 * dir)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // all senders gone
@@ -752,19 +768,21 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     st = ST_PENDING;
                     break;
                 }
-                uint32_t e0 = 3 + dir * P.chan_queue * 3;
-                uint4 u3 = make_uint4((cx & 0x1ff) | (1u << 16), CONNW(id, e0), CONNW(id, e0 + 1), CONNW(id, e0 + 2));   // backoff = 1 ms
-                for (uint32_t i = 1; i < qn; i++)              // VecDeque::pop_front
-                    for (uint32_t k = 0; k < 3; k++) CONNW(id, e0 + (i - 1) * 3 + k) = CONNW(id, e0 + i * 3 + k);
+                if (!Hoist<K>::CHAN) { h0 = CONNW(id, e0); h1 = CONNW(id, e0 + 1); h2 = CONNW(id, e0 + 2); }
+                uint4 u3 = make_uint4((cx & 0x1ff) | (1u << 16), h0, h1, h2);   // backoff = 1 ms
+                for (uint32_t i = 1; i < qn; i++) {            // VecDeque::pop_front (an entry's three loads first, then its three stores)
+                    const uint32_t m0 = CONNW(id, e0 + i * 3), m1 = CONNW(id, e0 + i * 3 + 1), m2 = CONNW(id, e0 + i * 3 + 2);
+                    CONNW(id, e0 + (i - 1) * 3) = m0; CONNW(id, e0 + (i - 1) * 3 + 1) = m1; CONNW(id, e0 + (i - 1) * 3 + 2) = m2;
+                }
                 CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * dir))) | ((qn - 1) << (17 + 4 * dir));
-                TU(c, slot, c.P.chan_unit) = u3;
-                crecv_arm();
+                cu_set(u3);
+                crecv_arm(u3);
                 break;
             }
             case MS_OP_CCLOSE: {
                 if (!K::FC) { st = ST_PANIC; break; }
-                uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
-                if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
+                uint32_t cx = cu0_get();
+                if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0); cu0_set(cx | 0xff); }
                 pc++;
                 break;
             }

@@ -332,6 +332,27 @@ template <class K> __device__ __forceinline__ uint4 load_u1(const Ctx& c, uint32
     else t = LDS64(c.task1 + (slot << LWSH<K>(c)));
     return make_uint4(t.x, t.y, 0, 0);
 }
+// Global-state builds: words of the polled task's granule beyond units 0 and 1 that its poll is likely to want, loaded with
+// them before the ready-queue draw (k_main.h) — the same 64- or 128-byte line, so they arrive with unit 0 instead of costing the
+// poll a dependent round trip of their own:  d2 = timeout()'s deadline (unit 2 z/w; k_poll.h recv_timeout_poll, rpc_call_poll).
+// poll_task keeps the copies current through its own writes; nobody else writes these words of a task that is being polled.
+// cu = the connection unit {conn | side | backoff, staged payload, arrive} (k_poll.h: every channel op starts from it).
+// Load hoists that cost a register each across a handler (k_channel.h, k_poll.h channel ops): the channel-only global-state builds
+// take them; the builds with every op class spill registers already and keep the lazy reads.
+template <class K> struct Hoist { static constexpr bool CHAN = K::G && K::FEAT == MADSIM_FEAT_CHAN; };
+struct PollPrefetch { uint32_t d2lo, d2hi; uint4 cu; };
+__device__ __forceinline__ bool has_t0_unit(const KParams& P) { return P.task_units > 2 && !(P.uses_chan && P.chan_unit == 2); }   // geometry.h `t0`
+template <class K> __device__ __forceinline__ PollPrefetch poll_prefetch(const Ctx& c, uint32_t slot) {
+    PollPrefetch pp = {0, 0, make_uint4(0, 0, 0, 0)};
+    if (K::G && K::FT && has_t0_unit(c.P)) { const uint2 t = buf_load64(c.gs, gs_addr_task(c, slot, 2 * 16u + 8u)); pp.d2lo = t.x; pp.d2hi = t.y; }
+    // (the whole unit in the channel-only builds; the builds that carry every op class are short of registers: word 0 only, the
+    // rest is read where it is wanted — k_poll.h cu_get)
+    if (K::G && K::FC && c.P.uses_chan) {
+        if (K::FEAT == MADSIM_FEAT_CHAN) pp.cu = gs_load128(c.gs, gs_addr_task(c, slot, c.P.chan_unit * 16u));
+        else pp.cu.x = gs_load32(c.gs, gs_addr_task(c, slot, c.P.chan_unit * 16u));
+    }
+    return pp;
+}
 #define TU(c_, slot_, u_) tu_ref<K>((c_), (slot_), (u_))
 #define TWORD(c_, slot_, u_, k_) tword_ref<K>((c_), (slot_), (u_), (k_))
 template <class K> __device__ __forceinline__ WRef<K::G> hw_ref_plain(const Ctx& c, uint32_t p) {

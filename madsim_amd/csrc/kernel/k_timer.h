@@ -50,10 +50,27 @@ __device__ __forceinline__ uint4 heap_get(const Ctx& c, const Lane& L, uint32_t 
         return i == 0 ? make_uint4((uint32_t)L.top_dl, (uint32_t)(L.top_dl >> 32), L.top_meta, 0) : make_uint4((uint32_t)d, (uint32_t)(d >> 32), e.y, 0);
     }
     if (!K::SPILL) return heap_lds_get<K>(c, i);
-    uint32_t cap = c.P.heap_lds;
-    uint4 v = heap_lds_get<K>(c, i < cap ? i : cap - 1);
-    if (i >= cap) v = spill_load(c, i - cap);
+    // (a branch, not an unconditional LDS read of a clamped index overwritten by the spilled value: that form made every spilled
+    // access wait for an LDS round trip first — the compiler overwrites the LDS result's registers under the other lanes' mask and
+    // must see the LDS read complete before it may issue the buffer load.  Both sides are explicit address spaces — ds_* and
+    // buffer_* — so nothing can merge them into flat_* accesses.)
+    const uint32_t cap = c.P.heap_lds;
+    uint4 v;
+    if (i < cap) v = heap_lds_get<K>(c, i); else v = spill_load(c, i - cap);
     return v;
+}
+// Two entries lo < hi at once (the children of a sift-down level; parent and grandparent of a sift-up trip, hi = the deeper one):
+// when both are spilled — every level below the LDS part of the heap — the two buffer loads go out back to back with no LDS
+// access between them.
+template <class K>
+__device__ __forceinline__ void heap_get2(const Ctx& c, const Lane& L, uint32_t lo, uint32_t hi, uint4& vlo, uint4& vhi) {
+    if (K::SPILL && !K::CMP) {
+        const uint32_t cap = c.P.heap_lds;
+        if (lo >= cap) { vlo = spill_load(c, lo - cap); vhi = spill_load(c, hi - cap); }
+        else { vlo = heap_lds_get<K>(c, lo); vhi = heap_get<K>(c, L, hi); }
+        return;
+    }
+    vlo = heap_get<K>(c, L, lo); vhi = heap_get<K>(c, L, hi);
 }
 template <class K>
 __device__ __forceinline__ void heap_set(const Ctx& c, Lane& L, uint32_t i, const uint4& e) {
@@ -83,10 +100,11 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos
     while (up) {                                       // (one exit: see k_main.h)
         REG(11);
         const uint32_t parent = (pos - 1) >> 1;
-        const uint4 p = heap_get<K>(c, L, parent);
         if (K::SPILL) {
             const uint32_t gp = parent > 0 ? (parent - 1) >> 1 : 0;
-            const uint4 g = heap_get<K>(c, L, gp);
+            uint4 p, g;
+            if (parent > 0) heap_get2<K>(c, L, gp, parent, g, p);
+            else { p = heap_get<K>(c, L, 0); g = p; }
             up = hd < (parent == 0 ? L.top_dl : ev_deadline(p));
             if (up) {
                 heap_set<K>(c, L, pos, p); pos = parent;
@@ -94,6 +112,7 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos
                 if (up) { heap_set<K>(c, L, pos, g); pos = gp; up = pos > 0; }
             }
         } else {
+            const uint4 p = heap_get<K>(c, L, parent);
             // hole <= parent in heap order: stop (the root's deadline is mirrored in a register)
             up = hd < (parent == 0 ? L.top_dl : ev_deadline(p));
             if (up) { heap_set<K>(c, L, pos, p); pos = parent; up = pos > 0; }
@@ -197,7 +216,8 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
         uint4 m = item;                                     // the entry last moved up: it now sits at parent(pos)
         while (child + 1 < end) {
             REG(21);
-            uint4 l = heap_get<K>(c, L, child), r = heap_get<K>(c, L, child + 1);
+            uint4 l, r;
+            heap_get2<K>(c, L, child, child + 1, l, r);
             bool right = ev_deadline(l) >= ev_deadline(r);   // left <= right in heap order: take right
             m = right ? r : l;
             heap_set<K>(c, L, pos, m);

@@ -47,6 +47,7 @@ void emu_site(int kind, const void* base, uint32_t off);
 static inline uint32_t buf_load32(const BufRef& b, uint32_t off) { EMU_SITE(0, b, off); return *(const uint32_t*)(b.base + off); }
 static inline void buf_store32(const BufRef& b, uint32_t off, uint32_t v) { EMU_SITE(1, b, off); *(uint32_t*)(b.base + off) = v; }
 static inline uint2 buf_load64(const BufRef& b, uint32_t off) { EMU_SITE(0, b, off); return *(const uint2*)(b.base + off); }
+static inline void buf_store64(const BufRef& b, uint32_t off, const uint2& e) { EMU_SITE(1, b, off); *(uint2*)(b.base + off) = e; }
 static inline uint4 buf_load128(const BufRef& b, uint32_t off) { EMU_SITE(2, b, off); return *(const uint4*)(b.base + off); }
 static inline void buf_store128(const BufRef& b, uint32_t off, const uint4& e) { EMU_SITE(3, b, off); *(uint4*)(b.base + off) = e; }
 template <int K_> static inline uint64_t rotl64(uint64_t x) { return (x << K_) | (x >> (64 - K_)); }
@@ -54,6 +55,7 @@ static inline uint64_t add64_1(uint64_t a, uint64_t b) { return a + b; }
 template <int K_> static inline uint64_t shl64(uint64_t x) { return x << K_; }
 template <int K_> static inline uint64_t mul_pow2p1(uint64_t v) { return (v << K_) + v; }
 static inline uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) { return a ^ b ^ c; }
+static inline bool wave_all(bool p) { return p; }                        // (one emulated lane at a time: results may not depend on the vote)
 static inline uint32_t table_copy_first() { return 0; }                   // emulated threads run one after another:
 static inline uint32_t table_copy_stride(uint32_t) { return 1; }          // each copies everything
 }

@@ -10,7 +10,7 @@
 #   bench:<args>      python bench.py <args with ',' for spaces>, e.g. bench:--workload,raft,--steps,12
 #   line:<wl>[:<steps>]  one bench line of workload <wl> without the extra legs (fast A/B)
 #   prof:<wl>[:full]  tools/prof_workload.sh on workload <wl> (kernel-trace --stats + PMC passes; full adds FETCH/WRITE)
-#   phase:<wl>        tools/phase_prof.py on workload <wl> (in-kernel s_memtime probes of an EXP_PROF build)
+#   phase:<wl>[:<n>[:<tag>]]  tools/phase_prof.py on workload <wl> (in-kernel s_memtime probes of an EXP_PROF build), n batches in flight, libmadsim_hip_<tag>.so
 #   fuzz[:<seconds>[:<generators>]]  tools/fuzz_campaign.py with a clock-derived base seed
 #   ab:<wl>:<steps>   every madsim_amd/libmadsim_hip*.so back to back on workload <wl> (A/B builds from tools/build_variant.sh)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -52,7 +52,8 @@ for st in "$@"; do
       args=""; [ "$a1" != pingpong ] && args="--workload $a1"
       bash tools/prof_workload.sh "$TAG/prof_$a1" "$args" "$a2"; tail -14 "$O/prof_$a1/summary.txt";;
     phase)   # needs madsim_amd/libmadsim_hip_prof.so (tools/build_variant.sh prof -DEXP_PROF), built before the call
-      MADSIM_HIP_LIB=$PWD/madsim_amd/libmadsim_hip_prof.so timeout 300 python tools/phase_prof.py "$a1" > "$O/phase_$a1.txt" 2>&1; cat "$O/phase_$a1.txt";;
+      # phase:<wl>[:<batches in flight>[:<lib tag>]] — 0 batches in flight = one launch alone; lib tag picks libmadsim_hip_<tag>.so (default prof)
+      PROF_STREAMS=${a2:-0} MADSIM_HIP_LIB=$PWD/madsim_amd/libmadsim_hip_${a3:-prof}.so timeout 300 python tools/phase_prof.py "$a1" > "$O/phase_${a1}_${a2:-0}_${a3:-prof}.txt" 2>&1; cat "$O/phase_${a1}_${a2:-0}_${a3:-prof}.txt";;
     fuzz)
       timeout $(( ${a1:-90} + 120 )) python tools/fuzz_campaign.py "${a1:-90}" "$(( $(date +%s) * 1000 ))" $a2 > "$O/fuzz.txt" 2>&1; tail -2 "$O/fuzz.txt";;
     ab)

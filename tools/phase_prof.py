@@ -13,7 +13,22 @@ out = (C.c_uint64 * 16)()
 L = runtime.lib()
 runtime.run_batch_device(w, 0, 65536, buf.data_ptr(), 0, None, lim)
 L.madsim_hip_debug_counters(out)
-s = runtime.run_batch_device(w, 65536, 65536, buf.data_ptr(), 0, None, lim)
+ns = int(os.environ.get("PROF_STREAMS", "0"))          # > 0: that many batches in flight, PROF_ROUNDS rounds (the loaded regime of bench.py)
+if ns:
+    import time
+    streams = [torch.cuda.Stream() for _ in range(ns)]
+    bufs = [torch.empty(65536 * 48, dtype=torch.uint8, device="cuda") for _ in range(ns)]
+    rounds = int(os.environ.get("PROF_ROUNDS", "3"))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for r in range(rounds):
+        for i, st in enumerate(streams):
+            runtime.run_batch_async(w, (2 + r * ns + i) * 65536, 65536, bufs[i].data_ptr(), 0, st.cuda_stream, None, lim)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    class S: kernel_ms = dt * 1e3 / (rounds * ns)
+    s = S()
+    print(f"{ns} batches in flight, {rounds} rounds: {s.kernel_ms:.3f} ms wall time per batch")
+else:
+    s = runtime.run_batch_device(w, 65536, 65536, buf.data_ptr(), 0, None, lim)
 L.madsim_hip_debug_counters(out)
 v = list(out)
 names = ["loop top/seed init+result", "idx draw + ready pop + task load", "poll_task exit (writeback u1)", "writeback + advance draw", "fire/idle loop",
