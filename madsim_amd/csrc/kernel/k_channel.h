@@ -127,12 +127,14 @@ __device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_
 // count the live (Sender, Receiver) pairs of a socket; an Endpoint dropped while that count is non-zero leaves the marker
 // ~0 in the owner word instead of unbinding.  BindGuard::drop runs with the last owner and does nothing when the binder's
 // NodeInfo is killed (net/mod.rs:483-493): reset_node has emptied the table — and the counts — by then.
+// (`h` = the socket's header word, when the caller holds it)
 template <class K>
-__device__ __forceinline__ void guard_acquire(const Ctx& c, Lane& L, uint32_t s) {
-    const uint32_t h = SW(c, s, 0);
+__device__ __forceinline__ void guard_acquire_with(const Ctx& c, Lane& L, uint32_t s, uint32_t h) {
     if ((h >> 25) == 0x7fu) { L.ovf |= OVF_CAP; return; }            // (a seven-bit count: 127 connection ends per socket)
     SW(c, s, 0) = h + (1u << 25);
 }
+template <class K>
+__device__ __forceinline__ void guard_acquire(const Ctx& c, Lane& L, uint32_t s) { guard_acquire_with<K>(c, L, s, SW(c, s, 0)); }
 template <class K>
 __device__ __forceinline__ void guard_release(const Ctx& c, Lane& L, uint32_t s, bool node_killed) {
     if (node_killed) return;

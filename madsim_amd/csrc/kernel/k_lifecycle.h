@@ -52,11 +52,12 @@ template <class K> __device__ __forceinline__ void endpoint_drop(const Ctx& c, L
 template <class K> __device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_t s);
 
 // The locals of a task body drop: its (Sender, Receiver) pair, then the Endpoints it holds (table order).  `f` = its flag word.
+// (`known` / `cx_known`: the caller holds word 0 of the task's connection unit — the task that finishes inside its own poll)
 template <class K>
-__device__ __forceinline__ void task_drop_locals(const Ctx& c, Lane& L, uint32_t slot, uint32_t f) {
+__device__ __forceinline__ void task_drop_locals(const Ctx& c, Lane& L, uint32_t slot, uint32_t f, bool known = false, uint32_t cx_known = 0) {
     const uint32_t gen = (f >> 8) & 0xffff;
     if (K::FC && c.P.uses_chan) {
-        uint32_t cx = TWORD(c, slot, c.P.chan_unit, 0);
+        uint32_t cx = known ? cx_known : (uint32_t)TWORD(c, slot, c.P.chan_unit, 0);
         if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (f & TF_KILLED) != 0); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
     }
     if (f & TF_OWNER) {
@@ -79,15 +80,20 @@ __device__ __forceinline__ void task_drop_guard(const Ctx& c, Lane& L, uint32_t 
 }
 
 // The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
+// `kn` (global-state builds, the task that completes inside its own poll — MS_OP_DONE): the words of the task the poll holds in
+// registers and has just written back — flag word, awaiter link (unit 1 word 0), connection word — instead of three dependent reads.
+struct FinishKnown { bool have; uint32_t f, link, cx; };
 template <class K>
-__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome, bool guard = true) {
-    uint32_t f = TWORD(c, slot, 0, 0);
+__device__ __forceinline__ uint32_t task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome, bool guard = true, FinishKnown kn = FinishKnown{false, 0, 0, 0}) {
+    uint32_t f = kn.have ? kn.f : (uint32_t)TWORD(c, slot, 0, 0);
     uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
-    task_drop_locals<K>(c, L, slot, f);
+    const uint32_t h_pre = kn.have ? (uint32_t)HW(prog) : 0u;       // (requested before the locals drop: it arrives with their first read)
+    task_drop_locals<K>(c, L, slot, f, kn.have, kn.cx);
     if (guard) task_drop_guard<K>(c, L, slot, prog);
-    uint32_t h = HW(prog);
+    // (h_pre stays valid: between its read and here only this task's own locals dropped — no JoinHandle word is written by that)
+    uint32_t h = kn.have && !(K::FN && K::FA) ? h_pre : (uint32_t)HW(prog);
     if (h == (H_RUNNING | (slot << 8) | (gen << 16))) { HW(prog) = (h & ~3u) | outcome; if (prog == 0) L.main_done = 1; }
-    uint32_t link = TWORD(c, slot, 1, 0);
+    uint32_t link = kn.have ? kn.link : (uint32_t)TWORD(c, slot, 1, 0);
     TWORD(c, slot, 0, 0) = f & ~(TF_ALIVE | TF_SCHED | TF_RUN | TF_INBOX);
     if (K::G) AMASK(slot >> 5) &= ~(1u << (slot & 31));
     uint32_t j = (link >> 8) & 0xff;
@@ -99,6 +105,7 @@ __device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot
         }
         wake<K>(c, L, j, link >> 16);
     }
+    return f & ~(TF_ALIVE | TF_SCHED | TF_RUN | TF_INBOX);       // the flag word as this call left it
 }
 
 // NodeInfo::kill (task/mod.rs:133-140): mark + wake every live task holding NodeInfo `info_gen` of `node`, in
@@ -125,7 +132,7 @@ __device__ __forceinline__ void info_kill(const Ctx& c, Lane& L, uint32_t node, 
 }
 
 template <class K>
-__device__ __forceinline__ void task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome, bool guard);
+__device__ __forceinline__ uint32_t task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome, bool guard, FinishKnown kn);
 
 // node.paused.clear() (task/mod.rs:365,392): the parked Runnables of `node` are dropped, in order.
 template <class K>

@@ -214,18 +214,24 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     auto accept_check = [&](uint32_t a) -> bool {
         uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
         const uint32_t q_lo = SW(c, a, base);
-        const uint32_t q_hi = Hoist<K>::CHAN ? (uint32_t)SW(c, a, base + 2) : 0u;      // (global-state builds: both halves of the queue word at once)
+        const uint32_t q_hi = Hoist<K>::CHAN ? (uint32_t)SW(c, a, base + 2) : 0u;      // (global-state builds: both halves of the queue word at once,
+        uint32_t ha = Hoist<K>::CHAN ? (uint32_t)SW(c, a, 0) : 0u;                     //  and the header guard_acquire wants below)
         uint32_t n = q_lo & 0xf;
         if (n == 0) { SW(c, a, base + 1) = 1u | (slot << 1) | (gen << 9); st = ST_PENDING; return false; }
         uint64_t q = Hoist<K>::CHAN ? u64of(q_lo, q_hi) : acceptq_load<K>(c, a);
         uint32_t id = (uint32_t)(q >> 4) & 0x7f;
         acceptq_store<K>(c, a, (uint64_t)(n - 1) | ((q >> 11) << 4));           // pop front
         uint32_t cx = cu0_get();
-        if ((cx & 0xff) != 0xff) conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0);
+        const uint32_t cw_p = Hoist<K>::CHAN ? (uint32_t)CONNW(id, 0) : 0u;           // (with the drop's reads below, if any)
+        if ((cx & 0xff) != 0xff) {
+            conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (u0.x & TF_KILLED) != 0);
+            if (Hoist<K>::CHAN) ha = SW(c, a, 0);                                      // (the drop may have released a guard of `a`)
+        }
         cu0_set(id | (1u << 8));                                           // server side
         // Sender { _guard: self.guard.clone(), tx }, Receiver { _guard: self.guard.clone(), rx } (endpoint.rs:203-210)
-        CONNW(id, 0) = (CONNW(id, 0) & ~(0x7fu << 25)) | (a << 25) | (1u << 31);
-        guard_acquire<K>(c, L, a);
+        // (the connection dropped above is another one — this one sat in the queue — so its header word read before the drop stands)
+        CONNW(id, 0) = ((Hoist<K>::CHAN ? cw_p : (uint32_t)CONNW(id, 0)) & ~(0x7fu << 25)) | (a << 25) | (1u << 31);
+        if (Hoist<K>::CHAN) guard_acquire_with<K>(c, L, a, ha); else guard_acquire<K>(c, L, a);
         return true;
     };
     // the receiver stream of channel() (net/mod.rs:386-400) from "a payload is in hand" (sub 1): either sleep(backoff)
@@ -309,22 +315,38 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         u0.w = MADSIM_VAL_REFUSED;
                     } else {
                         uint32_t id = 0;
-                        while (id < P.max_conns && (CONNW(id, 0) & 1)) id++;
                         uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
-                        uint64_t q = acceptq_load<K>(c, (uint32_t)ds);
+                        uint64_t q;
+                        uint32_t own_p = 0, acc_p = 0, ha_p = 0;
+                        if (Hoist<K>::CHAN) {
+                            // one round trip for everything the rest of the op reads: the first four connection headers (the free-slot
+                            // search), the listener's queue word, owner word and parked acceptor, this Endpoint's header.  What is
+                            // stored between here and their use — connection words, the guard count of `a` — touches none of them.
+                            const uint32_t c0 = CONNW(0, 0), c1 = P.max_conns > 1 ? (uint32_t)CONNW(1, 0) : 1u,
+                                           c2 = P.max_conns > 2 ? (uint32_t)CONNW(2, 0) : 1u, c3 = P.max_conns > 3 ? (uint32_t)CONNW(3, 0) : 1u;
+                            const uint32_t q_lo = SW(c, ds, base), q_hi = SW(c, ds, base + 2);
+                            own_p = SW(c, ds, 1); acc_p = SW(c, ds, base + 1); ha_p = SW(c, a, 0);
+                            q = u64of(q_lo, q_hi);
+                            id = !(c0 & 1) ? 0u : !(c1 & 1) ? 1u : !(c2 & 1) ? 2u : !(c3 & 1) ? 3u : 4u;
+                            while (id >= 4 && id < P.max_conns && (CONNW(id, 0) & 1)) id++;      // (beyond the first four: one at a time)
+                        } else {
+                            while (id < P.max_conns && (CONNW(id, 0) & 1)) id++;
+                            q = acceptq_load<K>(c, (uint32_t)ds);
+                        }
                         if (id >= P.max_conns || ((uint32_t)q & 0xf) >= MADSIM_ACCEPTQ) { L.ovf |= OVF_CAP; }
                         else {
                             CONNW(id, 0) = 1u | (a << 1) | (dial << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
                             cu0_set(id);                                        // client side
-                            guard_acquire<K>(c, L, a);             // Sender / Receiver { _guard: self.guard.clone(), .. } (endpoint.rs:181-190)
+                            if (Hoist<K>::CHAN) guard_acquire_with<K>(c, L, a, ha_p);
+                            else guard_acquire<K>(c, L, a);        // Sender / Receiver { _guard: self.guard.clone(), .. } (endpoint.rs:181-190)
                             u0.w = 0;
-                            if (SW(c, ds, 1) == ~0u) {             // the listener's Endpoint is gone (connections it accepted hold the
+                            if ((Hoist<K>::CHAN ? own_p : (uint32_t)SW(c, ds, 1)) == ~0u) {   // the listener's Endpoint is gone (connections it accepted hold the
                                 conn_drop_raw<K>(c, L, id, 1);     // address): `let _ = conn_tx.try_send(..)` drops (tx2, rx1) here
                             } else {
                                 uint32_t n = (uint32_t)q & 0xf;    // socket.new_connection -> conn_tx.try_send
                                 acceptq_store<K>(c, (uint32_t)ds, (q & ~0xfull) | (n + 1) | ((uint64_t)id << (4 + 7 * n)));
-                                uint32_t acc = SW(c, ds, base + 1);
+                                uint32_t acc = Hoist<K>::CHAN ? acc_p : (uint32_t)SW(c, ds, base + 1);
                                 if (acc & 1) { SW(c, ds, base + 1) = 0; wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9); }
                             }
                         }
@@ -577,8 +599,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     info_kill<K>(c, L, node, u1.y >> 24);
                     done_guard = false;
                 }
-                task_finish<K>(c, L, slot, H_COMPLETED, done_guard);
-                u0.x = TWORD(c, slot, 0, 0);
+                if (K::G) u0.x = task_finish<K>(c, L, slot, H_COMPLETED, done_guard, FinishKnown{done_guard, u0.x, u1.x, (K::FC && P.uses_chan) ? cu0_get() : 0u});
+                else { task_finish<K>(c, L, slot, H_COMPLETED, done_guard); u0.x = TWORD(c, slot, 0, 0); }
                 st = ST_FINISHED;
                 break;
             case MS_OP_SPAWN: {

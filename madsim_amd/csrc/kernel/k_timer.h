@@ -100,7 +100,7 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos
     while (up) {                                       // (one exit: see k_main.h)
         REG(11);
         const uint32_t parent = (pos - 1) >> 1;
-        if (K::SPILL) {
+        if (K::SPILL || K::G) {          // (global-state builds without a spill region too: two LDS levels per round trip)
             const uint32_t gp = parent > 0 ? (parent - 1) >> 1 : 0;
             uint4 p, g;
             if (parent > 0) heap_get2<K>(c, L, gp, parent, g, p);
