@@ -60,7 +60,27 @@ __device__ __forceinline__ void task_drop_locals(const Ctx& c, Lane& L, uint32_t
         uint32_t cx = known ? cx_known : (uint32_t)TWORD(c, slot, c.P.chan_unit, 0);
         if ((cx & 0xff) != 0xff) { conn_drop_handles<K>(c, L, cx & 0xff, (cx >> 8) & 1, (f & TF_KILLED) != 0); TWORD(c, slot, c.P.chan_unit, 0) = cx | 0xff; }
     }
-    if (f & TF_OWNER) {
+    if (K::G && (f & TF_OWNER)) {
+        // Global-state builds: the candidates are the sockets bound by a task that is still around (the owner mask, LDS); their owner
+        // words are read four to a round trip — a finishing task used to walk them one dependent read at a time, the wave waiting
+        // on each.  Table order is kept; dropping one Endpoint writes no other socket's owner word.
+        const uint32_t key = slot | (gen << 16);
+        for (uint32_t wi = 0; wi < 2; wi++) {
+            uint32_t m = OMASK(wi);
+            while (m) {
+                uint32_t ix[4], ow[4], n = 0;
+                for (uint32_t k = 0; k < 4; k++) { ix[k] = wi * 32 + (uint32_t)__builtin_ctz(m | 0x80000000u); if (m) { n++; m &= m - 1; } }
+                for (uint32_t k = 0; k < 4; k++) ow[k] = SW(c, k < n ? ix[k] : ix[0], 1);
+                for (uint32_t k = 0; k < 4; k++) {
+                    if (k >= n || ow[k] != key) continue;
+                    const uint32_t i = ix[k];
+                    OMASK(i >> 5) &= ~(1u << (i & 31));
+                    endpoint_drop<K>(c, L, i, (f & TF_KILLED) != 0);
+                    if (SW(c, i, 1) != ~0u) SW(c, i, 1) = 0x0000ff00u;    // nobody's: no owner word has bits 8-15 set
+                }
+            }
+        }
+    } else if (f & TF_OWNER) {
         for (uint32_t i = 0; i < c.P.n_socks; i++) {
             if (K::G && !((OMASK(i >> 5) >> (i & 31)) & 1)) continue;      // never bound by a task that is still around
             const uint32_t hdr = SW(c, i, 0);
@@ -116,6 +136,7 @@ __device__ __forceinline__ void info_kill(const Ctx& c, Lane& L, uint32_t node, 
     for (;;) {
         uint32_t best = 0xffffffffu, best_seq = 0xffffffffu;
         for (uint32_t t = 0; t < c.P.max_tasks; t++) {
+            if (K::G && !((AMASK(t >> 5) >> (t & 31)) & 1)) continue;      // (the alive mask, LDS: no read of a free slot's flag word)
             uint32_t f = TWORD(c, t, 0, 0);
             if (!(f & TF_ALIVE) || (PROGW(c, f >> 24) & 0xff) != node) continue;
             uint32_t sw = TWORD(c, t, 1, 1);
