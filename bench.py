@@ -604,8 +604,10 @@ def main():
             # the global-state builds with a heap-spill region, else three
             xn = min(n_streams, flights(xg0))
             nsub = max(1, baseline_batch[name] // count)
-            xtimed = max(2, -(-3 * xn // nsub))      # timed steps: at least three sub-launches per stream
-            xs, xwu = xtimed * nsub, xn   # timed sub-launches after one untimed per stream: the timed ones start into a busy chip
+            xtimed = max(4, -(-8 * xn // nsub))      # timed steps: at least eight sub-launches per stream (the region starts on an empty
+                                                     # chip and ends with a drain — a launch lasts 3-4 sub-launch periods — so three per
+                                                     # stream, as in round 3, measured ramp and tail more than the steady state)
+            xs, xwu = xtimed * nsub, xn   # timed sub-launches after one untimed per stream (and a synchronize: ramp and drain are inside the timed region)
             xring = torch.zeros((xs + xwu, REPORT_WORDS), dtype=torch.int64, device=dev)
             last = {}
 
@@ -674,7 +676,7 @@ def main():
             tdetail = {"FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"], "source": pmc["source"]}
         elif world == 1 and per_gpu == workload.BENCH_SEEDS_PER_GPU and headline and not args.loss:
             # the committed rocprofv3 PMC passes of this same command (tools/prof_workload.sh): FETCH_SIZE x2 + WRITE_SIZE
-            for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+            for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tpath):
                     tj = json.load(open(tpath))

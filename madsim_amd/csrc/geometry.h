@@ -209,6 +209,10 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
     return 0;
 }
 
+// buckets of the re-registration table (a power of two; k_timer.h dedup_note): a seed's share of the launch's working set
+#ifndef MADSIM_DEDUP_BUCKETS
+#define MADSIM_DEDUP_BUCKETS 64
+#endif
 inline int make_geometry(const Device& g, const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim, uint64_t count, Geo* G, std::string* err, bool trace = false) {
     KParams& P = G->P;
     memset(&P, 0, sizeof P);
@@ -346,7 +350,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             P.dedup_off = P.max_tasks << P.gs_gran_sh;
             // (tried in round 4: the every-class build with the switch — the topology's heap holds 68 entries of which 30 are distinct —
             // bit-exact, but the build, already 24 registers short, lost 3 % with the code compiled in and 10 % with it switched on)
-            P.dedup_n = ((L.state_mem & MADSIM_STATE_DEDUP_TIMERS) && P.features == MADSIM_FEAT_TIME && !trace) ? 64u : 0u;
+            P.dedup_n = ((L.state_mem & MADSIM_STATE_DEDUP_TIMERS) && P.features == MADSIM_FEAT_TIME && !trace) ? (uint32_t)MADSIM_DEDUP_BUCKETS : 0u;
             P.gs_planes = P.dedup_off + P.dedup_n * 16;
             P.gs_stride = (P.gs_planes + P.gs_plane_words * 4 + 63) & ~63u;
             P.off_amask = (P.max_tasks + 3) / 4;               // LDS planes: ready queue (a byte per entry), alive-task mask, owned-socket mask

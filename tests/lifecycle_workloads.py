@@ -740,6 +740,102 @@ ALL.update(spawn_in_future_drop_by_aborting_task=spawn_in_future_drop_by_abortin
 CONFIGS = {"buggify_rates": dict(loss_table=(0.0, 0.25, 0.1))}
 
 
+# ---- round 4: the paths the global-state builds changed (batched reads, words held in registers across a poll) ---------------
+
+def many_endpoints_dropped_in_table_order():
+    """A task that holds six Endpoints — with another task's Endpoints between them in the table, 40 table entries so the owner
+    mask spans two words — completes: every Endpoint it bound is dropped (net/mod.rs:483-493 BindGuard::drop -> Network::close),
+    the neighbours stay.  Afterwards the same addresses bind again, a datagram for a closed one is lost, one for a kept one arrives."""
+    from madsim_amd import _abi as A
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    mine = [wl.addr(n1, 100 + 3 * i) for i in range(6)]
+    theirs = [wl.addr(n1, 101 + 3 * i) for i in range(6)]
+    filler = [wl.addr(n1, 200 + i) for i in range(27)]           # entries 12..38: never bound
+    far = wl.addr(n1, 300)                                       # entry 39: second word of the owner mask
+    a2 = wl.addr(n2, 1)
+    keeper = wl.task(n1)
+    for a in theirs:
+        keeper.bind(a)
+    keeper.bind(far)
+    keeper.recv_from(theirs[2], 7); keeper.assert_val(70); keeper.recv_from(far, 8); keeper.assert_val(80); keeper.sleep(secs=5)
+    holder = wl.task(n1)
+    for a in mine:
+        holder.bind(a)
+    holder.sleep(ms=20)                                          # completes: the six go
+    again = wl.task(n1)
+    again.sleep(ms=200)
+    for a in mine:
+        again.bind(a)                                            # .unwrap(): AddrInUse would panic
+    again.recv_from_timeout(mine[4], 9, ms=300); again.assert_val(A.VAL_TIMEOUT)      # the datagram sent at 100 ms was lost
+    snd = wl.task(n2)
+    snd.bind(a2); snd.sleep(ms=100); snd.send_to(a2, mine[4], 9, 90); snd.send_to(a2, theirs[2], 7, 70); snd.send_to(a2, far, 8, 80)
+    m = wl.main()
+    for t in (keeper, holder, again, snd):
+        m.spawn(t)
+    m.join(again); m.join(snd)
+    return wl.build()
+
+
+def six_connections_at_once():
+    """Six clients hold a connection each at the same time (connect1's search for a free connection slot goes past the first four);
+    the server's handlers answer after the last has connected; then everything is dropped and six more are made."""
+    wl = W.WorkloadBuilder()
+    ns = wl.create_node()
+    asv = wl.addr(ns, 2379)
+    handler = wl.task(ns)
+    handler.chan_recv(); handler.assert_val(0x11); handler.sleep(ms=50); handler.flag_add(0, 1); handler.chan_send(0x22)
+    srv = wl.task(ns)
+    srv.bind(asv)
+    top = srv.label()
+    srv.accept1(asv); srv.spawn(handler, move_conn=True); srv.jmp(top)
+    clients = []
+    for i in range(6):
+        nc = wl.create_node()
+        acl = wl.addr(nc, 1)
+        c = wl.task(nc)
+        c.bind(acl); c.sleep(ms=10 + i); c.set(0, 2)
+        top = c.label()
+        c.connect1(acl, asv); c.assert_val(0); c.chan_send(0x11); c.chan_recv(); c.assert_val(0x22); c.chan_close(); c.sleep(ms=5); c.djnz(0, top)
+        clients.append(c)
+    m = wl.main()
+    m.spawn(srv)
+    for c in clients:
+        m.spawn(c)
+    for c in clients:
+        m.join(c)
+    m.assert_flag(0, 12)
+    return wl.build()
+
+
+def dead_registrations_swept_by_delivery():
+    """Five timed-out receives leave five dead registrations in one mailbox (endpoint.rs:353-362: the Vec keeps them); a sixth,
+    live one follows.  The next datagram sweeps the dead ones on its way (Mailbox::deliver, endpoint.rs:331-351) and is taken by
+    the live receive; a second datagram with another tag finds its own registration behind them."""
+    from madsim_amd import _abi as A
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+    r = wl.task(n1)
+    r.bind(a1)
+    for _ in range(5):
+        r.recv_from_timeout(a1, 1, ms=10); r.assert_val(A.VAL_TIMEOUT)
+    r.recv_from_timeout(a1, 1, secs=2); r.assert_val(41)
+    r.recv_from_timeout(a1, 1, ms=10); r.assert_val(A.VAL_TIMEOUT); r.recv_from_timeout(a1, 1, ms=10); r.assert_val(A.VAL_TIMEOUT)
+    r.recv_from(a1, 1); r.assert_val(43)
+    other = wl.task(n1)
+    other.sleep(ms=5); other.recv_from(a1, 2); other.assert_val(42)
+    s = wl.task(n2)
+    s.bind(a2); s.sleep(ms=200); s.send_to(a2, a1, 1, 41); s.sleep(ms=100); s.send_to(a2, a1, 2, 42); s.sleep(ms=100); s.send_to(a2, a1, 1, 43)
+    m = wl.main()
+    m.spawn(r); m.spawn(other); m.spawn(s); m.join(r); m.join(other)
+    return wl.build()
+
+
+ALL.update(many_endpoints_dropped_in_table_order=many_endpoints_dropped_in_table_order, six_connections_at_once=six_connections_at_once,
+           dead_registrations_swept_by_delivery=dead_registrations_swept_by_delivery)
+
+
 def config(name):
     """Non-default Config a workload is meant to run under (None = Config::default())."""
     return A.Config.default(**CONFIGS[name]) if name in CONFIGS else None
@@ -752,6 +848,15 @@ def limits(name):
         return lim
     if name == "ipvs_round_robin_datagrams":             # four replies may queue up before the sender starts receiving
         lim = A.Limits(); lim.mbox_msgs = 6
+        return lim
+    if name == "six_connections_at_once":
+        lim = A.Limits(); lim.max_conns, lim.max_tasks = 8, 16
+        return lim
+    if name == "dead_registrations_swept_by_delivery":
+        lim = A.Limits(); lim.mbox_regs, lim.mbox_msgs = 12, 4
+        return lim
+    if name == "many_endpoints_dropped_in_table_order":
+        lim = A.Limits(); lim.max_tasks = 8
         return lim
     if name == "join_handle_awaits_the_task_it_named":   # two instances of one program alive at once
         lim = A.Limits(); lim.max_tasks = 6
