@@ -398,7 +398,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             uint32_t per_simd = gv > 0 ? 512u / (uint32_t)((gv + 7) & ~7) : gsel.feat != MADSIM_FEAT_ALL ? 3u : 2u;
             per_simd = per_simd < 2 ? 2u : per_simd > 4 ? 4u : per_simd;         // workgroups of four waves, one wave per SIMD each
             const size_t quota = g.lds_per_cu / per_simd;                    // (a large instruction table can eat a workgroup's whole share:
-            const size_t per_seed = quota > (size_t)sh_bytes + 1280 ? (quota - sh_bytes - 1280) / (4 * 64) : 0;   // no size_t underflow)
+            const size_t glw = L.lanes_per_wave ? lw : 64;                   // (auto: full waves, whatever the LDS-resident sizing above tried)
+            const size_t per_seed = quota > (size_t)sh_bytes + 1280 ? (quota - sh_bytes - 1280) / (4 * glw) : 0;   // no size_t underflow)
             const size_t fixed = 4 * (((size_t)P.max_tasks + 3) / 4 + (P.max_tasks + 31) / 32 + 2);
             uint32_t fit = per_seed > fixed + 64 ? (uint32_t)((per_seed - fixed) / 16) : 4u;
             if (P.heap_lds > fit) { P.heap_spill += P.heap_lds - fit; P.heap_lds = fit; }
@@ -406,7 +407,10 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         }
         if (lw == 64 || !P.rq_in_reg) break;
     }
-    if (P.gstate_mode && lw != 64) return fail(err, MADSIM_E_LIMITS, "global state (state_mem = 2) runs full 64-lane waves only");
+    // (32 seed lanes per wave: half the seeds share a CU's LDS — twice the timer-heap entries per seed stay out of the spill region —
+    // and the launch's working set halves; the election loop keeps 0.9 of its rate with every other lane idle, round 4)
+    if (P.gstate_mode && lw != 64 && !(lw == 32 && P.features == MADSIM_FEAT_TIME))
+        return fail(err, MADSIM_E_LIMITS, "global state (state_mem = 2) runs full 64-lane waves; 32 seed lanes per wave for timeout-only workloads");
     P.lw_shift = lw == 8 ? 3 : lw == 16 ? 4 : lw == 32 ? 5 : 6;
     // The compact base-op layout (sim_kernel.h MADSIM_FEAT_COMPACT): 8-byte heap entries with the root in registers, the main
     // task's 24 bytes in global memory.  Taken when it buys a CU another 4-wave workgroup (the 4-node ping-pong: 200 -> 152 bytes

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEA
         c.ipvs0 = pl + (P.off_ipvs << P.lw_shift);
     }
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
-    const uint32_t glane = ((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane;
+    if (EXP_LANE_DIV > 1 && (lane % EXP_LANE_DIV)) return;          // (timing experiments only: tools/experiment/k_experiment.h EXP_HALF_LANES)
+    const uint32_t glane = (((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane) / EXP_LANE_DIV;
     c.spill_off = glane * 16u;
     c.spill = buf_make(P.spill, (uint64_t)P.heap_spill * P.total_lanes * 16u);
     c.gs_lane = glane;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEA
             // next unit: static striding, or the per-launch work queue (a lane whose seeds end early — deadlocks under
             // packet loss — then keeps pulling work instead of idling behind the slowest lane of its stride)
             if (P.work_ctr) next = P.total_lanes + atomicAdd(P.work_ctr, 1ull);
-            else next += P.total_lanes;
+            else next += P.total_lanes / EXP_LANE_DIV;
         }
     }
 #ifdef MADSIM_K_PROF

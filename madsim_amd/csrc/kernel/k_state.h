@@ -11,10 +11,11 @@ namespace madsim_k {
 #include <type_traits>
 #include "../../../tools/experiment/k_experiment.h"
 #else
-#if defined(EXP_NOLOG) || defined(EXP_ALWAYS_ACCEPT) || defined(EXP_PROF) || defined(EXP_PROF2) || defined(EXP_NO_LWS_VARIANTS)
+#if defined(EXP_NOLOG) || defined(EXP_ALWAYS_ACCEPT) || defined(EXP_PROF) || defined(EXP_PROF2) || defined(EXP_NO_LWS_VARIANTS) || defined(EXP_HALF_LANES)
 #error "EXP_* switches make a non-bit-exact kernel: build experiment variants with tools/build_variant.sh, never the product Makefile"
 #endif
 #define EXP_ACCEPT(x) (x)
+#define EXP_LANE_DIV 1u
 #define MADSIM_K_LOG_ENABLED 1
 #define PROBE(i) do { } while (0)
 #define PROBE2(i) do { } while (0)

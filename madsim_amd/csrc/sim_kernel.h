@@ -121,6 +121,7 @@ struct KParams {
     X(false, true, 3, MADSIM_FEAT_ALL, false, false)   \
     X(false, true, -1, MADSIM_FEAT_ALL, false, false)  \
     X(false, true, 6, MADSIM_FEAT_TIME, false, true)   \
+    X(false, true, 5, MADSIM_FEAT_TIME, false, true)   \
     X(false, true, 6, MADSIM_FEAT_CHAN, false, true)   \
     X(false, false, 6, MADSIM_FEAT_CHAN, false, true)  \
     X(false, true, 6, MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR, false, true) \
@@ -145,6 +146,10 @@ inline VariantSel select_variant(const KParams& P, bool trace) {
         if (cls == MADSIM_FEAT_ALL && !(feat & MADSIM_FEAT_ADDR)) return {0, 1, 6, MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR, 0, 1};   // plain addresses
         // (connection workloads keep short heaps — a handful of backoff / timeout timers — that sit in LDS whole: a build
         // without the spill path, like the base-op builds have)
+        // 32 seed lanes per wave: the timeout-only build has the variant.  (Round 4 also tried 16 lanes there — the election loop fell
+        // from 9.2 to 6.5 G steps/s — and 32 lanes on the every-class build, which hung on the topology: not compiled, refused by
+        // make_geometry.)
+        if (lw == 5 && cls == MADSIM_FEAT_TIME) return {0, 1, 5, cls, 0, 1};
         return {0, cls == MADSIM_FEAT_CHAN ? spill : 1, 6, cls, 0, 1};
     }
     if (cls != MADSIM_FEAT_ALL) return {0, 1, -1, cls, 0, 0};

@@ -698,13 +698,18 @@ def raft_election_limits():
     per socket, 8 queued messages).  The mailboxes live in global memory (Variant::G), so their
     capacity costs no LDS; rarer seeds still come back MADSIM_OVERFLOW and are re-run by run_batch_auto."""
     lim = A.Limits()
-    lim.heap_lds_slots, lim.heap_spill_slots = 16, 240
+    lim.heap_lds_slots, lim.heap_spill_slots = 22, 234
     lim.mbox_regs, lim.mbox_msgs = 80, 10
     # a third of this workload's Timer::add calls re-register a pending Sleep (time/sleep.rs:51-53): kept as counts beside the
     # first entry (include/madsim_hip.h MADSIM_STATE_DEDUP_TIMERS; the layout itself stays on auto) — 25 % fewer global accesses
     # per step, the timer-fire phase a third shorter, +2-4 % measured (profiles/r3_experiments.md); 5e-4 of the seeds meet a tie
     # between different events and are run again by the kernel with the literal heap
-    lim.state_mem = A.STATE_AUTO | A.STATE_DEDUP_TIMERS
+    # Round 4: 32 seed lanes per wave on the global-state build.  This workload's rate is set by the memory system per lane access
+    # (with every other lane idle it keeps 0.9 of its rate: tools/experiment/k_experiment.h EXP_HALF_LANES), so half the seeds per
+    # wave at twice the LDS per seed — 22 of the ~20 distinct heap entries out of the spill region — wins: 9.25 G steps/s against
+    # 8.44 with 64 lanes and 10 entries, 8.87 with 64 lanes, 16 entries and two waves per SIMD (profiles/r4_experiments.md).
+    lim.lanes_per_wave = 32
+    lim.state_mem = A.STATE_GLOBAL | A.STATE_DEDUP_TIMERS
     return lim
 
 

@@ -1071,6 +1071,7 @@ def dedup_limits(base=None):
     """Global-state layout with the re-registered Sleep timers kept as counts (MADSIM_STATE_DEDUP_TIMERS)."""
     import copy
     lim = copy.copy(base) if base is not None else A.Limits()
-    lim.lanes_per_wave = 0
+    if lim.lanes_per_wave != 32:            # (the election loop's limits ask for 32 seed lanes per wave on the global-state build: kept)
+        lim.lanes_per_wave = 0
     lim.state_mem = A.STATE_GLOBAL | A.STATE_DEDUP_TIMERS
     return lim

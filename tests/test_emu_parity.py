@@ -213,12 +213,12 @@ def test_every_bench_workload_runs_on_the_build_its_ops_need():
     pay for extended ops, mixed workloads take the full build — without general address resolution (FEAT 15) when every
     address is a plain node IP and the state lives in global memory."""
     from madsim_amd import runtime
-    want = {"pingpong": (0, 6, 0), "timers": (0, 15, 0), "raft": (1, 6, 16), "kv": (2, 6, 16), "topo": (15, 6, 16)}
+    want = {"pingpong": (0, 6, 0), "timers": (0, 15, 0), "raft": (1, 5, 16), "kv": (2, 6, 16), "topo": (15, 6, 16)}   # (raft: 32 seed lanes per wave since round 4 — lane stride 5)
     for name, (feat, lws, glob) in want.items():
         w, lim, _ = W.bench_case(name)
         g = runtime.geometry(w, lim)
         assert ((g.variant >> 8) & 0x1f, (g.variant >> 16) & 0xf, g.variant & 16) == (feat, lws, glob), (name, hex(g.variant))
-        assert (g.global_bytes_per_seed > 0) == bool(glob) and (not glob or g.lanes_per_wave == 64)
+        assert (g.global_bytes_per_seed > 0) == bool(glob) and (not glob or g.lanes_per_wave == (32 if name == "raft" else 64))
         lim.state_mem = A.STATE_LDS                     # the LDS-resident layout stays selectable
         g = runtime.geometry(w, lim)
         assert g.variant & 16 == 0 and g.global_bytes_per_seed == 0
@@ -681,3 +681,23 @@ def test_socket_of_a_restarted_nodes_dead_task_serves_a_receive_another_holder_r
     # the connection op changes the kernel build, not the run: same verdicts, clocks and observations
     for f in ("verdict", "steps", "clock_ns", "msg_count", "rng_calls", "trace_hash", "obs_hash"):
         assert (outs[0][f] == outs[2][f]).all(), f
+
+
+@pytest.mark.parametrize("name", ["receiver_drop", "request_timeout_with_stale_timers", "dead_registrations_swept_by_delivery",
+                                  "many_endpoints_dropped_in_table_order"])
+def test_global_state_with_32_seed_lanes_per_wave(name):
+    """Round 4: the timeout-only global-state build also runs 32 seed lanes per wave (the election loop's bench case): same bytes."""
+    lim = LW.limits(name) or A.Limits()
+    lim.lanes_per_wave, lim.state_mem = 32, A.STATE_GLOBAL
+    g = emu.geometry_params(LW.ALL[name](), lim)
+    assert g["gstate_mode"] == 1 and g["features"] == 1
+    _same(LW.ALL[name](), 0, 160, LW.config(name), lim)
+    lim.state_mem |= A.STATE_DEDUP_TIMERS
+    _same(LW.ALL[name](), 0, 160, A.Config.default(packet_loss_rate=0.05), lim)
+
+
+def test_global_state_32_lanes_is_refused_for_other_op_classes():
+    lim = LW.limits("kv_rpc") or A.Limits()
+    lim.lanes_per_wave, lim.state_mem = 32, A.STATE_GLOBAL
+    with pytest.raises(RuntimeError):
+        emu.run_batch(LW.ALL["kv_rpc"](), 0, 8, None, lim)

@@ -1121,3 +1121,37 @@ def test_run_batch_multi_over_k_contexts_equals_k_independent_calls(hip):
         for c in ctxs:
             c.close()
     assert (got == want).all()
+
+
+# ---- round 4: 32 seed lanes per wave on the timeout-only global-state build (the election loop's bench case) -----------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["receiver_drop", "request_timeout_with_stale_timers", "dead_registrations_swept_by_delivery",
+                                  "many_endpoints_dropped_in_table_order"])
+def test_global_state_with_32_seed_lanes_per_wave_gpu(hip, name):
+    lim = LW.limits(name) or A.Limits()
+    lim.lanes_per_wave, lim.state_mem = 32, A.STATE_GLOBAL
+    g = hip.geometry(LW.ALL[name](), lim)
+    assert g.lanes_per_wave == 32 and g.global_bytes_per_seed > 0 and (g.variant >> 16) & 0xf == 5
+    _cmp(hip, LW.ALL[name](), 0, 1024, LW.config(name), lim)
+    lim.state_mem |= A.STATE_DEDUP_TIMERS
+    _cmp(hip, LW.ALL[name](), 5000, 1024, A.Config.default(packet_loss_rate=0.05), lim)
+
+
+@pytest.mark.gpu
+def test_election_loop_32_and_64_seed_lanes_give_the_same_bytes_gpu(hip):
+    """The bench case of the election loop (32 seed lanes per wave, 22 heap entries in LDS) against the same workload on full waves:
+    65 536 seeds compared with each other, 1 024 contiguous and 128 scattered ones with the oracle."""
+    w, lim = W.raft_election(), W.raft_election_limits()
+    assert lim.lanes_per_wave == 32 and hip.geometry(w, lim).lanes_per_wave == 32
+    full = W.raft_election_limits(); full.lanes_per_wave = 0; full.state_mem = A.STATE_AUTO | A.STATE_DEDUP_TIMERS
+    assert hip.geometry(w, full).lanes_per_wave == 64
+    a, _ = hip.run_batch(w, 0, 65536, None, lim)
+    b, _ = hip.run_batch(w, 0, 65536, None, full)
+    ok = (a == b) | (a["verdict"] == A.OVERFLOW) | (b["verdict"] == A.OVERFLOW)
+    assert ok.all()
+    want, _ = oracle.run_batch(w, 20000, 1024, None, lim)
+    assert ((a[20000:21024] == want) | (a[20000:21024]["verdict"] == A.OVERFLOW)).all()
+    for s in [(k * 4093) % 65536 for k in range(128)]:
+        want, _ = oracle.run_batch(w, s, 1, None, lim)
+        assert a[s] == want[0] or a[s]["verdict"] == A.OVERFLOW, f"seed {s}"

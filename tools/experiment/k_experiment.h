@@ -36,6 +36,15 @@
 #define PROBE(i) do { } while (0)
 #endif
 
+// -DEXP_HALF_LANES[=n]: only every n-th lane of a wave (default 2) carries seeds, each of them n seeds of the launch one after the other; the
+// state layout is packed over the carrying lanes.  What does a wave-iteration cost with half the lanes (fewer divergent paths, half
+// the working set), at unchanged LDS per seed?  Results stay complete and bit-exact.
+#ifdef EXP_HALF_LANES
+#define EXP_LANE_DIV (EXP_HALF_LANES + 0 > 1 ? EXP_HALF_LANES + 0 : 2u)
+#else
+#define EXP_LANE_DIV 1u
+#endif
+
 #ifdef EXP_NO_LWS_VARIANTS
 #define MADSIM_K_NO_LWS_VARIANTS 1
 #endif
