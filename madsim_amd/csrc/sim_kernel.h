@@ -147,8 +147,8 @@ inline VariantSel select_variant(const KParams& P, bool trace) {
         // (connection workloads keep short heaps — a handful of backoff / timeout timers — that sit in LDS whole: a build
         // without the spill path, like the base-op builds have)
         // 32 seed lanes per wave: the timeout-only build has the variant.  (Round 4 also tried 16 lanes there — the election loop fell
-        // from 9.2 to 6.5 G steps/s — and 32 lanes on the every-class build, which hung on the topology: not compiled, refused by
-        // make_geometry.)
+        // from 9.2 to 6.5 G steps/s — and 32 lanes on the every-class build — the topology: 4.10 G steps/s with 20 heap entries in LDS
+        // against 4.30 on full waves with 8: neither is compiled, make_geometry refuses both.)
         if (lw == 5 && cls == MADSIM_FEAT_TIME) return {0, 1, 5, cls, 0, 1};
         return {0, cls == MADSIM_FEAT_CHAN ? spill : 1, 6, cls, 0, 1};
     }
