@@ -301,7 +301,9 @@ typedef struct madsim_limits {
     uint32_t max_tasks;          /* live task instances per seed; 0 = auto (n_progs + restarts)      */
     uint32_t mbox_regs;          /* pending recv registrations per socket; 0 = auto (2)              */
     uint32_t mbox_msgs;          /* undelivered messages per socket; 0 = auto (2), MADSIM_LIMIT_NONE = none */
-    uint32_t lanes_per_wave;     /* seeds carried per 64-lane wave (8/16/32/64); 0 = auto            */
+    uint32_t lanes_per_wave;     /* seeds carried per 64-lane wave (8/16/32/64); 0 = auto.  With state_mem = MADSIM_STATE_GLOBAL: 64,
+                                    or 32 for timeout-only workloads (twice the LDS per seed: more of the timer heap out of the
+                                    spill region — the election loop's setting); anything else there is MADSIM_E_LIMITS */
     uint32_t max_conns;          /* live reliable-channel connections per seed; 0 = auto (4)         */
     uint32_t chan_queue;         /* queued payloads per channel direction; 0 = auto (2)              */
     uint32_t sched;              /* MADSIM_SCHED_*: how lanes pick up further seeds when a launch holds more
