@@ -395,7 +395,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             // quota moves to the coalesced spill region, same capacity.
             const madsim_k::VariantSel gsel = madsim_k::select_variant(P, trace);
             const int gv = g.vgprs ? g.vgprs(&gsel) : -1;
-            uint32_t per_simd = gv > 0 ? 512u / (uint32_t)((gv + 7) & ~7) : gsel.feat != MADSIM_FEAT_ALL ? 3u : 2u;
+            uint32_t per_simd = gv > 0 ? 512u / (uint32_t)((gv + 7) & ~7) : (gsel.feat & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) != (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR) ? 3u : 2u;
             per_simd = per_simd < 2 ? 2u : per_simd > 4 ? 4u : per_simd;         // workgroups of four waves, one wave per SIMD each
             const size_t quota = g.lds_per_cu / per_simd;                    // (a large instruction table can eat a workgroup's whole share:
             const size_t glw = L.lanes_per_wave ? lw : 64;                   // (auto: full waves, whatever the LDS-resident sizing above tried)
@@ -455,7 +455,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // VGPR budget (tools/kernel_meta.sh): base builds ~110 VGPRs = 4 waves per SIMD, single-class builds 133 / 151 = 3,
     // the full extended build ~180 = 2
     const madsim_k::VariantSel vsel = madsim_k::select_variant(P, trace);
-    uint32_t cap = vsel.feat == 0 ? 16u : (vsel.feat == MADSIM_FEAT_TIME || vsel.feat == MADSIM_FEAT_CHAN || (vsel.g && vsel.feat != MADSIM_FEAT_ALL)) ? 12u : 8u;
+    uint32_t cap = vsel.feat == 0 ? 16u : (vsel.feat == MADSIM_FEAT_TIME || vsel.feat == MADSIM_FEAT_CHAN || (vsel.g && (vsel.feat & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) != (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR))) ? 12u : 8u;
     if (g.vgprs) {                       // 512 VGPRs per SIMD lane, allocated in blocks of 8; at most 8 waves per SIMD
         int r = g.vgprs(&vsel);
         if (r > 0) { uint32_t per_simd = 512u / (uint32_t)((r + 7) & ~7); cap = 4u * (per_simd > 8 ? 8u : per_simd < 1 ? 1u : per_simd); }

@@ -44,12 +44,15 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
 }
 
 // Global-state builds wait on memory most of the time (rocprofv3: 60-70 % of wave cycles), so they trade registers for
-// resident waves: MADSIM_G_WAVES_PER_EU waves per SIMD (the second __launch_bounds__ argument caps the VGPR budget).
+// resident waves: MADSIM_G_WAVES_PER_EU waves per SIMD (the second __launch_bounds__ argument caps the VGPR budget) — the single-class
+// builds, which fit 168 registers.  The every-class builds do not (24 spilled registers at three waves): two waves per SIMD, 215
+// registers, no scratch, and the LDS a third workgroup would have taken holds 15 timer-heap entries per seed instead of 8 —
+// the topology 4.65 against 4.13 G steps/s (round 4, gpurun_out/r4v).
 #ifndef MADSIM_G_WAVES_PER_EU
 #define MADSIM_G_WAVES_PER_EU 3
 #endif
 template <class K>
-__global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : K::FEAT == MADSIM_FEAT_ALL ? 2 : MADSIM_G_WAVES_PER_EU) void sim_kernel(const KParams P) {
+__global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) == (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR) ? 2 : MADSIM_G_WAVES_PER_EU) void sim_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // workgroup-shared tables
     uint32_t* sh = SMEM;
