@@ -92,7 +92,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     bool first_poll = false;
     // this task's connection unit: global-state builds hold it in registers for the poll (it came with unit 0: k_state.h
     // PollPrefetch) and write through; the other builds read LDS as before
-    constexpr bool CU_FULL = K::G && K::FEAT == MADSIM_FEAT_CHAN;      // (else word 0 only: k_state.h poll_prefetch)
+    constexpr bool CU_FULL = Hoist<K>::CHAN;      // (else word 0 only: k_state.h poll_prefetch)
     auto cu_get = [&]() -> uint4 { if (CU_FULL) return pp.cu; return (uint4)TU(c, slot, c.P.chan_unit); };
     auto cu0_get = [&]() -> uint32_t { if (K::G) return pp.cu.x; return (uint32_t)TWORD(c, slot, c.P.chan_unit, 0); };
     auto cu0_set = [&](uint32_t v) { if (K::G) pp.cu.x = v; TWORD(c, slot, c.P.chan_unit, 0) = v; };

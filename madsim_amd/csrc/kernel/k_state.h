@@ -339,8 +339,11 @@ template <class K> __device__ __forceinline__ uint4 load_u1(const Ctx& c, uint32
 // poll_task keeps the copies current through its own writes; nobody else writes these words of a task that is being polled.
 // cu = the connection unit {conn | side | backoff, staged payload, arrive} (k_poll.h: every channel op starts from it).
 // Load hoists that cost a register each across a handler (k_channel.h, k_poll.h channel ops): the channel-only global-state builds
-// take them; the builds with every op class spill registers already and keep the lazy reads.
-template <class K> struct Hoist { static constexpr bool CHAN = K::G && K::FEAT == MADSIM_FEAT_CHAN; };
+// take them, and the every-class ones since they run two waves per SIMD (256 registers: k_main.h) — at three they spilled.
+template <class K> struct Hoist {
+    static constexpr bool ALLG = K::G && (K::FEAT & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) == (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR);
+    static constexpr bool CHAN = (K::G && K::FEAT == MADSIM_FEAT_CHAN) || ALLG;
+};
 struct PollPrefetch { uint32_t d2lo, d2hi; uint4 cu; };
 __device__ __forceinline__ bool has_t0_unit(const KParams& P) { return P.task_units > 2 && !(P.uses_chan && P.chan_unit == 2); }   // geometry.h `t0`
 template <class K> __device__ __forceinline__ PollPrefetch poll_prefetch(const Ctx& c, uint32_t slot) {
@@ -349,7 +352,7 @@ template <class K> __device__ __forceinline__ PollPrefetch poll_prefetch(const C
     // (the whole unit in the channel-only builds; the builds that carry every op class are short of registers: word 0 only, the
     // rest is read where it is wanted — k_poll.h cu_get)
     if (K::G && K::FC && c.P.uses_chan) {
-        if (K::FEAT == MADSIM_FEAT_CHAN) pp.cu = gs_load128(c.gs, gs_addr_task(c, slot, c.P.chan_unit * 16u));
+        if (Hoist<K>::CHAN) pp.cu = gs_load128(c.gs, gs_addr_task(c, slot, c.P.chan_unit * 16u));
         else pp.cu.x = gs_load32(c.gs, gs_addr_task(c, slot, c.P.chan_unit * 16u));
     }
     return pp;
