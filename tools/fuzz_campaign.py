@@ -29,7 +29,9 @@ while time.time() - t0 < budget:
     if max_tasks: lim.max_tasks = max_tasks
     if (k // len(gens)) % 2:          # every other round: per-seed state in the global-memory block instead of LDS (Variant::G)
         lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL
-        if name == "timeouts": lim.state_mem |= A.STATE_DEDUP_TIMERS      # re-registered Sleep timers as counts (k_timer.h dedup_note)
+        if name == "timeouts":
+            lim.state_mem |= A.STATE_DEDUP_TIMERS      # re-registered Sleep timers as counts (k_timer.h dedup_note)
+            if (k // len(gens)) % 4 == 3: lim.lanes_per_wave = 32     # ... on 32 seed lanes per wave (the election loop's layout since round 4)
     if k % 5 == 4:                    # every fifth program in the reference's plain mode: no determinism-log fingerprint (rand.rs:67)
         lim.no_trace_hash = 1
     n = 96
