@@ -66,3 +66,28 @@ for D in (4, 6, 8, 12, 16):
         gp, dt = gen_passes / tot_iters, dry_trips / tot_iters
         valu = gp * (GEN + PUSH) + today_trips * (ACC + POP) + dt * (GEN + ACC)
         print(f"{D:10d} {R:14d} {gp:22.2f} {dt:18.2f} {valu:14.0f} {valu / (today_trips * (GEN + ACC)):9.2f}")
+
+# Policy B: no refill passes at all — a lane banks outputs while it idles in SOMEBODY ELSE'S rejection trips (the generator step of a trip is issued
+# for the whole wave anyway), and every draw pops its own ring first.  A trip then costs the step + accept test + a push for the idle lanes.
+print()
+print("policy B: lanes bank outputs during the other lanes' rejection trips (no refill passes)")
+print(f"{'ring depth':>10s} {'generator trips/pass':>21s} {'pop trips/pass':>15s} {'VALU per pass':>14s} {'vs today':>9s}")
+for D in (1, 2, 3, 4, 5, 6, 8, 12):
+    gen_trips = pop_trips = 0.0
+    for x in waves:
+        lanes = x.shape[1]
+        avail = np.zeros(lanes, dtype=np.int64)
+        for it in range(len(x)):
+            for s in range(5):
+                c = x[it, :, s]
+                take = np.minimum(c, avail); avail -= take
+                pop_trips += take.max()                       # the pop loop runs at its slowest lane too
+                r = c - take
+                T = int(r.max())
+                gen_trips += T
+                if T:
+                    idle = T - r                                # trips in which the lane has nothing of its own to draw
+                    avail += np.minimum(idle, D - avail)
+    gt, pt = gen_trips / tot_iters, pop_trips / tot_iters
+    valu = gt * (GEN + ACC + PUSH + 2) + pt * (ACC + POP)
+    print(f"{D:10d} {gt:21.2f} {pt:15.2f} {valu:14.0f} {valu / (today_trips * (GEN + ACC)):9.2f}")
