@@ -80,12 +80,10 @@ __device__ __forceinline__ void task_drop_locals(const Ctx& c, Lane& L, uint32_t
                 }
             }
         }
-    } else if (f & TF_OWNER) {
+    } else if (f & TF_OWNER) {                                // LDS-resident builds: every table entry, in order
         for (uint32_t i = 0; i < c.P.n_socks; i++) {
-            if (K::G && !((OMASK(i >> 5) >> (i & 31)) & 1)) continue;      // never bound by a task that is still around
             const uint32_t hdr = SW(c, i, 0);
             if (!sock_owned_by<K>(c, i, hdr, slot, gen)) continue;
-            if (K::G) OMASK(i >> 5) &= ~(1u << (i & 31));
             endpoint_drop<K>(c, L, i, (f & TF_KILLED) != 0);
             if (K::LIFE && SW(c, i, 1) != ~0u) SW(c, i, 1) = 0x0000ff00u;    // nobody's: no owner word has bits 8-15 set
         }
