@@ -56,7 +56,7 @@ enum madsim_op {
     MS_OP_YIELD = 4,       /* tokio::task::yield_now().await (re-export task/mod.rs:30)              */
     MS_OP_PANIC = 5,       /* a=0: panic!() with message code imm (0..254); a=1: panic!("{}", flag[b & 3] + imm): the message is
                               the decimal text of that value, which is also its code — values above
-                              madsim_workload_t.panic_dyn_max yield MADSIM_OVERFLOW.  The code is what
+                              madsim_workload_t.panic_dyn_max yield MADSIM_UNSUPPORTED.  The code is what
                               NodeBuilder::restart_on_panic_matching looks at (task/mod.rs:297-300; madsim_workload_t.panic_match);
                               any other panic (failed assert, unwrap of an Err) carries code 255, which no pattern names */
     MS_OP_SET = 6,         /* a=reg(0..1): cnt[a] = imm (a loop bound; registers are 16 bit)          */
@@ -230,7 +230,7 @@ typedef struct madsim_sock {
  * the address it was GIVEN, rpc.rs:126: a typed call through a virtual address panics when the real server answers, as in
  * the reference.)  The table gives every service's address and its state before the first task runs; MS_OP_IPVS changes
  * that state at run time (add_service / del_service / add_server / del_server, ipvs.rs:50-85), per seed, at most 6 servers
- * per service at any time (a seventh add_server yields MADSIM_OVERFLOW). */
+ * per service at any time (a seventh add_server yields MADSIM_UNSUPPORTED: no limit grows that word). */
 typedef struct madsim_service {
     uint8_t vaddr;       /* socket-table entry holding the service address (any kind; typically MADSIM_ADDR_VIRTUAL) */
     uint8_t n_servers;   /* 0..6 real servers, in add_server order; 0 = get_server() returns None: no rewrite.
@@ -269,7 +269,7 @@ typedef struct madsim_workload {
     uint32_t n_services;         /* IPVS virtual services (<= MADSIM_MAX_SERVICES); their use selects the general-address build */
     uint32_t panic_dyn_max;      /* largest message code a run-time formatted panic (MS_OP_PANIC a=1) may produce; 0 = 254.
                                     A workload that also uses literal messages gives those the codes above it; a formatted value
-                                    beyond it yields MADSIM_OVERFLOW for the seed (never a silently different answer)          */
+                                    beyond it yields MADSIM_UNSUPPORTED for the seed (never a silently different answer)       */
     const madsim_service_t* services;   /* [n_services] or NULL                                                       */
     const uint32_t* panic_match; /* NULL, or [n_nodes+1][8]: bit c of row n = "a panic whose message code is c restarts node n"
                                     (NodeBuilder::restart_on_panic_matching, `error_msg.contains(pattern)` task/mod.rs:297-300,
@@ -351,12 +351,16 @@ enum madsim_verdict {
     MADSIM_DEADLOCK = 2,    /* "no events, all tasks will block forever" (task/mod.rs:250)           */
     MADSIM_TIME_LIMIT = 3,  /* "time limit exceeded" (task/mod.rs:253-258)                           */
     MADSIM_OVERFLOW = 4,    /* a device capacity in madsim_limits_t was exceeded: re-run the seed with
-                               larger limits (not a reference verdict; never silently wrong)         */
+                               larger limits (not a reference verdict; never silently wrong).  Only capacities a larger
+                               limit CAN lift give this verdict; the FIRST capacity or model event of a seed decides
+                               its runner verdict (what follows it in the same round runs on spoiled state)            */
     MADSIM_STEP_LIMIT = 5,  /* max_steps reached (not a reference verdict)                           */
     MADSIM_UNSUPPORTED = 6, /* the seed left the workload MODEL (not a reference verdict, and larger limits do not help:
                                never re-run): a port-0 table entry bound again while the Endpoint of its previous bind is
-                               alive — an entry names one Endpoint at a time, `close` it first.  The oracle reports the
-                               same verdict for the same seed; every other result field is 0                            */
+                               alive — an entry names one Endpoint at a time, `close` it first; a seventh server added to
+                               an IPVS service; a ninth connection waiting in one Endpoint's accept1 queue; a formatted panic
+                               value above madsim_workload_t.panic_dyn_max.  The oracle reports the same verdict for the same
+                               seed, decided at the same instruction; every other result field is 0                     */
     MADSIM_INTERNAL = 7     /* an invariant of the device code broke (a bug in this library, never a property of the
                                workload): the parity tests assert that no seed ever carries it; other fields 0        */
 };

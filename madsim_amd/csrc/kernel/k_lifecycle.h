@@ -20,7 +20,7 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
     } else {
         while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
     }
-    if (slot >= c.P.max_tasks) { L.ovf |= OVF_CAP; return 0xffffffffu; }
+    if (slot >= c.P.max_tasks) { OVF_SET(L, OVF_CAP); return 0xffffffffu; }
     if (K::G) AMASK(slot >> 5) |= 1u << (slot & 31);
     uint32_t gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
     uint32_t pw = PROGW(c, prog);

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
                     rng_log<K>(c, L);
                     uint64_t delay = NS_PER_S + __umul64hi(v, range);
                     node_kill<K>(c, L, node);                 // self.kill(node_id)
-                    if (!timer_add<K>(c, L, L.clock + delay, (EV_RESTART << EV_SHIFT) | node, 0)) L.ovf |= OVF_CAP;
+                    if (!timer_add<K>(c, L, L.clock + delay, (EV_RESTART << EV_SHIFT) | node, 0)) OVF_SET(L, OVF_CAP);
                     panicked = false;
                 }
             }

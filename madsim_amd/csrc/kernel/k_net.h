@@ -163,7 +163,7 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
         } else if (K::LIFE && SW(c, s, 1) == ~0u) {              // (the owner word is read only when nobody took the message)
             SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);      // (dead registrations swept on the way stay swept)
         } else if (nmsg >= c.P.mbox_msgs) {
-            L.ovf |= OVF_CAP;
+            OVF_SET(L, OVF_CAP);
         } else {
             if (rsp) tag = 0xfe;                           // nobody holds that rsp_tag any more: it can never be received
             SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);
@@ -183,7 +183,7 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
     // Global-state builds queue a round's Timer::add calls in the lane (k_timer.h timer_schedule): whoever reads the heap — top_dl, a
     // pop — must come after timer_flush.  Checked in the host-compiled kernel on every call (the emulation suite asserts that no
     // seed ends MADSIM_INTERNAL); a new op that fires timers inside a round without flushing first shows up there.
-    if (K::G && L.pq_n) L.ovf |= OVF_BUG;
+    if (K::G && L.pq_n) OVF_SET(L, OVF_BUG);
 #endif
     while (L.top_dl <= now) {
         // Global-state builds: the callback's first loads (the woken task's flag word; the destination socket's header and

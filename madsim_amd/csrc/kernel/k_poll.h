@@ -56,7 +56,7 @@ __device__ __forceinline__ uint4 insn_fetch(const Ctx& c, Lane& L, uint32_t pc) 
         if (own && (SOCKW(c, s) & 0x8000u)) {
             if (handle_names_its_socket<K>(c, s)) in.x = (in.x & ~0xff00u) | (sock_resolve<K>(c, s) << 8);
             else if (op == MS_OP_CLOSE) in = make_uint4(MS_OP_JMP | ((pc + 1) << 16), 0, 0, 0);
-            else { L.ovf |= OVF_MODEL; in.x = (in.x & ~0xff00u) | (sock_resolve<K>(c, s) << 8); }
+            else { OVF_SET(L, OVF_MODEL); in.x = (in.x & ~0xff00u) | (sock_resolve<K>(c, s) << 8); }
         }
     }
     return in;
@@ -169,8 +169,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.x &= ~TF_INBOX;
                 uint32_t h = SW(c, ca, 0);
                 uint32_t nreg = (h >> 9) & 0xff;
-                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) L.ovf |= OVF_CAP;   // 8-bit rxseq wrapped onto a dead twin
-                if (nreg >= P.mbox_regs) L.ovf |= OVF_CAP;
+                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) OVF_SET(L, OVF_CAP);   // 8-bit rxseq wrapped onto a dead twin
+                if (nreg >= P.mbox_regs) OVF_SET(L, OVF_CAP);
                 else {
                     SW(c, ca, 2 + nreg) = reg;
                     SW(c, ca, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
@@ -229,8 +229,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         }
         cu0_set(id | (1u << 8));                                           // server side
         // Sender { _guard: self.guard.clone(), tx }, Receiver { _guard: self.guard.clone(), rx } (endpoint.rs:203-210)
-        // (the connection dropped above is another one — this one sat in the queue — so its header word read before the drop stands)
-        CONNW(id, 0) = ((Hoist<K>::CHAN ? cw_p : (uint32_t)CONNW(id, 0)) & ~(0x7fu << 25)) | (a << 25) | (1u << 31);
+        // (the header word read before the drop stands when the drop was of ANOTHER connection; a task that accepts its own
+        //  outgoing connection — bind a; connect1(a, a); accept1(a) — has just closed this one's client handles: read it again)
+        const bool own = (cx & 0xff) == id;
+        CONNW(id, 0) = ((Hoist<K>::CHAN && !own ? cw_p : (uint32_t)CONNW(id, 0)) & ~(0x7fu << 25)) | (a << 25) | (1u << 31);
         if (Hoist<K>::CHAN) guard_acquire_with<K>(c, L, a, ha); else guard_acquire<K>(c, L, a);
         return true;
     };
@@ -333,7 +335,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                             while (id < P.max_conns && (CONNW(id, 0) & 1)) id++;
                             q = acceptq_load<K>(c, (uint32_t)ds);
                         }
-                        if (id >= P.max_conns || ((uint32_t)q & 0xf) >= MADSIM_ACCEPTQ) { L.ovf |= OVF_CAP; }
+                        if (id >= P.max_conns) { OVF_SET(L, OVF_CAP); }
                         else {
                             CONNW(id, 0) = 1u | (a << 1) | (dial << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
@@ -345,6 +347,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                                 conn_drop_raw<K>(c, L, id, 1);     // address): `let _ = conn_tx.try_send(..)` drops (tx2, rx1) here
                             } else {
                                 uint32_t n = (uint32_t)q & 0xf;    // socket.new_connection -> conn_tx.try_send
+                                // (conn_tx is unbounded; this queue word holds MADSIM_ACCEPTQ ids.  A ninth connection waiting for accept1 is
+                                //  outside the model — no limit of madsim_limits_t grows the word — so it is MADSIM_UNSUPPORTED, decided at the
+                                //  same instruction by the oracle, not a capacity verdict that a re-run could never resolve)
+                                if (n >= MADSIM_ACCEPTQ) { OVF_SET(L, OVF_MODEL); n = MADSIM_ACCEPTQ - 1; }
                                 acceptq_store<K>(c, (uint32_t)ds, (q & ~0xfull) | (n + 1) | ((uint64_t)id << (4 + 7 * n)));
                                 uint32_t acc = Hoist<K>::CHAN ? acc_p : (uint32_t)SW(c, ds, base + 1);
                                 if (acc & 1) { SW(c, ds, base + 1) = 0; wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9); }
@@ -366,10 +372,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         // Rust: a second `Endpoint::bind("0.0.0.0:0")` beside the first) the two would have to coexist under one
                         // name: outside the model — the verdict says so, the oracle says the same (include/madsim_hip.h).  The
                         // handle word keeps {candidate, valid, the candidate's socket gen after that bind} to know.
-                        if (handle_names_its_socket<K>(c, a) && SW(c, base + ((uint32_t)SW(c, a, 0) >> 25), 1) != ~0u) L.ovf |= OVF_MODEL;
+                        if (handle_names_its_socket<K>(c, a) && SW(c, base + ((uint32_t)SW(c, a, 0) >> 25), 1) != ~0u) OVF_SET(L, OVF_MODEL);
                         uint32_t p = 0;
                         while (p < nk && find_exact<K>(c, node, (sw & 0x7fffu) | ((p + 1) << 16)) >= 0) p++;
-                        if (p == nk) { if (!(L.ovf & OVF_MODEL)) L.ovf |= OVF_CAP; p = 0; }    // (beside its own live Endpoint the handle has no candidate left by construction)
+                        if (p == nk) { OVF_SET(L, OVF_CAP); p = 0; }    // (beside its own live Endpoint the handle has no candidate left by construction)
                         SW(c, a, 0) = (p << 25) | (1u << 24) | (((((uint32_t)SW(c, base + p, 0) >> 1) + 1) & 0xff) << 16);
                         a = base + p;
                     }
@@ -498,12 +504,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     sub = 2;                               // oneshot already holds the value
                     SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
                 } else {
-                    if (nreg >= P.mbox_regs) L.ovf |= OVF_CAP;            // (a capacity verdict: the state no longer matters)
+                    if (nreg >= P.mbox_regs) OVF_SET(L, OVF_CAP);            // (a capacity verdict: the state no longer matters)
                     else {
                         const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
                         // dead registrations (timed-out / dropped receives, extended ops only) stay in the Vec like the
                         // reference's; an 8-bit rxseq that wraps onto one of them would make it look live: overflow, never a different answer
-                        if ((K::FT || K::FN) && may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf |= OVF_CAP;
+                        if ((K::FT || K::FN) && may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) OVF_SET(L, OVF_CAP);
                         SW(c, a, 2 + nreg) = reg;
                         SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
                         sub = 1;
@@ -538,10 +544,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.x |= TF_INBOX;
                 SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
             } else if (nreg >= P.mbox_regs) {
-                L.ovf |= OVF_CAP;
+                OVF_SET(L, OVF_CAP);
             } else {
                 const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
-                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) L.ovf |= OVF_CAP;   // rxseq wrapped onto a dead twin
+                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) OVF_SET(L, OVF_CAP);   // rxseq wrapped onto a dead twin
                 SW(c, a, 2 + nreg) = reg;
                 SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
             }
@@ -664,7 +670,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 else if (a == MADSIM_IPVS_DEL_SERVICE) d1 &= ~(1u << 24);                    // remove
                 else if (!((d1 >> 24) & 1u)) ok = false;                                     // .expect("service not found")
                 else if (a == MADSIM_IPVS_ADD_SERVER) {                                      // servers.push
-                    if (n >= 6) L.ovf |= OVF_CAP;
+                    if (n >= 6) OVF_SET(L, OVF_MODEL);                                       // (a seventh server: the seed's two state words are full — the oracle says MADSIM_UNSUPPORTED at the same call)
                     else {
                         if (n < 4) d0 |= (imm & 0xff) << (8 * n); else d1 |= (imm & 0xff) << (8 * (n - 4));
                         d1 += 1u << 16;
@@ -701,7 +707,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     uint32_t code = imm & 0xff;
                     if (a & 1) {       // panic!("{}", flag + imm): the message is the decimal text of the value, and the nodes' rows were
                         code = (uint32_t)GREGW(b & 3) + imm;     // evaluated for values up to panic_dyn_max only
-                        if (code > P.panic_dyn_max) { L.ovf |= OVF_CAP; code = MADSIM_PANIC_CODE_OTHER; }
+                        if (code > P.panic_dyn_max) { OVF_SET(L, OVF_MODEL); code = MADSIM_PANIC_CODE_OTHER; }   // (the workload's own declaration: MADSIM_UNSUPPORTED on both sides)
                     }
                     L.panic_code = code;
                 }
@@ -764,7 +770,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (arrive == CHAN_LINK_PANIC) { st = ST_PANIC; break; }
                 if (!(cw & (1u << (14 + 2 * side)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // ConnectionReset
                 uint32_t qn = (cw >> (17 + 4 * side)) & 0xf;
-                if (qn >= P.chan_queue) { L.ovf |= OVF_CAP; pc++; break; }
+                if (qn >= P.chan_queue) { OVF_SET(L, OVF_CAP); pc++; break; }
                 uint32_t e = 3 + (side * P.chan_queue + qn) * 3;
                 CONNW(id, e) = imm; CONNW(id, e + 1) = (uint32_t)arrive; CONNW(id, e + 2) = (uint32_t)(arrive >> 32);
                 CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * side))) | ((qn + 1) << (17 + 4 * side));

@@ -82,8 +82,19 @@ template <bool TRACE_, bool SPILL_, int LWS_, int FEAT_, bool RQ_ = false, bool 
 
 // Lane::ovf: OVF_CAP = a device capacity was exceeded (MADSIM_OVERFLOW: run again with larger limits); OVF_MODEL = the seed
 // did what the workload model cannot say (MADSIM_UNSUPPORTED; the oracle reports the same); OVF_BUG = an invariant of this code
-// broke (MADSIM_INTERNAL: the parity tests assert it never shows).  A capacity verdict wins: the re-run decides the rest.
+// broke (MADSIM_INTERNAL: the parity tests assert it never shows).  The FIRST bit raised is the seed's verdict: what runs
+// after it inside the same round runs on state the event already spoiled (a dropped message, a stale handle), so a later bit says
+// nothing — a capacity verdict raised first is re-run with larger limits and decides the rest then; a model verdict raised first
+// is what the oracle reports at that very instruction.
 enum : uint32_t { OVF_CAP = 1, OVF_MODEL = 2, OVF_BUG = 4 };
+// OVF_SET(L, bits): the one way a verdict bit is raised.  The host-compiled test harness (tests/emu) can name the site that raised
+// it (MADSIM_EMU_OVF_DEBUG=1: file:line on stderr) — "which capacity was it" is the first question behind every MADSIM_OVERFLOW.
+#ifdef MADSIM_EMU
+void madsim_emu_ovf_note(const char* file, int line, uint32_t bits);
+#define OVF_SET(L, bits) ((L).ovf = (L).ovf ? (L).ovf : (bits), madsim_emu_ovf_note(__FILE__, __LINE__, (bits)))
+#else
+#define OVF_SET(L, bits) ((L).ovf = (L).ovf ? (L).ovf : (bits))
+#endif
 struct Lane {
     // GlobalRng
     uint64_t s0, s1, s2, s3;

@@ -170,10 +170,10 @@ __device__ __forceinline__ bool dedup_note(const Ctx& c, uint64_t deadline, uint
 template <class K>
 // `again` = the call re-registers a Sleep whose first timer is still in the heap (DEDUP builds: see dedup_note).
 __device__ __forceinline__ void timer_schedule(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val, bool wake, bool again = false) {
-    if (!K::G) { if (!timer_add<K>(c, L, deadline, meta, val)) L.ovf |= OVF_CAP; return; }
+    if (!K::G) { if (!timer_add<K>(c, L, deadline, meta, val)) OVF_SET(L, OVF_CAP); return; }
     if (wake) {
         const uint32_t n = L.pq_n & 7u;
-        if (n >= 3) L.ovf |= OVF_BUG;                            // (cannot happen: a round makes at most three; never a lost timer)
+        if (n >= 3) OVF_SET(L, OVF_BUG);                            // (cannot happen: a round makes at most three; never a lost timer)
         else {
             // (value selects, not `if (n == 0) L.pq_w0 = ..`: a store through a selected field address keeps the whole Lane in scratch)
             L.pq_w0 = n == 0 ? deadline : L.pq_w0; L.pq_w1 = n == 1 ? deadline : L.pq_w1; L.pq_w2 = n == 2 ? deadline : L.pq_w2;
@@ -181,7 +181,7 @@ __device__ __forceinline__ void timer_schedule(const Ctx& c, Lane& L, uint64_t d
             if (K::DEDUP && again) L.pq_n |= 8u << n;
         }
     } else {
-        if (L.pq_n) L.ovf |= OVF_BUG;                            // (cannot happen: one delivery per round, before its wake-ups)
+        if (L.pq_n) OVF_SET(L, OVF_BUG);                            // (cannot happen: one delivery per round, before its wake-ups)
         L.pq_deliv_dl = deadline; L.pq_deliv_meta = meta; L.pq_deliv_val = val; L.pq_n |= 0x80u;
     }
 }
@@ -199,7 +199,7 @@ __device__ __forceinline__ void timer_flush(const Ctx& c, Lane& L, uint32_t wake
             L.pq_n = ((L.pq_n & 7u) - 1u) | ((L.pq_n >> 1) & 0x18u);        // one wake-up less; the repeat flags move down with their deadlines
             if (again && c.P.dedup_n && !L.exact && dedup_note(c, dl, meta)) continue;
         }
-        if (!timer_add<K>(c, L, dl, meta, val)) L.ovf |= OVF_CAP;
+        if (!timer_add<K>(c, L, dl, meta, val)) OVF_SET(L, OVF_CAP);
     }
 }
 

@@ -776,7 +776,9 @@ static int poll_task(sim_t* S, uint16_t slot) {
             else {
                 if (!S->ipvs_present[k]) return 1;         /* .expect("service not found") */
                 if (in->a == MADSIM_IPVS_ADD_SERVER) {
-                    if (S->ipvs_n[k] >= 256) return 1;      /* (this restatement's own bound; the device gives MADSIM_OVERFLOW beyond six) */
+                    /* servers is an unbounded Vec (net/ipvs.rs:66-72); the workload model holds six servers per service (include/madsim_hip.h,
+                     * MADSIM_UNSUPPORTED): a seventh leaves the model at this call, on the device at the same one */
+                    if (S->ipvs_n[k] >= 6) { S->unsupported = 1; return 1; }
                     S->ipvs_srv[k][S->ipvs_n[k]++] = (uint8_t)in->imm;      /* servers.push */
                 } else {                                    /* servers.retain(|addr| addr != server_addr): equal address strings */
                     const addr_t gone = addr_of_sock(S, in->imm);
@@ -800,10 +802,11 @@ static int poll_task(sim_t* S, uint16_t slot) {
         }
         case MS_OP_PANIC:                                  /* the message code restart_on_panic_matching looks at */
             /* a run-time formatted message is the decimal text of its value: values beyond the workload's panic_dyn_max are outside
-             * what the patterns were evaluated for (the device reports MADSIM_OVERFLOW there; here: a message no pattern names) */
+             * what the patterns were evaluated for */
             if (in->a & 1) {
                 const uint32_t v = S->greg[in->b & 3] + in->imm, dyn_max = w->panic_dyn_max ? w->panic_dyn_max : 254u;
-                S->panic_code = v > dyn_max ? MADSIM_PANIC_CODE_OTHER : (uint8_t)v;
+                if (v > dyn_max) { S->unsupported = 1; return 1; }      /* the workload declared the largest value it formats: beyond it, outside the model */
+                S->panic_code = (uint8_t)v;
             } else S->panic_code = (uint8_t)in->imm;
             return 1;
         case MS_OP_SET:
@@ -963,6 +966,9 @@ static int poll_task(sim_t* S, uint16_t slot) {
                         conn_drop_handles(S, (int)id, 1, 0);   /* the listener's Endpoint is gone (its address is held by connections
                                                                   it accepted): the channel is closed, (tx2, rx1) are dropped here */
                     } else {
+                        /* conn_tx is an unbounded channel (endpoint.rs:307); the workload model holds eight connections waiting for
+                         * accept1 per Endpoint (include/madsim_hip.h): a ninth leaves the model here (MADSIM_UNSUPPORTED, both sides) */
+                        if (k->acceptq.n >= 8) { S->unsupported = 1; return 1; }
                         vec_push(k->acceptq, (uint8_t)id);
                         if (k->acc_task >= 0) { int32_t a = k->acc_task; k->acc_task = -1; wake(S, (uint16_t)a, k->acc_gen); }
                     }

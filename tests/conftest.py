@@ -30,3 +30,16 @@ def hip():
     runtime.init(0)
     yield runtime
     runtime.shutdown()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """The fuzz suites' account of themselves: per generator, seeds compared / re-run with grown capacities after a first-pass
+    MADSIM_OVERFLOW / proven beyond the layout's ceilings (tests/parity.py: the only seeds that are not compared)."""
+    for modname in ("tests.test_gpu_parity", "tests.test_emu_parity"):
+        mod = sys.modules.get(modname)
+        t = getattr(mod, "TALLY", None)
+        if t is not None and t.rows:
+            terminalreporter.write_line(f"[{modname}] fuzz parity: {t.n} seeds compared with the oracle, {t.rerun} of them after a re-run "
+                                        f"with grown capacities, {t.unresolved} proven beyond the layout's ceilings")
+            for k, v in sorted(t.rows.items()):
+                terminalreporter.write_line(f"    {k}: seeds {v[0]}, re-run {v[1]}, beyond ceilings {v[2]}")

@@ -22,10 +22,21 @@ _SRCS = [os.path.join(_HERE, "emu_driver.cpp"), os.path.join(_HERE, "emu_shim.h"
          os.path.join(_ROOT, "include", "madsim_hip.h")]
 
 
+def _stale():
+    return not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in _SRCS)
+
+
 def build():
-    if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in _SRCS):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DMADSIM_EMU", "-x", "c++",
-                               "-I" + _HERE, "-o", _LIB, _SRCS[0]])
+    """(pytest-xdist workers may arrive together: one builds under a file lock into a temporary name, the others wait)"""
+    if _stale():
+        import fcntl
+        with open(_LIB + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if _stale():
+                tmp = f"{_LIB}.{os.getpid()}.tmp"
+                subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DMADSIM_EMU", "-x", "c++",
+                                       "-I" + _HERE, "-o", tmp, _SRCS[0]])
+                os.replace(tmp, _LIB)
     return _LIB
 
 

@@ -104,6 +104,14 @@ extern "C" uint64_t madsim_emu_gstat(int kind, uint32_t word) { return word < gs
 extern "C" void madsim_emu_gstat_reset(uint32_t stride) { for (auto& g : gstat) g.clear(); gstat_stride = stride ? stride : 1; }
 #endif
 
+// k_state.h OVF_SET: which site raised a verdict bit (MADSIM_EMU_OVF_DEBUG=1 -> stderr)
+namespace madsim_k {
+void madsim_emu_ovf_note(const char* file, int line, uint32_t bits) {
+    static const bool on = getenv("MADSIM_EMU_OVF_DEBUG") != nullptr;
+    if (on) { const char* b = strrchr(file, '/'); fprintf(stderr, "[emu] verdict bit %u raised at %s:%d\n", bits, b ? b + 1 : file, line); }
+}
+}  // namespace madsim_k
+
 extern "C" const char* madsim_emu_last_error(void) { return emu_err.c_str(); }
 
 extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,

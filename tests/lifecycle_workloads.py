@@ -594,6 +594,38 @@ ALL.update(endpoint_bind_ephemeral=endpoint_bind_ephemeral, ephemeral_clients=ep
            channel_wildcard_listener=channel_wildcard_listener, channel_loopback=channel_loopback)
 
 
+def channel_self_connect_accept():
+    """One task on both ends of its own connection: `ep.connect1(ep.addr)` then `ep.accept1()` (net/mod.rs:337-364,
+    endpoint.rs:196-212).  The (tx, rx) the accept returns replaces the client pair the task held, so the client's Sender and
+    Receiver drop at that assignment: the accepted Receiver sees the channel closed (RESET), after whatever the client end
+    had sent first.  (Round-4 advisor finding: the global-state builds wrote a stale connection header back here.)"""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    a = wl.addr(n, 1)
+    t = wl.task(n); t.bind(a); t.connect1(a, a); t.assert_val(0); t.accept1(a); t.chan_recv(); t.assert_val(A.VAL_RESET); t.done()
+    m = wl.main(); m.spawn(t); m.join(t)
+    return wl.build()
+
+
+def channel_self_connect_send_then_accept():
+    """As above with a payload in flight: the client end sends 5, then the task accepts its own connection (dropping the
+    client pair) and receives 5 through the accepted Receiver, then RESET; a second task dials the same Endpoint meanwhile so
+    the accept queue holds two connections and the drop happens beside a live one."""
+    wl = W.WorkloadBuilder()
+    n, n2 = wl.create_node(), wl.create_node()
+    a, b = wl.addr(n, 1), wl.addr(n2, 1)
+    t = wl.task(n); t.bind(a); t.connect1(a, a); t.assert_val(0); t.chan_send(5); t.sleep(ms=20)
+    t.accept1(a); t.chan_recv(); t.trace_val(); t.chan_recv(); t.trace_val()
+    t.accept1(a); t.chan_recv(); t.trace_val(); t.done()
+    o = wl.task(n2); o.bind(b); o.sleep(ms=5); o.connect1(b, a); o.assert_val(0); o.chan_send(9); o.sleep(ms=200); o.done()
+    m = wl.main(); m.spawn(t); m.spawn(o); m.join(t); m.join(o)
+    return wl.build()
+
+
+ALL.update(channel_self_connect_accept=channel_self_connect_accept,
+           channel_self_connect_send_then_accept=channel_self_connect_send_then_accept)
+
+
 def std_system_time():
     """time/system_time.rs:122-154: `t0 = SystemTime::now(); sleep(1 s); assert!(t0.elapsed() >= 1 s); t0` — the observed
     wall-clock time depends on the seed (base time drawn around 2022), the Instant-based duration does not."""

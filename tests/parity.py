@@ -1,0 +1,170 @@
+"""Strict parity comparison for the fuzz suites (test infrastructure).
+
+A device capacity verdict (MADSIM_OVERFLOW) is a statement about the runner, not about the simulated program: the reference's
+containers are unbounded (net/endpoint.rs:288-300 `Vec` mailboxes, time/mod.rs:158-165 the timer heap) and the oracle has no
+capacities at all.  So a seed that comes back OVERFLOW has not been compared with anything yet.  `compare()` therefore runs
+such seeds AGAIN with grown capacities — the product's own `madsim_hip_run_batch_auto` on the GPU, the same growth rule applied
+seed by seed on the host-compiled kernel — and compares what that returns with the oracle on all 48 result bytes.  A seed that
+is still a runner verdict after the largest capacities fails the test unless the oracle's own high-water marks prove that
+it needs more than the device layout can hold at all (counted apart, `beyond`): every fuzzed seed is a compared seed.
+
+(The step cap is modelled by the oracle — MADSIM_STEP_LIMIT at the same step — so it is compared like any other verdict and the
+re-run keeps the cap where it was: `max_steps_ceiling` is pinned to the first pass's cap.)
+"""
+import numpy as np
+
+import oracle
+from madsim_amd import _abi as A
+
+LIMIT_NONE = 0xFFFFFFFF
+
+
+def grow(lim, n_progs):
+    """One round of madsim_hip.cpp `grow()` for capacity verdicts: every device capacity doubled."""
+    def dbl(v, dflt, cap):
+        x = dflt if v in (0, LIMIT_NONE) else v
+        return min(2 * x, cap)
+    g = A.Limits()
+    for f, _ in A.Limits._fields_:
+        setattr(g, f, getattr(lim, f))
+    g.lanes_per_wave = 0
+    if (g.state_mem & 0xff) == A.STATE_COMPACT:
+        g.state_mem = (g.state_mem & ~0xff) | A.STATE_AUTO
+    g.heap_lds_slots = g.heap_lds_slots or 8
+    g.heap_spill_slots = dbl(g.heap_spill_slots, 32, 1 << 20)
+    g.max_tasks = dbl(g.max_tasks, n_progs + 8, 254)
+    g.mbox_regs = dbl(g.mbox_regs, 2, 255)
+    g.mbox_msgs = dbl(g.mbox_msgs, 2, 255)
+    g.max_conns = dbl(g.max_conns, 4, 127)
+    g.chan_queue = dbl(g.chan_queue, 2, 15)
+    return g
+
+
+def pin_step_cap(lim):
+    g = A.Limits()
+    for f, _ in A.Limits._fields_:
+        setattr(g, f, getattr(lim, f))
+    g.max_steps_ceiling = 1                     # (floored at the first pass's cap: STEP_LIMIT seeds are not re-run, the oracle models them)
+    return g
+
+
+class Tally:
+    """seeds compared / re-run with grown capacities / proven beyond the layout's ceilings (the only seeds not compared), per label."""
+
+    def __init__(self):
+        self.rows = {}
+        self.verdicts = set()
+
+    def add(self, label, n, rerun, unresolved, verdicts=()):
+        r = self.rows.setdefault(label, [0, 0, 0])
+        r[0] += n; r[1] += rerun; r[2] += unresolved
+        self.verdicts |= set(verdicts)
+
+    @property
+    def n(self):
+        return sum(r[0] for r in self.rows.values())
+
+    @property
+    def rerun(self):
+        return sum(r[1] for r in self.rows.values())
+
+    @property
+    def unresolved(self):
+        return sum(r[2] for r in self.rows.values())
+
+    def __str__(self):
+        return "; ".join(f"{k}: seeds {v[0]}, re-run {v[1]}, beyond ceilings {v[2]}" for k, v in self.rows.items())
+
+
+def resolve_with_auto(run_auto, w, seed0, count, cfg, lim, max_rounds=8):
+    """GPU: the product's own re-run (madsim_hip_run_batch_auto) with the step cap pinned."""
+    got, _ = run_auto(w, seed0, count, cfg, pin_step_cap(lim), max_rounds=max_rounds)
+    return got
+
+
+def resolve_seed_by_seed(run, w, seed0, got, cfg, lim, max_rounds=8):
+    """Host-compiled kernel: the same growth rule, one seed per call."""
+    out = got.copy()
+    cur = lim
+    for _ in range(max_rounds):
+        idx = np.nonzero(out["verdict"] == A.OVERFLOW)[0]
+        if not len(idx):
+            break
+        cur = grow(cur, w.struct.n_progs)
+        for i in idx:
+            out[i] = run(w, seed0 + int(i), 1, cfg, cur)[0]
+    return out
+
+
+# The absolute ceilings of the device layout (include/madsim_hip.h): the largest value `grow()` can reach per capacity.
+CEILINGS = dict(max_tasks=254, max_regs=255, max_msgs=255, max_conns=127, max_cq=15, max_heap=8 + (1 << 20))
+
+
+def beyond_ceiling(w, seed, cfg, lim):
+    """Does this seed NEED more than the device layout can hold at its largest?  Decided by the oracle's own high-water marks
+    (its containers are the reference's unbounded ones): the name of a capacity whose mark exceeds the ceiling, or None."""
+    _, _, st = oracle.run_batch(w, seed, 1, cfg, lim, want_stats=True)
+    for f, cap in CEILINGS.items():
+        if getattr(st, f) > cap:
+            return f"{f} {getattr(st, f)} > {cap}"
+    return None
+
+
+def compare(got, want, resolve, label="", tally=None, what=None, ceiling=None):
+    """`got` = first pass of the kernel under test, `want` = the oracle.  Seeds with a capacity verdict are resolved through
+    `resolve()` (-> a full result array of the same shape with those seeds re-run) and then compared strictly.
+    A seed that is STILL a capacity verdict after the largest capacities is accepted only with a proof: `ceiling(i)` must name a
+    capacity whose high-water mark in the oracle's run of that seed exceeds what the layout can hold at all (a livelocked program
+    that leaks a registration per round, say).  Such seeds are counted apart (`beyond`); anything else fails."""
+    ovf = got["verdict"] == A.OVERFLOW
+    n_rerun = int(ovf.sum())
+    final = got
+    if n_rerun:
+        final = resolve()
+        # a re-run may only change seeds that had a runner verdict
+        same = (final == got) | ovf
+        assert same.all(), (what, "the re-run changed a seed that had a genuine verdict", got[~same][0], final[~same][0])
+    bad = final != want
+    still = np.nonzero(final["verdict"] == A.OVERFLOW)[0]
+    beyond = 0
+    for i in still:
+        why = ceiling(int(i)) if ceiling else None
+        assert why, (what, f"seed index {int(i)} is still MADSIM_OVERFLOW after the largest capacities and the oracle's high-water marks "
+                           "are all inside the layout's ceilings: an unexplained capacity verdict", final[i], want[i])
+        bad[i] = False
+        beyond += 1
+    if tally is not None:
+        tally.add(label, len(got), n_rerun, beyond, want["verdict"].tolist())
+    assert not bad.any(), (what, f"{int(bad.sum())} of {len(got)} seeds differ (re-run {n_rerun}, beyond the layout's ceilings {beyond})",
+                           final[bad][0], want[bad][0])
+    return final
+
+
+def gpu_compare(hip, w, seed0, count, cfg, lim, label="", tally=None, what=None, max_rounds=8):
+    lim = lim or A.Limits()
+    got, _ = hip.run_batch(w, seed0, count, cfg, lim)
+    want, _ = oracle.run_batch(w, seed0, count, cfg, lim)
+    return compare(got, want, lambda: resolve_with_auto(hip.run_batch_auto, w, seed0, count, cfg, lim, max_rounds), label, tally, what,
+                   lambda i: beyond_ceiling(w, seed0 + i, cfg, lim)), want
+
+
+def emu_compare(emu, w, seed0, count, cfg, lim, label="", tally=None, what=None, max_rounds=8):
+    lim = lim or A.Limits()
+    got = emu.run_batch(w, seed0, count, cfg, lim)
+    want, _ = oracle.run_batch(w, seed0, count, cfg, lim)
+    return compare(got, want, lambda: resolve_seed_by_seed(emu.run_batch, w, seed0, got, cfg, lim, max_rounds), label, tally, what,
+                   lambda i: beyond_ceiling(w, seed0 + i, cfg, lim)), want
+
+
+def run_resolved(hip, w, seed0, count, cfg, lim, max_rounds=8):
+    """Batch-size comparisons: the plain call (what bench.py times), then — when a capacity verdict shows — the product's own re-run;
+    -> (final results, number of first-pass capacity verdicts).  No seed of `final` may still be MADSIM_OVERFLOW."""
+    lim = lim or A.Limits()
+    first, _ = hip.run_batch(w, seed0, count, cfg, lim)
+    ovf = first["verdict"] == A.OVERFLOW
+    if not ovf.any():
+        return first, 0
+    final, _ = hip.run_batch_auto(w, seed0, count, cfg, pin_step_cap(lim), max_rounds=max_rounds)
+    assert ((final == first) | ovf).all(), "the re-run changed a seed that had a genuine verdict"
+    assert not (final["verdict"] == A.OVERFLOW).any(), f"{int((final['verdict'] == A.OVERFLOW).sum())} seeds still MADSIM_OVERFLOW after {max_rounds} rounds"
+    return final, int(ovf.sum())

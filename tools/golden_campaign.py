@@ -31,7 +31,7 @@ for gi, gname in enumerate(gens):
         seeds = (0, 1, 2, 3, 7)
         want, _ = oracle.run_batch(w, 0, max(seeds) + 1, config=cfg, limits=lim)
         for s in seeds:
-            if int(want[s]["verdict"]) in (A.OVERFLOW, A.STEP_LIMIT):      # the runner's limits, not a verdict of the simulation
+            if int(want[s]["verdict"]) in (A.OVERFLOW, A.STEP_LIMIT, A.UNSUPPORTED):      # the runner's limits / the workload model's, not a verdict of the simulation
                 continue
             g = G.Sim(w, cfg, s).run()
             o = {f: int(want[s][f]) for f in FIELDS}
