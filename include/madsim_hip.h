@@ -323,7 +323,8 @@ typedef struct madsim_limits {
 #define MADSIM_STATE_AUTO   0u   /* LDS unless an extended-op workload's state leaves a CU fewer than 4 full waves       */
 #define MADSIM_STATE_LDS    1u   /* all per-seed state in LDS ([word][lane] planes)                                       */
 #define MADSIM_STATE_GLOBAL 2u   /* extended-op workloads: task table + planes in global memory ([unit][lane] across the launch:
-                                    L2 / Infinity Cache / HBM), only the timer-heap top and the ready queue in LDS       */
+                                    L2 / Infinity Cache / HBM), only the timer-heap top and the ready queue in LDS.  A workload
+                                    of base ops only has no such build and keeps its state in LDS (the setting is ignored)  */
 
 #define MADSIM_STATE_COMPACT 3u  /* base-op workloads on full waves, <= 8 tasks, no heap spill, sleeps < 2.1 s: 8-byte timer-heap entries (low
                                     deadline word: exact inside that horizon), heap root in registers, the main task in global memory —

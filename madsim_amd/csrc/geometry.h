@@ -455,7 +455,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // VGPR budget (tools/kernel_meta.sh): base builds ~110 VGPRs = 4 waves per SIMD, single-class builds 133 / 151 = 3,
     // the full extended build ~180 = 2
     const madsim_k::VariantSel vsel = madsim_k::select_variant(P, trace);
-    uint32_t cap = vsel.feat == 0 ? 16u : (vsel.feat == MADSIM_FEAT_TIME || vsel.feat == MADSIM_FEAT_CHAN || (vsel.g && (vsel.feat & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) != (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR))) ? 12u : 8u;
+    uint32_t cap = (vsel.feat & MADSIM_FEAT_ALL) == 0 ? 16u : (vsel.feat == MADSIM_FEAT_TIME || vsel.feat == MADSIM_FEAT_CHAN || (vsel.g && (vsel.feat & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) != (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR))) ? 12u : 8u;
     if (g.vgprs) {                       // 512 VGPRs per SIMD lane, allocated in blocks of 8; at most 8 waves per SIMD
         int r = g.vgprs(&vsel);
         if (r > 0) { uint32_t per_simd = 512u / (uint32_t)((r + 7) & ~7); cap = 4u * (per_simd > 8 ? 8u : per_simd < 1 ? 1u : per_simd); }
@@ -482,6 +482,12 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     G->grid = (uint32_t)(want_blocks < resident ? want_blocks : resident);
     if (G->grid == 0) G->grid = 1;
     P.total_lanes = G->grid * W * lw;
+    // the pair (parameter block, build) and the LDS arithmetic are checked once more as a whole: an inconsistent pair is refused here,
+    // it is never launched (sim_kernel.h variant_mismatch; tests/test_geometry_consistency.py walks the combinations)
+    if (const char* why = madsim_k::variant_mismatch(P, madsim_k::select_variant(P, trace), trace))
+        return fail(err, MADSIM_E_LIMITS, std::string("no kernel build for this geometry: ") + why);
+    if ((size_t)G->lds_bytes > g.lds_per_cu || (size_t)G->blocks_per_cu * lds_alloc(W) > std::max<size_t>(g.lds_per_cu, lds_alloc(W)))
+        return fail(err, MADSIM_E_LIMITS, "no kernel build for this geometry: the workgroups of a CU exceed its LDS");
     return 0;
 }
 

@@ -206,6 +206,9 @@ __device__ __forceinline__ void timer_flush(const Ctx& c, Lane& L, uint32_t wake
 // BinaryHeap::pop: swap the last element into the root, sift_down_to_bottom(0), then sift_up.
 template <class K>
 __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
+#ifdef MADSIM_EMU
+    if (K::G && L.pq_n) OVF_SET(L, OVF_BUG);      // a pop with Timer::add calls of the round still queued (see timer_expire, k_net.h): MADSIM_INTERNAL in the emulation suite
+#endif
     PROBE2(0);
     REG(20);
     uint32_t end = --L.heap_len;

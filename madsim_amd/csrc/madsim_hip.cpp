@@ -344,8 +344,7 @@ int madsim_hip_ctx::run_host(const madsim_workload_t* w, const madsim_config_t* 
     int rc;
     if (count > PIPE_BATCH_HOST) {             // more than one batch: sub-launches kept in flight, copies overlapped (run_pipelined)
         if ((rc = madsim_geo::validate(w, cfg, &g_err))) return rc;
-        if (!out) return fail(MADSIM_E_ARG, "null result buffer");
-        unsigned long long a[6];
+        unsigned long long a[6];                     // (`out` may be NULL: summary only — no staging buffers, no copies)
         double ms = 0.0;
         madsim_hip_ctx* one[1] = {this};
         if ((rc = run_pipelined_fwd(one, 1, w, cfg, seed0, count, lim, out, a, &ms))) return rc;
@@ -536,7 +535,7 @@ int run_pipelined(madsim_hip_ctx* const* ctxs, int n_ctx, const madsim_workload_
         int e;
         if (note(e = p.c->bind())) break;
         p.F = (uint32_t)std::min<uint64_t>(p.nb, p.c->flights_for(w, cfg, lim, std::min(p.n, PIPE_BATCH)));
-        if (note(e = p.c->ensure_flights(p.F, std::min(p.n, PIPE_BATCH), true))) break;
+        if (note(e = p.c->ensure_flights(p.F, std::min(p.n, PIPE_BATCH), out != nullptr))) break;
     }
     if (first_err) return fail(first_err, first_msg);
     auto queue = [&](Pipe& p) -> int {
@@ -583,7 +582,16 @@ int run_pipelined(madsim_hip_ctx* const* ctxs, int n_ctx, const madsim_workload_
             if (p.harvested < p.launched) { note(harvest(p)); any = true; }
         if (!any) break;
     }
-    if (first_err) return fail(first_err, first_msg);
+    if (first_err) {
+        // A queue() that failed between its kernel launch and the record of `done` leaves that event stale (or never recorded): the
+        // harvest above returned at once.  No kernel may stay in flight behind an error return — it would still be writing the
+        // flight's buffers — so every stream this call used is drained for real.
+        for (Pipe& p : pp) {
+            if (!p.F || p.c->bind()) continue;
+            for (uint32_t i = 0; i < p.F; i++) (void)hipStreamSynchronize(p.c->flights[i].stream);
+        }
+        return fail(first_err, first_msg);
+    }
     unsigned long long a[6] = {~0ull, 0, 0, 0, ~0ull, 0};
     double ms = 0.0;
     for (Pipe& p : pp) {
@@ -868,7 +876,10 @@ int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* c, const madsim_workload_t* w,
     }
     out->batches_launched = launched;
     out->wall_s = since(t0);
-    if (first_err) return fail(first_err, first_msg);
+    if (first_err) {                                             // (as in run_pipelined: a stale `done` must not let a kernel outlive the call)
+        for (uint32_t i = 0; i < in_flight; i++) (void)hipStreamSynchronize(c->flights[i].stream);
+        return fail(first_err, first_msg);
+    }
     return 0;
 }
 

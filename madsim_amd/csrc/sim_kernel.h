@@ -158,6 +158,41 @@ inline VariantSel select_variant(const KParams& P, bool trace) {
     return {0, 1, -1, MADSIM_FEAT_ALL, 0, 0};
 }
 
+// Is the build `v` names one of the compiled set?  (Host-side twin of the dispatch chain in sim_kernel.hip: same macro, no kernels.)
+inline bool variant_compiled(const VariantSel& v) {
+    bool hit = false;
+#define MADSIM_VARIANT_HIT(T_, S_, L_, F_, R_, G_) \
+    hit = hit || (v.trace == (int)(T_) && v.spill == (int)(S_) && v.lws == (L_) && v.feat == (F_) && v.rq == (int)(R_) && v.g == (int)(G_));
+    MADSIM_FOR_EACH_VARIANT(MADSIM_VARIANT_HIT)
+#undef MADSIM_VARIANT_HIT
+    return hit;
+}
+
+// The contract between a parameter block and the build that will run it — checked by make_geometry before anything can be launched
+// (round 4 ran the 64-lane build of the every-class kernel on a 32-lane geometry once: a selection-order slip that hung a GPU box;
+// with this check such a pair is MADSIM_E_LIMITS, never a launch) and walked by tests/test_geometry_consistency.py over every
+// workload class x state_mem x lanes_per_wave.  Returns nullptr when consistent, else what is wrong.
+inline const char* variant_mismatch(const KParams& P, const VariantSel& v, bool trace) {
+    if (!variant_compiled(v)) return "select_variant names a build that is not compiled";
+    if (v.lws >= 0 && v.lws != (int)P.lw_shift) return "the build's compile-time lane stride differs from the geometry's";
+    if (P.lw_shift < 3 || P.lw_shift > 6) return "lane stride outside 8..64 seed lanes per wave";
+    if ((v.g != 0) != (P.gstate_mode != 0)) return "global-state build on an LDS-resident layout (or the reverse)";
+    if ((v.rq != 0) != (P.rq_in_reg != 0)) return "register ready queue build on a layout with an LDS ready queue (or the reverse)";
+    if (v.rq && (P.max_tasks > 8 || P.lw_shift != 6 || P.lifecycle)) return "register ready queue needs <= 8 tasks, full waves, base ops";
+    if (!v.spill && P.heap_spill) return "a build without the spill path on a geometry with spilled heap levels";
+    const int classes = v.feat & MADSIM_FEAT_ALL;
+    if (((int)P.features & ~classes) != 0) return "the build lacks an op class the workload uses";
+    if ((classes != 0) != (P.lifecycle != 0)) return "extended-op build on the base-op LDS layout (or the reverse)";
+    if (((v.feat & MADSIM_FEAT_COMPACT) != 0) != (P.compact != 0)) return "compact build on a plain layout (or the reverse)";
+    if (P.compact && (P.heap_spill || P.lifecycle || P.lw_shift != 6 || !P.rq_in_reg || P.max_tasks > 8)) return "compact layout outside its conditions";
+    if ((v.feat & MADSIM_FEAT_NOLOG) && (!P.no_log || trace)) return "a build without the determinism-log fold for a run that wants it";
+    if (P.dedup_n && !(v.g && classes == MADSIM_FEAT_TIME)) return "re-registration counts on a build that does not carry them";
+    if (P.dedup_n & (P.dedup_n - 1)) return "dedup_n must be a power of two";
+    if (P.waves_per_block != 1 && P.waves_per_block != 2 && P.waves_per_block != 4) return "a workgroup is 1, 2 or 4 waves";
+    if (trace != (v.trace != 0)) return "trace build / trace launch mismatch";
+    return nullptr;
+}
+
 }  // namespace madsim_k
 
 extern "C" {
