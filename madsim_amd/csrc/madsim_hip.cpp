@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <cstdlib>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -129,7 +130,19 @@ struct madsim_hip_ctx {
     uint32_t flights_for(const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim, uint64_t batch);
 };
 
+// The library keeps up to five sub-batches of a call in flight, each on its own HIP stream (run_pipelined, campaigns).  ROCclr maps
+// the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4): with more streams than queues two sub-batches share a
+// queue and run one after the other — measured on an MI355X (round 5, tools/experiment/exp_r5_runbatch.py): madsim_hip_run_batch(262 144)
+// 8.3 ms with the default, ~5 ms with 16 queues.  The variable is read when the HIP runtime initialises, so it is set here, before this
+// library's first HIP call, unless the host application has chosen a value itself (a process that has initialised HIP before
+// creating its first context keeps whatever it had).
+static void want_hw_queues() {
+    static const int once = setenv("GPU_MAX_HW_QUEUES", "16", 0 /* never override the host's own choice */);
+    (void)once;
+}
+
 int madsim_hip_ctx::open(int dev_index) {
+    want_hw_queues();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(MADSIM_E_HIP, "no HIP device visible (this library has no CPU fallback)");

@@ -35,6 +35,11 @@ if "SQ_WAVE_CYCLES" in m:
             out.append(f"{k} / SQ_WAVE_CYCLES = {m[k] / m['SQ_WAVE_CYCLES']:.3f}")
 if "SQ_INSTS_VALU" in m and "SQ_WAVES" in m:
     out.append(f"VALU insts per wave = {m['SQ_INSTS_VALU'] / m['SQ_WAVES']:.0f}; LDS insts per wave = {m.get('SQ_INSTS_LDS', 0) / m['SQ_WAVES']:.0f}; SALU per wave = {m.get('SQ_INSTS_SALU', 0) / m['SQ_WAVES']:.0f}")
+if "SQC_ICACHE_REQ" in m and m["SQC_ICACHE_REQ"]:
+    out.append(f"instruction cache: {m['SQC_ICACHE_MISSES'] / m['SQC_ICACHE_REQ']:.4f} misses per request ({m['SQC_ICACHE_MISSES']:.0f} of {m['SQC_ICACHE_REQ']:.0f}); "
+               f"SQ_IFETCH / SQ_WAVE_CYCLES = {m.get('SQ_IFETCH', 0) / m['SQ_WAVE_CYCLES']:.4f}" if "SQ_WAVE_CYCLES" in m else "")
+if "TCC_HIT_sum" in m and (m["TCC_HIT_sum"] + m.get("TCC_MISS_sum", 0)):
+    out.append(f"L2 hit rate = {m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']):.3f} ({m['TCC_HIT_sum']:.0f} hits, {m['TCC_MISS_sum']:.0f} misses)")
 if "FETCH_SIZE" in m:
     out.append(f"FETCH_SIZE = {m['FETCH_SIZE']:.1f} KB/dispatch (gfx950: doubles for wide coalesced reads, MI355X_MICROARCH.md §HBM)")
 if "WRITE_SIZE" in m:
