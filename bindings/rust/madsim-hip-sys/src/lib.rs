@@ -286,8 +286,9 @@ extern "C" {
     pub fn madsim_hip_ctx_timing_ms(ctx: *mut madsim_hip_ctx_t, timing_slot: c_int, ms: *mut f64) -> c_int;
     pub fn madsim_hip_ctx_trace_seed(ctx: *mut madsim_hip_ctx_t, w: *const madsim_workload_t, cfg: *const madsim_config_t, seed: u64, lim: *const madsim_limits_t, log: *mut u8, cap: u64, out: *mut madsim_result_t) -> i64;
     pub fn madsim_hip_run_batch_multi(ctxs: *const *mut madsim_hip_ctx_t, n_ctx: c_int, w: *const madsim_workload_t, cfg: *const madsim_config_t, seed0: u64, count: u64, lim: *const madsim_limits_t, out: *mut madsim_result_t, summary: *mut madsim_summary_t, max_rounds: c_int) -> c_int;
-    pub fn madsim_hip_ctx_run_campaign(ctx: *mut madsim_hip_ctx_t, w: *const madsim_workload_t, cfg: *const madsim_config_t, seed0: u64, total: u64, batch: u64, in_flight: u32, flags: u32, lim: *const madsim_limits_t, out: *mut madsim_campaign_t) -> define MADSIM_CAMPAIGN_STOP_AT_FAILURE 1u int;
+    pub fn madsim_hip_ctx_run_campaign(ctx: *mut madsim_hip_ctx_t, w: *const madsim_workload_t, cfg: *const madsim_config_t, seed0: u64, total: u64, batch: u64, in_flight: u32, flags: u32, lim: *const madsim_limits_t, out: *mut madsim_campaign_t) -> c_int;
     pub fn madsim_hip_run_campaign(w: *const madsim_workload_t, cfg: *const madsim_config_t, seed0: u64, total: u64, batch: u64, in_flight: u32, flags: u32, lim: *const madsim_limits_t, out: *mut madsim_campaign_t) -> c_int;
+    pub fn madsim_hip_run_campaign_multi(ctxs: *const *mut madsim_hip_ctx_t, n_ctx: c_int, w: *const madsim_workload_t, cfg: *const madsim_config_t, seed0: u64, total: u64, batch: u64, in_flight: u32, flags: u32, lim: *const madsim_limits_t, out: *mut madsim_campaign_t) -> c_int;
     pub fn madsim_hip_geometry(w: *const madsim_workload_t, lim: *const madsim_limits_t, g: *mut madsim_geometry_t) -> c_int;
     pub fn madsim_hip_debug_counters(out16: *mut u64) -> c_int;
     pub fn madsim_workload_pingpong(n_nodes: u32, rounds: u32, nodes: *mut madsim_node_t, progs: *mut madsim_prog_t, socks: *mut madsim_sock_t, insns: *mut madsim_insn_t, cap_insns: u32, w: *mut madsim_workload_t) -> c_int;

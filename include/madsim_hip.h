@@ -526,6 +526,17 @@ int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* ctx, const madsim_workload_t* 
 int madsim_hip_run_campaign(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t total,
                             uint64_t batch, uint32_t in_flight, uint32_t flags, const madsim_limits_t* lim,
                             madsim_campaign_t* out);
+/* The campaign over several devices from ONE host thread (one context per GPU; the multi-GPU form of `first-fail seeds per hour`):
+ * batch k of the range runs on context k % n_ctx, `in_flight` batches per context (0 = auto), and the reports are read in batch order.
+ * The devices advance through the seed range together, so MADSIM_CAMPAIGN_STOP_AT_FAILURE stops every device within one round of
+ * batches of the first genuine failure, and the report — first_failing_seed, n_failed, n_runner, steps, clock of the prefix
+ * [seed0, seed0 + seeds_run) — is the one a single context gives for the same prefix (runtime/builder.rs:129-160: the seeds are
+ * seed0 .. seed0 + count whatever runs them, the first failure in seed order is the one reported).  No collective: a report is
+ * 48 bytes per batch and the calling thread reads them anyway; ranks that are separate processes gather theirs over RCCL
+ * (madsim_amd/dist.py).  Locks the contexts in address order, drains every stream before an error return. */
+int madsim_hip_run_campaign_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const madsim_workload_t* w,
+                                  const madsim_config_t* cfg, uint64_t seed0, uint64_t total, uint64_t batch,
+                                  uint32_t in_flight, uint32_t flags, const madsim_limits_t* lim, madsim_campaign_t* out);
 
 /* Geometry the library picked for a workload (for DESIGN/bench reporting). */
 typedef struct madsim_geometry {

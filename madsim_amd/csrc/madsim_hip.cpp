@@ -826,29 +826,44 @@ int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const m
 }
 
 // ---- campaigns -------------------------------------------------------------------------------------------------------------
-int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* c, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t total,
-                                uint64_t batch, uint32_t in_flight, uint32_t flags, const madsim_limits_t* lim, madsim_campaign_t* out) {
-    if (!out) return fail(MADSIM_E_ARG, "null campaign report");
-    CTX_ENTER(c);
+// One implementation for one context and for several (madsim_hip_run_campaign_multi): batch k of the range runs on context k % n,
+// on that context's flight (k / n) % in_flight — the devices advance through the seed space TOGETHER, so with
+// MADSIM_CAMPAIGN_STOP_AT_FAILURE the search ends within one round of batches of the first genuine failure (contiguous blocks per
+// device — the rule of madsim_hip_run_batch_multi — would leave the devices that hold the smaller seeds running to their end).
+// Reports are read in batch order, so `first_failing_seed` is the smallest failing seed of the prefix [seed0, seed0 + seeds_run)
+// whatever the number of devices: the report of n contexts equals the report of one.  Builder::run's fan-out with an early exit
+// (runtime/builder.rs:129-160: every thread's result is joined in seed order, the first failure is re-raised).
+namespace {
+int run_campaign_impl(madsim_hip_ctx* const* ctxs, int n_ctx, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t total,
+                      uint64_t batch, uint32_t in_flight, uint32_t flags, const madsim_limits_t* lim, madsim_campaign_t* out) {
     auto t0 = std::chrono::steady_clock::now();
     memset(out, 0, sizeof *out);
     out->first_failing_seed = UINT64_MAX;
     int rc = madsim_geo::validate(w, cfg, &g_err);
     if (rc) return rc;
     if (batch == 0) batch = 65536;
-    if (in_flight == 0) in_flight = c->flights_for(w, cfg, lim, batch);
-    if (in_flight > (uint32_t)madsim_hip_ctx::CAMPAIGN_MAX) return fail(MADSIM_E_ARG, "at most 8 batches in flight");
+    if (in_flight > (uint32_t)madsim_hip_ctx::CAMPAIGN_MAX) return fail(MADSIM_E_ARG, "at most 8 batches in flight per context");
     if (seed0 + total < seed0) return fail(MADSIM_E_ARG, "seed0 + total wraps");
     if (total == 0) return 0;
-    const uint64_t n_batches = (total + batch - 1) / batch;
-    if (n_batches < in_flight) in_flight = (uint32_t)n_batches;
-    if ((rc = c->ensure_flights(in_flight, batch, false))) return rc;
+    const uint64_t n_batches = (total + batch - 1) / batch, N = (uint64_t)n_ctx;
+    std::vector<uint32_t> F(n_ctx);                             // flights per context: what its occupancy rewards, no more than it has batches
+    for (int g = 0; g < n_ctx; g++) {
+        if ((rc = ctxs[g]->bind())) return rc;
+        const uint64_t mine = (n_batches + N - 1 - (uint64_t)g) / N;      // batches g, g + n, g + 2n, ...
+        uint32_t f = in_flight ? in_flight : ctxs[g]->flights_for(w, cfg, lim, batch);
+        if ((uint64_t)f > mine) f = (uint32_t)mine;
+        F[g] = f;
+        if (f && (rc = ctxs[g]->ensure_flights(f, batch, false))) return rc;
+    }
     int first_err = 0;
     std::string first_msg;
-    auto queue = [&](uint64_t k) -> int {                       // batch k on flight k % in_flight
-        madsim_hip_ctx::Flight& f = c->flights[k % in_flight];
+    auto flight_of = [&](uint64_t k) -> madsim_hip_ctx::Flight& { const int g = (int)(k % N); return ctxs[g]->flights[(k / N) % F[g]]; };
+    auto queue = [&](uint64_t k) -> int {
+        madsim_hip_ctx* c = ctxs[k % N];
+        madsim_hip_ctx::Flight& f = flight_of(k);
         const uint64_t lo = k * batch, n = std::min(batch, total - lo);
         int e;
+        if ((e = c->bind())) return e;
         HIP_TRY(hipMemsetAsync(f.d_acc6, 0xff, 8, f.stream));
         HIP_TRY(hipMemsetAsync((char*)f.d_acc6 + 8, 0, 24, f.stream));
         HIP_TRY(hipMemsetAsync((char*)f.d_acc6 + 32, 0xff, 8, f.stream));
@@ -864,7 +879,10 @@ int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* c, const madsim_workload_t* w,
     };
     bool stop = false;
     auto harvest = [&](uint64_t k) -> int {                     // wait for batch k, fold its report (batches are read in order)
-        madsim_hip_ctx::Flight& f = c->flights[k % in_flight];
+        madsim_hip_ctx* c = ctxs[k % N];
+        madsim_hip_ctx::Flight& f = flight_of(k);
+        int e;
+        if ((e = c->bind())) return e;
         HIP_TRY(hipEventSynchronize(f.done));
         if (first_err) return 0;                                // (draining after an error: nothing is folded any more)
         const uint64_t lo = k * batch, n = std::min(batch, total - lo);
@@ -882,18 +900,49 @@ int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* c, const madsim_workload_t* w,
         return 0;
     };
     auto note = [&](int e) { if (e && !first_err) { first_err = e; first_msg = g_err; } };
+    // batch k may be queued once batch k - n * F[k % n] (the previous user of its flight) has been harvested
     uint64_t launched = 0, harvested = 0;
     while (harvested < launched || (launched < n_batches && !stop && !first_err)) {
-        if (launched < n_batches && !stop && !first_err && launched - harvested < in_flight) { note(queue(launched)); launched++; continue; }
+        const bool room = launched < n_batches && launched < harvested + N * (uint64_t)F[launched % N];
+        if (room && !stop && !first_err) { note(queue(launched)); launched++; continue; }
         note(harvest(harvested)); harvested++;                  // the oldest batch in flight: its stream takes the next launch
     }
     out->batches_launched = launched;
     out->wall_s = since(t0);
     if (first_err) {                                             // (as in run_pipelined: a stale `done` must not let a kernel outlive the call)
-        for (uint32_t i = 0; i < in_flight; i++) (void)hipStreamSynchronize(c->flights[i].stream);
+        for (int g = 0; g < n_ctx; g++) {
+            if (ctxs[g]->bind()) continue;
+            for (uint32_t i = 0; i < F[g]; i++) (void)hipStreamSynchronize(ctxs[g]->flights[i].stream);
+        }
         return fail(first_err, first_msg);
     }
     return 0;
+}
+}  // namespace
+
+int madsim_hip_ctx_run_campaign(madsim_hip_ctx_t* c, const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t total,
+                                uint64_t batch, uint32_t in_flight, uint32_t flags, const madsim_limits_t* lim, madsim_campaign_t* out) {
+    if (!out) return fail(MADSIM_E_ARG, "null campaign report");
+    CTX_ENTER(c);
+    madsim_hip_ctx* one[1] = {c};
+    return run_campaign_impl(one, 1, w, cfg, seed0, total, batch, in_flight, flags, lim, out);
+}
+
+int madsim_hip_run_campaign_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const madsim_workload_t* w, const madsim_config_t* cfg,
+                                  uint64_t seed0, uint64_t total, uint64_t batch, uint32_t in_flight, uint32_t flags,
+                                  const madsim_limits_t* lim, madsim_campaign_t* out) {
+    if (!out) return fail(MADSIM_E_ARG, "null campaign report");
+    if (!ctxs || n_ctx < 1) return fail(MADSIM_E_ARG, "run_campaign_multi needs at least one context");
+    for (int g = 0; g < n_ctx; g++) {
+        if (!ctxs[g]) return fail(MADSIM_E_NOINIT, "null context");
+        for (int h = 0; h < g; h++) if (ctxs[h] == ctxs[g]) return fail(MADSIM_E_ARG, "the same context appears twice");
+    }
+    std::vector<madsim_hip_ctx*> order(ctxs, ctxs + n_ctx);      // locks in address order (see madsim_hip_run_batch_multi)
+    std::sort(order.begin(), order.end(), [](madsim_hip_ctx* a, madsim_hip_ctx* b) { return std::less<madsim_hip_ctx*>()(a, b); });
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (madsim_hip_ctx* c : order) locks.emplace_back(c->mu);
+    for (int g = 0; g < n_ctx; g++) if (ctxs[g]->device < 0) return fail(MADSIM_E_NOINIT, "closed context");
+    return run_campaign_impl(ctxs, n_ctx, w, cfg, seed0, total, batch, in_flight, flags, lim, out);
 }
 
 

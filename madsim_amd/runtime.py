@@ -105,6 +105,7 @@ def lib():
         L.madsim_hip_run_campaign.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64, C.c_uint64, C.c_uint64,
                                               C.c_uint32, C.c_uint32, C.POINTER(A.Limits), C.POINTER(A.Campaign)]
         L.madsim_hip_ctx_run_campaign.argtypes = [ctxp] + L.madsim_hip_run_campaign.argtypes
+        L.madsim_hip_run_campaign_multi.argtypes = [C.POINTER(ctxp), C.c_int] + L.madsim_hip_run_campaign.argtypes
         if L.madsim_hip_version() != A.ABI_VERSION:
             raise MadsimHipError("libmadsim_hip.so ABI version mismatch")
         # build identity: MADSIM_HIP_LIB may name an A/B build of THIS library (tools/build_variant.sh), nothing else — an
@@ -270,6 +271,18 @@ def run_batch_multi(contexts, workload, seed0, count, config=None, limits=None, 
     _check(lib().madsim_hip_run_batch_multi(arr, len(contexts), workload.ref(), C.byref(cfg), seed0, count, C.byref(lim),
                                             out.ctypes.data_as(C.c_void_p), C.byref(summ), max_rounds))
     return out, summ
+
+
+def run_campaign_multi(contexts, workload, seed0, total, batch=0, in_flight=0, stop_at_failure=False, config=None, limits=None):
+    """madsim_hip_run_campaign_multi: the seed search over several contexts (one per GPU) from one host thread — batch k on context
+    k % n, reports read in batch order, every device stopped within one round of batches of the first genuine failure."""
+    cfg = config or A.Config.default()
+    lim = limits or A.Limits()
+    rep = A.Campaign()
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _check(lib().madsim_hip_run_campaign_multi(arr, len(contexts), workload.ref(), C.byref(cfg), seed0, total, batch, in_flight,
+                                               A.CAMPAIGN_STOP_AT_FAILURE if stop_at_failure else 0, C.byref(lim), C.byref(rep)))
+    return rep
 
 
 def timing_ms(slot):

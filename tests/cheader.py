@@ -57,6 +57,7 @@ def functions(text=None, with_names=False):
     text = text or header_text()
     text = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", text, flags=re.S)
     text = re.sub(r"enum\s+\w+\s*\{.*?\}\s*;", " ", text, flags=re.S)
+    text = re.sub(r"^[ \t]*#.*$", " ", text, flags=re.M)            # preprocessor lines (a #define just before a prototype is not its return type)
     out = {}
     for m in re.finditer(r"([\w\*\s]+?)\b(madsim_\w+)\s*\(([^()]*)\)\s*;", text):
         ret = " ".join(m.group(1).replace("extern", "").split())

@@ -239,3 +239,7 @@ def test_context_api_without_gpu_fails_loudly():
     w = workload.pingpong(2, 1)
     arr = (C.c_void_p * 1)(None)
     assert L.madsim_hip_run_batch_multi(arr, 1, w.ref(), C.byref(cfg), 0, 0, C.byref(lim), None, C.byref(summ), 1) == -3
+    rep = A.Campaign()
+    assert L.madsim_hip_run_campaign_multi(arr, 1, w.ref(), C.byref(cfg), 0, 100, 0, 0, 0, C.byref(lim), C.byref(rep)) == -3      # null context
+    assert L.madsim_hip_run_campaign_multi(arr, 0, w.ref(), C.byref(cfg), 0, 100, 0, 0, 0, C.byref(lim), C.byref(rep)) == -1      # no contexts
+    assert L.madsim_hip_run_campaign_multi(arr, 1, w.ref(), C.byref(cfg), 0, 100, 0, 0, 0, C.byref(lim), None) == -1            # no report

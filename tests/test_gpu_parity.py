@@ -1169,3 +1169,38 @@ def test_summary_only_call_with_null_result_array(hip):
         assert (s.n_failed, s.first_failing_seed, s.total_steps, s.total_clock_ns) == \
                (want.n_failed, want.first_failing_seed, want.total_steps, want.total_clock_ns)
         assert s.n_failed == int((got["verdict"] != A.PASS).sum())
+
+
+def test_campaign_over_several_contexts_reports_like_one_and_stops_everywhere(hip):
+    """madsim_hip_run_campaign_multi (runtime/builder.rs:129-160 across devices): batch k on context k % n, reports read in batch
+    order.  k contexts (all on GPU 0 here: the code path of one per GPU) give the report of ONE context for the same range — no stop:
+    every count and the oracle's first failing seed; STOP_AT_FAILURE: the same first failing seed after reading exactly the batches up
+    to it, at most one round of n x in_flight batches launched beyond; ragged ranges, fewer batches than contexts, one batch."""
+    w = W.pingpong(4, 16)
+    FIELDS = ("seeds_run", "batches_run", "first_failing_seed", "n_failed", "n_runner", "total_steps", "total_clock_ns")
+    with hip.Context(0) as c0, hip.Context(0) as c1, hip.Context(0) as c2:
+        for ctxs in ([c0, c1], [c0, c1, c2], [c2]):
+            cfg = A.Config.default(packet_loss_rate=0.002)
+            for total, batch in ((40_000, 4096), (4096 * 7 + 5, 4096), (1000, 4096), (4096 * 2, 4096)):
+                one = hip.run_campaign(w, 5_000_000, total, batch, 3, False, cfg)
+                many = hip.run_campaign_multi(ctxs, w, 5_000_000, total, batch, 2, False, cfg)
+                assert [getattr(many, f) for f in FIELDS] == [getattr(one, f) for f in FIELDS], (len(ctxs), total)
+                assert many.batches_launched == many.batches_run == (total + batch - 1) // batch
+            _, osum = oracle.run_batch(w, 5_000_000, 40_000, cfg)
+            assert (many.n_failed, many.first_failing_seed) != (0, (1 << 64) - 1)
+            many = hip.run_campaign_multi(ctxs, w, 5_000_000, 40_000, 4096, 2, False, cfg)
+            assert (many.n_failed, many.first_failing_seed, many.total_steps) == (osum.n_failed, osum.first_failing_seed, osum.total_steps)
+            # rare failures: every device stops within one round of the batch that holds the first one
+            cfg = A.Config.default(packet_loss_rate=0.000002)
+            batch = 4096
+            one = hip.run_campaign(w, 9_000_000, 64 * batch, batch, 3, True, cfg)
+            many = hip.run_campaign_multi(ctxs, w, 9_000_000, 64 * batch, batch, 2, True, cfg)
+            assert many.first_failing_seed == one.first_failing_seed != (1 << 64) - 1
+            j = (many.first_failing_seed - 9_000_000) // batch
+            assert [getattr(many, f) for f in FIELDS] == [getattr(one, f) for f in FIELDS]
+            assert many.batches_run == j + 1 and j + 1 <= many.batches_launched <= j + 1 + 2 * len(ctxs)
+        # the same context twice / none: refused, nothing launched
+        with pytest.raises(hip.MadsimHipError):
+            hip.run_campaign_multi([c0, c0], w, 0, 100)
+        with pytest.raises(hip.MadsimHipError):
+            hip.run_campaign_multi([], w, 0, 100)
