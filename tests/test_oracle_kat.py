@@ -47,6 +47,32 @@ def test_seed_from_u64_splitmix():
         assert [str(L.oracle_xoshiro_next(s)) for _ in range(4)] == d["first"]
 
 
+def test_splitmix64_published_vector_seed_1234567():
+    """The published SplitMix64 test vector (Rosetta Code task "Pseudo-random numbers/Splitmix64": seed 1234567 ->
+    6457827717110365317, 3203168211198807973, 9817491932198370423, 4593380528125082431, 16408922859458223821; the same five
+    numbers follow from Vigna's reference splitmix64.c) against `seed_from_u64` — rand_core fills the 32 seed bytes of
+    Xoshiro256PlusPlus with four consecutive SplitMix64 outputs, little-endian (rand.rs:42-61 [DEP rand_xoshiro 0.6, rand_core
+    0.6 SeedableRng::seed_from_u64... Xoshiro256PlusPlus overrides it with SplitMix64]) — and, through the state it seeds, the
+    generator's next outputs against an independent statement of xoshiro256++ written out here."""
+    L = oracle.lib()
+    s = _state([0] * 4)
+    L.oracle_seed_from_u64(1234567, s)
+    assert list(s) == [6457827717110365317, 3203168211198807973, 9817491932198370423, 4593380528125082431]
+    # the fifth published output = the first state word of the NEXT block of four (seed advanced by four increments of the golden gamma)
+    L.oracle_seed_from_u64((1234567 + 4 * 0x9E3779B97F4A7C15) & (2**64 - 1), s)
+    assert s[0] == 16408922859458223821
+    # 1 000 outputs of the generator from the published state, against xoshiro256++ as Blackman & Vigna publish it
+    M = 2**64 - 1
+    st = [6457827717110365317, 3203168211198807973, 9817491932198370423, 4593380528125082431]
+    L.oracle_seed_from_u64(1234567, s)
+    rotl = lambda x, k: ((x << k) | (x >> (64 - k))) & M      # noqa: E731
+    for _ in range(1000):
+        want = (rotl((st[0] + st[3]) & M, 23) + st[0]) & M
+        t = (st[1] << 17) & M
+        st[2] ^= st[0]; st[3] ^= st[1]; st[1] ^= st[2]; st[0] ^= st[3]; st[2] ^= t; st[3] = rotl(st[3], 45)
+        assert L.oracle_xoshiro_next(s) == want
+
+
 def test_gen_range_values_and_attempt_counts():
     """rand 0.8 UniformInt::sample_single: values AND the number of next_u64 calls (rejections)."""
     L = oracle.lib()
