@@ -54,11 +54,15 @@ class Tally:
     def __init__(self):
         self.rows = {}
         self.verdicts = set()
+        self.reasons = {}            # capacity name -> seeds proven beyond it
 
-    def add(self, label, n, rerun, unresolved, verdicts=()):
+    def add(self, label, n, rerun, unresolved, verdicts=(), reasons=()):
         r = self.rows.setdefault(label, [0, 0, 0])
         r[0] += n; r[1] += rerun; r[2] += unresolved
         self.verdicts |= set(verdicts)
+        for why in reasons:
+            k = why.split()[0]
+            self.reasons[k] = self.reasons.get(k, 0) + 1
 
     @property
     def n(self):
@@ -127,14 +131,16 @@ def compare(got, want, resolve, label="", tally=None, what=None, ceiling=None):
     bad = final != want
     still = np.nonzero(final["verdict"] == A.OVERFLOW)[0]
     beyond = 0
+    reasons = []
     for i in still:
         why = ceiling(int(i)) if ceiling else None
         assert why, (what, f"seed index {int(i)} is still MADSIM_OVERFLOW after the largest capacities and the oracle's high-water marks "
                            "are all inside the layout's ceilings: an unexplained capacity verdict", final[i], want[i])
         bad[i] = False
         beyond += 1
+        reasons.append(why)
     if tally is not None:
-        tally.add(label, len(got), n_rerun, beyond, want["verdict"].tolist())
+        tally.add(label, len(got), n_rerun, beyond, want["verdict"].tolist(), reasons)
     assert not bad.any(), (what, f"{int(bad.sum())} of {len(got)} seeds differ (re-run {n_rerun}, beyond the layout's ceilings {beyond})",
                            final[bad][0], want[bad][0])
     return final

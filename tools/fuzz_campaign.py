@@ -49,3 +49,4 @@ print(f"fuzz campaign ok: {k} workloads, {tally.n} seeds in {time.time() - t0:.0
       f"{tally.rerun} of them after a re-run with grown capacities (first pass MADSIM_OVERFLOW); unresolved: {tally.unresolved} "
       f"(proven beyond the layout's ceilings by the oracle's high-water marks; anything else fails); oracle verdicts seen: {sorted(tally.verdicts)}")
 print("per generator:", tally)
+if tally.reasons: print("beyond the ceilings, by capacity (the oracle's high-water mark of the seed exceeds what the layout can hold at all):", tally.reasons)
