@@ -51,6 +51,15 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
 #ifndef MADSIM_G_WAVES_PER_EU
 #define MADSIM_G_WAVES_PER_EU 3
 #endif
+// Priority of a wave that has done `pass` of about `est` passes: who is behind is served first.  Four levels, one per quarter of the
+// work, looked at every 16th pass — measured against finer resolution near the end (the last 1/2, 1/4, 1/8: equal on finite sets, 1 %
+// worse in long regions; the last 1/4, 1/8, 1/16: no gain at all) and against every 4th / 64th pass (+0.7 % / +0.6 %): profiles/r5_experiments.md.
+constexpr uint32_t MADSIM_PRIO_EVERY_MASK = 15u;
+__device__ __forceinline__ uint32_t progress_priority(uint32_t pass, uint32_t est) {
+    const uint32_t q = pass * 4u / est;
+    return q >= 3 ? 0u : 3u - q;
+}
+
 template <class K>
 __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) == (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR) ? 2 : MADSIM_G_WAVES_PER_EU) void sim_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -116,7 +125,26 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
     L.exact = 0; L.hazard = 0;
     uint64_t next = glane;          // first unit of lane g; then g+G, g+2G, ... or the work queue (below)
     bool have = false;
+    // Progress-based issue priority (round 5).  The SIMD's arbiter serves priority first, then the OLDEST wave: launches resident
+    // together do not share a SIMD evenly, the oldest runs at nearly its solo speed and the youngest gets the rest — so a finite set
+    // of launches (the sub-batches of one madsim_hip_run_batch call, a campaign's last batches, a short timed region) ends 0.5-0.9 ms
+    // apart and the last launch finishes on SIMDs it has to itself, at a third of their issue rate (profiles/r5_experiments.md).
+    // A wave that knows how far through its work it is can undo that: priority 3 in the first quarter of its passes, 2 / 1 / 0 in
+    // the next ones — whoever is behind is served first, co-resident launches finish together.  "How many passes" is what the last
+    // finished wave of this workload counted (one word per workload table set, written below); until one has finished: no priority.
+    uint32_t pass_est = (K::TRACE || !P.iter_est) ? 0u : wave_uniform(*P.iter_est);
+    uint32_t pass = 0;
     for (;;) {
+        if (!K::TRACE && P.iter_est) {
+            const uint32_t pu = wave_uniform(pass);
+            if ((pu & MADSIM_PRIO_EVERY_MASK) == 0) {
+                // (the first launches of a workload start without an estimate: they look again until a wave has finished — the drain, where
+                //  the priorities matter, comes after that)
+                if (!pass_est && (pu & 63u) == 0) pass_est = wave_uniform(__atomic_load_n(P.iter_est, __ATOMIC_RELAXED));
+                if (pass_est) wave_set_priority(progress_priority(pu, pass_est));
+            }
+        }
+        pass++;
         if (!have) {
             if (next >= P.count) break;
             seed_init<K>(c, L, P.seed_list ? P.seed_list[next] : P.seed0 + next);
@@ -249,6 +277,7 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
             else next += P.total_lanes / EXP_LANE_DIV;
         }
     }
+    if (!K::TRACE && P.iter_est && lane == 0 && pass > 16) *P.iter_est = pass;      // (any finished wave's count will do: same workload, same shape of launch)
 #ifdef MADSIM_K_PROF
     PROBE2(0);
     if (lane == 0 && P.prof) { for (int i = 0; i < 12; i++) atomicAdd((unsigned long long*)&P.prof[i], (unsigned long long)L.prof_acc[i]); atomicAdd((unsigned long long*)&P.prof[12], (unsigned long long)prof_iters); atomicAdd((unsigned long long*)&P.prof[13], 1ull); }

@@ -91,6 +91,14 @@ __device__ __forceinline__ uint64_t mul_pow2p1(uint64_t v) {
     return p;
 }
 
+// Issue priority of this wave (0..3; s_setprio takes an immediate, hence the ladder).  `q` must be wave-uniform.
+__device__ __forceinline__ void wave_set_priority(uint32_t q) {
+    q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+    if (q == 0) __builtin_amdgcn_s_setprio(0); else if (q == 1) __builtin_amdgcn_s_setprio(1);
+    else if (q == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+}
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 // true when `p` holds in every active lane of the wave (a scalar: branches on it are uniform)
 __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
 

@@ -80,6 +80,7 @@ struct madsim_hip_ctx {
         uint64_t hash = 0;
         std::vector<uint32_t> host;      // insns | progs | socks | durs (as 32-bit words) | n_insns
         uint4* insns = nullptr; uint32_t* progs = nullptr; uint32_t* socks = nullptr; uint32_t* nodes = nullptr; uint64_t* durs = nullptr;
+        uint32_t* iter_est = nullptr;    // one word: how many passes a wave of this workload runs (written by finishing waves, k_main.h)
     };
     std::vector<Tables> tables;
     // per-stream scratch: launches on one stream run in order, launches on different streams may overlap and must
@@ -110,6 +111,7 @@ struct madsim_hip_ctx {
         if (t.socks) (void)hipFree(t.socks);
         if (t.nodes) (void)hipFree(t.nodes);
         if (t.durs) (void)hipFree(t.durs);
+        if (t.iter_est) (void)hipFree(t.iter_est);
         t = Tables();
     }
     int open(int dev_index);
@@ -228,6 +230,8 @@ int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
             HIP_TRY(hipMalloc(&t.socks, T.socks.size() * 4 + 16));
             HIP_TRY(hipMalloc(&t.durs, T.durs.size() * 8 + 16));
             HIP_TRY(hipMalloc(&t.nodes, T.nodes.size() * 4 + 16));
+            HIP_TRY(hipMalloc(&t.iter_est, 16));
+            HIP_TRY(hipMemset(t.iter_est, 0, 16));
             HIP_TRY(hipMemcpy(t.nodes, T.nodes.data(), T.nodes.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(t.insns, T.insns.data(), T.insns.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(t.progs, T.progs.data(), T.progs.size() * 4, hipMemcpyHostToDevice));
@@ -241,6 +245,9 @@ int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
         hit = &tables.back();
     }
     P.insns = hit->insns; P.progs = hit->progs; P.socks = hit->socks; P.nodes = hit->nodes; P.dur_table = hit->durs;
+    // (MADSIM_HIP_NO_PRIO=1 in the environment: launches without the progress-based wave priorities of k_main.h — a diagnostic / A-B switch,
+    //  results are the same either way)
+    { static const bool off = getenv("MADSIM_HIP_NO_PRIO") != nullptr; P.iter_est = off ? nullptr : hit->iter_est; }
     return 0;
 }
 

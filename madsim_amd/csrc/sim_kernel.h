@@ -93,6 +93,8 @@ struct KParams {
     // {deadline lo, hi, wake meta, count} behind the task units, at logical byte dedup_off of the lane's block (k_timer.h dedup_note)
     uint32_t dedup_n, dedup_off;
     uint64_t* prof;            // profiling builds (tools/experiment): per-phase cycle accumulators
+    uint32_t* iter_est;        // one word per workload: the passes a wave of it runs, as the last finished wave counted them (0 = nothing
+                               // finished yet); null = no progress-based priority (k_main.h wave_progress_priority)
 };
 
 // Kernel variants (Variant<TRACE, SPILL, LWS, FEAT, RQ>): the trace build; for base-op workloads on full 64-lane waves one

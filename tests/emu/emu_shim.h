@@ -55,6 +55,8 @@ static inline uint64_t add64_1(uint64_t a, uint64_t b) { return a + b; }
 template <int K_> static inline uint64_t shl64(uint64_t x) { return x << K_; }
 template <int K_> static inline uint64_t mul_pow2p1(uint64_t v) { return (v << K_) + v; }
 static inline uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) { return a ^ b ^ c; }
+static inline void wave_set_priority(uint32_t) {}
+static inline uint32_t wave_uniform(uint32_t v) { return v; }
 static inline bool wave_all(bool p) { return p; }                        // (one emulated lane at a time: results may not depend on the vote)
 static inline uint32_t table_copy_first() { return 0; }                   // emulated threads run one after another:
 static inline uint32_t table_copy_stride(uint32_t) { return 1; }          // each copies everything
