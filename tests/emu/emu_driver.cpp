@@ -191,7 +191,8 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
         reg_iters += (double)iters;
         if (const char* dp = getenv("MADSIM_EMU_DUMP")) {      // raw RNG-attempt counts: [wave][iter][lane][5] bytes
             FILE* f = fopen(dp, b == 0 ? "wb" : "ab");
-            static const int ids[5] = {1, 7, 8, 16, 18};
+            static int ids[5] = {1, 7, 8, 16, 18};               // (MADSIM_EMU_DUMP_IDS=a,b,c,d,e: five other region ids)
+            if (const char* e = getenv("MADSIM_EMU_DUMP_IDS")) sscanf(e, "%d,%d,%d,%d,%d", &ids[0], &ids[1], &ids[2], &ids[3], &ids[4]);
             uint32_t hdr[2] = {(uint32_t)iters, (uint32_t)logs.size()};
             fwrite(hdr, 4, 2, f);
             for (size_t i = 0; i < iters; i++)
