@@ -254,6 +254,7 @@ pub const MADSIM_STATE_COMPACT: u32 = 3;
 pub const MADSIM_STATE_DEDUP_TIMERS: u32 = 0x100;
 pub const MADSIM_SCHED_STATIC: u32 = 0;
 pub const MADSIM_SCHED_QUEUE: u32 = 1;
+pub const MADSIM_MAX_LIVE_TASKS: u32 = 254;
 pub const MADSIM_E_ARG: c_int = -1;
 pub const MADSIM_E_HIP: c_int = -2;
 pub const MADSIM_E_NOINIT: c_int = -3;

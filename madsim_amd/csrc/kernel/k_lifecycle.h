@@ -20,7 +20,10 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
     } else {
         while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
     }
-    if (slot >= c.P.max_tasks) { OVF_SET(L, OVF_CAP); return 0xffffffffu; }
+    // (the task table holds max_tasks <= 254 live tasks — an 8-bit slot.  Short of that a larger limit lifts it: a capacity verdict, the seed is
+    //  run again.  AT 254 nothing does: the 255th live task leaves the workload model, MADSIM_UNSUPPORTED — and since the oracle fills its
+    //  unbounded Vec lowest free slot first, as this does, it says so at the same spawn)
+    if (slot >= c.P.max_tasks) { OVF_SET(L, c.P.max_tasks >= MADSIM_MAX_LIVE_TASKS ? OVF_MODEL : OVF_CAP); return 0xffffffffu; }
     if (K::G) AMASK(slot >> 5) |= 1u << (slot & 31);
     uint32_t gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
     uint32_t pw = PROGW(c, prog);

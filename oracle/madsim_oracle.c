@@ -495,6 +495,10 @@ static int spawn_task(sim_t* S, unsigned prog, int record_handle) { return spawn
 static int spawn_task_from(sim_t* S, unsigned prog, int record_handle, int via_handle, int parent) {   /* task/mod.rs:627-654 */
     size_t slot = 0;
     while (slot < S->tasks.n && S->tasks.p[slot].alive) slot++;
+    /* the reference's task set is unbounded; the workload model holds MADSIM_MAX_LIVE_TASKS live tasks (the device's 8-bit task slot, filled
+     * lowest free slot first like this Vec): a 255th leaves the model at this spawn — MADSIM_UNSUPPORTED, reported when the run ends (this
+     * restatement simply goes on; the verdict is the whole answer, include/madsim_hip.h) */
+    if (slot >= MADSIM_MAX_LIVE_TASKS) S->unsupported = 1;
     if (slot == S->tasks.n) { task_t z; memset(&z, 0, sizeof z); vec_push(S->tasks, z); }
     task_t* t = &S->tasks.p[slot];
     uint16_t gen = (uint16_t)(t->gen + 1);

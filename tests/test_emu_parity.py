@@ -186,7 +186,7 @@ def test_fuzz_ipvs_runtime_workloads():
 def test_hard_model_limits_are_unsupported_on_both_sides():
     """Limits no `madsim_limits_t` field can lift are MODEL limits: a seventh server of an IPVS service (net/ipvs.rs:66-72 pushes to an
     unbounded Vec), a ninth connection waiting in one accept1 queue (endpoint.rs:307: an unbounded channel), a formatted panic value
-    above the workload's declared panic_dyn_max.  Kernel and oracle give MADSIM_UNSUPPORTED at the same instruction, every other
+    above the workload's declared panic_dyn_max, a 255th live task (task/mod.rs:607-654: an unbounded set).  Kernel and oracle give MADSIM_UNSUPPORTED at the same instruction, every other
     field 0 — never MADSIM_OVERFLOW (a re-run could not resolve it), never a shorter list."""
     ws = []
     wl = W.WorkloadBuilder()
@@ -214,6 +214,12 @@ def test_hard_model_limits_are_unsupported_on_both_sides():
     t = wl.task(n); t.flag_add(0, 300); t.panic_with_flag(0, 7)
     m = wl.main(); m.spawn(t); m.join(t, expect_err=True)
     ws.append((wl.build(), None))
+    wl = W.WorkloadBuilder()                               # a spawn storm: 300 sleepers alive at once (the layout's 8-bit task slot holds 254)
+    n = wl.create_node()
+    sl = wl.task(n); sl.sleep(secs=1); sl.done()
+    m = wl.main(); m.set(0, 300); top = m.label(); m.spawn(sl); m.djnz(0, top); m.sleep(secs=2); m.done()
+    lim = A.Limits(); lim.max_tasks = 254
+    ws.append((wl.build(), lim))
     for w, lim in ws:
         o, _ = oracle.run_batch(w, 0, 8, None, lim)
         assert (o["verdict"] == A.UNSUPPORTED).all() and not o["steps"].any() and not o["rng_calls"].any()
