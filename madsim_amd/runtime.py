@@ -285,6 +285,18 @@ def run_campaign_multi(contexts, workload, seed0, total, batch=0, in_flight=0, s
     return rep
 
 
+def run_campaign_over_ranks(workload, seed0, total, batch=65536, stop_at_failure=True, config=None, limits=None, device_tensors=None, group=None):
+    """The seed search with ONE PROCESS PER GPU (torch.distributed; RCCL when the backend is "nccl"): batch k of the range belongs to rank
+    k % world, every rank runs its batch through `madsim_hip_run_campaign` on its own GPU, and one all-gather of the 48-byte reports per
+    round lets every rank fold the same answer (madsim_amd/dist.py campaign_over_ranks).  Without a process group: the single-GPU search."""
+    from madsim_amd import dist as mdist
+
+    def one(seed_lo, n):
+        rep = run_campaign(workload, seed_lo, n, n, 1, False, config, limits)
+        return rep.first_failing_seed, rep.n_failed, rep.n_runner, rep.total_steps, rep.total_clock_ns
+    return mdist.campaign_over_ranks(one, seed0, total, batch, stop_at_failure, device_tensors or "cpu", group)
+
+
 def timing_ms(slot):
     ms = C.c_double(0.0)
     _check(lib().madsim_hip_timing_ms(slot, C.byref(ms)))

@@ -154,3 +154,64 @@ def test_check_ranks_refuses_a_missing_or_doubled_rank():
     for bad in ([(r, r) for r in range(7)] + [(6, 6)], [(r, r) for r in range(7)], [(r, r) for r in range(9)]):
         with pytest.raises(launch.LaunchError):
             launch.check_ranks(bad, 8)
+
+
+# ---- the seed search over ranks (madsim_amd/dist.py campaign_over_ranks): one all-gather per round ------------------------------------
+def _oracle_report(w, cfg):
+    import oracle
+    from madsim_amd import _abi as A
+
+    def run(seed_lo, n):
+        out, _ = oracle.run_batch(w, seed_lo, n, cfg)
+        v = out["verdict"]
+        genuine = (v != A.PASS) & (v < A.OVERFLOW)
+        first = int(seed_lo + int(np.nonzero(genuine)[0][0])) if genuine.any() else (1 << 64) - 1
+        return first, int(genuine.sum()), int((v >= A.OVERFLOW).sum()), int(out["steps"].astype(np.int64).sum()), int(out["clock_ns"].astype(np.int64).sum())
+    return run
+
+
+def _worker_campaign(rank, world, port, cases, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from madsim_amd import _abi as A
+    from madsim_amd import workload as W
+    w = W.pingpong(4, 8)
+    res = []
+    for loss, seed0, total, batch, stop in cases:
+        res.append(mdist.campaign_over_ranks(_oracle_report(w, A.Config.default(packet_loss_rate=loss)), seed0, total, batch, stop))
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_campaign_over_ranks_matches_one_process_and_stops_within_a_round():
+    """world 3 over gloo, the oracle standing in for the GPU: without stop the report of the whole range; with stop the smallest failing
+    seed, found in the round that holds it, counting exactly the batches up to the failing one; ragged last batch, fewer batches than
+    ranks, no failure at all.  Every rank computes the same dict from the one all-gather per round."""
+    from madsim_amd import _abi as A
+    from madsim_amd import workload as W
+    cases = [(0.01, 7000, 1000, 64, False), (0.002, 50_000, 4000, 128, True), (0.0, 0, 500, 64, True), (0.01, 90_000, 100, 64, True)]
+    world = 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_campaign, args=(r, world, port, cases, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == res[2]                      # no second collective needed: every rank folds the same rows
+    w = W.pingpong(4, 8)
+    for (loss, seed0, total, batch, stop), got in zip(cases, res[0]):
+        one = mdist.campaign_over_ranks(_oracle_report(w, A.Config.default(packet_loss_rate=loss)), seed0, total, batch, stop)   # world 1, no process group
+        for f in ("first_failing_seed", "n_failed", "n_runner", "total_steps", "total_clock_ns", "seeds_run", "batches_run"):
+            assert got[f] == one[f], (loss, f, got, one)
+        n_batches = -(-total // batch)
+        if stop and got["first_failing_seed"] != (1 << 64) - 1:
+            j = (got["first_failing_seed"] - seed0) // batch
+            assert got["batches_run"] == j + 1 and got["rounds"] == j // world + 1
+        else:
+            assert got["batches_run"] == n_batches and got["seeds_run"] == total and got["rounds"] == -(-n_batches // world)
+    assert res[0][0]["n_failed"] > 0 and res[0][1]["first_failing_seed"] != (1 << 64) - 1 and res[0][2]["n_failed"] == 0

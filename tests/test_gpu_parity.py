@@ -1204,3 +1204,15 @@ def test_campaign_over_several_contexts_reports_like_one_and_stops_everywhere(hi
             hip.run_campaign_multi([c0, c0], w, 0, 100)
         with pytest.raises(hip.MadsimHipError):
             hip.run_campaign_multi([], w, 0, 100)
+
+
+def test_campaign_over_ranks_on_one_gpu_equals_the_library_campaign(hip):
+    """madsim_amd/runtime.py run_campaign_over_ranks without a process group (world 1; the multi-rank fold is tested over gloo on the CPU,
+    tests/test_dist_gloo.py): the same report as madsim_hip_run_campaign for the same prefix, with and without the early stop."""
+    w = W.pingpong(4, 16)
+    for loss, total, stop in ((0.002, 40_000, False), (0.000002, 64 * 4096, True)):
+        cfg = A.Config.default(packet_loss_rate=loss)
+        one = hip.run_campaign(w, 9_000_000, total, 4096, 3, stop, cfg)
+        got = hip.run_campaign_over_ranks(w, 9_000_000, total, 4096, stop, cfg)
+        assert (got["first_failing_seed"], got["n_failed"], got["n_runner"], got["total_steps"], got["seeds_run"], got["batches_run"]) == \\
+               (one.first_failing_seed, one.n_failed, one.n_runner, one.total_steps, one.seeds_run, one.batches_run)
