@@ -1214,5 +1214,5 @@ def test_campaign_over_ranks_on_one_gpu_equals_the_library_campaign(hip):
         cfg = A.Config.default(packet_loss_rate=loss)
         one = hip.run_campaign(w, 9_000_000, total, 4096, 3, stop, cfg)
         got = hip.run_campaign_over_ranks(w, 9_000_000, total, 4096, stop, cfg)
-        assert (got["first_failing_seed"], got["n_failed"], got["n_runner"], got["total_steps"], got["seeds_run"], got["batches_run"]) == \\
+        assert (got["first_failing_seed"], got["n_failed"], got["n_runner"], got["total_steps"], got["seeds_run"], got["batches_run"]) == \
                (one.first_failing_seed, one.n_failed, one.n_runner, one.total_steps, one.seeds_run, one.batches_run)
