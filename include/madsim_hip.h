@@ -359,13 +359,16 @@ enum madsim_verdict {
     MADSIM_UNSUPPORTED = 6, /* the seed left the workload MODEL (not a reference verdict, and larger limits do not help:
                                never re-run): a port-0 table entry bound again while the Endpoint of its previous bind is
                                alive — an entry names one Endpoint at a time, `close` it first; a seventh server added to
-                               an IPVS service; a ninth connection waiting in one Endpoint's accept1 queue; a 255th live task; a formatted panic
+                               an IPVS service; a ninth connection waiting in one Endpoint's accept1 queue; a 255th live task, a 256th registration of one socket, a 16th queued channel payload (the ceilings of
+                               max_tasks / mbox_regs / chan_queue); a formatted panic
                                value above madsim_workload_t.panic_dyn_max.  The oracle reports the same verdict for the same
                                seed, decided at the same instruction; every other result field is 0                     */
     MADSIM_INTERNAL = 7     /* an invariant of the device code broke (a bug in this library, never a property of the
                                workload): the parity tests assert that no seed ever carries it; other fields 0        */
 };
 #define MADSIM_MAX_LIVE_TASKS 254u   /* the ceiling of madsim_limits_t.max_tasks: a 255th live task is MADSIM_UNSUPPORTED (kernel and oracle) */
+#define MADSIM_MAX_MBOX_REGS 255u    /* the ceiling of mbox_regs: a 256th pending / dead registration of one socket is MADSIM_UNSUPPORTED          */
+#define MADSIM_MAX_CHAN_QUEUE 15u    /* the ceiling of chan_queue: a 16th payload queued in one channel direction is MADSIM_UNSUPPORTED             */
 /* verdicts >= MADSIM_OVERFLOW are RUNNER verdicts: statements about this runner, never a test's failure */
 #define MADSIM_IS_RUNNER_VERDICT(v) ((v) >= MADSIM_OVERFLOW)
 

@@ -35,7 +35,8 @@ __device__ __forceinline__ uint32_t loss_always_at(const KParams& P, uint32_t i)
 // A registration word identifies its receiver by 8 bits of receive sequence number and 8 bits of task generation.  A dead
 // registration (timed-out / dropped receive) equal to a NEW word — which would make it look live — can only exist once one
 // of the two has wrapped: this task's rxseq (TF_RXWRAP) or its slot's generation (>= 256 instances).  Only then is the
-// mailbox scanned for a twin (=> MADSIM_OVERFLOW, never a different answer).
+// mailbox scanned for a twin (=> MADSIM_UNSUPPORTED — no limit lifts it; the oracle, whose sequence numbers do not wrap, checks the same
+// agreement of the low bytes at the same registration: oracle/madsim_oracle.c reg_model_limits).
 __device__ __forceinline__ bool may_have_twin(uint32_t flags, uint32_t gen) { return (flags & TF_RXWRAP) || gen > 0xff; }
 
 // Instruction fetch.  Workloads with ephemeral Endpoints (full-address builds only): an Endpoint operand naming a handle
@@ -78,6 +79,9 @@ template <class K>
 __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t slot, uint4& u0, uint4 u1, PollPrefetch pp) {
     enum : uint32_t { ST_RUN = 0, ST_PENDING = 1, ST_FINISHED = 2, ST_PANIC = 3 };
     const KParams& P = c.P;
+    // a full registration list: short of the ceiling of 255 a larger mbox_regs lifts it (a capacity verdict, the seed is run again); AT the ceiling the
+    // 256th registration leaves the workload model — the oracle's Vec holds the same registrations, it says MADSIM_UNSUPPORTED at the same receive
+    const uint32_t REGS_FULL = P.mbox_regs >= MADSIM_MAX_MBOX_REGS ? (uint32_t)OVF_MODEL : (uint32_t)OVF_CAP;
     bool u1_dirty = false;
     uint32_t pc = u0.y & 0xffff, sub = (u0.y >> 16) & 0xff, from = u0.y >> 24;
     const uint32_t gen = (u0.x >> 8) & 0xffff;
@@ -169,8 +173,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.x &= ~TF_INBOX;
                 uint32_t h = SW(c, ca, 0);
                 uint32_t nreg = (h >> 9) & 0xff;
-                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) OVF_SET(L, OVF_CAP);   // 8-bit rxseq wrapped onto a dead twin
-                if (nreg >= P.mbox_regs) OVF_SET(L, OVF_CAP);
+                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) OVF_SET(L, OVF_MODEL);   // 8-bit rxseq wrapped onto a dead twin
+                if (nreg >= P.mbox_regs) OVF_SET(L, REGS_FULL);
                 else {
                     SW(c, ca, 2 + nreg) = reg;
                     SW(c, ca, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
@@ -504,12 +508,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     sub = 2;                               // oneshot already holds the value
                     SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
                 } else {
-                    if (nreg >= P.mbox_regs) OVF_SET(L, OVF_CAP);            // (a capacity verdict: the state no longer matters)
+                    if (nreg >= P.mbox_regs) OVF_SET(L, REGS_FULL);          // (a runner verdict: the state no longer matters)
                     else {
                         const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
                         // dead registrations (timed-out / dropped receives, extended ops only) stay in the Vec like the
                         // reference's; an 8-bit rxseq that wraps onto one of them would make it look live: overflow, never a different answer
-                        if ((K::FT || K::FN) && may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) OVF_SET(L, OVF_CAP);
+                        if ((K::FT || K::FN) && may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) OVF_SET(L, OVF_MODEL);
                         SW(c, a, 2 + nreg) = reg;
                         SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
                         sub = 1;
@@ -544,10 +548,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u0.x |= TF_INBOX;
                 SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
             } else if (nreg >= P.mbox_regs) {
-                OVF_SET(L, OVF_CAP);
+                OVF_SET(L, REGS_FULL);
             } else {
                 const uint32_t reg = tag | (slot << 8) | (rxseq << 16) | ((gen & 0xff) << 24);
-                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) OVF_SET(L, OVF_CAP);   // rxseq wrapped onto a dead twin
+                if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, a, 2 + i) == reg) OVF_SET(L, OVF_MODEL);   // rxseq wrapped onto a dead twin
                 SW(c, a, 2 + nreg) = reg;
                 SW(c, a, 0) = (h & ~(0xffu << 9)) | ((nreg + 1) << 9);
             }
@@ -770,7 +774,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (arrive == CHAN_LINK_PANIC) { st = ST_PANIC; break; }
                 if (!(cw & (1u << (14 + 2 * side)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // ConnectionReset
                 uint32_t qn = (cw >> (17 + 4 * side)) & 0xf;
-                if (qn >= P.chan_queue) { OVF_SET(L, OVF_CAP); pc++; break; }
+                // (below the ceiling of 15 queued payloads a larger chan_queue lifts it; AT the ceiling the 16th leaves the model: the oracle's queue
+                //  holds the same payloads, it says MADSIM_UNSUPPORTED at the same send)
+                if (qn >= P.chan_queue) { OVF_SET(L, P.chan_queue >= MADSIM_MAX_CHAN_QUEUE ? OVF_MODEL : OVF_CAP); pc++; break; }
                 uint32_t e = 3 + (side * P.chan_queue + qn) * 3;
                 CONNW(id, e) = imm; CONNW(id, e + 1) = (uint32_t)arrive; CONNW(id, e + 2) = (uint32_t)(arrive >> 32);
                 CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * side))) | ((qn + 1) << (17 + 4 * side));

@@ -95,7 +95,9 @@ typedef struct {           /* naive_timer::Event: deadline + boxed callback     
                               cloned when the message was sent and consulted when it arrives (net/mod.rs:321-328) */
 } event_t;
 
-typedef struct { uint64_t tag; uint16_t slot, gen; uint8_t rxseq; } reg_t; /* (tag, oneshot::Sender) */
+typedef struct { uint64_t tag; uint16_t slot, gen; uint32_t rxseq; uint8_t tag8; } reg_t; /* (tag, oneshot::Sender).  rxseq names the oneshot channel: a counter that never
+                                                                               repeats here (the device keeps 8 bits of it: reg_model_limits below); tag8 = the
+                                                                               tag byte of the device's registration word: the tag, 0xff for an rsp_tag */
 typedef struct { uint64_t tag; uint32_t from; uint32_t val; uint64_t aux; } msg_t;   /* endpoint.rs:288-292 */
 
 typedef struct { uint32_t val; uint8_t has_arrive; uint64_t arrive; } cmsg_t;   /* (Payload, State) net/mod.rs:411-415 */
@@ -146,7 +148,7 @@ typedef struct {
     uint32_t val; uint32_t from;
     uint64_t aux;          /* rsp_tag of the typed RPC request in hand (rpc.rs:163-165)             */
     uint64_t rsp_tag;      /* rsp_tag of the call in flight (rpc.rs:121)                            */
-    uint8_t  inbox_full; uint8_t rxseq;   /* the oneshot::Receiver currently held                    */
+    uint8_t  inbox_full; uint32_t rxseq;  /* the oneshot::Receiver currently held                    */
     uint64_t inbox_aux;
     int32_t  joiner; uint16_t joiner_gen; /* async-task awaiter                                      */
     uint8_t  join_state;                  /* parked in MS_OP_JOIN: 1 awaiting, 2 / 3 the awaited task completed / was cancelled */
@@ -454,6 +456,19 @@ static void mailbox_deliver(sim_t* S, event_t* e) {
  * task lifecycle
  * ---------------------------------------------------------------------------------------------- */
 static void sock_drop_acceptq(sim_t* S, sock_t* k);
+/* A registration about to be pushed.  The workload model identifies a registration's receiver by 8 bits of its receive sequence number and 8 bits of
+ * its task generation (the device's registration word): a DEAD registration still in the list that agrees with the new one in tag, slot and both
+ * low bytes would be taken for it — possible only after one of the two counters has wrapped (256 receives of one task with a dead registration
+ * surviving, 256 instances of one slot).  Such a seed leaves the model (MADSIM_UNSUPPORTED; the device checks the same thing, k_poll.h
+ * may_have_twin); it also enforces the model's ceiling of registrations per socket.  The run goes on: the verdict is the whole answer. */
+static void reg_model_limits(sim_t* S, const sock_t* k, const reg_t* r) {
+    if (k->registered.n >= MADSIM_MAX_MBOX_REGS) S->unsupported = 1;
+    for (size_t i = 0; i < k->registered.n; i++) {
+        const reg_t* o = &k->registered.p[i];
+        if (o->tag8 == r->tag8 && o->slot == r->slot && (o->gen & 0xff) == (r->gen & 0xff) && (o->rxseq & 0xff) == (r->rxseq & 0xff))
+            S->unsupported = 1;
+    }
+}
 /* An EndpointSocket lives while the node's socket table (`bound`) or its Endpoint (`ep_alive`) holds an Arc of it (in-flight
  * delivery closures are not counted); when it dies conn_tx dies, and with it the connections nobody accepted. */
 static void sock_maybe_free(sim_t* S, sock_t* k) {
@@ -925,7 +940,8 @@ static int poll_task(sim_t* S, uint16_t slot) {
                     k->msgs.p[idx] = k->msgs.p[--k->msgs.n];            /* swap_remove */
                     t->inbox_full = 1; t->val = m.val; t->from = m.from; t->inbox_aux = m.aux;
                 } else {
-                    reg_t r = { tag, slot, t->gen, t->rxseq };
+                    reg_t r = { tag, slot, t->gen, t->rxseq, (uint8_t)tag };
+                    reg_model_limits(S, k, &r);
                     vec_push(k->registered, r);
                     if (k->registered.n > S->st.max_regs) S->st.max_regs = (uint32_t)k->registered.n;
                 }
@@ -1005,6 +1021,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (link < 0) return 1;                        /* `.ip.unwrap()` inside try_send (network.rs:309) */
             m.has_arrive = (uint8_t)link;
             if (!d->rx_alive) { t->val = MADSIM_VAL_RESET; t->pc++; break; }        /* ConnectionReset */
+            if (d->q.n >= MADSIM_MAX_CHAN_QUEUE) S->unsupported = 1;                /* the model's ceiling: a 16th queued payload */
             vec_push(d->q, m);
             if (d->q.n > S->st.max_cq) S->st.max_cq = (uint32_t)d->q.n;
             if (d->rx_task >= 0) { int32_t r = d->rx_task; d->rx_task = -1; wake(S, (uint16_t)r, d->rx_gen); }
@@ -1082,7 +1099,8 @@ static int poll_task(sim_t* S, uint16_t slot) {
                     k->msgs.p[idx] = k->msgs.p[--k->msgs.n];
                     t->inbox_full = 1; t->val = m.val; t->from = m.from; t->inbox_aux = m.aux;
                 } else {
-                    reg_t r = { tag, slot, t->gen, t->rxseq };
+                    reg_t r = { tag, slot, t->gen, t->rxseq, (uint8_t)tag };
+                    reg_model_limits(S, k, &r);
                     vec_push(k->registered, r);
                     if (k->registered.n > S->st.max_regs) S->st.max_regs = (uint32_t)k->registered.n;
                 }
@@ -1143,7 +1161,8 @@ static int poll_task(sim_t* S, uint16_t slot) {
                     k->msgs.p[idx] = k->msgs.p[--k->msgs.n];
                     t->inbox_full = 1; t->val = m.val; t->from = m.from; t->inbox_aux = m.aux;
                 } else {
-                    reg_t r = { t->rsp_tag, slot, t->gen, t->rxseq };
+                    reg_t r = { t->rsp_tag, slot, t->gen, t->rxseq, 0xff };
+                    reg_model_limits(S, k, &r);
                     vec_push(k->registered, r);
                     if (k->registered.n > S->st.max_regs) S->st.max_regs = (uint32_t)k->registered.n;
                 }

@@ -186,7 +186,8 @@ def test_fuzz_ipvs_runtime_workloads():
 def test_hard_model_limits_are_unsupported_on_both_sides():
     """Limits no `madsim_limits_t` field can lift are MODEL limits: a seventh server of an IPVS service (net/ipvs.rs:66-72 pushes to an
     unbounded Vec), a ninth connection waiting in one accept1 queue (endpoint.rs:307: an unbounded channel), a formatted panic value
-    above the workload's declared panic_dyn_max, a 255th live task (task/mod.rs:607-654: an unbounded set).  Kernel and oracle give MADSIM_UNSUPPORTED at the same instruction, every other
+    above the workload's declared panic_dyn_max, a 255th live task (task/mod.rs:607-654: an unbounded set), a 256th registration of one
+    socket (endpoint.rs:288-300: an unbounded Vec), a 16th payload queued in one channel direction (net/mod.rs:417-421: an unbounded channel).  Kernel and oracle give MADSIM_UNSUPPORTED at the same instruction, every other
     field 0 — never MADSIM_OVERFLOW (a re-run could not resolve it), never a shorter list."""
     ws = []
     wl = W.WorkloadBuilder()
@@ -219,6 +220,35 @@ def test_hard_model_limits_are_unsupported_on_both_sides():
     sl = wl.task(n); sl.sleep(secs=1); sl.done()
     m = wl.main(); m.set(0, 300); top = m.label(); m.spawn(sl); m.djnz(0, top); m.sleep(secs=2); m.done()
     lim = A.Limits(); lim.max_tasks = 254
+    ws.append((wl.build(), lim))
+    wl = W.WorkloadBuilder()                               # 3 x 86 timed-out receives on one socket: 255 dead registrations stay, the 256th has no room
+    n = wl.create_node()
+    a = wl.addr(n, 1)
+    ts = []
+    for i in range(3):
+        t = wl.task(n)
+        if i == 0: t.bind(a)
+        else: t.sleep(us=300 * i)
+        t.set(0, 86); top = t.label(); t.recv_from_timeout(a, 1, ms=1); t.djnz(0, top); t.sleep(secs=1); t.done(); ts.append(t)
+    m = wl.main()
+    for t in ts: m.spawn(t)
+    for t in ts: m.join(t)
+    lim = A.Limits(); lim.mbox_regs = 255
+    ws.append((wl.build(), lim))
+    wl = W.WorkloadBuilder()                               # ONE task, 129 timed-out receives: its 8-bit receive sequence number wraps onto a dead registration
+    n = wl.create_node()
+    a = wl.addr(n, 1)
+    t = wl.task(n); t.bind(a); t.set(0, 129); top = t.label(); t.recv_from_timeout(a, 1, ms=1); t.djnz(0, top); t.done()
+    m = wl.main(); m.spawn(t); m.join(t)
+    lim = A.Limits(); lim.mbox_regs = 255
+    ws.append((wl.build(), lim))
+    wl = W.WorkloadBuilder()                               # 16 payloads queued in one channel direction (the receiver never receives)
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
+    srv = wl.task(ns); srv.bind(asv); srv.accept1(asv); srv.sleep(secs=30); srv.done()
+    cl = wl.task(nc); cl.bind(acl); cl.sleep(ms=10); cl.connect1(acl, asv); cl.set(0, 16); top = cl.label(); cl.chan_send(7); cl.djnz(0, top); cl.done()
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.join(cl)
+    lim = A.Limits(); lim.chan_queue = 15
     ws.append((wl.build(), lim))
     for w, lim in ws:
         o, _ = oracle.run_batch(w, 0, 8, None, lim)
