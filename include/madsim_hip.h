@@ -359,10 +359,14 @@ enum madsim_verdict {
     MADSIM_UNSUPPORTED = 6, /* the seed left the workload MODEL (not a reference verdict, and larger limits do not help:
                                never re-run): a port-0 table entry bound again while the Endpoint of its previous bind is
                                alive — an entry names one Endpoint at a time, `close` it first; a seventh server added to
-                               an IPVS service; a ninth connection waiting in one Endpoint's accept1 queue; a 255th live task, a 256th registration of one socket, a 16th queued channel payload (the ceilings of
-                               max_tasks / mbox_regs / chan_queue); a formatted panic
-                               value above madsim_workload_t.panic_dyn_max.  The oracle reports the same verdict for the same
-                               seed, decided at the same instruction; every other result field is 0                     */
+                               an IPVS service; a ninth connection waiting in one Endpoint's accept1 queue; a 255th live task,
+                               a 256th registration of one socket, a 16th queued channel payload (the ceilings of max_tasks /
+                               mbox_regs / chan_queue: below them the verdict is MADSIM_OVERFLOW and a re-run lifts it); a new
+                               receive whose registration word — 8 bits of the task's receive count, 8 of its slot's generation —
+                               equals a dead registration's still in the list (256 receives of one task while a timed-out one
+                               lingers, 256 instances of one slot); a formatted panic value above
+                               madsim_workload_t.panic_dyn_max.  The oracle reports the same verdict for the same seed, decided at
+                               the same instruction; every other result field is 0                                          */
     MADSIM_INTERNAL = 7     /* an invariant of the device code broke (a bug in this library, never a property of the
                                workload): the parity tests assert that no seed ever carries it; other fields 0        */
 };
