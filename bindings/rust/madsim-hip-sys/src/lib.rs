@@ -81,6 +81,10 @@ pub struct madsim_config_t {
     pub buggify: u32,
     pub n_loss_table: u32,
     pub loss_table: [f64; 4],
+    pub n_lat_table: u32,
+    pub reserved0: u32,
+    pub lat_table_lo_ns: [u64; 4],
+    pub lat_table_hi_ns: [u64; 4],
 }
 
 #[repr(C)]
@@ -209,6 +213,7 @@ pub const MS_OP_TRACE_TIME: u8 = 55;
 pub const MS_OP_HOOK_REQ: u8 = 56;
 pub const MS_OP_HOOK_RSP: u8 = 57;
 pub const MS_OP_IPVS: u8 = 58;
+pub const MS_OP_SET_LATENCY: u8 = 59;
 pub const MADSIM_PASS: u32 = 0;
 pub const MADSIM_PANIC: u32 = 1;
 pub const MADSIM_DEADLOCK: u32 = 2;
@@ -219,7 +224,7 @@ pub const MADSIM_UNSUPPORTED: u32 = 6;
 pub const MADSIM_INTERNAL: u32 = 7;
 
 // ---- #define constants -------------------------------------------------------------------------------------------
-pub const MADSIM_HIP_ABI_VERSION: u32 = 3;
+pub const MADSIM_HIP_ABI_VERSION: u32 = 4;
 pub const MADSIM_IPVS_ADD_SERVICE: u32 = 0;
 pub const MADSIM_IPVS_DEL_SERVICE: u32 = 1;
 pub const MADSIM_IPVS_ADD_SERVER: u32 = 2;

@@ -17,16 +17,22 @@ pub struct NetConfig {
     pub packet_loss_rate: f64,
     pub send_latency: std::ops::Range<Duration>,
     pub buggify: bool,
+    /// Ranges a workload's `set_latency(i)` switches to: `NetSim::update_config(|c| c.send_latency = latency_table[i])`
+    /// (`net/mod.rs:138-141`); at most four.
+    pub latency_table: Vec<std::ops::Range<Duration>>,
 }
 
 impl Default for NetConfig {
     fn default() -> Self {
-        NetConfig { packet_loss_rate: 0.0, send_latency: Duration::from_millis(1)..Duration::from_millis(10), buggify: false }
+        NetConfig { packet_loss_rate: 0.0, send_latency: Duration::from_millis(1)..Duration::from_millis(10), buggify: false, latency_table: Vec::new() }
     }
 }
 
 impl NetConfig {
     pub fn raw(&self) -> sys::madsim_config_t {
+        assert!(self.latency_table.len() <= 4, "at most four latency_table entries");
+        let (mut lo, mut hi) = ([0u64; 4], [0u64; 4]);
+        for (i, r) in self.latency_table.iter().enumerate() { lo[i] = r.start.as_nanos() as u64; hi[i] = r.end.as_nanos() as u64; }
         sys::madsim_config_t {
             packet_loss_rate: self.packet_loss_rate,
             lat_lo_ns: self.send_latency.start.as_nanos() as u64,
@@ -34,6 +40,10 @@ impl NetConfig {
             buggify: self.buggify as u32,
             n_loss_table: 0,
             loss_table: [0.0; 4],
+            n_lat_table: self.latency_table.len() as u32,
+            reserved0: 0,
+            lat_table_lo_ns: lo,
+            lat_table_hi_ns: hi,
         }
     }
 }

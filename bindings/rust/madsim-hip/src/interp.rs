@@ -34,6 +34,7 @@ struct Shared {
     socks: Vec<sys::madsim_sock_t>,
     insns: Vec<sys::madsim_insn_t>,
     payloads: Vec<Vec<u8>>,
+    lat_table: Vec<std::ops::Range<Duration>>,
     node_handles: Mutex<Vec<Option<NodeHandle>>>,
     join_handles: Mutex<Vec<Option<JoinHandle<()>>>>,
     flags: [AtomicUsize; 4],
@@ -167,6 +168,10 @@ fn run_task(sh: Arc<Shared>, prog: usize) -> Task {
                     if b & 1 == 1 { if clog { net.clog_node_in(id) } else { net.unclog_node_in(id) } }
                     if b & 2 == 2 { if clog { net.clog_node_out(id) } else { net.unclog_node_out(id) } }
                 }
+                sys::MS_OP_SET_LATENCY => {
+                    let r = sh.lat_table[a as usize].clone();
+                    NetSim::current().update_config(|c| c.send_latency = r);
+                }
                 other => panic!("interp: unsupported op {other}"),
             }
         }
@@ -176,12 +181,18 @@ fn run_task(sh: Arc<Shared>, prog: usize) -> Task {
 /// The future to hand to `Runtime::block_on`: creates the nodes (in table order, `10.0.0.<id>`), runs program 0 and returns
 /// what the run made observable.  Panics of the workload propagate as panics of the future (= madsim's own behaviour).
 pub async fn main_future(w: &Workload, payloads: Vec<Vec<u8>>) -> Observed {
+    main_future_with(w, payloads, Vec::new()).await
+}
+
+/// `main_future` for a workload that calls `set_latency(i)`: `latency_table[i]` is what `NetConfig::latency_table` hands the GPU runner.
+pub async fn main_future_with(w: &Workload, payloads: Vec<Vec<u8>>, latency_table: Vec<std::ops::Range<Duration>>) -> Observed {
     let sh = Arc::new(Shared {
         nodes: w.nodes.clone(),
         progs: w.progs.clone(),
         socks: w.socks.clone(),
         insns: w.insns.clone(),
         payloads,
+        lat_table: latency_table,
         node_handles: Mutex::new((0..w.nodes.len()).map(|_| None).collect()),
         join_handles: Mutex::new((0..w.progs.len()).map(|_| None).collect()),
         flags: [AtomicUsize::new(0), AtomicUsize::new(0), AtomicUsize::new(0), AtomicUsize::new(0)],

@@ -101,6 +101,8 @@ impl TaskBuilder {
     pub fn unclog_node(&mut self, node: u8) -> &mut Self { self.emit(sys::MS_OP_UNCLOG_NODE, node, 3, 0, false) }
     pub fn clog_link(&mut self, src: u8, dst: u8) -> &mut Self { self.emit(sys::MS_OP_CLOG_LINK, src, dst as u16, 0, false) }
     pub fn unclog_link(&mut self, src: u8, dst: u8) -> &mut Self { self.emit(sys::MS_OP_UNCLOG_LINK, src, dst as u16, 0, false) }
+    /// `NetSim::current().update_config(|c| c.send_latency = latency_table[index])` (`net/mod.rs:138-141`)
+    pub fn set_latency(&mut self, index: u8) -> &mut Self { self.emit(sys::MS_OP_SET_LATENCY, index, 0, 0, false) }
     // ---- shared flags (the Arc<AtomicUsize> the reference's tests observe) ------------------------------------------------------
     pub fn flag_store(&mut self, flag: u8, v: u32) -> &mut Self { self.emit(sys::MS_OP_GSET, flag, 0, v, false) }
     pub fn flag_add(&mut self, flag: u8, v: u32) -> &mut Self { self.emit(sys::MS_OP_GADD, flag, 0, v, false) }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MADSIM_HIP_ABI_VERSION 3u
+#define MADSIM_HIP_ABI_VERSION 4u
 
 /* ------------------------------------------------------------------------------------------------
  * Workload: the actor program (read-only, caller-owned POD).
@@ -146,6 +146,11 @@ enum madsim_op {
                               (`.expect("service not found")`: the calling task panics when the service is absent);
                               DEL_SERVER = servers.retain(|a| a != server_addr), rr_index untouched — get_server resets an
                               index that ran off the end (ipvs.rs:96-98).  No draw, no await.                              */
+    /* -- ABI v4 -- */
+    MS_OP_SET_LATENCY = 59,/* a=index into madsim_config_t.lat_table: NetSim::update_config(|c| c.send_latency = lo..hi)
+                              (net/mod.rs:138-141 -> Network::update_config, net/network.rs:129): every later link test samples
+                              the new range (network.rs:267) — datagram sends, connect1, channel sends and their retries alike;
+                              messages already in flight keep the latency they drew.  No draw, no await.                    */
     MS_OP__COUNT
 };
 #define MADSIM_IPVS_ADD_SERVICE 0u
@@ -289,6 +294,13 @@ typedef struct madsim_config {
     uint32_t buggify;            /* non-zero: buggify enabled for the whole run (rand.rs:113-134)    */
     uint32_t n_loss_table;       /* entries in loss_table used by MS_OP_SET_LOSS                     */
     double   loss_table[4];
+    /* -- ABI v4 -- */
+    uint32_t n_lat_table;        /* entries in lat_table_* used by MS_OP_SET_LATENCY (<= 4); every entry must be a non-empty range
+                                    (`gen_range` of an empty range panics in the reference, network.rs:267), and an op that names
+                                    an entry >= n_lat_table is refused (MADSIM_E_WORKLOAD)                                   */
+    uint32_t reserved0;          /* 0 */
+    uint64_t lat_table_lo_ns[4]; /* send_latency.start of entry i                                    */
+    uint64_t lat_table_hi_ns[4]; /* send_latency.end (exclusive) of entry i                          */
 } madsim_config_t;
 
 #define MADSIM_LIMIT_NONE 0xffffffffu  /* a capacity of zero (0 itself means "pick a default") */

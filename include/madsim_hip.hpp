@@ -59,6 +59,8 @@ struct Config {
     double packet_loss_rate = 0.0;
     uint64_t send_latency_start_ns = 1000000, send_latency_end_ns = 10000000;
     bool buggify = false;
+    // ranges Task::set_latency(i) switches to — NetSim::update_config(|c| c.send_latency = ..) (net/mod.rs:138-141); at most four {start, end} in ns
+    std::vector<std::pair<uint64_t, uint64_t>> latency_table;
 
     // `content.parse::<Config>()` of MADSIM_TEST_CONFIG (builder.rs:81-88; config.rs:29-35 = toml::from_str): the [net] table —
     // packet_loss_rate and send_latency = { start = { secs, nanos }, end = { secs, nanos } } — in either TOML spelling (inline
@@ -144,6 +146,9 @@ struct Config {
         madsim_config_t c{};
         c.packet_loss_rate = packet_loss_rate; c.lat_lo_ns = send_latency_start_ns; c.lat_hi_ns = send_latency_end_ns;
         c.buggify = buggify ? 1 : 0;
+        if (latency_table.size() > 4) throw std::invalid_argument("at most four latency_table entries");
+        c.n_lat_table = (uint32_t)latency_table.size();
+        for (size_t i = 0; i < latency_table.size(); i++) { c.lat_table_lo_ns[i] = latency_table[i].first; c.lat_table_hi_ns[i] = latency_table[i].second; }
         return c;
     }
 };
@@ -233,6 +238,7 @@ class Task {
     Task& panic_if_flag_lt(int flag, uint32_t v) { return emit(MS_OP_PANIC_IF_G_LT, (uint8_t)flag, 0, v); }
     Task& clog_node(int node) { return emit(MS_OP_CLOG_NODE, (uint8_t)node, 3); }
     Task& unclog_node(int node) { return emit(MS_OP_UNCLOG_NODE, (uint8_t)node, 3); }
+    Task& set_latency(int index) { return emit(MS_OP_SET_LATENCY, (uint8_t)index); }   // NetSim::update_config(|c| c.send_latency = latency_table[index])
     Task& clog_link(int src, int dst) { return emit(MS_OP_CLOG_LINK, (uint8_t)src, (uint16_t)dst); }
     Task& unclog_link(int src, int dst) { return emit(MS_OP_UNCLOG_LINK, (uint8_t)src, (uint16_t)dst); }
 

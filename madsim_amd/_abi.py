@@ -6,7 +6,7 @@ same structs, so a parity test hands identical bytes to both sides.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 U64_MAX = (1 << 64) - 1
 LIMIT_NONE = 0xFFFFFFFF
 SCHED_STATIC, SCHED_QUEUE = 0, 1
@@ -64,12 +64,17 @@ class Config(C.Structure):
     _fields_ = [
         ("packet_loss_rate", C.c_double), ("lat_lo_ns", C.c_uint64), ("lat_hi_ns", C.c_uint64),
         ("buggify", C.c_uint32), ("n_loss_table", C.c_uint32), ("loss_table", C.c_double * 4),
+        ("n_lat_table", C.c_uint32), ("reserved0", C.c_uint32), ("lat_table_lo_ns", C.c_uint64 * 4), ("lat_table_hi_ns", C.c_uint64 * 4),
     ]
 
     @classmethod
     def default(cls, packet_loss_rate=0.0, lat_lo_ns=1_000_000, lat_hi_ns=10_000_000, buggify=False,
-                loss_table=()):
+                loss_table=(), lat_table=()):
+        """`lat_table`: up to four (lo_ns, hi_ns) ranges that MS_OP_SET_LATENCY (TaskBuilder.set_latency) switches between."""
         c = cls()
+        c.n_lat_table = len(lat_table)
+        for i, (lo, hi) in enumerate(lat_table):
+            c.lat_table_lo_ns[i], c.lat_table_hi_ns[i] = lo, hi
         c.packet_loss_rate = packet_loss_rate
         c.lat_lo_ns, c.lat_hi_ns = lat_lo_ns, lat_hi_ns
         c.buggify = 1 if buggify else 0
@@ -129,7 +134,7 @@ class Geometry(C.Structure):
 
 HEADER_STRUCTS["madsim_campaign_t"] = Campaign
 assert C.sizeof(Insn) == 8 and C.sizeof(Prog) == 4 and C.sizeof(Sock) == 4 and C.sizeof(Node) == 4
-assert C.sizeof(Result) == 48 and C.sizeof(Summary) == 48 and C.sizeof(Limits) == 64
+assert C.sizeof(Result) == 48 and C.sizeof(Summary) == 48 and C.sizeof(Limits) == 64 and C.sizeof(Config) == 136
 
 # numpy view of a result array: one record per seed, same layout as madsim_result_t
 RESULT_DTYPE = [("verdict", "<u4"), ("steps", "<u4"), ("clock_ns", "<u8"), ("msg_count", "<u8"),
@@ -149,7 +154,7 @@ OP = dict(
     SLEEP=10, MARK=11, SLEEP_UNTIL=12, ASSERT_ELAPSED=13, ADVANCE=14, BUILD=15,
     BIND=20, SEND=21, REPLY=22, RECV=23, ASSERT_VAL=24, RECV_TIMEOUT=25, CLOSE=26,
     KILL=30, RESTART=31, PAUSE=32, RESUME=33, CLOG_NODE=34, UNCLOG_NODE=35, CLOG_LINK=36,
-    UNCLOG_LINK=37, ASSERT_EXIT=38, SET_LOSS=39, SLEEP_RAND=40, GSET=41, GADD=42, ASSERT_G=43, PANIC_IF_G_LT=44, JEQ=45, CONNECT=46, ACCEPT=47, CSEND=48, CRECV=49, CCLOSE=50, RPC_CALL=51, RPC_REPLY=52, RAND_BOOL=53, RANDOM=54, TRACE_TIME=55, HOOK_REQ=56, HOOK_RSP=57, IPVS=58,
+    UNCLOG_LINK=37, ASSERT_EXIT=38, SET_LOSS=39, SLEEP_RAND=40, GSET=41, GADD=42, ASSERT_G=43, PANIC_IF_G_LT=44, JEQ=45, CONNECT=46, ACCEPT=47, CSEND=48, CRECV=49, CCLOSE=50, RPC_CALL=51, RPC_REPLY=52, RAND_BOOL=53, RANDOM=54, TRACE_TIME=55, HOOK_REQ=56, HOOK_RSP=57, IPVS=58, SET_LATENCY=59,
 )
 PROG_INIT, PROG_PRE, PROG_DROP_SPAWN = 1, 2, 4
 NODE_RESTART_ON_PANIC = 1

@@ -206,7 +206,23 @@ inline int validate(const madsim_workload_t* w, const madsim_config_t* cfg, std:
     }
     if (cfg->lat_lo_ns >= cfg->lat_hi_ns) return fail(err, MADSIM_E_ARG, "send_latency: cannot sample empty range");
     if (!(cfg->packet_loss_rate >= 0.0 && cfg->packet_loss_rate <= 1.0)) return fail(err, MADSIM_E_ARG, "packet_loss_rate not in [0,1]");
+    // MS_OP_SET_LATENCY: `gen_range` of an empty send_latency panics at the next link test (network.rs:267): a table entry must be a range
+    if (cfg->n_lat_table > 4) return fail(err, MADSIM_E_ARG, "lat_table holds at most 4 entries");
+    for (uint32_t k = 0; k < cfg->n_lat_table; k++)
+        if (cfg->lat_table_lo_ns[k] >= cfg->lat_table_hi_ns[k]) return fail(err, MADSIM_E_ARG, "lat_table: cannot sample empty range");
+    for (uint32_t i = 0; i < w->n_insns; i++)
+        if (w->insns[i].op == MS_OP_SET_LATENCY && w->insns[i].a >= cfg->n_lat_table)
+            return fail(err, MADSIM_E_WORKLOAD, "set_latency names an entry beyond madsim_config_t.n_lat_table");
     return 0;
+}
+
+// The config a geometry query runs with (madsim_hip_geometry has no config argument): Config::default() and a full latency table, so
+// that a workload with MS_OP_SET_LATENCY validates — the layout does not depend on what the entries hold.
+inline madsim_config_t probe_config() {
+    madsim_config_t cfg{}; cfg.lat_lo_ns = 1000000; cfg.lat_hi_ns = 10000000;
+    cfg.n_lat_table = 4;
+    for (int i = 0; i < 4; i++) { cfg.lat_table_lo_ns[i] = 1000000; cfg.lat_table_hi_ns[i] = 10000000; }
+    return cfg;
 }
 
 // buckets of the re-registration table (a power of two; k_timer.h dedup_note): a seed's share of the launch's working set
@@ -226,6 +242,9 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     uint32_t dummy; bernoulli(0.1, &P.bug_pint, &dummy);
     uniform_duration_params(cfg->lat_lo_ns, cfg->lat_hi_ns, &P.lat_mode, &P.lat_low, &P.lat_range, &P.lat_zone);
     for (int i = 0; i < 4; i++) bernoulli(i < (int)cfg->n_loss_table ? cfg->loss_table[i] : 0.0, &P.loss_table_pint[i], &P.loss_table_always[i]);
+    P.uses_set_lat = uses_op(w, MS_OP_SET_LATENCY);
+    for (uint32_t i = 0; i < 4 && i < cfg->n_lat_table; i++)
+        uniform_duration_params(cfg->lat_table_lo_ns[i], cfg->lat_table_hi_ns[i], &P.lat_tab_mode[i], &P.lat_tab_low[i], &P.lat_tab_range[i], &P.lat_tab_zone[i]);
     P.time_limit = L.time_limit_ns;
     P.max_steps = L.max_steps ? L.max_steps : (1u << 24);
     P.no_log = L.no_trace_hash ? 1u : 0u;
@@ -292,7 +311,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // (select_variant), and any of them switches the per-seed LDS layout to its extended form.
     P.features = 0;
     if (uses_op(w, MS_OP_RECV_TIMEOUT) || uses_op(w, MS_OP_MARK) || uses_op(w, MS_OP_SLEEP_UNTIL) || uses_op(w, MS_OP_ASSERT_ELAPSED) ||
-        uses_op(w, MS_OP_ADVANCE) || uses_op(w, MS_OP_TRACE_TIME)) P.features |= MADSIM_FEAT_TIME;
+        uses_op(w, MS_OP_ADVANCE) || uses_op(w, MS_OP_TRACE_TIME) || P.uses_set_lat) P.features |= MADSIM_FEAT_TIME;   // (set_latency: any extended build; this is the leanest)
     if (P.uses_chan) P.features |= MADSIM_FEAT_CHAN;
     if (P.uses_rpc) P.features |= MADSIM_FEAT_RPC | MADSIM_FEAT_TIME;            // call_timeout rides the timeout unit
     if (P.has_restart_on_panic || uses_op(w, MS_OP_KILL) || uses_op(w, MS_OP_RESTART) || uses_op(w, MS_OP_PAUSE) || uses_op(w, MS_OP_RESUME) ||

@@ -28,7 +28,7 @@ __device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_
         bool clogged = false;
         if (P.has_clog) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
         if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
-        if (!clogged && !gen_bool_pint<K>(c, L, L.loss_pint, L.loss_always)) {
+        if (!clogged && !gen_bool_pint<K>(c, L, L.loss_pint, K::LIFE ? (L.loss_always & 1u) : L.loss_always)) {
             L.msg_count++;
             *latency = sample_latency<K>(c, L);
             int ds;

@@ -895,7 +895,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             case MS_OP_SET_LOSS:
                 L.loss_pint = loss_pint_at(P, a);
-                L.loss_always = loss_always_at(P, a);
+                L.loss_always = K::LIFE ? ((L.loss_always & ~1u) | loss_always_at(P, a)) : loss_always_at(P, a);
+                pc++;
+                break;
+            case MS_OP_SET_LATENCY:                         // NetSim::update_config(|c| c.send_latency = ..) (net/mod.rs:138-141, network.rs:129)
+                if (!K::LIFE) { st = ST_PANIC; break; }     // (geometry.h routes every workload with the op to an extended build)
+                L.loss_always = (L.loss_always & ~0x70u) | (((a & 3u) + 1u) << 4);
                 pc++;
                 break;
             default:

@@ -110,22 +110,34 @@ __device__ __forceinline__ bool gen_bool_pint(const Ctx& c, Lane& L, uint64_t p_
 }
 
 // UniformDuration sample on the GlobalRng itself (network.rs:267): one with() per attempt [DEP A.3].
+// The range is `self.config.send_latency` at the moment of the call: the launch's (KParams.lat_*), or — extended builds, workloads
+// with MS_OP_SET_LATENCY — the lat_table entry the seed's last NetSim::update_config named (Lane::loss_always bits 4-6).
+// (select chains, not P.lat_tab_low[k]: a per-lane index into the by-value kernel-argument block would copy the block to scratch)
 template <class K>
 __device__ __forceinline__ uint64_t sample_latency(const Ctx& c, Lane& L) {
     const KParams& P = c.P;
+    uint32_t mode = P.lat_mode;
+    uint64_t low = P.lat_low, range = P.lat_range, zone = P.lat_zone;
+    if (K::LIFE && P.uses_set_lat) {
+        const uint32_t k = (L.loss_always >> 4) & 7u;
+        mode = k == 0 ? mode : k == 1 ? P.lat_tab_mode[0] : k == 2 ? P.lat_tab_mode[1] : k == 3 ? P.lat_tab_mode[2] : P.lat_tab_mode[3];
+        low = k == 0 ? low : k == 1 ? P.lat_tab_low[0] : k == 2 ? P.lat_tab_low[1] : k == 3 ? P.lat_tab_low[2] : P.lat_tab_low[3];
+        range = k == 0 ? range : k == 1 ? P.lat_tab_range[0] : k == 2 ? P.lat_tab_range[1] : k == 3 ? P.lat_tab_range[2] : P.lat_tab_range[3];
+        zone = k == 0 ? zone : k == 1 ? P.lat_tab_zone[0] : k == 2 ? P.lat_tab_zone[1] : k == 3 ? P.lat_tab_zone[2] : P.lat_tab_zone[3];
+    }
     uint64_t res;
     bool ok;
     do {                                                // (one exit: see k_main.h on exit edges)
         REG(8);
         uint64_t v = rng_next(L);
         rng_log<K>(c, L);
-        if (P.lat_mode == 0) {
-            uint64_t m = (uint64_t)(uint32_t)(v >> 32) * (uint64_t)(uint32_t)P.lat_range;
-            ok = (uint32_t)m <= (uint32_t)P.lat_zone;
-            res = P.lat_low + (m >> 32);
+        if (mode == 0) {
+            uint64_t m = (uint64_t)(uint32_t)(v >> 32) * (uint64_t)(uint32_t)range;
+            ok = (uint32_t)m <= (uint32_t)zone;
+            res = low + (m >> 32);
         } else {
-            ok = v * P.lat_range <= P.lat_zone;
-            res = P.lat_low + __umul64hi(v, P.lat_range);
+            ok = v * range <= zone;
+            res = low + __umul64hi(v, range);
         }
     } while (!ok);
     return res;

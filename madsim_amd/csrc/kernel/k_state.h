@@ -120,9 +120,9 @@ struct Lane {
     uint32_t main_done;  // handle[0] left H_RUNNING: block_on's task.is_finished()
     uint32_t panic_code; // message code of the panic being unwound (MS_OP_PANIC), MADSIM_PANIC_CODE_OTHER for the rest
     uint32_t ovf;        // sticky OVF_* bits: the seed ends with a runner verdict (k_main.h), whatever its state says by then
-    // runtime-mutable net config (MS_OP_SET_LOSS)
+    // runtime-mutable net config (MS_OP_SET_LOSS, MS_OP_SET_LATENCY)
     uint64_t loss_pint;
-    uint32_t loss_always;
+    uint32_t loss_always;   // bit 0: packet_loss_rate == 1; bits 4-6 (extended builds): current send_latency = 0 the launch's, k + 1 = lat_table[k]
     // Global-state builds: the Timer::add calls of one poll round, held back and performed at ONE site (poll_task's round
     // head, k_timer.h timer_flush) in their original order: at most one delivery event, then up to three wake-ups of the
     // polled task.  Inlined at each of its ~20 call sites the push's sift-up ran once per site, for the few lanes that

@@ -1031,7 +1031,7 @@ int madsim_hip_run_campaign(const madsim_workload_t* w, const madsim_config_t* c
 
 int madsim_hip_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* out) {
     if (!out) return fail(MADSIM_E_ARG, "null geometry");
-    madsim_config_t cfg{}; cfg.lat_lo_ns = 1000000; cfg.lat_hi_ns = 10000000;
+    madsim_config_t cfg = madsim_geo::probe_config();
     int rc = madsim_geo::validate(w, &cfg, &g_err);
     if (rc) return rc;
     Geo G;

@@ -43,6 +43,9 @@ struct KParams {
     uint64_t loss_pint; uint32_t loss_always; uint32_t buggify; uint64_t bug_pint;
     uint32_t lat_mode; uint32_t has_clog_link; uint32_t has_clog; uint32_t pad0; uint64_t lat_low, lat_range, lat_zone;
     uint64_t loss_table_pint[4]; uint32_t loss_table_always[4];
+    // MS_OP_SET_LATENCY (extended builds): madsim_config_t.lat_table as UniformDuration parameters; a lane keeps the index of its
+    // current entry (Lane::loss_always bits 4-6: 0 = lat_* above) and sample_latency selects
+    uint32_t uses_set_lat; uint32_t lat_tab_mode[4]; uint64_t lat_tab_low[4], lat_tab_range[4], lat_tab_zone[4];
     // limits
     uint64_t time_limit; uint32_t max_steps;
     // capacities

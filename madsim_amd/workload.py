@@ -225,6 +225,10 @@ class TaskBuilder:
     def set_loss(self, table_index):
         return self._emit("SET_LOSS", a=table_index)
 
+    def set_latency(self, table_index):
+        """NetSim::current().update_config(|c| c.send_latency = lat_table[table_index]) (net/mod.rs:138-141)"""
+        return self._emit("SET_LATENCY", a=table_index)
+
     # -- shared flags (Arc<AtomicUsize> in the reference's tests) ------------------------------------
     def flag_store(self, flag, value):
         return self._emit("GSET", a=flag, imm=value)

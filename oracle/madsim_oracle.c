@@ -1218,6 +1218,14 @@ static int poll_task(sim_t* S, uint16_t slot) {
             t->pc++;
             break;
         }
+        case MS_OP_SET_LATENCY: {                          /* NetSim::update_config(|c| c.send_latency = lo..hi): net/mod.rs:138-141 ->
+                                                              Network::update_config (network.rs:129); test_link samples
+                                                              `self.config.send_latency.clone()` on every call (:267) */
+            const uint32_t k = in->a & 3;
+            oracle_uniform_duration_params(S->cfg->lat_table_lo_ns[k], S->cfg->lat_table_hi_ns[k], &S->lat_mode, &S->lat_low, &S->lat_range, &S->lat_zone);
+            t->pc++;
+            break;
+        }
         case MS_OP_RANDOM: {                               /* one with() on the GlobalRng's RngCore impl (rand.rs:142-158) */
             uint64_t v = rng_next(S); rng_log(S);
             /* a=0: gen::<u32>() = next_u32 = upper half [DEP A.1]; a=1: fill_bytes of 1 byte = first LE byte of next_u32
@@ -1376,6 +1384,9 @@ static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
     }
     if (cfg->lat_lo_ns >= cfg->lat_hi_ns) return -1;      /* "cannot sample empty range" */
     if (!(cfg->packet_loss_rate >= 0.0 && cfg->packet_loss_rate <= 1.0)) return -1;
+    if (cfg->n_lat_table > 4) return -1;
+    for (uint32_t k = 0; k < cfg->n_lat_table; k++) if (cfg->lat_table_lo_ns[k] >= cfg->lat_table_hi_ns[k]) return -1;   /* an empty range would panic at the next send */
+    for (uint32_t i = 0; i < w->n_insns; i++) if (w->insns[i].op == MS_OP_SET_LATENCY && w->insns[i].a >= cfg->n_lat_table) return -1;
     return 0;
 }
 

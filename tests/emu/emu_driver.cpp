@@ -211,7 +211,7 @@ extern "C" int madsim_emu_run_batch(const madsim_workload_t* w, const madsim_con
 }
 
 extern "C" int madsim_emu_geometry(const madsim_workload_t* w, const madsim_limits_t* lim, madsim_geometry_t* out) {
-    madsim_config_t cfg{}; cfg.lat_lo_ns = 1000000; cfg.lat_hi_ns = 10000000;
+    madsim_config_t cfg = madsim_geo::probe_config();
     int rc = madsim_geo::validate(w, &cfg, &emu_err);
     if (rc) return rc;
     madsim_geo::Geo G; madsim_geo::Device dev;
@@ -225,7 +225,7 @@ extern "C" int madsim_emu_geometry(const madsim_workload_t* w, const madsim_limi
 
 // selected KParams of the geometry a workload gets (tools/gstate_access_model.py)
 extern "C" int madsim_emu_geometry_params(const madsim_workload_t* w, const madsim_limits_t* lim, uint32_t* out32) {
-    madsim_config_t cfg{}; cfg.lat_lo_ns = 1000000; cfg.lat_hi_ns = 10000000;
+    madsim_config_t cfg = madsim_geo::probe_config();
     madsim_geo::Device dev; dev.num_cus = 1;
     madsim_geo::Geo G;
     int rc = madsim_geo::make_geometry(dev, w, &cfg, lim, 64, &G, &emu_err);

@@ -112,6 +112,86 @@ def random_workload(rng: random.Random, max_nodes=4, max_rounds=6):
     return wl.build(), cfg, "+".join(desc)
 
 
+LATENCY_RANGES = [(1_000_000, 10_000_000), (1, 2), (0, 10_000_000), (900_000_000, 1_100_000_000), (900_000_000, 2_100_000_000),
+                  (5_000_000, 5_000_001), (20_000_000, 60_000_000), (999_999_999, 1_000_000_001)]
+
+
+def random_latency_workload(rng: random.Random, max_nodes=4):
+    """`NetSim::update_config(|c| c.send_latency = ..)` from everywhere (SURVEY §8f row 1; net/mod.rs:138-141, network.rs:129,267): the
+    supervisor and the senders themselves switch between up to four ranges — both UniformDuration paths (Small: inside one second;
+    Medium: across a seconds boundary, A.3), 1 ns wide and 0-based ones — between datagrams, under timeouts, clogs and loss, so that
+    messages drawn under different ranges overtake each other.  Every task traces when things arrive (Instant), so a latency drawn from
+    the wrong range shows in obs_hash as well as in the clock and the log.  Returns (BuiltWorkload, Config, description)."""
+    n_nodes = rng.randint(2, max_nodes)
+    wl = W.WorkloadBuilder()
+    nodes = [wl.create_node() for _ in range(n_nodes)]
+    addrs = [wl.addr(n, 1) for n in nodes]
+    n_tab = rng.randint(1, 4)
+    table = tuple(rng.choice(LATENCY_RANGES) for _ in range(n_tab))
+    tasks, desc = [], []
+    for i, n in enumerate(nodes):
+        t = wl.task(n)
+        kind = rng.choice(["echo", "sender", "sender", "listener"])
+        desc.append(kind)
+        t.bind(addrs[i])
+        rounds = rng.randint(1, 6)
+        if kind == "echo":
+            t.set(0, rounds); top = t.label()
+            t.recv_from(addrs[i], 1); t.trace_instant()
+            if rng.random() < 0.4:
+                t.set_latency(rng.randrange(n_tab))
+            t.reply(addrs[i], 2, 0xA0 + i)
+            t.djnz(0, top)
+        elif kind == "sender":
+            peer = rng.choice([j for j in range(n_nodes) if j != i])
+            if rng.random() < 0.5:
+                t.sleep(ms=rng.randint(0, 30))
+            t.set(0, rounds); top = t.label()
+            if rng.random() < 0.7:
+                t.set_latency(rng.randrange(n_tab))
+            t.send_to(addrs[i], addrs[peer], 1, 0xB0 + i)
+            if rng.random() < 0.5:
+                t.set_latency(rng.randrange(n_tab))
+                t.send_to(addrs[i], addrs[rng.choice([j for j in range(n_nodes) if j != i])], rng.choice([1, 2]), 0xC0 + i)
+            r = rng.random()
+            if r < 0.5:
+                t.recv_from_timeout(addrs[i], 2, ms=rng.choice([2, 40, 1500, 2500])); t.trace_val()
+            elif r < 0.7:
+                t.sleep(ms=rng.choice([0, 3, 700]))
+            t.trace_instant()
+            t.djnz(0, top)
+        else:
+            t.set(0, rounds); top = t.label()
+            t.recv_from_timeout(addrs[i], rng.choice([1, 2]), ms=rng.choice([5, 50, 1200, 3000])); t.trace_val(); t.trace_instant()
+            t.djnz(0, top)
+        t.done()
+        tasks.append(t)
+    m = wl.main()
+    order = list(range(n_nodes)); rng.shuffle(order)
+    for i in order:
+        m.spawn(tasks[i])
+    for _ in range(rng.randint(1, 5)):
+        act = rng.choice(["sleep", "latency", "latency", "clog", "unclog", "loss"])
+        if act == "sleep":
+            m.sleep(ms=rng.choice([0, 1, 7, 25, 400]))
+        elif act == "latency":
+            m.set_latency(rng.randrange(n_tab))
+        elif act == "clog":
+            m.clog_node(rng.choice(nodes), rng.choice(["in", "out", "both"]))
+        elif act == "unclog":
+            m.unclog_node(rng.choice(nodes), rng.choice(["in", "out", "both"]))
+        else:
+            m.set_loss(rng.randint(0, 2))
+    for i in order:
+        if rng.random() < 0.8:
+            m.join(tasks[i])
+    m.done()
+    lo, hi = rng.choice(LATENCY_RANGES)
+    cfg = A.Config.default(packet_loss_rate=rng.choice([0.0, 0.0, 0.05]), lat_lo_ns=lo, lat_hi_ns=hi, buggify=rng.random() < 0.15,
+                           loss_table=(0.0, rng.choice([0.0, 0.3]), 1.0), lat_table=table)
+    return wl.build(), cfg, "+".join(desc) + f" table={n_tab}"
+
+
 def random_lifecycle_workload(rng: random.Random, max_nodes=4, guards=False):
     """Programs that also exercise node lifecycle: init tasks, kill / restart / pause / resume / abort,
     restart_on_panic nodes, spawns on dead nodes, shared flags.  Returns (BuiltWorkload, Config, description).

@@ -766,6 +766,8 @@ class Sim:
                 if b & 2: self.clog_out.discard(a)
             elif name == "SET_LOSS":
                 self.loss = self.cfg.loss_table[a & 3]
+            elif name == "SET_LATENCY":                      # NetSim::update_config(|c| c.send_latency = ..) (net/mod.rs:138-141)
+                self.lat = duration_params(self.cfg.lat_table_lo_ns[a & 3], self.cfg.lat_table_hi_ns[a & 3])
             else:
                 raise NotImplementedError(name)
             pc = nxt
@@ -865,7 +867,8 @@ def workloads():
                          ("random_addr_workload", 880000, 24), ("random_ephemeral_workload", 870000, 16),
                          ("random_channel_workload", 860000, 24), ("random_guard_workload", 850000, 16),
                          ("random_supervisor_workload", 840000, 16), ("random_mixed_workload", 845000, 16),
-                         ("random_ipvs_workload", 895000, 16), ("random_ipvs_runtime_workload", 897000, 16)):
+                         ("random_ipvs_workload", 895000, 16), ("random_ipvs_runtime_workload", 897000, 16),
+                         ("random_latency_workload", 898000, 24)):
         for k in range(n):
             r = getattr(fuzz, gen)(random.Random(base + k))
             out["%s_%02d" % (gen.replace("random_", "fuzz_").replace("_workload", ""), k)] = (r[0], r[1])
@@ -879,12 +882,16 @@ CFG_FIELDS = ("packet_loss_rate", "lat_lo_ns", "lat_hi_ns", "buggify")
 
 
 def cfg_to_json(cfg):
-    return dict({f: getattr(cfg, f) for f in CFG_FIELDS}, loss_table=[cfg.loss_table[i] for i in range(4)])
+    d = dict({f: getattr(cfg, f) for f in CFG_FIELDS}, loss_table=[cfg.loss_table[i] for i in range(4)])
+    if cfg.n_lat_table:                                 # (only where used: the entries of rounds 1-5 keep their bytes)
+        d["lat_table"] = [[cfg.lat_table_lo_ns[i], cfg.lat_table_hi_ns[i]] for i in range(cfg.n_lat_table)]
+    return d
 
 
 def cfg_from_json(d):
     return A.Config.default(packet_loss_rate=d["packet_loss_rate"], lat_lo_ns=d["lat_lo_ns"], lat_hi_ns=d["lat_hi_ns"],
-                            buggify=bool(d["buggify"]), loss_table=tuple(d["loss_table"]))
+                            buggify=bool(d["buggify"]), loss_table=tuple(d["loss_table"]),
+                            lat_table=tuple(tuple(r) for r in d.get("lat_table", ())))
 
 
 def main():
@@ -892,7 +899,9 @@ def main():
     ex = {}
     for name, (w, own) in workloads().items():
         ex[name] = {}
-        cfgs = [("default", A.Config.default()), ("loss20", A.Config.default(packet_loss_rate=0.2))]
+        # (a workload that switches latencies needs its table under every config: an op naming a missing entry is refused)
+        tab = tuple((own.lat_table_lo_ns[i], own.lat_table_hi_ns[i]) for i in range(own.n_lat_table)) if own is not None else ()
+        cfgs = [("default", A.Config.default(lat_table=tab)), ("loss20", A.Config.default(packet_loss_rate=0.2, lat_table=tab))]
         if own is not None:
             cfgs.append(("own", own))
             ex[name]["_own_config"] = cfg_to_json(own)

@@ -868,6 +868,53 @@ ALL.update(many_endpoints_dropped_in_table_order=many_endpoints_dropped_in_table
            dead_registrations_swept_by_delivery=dead_registrations_swept_by_delivery)
 
 
+# ---- round 6: NetSim::update_config of send_latency (net/mod.rs:138-141, network.rs:129, consumed at :267) ----
+
+def update_config_latency():
+    """`NetSim::current().update_config(|c| c.send_latency = lo..hi)` between datagrams: every link test samples the range in force at
+    that moment (network.rs:267), a message in flight keeps the latency it drew.  The table: 100..101 ms (UniformDuration's Small path,
+    A.3), 1.5..3.5 s (Medium path: the range crosses a seconds boundary), 1..2 ns (exactly 1 ns).  The receiver times every arrival
+    from its own t0; with the default 1..10 ms in force throughout every assert but the first would fail."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a_tx, a_rx = wl.addr(n1, 1), wl.addr(n2, 1)
+    rx = wl.task(n2); rx.mark(); rx.bind(a_rx)
+    rx.recv_from(a_rx, 1); rx.assert_val(0xA); rx.assert_elapsed(">=", ms=12); rx.assert_elapsed("<", ms=25); rx.trace_instant()
+    rx.recv_from(a_rx, 2); rx.assert_val(0xB); rx.assert_elapsed(">=", ms=110); rx.assert_elapsed("<", ms=120); rx.trace_instant()
+    rx.recv_from(a_rx, 3); rx.assert_val(0xC); rx.assert_elapsed(">=", secs=1, ms=500); rx.assert_elapsed("<", secs=3, ms=600); rx.trace_instant()
+    rx.recv_from(a_rx, 4); rx.assert_val(0xD); rx.assert_elapsed(">=", secs=5, ms=2); rx.assert_elapsed("<", secs=5, ms=4); rx.trace_instant()
+    tx = wl.task(n1); tx.mark(); tx.bind(a_tx); tx.sleep(ms=10)
+    tx.send_to(a_tx, a_rx, 1, 0xA)
+    tx.set_latency(0); tx.send_to(a_tx, a_rx, 2, 0xB)
+    tx.set_latency(1); tx.send_to(a_tx, a_rx, 3, 0xC)
+    tx.sleep_until(secs=5); tx.set_latency(2); tx.send_to(a_tx, a_rx, 4, 0xD)
+    m = wl.main(); m.spawn(rx); m.spawn(tx); m.join(rx); m.join(tx)
+    return wl.build()
+
+
+def update_config_latency_channel():
+    """The same switch seen by the reliable channel: connect1's link test draws (and discards) a latency, `tx.send` stamps the payload
+    with now + latency (net/mod.rs:417-421, 375-380) and the receiver sleeps until then (:399).  The supervisor — a different task on a
+    different node: the config is the simulator's, not the caller's — sets 200..201 ms before the second payload and the launch's own
+    default never comes back."""
+    wl = W.WorkloadBuilder()
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
+    srv = wl.task(ns); srv.bind(asv); srv.accept1(asv)
+    srv.chan_recv(); srv.assert_val(1); srv.mark()
+    srv.chan_recv(); srv.assert_val(2); srv.assert_elapsed(">=", ms=280); srv.assert_elapsed("<", ms=305); srv.trace_instant()
+    srv.chan_recv(); srv.assert_val(3); srv.assert_elapsed("<", ms=310); srv.trace_instant()       # sent right behind it, same range: ordered delivery
+    cl = wl.task(nc); cl.bind(acl); cl.sleep(ms=10); cl.connect1(acl, asv); cl.assert_val(0); cl.chan_send(1)
+    cl.sleep(ms=100); cl.chan_send(2); cl.chan_send(3); cl.sleep(secs=1)
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.sleep(ms=60); m.set_latency(0); m.join(srv)
+    return wl.build()
+
+
+ALL.update(update_config_latency=update_config_latency, update_config_latency_channel=update_config_latency_channel)
+CONFIGS["update_config_latency"] = dict(lat_table=((100_000_000, 101_000_000), (1_500_000_000, 3_500_000_000), (1, 2)))
+CONFIGS["update_config_latency_channel"] = dict(lat_table=((200_000_000, 201_000_000),))
+
+
 def config(name):
     """Non-default Config a workload is meant to run under (None = Config::default())."""
     return A.Config.default(**CONFIGS[name]) if name in CONFIGS else None

@@ -144,6 +144,21 @@ def test_fuzz_supervisor_workloads():
         e = _strict(w, k * 3, o, e, cfg, lim, (k, desc,))
 
 
+def test_fuzz_latency_workloads():
+    """NetSim::update_config of send_latency from the supervisor and the senders (MS_OP_SET_LATENCY), both state layouts."""
+    verdicts = set()
+    for k in range(200):
+        w, cfg, desc = fuzz.random_latency_workload(random.Random(61000 + k))
+        lim = fuzz.mailbox_limits()
+        if k % 2:
+            lim = _global(lim)
+        o, _ = oracle.run_batch(w, k * 5, 12, cfg, lim)
+        e = emu.run_batch(w, k * 5, 12, cfg, lim)
+        e = _strict(w, k * 5, o, e, cfg, lim, (k, desc,))
+        verdicts |= set(o["verdict"].tolist())
+    assert {A.PASS, A.DEADLOCK} <= verdicts
+
+
 def test_fuzz_mixed_workloads():
     """Everything from everywhere: supervisor calls, datagrams, channel and RPC exchanges from every task, both state layouts."""
     for k in range(160):

@@ -185,7 +185,8 @@ GENS = [("random_workload", fuzz.generous_limits), ("random_lifecycle_workload",
         ("random_supervisor_workload", fuzz.mixed_limits), ("random_mixed_workload", fuzz.mixed_limits),
         ("random_ipvs_workload", fuzz.generous_limits), ("random_ipvs_runtime_workload", fuzz.generous_limits),
         ("random_timeout_workload", fuzz.mailbox_limits), ("random_reply_without_receive_workload", fuzz.mailbox_limits),
-        ("random_unstructured_workload", fuzz.generous_limits), ("random_unstructured_wide_workload", fuzz.wide_limits)]
+        ("random_unstructured_workload", fuzz.generous_limits), ("random_unstructured_wide_workload", fuzz.wide_limits),
+        ("random_latency_workload", fuzz.mailbox_limits)]
 
 
 @pytest.mark.parametrize("gen,limits", GENS, ids=[g[0] for g in GENS])

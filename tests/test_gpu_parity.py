@@ -313,6 +313,13 @@ def test_fuzz_supervisor_workloads_gpu(hip):
     _fuzz_two_blocks(hip, fuzz.random_supervisor_workload, 7800, 200, 100, 4, count=64, seed_mul=17, limits=_lim_tasks(48), alt_global=True)
 
 
+def test_fuzz_latency_workloads_gpu(hip):
+    """NetSim::update_config of send_latency (MS_OP_SET_LATENCY, SURVEY §8f row 1) from the supervisor and the senders, both
+    UniformDuration paths, under timeouts / clogs / loss; odd rounds with the per-seed state in the global-memory block."""
+    from tests import fuzz
+    _fuzz_two_blocks(hip, fuzz.random_latency_workload, 61000, 200, 100, 17, count=64, seed_mul=5, limits=fuzz.mailbox_limits, alt_global=True)
+
+
 def test_fuzz_mixed_workloads_gpu(hip):
     """Everything from everywhere — supervisor calls, datagrams, channel and RPC exchanges, service tasks (echo, RPC handler,
     accept loop) — from every task: the deepest generator, LDS-resident (even rounds) and global-state (odd rounds) builds."""

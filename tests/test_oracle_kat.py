@@ -166,7 +166,8 @@ def test_executor_golden_async_formulation(name):
     for cfgname, seeds in ASYNC[name].items():
         if cfgname == "_own_config":
             continue
-        cfg = {"default": lambda: A.Config.default(), "loss20": lambda: A.Config.default(packet_loss_rate=0.2),
+        tab = tuple(tuple(r) for r in ASYNC[name].get("_own_config", {}).get("lat_table", ()))     # (MS_OP_SET_LATENCY's table goes with every config)
+        cfg = {"default": lambda: A.Config.default(lat_table=tab), "loss20": lambda: A.Config.default(packet_loss_rate=0.2, lat_table=tab),
                "own": lambda: mod.cfg_from_json(ASYNC[name]["_own_config"])}[cfgname]()
         for seed, want in seeds.items():
             log, res = oracle.trace_seed(w, int(seed), cfg)

@@ -14,14 +14,14 @@ gens = [("random_workload", None, None), ("random_lifecycle_workload", 24, None)
         ("random_addr_workload", None, None), ("random_ephemeral_workload", None, None), ("random_channel_workload", 24, None),
         ("random_guard_workload", 24, None), ("random_supervisor_workload", 48, None), ("random_mixed_workload", 60, None), ("random_ipvs_workload", 24, None), ("random_ipvs_runtime_workload", 24, None),
         ("random_timeout_workload", None, None), ("random_reply_without_receive_workload", None, None),
-        ("random_unstructured_workload", 16, None)]
+        ("random_unstructured_workload", 16, None), ("random_latency_workload", None, None)]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200; base = int(sys.argv[2]) if len(sys.argv) > 2 else 3_000_000; TIGHT = len(sys.argv) > 3 and sys.argv[3] == 'tight'; t0=time.time(); total=0; bad=0; tally=parity.Tally()
 for gi,(g,mt,opt) in enumerate(gens):
     for k in range(N):
         rng = random.Random(base + 100000*gi + k)
         r = fuzz.random_rpc_workload(rng, hooks=True) if opt else getattr(fuzz, g)(rng)
         w, cfg, desc = r[0], r[1], r[2]
-        lim = fuzz.mixed_limits() if mt == 60 else fuzz.mailbox_limits() if g in ('random_timeout_workload', 'random_reply_without_receive_workload') else fuzz.generous_limits()
+        lim = fuzz.mixed_limits() if mt == 60 else fuzz.mailbox_limits() if g in ('random_timeout_workload', 'random_reply_without_receive_workload', 'random_latency_workload') else fuzz.generous_limits()
         if mt and mt != 60: lim.max_tasks = mt
         if TIGHT:
             lr = random.Random(k)

@@ -18,14 +18,14 @@ gens = [("plain", fuzz.random_workload, None), ("lifecycle", fuzz.random_lifecyc
         ("guards", fuzz.random_guard_workload, 24), ("supervisor", fuzz.random_supervisor_workload, 48),
         ("mixed", fuzz.random_mixed_workload, 60), ("ipvs", fuzz.random_ipvs_workload, 24), ("ipvs_rt", fuzz.random_ipvs_runtime_workload, 24),
         ("timeouts", fuzz.random_timeout_workload, None), ("stale_from", fuzz.random_reply_without_receive_workload, None),
-        ("op_soup", fuzz.random_unstructured_workload, 16)]
+        ("op_soup", fuzz.random_unstructured_workload, 16), ("latency", fuzz.random_latency_workload, None)]
 if len(sys.argv) > 3:                              # optional: only the generators whose name contains one of these (comma-separated)
     gens = [g for g in gens if any(x in g[0] for x in sys.argv[3].split(","))]
 t0 = time.time(); k = 0; tally = parity.Tally()
 while time.time() - t0 < budget:
     name, gen, max_tasks = gens[k % len(gens)]
     w, cfg, desc = gen(random.Random(base + k))
-    lim = fuzz.mailbox_limits() if name in ("timeouts", "stale_from") else fuzz.generous_limits()
+    lim = fuzz.mailbox_limits() if name in ("timeouts", "stale_from", "latency") else fuzz.generous_limits()
     if max_tasks: lim.max_tasks = max_tasks
     if (k // len(gens)) % 2:          # every other round: per-seed state in the global-memory block instead of LDS (Variant::G)
         lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL

@@ -16,7 +16,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 base = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
 gens = ["random_workload", "random_lifecycle_workload", "random_rpc_workload", "random_rpc_workload+hooks", "random_addr_workload",
         "random_ephemeral_workload", "random_channel_workload", "random_guard_workload", "random_supervisor_workload", "random_mixed_workload", "random_ipvs_workload", "random_ipvs_runtime_workload",
-        "random_timeout_workload"]
+        "random_timeout_workload", "random_latency_workload"]
 if len(sys.argv) > 3:                              # optional: only the generators whose name contains this
     gens = [g for g in gens if sys.argv[3] in g]
 t0 = time.time(); total = 0; verdicts = collections.Counter()
