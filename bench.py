@@ -201,7 +201,7 @@ def main():
 
     w, lim, wname = workload.bench_case(args.workload, args.nodes, workload.BENCH_ROUNDS, args.heap_lds)
     headline = args.workload == "pingpong" and args.nodes == workload.BENCH_NODES
-    lim.lanes_per_wave = args.lpw or lim.lanes_per_wave       # (a bench case may bring its own: the election loop runs 32 seed lanes per wave)
+    lim.lanes_per_wave = args.lpw or int(os.environ.get("MADSIM_BENCH_LPW", 0)) or lim.lanes_per_wave       # (a bench case may bring its own: the election loop runs 32 seed lanes per wave)
     lim.state_mem = args.state_mem or lim.state_mem
     if "MADSIM_BENCH_STATE_FLAGS" in os.environ:         # experiments: OR into / clear from state_mem (e.g. 0x100 = MADSIM_STATE_DEDUP_TIMERS; "-0x100" clears it)
         v = os.environ["MADSIM_BENCH_STATE_FLAGS"]

@@ -352,6 +352,15 @@ typedef struct madsim_limits {
    5e-4 of its seeds meet a tie). */
 #define MADSIM_STATE_DEDUP_TIMERS 0x100u
 
+/* OR-ed into madsim_limits_t.state_mem like MADSIM_STATE_DEDUP_TIMERS: global-state builds with a heap-spill region keep every timer-heap
+   entry as 8 bytes {low 32 bits of the deadline, event word} instead of 16 — twice the heap levels in the same LDS, half the bytes per
+   spilled level; the payload of a datagram delivery waits in a per-seed record pool in global memory until its entry reaches the root.
+   Exact while every live deadline lies within 2^31 ns (2.1 s) of the clock: the host admits the layout only for workloads whose sleeps,
+   timeouts and latencies stay below that (no buggify, no restart_on_panic), and the device checks every push — a seed that does exceed
+   it (a channel back-off past 2 s) gets a capacity verdict and is run again on the 16-byte entries by madsim_hip_run_batch_auto.  Results
+   never differ.  Ignored by builds without the variant (LDS-resident state, connection-only workloads, general address resolution). */
+#define MADSIM_STATE_NARROW_HEAP 0x200u
+
 #define MADSIM_SCHED_STATIC 0u   /* lane g runs seeds g, g+G, g+2G, ...                                */
 #define MADSIM_SCHED_QUEUE  1u   /* a finished lane pulls the next seed from a per-launch atomic counter */
 

@@ -12,6 +12,7 @@ LIMIT_NONE = 0xFFFFFFFF
 SCHED_STATIC, SCHED_QUEUE = 0, 1
 STATE_AUTO, STATE_LDS, STATE_GLOBAL, STATE_COMPACT = 0, 1, 2, 3
 STATE_DEDUP_TIMERS = 0x100     # OR-ed into state_mem: re-registered Sleep timers as counts (include/madsim_hip.h)
+STATE_NARROW_HEAP = 0x200      # OR-ed into state_mem: 8-byte timer-heap entries + delivery record pool (global-state builds with a spill region)
 VAL_TIMEOUT = 0xFFFFFFFF
 VAL_REFUSED = 0xFFFFFFFE
 VAL_RESET = 0xFFFFFFFD

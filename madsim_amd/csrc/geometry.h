@@ -329,8 +329,27 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // would leave a CU with fewer than four full waves — global memory, [unit][lane] across the launch (Variant::G, k_state.h).
     // (its low byte; MADSIM_STATE_DEDUP_TIMERS rides above it)
     const uint32_t state_mem = L.state_mem & 0xffu;
-    if (state_mem > MADSIM_STATE_COMPACT || (L.state_mem & ~(0xffu | MADSIM_STATE_DEDUP_TIMERS)))
-        return fail(err, MADSIM_E_LIMITS, "state_mem must be 0 (auto), 1 (LDS), 2 (global) or 3 (compact), optionally | MADSIM_STATE_DEDUP_TIMERS");
+    if (state_mem > MADSIM_STATE_COMPACT || (L.state_mem & ~(0xffu | MADSIM_STATE_DEDUP_TIMERS | MADSIM_STATE_NARROW_HEAP)))
+        return fail(err, MADSIM_E_LIMITS, "state_mem must be 0 (auto), 1 (LDS), 2 (global) or 3 (compact), optionally | MADSIM_STATE_DEDUP_TIMERS | MADSIM_STATE_NARROW_HEAP");
+    // MADSIM_STATE_NARROW_HEAP: 8-byte heap entries hold the low deadline word — admitted when nothing the workload can ask for lies 2^31 ns
+    // ahead of the clock (the device checks every push all the same: a channel back-off can grow past it at run time)
+    bool narrow_ok = (L.state_mem & MADSIM_STATE_NARROW_HEAP) && !trace && !cfg->buggify && !P.has_restart_on_panic;
+    {
+        uint64_t horizon = std::max<uint64_t>(cfg->lat_hi_ns, 1000000ull);
+        for (uint32_t i = 0; i < cfg->n_lat_table && i < 4; i++) horizon = std::max<uint64_t>(horizon, cfg->lat_table_hi_ns[i]);
+        for (uint32_t i = 0; i < w->n_insns; i++) {
+            const madsim_insn_t& in = w->insns[i];
+            if (in.op == MS_OP_SLEEP || in.op == MS_OP_SLEEP_RAND || in.op == MS_OP_SLEEP_UNTIL || in.op == MS_OP_ADVANCE)
+                horizon = std::max<uint64_t>(horizon, (uint64_t)in.b * 1000000000ull + in.imm);
+            if (in.op == MS_OP_RECV_TIMEOUT) horizon = std::max<uint64_t>(horizon, (uint64_t)(in.b & 0xff) * 1000000000ull + in.imm);
+            if (in.op == MS_OP_RPC_CALL) horizon = std::max<uint64_t>(horizon, (uint64_t)(in.imm >> 8) * 1000000ull);
+        }
+        if (horizon >= (1ull << 31) - (1ull << 24)) narrow_ok = false;
+    }
+    P.narrow = 0; P.pool_n = 0; P.pool_off = 0; P.off_pmask = 0;
+    bool use_narrow = false;
+    // delivery records of a narrow heap: a quarter of the heap's capacity (in-flight datagrams are a fifth of its entries), 32 .. 256
+    auto pool_records = [](uint32_t heap_cap) { return std::min<uint32_t>(256u, std::max<uint32_t>(32u, (heap_cap / 4 + 31) & ~31u)); };
     P.gstate_mode = 0;
     P.dedup_n = 0; P.dedup_off = 0;
     // base-op builds: no owner word per socket (the owner's slot rides in the header, k_state.h) and 8-byte unit1
@@ -375,6 +394,16 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             P.off_amask = (P.max_tasks + 3) / 4;               // LDS planes: ready queue (a byte per entry), alive-task mask, owned-socket mask
             P.off_omask = P.off_amask + (P.max_tasks + 31) / 32;
             P.lane_words = P.off_omask + 2;
+            // narrow heap entries, where the layout has a spill region and a build with the variant exists (sim_kernel.h): the delivery
+            // records — a quarter of the heap's capacity, in-flight datagrams are a fifth of its entries — behind the planes
+            P.narrow = use_narrow ? 1u : 0u;                    // (decided where the LDS quota was split, below)
+            P.pool_n = use_narrow ? pool_records(P.heap_lds + P.heap_spill) : 0u;
+            if (P.narrow) {
+                P.pool_off = P.gs_stride;
+                P.gs_stride += P.pool_n * 8;
+                P.off_pmask = P.off_omask + 2;
+                P.lane_words = P.off_pmask + P.pool_n / 32;
+            }
         }
         P.sh_insns = 0;
         P.sh_progs = P.sh_insns + 4 * P.n_insns;
@@ -382,7 +411,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
         P.sh_nodes = P.sh_socks + P.n_socks;
         P.sh_heap = (P.sh_nodes + P.n_nodetab + 3) & ~3u;
         sh_bytes = P.sh_heap * 4;
-        G->lds_per_seed = P.heap_lds * heap_bytes + (P.gstate_mode ? 0 : P.max_tasks * task_bytes) + P.lane_words * 4;
+        G->lds_per_seed = P.heap_lds * (P.narrow ? 8u : heap_bytes) + (P.gstate_mode ? 0 : P.max_tasks * task_bytes) + P.lane_words * 4;
         if (sh_bytes + 8 * (size_t)G->lds_per_seed > g.lds_per_cu && (state_mem == MADSIM_STATE_LDS || !P.lifecycle || trace || P.gstate_mode)) return fail(err, MADSIM_E_LIMITS, "per-seed LDS state too large: lower heap_lds_slots / mailbox capacities");
         // Lanes per wave (lw): how many of a wave's 64 lanes carry a seed.  Measured on MI355X (4-node
         // ping-pong, 65 536 seeds, profiles/r1_lanes_per_wave.md): every wave-instruction costs the SIMD
@@ -421,6 +450,18 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             const size_t per_seed = quota > (size_t)sh_bytes + 1280 ? (quota - sh_bytes - 1280) / (4 * glw) : 0;   // no size_t underflow)
             const size_t fixed = 4 * (((size_t)P.max_tasks + 3) / 4 + (P.max_tasks + 31) / 32 + 2);
             uint32_t fit = per_seed > fixed + 64 ? (uint32_t)((per_seed - fixed) / 16) : 4u;
+            // Narrow heap entries (MADSIM_STATE_NARROW_HEAP) where the 16-byte layout would spill and a build with the variant exists:
+            // 8 bytes per entry and the record pool's mask words in the same quota — what then fits may well be the whole heap
+            use_narrow = false;
+            if (narrow_ok && (P.heap_spill || P.heap_lds > fit)) {
+                KParams Q = P; Q.narrow = 1; Q.gstate_mode = 1; Q.lw_shift = glw == 32 ? 5 : 6;
+                if (!Q.heap_spill) Q.heap_spill = 1;
+                use_narrow = madsim_k::variant_compiled(madsim_k::select_variant(Q, trace));
+            }
+            if (use_narrow) {
+                const size_t fixed_n = fixed + 4 * (pool_records(P.heap_lds + P.heap_spill) / 32);
+                fit = per_seed > fixed_n + 64 ? (uint32_t)((per_seed - fixed_n) / 8) : 4u;
+            }
             if (P.heap_lds > fit) { P.heap_spill += P.heap_lds - fit; P.heap_lds = fit; }
             continue;
         }
@@ -436,7 +477,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
     // per seed, three -> four waves per SIMD) and every live deadline provably stays within 2^31 ns of the clock: the longest
     // sleep of the program, the latency range, rand_delay's 1 ms floor — or buggify's 1..5 s, which rules it out.
     P.compact = 0;
-    uint32_t heap_n = P.heap_lds, heap_b = heap_bytes, task_n = P.max_tasks;
+    uint32_t heap_n = P.heap_lds, heap_b = P.narrow ? 8u : heap_bytes, task_n = P.max_tasks;
     {
         uint64_t horizon = std::max<uint64_t>(cfg->lat_hi_ns, 1000000ull);
         if (cfg->buggify) horizon = ~0ull;

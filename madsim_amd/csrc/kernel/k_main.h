@@ -13,6 +13,7 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
         for (uint32_t w = 0; w < P.gs_plane_words; w++) gs_store32(c.gs, gs_addr_word(c, P.gs_planes + w * 4), 0);
         for (uint32_t w = 0; w < (P.max_tasks + 31) / 32; w++) AMASK(w) = 0;
         OMASK(0) = 0; OMASK(1) = 0;
+        if (K::NH) for (uint32_t w = 0; w < P.pool_n / 32; w++) PMASK(w) = 0;
     }
     else for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;     // plane 0 is the ready queue: RW spans all planes
     if (K::DEDUP) { for (uint32_t b = 0; b < P.dedup_n; b++) gs_store32(c.gs, gs_addr_uword(c, P.dedup_off + b * 16u + 12u), 0); L.hazard = 0; }   // empty buckets
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
     c.sockt0 = P.sh_socks;
     c.nodet0 = P.sh_nodes;
     const uint32_t wbase = wv * P.wave_words;       // this wave's slice of the workgroup's LDS
-    if (K::LIFE) c.heap0 = (P.sh_heap + wbase) / 4 + lane;
+    if (K::NH) c.heap0 = (P.sh_heap + wbase) / 2 + lane;          // 8-byte entries: a uint2 index
+    else if (K::LIFE) c.heap0 = (P.sh_heap + wbase) / 4 + lane;
     else if (K::CMP) { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = 0; }        // 8-byte entries 1 .. heap_lds - 1 (entry 0: registers)
     else { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = P.sh_heap + wbase + ((P.heap_lds * 2) << P.lw_shift) + lane; }
     c.lws = P.lw_shift;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
     c.ready0 = pl + (P.off_ready << P.lw_shift);
     c.amask0 = pl + (P.off_amask << P.lw_shift);
     c.omask0 = pl + (P.off_omask << P.lw_shift);
+    c.pmask0 = pl + (P.off_pmask << P.lw_shift);
     if (K::G) {                                      // byte offsets inside the lane's global state block
         c.task0 = 0;
         c.sock0 = P.gs_planes + P.off_socks * 4; c.hand0 = P.gs_planes + P.off_handles * 4; c.node0 = P.gs_planes + P.off_nodes * 4;
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
     if (EXP_LANE_DIV > 1 && (lane % EXP_LANE_DIV)) return;          // (timing experiments only: tools/experiment/k_experiment.h EXP_HALF_LANES)
     const uint32_t glane = (((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane) / EXP_LANE_DIV;
-    c.spill_off = glane * 16u;
-    c.spill = buf_make(P.spill, (uint64_t)P.heap_spill * P.total_lanes * 16u);
+    c.spill_off = glane * (K::NH ? 8u : 16u);
+    c.spill = buf_make(P.spill, (uint64_t)P.heap_spill * P.total_lanes * (K::NH ? 8u : 16u));
     c.gs_lane = glane;
     c.gs = buf_make(P.gstate, (uint64_t)P.gs_stride * P.total_lanes);
     c.tlog = P.trace_log;

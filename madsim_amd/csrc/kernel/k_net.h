@@ -192,10 +192,14 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
         // costing a round trip of their own afterwards.  The pop touches neither task nor socket state.
         uint32_t pf_flags = 0;
         DeliverPrefetch pf = {0, 0};
+        uint2 pf_rec = make_uint2(0, 0);                  // narrow-heap builds: the root delivery's pool record {full event word, payload}
         if (K::G) {
-            const uint32_t rz = heap_lds_get<K>(c, 0).z, rk = rz >> EV_SHIFT;
+            const uint32_t rz = heap_root_meta<K>(c), rk = rz >> EV_SHIFT;
             if (rk == EV_WAKE) pf_flags = TWORD(c, rz & 0xff, 0, 0);
-            else if (rk == EV_DELIVER) { pf.hdr = SW(c, rz & 0x3f, 0); pf.reg0 = SW(c, rz & 0x3f, 2); }
+            else if (rk == EV_DELIVER) {
+                pf.hdr = SW(c, rz & 0x3f, 0); pf.reg0 = SW(c, rz & 0x3f, 2);
+                if (K::NH) pf_rec = buf_load64(c.gs, pool_addr(c, (rz >> 6) & 0x7fffu));
+            }
         }
         // DEDUP builds: the bucket that may hold repeats of the root wake-up (k_timer.h dedup_note) — like the loads above it
         // depends on the root entry alone
@@ -203,17 +207,22 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
         uint32_t dd_at = 0;
         uint4 dd_u = make_uint4(0, 0, 0, 0);
         if (K::DEDUP && dd) {
-            const uint32_t rz = heap_lds_get<K>(c, 0).z;
+            const uint32_t rz = heap_root_meta<K>(c);
             if ((rz >> EV_SHIFT) == EV_WAKE) { dd_at = dedup_bucket(c, L.top_dl, rz); dd_u = gs_load128(c.gs, gs_addr_unit(c, dd_at)); }
         }
         uint4 e = timer_pop<K>(c, L);
         L.steps++;
         uint32_t kind = e.z >> EV_SHIFT;
+        const uint32_t popped_meta = e.z;                 // (as it sat in the heap: what a tie is recognised by)
+        if (K::NH && kind == EV_DELIVER) { pool_free<K>(c, (e.z >> 6) & 0x7fffu); e.z = pf_rec.x; e.w = pf_rec.y; }
         if (K::DEDUP && dd) {
             // the repeats of this wake-up fire with it: a step each, their task is SCHEDULED by the first already
             if (dd_u.w != 0 && dd_u.x == e.x && dd_u.y == e.y && dd_u.z == e.z) { L.steps += dd_u.w; gs_store32(c.gs, gs_addr_uword(c, dd_at + 12u), 0); }
             // two DIFFERENT events with one deadline: which fires first is a matter of the heap's shape (restart the seed exactly)
-            if (L.heap_len > 0 && L.top_dl == ev_deadline(e)) { const uint4 r = heap_lds_get<K>(c, 0); if (r.z != e.z || r.w != e.w) L.hazard = 1; }
+            if (L.heap_len > 0 && L.top_dl == ev_deadline(e)) {
+                if (K::NH) { if (heap_root_meta<K>(c) != popped_meta) L.hazard = 1; }     // (two deliveries never share a record: always different)
+                else { const uint4 r = heap_lds_get<K>(c, 0); if (r.z != e.z || r.w != e.w) L.hazard = 1; }
+            }
         }
         if (kind == EV_WAKE) {                                                              // time/sleep.rs:52
             REG(22);

@@ -840,6 +840,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_ADVANCE:                            // time/mod.rs:103-106
                 if (!K::FT) { st = ST_PANIC; break; }
                 if (K::G && L.pq_n) break;                 // pushes of this round are still queued: flush at the head, then come back here
+                if (K::NH && (uint64_t)b * NS_PER_S + imm >= NH_HORIZON) OVF_SET(L, OVF_CAP);   // (the 8-byte entries' deadlines are read relative to the clock)
                 L.clock += (uint64_t)b * NS_PER_S + imm;
                 pc++;
                 u0.y = pc | (sub << 16) | (from << 24);

@@ -67,6 +67,8 @@ template <bool TRACE_, bool SPILL_, int LWS_, int FEAT_, bool RQ_ = false, bool 
     // the compact base-op layout (sim_kernel.h MADSIM_FEAT_COMPACT): 8-byte heap entries + root in registers + main task in global memory
     static constexpr bool CMP = (FEAT_ & MADSIM_FEAT_COMPACT) != 0;
     static constexpr bool NOLOG = (FEAT_ & MADSIM_FEAT_NOLOG) != 0;
+    // 8-byte timer-heap entries + delivery record pool (sim_kernel.h MADSIM_FEAT_NARROW; k_timer.h)
+    static constexpr bool NH = (FEAT_ & MADSIM_FEAT_NARROW) != 0;
     static constexpr bool LOGSW = !NOLOG && !TRACE_ && (LIFE || SPILL_ || LWS_ != 6);
     // MADSIM_STATE_DEDUP_TIMERS (KParams.dedup_n): only the global-state build of timeout-only workloads carries the code
     static constexpr bool DEDUP = G_ && !TRACE_ && (FEAT_ & MADSIM_FEAT_ALL) == MADSIM_FEAT_TIME;
@@ -162,6 +164,7 @@ struct Ctx {
     // task slot t holds a live task (spawn's free-slot search), bit s of the owner mask = socket s was bound by a task that
     // has not finished yet (task_finish's "which endpoints did this task own" search)
     uint32_t amask0, omask0;
+    uint32_t pmask0;     // Variant::NH: word index of the delivery-record pool's used mask (bit r of word r / 32 = record r holds a message in flight)
     uint8_t* tlog;       // trace mode only
     __device__ Ctx(const KParams& p) : P(p) {}
 };
@@ -181,6 +184,7 @@ template <class K> __device__ __forceinline__ void rq_set(const Ctx& c, uint32_t
 }
 #define AMASK(i) SMEM[c.amask0 + ((i) << LWSH<K>(c))]
 #define OMASK(i) SMEM[c.omask0 + ((i) << LWSH<K>(c))]
+#define PMASK(i) SMEM[c.pmask0 + ((i) << LWSH<K>(c))]
 
 // ---- the lane's state block in global memory (K::G builds) -----------------------------------------------------------
 // Reached through a buffer resource like the heap spill region (k_mem.h).  A block belongs to one lane for the whole launch.

@@ -22,6 +22,46 @@ __device__ __forceinline__ void spill_store(const Ctx& c, uint32_t slot, const u
     buf_store128(c.spill, slot * c.P.total_lanes * 16u + c.spill_off, e);
 }
 
+// ---- Variant::NH: 8-byte entries {low deadline word, event word} in LDS and in the spill region ---------------------------------
+// The full deadline is clock + sign-extended (low word - low word of the clock): exact while every live deadline lies within 2^31 ns
+// of the clock (timer_add checks each push; the compact base-op layout below does the same with a host-side proof).  The comparisons
+// of push / pop run on these reconstructed 64-bit values, i.e. on the same numbers as the 16-byte layout.
+// Event word: EV_WAKE / EV_RESTART / EV_NOP as everywhere; EV_DELIVER: kind << 29 | socket gen << 21 | pool record << 6 | destination
+// socket — what the pop's prefetch needs (socket, record); tag, sender and payload wait in the record {full event word, payload}.
+constexpr uint64_t NH_HORIZON = (1ull << 31) - (1ull << 24);
+__device__ __forceinline__ uint4 nh_expand(const Lane& L, const uint2& e) {
+    const uint64_t d = L.clock + (uint64_t)(int64_t)(int32_t)(e.x - (uint32_t)L.clock);
+    return make_uint4((uint32_t)d, (uint32_t)(d >> 32), e.y, 0);
+}
+template <class K>
+__device__ __forceinline__ uint2 nh_load(const Ctx& c, uint32_t i) {
+    const uint32_t cap = c.P.heap_lds;
+    uint2 v;
+    if (!K::SPILL || i < cap) v = LDS64(c.heap0 + (i << LWSH<K>(c)));
+    else v = buf_load64(c.spill, (i - cap) * c.P.total_lanes * 8u + c.spill_off);
+    return v;
+}
+template <class K>
+__device__ __forceinline__ void nh_store(const Ctx& c, uint32_t i, const uint2& v) {
+    if (!K::SPILL || i < c.P.heap_lds) LDS64(c.heap0 + (i << LWSH<K>(c))) = v;
+    else buf_store64(c.spill, (i - c.P.heap_lds) * c.P.total_lanes * 8u + c.spill_off, v);
+}
+// the delivery-record pool: record r of this lane at [r][global lane], 8 bytes, behind the planes of the state buffer
+__device__ __forceinline__ uint32_t pool_addr(const Ctx& c, uint32_t r) { return __umul24(c.P.pool_off + r * 8u, c.P.total_lanes) + c.gs_lane * 8u; }
+template <class K>
+__device__ __forceinline__ uint32_t pool_alloc(const Ctx& c) {          // lowest free record, or ~0
+    uint32_t r = ~0u;
+    for (uint32_t w = 0; w < c.P.pool_n / 32 && r == ~0u; w++) {
+        const uint32_t m = PMASK(w);
+        if (~m) { const uint32_t b = (uint32_t)__builtin_ctz(~m); PMASK(w) = m | (1u << b); r = w * 32 + b; }
+    }
+    return r;
+}
+template <class K>
+__device__ __forceinline__ void pool_free(const Ctx& c, uint32_t r) { PMASK(r >> 5) &= ~(1u << (r & 31)); }
+// the event word of the root entry (its kind and operands steer timer_expire's prefetch)
+template <class K> __device__ __forceinline__ uint32_t heap_root_meta(const Ctx& c);
+
 // LDS entry i of this lane.  Extended builds: one 16-byte unit {deadline, meta, payload}.  Base-op builds: 12 bytes — the
 // deadline in an 8-byte array, meta in a 4-byte one, no payload word: their only events with a payload are datagram
 // deliveries, whose tag / sender / payload are fields of the sending instruction, so meta names that instruction instead
@@ -42,8 +82,13 @@ __device__ __forceinline__ void heap_lds_set(const Ctx& c, uint32_t i, const uin
 // i >= 1 is 8 bytes in LDS — the low 32 bits of its deadline and its meta word.  The host admits the layout only when every
 // live deadline lies within 2^31 ns of the clock (geometry.h: the workload's longest sleep), so clock + sign-extended
 // (low word - low word of the clock) IS the deadline: the comparisons below run on the same 64-bit values as everywhere else.
+template <class K> __device__ __forceinline__ uint32_t heap_root_meta(const Ctx& c) {
+    if (K::NH) return LDS64(c.heap0).y;
+    return heap_lds_get<K>(c, 0).z;
+}
 template <class K>
 __device__ __forceinline__ uint4 heap_get(const Ctx& c, const Lane& L, uint32_t i) {
+    if (K::NH) return nh_expand(L, nh_load<K>(c, i));
     if (K::CMP) {
         const uint2 e = LDS64(c.heap0 + ((i ? i - 1 : 0) << LWSH<K>(c)));
         const uint64_t d = L.clock + (uint64_t)(int64_t)(int32_t)(e.x - (uint32_t)L.clock);
@@ -64,6 +109,15 @@ __device__ __forceinline__ uint4 heap_get(const Ctx& c, const Lane& L, uint32_t 
 // access between them.
 template <class K>
 __device__ __forceinline__ void heap_get2(const Ctx& c, const Lane& L, uint32_t lo, uint32_t hi, uint4& vlo, uint4& vhi) {
+    if (K::NH) {
+        const uint32_t cap = c.P.heap_lds;
+        uint2 a, b;
+        if (K::SPILL && lo >= cap) {       // both spilled: the two loads back to back
+            a = buf_load64(c.spill, (lo - cap) * c.P.total_lanes * 8u + c.spill_off); b = buf_load64(c.spill, (hi - cap) * c.P.total_lanes * 8u + c.spill_off);
+        } else { a = LDS64(c.heap0 + (lo << LWSH<K>(c))); b = nh_load<K>(c, hi); }
+        vlo = nh_expand(L, a); vhi = nh_expand(L, b);
+        return;
+    }
     if (K::SPILL && !K::CMP) {
         const uint32_t cap = c.P.heap_lds;
         if (lo >= cap) { vlo = spill_load(c, lo - cap); vhi = spill_load(c, hi - cap); }
@@ -74,6 +128,7 @@ __device__ __forceinline__ void heap_get2(const Ctx& c, const Lane& L, uint32_t 
 }
 template <class K>
 __device__ __forceinline__ void heap_set(const Ctx& c, Lane& L, uint32_t i, const uint4& e) {
+    if (K::NH) { nh_store<K>(c, i, make_uint2(e.x, e.z)); return; }
     if (K::CMP) {
         if (i == 0) { L.top_dl = u64of(e.x, e.y); L.top_meta = e.z; }
         else LDS64(c.heap0 + ((i - 1) << LWSH<K>(c))) = make_uint2(e.x, e.z);
@@ -127,7 +182,20 @@ template <class K>
 __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val) {
     PROBE2(0);
     REG(10);
-    const bool room = L.heap_len < c.P.heap_lds + (K::SPILL ? c.P.heap_spill : 0u);
+    bool room = L.heap_len < c.P.heap_lds + (K::SPILL ? c.P.heap_spill : 0u);
+    if (K::NH) {
+        // the 8-byte entry keeps the low deadline word: a deadline 2^31 ns or more ahead of the clock cannot be told from an earlier one.
+        // A capacity verdict like a full heap: the re-run leaves the narrow layout (madsim_hip.cpp grow)
+        if (deadline - L.clock >= NH_HORIZON) room = false;
+        if (room && (meta >> EV_SHIFT) == EV_DELIVER) {      // tag, sender and payload wait in a pool record until the entry is the root
+            const uint32_t r = pool_alloc<K>(c);
+            if (r == ~0u) room = false;
+            else {
+                buf_store64(c.gs, pool_addr(c, r), make_uint2(meta, val));
+                meta = (meta & 0xffe0003fu) | (r << 6);
+            }
+        }
+    }
     if (room) {                                        // (no early return: see k_main.h on exit edges)
         uint4 e = make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, val);
         heap_sift_up<K>(c, L, L.heap_len, e);

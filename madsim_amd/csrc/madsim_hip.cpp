@@ -267,7 +267,7 @@ int madsim_hip_ctx::ensure_scratch(KParams& P, hipStream_t stream, bool work_que
         P.gstate = sc.gstate;
     }
     if (P.heap_spill) {
-        size_t need = (size_t)P.heap_spill * P.total_lanes * sizeof(uint4);
+        size_t need = (size_t)P.heap_spill * P.total_lanes * (P.narrow ? 8 : sizeof(uint4));
         if (need >= (1ull << 32)) return fail(MADSIM_E_LIMITS, "heap spill region exceeds 4 GiB: lower heap_spill_slots");
         if (need > sc.spill_bytes) {
             if (sc.spill) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(sc.spill); }
@@ -462,6 +462,8 @@ void grow(madsim_limits_t& L, const madsim_workload_t* w, bool any_ovf, bool any
         // the compact base-op layout admits no heap spill and at most eight task slots: a grown re-run must be free to leave
         // it (an explicit MADSIM_STATE_COMPACT would fail make_geometry with MADSIM_E_LIMITS and take the whole call with it)
         if ((L.state_mem & 0xffu) == MADSIM_STATE_COMPACT) L.state_mem = (L.state_mem & ~0xffu) | MADSIM_STATE_AUTO;
+        // ... and the 8-byte heap entries: a deadline beyond their 2^31 ns horizon is reported as a capacity verdict (k_timer.h timer_add)
+        L.state_mem &= ~MADSIM_STATE_NARROW_HEAP;
         L.heap_lds_slots = L.heap_lds_slots ? L.heap_lds_slots : 8;
         L.heap_spill_slots = dbl(L.heap_spill_slots, 32, 1u << 20);
         L.max_tasks = dbl(L.max_tasks, w->n_progs + 8, 254);

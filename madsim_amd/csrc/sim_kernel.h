@@ -26,6 +26,13 @@
    while every live deadline lies within 2^31 ns of the clock, which the host checks against the workload's longest sleep), the
    heap's root in registers, and the main task's state — polled a handful of times per run — in global memory. */
 #define MADSIM_FEAT_COMPACT 64
+/* Variant<..., FEAT, ...> only: global-state builds with NARROW timer-heap entries (KParams.narrow, madsim_limits_t.state_mem |
+   MADSIM_STATE_NARROW_HEAP): every heap entry — in LDS and in the spill region — is 8 bytes {low deadline word, meta} instead of 16
+   {deadline, meta, payload}; the 32-bit payload and the tag / sender fields of a datagram delivery (a fifth of the entries) live in a
+   per-seed record pool in global memory, written once by the push and read once when the entry is the root (k_timer.h).  Twice
+   the heap levels per LDS byte, half the bytes per spilled level.  Exact while every live deadline lies within 2^31 ns of the clock:
+   checked per push on the device (a violation is a capacity verdict: the re-run uses the wide entries). */
+#define MADSIM_FEAT_NARROW 128
 
 namespace madsim_k {
 
@@ -95,6 +102,10 @@ struct KParams {
     // MADSIM_STATE_DEDUP_TIMERS (global-state timeout-only build): dedup_n (a power of two, 0 = off) 16-byte buckets
     // {deadline lo, hi, wake meta, count} behind the task units, at logical byte dedup_off of the lane's block (k_timer.h dedup_note)
     uint32_t dedup_n, dedup_off;
+    // MADSIM_STATE_NARROW_HEAP (Variant::NH): 8-byte heap entries; pool_n (a multiple of 32) delivery records of 8 bytes {meta, payload}
+    // behind the planes of the lane's global block, at logical byte pool_off ([record][global lane]); free / used mask = pool_n / 32 LDS
+    // plane words from off_pmask
+    uint32_t narrow, pool_n, pool_off, off_pmask;
     uint64_t* prof;            // profiling builds (tools/experiment): per-phase cycle accumulators
     uint32_t* iter_est;        // one word per workload: the passes a wave of it runs, as the last finished wave counted them (0 = nothing
                                // finished yet); null = no progress-based priority (k_main.h wave_progress_priority)
@@ -130,7 +141,10 @@ struct KParams {
     X(false, true, 6, MADSIM_FEAT_CHAN, false, true)   \
     X(false, false, 6, MADSIM_FEAT_CHAN, false, true)  \
     X(false, true, 6, MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR, false, true) \
-    X(false, true, 6, MADSIM_FEAT_ALL, false, true)
+    X(false, true, 6, MADSIM_FEAT_ALL, false, true)    \
+    X(false, true, 6, MADSIM_FEAT_TIME | MADSIM_FEAT_NARROW, false, true) \
+    X(false, true, 5, MADSIM_FEAT_TIME | MADSIM_FEAT_NARROW, false, true) \
+    X(false, true, 6, (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR) | MADSIM_FEAT_NARROW, false, true)
 #endif
 
 // Which compiled specialisation of sim_kernel a parameter block runs on (one rule for the launcher and for
@@ -148,14 +162,15 @@ inline VariantSel select_variant(const KParams& P, bool trace) {
     // (general address resolution only exists in the full build: rare, and it would cost the lean builds ~5 %)
     const int cls = (feat & ~MADSIM_FEAT_TIME) == 0 ? MADSIM_FEAT_TIME : (feat & ~MADSIM_FEAT_CHAN) == 0 ? MADSIM_FEAT_CHAN : MADSIM_FEAT_ALL;
     if (P.gstate_mode) {                                                // task table + planes in global memory: full waves
-        if (cls == MADSIM_FEAT_ALL && !(feat & MADSIM_FEAT_ADDR)) return {0, 1, 6, MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR, 0, 1};   // plain addresses
+        const int nh = P.narrow ? MADSIM_FEAT_NARROW : 0;               // 8-byte heap entries (make_geometry sets it only where such a build exists)
+        if (cls == MADSIM_FEAT_ALL && !(feat & MADSIM_FEAT_ADDR)) return {0, 1, 6, (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR) | nh, 0, 1};   // plain addresses
         // (connection workloads keep short heaps — a handful of backoff / timeout timers — that sit in LDS whole: a build
         // without the spill path, like the base-op builds have)
         // 32 seed lanes per wave: the timeout-only build has the variant.  (Round 4 also tried 16 lanes there — the election loop fell
         // from 9.2 to 6.5 G steps/s — and 32 lanes on the every-class build — the topology: 4.10 G steps/s with 20 heap entries in LDS
         // against 4.30 on full waves with 8: neither is compiled, make_geometry refuses both.)
-        if (lw == 5 && cls == MADSIM_FEAT_TIME) return {0, 1, 5, cls, 0, 1};
-        return {0, cls == MADSIM_FEAT_CHAN ? spill : 1, 6, cls, 0, 1};
+        if (lw == 5 && cls == MADSIM_FEAT_TIME) return {0, 1, 5, cls | nh, 0, 1};
+        return {0, cls == MADSIM_FEAT_CHAN ? spill : 1, 6, cls | nh, 0, 1};
     }
     if (cls != MADSIM_FEAT_ALL) return {0, 1, -1, cls, 0, 0};
     if (lw == 6) return {0, spill, 6, MADSIM_FEAT_ALL, 0, 0};
@@ -193,6 +208,8 @@ inline const char* variant_mismatch(const KParams& P, const VariantSel& v, bool 
     if ((v.feat & MADSIM_FEAT_NOLOG) && (!P.no_log || trace)) return "a build without the determinism-log fold for a run that wants it";
     if (P.dedup_n && !(v.g && classes == MADSIM_FEAT_TIME)) return "re-registration counts on a build that does not carry them";
     if (P.dedup_n & (P.dedup_n - 1)) return "dedup_n must be a power of two";
+    if (((v.feat & MADSIM_FEAT_NARROW) != 0) != (P.narrow != 0)) return "narrow-heap build on a wide-entry layout (or the reverse)";
+    if (P.narrow && (!v.g || (P.pool_n & 31) || !P.pool_n)) return "narrow heap entries outside their conditions";
     if (P.waves_per_block != 1 && P.waves_per_block != 2 && P.waves_per_block != 4) return "a workgroup is 1, 2 or 4 waves";
     if (trace != (v.trace != 0)) return "trace build / trace launch mismatch";
     return nullptr;

@@ -72,7 +72,7 @@ def geometry_params(workload, limits=None):
     (MADSIM_FEAT_* mask), whether the state lives in global memory, and the de-duplication table (buckets, byte offset)."""
     names = ["gs_stride", "gs_planes", "max_tasks", "task_units", "n_socks", "sock_words", "mbox_regs", "mbox_msgs", "off_socks",
              "off_handles", "off_nodes", "off_clog", "off_pause", "off_greg", "off_conn", "gs_plane_words", "n_progs",
-             "features", "gstate_mode", "dedup_n", "dedup_off"]
+             "features", "gstate_mode", "dedup_n", "dedup_off", "narrow", "pool_n", "heap_lds", "heap_spill", "lds_per_seed"]
     kp = (C.c_uint32 * 32)()
     L = lib()
     L.madsim_emu_geometry_params.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Limits), C.POINTER(C.c_uint32)]

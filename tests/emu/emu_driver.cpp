@@ -233,7 +233,7 @@ extern "C" int madsim_emu_geometry_params(const madsim_workload_t* w, const mads
     const madsim_k::KParams& P = G.P;
     const uint32_t v[] = {P.gs_stride, P.gs_planes, P.max_tasks, P.task_units, P.n_socks, P.sock_words, P.mbox_regs, P.mbox_msgs, P.off_socks,
                           P.off_handles, P.off_nodes, P.off_clog, P.off_pause, P.off_greg, P.off_conn, P.gs_plane_words, P.n_progs,
-                          P.features, P.gstate_mode, P.dedup_n, P.dedup_off};
+                          P.features, P.gstate_mode, P.dedup_n, P.dedup_off, P.narrow, P.pool_n, P.heap_lds, P.heap_spill, G.lds_per_seed};
     for (size_t i = 0; i < sizeof v / sizeof *v; i++) out32[i] = v[i];
     return 0;
 }

@@ -30,6 +30,7 @@ def grow(lim, n_progs):
     g.lanes_per_wave = 0
     if (g.state_mem & 0xff) == A.STATE_COMPACT:
         g.state_mem = (g.state_mem & ~0xff) | A.STATE_AUTO
+    g.state_mem &= ~A.STATE_NARROW_HEAP
     g.heap_lds_slots = g.heap_lds_slots or 8
     g.heap_spill_slots = dbl(g.heap_spill_slots, 32, 1 << 20)
     g.max_tasks = dbl(g.max_tasks, n_progs + 8, 254)

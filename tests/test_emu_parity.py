@@ -537,7 +537,7 @@ def test_dedup_timers_switch_selects_the_timeout_only_global_build_and_nothing_e
     assert emu.geometry_params(raft, lim)["dedup_n"] == 0
     for w, base in ((W.kv_rpc(), W.kv_rpc_limits()), (W.streaming_topology(), W.streaming_topology_limits()), (W.pingpong(4, 8), None)):
         assert emu.geometry_params(w, LW.dedup_limits(base))["dedup_n"] == 0                  # other op classes / base ops: ignored
-    lim = A.Limits(); lim.state_mem = 0x200
+    lim = A.Limits(); lim.state_mem = 0x400
     with pytest.raises(RuntimeError, match="state_mem"):
         emu.geometry_params(raft, lim)
 
@@ -586,6 +586,136 @@ def test_dedup_timers_fuzz():
         seen |= set(o["verdict"].tolist())
         active += emu.geometry_params(w, lim)["dedup_n"] != 0
     assert {A.PASS, A.PANIC, A.DEADLOCK} <= seen and active > 200
+
+
+# ---- MADSIM_STATE_NARROW_HEAP: 8-byte timer-heap entries + delivery record pool (k_timer.h nh_*, round 6) -------------------------
+
+def _narrow(lim, heap_lds=None):
+    import copy
+    l2 = copy.copy(lim) if lim is not None else A.Limits()
+    l2.state_mem = (l2.state_mem if (l2.state_mem & 0xff) else A.STATE_GLOBAL) | A.STATE_NARROW_HEAP
+    if l2.lanes_per_wave != 32:
+        l2.lanes_per_wave = 0                   # (the fuzz limits ask for sub-wave occupancy of the LDS-resident builds)
+    if heap_lds is not None:
+        l2.heap_spill_slots, l2.heap_lds_slots = l2.heap_spill_slots + max(0, l2.heap_lds_slots - heap_lds), heap_lds
+    return l2
+
+
+def test_narrow_heap_switch_selects_builds_with_a_spill_region_and_a_short_horizon():
+    topo, raft = W.streaming_topology(), W.raft_election()
+    g = emu.geometry_params(topo, _narrow(W.streaming_topology_limits()))
+    assert g["narrow"] == 1 and g["pool_n"] == 64 and g["lds_per_seed"] < 200
+    wide = emu.geometry_params(topo, W.streaming_topology_limits())
+    assert wide["narrow"] == 0 and g["gs_stride"] == wide["gs_stride"] + 64 * 8            # the record pool behind the planes
+    g = emu.geometry_params(raft, _narrow(W.raft_election_limits(), 44))
+    assert g["narrow"] == 1 and g["heap_lds"] == 44 and g["dedup_n"] == 64                 # with the re-registration counts
+    # not for: LDS-resident state, connection-only workloads (no build), base ops, a workload that sleeps past 2^31 ns, buggify
+    lim = W.raft_election_limits(); lim.state_mem = A.STATE_LDS | A.STATE_NARROW_HEAP; lim.lanes_per_wave = 0
+    assert emu.geometry_params(raft, lim)["narrow"] == 0
+    assert emu.geometry_params(W.kv_rpc(), _narrow(W.kv_rpc_limits()))["narrow"] == 0
+    assert emu.geometry_params(W.pingpong(4, 8), _narrow(None))["narrow"] == 0
+    wl = W.WorkloadBuilder(); n = wl.create_node(); a = wl.addr(n, 1)
+    t = wl.task(n); t.bind(a); t.recv_from_timeout(a, 1, ms=5); t.sleep(secs=3)
+    m = wl.main(); m.spawn(t); m.join(t)
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 2, 30
+    assert emu.geometry_params(wl.build(), _narrow(lim))["narrow"] == 0
+
+
+def test_narrow_heap_topology_and_election_loop():
+    """configs[2] / configs[4] shapes on 8-byte heap entries: every result byte as the oracle has it, at several LDS quotas (the whole
+    heap spilled below the root's children .. the whole heap in LDS), static striding and work queue with several seeds per lane."""
+    for w, lim, quotas in ((W.streaming_topology(), W.streaming_topology_limits(), (3, 15, 31, 120)),
+                           (W.raft_election(), W.raft_election_limits(), (2, 22, 44))):
+        want, _ = oracle.run_batch(w, 0, 900, None, lim)
+        for q in quotas:
+            l2 = _narrow(lim, q)
+            assert emu.geometry_params(w, l2)["narrow"] == 1
+            for sched in (A.SCHED_STATIC, A.SCHED_QUEUE):
+                l2.sched = sched
+                e = emu.run_batch(w, 0, 900 if q == quotas[1] else 200, None, l2, num_cus=1)
+                assert (e == want[:len(e)]).all(), (q, sched)
+        _same(w, 77, 96, A.Config.default(packet_loss_rate=0.05), _narrow(lim, quotas[1]))
+
+
+def test_narrow_heap_horizon_is_a_capacity_verdict_and_the_rerun_is_wide():
+    """A deadline 2^31 ns or more ahead of the clock cannot live in an 8-byte entry: the host refuses the layout when the workload can
+    ask for one by itself (above); what only shows at run time — a channel back-off that doubled past 2 s under a long partition
+    (net/mod.rs:388-398) — is a capacity verdict on that seed, and the re-run (tests/parity.py grow = madsim_hip.cpp grow) leaves the
+    narrow layout and answers what the oracle answers."""
+    wl = W.WorkloadBuilder()
+    ns, nc, nx = wl.create_node(), wl.create_node(), wl.create_node()
+    asv, acl, ax = wl.addr(ns, 1), wl.addr(nc, 1), wl.addr(nx, 1)
+    srv = wl.task(ns); srv.bind(asv); srv.accept1(asv); srv.mark(); srv.chan_recv(); srv.assert_val(7); srv.assert_elapsed(">=", secs=5); srv.trace_instant()
+    cl = wl.task(nc); cl.bind(acl); cl.sleep(ms=10); cl.connect1(acl, asv); cl.assert_val(0); cl.sleep(ms=100); cl.chan_send(7); cl.sleep(secs=1)
+    idle = wl.task(nx); idle.bind(ax); idle.recv_from_timeout(ax, 1, ms=20); idle.rpc_call(ax, asv, 0, 1, timeout_ms=5)    # every op class: the build that has the variant
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.spawn(idle); m.sleep(ms=50); m.clog_link(nc, ns); m.sleep(ms=1900); m.sleep(ms=1900); m.sleep(ms=1900)
+    m.kill(nx); m.unclog_link(nc, ns); m.join(srv)
+    w = wl.build()
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 2, 30; lim.mbox_regs, lim.mbox_msgs = 4, 4
+    l2 = _narrow(lim)
+    assert emu.geometry_params(w, l2)["narrow"] == 1
+    o, _ = oracle.run_batch(w, 0, 64, None, l2)
+    e = emu.run_batch(w, 0, 64, None, l2)
+    assert (o["verdict"] == A.PASS).all() and (e["verdict"] == A.OVERFLOW).all()           # the 4 096 ms back-off
+    _strict(w, 0, o, e, None, l2, "narrow horizon")
+
+
+def test_narrow_heap_pool_exhaustion_is_a_capacity_verdict():
+    """More datagrams in flight than the record pool holds (32 with a small heap): MADSIM_OVERFLOW, re-run, compared."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+    rx = wl.task(n2); rx.bind(a2); rx.set(0, 40); top = rx.label(); rx.recv_from_timeout(a2, 1, ms=900); rx.trace_val(); rx.djnz(0, top)
+    senders = []
+    for k in range(10):
+        t = wl.task(n1); t.sleep(ms=5)
+        for _ in range(4):
+            t.send_to(a1, a2, 1, 0x100 + k)
+        senders.append(t)
+    b = wl.task(n1); b.bind(a1); b.sleep(secs=1)
+    m = wl.main(); m.spawn(b); m.spawn(rx); m.sleep(ms=3)
+    for t in senders:
+        m.spawn(t)
+    m.join(rx)
+    w = wl.build()
+    cfg = A.Config.default(lat_lo_ns=400_000_000, lat_hi_ns=800_000_000)
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 4, 60; lim.mbox_regs, lim.mbox_msgs = 4, 48; lim.max_tasks = 16
+    l2 = _narrow(lim)
+    g = emu.geometry_params(w, l2)
+    assert g["narrow"] == 1 and g["pool_n"] == 32
+    o, _ = oracle.run_batch(w, 0, 48, cfg, l2)
+    e = emu.run_batch(w, 0, 48, cfg, l2)
+    assert (e["verdict"] == A.OVERFLOW).any()
+    _strict(w, 0, o, e, cfg, l2, "narrow pool")
+
+
+def test_narrow_heap_fuzz():
+    """Random programs of the generators whose builds carry the variant — timeout-only (with and without the re-registration counts,
+    64 and 32 seed lanes per wave), latency switches, mixed / supervisor / RPC (every op class, plain addresses) — on 8-byte entries
+    with small LDS quotas, so pushes and pops walk the spilled levels; deliveries ride the record pool."""
+    seen, active = set(), 0
+    gens = [fuzz.random_timeout_workload, fuzz.random_latency_workload, fuzz.random_mixed_workload, fuzz.random_rpc_workload,
+            fuzz.random_timeout_workload, fuzz.random_workload]
+    for k in range(360):
+        gen = gens[k % len(gens)]
+        w, cfg, desc = gen(random.Random(66000 + k))[:3]
+        lim = fuzz.mixed_limits() if gen is fuzz.random_mixed_workload else fuzz.mailbox_limits()
+        lim = _narrow(lim, [1, 2, 3, 5, 8][k % 5])
+        if gen is fuzz.random_timeout_workload and k % 2:
+            lim.state_mem |= A.STATE_DEDUP_TIMERS
+            if k % 4 == 3:
+                lim.lanes_per_wave = 32
+        if k % 7 == 6:
+            lim.no_trace_hash = 1
+        try:
+            e = emu.run_batch(w, k * 7, 10, cfg, lim)
+        except RuntimeError:
+            continue
+        o, _ = oracle.run_batch(w, k * 7, 10, cfg, lim)
+        e = _strict(w, k * 7, o, e, cfg, lim, (k, gen.__name__, desc,))
+        seen |= set(o["verdict"].tolist())
+        active += emu.geometry_params(w, lim)["narrow"] != 0
+    assert {A.PASS, A.PANIC, A.DEADLOCK} <= seen and active > 150, active
 
 
 def test_fuzz_reply_without_receive():

@@ -943,6 +943,54 @@ def test_dedup_timers_ties_and_lane_reuse_gpu(hip):
     assert (ref[n - 2048:] == want).all()
 
 
+# ---- MADSIM_STATE_NARROW_HEAP: 8-byte timer-heap entries + delivery record pool (k_timer.h nh_*, round 6) -------------------------
+
+def _narrow(lim, heap_lds=None):
+    l2 = copy_limits(lim) if lim is not None else A.Limits()
+    l2.state_mem = (l2.state_mem if (l2.state_mem & 0xff) else A.STATE_GLOBAL) | A.STATE_NARROW_HEAP
+    if l2.lanes_per_wave != 32:
+        l2.lanes_per_wave = 0
+    if heap_lds is not None:
+        l2.heap_spill_slots, l2.heap_lds_slots = l2.heap_spill_slots + max(0, l2.heap_lds_slots - heap_lds), heap_lds
+    return l2
+
+
+@pytest.mark.parametrize("name,quotas", [("topo", (15, 31)), ("raft", (22, 44))])
+def test_narrow_heap_bench_workloads_gpu(hip, name, quotas):
+    """configs[2] / configs[4] shapes on 8-byte heap entries: the same 48 bytes per seed as on the 16-byte entries (65 536 seeds compared
+    with each other at two LDS quotas), contiguous and sampled seeds against the oracle, packet loss."""
+    w, lim, _ = W.bench_case(name)
+    wide, n_ovf = parity.run_resolved(hip, w, 0, 65536, None, lim)
+    for q in quotas:
+        l2 = _narrow(lim, q)
+        assert (hip.geometry(w, l2).variant >> 8) & 0x80, "the narrow-heap build was not selected"
+        got, _ = parity.run_resolved(hip, w, 0, 65536, None, l2)
+        assert (got == wide).all(), q
+    want, _ = oracle.run_batch(w, 50000, 768, None, lim)
+    assert (wide[50000:50768] == want).all()
+    _cmp(hip, w, 8_100_000, 1024, A.Config.default(packet_loss_rate=0.04), _narrow(hip.grow_limits(lim), quotas[0]))
+
+
+def test_narrow_heap_fuzz_gpu(hip):
+    """Random timeout-only / latency / mixed / RPC programs on 8-byte heap entries with small LDS quotas (pushes and pops walk the spilled
+    levels; deliveries ride the record pool; a deadline beyond the horizon or a full pool is a capacity verdict, re-run wide)."""
+    from tests import fuzz
+
+    def limits_of(base, quota):
+        def f():
+            f.k += 1
+            lim = _narrow(base(), quota[f.k % len(quota)])
+            if base is fuzz.mailbox_limits and f.k % 3 == 0:
+                lim.state_mem |= A.STATE_DEDUP_TIMERS
+            return lim
+        f.k = 0
+        return f
+    _fuzz_two_blocks(hip, fuzz.random_timeout_workload, 66100, 120, 60, 21, count=64, seed_mul=13, limits=limits_of(fuzz.mailbox_limits, (1, 2, 3, 5, 8)))
+    _fuzz_two_blocks(hip, fuzz.random_latency_workload, 66300, 100, 50, 22, count=64, seed_mul=5, limits=limits_of(fuzz.mailbox_limits, (1, 3, 8)))
+    _fuzz_two_blocks(hip, fuzz.random_mixed_workload, 66500, 100, 50, 23, count=64, seed_mul=3, limits=limits_of(fuzz.mixed_limits, (2, 4, 8)))
+    _fuzz_two_blocks(hip, fuzz.random_rpc_workload, 66700, 80, 40, 24, count=64, seed_mul=7, limits=limits_of(fuzz.mailbox_limits, (1, 2, 6)))
+
+
 def copy_limits(lim):
     import copy
     return copy.copy(lim)
