@@ -45,6 +45,9 @@ def lib():
         L.madsim_oracle_run_batch.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64, C.c_uint64,
                                               C.POINTER(A.Limits), C.c_void_p, C.POINTER(A.Summary),
                                               C.POINTER(OracleStats)]
+        L.madsim_oracle_run_batch_pure.restype = C.c_int
+        L.madsim_oracle_run_batch_pure.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64, C.c_uint64,
+                                                   C.POINTER(A.Limits), C.c_void_p, C.c_void_p]
         L.madsim_oracle_trace_seed.restype = C.c_int64
         L.madsim_oracle_trace_seed.argtypes = [C.POINTER(A.Workload), C.POINTER(A.Config), C.c_uint64,
                                                C.POINTER(A.Limits), C.c_void_p, C.c_uint64, C.POINTER(A.Result)]
@@ -75,6 +78,35 @@ def run_batch(workload, seed0, count, config=None, limits=None, want_stats=False
     if rc != 0:
         raise RuntimeError(f"oracle error {rc}")
     return (out, summ, st) if want_stats else (out, summ)
+
+
+ME_NAMES = {1: "live tasks > 254", 2: "registrations per socket > 255", 4: "registration word aliases a dead one", 8: "queued channel payloads > 15",
+            16: "connections waiting for accept1 > 8", 32: "servers per IPVS service > 6", 64: "formatted panic value > panic_dyn_max",
+            128: "port-0 entry bound beside its live Endpoint", 256: "op through a port-0 entry that lost its socket"}
+
+
+def run_batch_pure(workload, seed0, count, config=None, limits=None):
+    """The restatement with the workload model's ceilings OFF (madsim_oracle.c model_event): (results, events) — events[i] is the mask
+    of model events seed i met (ME_NAMES); 0 = the seed stayed inside the model and its result is the reference's."""
+    cfg = config or A.Config.default()
+    lim = limits or A.Limits()
+    out = np.zeros(count, dtype=A.RESULT_DTYPE)
+    ev = np.zeros(count, dtype=np.uint32)
+    rc = lib().madsim_oracle_run_batch_pure(workload.ref(), C.byref(cfg), seed0, count, C.byref(lim),
+                                            out.ctypes.data_as(C.c_void_p), ev.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"oracle error {rc}")
+    return out, ev
+
+
+def expected_of_pure(pure, events):
+    """What the device runner must report, DERIVED from the pure run: the pure result where the seed stayed inside the workload model,
+    the verdict MADSIM_UNSUPPORTED (every other field 0) where it left it."""
+    want = pure.copy()
+    out = events != 0
+    want[out] = np.zeros(1, dtype=A.RESULT_DTYPE)[0]
+    want["verdict"][out] = A.UNSUPPORTED
+    return want
 
 
 def trace_seed(workload, seed, config=None, limits=None, cap=1 << 20):

@@ -203,8 +203,29 @@ typedef struct {
     VEC(conn_t) conns;
     uint32_t panic; int main_slot;
     int unsupported;                                     /* the seed left the workload model (MADSIM_UNSUPPORTED): stop at once */
+    int model_limits;                                    /* 1: the workload MODEL's ceilings decide verdicts (what the device runner reports);
+                                                            0: the reference's unbounded containers all the way, ceilings only recorded */
+    uint32_t model_events;                               /* MADSIM_ORACLE_ME_* of this seed, recorded either way */
     madsim_oracle_stats_t st;
 } sim_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * The workload MODEL's ceilings — a layer on top of the restatement, not part of it.
+ * The reference's containers are unbounded (Vec mailboxes, Vec<Weak<TaskInfo>>, unbounded channels); the device runner's workload
+ * model is not: 254 live tasks, 255 registrations per socket, 8-bit receive-sequence / generation bytes in a registration word, 15
+ * queued channel payloads, 8 connections waiting for accept1, 6 servers per IPVS service — and the table FORMAT cannot say some things
+ * Rust can (two Endpoints under one port-0 entry, a formatted panic message beyond the values its patterns were evaluated for).
+ * Every such event is recorded in sim_t.model_events.  With model_limits on (the default: what every parity test compares the
+ * device with) the seed's verdict becomes MADSIM_UNSUPPORTED, decided at the same instruction as on the device; with it off
+ * (madsim_oracle_run_batch_pure) nothing in the run depends on a ceiling — the containers simply grow — and the caller derives the
+ * runner verdict from the event mask.  tests/test_oracle_model_limits.py: on every seed without an event the two runs are
+ * byte-identical.  Returns whether the caller should stop the run at once (only ever with the limits on).
+ * ---------------------------------------------------------------------------------------------- */
+static int model_event(sim_t* S, uint32_t bit) {
+    S->model_events |= bit;
+    if (S->model_limits) S->unsupported = 1;
+    return S->model_limits;
+}
 
 /* ------------------------------------------------------------------------------------------------
  * GlobalRng::with + determinism log                                   rand.rs:64-88, A.6
@@ -462,11 +483,11 @@ static void sock_drop_acceptq(sim_t* S, sock_t* k);
  * surviving, 256 instances of one slot).  Such a seed leaves the model (MADSIM_UNSUPPORTED; the device checks the same thing, k_poll.h
  * may_have_twin); it also enforces the model's ceiling of registrations per socket.  The run goes on: the verdict is the whole answer. */
 static void reg_model_limits(sim_t* S, const sock_t* k, const reg_t* r) {
-    if (k->registered.n >= MADSIM_MAX_MBOX_REGS) S->unsupported = 1;
+    if (k->registered.n >= MADSIM_MAX_MBOX_REGS) model_event(S, MADSIM_ORACLE_ME_REGS);
     for (size_t i = 0; i < k->registered.n; i++) {
         const reg_t* o = &k->registered.p[i];
         if (o->tag8 == r->tag8 && o->slot == r->slot && (o->gen & 0xff) == (r->gen & 0xff) && (o->rxseq & 0xff) == (r->rxseq & 0xff))
-            S->unsupported = 1;
+            model_event(S, MADSIM_ORACLE_ME_REG_ALIAS);
     }
 }
 /* An EndpointSocket lives while the node's socket table (`bound`) or its Endpoint (`ep_alive`) holds an Arc of it (in-flight
@@ -513,7 +534,7 @@ static int spawn_task_from(sim_t* S, unsigned prog, int record_handle, int via_h
     /* the reference's task set is unbounded; the workload model holds MADSIM_MAX_LIVE_TASKS live tasks (the device's 8-bit task slot, filled
      * lowest free slot first like this Vec): a 255th leaves the model at this spawn — MADSIM_UNSUPPORTED, reported when the run ends (this
      * restatement simply goes on; the verdict is the whole answer, include/madsim_hip.h) */
-    if (slot >= MADSIM_MAX_LIVE_TASKS) S->unsupported = 1;
+    if (slot >= MADSIM_MAX_LIVE_TASKS) model_event(S, MADSIM_ORACLE_ME_TASKS);
     if (slot == S->tasks.n) { task_t z; memset(&z, 0, sizeof z); vec_push(S->tasks, z); }
     task_t* t = &S->tasks.p[slot];
     uint16_t gen = (uint16_t)(t->gen + 1);
@@ -694,7 +715,8 @@ static int poll_task(sim_t* S, uint16_t slot) {
              * bound or has dropped; the table format can say it, and the device (whose port-0 entries of one (node, IP) share
              * their candidate sockets, geometry.h) could only answer with a stranger's mailbox: outside the model, on both sides
              * (`drop(ep)` of such a name stays a no-op: MS_OP_CLOSE below) */
-            if (in->a < w->n_socks && w->socks[in->a].port == 0 && !S->socks[in->a].bound) { S->unsupported = 1; return 1; }
+            /* (model limits off: the op goes on against this entry's own — dead — socket, which is what this restatement's tables say) */
+            if (in->a < w->n_socks && w->socks[in->a].port == 0 && !S->socks[in->a].bound && model_event(S, MADSIM_ORACLE_ME_EPH_STALE)) return 1;
             break;
         default: break;
         }
@@ -797,8 +819,8 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 if (in->a == MADSIM_IPVS_ADD_SERVER) {
                     /* servers is an unbounded Vec (net/ipvs.rs:66-72); the workload model holds six servers per service (include/madsim_hip.h,
                      * MADSIM_UNSUPPORTED): a seventh leaves the model at this call, on the device at the same one */
-                    if (S->ipvs_n[k] >= 6) { S->unsupported = 1; return 1; }
-                    S->ipvs_srv[k][S->ipvs_n[k]++] = (uint8_t)in->imm;      /* servers.push */
+                    if (S->ipvs_n[k] >= 6 && model_event(S, MADSIM_ORACLE_ME_IPVS)) return 1;
+                    if (S->ipvs_n[k] < 256) S->ipvs_srv[k][S->ipvs_n[k]++] = (uint8_t)in->imm;      /* servers.push (a Vec: this array is simply long) */
                 } else {                                    /* servers.retain(|addr| addr != server_addr): equal address strings */
                     const addr_t gone = addr_of_sock(S, in->imm);
                     uint32_t n = 0;
@@ -824,7 +846,9 @@ static int poll_task(sim_t* S, uint16_t slot) {
              * what the patterns were evaluated for */
             if (in->a & 1) {
                 const uint32_t v = S->greg[in->b & 3] + in->imm, dyn_max = w->panic_dyn_max ? w->panic_dyn_max : 254u;
-                if (v > dyn_max) { S->unsupported = 1; return 1; }      /* the workload declared the largest value it formats: beyond it, outside the model */
+                /* the workload declared the largest value it formats: beyond it the patterns' verdict on the message is not in the table —
+                 * outside the model; with the limits off the run goes on as for a message no pattern names */
+                if (v > dyn_max) { model_event(S, MADSIM_ORACLE_ME_PANIC_DYN); S->panic_code = MADSIM_PANIC_CODE_OTHER; return 1; }
                 S->panic_code = (uint8_t)v;
             } else S->panic_code = (uint8_t)in->imm;
             return 1;
@@ -880,7 +904,8 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 else if (port == 0) {                      /* :224-236 "resolve port if unspecified": the first free one */
                     /* a table entry names ONE Endpoint at a time: bound again while the Endpoint of its previous bind is alive, the
                      * two would coexist under one name — outside the workload model, and the verdict says so (MADSIM_UNSUPPORTED) */
-                    if (S->socks[in->a].bound && S->socks[in->a].ep_alive) { S->unsupported = 1; return 1; }
+                    /* (model limits off: the entry is bound again over its live Endpoint — this restatement's table has one socket per entry) */
+                    if (S->socks[in->a].bound && S->socks[in->a].ep_alive && model_event(S, MADSIM_ORACLE_ME_EPH_REBIND)) return 1;
                     addr_t cand = { a->kind, a->node, 0 };
                     for (uint32_t p = 1; p <= 65535 && port == 0; p++) { cand.port = (uint16_t)p; if (find_exact(S, t->node, cand) < 0) port = (uint16_t)p; }
                     if (port == 0) bind_err = MADSIM_VAL_ADDR_IN_USE;      /* "no available ephemeral port" */
@@ -988,7 +1013,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                     } else {
                         /* conn_tx is an unbounded channel (endpoint.rs:307); the workload model holds eight connections waiting for
                          * accept1 per Endpoint (include/madsim_hip.h): a ninth leaves the model here (MADSIM_UNSUPPORTED, both sides) */
-                        if (k->acceptq.n >= 8) { S->unsupported = 1; return 1; }
+                        if (k->acceptq.n >= 8 && model_event(S, MADSIM_ORACLE_ME_ACCEPTQ)) return 1;
                         vec_push(k->acceptq, (uint8_t)id);
                         if (k->acc_task >= 0) { int32_t a = k->acc_task; k->acc_task = -1; wake(S, (uint16_t)a, k->acc_gen); }
                     }
@@ -1021,7 +1046,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
             if (link < 0) return 1;                        /* `.ip.unwrap()` inside try_send (network.rs:309) */
             m.has_arrive = (uint8_t)link;
             if (!d->rx_alive) { t->val = MADSIM_VAL_RESET; t->pc++; break; }        /* ConnectionReset */
-            if (d->q.n >= MADSIM_MAX_CHAN_QUEUE) S->unsupported = 1;                /* the model's ceiling: a 16th queued payload */
+            if (d->q.n >= MADSIM_MAX_CHAN_QUEUE) model_event(S, MADSIM_ORACLE_ME_CHAN_QUEUE);   /* the model's ceiling: a 16th queued payload */
             vec_push(d->q, m);
             if (d->q.n > S->st.max_cq) S->st.max_cq = (uint32_t)d->q.n;
             if (d->rx_task >= 0) { int32_t r = d->rx_task; d->rx_task = -1; wake(S, (uint16_t)r, d->rx_gen); }
@@ -1392,9 +1417,9 @@ static int validate(const madsim_workload_t* w, const madsim_config_t* cfg) {
 
 static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim,
                     uint64_t seed, madsim_result_t* out, uint8_t* log, uint64_t log_cap,
-                    uint64_t* log_len, madsim_oracle_stats_t* stats) {
+                    uint64_t* log_len, madsim_oracle_stats_t* stats, int model_limits, uint32_t* events) {
     sim_t S; memset(&S, 0, sizeof S);
-    S.w = w; S.cfg = cfg;
+    S.w = w; S.cfg = cfg; S.model_limits = model_limits;
     S.handles = calloc(w->n_progs, sizeof *S.handles);
     S.nodes = calloc(w->n_nodes + 1, sizeof *S.nodes);
     S.socks = calloc(w->n_socks ? w->n_socks : 1, sizeof *S.socks);
@@ -1453,6 +1478,7 @@ static void run_one(const madsim_workload_t* w, const madsim_config_t* cfg, cons
     out->obs_hash = S.obs_hash;
     if (S.unsupported) { memset(out, 0, sizeof *out); out->verdict = MADSIM_UNSUPPORTED; }   /* the verdict is the whole answer */
     if (log_len) *log_len = S.log_len;
+    if (events) *events = S.model_events;
     if (stats) {
         if (S.st.max_heap > stats->max_heap) stats->max_heap = S.st.max_heap;
         if (S.st.max_ready > stats->max_ready) stats->max_ready = S.st.max_ready;
@@ -1483,7 +1509,7 @@ int madsim_oracle_run_batch(const madsim_workload_t* w, const madsim_config_t* c
     uint64_t first = UINT64_MAX, nfail = 0, tsteps = 0, tclock = 0;
     for (uint64_t i = 0; i < count; i++) {
         madsim_result_t r;
-        run_one(w, cfg, lim, seed0 + i, &r, NULL, 0, NULL, stats);
+        run_one(w, cfg, lim, seed0 + i, &r, NULL, 0, NULL, stats, 1, NULL);
         if (out) out[i] = r;
         if (r.verdict != MADSIM_PASS) { nfail++; if (seed0 + i < first) first = seed0 + i; }
         tsteps += r.steps; tclock += r.clock_ns;
@@ -1500,9 +1526,24 @@ int64_t madsim_oracle_trace_seed(const madsim_workload_t* w, const madsim_config
                                  madsim_result_t* out) {
     if (!cfg || validate(w, cfg)) return MADSIM_E_ARG;
     madsim_result_t r; uint64_t n = 0;
-    run_one(w, cfg, lim, seed, &r, log, cap, &n, NULL);
+    run_one(w, cfg, lim, seed, &r, log, cap, &n, NULL, 1, NULL);
     if (out) *out = r;
     return (int64_t)n;
+}
+
+/* The restatement WITHOUT the workload model's ceilings (see model_event): results as the reference's unbounded containers give
+ * them, plus per seed the mask of model events it met.  A seed with events[i] == 0 never touched a ceiling: its result is what
+ * madsim_oracle_run_batch reports; for any other seed the device runner's answer is the verdict MADSIM_UNSUPPORTED. */
+int madsim_oracle_run_batch_pure(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                                 const madsim_limits_t* lim, madsim_result_t* out, uint32_t* events) {
+    if (!cfg || validate(w, cfg)) return MADSIM_E_ARG;
+    for (uint64_t i = 0; i < count; i++) {
+        madsim_result_t r; uint32_t ev = 0;
+        run_one(w, cfg, lim, seed0 + i, &r, NULL, 0, NULL, NULL, 0, &ev);
+        if (out) out[i] = r;
+        if (events) events[i] = ev;
+    }
+    return 0;
 }
 
 /* [DEP rand 0.8 gen_range on u64] exposed for the known-answer tests. */
@@ -1530,7 +1571,7 @@ int64_t madsim_oracle_observe_seed(const madsim_workload_t* w, const madsim_conf
     if (!cfg || validate(w, cfg)) return MADSIM_E_ARG;
     madsim_result_t r;
     g_obs_buf = obs; g_obs_cap = cap; g_obs_len = 0;
-    run_one(w, cfg, lim, seed, &r, NULL, 0, NULL, NULL);
+    run_one(w, cfg, lim, seed, &r, NULL, 0, NULL, NULL, 1, NULL);
     g_obs_buf = NULL;
     if (out) *out = r;
     return (int64_t)g_obs_len;

@@ -22,9 +22,25 @@ typedef struct madsim_oracle_stats {
     uint32_t max_cq;     /* queued payloads per channel direction */
 } madsim_oracle_stats_t;
 
+/* Events in which a seed leaves the device runner's workload MODEL (not reference concepts; madsim_oracle.c model_event). */
+#define MADSIM_ORACLE_ME_TASKS      1u   /* a 255th live task                                                              */
+#define MADSIM_ORACLE_ME_REGS       2u   /* a 256th registration in one socket's mailbox                                   */
+#define MADSIM_ORACLE_ME_REG_ALIAS  4u   /* a new registration whose 8-bit rxseq / generation bytes equal a dead one's      */
+#define MADSIM_ORACLE_ME_CHAN_QUEUE 8u   /* a 16th payload queued in one channel direction                                 */
+#define MADSIM_ORACLE_ME_ACCEPTQ    16u  /* a ninth connection waiting in one Endpoint's accept1 queue                     */
+#define MADSIM_ORACLE_ME_IPVS       32u  /* a seventh server of one IPVS service                                           */
+#define MADSIM_ORACLE_ME_PANIC_DYN  64u  /* a formatted panic value above madsim_workload_t.panic_dyn_max                  */
+#define MADSIM_ORACLE_ME_EPH_REBIND 128u /* a port-0 entry bound again beside the live Endpoint of its previous bind       */
+#define MADSIM_ORACLE_ME_EPH_STALE  256u /* an op through a port-0 entry that no longer names the socket its last bind made */
+
 int madsim_oracle_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0,
                             uint64_t count, const madsim_limits_t* lim, madsim_result_t* out,
                             madsim_summary_t* summary, madsim_oracle_stats_t* stats);
+
+/* The same restatement with the model's ceilings switched OFF: unbounded containers throughout, `events[i]` = MADSIM_ORACLE_ME_*
+ * mask of seed i (0 = the seed never met a ceiling, and its result equals madsim_oracle_run_batch's byte for byte). */
+int madsim_oracle_run_batch_pure(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
+                                 const madsim_limits_t* lim, madsim_result_t* out, uint32_t* events);
 
 /* CPU twin of madsim_hip_run_batch with the identical signature. */
 int madsim_cpu_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0, uint64_t count,

@@ -915,6 +915,75 @@ CONFIGS["update_config_latency"] = dict(lat_table=((100_000_000, 101_000_000), (
 CONFIGS["update_config_latency_channel"] = dict(lat_table=((200_000_000, 201_000_000),))
 
 
+def model_ceiling_workloads():
+    """One workload per ceiling of the device runner's workload MODEL (include/madsim_hip.h MADSIM_UNSUPPORTED): (name, workload, limits,
+    the oracle's event bit — oracle/madsim_oracle.h MADSIM_ORACLE_ME_*).  The reference itself has none of these ceilings."""
+    from madsim_amd import _abi as A
+    ws = []
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    v = wl.virtual_addr(1, 80); a = wl.addr(n, 1)
+    svc = wl.ipvs_service(v, [a] * 6)
+    t = wl.task(n); t.sleep(ms=1); t.ipvs_add_server(svc, a)
+    m = wl.main(); m.spawn(t); m.join(t)
+    ws.append(("ipvs_seventh_server", wl.build(), None, 32))
+    wl = W.WorkloadBuilder()                               # nine clients dial one listener that never accepts
+    ns, nc = wl.create_node(), wl.create_node()
+    asv = wl.addr(ns, 1)
+    srv = wl.task(ns); srv.bind(asv); srv.sleep(secs=5); srv.done()
+    cls = []
+    for i in range(9):
+        ac = wl.addr(nc, 2 + i)
+        c = wl.task(nc); c.bind(ac); c.sleep(ms=10); c.connect1(ac, asv); c.sleep(secs=1); c.done(); cls.append(c)
+    m = wl.main(); m.spawn(srv)
+    for c in cls: m.spawn(c)
+    for c in cls: m.join(c)
+    lim = A.Limits(); lim.max_conns, lim.max_tasks = 16, 16
+    ws.append(("ninth_queued_connection", wl.build(), lim, 16))
+    wl = W.WorkloadBuilder()                               # panic!("{}", flag + 7) with flag = 300 > panic_dyn_max
+    n = wl.create_node(restart_on_panic_matching=("1",))
+    t = wl.task(n); t.flag_add(0, 300); t.panic_with_flag(0, 7)
+    m = wl.main(); m.spawn(t); m.join(t, expect_err=True)
+    ws.append(("panic_dyn_beyond_max", wl.build(), None, 64))
+    wl = W.WorkloadBuilder()                               # a spawn storm: 300 sleepers alive at once (the layout's 8-bit task slot holds 254)
+    n = wl.create_node()
+    sl = wl.task(n); sl.sleep(secs=1); sl.done()
+    m = wl.main(); m.set(0, 300); top = m.label(); m.spawn(sl); m.djnz(0, top); m.sleep(secs=2); m.done()
+    lim = A.Limits(); lim.max_tasks = 254
+    ws.append(("spawn_storm_255_tasks", wl.build(), lim, 1))
+    wl = W.WorkloadBuilder()                               # 3 x 86 timed-out receives on one socket: 255 dead registrations stay, the 256th has no room
+    n = wl.create_node()
+    a = wl.addr(n, 1)
+    ts = []
+    for i in range(3):
+        t = wl.task(n)
+        if i == 0: t.bind(a)
+        else: t.sleep(us=300 * i)
+        t.set(0, 86); top = t.label(); t.recv_from_timeout(a, 1, ms=1); t.djnz(0, top); t.sleep(secs=1); t.done(); ts.append(t)
+    m = wl.main()
+    for t in ts: m.spawn(t)
+    for t in ts: m.join(t)
+    lim = A.Limits(); lim.mbox_regs = 255
+    ws.append(("registrations_256", wl.build(), lim, 2))
+    wl = W.WorkloadBuilder()                               # ONE task, 129 timed-out receives: its 8-bit receive sequence number wraps onto a dead registration
+    n = wl.create_node()
+    a = wl.addr(n, 1)
+    t = wl.task(n); t.bind(a); t.set(0, 129); top = t.label(); t.recv_from_timeout(a, 1, ms=1); t.djnz(0, top); t.done()
+    m = wl.main(); m.spawn(t); m.join(t)
+    lim = A.Limits(); lim.mbox_regs = 255
+    ws.append(("rxseq_wraps_onto_dead_registration", wl.build(), lim, 4))
+    wl = W.WorkloadBuilder()                               # 16 payloads queued in one channel direction (the receiver never receives)
+    ns, nc = wl.create_node(), wl.create_node()
+    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
+    srv = wl.task(ns); srv.bind(asv); srv.accept1(asv); srv.sleep(secs=30); srv.done()
+    cl = wl.task(nc); cl.bind(acl); cl.sleep(ms=10); cl.connect1(acl, asv); cl.set(0, 16); top = cl.label(); cl.chan_send(7); cl.djnz(0, top); cl.done()
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.join(cl)
+    lim = A.Limits(); lim.chan_queue = 15
+    ws.append(("sixteenth_queued_payload", wl.build(), lim, 8))
+
+    return ws
+
+
 def config(name):
     """Non-default Config a workload is meant to run under (None = Config::default())."""
     return A.Config.default(**CONFIGS[name]) if name in CONFIGS else None

@@ -21,7 +21,11 @@ def _strict(w, seed0, o, e, cfg, lim, what):
     """Every fuzzed seed is a compared seed: a first-pass capacity verdict (MADSIM_OVERFLOW) is re-run with grown capacities
     (tests/parity.py) and what comes back is compared with the oracle like every other seed; none may stay a runner verdict."""
     lim = lim or A.Limits()
-    return parity.compare(e, o, lambda: parity.resolve_seed_by_seed(emu.run_batch, w, seed0, e, cfg, lim),
+    # the expectation is DERIVED from the oracle's run without the workload model's ceilings (parity.expected); the oracle's own
+    # model-limits layer — `o`, what the caller ran — must say the same on every fuzzed seed
+    want = parity.expected(w, seed0, len(e), cfg, lim)
+    assert (want == o).all(), (what, "oracle.run_batch differs from the verdicts derived from oracle.run_batch_pure")
+    return parity.compare(e, want, lambda: parity.resolve_seed_by_seed(emu.run_batch, w, seed0, e, cfg, lim),
                           sys._getframe(1).f_code.co_name, TALLY, what, lambda i: parity.beyond_ceiling(w, seed0 + i, cfg, lim))
 
 
@@ -204,67 +208,7 @@ def test_hard_model_limits_are_unsupported_on_both_sides():
     above the workload's declared panic_dyn_max, a 255th live task (task/mod.rs:607-654: an unbounded set), a 256th registration of one
     socket (endpoint.rs:288-300: an unbounded Vec), a 16th payload queued in one channel direction (net/mod.rs:417-421: an unbounded channel).  Kernel and oracle give MADSIM_UNSUPPORTED at the same instruction, every other
     field 0 — never MADSIM_OVERFLOW (a re-run could not resolve it), never a shorter list."""
-    ws = []
-    wl = W.WorkloadBuilder()
-    n = wl.create_node()
-    v = wl.virtual_addr(1, 80); a = wl.addr(n, 1)
-    svc = wl.ipvs_service(v, [a] * 6)
-    t = wl.task(n); t.sleep(ms=1); t.ipvs_add_server(svc, a)
-    m = wl.main(); m.spawn(t); m.join(t)
-    ws.append((wl.build(), None))
-    wl = W.WorkloadBuilder()                               # nine clients dial one listener that never accepts
-    ns, nc = wl.create_node(), wl.create_node()
-    asv = wl.addr(ns, 1)
-    srv = wl.task(ns); srv.bind(asv); srv.sleep(secs=5); srv.done()
-    cls = []
-    for i in range(9):
-        ac = wl.addr(nc, 2 + i)
-        c = wl.task(nc); c.bind(ac); c.sleep(ms=10); c.connect1(ac, asv); c.sleep(secs=1); c.done(); cls.append(c)
-    m = wl.main(); m.spawn(srv)
-    for c in cls: m.spawn(c)
-    for c in cls: m.join(c)
-    lim = A.Limits(); lim.max_conns, lim.max_tasks = 16, 16
-    ws.append((wl.build(), lim))
-    wl = W.WorkloadBuilder()                               # panic!("{}", flag + 7) with flag = 300 > panic_dyn_max
-    n = wl.create_node(restart_on_panic_matching=("1",))
-    t = wl.task(n); t.flag_add(0, 300); t.panic_with_flag(0, 7)
-    m = wl.main(); m.spawn(t); m.join(t, expect_err=True)
-    ws.append((wl.build(), None))
-    wl = W.WorkloadBuilder()                               # a spawn storm: 300 sleepers alive at once (the layout's 8-bit task slot holds 254)
-    n = wl.create_node()
-    sl = wl.task(n); sl.sleep(secs=1); sl.done()
-    m = wl.main(); m.set(0, 300); top = m.label(); m.spawn(sl); m.djnz(0, top); m.sleep(secs=2); m.done()
-    lim = A.Limits(); lim.max_tasks = 254
-    ws.append((wl.build(), lim))
-    wl = W.WorkloadBuilder()                               # 3 x 86 timed-out receives on one socket: 255 dead registrations stay, the 256th has no room
-    n = wl.create_node()
-    a = wl.addr(n, 1)
-    ts = []
-    for i in range(3):
-        t = wl.task(n)
-        if i == 0: t.bind(a)
-        else: t.sleep(us=300 * i)
-        t.set(0, 86); top = t.label(); t.recv_from_timeout(a, 1, ms=1); t.djnz(0, top); t.sleep(secs=1); t.done(); ts.append(t)
-    m = wl.main()
-    for t in ts: m.spawn(t)
-    for t in ts: m.join(t)
-    lim = A.Limits(); lim.mbox_regs = 255
-    ws.append((wl.build(), lim))
-    wl = W.WorkloadBuilder()                               # ONE task, 129 timed-out receives: its 8-bit receive sequence number wraps onto a dead registration
-    n = wl.create_node()
-    a = wl.addr(n, 1)
-    t = wl.task(n); t.bind(a); t.set(0, 129); top = t.label(); t.recv_from_timeout(a, 1, ms=1); t.djnz(0, top); t.done()
-    m = wl.main(); m.spawn(t); m.join(t)
-    lim = A.Limits(); lim.mbox_regs = 255
-    ws.append((wl.build(), lim))
-    wl = W.WorkloadBuilder()                               # 16 payloads queued in one channel direction (the receiver never receives)
-    ns, nc = wl.create_node(), wl.create_node()
-    asv, acl = wl.addr(ns, 1), wl.addr(nc, 1)
-    srv = wl.task(ns); srv.bind(asv); srv.accept1(asv); srv.sleep(secs=30); srv.done()
-    cl = wl.task(nc); cl.bind(acl); cl.sleep(ms=10); cl.connect1(acl, asv); cl.set(0, 16); top = cl.label(); cl.chan_send(7); cl.djnz(0, top); cl.done()
-    m = wl.main(); m.spawn(srv); m.spawn(cl); m.join(cl)
-    lim = A.Limits(); lim.chan_queue = 15
-    ws.append((wl.build(), lim))
+    ws = [(w, lim) for _, w, lim, _ in LW.model_ceiling_workloads()]
     for w, lim in ws:
         o, _ = oracle.run_batch(w, 0, 8, None, lim)
         assert (o["verdict"] == A.UNSUPPORTED).all() and not o["steps"].any() and not o["rng_calls"].any()
