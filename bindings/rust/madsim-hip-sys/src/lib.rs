@@ -257,11 +257,15 @@ pub const MADSIM_STATE_LDS: u32 = 1;
 pub const MADSIM_STATE_GLOBAL: u32 = 2;
 pub const MADSIM_STATE_COMPACT: u32 = 3;
 pub const MADSIM_STATE_DEDUP_TIMERS: u32 = 0x100;
+pub const MADSIM_STATE_NARROW_HEAP: u32 = 0x200;
 pub const MADSIM_SCHED_STATIC: u32 = 0;
 pub const MADSIM_SCHED_QUEUE: u32 = 1;
 pub const MADSIM_MAX_LIVE_TASKS: u32 = 254;
 pub const MADSIM_MAX_MBOX_REGS: u32 = 255;
 pub const MADSIM_MAX_CHAN_QUEUE: u32 = 15;
+pub const MADSIM_MAX_CONNS: u32 = 127;
+pub const MADSIM_MAX_MBOX_MSGS: u32 = 255;
+pub const MADSIM_MAX_SOCKET_GUARDS: u32 = 127;
 pub const MADSIM_E_ARG: c_int = -1;
 pub const MADSIM_E_HIP: c_int = -2;
 pub const MADSIM_E_NOINIT: c_int = -3;

@@ -373,16 +373,22 @@ enum madsim_verdict {
     MADSIM_DEADLOCK = 2,    /* "no events, all tasks will block forever" (task/mod.rs:250)           */
     MADSIM_TIME_LIMIT = 3,  /* "time limit exceeded" (task/mod.rs:253-258)                           */
     MADSIM_OVERFLOW = 4,    /* a device capacity in madsim_limits_t was exceeded: re-run the seed with
-                               larger limits (not a reference verdict; never silently wrong).  Only capacities a larger
-                               limit CAN lift give this verdict; the FIRST capacity or model event of a seed decides
+                               larger limits (not a reference verdict; never silently wrong).  Capacities a larger limit
+                               CAN lift give this verdict (at their ceilings the same events are MADSIM_UNSUPPORTED, below) — with
+                               two exceptions that stay capacity verdicts at the ceiling, where a re-run cannot help: the timer
+                               heap at 2^20 spilled entries, and the 128th message queued in one mailbox of a workload without
+                               extended ops (its header keeps 7 bits).  The FIRST capacity or model event of a seed decides
                                its runner verdict (what follows it in the same round runs on spoiled state)            */
     MADSIM_STEP_LIMIT = 5,  /* max_steps reached (not a reference verdict)                           */
     MADSIM_UNSUPPORTED = 6, /* the seed left the workload MODEL (not a reference verdict, and larger limits do not help:
                                never re-run): a port-0 table entry bound again while the Endpoint of its previous bind is
                                alive — an entry names one Endpoint at a time, `close` it first; a seventh server added to
                                an IPVS service; a ninth connection waiting in one Endpoint's accept1 queue; a 255th live task,
-                               a 256th registration of one socket, a 16th queued channel payload (the ceilings of max_tasks /
-                               mbox_regs / chan_queue: below them the verdict is MADSIM_OVERFLOW and a re-run lifts it); a new
+                               a 256th registration of one socket, a 16th queued channel payload, a 128th live connection, a 256th
+                               message queued in one mailbox (the ceilings of max_tasks / mbox_regs / chan_queue / max_conns /
+                               mbox_msgs: below them the verdict is MADSIM_OVERFLOW and a re-run lifts it); a 128th connection end
+                               holding one Endpoint's address; an ephemeral bind when every candidate port the table has for that
+                               (node, IP) is taken (addresses kept alive by connections of Endpoints long dropped); a new
                                receive whose registration word — 8 bits of the task's receive count, 8 of its slot's generation —
                                equals a dead registration's still in the list (256 receives of one task while a timed-out one
                                lingers, 256 instances of one slot); a formatted panic value above
@@ -394,6 +400,9 @@ enum madsim_verdict {
 #define MADSIM_MAX_LIVE_TASKS 254u   /* the ceiling of madsim_limits_t.max_tasks: a 255th live task is MADSIM_UNSUPPORTED (kernel and oracle) */
 #define MADSIM_MAX_MBOX_REGS 255u    /* the ceiling of mbox_regs: a 256th pending / dead registration of one socket is MADSIM_UNSUPPORTED          */
 #define MADSIM_MAX_CHAN_QUEUE 15u    /* the ceiling of chan_queue: a 16th payload queued in one channel direction is MADSIM_UNSUPPORTED             */
+#define MADSIM_MAX_CONNS 127u        /* the ceiling of max_conns: a 128th live connection is MADSIM_UNSUPPORTED                                     */
+#define MADSIM_MAX_MBOX_MSGS 255u    /* the ceiling of mbox_msgs (workloads with extended ops; 127 without): a 256th message queued in one mailbox is MADSIM_UNSUPPORTED */
+#define MADSIM_MAX_SOCKET_GUARDS 127u /* connection ends (Sender + Receiver pairs) that may hold one Endpoint's BindGuard at a time: the 128th is MADSIM_UNSUPPORTED */
 /* verdicts >= MADSIM_OVERFLOW are RUNNER verdicts: statements about this runner, never a test's failure */
 #define MADSIM_IS_RUNNER_VERDICT(v) ((v) >= MADSIM_OVERFLOW)
 

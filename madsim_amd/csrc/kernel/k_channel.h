@@ -130,7 +130,7 @@ __device__ __forceinline__ void sock_drop_acceptq(const Ctx& c, Lane& L, uint32_
 // (`h` = the socket's header word, when the caller holds it)
 template <class K>
 __device__ __forceinline__ void guard_acquire_with(const Ctx& c, Lane& L, uint32_t s, uint32_t h) {
-    if ((h >> 25) == 0x7fu) { OVF_SET(L, OVF_CAP); return; }            // (a seven-bit count: 127 connection ends per socket)
+    if ((h >> 25) == 0x7fu) { OVF_SET(L, OVF_MODEL); return; }          // (a seven-bit count: 127 connection ends per socket — no limit grows it: the model's edge, the oracle says the same)
     SW(c, s, 0) = h + (1u << 25);
 }
 template <class K>

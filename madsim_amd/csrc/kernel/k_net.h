@@ -163,7 +163,8 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
         } else if (K::LIFE && SW(c, s, 1) == ~0u) {              // (the owner word is read only when nobody took the message)
             SW(c, s, 0) = (h & ~(0xffu << 9)) | (nreg << 9);      // (dead registrations swept on the way stay swept)
         } else if (nmsg >= c.P.mbox_msgs) {
-            OVF_SET(L, OVF_CAP);
+            // (short of the ceiling of 255 queued messages a larger mbox_msgs lifts it; AT the ceiling the 256th leaves the model)
+            OVF_SET(L, c.P.mbox_msgs >= MADSIM_MAX_MBOX_MSGS ? OVF_MODEL : OVF_CAP);
         } else {
             if (rsp) tag = 0xfe;                           // nobody holds that rsp_tag any more: it can never be received
             SW(c, s, 2 + c.P.mbox_regs + 2 * nmsg) = tag | (from << 8);

@@ -339,7 +339,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                             while (id < P.max_conns && (CONNW(id, 0) & 1)) id++;
                             q = acceptq_load<K>(c, (uint32_t)ds);
                         }
-                        if (id >= P.max_conns) { OVF_SET(L, OVF_CAP); }
+                        // (below the ceiling of 127 connections a larger max_conns lifts it; AT the ceiling the 128th leaves the model: the oracle
+                        //  fills its connection Vec lowest free slot first like this and says MADSIM_UNSUPPORTED at the same connect1)
+                        if (id >= P.max_conns) { OVF_SET(L, P.max_conns >= MADSIM_MAX_CONNS ? OVF_MODEL : OVF_CAP); }
                         else {
                             CONNW(id, 0) = 1u | (a << 1) | (dial << 7) | (0xfu << 13);     // client Endpoint, the address it dialled
                             CONNW(id, 1) = 0; CONNW(id, 2) = 0;
@@ -354,10 +356,14 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                                 // (conn_tx is unbounded; this queue word holds MADSIM_ACCEPTQ ids.  A ninth connection waiting for accept1 is
                                 //  outside the model — no limit of madsim_limits_t grows the word — so it is MADSIM_UNSUPPORTED, decided at the
                                 //  same instruction by the oracle, not a capacity verdict that a re-run could never resolve)
-                                if (n >= MADSIM_ACCEPTQ) { OVF_SET(L, OVF_MODEL); n = MADSIM_ACCEPTQ - 1; }
-                                acceptq_store<K>(c, (uint32_t)ds, (q & ~0xfull) | (n + 1) | ((uint64_t)id << (4 + 7 * n)));
-                                uint32_t acc = Hoist<K>::CHAN ? acc_p : (uint32_t)SW(c, ds, base + 1);
-                                if (acc & 1) { SW(c, ds, base + 1) = 0; wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9); }
+                                // (the queue word stays as it is: the seed's state is spoiled from here on, but never out of bounds —
+                                //  OR-ing a ninth id over slot 7 made ids up to 127 that a later accept1 would index the connection table with)
+                                if (n >= MADSIM_ACCEPTQ) OVF_SET(L, OVF_MODEL);
+                                else {
+                                    acceptq_store<K>(c, (uint32_t)ds, (q & ~0xfull) | (n + 1) | ((uint64_t)id << (4 + 7 * n)));
+                                    uint32_t acc = Hoist<K>::CHAN ? acc_p : (uint32_t)SW(c, ds, base + 1);
+                                    if (acc & 1) { SW(c, ds, base + 1) = 0; wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9); }
+                                }
                             }
                         }
                     }
@@ -379,7 +385,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         if (handle_names_its_socket<K>(c, a) && SW(c, base + ((uint32_t)SW(c, a, 0) >> 25), 1) != ~0u) OVF_SET(L, OVF_MODEL);
                         uint32_t p = 0;
                         while (p < nk && find_exact<K>(c, node, (sw & 0x7fffu) | ((p + 1) << 16)) >= 0) p++;
-                        if (p == nk) { OVF_SET(L, OVF_CAP); p = 0; }    // (beside its own live Endpoint the handle has no candidate left by construction)
+                        // every candidate port of this (node, IP) is held — by addresses that outlived two Endpoints of one entry through their
+                        // connections, say: no madsim_limits_t field adds table entries, so this is the model's edge, not a capacity (the oracle,
+                        // which searches ports 1 .. 65 535, reports the same verdict when the port it finds lies beyond the candidates)
+                        if (p == nk) { OVF_SET(L, OVF_MODEL); p = 0; }
                         SW(c, a, 0) = (p << 25) | (1u << 24) | (((((uint32_t)SW(c, base + p, 0) >> 1) + 1) & 0xff) << 16);
                         a = base + p;
                     }

@@ -82,7 +82,9 @@ def run_batch(workload, seed0, count, config=None, limits=None, want_stats=False
 
 ME_NAMES = {1: "live tasks > 254", 2: "registrations per socket > 255", 4: "registration word aliases a dead one", 8: "queued channel payloads > 15",
             16: "connections waiting for accept1 > 8", 32: "servers per IPVS service > 6", 64: "formatted panic value > panic_dyn_max",
-            128: "port-0 entry bound beside its live Endpoint", 256: "op through a port-0 entry that lost its socket"}
+            128: "port-0 entry bound beside its live Endpoint", 256: "op through a port-0 entry that lost its socket",
+            512: "connection ends per Endpoint guard > 127", 1024: "ephemeral port beyond the table's candidates", 2048: "live connections > 127",
+            4096: "queued messages per mailbox > 255"}
 
 
 def run_batch_pure(workload, seed0, count, config=None, limits=None):

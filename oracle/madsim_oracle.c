@@ -468,6 +468,7 @@ static void mailbox_deliver(sim_t* S, event_t* e) {
     if (!k->ep_alive) return;     /* the Endpoint object is gone (the address is held by its connections, or its node was killed before the
                                      guard dropped: net/mod.rs:483-493): a receive registered by another holder was served above; with
                                      none, nobody is left to read what would be queued here */
+    if (k->msgs.n >= MADSIM_MAX_MBOX_MSGS) model_event(S, MADSIM_ORACLE_ME_MSGS);     /* the model's ceiling: a 256th queued message */
     msg_t m = { e->tag, e->from, e->val, e->aux };
     vec_push(k->msgs, m);
     if (k->msgs.n > S->st.max_msgs) S->st.max_msgs = (uint32_t)k->msgs.n;
@@ -903,12 +904,25 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 if (a->node != t->node) bind_err = MADSIM_VAL_ADDR_NOT_AVAILABLE;
                 else if (port == 0) {                      /* :224-236 "resolve port if unspecified": the first free one */
                     /* a table entry names ONE Endpoint at a time: bound again while the Endpoint of its previous bind is alive, the
-                     * two would coexist under one name — outside the workload model, and the verdict says so (MADSIM_UNSUPPORTED) */
-                    /* (model limits off: the entry is bound again over its live Endpoint — this restatement's table has one socket per entry) */
+                     * two would coexist under one name — outside the workload model, and the verdict says so (MADSIM_UNSUPPORTED)
+                     * (model limits off: the entry is bound again over its live Endpoint — this restatement's table has one socket per entry).
+                     * KNOWN GAP: an entry re-bound while its previous address is only kept in the table by connections made
+                     * from it (endpoint.rs:181-190) takes the next port, as in the reference — but this table, one socket per entry, then
+                     * forgets the older address; a THIRD bind, or a connect1 to the forgotten address, would differ from the reference.
+                     * The device keeps both addresses (geometry.h device_socks: two candidates per entry) and reports MADSIM_UNSUPPORTED when a
+                     * third is needed; the event below (a port beyond the candidates) catches the cases this table can see. */
                     if (S->socks[in->a].bound && S->socks[in->a].ep_alive && model_event(S, MADSIM_ORACLE_ME_EPH_REBIND)) return 1;
                     addr_t cand = { a->kind, a->node, 0 };
                     for (uint32_t p = 1; p <= 65535 && port == 0; p++) { cand.port = (uint16_t)p; if (find_exact(S, t->node, cand) < 0) port = (uint16_t)p; }
                     if (port == 0) bind_err = MADSIM_VAL_ADDR_IN_USE;      /* "no available ephemeral port" */
+                    else {
+                        /* the workload model holds as many candidate ports per (node, IP) as the table has entries for it — twice that when
+                         * connections can keep an address alive past its Endpoint (geometry.h device_socks): a port beyond them is outside it */
+                        uint32_t cand_ports = 0; int conns = 0;
+                        for (uint32_t j = 0; j < w->n_socks; j++) cand_ports += w->socks[j].node == a->node && w->socks[j].kind == a->kind;
+                        for (uint32_t j = 0; j < w->n_insns; j++) conns |= w->insns[j].op == MS_OP_CONNECT;
+                        if (port > cand_ports * (conns ? 2u : 1u)) model_event(S, MADSIM_ORACLE_ME_EPH_PORTS);
+                    }
                 } else {
                     addr_t want = { a->kind, a->node, port };
                     if (find_exact(S, t->node, want) >= 0) bind_err = MADSIM_VAL_ADDR_IN_USE;   /* :238-246 */
@@ -996,6 +1010,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                 } else {
                     size_t id = 0;
                     while (id < S->conns.n && S->conns.p[id].alive) id++;
+                    if (id >= MADSIM_MAX_CONNS) model_event(S, MADSIM_ORACLE_ME_CONNS);     /* the model's ceiling: a 128th live connection */
                     if (id == S->conns.n) { conn_t z; memset(&z, 0, sizeof z); vec_push(S->conns, z); }
                     conn_t* c = &S->conns.p[id];
                     c->alive = 1; c->c_node = w->socks[in->a].node; c->s_node = w->socks[ds].node;
@@ -1003,6 +1018,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
                     c->src_kind = lb ? MADSIM_ADDR_LOOPBACK : MADSIM_ADDR_IP; c->src_port = S->socks[in->a].port;   /* src = (ip, port) :355 */
                     for (int d = 0; d < 2; d++) { c->d[d].tx_alive = c->d[d].rx_alive = 1; c->d[d].q.n = 0; c->d[d].rx_task = -1; }
                     c->guard_sock[0] = in->a; c->guard_sock[1] = -1;
+                    if (S->socks[in->a].guards >= MADSIM_MAX_SOCKET_GUARDS) model_event(S, MADSIM_ORACLE_ME_GUARDS);
                     S->socks[in->a].guards++;              /* Sender { _guard: self.guard.clone(), .. }, Receiver { .. } (endpoint.rs:181-190) */
                     t->conn = (int8_t)id; t->side = 0; t->val = 0;
                     if (S->conns.n > S->st.max_conns) S->st.max_conns = (uint32_t)S->conns.n;
@@ -1033,6 +1049,7 @@ static int poll_task(sim_t* S, uint16_t slot) {
             memmove(k->acceptq.p, k->acceptq.p + 1, --k->acceptq.n);
             if (t->conn >= 0) { int id = t->conn; t->conn = -1; conn_drop_handles(S, id, t->side, t->killed); t = &S->tasks.p[slot]; k = &S->socks[in->a]; }
             t->conn = taken;
+            if (k->guards >= MADSIM_MAX_SOCKET_GUARDS) model_event(S, MADSIM_ORACLE_ME_GUARDS);
             S->conns.p[t->conn].guard_sock[1] = in->a; k->guards++;   /* Sender / Receiver { _guard: self.guard.clone() } (endpoint.rs:203-210) */
             t->side = 1; t->sub = 0; t->pc++;
             break;

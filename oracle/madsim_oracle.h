@@ -32,6 +32,10 @@ typedef struct madsim_oracle_stats {
 #define MADSIM_ORACLE_ME_PANIC_DYN  64u  /* a formatted panic value above madsim_workload_t.panic_dyn_max                  */
 #define MADSIM_ORACLE_ME_EPH_REBIND 128u /* a port-0 entry bound again beside the live Endpoint of its previous bind       */
 #define MADSIM_ORACLE_ME_EPH_STALE  256u /* an op through a port-0 entry that no longer names the socket its last bind made */
+#define MADSIM_ORACLE_ME_GUARDS     512u /* a 128th connection end holding one Endpoint's BindGuard                          */
+#define MADSIM_ORACLE_ME_EPH_PORTS  1024u /* an ephemeral bind whose port lies beyond the table's candidate ports of that (node, IP) */
+#define MADSIM_ORACLE_ME_CONNS      2048u /* a 128th live connection                                                        */
+#define MADSIM_ORACLE_ME_MSGS       4096u /* a 256th message queued in one mailbox                                          */
 
 int madsim_oracle_run_batch(const madsim_workload_t* w, const madsim_config_t* cfg, uint64_t seed0,
                             uint64_t count, const madsim_limits_t* lim, madsim_result_t* out,

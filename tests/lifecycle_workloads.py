@@ -981,6 +981,14 @@ def model_ceiling_workloads():
     lim = A.Limits(); lim.chan_queue = 15
     ws.append(("sixteenth_queued_payload", wl.build(), lim, 8))
 
+    wl = W.WorkloadBuilder()                               # 256 datagrams for a bound socket nobody receives from: the 256th has no room in the model's mailbox
+    n1, n2 = wl.create_node(), wl.create_node()
+    a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+    rx = wl.task(n2); rx.bind(a2); rx.recv_from_timeout(a2, 9, ms=1); rx.sleep(secs=30); rx.done()      # (an extended op: mailboxes of 255)
+    tx = wl.task(n1); tx.bind(a1); tx.sleep(ms=5); tx.set(0, 256); top = tx.label(); tx.send_to(a1, a2, 1, 9); tx.djnz(0, top); tx.sleep(ms=50); tx.done()
+    m = wl.main(); m.spawn(rx); m.spawn(tx); m.join(tx)
+    lim = A.Limits(); lim.mbox_msgs = 255
+    ws.append(("queued_messages_256", wl.build(), lim, 4096))
     return ws
 
 

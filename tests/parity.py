@@ -102,7 +102,7 @@ def resolve_seed_by_seed(run, w, seed0, got, cfg, lim, max_rounds=8):
 
 
 # The absolute ceilings of the device layout (include/madsim_hip.h): the largest value `grow()` can reach per capacity.
-CEILINGS = dict(max_msgs=255, max_conns=127, max_heap=8 + (1 << 20))    # (a 255th live task, a 256th registration, a 16th queued payload: MADSIM_UNSUPPORTED on both sides, compared)
+CEILINGS = dict(max_heap=8 + (1 << 20))    # (live tasks, registrations, queued messages, connections, queued payloads at THEIR ceilings are MADSIM_UNSUPPORTED on both sides: compared)
 
 
 def beyond_ceiling(w, seed, cfg, lim):
