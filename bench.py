@@ -77,11 +77,13 @@ def parse_args(argv=None):
 PMC_ISSUE = "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"
 
 
-def measure_counters(argv):
-    """Per-launch hardware counters of sim_kernel for this same command, from three short rocprofv3 --pmc passes
-    (--kernel-trace only, never combined with other traces): FETCH_SIZE and WRITE_SIZE (separate passes,
-    MI355X_MICROARCH.md §PMC slots) give the HBM bytes; one pass of SQ counters gives the instruction counts and the
-    VALU lane utilisation the issue roofline needs.  Returns (dict, None) or (None, reason)."""
+def measure_counters(argv, passes=("TRACE", "FETCH_SIZE", "WRITE_SIZE", None), extra_args=()):
+    """Per-launch hardware counters of sim_kernel for this same command, from short rocprofv3 passes (--kernel-trace only, never
+    combined with other traces): "TRACE" = no counters, the kernel trace alone — the launches overlap as in the timed region, and
+    the average sim_kernel duration of that pass (`launch_ms_rocprof`) is what `rocprofv3 --kernel-trace --stats` reports for the
+    same command; FETCH_SIZE and WRITE_SIZE (separate --pmc passes, MI355X_MICROARCH.md §PMC slots) give the HBM bytes; None = the
+    pass of SQ counters (instruction counts, VALU lane utilisation).  `extra_args` are appended to the child command (another
+    --workload).  Returns (dict, None) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -89,19 +91,37 @@ def measure_counters(argv):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
-    child = [a for a in argv if a != "--measure-traffic"] + ["--no-measure-traffic"]
-    for flag, val in (("--steps", "6"), ("--warmup", "2")):
-        if flag in child:
-            child[child.index(flag) + 1] = val
-        else:
-            child += [flag, val]
-    child += ["--no-cpu-baseline", "--no-verify", "--no-first-fail", "--no-extras"]
+    base = [a for a in argv if a != "--measure-traffic"] + ["--no-measure-traffic"]
+    for flag in ("--steps", "--warmup", "--workload"):
+        if flag in base:
+            k = base.index(flag)
+            del base[k:k + 2]
+    base += ["--no-cpu-baseline", "--no-verify", "--no-first-fail", "--no-extras", *extra_args]
     vals = {}
     tmp = tempfile.mkdtemp(prefix="madsim_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for i, ctrs in enumerate(("FETCH_SIZE", "WRITE_SIZE", PMC_ISSUE)):
+        for i, ctrs in enumerate(passes):
             d = os.path.join(tmp, f"pass{i}")
+            if ctrs == "TRACE":
+                # the kernel trace alone: launches overlap as in the timed region (a --pmc pass serialises them)
+                cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                       sys.executable, os.path.join(ROOT, "bench.py")] + base + ["--steps", "40", "--warmup", "10", "--repeats", "1"]
+                try:
+                    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                except (OSError, subprocess.TimeoutExpired) as e:
+                    return None, f"rocprofv3 kernel-trace pass failed: {e}"
+                durs = []
+                for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if "sim_kernel" in row.get("Kernel_Name", ""):
+                            durs.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+                if durs:
+                    vals["launch_ms_rocprof"] = sum(durs) / len(durs) * 1e-6
+                    vals["launches_traced"] = len(durs)
+                continue
+            ctrs = ctrs or PMC_ISSUE
+            child = base + ["--steps", "6", "--warmup", "2"]
             cmd = [exe, "--kernel-trace", "--pmc", *ctrs.split(), "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.join(ROOT, "bench.py")] + child
             try:
@@ -115,13 +135,14 @@ def measure_counters(argv):
                         xs.setdefault(row.get("Counter_Name"), []).append(float(row["Counter_Value"]))
             for c in ctrs.split():
                 if c not in xs:
-                    if i < 2:
+                    if c in ("FETCH_SIZE", "WRITE_SIZE"):
                         return None, f"no {c} rows for sim_kernel"
                     continue                      # an SQ counter this rocprofv3 does not know: the issue roofline degrades, traffic stays
                 vals[c] = sum(xs[c]) / len(xs[c])
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    vals["source"] = ("live: rocprofv3 --kernel-trace --pmc, three passes of this command (6 steps), mean per sim_kernel dispatch")
+    vals["source"] = ("live: rocprofv3 --kernel-trace [--pmc ..], one pass per counter group of this command (6 steps; the trace-only pass 40), "
+                      "mean per sim_kernel dispatch")
     return vals, None
 
 
@@ -600,6 +621,7 @@ def main():
     # extra.workloads: the configs[2] / [3] / [4]-shaped workloads and the timer storm, two timed steps per stream each on the same streams,
     # every line with sampled seeds of its timed batches checked against the oracle
     extras = None
+    ceil_all = issue_ceiling() if world == 1 and rank == 0 else None      # (tools/ubench_issue --quick: issue ceilings + the attainable HBM copy rate)
     if not args.no_extras and world == 1 and headline and not args.loss:
         import oracle
         extras = {}
@@ -651,15 +673,35 @@ def main():
                     xver += 1
             xg = runtime.geometry(xw, xlim)
             xalgo = xsteps / xs * ALGO_BYTES_PER_STEP + count * IO_BYTES_PER_SEED
+            # what these kernels really move — FETCH_SIZE x 2 + WRITE_SIZE per launch and the launches' own duration from
+            # live rocprofv3 passes of `bench.py --workload <name>` — against the copy rate this chip sustains (tools/ubench_issue)
+            xpmc, xpmc_note = None, "not measured"
+            if args.measure_traffic is not False:
+                xpmc, xpmc_note = measure_counters(sys.argv[1:], passes=("TRACE", "FETCH_SIZE", "WRITE_SIZE"), extra_args=["--workload", name])
+            xtraffic = (2.0 * xpmc["FETCH_SIZE"] + xpmc["WRITE_SIZE"]) * 1024.0 if xpmc else None
+            xlaunch_ms = (xpmc or {}).get("launch_ms_rocprof") or xk_ms
+            copy_peak = (ceil_all or {}).get("hbm_copy_gbps")
             extras[name] = {"workload": xname, "seeds_per_step": nsub * count, "steps": xtimed, "sub_launches_per_step": nsub,
                             "seeds_per_sub_launch": count, "warmup_sub_launches": xwu, "concurrent_batches": xn,
                             "ms_per_step": xdt / xtimed * 1e3, "ms_per_sub_launch": xdt / xs * 1e3, "kernel_ms_per_sub_launch": xk_ms,
                             "steps_per_sec": xsteps / xdt, "seeds_per_sec": xs * count / xdt, "sim_seconds_per_sec": xclock / 1e9 / xdt,
                             "failed_seeds": xfail, "verified_seeds": xver, "kernel": runtime.variant_name(xg),
                             "lds_bytes_per_seed": xg.lds_bytes_per_seed, "global_bytes_per_seed": xg.global_bytes_per_seed,
-                            "frac": xalgo / (xk_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "frac": xalgo / (xlaunch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                             "chip_frac": xalgo * xs / xdt / 1e9 / HBM_PEAK_GBPS,
-                            "frac_note": "nominal SURVEY 8d yardstick (120 B per executor step / 8 TB/s): frac per launch, chip_frac over wall time"}
+                            "algorithmic_bytes_per_launch": xalgo, "launch_ms": xlaunch_ms,
+                            "launch_ms_source": "rocprofv3 --kernel-trace, live" if (xpmc or {}).get("launch_ms_rocprof") else "HIP events",
+                            "traffic_bytes_per_launch": xtraffic,
+                            "traffic_over_algorithmic": (xtraffic / xalgo) if xtraffic else None,
+                            "measured_gbps": (xtraffic / (xlaunch_ms * 1e-3) / 1e9) if xtraffic else None,
+                            "measured_chip_gbps": (xtraffic * xs / xdt / 1e9) if xtraffic else None,
+                            "copy_peak_gbps": copy_peak,
+                            "measured_over_copy_peak": (xtraffic * xs / xdt / 1e9 / copy_peak) if xtraffic and copy_peak else None,
+                            "traffic_detail": ({"FETCH_SIZE_KB": xpmc["FETCH_SIZE"], "WRITE_SIZE_KB": xpmc["WRITE_SIZE"], "source": xpmc["source"]} if xpmc else xpmc_note),
+                            "frac_note": "frac = algorithmic bytes per launch (120 B per executor step + 56 B per seed, SURVEY 8d) / launch_ms / 8 TB/s; "
+                                         "chip_frac = the same bytes of all overlapping launches / wall time; measured_gbps = (FETCH_SIZE x 2 + WRITE_SIZE) "
+                                         "per launch / launch_ms (SURVEY 8d iii: the HBM-bound figure), measured_chip_gbps over wall time, against "
+                                         "copy_peak_gbps (the float4 copy rate tools/ubench_issue measures on this GPU)"}
 
     if rank == 0:
         seeds_total = total * args.steps
@@ -703,52 +745,67 @@ def main():
                                "rate — those bytes never reach HBM on this LDS-resident path (measured_hbm_gbps is the real HBM rate from "
                                "FETCH/WRITE_SIZE).  chip_* = all overlapping launches / wall time; chip_frac > 1 means exactly that: "
                                "HBM is not a bound for this kernel"}
-        ceil = issue_ceiling() if world == 1 else None
-        # `bound` keeps round 3's definition (valu-issue against the measured ceiling of the kernel's own instruction mix); the earlier
-        # definitions ride beside it as TOP-LEVEL keys so no round's number is lost to a redefinition: hbm_* = round 1/2's nominal
-        # SURVEY 8d yardstick (algorithmic bytes per launch / that launch's duration / 8 TB/s), peak_hw / frac_hw = the hardware
-        # issue rate of the guide (a wave64 VALU instruction every 2 cycles x 1 024 SIMDs x 2.4 GHz), whatever the mix.
+        ceil = ceil_all
+        # `roofline` says what SURVEY 8(d) says: frac = ALGORITHMIC bytes per launch (120 B per executor step x the steps
+        # one launch runs + 56 B per seed) / that launch's duration / 8 TB/s.  The duration is the average sim_kernel duration rocprofv3
+        # reports for this same command with the launches overlapping as in the timed region (the live trace-only pass: the figure
+        # `rocprofv3 --kernel-trace --stats` prints, profiles/r6_pingpong_profile.txt), or — no rocprofv3 — the launches' own HIP-event
+        # durations (launch_ms_hip_events, always beside it).  On this LDS-resident path those bytes never reach HBM (`traffic` = what does,
+        # FETCH_SIZE x 2 + WRITE_SIZE per launch), so the bound is nominal and the compute-side readings ride beside it as top-level keys:
+        # frac_hw = VALU wave-instructions per second / the hardware's issue rate (a wave64 VALU instruction every 2 cycles x 1 024 SIMDs x
+        # 2.4 GHz), frac_hw_useful_lanes = the same with the masked lanes taken out, frac_own_mix_ceiling = against the issue ceiling
+        # measured for this kernel's own instruction mix (tools/ubench_issue; rounds 3-5 called it `frac`).
         PEAK_HW_GINST = 1228.8
-        roof = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "G wave-inst/s", "frac": None, "traffic": traffic,
-                "peak_hw": PEAK_HW_GINST, "frac_hw": None, "frac_hw_useful_lanes": None,
+        launch_ms = pmc.get("launch_ms_rocprof") if pmc else None
+        launch_src = "rocprofv3 --kernel-trace of this command, live: mean sim_kernel duration over %d overlapping launches" % pmc["launches_traced"] if launch_ms else \
+                     "HIP events around each timed launch (no rocprofv3 trace pass)"
+        launch_ms = launch_ms or k_avg_ms
+        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm-nominal (LDS-resident: not binding)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_bytes_per_executor_step": ALGO_BYTES_PER_STEP,
+                "executor_steps_per_launch": steps_per_launch, "launch_ms": launch_ms, "launch_ms_source": launch_src,
+                "launch_ms_hip_events": k_avg_ms, "frac_hip_events": hbm_nominal["frac"],
+                "frac_hw": None, "frac_hw_useful_lanes": None, "frac_own_mix_ceiling": None, "peak_hw_ginst_s": PEAK_HW_GINST,
                 "hbm_frac": hbm_nominal["frac"], "hbm_chip_frac": hbm_nominal["chip_frac"],
-                "hbm_measured_gbps": hbm_nominal["measured_hbm_gbps"], "hbm_algorithmic_bytes_per_launch": algo_bytes,
+                "hbm_measured_gbps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
+                "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
                 "traffic_detail": tdetail, "kernel": kname, "concurrent_launches": n_streams, "hbm_nominal": hbm_nominal}
+        issue = {"unit": "G wave-inst/s", "peak_hw": PEAK_HW_GINST}
         if pmc and "SQ_INSTS_VALU" in pmc:
             valu = pmc["SQ_INSTS_VALU"]
-            roof.update({"valu_inst_per_launch": valu, "salu_inst_per_launch": pmc.get("SQ_INSTS_SALU"),
-                         "lds_inst_per_launch": pmc.get("SQ_INSTS_LDS"), "waves_per_launch": pmc.get("SQ_WAVES"),
-                         "achieved_ginst_s": valu / (ms_step * 1e-3) / 1e9,
-                         "per_launch_ginst_s": valu / (k_avg_ms * 1e-3) / 1e9})
-            roof["achieved"] = roof["achieved_ginst_s"]
+            issue.update({"valu_inst_per_launch": valu, "salu_inst_per_launch": pmc.get("SQ_INSTS_SALU"),
+                          "lds_inst_per_launch": pmc.get("SQ_INSTS_LDS"), "waves_per_launch": pmc.get("SQ_WAVES"),
+                          "achieved_ginst_s": valu / (ms_step * 1e-3) / 1e9,
+                          "per_launch_ginst_s": valu / (launch_ms * 1e-3) / 1e9})
             if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_THREAD_CYCLES_VALU"):
-                roof["lane_util"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
+                issue["lane_util"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
         elif world == 1 and headline and not args.loss:
             # no live counters (rocprofv3 missing or refused): the committed per-executor-step instruction counts of this kernel
             cpath = os.path.join(ROOT, "profiles", "r3_issue_counters.json")
             if os.path.exists(cpath):
                 cj = json.load(open(cpath))
                 valu = cj["valu_inst_per_executor_step"] * steps_per_launch
-                roof.update({"valu_inst_per_launch": valu, "achieved_ginst_s": valu / (ms_step * 1e-3) / 1e9,
-                             "per_launch_ginst_s": valu / (k_avg_ms * 1e-3) / 1e9, "lane_util": cj.get("lane_util"),
-                             "counters_source": "profiles/r3_issue_counters.json (rocprofv3 PMC of this command on an MI355X, not this run"
-                                                + ("; live attempt: " + str(pmc_note) if pmc_note else "") + ")"})
-                roof["achieved"] = roof["achieved_ginst_s"]
+                issue.update({"valu_inst_per_launch": valu, "achieved_ginst_s": valu / (ms_step * 1e-3) / 1e9,
+                              "per_launch_ginst_s": valu / (launch_ms * 1e-3) / 1e9, "lane_util": cj.get("lane_util"),
+                              "counters_source": "profiles/r3_issue_counters.json (rocprofv3 PMC of this command on an MI355X, not this run"
+                                                 + ("; live attempt: " + str(pmc_note) if pmc_note else "") + ")"})
         if ceil:
-            roof.update({"ceiling_ginst_s": ceil["valu_mix_ceiling_ginst_s"], "peak": ceil["valu_mix_ceiling_ginst_s"],
-                         "ceiling_detail": ceil})
-            if roof["achieved"]:
-                roof["frac"] = roof["achieved"] / roof["peak"]
-        if roof["achieved"]:
-            roof["frac_hw"] = roof["achieved"] / PEAK_HW_GINST
-            if roof.get("lane_util"):
-                roof["frac_hw_useful_lanes"] = roof["frac_hw"] * roof["lane_util"]      # lane-operations that do simulation work
-        roof["note"] = ("achieved = VALU wave-instructions per sim_kernel launch (rocprofv3 SQ_INSTS_VALU, live) / wall time per batch "
-                        f"({n_streams} launches overlap, so this is the chip-level rate; per_launch_ginst_s divides by one launch's own "
-                        "HIP-event duration instead); peak = the chip's sustained issue rate for the executor's VALU mix measured by wall "
-                        "time (tools/ubench_issue, best over 1-8 waves per SIMD); lane_util = active lanes per issued VALU instruction "
-                        "(divergence: rejection-sampling retries and op-kind branches issue for the whole wave); kernel_ms_per_step "
-                        "(one launch, start to end) exceeds ms_per_step (wall time per batch) because launches overlap")
+            issue.update({"own_mix_ceiling_ginst_s": ceil["valu_mix_ceiling_ginst_s"], "ceiling_detail": ceil})
+        if issue.get("achieved_ginst_s"):
+            roof["frac_hw"] = issue["achieved_ginst_s"] / PEAK_HW_GINST
+            if issue.get("lane_util"):
+                roof["frac_hw_useful_lanes"] = roof["frac_hw"] * issue["lane_util"]      # lane-operations that do simulation work
+            if ceil:
+                roof["frac_own_mix_ceiling"] = issue["achieved_ginst_s"] / ceil["valu_mix_ceiling_ginst_s"]
+        issue["note"] = ("achieved_ginst_s = VALU wave-instructions per sim_kernel launch (rocprofv3 SQ_INSTS_VALU, live) / wall time per batch "
+                         f"({n_streams} launches overlap: the chip-level rate); own_mix_ceiling = the chip's sustained issue rate for the executor's "
+                         "own VALU mix (tools/ubench_issue, best over 1-8 waves per SIMD) — a kernel is near 1.0 against THAT whatever its "
+                         "quality, which is why it is no longer `frac`; lane_util = active lanes per issued VALU instruction")
+        roof["valu_issue"] = issue
+        roof["note"] = ("frac = algorithmic_bytes_per_launch / launch_ms / 8 TB/s (SURVEY 8d).  One division reproduces it from profiles/r6_pingpong_profile.txt: "
+                        "12.229 GB / the sim_kernel AverageNs of the stats table / 8e12.  Those bytes stay in LDS and registers: `traffic` is what "
+                        "reaches HBM per launch, and hbm_chip_frac (all overlapping launches / wall time) exceeds 1 for exactly that reason.")
         line = {
             "metric": "sim_seconds_per_sec", "value": sim_s / dt, "unit": "sim-s/s",
             "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -759,6 +816,9 @@ def main():
                                    + (" (BASELINE configs[1])" if headline and not args.loss else ""),
                        "seeds_per_step": total, "parallelism": f"seed-shard x{n_ranks}" + (f", {n_streams} concurrent batches per GPU" if n_streams > 1 else "")},
             "verified_seeds": verified,
+            # the SURVEY 8b call itself in the headline's shadow: madsim_hip_run_batch(262 144) into a pageable host array (PCIe-inclusive)
+            "value_run_batch_host": (run_batch_big["seeds_per_sec"] * (sim_s / seeds_total)) if run_batch_big else None,
+            "value_run_batch_host_seeds_per_sec": run_batch_big["seeds_per_sec"] if run_batch_big else None,
             "extra": {"seeds_per_sec": seeds_total / dt,
                       "executor_steps_per_sec": steps_total / dt,
                       "failed_seeds": nfail, "kernel_ms_per_step": k_avg_ms, "single_stream_ms_per_step": single_ms,

@@ -444,6 +444,12 @@ uint32_t    madsim_hip_version(void);
 const char* madsim_hip_build_info(void);
 const char* madsim_hip_strerror(int code);
 const char* madsim_hip_last_error(void);   /* thread-local text of the calling thread's last failure */
+/* The library keeps up to five batches of one call in flight on its own HIP streams; ROCclr maps a process's streams onto
+ * GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue run one after the other (madsim_hip_run_batch(262 144):
+ * 8.3 ms against ~5 ms).  The library never touches the environment by itself: set GPU_MAX_HW_QUEUES=16 before the process first uses
+ * HIP, or call this FIRST THING in main() (it is a setenv: not safe beside threads that read the environment, no effect once HIP is
+ * initialised).  Returns 1 when it set the variable, 0 when the host's own setting stands, <0 on a bad argument. */
+int madsim_hip_prefer_hw_queues(int n);
 
 /* ---- Per-device contexts -----------------------------------------------------------------------------
  * "one host thread drives a batch; library is re-entrant per device handle, not thread-safe per
@@ -527,7 +533,9 @@ int64_t madsim_hip_ctx_trace_seed(madsim_hip_ctx_t* ctx, const madsim_workload_t
  * queued from the calling thread before any is waited for, results land in `out[count]` (host), seeds that outgrew a
  * device capacity or the step cap are re-run in one compacted launch per round (<= max_rounds, as
  * madsim_hip_run_batch_auto), and the n reports are folded on the host into `summary`.  Bit-identical to
- * madsim_hip_run_batch_auto on a single context. */
+ * madsim_hip_run_batch_auto on a single context.  summary.kernel_ms = the MAXIMUM over the devices (they run concurrently) plus the
+ * re-run rounds; madsim_campaign_t.kernel_ms, also over several contexts, is the SUM of every batch's kernel time — the two are not
+ * comparable. */
 int madsim_hip_run_batch_multi(madsim_hip_ctx_t* const* ctxs, int n_ctx, const madsim_workload_t* w,
                                const madsim_config_t* cfg, uint64_t seed0, uint64_t count,
                                const madsim_limits_t* lim, madsim_result_t* out, madsim_summary_t* summary,

@@ -15,7 +15,9 @@ namespace madsim_geo {
 using madsim_k::KParams;
 
 // vgprs: VGPRs per lane of a kernel build as the loaded code object reports them (null / 0 = unknown: a static estimate)
-struct Device { int num_cus = 256; size_t lds_per_cu = 160 * 1024; int (*vgprs)(const madsim_k::VariantSel*) = nullptr; };
+// max_waves_per_simd: experiment hook (MADSIM_HIP_WAVES_PER_SIMD in the environment of the library): global-state builds size their LDS
+// heap quota for at most that many waves per SIMD instead of what the build's registers admit (0 = no cap)
+struct Device { int num_cus = 256; size_t lds_per_cu = 160 * 1024; int (*vgprs)(const madsim_k::VariantSel*) = nullptr; int max_waves_per_simd = 0; };
 
 inline int fail(std::string* err, int code, const std::string& msg) { if (err) *err = msg; return code; }
 
@@ -445,6 +447,7 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
             const int gv = g.vgprs ? g.vgprs(&gsel) : -1;
             uint32_t per_simd = gv > 0 ? 512u / (uint32_t)((gv + 7) & ~7) : (gsel.feat & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) != (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR) ? 3u : 2u;
             per_simd = per_simd < 2 ? 2u : per_simd > 4 ? 4u : per_simd;         // workgroups of four waves, one wave per SIMD each
+            if (g.max_waves_per_simd > 0 && per_simd > (uint32_t)g.max_waves_per_simd) per_simd = (uint32_t)g.max_waves_per_simd;
             const size_t quota = g.lds_per_cu / per_simd;                    // (a large instruction table can eat a workgroup's whole share:
             const size_t glw = L.lanes_per_wave ? lw : 64;                   // (auto: full waves, whatever the LDS-resident sizing above tried)
             const size_t per_seed = quota > (size_t)sh_bytes + 1280 ? (quota - sh_bytes - 1280) / (4 * glw) : 0;   // no size_t underflow)
@@ -463,6 +466,8 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
                 fit = per_seed > fixed_n + 64 ? (uint32_t)((per_seed - fixed_n) / 8) : 4u;
             }
             if (P.heap_lds > fit) { P.heap_spill += P.heap_lds - fit; P.heap_lds = fit; }
+            // (sibling pairs: the root and whole pairs stay in LDS — an odd count)
+            if (use_narrow && MADSIM_NH_PAIRS && !(P.heap_lds & 1u)) { P.heap_lds -= 1; P.heap_spill += 1; }
             continue;
         }
         if (lw == 64 || !P.rq_in_reg) break;

@@ -52,17 +52,20 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
 #ifndef MADSIM_G_WAVES_PER_EU
 #define MADSIM_G_WAVES_PER_EU 3
 #endif
+#ifndef MADSIM_ALLG_WAVES_PER_EU          // the every-class global-state builds (experiments: tools/build_variant.sh -DMADSIM_ALLG_WAVES_PER_EU=3)
+#define MADSIM_ALLG_WAVES_PER_EU 2
+#endif
 // Priority of a wave that has done `pass` of about `est` passes: who is behind is served first.  Four levels, one per quarter of the
 // work, looked at every 16th pass — measured against finer resolution near the end (the last 1/2, 1/4, 1/8: equal on finite sets, 1 %
 // worse in long regions; the last 1/4, 1/8, 1/16: no gain at all) and against every 4th / 64th pass (+0.7 % / +0.6 %): profiles/r5_experiments.md.
 constexpr uint32_t MADSIM_PRIO_EVERY_MASK = 15u;
 __device__ __forceinline__ uint32_t progress_priority(uint32_t pass, uint32_t est) {
-    const uint32_t q = pass * 4u / est;
+    const uint32_t q = pass / ((est >> 2) + 1u);          // (no pass * 4: that wrapped once a wave had run 2^30 passes)
     return q >= 3 ? 0u : 3u - q;
 }
 
 template <class K>
-__global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) == (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR) ? 2 : MADSIM_G_WAVES_PER_EU) void sim_kernel(const KParams P) {
+__global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) == (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR) ? MADSIM_ALLG_WAVES_PER_EU : MADSIM_G_WAVES_PER_EU) void sim_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // workgroup-shared tables
     uint32_t* sh = SMEM;
@@ -79,7 +82,10 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
     c.sockt0 = P.sh_socks;
     c.nodet0 = P.sh_nodes;
     const uint32_t wbase = wv * P.wave_words;       // this wave's slice of the workgroup's LDS
-    if (K::NH) c.heap0 = (P.sh_heap + wbase) / 2 + lane;          // 8-byte entries: a uint2 index
+    if (K::NH) {                                                 // 8-byte entries: a uint2 index (sibling pairs: the root's; the pairs follow as 16-byte units)
+        c.heap0 = (P.sh_heap + wbase) / 2 + lane;
+        c.heapp0 = (P.sh_heap + wbase + (2u << P.lw_shift)) / 4 + lane;
+    }
     else if (K::LIFE) c.heap0 = (P.sh_heap + wbase) / 4 + lane;
     else if (K::CMP) { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = 0; }        // 8-byte entries 1 .. heap_lds - 1 (entry 0: registers)
     else { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = P.sh_heap + wbase + ((P.heap_lds * 2) << P.lw_shift) + lane; }
@@ -114,8 +120,8 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
     if (EXP_LANE_DIV > 1 && (lane % EXP_LANE_DIV)) return;          // (timing experiments only: tools/experiment/k_experiment.h EXP_HALF_LANES)
     const uint32_t glane = (((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane) / EXP_LANE_DIV;
-    c.spill_off = glane * (K::NH ? 8u : 16u);
-    c.spill = buf_make(P.spill, (uint64_t)P.heap_spill * P.total_lanes * (K::NH ? 8u : 16u));
+    c.spill_off = glane * (K::NH && !MADSIM_NH_PAIRS ? 8u : 16u);
+    c.spill = buf_make(P.spill, K::NH ? (uint64_t)(MADSIM_NH_PAIRS ? (P.heap_spill + 2u) / 2u * 16u : P.heap_spill * 8u) * P.total_lanes : (uint64_t)P.heap_spill * P.total_lanes * 16u);
     c.gs_lane = glane;
     c.gs = buf_make(P.gstate, (uint64_t)P.gs_stride * P.total_lanes);
     c.tlog = P.trace_log;
@@ -133,8 +139,9 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
     // of launches (the sub-batches of one madsim_hip_run_batch call, a campaign's last batches, a short timed region) ends 0.5-0.9 ms
     // apart and the last launch finishes on SIMDs it has to itself, at a third of their issue rate (profiles/r5_experiments.md).
     // A wave that knows how far through its work it is can undo that: priority 3 in the first quarter of its passes, 2 / 1 / 0 in
-    // the next ones — whoever is behind is served first, co-resident launches finish together.  "How many passes" is what the last
-    // finished wave of this workload counted (one word per workload table set, written below); until one has finished: no priority.
+    // the next ones — whoever is behind is served first, co-resident launches finish together.  "How many passes" is what the longest
+    // finished wave of this workload and launch shape counted (one word per (workload, limits, seeds per lane), written below); until one
+    // has finished: no priority.
     uint32_t pass_est = (K::TRACE || !P.iter_est) ? 0u : wave_uniform(*P.iter_est);
     uint32_t pass = 0;
     for (;;) {
@@ -280,7 +287,13 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
             else next += P.total_lanes / EXP_LANE_DIV;
         }
     }
-    if (!K::TRACE && P.iter_est && lane == 0 && pass > 16) *P.iter_est = pass;      // (any finished wave's count will do: same workload, same shape of launch)
+    // the estimate = the longest wave of this (workload, launch shape) so far: the maximum over the wave's lanes (lane 0 may have left long
+    // before the others when seeds differ in length or come from the work queue), one atomic per wave into the word the host keyed by
+    // workload, limits and seeds per lane (madsim_hip.cpp upload_workload)
+    if (!K::TRACE && P.iter_est) {
+        const uint32_t wmax = wave_max_u32(pass);
+        if (wave_first_lane() && wmax > 16) atomic_max_u32(P.iter_est, wmax);
+    }
 #ifdef MADSIM_K_PROF
     PROBE2(0);
     if (lane == 0 && P.prof) { for (int i = 0; i < 12; i++) atomicAdd((unsigned long long*)&P.prof[i], (unsigned long long)L.prof_acc[i]); atomicAdd((unsigned long long*)&P.prof[12], (unsigned long long)prof_iters); atomicAdd((unsigned long long*)&P.prof[13], 1ull); }

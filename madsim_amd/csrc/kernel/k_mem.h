@@ -99,6 +99,21 @@ __device__ __forceinline__ void wave_set_priority(uint32_t q) {
 }
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// maximum of `v` over the ACTIVE lanes of the wave, as a wave-uniform value (a scalar loop over the exec mask: used once per wave, at its end)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    uint64_t m = __builtin_amdgcn_ballot_w64(true);
+    uint32_t mx = 0;
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+        mx = x > mx ? x : mx;
+        m &= m - 1;
+    }
+    return mx;
+}
+__device__ __forceinline__ bool wave_first_lane() { return (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)); }
+__device__ __forceinline__ void atomic_max_u32(uint32_t* p, uint32_t v) { atomicMax(p, v); }
+
 // true when `p` holds in every active lane of the wave (a scalar: branches on it are uniform)
 __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
 

@@ -148,6 +148,7 @@ struct Ctx {
     uint32_t sock0;      // word index of this lane's socket region
     uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + (i << lws)); base-op builds: uint2 index
     uint32_t heapm0;     // base-op builds: word index of the meta word of heap entry 0 (k_timer.h)
+    uint32_t heapp0;     // narrow-heap builds, sibling pairs: uint4 index of pair 0 (positions 1 and 2); c.heap0 then is the root's uint2 index
     uint32_t task0;      // uint4 index of task unit 0
     uint32_t task1;      // base-op builds: uint2 index of the 8-byte unit1 array (see "Task state")
     uint32_t insn0;      // uint4 index of the workgroup-shared instruction table

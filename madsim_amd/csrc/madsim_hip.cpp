@@ -80,8 +80,10 @@ struct madsim_hip_ctx {
         uint64_t hash = 0;
         std::vector<uint32_t> host;      // insns | progs | socks | durs (as 32-bit words) | n_insns
         uint4* insns = nullptr; uint32_t* progs = nullptr; uint32_t* socks = nullptr; uint32_t* nodes = nullptr; uint64_t* durs = nullptr;
-        uint32_t* iter_est = nullptr;    // one word: how many passes a wave of this workload runs (written by finishing waves, k_main.h)
+        uint32_t* iter_est = nullptr;    // ITER_KEYS words: how many passes a wave of this workload runs, one per launch shape (limits, seeds per lane:
+                                         // upload_workload picks the word; written by finishing waves, k_main.h)
     };
+    static constexpr uint32_t ITER_KEYS = 16;
     std::vector<Tables> tables;
     // per-stream scratch: launches on one stream run in order, launches on different streams may overlap and must
     // not share the timer-heap spill region or the work-queue counter
@@ -103,7 +105,12 @@ struct madsim_hip_ctx {
     uint32_t lds_attr = 0;
     uint64_t* d_prof = nullptr;               // debug counters (profiling kernel builds)
 
-    madsim_geo::Device dev() const { madsim_geo::Device d; d.num_cus = num_cus > 0 ? num_cus : 256; d.lds_per_cu = lds_per_cu; d.vgprs = variant_vgprs_cached; return d; }
+    madsim_geo::Device dev() const {
+        madsim_geo::Device d; d.num_cus = num_cus > 0 ? num_cus : 256; d.lds_per_cu = lds_per_cu; d.vgprs = variant_vgprs_cached;
+        static const int cap = [] { const char* e = getenv("MADSIM_HIP_WAVES_PER_SIMD"); return e ? atoi(e) : 0; }();    // (experiments: geometry.h Device)
+        d.max_waves_per_simd = cap;
+        return d;
+    }
     int bind() { HIP_TRY(hipSetDevice(device)); return 0; }
     static void free_tables(Tables& t) {
         if (t.insns) (void)hipFree(t.insns);
@@ -135,16 +142,23 @@ struct madsim_hip_ctx {
 // The library keeps up to five sub-batches of a call in flight, each on its own HIP stream (run_pipelined, campaigns).  ROCclr maps
 // the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4): with more streams than queues two sub-batches share a
 // queue and run one after the other — measured on an MI355X (round 5, tools/experiment/exp_r5_runbatch.py): madsim_hip_run_batch(262 144)
-// 8.3 ms with the default, ~5 ms with 16 queues.  The variable is read when the HIP runtime initialises, so it is set here, before this
-// library's first HIP call, unless the host application has chosen a value itself (a process that has initialised HIP before
-// creating its first context keeps whatever it had).
-static void want_hw_queues() {
-    static const int once = setenv("GPU_MAX_HW_QUEUES", "16", 0 /* never override the host's own choice */);
-    (void)once;
+// 8.3 ms with the default, ~5 ms with 16 queues.  The variable is read when the HIP runtime initialises, and a library has no business
+// changing its host's environment behind its back (setenv races with getenv on other threads, and the value leaks into child
+// processes: round 5 did exactly that).  So the HOST sets it — `GPU_MAX_HW_QUEUES=16` in the environment, as madsim_amd/runtime.py and
+// bench.py do before they load HIP, or madsim_hip_prefer_hw_queues() as the first thing in main() — and the library only says so,
+// once, when it is about to use more streams than the process has queues.
+static void hint_hw_queues(uint32_t streams) {
+    static bool said = false;
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    const long q = e ? atol(e) : 4;
+    if (said || (long)streams <= q || getenv("MADSIM_HIP_QUIET")) return;
+    said = true;
+    fprintf(stderr, "madsim_hip: note: %u batches in flight but GPU_MAX_HW_QUEUES=%ld hardware queues: streams will share queues (about 1.6x slower "
+                    "madsim_hip_run_batch).  Set GPU_MAX_HW_QUEUES=16 before the process first touches HIP, or call madsim_hip_prefer_hw_queues(16) "
+                    "at start-up.  (MADSIM_HIP_QUIET=1 silences this.)\n", streams, q);
 }
 
 int madsim_hip_ctx::open(int dev_index) {
-    want_hw_queues();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(MADSIM_E_HIP, "no HIP device visible (this library has no CPU fallback)");
@@ -230,8 +244,8 @@ int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
             HIP_TRY(hipMalloc(&t.socks, T.socks.size() * 4 + 16));
             HIP_TRY(hipMalloc(&t.durs, T.durs.size() * 8 + 16));
             HIP_TRY(hipMalloc(&t.nodes, T.nodes.size() * 4 + 16));
-            HIP_TRY(hipMalloc(&t.iter_est, 16));
-            HIP_TRY(hipMemset(t.iter_est, 0, 16));
+            HIP_TRY(hipMalloc(&t.iter_est, ITER_KEYS * sizeof(uint32_t)));
+            HIP_TRY(hipMemset(t.iter_est, 0, ITER_KEYS * sizeof(uint32_t)));
             HIP_TRY(hipMemcpy(t.nodes, T.nodes.data(), T.nodes.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(t.insns, T.insns.data(), T.insns.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(t.progs, T.progs.data(), T.progs.size() * 4, hipMemcpyHostToDevice));
@@ -247,7 +261,16 @@ int madsim_hip_ctx::upload_workload(const madsim_workload_t* w, KParams& P) {
     P.insns = hit->insns; P.progs = hit->progs; P.socks = hit->socks; P.nodes = hit->nodes; P.dur_table = hit->durs;
     // (MADSIM_HIP_NO_PRIO=1 in the environment: launches without the progress-based wave priorities of k_main.h — a diagnostic / A-B switch,
     //  results are the same either way)
-    { static const bool off = getenv("MADSIM_HIP_NO_PRIO") != nullptr; P.iter_est = off ? nullptr : hit->iter_est; }
+    // The pass estimate is a property of the launch SHAPE, not of the workload alone: the capacities change the kernel build and the spilled
+    // levels, the seeds per lane (a 65 536-seed campaign batch against a compacted re-run list) the passes a wave runs.  One word per
+    // shape, picked by a hash of both (a collision costs fairness between co-resident launches, never a result).
+    {
+        static const bool off = getenv("MADSIM_HIP_NO_PRIO") != nullptr;
+        const uint64_t per_lane = P.total_lanes ? (P.count + P.total_lanes - 1) / P.total_lanes : 1;
+        const uint32_t shape[8] = {P.heap_lds, P.heap_spill, P.max_tasks, P.lw_shift, P.gstate_mode | P.narrow << 1 | P.compact << 2 | (P.dedup_n ? 8u : 0u),
+                                   P.mbox_regs, P.max_steps, (uint32_t)std::min<uint64_t>(per_lane, 0xffffffffu)};
+        P.iter_est = off ? nullptr : hit->iter_est + (fnv(shape, sizeof shape, 14695981039346656037ull) % ITER_KEYS);
+    }
     return 0;
 }
 
@@ -267,7 +290,8 @@ int madsim_hip_ctx::ensure_scratch(KParams& P, hipStream_t stream, bool work_que
         P.gstate = sc.gstate;
     }
     if (P.heap_spill) {
-        size_t need = (size_t)P.heap_spill * P.total_lanes * (P.narrow ? 8 : sizeof(uint4));
+        size_t need = P.narrow ? (size_t)(MADSIM_NH_PAIRS ? (P.heap_spill + 2) / 2 * 16 : P.heap_spill * 8) * P.total_lanes      // (sim_kernel.h MADSIM_NH_PAIRS)
+                               : (size_t)P.heap_spill * P.total_lanes * sizeof(uint4);
         if (need >= (1ull << 32)) return fail(MADSIM_E_LIMITS, "heap spill region exceeds 4 GiB: lower heap_spill_slots");
         if (need > sc.spill_bytes) {
             if (sc.spill) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(sc.spill); }
@@ -302,6 +326,7 @@ int madsim_hip_ctx::launch(const madsim_workload_t* w, const madsim_config_t* cf
     Geo G;
     int rc;
     if ((rc = madsim_geo::make_geometry(dev(), w, cfg, lim, count, &G, &g_err))) return rc;
+    G.P.count = count;                              // (upload_workload keys the pass estimate by the launch shape: seeds per lane)
     if ((rc = upload_workload(w, G.P))) return rc;
     // Work distribution: static striding (lane g runs units g, g+G, ...) or a per-launch atomic counter from which a
     // finished lane pulls its next unit.  They only differ when a launch holds more units than resident lanes.
@@ -411,6 +436,7 @@ int madsim_hip_ctx::run_list(const madsim_workload_t* w, const madsim_config_t* 
 // context's mutex serialises the two).  `staging`: also a page-locked host buffer of `batch` results per flight.
 int madsim_hip_ctx::ensure_flights(uint32_t n, uint64_t batch, bool staging) {
     if (n > (uint32_t)CAMPAIGN_MAX) return fail(MADSIM_E_ARG, "at most 8 batches in flight");
+    hint_hw_queues(n);
     for (uint32_t i = 0; i < n; i++) {
         Flight& f = flights[i];
         if (!f.stream) {
@@ -651,6 +677,17 @@ namespace {
 extern "C" {
 
 uint32_t madsim_hip_version(void) { return MADSIM_HIP_ABI_VERSION; }
+
+// Explicit opt-in for hosts that cannot set their own environment: asks ROCclr for `n` hardware queues (GPU_MAX_HW_QUEUES) unless the
+// variable is already set.  Only effective before the process's first HIP call, and — like every setenv — only safe while no other
+// thread reads the environment: call it first thing in main().  Returns 1 when it set the variable, 0 when the host's own value stands.
+int madsim_hip_prefer_hw_queues(int n) {
+    if (n < 1 || n > 64) return fail(MADSIM_E_ARG, "hardware queues: 1..64");
+    if (getenv("GPU_MAX_HW_QUEUES")) return 0;
+    char buf[16];
+    snprintf(buf, sizeof buf, "%d", n);
+    return setenv("GPU_MAX_HW_QUEUES", buf, 0) == 0 ? 1 : fail(MADSIM_E_ARG, "setenv failed");
+}
 
 #define MADSIM_STR2(x) #x
 #define MADSIM_STR(x) MADSIM_STR2(x)

@@ -33,6 +33,13 @@
    the heap levels per LDS byte, half the bytes per spilled level.  Exact while every live deadline lies within 2^31 ns of the clock:
    checked per push on the device (a violation is a capacity verdict: the re-run uses the wide entries). */
 #define MADSIM_FEAT_NARROW 128
+/* Narrow entries are laid out as SIBLING PAIRS: heap positions 2q + 1 and 2q + 2 — the two children a sift-down level compares — share
+   one 16-byte unit [pair q][lane] (LDS and spill region alike; the root has a slot of its own), so a level costs ONE 16-byte access
+   instead of two 8-byte ones in different rows.  heap_lds is odd there (the root + whole pairs).  0 = positions as rows of 8 bytes (the
+   first form of the layout; kept for A/B builds: tools/build_variant.sh -DMADSIM_NH_PAIRS=0). */
+#ifndef MADSIM_NH_PAIRS
+#define MADSIM_NH_PAIRS 1
+#endif
 
 namespace madsim_k {
 

@@ -75,34 +75,42 @@ def decode_first_fail(key):
 
 
 # ---- the seed SEARCH over ranks: one process per GPU, one small collective per round ---------------------------------------------
-CAMPAIGN_WORDS = 6      # {first genuine failing seed ^ (1 << 63), genuine failures, runner verdicts, steps, clock, seeds run}
+CAMPAIGN_WORDS = 7      # {first genuine failing seed ^ (1 << 63), genuine failures, runner verdicts, steps, clock, seeds run, batches run}
 
 
-def campaign_over_ranks(run_batch_report, seed0, total, batch=65536, stop_at_failure=True, device="cpu", group=None):
+def campaign_over_ranks(run_chunk_report, seed0, total, batch=65536, stop_at_failure=True, device="cpu", group=None, round_batches=1):
     """`first-fail seeds per hour` across processes (BASELINE.json's second metric; runtime/builder.rs:129-160 with an early exit).
 
-    Batch k of [seed0, seed0 + total) belongs to rank k % world — the ranks advance through the seed space TOGETHER, as the contexts of
-    madsim_hip_run_campaign_multi do inside one process — and after every round (one batch per rank) the ranks exchange their 48-byte
-    reports with ONE all-gather (RCCL over xGMI when the backend is "nccl").  Every rank folds the rows in batch order, so all of them
-    reach the same answer without a second collective: with `stop_at_failure` the search ends with the round that holds the first
-    genuine failure, and only the batches up to the failing one count (the later ones of that round ran, but are not part of the
-    prefix) — the report is the single-process campaign's for the same prefix.
+    The range [seed0, seed0 + total) is cut into CHUNKS of `round_batches` batches; chunk c belongs to rank c % world, so the ranks
+    advance through the seed space TOGETHER (as the contexts of madsim_hip_run_campaign_multi do inside one process).  A round = one
+    chunk per rank: every rank runs its chunk as ONE pipelined call on its own GPU — `madsim_hip_run_campaign` keeps the chunk's batches
+    in flight and, with `stop_at_failure`, stops inside the chunk — and then the ranks exchange their 56-byte reports with ONE
+    all-gather (RCCL over xGMI when the backend is "nccl").  Every rank folds the rows in chunk order, so all of them reach the same
+    answer without a second collective: the search ends with the round that holds the first genuine failure, and only the chunks up to
+    the failing one count (later chunks of that round ran, but are not part of the prefix) — the report is the single-process
+    campaign's for the same prefix.  (Round 5 ran one batch per rank and round — a solo launch is 3.4 ms against 1.15 ms per batch
+    pipelined: VERDICT r5 weak #4; `round_batches` = 1 is that.)
 
-    `run_batch_report(seed_lo, n) -> (first_genuine_failing_seed | U64_MAX, n_failed_genuine, n_runner, total_steps, total_clock_ns)`
-    is the rank's own device call: `runtime.Context.run_campaign` on one batch in production, anything with that contract in a test.
+    `run_chunk_report(seed_lo, n) -> (first_genuine_failing_seed | U64_MAX, n_failed_genuine, n_runner, total_steps, total_clock_ns
+    [, seeds_run, batches_run])` is the rank's own device call on a chunk (`runtime.run_campaign` in production: seeds_run / batches_run
+    are the prefix it ran before it stopped; a 5-tuple means the whole chunk ran), anything with that contract in a test.
     Returns a dict: first_failing_seed, n_failed, n_runner, total_steps, total_clock_ns, seeds_run, batches_run, rounds."""
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    n_batches = -(-total // batch) if total else 0
+    chunk = batch * max(1, int(round_batches))
+    n_chunks = -(-total // chunk) if total else 0
     out = dict(first_failing_seed=U64_MAX, n_failed=0, n_runner=0, total_steps=0, total_clock_ns=0, seeds_run=0, batches_run=0, rounds=0)
-    for r in range(-(-n_batches // world) if n_batches else 0):
-        k = r * world + rank
-        row = [U64_MAX, 0, 0, 0, 0, 0]
-        if k < n_batches:
-            lo = k * batch
-            n = min(batch, total - lo)
-            f, nf, nr, st, ck = run_batch_report(seed0 + lo, n)
-            row = [int(f), int(nf), int(nr), int(st), int(ck), n]
+    for r in range(-(-n_chunks // world) if n_chunks else 0):
+        c = r * world + rank
+        row = [U64_MAX, 0, 0, 0, 0, 0, 0]
+        if c < n_chunks:
+            lo = c * chunk
+            n = min(chunk, total - lo)
+            rep = tuple(run_chunk_report(seed0 + lo, n))
+            f, nf, nr, st, ck = rep[:5]
+            ran = rep[5] if len(rep) > 5 else n
+            nb = rep[6] if len(rep) > 6 else -(-ran // batch)
+            row = [int(f), int(nf), int(nr), int(st), int(ck), int(ran), int(nb)]
         key = row[0] ^ (1 << 63)
         row[0] = key - (1 << 64) if key > _I63 else key
         mine = torch.tensor(row, dtype=torch.int64, device=device)
@@ -110,12 +118,12 @@ def campaign_over_ranks(run_batch_report, seed0, total, batch=65536, stop_at_fai
         gather_report_device(mine, rows, group)                    # the round's ONE collective
         out["rounds"] += 1
         stop = False
-        for g, rw in enumerate(rows.tolist()):                     # rank order = batch order inside a round
-            if r * world + g >= n_batches or stop:
+        for g, rw in enumerate(rows.tolist()):                     # rank order = chunk order inside a round
+            if r * world + g >= n_chunks or stop:
                 continue
             first = decode_first_fail(rw[0])
             out["n_failed"] += rw[1]; out["n_runner"] += rw[2]; out["total_steps"] += rw[3]; out["total_clock_ns"] += rw[4]
-            out["seeds_run"] += rw[5]; out["batches_run"] += 1
+            out["seeds_run"] += rw[5]; out["batches_run"] += rw[6]
             if first < out["first_failing_seed"]:
                 out["first_failing_seed"] = first
             if stop_at_failure and first != U64_MAX:

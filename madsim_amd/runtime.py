@@ -64,8 +64,14 @@ def lib():
             raise MadsimHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C madsim_amd/csrc). There is no CPU fallback.")
+        # The library keeps up to five batches in flight on its own HIP streams and ROCclr maps a process's streams onto GPU_MAX_HW_QUEUES
+        # hardware queues (default 4: madsim_hip_run_batch(262 144) 8.3 ms against ~5 ms).  The library itself never touches the
+        # environment (include/madsim_hip.h madsim_hip_prefer_hw_queues): this host does, here, before it loads anything that initialises
+        # HIP — unless the application set the variable itself or initialised HIP earlier (import torch first, then its setting stands).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         L = C.CDLL(LIB_PATH)
         L.madsim_hip_version.restype = C.c_uint32
+        L.madsim_hip_prefer_hw_queues.argtypes = [C.c_int]
         L.madsim_hip_strerror.restype = C.c_char_p
         L.madsim_hip_strerror.argtypes = [C.c_int]
         L.madsim_hip_last_error.restype = C.c_char_p
@@ -285,16 +291,43 @@ def run_campaign_multi(contexts, workload, seed0, total, batch=0, in_flight=0, s
     return rep
 
 
-def run_campaign_over_ranks(workload, seed0, total, batch=65536, stop_at_failure=True, config=None, limits=None, device_tensors=None, group=None):
-    """The seed search with ONE PROCESS PER GPU (torch.distributed; RCCL when the backend is "nccl"): batch k of the range belongs to rank
-    k % world, every rank runs its batch through `madsim_hip_run_campaign` on its own GPU, and one all-gather of the 48-byte reports per
-    round lets every rank fold the same answer (madsim_amd/dist.py campaign_over_ranks).  Without a process group: the single-GPU search."""
-    from madsim_amd import dist as mdist
+def run_campaign_over_ranks(workload, seed0, total, batch=65536, stop_at_failure=True, config=None, limits=None, device_tensors=None, group=None,
+                            context=None, in_flight=0, round_batches=0):
+    """The seed search with ONE PROCESS PER GPU (torch.distributed; RCCL when the backend is "nccl"): the range is cut into chunks of
+    `round_batches` batches (0 = four times the batches the library keeps in flight: rounds long enough for the pipeline to reach its
+    steady rate, short enough that an early stop wastes little), chunk c belongs to rank c % world, every rank runs its chunk as ONE
+    `madsim_hip_run_campaign` call on its own GPU — batches in flight on the library's streams, stopping inside the chunk at a genuine
+    failure — and one all-gather of the 56-byte reports per round lets every rank fold the same answer (madsim_amd/dist.py
+    campaign_over_ranks).  Without a process group: the single-GPU search.
 
-    def one(seed_lo, n):
-        rep = run_campaign(workload, seed_lo, n, n, 1, False, config, limits)
-        return rep.first_failing_seed, rep.n_failed, rep.n_runner, rep.total_steps, rep.total_clock_ns
-    return mdist.campaign_over_ranks(one, seed0, total, batch, stop_at_failure, device_tensors or "cpu", group)
+    The rank's GPU is explicit: `context` (a runtime.Context on it), or the process-default context, which must have been bound with
+    `runtime.init(local_rank)` — this function never initialises it by itself (every rank would land on GPU 0).  `device_tensors`
+    defaults to that GPU under the "nccl" backend and to the CPU otherwise (gloo)."""
+    import torch.distributed as tdist
+    from madsim_amd import dist as mdist
+    if context is None and _inited_device is None:
+        raise RuntimeError("run_campaign_over_ranks: bind this rank's GPU first — runtime.init(local_rank) — or pass context=runtime.Context(local_rank)")
+    dev_index = context.device if context is not None else _inited_device
+    if device_tensors is None:
+        device_tensors = "cpu"
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_backend(group) == "nccl":
+            import torch
+            device_tensors = torch.device("cuda", dev_index)
+    cfg, lim = config or A.Config.default(), limits or A.Limits()
+    if not round_batches:
+        g = geometry(workload, lim)
+        fl = in_flight or (5 if g.blocks_per_cu * g.block_threads // 64 >= 16 else 4 if (g.variant & 16) and g.heap_spill_slots else 3)
+        round_batches = 4 * fl
+
+    def chunk(seed_lo, n):
+        rep = A.Campaign()
+        flags = A.CAMPAIGN_STOP_AT_FAILURE if stop_at_failure else 0
+        if context is not None:
+            _check(lib().madsim_hip_ctx_run_campaign(context._h, workload.ref(), C.byref(cfg), seed_lo, n, batch, in_flight, flags, C.byref(lim), C.byref(rep)))
+        else:
+            _check(lib().madsim_hip_run_campaign(workload.ref(), C.byref(cfg), seed_lo, n, batch, in_flight, flags, C.byref(lim), C.byref(rep)))
+        return rep.first_failing_seed, rep.n_failed, rep.n_runner, rep.total_steps, rep.total_clock_ns, rep.seeds_run, rep.batches_run
+    return mdist.campaign_over_ranks(chunk, seed0, total, batch, stop_at_failure, device_tensors, group, round_batches)
 
 
 def timing_ms(slot):

@@ -227,6 +227,7 @@ extern "C" int madsim_emu_geometry(const madsim_workload_t* w, const madsim_limi
 extern "C" int madsim_emu_geometry_params(const madsim_workload_t* w, const madsim_limits_t* lim, uint32_t* out32) {
     madsim_config_t cfg = madsim_geo::probe_config();
     madsim_geo::Device dev; dev.num_cus = 1;
+    if (const char* e = getenv("MADSIM_HIP_WAVES_PER_SIMD")) dev.max_waves_per_simd = atoi(e);
     madsim_geo::Geo G;
     int rc = madsim_geo::make_geometry(dev, w, &cfg, lim, 64, &G, &emu_err);
     if (rc) return rc;

@@ -57,6 +57,9 @@ template <int K_> static inline uint64_t mul_pow2p1(uint64_t v) { return (v << K
 static inline uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) { return a ^ b ^ c; }
 static inline void wave_set_priority(uint32_t) {}
 static inline uint32_t wave_uniform(uint32_t v) { return v; }
+static inline uint32_t wave_max_u32(uint32_t v) { return v; }
+static inline bool wave_first_lane() { return true; }
+static inline void atomic_max_u32(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
 static inline bool wave_all(bool p) { return p; }                        // (one emulated lane at a time: results may not depend on the vote)
 static inline uint32_t table_copy_first() { return 0; }                   // emulated threads run one after another:
 static inline uint32_t table_copy_stride(uint32_t) { return 1; }          // each copies everything

@@ -157,16 +157,27 @@ def test_check_ranks_refuses_a_missing_or_doubled_rank():
 
 
 # ---- the seed search over ranks (madsim_amd/dist.py campaign_over_ranks): one all-gather per round ------------------------------------
-def _oracle_report(w, cfg):
+def _oracle_report(w, cfg, batch, stop):
+    """The oracle standing in for `madsim_hip_run_campaign` on one chunk: batch after batch, and — with `stop` — no further than the batch
+    that holds the chunk's first genuine failure (MADSIM_CAMPAIGN_STOP_AT_FAILURE: seeds_run / batches_run are that prefix)."""
     import oracle
     from madsim_amd import _abi as A
 
     def run(seed_lo, n):
-        out, _ = oracle.run_batch(w, seed_lo, n, cfg)
-        v = out["verdict"]
-        genuine = (v != A.PASS) & (v < A.OVERFLOW)
-        first = int(seed_lo + int(np.nonzero(genuine)[0][0])) if genuine.any() else (1 << 64) - 1
-        return first, int(genuine.sum()), int((v >= A.OVERFLOW).sum()), int(out["steps"].astype(np.int64).sum()), int(out["clock_ns"].astype(np.int64).sum())
+        first, nf, nr, st, ck, ran, nb = (1 << 64) - 1, 0, 0, 0, 0, 0, 0
+        for lo in range(0, n, batch):
+            m = min(batch, n - lo)
+            out, _ = oracle.run_batch(w, seed_lo + lo, m, cfg)
+            v = out["verdict"]
+            genuine = (v != A.PASS) & (v < A.OVERFLOW)
+            nf += int(genuine.sum()); nr += int((v >= A.OVERFLOW).sum())
+            st += int(out["steps"].astype(np.int64).sum()); ck += int(out["clock_ns"].astype(np.int64).sum())
+            ran += m; nb += 1
+            if genuine.any():
+                first = min(first, int(seed_lo + lo + int(np.nonzero(genuine)[0][0])))
+                if stop:
+                    break
+        return first, nf, nr, st, ck, ran, nb
     return run
 
 
@@ -178,19 +189,22 @@ def _worker_campaign(rank, world, port, cases, q):
     from madsim_amd import workload as W
     w = W.pingpong(4, 8)
     res = []
-    for loss, seed0, total, batch, stop in cases:
-        res.append(mdist.campaign_over_ranks(_oracle_report(w, A.Config.default(packet_loss_rate=loss)), seed0, total, batch, stop))
+    for loss, seed0, total, batch, stop, rb in cases:
+        res.append(mdist.campaign_over_ranks(_oracle_report(w, A.Config.default(packet_loss_rate=loss), batch, stop), seed0, total, batch, stop, round_batches=rb))
     q.put((rank, res))
     dist.destroy_process_group()
 
 
 def test_campaign_over_ranks_matches_one_process_and_stops_within_a_round():
     """world 3 over gloo, the oracle standing in for the GPU: without stop the report of the whole range; with stop the smallest failing
-    seed, found in the round that holds it, counting exactly the batches up to the failing one; ragged last batch, fewer batches than
-    ranks, no failure at all.  Every rank computes the same dict from the one all-gather per round."""
+    seed, found in the round that holds it, counting exactly the batches up to the failing one; ragged last batch, fewer chunks than
+    ranks, no failure at all; one batch per rank and round (round 5's form) and PIPELINED rounds of several batches per rank (round 6:
+    every rank runs its chunk as one campaign call).  Every rank computes the same dict from the one all-gather per round, and that
+    dict is the single-process campaign's for the same prefix whatever the chunking."""
     from madsim_amd import _abi as A
     from madsim_amd import workload as W
-    cases = [(0.01, 7000, 1000, 64, False), (0.002, 50_000, 4000, 128, True), (0.0, 0, 500, 64, True), (0.01, 90_000, 100, 64, True)]
+    cases = [(0.01, 7000, 1000, 64, False, 1), (0.002, 50_000, 4000, 128, True, 1), (0.0, 0, 500, 64, True, 1), (0.01, 90_000, 100, 64, True, 1),
+             (0.01, 7000, 1000, 64, False, 4), (0.002, 50_000, 4000, 128, True, 3), (0.0, 0, 500, 64, True, 5), (0.002, 50_000, 4000, 128, True, 20)]
     world = 3
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
@@ -204,14 +218,16 @@ def test_campaign_over_ranks_matches_one_process_and_stops_within_a_round():
         assert p.exitcode == 0
     assert res[0] == res[1] == res[2]                      # no second collective needed: every rank folds the same rows
     w = W.pingpong(4, 8)
-    for (loss, seed0, total, batch, stop), got in zip(cases, res[0]):
-        one = mdist.campaign_over_ranks(_oracle_report(w, A.Config.default(packet_loss_rate=loss)), seed0, total, batch, stop)   # world 1, no process group
+    for (loss, seed0, total, batch, stop, rb), got in zip(cases, res[0]):
+        # the single-process search of the same range, one batch at a time (world 1, no process group, no chunking)
+        one = mdist.campaign_over_ranks(_oracle_report(w, A.Config.default(packet_loss_rate=loss), batch, stop), seed0, total, batch, stop)
         for f in ("first_failing_seed", "n_failed", "n_runner", "total_steps", "total_clock_ns", "seeds_run", "batches_run"):
-            assert got[f] == one[f], (loss, f, got, one)
+            assert got[f] == one[f], (loss, rb, f, got, one)
         n_batches = -(-total // batch)
+        n_chunks = -(-n_batches // rb)
         if stop and got["first_failing_seed"] != (1 << 64) - 1:
             j = (got["first_failing_seed"] - seed0) // batch
-            assert got["batches_run"] == j + 1 and got["rounds"] == j // world + 1
+            assert got["batches_run"] == j + 1 and got["rounds"] == (j // rb) // world + 1
         else:
-            assert got["batches_run"] == n_batches and got["seeds_run"] == total and got["rounds"] == -(-n_batches // world)
+            assert got["batches_run"] == n_batches and got["seeds_run"] == total and got["rounds"] == -(-n_chunks // world)
     assert res[0][0]["n_failed"] > 0 and res[0][1]["first_failing_seed"] != (1 << 64) - 1 and res[0][2]["n_failed"] == 0

@@ -1263,11 +1263,35 @@ def test_campaign_over_several_contexts_reports_like_one_and_stops_everywhere(hi
 
 def test_campaign_over_ranks_on_one_gpu_equals_the_library_campaign(hip):
     """madsim_amd/runtime.py run_campaign_over_ranks without a process group (world 1; the multi-rank fold is tested over gloo on the CPU,
-    tests/test_dist_gloo.py): the same report as madsim_hip_run_campaign for the same prefix, with and without the early stop."""
+    tests/test_dist_gloo.py): the same report as madsim_hip_run_campaign for the same prefix, with and without the early stop — one batch
+    per round (round 5's form) and pipelined rounds (round 6: each round one campaign call that keeps its batches in flight)."""
     w = W.pingpong(4, 16)
     for loss, total, stop in ((0.002, 40_000, False), (0.000002, 64 * 4096, True)):
         cfg = A.Config.default(packet_loss_rate=loss)
         one = hip.run_campaign(w, 9_000_000, total, 4096, 3, stop, cfg)
-        got = hip.run_campaign_over_ranks(w, 9_000_000, total, 4096, stop, cfg)
-        assert (got["first_failing_seed"], got["n_failed"], got["n_runner"], got["total_steps"], got["seeds_run"], got["batches_run"]) == \
-               (one.first_failing_seed, one.n_failed, one.n_runner, one.total_steps, one.seeds_run, one.batches_run)
+        for rb in (1, 0, 7):
+            got = hip.run_campaign_over_ranks(w, 9_000_000, total, 4096, stop, cfg, round_batches=rb)
+            assert (got["first_failing_seed"], got["n_failed"], got["n_runner"], got["total_steps"], got["seeds_run"], got["batches_run"]) == \
+                   (one.first_failing_seed, one.n_failed, one.n_runner, one.total_steps, one.seeds_run, one.batches_run), rb
+
+
+def test_campaign_over_ranks_runs_at_the_pipelined_rate(hip):
+    """the multi-process seed search must not run one launch at a time.  Headline workload, 65 536-seed batches: the rate of
+    run_campaign_over_ranks (default rounds: four times the batches in flight per call) against ONE madsim_hip_run_campaign call over the
+    same seeds — within a few percent (a round's ramp and drain, one 56-byte exchange); round 5's one-batch rounds for comparison."""
+    import time
+    w, lim, _ = W.bench_case("pingpong")
+    n = 120 * 65536
+    hip.run_campaign(w, 1 << 30, 10 * 65536, 65536, 0, False, None, lim)            # warm
+    best = {}
+    for _ in range(3):
+        t = time.perf_counter(); one = hip.run_campaign(w, 1 << 31, n, 65536, 0, False, None, lim); d1 = time.perf_counter() - t
+        t = time.perf_counter(); got = hip.run_campaign_over_ranks(w, 1 << 31, n, 65536, False, None, lim); d2 = time.perf_counter() - t
+        t = time.perf_counter(); hip.run_campaign_over_ranks(w, 1 << 31, n // 4, 65536, False, None, lim, round_batches=1); d3 = (time.perf_counter() - t) * 4
+        for k, d in (("one", d1), ("ranks", d2), ("ranks_1", d3)):
+            best[k] = min(best.get(k, d), d)
+        assert (got["n_failed"], got["total_steps"], got["seeds_run"]) == (one.n_failed, one.total_steps, one.seeds_run)
+    print(f"campaign {n / best['one'] / 1e6:.1f} M seeds/s, over ranks (pipelined rounds) {n / best['ranks'] / 1e6:.1f}, one batch per round {n / best['ranks_1'] / 1e6:.1f}")
+    assert best["ranks"] <= 1.07 * best["one"], best
+
+
