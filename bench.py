@@ -227,6 +227,8 @@ def main():
     if "MADSIM_BENCH_STATE_FLAGS" in os.environ:         # experiments: OR into / clear from state_mem (e.g. 0x100 = MADSIM_STATE_DEDUP_TIMERS; "-0x100" clears it)
         v = os.environ["MADSIM_BENCH_STATE_FLAGS"]
         lim.state_mem = (lim.state_mem & ~int(v[1:], 0)) if v.startswith("-") else (lim.state_mem | int(v, 0))
+    if "MADSIM_BENCH_CLEAR_FLAGS" in os.environ:         # experiments: clear bits of state_mem (beside MADSIM_BENCH_STATE_FLAGS, which sets some)
+        lim.state_mem &= ~int(os.environ["MADSIM_BENCH_CLEAR_FLAGS"], 0)
     if "MADSIM_BENCH_HEAP_LDS" in os.environ:            # experiments: move timer-heap entries between LDS and the HBM spill region
         n = int(os.environ["MADSIM_BENCH_HEAP_LDS"])
         lim.heap_spill_slots, lim.heap_lds_slots = lim.heap_spill_slots + max(0, lim.heap_lds_slots - n), n
@@ -519,6 +521,34 @@ def main():
         campaign = {"entry_point": "madsim_hip_run_campaign", "batches": nb, "batches_in_flight": n_streams, "seeds_per_batch": count,
                     "ms_per_batch": rep.wall_s / nb * 1e3, "seeds_per_sec": rep.seeds_run / rep.wall_s,
                     "executor_steps_per_sec": rep.total_steps / rep.wall_s, "failed_seeds": int(rep.n_failed), "runner_verdicts": int(rep.n_runner)}
+
+    # extra.first_fail_over_ranks: the seed search with ONE PROCESS PER GPU (runtime.run_campaign_over_ranks -> madsim_amd/dist.py): every rank
+    # runs chunks of the seed range as pipelined madsim_hip_run_campaign calls on its own GPU, one all-gather of the 56-byte reports per
+    # round (RCCL over xGMI under "nccl").  The half of BASELINE's metric that `--gpus N` measures at N > 1: seeds searched per hour when
+    # nothing fails (the steady rate of the search), and the wall time to a very rare first failure.  At N = 1 the same path, no collective.
+    ranks_search = None
+    if not args.no_first_fail and headline and not args.loss:
+        rb = 4 * n_streams
+        per_round = rb * count * n_ranks
+        runtime.run_campaign_over_ranks(w, 1 << 52, per_round, count, False, cfg, lim, device_tensors=cdev, round_batches=rb)       # warm (streams, buffers, tables, the communicator)
+        sync()
+        t1 = time.perf_counter()
+        rep = runtime.run_campaign_over_ranks(w, (1 << 52) + per_round, 3 * per_round, count, True, cfg, lim, device_tensors=cdev, round_batches=rb)
+        sync()
+        sdt = time.perf_counter() - t1
+        fcfg2 = A.Config.default(packet_loss_rate=args.very_rare_loss)
+        sync()
+        t1 = time.perf_counter()
+        rep2 = runtime.run_campaign_over_ranks(w, 1 << 53, 6 * per_round, count, True, fcfg2, lim, device_tensors=cdev, round_batches=rb)
+        sync()
+        fdt = time.perf_counter() - t1
+        ranks_search = {"entry_point": "runtime.run_campaign_over_ranks (madsim_hip_run_campaign per rank and round, one all-gather per round)",
+                        "world": n_ranks, "round_batches_per_rank": rb, "seeds_per_batch": count,
+                        "seeds_searched": int(rep["seeds_run"]), "rounds": int(rep["rounds"]), "failed": int(rep["n_failed"]),
+                        "seeds_per_sec": rep["seeds_run"] / sdt, "seeds_per_hour": rep["seeds_run"] / sdt * 3600.0,
+                        "very_rare": {"packet_loss_rate": args.very_rare_loss, "found": rep2["first_failing_seed"] != (1 << 64) - 1,
+                                      "first_failing_seed_offset": (int(rep2["first_failing_seed"]) - (1 << 53)) if rep2["first_failing_seed"] != (1 << 64) - 1 else None,
+                                      "seeds_searched": int(rep2["seeds_run"]), "rounds": int(rep2["rounds"]), "time_to_first_fail_ms": fdt * 1e3}}
 
     # extra.run_batch_262144: the SURVEY 8b entry point itself — one plain madsim_hip_run_batch call with host buffers for four batches
     # of seeds (Builder::run hands over all its seeds at once, runtime/builder.rs:121-162).  The library cuts the call into sub-launches
@@ -828,7 +858,9 @@ def main():
                       "workloads": extras, "campaign": campaign, "plain_run": plain, "run_batch_262144": run_batch_big,
                       "regions": region_stats,
                       "stream_trial_ms_per_step": stream_trial,
-                      "first_fail_seeds_per_hour": (first_fail_rare or {}).get("seeds_per_hour") or (first_fail["seeds_per_hour"] if first_fail else None)},
+                      "first_fail_over_ranks": ranks_search,
+                      "first_fail_seeds_per_hour": ((ranks_search or {}).get("seeds_per_hour") if n_ranks > 1 else None)
+                                                   or (first_fail_rare or {}).get("seeds_per_hour") or (first_fail["seeds_per_hour"] if first_fail else None)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

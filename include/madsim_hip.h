@@ -598,7 +598,8 @@ typedef struct madsim_geometry {
     uint32_t variant;              /* kernel specialisation: bit0 heap spill, bit1 extended ops, bit2 ready queue in a
                                     * register, bit3 runtime lane stride, bit4 global-state build; bits 8-12 = classes of extended ops compiled in
                                     * (1 timeouts, 2 channel, 4 RPC, 8 node lifecycle, 16 general address resolution), bit 13 = built without the determinism-log
-                                    * fold (madsim_limits_t.no_trace_hash on a base-op workload), bit 14 = the compact base-op layout (MADSIM_STATE_COMPACT); bits 16-19 = compile-time log2 lane
+                                    * fold (madsim_limits_t.no_trace_hash on a base-op workload), bit 14 = the compact base-op layout (MADSIM_STATE_COMPACT), bit 15 = 8-byte
+                                    * timer-heap entries (MADSIM_STATE_NARROW_HEAP); bits 16-19 = compile-time log2 lane
                                     * stride (15 = runtime) */
     uint32_t global_bytes_per_seed; /* size of a lane's state block in global memory (global-state builds), else 0 */
 } madsim_geometry_t;

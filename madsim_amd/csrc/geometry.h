@@ -466,8 +466,6 @@ inline int make_geometry(const Device& g, const madsim_workload_t* w, const mads
                 fit = per_seed > fixed_n + 64 ? (uint32_t)((per_seed - fixed_n) / 8) : 4u;
             }
             if (P.heap_lds > fit) { P.heap_spill += P.heap_lds - fit; P.heap_lds = fit; }
-            // (sibling pairs: the root and whole pairs stay in LDS — an odd count)
-            if (use_narrow && MADSIM_NH_PAIRS && !(P.heap_lds & 1u)) { P.heap_lds -= 1; P.heap_spill += 1; }
             continue;
         }
         if (lw == 64 || !P.rq_in_reg) break;

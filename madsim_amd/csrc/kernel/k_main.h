@@ -60,7 +60,7 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
 // worse in long regions; the last 1/4, 1/8, 1/16: no gain at all) and against every 4th / 64th pass (+0.7 % / +0.6 %): profiles/r5_experiments.md.
 constexpr uint32_t MADSIM_PRIO_EVERY_MASK = 15u;
 __device__ __forceinline__ uint32_t progress_priority(uint32_t pass, uint32_t est) {
-    const uint32_t q = pass / ((est >> 2) + 1u);          // (no pass * 4: that wrapped once a wave had run 2^30 passes)
+    const uint32_t q = (pass < (1u << 30) ? pass : (1u << 30) - 1u) * 4u / est;      // (saturating: pass * 4 wrapped once a wave had run 2^30 passes; one s_min_u32)
     return q >= 3 ? 0u : 3u - q;
 }
 
@@ -82,10 +82,7 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
     c.sockt0 = P.sh_socks;
     c.nodet0 = P.sh_nodes;
     const uint32_t wbase = wv * P.wave_words;       // this wave's slice of the workgroup's LDS
-    if (K::NH) {                                                 // 8-byte entries: a uint2 index (sibling pairs: the root's; the pairs follow as 16-byte units)
-        c.heap0 = (P.sh_heap + wbase) / 2 + lane;
-        c.heapp0 = (P.sh_heap + wbase + (2u << P.lw_shift)) / 4 + lane;
-    }
+    if (K::NH) c.heap0 = (P.sh_heap + wbase) / 2 + lane;          // 8-byte entries: a uint2 index
     else if (K::LIFE) c.heap0 = (P.sh_heap + wbase) / 4 + lane;
     else if (K::CMP) { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = 0; }        // 8-byte entries 1 .. heap_lds - 1 (entry 0: registers)
     else { c.heap0 = (P.sh_heap + wbase) / 2 + lane; c.heapm0 = P.sh_heap + wbase + ((P.heap_lds * 2) << P.lw_shift) + lane; }
@@ -120,8 +117,8 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
     if (lane >= (1u << P.lw_shift)) return;      // sub-wave occupancy: only lw = 2^lw_shift lanes carry seeds
     if (EXP_LANE_DIV > 1 && (lane % EXP_LANE_DIV)) return;          // (timing experiments only: tools/experiment/k_experiment.h EXP_HALF_LANES)
     const uint32_t glane = (((blockIdx.x * P.waves_per_block + wv) << P.lw_shift) + lane) / EXP_LANE_DIV;
-    c.spill_off = glane * (K::NH && !MADSIM_NH_PAIRS ? 8u : 16u);
-    c.spill = buf_make(P.spill, K::NH ? (uint64_t)(MADSIM_NH_PAIRS ? (P.heap_spill + 2u) / 2u * 16u : P.heap_spill * 8u) * P.total_lanes : (uint64_t)P.heap_spill * P.total_lanes * 16u);
+    c.spill_off = glane * (K::NH ? 8u : 16u);
+    c.spill = buf_make(P.spill, (uint64_t)P.heap_spill * P.total_lanes * (K::NH ? 8u : 16u));
     c.gs_lane = glane;
     c.gs = buf_make(P.gstate, (uint64_t)P.gs_stride * P.total_lanes);
     c.tlog = P.trace_log;
@@ -290,9 +287,12 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
     // the estimate = the longest wave of this (workload, launch shape) so far: the maximum over the wave's lanes (lane 0 may have left long
     // before the others when seeds differ in length or come from the work queue), one atomic per wave into the word the host keyed by
     // workload, limits and seeds per lane (madsim_hip.cpp upload_workload)
+    // (the base-op builds — every seed of theirs runs the same program at nearly the same pace — keep round 5's form: lane 0's own count)
     if (!K::TRACE && P.iter_est) {
-        const uint32_t wmax = wave_max_u32(pass);
-        if (wave_first_lane() && wmax > 16) atomic_max_u32(P.iter_est, wmax);
+        if (K::LIFE) {
+            const uint32_t wmax = wave_max_u32(pass);
+            if (wave_first_lane() && wmax > 16) atomic_max_u32(P.iter_est, wmax);
+        } else if (lane == 0 && pass > 16) *P.iter_est = pass;
     }
 #ifdef MADSIM_K_PROF
     PROBE2(0);

@@ -229,6 +229,16 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
             REG(22);
             if (K::G) wake_with<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff, pf_flags);
             else wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff);
+#if MADSIM_FIRE_COPIES
+            // Copies of this wake-up (the re-registrations of one pending Sleep: same deadline, same waker) are next in line, and firing them
+            // changes nothing: the first made its task SCHEDULED — or found it gone, or of another generation — and so does every copy.
+            // They are popped here, a step each (Timer::expire counts every entry), without the flag-word load and the store of a
+            // callback.  Nothing else can sit between them: the heap hands out equal deadlines in ITS order, and only an entry equal in
+            // deadline AND event word is skipped.
+            if (K::G && !K::DEDUP) {
+                while (L.heap_len > 0 && L.top_dl == ev_deadline(e) && heap_root_meta<K>(c) == popped_meta) { (void)timer_pop<K>(c, L); L.steps++; }
+            }
+#endif
         }
         else if (kind == EV_DELIVER) { REG(23); mailbox_deliver<K>(c, L, e.z, e.w, K::G ? &pf : nullptr); }      // net/mod.rs:323-330
         else if (K::FN && kind == EV_RESTART) node_restart<K>(c, L, e.z & 0xff);   // task/mod.rs:313

@@ -908,13 +908,12 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 L.loss_always = K::LIFE ? ((L.loss_always & ~1u) | loss_always_at(P, a)) : loss_always_at(P, a);
                 pc++;
                 break;
-            case MS_OP_SET_LATENCY:                         // NetSim::update_config(|c| c.send_latency = ..) (net/mod.rs:138-141, network.rs:129)
-                if (!K::LIFE) { st = ST_PANIC; break; }     // (geometry.h routes every workload with the op to an extended build)
-                L.loss_always = (L.loss_always & ~0x70u) | (((a & 3u) + 1u) << 4);
-                pc++;
-                break;
             default:
-                st = ST_PANIC;
+                // NetSim::update_config(|c| c.send_latency = ..) (net/mod.rs:138-141, network.rs:129): extended builds only — geometry.h routes
+                // every workload with the op to one.  (Under `default`, not a case of its own: the base-op builds' switch — the headline
+                // kernel's — keeps round 5's code byte for byte; a case label here cost it 1.4 % on the GPU, profiles/r6_experiments.md.)
+                if (K::LIFE && op == MS_OP_SET_LATENCY) { L.loss_always = (L.loss_always & ~0x70u) | (((a & 3u) + 1u) << 4); pc++; }
+                else st = ST_PANIC;
                 break;
             }
         }

@@ -148,7 +148,6 @@ struct Ctx {
     uint32_t sock0;      // word index of this lane's socket region
     uint32_t heap0;      // uint4 index of heap entry 0: entry i = LDS128(heap0 + (i << lws)); base-op builds: uint2 index
     uint32_t heapm0;     // base-op builds: word index of the meta word of heap entry 0 (k_timer.h)
-    uint32_t heapp0;     // narrow-heap builds, sibling pairs: uint4 index of pair 0 (positions 1 and 2); c.heap0 then is the root's uint2 index
     uint32_t task0;      // uint4 index of task unit 0
     uint32_t task1;      // base-op builds: uint2 index of the 8-byte unit1 array (see "Task state")
     uint32_t insn0;      // uint4 index of the workgroup-shared instruction table
@@ -289,6 +288,10 @@ template <class K> __device__ __forceinline__ WRef<K::G> plane_ref(const Ctx& c,
 // Base-op builds have no owner word: the owner's task slot rides in header bits 24-31 (nmsg keeps 7 bits) — a bound
 // socket's owner is alive (its finish unbinds it, nothing else can kill it), so the slot alone identifies it.
 template <class K> __device__ __forceinline__ uint32_t sock_field(uint32_t f) { return K::LIFE ? f : (f ? f - 1 : 0); }
+// (Round 6 built the words one delivery / one receive touches together — header, owner, first registration, first message word — as ONE
+// 16-byte unit [socket][lane] (VERDICT r5 #1b), bit-exact; A/B on one MI355X, three rounds: topology 5.03 against 5.32 G steps/s (-5.5 %),
+// election loop 9.38 / 9.85 (-4.8 %), KV 11.16 / 12.80 (-13 %).  As with round 4's per-socket granules: lanes of a wave that touch the same
+// word of the same socket share the [word][lane] rows' lines, a 16-byte unit per lane shares a quarter as much.  profiles/r6_ab_socket_unit.txt.)
 #define SW(c_, s_, f_) plane_ref<K>((c_), (c_).sock0, (s_) * (c_).P.sock_words + sock_field<K>(f_))
 template <class K> struct SockHdr { static constexpr uint32_t NMSG_MASK = K::LIFE ? 0xffu : 0x7fu; };
 #define HDR_NMSG(h_) (((h_) >> 17) & SockHdr<K>::NMSG_MASK)

@@ -33,34 +33,22 @@ __device__ __forceinline__ uint4 nh_expand(const Lane& L, const uint2& e) {
     const uint64_t d = L.clock + (uint64_t)(int64_t)(int32_t)(e.x - (uint32_t)L.clock);
     return make_uint4((uint32_t)d, (uint32_t)(d >> 32), e.y, 0);
 }
-// Layout (sim_kernel.h MADSIM_NH_PAIRS): the root in its own 8-byte slot, position i >= 1 as element (i - 1) & 1 of the 16-byte unit of
-// sibling pair (i - 1) >> 1 — pairs [0, (heap_lds - 1) / 2) in LDS as [pair][lane], the others in the spill region as [pair][global lane].
+// Layout: position i as one 8-byte row element [i][lane] in LDS, [i - heap_lds][global lane] in the spill region.  (Round 6 also built SIBLING
+// PAIRS — positions 2q + 1 and 2q + 2 in one 16-byte unit, one access per sift-down level — bit-exact, measured on one MI355X: topology
+// 5.17 against 5.36 G steps/s for the rows (-3.6 %), election loop +1 % (noise): the single-entry stores of a sift, which dominate, coalesce
+// half as well at a 16-byte lane stride.  the layout is in the tree at commit ae53d2e; profiles/r6_experiments.md.)
 template <class K>
 __device__ __forceinline__ uint2 nh_load(const Ctx& c, uint32_t i) {
     const uint32_t cap = c.P.heap_lds;
     uint2 v;
-#if MADSIM_NH_PAIRS
-    const uint32_t q = (i - 1u) >> 1, e = (i - 1u) & 1u, npl = (cap - 1u) >> 1;
-    if (i == 0) v = LDS64(c.heap0);
-    else if (!K::SPILL || i < cap) v = LDS64((c.heapp0 + (q << LWSH<K>(c))) * 2u + e);
-    else v = buf_load64(c.spill, (q - npl) * c.P.total_lanes * 16u + c.spill_off + e * 8u);
-#else
     if (!K::SPILL || i < cap) v = LDS64(c.heap0 + (i << LWSH<K>(c)));
     else v = buf_load64(c.spill, (i - cap) * c.P.total_lanes * 8u + c.spill_off);
-#endif
     return v;
 }
 template <class K>
 __device__ __forceinline__ void nh_store(const Ctx& c, uint32_t i, const uint2& v) {
-#if MADSIM_NH_PAIRS
-    const uint32_t cap = c.P.heap_lds, q = (i - 1u) >> 1, e = (i - 1u) & 1u, npl = (cap - 1u) >> 1;
-    if (i == 0) LDS64(c.heap0) = v;
-    else if (!K::SPILL || i < cap) LDS64((c.heapp0 + (q << LWSH<K>(c))) * 2u + e) = v;
-    else buf_store64(c.spill, (q - npl) * c.P.total_lanes * 16u + c.spill_off + e * 8u, v);
-#else
     if (!K::SPILL || i < c.P.heap_lds) LDS64(c.heap0 + (i << LWSH<K>(c))) = v;
     else buf_store64(c.spill, (i - c.P.heap_lds) * c.P.total_lanes * 8u + c.spill_off, v);
-#endif
 }
 // the delivery-record pool: record r of this lane at [r][global lane], 8 bytes, behind the planes of the state buffer
 __device__ __forceinline__ uint32_t pool_addr(const Ctx& c, uint32_t r) { return __umul24(c.P.pool_off + r * 8u, c.P.total_lanes) + c.gs_lane * 8u; }
@@ -128,19 +116,9 @@ __device__ __forceinline__ void heap_get2(const Ctx& c, const Lane& L, uint32_t 
     if (K::NH) {
         const uint32_t cap = c.P.heap_lds;
         uint2 a, b;
-#if MADSIM_NH_PAIRS
-        if (hi == lo + 1u && (lo & 1u)) {      // siblings (the two children of a sift-down level): one 16-byte unit
-            const uint32_t q = (lo - 1u) >> 1, npl = (cap - 1u) >> 1;
-            uint4 u;
-            if (!K::SPILL || lo < cap) u = LDS128(c.heapp0 + (q << LWSH<K>(c)));
-            else u = buf_load128(c.spill, (q - npl) * c.P.total_lanes * 16u + c.spill_off);
-            a = make_uint2(u.x, u.y); b = make_uint2(u.z, u.w);
-        } else { a = nh_load<K>(c, lo); b = nh_load<K>(c, hi); }      // (grandparent and parent of a sift-up trip)
-#else
         if (K::SPILL && lo >= cap) {       // both spilled: the two loads back to back
             a = buf_load64(c.spill, (lo - cap) * c.P.total_lanes * 8u + c.spill_off); b = buf_load64(c.spill, (hi - cap) * c.P.total_lanes * 8u + c.spill_off);
         } else { a = LDS64(c.heap0 + (lo << LWSH<K>(c))); b = nh_load<K>(c, hi); }
-#endif
         vlo = nh_expand(L, a); vhi = nh_expand(L, b);
         return;
     }

@@ -290,8 +290,7 @@ int madsim_hip_ctx::ensure_scratch(KParams& P, hipStream_t stream, bool work_que
         P.gstate = sc.gstate;
     }
     if (P.heap_spill) {
-        size_t need = P.narrow ? (size_t)(MADSIM_NH_PAIRS ? (P.heap_spill + 2) / 2 * 16 : P.heap_spill * 8) * P.total_lanes      // (sim_kernel.h MADSIM_NH_PAIRS)
-                               : (size_t)P.heap_spill * P.total_lanes * sizeof(uint4);
+        size_t need = (size_t)P.heap_spill * P.total_lanes * (P.narrow ? 8 : sizeof(uint4));
         if (need >= (1ull << 32)) return fail(MADSIM_E_LIMITS, "heap spill region exceeds 4 GiB: lower heap_spill_slots");
         if (need > sc.spill_bytes) {
             if (sc.spill) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(sc.spill); }

@@ -359,7 +359,7 @@ def variant_name(g):
     """The sim_kernel specialisation a madsim_geometry_t selects (madsim_k_launch_sim's dispatch), as rocprofv3 names it."""
     b = lambda x: "true" if x else "false"
     lws = (g.variant >> 16) & 0xf
-    return (f"sim_kernel<Variant<false, {b(g.variant & 1)}, {-1 if lws == 15 else lws}, {(g.variant >> 8) & 0x7f}, "
+    return (f"sim_kernel<Variant<false, {b(g.variant & 1)}, {-1 if lws == 15 else lws}, {(g.variant >> 8) & 0xff}, "
             f"{b(g.variant & 4)}, {b(g.variant & 16)}>>")
 
 

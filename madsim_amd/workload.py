@@ -692,7 +692,10 @@ def streaming_topology_limits():
     lim.max_tasks = 28
     # (round 4: the every-class global-state build runs two waves per SIMD, and the LDS of the third workgroup holds 15 heap entries
     # per seed instead of 8: 4.65 against 4.13 G steps/s)
-    lim.heap_lds_slots, lim.heap_spill_slots = 15, 177
+    # (round 6: 8-byte heap entries — MADSIM_STATE_NARROW_HEAP, every sleep / timeout of the workload is far below the 2.1 s horizon — so the
+    # same LDS holds 31 entries, heap levels 0-4 complete: 5.31 against 4.72 G steps/s, profiles/r6_experiments.md)
+    lim.heap_lds_slots, lim.heap_spill_slots = 31, 161
+    lim.state_mem = A.STATE_NARROW_HEAP
     lim.mbox_regs, lim.mbox_msgs = 6, 5
     lim.max_conns, lim.chan_queue = 4, 1
     return lim
@@ -714,8 +717,11 @@ def raft_election_limits():
     # (with every other lane idle it keeps 0.9 of its rate: tools/experiment/k_experiment.h EXP_HALF_LANES), so half the seeds per
     # wave at twice the LDS per seed — 22 of the ~20 distinct heap entries out of the spill region — wins: 9.25 G steps/s against
     # 8.44 with 64 lanes and 10 entries, 8.87 with 64 lanes, 16 entries and two waves per SIMD (profiles/r4_experiments.md).
-    lim.lanes_per_wave = 32
-    lim.state_mem = A.STATE_GLOBAL | A.STATE_DEDUP_TIMERS
+    # Round 6: 8-byte heap entries (MADSIM_STATE_NARROW_HEAP; the workload's longest sleep is 2 s, inside the horizon) keep on FULL waves the
+    # 20 entries in LDS that round 4 bought with 32 lanes and 22 wide ones — and the lanes are back: 9.83 against 9.2 G steps/s on one box
+    # (32 lanes with 44 narrow entries: 9.72), profiles/r6_experiments.md.
+    lim.lanes_per_wave = 0
+    lim.state_mem = A.STATE_GLOBAL | A.STATE_DEDUP_TIMERS | A.STATE_NARROW_HEAP
     return lim
 
 

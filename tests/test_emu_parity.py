@@ -236,12 +236,13 @@ def test_every_bench_workload_runs_on_the_build_its_ops_need():
     pay for extended ops, mixed workloads take the full build — without general address resolution (FEAT 15) when every
     address is a plain node IP and the state lives in global memory."""
     from madsim_amd import runtime
-    want = {"pingpong": (0, 6, 0), "timers": (0, 15, 0), "raft": (1, 5, 16), "kv": (2, 6, 16), "topo": (15, 6, 16)}   # (raft: 32 seed lanes per wave since round 4 — lane stride 5)
+    want = {"pingpong": (0, 6, 0), "timers": (0, 15, 0), "raft": (1, 6, 16), "kv": (2, 6, 16), "topo": (15, 6, 16)}   # (raft: full waves again since round 6 — the narrow heap entries)
     for name, (feat, lws, glob) in want.items():
         w, lim, _ = W.bench_case(name)
         g = runtime.geometry(w, lim)
         assert ((g.variant >> 8) & 0x1f, (g.variant >> 16) & 0xf, g.variant & 16) == (feat, lws, glob), (name, hex(g.variant))
-        assert (g.global_bytes_per_seed > 0) == bool(glob) and (not glob or g.lanes_per_wave == (32 if name == "raft" else 64))
+        assert (g.global_bytes_per_seed > 0) == bool(glob) and (not glob or g.lanes_per_wave == 64)
+        assert bool((g.variant >> 8) & 0x80) == (name in ("raft", "topo"))            # 8-byte heap entries (MADSIM_STATE_NARROW_HEAP) for the two spilling workloads
         lim.state_mem = A.STATE_LDS                     # the LDS-resident layout stays selectable
         g = runtime.geometry(w, lim)
         assert g.variant & 16 == 0 and g.global_bytes_per_seed == 0
@@ -547,12 +548,16 @@ def _narrow(lim, heap_lds=None):
 
 def test_narrow_heap_switch_selects_builds_with_a_spill_region_and_a_short_horizon():
     topo, raft = W.streaming_topology(), W.raft_election()
-    g = emu.geometry_params(topo, _narrow(W.streaming_topology_limits()))
-    assert g["narrow"] == 1 and g["pool_n"] == 64 and g["lds_per_seed"] < 200
-    wide = emu.geometry_params(topo, W.streaming_topology_limits())
-    assert wide["narrow"] == 0 and g["gs_stride"] == wide["gs_stride"] + 64 * 8            # the record pool behind the planes
-    g = emu.geometry_params(raft, _narrow(W.raft_election_limits(), 44))
-    assert g["narrow"] == 1 and g["heap_lds"] == 43 and g["dedup_n"] == 64                 # with the re-registration counts; the root + 21 sibling pairs (an odd count)
+    g = emu.geometry_params(topo, W.streaming_topology_limits())                           # (the bench case asks for the narrow entries itself)
+    assert g["narrow"] == 1 and g["pool_n"] == 64 and g["heap_lds"] == 31 and g["lds_per_seed"] == 31 * 8 + 48
+    lim = W.streaming_topology_limits(); lim.state_mem &= ~A.STATE_NARROW_HEAP
+    wide = emu.geometry_params(topo, lim)
+    assert wide["narrow"] == 0 and wide["heap_lds"] == 16 and wide["lds_per_seed"] == g["lds_per_seed"]     # the same LDS: 16 entries of 16 bytes
+    assert g["gs_stride"] == wide["gs_stride"] + 64 * 8                                                     # the record pool behind the planes
+    g = emu.geometry_params(raft, W.raft_election_limits())                                # (full waves: what fits beside three waves per SIMD)
+    assert g["narrow"] == 1 and g["heap_lds"] == 20 and g["dedup_n"] == 64                 # with the re-registration counts
+    l32 = W.raft_election_limits(); l32.lanes_per_wave = 32
+    assert emu.geometry_params(raft, _narrow(l32, 44))["heap_lds"] == 44                   # 32 seed lanes per wave: twice the LDS per seed
     # not for: LDS-resident state, connection-only workloads (no build), base ops, a workload that sleeps past 2^31 ns, buggify
     lim = W.raft_election_limits(); lim.state_mem = A.STATE_LDS | A.STATE_NARROW_HEAP; lim.lanes_per_wave = 0
     assert emu.geometry_params(raft, lim)["narrow"] == 0

@@ -27,7 +27,7 @@ from tests import fuzz, lifecycle_workloads as LW
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LDS_PER_CU = 160 * 1024
 E_WORKLOAD, E_LIMITS = -4, -5          # include/madsim_hip.h
-FEAT = dict(TIME=1, CHAN=2, RPC=4, NODE=8, ADDR=16, ALL=31, NOLOG=32, COMPACT=64)
+FEAT = dict(TIME=1, CHAN=2, RPC=4, NODE=8, ADDR=16, ALL=31, NOLOG=32, COMPACT=64, NARROW=128)
 
 
 def compiled_variants():
@@ -49,7 +49,7 @@ COMPILED = compiled_variants()
 def decode(v):
     """madsim_geometry_t.variant -> (spill, lws, feat, rq, g)  (include/madsim_hip.h)."""
     lws = (v >> 16) & 0xf
-    return (bool(v & 1), -1 if (v & 8) else lws, (v >> 8) & 0x7f, bool(v & 4), bool(v & 16))
+    return (bool(v & 1), -1 if (v & 8) else lws, (v >> 8) & 0xff, bool(v & 4), bool(v & 16))
 
 
 def classes_needed(w):
@@ -92,6 +92,8 @@ def check(w, lim, what):
         assert g.heap_spill_slots == 0, (what, "a build without the spill path on a geometry with spilled levels")
     need = classes_needed(w)
     assert need & ~(feat & FEAT["ALL"]) == 0, (what, f"build classes {feat & 31:#x} lack {need & ~feat:#x}")
+    if feat & FEAT["NARROW"]:
+        assert glob and (lim.state_mem & A.STATE_NARROW_HEAP), (what, "8-byte heap entries: global-state builds, on request only")
     if feat & FEAT["COMPACT"]:
         assert rq and not spill and lw == 64 and g.max_tasks <= 8 and (lim.state_mem & 0xff) in (A.STATE_AUTO, A.STATE_GLOBAL, A.STATE_COMPACT), what   # (GLOBAL: ignored for base ops = AUTO)
     if lim.lanes_per_wave:
@@ -121,12 +123,12 @@ def _copy(lim):
 
 def combos(base):
     for sm in (A.STATE_AUTO, A.STATE_LDS, A.STATE_GLOBAL, A.STATE_COMPACT):
-        for dd in (0, A.STATE_DEDUP_TIMERS):
+        for dd in (0, A.STATE_DEDUP_TIMERS, A.STATE_NARROW_HEAP, A.STATE_DEDUP_TIMERS | A.STATE_NARROW_HEAP):
             for lw in (0, 8, 16, 32, 64):
                 for nolog in (0, 1):
                     lim = _copy(base)
                     lim.state_mem, lim.lanes_per_wave, lim.no_trace_hash = sm | dd, lw, nolog
-                    yield lim, f"state_mem={sm}{'|DEDUP' if dd else ''} lanes_per_wave={lw} no_trace_hash={nolog}"
+                    yield lim, f"state_mem={sm}{'|DEDUP' if dd & A.STATE_DEDUP_TIMERS else ''}{'|NARROW' if dd & A.STATE_NARROW_HEAP else ''} lanes_per_wave={lw} no_trace_hash={nolog}"
 
 
 def walk(w, base, name):
@@ -154,9 +156,9 @@ def test_bench_cases_every_layout_and_lane_count(name):
     if name == "pingpong":
         assert feat & FEAT["COMPACT"] and g.blocks_per_cu * g.block_threads // 64 == 16
     if name == "raft":
-        assert glob and g.lanes_per_wave == 32 and (feat & 31) == FEAT["TIME"]
+        assert glob and g.lanes_per_wave == 64 and (feat & 31) == FEAT["TIME"] and (feat & FEAT["NARROW"])     # (full waves again since round 6: 8-byte heap entries)
     if name in ("kv", "topo"):
-        assert glob and g.lanes_per_wave == 64
+        assert glob and g.lanes_per_wave == 64 and bool(feat & FEAT["NARROW"]) == (name == "topo")
 
 
 def test_32_lane_global_layout_only_for_timeout_only_workloads():

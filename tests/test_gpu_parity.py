@@ -365,7 +365,7 @@ def test_config4_streaming_topology_524288_seeds(hip):
     typed-RPC brokers, 12 compute nodes, broker clog + restart), event heap mostly in the HBM spill region."""
     w, lim = W.streaming_topology(), W.streaming_topology_limits()
     g = hip.geometry(w, lim)
-    assert g.heap_spill_slots > 8 * g.heap_lds_slots
+    assert g.heap_spill_slots > 4 * g.heap_lds_slots and (g.variant >> 8) & 0x80       # mostly spilled; 8-byte entries since round 6
     n = 524288
     got, summ = hip.run_batch_auto(w, 0, n, None, lim)
     assert summ.n_failed == 0 and (got["verdict"] == A.PASS).all()
@@ -742,6 +742,10 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(hip):
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
     assert line["config"]["seeds_per_step"] == 2 * 65536 and line["verified_seeds"] >= 2 * 256
     assert line["extra"]["failed_seeds"] == 0 and line["extra"]["seeds_per_sec"] > 0
+    # ... and the seed SEARCH through the same ranks (runtime.run_campaign_over_ranks): pipelined chunks per rank, one all-gather per round
+    ff = line["extra"]["first_fail_over_ranks"]
+    assert ff["world"] == 2 and ff["failed"] == 0 and ff["rounds"] == 3 and ff["seeds_searched"] == 3 * 2 * ff["round_batches_per_rank"] * 65536
+    assert line["extra"]["first_fail_seeds_per_hour"] == ff["seeds_per_hour"] > 0
 
 
 def test_campaign_keeps_batches_in_flight_and_reports_like_the_oracle(hip):
@@ -955,12 +959,15 @@ def _narrow(lim, heap_lds=None):
     return l2
 
 
-@pytest.mark.parametrize("name,quotas", [("topo", (15, 31)), ("raft", (22, 44))])
+@pytest.mark.parametrize("name,quotas", [("topo", (15, 31)), ("raft", (8, 20))])
 def test_narrow_heap_bench_workloads_gpu(hip, name, quotas):
-    """configs[2] / configs[4] shapes on 8-byte heap entries: the same 48 bytes per seed as on the 16-byte entries (65 536 seeds compared
-    with each other at two LDS quotas), contiguous and sampled seeds against the oracle, packet loss."""
+    """configs[2] / configs[4] shapes on 8-byte heap entries (what bench.py runs since round 6): the same 48 bytes per seed as on the 16-byte
+    entries (65 536 seeds compared with each other at two LDS quotas), contiguous and sampled seeds against the oracle, packet loss."""
     w, lim, _ = W.bench_case(name)
-    wide, n_ovf = parity.run_resolved(hip, w, 0, 65536, None, lim)
+    assert (hip.geometry(w, lim).variant >> 8) & 0x80, "the bench case runs the narrow-heap build"
+    wlim = copy_limits(lim); wlim.state_mem &= ~A.STATE_NARROW_HEAP
+    assert not (hip.geometry(w, wlim).variant >> 8) & 0x80
+    wide, n_ovf = parity.run_resolved(hip, w, 0, 65536, None, wlim)
     for q in quotas:
         l2 = _narrow(lim, q)
         assert (hip.geometry(w, l2).variant >> 8) & 0x80, "the narrow-heap build was not selected"
@@ -1193,12 +1200,15 @@ def test_global_state_with_32_seed_lanes_per_wave_gpu(hip, name):
 
 @pytest.mark.gpu
 def test_election_loop_32_and_64_seed_lanes_give_the_same_bytes_gpu(hip):
-    """The bench case of the election loop (32 seed lanes per wave, 22 heap entries in LDS) against the same workload on full waves:
-    65 536 seeds compared with each other, 1 024 contiguous and 128 scattered ones with the oracle."""
-    w, lim = W.raft_election(), W.raft_election_limits()
-    assert lim.lanes_per_wave == 32 and hip.geometry(w, lim).lanes_per_wave == 32
-    full = W.raft_election_limits(); full.lanes_per_wave = 0; full.state_mem = A.STATE_AUTO | A.STATE_DEDUP_TIMERS
-    assert hip.geometry(w, full).lanes_per_wave == 64
+    """Round 4's layout of the election loop (32 seed lanes per wave, 22 wide heap entries in LDS) against the same workload on full waves (the
+    bench case since round 6, on 8-byte heap entries): 65 536 seeds compared with each other, 1 024 contiguous and 128 scattered ones with
+    the oracle."""
+    w, full = W.raft_election(), W.raft_election_limits()
+    g = hip.geometry(w, full)
+    assert full.lanes_per_wave == 0 and g.lanes_per_wave == 64 and (g.variant >> 8) & 0x80
+    lim = W.raft_election_limits(); lim.lanes_per_wave = 32; lim.state_mem = A.STATE_GLOBAL | A.STATE_DEDUP_TIMERS
+    g = hip.geometry(w, lim)
+    assert g.lanes_per_wave == 32 and (g.variant >> 16) & 0xf == 5 and not (g.variant >> 8) & 0x80
     a, na = parity.run_resolved(hip, w, 0, 65536, None, lim)
     b, nb = parity.run_resolved(hip, w, 0, 65536, None, full)
     assert (a == b).all() and na + nb < 0.01 * 65536, (na, nb)

@@ -33,7 +33,7 @@ def _check_schema(rec):
 @pytest.mark.parametrize("name", sorted(T.ALL))
 def test_twin_tables_pass_and_the_oracle_side_matches_the_schema(name):
     w = T.ALL[name]()
-    out, summ = oracle.run_batch(w, 0, 32)
+    out, summ = oracle.run_batch(w, 0, 32, T.config(name))
     if name in T.EXPECT_PANIC:                              # the reference test is #[should_panic]: verdict, no fingerprint tail
         assert (out["verdict"] == 1).all()
         rec = CMP.oracle_record(name, 5)

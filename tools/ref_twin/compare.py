@@ -23,7 +23,7 @@ import oracle                         # noqa: E402
 def oracle_record(name, seed, loss=0.0, want_log=False):
     """One record of the schema, from the CPU oracle."""
     w = T.ALL[name]()
-    cfg = A.Config.default(packet_loss_rate=loss)
+    cfg = T.config(name, loss)
     obs, res = oracle.observe_seed(w, seed, cfg)
     ok = res.verdict == A.PASS
     rec = {"workload": name, "seed": seed, "loss": loss, "verdict": T.VERDICTS[res.verdict],

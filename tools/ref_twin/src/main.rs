@@ -738,6 +738,63 @@ async fn ipvs_round_robin(obs: Obs) -> Tail {
     fingerprint_tail(t0, &obs)
 }
 
+/// `NetSim::update_config(|c| c.send_latency = ..)` between datagrams (net/mod.rs:138-141 -> network.rs:129; sampled at :267): 100..101 ms,
+/// 1.5..3.5 s, 1..2 ns; the receiver observes when each datagram arrives.  Table: twin_workloads.py::update_config_latency.
+async fn update_config_latency(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let node1 = h.create_node().ip("10.0.0.1".parse().unwrap()).build();
+    let node2 = h.create_node().ip("10.0.0.2".parse().unwrap()).build();
+    let o = obs.clone();
+    let rx = node2.spawn(async move {
+        let ep = Endpoint::bind("10.0.0.2:1").await.unwrap();
+        let mut buf = [0u8; 4];
+        for tag in 1..=4u64 {
+            ep.recv_from(tag, &mut buf).await.unwrap();
+            o.push(t0.elapsed().as_nanos() as u64);                 // MS_OP_TRACE_TIME a=1
+        }
+    });
+    let tx = node1.spawn(async move {
+        let t1 = Instant::now();                                    // the table's `mark`
+        let ep = Endpoint::bind("10.0.0.1:1").await.unwrap();
+        time::sleep(Duration::from_millis(10)).await;
+        let net = NetSim::current();
+        ep.send_to("10.0.0.2:1", 1, &[0xA]).await.unwrap();
+        net.update_config(|c| c.send_latency = Duration::from_millis(100)..Duration::from_millis(101));
+        ep.send_to("10.0.0.2:1", 2, &[0xB]).await.unwrap();
+        net.update_config(|c| c.send_latency = Duration::from_millis(1500)..Duration::from_millis(3500));
+        ep.send_to("10.0.0.2:1", 3, &[0xC]).await.unwrap();
+        time::sleep_until(t1 + Duration::from_secs(5)).await;
+        net.update_config(|c| c.send_latency = Duration::from_nanos(1)..Duration::from_nanos(2));
+        ep.send_to("10.0.0.2:1", 4, &[0xD]).await.unwrap();
+    });
+    rx.await.unwrap();
+    tx.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
+/// One task on both ends of its own connection (net/mod.rs:337-364, endpoint.rs:196-212): the pair `accept1` returns replaces the client
+/// pair, whose handles drop at the assignment.  Table: twin_workloads.py::self_connect_accept.
+async fn self_connect_accept(obs: Obs) -> Tail {
+    let t0 = Instant::now();
+    let h = Handle::current();
+    let node = h.create_node().ip("10.0.0.1".parse().unwrap()).build();
+    let o = obs.clone();
+    let f = node.spawn(async move {
+        let ep = Endpoint::bind("10.0.0.1:1").await.unwrap();
+        let (mut tx, mut rx) = ep.connect1("10.0.0.1:1".parse().unwrap()).await.unwrap();
+        tx.send(payload(5)).await.unwrap();
+        time::sleep(Duration::from_millis(20)).await;
+        (tx, rx, _) = ep.accept1().await.unwrap();                  // the right-hand side first, then the old pair drops
+        o.push(value(rx.recv().await.unwrap()));
+        assert_eq!(rx.recv().await.err().unwrap().kind(), std::io::ErrorKind::ConnectionReset);
+        o.push(1);
+        drop(tx);
+    });
+    f.await.unwrap();
+    fingerprint_tail(t0, &obs)
+}
+
 /// The 4-node ping-pong built ONCE with the Rust workload DSL (bindings/rust/madsim-hip, `pingpong_twin`) and interpreted on
 /// real madsim by `madsim_hip::interp` — the table `Builder::run_workload` hands to the GPU runner, run here by the reference.
 async fn pingpong4_dsl(obs: Obs) -> Tail {
@@ -787,6 +844,8 @@ fn run_one(name: &str, seed: u64, loss: f64) -> String {
                 "ipvs_runtime" => ipvs_runtime(o).await,
                 "pingpong4_dsl" => pingpong4_dsl(o).await,
                 "ns_ties" => ns_ties(o).await,
+                "update_config_latency" => update_config_latency(o).await,
+                "self_connect_accept" => self_connect_accept(o).await,
                 other => panic!("unknown workload {other}"),
             }
         });
@@ -812,7 +871,8 @@ const ALL: &[&str] = &["pingpong2", "pingpong4", "pingpong16", "sleep_1s", "yiel
                        "restart_on_panic", "receiver_drop", "localhost", "restart_on_panic_matching", "bind_ephemeral",
                        "channel_wildcard", "guard_keeps_address", "spawn_in_drop_abort", "spawn_in_drop_kill",
                        "spawn_after_own_restart", "join_names_its_task", "abort_own_handle", "rpc_hooks", "panic_substrings",
-                       "rebind_in_flight", "ipvs_round_robin", "ipvs_runtime", "pingpong4_dsl", "ns_ties"];
+                       "rebind_in_flight", "ipvs_round_robin", "ipvs_runtime", "pingpong4_dsl", "ns_ties", "update_config_latency",
+                       "self_connect_accept"];
 
 fn main() {
     let args: Vec<String> = std::env::args().collect();

@@ -483,6 +483,49 @@ def ns_ties():
     return wl.build()
 
 
+def update_config_latency():
+    """`NetSim::current().update_config(|c| c.send_latency = lo..hi)` between datagrams (net/mod.rs:138-141 -> network.rs:129; every link
+    test samples the range in force, :267): 100..101 ms (UniformDuration's Small path), 1.5..3.5 s (Medium path), 1..2 ns.  The receiver
+    observes the Instant of every arrival.  Round 6 (the latency half); the ranges: config() below."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a_tx, a_rx = wl.addr(n1, 1), wl.addr(n2, 1)
+    rx = wl.task(n2); rx.bind(a_rx)
+    for tag in (1, 2, 3, 4):
+        rx.recv_from(a_rx, tag); rx.trace_instant()
+    rx.done()
+    tx = wl.task(n1); tx.mark(); tx.bind(a_tx); tx.sleep(ms=10)
+    tx.send_to(a_tx, a_rx, 1, 0xA)
+    tx.set_latency(0); tx.send_to(a_tx, a_rx, 2, 0xB)
+    tx.set_latency(1); tx.send_to(a_tx, a_rx, 3, 0xC)
+    tx.sleep_until(secs=5); tx.set_latency(2); tx.send_to(a_tx, a_rx, 4, 0xD); tx.done()
+    m = wl.main(); m.spawn(rx); m.spawn(tx); m.join(rx); m.join(tx)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def self_connect_accept():
+    """One task on both ends of its own connection (net/mod.rs:337-364, endpoint.rs:196-212): `ep.connect1(ep's own address)`, a payload
+    sent from the client end, then `(tx, rx, _) = ep.accept1()` — the accepted pair replaces the client pair, whose Sender and Receiver
+    drop at that assignment: the accepted Receiver yields the payload, then ConnectionReset.  obs <- 5, then 1 for the reset.
+    (The round-4 advisor finding — a stale connection header written back in the global-state builds — as a reference twin.)"""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    a = wl.addr(n, 1)
+    t = wl.task(n); t.bind(a); t.connect1(a, a); t.assert_val(0); t.chan_send(5); t.sleep(ms=20)
+    t.accept1(a); t.chan_recv(); t.trace_val(); t.chan_recv(); t.assert_val(A.VAL_RESET); t.trace(1); t.done()
+    m = wl.main(); m.spawn(t); m.join(t)
+    fingerprint_tail(m)
+    return wl.build()
+
+
+def config(name, loss=0.0):
+    """The Config a twin runs under: Config::default() with the run's packet_loss_rate; `update_config_latency` brings its ranges."""
+    if name == "update_config_latency":
+        return A.Config.default(packet_loss_rate=loss, lat_table=((100_000_000, 101_000_000), (1_500_000_000, 3_500_000_000), (1, 2)))
+    return A.Config.default(packet_loss_rate=loss)
+
+
 # workloads that end in a panic by design (the reference test is #[should_panic])
 EXPECT_PANIC = {"restart_on_panic_matching", "panic_substrings"}
 
@@ -500,4 +543,6 @@ ALL = {
     "ipvs_round_robin": ipvs_round_robin, "ipvs_runtime": ipvs_runtime,
     "pingpong4_dsl": lambda: pingpong(4, 64),          # the same table, built by madsim_hip::pingpong_twin and run by madsim_hip::interp
     "ns_ties": ns_ties,                                # deadlines equal to the nanosecond: the heap's tie order for real
+    # round 6: the (f) rows closed since round 3 — run-time send_latency (8f row 1), a task on both ends of its own connection
+    "update_config_latency": update_config_latency, "self_connect_accept": self_connect_accept,
 }
