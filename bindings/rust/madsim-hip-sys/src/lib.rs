@@ -279,6 +279,7 @@ extern "C" {
     pub fn madsim_hip_build_info() -> *const c_char;
     pub fn madsim_hip_strerror(code: c_int) -> *const c_char;
     pub fn madsim_hip_last_error() -> *const c_char;
+    pub fn madsim_hip_prefer_hw_queues(n: c_int) -> c_int;
     pub fn madsim_hip_ctx_create(device: c_int, out: *mut *mut madsim_hip_ctx_t) -> c_int;
     pub fn madsim_hip_ctx_destroy(ctx: *mut madsim_hip_ctx_t) -> c_int;
     pub fn madsim_hip_ctx_device(ctx: *const madsim_hip_ctx_t) -> c_int;

@@ -135,10 +135,14 @@ __device__ __forceinline__ void mailbox_deliver(const Ctx& c, Lane& L, uint32_t 
             if ((r & 0xff) == tag && (!rsp || (r >> 8) == (val >> 8))) {
                 nreg--;
                 uint32_t slot = (r >> 8) & 0xff, rxseq = (r >> 16) & 0xff, g8 = r >> 24;
-                const uint32_t moved = SW(c, s, 2 + nreg);  // swap_remove: the three loads first, then the store
+                // swap_remove: the three loads first, then the store.  (Global-state builds: when the match IS the last registration — the
+                // usual mailbox holds one — nothing moves: no load of the last entry, no store over a position that is no longer part of
+                // the list.)
+                const bool last = K::G && i == nreg;
+                const uint32_t moved = last ? r : (uint32_t)SW(c, s, 2 + nreg);
                 uint4 u0 = TU(c, slot, 0);
                 uint32_t link = TWORD(c, slot, 1, 0);
-                SW(c, s, 2 + i) = moved;
+                if (!last) SW(c, s, 2 + i) = moved;
                 if (K::G) { known = true; r_known = moved; }
                 if ((u0.x & TF_ALIVE) && ((u0.x >> 8) & 0xff) == g8 && (link & 0xff) == rxseq && !(u0.x & TF_INBOX)) {
                     // oneshot::Sender::send Ok -> value stored, receiver task woken [DEP tokio oneshot]

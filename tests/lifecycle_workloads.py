@@ -915,6 +915,47 @@ CONFIGS["update_config_latency"] = dict(lat_table=((100_000_000, 101_000_000), (
 CONFIGS["update_config_latency_channel"] = dict(lat_table=((200_000_000, 201_000_000),))
 
 
+# ---- MADSIM_STATE_NARROW_HEAP: the two run-time conditions that send a seed back to the 16-byte entries (k_timer.h timer_add) -----------
+
+def narrow_heap_backoff_past_the_horizon():
+    """-> (workload, limits).  A channel receiver whose link stays clogged for 5.7 s: its back-off doubles to 4 096 ms (net/mod.rs:388-398), a
+    deadline the 8-byte entries' 2^31 ns horizon cannot hold — nothing in the table says so (every sleep is below 2 s).  Every op class is
+    present (a timeout, a typed call, a kill) so that the build is the one that carries the narrow-heap variant."""
+    wl = W.WorkloadBuilder()
+    ns, nc, nx = wl.create_node(), wl.create_node(), wl.create_node()
+    asv, acl, ax = wl.addr(ns, 1), wl.addr(nc, 1), wl.addr(nx, 1)
+    srv = wl.task(ns); srv.bind(asv); srv.accept1(asv); srv.mark(); srv.chan_recv(); srv.assert_val(7); srv.assert_elapsed(">=", secs=5); srv.trace_instant()
+    cl = wl.task(nc); cl.bind(acl); cl.sleep(ms=10); cl.connect1(acl, asv); cl.assert_val(0); cl.sleep(ms=100); cl.chan_send(7); cl.sleep(secs=1)
+    idle = wl.task(nx); idle.bind(ax); idle.recv_from_timeout(ax, 1, ms=20); idle.rpc_call(ax, asv, 0, 1, timeout_ms=5)
+    m = wl.main(); m.spawn(srv); m.spawn(cl); m.spawn(idle); m.sleep(ms=50); m.clog_link(nc, ns); m.sleep(ms=1900); m.sleep(ms=1900); m.sleep(ms=1900)
+    m.kill(nx); m.unclog_link(nc, ns); m.join(srv)
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 2, 30; lim.mbox_regs, lim.mbox_msgs = 4, 4
+    return wl.build(), lim
+
+
+def narrow_heap_forty_datagrams_in_flight():
+    """-> (workload, config, limits).  Ten senders x four datagrams under a 400-800 ms latency: forty deliveries in flight at once, more than the
+    32 records a small heap's pool holds."""
+    wl = W.WorkloadBuilder()
+    n1, n2 = wl.create_node(), wl.create_node()
+    a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
+    rx = wl.task(n2); rx.bind(a2); rx.set(0, 40); top = rx.label(); rx.recv_from_timeout(a2, 1, ms=900); rx.trace_val(); rx.djnz(0, top)
+    senders = []
+    for k in range(10):
+        t = wl.task(n1); t.sleep(ms=5)
+        for _ in range(4):
+            t.send_to(a1, a2, 1, 0x100 + k)
+        senders.append(t)
+    b = wl.task(n1); b.bind(a1); b.sleep(secs=1)
+    m = wl.main(); m.spawn(b); m.spawn(rx); m.sleep(ms=3)
+    for t in senders:
+        m.spawn(t)
+    m.join(rx)
+    cfg = A.Config.default(lat_lo_ns=400_000_000, lat_hi_ns=800_000_000)
+    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 4, 60; lim.mbox_regs, lim.mbox_msgs = 4, 48; lim.max_tasks = 16
+    return wl.build(), cfg, lim
+
+
 def model_ceiling_workloads():
     """One workload per ceiling of the device runner's workload MODEL (include/madsim_hip.h MADSIM_UNSUPPORTED): (name, workload, limits,
     the oracle's event bit — oracle/madsim_oracle.h MADSIM_ORACLE_ME_*).  The reference itself has none of these ceilings."""

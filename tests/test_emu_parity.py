@@ -591,16 +591,7 @@ def test_narrow_heap_horizon_is_a_capacity_verdict_and_the_rerun_is_wide():
     ask for one by itself (above); what only shows at run time — a channel back-off that doubled past 2 s under a long partition
     (net/mod.rs:388-398) — is a capacity verdict on that seed, and the re-run (tests/parity.py grow = madsim_hip.cpp grow) leaves the
     narrow layout and answers what the oracle answers."""
-    wl = W.WorkloadBuilder()
-    ns, nc, nx = wl.create_node(), wl.create_node(), wl.create_node()
-    asv, acl, ax = wl.addr(ns, 1), wl.addr(nc, 1), wl.addr(nx, 1)
-    srv = wl.task(ns); srv.bind(asv); srv.accept1(asv); srv.mark(); srv.chan_recv(); srv.assert_val(7); srv.assert_elapsed(">=", secs=5); srv.trace_instant()
-    cl = wl.task(nc); cl.bind(acl); cl.sleep(ms=10); cl.connect1(acl, asv); cl.assert_val(0); cl.sleep(ms=100); cl.chan_send(7); cl.sleep(secs=1)
-    idle = wl.task(nx); idle.bind(ax); idle.recv_from_timeout(ax, 1, ms=20); idle.rpc_call(ax, asv, 0, 1, timeout_ms=5)    # every op class: the build that has the variant
-    m = wl.main(); m.spawn(srv); m.spawn(cl); m.spawn(idle); m.sleep(ms=50); m.clog_link(nc, ns); m.sleep(ms=1900); m.sleep(ms=1900); m.sleep(ms=1900)
-    m.kill(nx); m.unclog_link(nc, ns); m.join(srv)
-    w = wl.build()
-    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 2, 30; lim.mbox_regs, lim.mbox_msgs = 4, 4
+    w, lim = LW.narrow_heap_backoff_past_the_horizon()
     l2 = _narrow(lim)
     assert emu.geometry_params(w, l2)["narrow"] == 1
     o, _ = oracle.run_batch(w, 0, 64, None, l2)
@@ -611,24 +602,7 @@ def test_narrow_heap_horizon_is_a_capacity_verdict_and_the_rerun_is_wide():
 
 def test_narrow_heap_pool_exhaustion_is_a_capacity_verdict():
     """More datagrams in flight than the record pool holds (32 with a small heap): MADSIM_OVERFLOW, re-run, compared."""
-    wl = W.WorkloadBuilder()
-    n1, n2 = wl.create_node(), wl.create_node()
-    a1, a2 = wl.addr(n1, 1), wl.addr(n2, 1)
-    rx = wl.task(n2); rx.bind(a2); rx.set(0, 40); top = rx.label(); rx.recv_from_timeout(a2, 1, ms=900); rx.trace_val(); rx.djnz(0, top)
-    senders = []
-    for k in range(10):
-        t = wl.task(n1); t.sleep(ms=5)
-        for _ in range(4):
-            t.send_to(a1, a2, 1, 0x100 + k)
-        senders.append(t)
-    b = wl.task(n1); b.bind(a1); b.sleep(secs=1)
-    m = wl.main(); m.spawn(b); m.spawn(rx); m.sleep(ms=3)
-    for t in senders:
-        m.spawn(t)
-    m.join(rx)
-    w = wl.build()
-    cfg = A.Config.default(lat_lo_ns=400_000_000, lat_hi_ns=800_000_000)
-    lim = A.Limits(); lim.heap_lds_slots, lim.heap_spill_slots = 4, 60; lim.mbox_regs, lim.mbox_msgs = 4, 48; lim.max_tasks = 16
+    w, cfg, lim = LW.narrow_heap_forty_datagrams_in_flight()
     l2 = _narrow(lim)
     g = emu.geometry_params(w, l2)
     assert g["narrow"] == 1 and g["pool_n"] == 32

@@ -633,7 +633,7 @@ def test_ref_twin_workloads_gpu(hip):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ref_twin"))
     import twin_workloads as T
     for name in sorted(T.ALL):
-        _cmp(hip, T.ALL[name](), 0, 512, None, T.limits(name))
+        _cmp(hip, T.ALL[name](), 0, 512, T.config(name), T.limits(name))
     _cmp(hip, T.ALL["pingpong4"](), 0, 512, A.Config.default(packet_loss_rate=0.01))
 
 
@@ -976,6 +976,24 @@ def test_narrow_heap_bench_workloads_gpu(hip, name, quotas):
     want, _ = oracle.run_batch(w, 50000, 768, None, lim)
     assert (wide[50000:50768] == want).all()
     _cmp(hip, w, 8_100_000, 1024, A.Config.default(packet_loss_rate=0.04), _narrow(hip.grow_limits(lim), quotas[0]))
+
+
+def test_narrow_heap_reruns_leave_the_layout_gpu(hip):
+    """The two run-time conditions the 8-byte entries cannot hold — a channel back-off past the 2^31 ns horizon, more datagrams in flight than the
+    record pool has records — are capacity verdicts of the plain call, and `madsim_hip_run_batch_auto` answers them on the 16-byte entries with
+    the oracle's bytes (madsim_hip.cpp grow() clears MADSIM_STATE_NARROW_HEAP)."""
+    from tests import lifecycle_workloads as LW
+    w, lim = LW.narrow_heap_backoff_past_the_horizon()
+    l2 = _narrow(lim)
+    assert (hip.geometry(w, l2).variant >> 8) & 0x80
+    first, _ = hip.run_batch(w, 0, 512, None, l2)
+    assert (first["verdict"] == A.OVERFLOW).all()
+    parity.gpu_compare(hip, w, 0, 512, None, l2, "narrow horizon", TALLY, "narrow horizon")
+    w, cfg, lim = LW.narrow_heap_forty_datagrams_in_flight()
+    l2 = _narrow(lim)
+    first, _ = hip.run_batch(w, 0, 512, cfg, l2)
+    assert (first["verdict"] == A.OVERFLOW).any()
+    parity.gpu_compare(hip, w, 0, 512, cfg, l2, "narrow pool", TALLY, "narrow pool")
 
 
 def test_narrow_heap_fuzz_gpu(hip):

@@ -6,7 +6,10 @@ set -u
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$1; mkdir -p $OUT
 CMD="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-verify --no-first-fail --no-extras --no-measure-traffic ${2:-}"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+# the stats pass runs what bench.py's live trace pass runs (measure_counters "TRACE": 40 steps after 10, one region), so that the AverageNs of
+# sim_kernel here and roofline.launch_ms in the bench line are the same measurement (round 6; the PMC passes below serialise launches and stay short)
+TCMD="python $R/bench.py --steps 40 --warmup 10 --repeats 1 --no-cpu-baseline --no-verify --no-first-fail --no-extras --no-measure-traffic ${2:-}"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $TCMD > $OUT/trace.log 2>&1
 SETS=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"
       "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU")
 if [ "${3:-}" = "full" ]; then
