@@ -254,6 +254,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     for (;;) {
         // global-state builds: the Timer::add calls of the previous round happen here, at one site for the whole wave
         timer_flush<K>(c, L, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot);
+        PROBE_FLUSH();          // (EXP_PROF builds: the pushes apart from the wait for the other lanes' further rounds behind the loop)
         if (st != ST_RUN) break;
         // (pc < n_insns always: validate() checks jump targets and that the table ends in DONE / JMP / PANIC)
         uint4 in = insn_fetch<K>(c, L, pc);

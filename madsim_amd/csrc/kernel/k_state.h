@@ -19,6 +19,7 @@ namespace madsim_k {
 #define MADSIM_K_LOG_ENABLED 1
 #define PROBE(i) do { } while (0)
 #define PROBE2(i) do { } while (0)
+#define PROBE_FLUSH() do { } while (0)
 #endif
 #define FNV_OFFSET 14695981039346656037ull
 #define FNV_PRIME 1099511628211ull

@@ -289,6 +289,43 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
         uint4 top = heap_get<K>(c, L, 0);
         uint32_t pos = 0, child = 1;
         uint4 m = item;                                     // the entry last moved up: it now sits at parent(pos)
+        if (MADSIM_POP_TOPDOWN && K::G && K::SPILL) {
+            // The same final array top-down.  sift_down_to_bottom moves the smaller child up on every level of the path (the right one on a tie), then
+            // sift_up carries `item` back up past every path entry with a deadline GREATER than its own — the path's deadlines do not decrease
+            // downwards, so those are a suffix of it and every one of them returns to the slot it came from.  Stopping at the first path entry that
+            // is greater and storing `item` there writes exactly the slots that end up different, and skips the loads of the levels below and
+            // the stores that would be undone.  (Measured: election loop +2 %, topology +0.1 %; the KV's build — no spill region, a heap of a few LDS
+            // entries — read 0.3 % slower with it and keeps the literal form.  Also built: two spilled levels per global round trip, the children's
+            // children loaded with them — topology and election loop both -0.8 %: the extra lane accesses cost more than the round trip.
+            // profiles/r6_experiments.md)
+            const uint64_t idl = ev_deadline(item);
+            bool go = child + 1 < end, stopped = false;
+            while (go) {                                   // (one exit: see k_main.h)
+                REG(21);
+                uint4 l, r;
+                heap_get2<K>(c, L, child, child + 1, l, r);
+                const bool right = ev_deadline(l) >= ev_deadline(r);
+                m = right ? r : l;
+                go = ev_deadline(m) <= idl;
+                if (go) {
+                    heap_set<K>(c, L, pos, m);
+                    if (pos == 0) L.top_dl = ev_deadline(m);
+                    pos = child + (right ? 1u : 0u);
+                    child = 2 * pos + 1;
+                    go = child + 1 < end;
+                } else stopped = true;
+            }
+            if (!stopped && child == end - 1) {
+                m = heap_get<K>(c, L, child);
+                if (ev_deadline(m) <= idl) {
+                    heap_set<K>(c, L, pos, m);
+                    if (pos == 0) L.top_dl = ev_deadline(m);
+                    pos = child;
+                }
+            }
+            heap_set<K>(c, L, pos, item);
+            if (pos == 0) L.top_dl = idl;
+        } else {
         while (child + 1 < end) {
             REG(21);
             uint4 l, r;
@@ -315,6 +352,7 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
             else heap_set<K>(c, L, pos, item);
         } else {
             heap_sift_up<K>(c, L, pos, item);
+        }
         }
         item = top;
     } else {

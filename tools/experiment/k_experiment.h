@@ -32,8 +32,12 @@
 #endif
 #ifdef EXP_PROF
 #define PROBE(i) do { uint64_t t_ = __builtin_readcyclecounter(); L.prof_acc[i] += t_ - L.prof_t; L.prof_t = t_; } while (0)
+// the top of a poll round, behind timer_flush: bucket 10 = the previous round's [C] tail + the pushes; what PROBE(9) behind the loop then collects is
+// the wait for the other lanes' further rounds (the probes are lane 0's: a lane that leaves after one round waits there for the slowest lane)
+#define PROBE_FLUSH() PROBE(10)
 #else
 #define PROBE(i) do { } while (0)
+#define PROBE_FLUSH() do { } while (0)
 #endif
 
 // -DEXP_HALF_LANES[=n]: only every n-th lane of a wave (default 2) carries seeds, each of them n seeds of the launch one after the other; the

@@ -32,7 +32,8 @@ else:
 L.madsim_hip_debug_counters(out)
 v = list(out)
 names = ["loop top/seed init+result", "idx draw + ready pop + task load", "poll_task exit (writeback u1)", "writeback + advance draw", "fire/idle loop",
-         "poll: entry, u1 load, insn fetch", "poll [A] await check + completion (try_send)", "poll [B] light ops", "poll [C] begin op (mailbox / rare switch)", "poll [C] rand_delay draw + timer push"]
+         "poll: entry, u1 load, insn fetch", "poll [A] await check + completion (try_send)", "poll [B] light ops", "poll [C] begin op (mailbox / rare switch)", "behind the poll loop: wait for other lanes' further rounds",
+         "poll [C] rand_delay draw + timer_flush (pushes); first round: poll entry"]
 waves, iters = v[13], v[12]
 tot = sum(v[:12])
 if os.environ.get("PROF2"):
