@@ -289,12 +289,12 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
         uint4 top = heap_get<K>(c, L, 0);
         uint32_t pos = 0, child = 1;
         uint4 m = item;                                     // the entry last moved up: it now sits at parent(pos)
-        if (MADSIM_POP_TOPDOWN && K::G && K::SPILL) {
+        if (MADSIM_POP_TOPDOWN && K::SPILL) {
             // The same final array top-down.  sift_down_to_bottom moves the smaller child up on every level of the path (the right one on a tie), then
             // sift_up carries `item` back up past every path entry with a deadline GREATER than its own — the path's deadlines do not decrease
             // downwards, so those are a suffix of it and every one of them returns to the slot it came from.  Stopping at the first path entry that
             // is greater and storing `item` there writes exactly the slots that end up different, and skips the loads of the levels below and
-            // the stores that would be undone.  (Measured: election loop +2 %, topology +0.1 %; the KV's build — no spill region, a heap of a few LDS
+            // the stores that would be undone.  (Measured: election loop +2 %, timer storm +2.2 %, topology +0.1 %; the KV's build — no spill region, a heap of a few LDS
             // entries — read 0.3 % slower with it and keeps the literal form.  Also built: two spilled levels per global round trip, the children's
             // children loaded with them — topology and election loop both -0.8 %: the extra lane accesses cost more than the round trip.
             // profiles/r6_experiments.md)

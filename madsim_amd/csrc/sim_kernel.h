@@ -40,7 +40,7 @@
 #ifndef MADSIM_FIRE_COPIES
 #define MADSIM_FIRE_COPIES 1
 #endif
-/* Global-state builds with a spill region: BinaryHeap::pop written top-down (k_timer.h timer_pop) — the array sift_down_to_bottom + sift_up leave, without the
+/* Builds with a spill region: BinaryHeap::pop written top-down (k_timer.h timer_pop) — the array sift_down_to_bottom + sift_up leave, without the
    levels below the moved entry's final slot. */
 #ifndef MADSIM_POP_TOPDOWN
 #define MADSIM_POP_TOPDOWN 1
