@@ -21,7 +21,7 @@ gens = [("plain", fuzz.random_workload, None), ("lifecycle", fuzz.random_lifecyc
         ("op_soup", fuzz.random_unstructured_workload, 16), ("latency", fuzz.random_latency_workload, None)]
 if len(sys.argv) > 3:                              # optional: only the generators whose name contains one of these (comma-separated)
     gens = [g for g in gens if any(x in g[0] for x in sys.argv[3].split(","))]
-t0 = time.time(); k = 0; tally = parity.Tally()
+t0 = time.time(); k = 0; tally = parity.Tally(); n_narrow = 0
 while time.time() - t0 < budget:
     name, gen, max_tasks = gens[k % len(gens)]
     w, cfg, desc = gen(random.Random(base + k))
@@ -32,10 +32,15 @@ while time.time() - t0 < budget:
         if name == "timeouts":
             lim.state_mem |= A.STATE_DEDUP_TIMERS      # re-registered Sleep timers as counts (k_timer.h dedup_note)
             if (k // len(gens)) % 4 == 3: lim.lanes_per_wave = 32     # ... on 32 seed lanes per wave (the election loop's layout since round 4)
+        if (k // len(gens)) % 8 >= 5:     # every other global round: 8-byte heap entries + delivery record pool (round 6), a small LDS quota so that the
+            lim.state_mem |= A.STATE_NARROW_HEAP          # spill region is in use; honoured where a narrow build exists for the program's op classes
+            q = 1 + (k // len(gens)) % 5
+            lim.heap_spill_slots, lim.heap_lds_slots = lim.heap_spill_slots + max(0, lim.heap_lds_slots - q), q
     if k % 5 == 4:                    # every fifth program in the reference's plain mode: no determinism-log fingerprint (rand.rs:67)
         lim.no_trace_hash = 1
     n = 96
-    try:                # every seed is compared: first-pass capacity verdicts go through madsim_hip_run_batch_auto and are then held against the oracle
+    try:
+        if (runtime.geometry(w, lim).variant >> 8) & 0x80: n_narrow += 1                # every seed is compared: first-pass capacity verdicts go through madsim_hip_run_batch_auto and are then held against the oracle
         parity.gpu_compare(runtime, w, 1000 + 7 * k, n, cfg, lim, name, tally, (f"generator={name} gen_seed={base + k}", desc))
     except runtime.MadsimHipError:            # refused by validate() (the op-soup generator writes programs that are): nothing to compare
         k += 1
@@ -48,5 +53,6 @@ verdicts = np.bincount(np.array(sorted(tally.verdicts), dtype=np.int64), minleng
 print(f"fuzz campaign ok: {k} workloads, {tally.n} seeds in {time.time() - t0:.0f} s, all 48 result bytes of EVERY seed equal to the oracle's; "
       f"{tally.rerun} of them after a re-run with grown capacities (first pass MADSIM_OVERFLOW); unresolved: {tally.unresolved} "
       f"(proven beyond the layout's ceilings by the oracle's high-water marks; anything else fails); oracle verdicts seen: {sorted(tally.verdicts)}")
+print(f"programs run on the narrow-heap builds: {n_narrow}")
 print("per generator:", tally)
 if tally.reasons: print("beyond the ceilings, by capacity (the oracle's high-water mark of the seed exceeds what the layout can hold at all):", tally.reasons)
