@@ -29,6 +29,7 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
 #define SPLITMIX(dst) x += 0x9e3779b97f4a7c15ull; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; dst = z ^ (z >> 31)
     SPLITMIX(L.s0); SPLITMIX(L.s1); SPLITMIX(L.s2); SPLITMIX(L.s3);
 #undef SPLITMIX
+    L.peek = rng_out(L);                                   // (k_rng.h Peek: the first with() has no log entry before it)
     L.rng_calls = 0; L.clock = 0; L.msg_count = 0; L.steps = 0;
     L.pq_n = 0; L.ready_len = 0; L.rq = 0; L.heap_len = 0; L.top_dl = ~0ull; L.top_meta = 0; L.verdict = MADSIM_RUNNING; L.ovf = 0; L.main_done = 0;
     L.loss_pint = P.loss_pint; L.loss_always = P.loss_always;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256, K::CMP ? 4 : !K::G ? 1 : (K::FEAT & (MADSIM_FE
                     // delay = gen_range(1 s..10 s) in ONE with(): UniformDuration Medium path [DEP A.3]
                     const uint64_t range = 9000000000ull, zone = ~0ull - ((~0ull - range + 1) % range);
                     uint64_t v;
-                    do { v = rng_next(L); } while (v * range > zone);
+                    do { v = rng_next(L); } while (v * range > zone);       // (an extended-build path: no peek, k_rng.h)
                     rng_log<K>(c, L);
                     uint64_t delay = NS_PER_S + __umul64hi(v, range);
                     node_kill<K>(c, L, node);                 // self.kill(node_id)

@@ -8,8 +8,8 @@ namespace madsim_k {
 // ---- GlobalRng ---------------------------------------------------------------------------------
 // Xoshiro256PlusPlus::next_u64 [DEP rand_xoshiro 0.6] without the call counter (rng_next below counts; the rejection loops
 // count their trips in a 32-bit register — a full-rate v_add_u32 per trip — and add once per draw)
-__device__ __forceinline__ uint64_t rng_step(Lane& L) {
-    uint64_t r = add64_1(rotl64<23>(L.s0 + L.s3), L.s0);
+__device__ __forceinline__ uint64_t rng_out(const Lane& L) { return add64_1(rotl64<23>(L.s0 + L.s3), L.s0); }
+__device__ __forceinline__ void rng_advance(Lane& L) {
     // s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= s1 << 17 with the two three-input xors as one v_bitop3_b32 per half
     const uint64_t t = shl64<17>(L.s1);
     const uint64_t d1 = L.s3 ^ L.s1;
@@ -17,11 +17,30 @@ __device__ __forceinline__ uint64_t rng_step(Lane& L) {
     const uint64_t c2 = xor3_64(L.s2, L.s0, t);
     L.s0 ^= d1; L.s1 = b1; L.s2 = c2;
     L.s3 = rotl64<45>(d1);
+}
+__device__ __forceinline__ uint64_t rng_step(Lane& L) {
+    const uint64_t r = rng_out(L);
+    rng_advance(L);
     return r;
 }
 __device__ __forceinline__ uint64_t rng_next(Lane& L) {
     L.rng_calls++;
     return rng_step(L);
+}
+// Builds that keep the determinism log hold the output of the CURRENT state in Lane::peek: the log's entry for a with() is a byte of
+// `rng.clone().gen()` (rand.rs:64-88), i.e. of the next with()'s first output, so rng_log computes that number anyway.  gen_index's hot loop starts from it.
+template <class K> struct Peek { static constexpr bool ON = MADSIM_RNG_PEEK && MADSIM_K_LOG_ENABLED && !K::NOLOG && (!K::LIFE || MADSIM_RNG_PEEK_LIFE), ALL = ON && MADSIM_RNG_PEEK > 1; };
+
+// One with()'s rejection loop: outputs until `rej` accepts one.
+// (Round 6 measured the first trip PEELED — it takes the peek and only advances, four VALU fewer per with() — on the headline kernel: +4 % time,
+//  timer storm +1.7 %.  The loop entered under the rejected lanes' mask pays more in phi copies of the generator state than the peel saves;
+//  profiles/r6_ab_rng_peek.txt.  The form that keeps the loop's shape is gen_index's below.)
+template <class K, int REGION, class Rej>
+__device__ __forceinline__ uint64_t rng_draw(Lane& L, uint32_t& trips, Rej rej) {
+    uint64_t v;
+    trips = 0;
+    do { REG(REGION); v = rng_step(L); trips++; } while (rej(v));
+    return v;
 }
 
 // rand 0.8's accept test `lo64(v * range) <= zone` for a range below 2^32: zone = (range << lz) - 1 has its low word all
@@ -40,10 +59,11 @@ __device__ __forceinline__ bool reject_const(uint64_t v, uint32_t zone_hi) {
 
 // One determinism-log byte per GlobalRng::with (rand.rs:64-88): clone.gen::<u8>() ^ xor-fold(elapsed).
 template <class K>
-__device__ __forceinline__ void rng_log(const Ctx& c, Lane& L) {
+__device__ __forceinline__ void rng_log(const Ctx& c, Lane& L, bool have = false) {     // have: Lane::peek is current (gen_index)
     if (!MADSIM_K_LOG_ENABLED || K::NOLOG) return;
+    if (Peek<K>::ON && !have) L.peek = rng_out(L);                  // what the clone's next_u64 would return = the next with()'s first output
     if (K::LOGSW && c.P.no_log) return;                    // (wave-uniform)
-    uint64_t r = add64_1(rotl64<23>(L.s0 + L.s3), L.s0);   // what the clone's next_u64 would return
+    const uint64_t r = Peek<K>::ON ? L.peek : rng_out(L);
     uint32_t v = (uint32_t)(r >> 32);
     uint32_t f = (uint32_t)L.clock ^ (uint32_t)(L.clock >> 32);
     f ^= f >> 16; f ^= f >> 8;
@@ -58,7 +78,9 @@ template <class K>
 __device__ __forceinline__ uint64_t gen_range_u64(const Ctx& c, Lane& L, uint64_t lo, uint64_t range) {
     uint64_t zone = (range << __builtin_clzll(range)) - 1;
     uint64_t v;
-    do { REG(16); v = rng_next(L); } while (v * range > zone);
+    uint32_t trips;
+    v = rng_draw<K, 16>(L, trips, [&](uint64_t x) { return x * range > zone; });
+    L.rng_calls += trips;
     rng_log<K>(c, L);
     return lo + __umul64hi(v, range);
 }
@@ -72,13 +94,27 @@ __device__ __forceinline__ uint32_t gen_index(const Ctx& c, Lane& L, uint32_t le
     // index is 0.  When that is so for every lane of the wave (k_mem.h wave_all) the accept test is one signed compare instead of
     // the two multiplies of reject32: ~7 wave trips an executor pass end here.  (Same outputs consumed, same results.)
     if (wave_all(len == 1)) {
-        do { REG(1); v = rng_step(L); trips++; } while (EXP_ACCEPT((int32_t)(uint32_t)(v >> 32) < 0));
+        if (Peek<K>::ON) {
+            // the accepted output itself is not needed (the index is 0): each trip tests the output in hand, advances and computes the next one —
+            // the do-while it always was, and the output left in hand at the exit is the log entry's number (rng_log_with)
+            uint64_t p = L.peek;
+#ifdef MADSIM_EMU
+            if (p != rng_out(L)) OVF_SET(L, OVF_BUG);          // every with() of these builds ends in rng_log: the peek is the current state's output
+#endif
+            bool rej;
+            do { REG(1); rej = EXP_ACCEPT((int32_t)(uint32_t)(p >> 32) < 0); rng_advance(L); p = rng_out(L); trips++; } while (rej);
+            L.peek = p;
+            L.rng_calls += trips;
+            rng_log<K>(c, L, true);
+            return 0;
+        }
+        v = rng_draw<K, 1>(L, trips, [&](uint64_t x) { return EXP_ACCEPT((int32_t)(uint32_t)(x >> 32) < 0); });
         L.rng_calls += trips;
         rng_log<K>(c, L);
         return 0;
     }
     const uint32_t zone_hi = (len << (__builtin_clz(len))) - 1;
-    do { REG(1); v = rng_step(L); trips++; } while (EXP_ACCEPT(reject32(v, len, zone_hi)));
+    v = rng_draw<K, 1>(L, trips, [&](uint64_t x) { return EXP_ACCEPT(reject32(x, len, zone_hi)); });
     L.rng_calls += trips;
     rng_log<K>(c, L);
     uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * len + (((uint64_t)(uint32_t)v * len) >> 32);
@@ -92,7 +128,25 @@ __device__ __forceinline__ uint32_t gen_range_small(const Ctx& c, Lane& L) {
     static_assert((uint32_t)zone == 0xffffffffu, "reject32 compares the high word only");
     uint64_t v;
     uint32_t trips = 0;
-    do { REG(RANGE == 50 ? 18 : 16); v = rng_step(L); trips++; } while (EXP_ACCEPT(reject_const<RANGE>(v, (uint32_t)(zone >> 32))));
+    constexpr bool POW2P1 = RANGE == 3 || RANGE == 5 || RANGE == 9 || RANGE == 17;
+    if (Peek<K>::ALL && !POW2P1) {
+        // gen_index's form: test the output in hand, advance, compute the next one.  The accept test's operand — the middle 64 bits of the 128-bit
+        // product v * RANGE — holds the RESULT in its high word, so the accepted output itself is not needed behind the loop.
+        // (ranges 2^k + 1 test with one shift-add and compute the result from the output afterwards: they keep the form below)
+        uint64_t p = L.peek, mid;
+        bool rej;
+        do {
+            REG(RANGE == 50 ? 18 : 16);
+            mid = (uint64_t)(uint32_t)(p >> 32) * RANGE + __umulhi((uint32_t)p, RANGE);
+            rej = EXP_ACCEPT((uint32_t)mid > (uint32_t)(zone >> 32));
+            rng_advance(L); p = rng_out(L); trips++;
+        } while (rej);
+        L.peek = p;
+        L.rng_calls += trips;
+        rng_log<K>(c, L, true);
+        return (uint32_t)(mid >> 32);
+    }
+    v = rng_draw<K, RANGE == 50 ? 18 : 16>(L, trips, [&](uint64_t x) { return EXP_ACCEPT(reject_const<RANGE>(x, (uint32_t)(zone >> 32))); });
     L.rng_calls += trips;
     rng_log<K>(c, L);
     uint64_t mid = (uint64_t)(uint32_t)(v >> 32) * RANGE + (((uint64_t)(uint32_t)v * RANGE) >> 32);
@@ -104,6 +158,12 @@ template <class K>
 __device__ __forceinline__ bool gen_bool_pint(const Ctx& c, Lane& L, uint64_t p_int, uint32_t always) {
     if (always) return true;
     REG(7);
+    if (Peek<K>::ALL) {                                    // the output in hand, then the next one for the log entry (gen_index)
+        const uint64_t v = L.peek;
+        L.rng_calls++; rng_advance(L); L.peek = rng_out(L);
+        rng_log<K>(c, L, true);
+        return v < p_int;
+    }
     uint64_t v = rng_next(L);
     rng_log<K>(c, L);
     return v < p_int;
@@ -129,8 +189,9 @@ __device__ __forceinline__ uint64_t sample_latency(const Ctx& c, Lane& L) {
     bool ok;
     do {                                                // (one exit: see k_main.h on exit edges)
         REG(8);
-        uint64_t v = rng_next(L);
-        rng_log<K>(c, L);
+        uint64_t v;
+        if (Peek<K>::ALL) { v = L.peek; L.rng_calls++; rng_advance(L); L.peek = rng_out(L); rng_log<K>(c, L, true); }
+        else { v = rng_next(L); rng_log<K>(c, L); }
         if (mode == 0) {
             uint64_t m = (uint64_t)(uint32_t)(v >> 32) * (uint64_t)(uint32_t)range;
             ok = (uint32_t)m <= (uint32_t)zone;

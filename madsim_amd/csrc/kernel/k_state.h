@@ -101,6 +101,7 @@ void madsim_emu_ovf_note(const char* file, int line, uint32_t bits);
 struct Lane {
     // GlobalRng
     uint64_t s0, s1, s2, s3;
+    uint64_t peek;           // rng_out of the current state where the build keeps the determinism log (k_rng.h Peek, rng_log, gen_index)
     uint64_t rng_calls;
     uint64_t trace_hash;
     uint64_t log_len;

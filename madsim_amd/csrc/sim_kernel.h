@@ -42,6 +42,13 @@
 #endif
 /* Builds with a spill region: BinaryHeap::pop written top-down (k_timer.h timer_pop) — the array sift_down_to_bottom + sift_up leave, without the
    levels below the moved entry's final slot. */
+/* Base-op builds that keep the determinism log: the ready-queue draw starts from the number the previous with()'s log entry computed (k_rng.h gen_index). */
+#ifndef MADSIM_RNG_PEEK
+#define MADSIM_RNG_PEEK 2        /* 1: the ready-queue draw only; 2: every with() whose accepted output is not needed behind its loop */
+#endif
+#ifndef MADSIM_RNG_PEEK_LIFE
+#define MADSIM_RNG_PEEK_LIFE 0   /* ... in the extended builds too */
+#endif
 #ifndef MADSIM_POP_TOPDOWN
 #define MADSIM_POP_TOPDOWN 1
 #endif
