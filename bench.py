@@ -757,7 +757,7 @@ def main():
             tdetail = {"FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"], "source": pmc["source"]}
         elif world == 1 and per_gpu == workload.BENCH_SEEDS_PER_GPU and headline and not args.loss:
             # the committed rocprofv3 PMC passes of this same command (tools/prof_workload.sh): FETCH_SIZE x2 + WRITE_SIZE
-            for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+            for name in ("r6_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tpath):
                     tj = json.load(open(tpath))
@@ -812,13 +812,13 @@ def main():
                 issue["lane_util"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
         elif world == 1 and headline and not args.loss:
             # no live counters (rocprofv3 missing or refused): the committed per-executor-step instruction counts of this kernel
-            cpath = os.path.join(ROOT, "profiles", "r3_issue_counters.json")
-            if os.path.exists(cpath):
+            cpath = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r6_issue_counters.json", "r3_issue_counters.json")) if os.path.exists(q)), "")
+            if cpath:
                 cj = json.load(open(cpath))
                 valu = cj["valu_inst_per_executor_step"] * steps_per_launch
                 issue.update({"valu_inst_per_launch": valu, "achieved_ginst_s": valu / (ms_step * 1e-3) / 1e9,
                               "per_launch_ginst_s": valu / (launch_ms * 1e-3) / 1e9, "lane_util": cj.get("lane_util"),
-                              "counters_source": "profiles/r3_issue_counters.json (rocprofv3 PMC of this command on an MI355X, not this run"
+                              "counters_source": "profiles/" + os.path.basename(cpath) + " (rocprofv3 PMC of this command on an MI355X, not this run"
                                                  + ("; live attempt: " + str(pmc_note) if pmc_note else "") + ")"})
         if ceil:
             issue.update({"own_mix_ceiling_ginst_s": ceil["valu_mix_ceiling_ginst_s"], "ceiling_detail": ceil})
