@@ -247,7 +247,10 @@ def main():
     # behind them, +5 % on the election loop and the topology; the KV build, whose heap sits in LDS, gains nothing from it:
     # tools/experiment/exp_gstreams.sh)
     def flights(g):
-        return 5 if g.blocks_per_cu * g.block_threads // 64 >= 16 else 4 if (g.variant & 16) and g.heap_spill_slots else 3
+        wcu = g.blocks_per_cu * g.block_threads // 64
+        # (round 6, profiles/r6_ab_launches_in_flight.txt: the election loop at three waves per SIMD +2 % with a fifth launch queued, the topology
+        #  at two waves per SIMD -1 %; sub-launch sizes from 16 384 to 131 072 seeds read the same within 1 %)
+        return 5 if wcu >= 16 else (5 if wcu >= 12 else 4) if (g.variant & 16) and g.heap_spill_slots else 3
     max_streams = args.streams if args.streams > 0 else flights(g0)
     n_streams = max_streams
     d_outs = [torch.empty(count * 48, dtype=torch.uint8, device=dev) for _ in range(max_streams)]   # results stay in HBM
@@ -663,7 +666,7 @@ def main():
             xg0 = runtime.geometry(xw, xlim)
             # batches in flight by THIS workload's occupancy (flights(), above): five only where four waves per SIMD fit, four for
             # the global-state builds with a heap-spill region, else three
-            xn = min(n_streams, flights(xg0))
+            xn = min(max_streams, flights(xg0))
             nsub = max(1, baseline_batch[name] // count)
             xtimed = max(4, -(-8 * xn // nsub))      # timed steps: at least eight sub-launches per stream (the region starts on an empty
                                                      # chip and ends with a drain — a launch lasts 3-4 sub-launch periods — so three per
