@@ -231,6 +231,7 @@ inline madsim_config_t probe_config() {
 #ifndef MADSIM_DEDUP_BUCKETS
 #define MADSIM_DEDUP_BUCKETS 64
 #endif
+static_assert(MADSIM_DEDUP_BUCKETS <= 64 && (MADSIM_DEDUP_BUCKETS & (MADSIM_DEDUP_BUCKETS - 1)) == 0, "Lane::dd_occ mirrors the buckets in 64 bits");
 inline int make_geometry(const Device& g, const madsim_workload_t* w, const madsim_config_t* cfg, const madsim_limits_t* lim, uint64_t count, Geo* G, std::string* err, bool trace = false) {
     KParams& P = G->P;
     memset(&P, 0, sizeof P);

@@ -26,8 +26,11 @@ __device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_
     if (dn >= 0) {
         const uint32_t dst_node = (uint32_t)dn;
         bool clogged = false;
-        if (P.has_clog) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
-        if (P.has_clog_link) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
+        // (extended builds mirror "some node is clogged" / "a link has been clogged" in the lane — Lane::loss_always bits 8, 9, kept by the
+        //  clog ops of k_poll.h: while nothing is clogged a send loads none of the three mask words)
+        const bool mir = K::LIFE && MADSIM_CLOG_MIRROR;
+        if (P.has_clog && (!mir || (L.loss_always & 0x100u))) clogged = ((CLOGW(1) >> src_node) & 1) | ((CLOGW(0) >> dst_node) & 1);
+        if (P.has_clog_link && (!mir || (L.loss_always & 0x200u))) clogged |= (CLOGW(2 + src_node) >> dst_node) & 1;
         if (!clogged && !gen_bool_pint<K>(c, L, L.loss_pint, K::LIFE ? (L.loss_always & 1u) : L.loss_always)) {
             L.msg_count++;
             *latency = sample_latency<K>(c, L);

@@ -16,7 +16,7 @@ __device__ __forceinline__ void seed_init(const Ctx& c, Lane& L, uint64_t seed) 
         if (K::NH) for (uint32_t w = 0; w < P.pool_n / 32; w++) PMASK(w) = 0;
     }
     else for (uint32_t w = 0; w < P.lane_words; w++) RW(w) = 0;     // plane 0 is the ready queue: RW spans all planes
-    if (K::DEDUP) { for (uint32_t b = 0; b < P.dedup_n; b++) gs_store32(c.gs, gs_addr_uword(c, P.dedup_off + b * 16u + 12u), 0); L.hazard = 0; }   // empty buckets
+    if (K::DEDUP) { for (uint32_t b = 0; b < P.dedup_n; b++) gs_store32(c.gs, gs_addr_uword(c, P.dedup_off + b * 16u + 12u), 0); L.hazard = 0; L.dd_occ = 0; }   // empty buckets
     for (uint32_t t = 0; t < P.max_tasks; t++) { TWORD(c, t, 0, 0) = 0; if (!K::LIFE) TWORD(c, t, 1, 1) = 0; }
     if (K::FA && P.ipvs_dyn)                               // the services as the table declares them: the ipvs calls made before the first task runs
         for (uint32_t k = 0; k < P.n_services; k++) {

@@ -209,11 +209,14 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
         // DEDUP builds: the bucket that may hold repeats of the root wake-up (k_timer.h dedup_note) — like the loads above it
         // depends on the root entry alone
         const bool dd = K::DEDUP && c.P.dedup_n && !L.exact;
-        uint32_t dd_at = 0;
+        uint32_t dd_at = 0, dd_ix = 0;
         uint4 dd_u = make_uint4(0, 0, 0, 0);
         if (K::DEDUP && dd) {
             const uint32_t rz = heap_root_meta<K>(c);
-            if ((rz >> EV_SHIFT) == EV_WAKE) { dd_at = dedup_bucket(c, L.top_dl, rz); dd_u = gs_load128(c.gs, gs_addr_unit(c, dd_at)); }
+            if ((rz >> EV_SHIFT) == EV_WAKE) {
+                dd_ix = dedup_index(c, L.top_dl, rz); dd_at = dedup_at(c, dd_ix);
+                if (!MADSIM_DEDUP_OCC || ((L.dd_occ >> dd_ix) & 1ull)) dd_u = gs_load128(c.gs, gs_addr_unit(c, dd_at));     // (an empty bucket: nothing to load)
+            }
         }
         uint4 e = timer_pop<K>(c, L);
         L.steps++;
@@ -222,7 +225,7 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
         if (K::NH && kind == EV_DELIVER) { pool_free<K>(c, (e.z >> 6) & 0x7fffu); e.z = pf_rec.x; e.w = pf_rec.y; }
         if (K::DEDUP && dd) {
             // the repeats of this wake-up fire with it: a step each, their task is SCHEDULED by the first already
-            if (dd_u.w != 0 && dd_u.x == e.x && dd_u.y == e.y && dd_u.z == e.z) { L.steps += dd_u.w; gs_store32(c.gs, gs_addr_uword(c, dd_at + 12u), 0); }
+            if (dd_u.w != 0 && dd_u.x == e.x && dd_u.y == e.y && dd_u.z == e.z) { L.steps += dd_u.w; gs_store32(c.gs, gs_addr_uword(c, dd_at + 12u), 0); if (MADSIM_DEDUP_OCC) L.dd_occ &= ~(1ull << dd_ix); }
             // two DIFFERENT events with one deadline: which fires first is a matter of the heap's shape (restart the seed exactly)
             if (L.heap_len > 0 && L.top_dl == ev_deadline(e)) {
                 if (K::NH) { if (heap_root_meta<K>(c) != popped_meta) L.hazard = 1; }     // (two deliveries never share a record: always different)

@@ -871,15 +871,18 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_CLOG_NODE:
                 if (b & 1) CLOGW(0) |= 1u << a;
                 if (b & 2) CLOGW(1) |= 1u << a;
+                if (K::LIFE && MADSIM_CLOG_MIRROR) L.loss_always |= 0x100u;          // "a node is clogged" mirrored in the lane (k_channel.h net_try_send)
                 pc++;
                 break;
             case MS_OP_UNCLOG_NODE:
                 if (b & 1) CLOGW(0) &= ~(1u << a);
                 if (b & 2) CLOGW(1) &= ~(1u << a);
+                if (K::LIFE && MADSIM_CLOG_MIRROR && ((uint32_t)CLOGW(0) | (uint32_t)CLOGW(1)) == 0) L.loss_always &= ~0x100u;
                 pc++;
                 break;
             case MS_OP_CLOG_LINK:
                 CLOGW(2 + a) |= 1u << b;
+                if (K::LIFE && MADSIM_CLOG_MIRROR) L.loss_always |= 0x200u;          // "a link has been clogged": stays set (unclog_link does not look at the other rows)
                 pc++;
                 break;
             case MS_OP_UNCLOG_LINK:

@@ -126,7 +126,7 @@ struct Lane {
     uint32_t ovf;        // sticky OVF_* bits: the seed ends with a runner verdict (k_main.h), whatever its state says by then
     // runtime-mutable net config (MS_OP_SET_LOSS, MS_OP_SET_LATENCY)
     uint64_t loss_pint;
-    uint32_t loss_always;   // bit 0: packet_loss_rate == 1; bits 4-6 (extended builds): current send_latency = 0 the launch's, k + 1 = lat_table[k]
+    uint32_t loss_always;   // bit 0: packet_loss_rate == 1; bits 4-6 (extended builds): current send_latency = 0 the launch's, k + 1 = lat_table[k]; bit 8: a node is clogged, bit 9: a link has been clogged (k_channel.h)
     // Global-state builds: the Timer::add calls of one poll round, held back and performed at ONE site (poll_task's round
     // head, k_timer.h timer_flush) in their original order: at most one delivery event, then up to three wake-ups of the
     // polled task.  Inlined at each of its ~20 call sites the push's sift-up ran once per site, for the few lanes that
@@ -138,6 +138,7 @@ struct Lane {
     // heap shape's, which the de-duplicated heap does not share with the reference's): the seed starts over with `exact` set —
     // every timer a heap entry, as everywhere else
     uint32_t exact, hazard;
+    uint64_t dd_occ;         // which buckets of the re-registration table hold a count (k_timer.h dedup_note)
 };
 
 #define LDS128(i) (reinterpret_cast<uint4*>(SMEM)[(i)])

@@ -220,19 +220,34 @@ __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadli
 // What the shorter heap cannot reproduce is the order of two DIFFERENT entries with equal deadlines (the array algorithm's tie
 // order depends on the heap's shape): timer_expire notices every such tie as it pops it (Lane::hazard) and the seed starts over
 // with Lane::exact set (k_main.h) — results never differ.
-__device__ __forceinline__ uint32_t dedup_bucket(const Ctx& c, uint64_t deadline, uint32_t meta) {
+__device__ __forceinline__ uint32_t dedup_index(const Ctx& c, uint64_t deadline, uint32_t meta) {
     const uint32_t lo = (uint32_t)deadline;
     const uint32_t h = lo ^ (lo >> 7) ^ (lo >> 15) ^ ((uint32_t)(deadline >> 32) * 0x9e3779b1u) ^ ((meta & 0xffu) * 0x85ebca6bu);
-    return c.P.dedup_off + ((h ^ (h >> 11)) & (c.P.dedup_n - 1u)) * 16u;        // logical byte offset of the bucket's unit
+    return (h ^ (h >> 11)) & (c.P.dedup_n - 1u);
 }
+__device__ __forceinline__ uint32_t dedup_at(const Ctx& c, uint32_t idx) { return c.P.dedup_off + idx * 16u; }   // logical byte offset of the bucket's unit
+// Which buckets hold a count is mirrored in a register (Lane::dd_occ, bit = bucket index; dedup_n <= 64): an EMPTY bucket is neither
+// loaded by the re-registration that fills it nor by the pop of a wake-up that maps to it (MADSIM_DEDUP_OCC; round 6: half of both kinds).
 // A re-registration of (deadline, meta): true = it now lives in the table; false = push it.
-__device__ __forceinline__ bool dedup_note(const Ctx& c, uint64_t deadline, uint32_t meta) {
-    const uint32_t at = dedup_bucket(c, deadline, meta);
-    const uint4 u = gs_load128(c.gs, gs_addr_unit(c, at));
-    const bool same = u.x == (uint32_t)deadline && u.y == (uint32_t)(deadline >> 32) && u.z == meta;
+__device__ __forceinline__ bool dedup_note(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta) {
+    const uint32_t idx = dedup_index(c, deadline, meta), at = dedup_at(c, idx);
     bool noted = false;
-    if (u.w == 0) { gs_store128(c.gs, gs_addr_unit(c, at), make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, 1u)); noted = true; }
-    else if (same && u.w != ~0u) { gs_store32(c.gs, gs_addr_uword(c, at + 12u), u.w + 1u); noted = true; }
+    if (MADSIM_DEDUP_OCC && !((L.dd_occ >> idx) & 1ull)) {
+#ifdef MADSIM_EMU
+        if (gs_load128(c.gs, gs_addr_unit(c, at)).w != 0) OVF_SET(L, OVF_BUG);        // the mirror says empty: it is
+#endif
+        gs_store128(c.gs, gs_addr_unit(c, at), make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, 1u));
+        L.dd_occ |= 1ull << idx;
+        noted = true;
+    } else {
+        const uint4 u = gs_load128(c.gs, gs_addr_unit(c, at));
+        const bool same = u.x == (uint32_t)deadline && u.y == (uint32_t)(deadline >> 32) && u.z == meta;
+#ifdef MADSIM_EMU
+        if (MADSIM_DEDUP_OCC && u.w == 0) OVF_SET(L, OVF_BUG);                          // the mirror says occupied: it is
+#endif
+        if (u.w == 0) { gs_store128(c.gs, gs_addr_unit(c, at), make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, 1u)); noted = true; }
+        else if (same && u.w != ~0u) { gs_store32(c.gs, gs_addr_uword(c, at + 12u), u.w + 1u); noted = true; }
+    }
     return noted;
 }
 
@@ -269,7 +284,7 @@ __device__ __forceinline__ void timer_flush(const Ctx& c, Lane& L, uint32_t wake
             dl = L.pq_w0; meta = wake_meta; val = 0; L.pq_w0 = L.pq_w1; L.pq_w1 = L.pq_w2;
             const bool again = (L.pq_n & 8u) != 0;
             L.pq_n = ((L.pq_n & 7u) - 1u) | ((L.pq_n >> 1) & 0x18u);        // one wake-up less; the repeat flags move down with their deadlines
-            if (again && c.P.dedup_n && !L.exact && dedup_note(c, dl, meta)) continue;
+            if (again && c.P.dedup_n && !L.exact && dedup_note(c, L, dl, meta)) continue;
         }
         if (!timer_add<K>(c, L, dl, meta, val)) OVF_SET(L, OVF_CAP);
     }

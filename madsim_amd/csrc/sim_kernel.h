@@ -49,6 +49,14 @@
 #ifndef MADSIM_RNG_PEEK_LIFE
 #define MADSIM_RNG_PEEK_LIFE 0   /* ... in the extended builds too */
 #endif
+/* MADSIM_STATE_DEDUP_TIMERS builds: the occupancy of the re-registration table mirrored in a register (k_timer.h dedup_note). */
+#ifndef MADSIM_DEDUP_OCC
+#define MADSIM_DEDUP_OCC 1
+#endif
+/* Extended builds: whether any clog exists is mirrored in the lane, a send loads the clog masks only then (k_channel.h net_try_send). */
+#ifndef MADSIM_CLOG_MIRROR
+#define MADSIM_CLOG_MIRROR 1
+#endif
 #ifndef MADSIM_POP_TOPDOWN
 #define MADSIM_POP_TOPDOWN 1
 #endif
