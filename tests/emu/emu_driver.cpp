@@ -36,7 +36,8 @@ static std::map<SiteKey, uint32_t> site_ids;
 static std::vector<SiteKey> site_keys;
 static thread_local std::vector<std::unordered_map<uint32_t, uint16_t>>* emu_site_log = nullptr;
 static std::vector<double> site_trips, site_visits;
-__attribute__((noinline)) void madsim_k::emu_site(int kind, const void*, uint32_t) {
+static std::vector<uint64_t> site_zero;      // loads whose (first) word read as zero: candidates for a mirror bit (tools/mem_site_model.py)
+__attribute__((noinline)) void madsim_k::emu_site(int kind, const void* base, uint32_t off) {
     if (!emu_site_log || emu_site_log->empty()) return;
     SiteKey k; memset(&k, 0, sizeof k); k.kind = kind;
     void** fp = (void**)__builtin_frame_address(0);
@@ -51,7 +52,13 @@ __attribute__((noinline)) void madsim_k::emu_site(int kind, const void*, uint32_
     uint32_t id;
     if (it == site_ids.end()) { id = (uint32_t)site_keys.size(); site_ids.emplace(k, id); site_keys.push_back(k); } else id = it->second;
     (*emu_site_log).back()[id]++;
+    if (kind == 0 || kind == 2) {
+        if (site_zero.size() <= id) site_zero.resize(id + 1);
+        const uint32_t* w = (const uint32_t*)((const uint8_t*)base + off);
+        if (kind == 0 ? w[0] == 0 : (w[0] | w[1] | w[2] | w[3]) == 0) site_zero[id]++;
+    }
 }
+extern "C" uint64_t madsim_emu_site_zero(uint32_t id) { return id < site_zero.size() ? site_zero[id] : 0; }
 extern "C" uint32_t madsim_emu_site_count(void) { return (uint32_t)site_keys.size(); }
 extern "C" void madsim_emu_site(uint32_t id, uintptr_t* ra, int* kind, double* trips, double* visits) {
     for (int i = 0; i < SITE_DEPTH; i++) ra[i] = site_keys[id].ra[i];

@@ -45,6 +45,7 @@ for line in open("/proc/self/maps"):
         lo = int(line.split("-")[0], 16)
         base = lo if base is None else min(base, lo)
 n = L.madsim_emu_site_count()
+L.madsim_emu_site_zero.restype = C.c_uint64; L.madsim_emu_site_zero.argtypes = [C.c_uint32]
 L.madsim_emu_site.argtypes = [C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
 sites = []
 addrs = set()
@@ -52,7 +53,7 @@ for i in range(n):
     ra = (C.c_size_t * 7)(); kind = C.c_int(); t = C.c_double(); v = C.c_double()
     L.madsim_emu_site(i, ra, C.byref(kind), C.byref(t), C.byref(v))
     ras = [int(x) - base for x in ra if x]
-    sites.append((ras, kind.value, t.value, v.value)); addrs.update(ras)
+    sites.append((ras, kind.value, t.value, v.value, int(L.madsim_emu_site_zero(i)))); addrs.update(ras)
 addrs = sorted(addrs)
 res = subprocess.run(["addr2line", "-f", "-C", "-e", LIB] + [hex(a - 1) for a in addrs], capture_output=True, text=True).stdout.splitlines()
 sym = {}
@@ -83,12 +84,13 @@ c_lo = sum(s[2] * cost(s[3] / s[2])[0] for s in sites if s[2]); c_hi = sum(s[2] 
 print(f"# priced with ubench_vmem: {c_lo / it:.0f} .. {c_hi / it:.0f} CU cycles of memory pipeline per wave-iteration "
       f"({c_lo / steps:.0f} .. {c_hi / steps:.0f} per lane-step); fully converged (64 lanes per instruction): "
       f"{tot_v / 64 * 165 / steps:.0f} .. {tot_v / 64 * 390 / steps:.0f} per lane-step")
-print(f"{'trips/iter':>10s} {'lanes':>6s} {'cyc/iter(L2)':>12s}  kind   site (innermost first)")
-for ras, kind, t, v in sorted(sites, key=lambda s: -s[2] * cost(s[3] / max(s[2], 1))[0])[:top]:
+print(f"{'trips/iter':>10s} {'lanes':>6s} {'cyc/iter(L2)':>12s}  kind   zero  site (innermost first; zero = share of the loads that read 0: a mirror bit could skip them)")
+for ras, kind, t, v, z in sorted(sites, key=lambda s: -s[2] * cost(s[3] / max(s[2], 1))[0])[:top]:
     chain = " < ".join(sym[a] for a in ras[:6] if sym[a].split(":")[0].strip() not in HELPERS or True)
-    print(f"{t / it:10.3f} {v / t:6.1f} {t * cost(v / t)[0] / it:12.0f}  {KIND[kind]:6s} {chain}")
+    zs = f"{z / v:5.2f}" if kind in (0, 2) and v else "    -"
+    print(f"{t / it:10.3f} {v / t:6.1f} {t * cost(v / t)[0] / it:12.0f}  {KIND[kind]:6s} {zs} {chain}")
 by_fn = collections.Counter(); by_fn_t = collections.Counter(); by_fn_v = collections.Counter()
-for ras, kind, t, v in sites:
+for ras, kind, t, v, _z in sites:
     if not t: continue
     names = [sym[a].split(":")[0].strip() for a in ras]
     key = next((x for x in names if not any(x.startswith(h) for h in HELPERS)), names[0])
