@@ -34,6 +34,10 @@ for gi,(g,mt,opt) in enumerate(gens):
         # (odd programs: the global-memory block; the re-registration counts with it for the timeout generator always, for the others
         # every fourth program — the builds that do not carry the switch ignore it)
         if k % 2: lim.lanes_per_wave, lim.state_mem = 0, A.STATE_GLOBAL | (A.STATE_DEDUP_TIMERS if g == "random_timeout_workload" or k % 4 == 3 else 0)
+        if k % 8 in (5, 7):                           # ... and 8-byte heap entries with a small LDS quota (round 6; honoured where a narrow build exists)
+            lim.state_mem |= A.STATE_NARROW_HEAP
+            q = 1 + k % 5
+            lim.heap_spill_slots, lim.heap_lds_slots = lim.heap_spill_slots + max(0, lim.heap_lds_slots - q), q
         try:
             e = emu.run_batch(w, k * 5, 8, cfg, lim)
         except RuntimeError:                      # refused by validate() (the op-soup generator writes programs that are)
