@@ -37,7 +37,7 @@ for gi,(g,mt,opt) in enumerate(gens):
         if k % 8 in (5, 7):                           # ... and 8-byte heap entries with a small LDS quota (round 6; honoured where a narrow build exists)
             lim.state_mem |= A.STATE_NARROW_HEAP
             q = 1 + k % 5
-            lim.heap_spill_slots, lim.heap_lds_slots = lim.heap_spill_slots + max(0, lim.heap_lds_slots - q), q
+            lim.heap_spill_slots, lim.heap_lds_slots = max(4, lim.heap_spill_slots + max(0, lim.heap_lds_slots - q)), q      # (from 4 slots the re-run rounds of tests/parity.py reach the 1 024 a restart storm wants)
         try:
             e = emu.run_batch(w, k * 5, 8, cfg, lim)
         except RuntimeError:                      # refused by validate() (the op-soup generator writes programs that are)
