@@ -7,7 +7,8 @@ namespace madsim_k {
 
 // ---- GlobalRng ---------------------------------------------------------------------------------
 // Xoshiro256PlusPlus::next_u64 [DEP rand_xoshiro 0.6] without the call counter (rng_next below counts; the rejection loops
-// count their trips in a 32-bit register — a full-rate v_add_u32 per trip — and add once per draw)
+// count their trips in a 32-bit register — the compiler keeps it scalar, a copy per trip — and add once per draw.  Round 6 measured a per-lane 32-bit
+// counter inside the loops, folded into the 64-bit field every 16th pass, instead: +0.8 % time on the headline kernel, profiles/r6_ab_rng_count_32bit.txt)
 __device__ __forceinline__ uint64_t rng_out(const Lane& L) { return add64_1(rotl64<23>(L.s0 + L.s3), L.s0); }
 __device__ __forceinline__ void rng_advance(Lane& L) {
     // s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= s1 << 17 with the two three-input xors as one v_bitop3_b32 per half
@@ -28,7 +29,8 @@ __device__ __forceinline__ uint64_t rng_next(Lane& L) {
     return rng_step(L);
 }
 // Builds that keep the determinism log hold the output of the CURRENT state in Lane::peek: the log's entry for a with() is a byte of
-// `rng.clone().gen()` (rand.rs:64-88), i.e. of the next with()'s first output, so rng_log computes that number anyway.  gen_index's hot loop starts from it.
+// `rng.clone().gen()` (rand.rs:64-88), i.e. of the next with()'s first output, so rng_log computes that number anyway.  The draws whose accepted output is not wanted
+// behind their loop start from it (gen_index at queue length 1, gen_range_small for general ranges, gen_bool, the latency draw): level 2; level 1 = gen_index only.
 template <class K> struct Peek { static constexpr bool ON = MADSIM_RNG_PEEK && MADSIM_K_LOG_ENABLED && !K::NOLOG && (!K::LIFE || MADSIM_RNG_PEEK_LIFE), ALL = ON && MADSIM_RNG_PEEK > 1; };
 
 // One with()'s rejection loop: outputs until `rej` accepts one.
