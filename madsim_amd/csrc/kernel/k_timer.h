@@ -141,6 +141,20 @@ __device__ __forceinline__ void heap_set(const Ctx& c, Lane& L, uint32_t i, cons
     if (!K::SPILL || i < c.P.heap_lds) heap_lds_set<K>(c, i, e);
     else spill_store(c, i - c.P.heap_lds, e);
 }
+// The children child, child + 1 of a level that lies in LDS, and a store to an LDS-resident slot: ds_* accesses only, nothing that waits on
+// the global-memory counter (timer_pop's walk through the LDS levels runs beside a spill-region load).
+template <class K>
+__device__ __forceinline__ void heap_lds_get2(const Ctx& c, const Lane& L, uint32_t child, uint4& vlo, uint4& vhi) {
+    if (K::NH) {
+        const uint2 a = LDS64(c.heap0 + (child << LWSH<K>(c))), b = LDS64(c.heap0 + ((child + 1) << LWSH<K>(c)));
+        vlo = nh_expand(L, a); vhi = nh_expand(L, b);
+    } else { vlo = heap_lds_get<K>(c, child); vhi = heap_lds_get<K>(c, child + 1); }
+}
+template <class K>
+__device__ __forceinline__ void heap_set_lds(const Ctx& c, Lane& L, uint32_t i, const uint4& e) {
+    if (K::NH) LDS64(c.heap0 + (i << LWSH<K>(c))) = make_uint2(e.x, e.z);
+    else heap_lds_set<K>(c, i, e);
+}
 // meta + payload of a datagram delivery event (net/mod.rs:323-330): destination socket `ds` of incarnation `sgen`.
 template <class K>
 __device__ __forceinline__ uint2 ev_deliver_meta(uint32_t sgen, uint32_t tag, uint32_t from, uint32_t ds, uint32_t val, uint32_t pc) {
@@ -314,32 +328,63 @@ __device__ __forceinline__ uint4 timer_pop(const Ctx& c, Lane& L) {
             // children loaded with them — topology and election loop both -0.8 %: the extra lane accesses cost more than the round trip.
             // profiles/r6_experiments.md)
             const uint64_t idl = ev_deadline(item);
+            // MADSIM_POP_LDS_FIRST: `item` is the heap's LAST entry — with any depth a load from the spill region — and the stop test of every level
+            // waits for it: the walk through the LDS-resident levels stood behind a global round trip it does not need.  Those levels are
+            // walked the literal way instead (sift_down_to_bottom: the smaller child moves up, no look at `item`), which brings the walk to the
+            // first spilled level while the load is still in flight: that level's children are requested beside it, one round trip instead of
+            // two.  The spilled levels keep the stop test.  If nothing moved there, `item` may belong above the LDS levels' last slot: the literal
+            // sift_up from it (parents in LDS; the common case — the old bottom entry belongs at the bottom again — compares with the entry in
+            // hand and loads nothing).  Same comparisons on the same values as sift_down_to_bottom + sift_up: the same array.
+            bool moved_below = false;
+            if (MADSIM_POP_LDS_FIRST && !K::CMP) {
+                const uint32_t cap = c.P.heap_lds;
+                while (child + 1 < end && child + 1 < cap) {
+                    REG(21);
+                    uint4 l, r;
+                    heap_lds_get2<K>(c, L, child, l, r);
+                    const bool right = ev_deadline(l) >= ev_deadline(r);
+                    m = right ? r : l;
+                    heap_set_lds<K>(c, L, pos, m);
+                    if (pos == 0) L.top_dl = ev_deadline(m);
+                    pos = child + (right ? 1u : 0u);
+                    child = 2 * pos + 1;
+                }
+            }
             bool go = child + 1 < end, stopped = false;
             while (go) {                                   // (one exit: see k_main.h)
                 REG(21);
                 uint4 l, r;
                 heap_get2<K>(c, L, child, child + 1, l, r);
                 const bool right = ev_deadline(l) >= ev_deadline(r);
-                m = right ? r : l;
-                go = ev_deadline(m) <= idl;
+                const uint4 cand = right ? r : l;
+                go = ev_deadline(cand) <= idl;
                 if (go) {
+                    m = cand;
                     heap_set<K>(c, L, pos, m);
                     if (pos == 0) L.top_dl = ev_deadline(m);
                     pos = child + (right ? 1u : 0u);
                     child = 2 * pos + 1;
                     go = child + 1 < end;
+                    moved_below = true;
                 } else stopped = true;
             }
             if (!stopped && child == end - 1) {
-                m = heap_get<K>(c, L, child);
-                if (ev_deadline(m) <= idl) {
+                const uint4 cand = heap_get<K>(c, L, child);
+                if (ev_deadline(cand) <= idl) {
+                    m = cand;
                     heap_set<K>(c, L, pos, m);
                     if (pos == 0) L.top_dl = ev_deadline(m);
                     pos = child;
+                    moved_below = true;
                 }
             }
-            heap_set<K>(c, L, pos, item);
-            if (pos == 0) L.top_dl = idl;
+            // (`m` = the entry last moved up: it sits at parent(pos).  Moved under the stop test it is <= item, and so is everything above it.)
+            if (MADSIM_POP_LDS_FIRST && !K::CMP && !moved_below && pos > 0 && idl < ev_deadline(m)) {
+                heap_set<K>(c, L, pos, m); pos = (pos - 1) >> 1; heap_sift_up<K>(c, L, pos, item);
+            } else {
+                heap_set<K>(c, L, pos, item);
+                if (pos == 0) L.top_dl = idl;
+            }
         } else {
         while (child + 1 < end) {
             REG(21);

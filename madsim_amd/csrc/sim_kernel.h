@@ -60,6 +60,10 @@
 #ifndef MADSIM_POP_TOPDOWN
 #define MADSIM_POP_TOPDOWN 1
 #endif
+/* ... with the LDS-resident levels walked before the heap's last entry (a spill-region load) has arrived (k_timer.h timer_pop). */
+#ifndef MADSIM_POP_LDS_FIRST
+#define MADSIM_POP_LDS_FIRST 1
+#endif
 
 namespace madsim_k {
 
