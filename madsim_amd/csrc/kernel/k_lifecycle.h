@@ -8,8 +8,14 @@ namespace madsim_k {
 // ---- task lifecycle ----------------------------------------------------------------------------
 // `via_handle`: spawned through a NodeHandle captured at build() (NodeHandle::spawn from another node's task:
 // that Spawner holds the ORIGINAL Arc<NodeInfo>); otherwise task::spawn / init on the node's current info.
+// `init` (MS_OP_SPAWN from the polled task, k_poll.h): words of the spawning task its poll holds in registers — its flag word and its
+// unit 1 word 1 (spawn order | info_gen << 24: the NodeInfo it runs under), so task::spawn reads neither — and what `async move` hands the
+// child: the request's value and sender (unit 0 w and y bits 24-31) and the request word of the rpc unit, stored WITH the new task's units
+// instead of over them afterwards.
+struct SpawnInit { bool parent_known; uint32_t parent_f, parent_u1y; bool move_req; uint32_t w, from, req; };
 template <class K>
-__device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record, bool via_handle = false, int parent = -1) {
+__device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record, bool via_handle = false, int parent = -1,
+                                               const SpawnInit init = SpawnInit{false, 0, 0, false, 0, 0, 0}) {
     uint32_t slot = 0;
     if (K::G) {                                              // first free slot = first zero bit of the alive mask (LDS)
         slot = c.P.max_tasks;
@@ -25,26 +31,63 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
     //  unbounded Vec lowest free slot first, as this does, it says so at the same spawn)
     if (slot >= c.P.max_tasks) { OVF_SET(L, c.P.max_tasks >= MADSIM_MAX_LIVE_TASKS ? OVF_MODEL : OVF_CAP); return 0xffffffffu; }
     if (K::G) AMASK(slot >> 5) |= 1u << (slot & 31);
-    uint32_t gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
-    uint32_t pw = PROGW(c, prog);
-    uint32_t node = pw & 0xff;
-    uint32_t killed = 0, info_gen = 0;
-    if (K::FN) {
-        uint32_t cur_gen = NODE_INFO_GEN(node);
-        info_gen = cur_gen;
-        if (parent >= 0) {           // task::spawn inside that task's context: its own Arc<NodeInfo>, whatever became of the node
-            killed = (TWORD(c, (uint32_t)parent, 0, 0) & TF_KILLED) ? 1u : 0u;
-            info_gen = TWORD(c, (uint32_t)parent, 1, 1) >> 24;
+    uint32_t pw, node, gen, killed = 0, info_gen = 0, seq = 0;
+    if constexpr (K::G) {
+        pw = PROGW(c, prog);
+        node = pw & 0xff;
+        // Every word the spawn reads is requested here, before the first is looked at (global-state builds: the old slot's generation, the
+        // node's info generation, the killed mask or the parent's words, the spawn counter came one dependent round trip after another —
+        // three for a task::spawn — with the whole wave waiting on each).  What the branches below do not use is not used; nothing is
+        // written in between.
+        const uint32_t w_old = TWORD(c, slot, 0, 0);
+        // (raw words only up to the last request: arithmetic on a loaded value inside a divergent block makes the compiler wait for it there)
+        uint32_t w_gen = 0, w_parent_f = init.parent_f, w_parent_y = init.parent_u1y, w_killed = 0;
+        const bool in_parent = parent >= 0;
+        if (K::FN) {
+            w_gen = NODEW(4 + (node >> 2));                      // NODE_INFO_GEN(node)
+            seq = NODEW(3);
+            if (!in_parent) w_killed = NODEW(via_handle ? 2u : 0u);
+            else if (!init.parent_known) { w_parent_f = TWORD(c, (uint32_t)parent, 0, 0); w_parent_y = TWORD(c, (uint32_t)parent, 1, 1); }
+#ifdef MADSIM_EMU
+            if (in_parent && init.parent_known && (((uint32_t)TWORD(c, (uint32_t)parent, 0, 0) ^ init.parent_f) & TF_KILLED)) OVF_SET(L, OVF_BUG);     // the poll's copy is current
+            if (in_parent && init.parent_known && (uint32_t)TWORD(c, (uint32_t)parent, 1, 1) != init.parent_u1y) OVF_SET(L, OVF_BUG);
+#endif
         }
-        else if (via_handle && cur_gen != 0) { killed = 1; info_gen = 0; }        // stale handle: dead info
-        else killed = ((via_handle ? NODEW(2) : NODEW(0)) >> node) & 1;          // task/mod.rs:632-634
+        gen = (((w_old >> 8) & 0xffff) + 1) & 0xffff;
+        if (K::FN) {
+            const uint32_t cur_gen = (w_gen >> ((node & 3) * 8)) & 0xff;
+            info_gen = cur_gen;
+            if (in_parent) {             // task::spawn inside that task's context: its own Arc<NodeInfo>, whatever became of the node
+                killed = (w_parent_f & TF_KILLED) ? 1u : 0u;
+                info_gen = w_parent_y >> 24;
+            }
+            else if (via_handle && cur_gen != 0) { killed = 1; info_gen = 0; }        // stale handle: dead info
+            else killed = (w_killed >> node) & 1;                                      // task/mod.rs:632-634
+            NODEW(3) = seq + 1;                                  // spawn order matters only to NodeInfo::kill
+        }
+    } else {
+        // (LDS-resident builds: the reads are LDS reads, in the order the code has always had)
+        gen = (((TWORD(c, slot, 0, 0) >> 8) & 0xffff) + 1) & 0xffff;
+        pw = PROGW(c, prog);
+        node = pw & 0xff;
+        if (K::FN) {
+            uint32_t cur_gen = NODE_INFO_GEN(node);
+            info_gen = cur_gen;
+            if (parent >= 0) {           // task::spawn inside that task's context: its own Arc<NodeInfo>, whatever became of the node
+                killed = (TWORD(c, (uint32_t)parent, 0, 0) & TF_KILLED) ? 1u : 0u;
+                info_gen = TWORD(c, (uint32_t)parent, 1, 1) >> 24;
+            }
+            else if (via_handle && cur_gen != 0) { killed = 1; info_gen = 0; }        // stale handle: dead info
+            else killed = ((via_handle ? NODEW(2) : NODEW(0)) >> node) & 1;          // task/mod.rs:632-634
+        }
+        if (K::FN) { seq = NODEW(3); NODEW(3) = seq + 1; }      // spawn order matters only to NodeInfo::kill
     }
-    uint32_t seq = 0;
-    if (K::FN) { seq = NODEW(3); NODEW(3) = seq + 1; }      // spawn order matters only to NodeInfo::kill
-    TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24), pw >> 16, 0, 0);
+    // (MS_OP_SPAWN with move_request: `async move` takes the request — rpc.rs:170 — its value, its sender and the rsp_tag word)
+    TU(c, slot, 0) = make_uint4(TF_ALIVE | TF_SCHED | (killed ? TF_KILLED : 0) | (gen << 8) | (prog << 24),
+                                init.move_req ? ((pw >> 16) & 0x00ffffffu) | (init.from << 24) : pw >> 16, 0, init.move_req ? init.w : 0u);
     tu1_store<K>(c, slot, make_uint4(0xffu << 8, (seq & 0xffffff) | (info_gen << 24), 0, 0));   // rxseq 0, no awaiter; spawn order
     if (K::FC && c.P.uses_chan) TU(c, slot, c.P.chan_unit) = make_uint4(0xff, 0, 0, 0);                // no connection held
-    if (K::FR && c.P.uses_rpc) { TWORD(c, slot, c.P.rpc_unit, 0) = 0; TWORD(c, slot, c.P.rpc_unit, 1) = 0; }   // no request in hand
+    if (K::FR && c.P.uses_rpc) { TWORD(c, slot, c.P.rpc_unit, 0) = init.move_req ? init.req : 0u; TWORD(c, slot, c.P.rpc_unit, 1) = 0; }   // no request in hand
     ready_push<K>(c, L, slot);
     if (record) HW(prog) = H_RUNNING | (slot << 8) | (gen << 16);
     return slot;
@@ -133,6 +176,46 @@ __device__ __forceinline__ uint32_t task_finish(const Ctx& c, Lane& L, uint32_t 
 // spawn order (the order of NodeInfo.tasks).  Tasks carry their spawn sequence number, so no list is stored.
 template <class K>
 __device__ __forceinline__ void info_kill(const Ctx& c, Lane& L, uint32_t node, uint32_t info_gen) {
+    if constexpr (K::G) {
+        // Global-state builds.  The walk below reads a task's flag word, looks at it, reads its unit 1, looks at it — two dependent round trips
+        // per live task, the whole list once per task it kills: ~60 round trips for the topology's kill + restart, and with 64 seeds reaching
+        // theirs in different passes the wave sat in this loop for 2.6 round trips of EVERY pass (tools/mem_site_model.py topo).  Here: the live
+        // tasks (alive mask, LDS) four at a time, both words of the four requested together; the matches kept as the four smallest
+        // (spawn order << 8 | slot) of one scan, killed in that order with their flag words read together; another scan only when more than four
+        // matched.  The same tasks get TF_KILLED and their wake-up in the same order.
+        uint32_t last = 0; bool any_last = false;
+        for (;;) {
+            uint32_t s0 = ~0u, s1 = ~0u, s2 = ~0u, s3 = ~0u; bool more = false;
+            for (uint32_t wi = 0; wi < (c.P.max_tasks + 31) / 32; wi++) {
+                uint32_t m = AMASK(wi);
+                while (m) {
+                    uint32_t ix[4], fw[4], sw[4], n = 0;
+                    for (uint32_t k = 0; k < 4; k++) { ix[k] = wi * 32 + (uint32_t)__builtin_ctz(m | 0x80000000u); if (m) { n++; m &= m - 1; } }
+                    for (uint32_t k = 0; k < 4; k++) { fw[k] = TWORD(c, k < n ? ix[k] : ix[0], 0, 0); sw[k] = TWORD(c, k < n ? ix[k] : ix[0], 1, 1); }
+                    for (uint32_t k = 0; k < 4; k++) {
+                        if (k >= n || !(fw[k] & TF_ALIVE) || (PROGW(c, fw[k] >> 24) & 0xff) != node || (sw[k] >> 24) != info_gen) continue;
+                        uint32_t t = (sw[k] << 8) | ix[k], u;           // spawn order (24 bits, unique) | slot
+                        if (any_last && t <= last) continue;
+                        u = t < s0 ? t : s0; t = t < s0 ? s0 : t; s0 = u;
+                        u = t < s1 ? t : s1; t = t < s1 ? s1 : t; s1 = u;
+                        u = t < s2 ? t : s2; t = t < s2 ? s2 : t; s2 = u;
+                        u = t < s3 ? t : s3; t = t < s3 ? s3 : t; s3 = u;
+                        if (t != ~0u) more = true;                      // a fifth match: it waits for the next scan
+                    }
+                }
+            }
+            const uint32_t f0 = s0 != ~0u ? (uint32_t)TWORD(c, s0 & 0xff, 0, 0) : 0u, f1 = s1 != ~0u ? (uint32_t)TWORD(c, s1 & 0xff, 0, 0) : 0u;
+            const uint32_t f2 = s2 != ~0u ? (uint32_t)TWORD(c, s2 & 0xff, 0, 0) : 0u, f3 = s3 != ~0u ? (uint32_t)TWORD(c, s3 & 0xff, 0, 0) : 0u;
+            // (a wake-up writes its own task's word only: the four words read together are what four reads in turn would have seen)
+            if (s0 != ~0u) { TWORD(c, s0 & 0xff, 0, 0) = f0 | TF_KILLED; wake_with<K>(c, L, s0 & 0xff, (f0 >> 8) & 0xffff, f0 | TF_KILLED); }
+            if (s1 != ~0u) { TWORD(c, s1 & 0xff, 0, 0) = f1 | TF_KILLED; wake_with<K>(c, L, s1 & 0xff, (f1 >> 8) & 0xffff, f1 | TF_KILLED); }
+            if (s2 != ~0u) { TWORD(c, s2 & 0xff, 0, 0) = f2 | TF_KILLED; wake_with<K>(c, L, s2 & 0xff, (f2 >> 8) & 0xffff, f2 | TF_KILLED); }
+            if (s3 != ~0u) { TWORD(c, s3 & 0xff, 0, 0) = f3 | TF_KILLED; wake_with<K>(c, L, s3 & 0xff, (f3 >> 8) & 0xffff, f3 | TF_KILLED); }
+            if (!more) break;
+            last = s3; any_last = true;
+        }
+        return;
+    }
     uint32_t last = 0xffffffffu;                            // "none yet": sequence numbers are < 2^24
     for (;;) {
         uint32_t best = 0xffffffffu, best_seq = 0xffffffffu;

@@ -27,6 +27,9 @@ __device__ __forceinline__ BufRef buf_make(const void* base, uint64_t bytes) {
 }
 __device__ __forceinline__ uint32_t buf_load32(const BufRef& b, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(b.rsrc, off, 0, 0); }
 __device__ __forceinline__ void buf_store32(const BufRef& b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b.rsrc, off, 0, 0); }
+// word += v with nobody waiting for it: buffer_atomic_add without a return value (the lane's own word: nothing contends; a later read by the
+// same lane sees it — program order).  A load + add + store would hold the wave for the load's round trip.
+__device__ __forceinline__ void buf_add32(const BufRef& b, uint32_t off, uint32_t v) { (void)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32((int)v, b.rsrc, off, 0, 0); }
 __device__ __forceinline__ uint2 buf_load64(const BufRef& b, uint32_t off) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(b.rsrc, off, 0, 0);

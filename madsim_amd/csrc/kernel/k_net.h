@@ -190,6 +190,13 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
     // seed ends MADSIM_INTERNAL); a new op that fires timers inside a round without flushing first shows up there.
     if (K::G && L.pq_n) OVF_SET(L, OVF_BUG);
 #endif
+    // Copies of a wake-up (below) — form 2: popped by this loop itself (builds with a spill region: the topology's); form 1: a loop of their own
+    // behind the wake-up (the other global-state builds: the KV's channel build, two spilled registers already, read 0.5 % slower with form 2's three
+    // live values).  last_dl / last_meta = the wake-up fired last in this call, which form 2 recognises its copies by.
+    constexpr bool COPIES2 = MADSIM_FIRE_COPIES == 2 && K::G && !K::DEDUP && K::SPILL;
+    constexpr bool COPIES1 = MADSIM_FIRE_COPIES != 0 && K::G && !K::DEDUP && !COPIES2;
+    uint64_t last_dl = ~0ull;
+    uint32_t last_meta = 0;
     while (L.top_dl <= now) {
         // Global-state builds: the callback's first loads (the woken task's flag word; the destination socket's header and
         // first registration) depend only on the ROOT entry, which sits in LDS — issue them before the pop, whose sift-down
@@ -198,9 +205,12 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
         uint32_t pf_flags = 0;
         DeliverPrefetch pf = {0, 0};
         uint2 pf_rec = make_uint2(0, 0);                  // narrow-heap builds: the root delivery's pool record {full event word, payload}
+        bool copy = false;
         if (K::G) {
             const uint32_t rz = heap_root_meta<K>(c), rk = rz >> EV_SHIFT;
-            if (rk == EV_WAKE) pf_flags = TWORD(c, rz & 0xff, 0, 0);
+            if (COPIES2) copy = L.top_dl == last_dl && rz == last_meta;
+            if (copy) { }
+            else if (rk == EV_WAKE) pf_flags = TWORD(c, rz & 0xff, 0, 0);
             else if (rk == EV_DELIVER) {
                 pf.hdr = SW(c, rz & 0x3f, 0); pf.reg0 = SW(c, rz & 0x3f, 2);
                 if (K::NH) pf_rec = buf_load64(c.gs, pool_addr(c, (rz >> 6) & 0x7fffu));
@@ -232,23 +242,27 @@ __device__ __forceinline__ void timer_expire(const Ctx& c, Lane& L, uint64_t now
                 else { const uint4 r = heap_lds_get<K>(c, 0); if (r.z != e.z || r.w != e.w) L.hazard = 1; }
             }
         }
-        if (kind == EV_WAKE) {                                                              // time/sleep.rs:52
+        // Form 2: a copy of the wake-up fired last is popped by THIS loop — a step, no callback — in the same trips as the other
+        // lanes' pops (form 1 popped them in a loop of its own behind the wake-up: 2.2 wave trips a pass with five lanes in them,
+        // tools/mem_site_model.py topo).  The same entries leave the heap in the same order.
+        if (COPIES2 && copy) { }
+        else if (kind == EV_WAKE) {                                                         // time/sleep.rs:52
             REG(22);
             if (K::G) wake_with<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff, pf_flags);
             else wake<K>(c, L, e.z & 0xff, (e.z >> 8) & 0xffff);
-#if MADSIM_FIRE_COPIES
+            if (COPIES2) { last_dl = ev_deadline(e); last_meta = popped_meta; }
             // Copies of this wake-up (the re-registrations of one pending Sleep: same deadline, same waker) are next in line, and firing them
             // changes nothing: the first made its task SCHEDULED — or found it gone, or of another generation — and so does every copy.
             // They are popped here, a step each (Timer::expire counts every entry), without the flag-word load and the store of a
             // callback.  Nothing else can sit between them: the heap hands out equal deadlines in ITS order, and only an entry equal in
             // deadline AND event word is skipped.
-            if (K::G && !K::DEDUP) {
+            if (COPIES1) {
                 while (L.heap_len > 0 && L.top_dl == ev_deadline(e) && heap_root_meta<K>(c) == popped_meta) { (void)timer_pop<K>(c, L); L.steps++; }
             }
-#endif
         }
-        else if (kind == EV_DELIVER) { REG(23); mailbox_deliver<K>(c, L, e.z, e.w, K::G ? &pf : nullptr); }      // net/mod.rs:323-330
-        else if (K::FN && kind == EV_RESTART) node_restart<K>(c, L, e.z & 0xff);   // task/mod.rs:313
+        else if (kind == EV_DELIVER) { REG(23); mailbox_deliver<K>(c, L, e.z, e.w, K::G ? &pf : nullptr); last_dl = ~0ull; }      // net/mod.rs:323-330
+        else if (K::FN && kind == EV_RESTART) { node_restart<K>(c, L, e.z & 0xff); last_dl = ~0ull; }   // task/mod.rs:313
+        else last_dl = ~0ull;
     }
 }
 

@@ -101,13 +101,21 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
     auto cu0_get = [&]() -> uint32_t { if (K::G) return pp.cu.x; return (uint32_t)TWORD(c, slot, c.P.chan_unit, 0); };
     auto cu0_set = [&](uint32_t v) { if (K::G) pp.cu.x = v; TWORD(c, slot, c.P.chan_unit, 0) = v; };
     auto cu_set = [&](const uint4& v) { if (CU_FULL) pp.cu = v; else if (K::G) pp.cu.x = v.x; TU(c, slot, c.P.chan_unit) = v; };
+    // this task's rpc unit (k_state.h PollPrefetch rq0 / rq1): the poll's copy where it has one, written through.  (Macros, not lambdas: builds
+    // without the copy must compile to what they were — the base-op kernels' register allocation follows every value the front end makes.)
+#ifdef MADSIM_EMU          // (the host-compiled kernel checks the copies against memory at every use)
+#define RQ_GET(k_) ((HoistRpc<K>::ON && ((k_) ? pp.rq1 : pp.rq0) != (uint32_t)TWORD(c, slot, P.rpc_unit, (k_)) ? (void)OVF_SET(L, OVF_BUG) : (void)0), (uint32_t)TWORD(c, slot, P.rpc_unit, (k_)))
+#else
+#define RQ_GET(k_) (HoistRpc<K>::ON ? ((k_) ? pp.rq1 : pp.rq0) : (uint32_t)TWORD(c, slot, P.rpc_unit, (k_)))
+#endif
+#define RQ_SET(k_, v_) do { const uint32_t rq_v_ = (v_); if (HoistRpc<K>::ON) { if (k_) pp.rq1 = rq_v_; else pp.rq0 = rq_v_; } TWORD(c, slot, P.rpc_unit, (k_)) = rq_v_; } while (0)
     auto recv_timeout_poll = [&]() -> bool {
         bool fut_ready = false;
         bool d1_new = false;
         if (sub == 1 && (u0.x & TF_INBOX)) {                 // oneshot ready -> rand_delay (endpoint.rs:145)
             u0.x &= ~TF_INBOX;
             from = u0.y >> 24;
-            if (K::FR && P.uses_rpc && (INSN(c, pc).x >> 24) >= MADSIM_TAG_RPC_FIRST) TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
+            if (K::FR && P.uses_rpc && (INSN(c, pc).x >> 24) >= MADSIM_TAG_RPC_FIRST) RQ_SET(0, RQ_GET(1));
             uint64_t d1 = rand_delay_deadline<K>(c, L);
             u1.z = (uint32_t)d1; u1.w = (uint32_t)(d1 >> 32); u1_dirty = true;
             sub = 2;
@@ -160,6 +168,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 uint32_t lb = 0, to_idx = dst, to_addr = SOCKW(c, dst);
                 if (!hooked) ipvs_rewrite<K>(c, to_idx, to_addr);          // after the hook, before try_send (net/mod.rs:312-317)
                 uint32_t dh = 0;
+                // (global-state builds: this Endpoint's header, which the registration below wants, requested with net_try_send's reads)
+                const uint32_t h_own = K::G ? (uint32_t)SW(c, ca, 0) : 0u;
                 const int sent = hooked ? 0 : net_try_send<K>(c, L, SOCKW(c, ca) & 0xff, to_addr, to_idx, &lat, &ds, &lb, &dh);
                 if (sent < 0) { st = ST_PANIC; return true; }
                 if (sent) {
@@ -171,7 +181,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
                 if (rxseq == 0) u0.x |= TF_RXWRAP;
                 u0.x &= ~TF_INBOX;
-                uint32_t h = SW(c, ca, 0);
+                uint32_t h = K::G ? h_own : (uint32_t)SW(c, ca, 0);
                 uint32_t nreg = (h >> 9) & 0xff;
                 if (may_have_twin(u0.x, gen)) for (uint32_t i = 0; i < nreg; i++) if (SW(c, ca, 2 + i) == reg) OVF_SET(L, OVF_MODEL);   // 8-bit rxseq wrapped onto a dead twin
                 if (nreg >= P.mbox_regs) OVF_SET(L, REGS_FULL);
@@ -251,11 +261,13 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         st = ST_PENDING;
     };
 
+    HeapPre heap_pre = {~0u, make_uint2(0, 0)};          // (k_timer.h timer_push_prefetch: requested when a round begins, used by the flush that ends it)
     for (;;) {
         // global-state builds: the Timer::add calls of the previous round happen here, at one site for the whole wave
-        timer_flush<K>(c, L, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot);
+        timer_flush<K>(c, L, (EV_WAKE << EV_SHIFT) | (gen << 8) | slot, heap_pre);
         PROBE_FLUSH();          // (EXP_PROF builds: the pushes apart from the wait for the other lanes' further rounds behind the loop)
         if (st != ST_RUN) break;
+        if (PushPrefetch<K>::ON) heap_pre = timer_push_prefetch<K>(c, L);
         // (pc < n_insns always: validate() checks jump targets and that the table ends in DONE / JMP / PANIC)
         uint4 in = insn_fetch<K>(c, L, pc);
         uint32_t op = in.x & 0xff, a = (in.x >> 8) & 0xff, b = in.x >> 16, imm = in.y;
@@ -272,7 +284,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     u0.x &= ~TF_INBOX;
                     from = u0.y >> 24;
                     if (K::FR && P.uses_rpc && (b >> 8) >= MADSIM_TAG_RPC_FIRST)   // (rsp_tag, req, data) = *data.downcast()
-                        TWORD(c, slot, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 1);
+                        RQ_SET(0, RQ_GET(1));
                     sub = 2;                               // -> rand_delay, begun in [C]
                 }
             } else if (op == MS_OP_YIELD) {
@@ -411,14 +423,19 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     uint32_t dst = (op == MS_OP_SEND) ? (b & 0xff) : (from & 0x3f);
                     uint32_t dst_addr = (op == MS_OP_SEND || PLAIN_ADDR) ? SOCKW(c, dst) : addr_of_from(c, from);
                     ipvs_rewrite<K>(c, dst, dst_addr);
-                    if (K::FR && op == MS_OP_RPC_REPLY) {    // send_to_raw(from, rsp_tag, rsp): rpc.rs:172-175
-                        b = 0xff00;
-                        imm = (imm & 0xff) | (TWORD(c, slot, P.rpc_unit, 0) << 8);
-                    }
+                    // (the request's rsp_tag word: requested here, looked at behind net_try_send — its destination-header request goes out in the
+                    //  same round trip instead of waiting for this one inside the divergent block)
+                    uint32_t rsp_tag_w = 0;
+                    const bool is_rpc_reply = K::FR && op == MS_OP_RPC_REPLY;
+                    if (is_rpc_reply) rsp_tag_w = RQ_GET(0);
                     // Network::try_send -> resolve_dest_node, test_link, socket lookup (network.rs:261-313)
                     uint64_t lat; int ds; uint32_t lb;
                     uint32_t dh = 0;
                     const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dst_addr, dst, &lat, &ds, &lb, &dh);
+                    if (is_rpc_reply) {                      // send_to_raw(from, rsp_tag, rsp): rpc.rs:172-175
+                        b = 0xff00;
+                        imm = (imm & 0xff) | (rsp_tag_w << 8);
+                    }
                     if (sent < 0) st = ST_PANIC;
                     else if (sent) {
                         {
@@ -513,7 +530,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);        // swap_remove
                     SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
                     u0.w = m1;
-                    if (K::FR && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 0) = m1 >> 8; }
+                    if (K::FR && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; RQ_SET(0, m1 >> 8); }
                     from = (m0 >> 8) & 0xff;
                     sub = 2;                               // oneshot already holds the value
                     SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
@@ -544,16 +561,25 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             if (rxseq == 0) u0.x |= TF_RXWRAP;
             u0.x &= ~TF_INBOX;
             uint32_t h = SW(c, a, 0);
+            const uint32_t mbase = 2 + P.mbox_regs;
+            // Global-state builds: the first queued message is requested with the header.  Three of four timeout(recv) calls of the topology find
+            // their datagram queued already, and the scan, the message's words and the swap_remove's last entry — the same words, when one
+            // message is queued — used to be four dependent round trips; now the header's, and one more only when something has to move.
+            uint32_t q0 = 0, q1 = 0;
+            if (K::G) { q0 = SW(c, a, mbase); q1 = SW(c, a, mbase + 1); }
             uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
-            uint32_t idx = 0, mbase = 2 + P.mbox_regs;
-            while (idx < nmsg && (SW(c, a, mbase + 2 * idx) & 0xff) != tag) idx++;
+            uint32_t idx = 0;
+            while (idx < nmsg && ((K::G && idx == 0 ? q0 : (uint32_t)SW(c, a, mbase + 2 * idx)) & 0xff) != tag) idx++;
             if (idx < nmsg) {
-                uint32_t m0 = SW(c, a, mbase + 2 * idx), m1 = SW(c, a, mbase + 2 * idx + 1);
+                uint32_t m0, m1;
+                if (K::G && idx == 0) { m0 = q0; m1 = q1; } else { m0 = SW(c, a, mbase + 2 * idx); m1 = SW(c, a, mbase + 2 * idx + 1); }
                 nmsg--;
-                SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);
-                SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
+                if (!K::G || idx != nmsg) {                   // swap_remove (the last entry onto itself: nothing moves)
+                    SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);
+                    SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
+                }
                 u0.w = m1;
-                if (K::FR && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; TWORD(c, slot, P.rpc_unit, 1) = m1 >> 8; }
+                if (K::FR && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; RQ_SET(1, m1 >> 8); }
                 u0.y = (u0.y & 0x00ffffffu) | (((m0 >> 8) & 0xff) << 24);
                 u0.x |= TF_INBOX;
                 SW(c, a, 0) = HDR_SET_NMSG(h, nmsg);
@@ -626,16 +652,25 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             case MS_OP_SPAWN: {
                 // another node's program: NodeHandle::spawn; this node's: task::spawn under this task's OWN NodeInfo (task/mod.rs:592-599)
                 const bool via = (PROGW(c, a) & 0xff) != node;
-                uint32_t child = spawn_task<K>(c, L, a, true, via, via ? -1 : (int)slot);
+                // (the request the child takes — rpc.rs:170 — goes into its units as spawn_task writes them; this task's request word is
+                //  requested with the spawn's own reads.  The poll's copies of this task's flag word and unit 1 are current: k_lifecycle.h SpawnInit)
+                uint32_t child;
+                if constexpr (K::G) {
+                    const bool mreq = K::FR && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST);
+                    const uint32_t req = mreq ? RQ_GET(0) : 0u;
+                    child = spawn_task<K>(c, L, a, true, via, via ? -1 : (int)slot, SpawnInit{!via, u0.x, u1.y, mreq, u0.w, from, req});
+                } else {
+                    child = spawn_task<K>(c, L, a, true, via, via ? -1 : (int)slot);
+                    if (K::FR && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST) && child != 0xffffffffu) {   // rpc.rs:170
+                        TWORD(c, child, 0, 3) = u0.w;
+                        TWORD(c, child, 0, 1) = (TWORD(c, child, 0, 1) & 0x00ffffffu) | (from << 24);
+                        TWORD(c, child, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 0);
+                    }
+                }
                 if (K::FC && P.uses_chan && (b & 2) && child != 0xffffffffu) {   // `async move`: the (tx, rx) pair moves
                     uint32_t cx = cu0_get();
                     TWORD(c, child, c.P.chan_unit, 0) = cx & 0x1ff;
                     cu0_set(cx | 0xff);
-                }
-                if (K::FR && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST) && child != 0xffffffffu) {   // rpc.rs:170
-                    TWORD(c, child, 0, 3) = u0.w;
-                    TWORD(c, child, 0, 1) = (TWORD(c, child, 0, 1) & 0x00ffffffu) | (from << 24);
-                    TWORD(c, child, P.rpc_unit, 0) = TWORD(c, slot, P.rpc_unit, 0);
                 }
             }
                 pc++;
@@ -831,7 +866,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 break;
             }
             case MS_OP_GSET: GREGW(a & 3) = imm; pc++; break;
-            case MS_OP_GADD: GREGW(a & 3) += imm; pc++; break;
+            case MS_OP_GADD: if constexpr (K::G) GREGW(a & 3).add(imm); else GREGW(a & 3) += imm; pc++; break;      // (global-state builds: an add in memory, no round trip — k_mem.h buf_add32)
             case MS_OP_ASSERT_G: if (GREGW(a & 3) != imm) st = ST_PANIC; else pc++; break;
             case MS_OP_PANIC_IF_G_LT: if (GREGW(a & 3) < imm) st = ST_PANIC; else pc++; break;
             case MS_OP_MARK:
@@ -857,7 +892,9 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 TU(c, slot, 0) = u0;
                 if (u1_dirty) { tu1_store<K>(c, slot, u1); u1_dirty = false; }
                 timer_expire<K>(c, L, L.clock);
+                heap_pre.idx = ~0u;                          // (the heap has changed)
                 u0 = TU(c, slot, 0); u1 = load_u1<K>(c, slot);
+                if (HoistRpc<K>::ON && P.uses_rpc) { pp.rq0 = TWORD(c, slot, P.rpc_unit, 0); pp.rq1 = TWORD(c, slot, P.rpc_unit, 1); }   // (a delivery to this task stages its rsp_tag)
                 from = u0.y >> 24;
                 break;
             case MS_OP_CLOSE: {

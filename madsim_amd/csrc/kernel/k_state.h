@@ -194,6 +194,7 @@ template <class K> __device__ __forceinline__ void rq_set(const Ctx& c, uint32_t
 // `off` = byte offset in the state buffer (the lane's gs_off already added).
 __device__ __forceinline__ uint32_t gs_load32(const BufRef& gs, uint32_t off) { EMU_GSTAT(off, 0); return buf_load32(gs, off); }
 __device__ __forceinline__ void gs_store32(const BufRef& gs, uint32_t off, uint32_t v) { EMU_GSTAT(off, 1); buf_store32(gs, off, v); }
+__device__ __forceinline__ void gs_add32(const BufRef& gs, uint32_t off, uint32_t v) { EMU_GSTAT(off, 1); buf_add32(gs, off, v); }
 __device__ __forceinline__ uint4 gs_load128(const BufRef& gs, uint32_t off) { EMU_GSTAT(off, 2); return buf_load128(gs, off); }
 __device__ __forceinline__ void gs_store128(const BufRef& gs, uint32_t off, const uint4& e) { EMU_GSTAT(off, 3); buf_store128(gs, off, e); }
 
@@ -204,6 +205,7 @@ __device__ __forceinline__ void gs_store128(const BufRef& gs, uint32_t off, cons
 template <bool G> struct WRef;
 template <> struct WRef<false> {
     uint32_t at;                      // LDS word index
+    __device__ __forceinline__ void add(uint32_t v) const { SMEM[at] += v; }
     __device__ __forceinline__ operator uint32_t() const { return SMEM[at]; }
     __device__ __forceinline__ uint32_t operator=(uint32_t v) const { SMEM[at] = v; return v; }
     __device__ __forceinline__ uint32_t operator=(const WRef& o) const { return *this = (uint32_t)o; }
@@ -213,6 +215,7 @@ template <> struct WRef<false> {
 };
 template <> struct WRef<true> {
     BufRef gs; uint32_t at;         // byte offset in the state buffer
+    __device__ __forceinline__ void add(uint32_t v) const { gs_add32(gs, at, v); }      // (nobody waits: k_mem.h buf_add32)
     __device__ __forceinline__ operator uint32_t() const { return gs_load32(gs, at); }
     __device__ __forceinline__ uint32_t operator=(uint32_t v) const { gs_store32(gs, at, v); return v; }
     __device__ __forceinline__ uint32_t operator=(const WRef& o) const { return *this = (uint32_t)o; }
@@ -366,10 +369,14 @@ template <class K> struct Hoist {
     static constexpr bool ALLG = K::G && (K::FEAT & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) == (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR);
     static constexpr bool CHAN = (K::G && K::FEAT == MADSIM_FEAT_CHAN) || ALLG;
 };
-struct PollPrefetch { uint32_t d2lo, d2hi; uint4 cu; };
+// rq0 / rq1 = the rpc unit's two words {rsp_tag in hand, rsp_tag staged with the oneshot value} (typed-RPC workloads): the completion of a request's
+// receive moves one to the other, rpc_reply and `spawn(async move)` read the first — each used to be a round trip of its own inside a divergent handler.
+struct PollPrefetch { uint32_t d2lo, d2hi; uint4 cu; uint32_t rq0, rq1; };
+template <class K> struct HoistRpc { static constexpr bool ON = K::G && K::FR; };
 __device__ __forceinline__ bool has_t0_unit(const KParams& P) { return P.task_units > 2 && !(P.uses_chan && P.chan_unit == 2); }   // geometry.h `t0`
 template <class K> __device__ __forceinline__ PollPrefetch poll_prefetch(const Ctx& c, uint32_t slot) {
-    PollPrefetch pp = {0, 0, make_uint4(0, 0, 0, 0)};
+    PollPrefetch pp = {0, 0, make_uint4(0, 0, 0, 0), 0, 0};
+    if (HoistRpc<K>::ON && c.P.uses_rpc) { const uint2 t = buf_load64(c.gs, gs_addr_task(c, slot, c.P.rpc_unit * 16u)); pp.rq0 = t.x; pp.rq1 = t.y; }
     if (K::G && K::FT && has_t0_unit(c.P)) { const uint2 t = buf_load64(c.gs, gs_addr_task(c, slot, 2 * 16u + 8u)); pp.d2lo = t.x; pp.d2hi = t.y; }
     // (the whole unit in the channel-only builds; the builds that carry every op class are short of registers: word 0 only, the
     // rest is read where it is wanted — k_poll.h cu_get)

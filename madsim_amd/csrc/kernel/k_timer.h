@@ -166,8 +166,14 @@ __device__ __forceinline__ uint2 ev_deliver_meta(uint32_t sgen, uint32_t tag, ui
 // Builds with a spill region walk two levels per trip: parent and grandparent are loaded together (their indices depend on
 // `pos` alone), so a sift through the spilled levels costs one global round trip per TWO levels; the comparisons and stores
 // are those of the one-level loop, in the same order.
+// `pre` (k_poll.h: MADSIM_PUSH_PREFETCH): the entry of heap slot pre.idx, requested when the poll round began — the parent of the slot the round's
+// first push starts from, a spilled one whose own parent lies in LDS — so that push compares at once instead of waiting a round trip.
+struct HeapPre { uint32_t idx; uint2 e; };
+// (the every-class builds: two waves per SIMD, registers to spare.  The single-class ones run three at 168 registers — the election loop's spilled
+//  three with this — and their heaps are short: a push's parent is an LDS entry there.)
+template <class K> struct PushPrefetch { static constexpr bool ON = MADSIM_PUSH_PREFETCH && K::G && K::NH && K::SPILL && (K::FEAT & (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR)) == (MADSIM_FEAT_ALL & ~MADSIM_FEAT_ADDR); };
 template <class K>
-__device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos, const uint4& hole) {
+__device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos, const uint4& hole, HeapPre pre = HeapPre{~0u, make_uint2(0, 0)}) {
     uint64_t hd = ev_deadline(hole);
     bool up = pos > 0;
     while (up) {                                       // (one exit: see k_main.h)
@@ -176,7 +182,15 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos
         if (K::SPILL || K::G) {          // (global-state builds without a spill region too: two LDS levels per round trip)
             const uint32_t gp = parent > 0 ? (parent - 1) >> 1 : 0;
             uint4 p, g;
-            if (parent > 0) heap_get2<K>(c, L, gp, parent, g, p);
+            if (PushPrefetch<K>::ON && parent == pre.idx) {              // (pre.idx >= heap_lds > 0, its parent in LDS: timer_push_prefetch)
+#ifdef MADSIM_EMU
+                { const uint2 now = nh_load<K>(c, parent); if (now.x != pre.e.x || now.y != pre.e.y) OVF_SET(L, OVF_BUG); }    // nothing touched the heap since
+#endif
+                p = nh_expand(L, pre.e);
+                g = nh_expand(L, LDS64(c.heap0 + (gp << LWSH<K>(c))));
+                pre.idx = ~0u;
+            }
+            else if (parent > 0) heap_get2<K>(c, L, gp, parent, g, p);
             else { p = heap_get<K>(c, L, 0); g = p; }
             up = hd < (parent == 0 ? L.top_dl : ev_deadline(p));
             if (up) {
@@ -197,7 +211,7 @@ __device__ __forceinline__ void heap_sift_up(const Ctx& c, Lane& L, uint32_t pos
 
 // Timer::add -> BinaryHeap::push.  Returns false on capacity overflow.
 template <class K>
-__device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val) {
+__device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadline, uint32_t meta, uint32_t val, HeapPre pre = HeapPre{~0u, make_uint2(0, 0)}) {
     PROBE2(0);
     REG(10);
     bool room = L.heap_len < c.P.heap_lds + (K::SPILL ? c.P.heap_spill : 0u);
@@ -216,7 +230,7 @@ __device__ __forceinline__ bool timer_add(const Ctx& c, Lane& L, uint64_t deadli
     }
     if (room) {                                        // (no early return: see k_main.h on exit edges)
         uint4 e = make_uint4((uint32_t)deadline, (uint32_t)(deadline >> 32), meta, val);
-        heap_sift_up<K>(c, L, L.heap_len, e);
+        heap_sift_up<K>(c, L, L.heap_len, e, pre);
         L.heap_len++;
     }
     PROBE2(10);
@@ -287,8 +301,23 @@ __device__ __forceinline__ void timer_schedule(const Ctx& c, Lane& L, uint64_t d
     }
 }
 // Perform the queued pushes, oldest first.  `wake_meta` = the wake-up event of the task being polled.
+// The request a poll round makes for its first push (k_poll.h): the parent of slot heap_len, when that is a spilled entry whose own parent is in LDS
+// (the topology's heap: 74 entries over 31 LDS slots — a push starts on level 6, its parent on level 5, the grandparent on level 4).
 template <class K>
-__device__ __forceinline__ void timer_flush(const Ctx& c, Lane& L, uint32_t wake_meta) {
+__device__ __forceinline__ HeapPre timer_push_prefetch(const Ctx& c, const Lane& L) {
+    HeapPre pre = {~0u, make_uint2(0, 0)};
+    if (PushPrefetch<K>::ON) {
+        const uint32_t cap = c.P.heap_lds, pos = L.heap_len;
+        if (pos >= 2 * cap + 1 && pos < 4 * cap + 3) {          // parent = (pos - 1) / 2 >= cap, grandparent = (parent - 1) / 2 < cap
+            const uint32_t parent = (pos - 1) >> 1;
+            pre.e = buf_load64(c.spill, (parent - cap) * c.P.total_lanes * 8u + c.spill_off);
+            pre.idx = parent;
+        }
+    }
+    return pre;
+}
+template <class K>
+__device__ __forceinline__ void timer_flush(const Ctx& c, Lane& L, uint32_t wake_meta, HeapPre pre = HeapPre{~0u, make_uint2(0, 0)}) {
     if (!K::G) return;
     while (L.pq_n) {
         uint64_t dl; uint32_t meta, val;
@@ -300,7 +329,8 @@ __device__ __forceinline__ void timer_flush(const Ctx& c, Lane& L, uint32_t wake
             L.pq_n = ((L.pq_n & 7u) - 1u) | ((L.pq_n >> 1) & 0x18u);        // one wake-up less; the repeat flags move down with their deadlines
             if (again && c.P.dedup_n && !L.exact && dedup_note(c, L, dl, meta)) continue;
         }
-        if (!timer_add<K>(c, L, dl, meta, val)) OVF_SET(L, OVF_CAP);
+        if (!timer_add<K>(c, L, dl, meta, val, pre)) OVF_SET(L, OVF_CAP);
+        pre.idx = ~0u;                                      // (the heap has changed: the request was for the round's first push)
     }
 }
 

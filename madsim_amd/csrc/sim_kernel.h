@@ -38,7 +38,7 @@
    earlier one; copies leave the heap back to back, and every one after the first finds its task SCHEDULED already (or gone): a step
    each and nothing else.  The batch pops them without their callback's loads.  (The part of VERDICT r5 #1c that removes work.) */
 #ifndef MADSIM_FIRE_COPIES
-#define MADSIM_FIRE_COPIES 1
+#define MADSIM_FIRE_COPIES 2        /* 1: a loop of its own behind the wake-up; 2: popped by the fire loop itself, in the other lanes' trips */
 #endif
 /* Builds with a spill region: BinaryHeap::pop written top-down (k_timer.h timer_pop) — the array sift_down_to_bottom + sift_up leave, without the
    levels below the moved entry's final slot. */
@@ -61,6 +61,11 @@
 #define MADSIM_POP_TOPDOWN 1
 #endif
 /* ... with the LDS-resident levels walked before the heap's last entry (a spill-region load) has arrived (k_timer.h timer_pop). */
+/* Narrow-heap global-state builds: a poll round requests the parent of the slot its first push will start from when it begins (k_timer.h
+   timer_push_prefetch), beside its handler's own reads. */
+#ifndef MADSIM_PUSH_PREFETCH
+#define MADSIM_PUSH_PREFETCH 0        /* measured: topology 5.75 with, 5.76 without (profiles/r6_ab_chains.txt): the three registers cost what the round trip saves */
+#endif
 #ifndef MADSIM_POP_LDS_FIRST
 #define MADSIM_POP_LDS_FIRST 1
 #endif

@@ -46,6 +46,7 @@ void emu_site(int kind, const void* base, uint32_t off);
 #endif
 static inline uint32_t buf_load32(const BufRef& b, uint32_t off) { EMU_SITE(0, b, off); return *(const uint32_t*)(b.base + off); }
 static inline void buf_store32(const BufRef& b, uint32_t off, uint32_t v) { EMU_SITE(1, b, off); *(uint32_t*)(b.base + off) = v; }
+static inline void buf_add32(const BufRef& b, uint32_t off, uint32_t v) { EMU_SITE(1, b, off); *(uint32_t*)(b.base + off) += v; }
 static inline uint2 buf_load64(const BufRef& b, uint32_t off) { EMU_SITE(0, b, off); return *(const uint2*)(b.base + off); }
 static inline void buf_store64(const BufRef& b, uint32_t off, const uint2& e) { EMU_SITE(1, b, off); *(uint2*)(b.base + off) = e; }
 static inline uint4 buf_load128(const BufRef& b, uint32_t off) { EMU_SITE(2, b, off); return *(const uint4*)(b.base + off); }

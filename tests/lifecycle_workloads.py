@@ -1055,6 +1055,9 @@ def limits(name):
     if name == "many_endpoints_dropped_in_table_order":
         lim = A.Limits(); lim.max_tasks = 8
         return lim
+    if name == "kill_many_tasks":                        # 13 sleepers + the init task, twice over while a restart's kill is pending
+        lim = A.Limits(); lim.max_tasks = 40
+        return lim
     if name == "join_handle_awaits_the_task_it_named":   # two instances of one program alive at once
         lim = A.Limits(); lim.max_tasks = 6
         return lim
@@ -1272,3 +1275,25 @@ def dedup_limits(base=None):
         lim.lanes_per_wave = 0
     lim.state_mem = A.STATE_GLOBAL | A.STATE_DEDUP_TIMERS
     return lim
+
+
+def kill_many_tasks(n_sleepers=13):
+    """NodeInfo::kill marks and wakes every task of the node IN SPAWN ORDER (task/mod.rs:133-140): a node with more tasks than the global-state
+    kernel's kill keeps per scan (four: k_lifecycle.h info_kill), killed, restarted twice (the second restart kills the first's tasks) and
+    killed again, with the tasks' timers still in the heap."""
+    wl = W.WorkloadBuilder()
+    n = wl.create_node()
+    ts = []
+    for i in range(n_sleepers):
+        t = wl.task(n); top = t.label(); t.sleep(ms=3 + i); t.flag_add(0, 1); t.jmp(top); ts.append(t)
+    ini = wl.task(n, init=True)
+    for t in ts:
+        ini.spawn(t)
+    top = ini.label(); ini.sleep(ms=50); ini.jmp(top)
+    m = wl.main()
+    m.build_node(n)
+    m.sleep(ms=20); m.kill(n); m.sleep(ms=5); m.restart(n); m.sleep(ms=17); m.restart(n); m.sleep(ms=9); m.kill(n); m.sleep(ms=3)
+    return wl.build()
+
+
+ALL.update(kill_many_tasks=kill_many_tasks)
