@@ -328,6 +328,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     uint32_t dial = b & 0xff, dial_addr = SOCKW(c, dial);
                     ipvs_rewrite<K>(c, dial, dial_addr);          // channel() below is built from the rewritten dst (net/mod.rs:345-357)
                     uint32_t dh;
+                    // (global-state builds, plain addresses — the listener's socket IS table entry `dial`: its parked acceptor's word goes out with
+                    //  net_try_send's header request, so the acceptor's flag word can go out with the batch below instead of after it)
+                    const bool acc_early = Hoist<K>::CHAN && PLAIN_ADDR;
+                    const uint32_t acc_e = acc_early ? (uint32_t)SW(c, dial, 3 + P.mbox_regs + 2 * P.mbox_msgs) : 0u;
                     const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dial_addr, dial, &lat, &ds, &lb, &dh);
                     if (sent < 0) st = ST_PANIC;
                     else if (!sent) {
@@ -336,7 +340,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                         uint32_t id = 0;
                         uint32_t base = 2 + P.mbox_regs + 2 * P.mbox_msgs;
                         uint64_t q;
-                        uint32_t own_p = 0, acc_p = 0, ha_p = 0;
+                        uint32_t own_p = 0, acc_p = 0, ha_p = 0, awf_p = 0;
                         if (Hoist<K>::CHAN) {
                             // one round trip for everything the rest of the op reads: the first four connection headers (the free-slot
                             // search), the listener's queue word, owner word and parked acceptor, this Endpoint's header.  What is
@@ -344,7 +348,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                             const uint32_t c0 = CONNW(0, 0), c1 = P.max_conns > 1 ? (uint32_t)CONNW(1, 0) : 1u,
                                            c2 = P.max_conns > 2 ? (uint32_t)CONNW(2, 0) : 1u, c3 = P.max_conns > 3 ? (uint32_t)CONNW(3, 0) : 1u;
                             const uint32_t q_lo = SW(c, ds, base), q_hi = SW(c, ds, base + 2);
-                            own_p = SW(c, ds, 1); acc_p = SW(c, ds, base + 1); ha_p = SW(c, a, 0);
+                            own_p = SW(c, ds, 1); acc_p = acc_early ? acc_e : (uint32_t)SW(c, ds, base + 1); ha_p = SW(c, a, 0);
+                            if (acc_early && (acc_e & 1)) awf_p = TWORD(c, (acc_e >> 1) & 0xff, 0, 0);
                             q = u64of(q_lo, q_hi);
                             id = !(c0 & 1) ? 0u : !(c1 & 1) ? 1u : !(c2 & 1) ? 2u : !(c3 & 1) ? 3u : 4u;
                             while (id >= 4 && id < P.max_conns && (CONNW(id, 0) & 1)) id++;      // (beyond the first four: one at a time)
@@ -375,7 +380,15 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                                 else {
                                     acceptq_store<K>(c, (uint32_t)ds, (q & ~0xfull) | (n + 1) | ((uint64_t)id << (4 + 7 * n)));
                                     uint32_t acc = Hoist<K>::CHAN ? acc_p : (uint32_t)SW(c, ds, base + 1);
-                                    if (acc & 1) { SW(c, ds, base + 1) = 0; wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9); }
+                                    if (acc & 1) {
+                                        SW(c, ds, base + 1) = 0;
+                                        if (acc_early) {
+#ifdef MADSIM_EMU
+                                            if ((uint32_t)ds != dial || awf_p != (uint32_t)TWORD(c, (acc >> 1) & 0xff, 0, 0)) OVF_SET(L, OVF_BUG);
+#endif
+                                            wake_with<K>(c, L, (acc >> 1) & 0xff, acc >> 9, awf_p);
+                                        } else wake<K>(c, L, (acc >> 1) & 0xff, acc >> 9);
+                                    }
                                 }
                             }
                         }
@@ -815,6 +828,10 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 uint32_t id = cx & 0xff, side = (cx >> 8) & 1;
                 uint32_t cw = CONNW(id, 0);
                 const uint32_t r_pre = Hoist<K>::CHAN ? (uint32_t)CONNW(id, 1 + side) : 0;   // (global-state builds: the parked receiver's word with the header, not after the link test)
+                // (... and that receiver's flag word, which the wake-up below wants, with the link test's destination header: the test draws and
+                //  stores nothing a task's flags depend on; the receiver is parked, not this task)
+                uint32_t wf_pre = 0;
+                if (Hoist<K>::CHAN && (r_pre & 1)) wf_pre = TWORD(c, (r_pre >> 1) & 0xff, 0, 0);
                 uint64_t arrive = chan_test_link<K>(c, L, cw, side);          // draws happen before the closed check
                 if (arrive == CHAN_LINK_PANIC) { st = ST_PANIC; break; }
                 if (!(cw & (1u << (14 + 2 * side)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // ConnectionReset
@@ -826,7 +843,15 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 CONNW(id, e) = imm; CONNW(id, e + 1) = (uint32_t)arrive; CONNW(id, e + 2) = (uint32_t)(arrive >> 32);
                 CONNW(id, 0) = (cw & ~(0xfu << (17 + 4 * side))) | ((qn + 1) << (17 + 4 * side));
                 uint32_t r = Hoist<K>::CHAN ? r_pre : (uint32_t)CONNW(id, 1 + side);
-                if (r & 1) { CONNW(id, 1 + side) = 0; wake<K>(c, L, (r >> 1) & 0xff, r >> 9); }   // mpsc wakes the parked receiver
+                if (r & 1) {                                                        // mpsc wakes the parked receiver
+                    CONNW(id, 1 + side) = 0;
+                    if (Hoist<K>::CHAN) {
+#ifdef MADSIM_EMU
+                        if (wf_pre != (uint32_t)TWORD(c, (r >> 1) & 0xff, 0, 0)) OVF_SET(L, OVF_BUG);
+#endif
+                        wake_with<K>(c, L, (r >> 1) & 0xff, r >> 9, wf_pre);
+                    } else wake<K>(c, L, (r >> 1) & 0xff, r >> 9);
+                }
                 pc++;
                 break;
             }
