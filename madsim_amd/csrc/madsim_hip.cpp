@@ -762,6 +762,9 @@ int madsim_hip_ctx_run_batch_async(madsim_hip_ctx_t* c, const madsim_workload_t*
     int rc = c->run_device(w, cfg, seed0, count, lim, (madsim_result_t*)d_out, st, nullptr);
     if (rc) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+#ifdef MADSIM_EXP_NO_SUMMARY      // (timing experiment, tools/build_variant.sh only: what the report reduction behind every launch costs the stream)
+    d_summary4 = nullptr;
+#endif
     if (d_summary4 && count) {
         // {UINT64_MAX, 0, 0, 0}, accumulated by the reduction kernel, then word 0 is flipped into its
         // order-preserving int64 form (seed ^ 1<<63) so a signed all-reduce(MIN) yields the unsigned minimum
