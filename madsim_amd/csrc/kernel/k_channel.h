@@ -12,7 +12,10 @@ namespace madsim_k {
 // scheduled, 0 when the message is dropped, -1 when the sender panics (`.ip.unwrap()` of an IP-less node, :309).
 template <class K>
 // `dst_hdr` receives the destination socket's header word (valid when the result is 1).
-__device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_node, uint32_t addr, uint32_t idx, uint64_t* latency, int* dst_sock, uint32_t* from_lb, uint32_t* dst_hdr) {
+// `known_idx` / `known_hdr` (k_poll.h stage [A]): the header word of table entry known_idx, requested before the handlers — one wait for the wave
+// instead of one in every handler that sends.
+__device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_node, uint32_t addr, uint32_t idx, uint64_t* latency, int* dst_sock, uint32_t* from_lb, uint32_t* dst_hdr,
+                                            uint32_t known_idx = ~0u, uint32_t known_hdr = 0) {
     const KParams& P = c.P;
     // (one result variable, no early returns: every extra way out of an inlined body costs phi copies where it is used)
     int res = 0;
@@ -20,7 +23,14 @@ __device__ __forceinline__ int net_try_send(const Ctx& c, Lane& L, uint32_t src_
     // requested here — with the clog words — and has arrived when the loss and latency draws are done, instead of costing a round
     // trip after them.  (Nothing is stored in between.)
     uint32_t hdr = 0;
-    if (K::G && PLAIN_ADDR) hdr = SW(c, idx, 0);
+    if (K::G && PLAIN_ADDR) {
+        if (idx == known_idx) {
+#ifdef MADSIM_EMU
+            if (known_hdr != (uint32_t)SW(c, idx, 0)) OVF_SET(L, OVF_BUG);     // nothing was stored since the request
+#endif
+            hdr = known_hdr;
+        } else hdr = SW(c, idx, 0);
+    }
     int dn = (int)(addr & 0xff);                            // resolve_dest_node: plain node IPs resolve to their node
     if (!PLAIN_ADDR) dn = resolve_dest_node<K>(c, src_node, addr);          // < 0: dropped, no draw
     if (dn >= 0) {

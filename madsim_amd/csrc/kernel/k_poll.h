@@ -109,6 +109,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
 #define RQ_GET(k_) (HoistRpc<K>::ON ? ((k_) ? pp.rq1 : pp.rq0) : (uint32_t)TWORD(c, slot, P.rpc_unit, (k_)))
 #endif
 #define RQ_SET(k_, v_) do { const uint32_t rq_v_ = (v_); if (HoistRpc<K>::ON) { if (k_) pp.rq1 = rq_v_; else pp.rq0 = rq_v_; } TWORD(c, slot, P.rpc_unit, (k_)) = rq_v_; } while (0)
+    // stage [A]'s requests for the ops that send in this round (HdrPrefetch): destination table entry, its header, the caller's own header (rpc call)
+    uint32_t a_dst = ~0u, a_hdr = 0, a_own = 0;
     auto recv_timeout_poll = [&]() -> bool {
         bool fut_ready = false;
         bool d1_new = false;
@@ -169,8 +171,15 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if (!hooked) ipvs_rewrite<K>(c, to_idx, to_addr);          // after the hook, before try_send (net/mod.rs:312-317)
                 uint32_t dh = 0;
                 // (global-state builds: this Endpoint's header, which the registration below wants, requested with net_try_send's reads)
-                const uint32_t h_own = K::G ? (uint32_t)SW(c, ca, 0) : 0u;
-                const int sent = hooked ? 0 : net_try_send<K>(c, L, SOCKW(c, ca) & 0xff, to_addr, to_idx, &lat, &ds, &lb, &dh);
+                // (`if constexpr`: a build without the requests must not even capture them — the closure's shape moves the base-op builds' registers)
+                uint32_t h_own, kn_idx = ~0u, kn_hdr = 0;
+                if constexpr (HdrPrefetch<K>::ON) {
+#ifdef MADSIM_EMU
+                    if (a_dst != to_idx || a_own != (uint32_t)SW(c, ca, 0)) OVF_SET(L, OVF_BUG);     // stage [A] requested exactly these
+#endif
+                    h_own = a_own; kn_idx = a_dst; kn_hdr = a_hdr;
+                } else h_own = K::G ? (uint32_t)SW(c, ca, 0) : 0u;
+                const int sent = hooked ? 0 : net_try_send<K>(c, L, SOCKW(c, ca) & 0xff, to_addr, to_idx, &lat, &ds, &lb, &dh, kn_idx, kn_hdr);
                 if (sent < 0) { st = ST_PANIC; return true; }
                 if (sent) {
                     uint32_t sgen = (dh >> 1) & 0xff;
@@ -274,6 +283,19 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
 
         PROBE(5);
         REG(2);
+        // Requests of stage [A]: the ops whose rand_delay has elapsed send in this round — send_to / reply / rpc_reply in the Sleep branch below, the
+        // call of an rpc in rpc_call_poll — and each used to wait for its destination's header inside its own divergent block.  The lanes of all of
+        // them request it here, together (and the rpc caller its own Endpoint's header, which the registration wants).
+        if constexpr (HdrPrefetch<K>::ON) a_dst = ~0u;
+        if constexpr (HdrPrefetch<K>::ON) if (sub != 0 && sub < SUB_JOIN_WAIT && L.clock >= u64of(u1.z, u1.w)) {
+            const bool snd = op == MS_OP_SEND || op == MS_OP_REPLY || (K::FR && op == MS_OP_RPC_REPLY);
+            const bool call = K::FR && op == MS_OP_RPC_CALL && sub == 1;
+            if (snd || call) {
+                a_dst = (op == MS_OP_SEND || call) ? (b & 0xff) : (from & 0x3f);
+                a_hdr = SW(c, a_dst, 0);
+                if (call) a_own = SW(c, a, 0);
+            }
+        }
         // ================= [A] the task is parked on an await of this op =========================
         if (sub != 0 && sub < SUB_JOIN_WAIT) {
             bool completed = false;                        // this op is done: step to the next one below
@@ -444,7 +466,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     // Network::try_send -> resolve_dest_node, test_link, socket lookup (network.rs:261-313)
                     uint64_t lat; int ds; uint32_t lb;
                     uint32_t dh = 0;
-                    const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dst_addr, dst, &lat, &ds, &lb, &dh);
+                    const int sent = net_try_send<K>(c, L, SOCKW(c, a) & 0xff, dst_addr, dst, &lat, &ds, &lb, &dh, a_dst, a_hdr);
                     if (is_rpc_reply) {                      // send_to_raw(from, rsp_tag, rsp): rpc.rs:172-175
                         b = 0xff00;
                         imm = (imm & 0xff) | (rsp_tag_w << 8);
@@ -489,6 +511,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             }
         }
 
+        if constexpr (HdrPrefetch<K>::ON) a_dst = ~0u;     // (stage [A]'s requests are spent)
         PROBE(6);
         // ================= [B] cheap ops that never await ========================================
         while (is_light(op)) {
@@ -525,6 +548,13 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         // ================= [C] begin the next op =================================================
         bool want_delay = false, want_sleep = false;
         uint64_t deadline = 0;
+        // Every-class global-state builds: a receive that begins here — recv_from or timeout(recv_from) — wants its Endpoint's header and first queued message.
+        // Both kinds request them HERE, in one instruction stream for the lanes of either, so the wave waits once for the two handlers, not once in
+        // each (a wave runs every handler some lane is in; each handler's wait holds all 64 lanes).  Nothing is stored between here and the handlers.
+        uint32_t c_hdr = 0, c_q0 = 0, c_q1 = 0;
+        if (RecvPrefetch<K>::ON && ((op == MS_OP_RECV && sub == 0) || (K::FT && op == MS_OP_RECV_TIMEOUT))) {
+            c_hdr = SW(c, a, 0); c_q0 = SW(c, a, 2 + P.mbox_regs); c_q1 = SW(c, a, 3 + P.mbox_regs);
+        }
         if (op == MS_OP_RECV) {
             if (sub == 0) {                                // Mailbox::recv (endpoint.rs:353-362)
                 REG(14);
@@ -533,15 +563,18 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
                 if (rxseq == 0) u0.x |= TF_RXWRAP;
                 u0.x &= ~TF_INBOX;
-                uint32_t h = SW(c, a, 0);
+                uint32_t h = RecvPrefetch<K>::ON ? c_hdr : (uint32_t)SW(c, a, 0);
                 uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
                 uint32_t idx = 0, mbase = 2 + P.mbox_regs;
-                while (idx < nmsg && (SW(c, a, mbase + 2 * idx) & 0xff) != tag) idx++;
+                while (idx < nmsg && ((RecvPrefetch<K>::ON && idx == 0 ? c_q0 : (uint32_t)SW(c, a, mbase + 2 * idx)) & 0xff) != tag) idx++;
                 if (idx < nmsg) {
-                    uint32_t m0 = SW(c, a, mbase + 2 * idx), m1 = SW(c, a, mbase + 2 * idx + 1);
+                    uint32_t m0, m1;
+                    if (RecvPrefetch<K>::ON && idx == 0) { m0 = c_q0; m1 = c_q1; } else { m0 = SW(c, a, mbase + 2 * idx); m1 = SW(c, a, mbase + 2 * idx + 1); }
                     nmsg--;
-                    SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);        // swap_remove
-                    SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
+                    if (!RecvPrefetch<K>::ON || idx != nmsg) {    // swap_remove (with the requests above: the last entry onto itself moves nothing)
+                        SW(c, a, mbase + 2 * idx) = SW(c, a, mbase + 2 * nmsg);
+                        SW(c, a, mbase + 2 * idx + 1) = SW(c, a, mbase + 2 * nmsg + 1);
+                    }
                     u0.w = m1;
                     if (K::FR && P.uses_rpc && tag >= MADSIM_TAG_RPC_FIRST) { u0.w = m1 & 0xff; RQ_SET(0, m1 >> 8); }
                     from = (m0 >> 8) & 0xff;
@@ -573,13 +606,14 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
             u1.x = (u1.x & ~0xffu) | rxseq; u1_dirty = true;
             if (rxseq == 0) u0.x |= TF_RXWRAP;
             u0.x &= ~TF_INBOX;
-            uint32_t h = SW(c, a, 0);
             const uint32_t mbase = 2 + P.mbox_regs;
-            // Global-state builds: the first queued message is requested with the header.  Three of four timeout(recv) calls of the topology find
-            // their datagram queued already, and the scan, the message's words and the swap_remove's last entry — the same words, when one
-            // message is queued — used to be four dependent round trips; now the header's, and one more only when something has to move.
-            uint32_t q0 = 0, q1 = 0;
-            if (K::G) { q0 = SW(c, a, mbase); q1 = SW(c, a, mbase + 1); }
+            // Global-state builds: the first queued message is requested with the header (above, with recv_from's).  Three of four timeout(recv) calls
+            // of the topology find their datagram queued already, and the scan, the message's words and the swap_remove's last entry — the same words,
+            // when one message is queued — used to be four dependent round trips; now the header's, and one more only when something has to move.
+            // (the other global-state builds request the three words here, in the handler)
+            uint32_t h, q0 = c_q0, q1 = c_q1;
+            if (RecvPrefetch<K>::ON) h = c_hdr;
+            else { h = SW(c, a, 0); if (K::G) { q0 = SW(c, a, mbase); q1 = SW(c, a, mbase + 1); } }
             uint32_t nreg = (h >> 9) & 0xff, nmsg = HDR_NMSG(h);
             uint32_t idx = 0;
             while (idx < nmsg && ((K::G && idx == 0 ? q0 : (uint32_t)SW(c, a, mbase + 2 * idx)) & 0xff) != tag) idx++;

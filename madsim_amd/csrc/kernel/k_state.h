@@ -373,6 +373,13 @@ template <class K> struct Hoist {
 // receive moves one to the other, rpc_reply and `spawn(async move)` read the first — each used to be a round trip of its own inside a divergent handler.
 struct PollPrefetch { uint32_t d2lo, d2hi; uint4 cu; uint32_t rq0, rq1; };
 template <class K> struct HoistRpc { static constexpr bool ON = K::G && K::FR; };
+// Every-class global-state builds with plain addresses at compile time: stage [A] of a poll round requests the destination socket's header for every lane whose
+// op sends in this round (k_poll.h), before the handlers.
+// (The every-class builds — two waves per SIMD, registers to spare: topology +2.4 %.  The KV's channel build, at its 168-register cap, spilled two more
+//  registers with them and read -4.4 %: profiles/r6_ab_stage_prefetch.txt.)
+template <class K> struct HdrPrefetch { static constexpr bool ON = Hoist<K>::ALLG && !K::FA; };
+// ... and stage [C]: the header and first queued message of the Endpoint a recv_from / timeout(recv_from) begins on, for the lanes of both at once.
+template <class K> struct RecvPrefetch { static constexpr bool ON = Hoist<K>::ALLG; };
 __device__ __forceinline__ bool has_t0_unit(const KParams& P) { return P.task_units > 2 && !(P.uses_chan && P.chan_unit == 2); }   // geometry.h `t0`
 template <class K> __device__ __forceinline__ PollPrefetch poll_prefetch(const Ctx& c, uint32_t slot) {
     PollPrefetch pp = {0, 0, make_uint4(0, 0, 0, 0), 0, 0};
