@@ -12,17 +12,24 @@ namespace madsim_k {
 // unit 1 word 1 (spawn order | info_gen << 24: the NodeInfo it runs under), so task::spawn reads neither — and what `async move` hands the
 // child: the request's value and sender (unit 0 w and y bits 24-31) and the request word of the rpc unit, stored WITH the new task's units
 // instead of over them afterwards.
-struct SpawnInit { bool parent_known; uint32_t parent_f, parent_u1y; bool move_req; uint32_t w, from, req; };
+// `words_known` (every-class global-state builds, k_poll.h stage [C]): the free slot and the words the spawn reads — the slot's old flag word, the
+// node's info-generation word, the spawn counter, the gen-0 killed mask of a NodeHandle::spawn — were requested with the stage's other reads.
+struct SpawnInit { bool parent_known; uint32_t parent_f, parent_u1y; bool move_req; uint32_t w, from, req;
+                   bool words_known; uint32_t slot, w_old, w_gen, seq, w_killed; };
 template <class K>
 __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t prog, bool record, bool via_handle = false, int parent = -1,
-                                               const SpawnInit init = SpawnInit{false, 0, 0, false, 0, 0, 0}) {
+                                               const SpawnInit init = SpawnInit{false, 0, 0, false, 0, 0, 0, false, 0, 0, 0, 0, 0}) {
     uint32_t slot = 0;
     if (K::G) {                                              // first free slot = first zero bit of the alive mask (LDS)
         slot = c.P.max_tasks;
-        for (uint32_t wi = 0; wi < (c.P.max_tasks + 31) / 32; wi++) {
+        if (init.words_known) slot = init.slot;              // (found by the caller, nothing spawned since)
+        else for (uint32_t wi = 0; wi < (c.P.max_tasks + 31) / 32; wi++) {
             uint32_t free_bits = ~AMASK(wi);
             if (free_bits) { slot = wi * 32 + (uint32_t)__builtin_ctz(free_bits); break; }
         }
+#ifdef MADSIM_EMU
+        if (init.words_known && ((AMASK(slot >> 5) >> (slot & 31)) & 1)) OVF_SET(L, OVF_BUG);
+#endif
     } else {
         while (slot < c.P.max_tasks && (TWORD(c, slot, 0, 0) & TF_ALIVE)) slot++;
     }
@@ -39,15 +46,25 @@ __device__ __forceinline__ uint32_t spawn_task(const Ctx& c, Lane& L, uint32_t p
         // node's info generation, the killed mask or the parent's words, the spawn counter came one dependent round trip after another —
         // three for a task::spawn — with the whole wave waiting on each).  What the branches below do not use is not used; nothing is
         // written in between.
-        const uint32_t w_old = TWORD(c, slot, 0, 0);
+        uint32_t w_old = init.w_old;
         // (raw words only up to the last request: arithmetic on a loaded value inside a divergent block makes the compiler wait for it there)
-        uint32_t w_gen = 0, w_parent_f = init.parent_f, w_parent_y = init.parent_u1y, w_killed = 0;
+        uint32_t w_gen = init.w_gen, w_parent_f = init.parent_f, w_parent_y = init.parent_u1y, w_killed = init.w_killed;
         const bool in_parent = parent >= 0;
+        seq = init.seq;
+        if (!init.words_known) {
+            w_old = TWORD(c, slot, 0, 0);
+            if (K::FN) {
+                w_gen = NODEW(4 + (node >> 2));                  // NODE_INFO_GEN(node)
+                seq = NODEW(3);
+                if (!in_parent) w_killed = NODEW(via_handle ? 2u : 0u);
+            }
+        }
+#ifdef MADSIM_EMU
+        if (init.words_known && (w_old != (uint32_t)TWORD(c, slot, 0, 0) || (K::FN && (w_gen != (uint32_t)NODEW(4 + (node >> 2)) || seq != (uint32_t)NODEW(3) ||
+                                  (!in_parent && w_killed != (uint32_t)NODEW(via_handle ? 2u : 0u)))))) OVF_SET(L, OVF_BUG);
+#endif
         if (K::FN) {
-            w_gen = NODEW(4 + (node >> 2));                      // NODE_INFO_GEN(node)
-            seq = NODEW(3);
-            if (!in_parent) w_killed = NODEW(via_handle ? 2u : 0u);
-            else if (!init.parent_known) { w_parent_f = TWORD(c, (uint32_t)parent, 0, 0); w_parent_y = TWORD(c, (uint32_t)parent, 1, 1); }
+            if (in_parent && !init.parent_known) { w_parent_f = TWORD(c, (uint32_t)parent, 0, 0); w_parent_y = TWORD(c, (uint32_t)parent, 1, 1); }
 #ifdef MADSIM_EMU
             if (in_parent && init.parent_known && (((uint32_t)TWORD(c, (uint32_t)parent, 0, 0) ^ init.parent_f) & TF_KILLED)) OVF_SET(L, OVF_BUG);     // the poll's copy is current
             if (in_parent && init.parent_known && (uint32_t)TWORD(c, (uint32_t)parent, 1, 1) != init.parent_u1y) OVF_SET(L, OVF_BUG);
@@ -146,12 +163,16 @@ __device__ __forceinline__ void task_drop_guard(const Ctx& c, Lane& L, uint32_t 
 // The future is gone: completed (outcome H_COMPLETED) or dropped by the executor (H_CANCELLED).
 // `kn` (global-state builds, the task that completes inside its own poll — MS_OP_DONE): the words of the task the poll holds in
 // registers and has just written back — flag word, awaiter link (unit 1 word 0), connection word — instead of three dependent reads.
-struct FinishKnown { bool have; uint32_t f, link, cx; };
+// (`have_h`: the JoinHandle word too — requested with the stage's other reads, k_poll.h stage [C])
+struct FinishKnown { bool have; uint32_t f, link, cx; bool have_h; uint32_t h; };
 template <class K>
-__device__ __forceinline__ uint32_t task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome, bool guard = true, FinishKnown kn = FinishKnown{false, 0, 0, 0}) {
+__device__ __forceinline__ uint32_t task_finish(const Ctx& c, Lane& L, uint32_t slot, uint32_t outcome, bool guard = true, FinishKnown kn = FinishKnown{false, 0, 0, 0, false, 0}) {
     uint32_t f = kn.have ? kn.f : (uint32_t)TWORD(c, slot, 0, 0);
     uint32_t gen = (f >> 8) & 0xffff, prog = f >> 24;
-    const uint32_t h_pre = kn.have ? (uint32_t)HW(prog) : 0u;       // (requested before the locals drop: it arrives with their first read)
+    const uint32_t h_pre = kn.have ? (kn.have_h ? kn.h : (uint32_t)HW(prog)) : 0u;       // (requested before the locals drop: it arrives with their first read)
+#ifdef MADSIM_EMU
+    if (kn.have && kn.have_h && kn.h != (uint32_t)HW(prog)) OVF_SET(L, OVF_BUG);
+#endif
     task_drop_locals<K>(c, L, slot, f, kn.have, kn.cx);
     if (guard) task_drop_guard<K>(c, L, slot, prog);
     // (h_pre stays valid: between its read and here only this task's own locals dropped — no JoinHandle word is written by that)

@@ -555,6 +555,23 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
         if (RecvPrefetch<K>::ON && ((op == MS_OP_RECV && sub == 0) || (K::FT && op == MS_OP_RECV_TIMEOUT))) {
             c_hdr = SW(c, a, 0); c_q0 = SW(c, a, 2 + P.mbox_regs); c_q1 = SW(c, a, 3 + P.mbox_regs);
         }
+        // (... and the first reads of `spawn` and of a task that ends — the two rare-op handlers every pass of the topology runs: with the receives'
+        //  requests above the whole stage waits once.  The free slot is the one spawn_task would find: the alive mask changes in spawn / finish only.)
+        uint32_t g_slot = ~0u, g_old = 0, g_gen = 0, g_seq = 0, g_killed = 0, g_hw = 0;
+        if constexpr (SwitchPrefetch<K>::ON) {
+            if (op == MS_OP_SPAWN) {
+                uint32_t sl = P.max_tasks;
+                for (uint32_t wi = 0; wi < (P.max_tasks + 31) / 32 && sl == P.max_tasks; wi++) {
+                    const uint32_t free_bits = ~AMASK(wi);
+                    if (free_bits) sl = wi * 32 + (uint32_t)__builtin_ctz(free_bits);
+                }
+                if (sl < P.max_tasks) {
+                    const uint32_t nd = PROGW(c, a) & 0xff;
+                    g_slot = sl; g_old = TWORD(c, sl, 0, 0);
+                    if (K::FN) { g_gen = NODEW(4 + (nd >> 2)); g_seq = NODEW(3); if (nd != node) g_killed = NODEW(2); }
+                }
+            } else if (op == MS_OP_DONE) g_hw = HW(u0.x >> 24);
+        }
         if (op == MS_OP_RECV) {
             if (sub == 0) {                                // Mailbox::recv (endpoint.rs:353-362)
                 REG(14);
@@ -692,7 +709,7 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                     info_kill<K>(c, L, node, u1.y >> 24);
                     done_guard = false;
                 }
-                if (K::G) u0.x = task_finish<K>(c, L, slot, H_COMPLETED, done_guard, FinishKnown{done_guard, u0.x, u1.x, (K::FC && P.uses_chan) ? cu0_get() : 0u});
+                if (K::G) u0.x = task_finish<K>(c, L, slot, H_COMPLETED, done_guard, FinishKnown{done_guard, u0.x, u1.x, (K::FC && P.uses_chan) ? cu0_get() : 0u, SwitchPrefetch<K>::ON, g_hw});
                 else { task_finish<K>(c, L, slot, H_COMPLETED, done_guard); u0.x = TWORD(c, slot, 0, 0); }
                 st = ST_FINISHED;
                 break;
@@ -705,7 +722,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 if constexpr (K::G) {
                     const bool mreq = K::FR && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST);
                     const uint32_t req = mreq ? RQ_GET(0) : 0u;
-                    child = spawn_task<K>(c, L, a, true, via, via ? -1 : (int)slot, SpawnInit{!via, u0.x, u1.y, mreq, u0.w, from, req});
+                    child = spawn_task<K>(c, L, a, true, via, via ? -1 : (int)slot, SpawnInit{!via, u0.x, u1.y, mreq, u0.w, from, req,
+                                                                                                       SwitchPrefetch<K>::ON && g_slot != ~0u, g_slot, g_old, g_gen, g_seq, g_killed});
                 } else {
                     child = spawn_task<K>(c, L, a, true, via, via ? -1 : (int)slot);
                     if (K::FR && P.uses_rpc && (b & MADSIM_SPAWN_MOVE_REQUEST) && child != 0xffffffffu) {   // rpc.rs:170

@@ -380,6 +380,9 @@ template <class K> struct HoistRpc { static constexpr bool ON = K::G && K::FR; }
 template <class K> struct HdrPrefetch { static constexpr bool ON = Hoist<K>::ALLG && !K::FA; };
 // ... and stage [C]: the header and first queued message of the Endpoint a recv_from / timeout(recv_from) begins on, for the lanes of both at once.
 template <class K> struct RecvPrefetch { static constexpr bool ON = Hoist<K>::ALLG; };
+// ... and the words a spawn (the free slot's old flag word, the node's info generation, the spawn counter, the gen-0 killed mask) and a finishing task
+// (its JoinHandle word) read first.
+template <class K> struct SwitchPrefetch { static constexpr bool ON = Hoist<K>::ALLG; };
 __device__ __forceinline__ bool has_t0_unit(const KParams& P) { return P.task_units > 2 && !(P.uses_chan && P.chan_unit == 2); }   // geometry.h `t0`
 template <class K> __device__ __forceinline__ PollPrefetch poll_prefetch(const Ctx& c, uint32_t slot) {
     PollPrefetch pp = {0, 0, make_uint4(0, 0, 0, 0), 0, 0};
