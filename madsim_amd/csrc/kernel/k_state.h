@@ -382,7 +382,10 @@ template <class K> struct HdrPrefetch { static constexpr bool ON = Hoist<K>::ALL
 template <class K> struct RecvPrefetch { static constexpr bool ON = Hoist<K>::ALLG; };
 // ... and the words a spawn (the free slot's old flag word, the node's info generation, the spawn counter, the gen-0 killed mask) and a finishing task
 // (its JoinHandle word) read first.
-template <class K> struct SwitchPrefetch { static constexpr bool ON = Hoist<K>::ALLG; };
+#ifndef MADSIM_SWITCH_PREFETCH_CHAN
+#define MADSIM_SWITCH_PREFETCH_CHAN 0        /* experiment: the channel-only global-state builds too (tools/build_variant.sh) */
+#endif
+template <class K> struct SwitchPrefetch { static constexpr bool ON = Hoist<K>::ALLG || (MADSIM_SWITCH_PREFETCH_CHAN && Hoist<K>::CHAN); };
 __device__ __forceinline__ bool has_t0_unit(const KParams& P) { return P.task_units > 2 && !(P.uses_chan && P.chan_unit == 2); }   // geometry.h `t0`
 template <class K> __device__ __forceinline__ PollPrefetch poll_prefetch(const Ctx& c, uint32_t slot) {
     PollPrefetch pp = {0, 0, make_uint4(0, 0, 0, 0), 0, 0};
