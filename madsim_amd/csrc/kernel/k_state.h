@@ -379,7 +379,10 @@ template <class K> struct HoistRpc { static constexpr bool ON = K::G && K::FR; }
 //  registers with them and read -4.4 %: profiles/r6_ab_stage_prefetch.txt.)
 template <class K> struct HdrPrefetch { static constexpr bool ON = Hoist<K>::ALLG && !K::FA; };
 // ... and stage [C]: the header and first queued message of the Endpoint a recv_from / timeout(recv_from) begins on, for the lanes of both at once.
-template <class K> struct RecvPrefetch { static constexpr bool ON = Hoist<K>::ALLG; };
+#ifndef MADSIM_RECV_PREFETCH_TIME
+#define MADSIM_RECV_PREFETCH_TIME 0          /* measured on the election loop's build: 10.62-10.69 with, 10.67-10.70 without (profiles/r6_ab_stage_prefetch.txt) */
+#endif
+template <class K> struct RecvPrefetch { static constexpr bool ON = Hoist<K>::ALLG || (MADSIM_RECV_PREFETCH_TIME && K::G && (K::FEAT & MADSIM_FEAT_ALL) == MADSIM_FEAT_TIME); };
 // ... and the words a spawn (the free slot's old flag word, the node's info generation, the spawn counter, the gen-0 killed mask) and a finishing task
 // (its JoinHandle word) read first.
 #ifndef MADSIM_SWITCH_PREFETCH_CHAN
