@@ -572,19 +572,6 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 }
             } else if (op == MS_OP_DONE) g_hw = HW(u0.x >> 24);
         }
-        // (... and a channel send / receive: the connection's header, the parked receiver's word or the oldest queued payload)
-        uint32_t g_cw = 0, g_x1 = 0, g_x2 = 0, g_x3 = 0;
-        if constexpr (ChanPrefetch<K>::ON) {
-            if (op == MS_OP_CSEND || op == MS_OP_CRECV) {
-                const uint32_t cx = pp.cu.x;
-                if ((cx & 0xff) != 0xff) {
-                    const uint32_t id = cx & 0xff, side = (cx >> 8) & 1;
-                    g_cw = CONNW(id, 0);
-                    if (op == MS_OP_CSEND) g_x1 = CONNW(id, 1 + side);
-                    else { const uint32_t e0 = 3 + (1 - side) * P.chan_queue * 3; g_x1 = CONNW(id, e0); g_x2 = CONNW(id, e0 + 1); g_x3 = CONNW(id, e0 + 2); }
-                }
-            }
-        }
         if (op == MS_OP_RECV) {
             if (sub == 0) {                                // Mailbox::recv (endpoint.rs:353-362)
                 REG(14);
@@ -891,11 +878,8 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 uint32_t cx = cu0_get();
                 if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
                 uint32_t id = cx & 0xff, side = (cx >> 8) & 1;
-                uint32_t cw = ChanPrefetch<K>::ON ? g_cw : (uint32_t)CONNW(id, 0);
-                const uint32_t r_pre = ChanPrefetch<K>::ON ? g_x1 : Hoist<K>::CHAN ? (uint32_t)CONNW(id, 1 + side) : 0;   // (global-state builds: the parked receiver's word with the header, not after the link test)
-#ifdef MADSIM_EMU
-                if (ChanPrefetch<K>::ON && (cw != (uint32_t)CONNW(id, 0) || r_pre != (uint32_t)CONNW(id, 1 + side))) OVF_SET(L, OVF_BUG);
-#endif
+                uint32_t cw = CONNW(id, 0);
+                const uint32_t r_pre = Hoist<K>::CHAN ? (uint32_t)CONNW(id, 1 + side) : 0;   // (global-state builds: the parked receiver's word with the header, not after the link test)
                 // (... and that receiver's flag word, which the wake-up below wants, with the link test's destination header: the test draws and
                 //  stores nothing a task's flags depend on; the receiver is parked, not this task)
                 uint32_t wf_pre = 0;
@@ -928,15 +912,11 @@ __device__ __forceinline__ bool poll_task(const Ctx& c, Lane& L, const uint32_t 
                 uint32_t cx = cu0_get();
                 if ((cx & 0xff) == 0xff) { u0.w = MADSIM_VAL_RESET; pc++; break; }
                 uint32_t id = cx & 0xff, dir = 1 - ((cx >> 8) & 1);
-                uint32_t cw = ChanPrefetch<K>::ON ? g_cw : (uint32_t)CONNW(id, 0);
+                uint32_t cw = CONNW(id, 0);
                 // (global-state builds: the oldest queued payload's three words go out with the header — one round trip, not two)
                 const uint32_t e0 = 3 + dir * P.chan_queue * 3;
                 uint32_t h0 = 0, h1 = 0, h2 = 0;
-                if (ChanPrefetch<K>::ON) { h0 = g_x1; h1 = g_x2; h2 = g_x3; }
-                else if (Hoist<K>::CHAN) { h0 = CONNW(id, e0); h1 = CONNW(id, e0 + 1); h2 = CONNW(id, e0 + 2); }
-#ifdef MADSIM_EMU
-                if (ChanPrefetch<K>::ON && (cw != (uint32_t)CONNW(id, 0) || h0 != (uint32_t)CONNW(id, e0) || h1 != (uint32_t)CONNW(id, e0 + 1) || h2 != (uint32_t)CONNW(id, e0 + 2))) OVF_SET(L, OVF_BUG);
-#endif
+                if (Hoist<K>::CHAN) { h0 = CONNW(id, e0); h1 = CONNW(id, e0 + 1); h2 = CONNW(id, e0 + 2); }
                 uint32_t qn = (cw >> (17 + 4 * dir)) & 0xf;
                 if (qn == 0) {
                     if (!(cw & (1u << (13 + 2 * dir)))) { u0.w = MADSIM_VAL_RESET; pc++; break; }   // all senders gone

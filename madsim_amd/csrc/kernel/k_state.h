@@ -385,9 +385,6 @@ template <class K> struct HdrPrefetch { static constexpr bool ON = Hoist<K>::ALL
 template <class K> struct RecvPrefetch { static constexpr bool ON = Hoist<K>::ALLG || (MADSIM_RECV_PREFETCH_TIME && K::G && (K::FEAT & MADSIM_FEAT_ALL) == MADSIM_FEAT_TIME); };
 // ... and the words a spawn (the free slot's old flag word, the node's info generation, the spawn counter, the gen-0 killed mask) and a finishing task
 // (its JoinHandle word) read first.
-// ... and the connection words a channel send / receive starts from (the connection's header; the parked receiver's word / the oldest queued payload):
-// the channel-only global-state builds too — the handlers hold the same four values, only earlier.
-template <class K> struct ChanPrefetch { static constexpr bool ON = MADSIM_CHAN_PREFETCH && Hoist<K>::CHAN; };
 #ifndef MADSIM_SWITCH_PREFETCH_CHAN
 #define MADSIM_SWITCH_PREFETCH_CHAN 0        /* experiment: the channel-only global-state builds too (tools/build_variant.sh) */
 #endif

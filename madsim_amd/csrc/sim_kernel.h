@@ -66,11 +66,6 @@
 #ifndef MADSIM_PUSH_PREFETCH
 #define MADSIM_PUSH_PREFETCH 0        /* measured: topology 5.75 with, 5.76 without (profiles/r6_ab_chains.txt): the three registers cost what the round trip saves */
 #endif
-/* Global-state builds with the channel hoists: a channel send's and a channel receive's first reads are requested together before the rare-op switch
-   (k_poll.h stage [C]). */
-#ifndef MADSIM_CHAN_PREFETCH
-#define MADSIM_CHAN_PREFETCH 0        /* measured: KV 12.48 with, 12.91 without (the channel build spills five registers instead of one), topology equal: profiles/r6_ab_stage_prefetch.txt */
-#endif
 #ifndef MADSIM_POP_LDS_FIRST
 #define MADSIM_POP_LDS_FIRST 1
 #endif
