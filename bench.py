@@ -250,7 +250,9 @@ def main():
         wcu = g.blocks_per_cu * g.block_threads // 64
         # (round 6, profiles/r6_ab_launches_in_flight.txt: the election loop at three waves per SIMD +2 % with a fifth launch queued, the topology
         #  at two waves per SIMD -1 %; sub-launch sizes from 16 384 to 131 072 seeds read the same within 1 %)
-        return 5 if wcu >= 16 else (5 if wcu >= 12 else 4) if (g.variant & 16) and g.heap_spill_slots else 3
+        # (the round's last kernels, tools/experiment/exp_r6_streams_final.sh: the topology — two waves per SIMD — reads 5.91-5.93 G steps/s with three
+        #  launches in flight, 5.87 with four, 5.79-5.82 with five; the election loop 10.28-10.30 with five against 10.14 with four; the KV three)
+        return 5 if wcu >= 16 else (5 if wcu >= 12 else 3) if (g.variant & 16) and g.heap_spill_slots else 3
     max_streams = args.streams if args.streams > 0 else flights(g0)
     n_streams = max_streams
     d_outs = [torch.empty(count * 48, dtype=torch.uint8, device=dev) for _ in range(max_streams)]   # results stay in HBM
